@@ -1,0 +1,285 @@
+/* pcompanion_hip.h -- C ABI of libpcompanion_hip.so (MI355X / gfx950).
+ *
+ * Drop-in boundary for the two embedding-learning hot paths of P-Companion.  The
+ * reference is pure Python/PyTorch: its "FFI for this path" is the nn.Module surface of
+ * src/models/{product2vec,type_transition,item_prediction,p_companion}.py plus the two
+ * loop bodies (product2vec.py:126-164, train.py:34-52).  Each entry point below replaces
+ * the ATen op sequence of one reference method (cited per function); the Python classes
+ * in p_companion_amd/ keep the reference's names/signatures and call these through ctypes.
+ *
+ * Conventions:
+ *   - raw DEVICE pointers + explicit sizes; fp32 data, int32 indices, row-major, dense;
+ *   - `stream` is a hipStream_t passed as void* (the caller's current stream); every call
+ *     is asynchronous w.r.t. the host and never synchronises, allocates or frees;
+ *   - caller-allocated outputs and workspace (pc_*_workspace_bytes queries);
+ *   - return: 0 ok, <0 invalid argument (PC_E*), >0 a hipError_t; nothing throws;
+ *   - no global mutable state: re-entrant across streams and devices.
+ *   Exceptions are the two host-side helpers (pc_mt_*), which take HOST pointers.
+ */
+#ifndef PCOMPANION_HIP_H
+#define PCOMPANION_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PC_OK 0
+#define PC_EINVAL (-1)   /* null pointer / non-positive size */
+#define PC_ESHAPE (-2)   /* dimension not supported by the kernels (see each function) */
+#define PC_EWORKSPACE (-3)
+
+#define PC_D 128         /* PRODUCT_EMB_DIM (config.py:8) */
+#define PC_H 256         /* HIDDEN_SIZE (config.py:10) */
+#define PC_HEADS 4       /* NUM_ATTENTION_HEADS (config.py:11) */
+#define PC_L 64          /* TYPE_EMB_DIM (config.py:9) */
+#define PC_MAX_SEG 4     /* BatchNorm call groups per launch (anchor, neighbours, positive, negative) */
+
+int pc_abi_version(void);
+
+/* ---------------------------------------------------------------------------------
+ * Product2Vec parameters, reference state_dict layout (product2vec.py:14-29):
+ *   ffn.0 Linear(D->H) w0[H,D] b0[H]; ffn.1 BatchNorm1d(H) gamma/beta/running_*[H];
+ *   ffn.3 Linear(H->H) w3[H,H] b3[H]; ffn.5 Linear(H->D) w5[D,H] b5[D];
+ *   attention.in_proj_weight[3D,D] in_proj_bias[3D]; out_proj.weight[D,D] .bias[D].
+ * The same struct type carries gradients (running_* / num_batches_tracked unused there).
+ * --------------------------------------------------------------------------------- */
+typedef struct {
+    float *w0, *b0, *gamma, *beta, *w3, *b3, *w5, *b5;
+    float *in_proj_w, *in_proj_b, *out_proj_w, *out_proj_b;
+    float *running_mean, *running_var;
+    int64_t *num_batches_tracked;
+} pc_p2v_tensors;
+
+/* Row groups ("segments") of one FFN launch.  The reference calls the FFN once per tensor
+ * (anchor, neighbours, positive, negative: product2vec.py:132-134 via :73,:78) and
+ * BatchNorm's batch statistics span exactly the rows of that call; a launch processes the
+ * concatenation of up to PC_MAX_SEG such calls, segment s = rows [start[s], start[s+1]). */
+typedef struct {
+    int nseg;
+    int start[PC_MAX_SEG + 1];
+} pc_segments;
+
+/* Saved-for-backward activations of one FFN launch over R rows (caller allocates). */
+typedef struct {
+    float *h0;        /* [R,H]  Linear0 output (pre-BatchNorm)                           */
+    float *a2;        /* [R,H]  tanh(Linear3(...))                                       */
+    float *bn_mean;   /* [nseg,H] batch mean per segment                                 */
+    float *bn_invstd; /* [nseg,H] 1/sqrt(biased var + 1e-5)                              */
+    float *bn_scale;  /* [nseg,H] gamma*invstd                                           */
+    float *bn_shift;  /* [nseg,H] beta - mean*gamma*invstd                               */
+} pc_ffn_saved;
+
+/* P6: Product2Vec.get_initial_embedding, training mode (product2vec.py:31-46; ffn :14-21).
+ *   y[r] = W5 tanh(W3 tanh(BN_s(W0 x_r + b0)) + b3) + b5,  x_r = idx ? table[idx[r]] : table[r]
+ * idx[r] == -1 gathers an all-zero row (collate_fn's zero padding, data_loader.py:186-198).
+ * Updates running_mean/var once per segment in segment order (momentum 0.1, unbiased var)
+ * and num_batches_tracked += nseg when `update_running` != 0.
+ * D=128, H=256 only.  ws: pc_p2v_ffn_workspace_bytes(R). */
+size_t pc_p2v_ffn_workspace_bytes(int rows);
+int pc_p2v_ffn_forward_train(const pc_p2v_tensors *p, const float *table, const int32_t *idx,
+                             int rows, const pc_segments *seg, int update_running,
+                             float *y, const pc_ffn_saved *saved, void *ws, size_t ws_bytes,
+                             void *stream);
+
+/* P6 / P11 eval mode: BatchNorm uses running statistics (product2vec.py:83-111 runs the
+ * model under self.eval()).  No saved activations. */
+int pc_p2v_ffn_forward_eval(const pc_p2v_tensors *p, const float *table, const int32_t *idx,
+                            int rows, float *y, void *ws, size_t ws_bytes, void *stream);
+
+/* Backward of P6 (what autograd derives for ffn :14-21).  dy[R,D] -> g->{w0,b0,gamma,beta,
+ * w3,b3,w5,b5}: overwritten when accumulate == 0, += otherwise.  dx (may be NULL) receives
+ * d(loss)/d(input rows) [R,D] for dense-tensor callers whose autograd graph continues below
+ * the features; the index path passes NULL (the feature table is frozen input data,
+ * synthetic_data.py:50-58).  `dy` is not modified. */
+int pc_p2v_ffn_backward(const pc_p2v_tensors *p, const pc_p2v_tensors *g, const float *table,
+                        const int32_t *idx, int rows, const pc_segments *seg, const float *dy,
+                        const pc_ffn_saved *saved, float *dx, int accumulate, void *ws,
+                        size_t ws_bytes, void *stream);
+
+/* P7: Product2Vec.apply_attention -> nn.MultiheadAttention(128, 4 heads), ONE query token
+ * per sample, keys == values == neighbour embeddings, no key-padding mask, dropout 0
+ * (product2vec.py:48-68).  query[B,D], keys[B*N,D] -> out[B,D].
+ * Saved for backward: q[B,D] (projected, unscaled), kv[B*N,2D] (K | V), probs[B,HEADS,N],
+ * ctx[B,D] (pre-out_proj).  ws: pc_p2v_attention_workspace_bytes(B,N). */
+typedef struct {
+    float *q, *kv, *probs, *ctx;
+} pc_attn_saved;
+size_t pc_p2v_attention_workspace_bytes(int batch, int n_keys);
+int pc_p2v_attention_forward(const pc_p2v_tensors *p, const float *query, const float *keys,
+                             int batch, int n_keys, float *out, const pc_attn_saved *saved,
+                             void *ws, size_t ws_bytes, void *stream);
+/* Backward of P7: dout[B,D] -> dquery[B,D], dkeys[B*N,D]; g->{in_proj_w,in_proj_b,
+ * out_proj_w,out_proj_b} overwritten (accumulate == 0) or +=. */
+int pc_p2v_attention_backward(const pc_p2v_tensors *p, const pc_p2v_tensors *g,
+                              const float *query, const float *keys, int batch, int n_keys,
+                              const float *dout, const pc_attn_saved *saved, float *dquery,
+                              float *dkeys, int accumulate, void *ws, size_t ws_bytes,
+                              void *stream);
+
+/* P9: the loss of Product2Vec.train_model (product2vec.py:137-154), forward + backward:
+ *   d+ = ||a - p + 1e-6||, d- = mean_j ||a - n_j + 1e-6||, loss = mean_b relu(margin - d+ + d-)
+ * a[B,D], p[B,D], n[B*K,D] (row b*K+j).  Outputs: loss[1], d_pos[B], d_neg[B] and, when
+ * non-NULL, da/dp/dn = d(loss)/d(.)  (already including the 1/B of the mean). */
+int pc_p2v_triplet_loss(const float *a, const float *p, const float *n, int batch, int k_neg,
+                        float margin, float *loss, float *d_pos, float *d_neg, float *da,
+                        float *dp, float *dn, void *stream);
+
+/* P10: torch.optim.Adam (scripts/pretrain_product2vec.py:34, train.py:24; defaults beta
+ * (0.9,0.999), eps 1e-8), no weight decay / amsgrad, bias-corrected, dense over `n` floats.
+ * `step_count` is a DEVICE int64 incremented by the call (so a captured graph replays);
+ * `scalars` is a DEVICE float[2] scratch.  All four arrays 16-byte aligned. */
+int pc_adam_step(float *param, const float *grad, float *exp_avg, float *exp_avg_sq, size_t n,
+                 int64_t *step_count, float *scalars, double lr, double beta1, double beta2,
+                 double eps, void *stream);
+
+/* P9 whole: one iteration of Product2Vec.train_model's loop body (product2vec.py:126-159)
+ * in index form: gather -> 4 FFN calls -> attention -> loss -> backward -> grads in `g`
+ * (overwritten, i.e. zero_grad + backward).  The optimizer step is a separate call.
+ *   anchor_idx[B], positive_idx[B], negative_idx[B*K], neighbor_idx[B*N] (-1 = zero row)
+ * Outputs: loss[1] (+ d_pos/d_neg[B], anchor_emb[B,D] when non-NULL).
+ * ws: pc_p2v_train_step_workspace_bytes(B,N,K). */
+size_t pc_p2v_train_step_workspace_bytes(int batch, int n_nbr, int k_neg);
+int pc_p2v_train_step(const pc_p2v_tensors *p, const pc_p2v_tensors *g, const float *table,
+                      const int32_t *anchor_idx, const int32_t *positive_idx,
+                      const int32_t *negative_idx, const int32_t *neighbor_idx, int batch,
+                      int n_nbr, int k_neg, float margin, float *loss, float *d_pos,
+                      float *d_neg, float *anchor_emb, void *ws, size_t ws_bytes, void *stream);
+
+/* P1-P4 on device: build one index batch from the CSR graph (bpg.py:24-38 get_neighbors,
+ * data_loader.py:27-40 negative sampling rules, :186-198 padding).  pair_ids[B] selects
+ * (anchor, positive) = sim_pairs[pair]; neighbours = co-view CSR row of the anchor, right
+ * padded with -1 to n_pad; negatives: k distinct uniform draws (Philox4x32-10 keyed by
+ * seed/step/sample) rejecting the anchor, the anchor's positives (sim CSR) and repeats. */
+int pc_build_similarity_batch(const int32_t *pair_ids, int batch, const int32_t *sim_pairs,
+                              const int32_t *cv_rowptr, const int32_t *cv_col,
+                              const int32_t *sim_rowptr, const int32_t *sim_col, int n_products,
+                              int n_pad, int k_neg, uint64_t seed, uint64_t step,
+                              int32_t *anchor_idx, int32_t *positive_idx, int32_t *negative_idx,
+                              int32_t *neighbor_idx, void *stream);
+
+/* P2 exact (HOST pointers, host code): SimilarityDataset._get_negative_samples
+ * (data_loader.py:27-40) on CPython's `random` stream: MT19937, random.seed(int) key
+ * schedule, choice() = _randbelow_with_getrandbits.  Bit-exact negative indices.
+ * `state` is an opaque buffer of pc_mt_state_bytes() bytes owned by the caller. */
+size_t pc_mt_state_bytes(void);
+int pc_mt_seed(void *state, uint64_t seed);
+uint32_t pc_mt_getrandbits(void *state, int k);            /* 1 <= k <= 32 */
+uint64_t pc_mt_randbelow(void *state, uint64_t n);
+int pc_mt_shuffle(void *state, int64_t *perm, int64_t n);  /* random.shuffle of perm */
+int pc_mt_negative_samples(void *state, int32_t n_products, const int32_t *sim_rowptr,
+                           const int32_t *sim_col, const int32_t *anchors, int64_t n, int k,
+                           int32_t *out);
+
+/* ---------------------------------------------------------------------------------
+ * P-Companion joint step.  Reference state_dict layout (p_companion.py:26-43,
+ * type_transition.py:11-12, item_prediction.py:11-20).
+ * --------------------------------------------------------------------------------- */
+typedef struct {
+    float *product_table;  /* [P,D] frozen (p_companion.py:26-29)                        */
+    float *enc_w, *enc_b;  /* type_transition.encoder  [L/2,L], [L/2]                    */
+    float *dec_w, *dec_b;  /* type_transition.decoder  [L,L/2], [L]                      */
+    float *typ_w, *typ_b;  /* item_prediction.type_projection [D,L], [D]                 */
+    float *itm_w, *itm_b;  /* item_prediction.item_projection [D,D], [D]                 */
+    float *query_types;    /* query_type_embeddings.weight [T,L]                         */
+    float *comp_types;     /* complementary_type_embeddings.weight [T,L]                 */
+} pc_joint_tensors;
+
+typedef struct {
+    float *h;       /* [B,L/2] relu(encoder(E_q[query_types]))   (type_transition.py:17)  */
+    float *c;       /* [B,L]   decoder(h)  (complementary base, type_transition.py:19)     */
+    float *pi;      /* [B,D]   item_projection(E_prod[query_idx]) (item_prediction.py:31)  */
+    float *tp;      /* [B*K,D] type_projection(E_c[topk])        (item_prediction.py:35)  */
+} pc_joint_saved;
+
+/* J3+J4+J5: PCompanion.forward (p_companion.py:45-77) with integer ids (the str->idx map
+ * of :47-49 stays host-side).
+ *   sims[B,T] = dec(relu(enc(E_q[query_types]))) . E_c^T ; topk[B,K] (int32, descending,
+ *   ties -> lower index first); proj[B,K,D] = item_proj(E_prod[query_idx])[:,None,:] *
+ *   type_proj(E_c[topk]).  D=128, L=64, K<=8, dropout 0.  The nn.Embedding lookups are
+ *   fused into the GEMM loaders as row gathers. */
+size_t pc_joint_workspace_bytes(int batch, int num_types, int k);
+int pc_joint_forward(const pc_joint_tensors *p, const int32_t *query_idx,
+                     const int32_t *query_types, int batch, int num_types, int k, float *sims,
+                     int32_t *topk, float *proj, const pc_joint_saved *saved, void *ws,
+                     size_t ws_bytes, void *stream);
+
+/* J6: PCompanion.compute_loss (p_companion.py:79-119), forward + backward w.r.t. its two
+ * differentiable inputs:  type = mean_b clamp(margin - S[b,pos_b] + S[b,neg_b], 0);
+ * item = mean_{b,k} clamp(margin - ||proj-pos_item|| + ||proj-neg_item||, 0);
+ * loss = alpha*item + (1-alpha)*type.  losses[3] = {loss, type, item}.
+ * dsims is SPARSE: dsims_val[B,2] holds d(loss)/dS at columns (pos_b, neg_b) -- the only
+ * non-zeros (the reference materialises a dense [B,T] zero gradient: SURVEY section 6).
+ * dsims_val / dproj may be NULL (forward only).  partials: device scratch float[2*B]. */
+int pc_joint_loss(const float *sims, const float *proj, const int32_t *pos_types,
+                  const int32_t *neg_types, const float *pos_items, const float *neg_items,
+                  int batch, int num_types, int k, float margin, float alpha, float *losses,
+                  float *dsims_val, float *dproj, float *partials, void *stream);
+
+/* Backward of J3-J5 from (dsims_val, dproj) -> g (overwritten = zero_grad + backward),
+ * including the row-sparse scatter-add into the two [T,L] type tables (J7): only rows
+ * query_types[b], topk[b,:], pos_types[b], neg_types[b] receive gradient. */
+int pc_joint_backward(const pc_joint_tensors *p, const pc_joint_tensors *g,
+                      const int32_t *query_idx, const int32_t *query_types,
+                      const int32_t *pos_types, const int32_t *neg_types, const int32_t *topk,
+                      int batch, int num_types, int k, const float *dsims_val,
+                      const float *dproj, const pc_joint_saved *saved, void *ws,
+                      size_t ws_bytes, void *stream);
+
+/* J8 loop body (train.py:42-46): forward + loss + backward; Adam is pc_adam_step. */
+int pc_joint_train_step(const pc_joint_tensors *p, const pc_joint_tensors *g,
+                        const int32_t *query_idx, const int32_t *query_types,
+                        const int32_t *pos_types, const int32_t *neg_types,
+                        const float *pos_items, const float *neg_items, int batch,
+                        int num_types, int k, float margin, float alpha, float *losses,
+                        int32_t *topk, void *ws, size_t ws_bytes, void *stream);
+
+/* ---------------------------------------------------------------------------------
+ * Building blocks the Python modules compose their autograd from (module / dense mode).
+ * --------------------------------------------------------------------------------- */
+/* nn.Linear forward (type_transition.py:11-12, item_prediction.py:11-20, and the
+ * similarity product p_companion.py:60-63 with b = NULL):
+ *   y[r] = act(W x_r + b), x_r = idx ? x[idx[r]] (zero row if idx[r] < 0) : x[r]
+ * w[out_dim,in_dim]; act 0 none, 1 tanh, 2 relu; in_dim % 4 == 0. */
+int pc_linear_forward(const float *x, const int32_t *idx, int rows, int in_dim, const float *w,
+                      const float *b, int out_dim, int act, float *y, void *stream);
+/* dx[rows,in_dim] = dy[rows,out_dim] W.  wt_scratch: in_dim*out_dim floats (holds W^T).
+ * act must be 0 (callers fold act' into dy); y_saved unused. */
+int pc_linear_backward_input(const float *dy, int rows, int out_dim, const float *w, int in_dim,
+                             int act, const float *y_saved, float *dx, float *wt_scratch,
+                             void *stream);
+/* dW[out,in] (+)= dy^T x, db[out] (+)= sum_r dy[r] (db may be NULL); x rows gathered by idx
+ * when non-NULL.  Fixed-order split-K reduction: bitwise reproducible. out_dim, in_dim % 4 == 0. */
+size_t pc_linear_backward_weight_workspace_bytes(int rows, int out_dim, int in_dim);
+int pc_linear_backward_weight(const float *dy, int rows, int out_dim, const float *x,
+                              const int32_t *idx, int in_dim, float *dw, float *db,
+                              int accumulate, void *ws, size_t ws_bytes, void *stream);
+/* torch.topk(sims, k, dim=1) (p_companion.py:64; metrics.py:21): idx_out[B,k] int32,
+ * val_out[B,k] (may be NULL); descending, ties -> lower index first; k <= 8. */
+int pc_topk_rows(const float *sims, int batch, int num_types, int k, int32_t *idx_out,
+                 float *val_out, void *stream);
+/* item_prediction.py:38: proj[b,k,:] = pi[b,:] * tp[b*K+k,:] and its backward
+ * (dpi[b] = sum_k dproj[b,k]*tp[b,k]; dtp[b,k] = dproj[b,k]*pi[b]).  D = 128. */
+int pc_hadamard_forward(const float *pi, const float *tp, int batch, int k, float *proj,
+                        void *stream);
+int pc_hadamard_backward(const float *dproj, const float *pi, const float *tp, int batch, int k,
+                         float *dpi, float *dtp, void *stream);
+
+/* ---------------------------------------------------------------------------------
+ * Row movers used by the sharded-table exchange and the modules.
+ * --------------------------------------------------------------------------------- */
+/* out[r] = idx[r] >= 0 ? table[idx[r]] : 0   (nn.Embedding lookup p_companion.py:51,54,65;
+ * feature gather of data_loader.py:50-55 in index form).  width % 4 == 0. */
+int pc_gather_rows(const float *table, const int32_t *idx, int rows, int width, float *out,
+                   void *stream);
+/* table[idx[r]] += src[r] (row-sparse embedding gradient, J7), deterministic per row order
+ * is NOT guaranteed (float atomics); idx < 0 skipped. */
+int pc_scatter_add_rows(float *table, const int32_t *idx, int rows, int width, const float *src,
+                        void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

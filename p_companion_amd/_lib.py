@@ -1,0 +1,125 @@
+"""ctypes binding of libpcompanion_hip.so (include/pcompanion_hip.h).
+
+There is NO fallback: if the shared object is missing or a call fails, this raises.
+"""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libpcompanion_hip.so")
+
+c_f32p = ctypes.c_void_p
+c_i32p = ctypes.c_void_p
+PC_MAX_SEG = 4
+D, H, HEADS, L = 128, 256, 4, 64
+
+_ERR = {-1: "PC_EINVAL (null pointer / bad size)", -2: "PC_ESHAPE (unsupported dimension/alignment)",
+        -3: "PC_EWORKSPACE (workspace too small)"}
+
+
+class HipKernelError(RuntimeError):
+    pass
+
+
+class P2VTensors(ctypes.Structure):
+    _fields_ = [(n, ctypes.c_void_p) for n in (
+        "w0", "b0", "gamma", "beta", "w3", "b3", "w5", "b5", "in_proj_w", "in_proj_b", "out_proj_w",
+        "out_proj_b", "running_mean", "running_var", "num_batches_tracked")]
+
+
+class Segments(ctypes.Structure):
+    _fields_ = [("nseg", ctypes.c_int), ("start", ctypes.c_int * (PC_MAX_SEG + 1))]
+
+
+class FfnSaved(ctypes.Structure):
+    _fields_ = [(n, ctypes.c_void_p) for n in ("h0", "a2", "bn_mean", "bn_invstd", "bn_scale", "bn_shift")]
+
+
+class AttnSaved(ctypes.Structure):
+    _fields_ = [(n, ctypes.c_void_p) for n in ("q", "kv", "probs", "ctx")]
+
+
+class JointTensors(ctypes.Structure):
+    _fields_ = [(n, ctypes.c_void_p) for n in (
+        "product_table", "enc_w", "enc_b", "dec_w", "dec_b", "typ_w", "typ_b", "itm_w", "itm_b",
+        "query_types", "comp_types")]
+
+
+class JointSaved(ctypes.Structure):
+    _fields_ = [(n, ctypes.c_void_p) for n in ("h", "c", "pi", "tp")]
+
+
+_vp, _i, _sz, _f, _d, _u64, _i64 = (ctypes.c_void_p, ctypes.c_int, ctypes.c_size_t, ctypes.c_float,
+                                    ctypes.c_double, ctypes.c_uint64, ctypes.c_int64)
+_P = ctypes.POINTER
+
+# name -> (restype, argtypes).  Must list every symbol include/pcompanion_hip.h declares
+# (tests/test_abi.py parses the header and checks this table and the .so against it).
+SIGNATURES = {
+    "pc_abi_version": (_i, []),
+    "pc_p2v_ffn_workspace_bytes": (_sz, [_i]),
+    "pc_p2v_ffn_forward_train": (_i, [_P(P2VTensors), _vp, _vp, _i, _P(Segments), _i, _vp, _P(FfnSaved), _vp, _sz, _vp]),
+    "pc_p2v_ffn_forward_eval": (_i, [_P(P2VTensors), _vp, _vp, _i, _vp, _vp, _sz, _vp]),
+    "pc_p2v_ffn_backward": (_i, [_P(P2VTensors), _P(P2VTensors), _vp, _vp, _i, _P(Segments), _vp, _P(FfnSaved),
+                                 _vp, _i, _vp, _sz, _vp]),
+    "pc_p2v_attention_workspace_bytes": (_sz, [_i, _i]),
+    "pc_p2v_attention_forward": (_i, [_P(P2VTensors), _vp, _vp, _i, _i, _vp, _P(AttnSaved), _vp, _sz, _vp]),
+    "pc_p2v_attention_backward": (_i, [_P(P2VTensors), _P(P2VTensors), _vp, _vp, _i, _i, _vp, _P(AttnSaved), _vp,
+                                       _vp, _i, _vp, _sz, _vp]),
+    "pc_p2v_triplet_loss": (_i, [_vp, _vp, _vp, _i, _i, _f, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "pc_adam_step": (_i, [_vp, _vp, _vp, _vp, _sz, _vp, _vp, _d, _d, _d, _d, _vp]),
+    "pc_p2v_train_step_workspace_bytes": (_sz, [_i, _i, _i]),
+    "pc_p2v_train_step": (_i, [_P(P2VTensors), _P(P2VTensors), _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _f, _vp, _vp,
+                               _vp, _vp, _vp, _sz, _vp]),
+    "pc_build_similarity_batch": (_i, [_vp, _i, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _u64, _u64, _vp, _vp, _vp,
+                                       _vp, _vp]),
+    "pc_mt_state_bytes": (_sz, []),
+    "pc_mt_seed": (_i, [_vp, _u64]),
+    "pc_mt_getrandbits": (ctypes.c_uint32, [_vp, _i]),
+    "pc_mt_randbelow": (_u64, [_vp, _u64]),
+    "pc_mt_shuffle": (_i, [_vp, _vp, _i64]),
+    "pc_mt_negative_samples": (_i, [_vp, ctypes.c_int32, _vp, _vp, _vp, _i64, _i, _vp]),
+    "pc_joint_workspace_bytes": (_sz, [_i, _i, _i]),
+    "pc_joint_forward": (_i, [_P(JointTensors), _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _P(JointSaved), _vp, _sz, _vp]),
+    "pc_joint_loss": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _f, _f, _vp, _vp, _vp, _vp, _vp]),
+    "pc_joint_backward": (_i, [_P(JointTensors), _P(JointTensors), _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp,
+                               _P(JointSaved), _vp, _sz, _vp]),
+    "pc_joint_train_step": (_i, [_P(JointTensors), _P(JointTensors), _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _f,
+                                 _f, _vp, _vp, _vp, _sz, _vp]),
+    "pc_linear_forward": (_i, [_vp, _vp, _i, _i, _vp, _vp, _i, _i, _vp, _vp]),
+    "pc_linear_backward_input": (_i, [_vp, _i, _i, _vp, _i, _i, _vp, _vp, _vp, _vp]),
+    "pc_linear_backward_weight_workspace_bytes": (_sz, [_i, _i, _i]),
+    "pc_linear_backward_weight": (_i, [_vp, _i, _i, _vp, _vp, _i, _vp, _vp, _i, _vp, _sz, _vp]),
+    "pc_topk_rows": (_i, [_vp, _i, _i, _i, _vp, _vp, _vp]),
+    "pc_hadamard_forward": (_i, [_vp, _vp, _i, _i, _vp, _vp]),
+    "pc_hadamard_backward": (_i, [_vp, _vp, _vp, _i, _i, _vp, _vp, _vp]),
+    "pc_gather_rows": (_i, [_vp, _vp, _i, _i, _vp, _vp]),
+    "pc_scatter_add_rows": (_i, [_vp, _vp, _i, _i, _vp, _vp]),
+}
+
+_lib = None
+
+
+def lib():
+    """The loaded shared object.  Raises if it has not been built (python -m p_companion_amd.build)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise HipKernelError(
+                f"{LIB_PATH} not found: build it with `python -m p_companion_amd.build` "
+                "(hipcc --offload-arch=gfx950).  There is no CPU fallback.")
+        L = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(L, name)          # AttributeError = symbol missing: fail loudly
+            fn.restype = res
+            fn.argtypes = args
+        _lib = L
+    return _lib
+
+
+def check(rc, what):
+    if rc == 0:
+        return
+    if rc < 0:
+        raise HipKernelError(f"{what}: {_ERR.get(rc, rc)}")
+    raise HipKernelError(f"{what}: hipError_t {rc}")

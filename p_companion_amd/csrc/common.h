@@ -1,0 +1,147 @@
+// Shared device/host helpers for the gfx950 kernels of libpcompanion_hip.so.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "../../include/pcompanion_hip.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+#define PC_WAVE 64
+
+#define PC_HIP_TRY(expr)                          \
+    do {                                          \
+        hipError_t _e = (expr);                   \
+        if (_e != hipSuccess) return (int)_e;     \
+    } while (0)
+
+#define PC_TRY(expr)                 \
+    do {                             \
+        int _r = (expr);             \
+        if (_r != 0) return _r;      \
+    } while (0)
+
+static inline int pc_launch_status() {
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? 0 : (int)e;
+}
+
+// Row segments (BatchNorm call groups) passed to kernels BY VALUE.
+struct SegInfo {
+    int nseg;
+    int start[PC_MAX_SEG + 1];   // row starts, start[nseg] = total rows
+    int tile0[PC_MAX_SEG + 1];   // first 128-row tile of each segment (tiles never straddle)
+};
+
+static inline SegInfo make_seginfo(const pc_segments* s, int rows, int tile_rows) {
+    SegInfo si;
+    si.nseg = 1;
+    for (int i = 0; i <= PC_MAX_SEG; i++) { si.start[i] = rows; si.tile0[i] = 0; }
+    si.start[0] = 0;
+    if (s) {
+        si.nseg = s->nseg;
+        for (int i = 0; i <= s->nseg; i++) si.start[i] = s->start[i];
+        for (int i = s->nseg + 1; i <= PC_MAX_SEG; i++) si.start[i] = s->start[s->nseg];
+    }
+    int t = 0;
+    for (int i = 0; i < PC_MAX_SEG; i++) {
+        si.tile0[i] = t;
+        int n = si.start[i + 1] - si.start[i];
+        t += (n + tile_rows - 1) / tile_rows;
+    }
+    si.tile0[PC_MAX_SEG] = t;
+    return si;
+}
+
+static inline int seg_valid(const pc_segments* s, int rows) {
+    if (!s) return 1;
+    if (s->nseg < 1 || s->nseg > PC_MAX_SEG || s->start[0] != 0 || s->start[s->nseg] != rows) return 0;
+    for (int i = 0; i < s->nseg; i++)
+        if (s->start[i + 1] < s->start[i]) return 0;
+    return 1;
+}
+
+#ifdef __HIPCC__
+__device__ __forceinline__ int seg_of_row(const SegInfo& si, int r) {
+    int s = 0;
+#pragma unroll
+    for (int i = 1; i < PC_MAX_SEG; i++) s += (i < si.nseg && r >= si.start[i]) ? 1 : 0;
+    return s;
+}
+
+__device__ __forceinline__ int seg_of_tile(const SegInfo& si, int t) {
+    int s = 0;
+#pragma unroll
+    for (int i = 1; i < PC_MAX_SEG; i++) s += (i < si.nseg && t >= si.tile0[i]) ? 1 : 0;
+    return s;
+}
+
+// tanh via one v_exp_f32 and one v_rcp_f32: tanh(x) = 1 - 2/(e^{2x}+1).
+// |abs err| < 2e-7 over the real line (saturates cleanly: e^{2x}=inf -> 1, 0 -> -1).
+__device__ __forceinline__ float fast_tanh(float x) {
+    float e = __expf(2.0f * x);
+    return 1.0f - 2.0f * __frcp_rn(e + 1.0f);
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+__device__ __forceinline__ float group16_sum(float v) {
+#pragma unroll
+    for (int o = 8; o >= 1; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+__device__ __forceinline__ f32x16 mfma32(float a, float b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
+}
+#endif
+
+// ---- internal launchers (defined in the .hip files) -------------------------------------
+enum NtPrologue { NT_PRO_NONE = 0, NT_PRO_BNTANH = 1 };
+enum NtEpilogue {
+    NT_EPI_NONE = 0,       // C = acc (+bias)
+    NT_EPI_TANH = 1,       // C = tanh(acc + bias)
+    NT_EPI_RELU = 2,       // C = relu(acc + bias)
+    NT_EPI_DTANH = 3,      // C = acc * (1 - S^2),  S = aux[m][n]
+    NT_EPI_DTANH_BN = 4,   // C = acc * (1 - S^2),  S = tanh(aux[m][n]*escale[s][n] + eshift[s][n])
+    NT_EPI_DRELU = 5       // C = acc * (aux[m][n] > 0)
+};
+enum NtStats {
+    NT_STAT_NONE = 0,
+    NT_STAT_SUMSQ = 1,     // per 128-row tile: sum_r C, sum_r C^2           (BatchNorm forward)
+    NT_STAT_BNBWD = 2      // per tile: sum_r C, sum_r C*xhat, xhat=(aux-mean)*invstd (BN backward)
+};
+
+struct NtArgs {
+    const float* A; int lda; const int32_t* gather;   // A row r = gather ? A[gather[r]] (or 0 if <0) : A[r]
+    const float* W; int ldw;                          // [N,K] row-major
+    const float* bias;                                // [N] or null
+    float* C; int ldc;                                // [M,N]
+    int M, N, K;
+    SegInfo seg;
+    int prologue; const float* pscale; const float* pshift;     // [nseg][K]
+    int epilogue; const float* aux; int ldaux;
+    const float* escale; const float* eshift;                    // [nseg][N]
+    int stats; float* stat_sum; float* stat_aux;                 // [ntiles][N] each
+    const float* mean; const float* invstd;                      // [nseg][N] for NT_STAT_BNBWD
+};
+int launch_gemm_nt(const NtArgs& a, hipStream_t st);
+int gemm_nt_tiles(const SegInfo& si);
+
+struct TnArgs {
+    // dW[No,Ni] (+)= sum_r Z[r][o] * A[r][i];  db[o] (+)= sum_r Z[r][o]
+    const float* Z; int ldz;
+    const float* A; int lda; const int32_t* gather;
+    int R, No, Ni;
+    SegInfo seg;
+    int prologue; const float* pscale; const float* pshift;      // bn-tanh on A, [nseg][Ni]
+    float* dW; int lddw; float* db;                              // db may be null
+    int accumulate;                                              // 1: +=, 0: overwrite
+    float* slabs; size_t slab_floats;                            // workspace
+};
+int launch_gemm_tn(const TnArgs& a, hipStream_t st);
+size_t gemm_tn_workspace_floats(int R, int No, int Ni);

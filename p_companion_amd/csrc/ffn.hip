@@ -1,0 +1,338 @@
+// P6: Product2Vec.get_initial_embedding = Linear(128->256) -> BatchNorm1d -> tanh ->
+// Linear(256->256) -> tanh -> Linear(256->128)  (product2vec.py:14-21,31-46), forward
+// (train / eval) and backward, as three fused fp32-MFMA passes each way:
+//
+//   fwd 1  gather rows + Linear0 + per-tile BatchNorm partial sums        (gemm_nt, STAT_SUMSQ)
+//          bn_finalize: fp64 fold of the partials -> mean/invstd/scale/shift, running stats
+//   fwd 2  BN-apply + tanh on the fly -> Linear3 -> tanh                  (gemm_nt, PRO_BNTANH)
+//   fwd 3  Linear5
+//   bwd 1  dZ2 = (dY W5) * (1-A2^2)            ; dW5, db5                 (gemm_nt + gemm_tn)
+//   bwd 2  dZ1 = (dZ2 W3) * (1-A1^2) + BN-backward partial sums ; dW3, db3 (A1 recomputed from H0)
+//          bn_bwd_finalize -> dgamma, dbeta, per-segment coefficients
+//   bwd 3  dH0 = BN backward (elementwise, in place) ; dW0, db0 with the row gather fused
+//
+// BatchNorm statistics are per SEGMENT (= per reference FFN call), see pc_segments.
+#include "common.h"
+
+#define BN_EPS 1e-5f
+#define BN_MOMENTUM 0.1f
+
+// ---------------------------------------------------------------------------------------
+// partial[t][j] over 128-row tiles -> per-segment statistics.  blockDim = (256 cols, 4)
+__global__ void bn_finalize_fwd_kernel(const float* psum, const float* psq, SegInfo si, const float* gamma,
+                                       const float* beta, float* running_mean, float* running_var,
+                                       int64_t* nbt, int update_running, float* mean_o, float* invstd_o,
+                                       float* scale_o, float* shift_o) {
+    __shared__ double red[2][4][PC_H];
+    const int j = threadIdx.x, q = threadIdx.y;
+    float rm = 0.f, rv = 0.f;
+    if (q == 0 && update_running) { rm = running_mean[j]; rv = running_var[j]; }
+    int nseen = 0;
+    for (int s = 0; s < si.nseg; s++) {
+        const int n = si.start[s + 1] - si.start[s];
+        double a = 0.0, b = 0.0;
+        for (int t = si.tile0[s] + q; t < si.tile0[s + 1]; t += 4) {
+            a += (double)psum[(size_t)t * PC_H + j];
+            b += (double)psq[(size_t)t * PC_H + j];
+        }
+        red[0][q][j] = a;
+        red[1][q][j] = b;
+        __syncthreads();
+        if (q == 0 && n > 0) {
+            a = red[0][0][j] + red[0][1][j] + red[0][2][j] + red[0][3][j];
+            b = red[1][0][j] + red[1][1][j] + red[1][2][j] + red[1][3][j];
+            const double m = a / n;
+            double var = b / n - m * m;
+            if (var < 0.0) var = 0.0;
+            const float mf = (float)m, vf = (float)var;
+            const float is = 1.0f / sqrtf(vf + BN_EPS);
+            const float sc = gamma[j] * is;
+            mean_o[s * PC_H + j] = mf;
+            invstd_o[s * PC_H + j] = is;
+            scale_o[s * PC_H + j] = sc;
+            shift_o[s * PC_H + j] = beta[j] - mf * sc;
+            if (update_running) {
+                const float unb = n > 1 ? (float)(var * ((double)n / (double)(n - 1))) : vf;
+                rm = BN_MOMENTUM * mf + (1.0f - BN_MOMENTUM) * rm;
+                rv = BN_MOMENTUM * unb + (1.0f - BN_MOMENTUM) * rv;
+            }
+            nseen++;
+        }
+        __syncthreads();
+    }
+    if (q == 0 && update_running) {
+        running_mean[j] = rm;
+        running_var[j] = rv;
+        if (j == 0 && nbt) *nbt += nseen;
+    }
+}
+
+__global__ void bn_eval_coeff_kernel(const float* gamma, const float* beta, const float* running_mean,
+                                     const float* running_var, float* scale_o, float* shift_o) {
+    const int j = threadIdx.x;
+    const float is = 1.0f / sqrtf(running_var[j] + BN_EPS);
+    const float sc = gamma[j] * is;
+    scale_o[j] = sc;
+    shift_o[j] = beta[j] - running_mean[j] * sc;
+}
+
+// per-tile (sum dz1, sum dz1*xhat) -> dgamma, dbeta (+ per-segment means c1 = dbeta_s/n, c2 = dgamma_s/n)
+__global__ void bn_finalize_bwd_kernel(const float* psum, const float* pdot, SegInfo si, float* dgamma,
+                                       float* dbeta, int accumulate, float* c1, float* c2) {
+    __shared__ double red[2][4][PC_H];
+    const int j = threadIdx.x, q = threadIdx.y;
+    double tg = 0.0, tb = 0.0;
+    for (int s = 0; s < si.nseg; s++) {
+        const int n = si.start[s + 1] - si.start[s];
+        double a = 0.0, b = 0.0;
+        for (int t = si.tile0[s] + q; t < si.tile0[s + 1]; t += 4) {
+            a += (double)psum[(size_t)t * PC_H + j];
+            b += (double)pdot[(size_t)t * PC_H + j];
+        }
+        red[0][q][j] = a;
+        red[1][q][j] = b;
+        __syncthreads();
+        if (q == 0) {
+            a = red[0][0][j] + red[0][1][j] + red[0][2][j] + red[0][3][j];
+            b = red[1][0][j] + red[1][1][j] + red[1][2][j] + red[1][3][j];
+            tb += a;
+            tg += b;
+            c1[s * PC_H + j] = n > 0 ? (float)(a / n) : 0.f;
+            c2[s * PC_H + j] = n > 0 ? (float)(b / n) : 0.f;
+        }
+        __syncthreads();
+    }
+    if (q == 0) {
+        dgamma[j] = accumulate ? dgamma[j] + (float)tg : (float)tg;
+        dbeta[j] = accumulate ? dbeta[j] + (float)tb : (float)tb;
+    }
+}
+
+// dH0 = scale_s * (dZ1 - c1_s - xhat*c2_s), xhat = (H0 - mean_s)*invstd_s; in place over dz [R,256]
+__global__ void bn_bwd_apply_kernel(float* dz, const float* h0, int rows, SegInfo si, const float* mean,
+                                    const float* invstd, const float* scale, const float* c1, const float* c2) {
+    const int c4 = (threadIdx.x & 63) * 4;                     // 64 threads x float4 = one 256-wide row
+    const int rl = threadIdx.x >> 6;                           // 4 rows per block pass
+    for (int r = blockIdx.x * 4 + rl; r < rows; r += gridDim.x * 4) {
+        const int s = seg_of_row(si, r);
+        float4 g = *reinterpret_cast<float4*>(dz + (size_t)r * PC_H + c4);
+        const float4 h = *reinterpret_cast<const float4*>(h0 + (size_t)r * PC_H + c4);
+        const float4 mu = *reinterpret_cast<const float4*>(mean + s * PC_H + c4);
+        const float4 is = *reinterpret_cast<const float4*>(invstd + s * PC_H + c4);
+        const float4 sc = *reinterpret_cast<const float4*>(scale + s * PC_H + c4);
+        const float4 a = *reinterpret_cast<const float4*>(c1 + s * PC_H + c4);
+        const float4 b = *reinterpret_cast<const float4*>(c2 + s * PC_H + c4);
+        g.x = sc.x * (g.x - a.x - (h.x - mu.x) * is.x * b.x);
+        g.y = sc.y * (g.y - a.y - (h.y - mu.y) * is.y * b.y);
+        g.z = sc.z * (g.z - a.z - (h.z - mu.z) * is.z * b.z);
+        g.w = sc.w * (g.w - a.w - (h.w - mu.w) * is.w * b.w);
+        *reinterpret_cast<float4*>(dz + (size_t)r * PC_H + c4) = g;
+    }
+}
+
+// out[c][r] = in[r][c]   (weights are <= 256x256: one pass, LDS tile 32x33)
+__global__ void transpose_kernel(const float* in, int rows, int cols, float* out) {
+    __shared__ float t[32][33];
+    const int bx = blockIdx.x * 32, by = blockIdx.y * 32;
+    for (int i = threadIdx.y; i < 32; i += 8) {
+        const int r = by + i, c = bx + threadIdx.x;
+        t[i][threadIdx.x] = (r < rows && c < cols) ? in[(size_t)r * cols + c] : 0.f;
+    }
+    __syncthreads();
+    for (int i = threadIdx.y; i < 32; i += 8) {
+        const int c = bx + i, r = by + threadIdx.x;
+        if (r < rows && c < cols) out[(size_t)c * rows + r] = t[threadIdx.x][i];
+    }
+}
+
+int launch_transpose(const float* in, int rows, int cols, float* out, hipStream_t st) {
+    hipLaunchKernelGGL(transpose_kernel, dim3((cols + 31) / 32, (rows + 31) / 32), dim3(32, 8), 0, st, in, rows, cols, out);
+    return pc_launch_status();
+}
+
+// ---------------------------------------------------------------------------------------
+static inline size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
+
+struct FfnWs {
+    float *stat_a, *stat_b;     // [ntiles][H] each
+    float *dz2, *dz1;           // [R,H] each (backward; also h0/a2 scratch for eval)
+    float *w5t, *w3t, *w0t;     // transposed weights
+    float *c1, *c2;             // [MAX_SEG][H]
+    float *coef;                // eval: scale, shift [2][H]
+    float *slabs; size_t slab_floats;
+    size_t total;
+};
+
+static FfnWs ffn_ws_layout(void* base, int rows) {
+    FfnWs w;
+    const int max_tiles = (rows + 127) / 128 + PC_MAX_SEG;
+    size_t off = 0;
+    auto take = [&](size_t floats) {
+        float* p = base ? reinterpret_cast<float*>(reinterpret_cast<char*>(base) + off) : nullptr;
+        off += align256(floats * sizeof(float));
+        return p;
+    };
+    w.stat_a = take((size_t)max_tiles * PC_H);
+    w.stat_b = take((size_t)max_tiles * PC_H);
+    w.dz2 = take((size_t)rows * PC_H);
+    w.dz1 = take((size_t)rows * PC_H);
+    w.w5t = take(PC_H * PC_D);
+    w.w3t = take(PC_H * PC_H);
+    w.w0t = take(PC_D * PC_H);
+    w.c1 = take(PC_MAX_SEG * PC_H);
+    w.c2 = take(PC_MAX_SEG * PC_H);
+    w.coef = take(2 * PC_H);
+    w.slab_floats = gemm_tn_workspace_floats(rows, PC_H, PC_H);
+    w.slabs = take(w.slab_floats);
+    w.total = off;
+    return w;
+}
+
+extern "C" size_t pc_p2v_ffn_workspace_bytes(int rows) {
+    if (rows <= 0) return 0;
+    return ffn_ws_layout(nullptr, rows).total;
+}
+
+static int ffn_check(const pc_p2v_tensors* p, const float* table, int rows, const pc_segments* seg, void* ws,
+                     size_t ws_bytes) {
+    if (!p || !table || rows <= 0 || !ws) return PC_EINVAL;
+    if (!p->w0 || !p->b0 || !p->gamma || !p->beta || !p->w3 || !p->b3 || !p->w5 || !p->b5) return PC_EINVAL;
+    if (!seg_valid(seg, rows)) return PC_EINVAL;
+    if (ws_bytes < pc_p2v_ffn_workspace_bytes(rows)) return PC_EWORKSPACE;
+    return PC_OK;
+}
+
+static NtArgs nt_plain(const float* A, int lda, const float* W, int ldw, const float* bias, float* C, int ldc, int M,
+                       int N, int K, const SegInfo& si) {
+    NtArgs a = {};
+    a.A = A; a.lda = lda; a.W = W; a.ldw = ldw; a.bias = bias; a.C = C; a.ldc = ldc;
+    a.M = M; a.N = N; a.K = K; a.seg = si;
+    return a;
+}
+
+extern "C" int pc_p2v_ffn_forward_train(const pc_p2v_tensors* p, const float* table, const int32_t* idx, int rows,
+                                        const pc_segments* seg, int update_running, float* y,
+                                        const pc_ffn_saved* sv, void* ws, size_t ws_bytes, void* stream) {
+    PC_TRY(ffn_check(p, table, rows, seg, ws, ws_bytes));
+    if (!y || !sv || !sv->h0 || !sv->a2 || !sv->bn_mean || !sv->bn_invstd || !sv->bn_scale || !sv->bn_shift)
+        return PC_EINVAL;
+    if (update_running && (!p->running_mean || !p->running_var)) return PC_EINVAL;
+    hipStream_t st = (hipStream_t)stream;
+    const SegInfo si = make_seginfo(seg, rows, 128);
+    FfnWs w = ffn_ws_layout(ws, rows);
+
+    NtArgs g1 = nt_plain(table, PC_D, p->w0, PC_D, p->b0, sv->h0, PC_H, rows, PC_H, PC_D, si);
+    g1.gather = idx;
+    g1.stats = NT_STAT_SUMSQ; g1.stat_sum = w.stat_a; g1.stat_aux = w.stat_b;
+    PC_TRY(launch_gemm_nt(g1, st));
+
+    hipLaunchKernelGGL(bn_finalize_fwd_kernel, dim3(1), dim3(PC_H, 4), 0, st, w.stat_a, w.stat_b, si, p->gamma,
+                       p->beta, p->running_mean, p->running_var, p->num_batches_tracked, update_running,
+                       sv->bn_mean, sv->bn_invstd, sv->bn_scale, sv->bn_shift);
+    PC_TRY(pc_launch_status());
+
+    NtArgs g2 = nt_plain(sv->h0, PC_H, p->w3, PC_H, p->b3, sv->a2, PC_H, rows, PC_H, PC_H, si);
+    g2.prologue = NT_PRO_BNTANH; g2.pscale = sv->bn_scale; g2.pshift = sv->bn_shift;
+    g2.epilogue = NT_EPI_TANH;
+    PC_TRY(launch_gemm_nt(g2, st));
+
+    NtArgs g3 = nt_plain(sv->a2, PC_H, p->w5, PC_H, p->b5, y, PC_D, rows, PC_D, PC_H, si);
+    return launch_gemm_nt(g3, st);
+}
+
+extern "C" int pc_p2v_ffn_forward_eval(const pc_p2v_tensors* p, const float* table, const int32_t* idx, int rows,
+                                       float* y, void* ws, size_t ws_bytes, void* stream) {
+    PC_TRY(ffn_check(p, table, rows, nullptr, ws, ws_bytes));
+    if (!y || !p->running_mean || !p->running_var) return PC_EINVAL;
+    hipStream_t st = (hipStream_t)stream;
+    const SegInfo si = make_seginfo(nullptr, rows, 128);
+    FfnWs w = ffn_ws_layout(ws, rows);
+    float* h0 = w.dz2;
+    float* a2 = w.dz1;
+    hipLaunchKernelGGL(bn_eval_coeff_kernel, dim3(1), dim3(PC_H), 0, st, p->gamma, p->beta, p->running_mean,
+                       p->running_var, w.coef, w.coef + PC_H);
+    PC_TRY(pc_launch_status());
+    NtArgs g1 = nt_plain(table, PC_D, p->w0, PC_D, p->b0, h0, PC_H, rows, PC_H, PC_D, si);
+    g1.gather = idx;
+    PC_TRY(launch_gemm_nt(g1, st));
+    NtArgs g2 = nt_plain(h0, PC_H, p->w3, PC_H, p->b3, a2, PC_H, rows, PC_H, PC_H, si);
+    g2.prologue = NT_PRO_BNTANH; g2.pscale = w.coef; g2.pshift = w.coef + PC_H;
+    g2.epilogue = NT_EPI_TANH;
+    PC_TRY(launch_gemm_nt(g2, st));
+    NtArgs g3 = nt_plain(a2, PC_H, p->w5, PC_H, p->b5, y, PC_D, rows, PC_D, PC_H, si);
+    return launch_gemm_nt(g3, st);
+}
+
+static int ffn_backward_impl(const pc_p2v_tensors* p, const pc_p2v_tensors* g, const float* table,
+                             const int32_t* idx, int rows, const pc_segments* seg, const float* dy,
+                             const pc_ffn_saved* sv, float* dx, int accumulate, void* ws, size_t ws_bytes,
+                             void* stream) {
+    PC_TRY(ffn_check(p, table, rows, seg, ws, ws_bytes));
+    if (!g || !dy || !sv || !sv->h0 || !sv->a2) return PC_EINVAL;
+    if (!g->w0 || !g->b0 || !g->gamma || !g->beta || !g->w3 || !g->b3 || !g->w5 || !g->b5) return PC_EINVAL;
+    hipStream_t st = (hipStream_t)stream;
+    const SegInfo si = make_seginfo(seg, rows, 128);
+    FfnWs w = ffn_ws_layout(ws, rows);
+
+    PC_TRY(launch_transpose(p->w5, PC_D, PC_H, w.w5t, st));   // [D,H] -> [H,D]
+    PC_TRY(launch_transpose(p->w3, PC_H, PC_H, w.w3t, st));
+
+    // dZ2 = (dY W5) * (1 - A2^2)
+    NtArgs b1 = nt_plain(dy, PC_D, w.w5t, PC_D, nullptr, w.dz2, PC_H, rows, PC_H, PC_D, si);
+    b1.epilogue = NT_EPI_DTANH; b1.aux = sv->a2; b1.ldaux = PC_H;
+    PC_TRY(launch_gemm_nt(b1, st));
+
+    // dW5 = dY^T A2, db5
+    TnArgs t5 = {};
+    t5.Z = dy; t5.ldz = PC_D; t5.A = sv->a2; t5.lda = PC_H; t5.R = rows; t5.No = PC_D; t5.Ni = PC_H; t5.seg = si;
+    t5.dW = g->w5; t5.lddw = PC_H; t5.db = g->b5; t5.accumulate = accumulate; t5.slabs = w.slabs;
+    t5.slab_floats = w.slab_floats;
+    PC_TRY(launch_gemm_tn(t5, st));
+
+    // dZ1 = (dZ2 W3) * (1 - A1^2), A1 = tanh(BN(H0)); plus BN-backward partial sums
+    NtArgs b2 = nt_plain(w.dz2, PC_H, w.w3t, PC_H, nullptr, w.dz1, PC_H, rows, PC_H, PC_H, si);
+    b2.epilogue = NT_EPI_DTANH_BN; b2.aux = sv->h0; b2.ldaux = PC_H; b2.escale = sv->bn_scale; b2.eshift = sv->bn_shift;
+    b2.stats = NT_STAT_BNBWD; b2.stat_sum = w.stat_a; b2.stat_aux = w.stat_b; b2.mean = sv->bn_mean;
+    b2.invstd = sv->bn_invstd;
+    PC_TRY(launch_gemm_nt(b2, st));
+
+    // dW3 = dZ2^T A1 (A1 recomputed from H0 in the loader), db3
+    TnArgs t3 = {};
+    t3.Z = w.dz2; t3.ldz = PC_H; t3.A = sv->h0; t3.lda = PC_H; t3.R = rows; t3.No = PC_H; t3.Ni = PC_H; t3.seg = si;
+    t3.prologue = NT_PRO_BNTANH; t3.pscale = sv->bn_scale; t3.pshift = sv->bn_shift;
+    t3.dW = g->w3; t3.lddw = PC_H; t3.db = g->b3; t3.accumulate = accumulate; t3.slabs = w.slabs;
+    t3.slab_floats = w.slab_floats;
+    PC_TRY(launch_gemm_tn(t3, st));
+
+    hipLaunchKernelGGL(bn_finalize_bwd_kernel, dim3(1), dim3(PC_H, 4), 0, st, w.stat_a, w.stat_b, si, g->gamma,
+                       g->beta, accumulate, w.c1, w.c2);
+    PC_TRY(pc_launch_status());
+
+    int blocks = (rows + 3) / 4;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(blocks), dim3(256), 0, st, w.dz1, sv->h0, rows, si, sv->bn_mean,
+                       sv->bn_invstd, sv->bn_scale, w.c1, w.c2);
+    PC_TRY(pc_launch_status());
+
+    // dW0 = dH0^T X (rows gathered again from the table), db0
+    TnArgs t0 = {};
+    t0.Z = w.dz1; t0.ldz = PC_H; t0.A = table; t0.lda = PC_D; t0.gather = idx; t0.R = rows; t0.No = PC_H;
+    t0.Ni = PC_D; t0.seg = si;
+    t0.dW = g->w0; t0.lddw = PC_D; t0.db = g->b0; t0.accumulate = accumulate; t0.slabs = w.slabs;
+    t0.slab_floats = w.slab_floats;
+    PC_TRY(launch_gemm_tn(t0, st));
+
+    if (dx) {
+        PC_TRY(launch_transpose(p->w0, PC_H, PC_D, w.w0t, st));   // [H,D] -> [D,H]
+        NtArgs b3 = nt_plain(w.dz1, PC_H, w.w0t, PC_H, nullptr, dx, PC_D, rows, PC_D, PC_H, si);
+        PC_TRY(launch_gemm_nt(b3, st));
+    }
+    return PC_OK;
+}
+
+extern "C" int pc_p2v_ffn_backward(const pc_p2v_tensors* p, const pc_p2v_tensors* g, const float* table,
+                                   const int32_t* idx, int rows, const pc_segments* seg, const float* dy,
+                                   const pc_ffn_saved* sv, float* dx, int accumulate, void* ws, size_t ws_bytes,
+                                   void* stream) {
+    return ffn_backward_impl(p, g, table, idx, rows, seg, dy, sv, dx, accumulate, ws, ws_bytes, stream);
+}

@@ -1,0 +1,170 @@
+// dW[No,Ni] (+)= sum_r Z[r][o] * prologue(A)[r][i],  db[o] (+)= sum_r Z[r][o]
+//
+// The weight-gradient products of nn.Linear / in_proj / out_proj backward (what autograd
+// derives for product2vec.py:14-28, type_transition.py:11-12, item_prediction.py:11-20):
+// the contraction runs over ROWS (hundreds of thousands) and the output is tiny, so the row
+// range is split over workgroups, each writes its fp32 partial tile to a slab and a second
+// pass sums the slabs in a fixed order (bitwise reproducible, no float atomics).
+//
+// Both operands are read exactly as they lie in HBM (row-major, one 512-B row segment per
+// 32 lanes), staged [32 rows][128] in LDS and consumed by v_mfma_f32_32x32x2_f32 with the
+// ROW index as the MFMA k: lane l reads element [k0 + (l>>5)][tile + (l&31)] -- 32
+// consecutive floats per half-wave, conflict-free ds_read_b32.
+#include "common.h"
+
+#define TM 128
+#define TK 32
+
+__global__ __launch_bounds__(256, 2) void gemm_tn_kernel(TnArgs a, int tiles_i, int nsplit, int rows_per_split) {
+    __shared__ __attribute__((aligned(16))) float smem[2][2][TK * TM];
+
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, wo = w >> 1, wi = w & 1;
+    const int split = blockIdx.x % nsplit;
+    const int tile = blockIdx.x / nsplit;
+    const int o0 = (tile / tiles_i) * TM, i0 = (tile % tiles_i) * TM;
+    const int r_begin = split * rows_per_split;
+    const int r_end = min(a.R, r_begin + rows_per_split);
+
+    const int lrow = tid >> 5, lcol = (tid & 31) * 4;   // 8 rows per pass, 4 passes
+    const bool zcol_ok = o0 + lcol < a.No, acol_ok = i0 + lcol < a.Ni;   // No, Ni multiples of 4
+
+    float4 rz[4], ra[4];
+    float4 dbacc = make_float4(0.f, 0.f, 0.f, 0.f);
+    auto gload = [&](int r0) {
+#pragma unroll
+        for (int p = 0; p < 4; p++) {
+            const int r = r0 + lrow + 8 * p;
+            const bool rv = r < r_end;
+            rz[p] = (rv && zcol_ok) ? *reinterpret_cast<const float4*>(a.Z + (size_t)r * a.ldz + o0 + lcol)
+                                    : make_float4(0.f, 0.f, 0.f, 0.f);
+            int src = r;
+            bool av = rv && acol_ok;
+            if (av && a.gather) { src = a.gather[r]; av = src >= 0; }
+            ra[p] = av ? *reinterpret_cast<const float4*>(a.A + (size_t)src * a.lda + i0 + lcol)
+                       : make_float4(0.f, 0.f, 0.f, 0.f);
+            if (a.prologue == NT_PRO_BNTANH && rv && acol_ok) {
+                const int s = seg_of_row(a.seg, r);
+                const float4 sc = *reinterpret_cast<const float4*>(a.pscale + (size_t)s * a.Ni + i0 + lcol);
+                const float4 sh = *reinterpret_cast<const float4*>(a.pshift + (size_t)s * a.Ni + i0 + lcol);
+                ra[p].x = fast_tanh(ra[p].x * sc.x + sh.x);
+                ra[p].y = fast_tanh(ra[p].y * sc.y + sh.y);
+                ra[p].z = fast_tanh(ra[p].z * sc.z + sh.z);
+                ra[p].w = fast_tanh(ra[p].w * sc.w + sh.w);
+            }
+            dbacc.x += rz[p].x; dbacc.y += rz[p].y; dbacc.z += rz[p].z; dbacc.w += rz[p].w;
+        }
+    };
+    auto lstore = [&](int buf) {
+#pragma unroll
+        for (int p = 0; p < 4; p++) {
+            *reinterpret_cast<float4*>(&smem[buf][0][(lrow + 8 * p) * TM + lcol]) = rz[p];
+            *reinterpret_cast<float4*>(&smem[buf][1][(lrow + 8 * p) * TM + lcol]) = ra[p];
+        }
+    };
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; i++)
+#pragma unroll
+        for (int j = 0; j < 2; j++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) acc[i][j][r] = 0.f;
+
+    const int nchunk = (r_end - r_begin + TK - 1) / TK;
+    if (nchunk > 0) {
+        gload(r_begin);
+        lstore(0);
+    }
+    __syncthreads();
+    const int fz = (lane >> 5) * TM + wo * 64 + (lane & 31);
+    const int fa = (lane >> 5) * TM + wi * 64 + (lane & 31);
+    for (int c = 0; c < nchunk; c++) {
+        const int cur = c & 1;
+        if (c + 1 < nchunk) gload(r_begin + (c + 1) * TK);
+        const float* Zs = &smem[cur][0][fz];
+        const float* As = &smem[cur][1][fa];
+#pragma unroll
+        for (int k = 0; k < TK; k += 2) {
+            const float z0 = Zs[k * TM], z1 = Zs[k * TM + 32];
+            const float x0 = As[k * TM], x1 = As[k * TM + 32];
+            acc[0][0] = mfma32(z0, x0, acc[0][0]);
+            acc[0][1] = mfma32(z0, x1, acc[0][1]);
+            acc[1][0] = mfma32(z1, x0, acc[1][0]);
+            acc[1][1] = mfma32(z1, x1, acc[1][1]);
+        }
+        if (c + 1 < nchunk) lstore(cur ^ 1);
+        __syncthreads();
+    }
+
+    float* slab = a.slabs + (size_t)split * ((size_t)a.No * a.Ni + a.No);
+#pragma unroll
+    for (int mt = 0; mt < 2; mt++)
+#pragma unroll
+        for (int nt = 0; nt < 2; nt++) {
+            const int i = i0 + wi * 64 + nt * 32 + (lane & 31);
+#pragma unroll
+            for (int reg = 0; reg < 16; reg++) {
+                const int o = o0 + wo * 64 + mt * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5);
+                if (o < a.No && i < a.Ni) slab[(size_t)o * a.Ni + i] = acc[mt][nt][reg];
+            }
+        }
+    if (a.db && i0 == 0) {
+        // fold the 8 loader row-groups (tid>>5) holding the same 4 columns
+        float* red = &smem[0][0][0];
+        *reinterpret_cast<float4*>(&red[lrow * TM + lcol]) = dbacc;
+        __syncthreads();
+        if (tid < TM && o0 + tid < a.No) {
+            float s = 0.f;
+#pragma unroll
+            for (int g = 0; g < 8; g++) s += red[g * TM + tid];
+            slab[(size_t)a.No * a.Ni + o0 + tid] = s;
+        }
+    }
+}
+
+// out[j] (+)= sum_s slabs[s][j] in increasing s, j over [No*Ni] then [No] (bias)
+__global__ void tn_reduce_kernel(const float* slabs, int nsplit, int n_w, int n_b, float* dW, float* db,
+                                 int accumulate) {
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t stride = (size_t)n_w + n_b;
+    if (j >= n_w + (db ? n_b : 0)) return;
+    float s = 0.f;
+    for (int k = 0; k < nsplit; k++) s += slabs[(size_t)k * stride + j];
+    float* dst = j < n_w ? dW + j : db + (j - n_w);
+    *dst = accumulate ? *dst + s : s;
+}
+
+static void tn_plan(int R, int No, int Ni, int* nsplit, int* rows_per_split) {
+    const int tiles = ((No + TM - 1) / TM) * ((Ni + TM - 1) / TM);
+    int s = (1024 + tiles - 1) / tiles;            // ~4 workgroups per CU in total
+    const int max_s = (R + 255) / 256;             // at least 8 chunks of 32 rows per split
+    if (s > max_s) s = max_s;
+    if (s < 1) s = 1;
+    int rps = (R + s - 1) / s;
+    rps = (rps + TK - 1) / TK * TK;
+    s = (R + rps - 1) / rps;
+    *nsplit = s;
+    *rows_per_split = rps;
+}
+
+size_t gemm_tn_workspace_floats(int R, int No, int Ni) {
+    int s, rps;
+    tn_plan(R, No, Ni, &s, &rps);
+    return (size_t)s * ((size_t)No * Ni + No);
+}
+
+int launch_gemm_tn(const TnArgs& a, hipStream_t st) {
+    if (!a.Z || !a.A || !a.dW || !a.slabs || a.R <= 0 || a.No <= 0 || a.Ni <= 0) return PC_EINVAL;
+    if (a.No % 4 || a.Ni % 4 || a.ldz % 4 || a.lda % 4 || a.lddw != a.Ni) return PC_ESHAPE;
+    int nsplit, rps;
+    tn_plan(a.R, a.No, a.Ni, &nsplit, &rps);
+    if ((size_t)nsplit * ((size_t)a.No * a.Ni + a.No) > a.slab_floats) return PC_EWORKSPACE;
+    const int tiles_o = (a.No + TM - 1) / TM, tiles_i = (a.Ni + TM - 1) / TM;
+    hipLaunchKernelGGL(gemm_tn_kernel, dim3(tiles_o * tiles_i * nsplit), dim3(256), 0, st, a, tiles_i, nsplit, rps);
+    PC_TRY(pc_launch_status());
+    const int n_w = a.No * a.Ni, n_b = a.No;
+    const int total = n_w + (a.db ? n_b : 0);
+    hipLaunchKernelGGL(tn_reduce_kernel, dim3((total + 255) / 256), dim3(256), 0, st, a.slabs, nsplit, n_w, n_b,
+                       a.dW, a.db, a.accumulate);
+    return pc_launch_status();
+}

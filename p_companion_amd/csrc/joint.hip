@@ -1,0 +1,430 @@
+// P-Companion joint step: PCompanion.forward and
+// compute_loss (p_companion.py:45-119), ComplementaryTypeTransition (type_transition.py:15-20),
+// ComplementaryItemPrediction (item_prediction.py:22-40), and their backward.
+//
+// The dense products go through the shared fp32-MFMA kernels (gemm_nt / gemm_tn) with the
+// nn.Embedding lookups fused into the loaders as row gathers; the pieces the reference
+// leaves to generic ATen ops are small wave-per-row kernels here: top-k over the type
+// similarities, the Hadamard item projection with both distance norms and the hinge, and
+// the two-column type hinge whose gradient stays SPARSE (the reference materialises a dense
+// [B,T] zero gradient and a dense [T,B]x[B,L] product for it).
+#include "common.h"
+
+int launch_transpose(const float* in, int rows, int cols, float* out, hipStream_t st);
+
+#define JMAX_K 8
+#define LH (PC_L / 2)
+
+static inline size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
+
+static NtArgs nt_plain(const float* A, int lda, const float* W, int ldw, const float* bias, float* C, int ldc, int M,
+                       int N, int K) {
+    NtArgs a = {};
+    a.A = A; a.lda = lda; a.W = W; a.ldw = ldw; a.bias = bias; a.C = C; a.ldc = ldc;
+    a.M = M; a.N = N; a.K = K; a.seg = make_seginfo(nullptr, M, 128);
+    return a;
+}
+
+// ---------------------------------------------------------------------------------------
+// Generic nn.Linear pieces (exported: the Python modules build their autograd on these).
+//   y = act(x W^T + b), x row r = idx ? x[idx[r]] : x[r];  act: 0 none, 1 tanh, 2 relu
+extern "C" int pc_linear_forward(const float* x, const int32_t* idx, int rows, int in_dim, const float* w,
+                                 const float* b, int out_dim, int act, float* y, void* stream) {
+    if (!x || !w || !y || rows <= 0 || in_dim <= 0 || out_dim <= 0) return PC_EINVAL;
+    if (act < 0 || act > 2) return PC_EINVAL;
+    NtArgs a = nt_plain(x, in_dim, w, in_dim, b, y, out_dim, rows, out_dim, in_dim);
+    a.gather = idx;
+    a.epilogue = act == 1 ? NT_EPI_TANH : act == 2 ? NT_EPI_RELU : NT_EPI_NONE;
+    return launch_gemm_nt(a, (hipStream_t)stream);
+}
+
+// dx = (dy W) * act'(y):  wt = W^T [in_dim,out_dim] scratch (in_dim*out_dim floats)
+extern "C" int pc_linear_backward_input(const float* dy, int rows, int out_dim, const float* w, int in_dim,
+                                        int act, const float* y_saved, float* dx, float* wt_scratch,
+                                        void* stream) {
+    if (!dy || !w || !dx || !wt_scratch || rows <= 0 || in_dim <= 0 || out_dim <= 0) return PC_EINVAL;
+    if (act != 0) return PC_ESHAPE;    // activation derivative is applied by the caller on dy
+    (void)y_saved;
+    hipStream_t st = (hipStream_t)stream;
+    PC_TRY(launch_transpose(w, out_dim, in_dim, wt_scratch, st));
+    return launch_gemm_nt(nt_plain(dy, out_dim, wt_scratch, out_dim, nullptr, dx, in_dim, rows, in_dim, out_dim), st);
+}
+
+extern "C" size_t pc_linear_backward_weight_workspace_bytes(int rows, int out_dim, int in_dim) {
+    if (rows <= 0 || out_dim <= 0 || in_dim <= 0) return 0;
+    return gemm_tn_workspace_floats(rows, out_dim, in_dim) * sizeof(float);
+}
+
+// dW[out,in] (+)= dy^T x, db (+)= sum_r dy
+extern "C" int pc_linear_backward_weight(const float* dy, int rows, int out_dim, const float* x,
+                                         const int32_t* idx, int in_dim, float* dw, float* db, int accumulate,
+                                         void* ws, size_t ws_bytes, void* stream) {
+    if (!dy || !x || !dw || !ws || rows <= 0) return PC_EINVAL;
+    TnArgs t = {};
+    t.Z = dy; t.ldz = out_dim; t.A = x; t.lda = in_dim; t.gather = idx; t.R = rows; t.No = out_dim; t.Ni = in_dim;
+    t.seg = make_seginfo(nullptr, rows, 128);
+    t.dW = dw; t.lddw = in_dim; t.db = db; t.accumulate = accumulate;
+    t.slabs = (float*)ws; t.slab_floats = ws_bytes / sizeof(float);
+    return launch_gemm_tn(t, (hipStream_t)stream);
+}
+
+// ---------------------------------------------------------------------------------------
+// torch.topk(sims, k, dim=1) (p_companion.py:64): one wavefront per row.  Each lane keeps
+// the k best of its strided columns (sorted, descending; ties keep the lower index), then k
+// rounds of a wave-wide arg-max pop the global winners.
+__global__ __launch_bounds__(256) void topk_rows_kernel(const float* sims, int B, int T, int K, int32_t* idx_out,
+                                                        float* val_out) {
+    const int lane = threadIdx.x & 63;
+    const int b = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (b >= B) return;
+    const float* row = sims + (size_t)b * T;
+    float v[JMAX_K];
+    int ix[JMAX_K];
+#pragma unroll
+    for (int j = 0; j < JMAX_K; j++) { v[j] = -INFINITY; ix[j] = 0x7fffffff; }
+    for (int t = lane; t < T; t += 64) {
+        float x = row[t];
+        int xi = t;
+#pragma unroll
+        for (int j = 0; j < JMAX_K; j++) {
+            if (j < K) {
+                const bool better = x > v[j] || (x == v[j] && xi < ix[j]);
+                if (better) { const float tv = v[j]; const int ti = ix[j]; v[j] = x; ix[j] = xi; x = tv; xi = ti; }
+            }
+        }
+    }
+    for (int r = 0; r < K; r++) {
+        float bv = v[0];
+        int bi = ix[0];
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) {
+            const float ov = __shfl_xor(bv, o, 64);
+            const int oi = __shfl_xor(bi, o, 64);
+            if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
+        }
+        if (ix[0] == bi) {            // the owning lane pops its head
+#pragma unroll
+            for (int j = 0; j < JMAX_K - 1; j++) { v[j] = v[j + 1]; ix[j] = ix[j + 1]; }
+            v[JMAX_K - 1] = -INFINITY; ix[JMAX_K - 1] = 0x7fffffff;
+        }
+        if (lane == 0) {
+            idx_out[(size_t)b * K + r] = bi;
+            if (val_out) val_out[(size_t)b * K + r] = bv;
+        }
+    }
+}
+
+extern "C" int pc_topk_rows(const float* sims, int batch, int num_types, int k, int32_t* idx_out, float* val_out,
+                            void* stream) {
+    if (!sims || !idx_out || batch <= 0 || num_types <= 0) return PC_EINVAL;
+    if (k < 1 || k > JMAX_K || k > num_types) return PC_ESHAPE;
+    hipLaunchKernelGGL(topk_rows_kernel, dim3((batch + 3) / 4), dim3(256), 0, (hipStream_t)stream, sims, batch,
+                       num_types, k, idx_out, val_out);
+    return pc_launch_status();
+}
+
+// proj[b,k,:] = pi[b,:] * tp[b*K+k,:]   (item_prediction.py:38)
+__global__ void hadamard_fwd_kernel(const float* pi, const float* tp, int B, int K, float* proj) {
+    const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;      // float4 index
+    const size_t total = (size_t)B * K * (PC_D / 4);
+    if (t >= total) return;
+    const size_t row = t / (PC_D / 4);
+    const int c = (int)(t % (PC_D / 4));
+    const float4 a = *reinterpret_cast<const float4*>(pi + (row / K) * PC_D + c * 4);
+    const float4 x = *reinterpret_cast<const float4*>(tp + t * 4);
+    *reinterpret_cast<float4*>(proj + t * 4) = make_float4(a.x * x.x, a.y * x.y, a.z * x.z, a.w * x.w);
+}
+
+// dpi[b] = sum_k dproj[b,k]*tp[b,k] ; dtp[b,k] = dproj[b,k]*pi[b] : one wave per sample
+__global__ __launch_bounds__(256) void hadamard_bwd_kernel(const float* dproj, const float* pi, const float* tp,
+                                                           int B, int K, float* dpi, float* dtp) {
+    const int lane = threadIdx.x & 63;
+    const int b = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (b >= B) return;
+    const float2 a = *reinterpret_cast<const float2*>(pi + (size_t)b * PC_D + 2 * lane);
+    float2 acc = make_float2(0.f, 0.f);
+    for (int k = 0; k < K; k++) {
+        const size_t o = ((size_t)b * K + k) * PC_D + 2 * lane;
+        const float2 g = *reinterpret_cast<const float2*>(dproj + o);
+        const float2 x = *reinterpret_cast<const float2*>(tp + o);
+        acc.x += g.x * x.x; acc.y += g.y * x.y;
+        *reinterpret_cast<float2*>(dtp + o) = make_float2(g.x * a.x, g.y * a.y);
+    }
+    *reinterpret_cast<float2*>(dpi + (size_t)b * PC_D + 2 * lane) = acc;
+}
+
+extern "C" int pc_hadamard_forward(const float* pi, const float* tp, int batch, int k, float* proj, void* stream) {
+    if (!pi || !tp || !proj || batch <= 0 || k <= 0) return PC_EINVAL;
+    const size_t total = (size_t)batch * k * (PC_D / 4);
+    hipLaunchKernelGGL(hadamard_fwd_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                       pi, tp, batch, k, proj);
+    return pc_launch_status();
+}
+
+extern "C" int pc_hadamard_backward(const float* dproj, const float* pi, const float* tp, int batch, int k,
+                                    float* dpi, float* dtp, void* stream) {
+    if (!dproj || !pi || !tp || !dpi || !dtp || batch <= 0 || k <= 0) return PC_EINVAL;
+    hipLaunchKernelGGL(hadamard_bwd_kernel, dim3((batch + 3) / 4), dim3(256), 0, (hipStream_t)stream, dproj, pi, tp,
+                       batch, k, dpi, dtp);
+    return pc_launch_status();
+}
+
+// ---------------------------------------------------------------------------------------
+// J6 (p_companion.py:79-119), one wave per sample, forward + backward:
+//   type_b = clamp(margin - S[b,pos] + S[b,neg], 0)
+//   item_bk = clamp(margin - ||proj_bk - pos_item_b|| + ||proj_bk - neg_item_b||, 0)   (torch.norm: no eps)
+//   loss = alpha * mean_{b,k} item + (1-alpha) * mean_b type
+__global__ __launch_bounds__(256) void joint_loss_kernel(const float* sims, const float* proj,
+                                                         const int32_t* pos_t, const int32_t* neg_t,
+                                                         const float* pos_items, const float* neg_items, int B,
+                                                         int T, int K, float margin, float alpha, float* part_type,
+                                                         float* part_item, float* dsims_val, float* dproj) {
+    const int lane = threadIdx.x & 63;
+    const int b = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (b >= B) return;
+    const float lt = margin - sims[(size_t)b * T + pos_t[b]] + sims[(size_t)b * T + neg_t[b]];
+    if (lane == 0) {
+        part_type[b] = lt > 0.f ? lt : 0.f;
+        if (dsims_val) {
+            const float g = lt > 0.f ? (1.0f - alpha) / (float)B : 0.f;
+            dsims_val[2 * b] = -g;
+            dsims_val[2 * b + 1] = g;
+        }
+    }
+    const float2 pp = *reinterpret_cast<const float2*>(pos_items + (size_t)b * PC_D + 2 * lane);
+    const float2 nn = *reinterpret_cast<const float2*>(neg_items + (size_t)b * PC_D + 2 * lane);
+    float li = 0.f;
+    for (int k = 0; k < K; k++) {
+        const size_t o = ((size_t)b * K + k) * PC_D + 2 * lane;
+        const float2 x = *reinterpret_cast<const float2*>(proj + o);
+        const float2 dp = make_float2(x.x - pp.x, x.y - pp.y), dn = make_float2(x.x - nn.x, x.y - nn.y);
+        const float np_ = sqrtf(wave_sum(dp.x * dp.x + dp.y * dp.y));
+        const float nn_ = sqrtf(wave_sum(dn.x * dn.x + dn.y * dn.y));
+        const float l = margin - np_ + nn_;
+        li += l > 0.f ? l : 0.f;
+        if (dproj) {
+            const float g = l > 0.f ? alpha / ((float)B * (float)K) : 0.f;
+            const float ip = g / np_, in = g / nn_;
+            *reinterpret_cast<float2*>(dproj + o) = make_float2(-dp.x * ip + dn.x * in, -dp.y * ip + dn.y * in);
+        }
+    }
+    if (lane == 0) part_item[b] = li;
+}
+
+__global__ void joint_loss_reduce_kernel(const float* part_type, const float* part_item, int B, int K, float alpha,
+                                         float* losses) {
+    __shared__ float r0[256], r1[256];
+    float a = 0.f, c = 0.f;
+    for (int b = threadIdx.x; b < B; b += 256) { a += part_type[b]; c += part_item[b]; }
+    r0[threadIdx.x] = a; r1[threadIdx.x] = c;
+    __syncthreads();
+    for (int o = 128; o >= 1; o >>= 1) {
+        if (threadIdx.x < o) { r0[threadIdx.x] += r0[threadIdx.x + o]; r1[threadIdx.x] += r1[threadIdx.x + o]; }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        const float tl = r0[0] / (float)B, il = r1[0] / ((float)B * (float)K);
+        losses[0] = alpha * il + (1.0f - alpha) * tl;
+        losses[1] = tl;
+        losses[2] = il;
+    }
+}
+
+extern "C" int pc_joint_loss(const float* sims, const float* proj, const int32_t* pos_types,
+                             const int32_t* neg_types, const float* pos_items, const float* neg_items, int batch,
+                             int num_types, int k, float margin, float alpha, float* losses, float* dsims_val,
+                             float* dproj, float* partials, void* stream) {
+    if (!sims || !proj || !pos_types || !neg_types || !pos_items || !neg_items || !losses || !partials)
+        return PC_EINVAL;
+    if (batch <= 0 || num_types <= 0 || k <= 0) return PC_EINVAL;
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(joint_loss_kernel, dim3((batch + 3) / 4), dim3(256), 0, st, sims, proj, pos_types, neg_types,
+                       pos_items, neg_items, batch, num_types, k, margin, alpha, partials, partials + batch,
+                       dsims_val, dproj);
+    PC_TRY(pc_launch_status());
+    hipLaunchKernelGGL(joint_loss_reduce_kernel, dim3(1), dim3(256), 0, st, partials, partials + batch, batch, k,
+                       alpha, losses);
+    return pc_launch_status();
+}
+
+// Sparse backward of sims = c E_c^T restricted to the two touched columns per row:
+//   dc[b] = v0 E_c[pos_b] + v1 E_c[neg_b];  dE_c[pos_b] += v0 c[b];  dE_c[neg_b] += v1 c[b]
+// one wave per sample, lane = one of the 64 type dims (256-B atomic rows: full-rate shape)
+__global__ __launch_bounds__(256) void type_hinge_bwd_kernel(const float* dsims_val, const int32_t* pos_t,
+                                                             const int32_t* neg_t, const float* c, const float* ec,
+                                                             int B, float* dc, float* dec) {
+    const int lane = threadIdx.x & 63;
+    const int b = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (b >= B) return;
+    const float v0 = dsims_val[2 * b], v1 = dsims_val[2 * b + 1];
+    const int p = pos_t[b], n = neg_t[b];
+    const float cb = c[(size_t)b * PC_L + lane];
+    dc[(size_t)b * PC_L + lane] = v0 * ec[(size_t)p * PC_L + lane] + v1 * ec[(size_t)n * PC_L + lane];
+    if (v0 != 0.f || v1 != 0.f) {
+        atomicAdd(dec + (size_t)p * PC_L + lane, v0 * cb);
+        atomicAdd(dec + (size_t)n * PC_L + lane, v1 * cb);
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+struct JointWs {
+    float *dpi, *dtp, *dce, *dc, *dh, *dt;
+    float *typ_wt, *dec_wt, *enc_wt;
+    float *sims, *proj, *dproj, *dsv, *partials;      // train_step scratch
+    float *h, *c, *pi, *tp;                           // train_step saved activations
+    float *slabs; size_t slab_floats;
+    size_t total;
+};
+
+static JointWs joint_ws_layout(void* base, int B, int T, int K) {
+    JointWs w;
+    size_t off = 0;
+    auto take = [&](size_t floats) {
+        float* p = base ? reinterpret_cast<float*>(reinterpret_cast<char*>(base) + off) : nullptr;
+        off += align256(floats * sizeof(float));
+        return p;
+    };
+    w.dpi = take((size_t)B * PC_D);
+    w.dtp = take((size_t)B * K * PC_D);
+    w.dce = take((size_t)B * K * PC_L);
+    w.dc = take((size_t)B * PC_L);
+    w.dh = take((size_t)B * LH);
+    w.dt = take((size_t)B * PC_L);
+    w.typ_wt = take(PC_L * PC_D);
+    w.dec_wt = take(LH * PC_L);
+    w.enc_wt = take(PC_L * LH);
+    w.sims = take((size_t)B * T);
+    w.proj = take((size_t)B * K * PC_D);
+    w.dproj = take((size_t)B * K * PC_D);
+    w.dsv = take((size_t)B * 2);
+    w.partials = take((size_t)B * 2);
+    w.h = take((size_t)B * LH);
+    w.c = take((size_t)B * PC_L);
+    w.pi = take((size_t)B * PC_D);
+    w.tp = take((size_t)B * K * PC_D);
+    size_t s = gemm_tn_workspace_floats(B * K, PC_D, PC_L);
+    size_t s2 = gemm_tn_workspace_floats(B, PC_D, PC_D);
+    if (s2 > s) s = s2;
+    w.slab_floats = s;
+    w.slabs = take(s);
+    w.total = off;
+    return w;
+}
+
+extern "C" size_t pc_joint_workspace_bytes(int batch, int num_types, int k) {
+    if (batch <= 0 || num_types <= 0 || k <= 0) return 0;
+    return joint_ws_layout(nullptr, batch, num_types, k).total;
+}
+
+static int joint_check(const pc_joint_tensors* p, int B, int T, int K) {
+    if (!p || !p->product_table || !p->enc_w || !p->enc_b || !p->dec_w || !p->dec_b || !p->typ_w || !p->typ_b ||
+        !p->itm_w || !p->itm_b || !p->query_types || !p->comp_types)
+        return PC_EINVAL;
+    if (B <= 0 || T <= 0) return PC_EINVAL;
+    if (K < 1 || K > JMAX_K || K > T) return PC_ESHAPE;
+    return PC_OK;
+}
+
+extern "C" int pc_joint_forward(const pc_joint_tensors* p, const int32_t* query_idx, const int32_t* query_types,
+                                int B, int T, int K, float* sims, int32_t* topk, float* proj,
+                                const pc_joint_saved* sv, void* ws, size_t ws_bytes, void* stream) {
+    PC_TRY(joint_check(p, B, T, K));
+    if (!query_idx || !query_types || !sims || !topk || !proj || !sv || !sv->h || !sv->c || !sv->pi || !sv->tp)
+        return PC_EINVAL;
+    (void)ws; (void)ws_bytes;
+    hipStream_t st = (hipStream_t)stream;
+    // h = relu(enc(E_q[query_types]))      type_transition.py:17 (dropout p = 0)
+    NtArgs e = nt_plain(p->query_types, PC_L, p->enc_w, PC_L, p->enc_b, sv->h, LH, B, LH, PC_L);
+    e.gather = query_types; e.epilogue = NT_EPI_RELU;
+    PC_TRY(launch_gemm_nt(e, st));
+    // c = dec(h)                            type_transition.py:19
+    PC_TRY(launch_gemm_nt(nt_plain(sv->h, LH, p->dec_w, LH, p->dec_b, sv->c, PC_L, B, PC_L, LH), st));
+    // sims = c E_c^T                        p_companion.py:60-63
+    PC_TRY(launch_gemm_nt(nt_plain(sv->c, PC_L, p->comp_types, PC_L, nullptr, sims, T, B, T, PC_L), st));
+    PC_TRY(pc_topk_rows(sims, B, T, K, topk, nullptr, stream));
+    // pi = item_projection(E_prod[query_idx])   item_prediction.py:31, p_companion.py:51
+    NtArgs ip = nt_plain(p->product_table, PC_D, p->itm_w, PC_D, p->itm_b, sv->pi, PC_D, B, PC_D, PC_D);
+    ip.gather = query_idx;
+    PC_TRY(launch_gemm_nt(ip, st));
+    // tp = type_projection(E_c[topk])           item_prediction.py:35, p_companion.py:65
+    NtArgs tpj = nt_plain(p->comp_types, PC_L, p->typ_w, PC_L, p->typ_b, sv->tp, PC_D, B * K, PC_D, PC_L);
+    tpj.gather = topk;
+    PC_TRY(launch_gemm_nt(tpj, st));
+    return pc_hadamard_forward(sv->pi, sv->tp, B, K, proj, stream);
+}
+
+extern "C" int pc_joint_backward(const pc_joint_tensors* p, const pc_joint_tensors* g, const int32_t* query_idx,
+                                 const int32_t* query_types, const int32_t* pos_types, const int32_t* neg_types,
+                                 const int32_t* topk, int B, int T, int K, const float* dsims_val,
+                                 const float* dproj, const pc_joint_saved* sv, void* ws, size_t ws_bytes,
+                                 void* stream) {
+    PC_TRY(joint_check(p, B, T, K));
+    if (!g || !g->enc_w || !g->enc_b || !g->dec_w || !g->dec_b || !g->typ_w || !g->typ_b || !g->itm_w ||
+        !g->itm_b || !g->query_types || !g->comp_types)
+        return PC_EINVAL;
+    if (!query_idx || !query_types || !pos_types || !neg_types || !topk || !dsims_val || !dproj || !sv || !ws)
+        return PC_EINVAL;
+    if (ws_bytes < pc_joint_workspace_bytes(B, T, K)) return PC_EWORKSPACE;
+    hipStream_t st = (hipStream_t)stream;
+    JointWs w = joint_ws_layout(ws, B, T, K);
+    const SegInfo siB = make_seginfo(nullptr, B, 128), siBK = make_seginfo(nullptr, B * K, 128);
+
+    PC_HIP_TRY(hipMemsetAsync(g->query_types, 0, (size_t)T * PC_L * 4, st));
+    PC_HIP_TRY(hipMemsetAsync(g->comp_types, 0, (size_t)T * PC_L * 4, st));
+    PC_TRY(launch_transpose(p->typ_w, PC_D, PC_L, w.typ_wt, st));   // [D,L] -> [L,D]
+    PC_TRY(launch_transpose(p->dec_w, PC_L, LH, w.dec_wt, st));     // [L,L/2] -> [L/2,L]
+    PC_TRY(launch_transpose(p->enc_w, LH, PC_L, w.enc_wt, st));     // [L/2,L] -> [L,L/2]
+
+    // ---- item branch
+    PC_TRY(pc_hadamard_backward(dproj, sv->pi, sv->tp, B, K, w.dpi, w.dtp, stream));
+    TnArgs ti = {};
+    ti.Z = w.dpi; ti.ldz = PC_D; ti.A = p->product_table; ti.lda = PC_D; ti.gather = query_idx; ti.R = B;
+    ti.No = PC_D; ti.Ni = PC_D; ti.seg = siB; ti.dW = g->itm_w; ti.lddw = PC_D; ti.db = g->itm_b;
+    ti.slabs = w.slabs; ti.slab_floats = w.slab_floats;
+    PC_TRY(launch_gemm_tn(ti, st));
+    TnArgs tt = {};
+    tt.Z = w.dtp; tt.ldz = PC_D; tt.A = p->comp_types; tt.lda = PC_L; tt.gather = topk; tt.R = B * K;
+    tt.No = PC_D; tt.Ni = PC_L; tt.seg = siBK; tt.dW = g->typ_w; tt.lddw = PC_L; tt.db = g->typ_b;
+    tt.slabs = w.slabs; tt.slab_floats = w.slab_floats;
+    PC_TRY(launch_gemm_tn(tt, st));
+    // dE_c[topk] += dtp typ_w     (row-sparse: only the K selected rows per sample)
+    PC_TRY(launch_gemm_nt(nt_plain(w.dtp, PC_D, w.typ_wt, PC_D, nullptr, w.dce, PC_L, B * K, PC_L, PC_D), st));
+    PC_TRY(pc_scatter_add_rows(g->comp_types, topk, B * K, PC_L, w.dce, stream));
+
+    // ---- type branch (two touched similarity columns per row)
+    hipLaunchKernelGGL(type_hinge_bwd_kernel, dim3((B + 3) / 4), dim3(256), 0, st, dsims_val, pos_types, neg_types,
+                       sv->c, p->comp_types, B, w.dc, g->comp_types);
+    PC_TRY(pc_launch_status());
+    TnArgs td = {};
+    td.Z = w.dc; td.ldz = PC_L; td.A = sv->h; td.lda = LH; td.R = B; td.No = PC_L; td.Ni = LH; td.seg = siB;
+    td.dW = g->dec_w; td.lddw = LH; td.db = g->dec_b; td.slabs = w.slabs; td.slab_floats = w.slab_floats;
+    PC_TRY(launch_gemm_tn(td, st));
+    NtArgs dh = nt_plain(w.dc, PC_L, w.dec_wt, PC_L, nullptr, w.dh, LH, B, LH, PC_L);
+    dh.epilogue = NT_EPI_DRELU; dh.aux = sv->h; dh.ldaux = LH;
+    PC_TRY(launch_gemm_nt(dh, st));
+    TnArgs te = {};
+    te.Z = w.dh; te.ldz = LH; te.A = p->query_types; te.lda = PC_L; te.gather = query_types; te.R = B;
+    te.No = LH; te.Ni = PC_L; te.seg = siB; te.dW = g->enc_w; te.lddw = PC_L; te.db = g->enc_b;
+    te.slabs = w.slabs; te.slab_floats = w.slab_floats;
+    PC_TRY(launch_gemm_tn(te, st));
+    PC_TRY(launch_gemm_nt(nt_plain(w.dh, LH, w.enc_wt, LH, nullptr, w.dt, PC_L, B, PC_L, LH), st));
+    return pc_scatter_add_rows(g->query_types, query_types, B, PC_L, w.dt, stream);
+}
+
+extern "C" int pc_joint_train_step(const pc_joint_tensors* p, const pc_joint_tensors* g, const int32_t* query_idx,
+                                   const int32_t* query_types, const int32_t* pos_types, const int32_t* neg_types,
+                                   const float* pos_items, const float* neg_items, int B, int T, int K,
+                                   float margin, float alpha, float* losses, int32_t* topk, void* ws,
+                                   size_t ws_bytes, void* stream) {
+    PC_TRY(joint_check(p, B, T, K));
+    if (!ws || !losses || !topk) return PC_EINVAL;
+    if (ws_bytes < pc_joint_workspace_bytes(B, T, K)) return PC_EWORKSPACE;
+    JointWs w = joint_ws_layout(ws, B, T, K);
+    pc_joint_saved sv;
+    sv.h = w.h; sv.c = w.c; sv.pi = w.pi; sv.tp = w.tp;
+    PC_TRY(pc_joint_forward(p, query_idx, query_types, B, T, K, w.sims, topk, w.proj, &sv, ws, ws_bytes, stream));
+    PC_TRY(pc_joint_loss(w.sims, w.proj, pos_types, neg_types, pos_items, neg_items, B, T, K, margin, alpha, losses,
+                         w.dsv, w.dproj, w.partials, stream));
+    return pc_joint_backward(p, g, query_idx, query_types, pos_types, neg_types, topk, B, T, K, w.dsv, w.dproj, &sv,
+                             ws, ws_bytes, stream);
+}

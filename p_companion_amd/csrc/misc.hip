@@ -1,0 +1,184 @@
+// Small HBM-bound kernels of the hot path: the triplet loss of Product2Vec.train_model
+// (forward + backward in one pass), dense Adam, row gather / row scatter-add.
+#include "common.h"
+
+// ---------------------------------------------------------------------------------------
+// P9 (product2vec.py:137-154): one wavefront per sample, lane l owns dims (2l, 2l+1).
+//   d+ = ||a - p + eps||, d-_j = ||a - n_j + eps||, d- = mean_j d-_j, l = relu(margin - d+ + d-)
+#define LOSS_MAX_K 8
+#define PAIR_EPS 1e-6f
+
+__global__ __launch_bounds__(256) void triplet_loss_kernel(const float* a, const float* p, const float* n, int B,
+                                                           int K, float margin, float* d_pos, float* d_neg,
+                                                           float* da, float* dp, float* dn) {
+    const int lane = threadIdx.x & 63;
+    const int b = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (b >= B) return;
+    const float2 av = *reinterpret_cast<const float2*>(a + (size_t)b * PC_D + 2 * lane);
+    const float2 pv = *reinterpret_cast<const float2*>(p + (size_t)b * PC_D + 2 * lane);
+    const float2 dpv = make_float2(av.x - pv.x + PAIR_EPS, av.y - pv.y + PAIR_EPS);
+    const float dpos = sqrtf(wave_sum(dpv.x * dpv.x + dpv.y * dpv.y));
+    float2 dnv[LOSS_MAX_K];
+    float dn_j[LOSS_MAX_K];
+    float dneg = 0.f;
+#pragma unroll
+    for (int j = 0; j < LOSS_MAX_K; j++) {
+        if (j < K) {
+            const float2 nv = *reinterpret_cast<const float2*>(n + ((size_t)b * K + j) * PC_D + 2 * lane);
+            dnv[j] = make_float2(av.x - nv.x + PAIR_EPS, av.y - nv.y + PAIR_EPS);
+            dn_j[j] = sqrtf(wave_sum(dnv[j].x * dnv[j].x + dnv[j].y * dnv[j].y));
+            dneg += dn_j[j];
+        }
+    }
+    dneg /= (float)K;
+    if (lane == 0) { d_pos[b] = dpos; d_neg[b] = dneg; }
+    if (!da) return;
+    const bool active = (margin - dpos + dneg) > 0.f;      // relu'(0) = 0 as in torch
+    const float gs = active ? 1.0f / (float)B : 0.f;        // d(mean)/d(l_b)
+    // d l / d d+ = -1 ; d l / d d-_j = 1/K
+    const float ip = gs / dpos;
+    float2 ga = make_float2(-dpv.x * ip, -dpv.y * ip);
+    *reinterpret_cast<float2*>(dp + (size_t)b * PC_D + 2 * lane) = make_float2(dpv.x * ip, dpv.y * ip);
+#pragma unroll
+    for (int j = 0; j < LOSS_MAX_K; j++) {
+        if (j < K) {
+            const float in = gs / ((float)K * dn_j[j]);
+            ga.x += dnv[j].x * in;
+            ga.y += dnv[j].y * in;
+            *reinterpret_cast<float2*>(dn + ((size_t)b * K + j) * PC_D + 2 * lane) =
+                make_float2(-dnv[j].x * in, -dnv[j].y * in);
+        }
+    }
+    *reinterpret_cast<float2*>(da + (size_t)b * PC_D + 2 * lane) = ga;
+}
+
+// loss = mean_b relu(margin - d+ + d-): single block, fixed summation order
+__global__ void hinge_mean_kernel(const float* d_pos, const float* d_neg, int B, float margin, float* loss) {
+    __shared__ float red[256];
+    float s = 0.f;
+    for (int b = threadIdx.x; b < B; b += 256) {
+        const float l = margin - d_pos[b] + d_neg[b];
+        s += l > 0.f ? l : 0.f;
+    }
+    red[threadIdx.x] = s;
+    __syncthreads();
+    for (int o = 128; o >= 1; o >>= 1) {
+        if (threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) *loss = red[0] / (float)B;
+}
+
+extern "C" int pc_p2v_triplet_loss(const float* a, const float* p, const float* n, int batch, int k_neg,
+                                   float margin, float* loss, float* d_pos, float* d_neg, float* da, float* dp,
+                                   float* dn, void* stream) {
+    if (!a || !p || !n || !loss || !d_pos || !d_neg || batch <= 0) return PC_EINVAL;
+    if (k_neg < 1 || k_neg > LOSS_MAX_K) return PC_ESHAPE;
+    if (da && (!dp || !dn)) return PC_EINVAL;
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(triplet_loss_kernel, dim3((batch + 3) / 4), dim3(256), 0, st, a, p, n, batch, k_neg, margin,
+                       d_pos, d_neg, da, dp, dn);
+    PC_TRY(pc_launch_status());
+    hipLaunchKernelGGL(hinge_mean_kernel, dim3(1), dim3(256), 0, st, d_pos, d_neg, batch, margin, loss);
+    return pc_launch_status();
+}
+
+// ---------------------------------------------------------------------------------------
+// P10: torch.optim.Adam (defaults) over a flat fp32 range.  Scalars follow torch's
+// single-tensor path: bias corrections and step size in fp64, rounded to fp32 at use.
+__global__ void adam_prep_kernel(int64_t* step_count, double lr, double beta1, double beta2, float* scal) {
+    const int64_t t = *step_count + 1;
+    *step_count = t;
+    const double bc1 = 1.0 - pow(beta1, (double)t);
+    const double bc2 = 1.0 - pow(beta2, (double)t);
+    scal[0] = (float)(lr / bc1);              // step_size
+    scal[1] = (float)sqrt(bc2);               // bias_correction2_sqrt
+}
+
+__global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                            float* __restrict__ v, size_t n, const float* scal, float omb1, float beta2,
+                            float omb2, float eps) {
+    const float step_size = scal[0], bc2s = scal[1];
+    const size_t i4 = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+    if (i4 + 3 < n) {
+        float4 pv = *reinterpret_cast<float4*>(p + i4);
+        const float4 gv = *reinterpret_cast<const float4*>(g + i4);
+        float4 mv = *reinterpret_cast<float4*>(m + i4);
+        float4 vv = *reinterpret_cast<float4*>(v + i4);
+#define ADAM1(c)                                                         \
+        mv.c = mv.c + (gv.c - mv.c) * omb1;                              \
+        vv.c = vv.c * beta2 + omb2 * gv.c * gv.c;                        \
+        pv.c = pv.c - step_size * (mv.c / (sqrtf(vv.c) / bc2s + eps));
+        ADAM1(x) ADAM1(y) ADAM1(z) ADAM1(w)
+        *reinterpret_cast<float4*>(p + i4) = pv;
+        *reinterpret_cast<float4*>(m + i4) = mv;
+        *reinterpret_cast<float4*>(v + i4) = vv;
+    } else {
+        for (size_t i = i4; i < n; i++) {
+            float mm = m[i] + (g[i] - m[i]) * omb1;
+            float vv = v[i] * beta2 + omb2 * g[i] * g[i];
+            p[i] = p[i] - step_size * (mm / (sqrtf(vv) / bc2s + eps));
+            m[i] = mm;
+            v[i] = vv;
+        }
+    }
+}
+
+extern "C" int pc_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, size_t n,
+                            int64_t* step_count, float* scalars, double lr, double beta1, double beta2,
+                            double eps, void* stream) {
+    if (!param || !grad || !exp_avg || !exp_avg_sq || !step_count || !scalars || n == 0) return PC_EINVAL;
+    if (((uintptr_t)param | (uintptr_t)grad | (uintptr_t)exp_avg | (uintptr_t)exp_avg_sq) & 15) return PC_ESHAPE;
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(adam_prep_kernel, dim3(1), dim3(1), 0, st, step_count, lr, beta1, beta2, scalars);
+    PC_TRY(pc_launch_status());
+    const size_t threads = (n + 3) / 4;
+    hipLaunchKernelGGL(adam_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, st, param, grad, exp_avg,
+                       exp_avg_sq, n, scalars, (float)(1.0 - beta1), (float)beta2, (float)(1.0 - beta2), (float)eps);
+    return pc_launch_status();
+}
+
+// ---------------------------------------------------------------------------------------
+// out[r] = idx[r] >= 0 ? table[idx[r]] : 0 ; one 16-B chunk per thread, rows coalesced
+__global__ void gather_rows_kernel(const float* table, const int32_t* idx, int rows, int w4, float* out) {
+    const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t total = (size_t)rows * w4;
+    if (t >= total) return;
+    const int r = (int)(t / w4), c = (int)(t % w4);
+    const int src = idx ? idx[r] : r;
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (src >= 0) v = *reinterpret_cast<const float4*>(table + ((size_t)src * w4 + c) * 4);
+    *reinterpret_cast<float4*>(out + t * 4) = v;
+}
+
+extern "C" int pc_gather_rows(const float* table, const int32_t* idx, int rows, int width, float* out,
+                              void* stream) {
+    if (!table || !out || rows <= 0 || width <= 0) return PC_EINVAL;
+    if (width % 4) return PC_ESHAPE;
+    const size_t total = (size_t)rows * (width / 4);
+    hipLaunchKernelGGL(gather_rows_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                       table, idx, rows, width / 4, out);
+    return pc_launch_status();
+}
+
+// table[idx[r]] += src[r] : one wave-instruction adds 64 consecutive floats of one row
+// (256 contiguous bytes per atomic instruction = the full-rate shape on gfx950)
+__global__ void scatter_add_rows_kernel(float* table, const int32_t* idx, int rows, int width, const float* src) {
+    const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t total = (size_t)rows * width;
+    if (t >= total) return;
+    const int r = (int)(t / width), c = (int)(t % width);
+    const int dst = idx[r];
+    if (dst >= 0) atomicAdd(table + (size_t)dst * width + c, src[t]);
+}
+
+extern "C" int pc_scatter_add_rows(float* table, const int32_t* idx, int rows, int width, const float* src,
+                                   void* stream) {
+    if (!table || !idx || !src || rows <= 0 || width <= 0) return PC_EINVAL;
+    const size_t total = (size_t)rows * width;
+    hipLaunchKernelGGL(scatter_add_rows_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0,
+                       (hipStream_t)stream, table, idx, rows, width, src);
+    return pc_launch_status();
+}
+
+extern "C" int pc_abi_version(void) { return 1; }

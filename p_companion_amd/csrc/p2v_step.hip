@@ -1,0 +1,130 @@
+// One iteration of Product2Vec.train_model's loop body (product2vec.py:126-159) in index
+// form: the four FFN calls of :132-134 run as ONE segmented launch sequence over the
+// concatenated rows [anchor | neighbours | positive | negatives] (BatchNorm statistics stay
+// per call), then attention, loss and the whole backward.  Gradients overwrite `g`
+// (= optimizer.zero_grad() + loss.backward()); the optimizer step is pc_adam_step.
+#include "common.h"
+
+static inline size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
+
+struct StepWs {
+    int32_t* idx_all;
+    float *y, *h0, *a2, *bn;     // bn: mean, invstd, scale, shift  [4][MAX_SEG][H]
+    float *q, *kv, *probs, *ctx, *emb;
+    float *dy, *demb, *dpos_tmp, *dneg_tmp;
+    void* ffn_ws; size_t ffn_bytes;
+    void* attn_ws; size_t attn_bytes;
+    size_t total;
+};
+
+static StepWs step_ws_layout(void* base, int B, int N, int K) {
+    StepWs w;
+    const size_t R = (size_t)B * (2 + N + K);
+    size_t off = 0;
+    auto take = [&](size_t bytes) {
+        void* p = base ? reinterpret_cast<char*>(base) + off : nullptr;
+        off += align256(bytes);
+        return p;
+    };
+    w.idx_all = (int32_t*)take(R * 4);
+    w.y = (float*)take(R * PC_D * 4);
+    w.h0 = (float*)take(R * PC_H * 4);
+    w.a2 = (float*)take(R * PC_H * 4);
+    w.bn = (float*)take(4 * PC_MAX_SEG * PC_H * 4);
+    w.q = (float*)take((size_t)B * PC_D * 4);
+    w.kv = (float*)take((size_t)B * (N > 0 ? N : 1) * 2 * PC_D * 4);
+    w.probs = (float*)take((size_t)B * PC_HEADS * (N > 0 ? N : 1) * 4);
+    w.ctx = (float*)take((size_t)B * PC_D * 4);
+    w.emb = (float*)take((size_t)B * PC_D * 4);
+    w.dy = (float*)take(R * PC_D * 4);
+    w.demb = (float*)take((size_t)B * PC_D * 4);
+    w.dpos_tmp = (float*)take((size_t)B * 4);
+    w.dneg_tmp = (float*)take((size_t)B * 4);
+    w.ffn_bytes = pc_p2v_ffn_workspace_bytes((int)R);
+    w.ffn_ws = take(w.ffn_bytes);
+    w.attn_bytes = N > 0 ? pc_p2v_attention_workspace_bytes(B, N) : 0;
+    w.attn_ws = take(w.attn_bytes);
+    w.total = off;
+    return w;
+}
+
+extern "C" size_t pc_p2v_train_step_workspace_bytes(int batch, int n_nbr, int k_neg) {
+    if (batch <= 0 || n_nbr < 0 || k_neg <= 0) return 0;
+    return step_ws_layout(nullptr, batch, n_nbr, k_neg).total;
+}
+
+__global__ void concat_idx_kernel(const int32_t* a, int na, const int32_t* b, int nb, const int32_t* c, int nc,
+                                  const int32_t* d, int nd, int32_t* out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < na) out[i] = a[i];
+    else if (i < na + nb) out[i] = b[i - na];
+    else if (i < na + nb + nc) out[i] = c[i - na - nb];
+    else if (i < na + nb + nc + nd) out[i] = d[i - na - nb - nc];
+}
+
+extern "C" int pc_p2v_ffn_backward(const pc_p2v_tensors* p, const pc_p2v_tensors* g, const float* table,
+                                   const int32_t* idx, int rows, const pc_segments* seg, const float* dy,
+                                   const pc_ffn_saved* sv, float* dx, int accumulate, void* ws, size_t ws_bytes,
+                                   void* stream);
+extern "C" int pc_p2v_attention_backward(const pc_p2v_tensors* p, const pc_p2v_tensors* g, const float* query,
+                                         const float* keys, int B, int N, const float* dout,
+                                         const pc_attn_saved* sv, float* dquery, float* dkeys, int accumulate,
+                                         void* ws, size_t ws_bytes, void* stream);
+
+extern "C" int pc_p2v_train_step(const pc_p2v_tensors* p, const pc_p2v_tensors* g, const float* table,
+                                 const int32_t* anchor_idx, const int32_t* positive_idx,
+                                 const int32_t* negative_idx, const int32_t* neighbor_idx, int B, int N, int K,
+                                 float margin, float* loss, float* d_pos, float* d_neg, float* anchor_emb,
+                                 void* ws, size_t ws_bytes, void* stream) {
+    if (!p || !g || !table || !anchor_idx || !positive_idx || !negative_idx || !loss || !ws) return PC_EINVAL;
+    if (B <= 0 || N < 0 || K <= 0 || (N > 0 && !neighbor_idx)) return PC_EINVAL;
+    if (ws_bytes < pc_p2v_train_step_workspace_bytes(B, N, K)) return PC_EWORKSPACE;
+    hipStream_t st = (hipStream_t)stream;
+    StepWs w = step_ws_layout(ws, B, N, K);
+    const int R = B * (2 + N + K);
+    const int rA = 0, rN = B, rP = B + B * N, rG = rP + B;
+
+    // call order of product2vec.py:132-134: anchor (:73), neighbours (:78), positive, negative
+    pc_segments seg;
+    if (N > 0) { seg.nseg = 4; seg.start[0] = rA; seg.start[1] = rN; seg.start[2] = rP; seg.start[3] = rG; seg.start[4] = R; }
+    else { seg.nseg = 3; seg.start[0] = rA; seg.start[1] = rP; seg.start[2] = rG; seg.start[3] = R; seg.start[4] = R; }
+
+    hipLaunchKernelGGL(concat_idx_kernel, dim3((R + 255) / 256), dim3(256), 0, st, anchor_idx, B, neighbor_idx,
+                       B * N, positive_idx, B, negative_idx, B * K, w.idx_all);
+    PC_TRY(pc_launch_status());
+
+    pc_ffn_saved sv;
+    sv.h0 = w.h0; sv.a2 = w.a2;
+    sv.bn_mean = w.bn; sv.bn_invstd = w.bn + PC_MAX_SEG * PC_H; sv.bn_scale = w.bn + 2 * PC_MAX_SEG * PC_H;
+    sv.bn_shift = w.bn + 3 * PC_MAX_SEG * PC_H;
+    PC_TRY(pc_p2v_ffn_forward_train(p, table, w.idx_all, R, &seg, 1, w.y, &sv, w.ffn_ws, w.ffn_bytes, stream));
+
+    pc_attn_saved as;
+    as.q = w.q; as.kv = w.kv; as.probs = w.probs; as.ctx = w.ctx;
+    const float* emb = w.y;                     // anchor embedding = FFN output when there are no neighbours
+    if (N > 0) {
+        PC_TRY(pc_p2v_attention_forward(p, w.y + (size_t)rA * PC_D, w.y + (size_t)rN * PC_D, B, N, w.emb, &as,
+                                        w.attn_ws, w.attn_bytes, stream));
+        emb = w.emb;
+    }
+
+    float* dp_out = d_pos ? d_pos : w.dpos_tmp;
+    float* dn_out = d_neg ? d_neg : w.dneg_tmp;
+    float* demb = N > 0 ? w.demb : w.dy + (size_t)rA * PC_D;
+    PC_TRY(pc_p2v_triplet_loss(emb, w.y + (size_t)rP * PC_D, w.y + (size_t)rG * PC_D, B, K, margin, loss, dp_out,
+                               dn_out, demb, w.dy + (size_t)rP * PC_D, w.dy + (size_t)rG * PC_D, stream));
+    if (anchor_emb)
+        PC_HIP_TRY(hipMemcpyAsync(anchor_emb, emb, (size_t)B * PC_D * 4, hipMemcpyDeviceToDevice, st));
+
+    if (N > 0) {
+        PC_TRY(pc_p2v_attention_backward(p, g, w.y + (size_t)rA * PC_D, w.y + (size_t)rN * PC_D, B, N, w.demb, &as,
+                                         w.dy + (size_t)rA * PC_D, w.dy + (size_t)rN * PC_D, 0, w.attn_ws,
+                                         w.attn_bytes, stream));
+    } else {
+        PC_HIP_TRY(hipMemsetAsync(g->in_proj_w, 0, 3 * PC_D * PC_D * 4, st));
+        PC_HIP_TRY(hipMemsetAsync(g->in_proj_b, 0, 3 * PC_D * 4, st));
+        PC_HIP_TRY(hipMemsetAsync(g->out_proj_w, 0, PC_D * PC_D * 4, st));
+        PC_HIP_TRY(hipMemsetAsync(g->out_proj_b, 0, PC_D * 4, st));
+    }
+    return pc_p2v_ffn_backward(p, g, table, w.idx_all, R, &seg, w.dy, &sv, nullptr, 0, w.ffn_ws, w.ffn_bytes, stream);
+}

@@ -1,0 +1,102 @@
+// P1-P4 on device: index-form batch construction for the Product2Vec loop.
+//   (anchor, positive) = sim_pairs[pair_id]                      data_loader.py:46
+//   neighbours = co-view CSR row of the anchor, -1 padded        bpg.py:24-38, data_loader.py:186-198
+//   negatives  = k distinct uniform products, rejecting the anchor, the anchor's positives
+//                and repeats                                     data_loader.py:27-40
+// The reference draws from CPython's sequential MT19937 stream (host path: host_mt.cpp, bit
+// exact).  This is the throughput path: the same rejection rules on a counter-based
+// Philox4x32-10 stream keyed by (seed; sample, step), so every sample draws independently.
+#include "common.h"
+
+struct Philox {
+    uint32_t c[4], k[2], out[4];
+    int have;
+    __device__ Philox(uint64_t seed, uint64_t step, uint32_t sample) {
+        k[0] = (uint32_t)seed; k[1] = (uint32_t)(seed >> 32);
+        c[0] = 0; c[1] = sample; c[2] = (uint32_t)step; c[3] = (uint32_t)(step >> 32);
+        have = 0;
+    }
+    __device__ void block() {
+        uint32_t x0 = c[0], x1 = c[1], x2 = c[2], x3 = c[3], k0 = k[0], k1 = k[1];
+#pragma unroll
+        for (int r = 0; r < 10; r++) {
+            const uint64_t p0 = (uint64_t)0xD2511F53u * x0, p1 = (uint64_t)0xCD9E8D57u * x2;
+            const uint32_t y0 = (uint32_t)(p1 >> 32) ^ x1 ^ k0, y1 = (uint32_t)p1;
+            const uint32_t y2 = (uint32_t)(p0 >> 32) ^ x3 ^ k1, y3 = (uint32_t)p0;
+            x0 = y0; x1 = y1; x2 = y2; x3 = y3;
+            k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+        }
+        out[0] = x0; out[1] = x1; out[2] = x2; out[3] = x3;
+        c[0]++;                      // draw-block counter
+        have = 4;
+    }
+    __device__ uint32_t next() {
+        if (have == 0) block();
+        return out[4 - have--];
+    }
+    // unbiased integer in [0, n): top bit_length(n) bits, redraw while >= n (the rule of
+    // CPython's _randbelow_with_getrandbits, applied to this stream)
+    __device__ uint32_t below(uint32_t n) {
+        const int bits = 32 - __clz(n);
+        uint32_t r = next() >> (32 - bits);
+        while (r >= n) r = next() >> (32 - bits);
+        return r;
+    }
+};
+
+__global__ void build_pairs_negatives_kernel(const int32_t* pair_ids, int B, const int32_t* sim_pairs,
+                                             const int32_t* sim_rowptr, const int32_t* sim_col, int n_products,
+                                             int K, uint64_t seed, uint64_t step, int32_t* anchor_idx,
+                                             int32_t* positive_idx, int32_t* negative_idx) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    const int pid = pair_ids[b];
+    const int a = sim_pairs[2 * pid], pos = sim_pairs[2 * pid + 1];
+    anchor_idx[b] = a;
+    positive_idx[b] = pos;
+    const int lo = sim_rowptr[a], hi = sim_rowptr[a + 1];
+    Philox rng(seed, step, (uint32_t)b);
+    int got = 0;
+    while (got < K) {
+        const int c = (int)rng.below((uint32_t)n_products);
+        bool ok = c != a;
+        for (int j = lo; ok && j < hi; j++) ok = sim_col[j] != c;
+        for (int j = 0; ok && j < got; j++) ok = negative_idx[(size_t)b * K + j] != c;
+        if (ok) negative_idx[(size_t)b * K + got++] = c;
+    }
+}
+
+__global__ void build_neighbors_kernel(const int32_t* anchor_idx, int B, const int32_t* cv_rowptr,
+                                       const int32_t* cv_col, int n_pad, int32_t* neighbor_idx) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= B * n_pad) return;
+    const int b = t / n_pad, j = t % n_pad;
+    const int a = anchor_idx[b];
+    const int lo = cv_rowptr[a], deg = cv_rowptr[a + 1] - lo;
+    neighbor_idx[t] = j < deg ? cv_col[lo + j] : -1;
+}
+
+extern "C" int pc_build_similarity_batch(const int32_t* pair_ids, int batch, const int32_t* sim_pairs,
+                                         const int32_t* cv_rowptr, const int32_t* cv_col,
+                                         const int32_t* sim_rowptr, const int32_t* sim_col, int n_products,
+                                         int n_pad, int k_neg, uint64_t seed, uint64_t step, int32_t* anchor_idx,
+                                         int32_t* positive_idx, int32_t* negative_idx, int32_t* neighbor_idx,
+                                         void* stream) {
+    if (!pair_ids || !sim_pairs || !cv_rowptr || !cv_col || !sim_rowptr || !sim_col || !anchor_idx ||
+        !positive_idx || !negative_idx)
+        return PC_EINVAL;
+    if (batch <= 0 || n_pad < 0 || k_neg <= 0 || n_products <= k_neg + 1) return PC_EINVAL;
+    if (n_pad > 0 && !neighbor_idx) return PC_EINVAL;
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(build_pairs_negatives_kernel, dim3((batch + 127) / 128), dim3(128), 0, st, pair_ids, batch,
+                       sim_pairs, sim_rowptr, sim_col, n_products, k_neg, seed, step, anchor_idx, positive_idx,
+                       negative_idx);
+    PC_TRY(pc_launch_status());
+    if (n_pad > 0) {
+        const int total = batch * n_pad;
+        hipLaunchKernelGGL(build_neighbors_kernel, dim3((total + 255) / 256), dim3(256), 0, st, anchor_idx, batch,
+                           cv_rowptr, cv_col, n_pad, neighbor_idx);
+        PC_TRY(pc_launch_status());
+    }
+    return PC_OK;
+}

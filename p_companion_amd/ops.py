@@ -1,0 +1,481 @@
+"""Tensor-level wrappers over the C ABI (include/pcompanion_hip.h).
+
+torch is used here for device memory and the current stream only: every computation is a
+HIP kernel of libpcompanion_hip.so.  All tensors must be CUDA(ROCm), contiguous, fp32 /
+int32; anything else raises (no silent conversion on the hot path, no CPU fallback).
+"""
+import ctypes
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import D, H, HEADS, L, PC_MAX_SEG, AttnSaved, FfnSaved, JointSaved, JointTensors, P2VTensors, Segments, check
+
+P2V_KEYS = ("ffn.0.weight", "ffn.0.bias", "ffn.1.weight", "ffn.1.bias", "ffn.3.weight", "ffn.3.bias",
+            "ffn.5.weight", "ffn.5.bias", "attention.in_proj_weight", "attention.in_proj_bias",
+            "attention.out_proj.weight", "attention.out_proj.bias")
+P2V_FIELDS = ("w0", "b0", "gamma", "beta", "w3", "b3", "w5", "b5", "in_proj_w", "in_proj_b", "out_proj_w",
+              "out_proj_b")
+P2V_SHAPES = ((H, D), (H,), (H,), (H,), (H, H), (H,), (D, H), (D,), (3 * D, D), (3 * D,), (D, D), (D,))
+P2V_BUFFERS = (("ffn.1.running_mean", "running_mean"), ("ffn.1.running_var", "running_var"),
+               ("ffn.1.num_batches_tracked", "num_batches_tracked"))
+
+JOINT_KEYS = ("type_transition.encoder.weight", "type_transition.encoder.bias",
+              "type_transition.decoder.weight", "type_transition.decoder.bias",
+              "item_prediction.type_projection.weight", "item_prediction.type_projection.bias",
+              "item_prediction.item_projection.weight", "item_prediction.item_projection.bias",
+              "query_type_embeddings.weight", "complementary_type_embeddings.weight")
+JOINT_FIELDS = ("enc_w", "enc_b", "dec_w", "dec_b", "typ_w", "typ_b", "itm_w", "itm_b", "query_types",
+                "comp_types")
+
+
+def _req(t, dtype, name, shape=None):
+    if not isinstance(t, torch.Tensor) or not t.is_cuda:
+        raise TypeError(f"{name}: expected a CUDA/ROCm tensor (the HIP path has no CPU fallback)")
+    if t.dtype != dtype:
+        raise TypeError(f"{name}: expected {dtype}, got {t.dtype}")
+    if not t.is_contiguous():
+        raise ValueError(f"{name}: must be contiguous")
+    if shape is not None and tuple(t.shape) != tuple(shape):
+        raise ValueError(f"{name}: expected shape {tuple(shape)}, got {tuple(t.shape)}")
+    return t
+
+
+def _p(t):
+    return ctypes.c_void_p(t.data_ptr()) if t is not None else None
+
+
+def _stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+_ws_cache = {}
+
+
+def workspace(nbytes, device, tag="ws"):
+    """Grow-only scratch buffer per (device, stream, tag); contents never outlive a call."""
+    key = (device.index, torch.cuda.current_stream(device).cuda_stream, tag)
+    buf = _ws_cache.get(key)
+    if buf is None or buf.numel() < nbytes:
+        buf = torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device=device)
+        _ws_cache[key] = buf
+    return buf
+
+
+def make_segments(starts, rows):
+    """starts: row starts of each BatchNorm call group, e.g. [0, B, B+B*N]; rows = total."""
+    if not 1 <= len(starts) <= PC_MAX_SEG:
+        raise ValueError("1..4 segments")
+    s = Segments()
+    s.nseg = len(starts)
+    arr = list(starts) + [rows] * (PC_MAX_SEG + 1 - len(starts))
+    for i, v in enumerate(arr):
+        s.start[i] = int(v)
+    for i in range(s.nseg):
+        n = s.start[i + 1] - s.start[i]
+        if n == 1:
+            # nn.BatchNorm1d raises the same in training mode (torch/nn/functional.py _verify_batch_size)
+            raise ValueError("Expected more than 1 value per channel when training, got input size "
+                             f"torch.Size([1, {H}])")
+    return s
+
+
+def p2v_struct(tensors, with_buffers=True):
+    """tensors: mapping reference-state_dict-key -> tensor (parameters or gradients)."""
+    st = P2VTensors()
+    dev = None
+    for key, field, shape in zip(P2V_KEYS, P2V_FIELDS, P2V_SHAPES):
+        t = _req(tensors[key], torch.float32, key, shape)
+        dev = t.device
+        setattr(st, field, t.data_ptr())
+    if with_buffers:
+        for key, field in P2V_BUFFERS:
+            t = tensors.get(key)
+            if t is not None:
+                _req(t, torch.int64 if "num_batches" in key else torch.float32, key)
+                setattr(st, field, t.data_ptr())
+    return st, dev
+
+
+def _new_p2v_grads(device):
+    return {k: torch.empty(s, dtype=torch.float32, device=device) for k, s in zip(P2V_KEYS, P2V_SHAPES)}
+
+
+# ----------------------------------------------------------------------------- P6
+def ffn_forward_train(params, table, idx, rows, seg_starts, update_running=True):
+    """Product2Vec.get_initial_embedding in training mode over `rows` rows made of
+    len(seg_starts) BatchNorm call groups.  Returns (y[rows,D], saved)."""
+    st, dev = p2v_struct(params)
+    _req(table, torch.float32, "table")
+    if idx is not None:
+        _req(idx, torch.int32, "idx", (rows,))
+    seg = make_segments(seg_starts, rows)
+    y = torch.empty(rows, D, dtype=torch.float32, device=dev)
+    sv = {"h0": torch.empty(rows, H, dtype=torch.float32, device=dev),
+          "a2": torch.empty(rows, H, dtype=torch.float32, device=dev),
+          "bn": torch.empty(4, PC_MAX_SEG, H, dtype=torch.float32, device=dev),
+          "seg_starts": list(seg_starts), "rows": rows}
+    nbytes = _lib.lib().pc_p2v_ffn_workspace_bytes(rows)
+    ws = workspace(nbytes, dev)
+    check(_lib.lib().pc_p2v_ffn_forward_train(ctypes.byref(st), _p(table), _p(idx), rows, ctypes.byref(seg),
+                                              1 if update_running else 0, _p(y), ctypes.byref(_ffn_saved(sv)),
+                                              _p(ws), nbytes, _stream()), "pc_p2v_ffn_forward_train")
+    return y, sv
+
+
+def _ffn_saved(sv):
+    s = FfnSaved()
+    s.h0, s.a2 = sv["h0"].data_ptr(), sv["a2"].data_ptr()
+    bn = sv["bn"]
+    s.bn_mean, s.bn_invstd, s.bn_scale, s.bn_shift = (bn[i].data_ptr() for i in range(4))
+    return s
+
+
+def ffn_forward_eval(params, table, idx, rows):
+    st, dev = p2v_struct(params)
+    _req(table, torch.float32, "table")
+    if idx is not None:
+        _req(idx, torch.int32, "idx", (rows,))
+    y = torch.empty(rows, D, dtype=torch.float32, device=dev)
+    nbytes = _lib.lib().pc_p2v_ffn_workspace_bytes(rows)
+    ws = workspace(nbytes, dev)
+    check(_lib.lib().pc_p2v_ffn_forward_eval(ctypes.byref(st), _p(table), _p(idx), rows, _p(y), _p(ws), nbytes,
+                                             _stream()), "pc_p2v_ffn_forward_eval")
+    return y
+
+
+def ffn_backward(params, table, idx, dy, sv, need_dx=False, grads=None, accumulate=False):
+    st, dev = p2v_struct(params)
+    rows = sv["rows"]
+    _req(dy, torch.float32, "dy", (rows, D))
+    if grads is None:
+        grads = _new_p2v_grads(dev)
+        accumulate = False
+    gst, _ = p2v_struct(grads, with_buffers=False)
+    seg = make_segments(sv["seg_starts"], rows)
+    dx = torch.empty(rows, D, dtype=torch.float32, device=dev) if need_dx else None
+    nbytes = _lib.lib().pc_p2v_ffn_workspace_bytes(rows)
+    ws = workspace(nbytes, dev)
+    check(_lib.lib().pc_p2v_ffn_backward(ctypes.byref(st), ctypes.byref(gst), _p(table), _p(idx), rows,
+                                         ctypes.byref(seg), _p(dy), ctypes.byref(_ffn_saved(sv)), _p(dx),
+                                         1 if accumulate else 0, _p(ws), nbytes, _stream()), "pc_p2v_ffn_backward")
+    return grads, dx
+
+
+# ----------------------------------------------------------------------------- P7
+def _attn_saved(sv):
+    s = AttnSaved()
+    s.q, s.kv, s.probs, s.ctx = (sv[k].data_ptr() for k in ("q", "kv", "probs", "ctx"))
+    return s
+
+
+def attention_forward(params, query, keys):
+    """query [B,D], keys [B,N,D] -> out [B,D], saved."""
+    st, dev = p2v_struct(params)
+    b, n, _ = keys.shape
+    _req(query, torch.float32, "query", (b, D))
+    _req(keys, torch.float32, "keys", (b, n, D))
+    out = torch.empty(b, D, dtype=torch.float32, device=dev)
+    sv = {"q": torch.empty(b, D, dtype=torch.float32, device=dev),
+          "kv": torch.empty(b * n, 2 * D, dtype=torch.float32, device=dev),
+          "probs": torch.empty(b, HEADS, n, dtype=torch.float32, device=dev),
+          "ctx": torch.empty(b, D, dtype=torch.float32, device=dev)}
+    nbytes = _lib.lib().pc_p2v_attention_workspace_bytes(b, n)
+    ws = workspace(nbytes, dev)
+    check(_lib.lib().pc_p2v_attention_forward(ctypes.byref(st), _p(query), _p(keys), b, n, _p(out),
+                                              ctypes.byref(_attn_saved(sv)), _p(ws), nbytes, _stream()),
+          "pc_p2v_attention_forward")
+    return out, sv
+
+
+def attention_backward(params, query, keys, dout, sv, grads=None, accumulate=False):
+    st, dev = p2v_struct(params)
+    b, n, _ = keys.shape
+    _req(dout, torch.float32, "dout", (b, D))
+    if grads is None:
+        grads = _new_p2v_grads(dev)
+        accumulate = False
+    gst, _ = p2v_struct(grads, with_buffers=False)
+    dq = torch.empty(b, D, dtype=torch.float32, device=dev)
+    dk = torch.empty(b, n, D, dtype=torch.float32, device=dev)
+    nbytes = _lib.lib().pc_p2v_attention_workspace_bytes(b, n)
+    ws = workspace(nbytes, dev)
+    check(_lib.lib().pc_p2v_attention_backward(ctypes.byref(st), ctypes.byref(gst), _p(query), _p(keys), b, n,
+                                               _p(dout), ctypes.byref(_attn_saved(sv)), _p(dq), _p(dk),
+                                               1 if accumulate else 0, _p(ws), nbytes, _stream()),
+          "pc_p2v_attention_backward")
+    return grads, dq, dk
+
+
+# ----------------------------------------------------------------------------- P9 / P10
+def triplet_loss(a, p, n, margin, need_grad=True):
+    """a,p [B,D]; n [B,K,D].  Returns dict(loss[1], d_pos[B], d_neg[B], da, dp, dn)."""
+    b, k, _ = n.shape
+    _req(a, torch.float32, "anchor_emb", (b, D)); _req(p, torch.float32, "positive_emb", (b, D))
+    _req(n, torch.float32, "negative_emb", (b, k, D))
+    dev = a.device
+    out = {"loss": torch.empty(1, dtype=torch.float32, device=dev),
+           "d_pos": torch.empty(b, dtype=torch.float32, device=dev),
+           "d_neg": torch.empty(b, dtype=torch.float32, device=dev)}
+    if need_grad:
+        out.update(da=torch.empty_like(a), dp=torch.empty_like(p), dn=torch.empty_like(n))
+    check(_lib.lib().pc_p2v_triplet_loss(_p(a), _p(p), _p(n), b, k, float(margin), _p(out["loss"]),
+                                         _p(out["d_pos"]), _p(out["d_neg"]), _p(out.get("da")), _p(out.get("dp")),
+                                         _p(out.get("dn")), _stream()), "pc_p2v_triplet_loss")
+    return out
+
+
+def adam_step(param, grad, exp_avg, exp_avg_sq, step_count, scalars, lr=1e-3, betas=(0.9, 0.999), eps=1e-8):
+    n = param.numel()
+    for t, nm in ((param, "param"), (grad, "grad"), (exp_avg, "exp_avg"), (exp_avg_sq, "exp_avg_sq")):
+        _req(t, torch.float32, nm)
+        if t.numel() != n:
+            raise ValueError("adam_step: size mismatch")
+    _req(step_count, torch.int64, "step_count"); _req(scalars, torch.float32, "scalars", (2,))
+    check(_lib.lib().pc_adam_step(_p(param), _p(grad), _p(exp_avg), _p(exp_avg_sq), n, _p(step_count), _p(scalars),
+                                  float(lr), float(betas[0]), float(betas[1]), float(eps), _stream()), "pc_adam_step")
+
+
+def p2v_train_step(params, grads, table, anchor_idx, positive_idx, negative_idx, neighbor_idx, margin,
+                   want_emb=False):
+    """One loop-body iteration of Product2Vec.train_model in index form (grads overwritten)."""
+    st, dev = p2v_struct(params)
+    gst, _ = p2v_struct(grads, with_buffers=False)
+    b = anchor_idx.numel()
+    k = negative_idx.shape[1]
+    n = 0 if neighbor_idx is None else neighbor_idx.shape[1]
+    _req(table, torch.float32, "table")
+    _req(anchor_idx, torch.int32, "anchor_idx", (b,)); _req(positive_idx, torch.int32, "positive_idx", (b,))
+    _req(negative_idx, torch.int32, "negative_idx", (b, k))
+    if n:
+        _req(neighbor_idx, torch.int32, "neighbor_idx", (b, n))
+    out = {"loss": torch.empty(1, dtype=torch.float32, device=dev),
+           "d_pos": torch.empty(b, dtype=torch.float32, device=dev),
+           "d_neg": torch.empty(b, dtype=torch.float32, device=dev)}
+    if want_emb:
+        out["anchor_emb"] = torch.empty(b, D, dtype=torch.float32, device=dev)
+    nbytes = _lib.lib().pc_p2v_train_step_workspace_bytes(b, n, k)
+    ws = workspace(nbytes, dev, "step")
+    check(_lib.lib().pc_p2v_train_step(ctypes.byref(st), ctypes.byref(gst), _p(table), _p(anchor_idx),
+                                       _p(positive_idx), _p(negative_idx), _p(neighbor_idx) if n else None, b, n, k,
+                                       float(margin), _p(out["loss"]), _p(out["d_pos"]), _p(out["d_neg"]),
+                                       _p(out.get("anchor_emb")), _p(ws), nbytes, _stream()), "pc_p2v_train_step")
+    return out
+
+
+# ----------------------------------------------------------------------------- P1-P4
+def build_similarity_batch(pair_ids, graph, n_pad, k_neg, seed, step):
+    """graph: dict of int32 CUDA tensors sim_pairs[S,2], cv_rowptr, cv_col, sim_rowptr, sim_col
+    and n_products.  Returns anchor_idx, positive_idx, negative_idx[B,K], neighbor_idx[B,n_pad]."""
+    b = pair_ids.numel()
+    dev = pair_ids.device
+    _req(pair_ids, torch.int32, "pair_ids")
+    for k in ("sim_pairs", "cv_rowptr", "cv_col", "sim_rowptr", "sim_col"):
+        _req(graph[k], torch.int32, k)
+    a = torch.empty(b, dtype=torch.int32, device=dev)
+    p = torch.empty(b, dtype=torch.int32, device=dev)
+    ng = torch.empty(b, k_neg, dtype=torch.int32, device=dev)
+    nb = torch.empty(b, n_pad, dtype=torch.int32, device=dev) if n_pad > 0 else None
+    check(_lib.lib().pc_build_similarity_batch(_p(pair_ids), b, _p(graph["sim_pairs"]), _p(graph["cv_rowptr"]),
+                                               _p(graph["cv_col"]), _p(graph["sim_rowptr"]), _p(graph["sim_col"]),
+                                               int(graph["n_products"]), n_pad, k_neg, int(seed), int(step), _p(a),
+                                               _p(p), _p(ng), _p(nb), _stream()), "pc_build_similarity_batch")
+    return a, p, ng, nb
+
+
+class CPythonRandom:
+    """Host-side exact restatement of the CPython `random` stream the reference samples
+    from (csrc/host_mt.cpp).  Host numpy arrays in, host numpy arrays out."""
+
+    def __init__(self, seed=0):
+        L_ = _lib.lib()
+        self._buf = ctypes.create_string_buffer(L_.pc_mt_state_bytes())
+        self.seed(seed)
+
+    def seed(self, s):
+        check(_lib.lib().pc_mt_seed(self._buf, abs(int(s))), "pc_mt_seed")
+
+    def getrandbits(self, k):
+        return int(_lib.lib().pc_mt_getrandbits(self._buf, k))
+
+    def randbelow(self, n):
+        return int(_lib.lib().pc_mt_randbelow(self._buf, n))
+
+    def shuffle(self, n):
+        perm = np.arange(n, dtype=np.int64)
+        check(_lib.lib().pc_mt_shuffle(self._buf, perm.ctypes.data, n), "pc_mt_shuffle")
+        return perm
+
+    def negative_samples(self, n_products, sim_rowptr, sim_col, anchors, k=5):
+        sim_rowptr = np.ascontiguousarray(sim_rowptr, np.int32)
+        sim_col = np.ascontiguousarray(sim_col, np.int32)
+        anchors = np.ascontiguousarray(anchors, np.int32)
+        out = np.empty((len(anchors), k), np.int32)
+        check(_lib.lib().pc_mt_negative_samples(self._buf, n_products, sim_rowptr.ctypes.data, sim_col.ctypes.data,
+                                                anchors.ctypes.data, len(anchors), k, out.ctypes.data),
+              "pc_mt_negative_samples")
+        return out
+
+
+# ----------------------------------------------------------------------------- joint step
+def joint_struct(tensors, table=None):
+    st = JointTensors()
+    dev = None
+    for key, field in zip(JOINT_KEYS, JOINT_FIELDS):
+        t = _req(tensors[key], torch.float32, key)
+        dev = t.device
+        setattr(st, field, t.data_ptr())
+    tbl = tensors.get("product_embeddings.weight") if table is None else table
+    if tbl is not None:
+        _req(tbl, torch.float32, "product_embeddings.weight")
+        st.product_table = tbl.data_ptr()
+    return st, dev
+
+
+def _joint_saved(sv):
+    s = JointSaved()
+    s.h, s.c, s.pi, s.tp = (sv[k].data_ptr() for k in ("h", "c", "pi", "tp"))
+    return s
+
+
+def joint_forward(params, query_idx, query_types, k):
+    st, dev = joint_struct(params)
+    b = query_idx.numel()
+    t = params["query_type_embeddings.weight"].shape[0]
+    _req(query_idx, torch.int32, "query_idx", (b,)); _req(query_types, torch.int32, "query_types", (b,))
+    f = dict(dtype=torch.float32, device=dev)
+    sims = torch.empty(b, t, **f)
+    topk = torch.empty(b, k, dtype=torch.int32, device=dev)
+    proj = torch.empty(b, k, D, **f)
+    sv = {"h": torch.empty(b, L // 2, **f), "c": torch.empty(b, L, **f), "pi": torch.empty(b, D, **f),
+          "tp": torch.empty(b * k, D, **f)}
+    check(_lib.lib().pc_joint_forward(ctypes.byref(st), _p(query_idx), _p(query_types), b, t, k, _p(sims), _p(topk),
+                                      _p(proj), ctypes.byref(_joint_saved(sv)), None, 0, _stream()),
+          "pc_joint_forward")
+    return sims, topk, proj, sv
+
+
+def joint_loss(sims, proj, pos_types, neg_types, pos_items, neg_items, margin, alpha, need_grad=True):
+    b, t = sims.shape
+    k = proj.shape[1]
+    dev = sims.device
+    _req(sims, torch.float32, "type_similarities"); _req(proj, torch.float32, "projected_embeddings", (b, k, D))
+    _req(pos_types, torch.int32, "positive_types", (b,)); _req(neg_types, torch.int32, "negative_types", (b,))
+    _req(pos_items, torch.float32, "positive_items", (b, D)); _req(neg_items, torch.float32, "negative_items", (b, D))
+    losses = torch.empty(3, dtype=torch.float32, device=dev)
+    dsv = torch.empty(b, 2, dtype=torch.float32, device=dev) if need_grad else None
+    dproj = torch.empty_like(proj) if need_grad else None
+    partials = torch.empty(2 * b, dtype=torch.float32, device=dev)
+    check(_lib.lib().pc_joint_loss(_p(sims), _p(proj), _p(pos_types), _p(neg_types), _p(pos_items), _p(neg_items),
+                                   b, t, k, float(margin), float(alpha), _p(losses), _p(dsv), _p(dproj),
+                                   _p(partials), _stream()), "pc_joint_loss")
+    return losses, dsv, dproj
+
+
+def joint_train_step(params, grads, query_idx, query_types, pos_types, neg_types, pos_items, neg_items, k, margin,
+                     alpha):
+    st, dev = joint_struct(params)
+    gst, _ = joint_struct(grads, table=params["product_embeddings.weight"])
+    b = query_idx.numel()
+    t = params["query_type_embeddings.weight"].shape[0]
+    for x, nm in ((query_idx, "query_idx"), (query_types, "query_types"), (pos_types, "positive_types"),
+                  (neg_types, "negative_types")):
+        _req(x, torch.int32, nm, (b,))
+    _req(pos_items, torch.float32, "positive_items", (b, D)); _req(neg_items, torch.float32, "negative_items", (b, D))
+    losses = torch.empty(3, dtype=torch.float32, device=dev)
+    topk = torch.empty(b, k, dtype=torch.int32, device=dev)
+    nbytes = _lib.lib().pc_joint_workspace_bytes(b, t, k)
+    ws = workspace(nbytes, dev, "joint")
+    check(_lib.lib().pc_joint_train_step(ctypes.byref(st), ctypes.byref(gst), _p(query_idx), _p(query_types),
+                                         _p(pos_types), _p(neg_types), _p(pos_items), _p(neg_items), b, t, k,
+                                         float(margin), float(alpha), _p(losses), _p(topk), _p(ws), nbytes, _stream()),
+          "pc_joint_train_step")
+    return losses, topk
+
+
+# ----------------------------------------------------------------------------- building blocks
+def linear_forward(x, w, b=None, idx=None, act=0, rows=None):
+    out_dim, in_dim = w.shape
+    _req(x, torch.float32, "x"); _req(w, torch.float32, "weight")
+    if b is not None:
+        _req(b, torch.float32, "bias", (out_dim,))
+    if idx is not None:
+        _req(idx, torch.int32, "idx")
+        rows = idx.numel()
+    elif rows is None:
+        rows = x.numel() // in_dim
+    y = torch.empty(rows, out_dim, dtype=torch.float32, device=w.device)
+    check(_lib.lib().pc_linear_forward(_p(x), _p(idx), rows, in_dim, _p(w), _p(b), out_dim, act, _p(y), _stream()),
+          "pc_linear_forward")
+    return y
+
+
+def linear_backward_input(dy, w):
+    out_dim, in_dim = w.shape
+    rows = dy.numel() // out_dim
+    _req(dy, torch.float32, "dy"); _req(w, torch.float32, "weight")
+    dx = torch.empty(rows, in_dim, dtype=torch.float32, device=w.device)
+    wt = torch.empty(in_dim, out_dim, dtype=torch.float32, device=w.device)
+    check(_lib.lib().pc_linear_backward_input(_p(dy), rows, out_dim, _p(w), in_dim, 0, None, _p(dx), _p(wt),
+                                              _stream()), "pc_linear_backward_input")
+    return dx
+
+
+def linear_backward_weight(dy, x, out_dim, in_dim, idx=None, want_bias=True):
+    rows = dy.numel() // out_dim
+    _req(dy, torch.float32, "dy"); _req(x, torch.float32, "x")
+    if idx is not None:
+        _req(idx, torch.int32, "idx", (rows,))
+    dev = dy.device
+    dw = torch.empty(out_dim, in_dim, dtype=torch.float32, device=dev)
+    db = torch.empty(out_dim, dtype=torch.float32, device=dev) if want_bias else None
+    nbytes = _lib.lib().pc_linear_backward_weight_workspace_bytes(rows, out_dim, in_dim)
+    ws = workspace(nbytes, dev)
+    check(_lib.lib().pc_linear_backward_weight(_p(dy), rows, out_dim, _p(x), _p(idx), in_dim, _p(dw), _p(db), 0,
+                                               _p(ws), nbytes, _stream()), "pc_linear_backward_weight")
+    return dw, db
+
+
+def topk_rows(sims, k, want_values=False):
+    b, t = sims.shape
+    _req(sims, torch.float32, "sims")
+    idx = torch.empty(b, k, dtype=torch.int32, device=sims.device)
+    val = torch.empty(b, k, dtype=torch.float32, device=sims.device) if want_values else None
+    check(_lib.lib().pc_topk_rows(_p(sims), b, t, k, _p(idx), _p(val), _stream()), "pc_topk_rows")
+    return (idx, val) if want_values else idx
+
+
+def hadamard_forward(pi, tp, k):
+    b = pi.shape[0]
+    _req(pi, torch.float32, "pi", (b, D)); _req(tp, torch.float32, "tp", (b * k, D))
+    proj = torch.empty(b, k, D, dtype=torch.float32, device=pi.device)
+    check(_lib.lib().pc_hadamard_forward(_p(pi), _p(tp), b, k, _p(proj), _stream()), "pc_hadamard_forward")
+    return proj
+
+
+def hadamard_backward(dproj, pi, tp):
+    b, k, _ = dproj.shape
+    _req(dproj, torch.float32, "dproj", (b, k, D))
+    dpi = torch.empty(b, D, dtype=torch.float32, device=pi.device)
+    dtp = torch.empty(b * k, D, dtype=torch.float32, device=pi.device)
+    check(_lib.lib().pc_hadamard_backward(_p(dproj), _p(pi), _p(tp), b, k, _p(dpi), _p(dtp), _stream()),
+          "pc_hadamard_backward")
+    return dpi, dtp
+
+
+def gather_rows(table, idx):
+    rows = idx.numel()
+    width = table.shape[1]
+    _req(table, torch.float32, "table"); _req(idx, torch.int32, "idx")
+    out = torch.empty(rows, width, dtype=torch.float32, device=table.device)
+    check(_lib.lib().pc_gather_rows(_p(table), _p(idx), rows, width, _p(out), _stream()), "pc_gather_rows")
+    return out
+
+
+def scatter_add_rows(table, idx, src):
+    rows = idx.numel()
+    width = table.shape[1]
+    _req(table, torch.float32, "table"); _req(idx, torch.int32, "idx"); _req(src, torch.float32, "src", (rows, width))
+    check(_lib.lib().pc_scatter_add_rows(_p(table), _p(idx), rows, width, _p(src), _stream()), "pc_scatter_add_rows")
+    return table

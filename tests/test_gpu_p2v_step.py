@@ -1,0 +1,133 @@
+"""Product2Vec training step on the GPU (C ABI pc_p2v_train_step + pc_adam_step) against the
+reference's golden vectors and the oracle.  Needs an MI355X."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import p2v_oracle
+
+
+def _load(golden, name):
+    g = golden(name)
+    st = {k[5:]: torch.from_numpy(g[k]).clone() for k in g.files if k.startswith("init.")}
+    return g, st
+
+
+def _flat(st, keys):
+    return torch.cat([st[k].reshape(-1) for k in keys])
+
+
+def _run_steps(ops, st, table, batch, n_steps):
+    """Flat parameter / gradient / moment buffers with per-tensor views, as the modules use."""
+    keys = ops.P2V_KEYS
+    sizes = [int(np.prod(s)) for s in ops.P2V_SHAPES]
+    flat = torch.cat([st[k].reshape(-1) for k in keys]).cuda()
+    gflat = torch.zeros_like(flat); m = torch.zeros_like(flat); v = torch.zeros_like(flat)
+    offs = np.concatenate([[0], np.cumsum(sizes)])
+    params = {k: flat[offs[i]:offs[i + 1]].view(s) for i, (k, s) in enumerate(zip(keys, ops.P2V_SHAPES))}
+    grads = {k: gflat[offs[i]:offs[i + 1]].view(s) for i, (k, s) in enumerate(zip(keys, ops.P2V_SHAPES))}
+    for k in ("ffn.1.running_mean", "ffn.1.running_var", "ffn.1.num_batches_tracked"):
+        params[k] = st[k].clone().cuda()
+    step = torch.zeros(1, dtype=torch.int64, device="cuda"); scal = torch.zeros(2, device="cuda")
+    outs, first_grads, after1 = [], None, None
+    for i in range(n_steps):
+        out = ops.p2v_train_step(params, grads, table, batch["anchor_idx"], batch["positive_idx"],
+                                 batch["negative_idx"], batch.get("neighbor_idx"), 1.0, want_emb=True)
+        if i == 0:
+            first_grads = {k: g.clone().cpu() for k, g in grads.items()}
+            bn1 = {k: params[k].clone().cpu() for k in params if "running" in k or "num_batches" in k}
+        ops.adam_step(flat, gflat, m, v, step, scal)
+        if i == 0:
+            after1 = {k: params[k].clone().cpu() for k in keys}
+        outs.append({k: t.clone().cpu() for k, t in out.items()})
+    return outs, first_grads, bn1, after1, {k: params[k].cpu() for k in keys}
+
+
+def _adam_close(actual, desired, steps, tight, lr=1e-3):
+    d = (actual - torch.as_tensor(desired)).abs()
+    assert float(d.max()) <= 1.05 * lr * steps
+    assert float((d <= tight).float().mean()) >= 0.999
+
+
+def _check(g, outs, first_grads, bn1, final, after3):
+    losses = [float(o["loss"]) for o in outs]
+    # north_star: fp32 loss within 1e-4 of the reference
+    np.testing.assert_allclose(losses, g["losses"], rtol=0, atol=1e-4)
+    np.testing.assert_allclose(outs[0]["anchor_emb"], g["anchor_emb"], atol=2e-5)
+    np.testing.assert_allclose(outs[0]["d_pos"], g["pos_distance"], atol=5e-5)
+    np.testing.assert_allclose(outs[0]["d_neg"], g["neg_distance"], atol=5e-5)
+    for k in p2v_oracle.TRAINABLE:
+        ref = g["grad." + k]
+        if k == "ffn.0.bias":
+            assert float(first_grads[k].abs().max()) < 1e-6      # analytically zero (BatchNorm)
+            continue
+        np.testing.assert_allclose(first_grads[k], ref, atol=2e-6 + 2e-4 * np.abs(ref).max(), err_msg=k)
+    for k, v in bn1.items():
+        np.testing.assert_allclose(v, g["bn_after1." + k], rtol=1e-5, atol=1e-5)
+    for k in p2v_oracle.TRAINABLE:
+        if k != "ffn.0.bias":
+            _adam_close(final[k], after3["after3." + k], 3, 5e-5)
+
+
+def test_train_step_golden_tiny(golden):
+    from p_companion_amd import ops
+    g, st = _load(golden, "g4_p2v_tiny.npz")
+    b = {k[6:]: torch.from_numpy(g[k]) for k in g.files if k.startswith("batch.")}
+    # dense golden batch -> table + indices (index form is the C ABI's input)
+    B, N = b["anchor_neighbors"].shape[:2]
+    table = torch.cat([b["anchor"], b["positive"], b["negative"].reshape(-1, 128),
+                       b["anchor_neighbors"].reshape(-1, 128)]).cuda()
+    ar = lambda lo, n: torch.arange(lo, lo + n, dtype=torch.int32).cuda()
+    nb = ar(B + B + 5 * B, B * N).view(B, N).clone()
+    nb[2, 4:] = -1; nb[5, 3:] = -1                     # the zero-padded rows of the fixture
+    batch = {"anchor_idx": ar(0, B), "positive_idx": ar(B, B), "negative_idx": ar(2 * B, 5 * B).view(B, 5),
+             "neighbor_idx": nb}
+    outs, fg, bn1, after1, final = _run_steps(ops, st, table, batch, 3)
+    _check(g, outs, fg, bn1, final, g)
+
+
+def test_train_step_golden_b256(golden):
+    from p_companion_amd import ops
+    g, st = _load(golden, "g4_p2v_b256.npz")
+    ints = golden("g2_bpg1000.npz")
+    table = torch.from_numpy(ints["features"]).cuda()
+    batch = {k: torch.from_numpy(g[k]).cuda() for k in ("anchor_idx", "positive_idx", "negative_idx", "neighbor_idx")}
+    outs, fg, bn1, after1, final = _run_steps(ops, st, table, batch, 3)
+    _check(g, outs, fg, bn1, final, golden("g4_p2v_b256_params3.npz"))
+
+
+def test_train_step_no_neighbors_vs_oracle():
+    """anchor_neighbors absent (data_loader.py:67-69): embedding = plain FFN, 3 BatchNorm calls,
+    attention parameters receive no gradient."""
+    from p_companion_amd import ops
+    st = p2v_oracle.init_state(5)
+    g = torch.Generator().manual_seed(6)
+    table = torch.randn(64, 128, generator=g)
+    B = 16
+    ai = torch.randint(0, 64, (B,), generator=g, dtype=torch.int32)
+    pi = torch.randint(0, 64, (B,), generator=g, dtype=torch.int32)
+    ni = torch.randint(0, 64, (B, 5), generator=g, dtype=torch.int32)
+    ref_st = {k: v.clone() for k, v in st.items()}
+    r = p2v_oracle.train_step(ref_st, {"anchor": table[ai.long()], "positive": table[pi.long()],
+                                       "negative": table[ni.long()], "anchor_neighbors": None}, 1.0,
+                              p2v_oracle.new_moments(ref_st), 1) if False else None
+    # oracle forward/grad without attention
+    leaves = {k: st[k].clone().requires_grad_(True) for k in p2v_oracle.TRAINABLE}
+    work = dict(st); work.update(leaves)
+    a = p2v_oracle.forward(table[ai.long()], None, work, True)
+    p = p2v_oracle.forward(table[pi.long()], None, work, True)
+    n = p2v_oracle.forward(table[ni.long()], None, work, True)
+    loss, _, _ = p2v_oracle.triplet_loss(a, p, n, 1.0)
+    grads_ref = torch.autograd.grad(loss, [leaves[k] for k in p2v_oracle.TRAINABLE], allow_unused=True)
+    params = {k: v.clone().cuda() for k, v in st.items()}
+    grads = {k: torch.full_like(params[k], 7.0) for k in ops.P2V_KEYS}
+    out = ops.p2v_train_step(params, grads, table.cuda(), ai.cuda(), pi.cuda(), ni.cuda(), None, 1.0)
+    assert abs(float(out["loss"]) - float(loss)) < 1e-5
+    for k, gr in zip(p2v_oracle.TRAINABLE, grads_ref):
+        if gr is None:
+            assert float(grads[k].abs().max()) == 0.0, k
+        elif k != "ffn.0.bias":
+            np.testing.assert_allclose(grads[k].cpu(), gr, atol=2e-6 + 2e-4 * float(gr.abs().max()), err_msg=k)
+    assert int(params["ffn.1.num_batches_tracked"]) == 3
