@@ -218,6 +218,13 @@ int pc_joint_loss(const float *sims, const float *proj, const int32_t *pos_types
                   int batch, int num_types, int k, float margin, float alpha, float *losses,
                   float *dsims_val, float *dproj, float *partials, void *stream);
 
+/* Dense form of the sparse type-hinge gradient, for callers whose autograd graph needs
+ * d(loss)/d(type_similarities) as a [B,T] tensor (what p_companion.py:96-97's advanced
+ * indexing produces in the reference): dense = 0; dense[b,pos_b] += v[b,0]; dense[b,neg_b] += v[b,1]. */
+int pc_expand_type_grad(const float *dsims_val, const int32_t *pos_types,
+                        const int32_t *neg_types, int batch, int num_types, float *dense,
+                        void *stream);
+
 /* Backward of J3-J5 from (dsims_val, dproj) -> g (overwritten = zero_grad + backward),
  * including the row-sparse scatter-add into the two [T,L] type tables (J7): only rows
  * query_types[b], topk[b,:], pos_types[b], neg_types[b] receive gradient. */

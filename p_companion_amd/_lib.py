@@ -82,6 +82,7 @@ SIGNATURES = {
     "pc_joint_workspace_bytes": (_sz, [_i, _i, _i]),
     "pc_joint_forward": (_i, [_P(JointTensors), _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _P(JointSaved), _vp, _sz, _vp]),
     "pc_joint_loss": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _f, _f, _vp, _vp, _vp, _vp, _vp]),
+    "pc_expand_type_grad": (_i, [_vp, _vp, _vp, _i, _i, _vp, _vp]),
     "pc_joint_backward": (_i, [_P(JointTensors), _P(JointTensors), _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp,
                                _P(JointSaved), _vp, _sz, _vp]),
     "pc_joint_train_step": (_i, [_P(JointTensors), _P(JointTensors), _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _f,

@@ -266,6 +266,28 @@ __global__ __launch_bounds__(256) void type_hinge_bwd_kernel(const float* dsims_
     }
 }
 
+// dense[b,:] = 0 except dense[b,pos_b] += v0, dense[b,neg_b] += v1 (autograd/module mode, where
+// the caller's graph needs d(loss)/d(type_similarities) as a tensor)
+__global__ void expand_type_grad_kernel(const float* dsims_val, const int32_t* pos_t, const int32_t* neg_t, int B,
+                                        int T, float* dense) {
+    const int b = blockIdx.x;
+    float* row = dense + (size_t)b * T;
+    for (int t = threadIdx.x; t < T; t += blockDim.x) row[t] = 0.f;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        row[pos_t[b]] += dsims_val[2 * b];
+        row[neg_t[b]] += dsims_val[2 * b + 1];
+    }
+}
+
+extern "C" int pc_expand_type_grad(const float* dsims_val, const int32_t* pos_types, const int32_t* neg_types,
+                                   int batch, int num_types, float* dense, void* stream) {
+    if (!dsims_val || !pos_types || !neg_types || !dense || batch <= 0 || num_types <= 0) return PC_EINVAL;
+    hipLaunchKernelGGL(expand_type_grad_kernel, dim3(batch), dim3(256), 0, (hipStream_t)stream, dsims_val, pos_types,
+                       neg_types, batch, num_types, dense);
+    return pc_launch_status();
+}
+
 // ---------------------------------------------------------------------------------------
 struct JointWs {
     float *dpi, *dtp, *dce, *dc, *dh, *dt;

@@ -1,0 +1,282 @@
+"""Integer-form Behavior-Product-Graph, the scalable synthetic generator and the index loaders.
+
+Replaces, for the hot path, the reference's string-keyed Python objects:
+  src/data/bpg.py                BehaviorProductGraph (Dict[str,dict] + Set[(src,tgt)], O(E) scans)
+  src/data/synthetic_data.py     SyntheticDataGenerator (O(N^2) itertools.combinations)
+  src/data/data_loader.py        SimilarityDataset / ComplementaryDataset / collate_fn
+with CSR arrays that live on the device: neighbours are an O(deg) row of (cv_rowptr, cv_col),
+a batch is a handful of int32 index arrays, and the feature gather happens inside the HIP
+kernels.  Product i is the reference's "P%06d" % i (synthetic_data.py:43).
+"""
+from dataclasses import dataclass, field
+from typing import Dict, Optional
+
+import numpy as np
+import torch
+
+CATEGORIES = ("electronics", "clothing", "sports", "home", "office")     # synthetic_data.py:36
+
+
+def _csr_from_pairs(src, dst, n):
+    order = np.argsort(src, kind="stable")
+    rowptr = np.zeros(n + 1, np.int64)
+    np.add.at(rowptr, src + 1, 1)
+    return np.cumsum(rowptr).astype(np.int32), dst[order].astype(np.int32)
+
+
+@dataclass
+class IntBPG:
+    """The BPG in integer form.  All arrays host numpy; .cuda() uploads what the kernels read."""
+    features: np.ndarray               # [P,128] float32   bpg.nodes[pid]['features']
+    type_idx: np.ndarray               # [P] int32         index into the dataset's type_to_idx
+    category: np.ndarray               # [P] int32
+    cv_rowptr: np.ndarray              # [P+1] int32       co-view out-neighbours (bpg.get_neighbors)
+    cv_col: np.ndarray                 # [E] int32
+    similarity_pairs: np.ndarray       # [S,2] int32       (Bcv & Bpv) - Bcp, list order = dataset order
+    complementary_pairs: np.ndarray    # [C,2] int32       Bcp - (Bpv | Bcv)
+    n_types: int
+    sim_rowptr: np.ndarray = field(default=None)   # positives of each anchor (data_loader.py:31)
+    sim_col: np.ndarray = field(default=None)
+    _dev: Dict[str, torch.Tensor] = field(default=None, repr=False)
+
+    def __post_init__(self):
+        if self.sim_rowptr is None:
+            sp = self.similarity_pairs
+            self.sim_rowptr, self.sim_col = _csr_from_pairs(sp[:, 0].astype(np.int64), sp[:, 1], self.num_products)
+
+    @property
+    def num_products(self):
+        return self.features.shape[0]
+
+    def degree(self, pids):
+        return self.cv_rowptr[np.asarray(pids) + 1] - self.cv_rowptr[np.asarray(pids)]
+
+    def get_neighbors(self, pid):
+        """bpg.py:24-38 for edge_type='co_view' (directed out-neighbours), O(deg)."""
+        return self.cv_col[self.cv_rowptr[pid]:self.cv_rowptr[pid + 1]]
+
+    @classmethod
+    def from_arrays(cls, z):
+        """From the integer-form arrays of tests/golden/g2_bpg1000.npz (the reference's own graph)."""
+        return cls(features=np.ascontiguousarray(z["features"], np.float32), type_idx=z["type_idx"].astype(np.int32),
+                   category=z["category"].astype(np.int32), cv_rowptr=z["cv_rowptr"].astype(np.int32),
+                   cv_col=z["cv_col"].astype(np.int32), similarity_pairs=z["similarity_pairs"].astype(np.int32),
+                   complementary_pairs=z["complementary_pairs"].astype(np.int32),
+                   n_types=int(z["type_idx"].max()) + 1)
+
+    def cuda(self, device="cuda"):
+        if self._dev is None:
+            t = lambda a, dt: torch.from_numpy(np.ascontiguousarray(a)).to(dt).to(device)
+            self._dev = {
+                "features": t(self.features, torch.float32), "type_idx": t(self.type_idx, torch.int32),
+                "cv_rowptr": t(self.cv_rowptr, torch.int32), "cv_col": t(self.cv_col, torch.int32),
+                "sim_pairs": t(self.similarity_pairs, torch.int32), "sim_rowptr": t(self.sim_rowptr, torch.int32),
+                "sim_col": t(self.sim_col, torch.int32), "n_products": self.num_products}
+        return self._dev
+
+
+def generate_scaled_bpg(num_products=100_000, num_types=100, seed=0, mean_degree=16.0, degree_cap=32,
+                        dim=128) -> IntBPG:
+    """Scalable restatement of SyntheticDataGenerator's distributions (synthetic_data.py:11-153).
+
+    The reference enumerates all P(P-1)/2 pairs and keeps 10% of them, so it cannot go past
+    ~10k products.  Here edges are drawn per source node with the reference's conditional
+    probabilities:
+      * type uniform over num_types = 5 categories x num_types/5 (:35-46);
+      * features N(0,1)^dim, +1.0 on dims [20c, 20c+20) of category c (:50-52);
+      * co-view out-degree: the reference's node i can only point at later nodes, so its degree
+        is Binomial(P-1-i, p): a uniform mixture of Poisson means from 0 to 2*mean.  Restated as
+        Poisson(2*mean*(1-u)), u ~ U(0,1), capped at degree_cap; same-category targets are
+        1.5x as likely (:107-108);
+      * purchase-after-view | co-view 0.2; co-purchase | PAV 0.15 (x0.5 same category);
+        similarity pair = co-view & PAV & not co-purchase (:110-121);
+      * complementary pair = co-purchase without co-view, 0.15 (x0.5 same category) (:122-127),
+        scaled to ~4.5 per product (measured 4.52 at the reference's 1k products).
+    Deviation: targets are uniform over all other products rather than 'later' ones.
+    """
+    rng = np.random.Generator(np.random.Philox(seed))
+    P = int(num_products)
+    per_cat = max(num_types // 5, 1)
+    type_idx = rng.integers(0, num_types, P, dtype=np.int32)
+    category = np.minimum(type_idx // per_cat, 4).astype(np.int32)
+    feats = rng.standard_normal((P, dim), dtype=np.float32)
+    cols = category[:, None] * 20 + np.arange(20)[None, :]
+    np.add.at(feats, (np.arange(P)[:, None], cols), 1.0)
+
+    def draw_targets(src, p_same, p_diff):
+        """uniform target != src, kept w.p. p_same / p_diff by category agreement (rejection)"""
+        tgt = rng.integers(0, P, src.shape[0], dtype=np.int64)
+        todo = np.arange(src.shape[0])
+        while todo.size:
+            same = category[tgt[todo]] == category[src[todo]]
+            bad = (tgt[todo] == src[todo]) | (rng.random(todo.size) >= np.where(same, p_same, p_diff))
+            todo = todo[bad]
+            tgt[todo] = rng.integers(0, P, todo.size, dtype=np.int64)
+        return tgt
+
+    lam = 2.0 * mean_degree * (1.0 - rng.random(P))
+    deg = np.minimum(rng.poisson(lam), degree_cap).astype(np.int64)
+    src = np.repeat(np.arange(P, dtype=np.int64), deg)
+    tgt = draw_targets(src, 1.0, 2.0 / 3.0)       # cv_prob x1.5 when same category
+    key = np.unique(src * P + tgt)                      # drop repeated (src,tgt); sorted by src
+    src, tgt = key // P, key % P
+    perm = rng.permutation(src.shape[0])                # neighbour order within a row: arbitrary, as a set's
+    order = perm[np.argsort(src[perm], kind="stable")]
+    src, tgt = src[order], tgt[order]
+    cv_rowptr, cv_col = _csr_from_pairs(src, tgt, P)
+
+    same = category[src] == category[tgt]
+    pav = rng.random(src.shape[0]) < 0.2
+    cp = rng.random(src.shape[0]) < np.where(same, 0.075, 0.15)
+    sim_mask = pav & ~cp
+    sim = np.stack([src[sim_mask], tgt[sim_mask]], 1).astype(np.int32)
+    sim = sim[rng.permutation(sim.shape[0])]            # list(set) order is arbitrary (:150)
+
+    csrc = np.repeat(np.arange(P, dtype=np.int64), rng.poisson(4.5, P))
+    ctgt = draw_targets(csrc, 0.5, 1.0)            # cp_prob x0.5 when same category
+    ckey = np.setdiff1d(np.unique(csrc * P + ctgt), key)   # not co-viewed
+    comp = np.stack([ckey // P, ckey % P], 1).astype(np.int32)
+    comp = comp[rng.permutation(comp.shape[0])]
+    return IntBPG(features=feats, type_idx=type_idx, category=category, cv_rowptr=cv_rowptr, cv_col=cv_col,
+                  similarity_pairs=sim, complementary_pairs=comp, n_types=int(num_types))
+
+
+class SimilarityIndexLoader:
+    """Index-form counterpart of DataLoader(SimilarityDataset, shuffle=True, collate_fn)
+    (scripts/pretrain_product2vec.py:24-30).  Yields device index batches; the dense feature
+    copies of data_loader.py:50-55 never exist.
+
+    sampler='philox' (throughput): the epoch permutation lives on the device, negatives come
+      from the HIP Philox sampler (same rejection rules as data_loader.py:33-38);
+    sampler='cpython' (parity): dataset order / random.shuffle and negatives are drawn from the
+      exact CPython `random` stream in the reference's consumption order, so negative indices
+      are bit-identical to the reference for the same random.seed().
+    """
+
+    def __init__(self, bpg: IntBPG, batch_size: int, shuffle=True, sampler="philox", seed=0, k_neg=5,
+                 drop_last=False, device="cuda"):
+        from . import ops
+        self.ops = ops
+        self.bpg = bpg
+        self.dataset = self                      # train_model reads train_loader.dataset.bpg (product2vec.py:170)
+        self.batch_size = int(batch_size)
+        self.shuffle = shuffle
+        self.sampler = sampler
+        self.seed = seed
+        self.k_neg = k_neg
+        self.drop_last = drop_last
+        self.device = device
+        self.epoch = 0
+        self.step = 0
+        self.g = bpg.cuda(device)
+        if sampler == "cpython":
+            self.rng = ops.CPythonRandom(seed)
+        elif sampler != "philox":
+            raise ValueError("sampler must be 'philox' or 'cpython'")
+        self._deg = bpg.degree(bpg.similarity_pairs[:, 0])
+
+    def __len__(self):
+        n = self.bpg.similarity_pairs.shape[0]
+        return n // self.batch_size if self.drop_last else (n + self.batch_size - 1) // self.batch_size
+
+    def __iter__(self):
+        S = self.bpg.similarity_pairs.shape[0]
+        if self.sampler == "cpython":
+            perm = self.rng.shuffle(S) if self.shuffle else np.arange(S, dtype=np.int64)
+        else:
+            rs = np.random.Generator(np.random.Philox([self.seed, self.epoch]))
+            perm = rs.permutation(S) if self.shuffle else np.arange(S, dtype=np.int64)
+        perm_dev = torch.from_numpy(perm.astype(np.int32)).to(self.device)
+        self.epoch += 1
+        for i in range(len(self)):
+            lo, hi = i * self.batch_size, min((i + 1) * self.batch_size, S)
+            ids = perm[lo:hi]
+            n_pad = int(self._deg[ids].max())           # collate_fn pads to the batch maximum
+            if self.sampler == "philox":
+                a, p, ng, nb = self.ops.build_similarity_batch(perm_dev[lo:hi], self.g, n_pad, self.k_neg,
+                                                               self.seed, self.step)
+            else:
+                pairs = self.bpg.similarity_pairs[ids]
+                negs = self.rng.negative_samples(self.bpg.num_products, self.bpg.sim_rowptr, self.bpg.sim_col,
+                                                 pairs[:, 0], self.k_neg)
+                nbr = np.full((len(ids), n_pad), -1, np.int32)
+                for r, a_ in enumerate(pairs[:, 0]):
+                    nb_ = self.bpg.get_neighbors(a_)
+                    nbr[r, :len(nb_)] = nb_
+                up = lambda x: torch.from_numpy(np.ascontiguousarray(x, np.int32)).to(self.device)
+                a, p, ng, nb = up(pairs[:, 0]), up(pairs[:, 1]), up(negs), (up(nbr) if n_pad else None)
+            self.step += 1
+            batch = {"anchor_idx": a, "positive_idx": p, "negative_idx": ng}
+            if nb is not None:
+                batch["neighbor_idx"] = nb
+            yield batch
+
+
+class ComplementaryIndexDataset:
+    """Index-form ComplementaryDataset (data_loader.py:90-157): labelled pairs = complementary
+    (+1) and similarity (-1) pairs, shuffled, split 80/10/10 by mode; per sample
+      label +1: positive_types = t(tgt), negative_types = (t(tgt)+1) % n_types,
+                positive_items = feat(tgt), negative_items = randn
+      label -1: positive_types = 0, negative_types = t(tgt),
+                positive_items = randn, negative_items = feat(tgt)              (:148-153)
+    The randn filler items are input data (drawn here from torch's generator on the device)."""
+
+    def __init__(self, bpg: IntBPG, mode="train", seed=0):
+        self.bpg = bpg
+        cp, sp = bpg.complementary_pairs, bpg.similarity_pairs
+        pairs = np.concatenate([np.concatenate([cp, np.ones((len(cp), 1), np.int32)], 1),
+                                np.concatenate([sp, -np.ones((len(sp), 1), np.int32)], 1)])
+        rs = np.random.Generator(np.random.Philox([seed, {"train": 0, "val": 1, "test": 2}[mode]]))
+        pairs = pairs[rs.permutation(len(pairs))]       # each mode shuffles independently (:119-126)
+        n = len(pairs)
+        lo, hi = {"train": (0, int(0.8 * n)), "val": (int(0.8 * n), int(0.9 * n)), "test": (int(0.9 * n), n)}[mode]
+        self.pairs = pairs[lo:hi]
+
+    def __len__(self):
+        return len(self.pairs)
+
+
+class ComplementaryIndexLoader:
+    """DataLoader(ComplementaryDataset, collate_fn) in index form (train.py:115-129)."""
+
+    def __init__(self, dataset: ComplementaryIndexDataset, batch_size, shuffle=True, seed=0, device="cuda"):
+        self.dataset = dataset
+        self.batch_size = int(batch_size)
+        self.shuffle = shuffle
+        self.seed = seed
+        self.device = device
+        self.epoch = 0
+        g = dataset.bpg.cuda(device)
+        self.features, self.type_idx = g["features"], g["type_idx"]
+        self.gen = torch.Generator(device=device)
+        self.gen.manual_seed(seed)
+
+    def __len__(self):
+        return (len(self.dataset) + self.batch_size - 1) // self.batch_size
+
+    def make_batch(self, rows):
+        from . import ops
+        ds = self.dataset
+        q = torch.from_numpy(np.ascontiguousarray(rows[:, 0])).to(self.device)
+        tgt = torch.from_numpy(np.ascontiguousarray(rows[:, 1])).to(self.device)
+        pos = torch.from_numpy(rows[:, 2] == 1).to(self.device)
+        tt = self.type_idx[tgt.long()]
+        n_types = ds.bpg.n_types
+        feat = ops.gather_rows(self.features, tgt)
+        filler = torch.randn(feat.shape, generator=self.gen, device=self.device)
+        zero = torch.zeros_like(tt)
+        return {
+            "query_idx": q, "query_types": self.type_idx[q.long()].contiguous(),
+            "positive_types": torch.where(pos, tt, zero).view(-1, 1),
+            "negative_types": torch.where(pos, (tt + 1) % n_types, tt).view(-1, 1),
+            "positive_items": torch.where(pos[:, None], feat, filler),
+            "negative_items": torch.where(pos[:, None], filler, feat),
+            "target_features": feat, "label": torch.from_numpy(rows[:, 2].copy()).to(self.device)}
+
+    def __iter__(self):
+        n = len(self.dataset)
+        rs = np.random.Generator(np.random.Philox([self.seed + 7, self.epoch]))
+        order = rs.permutation(n) if self.shuffle else np.arange(n)
+        self.epoch += 1
+        for i in range(len(self)):
+            yield self.make_batch(self.dataset.pairs[order[i * self.batch_size:(i + 1) * self.batch_size]])

@@ -373,6 +373,14 @@ def joint_loss(sims, proj, pos_types, neg_types, pos_items, neg_items, margin, a
     return losses, dsv, dproj
 
 
+def expand_type_grad(dsv, pos_types, neg_types, num_types):
+    b = dsv.shape[0]
+    dense = torch.empty(b, num_types, dtype=torch.float32, device=dsv.device)
+    check(_lib.lib().pc_expand_type_grad(_p(dsv), _p(pos_types), _p(neg_types), b, num_types, _p(dense), _stream()),
+          "pc_expand_type_grad")
+    return dense
+
+
 def joint_train_step(params, grads, query_idx, query_types, pos_types, neg_types, pos_items, neg_items, k, margin,
                      alpha):
     st, dev = joint_struct(params)
