@@ -1,0 +1,190 @@
+#!/usr/bin/env python3
+"""bench.py -- triplets/sec of the Product2Vec GAT triplet pretrain step on MI355X.
+
+Workload (BASELINE.json configs[1]): 100k products, 100 types, D=128,
+B=4096 triplets per GPU and step, 5 negatives, neighbours padded to the batch max (<=32),
+synthetic BPG (data='synthetic', random-init weights).  One step = device batch build
+(Philox negative sampling + CSR neighbour rows) + gather + 4 FFN/BatchNorm call groups +
+attention + triplet hinge + full backward + Adam: everything inside the timed region.
+
+    python bench.py --gpus 1 --steps 50 --warmup 10
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+Prints ONE JSON line on rank 0 (contract in the task statement) with `roofline` (dominant
+kernel gemm_nt_kernel: algorithmic FLOPs / HIP-event time on the launch stream, against the
+fp32 MFMA peak) and `cpu_baseline` (the oracle port timed on this box's host cores).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np
+import torch
+
+FP32_MFMA_PEAK_TFLOPS = 157.3     # /opt/skills/guides/MI355X_MICROARCH.md, Peak FP32 (matrix)
+HBM_PEAK_GBS = 8000.0
+
+
+def flops_per_triplet(n):
+    """fwd 328,192*N + 1,900,544; fwd+bwd = 3*fwd - 65,536*(N+7)."""
+    fwd = 328192 * n + 1900544
+    return 3 * fwd - 65536 * (n + 7)
+
+
+def bytes_per_triplet(n):
+    return 512 * (n + 7) + 4 * (n + 7)
+
+
+def cpu_baseline(bpg, batch, seconds=15.0):
+    """The oracle (CPU restatement pinned to the reference's golden vectors) timed on this
+    box's host cores: same workload shape, pre-gathered dense batch, fwd+bwd+Adam."""
+    from oracle import p2v_oracle
+    st = p2v_oracle.init_state(0)
+    feats = torch.from_numpy(bpg.features)
+    dense = p2v_oracle.gather_batch(feats, batch["anchor_idx"].cpu().numpy(), batch["positive_idx"].cpu().numpy(),
+                                    batch["negative_idx"].cpu().numpy(), batch["neighbor_idx"].cpu().numpy())
+    mom = p2v_oracle.new_moments(st)
+    b = dense["anchor"].shape[0]
+    p2v_oracle.train_step(st, dense, 1.0, mom, 1)            # warm-up
+    t0 = time.perf_counter()
+    n = 0
+    while True:
+        p2v_oracle.train_step(st, dense, 1.0, mom, n + 2)
+        n += 1
+        el = time.perf_counter() - t0
+        if el > seconds or n >= 50:
+            break
+    return {"value": b * n / el, "unit": "triplets/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"{n} steps of the same workload (B={b}, N={dense['anchor_neighbors'].shape[1]}, fwd+bwd+Adam, "
+                      f"pre-gathered batch) on {os.cpu_count()} host cpus, torch {torch.get_num_threads()} threads"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--products", type=int, default=100_000)
+    ap.add_argument("--types", type=int, default=100)
+    ap.add_argument("--batch", type=int, default=4096)
+    ap.add_argument("--table", choices=["replicated", "sharded"], default="replicated")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=15.0)
+    args = ap.parse_args()
+
+    from p_companion_amd import distributed as pdist
+    rank, world, local = pdist.init_from_env("cuda")
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+
+    from types import SimpleNamespace
+    from p_companion_amd import ops
+    from p_companion_amd.data import SimilarityIndexLoader, generate_scaled_bpg
+    from p_companion_amd.product2vec import FusedAdam, Product2Vec
+
+    cfg = SimpleNamespace(PRODUCT_EMB_DIM=128, TYPE_EMB_DIM=64, HIDDEN_SIZE=256, NUM_ATTENTION_HEADS=4, DROPOUT=0.0,
+                          MARGIN=1.0, BATCH_SIZE=args.batch, LEARNING_RATE=1e-3, DEVICE=dev)
+    bpg = generate_scaled_bpg(args.products, args.types, seed=0)
+    torch.manual_seed(0)
+    model = Product2Vec(cfg).to(dev)
+    model.train()
+    opt = FusedAdam(model, lr=cfg.LEARNING_RATE)
+    flat, gflat = model.flatten_parameters()
+    loader = SimilarityIndexLoader(bpg, args.batch, shuffle=True, sampler="philox", seed=1 + rank, drop_last=True,
+                                   device=dev)
+    table = bpg.cuda(dev)["features"]
+    sharded = None
+    if args.table == "sharded":
+        sharded = pdist.ShardedFeatureTable(pdist.ShardedFeatureTable.shard(table, rank, world), bpg.num_products,
+                                            rank, world)
+
+    def batches():
+        while True:
+            for b in loader:
+                yield b
+
+    it = batches()
+    prof = ops.KernelProfile(capacity=32 * max(args.steps, 1))
+    n_sum = 0
+
+    def step(b, profile=None):
+        tab = table
+        if sharded is not None:
+            ids = torch.cat([b["anchor_idx"], b["neighbor_idx"].reshape(-1), b["positive_idx"],
+                             b["negative_idx"].reshape(-1)])
+            tab, remap = sharded.lookup(ids)
+            B, N, K = b["anchor_idx"].numel(), b["neighbor_idx"].shape[1], b["negative_idx"].shape[1]
+            o = np.cumsum([0, B, B * N, B, B * K])
+            b = {"anchor_idx": remap[o[0]:o[1]].contiguous(), "neighbor_idx": remap[o[1]:o[2]].view(B, N).contiguous(),
+                 "positive_idx": remap[o[2]:o[3]].contiguous(), "negative_idx": remap[o[3]:o[4]].view(B, K).contiguous()}
+        loss = model.train_step_indexed(tab, b, profile=profile)
+        pdist.all_reduce_mean_(gflat, world)
+        opt.step()
+        return loss
+
+    last = None
+    for _ in range(args.warmup):
+        last = next(it)
+        step(last)
+    if world > 1:
+        torch.distributed.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        last = next(it)
+        n_sum += last["neighbor_idx"].shape[1]
+        loss = step(last, profile=prof)
+    torch.cuda.synchronize()
+    if world > 1:
+        torch.distributed.barrier()
+    el = time.perf_counter() - t0
+    t = torch.tensor([el], dtype=torch.float64, device=dev)
+    if world > 1:
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+    el = float(t)
+    if rank != 0:
+        return
+
+    n_avg = n_sum / max(args.steps, 1)
+    value = world * args.batch * args.steps / el
+    nt = prof.summary("gemm_nt_kernel")
+    tn = prof.summary("gemm_tn_kernel")
+    achieved = nt["total_flops"] / (nt["total_ms"] * 1e-3) / 1e12 if nt["total_ms"] > 0 else 0.0
+    roof = {"bound": "mfma", "kernel": "gemm_nt_kernel", "achieved": round(achieved, 2),
+            "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / FP32_MFMA_PEAK_TFLOPS, 4),
+            "traffic": None,
+            "launches": nt["launches"], "avg_launch_us": round(1e3 * nt["total_ms"] / max(nt["launches"], 1), 2),
+            "flops_per_launch": nt["total_flops"] / max(nt["launches"], 1),
+            "share_of_step": round(nt["total_ms"] / (el * 1e3), 3),
+            "gemm_tn_kernel": {"achieved": round(tn["total_flops"] / max(tn["total_ms"], 1e-9) / 1e9, 2),
+                               "launches": tn["launches"], "share_of_step": round(tn["total_ms"] / (el * 1e3), 3)},
+            "whole_step": {"flops_per_triplet": flops_per_triplet(round(n_avg)),
+                           "achieved": round(flops_per_triplet(n_avg) * value / world / 1e12, 2),
+                           "frac_mfma": round(flops_per_triplet(n_avg) * value / world / 1e12 / FP32_MFMA_PEAK_TFLOPS, 4),
+                           "gather_bytes_per_triplet": bytes_per_triplet(round(n_avg)),
+                           "frac_hbm_gather": round(bytes_per_triplet(n_avg) * value / world / 1e9 / HBM_PEAK_GBS, 5)}}
+    out = {"metric": "triplets/sec (Product2Vec pretrain step: gather+fwd+bwd+Adam)", "value": round(value, 1),
+           "unit": "triplets/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+           "ms_per_step": round(1e3 * el / args.steps, 4), "higher_is_better": True, "scaling": "weak",
+           "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+           "config": {"workload": f"Product2Vec GAT pretrain, {args.products} products, {args.types} types, dim=128, "
+                                  f"batch={args.batch}/GPU, 5 negatives, neighbours padded to batch max "
+                                  f"(avg N={n_avg:.1f})", "global_batch": world * args.batch,
+                      "table": args.table, "parallelism": f"dp{world}", "final_loss": round(float(loss), 5)},
+           "roofline": roof}
+    if not args.no_cpu_baseline and world == 1:
+        out["cpu_baseline"] = cpu_baseline(bpg, last, args.cpu_seconds)
+    else:
+        out["cpu_baseline"] = None
+    print(json.dumps(out), flush=True)
+
+
+if __name__ == "__main__":
+    main()

@@ -139,14 +139,26 @@ int pc_adam_step(float *param, const float *grad, float *exp_avg, float *exp_avg
  * in index form: gather -> 4 FFN calls -> attention -> loss -> backward -> grads in `g`
  * (overwritten, i.e. zero_grad + backward).  The optimizer step is a separate call.
  *   anchor_idx[B], positive_idx[B], negative_idx[B*K], neighbor_idx[B*N] (-1 = zero row)
- * Outputs: loss[1] (+ d_pos/d_neg[B], anchor_emb[B,D] when non-NULL).
+ * Outputs: loss[1] (+ d_pos/d_neg[B], anchor_emb[B,D] when non-NULL).  profile: NULL, or a
+ * pc_profile_create handle (see below).
  * ws: pc_p2v_train_step_workspace_bytes(B,N,K). */
 size_t pc_p2v_train_step_workspace_bytes(int batch, int n_nbr, int k_neg);
 int pc_p2v_train_step(const pc_p2v_tensors *p, const pc_p2v_tensors *g, const float *table,
                       const int32_t *anchor_idx, const int32_t *positive_idx,
                       const int32_t *negative_idx, const int32_t *neighbor_idx, int batch,
                       int n_nbr, int k_neg, float margin, float *loss, float *d_pos,
-                      float *d_neg, float *anchor_emb, void *ws, size_t ws_bytes, void *stream);
+                      float *d_neg, float *anchor_emb, void *profile, void *ws, size_t ws_bytes,
+                      void *stream);
+
+/* Optional measurement aid (bench.py's roofline leg; NULL everywhere else): a pool of HIP
+ * events that pc_p2v_train_step records on its stream around each of its GEMM launches.
+ * After synchronising the stream, pc_profile_summary totals launches / milliseconds /
+ * algorithmic FLOPs per kernel kind (0 = gemm_nt_kernel, 1 = gemm_tn_kernel). */
+int pc_profile_create(int capacity, void **out);
+int pc_profile_destroy(void *profile);
+int pc_profile_reset(void *profile);
+int pc_profile_summary(void *profile, int kind, int *launches, double *total_ms,
+                       double *total_flops);
 
 /* P1-P4 on device: build one index batch from the CSR graph (bpg.py:24-38 get_neighbors,
  * data_loader.py:27-40 negative sampling rules, :186-198 padding).  pair_ids[B] selects
@@ -285,6 +297,15 @@ int pc_gather_rows(const float *table, const int32_t *idx, int rows, int width, 
  * is NOT guaranteed (float atomics); idx < 0 skipped. */
 int pc_scatter_add_rows(float *table, const int32_t *idx, int rows, int width, const float *src,
                         void *stream);
+
+/* out[idx[r]] = src[r] (row assignment, idx < 0 skipped): writes the attention-updated rows
+ * back into the embedding table in the batched generate_all_embeddings pass
+ * (product2vec.py:108-109). width % 4 == 0. */
+int pc_scatter_rows(float *out, const int32_t *idx, int rows, int width, const float *src,
+                    void *stream);
+/* dx = dy * act'(y) for a stand-alone activation: act 1 = tanh (1 - y^2), 2 = relu (y > 0)
+ * (F.relu of type_transition.py:17 in module mode). */
+int pc_act_backward(const float *dy, const float *y, size_t n, int act, float *dx, void *stream);
 
 #ifdef __cplusplus
 }

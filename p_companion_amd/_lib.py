@@ -70,7 +70,11 @@ SIGNATURES = {
     "pc_adam_step": (_i, [_vp, _vp, _vp, _vp, _sz, _vp, _vp, _d, _d, _d, _d, _vp]),
     "pc_p2v_train_step_workspace_bytes": (_sz, [_i, _i, _i]),
     "pc_p2v_train_step": (_i, [_P(P2VTensors), _P(P2VTensors), _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _f, _vp, _vp,
-                               _vp, _vp, _vp, _sz, _vp]),
+                               _vp, _vp, _vp, _vp, _sz, _vp]),
+    "pc_profile_create": (_i, [_i, _P(ctypes.c_void_p)]),
+    "pc_profile_destroy": (_i, [_vp]),
+    "pc_profile_reset": (_i, [_vp]),
+    "pc_profile_summary": (_i, [_vp, _i, _P(ctypes.c_int), _P(ctypes.c_double), _P(ctypes.c_double)]),
     "pc_build_similarity_batch": (_i, [_vp, _i, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _u64, _u64, _vp, _vp, _vp,
                                        _vp, _vp]),
     "pc_mt_state_bytes": (_sz, []),
@@ -96,6 +100,8 @@ SIGNATURES = {
     "pc_hadamard_backward": (_i, [_vp, _vp, _vp, _i, _i, _vp, _vp, _vp]),
     "pc_gather_rows": (_i, [_vp, _vp, _i, _i, _vp, _vp]),
     "pc_scatter_add_rows": (_i, [_vp, _vp, _i, _i, _vp, _vp]),
+    "pc_scatter_rows": (_i, [_vp, _vp, _i, _i, _vp, _vp]),
+    "pc_act_backward": (_i, [_vp, _vp, _sz, _i, _vp, _vp]),
 }
 
 _lib = None

@@ -100,6 +100,24 @@ __device__ __forceinline__ f32x16 mfma32(float a, float b, f32x16 c) {
 }
 #endif
 
+// ---- optional per-launch timing (bench.py roofline leg): HIP events recorded on the launch
+// stream around every gemm_nt / gemm_tn launch of ONE C-ABI call.  The pointer is
+// thread-local and only set for the duration of that call (no persistent global state).
+struct pc_profile {
+    hipEvent_t* ev;      // 2 per bracket: start, stop
+    int* kind;           // per bracket
+    double* flops;       // per bracket: algorithmic FLOPs of the launch
+    int capacity, used;
+};
+enum { PC_KIND_GEMM_NT = 0, PC_KIND_GEMM_TN = 1 };
+extern thread_local pc_profile* pc_tls_profile;
+struct ProfileScope {
+    explicit ProfileScope(pc_profile* p) { pc_tls_profile = p; }
+    ~ProfileScope() { pc_tls_profile = nullptr; }
+};
+int pc_prof_begin(int kind, double flops, hipStream_t st);   // returns bracket index or -1
+void pc_prof_end(int bracket, hipStream_t st);
+
 // ---- internal launchers (defined in the .hip files) -------------------------------------
 enum NtPrologue { NT_PRO_NONE = 0, NT_PRO_BNTANH = 1 };
 enum NtEpilogue {

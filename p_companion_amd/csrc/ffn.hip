@@ -16,6 +16,7 @@
 
 #define BN_EPS 1e-5f
 #define BN_MOMENTUM 0.1f
+#define BNQ 4                 // tile lanes of the finalize kernels (blockDim.y)
 
 // ---------------------------------------------------------------------------------------
 // partial[t][j] over 128-row tiles -> per-segment statistics.  blockDim = (256 cols, 4)
@@ -31,9 +32,19 @@ __global__ void bn_finalize_fwd_kernel(const float* psum, const float* psq, SegI
     for (int s = 0; s < si.nseg; s++) {
         const int n = si.start[s + 1] - si.start[s];
         double a = 0.0, b = 0.0;
-        for (int t = si.tile0[s] + q; t < si.tile0[s + 1]; t += 4) {
-            a += (double)psum[(size_t)t * PC_H + j];
-            b += (double)psq[(size_t)t * PC_H + j];
+        {   // four independent chains per thread keep the strided loads in flight
+            double a1 = 0.0, b1 = 0.0, a2 = 0.0, b2 = 0.0, a3 = 0.0, b3 = 0.0;
+            int t = si.tile0[s] + q;
+            const int te = si.tile0[s + 1];
+            for (; t + 3 * BNQ < te; t += 4 * BNQ) {
+                a += (double)psum[(size_t)t * PC_H + j];             b += (double)psq[(size_t)t * PC_H + j];
+                a1 += (double)psum[(size_t)(t + BNQ) * PC_H + j];     b1 += (double)psq[(size_t)(t + BNQ) * PC_H + j];
+                a2 += (double)psum[(size_t)(t + 2 * BNQ) * PC_H + j]; b2 += (double)psq[(size_t)(t + 2 * BNQ) * PC_H + j];
+                a3 += (double)psum[(size_t)(t + 3 * BNQ) * PC_H + j]; b3 += (double)psq[(size_t)(t + 3 * BNQ) * PC_H + j];
+            }
+            for (; t < te; t += BNQ) { a += (double)psum[(size_t)t * PC_H + j]; b += (double)psq[(size_t)t * PC_H + j]; }
+            a = (a + a1) + (a2 + a3);
+            b = (b + b1) + (b2 + b3);
         }
         red[0][q][j] = a;
         red[1][q][j] = b;
@@ -85,9 +96,19 @@ __global__ void bn_finalize_bwd_kernel(const float* psum, const float* pdot, Seg
     for (int s = 0; s < si.nseg; s++) {
         const int n = si.start[s + 1] - si.start[s];
         double a = 0.0, b = 0.0;
-        for (int t = si.tile0[s] + q; t < si.tile0[s + 1]; t += 4) {
-            a += (double)psum[(size_t)t * PC_H + j];
-            b += (double)pdot[(size_t)t * PC_H + j];
+        {   // four independent chains per thread keep the strided loads in flight
+            double a1 = 0.0, b1 = 0.0, a2 = 0.0, b2 = 0.0, a3 = 0.0, b3 = 0.0;
+            int t = si.tile0[s] + q;
+            const int te = si.tile0[s + 1];
+            for (; t + 3 * BNQ < te; t += 4 * BNQ) {
+                a += (double)psum[(size_t)t * PC_H + j];             b += (double)pdot[(size_t)t * PC_H + j];
+                a1 += (double)psum[(size_t)(t + BNQ) * PC_H + j];     b1 += (double)pdot[(size_t)(t + BNQ) * PC_H + j];
+                a2 += (double)psum[(size_t)(t + 2 * BNQ) * PC_H + j]; b2 += (double)pdot[(size_t)(t + 2 * BNQ) * PC_H + j];
+                a3 += (double)psum[(size_t)(t + 3 * BNQ) * PC_H + j]; b3 += (double)pdot[(size_t)(t + 3 * BNQ) * PC_H + j];
+            }
+            for (; t < te; t += BNQ) { a += (double)psum[(size_t)t * PC_H + j]; b += (double)pdot[(size_t)t * PC_H + j]; }
+            a = (a + a1) + (a2 + a3);
+            b = (b + b1) + (b2 + b3);
         }
         red[0][q][j] = a;
         red[1][q][j] = b;
@@ -183,6 +204,8 @@ static FfnWs ffn_ws_layout(void* base, int rows) {
     w.c2 = take(PC_MAX_SEG * PC_H);
     w.coef = take(2 * PC_H);
     w.slab_floats = gemm_tn_workspace_floats(rows, PC_H, PC_H);
+    for (size_t f : {gemm_tn_workspace_floats(rows, PC_D, PC_H), gemm_tn_workspace_floats(rows, PC_H, PC_D)})
+        if (f > w.slab_floats) w.slab_floats = f;
     w.slabs = take(w.slab_floats);
     w.total = off;
     return w;

@@ -122,21 +122,42 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(TnArgs a, int tiles_i, 
     }
 }
 
-// out[j] (+)= sum_s slabs[s][j] in increasing s, j over [No*Ni] then [No] (bias)
-__global__ void tn_reduce_kernel(const float* slabs, int nsplit, int n_w, int n_b, float* dW, float* db,
-                                 int accumulate) {
-    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+// out[j] (+)= sum_s slabs[s][j], j over [No*Ni] then [No] (bias).  Eight lanes share one float4 of
+// outputs: lane g sums slabs g, g+8, ... and the eight partial sums fold in a fixed xor order
+// (bitwise reproducible), so a 256x256 gradient keeps ~500 workgroups streaming from HBM.
+__global__ __launch_bounds__(256) void tn_reduce_kernel(const float* slabs, int nsplit, int n_w, int n_b, float* dW,
+                                                        float* db, int accumulate) {
+    const int total4 = (n_w + (db ? n_b : 0)) / 4;          // n_w, n_b multiples of 4
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    const int j4 = t >> 3, g = t & 7;
+    if (j4 >= total4) return;                               // whole 8-lane groups leave together
     const size_t stride = (size_t)n_w + n_b;
-    if (j >= n_w + (db ? n_b : 0)) return;
-    float s = 0.f;
-    for (int k = 0; k < nsplit; k++) s += slabs[(size_t)k * stride + j];
-    float* dst = j < n_w ? dW + j : db + (j - n_w);
-    *dst = accumulate ? *dst + s : s;
+    const float* src = slabs + (size_t)j4 * 4;
+    float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll 4
+    for (int k = g; k < nsplit; k += 8) {
+        const float4 v = *reinterpret_cast<const float4*>(src + (size_t)k * stride);
+        s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+    }
+#pragma unroll
+    for (int o = 1; o < 8; o <<= 1) {
+        s.x += __shfl_xor(s.x, o, 64); s.y += __shfl_xor(s.y, o, 64);
+        s.z += __shfl_xor(s.z, o, 64); s.w += __shfl_xor(s.w, o, 64);
+    }
+    if (g == 0) {
+        const int j = j4 * 4;
+        float* dst = j < n_w ? dW + j : db + (j - n_w);
+        if (accumulate) {
+            const float4 old = *reinterpret_cast<const float4*>(dst);
+            s.x += old.x; s.y += old.y; s.z += old.z; s.w += old.w;
+        }
+        *reinterpret_cast<float4*>(dst) = s;
+    }
 }
 
 static void tn_plan(int R, int No, int Ni, int* nsplit, int* rows_per_split) {
     const int tiles = ((No + TM - 1) / TM) * ((Ni + TM - 1) / TM);
-    int s = (1024 + tiles - 1) / tiles;            // ~4 workgroups per CU in total
+    int s = (512 + tiles - 1) / tiles;             // ~2 workgroups per CU in total
     const int max_s = (R + 255) / 256;             // at least 8 chunks of 32 rows per split
     if (s > max_s) s = max_s;
     if (s < 1) s = 1;
@@ -156,15 +177,18 @@ size_t gemm_tn_workspace_floats(int R, int No, int Ni) {
 int launch_gemm_tn(const TnArgs& a, hipStream_t st) {
     if (!a.Z || !a.A || !a.dW || !a.slabs || a.R <= 0 || a.No <= 0 || a.Ni <= 0) return PC_EINVAL;
     if (a.No % 4 || a.Ni % 4 || a.ldz % 4 || a.lda % 4 || a.lddw != a.Ni) return PC_ESHAPE;
+    if (((uintptr_t)a.dW & 15) || (a.db && ((uintptr_t)a.db & 15)) || ((uintptr_t)a.slabs & 15)) return PC_ESHAPE;
     int nsplit, rps;
     tn_plan(a.R, a.No, a.Ni, &nsplit, &rps);
     if ((size_t)nsplit * ((size_t)a.No * a.Ni + a.No) > a.slab_floats) return PC_EWORKSPACE;
     const int tiles_o = (a.No + TM - 1) / TM, tiles_i = (a.Ni + TM - 1) / TM;
+    const int pb = pc_prof_begin(PC_KIND_GEMM_TN, 2.0 * a.R * (double)a.No * a.Ni, st);
     hipLaunchKernelGGL(gemm_tn_kernel, dim3(tiles_o * tiles_i * nsplit), dim3(256), 0, st, a, tiles_i, nsplit, rps);
+    pc_prof_end(pb, st);
     PC_TRY(pc_launch_status());
     const int n_w = a.No * a.Ni, n_b = a.No;
-    const int total = n_w + (a.db ? n_b : 0);
-    hipLaunchKernelGGL(tn_reduce_kernel, dim3((total + 255) / 256), dim3(256), 0, st, a.slabs, nsplit, n_w, n_b,
+    const int threads = (n_w + (a.db ? n_b : 0)) / 4 * 8;
+    hipLaunchKernelGGL(tn_reduce_kernel, dim3((threads + 255) / 256), dim3(256), 0, st, a.slabs, nsplit, n_w, n_b,
                        a.dW, a.db, a.accumulate);
     return pc_launch_status();
 }

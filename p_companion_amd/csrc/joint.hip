@@ -204,7 +204,7 @@ __global__ __launch_bounds__(256) void joint_loss_kernel(const float* sims, cons
         li += l > 0.f ? l : 0.f;
         if (dproj) {
             const float g = l > 0.f ? alpha / ((float)B * (float)K) : 0.f;
-            const float ip = g / np_, in = g / nn_;
+            const float ip = np_ > 0.f ? g / np_ : 0.f, in = nn_ > 0.f ? g / nn_ : 0.f;   // torch.norm: subgradient 0 at 0
             *reinterpret_cast<float2*>(dproj + o) = make_float2(-dp.x * ip + dn.x * in, -dp.y * ip + dn.y * in);
         }
     }
@@ -325,8 +325,9 @@ static JointWs joint_ws_layout(void* base, int B, int T, int K) {
     w.pi = take((size_t)B * PC_D);
     w.tp = take((size_t)B * K * PC_D);
     size_t s = gemm_tn_workspace_floats(B * K, PC_D, PC_L);
-    size_t s2 = gemm_tn_workspace_floats(B, PC_D, PC_D);
-    if (s2 > s) s = s2;
+    for (size_t f : {gemm_tn_workspace_floats(B, PC_D, PC_D), gemm_tn_workspace_floats(B, PC_L, LH),
+                     gemm_tn_workspace_floats(B, LH, PC_L)})
+        if (f > s) s = f;
     w.slab_floats = s;
     w.slabs = take(s);
     w.total = off;

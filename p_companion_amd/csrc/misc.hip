@@ -181,4 +181,39 @@ extern "C" int pc_scatter_add_rows(float* table, const int32_t* idx, int rows, i
     return pc_launch_status();
 }
 
+// out[idx[r]] = src[r]  (row assignment; idx < 0 skipped; duplicate targets: last writer wins)
+__global__ void scatter_rows_kernel(float* out, const int32_t* idx, int rows, int w4, const float* src) {
+    const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= (size_t)rows * w4) return;
+    const int r = (int)(t / w4), c = (int)(t % w4);
+    const int dst = idx[r];
+    if (dst >= 0) *reinterpret_cast<float4*>(out + ((size_t)dst * w4 + c) * 4) = *reinterpret_cast<const float4*>(src + t * 4);
+}
+
+extern "C" int pc_scatter_rows(float* out, const int32_t* idx, int rows, int width, const float* src,
+                               void* stream) {
+    if (!out || !idx || !src || rows <= 0 || width <= 0) return PC_EINVAL;
+    if (width % 4) return PC_ESHAPE;
+    const size_t total = (size_t)rows * (width / 4);
+    hipLaunchKernelGGL(scatter_rows_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                       out, idx, rows, width / 4, src);
+    return pc_launch_status();
+}
+
+// dx = dy * act'(y): act 1 tanh (1 - y^2), 2 relu (y > 0)
+__global__ void act_backward_kernel(const float* dy, const float* y, size_t n, int act, float* dx) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float v = y[i];
+    dx[i] = act == 1 ? dy[i] * (1.f - v * v) : (v > 0.f ? dy[i] : 0.f);
+}
+
+extern "C" int pc_act_backward(const float* dy, const float* y, size_t n, int act, float* dx, void* stream) {
+    if (!dy || !y || !dx || n == 0) return PC_EINVAL;
+    if (act != 1 && act != 2) return PC_EINVAL;
+    hipLaunchKernelGGL(act_backward_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, dy,
+                       y, n, act, dx);
+    return pc_launch_status();
+}
+
 extern "C" int pc_abi_version(void) { return 1; }

@@ -75,7 +75,8 @@ extern "C" int pc_p2v_train_step(const pc_p2v_tensors* p, const pc_p2v_tensors* 
                                  const int32_t* anchor_idx, const int32_t* positive_idx,
                                  const int32_t* negative_idx, const int32_t* neighbor_idx, int B, int N, int K,
                                  float margin, float* loss, float* d_pos, float* d_neg, float* anchor_emb,
-                                 void* ws, size_t ws_bytes, void* stream) {
+                                 void* profile, void* ws, size_t ws_bytes, void* stream) {
+    ProfileScope prof_scope((pc_profile*)profile);
     if (!p || !g || !table || !anchor_idx || !positive_idx || !negative_idx || !loss || !ws) return PC_EINVAL;
     if (B <= 0 || N < 0 || K <= 0 || (N > 0 && !neighbor_idx)) return PC_EINVAL;
     if (ws_bytes < pc_p2v_train_step_workspace_bytes(B, N, K)) return PC_EWORKSPACE;

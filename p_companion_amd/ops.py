@@ -237,8 +237,31 @@ def adam_step(param, grad, exp_avg, exp_avg_sq, step_count, scalars, lr=1e-3, be
                                   float(lr), float(betas[0]), float(betas[1]), float(eps), _stream()), "pc_adam_step")
 
 
+class KernelProfile:
+    """HIP-event brackets around the GEMM launches of the fused step (bench.py roofline leg)."""
+    KINDS = {"gemm_nt_kernel": 0, "gemm_tn_kernel": 1}
+
+    def __init__(self, capacity):
+        self.handle = ctypes.c_void_p()
+        check(_lib.lib().pc_profile_create(int(capacity), ctypes.byref(self.handle)), "pc_profile_create")
+
+    def reset(self):
+        check(_lib.lib().pc_profile_reset(self.handle), "pc_profile_reset")
+
+    def summary(self, kind):
+        n, ms, fl = ctypes.c_int(), ctypes.c_double(), ctypes.c_double()
+        check(_lib.lib().pc_profile_summary(self.handle, self.KINDS[kind], ctypes.byref(n), ctypes.byref(ms),
+                                            ctypes.byref(fl)), "pc_profile_summary")
+        return {"launches": n.value, "total_ms": ms.value, "total_flops": fl.value}
+
+    def close(self):
+        if self.handle:
+            _lib.lib().pc_profile_destroy(self.handle)
+            self.handle = ctypes.c_void_p()
+
+
 def p2v_train_step(params, grads, table, anchor_idx, positive_idx, negative_idx, neighbor_idx, margin,
-                   want_emb=False):
+                   want_emb=False, profile=None):
     """One loop-body iteration of Product2Vec.train_model in index form (grads overwritten)."""
     st, dev = p2v_struct(params)
     gst, _ = p2v_struct(grads, with_buffers=False)
@@ -260,7 +283,8 @@ def p2v_train_step(params, grads, table, anchor_idx, positive_idx, negative_idx,
     check(_lib.lib().pc_p2v_train_step(ctypes.byref(st), ctypes.byref(gst), _p(table), _p(anchor_idx),
                                        _p(positive_idx), _p(negative_idx), _p(neighbor_idx) if n else None, b, n, k,
                                        float(margin), _p(out["loss"]), _p(out["d_pos"]), _p(out["d_neg"]),
-                                       _p(out.get("anchor_emb")), _p(ws), nbytes, _stream()), "pc_p2v_train_step")
+                                       _p(out.get("anchor_emb")), profile.handle if profile else None, _p(ws),
+                                       nbytes, _stream()), "pc_p2v_train_step")
     return out
 
 
@@ -487,3 +511,17 @@ def scatter_add_rows(table, idx, src):
     _req(table, torch.float32, "table"); _req(idx, torch.int32, "idx"); _req(src, torch.float32, "src", (rows, width))
     check(_lib.lib().pc_scatter_add_rows(_p(table), _p(idx), rows, width, _p(src), _stream()), "pc_scatter_add_rows")
     return table
+
+
+def scatter_rows(out, idx, src):
+    rows, width = idx.numel(), out.shape[1]
+    _req(out, torch.float32, "out"); _req(idx, torch.int32, "idx"); _req(src, torch.float32, "src", (rows, width))
+    check(_lib.lib().pc_scatter_rows(_p(out), _p(idx), rows, width, _p(src), _stream()), "pc_scatter_rows")
+    return out
+
+
+def act_backward(dy, y, act):
+    _req(dy, torch.float32, "dy"); _req(y, torch.float32, "y", dy.shape)
+    dx = torch.empty_like(dy)
+    check(_lib.lib().pc_act_backward(_p(dy), _p(y), dy.numel(), act, _p(dx), _stream()), "pc_act_backward")
+    return dx

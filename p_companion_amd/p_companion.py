@@ -1,0 +1,169 @@
+"""PCompanion on MI355X -- drop-in for the reference's src/models/p_companion.py.
+
+Same constructor (config, pretrained_embeddings: Dict[str, Tensor]), forward(batch) ->
+{'projected_embeddings', 'complementary_types', 'type_similarities'}, compute_loss(batch,
+outputs), _compute_type_loss / _compute_item_loss, attributes and state_dict keys
+(p_companion.py:10-119).  Numbers come from the HIP kernels; nn.Embedding / nn.Linear are
+parameter containers only.  Two ways in:
+  * module mode: forward/compute_loss build an autograd graph of HIP Functions (works with
+    loss.backward() + any torch optimizer; gradients are dense like the reference's);
+  * fused mode: train_step(batch) = pc_joint_train_step -- forward, both hinge losses and the
+    whole backward with the type-hinge gradient kept sparse and the type tables updated by
+    row scatter-add -- gradients written into .grad, Adam as one launch (FusedAdam).
+"""
+from typing import Dict
+
+import torch
+import torch.nn as nn
+
+from . import ops
+from .functional import embedding, hadamard, linear
+from .item_prediction import ComplementaryItemPrediction
+from .product2vec import _FlatParamsMixin
+from .type_transition import ComplementaryTypeTransition
+
+
+class _JointLoss(torch.autograd.Function):
+    """compute_loss (p_companion.py:79-119) as one kernel; the backward hands autograd the
+    dense d(loss)/d(type_similarities) its graph needs (pc_expand_type_grad)."""
+
+    @staticmethod
+    def forward(ctx, sims, proj, pos_types, neg_types, pos_items, neg_items, margin, alpha, which):
+        losses, dsv, dproj = ops.joint_loss(sims, proj, pos_types, neg_types, pos_items, neg_items, margin, alpha)
+        ctx.save_for_backward(dsv, dproj, pos_types, neg_types)
+        ctx.num_types = sims.shape[1]
+        return losses[which]
+
+    @staticmethod
+    def backward(ctx, g):
+        dsv, dproj, pos_types, neg_types = ctx.saved_tensors
+        dense = ops.expand_type_grad(dsv, pos_types, neg_types, ctx.num_types)
+        return dense * g, dproj * g, None, None, None, None, None, None, None
+
+
+class PCompanion(nn.Module, _FlatParamsMixin):
+    _flat_keys = ops.JOINT_KEYS
+
+    def __init__(self, config, pretrained_embeddings):
+        super().__init__()
+        self.config = config
+        if (config.PRODUCT_EMB_DIM, config.TYPE_EMB_DIM) != (ops.D, ops.L):
+            raise ValueError("the gfx950 kernels are built for PRODUCT_EMB_DIM=128, TYPE_EMB_DIM=64")
+
+        if isinstance(pretrained_embeddings, torch.Tensor):
+            # index-mode extension: row i is product i ("P%06d" % i)
+            embedding_matrix = pretrained_embeddings.detach().float()
+            self.product_to_idx = _IdentityIds(embedding_matrix.shape[0])
+        else:
+            product_ids = list(pretrained_embeddings.keys())
+            self.product_to_idx = {pid: idx for idx, pid in enumerate(product_ids)}
+            embedding_matrix = torch.stack([pretrained_embeddings[pid].detach().float().cpu()
+                                            for pid in product_ids])       # one stack, not a Python row loop (:20-23)
+
+        self.product_embeddings = nn.Embedding.from_pretrained(embedding_matrix, freeze=True)
+        self.type_transition = ComplementaryTypeTransition(config)
+        self.item_prediction = ComplementaryItemPrediction(config)
+        self.query_type_embeddings = nn.Embedding(config.NUM_TYPES, config.TYPE_EMB_DIM)
+        self.complementary_type_embeddings = nn.Embedding(config.NUM_TYPES, config.TYPE_EMB_DIM)
+
+    # ------------------------------------------------------------------ helpers
+    def _query_indices(self, batch, device):
+        if "query_idx" in batch:
+            return batch["query_idx"].to(device=device, dtype=torch.int32).contiguous()
+        return torch.tensor([self.product_to_idx[pid] for pid in batch["query_ids"]],      # KeyError as :48
+                            dtype=torch.int32).to(device)
+
+    def _tensor_dict(self):
+        return dict(self.named_parameters())
+
+    @staticmethod
+    def _i32(t):
+        return t.reshape(-1).to(torch.int32).contiguous()
+
+    def _check(self):
+        if self.training and float(self.config.DROPOUT) != 0.0:
+            raise NotImplementedError("DROPOUT != 0 is not implemented in the HIP path; set config.DROPOUT = 0")
+
+    # ------------------------------------------------------------------ reference surface
+    def forward(self, batch):
+        self._check()
+        dev = self.query_type_embeddings.weight.device
+        k = int(self.config.NUM_COMP_TYPES)
+        query_indices = self._query_indices(batch, dev)
+        query_types = self._i32(batch["query_types"].to(dev))
+        if not (torch.is_grad_enabled() and self.training):
+            sims, topk, proj, _ = ops.joint_forward(self._tensor_dict(), query_indices, query_types, k)
+            return {"projected_embeddings": proj, "complementary_types": topk.long(), "type_similarities": sims}
+
+        query_embeddings = embedding(self.product_embeddings.weight, query_indices)
+        query_type_emb = embedding(self.query_type_embeddings.weight, query_types)
+        comp_base = self.type_transition(query_type_emb)
+        similarities = linear(comp_base, self.complementary_type_embeddings.weight)       # c . E_c^T
+        top_k = ops.topk_rows(similarities.detach(), k)                                     # indices: no gradient
+        comp_type_embeddings = embedding(self.complementary_type_embeddings.weight, top_k)
+        projected_embeddings = self.item_prediction(query_embeddings, comp_type_embeddings)
+        return {"projected_embeddings": projected_embeddings, "complementary_types": top_k.long(),
+                "type_similarities": similarities}
+
+    def _loss(self, batch, outputs, which):
+        dev = outputs["type_similarities"].device
+        return _JointLoss.apply(
+            outputs["type_similarities"].contiguous(), outputs["projected_embeddings"].contiguous(),
+            self._i32(batch["positive_types"].to(dev)), self._i32(batch["negative_types"].to(dev)),
+            batch["positive_items"].to(dev).float().contiguous(), batch["negative_items"].to(dev).float().contiguous(),
+            float(self.config.MARGIN), float(self.config.ALPHA), which)
+
+    def compute_loss(self, batch, outputs):
+        """Compute combined loss for type transition and item prediction (p_companion.py:79-93)"""
+        return self._loss(batch, outputs, 0)
+
+    def _compute_type_loss(self, type_similarities, positive_types, negative_types):
+        b = type_similarities.shape[0]
+        z = torch.zeros(b, ops.D, device=type_similarities.device)
+        proj = torch.zeros(b, 1, ops.D, device=type_similarities.device)
+        return _JointLoss.apply(type_similarities.contiguous(), proj, self._i32(positive_types),
+                                self._i32(negative_types), z, z, float(self.config.MARGIN), 0.0, 1)
+
+    def _compute_item_loss(self, projected_embeddings, positive_items, negative_items):
+        b = projected_embeddings.shape[0]
+        dev = projected_embeddings.device
+        sims = torch.zeros(b, 4, device=dev)
+        zi = torch.zeros(b, dtype=torch.int32, device=dev)
+        return _JointLoss.apply(sims, projected_embeddings.contiguous(), zi, zi, positive_items.float().contiguous(),
+                                negative_items.float().contiguous(), float(self.config.MARGIN), 1.0, 2)
+
+    # ------------------------------------------------------------------ fused loop body
+    def train_step(self, batch):
+        """train.py:42-46 (forward, compute_loss, zero_grad, backward) as one C-ABI call.
+        Returns (losses[3] = total/type/item on the device, complementary_types[B,K])."""
+        self._check()
+        self.flatten_parameters()
+        dev = self.query_type_embeddings.weight.device
+        params = self._tensor_dict()
+        params["product_embeddings.weight"] = self.product_embeddings.weight
+        grads = {k: p.grad for k, p in self.named_parameters() if p.grad is not None}
+        return ops.joint_train_step(
+            params, grads, self._query_indices(batch, dev), self._i32(batch["query_types"].to(dev)),
+            self._i32(batch["positive_types"].to(dev)), self._i32(batch["negative_types"].to(dev)),
+            batch["positive_items"].to(dev).float().contiguous(), batch["negative_items"].to(dev).float().contiguous(),
+            int(self.config.NUM_COMP_TYPES), float(self.config.MARGIN), float(self.config.ALPHA))
+
+    def _named_flat(self):
+        sd = dict(self.named_parameters())
+        return [(k, sd[k]) for k in self._flat_keys]
+
+
+class _IdentityIds:
+    """product_to_idx for an integer-id table: 'P000123' -> 123 without a 100M-entry dict."""
+
+    def __init__(self, n):
+        self.n = n
+
+    def __getitem__(self, pid):
+        i = int(pid[1:]) if isinstance(pid, str) else int(pid)
+        if not 0 <= i < self.n:
+            raise KeyError(pid)
+        return i
+
+    def __len__(self):
+        return self.n

@@ -1,0 +1,376 @@
+"""Product2Vec on MI355X -- drop-in for the reference's src/models/product2vec.py.
+
+Same constructor, method names/signatures, batch-dict keys and state_dict keys
+(ffn.0.weight ... attention.out_proj.bias, incl. the BatchNorm buffers); every number is
+produced by the HIP kernels of libpcompanion_hip.so through the C ABI.  torch.nn
+submodules are kept ONLY as parameter containers (so checkpoints interchange and the
+default initialisers / RNG consumption are the reference's); their forward() is never
+called and there is no CPU fallback.
+
+Two ways in:
+  * dense tensors (reference loader compatible): forward(features[, neighbors]) builds
+    the autograd graph from two custom Functions (FFN, attention) -> works with
+    loss.backward() and any torch optimizer, exactly like the reference module;
+  * index batches (anchor_idx / positive_idx / negative_idx / neighbor_idx over a device
+    resident feature table): train_model runs the fused step pc_p2v_train_step -- gather,
+    4 BatchNorm call groups, attention, loss, whole backward -- with gradients written
+    straight into .grad (views of one flat buffer) and, with FusedAdam, one Adam launch.
+"""
+import logging
+from typing import Dict, Optional
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from . import ops
+
+_FFN_KEYS = ops.P2V_KEYS[:8]
+_ATT_KEYS = ops.P2V_KEYS[8:]
+
+
+class _FFNFunction(torch.autograd.Function):
+    """get_initial_embedding on a [R,128] block, training mode (product2vec.py:31-46)."""
+
+    @staticmethod
+    def forward(ctx, module, x, *weights):
+        params = module._tensor_dict()
+        y, sv = ops.ffn_forward_train(params, x, None, x.shape[0], [0], update_running=True)
+        ctx.module, ctx.sv = module, sv
+        ctx.save_for_backward(x)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (x,) = ctx.saved_tensors
+        params = ctx.module._tensor_dict()
+        grads, dx = ops.ffn_backward(params, x, None, dy.contiguous(), ctx.sv, need_dx=ctx.needs_input_grad[1])
+        return (None, dx) + tuple(grads[k] for k in _FFN_KEYS)
+
+
+class _AttentionFunction(torch.autograd.Function):
+    """apply_attention (product2vec.py:48-68): query [B,D], keys [B,N,D] -> [B,D]."""
+
+    @staticmethod
+    def forward(ctx, module, query, keys, *weights):
+        params = module._tensor_dict()
+        out, sv = ops.attention_forward(params, query, keys)
+        ctx.module, ctx.sv = module, sv
+        ctx.save_for_backward(query, keys)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        query, keys = ctx.saved_tensors
+        params = ctx.module._tensor_dict()
+        grads, dq, dk = ops.attention_backward(params, query, keys, dout.contiguous(), ctx.sv)
+        return (None, dq, dk) + tuple(grads[k] for k in _ATT_KEYS)
+
+
+class _TripletLossFunction(torch.autograd.Function):
+    """The loss expression of train_model (product2vec.py:137-154) as one kernel."""
+
+    @staticmethod
+    def forward(ctx, a, p, n, margin):
+        out = ops.triplet_loss(a, p, n, margin, need_grad=True)
+        ctx.save_for_backward(out["da"], out["dp"], out["dn"])
+        return out["loss"].reshape(())
+
+    @staticmethod
+    def backward(ctx, g):
+        da, dp, dn = ctx.saved_tensors
+        return da * g, dp * g, dn * g, None
+
+
+class FusedAdam(torch.optim.Optimizer):
+    """torch.optim.Adam semantics (defaults of scripts/pretrain_product2vec.py:34) as ONE HIP
+    launch over the module's flat parameter buffer.  Opt-in: any torch optimizer works too."""
+
+    def __init__(self, module, lr=1e-3, betas=(0.9, 0.999), eps=1e-8):
+        self.module = module
+        super().__init__(list(module.parameters()), dict(lr=lr, betas=betas, eps=eps))
+        self._state_ready = False
+
+    def _ensure(self):
+        flat, gflat = self.module.flatten_parameters()
+        if not self._state_ready or self.exp_avg.data_ptr() == 0 or self.exp_avg.numel() != flat.numel() \
+                or self.exp_avg.device != flat.device:
+            self.exp_avg = torch.zeros_like(flat)
+            self.exp_avg_sq = torch.zeros_like(flat)
+            self.step_count = torch.zeros(1, dtype=torch.int64, device=flat.device)
+            self.scalars = torch.zeros(2, dtype=torch.float32, device=flat.device)
+            self._state_ready = True
+        return flat, gflat
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        flat, gflat = self._ensure()
+        g = self.param_groups[0]
+        ops.adam_step(flat, gflat, self.exp_avg, self.exp_avg_sq, self.step_count, self.scalars, g["lr"],
+                      g["betas"], g["eps"])
+
+    def zero_grad(self, set_to_none=False):
+        _, gflat = self._ensure()
+        gflat.zero_()
+
+
+class _FlatParamsMixin:
+    """Parameters as views of one flat fp32 buffer (+ a flat gradient buffer whose views are
+    the .grad tensors), so the fused step writes gradients in place and Adam is one launch."""
+
+    _flat_keys = ()
+
+    def _named_flat(self):
+        sd = dict(self.named_parameters())
+        return [(k, sd[k]) for k in self._flat_keys]
+
+    def flatten_parameters(self):
+        items = self._named_flat()
+        flat = getattr(self, "_flat", None)
+        ok = flat is not None and flat.device == items[0][1].device
+        if ok:
+            off = 0
+            for _, p in items:
+                if p.data_ptr() != flat.data_ptr() + 4 * off or p.grad is None or \
+                        p.grad.data_ptr() != self._gflat.data_ptr() + 4 * off:
+                    ok = False
+                    break
+                off += p.numel()
+        if not ok:
+            dev = items[0][1].device
+            n = sum(p.numel() for _, p in items)
+            flat = torch.empty(n, dtype=torch.float32, device=dev)
+            gflat = torch.zeros(n, dtype=torch.float32, device=dev)
+            off = 0
+            for _, p in items:
+                m = p.numel()
+                flat[off:off + m].copy_(p.data.reshape(-1))
+                if p.grad is not None:
+                    gflat[off:off + m].copy_(p.grad.reshape(-1))
+                p.data = flat[off:off + m].view(p.shape)
+                p.grad = gflat[off:off + m].view(p.shape)
+                off += m
+            self._flat, self._gflat = flat, gflat
+        return self._flat, self._gflat
+
+
+class Product2Vec(nn.Module, _FlatParamsMixin):
+    _flat_keys = ops.P2V_KEYS
+
+    def __init__(self, config):
+        super().__init__()
+        self.config = config
+        if (config.PRODUCT_EMB_DIM, config.HIDDEN_SIZE, config.NUM_ATTENTION_HEADS) != (ops.D, ops.H, ops.HEADS):
+            raise ValueError("the gfx950 kernels are built for PRODUCT_EMB_DIM=128, HIDDEN_SIZE=256, "
+                             "NUM_ATTENTION_HEADS=4 (config.py:8-11)")
+        # parameter containers only -- same construction order as product2vec.py:14-29, so
+        # torch.manual_seed(s) yields the reference's initial weights
+        self.ffn = nn.Sequential(
+            nn.Linear(config.PRODUCT_EMB_DIM, config.HIDDEN_SIZE),
+            nn.BatchNorm1d(config.HIDDEN_SIZE),
+            nn.Tanh(),
+            nn.Linear(config.HIDDEN_SIZE, config.HIDDEN_SIZE),
+            nn.Tanh(),
+            nn.Linear(config.HIDDEN_SIZE, config.PRODUCT_EMB_DIM))
+        self.attention = nn.MultiheadAttention(embed_dim=config.PRODUCT_EMB_DIM,
+                                               num_heads=config.NUM_ATTENTION_HEADS,
+                                               dropout=config.DROPOUT, batch_first=True)
+        self.last_embedding_table = None
+
+    # ------------------------------------------------------------------ plumbing
+    def _tensor_dict(self):
+        d = dict(self.named_parameters())
+        d.update(dict(self.named_buffers()))
+        return d
+
+    def _weights(self, keys):
+        d = dict(self.named_parameters())
+        return tuple(d[k] for k in keys)
+
+    def _check_dropout(self):
+        if self.training and float(getattr(self.config, "DROPOUT", 0.0)) != 0.0:
+            raise NotImplementedError(
+                "attention-weight dropout (config.DROPOUT != 0) is not implemented in the HIP path; "
+                "set DROPOUT = 0 (ATen's dropout RNG stream cannot be reproduced, SURVEY section 7)")
+
+    @staticmethod
+    def _dev(t):
+        if not t.is_cuda:
+            raise TypeError("Product2Vec runs on the GPU only: move inputs to config.DEVICE (no CPU fallback)")
+        return t.contiguous().float()
+
+    # ------------------------------------------------------------------ reference surface
+    def get_initial_embedding(self, features: torch.Tensor) -> torch.Tensor:
+        """Get initial embedding through FFN (product2vec.py:31-46)."""
+        if features.dim() == 1:
+            return self._ffn(features.unsqueeze(0)).squeeze(0)
+        elif features.dim() == 2:
+            return self._ffn(features)
+        elif features.dim() == 3:
+            B, N, D = features.shape
+            return self._ffn(features.reshape(-1, D)).reshape(B, N, -1)
+        raise ValueError(f"Unexpected input dimension: {features.dim()}")
+
+    def _ffn(self, x):
+        x = self._dev(x)
+        if self.training:
+            if x.shape[0] == 1:
+                raise ValueError(f"Expected more than 1 value per channel when training, got input size {x.shape}")
+            if torch.is_grad_enabled():
+                return _FFNFunction.apply(self, x, *self._weights(_FFN_KEYS))
+            y, _ = ops.ffn_forward_train(self._tensor_dict(), x, None, x.shape[0], [0], True)
+            return y
+        if torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in self.parameters())):
+            # eval-mode backward is not part of the reference's hot path
+            with torch.no_grad():
+                return ops.ffn_forward_eval(self._tensor_dict(), x, None, x.shape[0])
+        return ops.ffn_forward_eval(self._tensor_dict(), x, None, x.shape[0])
+
+    def apply_attention(self, query: torch.Tensor, key_value: torch.Tensor) -> torch.Tensor:
+        """Apply attention mechanism with proper reshaping (product2vec.py:48-68)."""
+        if query.dim() == 1:
+            query = query.unsqueeze(0).unsqueeze(0)
+        elif query.dim() == 2:
+            query = query.unsqueeze(1)
+        if key_value.dim() == 2:
+            key_value = key_value.unsqueeze(0)
+        if query.size(1) != 1:
+            raise ValueError("the HIP attention kernel handles one query token per sample "
+                             "(the only use in product2vec.py:70-81)")
+        self._check_dropout()
+        q2 = self._dev(query[:, 0, :])
+        kv = self._dev(key_value)
+        if torch.is_grad_enabled() and self.training:
+            out = _AttentionFunction.apply(self, q2, kv, *self._weights(_ATT_KEYS))
+        else:
+            out, _ = ops.attention_forward(self._tensor_dict(), q2, kv)
+        out = out.unsqueeze(1)
+        if query.size(0) == 1 and query.size(1) == 1:
+            out = out.squeeze(0).squeeze(0)
+        elif query.size(1) == 1:
+            out = out.squeeze(1)
+        return out
+
+    def forward(self, features: torch.Tensor, neighbors: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """Forward pass through Product2Vec model (product2vec.py:70-81)."""
+        embeddings = self.get_initial_embedding(features)
+        if neighbors is not None and neighbors.size(0) > 0:
+            neighbor_embeddings = self.get_initial_embedding(neighbors)
+            embeddings = self.apply_attention(embeddings, neighbor_embeddings)
+        return embeddings
+
+    # ------------------------------------------------------------------ P11
+    @torch.no_grad()
+    def generate_embedding_table(self, features: torch.Tensor, cv_rowptr: np.ndarray, cv_col: np.ndarray):
+        """Batched device pass of generate_all_embeddings (product2vec.py:83-111), eval mode:
+        pass 1 e1 = ffn(x) for every product; pass 2, for products with co-view out-neighbours,
+        attention(query = ffn(e1)  [the reference re-applies the FFN to the stored embedding,
+        :105-108 -> :73], keys = ffn(neighbour features) = e1[neighbours]) over the product's
+        exact neighbour list (no padding in this pass).  Products are grouped by degree so each
+        group is one rectangular attention launch."""
+        was_training = self.training
+        self.eval()
+        params = self._tensor_dict()
+        x = self._dev(features)
+        P = x.shape[0]
+        e1 = ops.ffn_forward_eval(params, x, None, P)
+        e2 = ops.ffn_forward_eval(params, e1, None, P)
+        out = e1.clone()
+        deg = np.diff(cv_rowptr)
+        cv_col = np.asarray(cv_col)
+        for d in np.unique(deg):
+            if d == 0:
+                continue
+            nodes = np.nonzero(deg == d)[0]
+            starts = cv_rowptr[nodes].astype(np.int64)
+            nb = cv_col[(starts[:, None] + np.arange(d)[None, :]).reshape(-1)]
+            nb_idx = torch.from_numpy(np.ascontiguousarray(nb, np.int32)).to(x.device)
+            node_idx = torch.from_numpy(nodes.astype(np.int32)).to(x.device)
+            keys = ops.gather_rows(e1, nb_idx).view(len(nodes), int(d), ops.D)
+            query = ops.gather_rows(e2, node_idx)
+            upd, _ = ops.attention_forward(params, query, keys)
+            ops.scatter_rows(out, node_idx, upd)
+        self.train(was_training)
+        self.last_embedding_table = out
+        return out
+
+    def generate_all_embeddings(self, bpg) -> Dict[str, torch.Tensor]:
+        """Generate embeddings for all products in the BPG (product2vec.py:83-111).
+        Accepts the integer BPG (p_companion_amd.data.IntBPG) or a reference-style
+        BehaviorProductGraph (nodes dict + edges['co_view'] set).  Returns Dict[str, Tensor[128]]
+        on the CPU like the reference; the device table stays in self.last_embedding_table."""
+        from .data import IntBPG
+        if isinstance(bpg, IntBPG):
+            ids = [f"P{i:06d}" for i in range(bpg.num_products)]
+            feats = bpg.cuda(self._device())["features"]
+            rowptr, col = bpg.cv_rowptr, bpg.cv_col
+        else:
+            ids = list(bpg.nodes.keys())
+            pos = {pid: i for i, pid in enumerate(ids)}
+            feats = torch.stack([bpg.nodes[p]["features"] for p in ids]).to(self._device())
+            lists = [[pos[t] for t in bpg.get_neighbors(p, edge_type="co_view")] for p in ids]
+            rowptr = np.concatenate([[0], np.cumsum([len(l) for l in lists])]).astype(np.int64)
+            col = np.array([t for l in lists for t in l], np.int32)
+        table = self.generate_embedding_table(feats, np.asarray(rowptr), np.asarray(col))
+        cpu = table.cpu()
+        return {pid: cpu[i] for i, pid in enumerate(ids)}
+
+    def _device(self):
+        return next(self.parameters()).device
+
+    # ------------------------------------------------------------------ P9 loop
+    def train_step_indexed(self, table, batch, profile=None):
+        """One loop-body iteration (product2vec.py:130-158 minus optimizer.step) on an index
+        batch.  Gradients land in .grad (flat-buffer views); returns the device loss tensor."""
+        self._check_dropout()
+        self.flatten_parameters()
+        params = self._tensor_dict()
+        grads = {k: p.grad for k, p in self.named_parameters()}
+        out = ops.p2v_train_step(params, grads, table, batch["anchor_idx"], batch["positive_idx"],
+                                 batch["negative_idx"], batch.get("neighbor_idx"), float(self.config.MARGIN),
+                                 profile=profile)
+        return out["loss"]
+
+    def train_model(self, train_loader, optimizer, num_epochs=10) -> Dict[str, torch.Tensor]:
+        """Train Product2Vec model and generate embeddings for all products
+        (product2vec.py:113-170).  Index batches take the fused HIP step; dense reference
+        batches take the autograd path.  The loss stays on the device; it is read back once
+        per epoch for the log line (the reference syncs every step, :162)."""
+        device = self.config.DEVICE
+        logger = logging.getLogger(__name__)
+        self.to(device)
+        bpg = train_loader.dataset.bpg
+        table = None
+        for epoch in range(num_epochs):
+            self.train()
+            total = None
+            num_batches = 0
+            for batch in train_loader:
+                batch = {k: v.to(device) if isinstance(v, torch.Tensor) else v for k, v in batch.items()}
+                if "anchor_idx" in batch:
+                    if table is None:
+                        table = bpg.cuda(device)["features"]
+                    loss = self.train_step_indexed(table, batch)       # zero_grad + backward, fused
+                    optimizer.step()
+                else:
+                    loss = self.dense_loss(batch)
+                    optimizer.zero_grad()
+                    loss.backward()
+                    optimizer.step()
+                    loss = loss.detach().reshape(1)
+                total = loss.clone() if total is None else total + loss
+                num_batches += 1
+            if num_batches:
+                logger.info(f"Epoch {epoch + 1}/{num_epochs}, Loss: {float(total) / num_batches:.4f}")
+        self.eval()
+        return self.generate_all_embeddings(bpg)
+
+    def dense_loss(self, batch):
+        """product2vec.py:132-154 on a dense reference batch (anchor/positive/negative[/anchor_neighbors])."""
+        anchor_emb = self(batch["anchor"], batch.get("anchor_neighbors"))
+        positive_emb = self(batch["positive"])
+        negative_emb = self(batch["negative"])
+        if negative_emb.dim() == 2:
+            negative_emb = negative_emb.unsqueeze(1)
+        return _TripletLossFunction.apply(anchor_emb.contiguous(), positive_emb.contiguous(),
+                                          negative_emb.contiguous(), float(self.config.MARGIN))
