@@ -154,7 +154,7 @@ extern "C" int pc_p2v_attention_forward(const pc_p2v_tensors* p, const float* qu
                                    2 * PC_D, B * N, 2 * PC_D, PC_D), st));
     PC_TRY(launch_gemm_nt(nt_plain(query, PC_D, p->in_proj_w, PC_D, p->in_proj_b, sv->q, PC_D, B, PC_D, PC_D), st));
     const size_t lds = (size_t)4 * PC_HEADS * N * sizeof(float);
-    hipLaunchKernelGGL(attn_core_fwd_kernel, dim3((B + 3) / 4), dim3(256), lds, st, sv->q, sv->kv, B, N, sv->ctx,
+    PC_LAUNCH(attn_core_fwd_kernel, dim3((B + 3) / 4), dim3(256), lds, st, sv->q, sv->kv, B, N, sv->ctx,
                        sv->probs);
     PC_TRY(pc_launch_status());
     return launch_gemm_nt(nt_plain(sv->ctx, PC_D, p->out_proj_w, PC_D, p->out_proj_b, out, PC_D, B, PC_D, PC_D), st);
@@ -184,7 +184,7 @@ extern "C" int pc_p2v_attention_backward(const pc_p2v_tensors* p, const pc_p2v_t
     PC_TRY(launch_gemm_tn(to, st));
 
     const size_t lds = (size_t)4 * PC_HEADS * N * sizeof(float);
-    hipLaunchKernelGGL(attn_core_bwd_kernel, dim3((B + 3) / 4), dim3(256), lds, st, w.dctx, sv->q, sv->kv, sv->probs,
+    PC_LAUNCH(attn_core_bwd_kernel, dim3((B + 3) / 4), dim3(256), lds, st, w.dctx, sv->q, sv->kv, sv->probs,
                        B, N, w.dq, w.dkv);
     PC_TRY(pc_launch_status());
 

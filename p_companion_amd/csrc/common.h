@@ -21,6 +21,14 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
         if (_r != 0) return _r;      \
     } while (0)
 
+// Kernel launch that first drops any stale (sticky) runtime error left by an unrelated earlier
+// call on this thread, so pc_launch_status() reports THIS launch only.
+#define PC_LAUNCH(...)                 \
+    do {                               \
+        (void)hipGetLastError();       \
+        hipLaunchKernelGGL(__VA_ARGS__); \
+    } while (0)
+
 static inline int pc_launch_status() {
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? 0 : (int)e;

@@ -167,7 +167,7 @@ __global__ void transpose_kernel(const float* in, int rows, int cols, float* out
 }
 
 int launch_transpose(const float* in, int rows, int cols, float* out, hipStream_t st) {
-    hipLaunchKernelGGL(transpose_kernel, dim3((cols + 31) / 32, (rows + 31) / 32), dim3(32, 8), 0, st, in, rows, cols, out);
+    PC_LAUNCH(transpose_kernel, dim3((cols + 31) / 32, (rows + 31) / 32), dim3(32, 8), 0, st, in, rows, cols, out);
     return pc_launch_status();
 }
 
@@ -249,7 +249,7 @@ extern "C" int pc_p2v_ffn_forward_train(const pc_p2v_tensors* p, const float* ta
     g1.stats = NT_STAT_SUMSQ; g1.stat_sum = w.stat_a; g1.stat_aux = w.stat_b;
     PC_TRY(launch_gemm_nt(g1, st));
 
-    hipLaunchKernelGGL(bn_finalize_fwd_kernel, dim3(1), dim3(PC_H, 4), 0, st, w.stat_a, w.stat_b, si, p->gamma,
+    PC_LAUNCH(bn_finalize_fwd_kernel, dim3(1), dim3(PC_H, 4), 0, st, w.stat_a, w.stat_b, si, p->gamma,
                        p->beta, p->running_mean, p->running_var, p->num_batches_tracked, update_running,
                        sv->bn_mean, sv->bn_invstd, sv->bn_scale, sv->bn_shift);
     PC_TRY(pc_launch_status());
@@ -272,7 +272,7 @@ extern "C" int pc_p2v_ffn_forward_eval(const pc_p2v_tensors* p, const float* tab
     FfnWs w = ffn_ws_layout(ws, rows);
     float* h0 = w.dz2;
     float* a2 = w.dz1;
-    hipLaunchKernelGGL(bn_eval_coeff_kernel, dim3(1), dim3(PC_H), 0, st, p->gamma, p->beta, p->running_mean,
+    PC_LAUNCH(bn_eval_coeff_kernel, dim3(1), dim3(PC_H), 0, st, p->gamma, p->beta, p->running_mean,
                        p->running_var, w.coef, w.coef + PC_H);
     PC_TRY(pc_launch_status());
     NtArgs g1 = nt_plain(table, PC_D, p->w0, PC_D, p->b0, h0, PC_H, rows, PC_H, PC_D, si);
@@ -327,13 +327,13 @@ static int ffn_backward_impl(const pc_p2v_tensors* p, const pc_p2v_tensors* g, c
     t3.slab_floats = w.slab_floats;
     PC_TRY(launch_gemm_tn(t3, st));
 
-    hipLaunchKernelGGL(bn_finalize_bwd_kernel, dim3(1), dim3(PC_H, 4), 0, st, w.stat_a, w.stat_b, si, g->gamma,
+    PC_LAUNCH(bn_finalize_bwd_kernel, dim3(1), dim3(PC_H, 4), 0, st, w.stat_a, w.stat_b, si, g->gamma,
                        g->beta, accumulate, w.c1, w.c2);
     PC_TRY(pc_launch_status());
 
     int blocks = (rows + 3) / 4;
     if (blocks > 4096) blocks = 4096;
-    hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(blocks), dim3(256), 0, st, w.dz1, sv->h0, rows, si, sv->bn_mean,
+    PC_LAUNCH(bn_bwd_apply_kernel, dim3(blocks), dim3(256), 0, st, w.dz1, sv->h0, rows, si, sv->bn_mean,
                        sv->bn_invstd, sv->bn_scale, w.c1, w.c2);
     PC_TRY(pc_launch_status());
 

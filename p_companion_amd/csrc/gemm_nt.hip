@@ -187,7 +187,7 @@ int launch_gemm_nt(const NtArgs& a, hipStream_t st) {
     const int ntn = (a.N + BN - 1) / BN;
     if (ntm <= 0) return PC_EINVAL;
     const int pb = pc_prof_begin(PC_KIND_GEMM_NT, 2.0 * a.M * (double)a.N * a.K, st);
-    hipLaunchKernelGGL(gemm_nt_kernel, dim3(ntm * ntn), dim3(256), 0, st, a, ntn);
+    PC_LAUNCH(gemm_nt_kernel, dim3(ntm * ntn), dim3(256), 0, st, a, ntn);
     pc_prof_end(pb, st);
     return pc_launch_status();
 }

@@ -183,12 +183,12 @@ int launch_gemm_tn(const TnArgs& a, hipStream_t st) {
     if ((size_t)nsplit * ((size_t)a.No * a.Ni + a.No) > a.slab_floats) return PC_EWORKSPACE;
     const int tiles_o = (a.No + TM - 1) / TM, tiles_i = (a.Ni + TM - 1) / TM;
     const int pb = pc_prof_begin(PC_KIND_GEMM_TN, 2.0 * a.R * (double)a.No * a.Ni, st);
-    hipLaunchKernelGGL(gemm_tn_kernel, dim3(tiles_o * tiles_i * nsplit), dim3(256), 0, st, a, tiles_i, nsplit, rps);
+    PC_LAUNCH(gemm_tn_kernel, dim3(tiles_o * tiles_i * nsplit), dim3(256), 0, st, a, tiles_i, nsplit, rps);
     pc_prof_end(pb, st);
     PC_TRY(pc_launch_status());
     const int n_w = a.No * a.Ni, n_b = a.No;
     const int threads = (n_w + (a.db ? n_b : 0)) / 4 * 8;
-    hipLaunchKernelGGL(tn_reduce_kernel, dim3((threads + 255) / 256), dim3(256), 0, st, a.slabs, nsplit, n_w, n_b,
+    PC_LAUNCH(tn_reduce_kernel, dim3((threads + 255) / 256), dim3(256), 0, st, a.slabs, nsplit, n_w, n_b,
                        a.dW, a.db, a.accumulate);
     return pc_launch_status();
 }

@@ -118,7 +118,7 @@ extern "C" int pc_topk_rows(const float* sims, int batch, int num_types, int k, 
                             void* stream) {
     if (!sims || !idx_out || batch <= 0 || num_types <= 0) return PC_EINVAL;
     if (k < 1 || k > JMAX_K || k > num_types) return PC_ESHAPE;
-    hipLaunchKernelGGL(topk_rows_kernel, dim3((batch + 3) / 4), dim3(256), 0, (hipStream_t)stream, sims, batch,
+    PC_LAUNCH(topk_rows_kernel, dim3((batch + 3) / 4), dim3(256), 0, (hipStream_t)stream, sims, batch,
                        num_types, k, idx_out, val_out);
     return pc_launch_status();
 }
@@ -156,7 +156,7 @@ __global__ __launch_bounds__(256) void hadamard_bwd_kernel(const float* dproj, c
 extern "C" int pc_hadamard_forward(const float* pi, const float* tp, int batch, int k, float* proj, void* stream) {
     if (!pi || !tp || !proj || batch <= 0 || k <= 0) return PC_EINVAL;
     const size_t total = (size_t)batch * k * (PC_D / 4);
-    hipLaunchKernelGGL(hadamard_fwd_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+    PC_LAUNCH(hadamard_fwd_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
                        pi, tp, batch, k, proj);
     return pc_launch_status();
 }
@@ -164,7 +164,7 @@ extern "C" int pc_hadamard_forward(const float* pi, const float* tp, int batch, 
 extern "C" int pc_hadamard_backward(const float* dproj, const float* pi, const float* tp, int batch, int k,
                                     float* dpi, float* dtp, void* stream) {
     if (!dproj || !pi || !tp || !dpi || !dtp || batch <= 0 || k <= 0) return PC_EINVAL;
-    hipLaunchKernelGGL(hadamard_bwd_kernel, dim3((batch + 3) / 4), dim3(256), 0, (hipStream_t)stream, dproj, pi, tp,
+    PC_LAUNCH(hadamard_bwd_kernel, dim3((batch + 3) / 4), dim3(256), 0, (hipStream_t)stream, dproj, pi, tp,
                        batch, k, dpi, dtp);
     return pc_launch_status();
 }
@@ -238,11 +238,11 @@ extern "C" int pc_joint_loss(const float* sims, const float* proj, const int32_t
         return PC_EINVAL;
     if (batch <= 0 || num_types <= 0 || k <= 0) return PC_EINVAL;
     hipStream_t st = (hipStream_t)stream;
-    hipLaunchKernelGGL(joint_loss_kernel, dim3((batch + 3) / 4), dim3(256), 0, st, sims, proj, pos_types, neg_types,
+    PC_LAUNCH(joint_loss_kernel, dim3((batch + 3) / 4), dim3(256), 0, st, sims, proj, pos_types, neg_types,
                        pos_items, neg_items, batch, num_types, k, margin, alpha, partials, partials + batch,
                        dsims_val, dproj);
     PC_TRY(pc_launch_status());
-    hipLaunchKernelGGL(joint_loss_reduce_kernel, dim3(1), dim3(256), 0, st, partials, partials + batch, batch, k,
+    PC_LAUNCH(joint_loss_reduce_kernel, dim3(1), dim3(256), 0, st, partials, partials + batch, batch, k,
                        alpha, losses);
     return pc_launch_status();
 }
@@ -283,7 +283,7 @@ __global__ void expand_type_grad_kernel(const float* dsims_val, const int32_t* p
 extern "C" int pc_expand_type_grad(const float* dsims_val, const int32_t* pos_types, const int32_t* neg_types,
                                    int batch, int num_types, float* dense, void* stream) {
     if (!dsims_val || !pos_types || !neg_types || !dense || batch <= 0 || num_types <= 0) return PC_EINVAL;
-    hipLaunchKernelGGL(expand_type_grad_kernel, dim3(batch), dim3(256), 0, (hipStream_t)stream, dsims_val, pos_types,
+    PC_LAUNCH(expand_type_grad_kernel, dim3(batch), dim3(256), 0, (hipStream_t)stream, dsims_val, pos_types,
                        neg_types, batch, num_types, dense);
     return pc_launch_status();
 }
@@ -415,7 +415,7 @@ extern "C" int pc_joint_backward(const pc_joint_tensors* p, const pc_joint_tenso
     PC_TRY(pc_scatter_add_rows(g->comp_types, topk, B * K, PC_L, w.dce, stream));
 
     // ---- type branch (two touched similarity columns per row)
-    hipLaunchKernelGGL(type_hinge_bwd_kernel, dim3((B + 3) / 4), dim3(256), 0, st, dsims_val, pos_types, neg_types,
+    PC_LAUNCH(type_hinge_bwd_kernel, dim3((B + 3) / 4), dim3(256), 0, st, dsims_val, pos_types, neg_types,
                        sv->c, p->comp_types, B, w.dc, g->comp_types);
     PC_TRY(pc_launch_status());
     TnArgs td = {};

@@ -76,10 +76,10 @@ extern "C" int pc_p2v_triplet_loss(const float* a, const float* p, const float* 
     if (k_neg < 1 || k_neg > LOSS_MAX_K) return PC_ESHAPE;
     if (da && (!dp || !dn)) return PC_EINVAL;
     hipStream_t st = (hipStream_t)stream;
-    hipLaunchKernelGGL(triplet_loss_kernel, dim3((batch + 3) / 4), dim3(256), 0, st, a, p, n, batch, k_neg, margin,
+    PC_LAUNCH(triplet_loss_kernel, dim3((batch + 3) / 4), dim3(256), 0, st, a, p, n, batch, k_neg, margin,
                        d_pos, d_neg, da, dp, dn);
     PC_TRY(pc_launch_status());
-    hipLaunchKernelGGL(hinge_mean_kernel, dim3(1), dim3(256), 0, st, d_pos, d_neg, batch, margin, loss);
+    PC_LAUNCH(hinge_mean_kernel, dim3(1), dim3(256), 0, st, d_pos, d_neg, batch, margin, loss);
     return pc_launch_status();
 }
 
@@ -130,10 +130,10 @@ extern "C" int pc_adam_step(float* param, const float* grad, float* exp_avg, flo
     if (!param || !grad || !exp_avg || !exp_avg_sq || !step_count || !scalars || n == 0) return PC_EINVAL;
     if (((uintptr_t)param | (uintptr_t)grad | (uintptr_t)exp_avg | (uintptr_t)exp_avg_sq) & 15) return PC_ESHAPE;
     hipStream_t st = (hipStream_t)stream;
-    hipLaunchKernelGGL(adam_prep_kernel, dim3(1), dim3(1), 0, st, step_count, lr, beta1, beta2, scalars);
+    PC_LAUNCH(adam_prep_kernel, dim3(1), dim3(1), 0, st, step_count, lr, beta1, beta2, scalars);
     PC_TRY(pc_launch_status());
     const size_t threads = (n + 3) / 4;
-    hipLaunchKernelGGL(adam_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, st, param, grad, exp_avg,
+    PC_LAUNCH(adam_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, st, param, grad, exp_avg,
                        exp_avg_sq, n, scalars, (float)(1.0 - beta1), (float)beta2, (float)(1.0 - beta2), (float)eps);
     return pc_launch_status();
 }
@@ -156,7 +156,7 @@ extern "C" int pc_gather_rows(const float* table, const int32_t* idx, int rows, 
     if (!table || !out || rows <= 0 || width <= 0) return PC_EINVAL;
     if (width % 4) return PC_ESHAPE;
     const size_t total = (size_t)rows * (width / 4);
-    hipLaunchKernelGGL(gather_rows_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+    PC_LAUNCH(gather_rows_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
                        table, idx, rows, width / 4, out);
     return pc_launch_status();
 }
@@ -176,7 +176,7 @@ extern "C" int pc_scatter_add_rows(float* table, const int32_t* idx, int rows, i
                                    void* stream) {
     if (!table || !idx || !src || rows <= 0 || width <= 0) return PC_EINVAL;
     const size_t total = (size_t)rows * width;
-    hipLaunchKernelGGL(scatter_add_rows_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0,
+    PC_LAUNCH(scatter_add_rows_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0,
                        (hipStream_t)stream, table, idx, rows, width, src);
     return pc_launch_status();
 }
@@ -195,7 +195,7 @@ extern "C" int pc_scatter_rows(float* out, const int32_t* idx, int rows, int wid
     if (!out || !idx || !src || rows <= 0 || width <= 0) return PC_EINVAL;
     if (width % 4) return PC_ESHAPE;
     const size_t total = (size_t)rows * (width / 4);
-    hipLaunchKernelGGL(scatter_rows_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+    PC_LAUNCH(scatter_rows_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
                        out, idx, rows, width / 4, src);
     return pc_launch_status();
 }
@@ -211,7 +211,7 @@ __global__ void act_backward_kernel(const float* dy, const float* y, size_t n, i
 extern "C" int pc_act_backward(const float* dy, const float* y, size_t n, int act, float* dx, void* stream) {
     if (!dy || !y || !dx || n == 0) return PC_EINVAL;
     if (act != 1 && act != 2) return PC_EINVAL;
-    hipLaunchKernelGGL(act_backward_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, dy,
+    PC_LAUNCH(act_backward_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, dy,
                        y, n, act, dx);
     return pc_launch_status();
 }

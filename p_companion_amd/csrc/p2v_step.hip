@@ -90,7 +90,7 @@ extern "C" int pc_p2v_train_step(const pc_p2v_tensors* p, const pc_p2v_tensors* 
     if (N > 0) { seg.nseg = 4; seg.start[0] = rA; seg.start[1] = rN; seg.start[2] = rP; seg.start[3] = rG; seg.start[4] = R; }
     else { seg.nseg = 3; seg.start[0] = rA; seg.start[1] = rP; seg.start[2] = rG; seg.start[3] = R; seg.start[4] = R; }
 
-    hipLaunchKernelGGL(concat_idx_kernel, dim3((R + 255) / 256), dim3(256), 0, st, anchor_idx, B, neighbor_idx,
+    PC_LAUNCH(concat_idx_kernel, dim3((R + 255) / 256), dim3(256), 0, st, anchor_idx, B, neighbor_idx,
                        B * N, positive_idx, B, negative_idx, B * K, w.idx_all);
     PC_TRY(pc_launch_status());
 

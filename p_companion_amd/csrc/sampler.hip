@@ -88,13 +88,13 @@ extern "C" int pc_build_similarity_batch(const int32_t* pair_ids, int batch, con
     if (batch <= 0 || n_pad < 0 || k_neg <= 0 || n_products <= k_neg + 1) return PC_EINVAL;
     if (n_pad > 0 && !neighbor_idx) return PC_EINVAL;
     hipStream_t st = (hipStream_t)stream;
-    hipLaunchKernelGGL(build_pairs_negatives_kernel, dim3((batch + 127) / 128), dim3(128), 0, st, pair_ids, batch,
+    PC_LAUNCH(build_pairs_negatives_kernel, dim3((batch + 127) / 128), dim3(128), 0, st, pair_ids, batch,
                        sim_pairs, sim_rowptr, sim_col, n_products, k_neg, seed, step, anchor_idx, positive_idx,
                        negative_idx);
     PC_TRY(pc_launch_status());
     if (n_pad > 0) {
         const int total = batch * n_pad;
-        hipLaunchKernelGGL(build_neighbors_kernel, dim3((total + 255) / 256), dim3(256), 0, st, anchor_idx, batch,
+        PC_LAUNCH(build_neighbors_kernel, dim3((total + 255) / 256), dim3(256), 0, st, anchor_idx, batch,
                            cv_rowptr, cv_col, n_pad, neighbor_idx);
         PC_TRY(pc_launch_status());
     }

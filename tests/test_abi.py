@@ -1,0 +1,67 @@
+"""The C-ABI library loads without a GPU and exports every symbol include/pcompanion_hip.h
+declares; the ctypes table covers the header.  No compute calls here."""
+import ctypes
+import os
+import re
+
+from conftest import ROOT
+
+
+def header_functions():
+    txt = open(os.path.join(ROOT, "include", "pcompanion_hip.h")).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    return sorted(set(re.findall(r"\b(pc_[a-z0-9_]+)\s*\(", txt)))
+
+
+def test_header_declares_the_path():
+    fns = header_functions()
+    for must in ("pc_p2v_ffn_forward_train", "pc_p2v_ffn_backward", "pc_p2v_attention_forward",
+                 "pc_p2v_attention_backward", "pc_p2v_triplet_loss", "pc_adam_step", "pc_p2v_train_step",
+                 "pc_build_similarity_batch", "pc_mt_negative_samples", "pc_joint_forward", "pc_joint_loss",
+                 "pc_joint_backward", "pc_joint_train_step", "pc_gather_rows", "pc_scatter_add_rows"):
+        assert must in fns
+
+
+def test_library_exports_every_declared_symbol():
+    from p_companion_amd import _lib
+    assert os.path.exists(_lib.LIB_PATH), "run python -m p_companion_amd.build (hipcc cross-compiles gfx950)"
+    L = ctypes.CDLL(_lib.LIB_PATH)
+    for name in header_functions():
+        assert hasattr(L, name), f"{name} declared in the header but not exported"
+    assert L.pc_abi_version() == 1
+
+
+def test_ctypes_table_matches_header():
+    from p_companion_amd import _lib
+    assert sorted(_lib.SIGNATURES) == header_functions()
+    _lib.lib()          # binds every signature; raises on a missing symbol
+
+
+def test_missing_library_fails_loudly(monkeypatch, tmp_path):
+    from p_companion_amd import _lib
+    monkeypatch.setattr(_lib, "_lib", None)
+    monkeypatch.setattr(_lib, "LIB_PATH", str(tmp_path / "nope.so"))
+    import pytest
+    with pytest.raises(_lib.HipKernelError):
+        _lib.lib()
+
+
+def test_ops_refuse_cpu_tensors():
+    """No CPU fallback: CPU tensors are rejected before any kernel is touched."""
+    import pytest
+    import torch
+    from p_companion_amd import ops
+    with pytest.raises(TypeError):
+        ops.linear_forward(torch.zeros(4, 128), torch.zeros(8, 128))
+    with pytest.raises(TypeError):
+        ops.gather_rows(torch.zeros(4, 128), torch.zeros(2, dtype=torch.int32))
+
+
+def test_product_never_imports_oracle():
+    pkg = os.path.join(ROOT, "p_companion_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".cpp", ".h")):
+                src = open(os.path.join(dirpath, f)).read()
+                assert not re.search(r"^\s*(from|import)\s+oracle\b", src, flags=re.M), f
+                assert "oracle/" not in src, f

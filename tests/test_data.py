@@ -1,0 +1,59 @@
+"""Integer BPG, scalable generator, loaders' host logic.  CPU only."""
+import numpy as np
+
+from oracle import data_oracle
+from p_companion_amd.data import ComplementaryIndexDataset, IntBPG, generate_scaled_bpg
+
+
+def test_intbpg_from_reference_graph(golden):
+    z = golden("g2_bpg1000.npz")
+    bpg = IntBPG.from_arrays(z)
+    assert bpg.num_products == 1000 and bpg.n_types == 20
+    for pid in (0, 17, 500, 999):
+        assert np.array_equal(bpg.get_neighbors(pid), data_oracle.neighbors(z["cv_rowptr"], z["cv_col"], pid))
+    # positives CSR == {pair[1] for pair in similar_pairs if pair[0] == anchor} (data_loader.py:31)
+    sp = z["similarity_pairs"]
+    for a in np.unique(sp[:50, 0]):
+        assert set(bpg.sim_col[bpg.sim_rowptr[a]:bpg.sim_rowptr[a + 1]].tolist()) == set(sp[sp[:, 0] == a, 1].tolist())
+    # every similarity anchor has a co-view out-neighbour (synthetic_data.py:110-119)
+    assert bpg.degree(sp[:, 0]).min() >= 1
+
+
+def test_scaled_generator_distributions():
+    g = generate_scaled_bpg(20000, 100, seed=0)
+    deg = np.diff(g.cv_rowptr)
+    assert 14.5 < deg.mean() < 16.5 and deg.max() <= 32                      # mean 16, cap 32
+    assert 2.3 < len(g.similarity_pairs) / 20000 < 3.3                       # reference cfg1: 2.95 per product
+    assert 3.5 < len(g.complementary_pairs) / 20000 < 5.0                    # reference cfg1: 4.52
+    assert g.degree(g.similarity_pairs[:, 0]).min() >= 1
+    # feature recipe: +1.0 on the category block (synthetic_data.py:50-52)
+    for c in range(5):
+        rows = g.features[g.category == c]
+        assert abs(rows[:, 20 * c:20 * c + 20].mean() - 1.0) < 0.05
+        other = np.delete(rows, np.s_[20 * c:20 * c + 20], axis=1)
+        assert abs(other.mean()) < 0.05
+    assert g.type_idx.max() == 99 and np.array_equal(g.category, g.type_idx // 20)
+    # same-category co-views are 1.5x as likely as cross-category ones
+    src = np.repeat(np.arange(20000), deg)
+    same = (g.category[src] == g.category[g.cv_col]).mean()
+    assert abs(same - (0.2 * 1.5) / (0.2 * 1.5 + 0.8)) < 0.02
+    # no self loops / duplicate edges; complementary pairs are not co-viewed
+    key = src.astype(np.int64) * 20000 + g.cv_col
+    assert len(np.unique(key)) == len(key) and (src != g.cv_col).all()
+    ck = g.complementary_pairs[:, 0].astype(np.int64) * 20000 + g.complementary_pairs[:, 1]
+    assert not np.isin(ck, key).any()
+    g2 = generate_scaled_bpg(20000, 100, seed=0)
+    assert np.array_equal(g.cv_col, g2.cv_col) and np.array_equal(g.features, g2.features)   # seeded
+
+
+def test_complementary_dataset_split_and_labels(golden):
+    bpg = IntBPG.from_arrays(golden("g2_bpg1000.npz"))
+    tr, va, te = (ComplementaryIndexDataset(bpg, m, seed=0) for m in ("train", "val", "test"))
+    n = len(bpg.complementary_pairs) + len(bpg.similarity_pairs)
+    assert (len(tr), len(va)) == (int(0.8 * n), int(0.9 * n) - int(0.8 * n)) and len(tr) + len(va) + len(te) >= n - 1
+    assert set(np.unique(tr.pairs[:, 2]).tolist()) == {-1, 1}
+    for q, t, lab in tr.pairs[:20]:
+        want = data_oracle.complementary_sample_ints(q, t, lab, bpg.type_idx, bpg.n_types)
+        tt = int(bpg.type_idx[t])
+        assert want["positive_types"] == (tt if lab == 1 else 0)
+        assert want["negative_types"] == (tt if lab == -1 else (tt + 1) % bpg.n_types)
