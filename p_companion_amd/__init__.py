@@ -5,6 +5,8 @@ Everything numerical runs in hand-written HIP kernels (csrc/, libpcompanion_hip.
 C ABI in include/pcompanion_hip.h).  There is no CPU fallback: constructing the modules
 on a machine without the built library or without a GPU raises.
 """
+import torch  # noqa: F401  (first: see _lib.lib on the single-HIP-runtime rule)
+
 from . import _lib  # noqa: F401
 from ._lib import HipKernelError  # noqa: F401
 

@@ -115,6 +115,9 @@ def lib():
             raise HipKernelError(
                 f"{LIB_PATH} not found: build it with `python -m p_companion_amd.build` "
                 "(hipcc --offload-arch=gfx950).  There is no CPU fallback.")
+        # torch ships its own libamdhip64: it must be resident BEFORE this library is mapped so
+        # that both resolve to ONE HIP runtime (two runtimes => hipErrorNoDevice on torch's streams)
+        import torch  # noqa: F401
         L = ctypes.CDLL(LIB_PATH)
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(L, name)          # AttributeError = symbol missing: fail loudly
