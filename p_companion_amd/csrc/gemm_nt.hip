@@ -1,193 +1,307 @@
 // C[M,N] = prologue(A)[M,K] . W[N,K]^T (+bias) -> epilogue, exact fp32 on the matrix cores.
 //
-// One kernel serves every "activation x weight^T" product of the two hot paths
+// One kernel family serves every "activation x weight^T" product of the two hot paths
 // (nn.Linear forward, and dX = dY . W through a pre-transposed W): product2vec.py:14-21
 // (ffn), nn.MultiheadAttention's in/out projections (:23-28), type_transition.py:11-12,
 // item_prediction.py:11-20, p_companion.py:60-63 (similarities).
 //
-// gfx950 mapping: 128x128 output tile per 256-thread workgroup (4 waves, each 64x64 =
-// 2x2 v_mfma_f32_32x32x2_f32 accumulators, 64 VGPRs), K stepped by 32 through a
-// double-buffered LDS image (row stride 36 floats => ds_read_b128 of 16 distinct rows hits
-// 16 distinct 16-B slots: conflict-free).  Rows of A may be gathered by index straight from
-// the feature table (the BPG neighbour gather), tiles never straddle a BatchNorm segment,
-// and the epilogue can emit the per-tile column statistics BatchNorm needs, so the FFN's
-// first Linear, the row gather and the BN reduction are one pass over HBM.
+// These are SKINNY products: M = hundreds of thousands of rows, N,K <= 256.  At the fp32
+// MFMA rate they sit within 2x of the HBM roofline, so the kernel is built around the row
+// stream, not around K:
+//   * a workgroup owns 128 rows x the FULL N (up to 256 columns: 8 waves as 2 x 4, each 64x64
+//     = 2x2 v_mfma_f32_32x32x2_f32 accumulators) so A is read from HBM exactly once;
+//   * workgroups are PERSISTENT over row tiles and the K-chunk prefetch runs across tile
+//     boundaries (the first chunk of the next tile -- including its gather indices -- is in
+//     flight during the last chunk of this one), so short K (4-8 chunks) behaves like one
+//     long pipelined loop;
+//   * rows of A may be gathered by index straight from the feature table (BPG neighbour
+//     gather, -1 = zero row), tiles never straddle a BatchNorm segment, A can be transformed on
+//     load (BN-apply + tanh) and the epilogue can emit per-tile BatchNorm partial sums;
+//   * the epilogue goes through LDS so that C (and the aux operand of the d-activation
+//     epilogues) move as 16-B per lane, 8 full 128-B row segments per wave-instruction.
+// LDS image: [row][36 floats] (stride 144 B => ds_read_b128 of 16 distinct rows hits 16
+// distinct 16-B slots), double-buffered; operands are fetched with a permuted k order (lanes
+// 0-31 take k = 8j..8j+3, lanes 32-63 k = 8j+4..8j+7, identically for A and W) so one b128
+// read feeds four MFMAs.
 #include "common.h"
+#include <stdlib.h>
 
 #define BM 128
-#define BN 128
 #define BK 32
 #define LDS_LD 36
 
 int gemm_nt_tiles(const SegInfo& si) { return si.tile0[PC_MAX_SEG]; }
 
-__global__ __launch_bounds__(256, 2) void gemm_nt_kernel(NtArgs a, int ntn) {
-    __shared__ __attribute__((aligned(16))) float smem[2][2][BM * LDS_LD];
+template <int NWN>   // wave columns: BN = 64*NWN columns, 128*NWN threads
+__global__ __launch_bounds__(128 * NWN, 2) void gemm_nt_kernel(NtArgs a, int ntn, int total_tiles, int dbg) {
+    constexpr int THREADS = 128 * NWN;
+    constexpr int BN = 64 * NWN;
+    constexpr int APT = 1024 / THREADS;          // float4 of A per thread per chunk (2 or 4), one row
+    constexpr int TPR_A = 8 / APT;               // threads per A row
+    constexpr int BUF = (BM + BN) * LDS_LD;      // floats per stage: A image then W image
+    __shared__ __attribute__((aligned(16))) float smem[2 * BUF];
 
-    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, wm = w >> 1, wn = w & 1;
-    const int tile_n = blockIdx.x % ntn, tile_m = blockIdx.x / ntn;
-    const int seg = seg_of_tile(a.seg, tile_m);
-    const int row0 = a.seg.start[seg] + (tile_m - a.seg.tile0[seg]) * BM;
-    const int row_end = a.seg.start[seg + 1];
-    const int n0 = tile_n * BN;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, wm = w & 1, wn = w >> 1;
+    const int la_row = tid / TPR_A, la_c = (tid % TPR_A) * APT * 4;       // loader: A row / first float
+    const int lw_row = tid >> 1, lw_c = (tid & 1) * 16;                   // loader: W row / first float
+    const int nk = (a.K + BK - 1) / BK;
+    const bool pro = a.prologue == NT_PRO_BNTANH;
 
-    // ---- loader mapping: 8 threads cover one 128-B row chunk, 32 rows per pass, 4 passes
-    const int lr = tid >> 3, lc = (tid & 7) * 4;
-    const float* arow[4];
-    const float* wrow[4];
-    bool av[4], wv[4];
-#pragma unroll
-    for (int p = 0; p < 4; p++) {
-        int r = row0 + lr + 32 * p;
-        bool v = r < row_end;
-        int src = r;
-        if (v && a.gather) { src = a.gather[r]; v = src >= 0; }
-        av[p] = v;
-        arow[p] = a.A + (size_t)(v ? src : 0) * a.lda + lc;
-        int n = n0 + lr + 32 * p;
-        wv[p] = n < a.N;
-        wrow[p] = a.W + (size_t)(wv[p] ? n : 0) * a.ldw + lc;
-    }
-    const float* ps = a.prologue == NT_PRO_BNTANH ? a.pscale + (size_t)seg * a.K + lc : nullptr;
-    const float* psh = a.prologue == NT_PRO_BNTANH ? a.pshift + (size_t)seg * a.K + lc : nullptr;
+    // ---- per-tile state ------------------------------------------------------------------
+    int tile = blockIdx.x;
+    int row0 = 0, row_end = 0, n0 = 0, seg = 0;
+    const float* aptr = a.A;  bool aval = false;
+    const float* wptr = a.W;  bool wval = false;
+    auto tile_geom = [&](int t, int& r0, int& rend, int& nn0, int& sg) {
+        const int tm = t / ntn, tn = t % ntn;
+        sg = seg_of_tile(a.seg, tm);
+        r0 = a.seg.start[sg] + (tm - a.seg.tile0[sg]) * BM;
+        rend = a.seg.start[sg + 1];
+        nn0 = tn * BN;
+    };
+    // source row of this thread's A row: -1 = zero row (padding slot or past the segment end)
+    auto a_source = [&](int r0, int rend) -> int {
+        const int r = r0 + la_row;
+        if (r >= rend) return -1;
+        return a.gather ? a.gather[r] : r;
+    };
+    auto make_ptrs = [&](int src, int nn0, const float*& ap, bool& av, const float*& wp, bool& wv) {
+        av = src >= 0;
+        ap = a.A + (size_t)(av ? src : 0) * a.lda + la_c;
+        const int n = nn0 + lw_row;
+        wv = n < a.N;
+        wp = a.W + (size_t)(wv ? n : 0) * a.ldw + lw_c;
+    };
 
-    float4 ra[4], rw[4];
-    auto gload = [&](int k0) {
-        const bool kv = k0 + lc < a.K;       // K need only be a multiple of 4: the tail chunk is zero-filled
+    float4 ra[APT], rw[4];
+    auto gload = [&](int k0, const float* ap, bool av, const float* wp, bool wv, int sg) {
 #pragma unroll
-        for (int p = 0; p < 4; p++) {
-            ra[p] = (av[p] && kv) ? *reinterpret_cast<const float4*>(arow[p] + k0) : make_float4(0.f, 0.f, 0.f, 0.f);
-            rw[p] = (wv[p] && kv) ? *reinterpret_cast<const float4*>(wrow[p] + k0) : make_float4(0.f, 0.f, 0.f, 0.f);
-        }
-        if (ps && kv) {
-            float4 s = *reinterpret_cast<const float4*>(ps + k0);
-            float4 h = *reinterpret_cast<const float4*>(psh + k0);
-#pragma unroll
-            for (int p = 0; p < 4; p++) {
-                ra[p].x = fast_tanh(ra[p].x * s.x + h.x);
-                ra[p].y = fast_tanh(ra[p].y * s.y + h.y);
-                ra[p].z = fast_tanh(ra[p].z * s.z + h.z);
-                ra[p].w = fast_tanh(ra[p].w * s.w + h.w);
+        for (int j = 0; j < APT; j++) {
+            const bool kv = k0 + la_c + 4 * j < a.K;     // K is a multiple of 4: a tail chunk is zero-filled
+            ra[j] = (av && kv) ? *reinterpret_cast<const float4*>(ap + k0 + 4 * j) : make_float4(0.f, 0.f, 0.f, 0.f);
+            if (pro && kv) {
+                const float4 s = *reinterpret_cast<const float4*>(a.pscale + (size_t)sg * a.K + k0 + la_c + 4 * j);
+                const float4 h = *reinterpret_cast<const float4*>(a.pshift + (size_t)sg * a.K + k0 + la_c + 4 * j);
+                ra[j].x = fast_tanh(ra[j].x * s.x + h.x);
+                ra[j].y = fast_tanh(ra[j].y * s.y + h.y);
+                ra[j].z = fast_tanh(ra[j].z * s.z + h.z);
+                ra[j].w = fast_tanh(ra[j].w * s.w + h.w);
             }
+        }
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const bool kv = k0 + lw_c + 4 * j < a.K;
+            rw[j] = (wv && kv) ? *reinterpret_cast<const float4*>(wp + k0 + 4 * j) : make_float4(0.f, 0.f, 0.f, 0.f);
         }
     };
     auto lstore = [&](int buf) {
+        float* As = smem + buf * BUF;
+        float* Ws = As + BM * LDS_LD;
 #pragma unroll
-        for (int p = 0; p < 4; p++) {
-            *reinterpret_cast<float4*>(&smem[buf][0][(lr + 32 * p) * LDS_LD + lc]) = ra[p];
-            *reinterpret_cast<float4*>(&smem[buf][1][(lr + 32 * p) * LDS_LD + lc]) = rw[p];
-        }
+        for (int j = 0; j < APT; j++) *reinterpret_cast<float4*>(&As[la_row * LDS_LD + la_c + 4 * j]) = ra[j];
+#pragma unroll
+        for (int j = 0; j < 4; j++) *reinterpret_cast<float4*>(&Ws[lw_row * LDS_LD + lw_c + 4 * j]) = rw[j];
     };
 
     f32x16 acc[2][2];
+    auto zero_acc = [&]() {
 #pragma unroll
-    for (int i = 0; i < 2; i++)
+        for (int i = 0; i < 2; i++)
 #pragma unroll
-        for (int j = 0; j < 2; j++)
+            for (int j = 0; j < 2; j++)
 #pragma unroll
-            for (int r = 0; r < 16; r++) acc[i][j][r] = 0.f;
+                for (int r = 0; r < 16; r++) acc[i][j][r] = 0.f;
+    };
 
-    const int nk = (a.K + BK - 1) / BK;
-    gload(0);
+    if (tile >= total_tiles) return;
+    if ((dbg & 16) && (blockIdx.x & 256)) { __builtin_amdgcn_s_sleep(100); }   // probe: phase-shift half of the blocks
+    tile_geom(tile, row0, row_end, n0, seg);
+    make_ptrs(a_source(row0, row_end), n0, aptr, aval, wptr, wval);
+    gload(0, aptr, aval, wptr, wval, seg);
     lstore(0);
     __syncthreads();
+    zero_acc();
+    int cur = 0;
     const int frag = (lane & 31) * LDS_LD + 4 * (lane >> 5);
-    for (int kt = 0; kt < nk; kt++) {
-        const int cur = kt & 1;
-        if (kt + 1 < nk) gload((kt + 1) * BK);
-        const float* As = &smem[cur][0][wm * 64 * LDS_LD + frag];
-        const float* Ws = &smem[cur][1][wn * 64 * LDS_LD + frag];
-#pragma unroll
-        for (int kk = 0; kk < 4; kk++) {
-            // lanes 0-31 hold k = 8kk+0..3, lanes 32-63 hold k = 8kk+4..7 (same for A and W)
-            float4 a0 = *reinterpret_cast<const float4*>(As + kk * 8);
-            float4 a1 = *reinterpret_cast<const float4*>(As + 32 * LDS_LD + kk * 8);
-            float4 b0 = *reinterpret_cast<const float4*>(Ws + kk * 8);
-            float4 b1 = *reinterpret_cast<const float4*>(Ws + 32 * LDS_LD + kk * 8);
-            const float av0[4] = {a0.x, a0.y, a0.z, a0.w}, av1[4] = {a1.x, a1.y, a1.z, a1.w};
-            const float bv0[4] = {b0.x, b0.y, b0.z, b0.w}, bv1[4] = {b1.x, b1.y, b1.z, b1.w};
-#pragma unroll
-            for (int r = 0; r < 4; r++) {
-                acc[0][0] = mfma32(av0[r], bv0[r], acc[0][0]);
-                acc[0][1] = mfma32(av0[r], bv1[r], acc[0][1]);
-                acc[1][0] = mfma32(av1[r], bv0[r], acc[1][0]);
-                acc[1][1] = mfma32(av1[r], bv1[r], acc[1][1]);
-            }
-        }
-        if (kt + 1 < nk) lstore(cur ^ 1);
-        __syncthreads();
-    }
 
-    // ---- epilogue.  acc[mt][nt][reg]: row = (reg&3) + 8*(reg>>2) + 4*(lane>>5), col = lane&31
-    float s1[2] = {0.f, 0.f}, s2[2] = {0.f, 0.f};
-#pragma unroll
-    for (int nt = 0; nt < 2; nt++) {
-        const int col = n0 + wn * 64 + nt * 32 + (lane & 31);
-        const bool cv = col < a.N;
-        const float bias = (cv && a.bias) ? a.bias[col] : 0.f;
-        float es = 0.f, eh = 0.f, mu = 0.f, is = 0.f;
-        if (cv && a.epilogue == NT_EPI_DTANH_BN) {
-            es = a.escale[(size_t)seg * a.N + col];
-            eh = a.eshift[(size_t)seg * a.N + col];
+    while (true) {
+        // next tile's identity (prefetched during the last chunk of this one)
+        const int ntile = tile + gridDim.x;
+        int nrow0 = 0, nrow_end = 0, nn0 = 0, nseg = 0;
+        const float* naptr = a.A; bool naval = false;
+        const float* nwptr = a.W; bool nwval = false;
+        int nsrc = -1;                                        // gather index of the next tile: issued a tile early
+        if (ntile < total_tiles) {
+            tile_geom(ntile, nrow0, nrow_end, nn0, nseg);
+            nsrc = a_source(nrow0, nrow_end);
         }
-        if (cv && a.stats == NT_STAT_BNBWD) {
-            mu = a.mean[(size_t)seg * a.N + col];
-            is = a.invstd[(size_t)seg * a.N + col];
-        }
+
+        for (int kt = 0; kt < nk; kt++) {
+            bool loaded = false;
+            if (dbg & 2) { loaded = true; }
+            else if (kt + 1 < nk) { gload((kt + 1) * BK, aptr, aval, wptr, wval, seg); loaded = true; }
+            else if (ntile < total_tiles) {
+                make_ptrs(nsrc, nn0, naptr, naval, nwptr, nwval);
+                gload(0, naptr, naval, nwptr, nwval, nseg);
+                loaded = true;
+            }
+            const float* As = smem + cur * BUF + wm * 64 * LDS_LD + frag;
+            const float* Ws = smem + cur * BUF + (BM + wn * 64) * LDS_LD + frag;
 #pragma unroll
-        for (int mt = 0; mt < 2; mt++) {
+            for (int kk = 0; kk < 4; kk++) {
+                const float4 a0 = *reinterpret_cast<const float4*>(As + kk * 8);
+                const float4 a1 = *reinterpret_cast<const float4*>(As + 32 * LDS_LD + kk * 8);
+                const float4 b0 = *reinterpret_cast<const float4*>(Ws + kk * 8);
+                const float4 b1 = *reinterpret_cast<const float4*>(Ws + 32 * LDS_LD + kk * 8);
+                const float av0[4] = {a0.x, a0.y, a0.z, a0.w}, av1[4] = {a1.x, a1.y, a1.z, a1.w};
+                const float bv0[4] = {b0.x, b0.y, b0.z, b0.w}, bv1[4] = {b1.x, b1.y, b1.z, b1.w};
 #pragma unroll
-            for (int reg = 0; reg < 16; reg++) {
-                const int row = row0 + wm * 64 + mt * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5);
-                const bool ok = cv && row < row_end;
-                float v = acc[mt][nt][reg] + bias;
-                float ax = 0.f;
-                if (ok && a.aux) ax = a.aux[(size_t)row * a.ldaux + col];
-                switch (a.epilogue) {
-                    case NT_EPI_TANH: v = fast_tanh(v); break;
-                    case NT_EPI_RELU: v = v > 0.f ? v : 0.f; break;
-                    case NT_EPI_DTANH: v = v * (1.f - ax * ax); break;
-                    case NT_EPI_DTANH_BN: { float s = fast_tanh(ax * es + eh); v = v * (1.f - s * s); break; }
-                    case NT_EPI_DRELU: v = ax > 0.f ? v : 0.f; break;
-                    default: break;
-                }
-                if (ok) {
-                    a.C[(size_t)row * a.ldc + col] = v;
-                    if (a.stats == NT_STAT_SUMSQ) { s1[nt] += v; s2[nt] += v * v; }
-                    else if (a.stats == NT_STAT_BNBWD) { s1[nt] += v; s2[nt] += v * ((ax - mu) * is); }
+                for (int r = 0; r < 4; r++) {
+                    acc[0][0] = mfma32(av0[r], bv0[r], acc[0][0]);
+                    acc[0][1] = mfma32(av0[r], bv1[r], acc[0][1]);
+                    acc[1][0] = mfma32(av1[r], bv0[r], acc[1][0]);
+                    acc[1][1] = mfma32(av1[r], bv1[r], acc[1][1]);
                 }
             }
+            if (loaded && !(dbg & 4)) lstore(cur ^ 1);
+            if (!(dbg & 8)) __syncthreads();
+            cur ^= 1;
         }
-    }
-    if (a.stats != NT_STAT_NONE) {
-        // lanes l and l^32 hold the same column; then fold the two M-waves through LDS
-        float* red = &smem[0][0][0];   // [2 stats][2 wm][128 cols]; all MFMA reads are done (barrier above)
+
+        // ---- epilogue of `tile`.  Stage `cur` now holds the next tile's first chunk; the other
+        // stage is free: each wave transposes its 32x32 sub-tiles through a private 32x36 patch.
+        if (dbg & 1) { if (ntile >= total_tiles) break; zero_acc(); tile = ntile; row0 = nrow0; row_end = nrow_end; n0 = nn0; seg = nseg; aptr = naptr; aval = naval; wptr = nwptr; wval = nwval; continue; }
+        float* free_stage = smem + (cur ^ 1) * BUF;
+        float* stg = free_stage + w * (32 * LDS_LD);
+        const int er = lane >> 3, ec = (lane & 7) * 4;          // staged read: rows er+8i, cols ec..ec+3
+        const bool vec = ((a.N | a.ldc) & 3) == 0 && (!a.aux || (a.ldaux & 3) == 0);
+        float cs1[2][4], cs2[2][4];
+#pragma unroll
+        for (int nt = 0; nt < 2; nt++)
+#pragma unroll
+            for (int q = 0; q < 4; q++) { cs1[nt][q] = 0.f; cs2[nt][q] = 0.f; }
 #pragma unroll
         for (int nt = 0; nt < 2; nt++) {
-            s1[nt] += __shfl_xor(s1[nt], 32, 64);
-            s2[nt] += __shfl_xor(s2[nt], 32, 64);
-            if (lane < 32) {
-                red[(0 * 2 + wm) * BN + wn * 64 + nt * 32 + lane] = s1[nt];
-                red[(1 * 2 + wm) * BN + wn * 64 + nt * 32 + lane] = s2[nt];
+            const int col = n0 + wn * 64 + nt * 32 + ec;
+            float bias[4], es[4], eh[4], mu[4], is[4];
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                const bool cv = col + q < a.N;
+                bias[q] = (cv && a.bias) ? a.bias[col + q] : 0.f;
+                es[q] = eh[q] = mu[q] = is[q] = 0.f;
+                if (cv && a.epilogue == NT_EPI_DTANH_BN) {
+                    es[q] = a.escale[(size_t)seg * a.N + col + q];
+                    eh[q] = a.eshift[(size_t)seg * a.N + col + q];
+                }
+                if (cv && a.stats == NT_STAT_BNBWD) {
+                    mu[q] = a.mean[(size_t)seg * a.N + col + q];
+                    is[q] = a.invstd[(size_t)seg * a.N + col + q];
+                }
+            }
+#pragma unroll
+            for (int mt = 0; mt < 2; mt++) {
+#pragma unroll
+                for (int reg = 0; reg < 16; reg++)
+                    stg[((reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)) * LDS_LD + (lane & 31)] = acc[mt][nt][reg];
+                __builtin_amdgcn_wave_barrier();
+#pragma unroll
+                for (int i = 0; i < 4; i++) {
+                    const int row = row0 + wm * 64 + mt * 32 + er + 8 * i;
+                    const float4 v4 = *reinterpret_cast<const float4*>(&stg[(er + 8 * i) * LDS_LD + ec]);
+                    float v[4] = {v4.x, v4.y, v4.z, v4.w};
+                    float ax[4] = {0.f, 0.f, 0.f, 0.f};
+                    const bool rok = row < row_end;
+                    if (rok && a.aux) {
+                        if (vec && col + 3 < a.N) {
+                            const float4 x4 = *reinterpret_cast<const float4*>(a.aux + (size_t)row * a.ldaux + col);
+                            ax[0] = x4.x; ax[1] = x4.y; ax[2] = x4.z; ax[3] = x4.w;
+                        } else {
+#pragma unroll
+                            for (int q = 0; q < 4; q++)
+                                if (col + q < a.N) ax[q] = a.aux[(size_t)row * a.ldaux + col + q];
+                        }
+                    }
+#pragma unroll
+                    for (int q = 0; q < 4; q++) {
+                        float x = v[q] + bias[q];
+                        switch (a.epilogue) {
+                            case NT_EPI_TANH: x = fast_tanh(x); break;
+                            case NT_EPI_RELU: x = x > 0.f ? x : 0.f; break;
+                            case NT_EPI_DTANH: x = x * (1.f - ax[q] * ax[q]); break;
+                            case NT_EPI_DTANH_BN: { const float s = fast_tanh(ax[q] * es[q] + eh[q]); x = x * (1.f - s * s); break; }
+                            case NT_EPI_DRELU: x = ax[q] > 0.f ? x : 0.f; break;
+                            default: break;
+                        }
+                        v[q] = x;
+                        if (rok && col + q < a.N) {
+                            if (a.stats == NT_STAT_SUMSQ) { cs1[nt][q] += x; cs2[nt][q] += x * x; }
+                            else if (a.stats == NT_STAT_BNBWD) { cs1[nt][q] += x; cs2[nt][q] += x * ((ax[q] - mu[q]) * is[q]); }
+                        }
+                    }
+                    if (rok) {
+                        if (vec && col + 3 < a.N) {
+                            *reinterpret_cast<float4*>(a.C + (size_t)row * a.ldc + col) = make_float4(v[0], v[1], v[2], v[3]);
+                        } else {
+#pragma unroll
+                            for (int q = 0; q < 4; q++)
+                                if (col + q < a.N) a.C[(size_t)row * a.ldc + col + q] = v[q];
+                        }
+                    }
+                }
+                __builtin_amdgcn_wave_barrier();
             }
         }
-        __syncthreads();
-        if (tid < BN && n0 + tid < a.N) {
-            a.stat_sum[(size_t)tile_m * a.N + n0 + tid] = red[0 * BN + tid] + red[1 * BN + tid];
-            a.stat_aux[(size_t)tile_m * a.N + n0 + tid] = red[2 * BN + tid] + red[3 * BN + tid];
+        if (a.stats != NT_STAT_NONE) {
+            // fold the 8 row groups of a wave (lane>>3), then the two M-waves through LDS
+            __syncthreads();                                   // every wave is done with its staging patch
+            float* red = free_stage;                           // [2 stats][2 wm][BN]
+#pragma unroll
+            for (int nt = 0; nt < 2; nt++)
+#pragma unroll
+                for (int q = 0; q < 4; q++) {
+                    float s1 = cs1[nt][q], s2 = cs2[nt][q];
+#pragma unroll
+                    for (int o = 8; o <= 32; o <<= 1) { s1 += __shfl_xor(s1, o, 64); s2 += __shfl_xor(s2, o, 64); }
+                    if (lane < 8) {
+                        const int c = wn * 64 + nt * 32 + lane * 4 + q;
+                        red[(0 * 2 + wm) * BN + c] = s1;
+                        red[(1 * 2 + wm) * BN + c] = s2;
+                    }
+                }
+            __syncthreads();
+            const int tile_m = tile / ntn;
+            for (int c = tid; c < BN; c += THREADS)
+                if (n0 + c < a.N) {
+                    a.stat_sum[(size_t)tile_m * a.N + n0 + c] = red[0 * BN + c] + red[1 * BN + c];
+                    a.stat_aux[(size_t)tile_m * a.N + n0 + c] = red[2 * BN + c] + red[3 * BN + c];
+                }
         }
+        if (ntile >= total_tiles) break;
+        __syncthreads();                                       // free stage is written again by the next lstore
+        zero_acc();
+        tile = ntile; row0 = nrow0; row_end = nrow_end; n0 = nn0; seg = nseg;
+        aptr = naptr; aval = naval; wptr = nwptr; wval = nwval;
     }
 }
 
 int launch_gemm_nt(const NtArgs& a, hipStream_t st) {
     if (!a.A || !a.W || !a.C || a.M <= 0 || a.N <= 0 || a.K <= 0) return PC_EINVAL;
     if (a.K % 4 != 0 || a.lda % 4 != 0 || a.ldw % 4 != 0) return PC_ESHAPE;
-    if (((uintptr_t)a.A | (uintptr_t)a.W) & 15) return PC_ESHAPE;
+    if (((uintptr_t)a.A | (uintptr_t)a.W | (uintptr_t)a.C) & 15) return PC_ESHAPE;
+    if (a.aux && ((uintptr_t)a.aux & 15)) return PC_ESHAPE;
     const int ntm = gemm_nt_tiles(a.seg);
-    const int ntn = (a.N + BN - 1) / BN;
     if (ntm <= 0) return PC_EINVAL;
+    static const int dbg = getenv("PC_NT_DBG") ? atoi(getenv("PC_NT_DBG")) : 0;   // developer probe only
     const int pb = pc_prof_begin(PC_KIND_GEMM_NT, 2.0 * a.M * (double)a.N * a.K, st);
-    PC_LAUNCH(gemm_nt_kernel, dim3(ntm * ntn), dim3(256), 0, st, a, ntn);
+    if (a.N > 128) {
+        const int ntn = (a.N + 255) / 256, total = ntm * ntn;
+        const int grid = total < 256 ? total : 256;            // one 8-wave workgroup per CU
+        PC_LAUNCH(gemm_nt_kernel<4>, dim3(grid), dim3(512), 0, st, a, ntn, total, dbg);
+    } else {
+        const int ntn = 1, total = ntm;
+        const int grid = total < 512 ? total : 512;            // two 4-wave workgroups per CU
+        PC_LAUNCH(gemm_nt_kernel<2>, dim3(grid), dim3(256), 0, st, a, ntn, total, dbg);
+    }
     pc_prof_end(pb, st);
     return pc_launch_status();
 }
