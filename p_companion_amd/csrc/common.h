@@ -87,8 +87,10 @@ __device__ __forceinline__ int seg_of_tile(const SegInfo& si, int t) {
 // tanh via one v_exp_f32 and one v_rcp_f32: tanh(x) = 1 - 2/(e^{2x}+1).
 // |abs err| < 2e-7 over the real line (saturates cleanly: e^{2x}=inf -> 1, 0 -> -1).
 __device__ __forceinline__ float fast_tanh(float x) {
-    float e = __expf(2.0f * x);
-    return 1.0f - 2.0f * __frcp_rn(e + 1.0f);
+    // v_exp_f32 takes a base-2 exponent: e^{2x} = 2^{2x*log2(e)}; v_rcp_f32 is a 1-ulp reciprocal
+    // (__frcp_rn would expand to the ~10-instruction correctly-rounded division sequence)
+    const float e = __builtin_amdgcn_exp2f(x * 2.8853900817779268f);
+    return 1.0f - 2.0f * __builtin_amdgcn_rcpf(e + 1.0f);
 }
 
 __device__ __forceinline__ float wave_sum(float v) {
@@ -165,6 +167,10 @@ struct TnArgs {
     int R, No, Ni;
     SegInfo seg;
     int prologue; const float* pscale; const float* pshift;      // bn-tanh on A, [nseg][Ni]
+    // optional BatchNorm-backward transform of Z on load (Z = dZ1, zaux = H0, all [nseg][No]):
+    //   Z' = scale_s * (Z - c1_s - (zaux - mean_s) * invstd_s * c2_s)
+    const float* zaux; int ldzaux;
+    const float *z_mean, *z_invstd, *z_scale, *z_c1, *z_c2;
     float* dW; int lddw; float* db;                              // db may be null
     int accumulate;                                              // 1: +=, 0: overwrite
     float* slabs; size_t slab_floats;                            // workspace

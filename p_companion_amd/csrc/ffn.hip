@@ -16,42 +16,48 @@
 
 #define BN_EPS 1e-5f
 #define BN_MOMENTUM 0.1f
-#define BNQ 4                 // tile lanes of the finalize kernels (blockDim.y)
 
 // ---------------------------------------------------------------------------------------
-// partial[t][j] over 128-row tiles -> per-segment statistics.  blockDim = (256 cols, 4)
-__global__ void bn_finalize_fwd_kernel(const float* psum, const float* psq, SegInfo si, const float* gamma,
-                                       const float* beta, float* running_mean, float* running_var,
-                                       int64_t* nbt, int update_running, float* mean_o, float* invstd_o,
-                                       float* scale_o, float* shift_o) {
-    __shared__ double red[2][4][PC_H];
-    const int j = threadIdx.x, q = threadIdx.y;
+// partial[t][j] over 128-row tiles -> per-segment statistics.  grid = H/32 blocks of
+// (32 columns x 32 tile lanes): every column is independent, so the fold is spread over 8 CUs
+// and each thread walks tiles/32 entries in two chains; fp64 accumulation.
+#define FIN_COLS 32
+#define FIN_LANES 32
+__device__ __forceinline__ void fold_partials(const float* p1, const float* p2, int t0, int t1, int j, int q,
+                                              double (*red)[FIN_LANES][FIN_COLS], double* o1, double* o2) {
+    double a = 0.0, b = 0.0, a1 = 0.0, b1 = 0.0;
+    int t = t0 + q;
+    for (; t + FIN_LANES < t1; t += 2 * FIN_LANES) {
+        a += (double)p1[(size_t)t * PC_H + j];                b += (double)p2[(size_t)t * PC_H + j];
+        a1 += (double)p1[(size_t)(t + FIN_LANES) * PC_H + j]; b1 += (double)p2[(size_t)(t + FIN_LANES) * PC_H + j];
+    }
+    if (t < t1) { a += (double)p1[(size_t)t * PC_H + j]; b += (double)p2[(size_t)t * PC_H + j]; }
+    red[0][q][threadIdx.x] = a + a1;
+    red[1][q][threadIdx.x] = b + b1;
+    __syncthreads();
+    if (q == 0) {
+        double s1 = 0.0, s2 = 0.0;
+#pragma unroll 8
+        for (int i = 0; i < FIN_LANES; i++) { s1 += red[0][i][threadIdx.x]; s2 += red[1][i][threadIdx.x]; }
+        *o1 = s1; *o2 = s2;
+    }
+    __syncthreads();
+}
+
+__global__ __launch_bounds__(FIN_COLS * FIN_LANES) void bn_finalize_fwd_kernel(
+    const float* psum, const float* psq, SegInfo si, const float* gamma, const float* beta, float* running_mean,
+    float* running_var, int64_t* nbt, int update_running, float* mean_o, float* invstd_o, float* scale_o,
+    float* shift_o) {
+    __shared__ double red[2][FIN_LANES][FIN_COLS];
+    const int j = blockIdx.x * FIN_COLS + threadIdx.x, q = threadIdx.y;
     float rm = 0.f, rv = 0.f;
     if (q == 0 && update_running) { rm = running_mean[j]; rv = running_var[j]; }
     int nseen = 0;
     for (int s = 0; s < si.nseg; s++) {
         const int n = si.start[s + 1] - si.start[s];
         double a = 0.0, b = 0.0;
-        {   // four independent chains per thread keep the strided loads in flight
-            double a1 = 0.0, b1 = 0.0, a2 = 0.0, b2 = 0.0, a3 = 0.0, b3 = 0.0;
-            int t = si.tile0[s] + q;
-            const int te = si.tile0[s + 1];
-            for (; t + 3 * BNQ < te; t += 4 * BNQ) {
-                a += (double)psum[(size_t)t * PC_H + j];             b += (double)psq[(size_t)t * PC_H + j];
-                a1 += (double)psum[(size_t)(t + BNQ) * PC_H + j];     b1 += (double)psq[(size_t)(t + BNQ) * PC_H + j];
-                a2 += (double)psum[(size_t)(t + 2 * BNQ) * PC_H + j]; b2 += (double)psq[(size_t)(t + 2 * BNQ) * PC_H + j];
-                a3 += (double)psum[(size_t)(t + 3 * BNQ) * PC_H + j]; b3 += (double)psq[(size_t)(t + 3 * BNQ) * PC_H + j];
-            }
-            for (; t < te; t += BNQ) { a += (double)psum[(size_t)t * PC_H + j]; b += (double)psq[(size_t)t * PC_H + j]; }
-            a = (a + a1) + (a2 + a3);
-            b = (b + b1) + (b2 + b3);
-        }
-        red[0][q][j] = a;
-        red[1][q][j] = b;
-        __syncthreads();
+        fold_partials(psum, psq, si.tile0[s], si.tile0[s + 1], j, q, red, &a, &b);
         if (q == 0 && n > 0) {
-            a = red[0][0][j] + red[0][1][j] + red[0][2][j] + red[0][3][j];
-            b = red[1][0][j] + red[1][1][j] + red[1][2][j] + red[1][3][j];
             const double m = a / n;
             double var = b / n - m * m;
             if (var < 0.0) var = 0.0;
@@ -69,7 +75,6 @@ __global__ void bn_finalize_fwd_kernel(const float* psum, const float* psq, SegI
             }
             nseen++;
         }
-        __syncthreads();
     }
     if (q == 0 && update_running) {
         running_mean[j] = rm;
@@ -88,40 +93,22 @@ __global__ void bn_eval_coeff_kernel(const float* gamma, const float* beta, cons
 }
 
 // per-tile (sum dz1, sum dz1*xhat) -> dgamma, dbeta (+ per-segment means c1 = dbeta_s/n, c2 = dgamma_s/n)
-__global__ void bn_finalize_bwd_kernel(const float* psum, const float* pdot, SegInfo si, float* dgamma,
-                                       float* dbeta, int accumulate, float* c1, float* c2) {
-    __shared__ double red[2][4][PC_H];
-    const int j = threadIdx.x, q = threadIdx.y;
+__global__ __launch_bounds__(FIN_COLS * FIN_LANES) void bn_finalize_bwd_kernel(
+    const float* psum, const float* pdot, SegInfo si, float* dgamma, float* dbeta, int accumulate, float* c1,
+    float* c2) {
+    __shared__ double red[2][FIN_LANES][FIN_COLS];
+    const int j = blockIdx.x * FIN_COLS + threadIdx.x, q = threadIdx.y;
     double tg = 0.0, tb = 0.0;
     for (int s = 0; s < si.nseg; s++) {
         const int n = si.start[s + 1] - si.start[s];
         double a = 0.0, b = 0.0;
-        {   // four independent chains per thread keep the strided loads in flight
-            double a1 = 0.0, b1 = 0.0, a2 = 0.0, b2 = 0.0, a3 = 0.0, b3 = 0.0;
-            int t = si.tile0[s] + q;
-            const int te = si.tile0[s + 1];
-            for (; t + 3 * BNQ < te; t += 4 * BNQ) {
-                a += (double)psum[(size_t)t * PC_H + j];             b += (double)pdot[(size_t)t * PC_H + j];
-                a1 += (double)psum[(size_t)(t + BNQ) * PC_H + j];     b1 += (double)pdot[(size_t)(t + BNQ) * PC_H + j];
-                a2 += (double)psum[(size_t)(t + 2 * BNQ) * PC_H + j]; b2 += (double)pdot[(size_t)(t + 2 * BNQ) * PC_H + j];
-                a3 += (double)psum[(size_t)(t + 3 * BNQ) * PC_H + j]; b3 += (double)pdot[(size_t)(t + 3 * BNQ) * PC_H + j];
-            }
-            for (; t < te; t += BNQ) { a += (double)psum[(size_t)t * PC_H + j]; b += (double)pdot[(size_t)t * PC_H + j]; }
-            a = (a + a1) + (a2 + a3);
-            b = (b + b1) + (b2 + b3);
-        }
-        red[0][q][j] = a;
-        red[1][q][j] = b;
-        __syncthreads();
+        fold_partials(psum, pdot, si.tile0[s], si.tile0[s + 1], j, q, red, &a, &b);
         if (q == 0) {
-            a = red[0][0][j] + red[0][1][j] + red[0][2][j] + red[0][3][j];
-            b = red[1][0][j] + red[1][1][j] + red[1][2][j] + red[1][3][j];
             tb += a;
             tg += b;
             c1[s * PC_H + j] = n > 0 ? (float)(a / n) : 0.f;
             c2[s * PC_H + j] = n > 0 ? (float)(b / n) : 0.f;
         }
-        __syncthreads();
     }
     if (q == 0) {
         dgamma[j] = accumulate ? dgamma[j] + (float)tg : (float)tg;
@@ -249,7 +236,7 @@ extern "C" int pc_p2v_ffn_forward_train(const pc_p2v_tensors* p, const float* ta
     g1.stats = NT_STAT_SUMSQ; g1.stat_sum = w.stat_a; g1.stat_aux = w.stat_b;
     PC_TRY(launch_gemm_nt(g1, st));
 
-    PC_LAUNCH(bn_finalize_fwd_kernel, dim3(1), dim3(PC_H, 4), 0, st, w.stat_a, w.stat_b, si, p->gamma,
+    PC_LAUNCH(bn_finalize_fwd_kernel, dim3(PC_H / FIN_COLS), dim3(FIN_COLS, FIN_LANES), 0, st, w.stat_a, w.stat_b, si, p->gamma,
                        p->beta, p->running_mean, p->running_var, p->num_batches_tracked, update_running,
                        sv->bn_mean, sv->bn_invstd, sv->bn_scale, sv->bn_shift);
     PC_TRY(pc_launch_status());
@@ -327,22 +314,27 @@ static int ffn_backward_impl(const pc_p2v_tensors* p, const pc_p2v_tensors* g, c
     t3.slab_floats = w.slab_floats;
     PC_TRY(launch_gemm_tn(t3, st));
 
-    PC_LAUNCH(bn_finalize_bwd_kernel, dim3(1), dim3(PC_H, 4), 0, st, w.stat_a, w.stat_b, si, g->gamma,
+    PC_LAUNCH(bn_finalize_bwd_kernel, dim3(PC_H / FIN_COLS), dim3(FIN_COLS, FIN_LANES), 0, st, w.stat_a, w.stat_b, si, g->gamma,
                        g->beta, accumulate, w.c1, w.c2);
     PC_TRY(pc_launch_status());
 
-    int blocks = (rows + 3) / 4;
-    if (blocks > 4096) blocks = 4096;
-    PC_LAUNCH(bn_bwd_apply_kernel, dim3(blocks), dim3(256), 0, st, w.dz1, sv->h0, rows, si, sv->bn_mean,
-                       sv->bn_invstd, sv->bn_scale, w.c1, w.c2);
-    PC_TRY(pc_launch_status());
-
-    // dW0 = dH0^T X (rows gathered again from the table), db0
+    // dW0 = dH0^T X (rows gathered again from the table), db0.  Without a dx consumer the BatchNorm
+    // backward is applied to dZ1 on the fly inside the loader and dH0 never touches HBM.
     TnArgs t0 = {};
     t0.Z = w.dz1; t0.ldz = PC_H; t0.A = table; t0.lda = PC_D; t0.gather = idx; t0.R = rows; t0.No = PC_H;
     t0.Ni = PC_D; t0.seg = si;
     t0.dW = g->w0; t0.lddw = PC_D; t0.db = g->b0; t0.accumulate = accumulate; t0.slabs = w.slabs;
     t0.slab_floats = w.slab_floats;
+    if (dx) {
+        int blocks = (rows + 3) / 4;
+        if (blocks > 4096) blocks = 4096;
+        PC_LAUNCH(bn_bwd_apply_kernel, dim3(blocks), dim3(256), 0, st, w.dz1, sv->h0, rows, si, sv->bn_mean,
+                  sv->bn_invstd, sv->bn_scale, w.c1, w.c2);
+        PC_TRY(pc_launch_status());
+    } else {
+        t0.zaux = sv->h0; t0.ldzaux = PC_H;
+        t0.z_mean = sv->bn_mean; t0.z_invstd = sv->bn_invstd; t0.z_scale = sv->bn_scale; t0.z_c1 = w.c1; t0.z_c2 = w.c2;
+    }
     PC_TRY(launch_gemm_tn(t0, st));
 
     if (dx) {

@@ -26,26 +26,32 @@
 #include "common.h"
 #include <stdlib.h>
 
-#define BM 128
 #define BK 32
 #define LDS_LD 36
 
 int gemm_nt_tiles(const SegInfo& si) { return si.tile0[PC_MAX_SEG]; }
 
-template <int NWN>   // wave columns: BN = 64*NWN columns, 128*NWN threads
-__global__ __launch_bounds__(128 * NWN, 2) void gemm_nt_kernel(NtArgs a, int ntn, int total_tiles, int dbg) {
-    constexpr int THREADS = 128 * NWN;
-    constexpr int BN = 64 * NWN;
-    constexpr int APT = 1024 / THREADS;          // float4 of A per thread per chunk (2 or 4), one row
-    constexpr int TPR_A = 8 / APT;               // threads per A row
+// NWM x NWN waves of 64x64 each: BM = 64*NWM rows, BN = 64*NWN columns.
+//   <2,4> 128x256, 8 waves, one workgroup per CU   (N > 128)
+//   <4,2> 256x128, 8 waves, one workgroup per CU   (N <= 128, many rows)
+//   <1,2>  64x128, 2 waves                         (few rows: more, smaller tiles fill more CUs)
+// PRO / EPI / STATS are compile-time: a runtime switch per output element costs ~1200 scalar
+// branches per tile and wave (measured: 12 us of a 33 us tile) and the unused fusions' registers.
+template <int NWM, int NWN, bool PRO, int EPI, int STATS>
+__global__ __launch_bounds__(64 * NWM * NWN, 2) void gemm_nt_kernel(NtArgs a, int ntn, int total_tiles, int dbg) {
+    constexpr int THREADS = 64 * NWM * NWN;
+    constexpr int BM = 64 * NWM, BN = 64 * NWN;
+    constexpr int APT = BM * 8 / THREADS;        // float4 of A per thread per chunk, all from one row
+    constexpr int WPT = BN * 8 / THREADS;        // float4 of W per thread per chunk
+    constexpr int TPR_A = 8 / APT, TPR_W = 8 / WPT;
     constexpr int BUF = (BM + BN) * LDS_LD;      // floats per stage: A image then W image
     __shared__ __attribute__((aligned(16))) float smem[2 * BUF];
 
-    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, wm = w & 1, wn = w >> 1;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, wm = w % NWM, wn = w / NWM;
     const int la_row = tid / TPR_A, la_c = (tid % TPR_A) * APT * 4;       // loader: A row / first float
-    const int lw_row = tid >> 1, lw_c = (tid & 1) * 16;                   // loader: W row / first float
+    const int lw_row = tid / TPR_W, lw_c = (tid % TPR_W) * WPT * 4;       // loader: W row / first float
     const int nk = (a.K + BK - 1) / BK;
-    const bool pro = a.prologue == NT_PRO_BNTANH;
+    constexpr bool pro = PRO;
 
     // ---- per-tile state ------------------------------------------------------------------
     int tile = blockIdx.x;
@@ -73,7 +79,7 @@ __global__ __launch_bounds__(128 * NWN, 2) void gemm_nt_kernel(NtArgs a, int ntn
         wp = a.W + (size_t)(wv ? n : 0) * a.ldw + lw_c;
     };
 
-    float4 ra[APT], rw[4];
+    float4 ra[APT], rw[WPT];
     auto gload = [&](int k0, const float* ap, bool av, const float* wp, bool wv, int sg) {
 #pragma unroll
         for (int j = 0; j < APT; j++) {
@@ -89,7 +95,7 @@ __global__ __launch_bounds__(128 * NWN, 2) void gemm_nt_kernel(NtArgs a, int ntn
             }
         }
 #pragma unroll
-        for (int j = 0; j < 4; j++) {
+        for (int j = 0; j < WPT; j++) {
             const bool kv = k0 + lw_c + 4 * j < a.K;
             rw[j] = (wv && kv) ? *reinterpret_cast<const float4*>(wp + k0 + 4 * j) : make_float4(0.f, 0.f, 0.f, 0.f);
         }
@@ -100,7 +106,7 @@ __global__ __launch_bounds__(128 * NWN, 2) void gemm_nt_kernel(NtArgs a, int ntn
 #pragma unroll
         for (int j = 0; j < APT; j++) *reinterpret_cast<float4*>(&As[la_row * LDS_LD + la_c + 4 * j]) = ra[j];
 #pragma unroll
-        for (int j = 0; j < 4; j++) *reinterpret_cast<float4*>(&Ws[lw_row * LDS_LD + lw_c + 4 * j]) = rw[j];
+        for (int j = 0; j < WPT; j++) *reinterpret_cast<float4*>(&Ws[lw_row * LDS_LD + lw_c + 4 * j]) = rw[j];
     };
 
     f32x16 acc[2][2];
@@ -175,6 +181,7 @@ __global__ __launch_bounds__(128 * NWN, 2) void gemm_nt_kernel(NtArgs a, int ntn
         float* stg = free_stage + w * (32 * LDS_LD);
         const int er = lane >> 3, ec = (lane & 7) * 4;          // staged read: rows er+8i, cols ec..ec+3
         const bool vec = ((a.N | a.ldc) & 3) == 0 && (!a.aux || (a.ldaux & 3) == 0);
+        constexpr bool HAS_AUX = EPI == NT_EPI_DTANH || EPI == NT_EPI_DTANH_BN || EPI == NT_EPI_DRELU;
         float cs1[2][4], cs2[2][4];
 #pragma unroll
         for (int nt = 0; nt < 2; nt++)
@@ -189,11 +196,11 @@ __global__ __launch_bounds__(128 * NWN, 2) void gemm_nt_kernel(NtArgs a, int ntn
                 const bool cv = col + q < a.N;
                 bias[q] = (cv && a.bias) ? a.bias[col + q] : 0.f;
                 es[q] = eh[q] = mu[q] = is[q] = 0.f;
-                if (cv && a.epilogue == NT_EPI_DTANH_BN) {
+                if (cv && EPI == NT_EPI_DTANH_BN) {
                     es[q] = a.escale[(size_t)seg * a.N + col + q];
                     eh[q] = a.eshift[(size_t)seg * a.N + col + q];
                 }
-                if (cv && a.stats == NT_STAT_BNBWD) {
+                if (cv && STATS == NT_STAT_BNBWD) {
                     mu[q] = a.mean[(size_t)seg * a.N + col + q];
                     is[q] = a.invstd[(size_t)seg * a.N + col + q];
                 }
@@ -211,7 +218,7 @@ __global__ __launch_bounds__(128 * NWN, 2) void gemm_nt_kernel(NtArgs a, int ntn
                     float v[4] = {v4.x, v4.y, v4.z, v4.w};
                     float ax[4] = {0.f, 0.f, 0.f, 0.f};
                     const bool rok = row < row_end;
-                    if (rok && a.aux) {
+                    if (rok && HAS_AUX) {
                         if (vec && col + 3 < a.N) {
                             const float4 x4 = *reinterpret_cast<const float4*>(a.aux + (size_t)row * a.ldaux + col);
                             ax[0] = x4.x; ax[1] = x4.y; ax[2] = x4.z; ax[3] = x4.w;
@@ -224,7 +231,7 @@ __global__ __launch_bounds__(128 * NWN, 2) void gemm_nt_kernel(NtArgs a, int ntn
 #pragma unroll
                     for (int q = 0; q < 4; q++) {
                         float x = v[q] + bias[q];
-                        switch (a.epilogue) {
+                        switch (EPI) {
                             case NT_EPI_TANH: x = fast_tanh(x); break;
                             case NT_EPI_RELU: x = x > 0.f ? x : 0.f; break;
                             case NT_EPI_DTANH: x = x * (1.f - ax[q] * ax[q]); break;
@@ -234,11 +241,11 @@ __global__ __launch_bounds__(128 * NWN, 2) void gemm_nt_kernel(NtArgs a, int ntn
                         }
                         v[q] = x;
                         if (rok && col + q < a.N) {
-                            if (a.stats == NT_STAT_SUMSQ) { cs1[nt][q] += x; cs2[nt][q] += x * x; }
-                            else if (a.stats == NT_STAT_BNBWD) { cs1[nt][q] += x; cs2[nt][q] += x * ((ax[q] - mu[q]) * is[q]); }
+                            if (STATS == NT_STAT_SUMSQ) { cs1[nt][q] += x; cs2[nt][q] += x * x; }
+                            else if (STATS == NT_STAT_BNBWD) { cs1[nt][q] += x; cs2[nt][q] += x * ((ax[q] - mu[q]) * is[q]); }
                         }
                     }
-                    if (rok) {
+                    if (rok && !(dbg & 32)) {
                         if (vec && col + 3 < a.N) {
                             *reinterpret_cast<float4*>(a.C + (size_t)row * a.ldc + col) = make_float4(v[0], v[1], v[2], v[3]);
                         } else {
@@ -251,10 +258,10 @@ __global__ __launch_bounds__(128 * NWN, 2) void gemm_nt_kernel(NtArgs a, int ntn
                 __builtin_amdgcn_wave_barrier();
             }
         }
-        if (a.stats != NT_STAT_NONE) {
+        if (STATS != NT_STAT_NONE) {
             // fold the 8 row groups of a wave (lane>>3), then the two M-waves through LDS
             __syncthreads();                                   // every wave is done with its staging patch
-            float* red = free_stage;                           // [2 stats][2 wm][BN]
+            float* red = free_stage;                           // [2 stats][NWM][BN]
 #pragma unroll
             for (int nt = 0; nt < 2; nt++)
 #pragma unroll
@@ -264,16 +271,19 @@ __global__ __launch_bounds__(128 * NWN, 2) void gemm_nt_kernel(NtArgs a, int ntn
                     for (int o = 8; o <= 32; o <<= 1) { s1 += __shfl_xor(s1, o, 64); s2 += __shfl_xor(s2, o, 64); }
                     if (lane < 8) {
                         const int c = wn * 64 + nt * 32 + lane * 4 + q;
-                        red[(0 * 2 + wm) * BN + c] = s1;
-                        red[(1 * 2 + wm) * BN + c] = s2;
+                        red[(0 * NWM + wm) * BN + c] = s1;
+                        red[(1 * NWM + wm) * BN + c] = s2;
                     }
                 }
             __syncthreads();
             const int tile_m = tile / ntn;
             for (int c = tid; c < BN; c += THREADS)
                 if (n0 + c < a.N) {
-                    a.stat_sum[(size_t)tile_m * a.N + n0 + c] = red[0 * BN + c] + red[1 * BN + c];
-                    a.stat_aux[(size_t)tile_m * a.N + n0 + c] = red[2 * BN + c] + red[3 * BN + c];
+                    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+                    for (int m = 0; m < NWM; m++) { s1 += red[(0 * NWM + m) * BN + c]; s2 += red[(1 * NWM + m) * BN + c]; }
+                    a.stat_sum[(size_t)tile_m * a.N + n0 + c] = s1;
+                    a.stat_aux[(size_t)tile_m * a.N + n0 + c] = s2;
                 }
         }
         if (ntile >= total_tiles) break;
@@ -284,6 +294,41 @@ __global__ __launch_bounds__(128 * NWN, 2) void gemm_nt_kernel(NtArgs a, int ntn
     }
 }
 
+static SegInfo retile(const SegInfo& in, int tile_rows) {
+    SegInfo si = in;
+    int t = 0;
+    for (int i = 0; i < PC_MAX_SEG; i++) {
+        si.tile0[i] = t;
+        t += (si.start[i + 1] - si.start[i] + tile_rows - 1) / tile_rows;
+    }
+    si.tile0[PC_MAX_SEG] = t;
+    return si;
+}
+
+template <bool PRO, int EPI, int STATS>
+static void launch_variant(const NtArgs& a, int ntm, int dbg, hipStream_t st) {
+    if (PRO || a.N > 128 || STATS != NT_STAT_NONE) {
+        // 128 rows x 256 columns, 8 waves, one workgroup per CU
+        const int ntn = (a.N + 255) / 256, total = ntm * ntn;
+        PC_LAUNCH((gemm_nt_kernel<2, 4, PRO, EPI, STATS>), dim3(total < 256 ? total : 256), dim3(512), 0, st, a, ntn,
+                  total, dbg);
+    } else if (ntm >= 192) {
+        // 256 rows x 128 columns, 8 waves, one workgroup per CU
+        NtArgs b = a;
+        b.seg = retile(a.seg, 256);
+        const int total = gemm_nt_tiles(b.seg);
+        PC_LAUNCH((gemm_nt_kernel<4, 2, false, EPI, NT_STAT_NONE>), dim3(total < 256 ? total : 256), dim3(512), 0, st,
+                  b, 1, total, dbg);
+    } else {
+        // few rows (per-sample projections of the attention block, joint-step layers): 64-row
+        // tiles of 2 waves reach 2x the CUs
+        NtArgs b = a;
+        b.seg = retile(a.seg, 64);
+        const int total = gemm_nt_tiles(b.seg);
+        PC_LAUNCH((gemm_nt_kernel<1, 2, false, EPI, NT_STAT_NONE>), dim3(total), dim3(128), 0, st, b, 1, total, dbg);
+    }
+}
+
 int launch_gemm_nt(const NtArgs& a, hipStream_t st) {
     if (!a.A || !a.W || !a.C || a.M <= 0 || a.N <= 0 || a.K <= 0) return PC_EINVAL;
     if (a.K % 4 != 0 || a.lda % 4 != 0 || a.ldw % 4 != 0) return PC_ESHAPE;
@@ -291,16 +336,24 @@ int launch_gemm_nt(const NtArgs& a, hipStream_t st) {
     if (a.aux && ((uintptr_t)a.aux & 15)) return PC_ESHAPE;
     const int ntm = gemm_nt_tiles(a.seg);
     if (ntm <= 0) return PC_EINVAL;
+    if (a.prologue == NT_PRO_BNTANH && (!a.pscale || !a.pshift)) return PC_EINVAL;
+    const bool needs_aux = a.epilogue == NT_EPI_DTANH || a.epilogue == NT_EPI_DTANH_BN || a.epilogue == NT_EPI_DRELU;
+    if (needs_aux && !a.aux) return PC_EINVAL;
+    if (a.stats != NT_STAT_NONE && (a.N > 256 || !a.stat_sum || !a.stat_aux)) return PC_ESHAPE;
     static const int dbg = getenv("PC_NT_DBG") ? atoi(getenv("PC_NT_DBG")) : 0;   // developer probe only
+    // the fusions the two hot paths use (any other combination is refused)
+    const int key = a.prologue * 100 + a.epilogue * 10 + a.stats;
     const int pb = pc_prof_begin(PC_KIND_GEMM_NT, 2.0 * a.M * (double)a.N * a.K, st);
-    if (a.N > 128) {
-        const int ntn = (a.N + 255) / 256, total = ntm * ntn;
-        const int grid = total < 256 ? total : 256;            // one 8-wave workgroup per CU
-        PC_LAUNCH(gemm_nt_kernel<4>, dim3(grid), dim3(512), 0, st, a, ntn, total, dbg);
-    } else {
-        const int ntn = 1, total = ntm;
-        const int grid = total < 512 ? total : 512;            // two 4-wave workgroups per CU
-        PC_LAUNCH(gemm_nt_kernel<2>, dim3(grid), dim3(256), 0, st, a, ntn, total, dbg);
+    switch (key) {
+        case 0:   launch_variant<false, NT_EPI_NONE, NT_STAT_NONE>(a, ntm, dbg, st); break;      // plain Linear / dX
+        case 1:   launch_variant<false, NT_EPI_NONE, NT_STAT_SUMSQ>(a, ntm, dbg, st); break;     // Linear0 + BN sums
+        case 110: launch_variant<true, NT_EPI_TANH, NT_STAT_NONE>(a, ntm, dbg, st); break;       // BN+tanh -> Linear3 -> tanh
+        case 10:  launch_variant<false, NT_EPI_TANH, NT_STAT_NONE>(a, ntm, dbg, st); break;
+        case 20:  launch_variant<false, NT_EPI_RELU, NT_STAT_NONE>(a, ntm, dbg, st); break;
+        case 30:  launch_variant<false, NT_EPI_DTANH, NT_STAT_NONE>(a, ntm, dbg, st); break;     // dZ2
+        case 42:  launch_variant<false, NT_EPI_DTANH_BN, NT_STAT_BNBWD>(a, ntm, dbg, st); break; // dZ1 + BN-backward sums
+        case 50:  launch_variant<false, NT_EPI_DRELU, NT_STAT_NONE>(a, ntm, dbg, st); break;
+        default:  return PC_ESHAPE;
     }
     pc_prof_end(pb, st);
     return pc_launch_status();

@@ -30,6 +30,9 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(TnArgs a, int tiles_i, 
 
     float4 rz[4], ra[4];
     float4 dbacc = make_float4(0.f, 0.f, 0.f, 0.f);
+    // BN-backward coefficients of this thread's 4 columns, cached for one segment at a time
+    int zseg = -1;
+    float4 zmu, zis, zsc, zc1, zc2;
     auto gload = [&](int r0) {
 #pragma unroll
         for (int p = 0; p < 4; p++) {
@@ -37,6 +40,23 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(TnArgs a, int tiles_i, 
             const bool rv = r < r_end;
             rz[p] = (rv && zcol_ok) ? *reinterpret_cast<const float4*>(a.Z + (size_t)r * a.ldz + o0 + lcol)
                                     : make_float4(0.f, 0.f, 0.f, 0.f);
+            if (a.zaux && rv && zcol_ok) {
+                const int s = seg_of_row(a.seg, r);
+                if (s != zseg) {
+                    const size_t o = (size_t)s * a.No + o0 + lcol;
+                    zmu = *reinterpret_cast<const float4*>(a.z_mean + o);
+                    zis = *reinterpret_cast<const float4*>(a.z_invstd + o);
+                    zsc = *reinterpret_cast<const float4*>(a.z_scale + o);
+                    zc1 = *reinterpret_cast<const float4*>(a.z_c1 + o);
+                    zc2 = *reinterpret_cast<const float4*>(a.z_c2 + o);
+                    zseg = s;
+                }
+                const float4 h = *reinterpret_cast<const float4*>(a.zaux + (size_t)r * a.ldzaux + o0 + lcol);
+                rz[p].x = zsc.x * (rz[p].x - zc1.x - (h.x - zmu.x) * zis.x * zc2.x);
+                rz[p].y = zsc.y * (rz[p].y - zc1.y - (h.y - zmu.y) * zis.y * zc2.y);
+                rz[p].z = zsc.z * (rz[p].z - zc1.z - (h.z - zmu.z) * zis.z * zc2.z);
+                rz[p].w = zsc.w * (rz[p].w - zc1.w - (h.w - zmu.w) * zis.w * zc2.w);
+            }
             int src = r;
             bool av = rv && acol_ok;
             if (av && a.gather) { src = a.gather[r]; av = src >= 0; }
