@@ -26,25 +26,27 @@
 #include "common.h"
 #include <stdlib.h>
 
-#define BK 32
-#define LDS_LD 36
+#define PLD 36          // row stride (floats) of the per-wave epilogue transposition patch
 
 int gemm_nt_tiles(const SegInfo& si) { return si.tile0[PC_MAX_SEG]; }
 
 // NWM x NWN waves of 64x64 each: BM = 64*NWM rows, BN = 64*NWN columns.
 //   <2,4> 128x256, 8 waves, one workgroup per CU   (N > 128)
-//   <4,2> 256x128, 8 waves, one workgroup per CU   (N <= 128, many rows)
+//   <2,2> 128x128, 4 waves, two workgroups per CU  (N <= 128, many rows)
 //   <1,2>  64x128, 2 waves                         (few rows: more, smaller tiles fill more CUs)
 // PRO / EPI / STATS are compile-time: a runtime switch per output element costs ~1200 scalar
 // branches per tile and wave (measured: 12 us of a 33 us tile) and the unused fusions' registers.
-template <int NWM, int NWN, bool PRO, int EPI, int STATS>
-__global__ __launch_bounds__(64 * NWM * NWN, 2) void gemm_nt_kernel(NtArgs a, int ntn, int total_tiles, int dbg) {
+template <int NWM, int NWN, int BK, int OCC, bool PRO, int EPI, int STATS>
+__global__ __launch_bounds__(64 * NWM * NWN, OCC) void gemm_nt_kernel(NtArgs a, int ntn, int total_tiles, int dbg) {
     constexpr int THREADS = 64 * NWM * NWN;
     constexpr int BM = 64 * NWM, BN = 64 * NWN;
-    constexpr int APT = BM * 8 / THREADS;        // float4 of A per thread per chunk, all from one row
-    constexpr int WPT = BN * 8 / THREADS;        // float4 of W per thread per chunk
-    constexpr int TPR_A = 8 / APT, TPR_W = 8 / WPT;
-    constexpr int BUF = (BM + BN) * LDS_LD;      // floats per stage: A image then W image
+    constexpr int LDS_LD = BK + 4;               // row stride: (BK+4)*4 B = odd multiple of 16 B => conflict-free b128 reads
+    constexpr int CPR = BK / 4;                  // float4 chunks per row per K-step
+    constexpr int APT = BM * CPR / THREADS;      // float4 of A per thread per chunk, all from one row
+    constexpr int WPT = BN * CPR / THREADS;      // float4 of W per thread per chunk
+    constexpr int TPR_A = CPR / APT, TPR_W = CPR / WPT;
+    constexpr int BUF0 = (BM + BN) * LDS_LD;     // floats per stage: A image then W image
+    constexpr int BUF = BUF0 > (THREADS / 64) * 32 * PLD ? BUF0 : (THREADS / 64) * 32 * PLD;   // also hosts the epilogue patches
     __shared__ __attribute__((aligned(16))) float smem[2 * BUF];
 
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, wm = w % NWM, wn = w / NWM;
@@ -153,14 +155,20 @@ __global__ __launch_bounds__(64 * NWM * NWN, 2) void gemm_nt_kernel(NtArgs a, in
             }
             const float* As = smem + cur * BUF + wm * 64 * LDS_LD + frag;
             const float* Ws = smem + cur * BUF + (BM + wn * 64) * LDS_LD + frag;
+            // fragments of k-block kk+1 are requested before the 16 MFMAs of block kk are issued
+            float4 fa0 = *reinterpret_cast<const float4*>(As), fa1 = *reinterpret_cast<const float4*>(As + 32 * LDS_LD);
+            float4 fb0 = *reinterpret_cast<const float4*>(Ws), fb1 = *reinterpret_cast<const float4*>(Ws + 32 * LDS_LD);
 #pragma unroll
-            for (int kk = 0; kk < 4; kk++) {
-                const float4 a0 = *reinterpret_cast<const float4*>(As + kk * 8);
-                const float4 a1 = *reinterpret_cast<const float4*>(As + 32 * LDS_LD + kk * 8);
-                const float4 b0 = *reinterpret_cast<const float4*>(Ws + kk * 8);
-                const float4 b1 = *reinterpret_cast<const float4*>(Ws + 32 * LDS_LD + kk * 8);
-                const float av0[4] = {a0.x, a0.y, a0.z, a0.w}, av1[4] = {a1.x, a1.y, a1.z, a1.w};
-                const float bv0[4] = {b0.x, b0.y, b0.z, b0.w}, bv1[4] = {b1.x, b1.y, b1.z, b1.w};
+            for (int kk = 0; kk < BK / 8; kk++) {
+                float4 na0 = fa0, na1 = fa1, nb0 = fb0, nb1 = fb1;
+                if (kk + 1 < BK / 8) {
+                    na0 = *reinterpret_cast<const float4*>(As + (kk + 1) * 8);
+                    na1 = *reinterpret_cast<const float4*>(As + 32 * LDS_LD + (kk + 1) * 8);
+                    nb0 = *reinterpret_cast<const float4*>(Ws + (kk + 1) * 8);
+                    nb1 = *reinterpret_cast<const float4*>(Ws + 32 * LDS_LD + (kk + 1) * 8);
+                }
+                const float av0[4] = {fa0.x, fa0.y, fa0.z, fa0.w}, av1[4] = {fa1.x, fa1.y, fa1.z, fa1.w};
+                const float bv0[4] = {fb0.x, fb0.y, fb0.z, fb0.w}, bv1[4] = {fb1.x, fb1.y, fb1.z, fb1.w};
 #pragma unroll
                 for (int r = 0; r < 4; r++) {
                     acc[0][0] = mfma32(av0[r], bv0[r], acc[0][0]);
@@ -168,6 +176,11 @@ __global__ __launch_bounds__(64 * NWM * NWN, 2) void gemm_nt_kernel(NtArgs a, in
                     acc[1][0] = mfma32(av1[r], bv0[r], acc[1][0]);
                     acc[1][1] = mfma32(av1[r], bv1[r], acc[1][1]);
                 }
+                fa0 = na0; fa1 = na1; fb0 = nb0; fb1 = nb1;
+                // keep the request one whole block ahead of its use (the scheduler otherwise sinks the
+                // reads to just before the MFMA that consumes them and exposes the LDS latency)
+                if (kk + 1 < BK / 8) __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, 16, 0);
             }
             if (loaded && !(dbg & 4)) lstore(cur ^ 1);
             if (!(dbg & 8)) __syncthreads();
@@ -178,7 +191,7 @@ __global__ __launch_bounds__(64 * NWM * NWN, 2) void gemm_nt_kernel(NtArgs a, in
         // stage is free: each wave transposes its 32x32 sub-tiles through a private 32x36 patch.
         if (dbg & 1) { if (ntile >= total_tiles) break; zero_acc(); tile = ntile; row0 = nrow0; row_end = nrow_end; n0 = nn0; seg = nseg; aptr = naptr; aval = naval; wptr = nwptr; wval = nwval; continue; }
         float* free_stage = smem + (cur ^ 1) * BUF;
-        float* stg = free_stage + w * (32 * LDS_LD);
+        float* stg = free_stage + w * (32 * PLD);
         const int er = lane >> 3, ec = (lane & 7) * 4;          // staged read: rows er+8i, cols ec..ec+3
         const bool vec = ((a.N | a.ldc) & 3) == 0 && (!a.aux || (a.ldaux & 3) == 0);
         constexpr bool HAS_AUX = EPI == NT_EPI_DTANH || EPI == NT_EPI_DTANH_BN || EPI == NT_EPI_DRELU;
@@ -209,12 +222,12 @@ __global__ __launch_bounds__(64 * NWM * NWN, 2) void gemm_nt_kernel(NtArgs a, in
             for (int mt = 0; mt < 2; mt++) {
 #pragma unroll
                 for (int reg = 0; reg < 16; reg++)
-                    stg[((reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)) * LDS_LD + (lane & 31)] = acc[mt][nt][reg];
+                    stg[((reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)) * PLD + (lane & 31)] = acc[mt][nt][reg];
                 __builtin_amdgcn_wave_barrier();
 #pragma unroll
                 for (int i = 0; i < 4; i++) {
                     const int row = row0 + wm * 64 + mt * 32 + er + 8 * i;
-                    const float4 v4 = *reinterpret_cast<const float4*>(&stg[(er + 8 * i) * LDS_LD + ec]);
+                    const float4 v4 = *reinterpret_cast<const float4*>(&stg[(er + 8 * i) * PLD + ec]);
                     float v[4] = {v4.x, v4.y, v4.z, v4.w};
                     float ax[4] = {0.f, 0.f, 0.f, 0.f};
                     const bool rok = row < row_end;
@@ -308,24 +321,22 @@ static SegInfo retile(const SegInfo& in, int tile_rows) {
 template <bool PRO, int EPI, int STATS>
 static void launch_variant(const NtArgs& a, int ntm, int dbg, hipStream_t st) {
     if (PRO || a.N > 128 || STATS != NT_STAT_NONE) {
-        // 128 rows x 256 columns, 8 waves, one workgroup per CU
+        // 128 rows x 256 columns, 8 waves, one workgroup per CU: A is read once
         const int ntn = (a.N + 255) / 256, total = ntm * ntn;
-        PC_LAUNCH((gemm_nt_kernel<2, 4, PRO, EPI, STATS>), dim3(total < 256 ? total : 256), dim3(512), 0, st, a, ntn,
+        PC_LAUNCH((gemm_nt_kernel<2, 4, 32, 2, PRO, EPI, STATS>), dim3(total < 256 ? total : 256), dim3(512), 0, st, a, ntn,
                   total, dbg);
     } else if (ntm >= 192) {
-        // 256 rows x 128 columns, 8 waves, one workgroup per CU
-        NtArgs b = a;
-        b.seg = retile(a.seg, 256);
-        const int total = gemm_nt_tiles(b.seg);
-        PC_LAUNCH((gemm_nt_kernel<4, 2, false, EPI, NT_STAT_NONE>), dim3(total < 256 ? total : 256), dim3(512), 0, st,
-                  b, 1, total, dbg);
+        // N <= 128: 128x128 tiles, two independent 4-wave workgroups per CU (measured 89 vs 77 TF/s
+        // for one 256x128 8-wave workgroup: the second workgroup fills the first one's epilogue)
+        PC_LAUNCH((gemm_nt_kernel<2, 2, 32, 2, false, EPI, NT_STAT_NONE>), dim3(ntm < 512 ? ntm : 512), dim3(256), 0, st, a,
+                  1, ntm, dbg);
     } else {
         // few rows (per-sample projections of the attention block, joint-step layers): 64-row
         // tiles of 2 waves reach 2x the CUs
         NtArgs b = a;
         b.seg = retile(a.seg, 64);
         const int total = gemm_nt_tiles(b.seg);
-        PC_LAUNCH((gemm_nt_kernel<1, 2, false, EPI, NT_STAT_NONE>), dim3(total), dim3(128), 0, st, b, 1, total, dbg);
+        PC_LAUNCH((gemm_nt_kernel<1, 2, 32, 2, false, EPI, NT_STAT_NONE>), dim3(total), dim3(128), 0, st, b, 1, total, dbg);
     }
 }
 

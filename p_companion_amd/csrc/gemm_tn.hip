@@ -142,6 +142,150 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(TnArgs a, int tiles_i, 
     }
 }
 
+// ---------------------------------------------------------------------------------------
+// Full-tile variant for the FFN / attention weight gradients: ONE 8-wave workgroup per CU
+// computes the WHOLE dW (up to 256x256) for its slice of rows, so each operand row is read
+// from HBM exactly once (the 128x128-tile kernel above reads Z once per column tile and A
+// once per row tile: 2x the traffic for a 256x256 gradient, and these products sit near the
+// HBM roofline at the fp32 MFMA rate).  Wave grid WO x WI, each wave TO x TI MFMA tiles.
+//   <2,4,4,2> 256x256 (dW3)   <2,4,2,2> 128x256 (dW5)   <4,2,2,2> 256x128 (dW0, dW_kv)
+template <int WO, int WI, int TO, int TI, bool APRO, bool ZPRO>
+__global__ __launch_bounds__(512, 2) void gemm_tn8_kernel(TnArgs a, int nsplit, int rows_per_split) {
+    constexpr int NO = WO * TO * 32, NI = WI * TI * 32;
+    constexpr int ZP = NO / 64, AP = NI / 64;            // float4 per thread per chunk (Z, A)
+    constexpr int ZT = NO / 4, AT = NI / 4;              // threads per row
+    constexpr int STAGE = TK * (NO + NI);
+    __shared__ __attribute__((aligned(16))) float smem[2 * STAGE];
+
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, wo = w % WO, wi = w / WO;
+    const int split = blockIdx.x;
+    const int r_begin = split * rows_per_split;
+    const int r_end = min(a.R, r_begin + rows_per_split);
+    const int zrow = tid / ZT, zcol = (tid % ZT) * 4;    // 512/ZT rows per pass
+    const int arow = tid / AT, acol = (tid % AT) * 4;
+    const bool zcol_ok = zcol < a.No, acol_ok = acol < a.Ni;
+
+    float4 rz[ZP], ra[AP];
+    float4 dbacc = make_float4(0.f, 0.f, 0.f, 0.f);
+    int zseg = -1, aseg = -1;
+    float4 zmu, zis, zsc, zc1, zc2, asc, ash;
+    auto gload = [&](int r0) {
+#pragma unroll
+        for (int p = 0; p < ZP; p++) {
+            const int r = r0 + zrow + (512 / ZT) * p;
+            const bool rv = r < r_end && zcol_ok;
+            rz[p] = rv ? *reinterpret_cast<const float4*>(a.Z + (size_t)r * a.ldz + zcol) : make_float4(0.f, 0.f, 0.f, 0.f);
+            if (ZPRO && rv) {
+                const int s = seg_of_row(a.seg, r);
+                if (s != zseg) {
+                    const size_t o = (size_t)s * a.No + zcol;
+                    zmu = *reinterpret_cast<const float4*>(a.z_mean + o);
+                    zis = *reinterpret_cast<const float4*>(a.z_invstd + o);
+                    zsc = *reinterpret_cast<const float4*>(a.z_scale + o);
+                    zc1 = *reinterpret_cast<const float4*>(a.z_c1 + o);
+                    zc2 = *reinterpret_cast<const float4*>(a.z_c2 + o);
+                    zseg = s;
+                }
+                const float4 h = *reinterpret_cast<const float4*>(a.zaux + (size_t)r * a.ldzaux + zcol);
+                rz[p].x = zsc.x * (rz[p].x - zc1.x - (h.x - zmu.x) * zis.x * zc2.x);
+                rz[p].y = zsc.y * (rz[p].y - zc1.y - (h.y - zmu.y) * zis.y * zc2.y);
+                rz[p].z = zsc.z * (rz[p].z - zc1.z - (h.z - zmu.z) * zis.z * zc2.z);
+                rz[p].w = zsc.w * (rz[p].w - zc1.w - (h.w - zmu.w) * zis.w * zc2.w);
+            }
+            dbacc.x += rz[p].x; dbacc.y += rz[p].y; dbacc.z += rz[p].z; dbacc.w += rz[p].w;
+        }
+#pragma unroll
+        for (int p = 0; p < AP; p++) {
+            const int r = r0 + arow + (512 / AT) * p;
+            bool av = r < r_end && acol_ok;
+            int src = r;
+            if (av && a.gather) { src = a.gather[r]; av = src >= 0; }
+            ra[p] = av ? *reinterpret_cast<const float4*>(a.A + (size_t)src * a.lda + acol) : make_float4(0.f, 0.f, 0.f, 0.f);
+            if (APRO && r < r_end && acol_ok) {
+                const int s = seg_of_row(a.seg, r);
+                if (s != aseg) {
+                    asc = *reinterpret_cast<const float4*>(a.pscale + (size_t)s * a.Ni + acol);
+                    ash = *reinterpret_cast<const float4*>(a.pshift + (size_t)s * a.Ni + acol);
+                    aseg = s;
+                }
+                ra[p].x = fast_tanh(ra[p].x * asc.x + ash.x);
+                ra[p].y = fast_tanh(ra[p].y * asc.y + ash.y);
+                ra[p].z = fast_tanh(ra[p].z * asc.z + ash.z);
+                ra[p].w = fast_tanh(ra[p].w * asc.w + ash.w);
+            }
+        }
+    };
+    auto lstore = [&](int buf) {
+        float* Zs = smem + buf * STAGE;
+        float* As = Zs + TK * NO;
+#pragma unroll
+        for (int p = 0; p < ZP; p++) *reinterpret_cast<float4*>(&Zs[(zrow + (512 / ZT) * p) * NO + zcol]) = rz[p];
+#pragma unroll
+        for (int p = 0; p < AP; p++) *reinterpret_cast<float4*>(&As[(arow + (512 / AT) * p) * NI + acol]) = ra[p];
+    };
+
+    f32x16 acc[TO][TI];
+#pragma unroll
+    for (int i = 0; i < TO; i++)
+#pragma unroll
+        for (int j = 0; j < TI; j++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) acc[i][j][r] = 0.f;
+
+    const int nchunk = (r_end - r_begin + TK - 1) / TK;
+    if (nchunk > 0) {
+        gload(r_begin);
+        lstore(0);
+    }
+    __syncthreads();
+    const int fz = (lane >> 5) * NO + wo * (TO * 32) + (lane & 31);
+    const int fa = (lane >> 5) * NI + wi * (TI * 32) + (lane & 31);
+    for (int c = 0; c < nchunk; c++) {
+        const int cur = c & 1;
+        if (c + 1 < nchunk) gload(r_begin + (c + 1) * TK);
+        const float* Zs = smem + cur * STAGE + fz;
+        const float* As = smem + cur * STAGE + TK * NO + fa;
+#pragma unroll
+        for (int k = 0; k < TK; k += 2) {
+            float z[TO], x[TI];
+#pragma unroll
+            for (int i = 0; i < TO; i++) z[i] = Zs[k * NO + 32 * i];
+#pragma unroll
+            for (int j = 0; j < TI; j++) x[j] = As[k * NI + 32 * j];
+#pragma unroll
+            for (int i = 0; i < TO; i++)
+#pragma unroll
+                for (int j = 0; j < TI; j++) acc[i][j] = mfma32(z[i], x[j], acc[i][j]);
+        }
+        if (c + 1 < nchunk) lstore(cur ^ 1);
+        __syncthreads();
+    }
+
+    float* slab = a.slabs + (size_t)split * ((size_t)a.No * a.Ni + a.No);
+#pragma unroll
+    for (int i = 0; i < TO; i++)
+#pragma unroll
+        for (int j = 0; j < TI; j++) {
+            const int ci = wi * (TI * 32) + j * 32 + (lane & 31);
+#pragma unroll
+            for (int reg = 0; reg < 16; reg++) {
+                const int o = wo * (TO * 32) + i * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5);
+                if (o < a.No && ci < a.Ni) slab[(size_t)o * a.Ni + ci] = acc[i][j][reg];
+            }
+        }
+    if (a.db) {
+        float* red = smem;                                // [512/ZT row groups][NO]; all MFMA reads are done
+        *reinterpret_cast<float4*>(&red[zrow * NO + zcol]) = dbacc;
+        __syncthreads();
+        if (tid < NO && tid < a.No) {
+            float s = 0.f;
+#pragma unroll
+            for (int g = 0; g < 512 / ZT; g++) s += red[g * NO + tid];
+            slab[(size_t)a.No * a.Ni + tid] = s;
+        }
+    }
+}
+
 // out[j] (+)= sum_s slabs[s][j], j over [No*Ni] then [No] (bias).  Eight lanes share one float4 of
 // outputs: lane g sums slabs g, g+8, ... and the eight partial sums fold in a fixed xor order
 // (bitwise reproducible), so a 256x256 gradient keeps ~500 workgroups streaming from HBM.
@@ -175,10 +319,19 @@ __global__ __launch_bounds__(256) void tn_reduce_kernel(const float* slabs, int 
     }
 }
 
+static bool tn_full_tile(int R, int No, int Ni) {
+    return R >= 8192 && No <= 256 && Ni <= 256 && (No > 128 || Ni > 128) && No % 64 == 0 && Ni % 64 == 0;
+}
+
 static void tn_plan(int R, int No, int Ni, int* nsplit, int* rows_per_split) {
-    const int tiles = ((No + TM - 1) / TM) * ((Ni + TM - 1) / TM);
-    int s = (512 + tiles - 1) / tiles;             // ~2 workgroups per CU in total
-    const int max_s = (R + 255) / 256;             // at least 8 chunks of 32 rows per split
+    int s;
+    if (tn_full_tile(R, No, Ni)) {
+        s = 256;                                       // one workgroup per CU owns the whole dW
+    } else {
+        const int tiles = ((No + TM - 1) / TM) * ((Ni + TM - 1) / TM);
+        s = (512 + tiles - 1) / tiles;                 // ~2 workgroups per CU in total
+    }
+    const int max_s = (R + 255) / 256;                 // at least 8 chunks of 32 rows per split
     if (s > max_s) s = max_s;
     if (s < 1) s = 1;
     int rps = (R + s - 1) / s;
@@ -202,8 +355,22 @@ int launch_gemm_tn(const TnArgs& a, hipStream_t st) {
     tn_plan(a.R, a.No, a.Ni, &nsplit, &rps);
     if ((size_t)nsplit * ((size_t)a.No * a.Ni + a.No) > a.slab_floats) return PC_EWORKSPACE;
     const int tiles_o = (a.No + TM - 1) / TM, tiles_i = (a.Ni + TM - 1) / TM;
+    const bool apro = a.prologue == NT_PRO_BNTANH, zpro = a.zaux != nullptr;
     const int pb = pc_prof_begin(PC_KIND_GEMM_TN, 2.0 * a.R * (double)a.No * a.Ni, st);
-    PC_LAUNCH(gemm_tn_kernel, dim3(tiles_o * tiles_i * nsplit), dim3(256), 0, st, a, tiles_i, nsplit, rps);
+    if (tn_full_tile(a.R, a.No, a.Ni) && !(apro && zpro)) {
+#define TN8(WO, WI, TO, TI)                                                                                   \
+    do {                                                                                                      \
+        if (apro) PC_LAUNCH((gemm_tn8_kernel<WO, WI, TO, TI, true, false>), dim3(nsplit), dim3(512), 0, st, a, nsplit, rps);       \
+        else if (zpro) PC_LAUNCH((gemm_tn8_kernel<WO, WI, TO, TI, false, true>), dim3(nsplit), dim3(512), 0, st, a, nsplit, rps);  \
+        else PC_LAUNCH((gemm_tn8_kernel<WO, WI, TO, TI, false, false>), dim3(nsplit), dim3(512), 0, st, a, nsplit, rps);           \
+    } while (0)
+        if (a.No > 128 && a.Ni > 128) TN8(2, 4, 4, 2);
+        else if (a.No > 128) TN8(4, 2, 2, 2);
+        else TN8(2, 4, 2, 2);
+#undef TN8
+    } else {
+        PC_LAUNCH(gemm_tn_kernel, dim3(tiles_o * tiles_i * nsplit), dim3(256), 0, st, a, tiles_i, nsplit, rps);
+    }
     pc_prof_end(pb, st);
     PC_TRY(pc_launch_status());
     const int n_w = a.No * a.Ni, n_b = a.No;
