@@ -279,6 +279,15 @@ int pc_linear_backward_weight(const float *dy, int rows, int out_dim, const floa
  * val_out[B,k] (may be NULL); descending, ties -> lower index first; k <= 8. */
 int pc_topk_rows(const float *sims, int batch, int num_types, int k, int32_t *idx_out,
                  float *val_out, void *stream);
+/* Metrics.evaluate_model pieces (src/utils/metrics.py:62-117).
+ * pc_hit_rank: rank[r] = number of entries of sims[r,:] that beat the ground-truth column
+ *   gt = r (ties towards the lower index); hit@k <=> rank[r] < k.  Rows r >= cols can never
+ *   hit (rank = INT_MAX): the reference compares arange(B*K) with B columns (metrics.py:95-100).
+ * pc_cosine_rows: out[b*K+k] = cosine_similarity(x[b,k,:], y[b,:]) with torch's eps 1e-8
+ *   (metrics.py:44-60).  D = 128. */
+int pc_hit_rank(const float *sims, int rows, int cols, int32_t *rank, void *stream);
+int pc_cosine_rows(const float *x, const float *y, int batch, int k, float *out, void *stream);
+
 /* item_prediction.py:38: proj[b,k,:] = pi[b,:] * tp[b*K+k,:] and its backward
  * (dpi[b] = sum_k dproj[b,k]*tp[b,k]; dtp[b,k] = dproj[b,k]*pi[b]).  D = 128. */
 int pc_hadamard_forward(const float *pi, const float *tp, int batch, int k, float *proj,

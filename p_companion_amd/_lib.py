@@ -96,6 +96,8 @@ SIGNATURES = {
     "pc_linear_backward_weight_workspace_bytes": (_sz, [_i, _i, _i]),
     "pc_linear_backward_weight": (_i, [_vp, _i, _i, _vp, _vp, _i, _vp, _vp, _i, _vp, _sz, _vp]),
     "pc_topk_rows": (_i, [_vp, _i, _i, _i, _vp, _vp, _vp]),
+    "pc_hit_rank": (_i, [_vp, _i, _i, _vp, _vp]),
+    "pc_cosine_rows": (_i, [_vp, _vp, _i, _i, _vp, _vp]),
     "pc_hadamard_forward": (_i, [_vp, _vp, _i, _i, _vp, _vp]),
     "pc_hadamard_backward": (_i, [_vp, _vp, _vp, _i, _i, _vp, _vp, _vp]),
     "pc_gather_rows": (_i, [_vp, _vp, _i, _i, _vp, _vp]),

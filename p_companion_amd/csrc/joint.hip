@@ -12,7 +12,7 @@
 
 int launch_transpose(const float* in, int rows, int cols, float* out, hipStream_t st);
 
-#define JMAX_K 8
+#define JMAX_K 8   /* top-k capacity of topk_rows_kernel (NUM_COMP_TYPES = 3 in config.py:24) */
 #define LH (PC_L / 2)
 
 static inline size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
@@ -285,6 +285,53 @@ extern "C" int pc_expand_type_grad(const float* dsims_val, const int32_t* pos_ty
     if (!dsims_val || !pos_types || !neg_types || !dense || batch <= 0 || num_types <= 0) return PC_EINVAL;
     PC_LAUNCH(expand_type_grad_kernel, dim3(batch), dim3(256), 0, (hipStream_t)stream, dsims_val, pos_types,
                        neg_types, batch, num_types, dense);
+    return pc_launch_status();
+}
+
+// ---------------------------------------------------------------------------------------
+// Metrics.evaluate_model pieces (src/utils/metrics.py:62-117), one wave per row.
+//   hit@k (metrics.py:7-27): row r hits iff its ground-truth column gt = r is among the k largest
+//   of sims[r,:]; equivalently fewer than k entries beat sims[r,gt] (ties broken towards the
+//   lower index, as pc_topk_rows does).  gt >= cols can never hit: the reference compares
+//   arange(B*K) against only B columns (metrics.py:95-100) -- reproduced.
+__global__ __launch_bounds__(256) void hit_rank_kernel(const float* sims, int rows, int cols, int32_t* rank) {
+    const int lane = threadIdx.x & 63;
+    const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= rows) return;
+    if (r >= cols) { if (lane == 0) rank[r] = 0x7fffffff; return; }
+    const float* row = sims + (size_t)r * cols;
+    const float g = row[r];
+    int beat = 0;
+    for (int c = lane; c < cols; c += 64) {
+        const float v = row[c];
+        beat += (v > g || (v == g && c < r)) ? 1 : 0;
+    }
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) beat += __shfl_xor(beat, o, 64);
+    if (lane == 0) rank[r] = beat;
+}
+
+extern "C" int pc_hit_rank(const float* sims, int rows, int cols, int32_t* rank, void* stream) {
+    if (!sims || !rank || rows <= 0 || cols <= 0) return PC_EINVAL;
+    PC_LAUNCH(hit_rank_kernel, dim3((rows + 3) / 4), dim3(256), 0, (hipStream_t)stream, sims, rows, cols, rank);
+    return pc_launch_status();
+}
+
+//   mean_relevance (metrics.py:44-60): cos[b,k] = <x_bk, y_b> / (max(|x_bk|,eps) * max(|y_b|,eps)), eps 1e-8
+__global__ __launch_bounds__(256) void cosine_rows_kernel(const float* x, const float* y, int B, int K, float* out) {
+    const int lane = threadIdx.x & 63;
+    const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= B * K) return;
+    const float2 a = *reinterpret_cast<const float2*>(x + (size_t)r * PC_D + 2 * lane);
+    const float2 b = *reinterpret_cast<const float2*>(y + (size_t)(r / K) * PC_D + 2 * lane);
+    const float dot = wave_sum(a.x * b.x + a.y * b.y);
+    const float na = sqrtf(wave_sum(a.x * a.x + a.y * a.y)), nb = sqrtf(wave_sum(b.x * b.x + b.y * b.y));
+    if (lane == 0) out[r] = dot / (fmaxf(na, 1e-8f) * fmaxf(nb, 1e-8f));
+}
+
+extern "C" int pc_cosine_rows(const float* x, const float* y, int batch, int k, float* out, void* stream) {
+    if (!x || !y || !out || batch <= 0 || k <= 0) return PC_EINVAL;
+    PC_LAUNCH(cosine_rows_kernel, dim3((batch * k + 3) / 4), dim3(256), 0, (hipStream_t)stream, x, y, batch, k, out);
     return pc_launch_status();
 }
 

@@ -525,3 +525,19 @@ def act_backward(dy, y, act):
     dx = torch.empty_like(dy)
     check(_lib.lib().pc_act_backward(_p(dy), _p(y), dy.numel(), act, _p(dx), _stream()), "pc_act_backward")
     return dx
+
+
+def hit_rank(sims):
+    rows, cols = sims.shape
+    _req(sims, torch.float32, "similarities")
+    rank = torch.empty(rows, dtype=torch.int32, device=sims.device)
+    check(_lib.lib().pc_hit_rank(_p(sims), rows, cols, _p(rank), _stream()), "pc_hit_rank")
+    return rank
+
+
+def cosine_rows(x, y):
+    b, k, _ = x.shape
+    _req(x, torch.float32, "predictions", (b, k, D)); _req(y, torch.float32, "ground_truth", (b, D))
+    out = torch.empty(b * k, dtype=torch.float32, device=x.device)
+    check(_lib.lib().pc_cosine_rows(_p(x), _p(y), b, k, _p(out), _stream()), "pc_cosine_rows")
+    return out

@@ -1,0 +1,95 @@
+"""Phase drivers -- counterparts of scripts/pretrain_product2vec.py:11-53 and train.py:16-72.
+
+Same call signatures and the same checkpoint dict layouts (so files interchange with the
+reference): product2vec.pth = {'model_state_dict', 'embeddings', 'type_to_idx'};
+best_model.pth = {'epoch', 'model_state_dict', 'optimizer_state_dict', 'metrics'}."""
+import logging
+import os
+from typing import Dict
+
+import torch
+
+from .data import ComplementaryIndexDataset, ComplementaryIndexLoader, IntBPG, SimilarityIndexLoader
+from .metrics import Metrics
+from .p_companion import PCompanion
+from .product2vec import FusedAdam, Product2Vec
+
+
+def pretrain_product2vec(config, similarity_dataset) -> Dict[str, torch.Tensor]:
+    """Pretrain Product2Vec model and save embeddings (scripts/pretrain_product2vec.py:11-53).
+    `similarity_dataset`: an IntBPG (index loader built here), an index loader, or any iterable
+    of reference-style dense batches with a .dataset.bpg attribute."""
+    logger = logging.getLogger(__name__)
+    if isinstance(similarity_dataset, IntBPG):
+        loader = SimilarityIndexLoader(similarity_dataset, config.BATCH_SIZE, shuffle=True, sampler="philox",
+                                       device=config.DEVICE)
+    else:
+        loader = similarity_dataset
+    model = Product2Vec(config).to(config.DEVICE)
+    optimizer = FusedAdam(model, lr=config.LEARNING_RATE)
+    embeddings_dict = model.train_model(train_loader=loader, optimizer=optimizer, num_epochs=config.PRODUCT2VEC_EPOCHS)
+    os.makedirs(config.MODEL_DIR, exist_ok=True)
+    save_path = os.path.join(config.MODEL_DIR, "product2vec.pth")
+    bpg = loader.dataset.bpg
+    torch.save({"model_state_dict": {k: v.detach().cpu() for k, v in model.state_dict().items()},
+                "embeddings": embeddings_dict,
+                "type_to_idx": bpg.type_to_idx if hasattr(bpg, "type_to_idx") else None}, save_path)
+    logger.info(f"Saved pretrained Product2Vec model and embeddings to {save_path}")
+    pretrain_product2vec.last_model = model
+    return embeddings_dict
+
+
+def train(config, train_loader, val_loader, pretrained_embeddings, fused=True):
+    """Train P-Companion model (train.py:16-72): loop, per-epoch Metrics.evaluate_model, best
+    hit@10 checkpoint.  fused=True runs the loop body as pc_joint_train_step + one Adam launch;
+    fused=False runs model(batch) / compute_loss / backward / torch Adam like the reference."""
+    logger = logging.getLogger(__name__)
+    model = PCompanion(config, pretrained_embeddings).to(config.DEVICE)
+    optimizer = FusedAdam(model, lr=config.LEARNING_RATE) if fused else \
+        torch.optim.Adam(model.parameters(), lr=config.LEARNING_RATE)
+    best_hit10 = 0.0
+    for epoch in range(config.NUM_EPOCHS):
+        model.train()
+        total = None
+        nb = 0
+        for batch in train_loader:
+            batch = {k: v.to(config.DEVICE) if isinstance(v, torch.Tensor) else v for k, v in batch.items()}
+            if fused:
+                losses, _ = model.train_step(batch)
+                loss = losses[0:1]
+            else:
+                outputs = model(batch)
+                loss = model.compute_loss(batch, outputs)
+                optimizer.zero_grad()
+                loss.backward()
+                loss = loss.detach().reshape(1)
+            optimizer.step()
+            total = loss.clone() if total is None else total + loss
+            nb += 1
+        if nb:
+            logger.info(f"Epoch {epoch + 1}/{config.NUM_EPOCHS}, Loss: {float(total) / nb:.4f}")
+        metrics = Metrics.evaluate_model(model, val_loader, config.DEVICE)
+        for name, value in metrics.items():
+            logger.info(f"{name}: {value:.4f}")
+        if metrics["hit@10"] > best_hit10:
+            best_hit10 = metrics["hit@10"]
+            os.makedirs(config.MODEL_DIR, exist_ok=True)
+            torch.save({"epoch": epoch,
+                        "model_state_dict": {k: v.detach().cpu() for k, v in model.state_dict().items()},
+                        "optimizer_state_dict": optimizer.state_dict() if not fused else
+                        {"exp_avg": optimizer.exp_avg.cpu(), "exp_avg_sq": optimizer.exp_avg_sq.cpu(),
+                         "step": int(optimizer.step_count)},
+                        "metrics": metrics}, os.path.join(config.MODEL_DIR, "best_model.pth"))
+        logger.info(f"Best Hit@10: {best_hit10:.4f}")
+    return model
+
+
+def main(config, bpg: IntBPG):
+    """train.py:74-134 on an integer BPG: Product2Vec pretrain -> embeddings -> P-Companion."""
+    embeddings = pretrain_product2vec(config, bpg)
+    table = pretrain_product2vec.last_model.last_embedding_table
+    tr = ComplementaryIndexLoader(ComplementaryIndexDataset(bpg, "train"), config.BATCH_SIZE, shuffle=True,
+                                  device=config.DEVICE)
+    va = ComplementaryIndexLoader(ComplementaryIndexDataset(bpg, "val"), config.BATCH_SIZE, shuffle=False,
+                                  device=config.DEVICE)
+    return train(config, tr, va, table if table is not None else embeddings)

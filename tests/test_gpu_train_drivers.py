@@ -1,0 +1,84 @@
+"""Phase drivers and metrics on the GPU: Metrics.evaluate_model vs the reference's golden value,
+pretrain_product2vec / train end to end on the reference's own 1k-product graph, checkpoint
+layouts.  Needs an MI355X."""
+import os
+from types import SimpleNamespace
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import joint_oracle
+
+
+def cfg(tmp, **over):
+    c = SimpleNamespace(PRODUCT_EMB_DIM=128, TYPE_EMB_DIM=64, HIDDEN_SIZE=256, NUM_ATTENTION_HEADS=4, DROPOUT=0.0,
+                        MARGIN=1.0, ALPHA=0.8, NUM_COMP_TYPES=3, NUM_TYPES=100, DEVICE=torch.device("cuda"),
+                        LEARNING_RATE=1e-3, BATCH_SIZE=256, PRODUCT2VEC_EPOCHS=1, NUM_EPOCHS=2, MODEL_DIR=str(tmp))
+    c.__dict__.update(over)
+    return c
+
+
+def test_metrics_golden(golden, tmp_path):
+    from p_companion_amd.metrics import Metrics
+    from p_companion_amd.p_companion import PCompanion
+    g = golden("g8_metrics.npz")
+    st = {k[5:]: torch.from_numpy(g[k]).clone() for k in g.files if k.startswith("init.")}
+    c = cfg(tmp_path)
+    model = PCompanion(c, st["product_embeddings.weight"])
+    model.load_state_dict(st)
+    model = model.to(c.DEVICE)
+    batch = {"query_idx": torch.from_numpy(g["query_idx"]), "query_types": torch.from_numpy(g["query_types"]),
+             "positive_items": torch.from_numpy(g["positive_items"]), "target_features": torch.from_numpy(g["target_features"])}
+    m = Metrics.evaluate_model(model, [batch], c.DEVICE)
+    for name, val in zip(g["metric_names"], g["metric_values"]):
+        assert abs(m[str(name)] - float(val)) < 1e-5, (name, m[str(name)], float(val))
+    # rows >= B can never hit (metrics.py:95-100): hit@k is bounded by 1/K
+    assert m["hit@10"] <= 1.0 / 3 + 1e-6
+
+
+def test_hit_rank_and_cosine_vs_torch():
+    from p_companion_amd import ops
+    g = torch.Generator().manual_seed(0)
+    sims = torch.randn(30, 10, generator=g)
+    rank = ops.hit_rank(sims.cuda()).cpu()
+    for k in (1, 3, 10):
+        top = torch.topk(sims, k, dim=1).indices
+        want = (top == torch.arange(30).unsqueeze(1)).any(1)
+        assert torch.equal(rank < k, want)
+    x, y = torch.randn(7, 3, 128, generator=g), torch.randn(7, 128, generator=g)
+    cos = ops.cosine_rows(x.cuda(), y.cuda()).cpu().view(7, 3)
+    np.testing.assert_allclose(cos, torch.cosine_similarity(x, y.unsqueeze(1), dim=-1), atol=1e-6)
+
+
+def test_pipeline_end_to_end(golden, tmp_path):
+    """train.py:main() on the reference's own 1k-product graph: both phases, checkpoints in the
+    reference's dict layouts, loss decreasing."""
+    from p_companion_amd import train as drv
+    from p_companion_amd.data import (ComplementaryIndexDataset, ComplementaryIndexLoader, IntBPG,
+                                      SimilarityIndexLoader)
+    bpg = IntBPG.from_arrays(golden("g2_bpg1000.npz"))
+    c = cfg(tmp_path, NUM_TYPES=bpg.n_types, PRODUCT2VEC_EPOCHS=3)
+    torch.manual_seed(0)
+    emb = drv.pretrain_product2vec(c, bpg)
+    assert len(emb) == 1000
+    ck = torch.load(os.path.join(c.MODEL_DIR, "product2vec.pth"), weights_only=True)
+    assert set(ck) == {"model_state_dict", "embeddings", "type_to_idx"}                # pretrain_product2vec.py:44-49
+    assert "ffn.1.running_var" in ck["model_state_dict"] and ck["embeddings"]["P000999"].shape == (128,)
+    tr = ComplementaryIndexLoader(ComplementaryIndexDataset(bpg, "train"), 256, shuffle=True)
+    va = ComplementaryIndexLoader(ComplementaryIndexDataset(bpg, "val"), 256, shuffle=False)
+    b = next(iter(tr))
+    assert b["positive_types"].shape == (256, 1) and b["query_types"].dtype == torch.int32
+    lab = b["label"].cpu().numpy()
+    tt = bpg.type_idx[bpg.complementary_pairs[0, 1]]            # spot-check the label rules (data_loader.py:148-153)
+    assert set(np.unique(lab).tolist()) <= {-1, 1}
+    assert bool((b["positive_types"].cpu().numpy()[lab == -1] == 0).all())
+    model = drv.train(c, tr, va, emb)
+    best = torch.load(os.path.join(c.MODEL_DIR, "best_model.pth"), weights_only=True)
+    assert set(best) == {"epoch", "model_state_dict", "optimizer_state_dict", "metrics"}      # train.py:63-70
+    assert set(best["metrics"]) == {"hit@1", "hit@3", "hit@10", "type_diversity", "mean_relevance"}
+    # reference-style (unfused, torch Adam) loop on the same data also runs
+    c2 = cfg(tmp_path, NUM_TYPES=bpg.n_types, NUM_EPOCHS=1)
+    drv.train(c2, tr, va, emb, fused=False)
