@@ -306,6 +306,11 @@ int pc_gather_rows(const float *table, const int32_t *idx, int rows, int width, 
  * is NOT guaranteed (float atomics); idx < 0 skipped. */
 int pc_scatter_add_rows(float *table, const int32_t *idx, int rows, int width, const float *src,
                         void *stream);
+/* Same for a SMALL destination table (table_rows*width*4 <= 64 KB, e.g. the [T,64] type tables
+ * at T ~ 100): source rows are first summed into a per-workgroup LDS copy of the table. Falls
+ * back to pc_scatter_add_rows for larger tables. */
+int pc_scatter_add_rows_small(float *table, int table_rows, const int32_t *idx, int rows, int width,
+                              const float *src, void *stream);
 
 /* out[idx[r]] = src[r] (row assignment, idx < 0 skipped): writes the attention-updated rows
  * back into the embedding table in the batched generate_all_embeddings pass

@@ -102,6 +102,7 @@ SIGNATURES = {
     "pc_hadamard_backward": (_i, [_vp, _vp, _vp, _i, _i, _vp, _vp, _vp]),
     "pc_gather_rows": (_i, [_vp, _vp, _i, _i, _vp, _vp]),
     "pc_scatter_add_rows": (_i, [_vp, _vp, _i, _i, _vp, _vp]),
+    "pc_scatter_add_rows_small": (_i, [_vp, _i, _vp, _i, _i, _vp, _vp]),
     "pc_scatter_rows": (_i, [_vp, _vp, _i, _i, _vp, _vp]),
     "pc_act_backward": (_i, [_vp, _vp, _sz, _i, _vp, _vp]),
 }

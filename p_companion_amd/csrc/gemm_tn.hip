@@ -331,7 +331,7 @@ static void tn_plan(int R, int No, int Ni, int* nsplit, int* rows_per_split) {
         const int tiles = ((No + TM - 1) / TM) * ((Ni + TM - 1) / TM);
         s = (512 + tiles - 1) / tiles;                 // ~2 workgroups per CU in total
     }
-    const int max_s = (R + 255) / 256;                 // at least 8 chunks of 32 rows per split
+    const int max_s = (R + 63) / 64;                   // at least 2 chunks of 32 rows per split (few rows: spread them)
     if (s > max_s) s = max_s;
     if (s < 1) s = 1;
     int rps = (R + s - 1) / s;

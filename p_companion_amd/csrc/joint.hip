@@ -11,6 +11,8 @@
 #include "common.h"
 
 int launch_transpose(const float* in, int rows, int cols, float* out, hipStream_t st);
+extern "C" int pc_scatter_add_rows_small(float* table, int table_rows, const int32_t* idx, int rows, int width,
+                                         const float* src, void* stream);
 
 #define JMAX_K 8   /* top-k capacity of topk_rows_kernel (NUM_COMP_TYPES = 3 in config.py:24) */
 #define LH (PC_L / 2)
@@ -459,7 +461,7 @@ extern "C" int pc_joint_backward(const pc_joint_tensors* p, const pc_joint_tenso
     PC_TRY(launch_gemm_tn(tt, st));
     // dE_c[topk] += dtp typ_w     (row-sparse: only the K selected rows per sample)
     PC_TRY(launch_gemm_nt(nt_plain(w.dtp, PC_D, w.typ_wt, PC_D, nullptr, w.dce, PC_L, B * K, PC_L, PC_D), st));
-    PC_TRY(pc_scatter_add_rows(g->comp_types, topk, B * K, PC_L, w.dce, stream));
+    PC_TRY(pc_scatter_add_rows_small(g->comp_types, T, topk, B * K, PC_L, w.dce, stream));
 
     // ---- type branch (two touched similarity columns per row)
     PC_LAUNCH(type_hinge_bwd_kernel, dim3((B + 3) / 4), dim3(256), 0, st, dsims_val, pos_types, neg_types,
@@ -478,7 +480,7 @@ extern "C" int pc_joint_backward(const pc_joint_tensors* p, const pc_joint_tenso
     te.slabs = w.slabs; te.slab_floats = w.slab_floats;
     PC_TRY(launch_gemm_tn(te, st));
     PC_TRY(launch_gemm_nt(nt_plain(w.dh, LH, w.enc_wt, LH, nullptr, w.dt, PC_L, B, PC_L, LH), st));
-    return pc_scatter_add_rows(g->query_types, query_types, B, PC_L, w.dt, stream);
+    return pc_scatter_add_rows_small(g->query_types, T, query_types, B, PC_L, w.dt, stream);
 }
 
 extern "C" int pc_joint_train_step(const pc_joint_tensors* p, const pc_joint_tensors* g, const int32_t* query_idx,

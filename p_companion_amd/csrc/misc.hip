@@ -172,12 +172,49 @@ __global__ void scatter_add_rows_kernel(float* table, const int32_t* idx, int ro
     if (dst >= 0) atomicAdd(table + (size_t)dst * width + c, src[t]);
 }
 
+// Small tables (the [T,64] type tables at T ~ 100: thousands of source rows collide on a few
+// destination rows): each workgroup first accumulates its slice of source rows into a private LDS
+// copy of the table (LDS atomics), then adds the copy to HBM once -> global atomic traffic and
+// same-address contention drop by the number of source rows per workgroup.
+__global__ __launch_bounds__(256) void scatter_add_rows_lds_kernel(float* table, const int32_t* idx, int rows,
+                                                                   int width, int table_rows, const float* src,
+                                                                   int rows_per_block) {
+    extern __shared__ float priv[];
+    const int n = table_rows * width;
+    for (int i = threadIdx.x; i < n; i += blockDim.x) priv[i] = 0.f;
+    __syncthreads();
+    const int r0 = blockIdx.x * rows_per_block, r1 = min(rows, r0 + rows_per_block);
+    for (int t = r0 * width + threadIdx.x; t < r1 * width; t += blockDim.x) {
+        const int dst = idx[t / width];
+        if (dst >= 0) atomicAdd(&priv[dst * width + t % width], src[t]);
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < n; i += blockDim.x) {
+        const float v = priv[i];
+        if (v != 0.f) atomicAdd(table + i, v);
+    }
+}
+
 extern "C" int pc_scatter_add_rows(float* table, const int32_t* idx, int rows, int width, const float* src,
                                    void* stream) {
     if (!table || !idx || !src || rows <= 0 || width <= 0) return PC_EINVAL;
     const size_t total = (size_t)rows * width;
-    PC_LAUNCH(scatter_add_rows_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0,
-                       (hipStream_t)stream, table, idx, rows, width, src);
+    PC_LAUNCH(scatter_add_rows_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+              table, idx, rows, width, src);
+    return pc_launch_status();
+}
+
+// same, when the caller knows the destination table is small (table_rows * width * 4 <= 64 KB)
+extern "C" int pc_scatter_add_rows_small(float* table, int table_rows, const int32_t* idx, int rows, int width,
+                                         const float* src, void* stream) {
+    if (!table || !idx || !src || rows <= 0 || width <= 0 || table_rows <= 0) return PC_EINVAL;
+    const size_t bytes = (size_t)table_rows * width * sizeof(float);
+    if (bytes > 65536) return pc_scatter_add_rows(table, idx, rows, width, src, stream);
+    int blocks = (rows + 127) / 128;
+    if (blocks > 256) blocks = 256;
+    const int rpb = (rows + blocks - 1) / blocks;
+    PC_LAUNCH(scatter_add_rows_lds_kernel, dim3(blocks), dim3(256), bytes, (hipStream_t)stream, table, idx, rows, width,
+              table_rows, src, rpb);
     return pc_launch_status();
 }
 
