@@ -121,6 +121,38 @@ __global__ __launch_bounds__(64 * NWM * NWN, OCC) void gemm_nt_kernel(NtArgs a, 
                 for (int r = 0; r < 16; r++) acc[i][j][r] = 0.f;
     };
 
+    // aux operand of the d-activation epilogues, prefetched during the tile's LAST K-step in the
+    // layout the staged epilogue reads: [nt][mt][i] -> rows er+8i of sub-tile (mt,nt), cols ec..ec+3
+    constexpr bool HAS_AUX_ANY = EPI == NT_EPI_DTANH || EPI == NT_EPI_DTANH_BN || EPI == NT_EPI_DRELU;
+    constexpr bool HAS_AUX_K = HAS_AUX_ANY && NWM * NWN == 8;      // register budget: the 8-wave kernel only
+    constexpr int NAUX = HAS_AUX_K ? 16 : 1;
+    float4 auxr[NAUX];
+    const bool vec_k = ((a.N | a.ldc) & 3) == 0 && (!a.aux || (a.ldaux & 3) == 0);
+    auto aux_prefetch = [&]() {
+        if (!HAS_AUX_K) return;
+#pragma unroll
+        for (int nt = 0; nt < 2; nt++)
+#pragma unroll
+            for (int mt = 0; mt < 2; mt++)
+#pragma unroll
+                for (int i = 0; i < 4; i++) {
+                    const int row = row0 + wm * 64 + mt * 32 + (lane >> 3) + 8 * i;
+                    const int col = n0 + wn * 64 + nt * 32 + (lane & 7) * 4;
+                    float4 x4 = make_float4(0.f, 0.f, 0.f, 0.f);
+                    if (row < row_end) {
+                        if (vec_k && col + 3 < a.N) {
+                            x4 = *reinterpret_cast<const float4*>(a.aux + (size_t)row * a.ldaux + col);
+                        } else {
+                            if (col + 0 < a.N) x4.x = a.aux[(size_t)row * a.ldaux + col + 0];
+                            if (col + 1 < a.N) x4.y = a.aux[(size_t)row * a.ldaux + col + 1];
+                            if (col + 2 < a.N) x4.z = a.aux[(size_t)row * a.ldaux + col + 2];
+                            if (col + 3 < a.N) x4.w = a.aux[(size_t)row * a.ldaux + col + 3];
+                        }
+                    }
+                    auxr[HAS_AUX_K ? (nt * 2 + mt) * 4 + i : 0] = x4;
+                }
+    };
+
     if (tile >= total_tiles) return;
     if ((dbg & 16) && (blockIdx.x & 256)) { __builtin_amdgcn_s_sleep(100); }   // probe: phase-shift half of the blocks
     tile_geom(tile, row0, row_end, n0, seg);
@@ -146,6 +178,7 @@ __global__ __launch_bounds__(64 * NWM * NWN, OCC) void gemm_nt_kernel(NtArgs a, 
 
         for (int kt = 0; kt < nk; kt++) {
             bool loaded = false;
+            if (kt + 1 == nk) aux_prefetch();               // older than the prefetch below: its wait never covers it
             if (dbg & 2) { loaded = true; }
             else if (kt + 1 < nk) { gload((kt + 1) * BK, aptr, aval, wptr, wval, seg); loaded = true; }
             else if (ntile < total_tiles) {
@@ -231,7 +264,10 @@ __global__ __launch_bounds__(64 * NWM * NWN, OCC) void gemm_nt_kernel(NtArgs a, 
                     float v[4] = {v4.x, v4.y, v4.z, v4.w};
                     float ax[4] = {0.f, 0.f, 0.f, 0.f};
                     const bool rok = row < row_end;
-                    if (rok && HAS_AUX) {
+                    if (HAS_AUX_K) {
+                        const float4 x4 = auxr[HAS_AUX_K ? (nt * 2 + mt) * 4 + i : 0];
+                        ax[0] = x4.x; ax[1] = x4.y; ax[2] = x4.z; ax[3] = x4.w;
+                    } else if (rok && HAS_AUX) {
                         if (vec && col + 3 < a.N) {
                             const float4 x4 = *reinterpret_cast<const float4*>(a.aux + (size_t)row * a.ldaux + col);
                             ax[0] = x4.x; ax[1] = x4.y; ax[2] = x4.z; ax[3] = x4.w;
