@@ -46,8 +46,10 @@ def cpu_baseline(bpg, batch, seconds=15.0):
     from oracle import p2v_oracle
     st = p2v_oracle.init_state(0)
     feats = torch.from_numpy(bpg.features)
+    nbc = batch["neighbor_compact"]
+    nb_dense = nbc["nb_rows"].cpu().numpy()[nbc["slot_row"].cpu().numpy()]      # the reference's padded [B,N] layout
     dense = p2v_oracle.gather_batch(feats, batch["anchor_idx"].cpu().numpy(), batch["positive_idx"].cpu().numpy(),
-                                    batch["negative_idx"].cpu().numpy(), batch["neighbor_idx"].cpu().numpy())
+                                    batch["negative_idx"].cpu().numpy(), nb_dense)
     mom = p2v_oracle.new_moments(st)
     b = dense["anchor"].shape[0]
     p2v_oracle.train_step(st, dense, 1.0, mom, 1)            # warm-up
@@ -113,17 +115,19 @@ def main():
     it = batches()
     prof = ops.KernelProfile(capacity=32 * max(args.steps, 1))
     n_sum = 0
+    real_sum = 0
 
     def step(b, profile=None):
         tab = table
         if sharded is not None:
-            ids = torch.cat([b["anchor_idx"], b["neighbor_idx"].reshape(-1), b["positive_idx"],
-                             b["negative_idx"].reshape(-1)])
+            nbc = b["neighbor_compact"]
+            ids = torch.cat([b["anchor_idx"], nbc["nb_rows"], b["positive_idx"], b["negative_idx"].reshape(-1)])
             tab, remap = sharded.lookup(ids)
-            B, N, K = b["anchor_idx"].numel(), b["neighbor_idx"].shape[1], b["negative_idx"].shape[1]
-            o = np.cumsum([0, B, B * N, B, B * K])
-            b = {"anchor_idx": remap[o[0]:o[1]].contiguous(), "neighbor_idx": remap[o[1]:o[2]].view(B, N).contiguous(),
-                 "positive_idx": remap[o[2]:o[3]].contiguous(), "negative_idx": remap[o[3]:o[4]].view(B, K).contiguous()}
+            B, M1, K = b["anchor_idx"].numel(), nbc["nb_rows"].numel(), b["negative_idx"].shape[1]
+            o = np.cumsum([0, B, M1, B, B * K])
+            b = {"anchor_idx": remap[o[0]:o[1]].contiguous(), "positive_idx": remap[o[2]:o[3]].contiguous(),
+                 "negative_idx": remap[o[3]:o[4]].view(B, K).contiguous(),
+                 "neighbor_compact": {"nb_rows": remap[o[1]:o[2]].contiguous(), "slot_row": nbc["slot_row"]}}
         loss = model.train_step_indexed(tab, b, profile=profile)
         pdist.all_reduce_mean_(gflat, world)
         opt.step()
@@ -139,7 +143,8 @@ def main():
     t0 = time.perf_counter()
     for _ in range(args.steps):
         last = next(it)
-        n_sum += last["neighbor_idx"].shape[1]
+        n_sum += last["n_pad"]
+        real_sum += last["neighbor_compact"]["nb_rows"].numel() - 1
         loss = step(last, profile=prof)
     torch.cuda.synchronize()
     if world > 1:
@@ -177,7 +182,9 @@ def main():
            "config": {"workload": f"Product2Vec GAT pretrain, {args.products} products, {args.types} types, dim=128, "
                                   f"batch={args.batch}/GPU, 5 negatives, neighbours padded to batch max "
                                   f"(avg N={n_avg:.1f})", "global_batch": world * args.batch,
-                      "table": args.table, "parallelism": f"dp{world}", "final_loss": round(float(loss), 5)},
+                      "table": args.table, "parallelism": f"dp{world}", "final_loss": round(float(loss), 5),
+                      "padding_slots": "carried once (compact rows): avg %.0f real + 1 shared of %d neighbour slots per step"
+                                       % (real_sum / max(args.steps, 1), args.batch * round(n_avg))},
            "roofline": roof}
     if not args.no_cpu_baseline and world == 1:
         out["cpu_baseline"] = cpu_baseline(bpg, last, args.cpu_seconds)

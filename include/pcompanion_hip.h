@@ -60,6 +60,14 @@ typedef struct {
 typedef struct {
     int nseg;
     int start[PC_MAX_SEG + 1];
+    /* Optional row multiplicity (index path): at most ONE row of the launch, `weighted_row`
+     * (-1 = none), stands for `weight` identical rows -- the all-zero padding rows collate_fn
+     * appends to short neighbour lists (data_loader.py:186-198) are bit-identical inputs, so
+     * they are carried once.  count[s] (0 = physical row count) is the LOGICAL number of rows of
+     * segment s, i.e. what BatchNorm divides by. */
+    int count[PC_MAX_SEG];
+    int weighted_row;
+    float weight;
 } pc_segments;
 
 /* Saved-for-backward activations of one FFN launch over R rows (caller allocates). */
@@ -149,6 +157,29 @@ int pc_p2v_train_step(const pc_p2v_tensors *p, const pc_p2v_tensors *g, const fl
                       int n_nbr, int k_neg, float margin, float *loss, float *d_pos,
                       float *d_neg, float *anchor_emb, void *profile, void *ws, size_t ws_bytes,
                       void *stream);
+
+/* Same step with the neighbour rows COMPACTED: collate_fn pads short neighbour lists with all-zero
+ * rows (data_loader.py:186-198) which the reference pushes through the FFN, BatchNorm and the
+ * attention like any other row.  They are bit-identical inputs, hence bit-identical rows at every
+ * layer, so the step carries them ONCE: nb_rows[n_real+1] = the real neighbours of the batch in slot
+ * order followed by one -1 row; slot_row[B*N] = row of each slot (padding slots -> n_real).  The
+ * shared row enters BatchNorm's statistics with weight B*N - n_real and collects the summed gradient
+ * of the slots it stands for (the backward is linear in it): same numbers as the dense step up to
+ * fp32 summation order, ~30% fewer rows at the benchmark's degree distribution.
+ * Built by pc_build_similarity_batch_compact (row_off: device scratch int32[B+1]). */
+int pc_p2v_train_step_compact(const pc_p2v_tensors *p, const pc_p2v_tensors *g, const float *table,
+                              const int32_t *anchor_idx, const int32_t *positive_idx,
+                              const int32_t *negative_idx, const int32_t *nb_rows, int n_real,
+                              const int32_t *slot_row, int batch, int n_nbr, int k_neg, float margin,
+                              float *loss, float *d_pos, float *d_neg, float *anchor_emb, void *profile,
+                              void *ws, size_t ws_bytes, void *stream);
+int pc_build_similarity_batch_compact(const int32_t *pair_ids, int batch, const int32_t *sim_pairs,
+                                      const int32_t *cv_rowptr, const int32_t *cv_col,
+                                      const int32_t *sim_rowptr, const int32_t *sim_col,
+                                      int n_products, int n_pad, int k_neg, uint64_t seed,
+                                      uint64_t step, int32_t *anchor_idx, int32_t *positive_idx,
+                                      int32_t *negative_idx, int32_t *nb_rows, int32_t *slot_row,
+                                      int32_t *row_off, void *stream);
 
 /* Optional measurement aid (bench.py's roofline leg; NULL everywhere else): a pool of HIP
  * events that pc_p2v_train_step records on its stream around each of its GEMM launches.

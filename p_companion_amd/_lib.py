@@ -28,7 +28,8 @@ class P2VTensors(ctypes.Structure):
 
 
 class Segments(ctypes.Structure):
-    _fields_ = [("nseg", ctypes.c_int), ("start", ctypes.c_int * (PC_MAX_SEG + 1))]
+    _fields_ = [("nseg", ctypes.c_int), ("start", ctypes.c_int * (PC_MAX_SEG + 1)),
+                ("count", ctypes.c_int * PC_MAX_SEG), ("weighted_row", ctypes.c_int), ("weight", ctypes.c_float)]
 
 
 class FfnSaved(ctypes.Structure):
@@ -71,6 +72,10 @@ SIGNATURES = {
     "pc_p2v_train_step_workspace_bytes": (_sz, [_i, _i, _i]),
     "pc_p2v_train_step": (_i, [_P(P2VTensors), _P(P2VTensors), _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _f, _vp, _vp,
                                _vp, _vp, _vp, _vp, _sz, _vp]),
+    "pc_p2v_train_step_compact": (_i, [_P(P2VTensors), _P(P2VTensors), _vp, _vp, _vp, _vp, _vp, _i, _vp, _i, _i, _i, _f,
+                                       _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "pc_build_similarity_batch_compact": (_i, [_vp, _i, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _u64, _u64, _vp, _vp, _vp,
+                                               _vp, _vp, _vp, _vp]),
     "pc_profile_create": (_i, [_i, _P(ctypes.c_void_p)]),
     "pc_profile_destroy": (_i, [_vp]),
     "pc_profile_reset": (_i, [_vp]),

@@ -17,8 +17,11 @@ int launch_transpose(const float* in, int rows, int cols, float* out, hipStream_
 #define HEAD_DIM (PC_D / PC_HEADS)
 
 // grid: ceil(B/4) blocks of 256; dynamic LDS: 4 waves * HEADS * N floats
+// slot_row (optional): key/value row of neighbour slot (b,n) inside kv -- the compact layout of
+// the index path, where every zero-padded slot points at ONE shared row (identical inputs give
+// identical K/V); NULL = dense layout, slot (b,n) is row b*N+n.
 __global__ __launch_bounds__(256) void attn_core_fwd_kernel(const float* q, const float* kv, int B, int N,
-                                                            float* ctx, float* probs) {
+                                                            float* ctx, float* probs, const int32_t* slot_row) {
     extern __shared__ float sc_all[];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, h = lane >> 4;
     const int b = blockIdx.x * 4 + w;
@@ -27,10 +30,12 @@ __global__ __launch_bounds__(256) void attn_core_fwd_kernel(const float* q, cons
     const float scale = 0.17677669529663687f;            // 1/sqrt(32), applied to q as torch does
     float2 qv = *reinterpret_cast<const float2*>(q + (size_t)b * PC_D + 2 * lane);
     qv.x *= scale; qv.y *= scale;
-    const float* kvb = kv + (size_t)b * N * (2 * PC_D);
+    const int32_t* sr = slot_row ? slot_row + (size_t)b * N : nullptr;
+    const size_t base = (size_t)b * N;
     float m = -INFINITY;
     for (int n = 0; n < N; n++) {
-        const float2 k2 = *reinterpret_cast<const float2*>(kvb + (size_t)n * (2 * PC_D) + 2 * lane);
+        const float* kvr = kv + (sr ? (size_t)sr[n] : base + n) * (2 * PC_D);
+        const float2 k2 = *reinterpret_cast<const float2*>(kvr + 2 * lane);
         const float s = group16_sum(qv.x * k2.x + qv.y * k2.y);
         if ((lane & 15) == 0) sc[h * N + n] = s;
         m = fmaxf(m, s);
@@ -40,7 +45,8 @@ __global__ __launch_bounds__(256) void attn_core_fwd_kernel(const float* q, cons
     float2 o = make_float2(0.f, 0.f);
     for (int n = 0; n < N; n++) {
         const float e = expf(sc[h * N + n] - m);
-        const float2 v2 = *reinterpret_cast<const float2*>(kvb + (size_t)n * (2 * PC_D) + PC_D + 2 * lane);
+        const float* kvr = kv + (sr ? (size_t)sr[n] : base + n) * (2 * PC_D);
+        const float2 v2 = *reinterpret_cast<const float2*>(kvr + PC_D + 2 * lane);
         sum += e;
         o.x += e * v2.x;
         o.y += e * v2.y;
@@ -54,9 +60,13 @@ __global__ __launch_bounds__(256) void attn_core_fwd_kernel(const float* q, cons
 }
 
 // dctx[B,D] -> dq[B,D], dkv[B*N,2D]
+// With a slot map, gradients of slots that share the padding row are summed per sample into
+// dkv_pad[b] (their K/V -- hence p and ds -- are identical within a sample); a column sum over
+// samples then forms the shared row's gradient (fixed order, no atomics).
 __global__ __launch_bounds__(256) void attn_core_bwd_kernel(const float* dctx, const float* q, const float* kv,
                                                             const float* probs, int B, int N, float* dq,
-                                                            float* dkv) {
+                                                            float* dkv, const int32_t* slot_row, int pad_row,
+                                                            float* dkv_pad) {
     extern __shared__ float sc_all[];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, h = lane >> 4;
     const int b = blockIdx.x * 4 + w;
@@ -66,41 +76,68 @@ __global__ __launch_bounds__(256) void attn_core_bwd_kernel(const float* dctx, c
     const float2 g = *reinterpret_cast<const float2*>(dctx + (size_t)b * PC_D + 2 * lane);
     float2 qs = *reinterpret_cast<const float2*>(q + (size_t)b * PC_D + 2 * lane);
     qs.x *= scale; qs.y *= scale;
-    const float* kvb = kv + (size_t)b * N * (2 * PC_D);
-    float* dkvb = dkv + (size_t)b * N * (2 * PC_D);
+    const int32_t* sr = slot_row ? slot_row + (size_t)b * N : nullptr;
+    const size_t base = (size_t)b * N;
     const float* pb = probs + (size_t)b * PC_HEADS * N + h * N;
     float dsum = 0.f;                                     // sum_n p_n * dp_n  (softmax backward)
     for (int n = 0; n < N; n++) {
-        const float2 v2 = *reinterpret_cast<const float2*>(kvb + (size_t)n * (2 * PC_D) + PC_D + 2 * lane);
+        const float* kvr = kv + (sr ? (size_t)sr[n] : base + n) * (2 * PC_D);
+        const float2 v2 = *reinterpret_cast<const float2*>(kvr + PC_D + 2 * lane);
         const float dp = group16_sum(g.x * v2.x + g.y * v2.y);
         if ((lane & 15) == 0) dps[h * N + n] = dp;
         dsum += pb[n] * dp;
     }
     __builtin_amdgcn_wave_barrier();
-    float2 dqa = make_float2(0.f, 0.f);
+    float2 dqa = make_float2(0.f, 0.f), pk = make_float2(0.f, 0.f), pv = make_float2(0.f, 0.f);
     for (int n = 0; n < N; n++) {
         const float p = pb[n];
         const float ds = p * (dps[h * N + n] - dsum);
-        const float2 k2 = *reinterpret_cast<const float2*>(kvb + (size_t)n * (2 * PC_D) + 2 * lane);
+        const size_t row = sr ? (size_t)sr[n] : base + n;
+        const float2 k2 = *reinterpret_cast<const float2*>(kv + row * (2 * PC_D) + 2 * lane);
         dqa.x += ds * k2.x;
         dqa.y += ds * k2.y;
-        *reinterpret_cast<float2*>(dkvb + (size_t)n * (2 * PC_D) + 2 * lane) = make_float2(ds * qs.x, ds * qs.y);
-        *reinterpret_cast<float2*>(dkvb + (size_t)n * (2 * PC_D) + PC_D + 2 * lane) = make_float2(p * g.x, p * g.y);
+        if (sr && (int)row == pad_row) {                   // wave-uniform: the slot map is per sample
+            pk.x += ds * qs.x; pk.y += ds * qs.y;
+            pv.x += p * g.x;   pv.y += p * g.y;
+        } else {
+            *reinterpret_cast<float2*>(dkv + row * (2 * PC_D) + 2 * lane) = make_float2(ds * qs.x, ds * qs.y);
+            *reinterpret_cast<float2*>(dkv + row * (2 * PC_D) + PC_D + 2 * lane) = make_float2(p * g.x, p * g.y);
+        }
+    }
+    if (dkv_pad) {
+        *reinterpret_cast<float2*>(dkv_pad + (size_t)b * (2 * PC_D) + 2 * lane) = pk;
+        *reinterpret_cast<float2*>(dkv_pad + (size_t)b * (2 * PC_D) + PC_D + 2 * lane) = pv;
     }
     *reinterpret_cast<float2*>(dq + (size_t)b * PC_D + 2 * lane) = make_float2(dqa.x * scale, dqa.y * scale);
+}
+
+// out[c] = sum_b x[b][c] over B rows of 2D columns: grid 2D/32 blocks of (32 columns x 32 row lanes)
+__global__ __launch_bounds__(1024) void colsum_kernel(const float* x, int B, float* out) {
+    __shared__ float red[32][33];
+    const int c = blockIdx.x * 32 + threadIdx.x, q = threadIdx.y;
+    float s = 0.f;
+    for (int b = q; b < B; b += 32) s += x[(size_t)b * (2 * PC_D) + c];
+    red[q][threadIdx.x] = s;
+    __syncthreads();
+    if (q == 0) {
+        float t = 0.f;
+#pragma unroll 8
+        for (int i = 0; i < 32; i++) t += red[i][threadIdx.x];
+        out[c] = t;
+    }
 }
 
 // ---------------------------------------------------------------------------------------
 static inline size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
 
 struct AttnWs {
-    float *dctx, *dq, *dkv;       // backward intermediates
+    float *dctx, *dq, *dkv, *dkv_pad;   // backward intermediates
     float *wot, *wqt, *wkvt;      // transposed projections
     float *slabs; size_t slab_floats;
     size_t total;
 };
 
-static AttnWs attn_ws_layout(void* base, int B, int N) {
+static AttnWs attn_ws_layout(void* base, int B, int key_rows) {
     AttnWs w;
     size_t off = 0;
     auto take = [&](size_t floats) {
@@ -110,11 +147,12 @@ static AttnWs attn_ws_layout(void* base, int B, int N) {
     };
     w.dctx = take((size_t)B * PC_D);
     w.dq = take((size_t)B * PC_D);
-    w.dkv = take((size_t)B * N * 2 * PC_D);
+    w.dkv = take((size_t)key_rows * 2 * PC_D);
+    w.dkv_pad = take((size_t)B * 2 * PC_D);
     w.wot = take(PC_D * PC_D);
     w.wqt = take(PC_D * PC_D);
     w.wkvt = take(2 * PC_D * PC_D);
-    size_t s1 = gemm_tn_workspace_floats(B * N, 2 * PC_D, PC_D);
+    size_t s1 = gemm_tn_workspace_floats(key_rows, 2 * PC_D, PC_D);
     size_t s2 = gemm_tn_workspace_floats(B, PC_D, PC_D);
     w.slab_floats = s1 > s2 ? s1 : s2;
     w.slabs = take(w.slab_floats);
@@ -124,7 +162,7 @@ static AttnWs attn_ws_layout(void* base, int B, int N) {
 
 extern "C" size_t pc_p2v_attention_workspace_bytes(int batch, int n_keys) {
     if (batch <= 0 || n_keys <= 0) return 0;
-    return attn_ws_layout(nullptr, batch, n_keys).total;
+    return attn_ws_layout(nullptr, batch, batch * n_keys).total;     // dense layout bounds the compact one
 }
 
 static NtArgs nt_plain(const float* A, int lda, const float* W, int ldw, const float* bias, float* C, int ldc, int M,
@@ -135,7 +173,9 @@ static NtArgs nt_plain(const float* A, int lda, const float* W, int ldw, const f
     return a;
 }
 
-static int attn_check(const pc_p2v_tensors* p, int B, int N, const pc_attn_saved* sv, void* ws, size_t ws_bytes) {
+static int attn_check(const pc_p2v_tensors* p, int B, int N, int key_rows, const int32_t* slot_row,
+                      const pc_attn_saved* sv, void* ws, size_t ws_bytes) {
+    if (key_rows <= 0 || key_rows > B * N + 1 || (!slot_row && key_rows != B * N)) return PC_EINVAL;
     if (!p || !p->in_proj_w || !p->in_proj_b || !p->out_proj_w || !p->out_proj_b) return PC_EINVAL;
     if (B <= 0 || N <= 0 || !sv || !sv->q || !sv->kv || !sv->probs || !sv->ctx || !ws) return PC_EINVAL;
     if ((size_t)4 * PC_HEADS * N * sizeof(float) > 60000) return PC_ESHAPE;   // scores must fit LDS
@@ -143,33 +183,41 @@ static int attn_check(const pc_p2v_tensors* p, int B, int N, const pc_attn_saved
     return PC_OK;
 }
 
-extern "C" int pc_p2v_attention_forward(const pc_p2v_tensors* p, const float* query, const float* keys, int B,
-                                        int N, float* out, const pc_attn_saved* sv, void* ws, size_t ws_bytes,
-                                        void* stream) {
-    PC_TRY(attn_check(p, B, N, sv, ws, ws_bytes));
+// Compact form used by the fused step: keys[key_rows,D] holds each distinct neighbour row once and
+// slot_row[B*N] maps slot (b,n) to its row (all padding slots -> one shared row).
+int attention_forward_impl(const pc_p2v_tensors* p, const float* query, const float* keys, int B, int N,
+                           int key_rows, const int32_t* slot_row, float* out, const pc_attn_saved* sv, void* ws,
+                           size_t ws_bytes, void* stream) {
+    PC_TRY(attn_check(p, B, N, key_rows, slot_row, sv, ws, ws_bytes));
     if (!query || !keys || !out) return PC_EINVAL;
     hipStream_t st = (hipStream_t)stream;
     // in_proj rows [0,D) = Wq, [D,3D) = [Wk;Wv]  (torch packs q,k,v in this order)
     PC_TRY(launch_gemm_nt(nt_plain(keys, PC_D, p->in_proj_w + PC_D * PC_D, PC_D, p->in_proj_b + PC_D, sv->kv,
-                                   2 * PC_D, B * N, 2 * PC_D, PC_D), st));
+                                   2 * PC_D, key_rows, 2 * PC_D, PC_D), st));
     PC_TRY(launch_gemm_nt(nt_plain(query, PC_D, p->in_proj_w, PC_D, p->in_proj_b, sv->q, PC_D, B, PC_D, PC_D), st));
     const size_t lds = (size_t)4 * PC_HEADS * N * sizeof(float);
     PC_LAUNCH(attn_core_fwd_kernel, dim3((B + 3) / 4), dim3(256), lds, st, sv->q, sv->kv, B, N, sv->ctx,
-                       sv->probs);
+                       sv->probs, slot_row);
     PC_TRY(pc_launch_status());
     return launch_gemm_nt(nt_plain(sv->ctx, PC_D, p->out_proj_w, PC_D, p->out_proj_b, out, PC_D, B, PC_D, PC_D), st);
 }
 
-extern "C" int pc_p2v_attention_backward(const pc_p2v_tensors* p, const pc_p2v_tensors* g, const float* query,
-                                         const float* keys, int B, int N, const float* dout,
-                                         const pc_attn_saved* sv, float* dquery, float* dkeys, int accumulate,
-                                         void* ws, size_t ws_bytes, void* stream) {
-    PC_TRY(attn_check(p, B, N, sv, ws, ws_bytes));
+extern "C" int pc_p2v_attention_forward(const pc_p2v_tensors* p, const float* query, const float* keys, int B,
+                                        int N, float* out, const pc_attn_saved* sv, void* ws, size_t ws_bytes,
+                                        void* stream) {
+    return attention_forward_impl(p, query, keys, B, N, B * N, nullptr, out, sv, ws, ws_bytes, stream);
+}
+
+int attention_backward_impl(const pc_p2v_tensors* p, const pc_p2v_tensors* g, const float* query, const float* keys,
+                            int B, int N, int key_rows, const int32_t* slot_row, int pad_row, const float* dout,
+                            const pc_attn_saved* sv, float* dquery, float* dkeys, int accumulate, void* ws,
+                            size_t ws_bytes, void* stream) {
+    PC_TRY(attn_check(p, B, N, key_rows, slot_row, sv, ws, ws_bytes));
     if (!g || !g->in_proj_w || !g->in_proj_b || !g->out_proj_w || !g->out_proj_b) return PC_EINVAL;
     if (!query || !keys || !dout || !dquery || !dkeys) return PC_EINVAL;
     hipStream_t st = (hipStream_t)stream;
-    AttnWs w = attn_ws_layout(ws, B, N);
-    const SegInfo si1 = make_seginfo(nullptr, B, 128), si2 = make_seginfo(nullptr, B * N, 128);
+    AttnWs w = attn_ws_layout(ws, B, slot_row ? key_rows : B * N);
+    const SegInfo si1 = make_seginfo(nullptr, B, 128), si2 = make_seginfo(nullptr, key_rows, 128);
 
     PC_TRY(launch_transpose(p->out_proj_w, PC_D, PC_D, w.wot, st));
     PC_TRY(launch_transpose(p->in_proj_w, PC_D, PC_D, w.wqt, st));
@@ -184,9 +232,14 @@ extern "C" int pc_p2v_attention_backward(const pc_p2v_tensors* p, const pc_p2v_t
     PC_TRY(launch_gemm_tn(to, st));
 
     const size_t lds = (size_t)4 * PC_HEADS * N * sizeof(float);
+    const bool has_pad = slot_row && pad_row >= 0;
     PC_LAUNCH(attn_core_bwd_kernel, dim3((B + 3) / 4), dim3(256), lds, st, w.dctx, sv->q, sv->kv, sv->probs,
-                       B, N, w.dq, w.dkv);
+                       B, N, w.dq, w.dkv, slot_row, has_pad ? pad_row : -1, has_pad ? w.dkv_pad : nullptr);
     PC_TRY(pc_launch_status());
+    if (has_pad) {
+        PC_LAUNCH(colsum_kernel, dim3(2 * PC_D / 32), dim3(32, 32), 0, st, w.dkv_pad, B, w.dkv + (size_t)pad_row * 2 * PC_D);
+        PC_TRY(pc_launch_status());
+    }
 
     // q = query Wq^T + bq
     PC_TRY(launch_gemm_nt(nt_plain(w.dq, PC_D, w.wqt, PC_D, nullptr, dquery, PC_D, B, PC_D, PC_D), st));
@@ -197,11 +250,19 @@ extern "C" int pc_p2v_attention_backward(const pc_p2v_tensors* p, const pc_p2v_t
     PC_TRY(launch_gemm_tn(tq, st));
 
     // [k|v] = keys [Wk;Wv]^T + [bk;bv]
-    PC_TRY(launch_gemm_nt(nt_plain(w.dkv, 2 * PC_D, w.wkvt, 2 * PC_D, nullptr, dkeys, PC_D, B * N, PC_D, 2 * PC_D), st));
+    PC_TRY(launch_gemm_nt(nt_plain(w.dkv, 2 * PC_D, w.wkvt, 2 * PC_D, nullptr, dkeys, PC_D, key_rows, PC_D, 2 * PC_D), st));
     TnArgs tk = {};
-    tk.Z = w.dkv; tk.ldz = 2 * PC_D; tk.A = keys; tk.lda = PC_D; tk.R = B * N; tk.No = 2 * PC_D; tk.Ni = PC_D;
+    tk.Z = w.dkv; tk.ldz = 2 * PC_D; tk.A = keys; tk.lda = PC_D; tk.R = key_rows; tk.No = 2 * PC_D; tk.Ni = PC_D;
     tk.seg = si2;
     tk.dW = g->in_proj_w + PC_D * PC_D; tk.lddw = PC_D; tk.db = g->in_proj_b + PC_D; tk.accumulate = accumulate;
     tk.slabs = w.slabs; tk.slab_floats = w.slab_floats;
     return launch_gemm_tn(tk, st);
+}
+
+extern "C" int pc_p2v_attention_backward(const pc_p2v_tensors* p, const pc_p2v_tensors* g, const float* query,
+                                         const float* keys, int B, int N, const float* dout,
+                                         const pc_attn_saved* sv, float* dquery, float* dkeys, int accumulate,
+                                         void* ws, size_t ws_bytes, void* stream) {
+    return attention_backward_impl(p, g, query, keys, B, N, B * N, nullptr, -1, dout, sv, dquery, dkeys, accumulate, ws,
+                                   ws_bytes, stream);
 }

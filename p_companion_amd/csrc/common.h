@@ -39,6 +39,9 @@ struct SegInfo {
     int nseg;
     int start[PC_MAX_SEG + 1];   // row starts, start[nseg] = total rows
     int tile0[PC_MAX_SEG + 1];   // first 128-row tile of each segment (tiles never straddle)
+    int count[PC_MAX_SEG];       // logical rows per segment (what BatchNorm divides by)
+    int wrow;                    // the one row that stands for `wmult` identical rows (-1: none)
+    float wmult;
 };
 
 static inline SegInfo make_seginfo(const pc_segments* s, int rows, int tile_rows) {
@@ -46,10 +49,18 @@ static inline SegInfo make_seginfo(const pc_segments* s, int rows, int tile_rows
     si.nseg = 1;
     for (int i = 0; i <= PC_MAX_SEG; i++) { si.start[i] = rows; si.tile0[i] = 0; }
     si.start[0] = 0;
+    si.wrow = -1;
+    si.wmult = 1.f;
     if (s) {
         si.nseg = s->nseg;
         for (int i = 0; i <= s->nseg; i++) si.start[i] = s->start[i];
         for (int i = s->nseg + 1; i <= PC_MAX_SEG; i++) si.start[i] = s->start[s->nseg];
+        si.wrow = s->weighted_row;
+        si.wmult = s->weight;
+    }
+    for (int i = 0; i < PC_MAX_SEG; i++) {
+        const int phys = si.start[i + 1] - si.start[i];
+        si.count[i] = (s && i < s->nseg && s->count[i] > 0) ? s->count[i] : phys;
     }
     int t = 0;
     for (int i = 0; i < PC_MAX_SEG; i++) {
@@ -65,7 +76,8 @@ static inline int seg_valid(const pc_segments* s, int rows) {
     if (!s) return 1;
     if (s->nseg < 1 || s->nseg > PC_MAX_SEG || s->start[0] != 0 || s->start[s->nseg] != rows) return 0;
     for (int i = 0; i < s->nseg; i++)
-        if (s->start[i + 1] < s->start[i]) return 0;
+        if (s->start[i + 1] < s->start[i] || s->count[i] < 0) return 0;
+    if (s->weighted_row >= rows || (s->weighted_row >= 0 && s->weight < 0.f)) return 0;
     return 1;
 }
 

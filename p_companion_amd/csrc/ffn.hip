@@ -54,7 +54,7 @@ __global__ __launch_bounds__(FIN_COLS * FIN_LANES) void bn_finalize_fwd_kernel(
     if (q == 0 && update_running) { rm = running_mean[j]; rv = running_var[j]; }
     int nseen = 0;
     for (int s = 0; s < si.nseg; s++) {
-        const int n = si.start[s + 1] - si.start[s];
+        const int n = si.count[s];                            // logical rows (a weighted row counts wmult times)
         double a = 0.0, b = 0.0;
         fold_partials(psum, psq, si.tile0[s], si.tile0[s + 1], j, q, red, &a, &b);
         if (q == 0 && n > 0) {
@@ -100,7 +100,7 @@ __global__ __launch_bounds__(FIN_COLS * FIN_LANES) void bn_finalize_bwd_kernel(
     const int j = blockIdx.x * FIN_COLS + threadIdx.x, q = threadIdx.y;
     double tg = 0.0, tb = 0.0;
     for (int s = 0; s < si.nseg; s++) {
-        const int n = si.start[s + 1] - si.start[s];
+        const int n = si.count[s];                            // logical rows (a weighted row counts wmult times)
         double a = 0.0, b = 0.0;
         fold_partials(psum, pdot, si.tile0[s], si.tile0[s + 1], j, q, red, &a, &b);
         if (q == 0) {
@@ -123,6 +123,7 @@ __global__ void bn_bwd_apply_kernel(float* dz, const float* h0, int rows, SegInf
     const int rl = threadIdx.x >> 6;                           // 4 rows per block pass
     for (int r = blockIdx.x * 4 + rl; r < rows; r += gridDim.x * 4) {
         const int s = seg_of_row(si, r);
+        const float m = r == si.wrow ? si.wmult : 1.f;          // sum over the rows this one stands for
         float4 g = *reinterpret_cast<float4*>(dz + (size_t)r * PC_H + c4);
         const float4 h = *reinterpret_cast<const float4*>(h0 + (size_t)r * PC_H + c4);
         const float4 mu = *reinterpret_cast<const float4*>(mean + s * PC_H + c4);
@@ -130,10 +131,10 @@ __global__ void bn_bwd_apply_kernel(float* dz, const float* h0, int rows, SegInf
         const float4 sc = *reinterpret_cast<const float4*>(scale + s * PC_H + c4);
         const float4 a = *reinterpret_cast<const float4*>(c1 + s * PC_H + c4);
         const float4 b = *reinterpret_cast<const float4*>(c2 + s * PC_H + c4);
-        g.x = sc.x * (g.x - a.x - (h.x - mu.x) * is.x * b.x);
-        g.y = sc.y * (g.y - a.y - (h.y - mu.y) * is.y * b.y);
-        g.z = sc.z * (g.z - a.z - (h.z - mu.z) * is.z * b.z);
-        g.w = sc.w * (g.w - a.w - (h.w - mu.w) * is.w * b.w);
+        g.x = sc.x * (g.x - m * (a.x + (h.x - mu.x) * is.x * b.x));
+        g.y = sc.y * (g.y - m * (a.y + (h.y - mu.y) * is.y * b.y));
+        g.z = sc.z * (g.z - m * (a.z + (h.z - mu.z) * is.z * b.z));
+        g.w = sc.w * (g.w - m * (a.w + (h.w - mu.w) * is.w * b.w));
         *reinterpret_cast<float4*>(dz + (size_t)r * PC_H + c4) = g;
     }
 }

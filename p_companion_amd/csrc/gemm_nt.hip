@@ -290,7 +290,10 @@ __global__ __launch_bounds__(64 * NWM * NWN, OCC) void gemm_nt_kernel(NtArgs a, 
                         }
                         v[q] = x;
                         if (rok && col + q < a.N) {
-                            if (STATS == NT_STAT_SUMSQ) { cs1[nt][q] += x; cs2[nt][q] += x * x; }
+                            if (STATS == NT_STAT_SUMSQ) {
+                                const float wt = row == a.seg.wrow ? a.seg.wmult : 1.f;   // the row that stands for many
+                                cs1[nt][q] += wt * x; cs2[nt][q] += wt * x * x;
+                            }
                             else if (STATS == NT_STAT_BNBWD) { cs1[nt][q] += x; cs2[nt][q] += x * ((ax[q] - mu[q]) * is[q]); }
                         }
                     }
@@ -356,7 +359,14 @@ static SegInfo retile(const SegInfo& in, int tile_rows) {
 
 template <bool PRO, int EPI, int STATS>
 static void launch_variant(const NtArgs& a, int ntm, int dbg, hipStream_t st) {
-    if (PRO || a.N > 128 || STATS != NT_STAT_NONE) {
+    if ((dbg & 64) && !PRO && STATS == NT_STAT_NONE && a.N > 128) {
+        // probe: 64 rows x 256 columns, 4 waves, BK 16, three workgroups per CU
+        NtArgs b = a;
+        b.seg = retile(a.seg, 64);
+        const int ntn = (a.N + 255) / 256, total = gemm_nt_tiles(b.seg) * ntn;
+        PC_LAUNCH((gemm_nt_kernel<1, 4, 16, 3, false, EPI, NT_STAT_NONE>), dim3(total < 768 ? total : 768), dim3(256), 0, st,
+                  b, ntn, total, dbg);
+    } else if (PRO || a.N > 128 || STATS != NT_STAT_NONE) {
         // 128 rows x 256 columns, 8 waves, one workgroup per CU: A is read once
         const int ntn = (a.N + 255) / 256, total = ntm * ntn;
         PC_LAUNCH((gemm_nt_kernel<2, 4, 32, 2, PRO, EPI, STATS>), dim3(total < 256 ? total : 256), dim3(512), 0, st, a, ntn,

@@ -52,10 +52,11 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(TnArgs a, int tiles_i, 
                     zseg = s;
                 }
                 const float4 h = *reinterpret_cast<const float4*>(a.zaux + (size_t)r * a.ldzaux + o0 + lcol);
-                rz[p].x = zsc.x * (rz[p].x - zc1.x - (h.x - zmu.x) * zis.x * zc2.x);
-                rz[p].y = zsc.y * (rz[p].y - zc1.y - (h.y - zmu.y) * zis.y * zc2.y);
-                rz[p].z = zsc.z * (rz[p].z - zc1.z - (h.z - zmu.z) * zis.z * zc2.z);
-                rz[p].w = zsc.w * (rz[p].w - zc1.w - (h.w - zmu.w) * zis.w * zc2.w);
+                const float zm = r == a.seg.wrow ? a.seg.wmult : 1.f;
+                rz[p].x = zsc.x * (rz[p].x - zm * (zc1.x + (h.x - zmu.x) * zis.x * zc2.x));
+                rz[p].y = zsc.y * (rz[p].y - zm * (zc1.y + (h.y - zmu.y) * zis.y * zc2.y));
+                rz[p].z = zsc.z * (rz[p].z - zm * (zc1.z + (h.z - zmu.z) * zis.z * zc2.z));
+                rz[p].w = zsc.w * (rz[p].w - zm * (zc1.w + (h.w - zmu.w) * zis.w * zc2.w));
             }
             int src = r;
             bool av = rv && acol_ok;
@@ -187,10 +188,11 @@ __global__ __launch_bounds__(512, 2) void gemm_tn8_kernel(TnArgs a, int nsplit, 
                     zseg = s;
                 }
                 const float4 h = *reinterpret_cast<const float4*>(a.zaux + (size_t)r * a.ldzaux + zcol);
-                rz[p].x = zsc.x * (rz[p].x - zc1.x - (h.x - zmu.x) * zis.x * zc2.x);
-                rz[p].y = zsc.y * (rz[p].y - zc1.y - (h.y - zmu.y) * zis.y * zc2.y);
-                rz[p].z = zsc.z * (rz[p].z - zc1.z - (h.z - zmu.z) * zis.z * zc2.z);
-                rz[p].w = zsc.w * (rz[p].w - zc1.w - (h.w - zmu.w) * zis.w * zc2.w);
+                const float zm = r == a.seg.wrow ? a.seg.wmult : 1.f;
+                rz[p].x = zsc.x * (rz[p].x - zm * (zc1.x + (h.x - zmu.x) * zis.x * zc2.x));
+                rz[p].y = zsc.y * (rz[p].y - zm * (zc1.y + (h.y - zmu.y) * zis.y * zc2.y));
+                rz[p].z = zsc.z * (rz[p].z - zm * (zc1.z + (h.z - zmu.z) * zis.z * zc2.z));
+                rz[p].w = zsc.w * (rz[p].w - zm * (zc1.w + (h.w - zmu.w) * zis.w * zc2.w));
             }
             dbacc.x += rz[p].x; dbacc.y += rz[p].y; dbacc.z += rz[p].z; dbacc.w += rz[p].w;
         }

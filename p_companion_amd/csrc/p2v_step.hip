@@ -19,7 +19,7 @@ struct StepWs {
 
 static StepWs step_ws_layout(void* base, int B, int N, int K) {
     StepWs w;
-    const size_t R = (size_t)B * (2 + N + K);
+    const size_t R = (size_t)B * (2 + N + K) + 1;          // +1: the shared padding row of the compact layout
     size_t off = 0;
     auto take = [&](size_t bytes) {
         void* p = base ? reinterpret_cast<char*>(base) + off : nullptr;
@@ -66,32 +66,45 @@ extern "C" int pc_p2v_ffn_backward(const pc_p2v_tensors* p, const pc_p2v_tensors
                                    const int32_t* idx, int rows, const pc_segments* seg, const float* dy,
                                    const pc_ffn_saved* sv, float* dx, int accumulate, void* ws, size_t ws_bytes,
                                    void* stream);
-extern "C" int pc_p2v_attention_backward(const pc_p2v_tensors* p, const pc_p2v_tensors* g, const float* query,
-                                         const float* keys, int B, int N, const float* dout,
-                                         const pc_attn_saved* sv, float* dquery, float* dkeys, int accumulate,
-                                         void* ws, size_t ws_bytes, void* stream);
+int attention_forward_impl(const pc_p2v_tensors* p, const float* query, const float* keys, int B, int N,
+                           int key_rows, const int32_t* slot_row, float* out, const pc_attn_saved* sv, void* ws,
+                           size_t ws_bytes, void* stream);
+int attention_backward_impl(const pc_p2v_tensors* p, const pc_p2v_tensors* g, const float* query, const float* keys,
+                            int B, int N, int key_rows, const int32_t* slot_row, int pad_row, const float* dout,
+                            const pc_attn_saved* sv, float* dquery, float* dkeys, int accumulate, void* ws,
+                            size_t ws_bytes, void* stream);
 
-extern "C" int pc_p2v_train_step(const pc_p2v_tensors* p, const pc_p2v_tensors* g, const float* table,
-                                 const int32_t* anchor_idx, const int32_t* positive_idx,
-                                 const int32_t* negative_idx, const int32_t* neighbor_idx, int B, int N, int K,
-                                 float margin, float* loss, float* d_pos, float* d_neg, float* anchor_emb,
-                                 void* profile, void* ws, size_t ws_bytes, void* stream) {
+// nb_idx: neighbour rows of the step, nbc of them.  Dense layout: nbc = B*N slots in slot order
+// (slot_row NULL).  Compact layout: the M real neighbours then one -1 row (nbc = M + 1), slot_row[B*N]
+// maps every slot to its row and the -1 row carries the weight of all padding slots.
+static int p2v_step_impl(const pc_p2v_tensors* p, const pc_p2v_tensors* g, const float* table,
+                         const int32_t* anchor_idx, const int32_t* positive_idx, const int32_t* negative_idx,
+                         const int32_t* nb_idx, int nbc, const int32_t* slot_row, int B, int N, int K, float margin,
+                         float* loss, float* d_pos, float* d_neg, float* anchor_emb, void* profile, void* ws,
+                         size_t ws_bytes, void* stream) {
     ProfileScope prof_scope((pc_profile*)profile);
     if (!p || !g || !table || !anchor_idx || !positive_idx || !negative_idx || !loss || !ws) return PC_EINVAL;
-    if (B <= 0 || N < 0 || K <= 0 || (N > 0 && !neighbor_idx)) return PC_EINVAL;
+    if (B <= 0 || N < 0 || K <= 0 || (N > 0 && !nb_idx) || nbc < 0 || nbc > B * N + 1) return PC_EINVAL;
     if (ws_bytes < pc_p2v_train_step_workspace_bytes(B, N, K)) return PC_EWORKSPACE;
     hipStream_t st = (hipStream_t)stream;
     StepWs w = step_ws_layout(ws, B, N, K);
-    const int R = B * (2 + N + K);
-    const int rA = 0, rN = B, rP = B + B * N, rG = rP + B;
+    const int R = 2 * B + nbc + B * K;
+    const int rA = 0, rN = B, rP = B + nbc, rG = rP + B;
 
     // call order of product2vec.py:132-134: anchor (:73), neighbours (:78), positive, negative
-    pc_segments seg;
-    if (N > 0) { seg.nseg = 4; seg.start[0] = rA; seg.start[1] = rN; seg.start[2] = rP; seg.start[3] = rG; seg.start[4] = R; }
-    else { seg.nseg = 3; seg.start[0] = rA; seg.start[1] = rP; seg.start[2] = rG; seg.start[3] = R; seg.start[4] = R; }
+    pc_segments seg = {};
+    seg.weighted_row = -1;
+    seg.weight = 1.f;
+    if (N > 0) {
+        seg.nseg = 4; seg.start[0] = rA; seg.start[1] = rN; seg.start[2] = rP; seg.start[3] = rG; seg.start[4] = R;
+        seg.count[1] = B * N;                                  // BatchNorm sees every padded slot
+        if (slot_row) { seg.weighted_row = rN + nbc - 1; seg.weight = (float)(B * N - (nbc - 1)); }
+    } else {
+        seg.nseg = 3; seg.start[0] = rA; seg.start[1] = rP; seg.start[2] = rG; seg.start[3] = R; seg.start[4] = R;
+    }
 
-    PC_LAUNCH(concat_idx_kernel, dim3((R + 255) / 256), dim3(256), 0, st, anchor_idx, B, neighbor_idx,
-                       B * N, positive_idx, B, negative_idx, B * K, w.idx_all);
+    PC_LAUNCH(concat_idx_kernel, dim3((R + 255) / 256), dim3(256), 0, st, anchor_idx, B, nb_idx, nbc, positive_idx, B,
+              negative_idx, B * K, w.idx_all);
     PC_TRY(pc_launch_status());
 
     pc_ffn_saved sv;
@@ -104,8 +117,8 @@ extern "C" int pc_p2v_train_step(const pc_p2v_tensors* p, const pc_p2v_tensors* 
     as.q = w.q; as.kv = w.kv; as.probs = w.probs; as.ctx = w.ctx;
     const float* emb = w.y;                     // anchor embedding = FFN output when there are no neighbours
     if (N > 0) {
-        PC_TRY(pc_p2v_attention_forward(p, w.y + (size_t)rA * PC_D, w.y + (size_t)rN * PC_D, B, N, w.emb, &as,
-                                        w.attn_ws, w.attn_bytes, stream));
+        PC_TRY(attention_forward_impl(p, w.y + (size_t)rA * PC_D, w.y + (size_t)rN * PC_D, B, N, nbc, slot_row, w.emb,
+                                      &as, w.attn_ws, w.attn_bytes, stream));
         emb = w.emb;
     }
 
@@ -118,9 +131,9 @@ extern "C" int pc_p2v_train_step(const pc_p2v_tensors* p, const pc_p2v_tensors* 
         PC_HIP_TRY(hipMemcpyAsync(anchor_emb, emb, (size_t)B * PC_D * 4, hipMemcpyDeviceToDevice, st));
 
     if (N > 0) {
-        PC_TRY(pc_p2v_attention_backward(p, g, w.y + (size_t)rA * PC_D, w.y + (size_t)rN * PC_D, B, N, w.demb, &as,
-                                         w.dy + (size_t)rA * PC_D, w.dy + (size_t)rN * PC_D, 0, w.attn_ws,
-                                         w.attn_bytes, stream));
+        PC_TRY(attention_backward_impl(p, g, w.y + (size_t)rA * PC_D, w.y + (size_t)rN * PC_D, B, N, nbc, slot_row,
+                                       slot_row ? nbc - 1 : -1, w.demb, &as, w.dy + (size_t)rA * PC_D,
+                                       w.dy + (size_t)rN * PC_D, 0, w.attn_ws, w.attn_bytes, stream));
     } else {
         PC_HIP_TRY(hipMemsetAsync(g->in_proj_w, 0, 3 * PC_D * PC_D * 4, st));
         PC_HIP_TRY(hipMemsetAsync(g->in_proj_b, 0, 3 * PC_D * 4, st));
@@ -128,4 +141,24 @@ extern "C" int pc_p2v_train_step(const pc_p2v_tensors* p, const pc_p2v_tensors* 
         PC_HIP_TRY(hipMemsetAsync(g->out_proj_b, 0, PC_D * 4, st));
     }
     return pc_p2v_ffn_backward(p, g, table, w.idx_all, R, &seg, w.dy, &sv, nullptr, 0, w.ffn_ws, w.ffn_bytes, stream);
+}
+
+extern "C" int pc_p2v_train_step(const pc_p2v_tensors* p, const pc_p2v_tensors* g, const float* table,
+                                 const int32_t* anchor_idx, const int32_t* positive_idx,
+                                 const int32_t* negative_idx, const int32_t* neighbor_idx, int B, int N, int K,
+                                 float margin, float* loss, float* d_pos, float* d_neg, float* anchor_emb,
+                                 void* profile, void* ws, size_t ws_bytes, void* stream) {
+    return p2v_step_impl(p, g, table, anchor_idx, positive_idx, negative_idx, neighbor_idx, B * N, nullptr, B, N, K,
+                         margin, loss, d_pos, d_neg, anchor_emb, profile, ws, ws_bytes, stream);
+}
+
+extern "C" int pc_p2v_train_step_compact(const pc_p2v_tensors* p, const pc_p2v_tensors* g, const float* table,
+                                         const int32_t* anchor_idx, const int32_t* positive_idx,
+                                         const int32_t* negative_idx, const int32_t* nb_rows, int n_real,
+                                         const int32_t* slot_row, int B, int N, int K, float margin, float* loss,
+                                         float* d_pos, float* d_neg, float* anchor_emb, void* profile, void* ws,
+                                         size_t ws_bytes, void* stream) {
+    if (!slot_row || !nb_rows || N <= 0 || n_real < 0 || n_real > B * N) return PC_EINVAL;
+    return p2v_step_impl(p, g, table, anchor_idx, positive_idx, negative_idx, nb_rows, n_real + 1, slot_row, B, N, K,
+                         margin, loss, d_pos, d_neg, anchor_emb, profile, ws, ws_bytes, stream);
 }

@@ -76,6 +76,77 @@ __global__ void build_neighbors_kernel(const int32_t* anchor_idx, int B, const i
     neighbor_idx[t] = j < deg ? cv_col[lo + j] : -1;
 }
 
+// Compact neighbour layout: every real neighbour of the batch once, in slot order, then ONE row
+// with index -1 standing for all the zero-padding slots.  row_off = exclusive scan of the (capped)
+// degrees; single workgroup (B is a few thousand).
+__global__ __launch_bounds__(1024) void degree_scan_kernel(const int32_t* anchor_idx, int B, const int32_t* cv_rowptr,
+                                                           int n_pad, int32_t* row_off) {
+    __shared__ int part[1024];
+    const int t = threadIdx.x;
+    const int per = (B + 1023) / 1024;
+    const int lo = t * per, hi = min(B, lo + per);
+    int s = 0;
+    for (int b = lo; b < hi; b++) {
+        const int a = anchor_idx[b];
+        s += min(cv_rowptr[a + 1] - cv_rowptr[a], n_pad);
+    }
+    part[t] = s;
+    __syncthreads();
+    for (int o = 1; o < 1024; o <<= 1) {                 // Hillis-Steele inclusive scan of the partials
+        const int v = t >= o ? part[t - o] : 0;
+        __syncthreads();
+        part[t] += v;
+        __syncthreads();
+    }
+    int run = part[t] - s;                               // exclusive prefix of this thread's chunk
+    for (int b = lo; b < hi; b++) {
+        row_off[b] = run;
+        const int a = anchor_idx[b];
+        run += min(cv_rowptr[a + 1] - cv_rowptr[a], n_pad);
+    }
+    if (t == 1023) row_off[B] = part[1023];
+}
+
+__global__ void build_neighbors_compact_kernel(const int32_t* anchor_idx, int B, const int32_t* cv_rowptr,
+                                               const int32_t* cv_col, int n_pad, const int32_t* row_off,
+                                               int32_t* nb_rows, int32_t* slot_row) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= B * n_pad) return;
+    const int b = t / n_pad, j = t % n_pad;
+    const int a = anchor_idx[b];
+    const int lo = cv_rowptr[a], deg = min(cv_rowptr[a + 1] - lo, n_pad);
+    const int M = row_off[B];
+    if (j < deg) {
+        nb_rows[row_off[b] + j] = cv_col[lo + j];
+        slot_row[t] = row_off[b] + j;
+    } else {
+        slot_row[t] = M;
+    }
+    if (t == 0) nb_rows[M] = -1;
+}
+
+extern "C" int pc_build_similarity_batch_compact(const int32_t* pair_ids, int batch, const int32_t* sim_pairs,
+                                                 const int32_t* cv_rowptr, const int32_t* cv_col,
+                                                 const int32_t* sim_rowptr, const int32_t* sim_col, int n_products,
+                                                 int n_pad, int k_neg, uint64_t seed, uint64_t step,
+                                                 int32_t* anchor_idx, int32_t* positive_idx, int32_t* negative_idx,
+                                                 int32_t* nb_rows, int32_t* slot_row, int32_t* row_off, void* stream) {
+    if (!pair_ids || !sim_pairs || !cv_rowptr || !cv_col || !sim_rowptr || !sim_col || !anchor_idx ||
+        !positive_idx || !negative_idx || !nb_rows || !slot_row || !row_off)
+        return PC_EINVAL;
+    if (batch <= 0 || n_pad <= 0 || k_neg <= 0 || n_products <= k_neg + 1) return PC_EINVAL;
+    hipStream_t st = (hipStream_t)stream;
+    PC_LAUNCH(build_pairs_negatives_kernel, dim3((batch + 127) / 128), dim3(128), 0, st, pair_ids, batch, sim_pairs,
+              sim_rowptr, sim_col, n_products, k_neg, seed, step, anchor_idx, positive_idx, negative_idx);
+    PC_TRY(pc_launch_status());
+    PC_LAUNCH(degree_scan_kernel, dim3(1), dim3(1024), 0, st, anchor_idx, batch, cv_rowptr, n_pad, row_off);
+    PC_TRY(pc_launch_status());
+    const int total = batch * n_pad;
+    PC_LAUNCH(build_neighbors_compact_kernel, dim3((total + 255) / 256), dim3(256), 0, st, anchor_idx, batch, cv_rowptr,
+              cv_col, n_pad, row_off, nb_rows, slot_row);
+    return pc_launch_status();
+}
+
 extern "C" int pc_build_similarity_batch(const int32_t* pair_ids, int batch, const int32_t* sim_pairs,
                                          const int32_t* cv_rowptr, const int32_t* cv_col,
                                          const int32_t* sim_rowptr, const int32_t* sim_col, int n_products,

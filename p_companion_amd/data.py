@@ -154,7 +154,7 @@ class SimilarityIndexLoader:
     """
 
     def __init__(self, bpg: IntBPG, batch_size: int, shuffle=True, sampler="philox", seed=0, k_neg=5,
-                 drop_last=False, device="cuda"):
+                 drop_last=False, device="cuda", compact=True):
         from . import ops
         self.ops = ops
         self.bpg = bpg
@@ -166,6 +166,7 @@ class SimilarityIndexLoader:
         self.k_neg = k_neg
         self.drop_last = drop_last
         self.device = device
+        self.compact = compact          # carry the zero-padding rows once (pc_p2v_train_step_compact)
         self.epoch = 0
         self.step = 0
         self.g = bpg.cuda(device)
@@ -192,7 +193,13 @@ class SimilarityIndexLoader:
             lo, hi = i * self.batch_size, min((i + 1) * self.batch_size, S)
             ids = perm[lo:hi]
             n_pad = int(self._deg[ids].max())           # collate_fn pads to the batch maximum
-            if self.sampler == "philox":
+            nbc = None
+            if self.sampler == "philox" and self.compact and n_pad > 0:
+                n_real = int(np.minimum(self._deg[ids], n_pad).sum())
+                a, p, ng, nbc = self.ops.build_similarity_batch_compact(perm_dev[lo:hi], self.g, n_pad, self.k_neg,
+                                                                        self.seed, self.step, n_real)
+                nb = None
+            elif self.sampler == "philox":
                 a, p, ng, nb = self.ops.build_similarity_batch(perm_dev[lo:hi], self.g, n_pad, self.k_neg,
                                                                self.seed, self.step)
             else:
@@ -206,9 +213,13 @@ class SimilarityIndexLoader:
                 up = lambda x: torch.from_numpy(np.ascontiguousarray(x, np.int32)).to(self.device)
                 a, p, ng, nb = up(pairs[:, 0]), up(pairs[:, 1]), up(negs), (up(nbr) if n_pad else None)
             self.step += 1
-            batch = {"anchor_idx": a, "positive_idx": p, "negative_idx": ng}
+            batch = {"anchor_idx": a, "positive_idx": p, "negative_idx": ng, "n_pad": n_pad}
             if nb is not None:
                 batch["neighbor_idx"] = nb
+                if self.compact:
+                    batch["neighbor_compact"] = self.ops.compact_neighbors(nb)
+            if nbc is not None:
+                batch["neighbor_compact"] = nbc
             yield batch
 
 

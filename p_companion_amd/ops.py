@@ -68,6 +68,8 @@ def make_segments(starts, rows):
     if not 1 <= len(starts) <= PC_MAX_SEG:
         raise ValueError("1..4 segments")
     s = Segments()
+    s.weighted_row = -1
+    s.weight = 1.0
     s.nseg = len(starts)
     arr = list(starts) + [rows] * (PC_MAX_SEG + 1 - len(starts))
     for i, v in enumerate(arr):
@@ -267,11 +269,17 @@ def p2v_train_step(params, grads, table, anchor_idx, positive_idx, negative_idx,
     gst, _ = p2v_struct(grads, with_buffers=False)
     b = anchor_idx.numel()
     k = negative_idx.shape[1]
-    n = 0 if neighbor_idx is None else neighbor_idx.shape[1]
+    compact = isinstance(neighbor_idx, dict)          # {"nb_rows": [M+1], "slot_row": [B,N]}
+    if compact:
+        nb_rows, slot_row = neighbor_idx["nb_rows"], neighbor_idx["slot_row"]
+        n, n_real = slot_row.shape[1], nb_rows.numel() - 1
+        _req(nb_rows, torch.int32, "nb_rows"); _req(slot_row, torch.int32, "slot_row", (b, n))
+    else:
+        n = 0 if neighbor_idx is None else neighbor_idx.shape[1]
     _req(table, torch.float32, "table")
     _req(anchor_idx, torch.int32, "anchor_idx", (b,)); _req(positive_idx, torch.int32, "positive_idx", (b,))
     _req(negative_idx, torch.int32, "negative_idx", (b, k))
-    if n:
+    if n and not compact:
         _req(neighbor_idx, torch.int32, "neighbor_idx", (b, n))
     out = {"loss": torch.empty(1, dtype=torch.float32, device=dev),
            "d_pos": torch.empty(b, dtype=torch.float32, device=dev),
@@ -280,6 +288,13 @@ def p2v_train_step(params, grads, table, anchor_idx, positive_idx, negative_idx,
         out["anchor_emb"] = torch.empty(b, D, dtype=torch.float32, device=dev)
     nbytes = _lib.lib().pc_p2v_train_step_workspace_bytes(b, n, k)
     ws = workspace(nbytes, dev, "step")
+    if compact:
+        check(_lib.lib().pc_p2v_train_step_compact(
+            ctypes.byref(st), ctypes.byref(gst), _p(table), _p(anchor_idx), _p(positive_idx), _p(negative_idx),
+            _p(nb_rows), n_real, _p(slot_row), b, n, k, float(margin), _p(out["loss"]), _p(out["d_pos"]),
+            _p(out["d_neg"]), _p(out.get("anchor_emb")), profile.handle if profile else None, _p(ws), nbytes,
+            _stream()), "pc_p2v_train_step_compact")
+        return out
     check(_lib.lib().pc_p2v_train_step(ctypes.byref(st), ctypes.byref(gst), _p(table), _p(anchor_idx),
                                        _p(positive_idx), _p(negative_idx), _p(neighbor_idx) if n else None, b, n, k,
                                        float(margin), _p(out["loss"]), _p(out["d_pos"]), _p(out["d_neg"]),
@@ -306,6 +321,37 @@ def build_similarity_batch(pair_ids, graph, n_pad, k_neg, seed, step):
                                                int(graph["n_products"]), n_pad, k_neg, int(seed), int(step), _p(a),
                                                _p(p), _p(ng), _p(nb), _stream()), "pc_build_similarity_batch")
     return a, p, ng, nb
+
+
+def build_similarity_batch_compact(pair_ids, graph, n_pad, k_neg, seed, step, n_real):
+    """Same batch with the neighbour rows compacted (pc_build_similarity_batch_compact): returns
+    anchor_idx, positive_idx, negative_idx, {"nb_rows": [n_real+1], "slot_row": [B,n_pad]}.  n_real =
+    sum of the batch's (capped) co-view degrees, known to the host loader."""
+    b = pair_ids.numel()
+    dev = pair_ids.device
+    _req(pair_ids, torch.int32, "pair_ids")
+    a = torch.empty(b, dtype=torch.int32, device=dev)
+    p = torch.empty(b, dtype=torch.int32, device=dev)
+    ng = torch.empty(b, k_neg, dtype=torch.int32, device=dev)
+    nb_rows = torch.empty(n_real + 1, dtype=torch.int32, device=dev)
+    slot_row = torch.empty(b, n_pad, dtype=torch.int32, device=dev)
+    row_off = torch.empty(b + 1, dtype=torch.int32, device=dev)
+    check(_lib.lib().pc_build_similarity_batch_compact(
+        _p(pair_ids), b, _p(graph["sim_pairs"]), _p(graph["cv_rowptr"]), _p(graph["cv_col"]), _p(graph["sim_rowptr"]),
+        _p(graph["sim_col"]), int(graph["n_products"]), n_pad, k_neg, int(seed), int(step), _p(a), _p(p), _p(ng),
+        _p(nb_rows), _p(slot_row), _p(row_off), _stream()), "pc_build_similarity_batch_compact")
+    return a, p, ng, {"nb_rows": nb_rows, "slot_row": slot_row}
+
+
+def compact_neighbors(neighbor_idx):
+    """Host-side compaction of a dense [B,N] neighbour index matrix (-1 = padding slot)."""
+    idx = neighbor_idx.cpu().numpy()
+    real = idx >= 0
+    nb_rows = np.concatenate([idx[real], [-1]]).astype(np.int32)
+    slot = np.full(idx.shape, int(real.sum()), np.int32)
+    slot[real] = np.arange(int(real.sum()), dtype=np.int32)
+    dev = neighbor_idx.device
+    return {"nb_rows": torch.from_numpy(nb_rows).to(dev), "slot_row": torch.from_numpy(slot).to(dev)}
 
 
 class CPythonRandom:

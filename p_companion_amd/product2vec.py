@@ -326,9 +326,9 @@ class Product2Vec(nn.Module, _FlatParamsMixin):
         self.flatten_parameters()
         params = self._tensor_dict()
         grads = {k: p.grad for k, p in self.named_parameters()}
+        nbr = batch.get("neighbor_compact", batch.get("neighbor_idx"))      # compact rows when the loader built them
         out = ops.p2v_train_step(params, grads, table, batch["anchor_idx"], batch["positive_idx"],
-                                 batch["negative_idx"], batch.get("neighbor_idx"), float(self.config.MARGIN),
-                                 profile=profile)
+                                 batch["negative_idx"], nbr, float(self.config.MARGIN), profile=profile)
         return out["loss"]
 
     def train_model(self, train_loader, optimizer, num_epochs=10) -> Dict[str, torch.Tensor]:

@@ -32,9 +32,10 @@ def _run_steps(ops, st, table, batch, n_steps):
         params[k] = st[k].clone().cuda()
     step = torch.zeros(1, dtype=torch.int64, device="cuda"); scal = torch.zeros(2, device="cuda")
     outs, first_grads, after1 = [], None, None
+    nbr = batch.get("neighbor_idx")
     for i in range(n_steps):
         out = ops.p2v_train_step(params, grads, table, batch["anchor_idx"], batch["positive_idx"],
-                                 batch["negative_idx"], batch.get("neighbor_idx"), 1.0, want_emb=True)
+                                 batch["negative_idx"], nbr, 1.0, want_emb=True)
         if i == 0:
             first_grads = {k: g.clone().cpu() for k, g in grads.items()}
             bn1 = {k: params[k].clone().cpu() for k in params if "running" in k or "num_batches" in k}
@@ -127,3 +128,55 @@ def test_train_step_no_neighbors_vs_oracle():
         elif k != "ffn.0.bias":
             np.testing.assert_allclose(grads[k].cpu(), gr, atol=2e-6 + 2e-4 * float(gr.abs().max()), err_msg=k)
     assert int(params["ffn.1.num_batches_tracked"]) == 3
+
+
+# ------------------------------------------------------------------ compact neighbour rows
+def test_train_step_compact_golden_b256(golden):
+    """pc_p2v_train_step_compact (zero-padding rows carried once, weighted in BatchNorm) against
+    the REFERENCE's golden step: 37% of this batch's neighbour slots are padding."""
+    from p_companion_amd import ops
+    g, st = _load(golden, "g4_p2v_b256.npz")
+    ints = golden("g2_bpg1000.npz")
+    table = torch.from_numpy(ints["features"]).cuda()
+    batch = {k: torch.from_numpy(g[k]).cuda() for k in ("anchor_idx", "positive_idx", "negative_idx")}
+    nb = torch.from_numpy(g["neighbor_idx"]).cuda()
+    comp = ops.compact_neighbors(nb)
+    assert comp["nb_rows"].numel() - 1 == int((g["neighbor_idx"] >= 0).sum()) < nb.numel()
+    batch["neighbor_idx"] = comp
+    outs, fg, bn1, after1, final = _run_steps(ops, st, table, batch, 3)
+    _check(g, outs, fg, bn1, final, golden("g4_p2v_b256_params3.npz"))
+
+
+def test_train_step_compact_golden_tiny(golden):
+    from p_companion_amd import ops
+    g, st = _load(golden, "g4_p2v_tiny.npz")
+    b = {k[6:]: torch.from_numpy(g[k]) for k in g.files if k.startswith("batch.")}
+    B, N = b["anchor_neighbors"].shape[:2]
+    table = torch.cat([b["anchor"], b["positive"], b["negative"].reshape(-1, 128),
+                       b["anchor_neighbors"].reshape(-1, 128)]).cuda()
+    ar = lambda lo, n: torch.arange(lo, lo + n, dtype=torch.int32).cuda()
+    nb = ar(B + B + 5 * B, B * N).view(B, N).clone()
+    nb[2, 4:] = -1; nb[5, 3:] = -1
+    batch = {"anchor_idx": ar(0, B), "positive_idx": ar(B, B), "negative_idx": ar(2 * B, 5 * B).view(B, 5),
+             "neighbor_idx": ops.compact_neighbors(nb)}
+    outs, fg, bn1, after1, final = _run_steps(ops, st, table, batch, 3)
+    _check(g, outs, fg, bn1, final, g)
+
+
+def test_compact_builder_matches_dense_builder(golden):
+    from p_companion_amd import ops
+    from p_companion_amd.data import IntBPG
+    bpg = IntBPG.from_arrays(golden("g2_bpg1000.npz"))
+    gdev = bpg.cuda()
+    ids = np.arange(100, 356, dtype=np.int32)
+    deg = bpg.degree(bpg.similarity_pairs[ids, 0])
+    n_pad = int(deg.max())
+    a, p, ng, nb = ops.build_similarity_batch(torch.from_numpy(ids).cuda(), gdev, n_pad, 5, seed=9, step=4)
+    a2, p2, ng2, comp = ops.build_similarity_batch_compact(torch.from_numpy(ids).cuda(), gdev, n_pad, 5, 9, 4,
+                                                          int(deg.sum()))
+    assert torch.equal(a, a2) and torch.equal(p, p2) and torch.equal(ng, ng2)
+    ref = ops.compact_neighbors(nb)
+    assert torch.equal(comp["nb_rows"], ref["nb_rows"]) and torch.equal(comp["slot_row"], ref["slot_row"])
+    # slot map reconstructs the dense matrix
+    rows = comp["nb_rows"].cpu().numpy()
+    assert np.array_equal(rows[comp["slot_row"].cpu().numpy()], nb.cpu().numpy())
