@@ -40,6 +40,25 @@ def bytes_per_triplet(n):
     return 512 * (n + 7) + 4 * (n + 7)
 
 
+def pmc_traffic_per_launch():
+    """HBM bytes per gemm_nt_kernel launch from the committed rocprofv3 --pmc passes of this same
+    command (profiles/*_pmc_traffic.json: FETCH_SIZE and WRITE_SIZE in separate passes, KiB -> bytes,
+    FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950).  None if no profile is committed:
+    PMC counters cannot be collected from inside the bench process."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_traffic.json")))
+    if not files:
+        return None
+    with open(files[-1]) as f:
+        d = json.load(f)
+    nt = [v for k, v in d.items() if "gemm_nt_kernel" in k]
+    n = sum(v["launches"] for v in nt)
+    if not n:
+        return None
+    return {"hbm_bytes_per_launch": round(sum((v["fetch_bytes_corrected"] + v["write_bytes"]) * v["launches"] for v in nt) / n),
+            "source": os.path.relpath(files[-1], ROOT)}
+
+
 def cpu_baseline(bpg, batch, seconds=15.0):
     """The oracle (CPU restatement pinned to the reference's golden vectors) timed on this
     box's host cores: same workload shape, pre-gathered dense batch, fwd+bwd+Adam."""
@@ -164,7 +183,7 @@ def main():
     achieved = nt["total_flops"] / (nt["total_ms"] * 1e-3) / 1e12 if nt["total_ms"] > 0 else 0.0
     roof = {"bound": "mfma", "kernel": "gemm_nt_kernel", "achieved": round(achieved, 2),
             "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / FP32_MFMA_PEAK_TFLOPS, 4),
-            "traffic": None,
+            "traffic": pmc_traffic_per_launch(),
             "launches": nt["launches"], "avg_launch_us": round(1e3 * nt["total_ms"] / max(nt["launches"], 1), 2),
             "flops_per_launch": nt["total_flops"] / max(nt["launches"], 1),
             "share_of_step": round(nt["total_ms"] / (el * 1e3), 3),

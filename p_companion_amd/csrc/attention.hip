@@ -32,9 +32,16 @@ __global__ __launch_bounds__(256) void attn_core_fwd_kernel(const float* q, cons
     qv.x *= scale; qv.y *= scale;
     const int32_t* sr = slot_row ? slot_row + (size_t)b * N : nullptr;
     const size_t base = (size_t)b * N;
+    // slot -> row: one coalesced load per wave, broadcast by shuffle (a per-key index load would put
+    // an extra dependent memory round trip in front of every K/V row)
+    const bool sr_reg = sr && N <= 64;
+    const int my_row = (sr_reg && lane < N) ? sr[lane] : 0;
+    auto row_of = [&](int n) -> size_t {
+        return sr_reg ? (size_t)__shfl(my_row, n, 64) : (sr ? (size_t)sr[n] : base + n);
+    };
     float m = -INFINITY;
     for (int n = 0; n < N; n++) {
-        const float* kvr = kv + (sr ? (size_t)sr[n] : base + n) * (2 * PC_D);
+        const float* kvr = kv + row_of(n) * (2 * PC_D);
         const float2 k2 = *reinterpret_cast<const float2*>(kvr + 2 * lane);
         const float s = group16_sum(qv.x * k2.x + qv.y * k2.y);
         if ((lane & 15) == 0) sc[h * N + n] = s;
@@ -45,7 +52,7 @@ __global__ __launch_bounds__(256) void attn_core_fwd_kernel(const float* q, cons
     float2 o = make_float2(0.f, 0.f);
     for (int n = 0; n < N; n++) {
         const float e = expf(sc[h * N + n] - m);
-        const float* kvr = kv + (sr ? (size_t)sr[n] : base + n) * (2 * PC_D);
+        const float* kvr = kv + row_of(n) * (2 * PC_D);
         const float2 v2 = *reinterpret_cast<const float2*>(kvr + PC_D + 2 * lane);
         sum += e;
         o.x += e * v2.x;
@@ -78,10 +85,15 @@ __global__ __launch_bounds__(256) void attn_core_bwd_kernel(const float* dctx, c
     qs.x *= scale; qs.y *= scale;
     const int32_t* sr = slot_row ? slot_row + (size_t)b * N : nullptr;
     const size_t base = (size_t)b * N;
+    const bool sr_reg = sr && N <= 64;
+    const int my_row = (sr_reg && lane < N) ? sr[lane] : 0;
+    auto row_of = [&](int n) -> size_t {
+        return sr_reg ? (size_t)__shfl(my_row, n, 64) : (sr ? (size_t)sr[n] : base + n);
+    };
     const float* pb = probs + (size_t)b * PC_HEADS * N + h * N;
     float dsum = 0.f;                                     // sum_n p_n * dp_n  (softmax backward)
     for (int n = 0; n < N; n++) {
-        const float* kvr = kv + (sr ? (size_t)sr[n] : base + n) * (2 * PC_D);
+        const float* kvr = kv + row_of(n) * (2 * PC_D);
         const float2 v2 = *reinterpret_cast<const float2*>(kvr + PC_D + 2 * lane);
         const float dp = group16_sum(g.x * v2.x + g.y * v2.y);
         if ((lane & 15) == 0) dps[h * N + n] = dp;
@@ -92,7 +104,7 @@ __global__ __launch_bounds__(256) void attn_core_bwd_kernel(const float* dctx, c
     for (int n = 0; n < N; n++) {
         const float p = pb[n];
         const float ds = p * (dps[h * N + n] - dsum);
-        const size_t row = sr ? (size_t)sr[n] : base + n;
+        const size_t row = row_of(n);
         const float2 k2 = *reinterpret_cast<const float2*>(kv + row * (2 * PC_D) + 2 * lane);
         dqa.x += ds * k2.x;
         dqa.y += ds * k2.y;
@@ -111,27 +123,36 @@ __global__ __launch_bounds__(256) void attn_core_bwd_kernel(const float* dctx, c
     *reinterpret_cast<float2*>(dq + (size_t)b * PC_D + 2 * lane) = make_float2(dqa.x * scale, dqa.y * scale);
 }
 
-// out[c] = sum_b x[b][c] over B rows of 2D columns: grid 2D/32 blocks of (32 columns x 32 row lanes)
-__global__ __launch_bounds__(1024) void colsum_kernel(const float* x, int B, float* out) {
-    __shared__ float red[32][33];
-    const int c = blockIdx.x * 32 + threadIdx.x, q = threadIdx.y;
-    float s = 0.f;
-    for (int b = q; b < B; b += 32) s += x[(size_t)b * (2 * PC_D) + c];
-    red[q][threadIdx.x] = s;
-    __syncthreads();
-    if (q == 0) {
-        float t = 0.f;
-#pragma unroll 8
-        for (int i = 0; i < 32; i++) t += red[i][threadIdx.x];
-        out[c] = t;
+// out[c] = sum_b x[b][c] over B rows of 2D = 256 columns, in two fixed-order stages: COLSUM_CHUNKS
+// workgroups each fold a contiguous slice of rows (thread = column, coalesced 1-KB rows), then one
+// workgroup folds the partials.
+#define COLSUM_CHUNKS 64
+__global__ __launch_bounds__(256) void colsum_partial_kernel(const float* x, int B, float* part) {
+    const int c = threadIdx.x;
+    const int per = (B + COLSUM_CHUNKS - 1) / COLSUM_CHUNKS;
+    const int b0 = blockIdx.x * per, b1 = min(B, b0 + per);
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    int b = b0;
+    for (; b + 3 < b1; b += 4) {
+        s0 += x[(size_t)b * 256 + c]; s1 += x[(size_t)(b + 1) * 256 + c];
+        s2 += x[(size_t)(b + 2) * 256 + c]; s3 += x[(size_t)(b + 3) * 256 + c];
     }
+    for (; b < b1; b++) s0 += x[(size_t)b * 256 + c];
+    part[blockIdx.x * 256 + c] = (s0 + s1) + (s2 + s3);
+}
+__global__ __launch_bounds__(256) void colsum_final_kernel(const float* part, float* out) {
+    const int c = threadIdx.x;
+    float s = 0.f;
+#pragma unroll 8
+    for (int i = 0; i < COLSUM_CHUNKS; i++) s += part[i * 256 + c];
+    out[c] = s;
 }
 
 // ---------------------------------------------------------------------------------------
 static inline size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
 
 struct AttnWs {
-    float *dctx, *dq, *dkv, *dkv_pad;   // backward intermediates
+    float *dctx, *dq, *dkv, *dkv_pad, *pad_part;   // backward intermediates
     float *wot, *wqt, *wkvt;      // transposed projections
     float *slabs; size_t slab_floats;
     size_t total;
@@ -149,6 +170,7 @@ static AttnWs attn_ws_layout(void* base, int B, int key_rows) {
     w.dq = take((size_t)B * PC_D);
     w.dkv = take((size_t)key_rows * 2 * PC_D);
     w.dkv_pad = take((size_t)B * 2 * PC_D);
+    w.pad_part = take((size_t)COLSUM_CHUNKS * 2 * PC_D);
     w.wot = take(PC_D * PC_D);
     w.wqt = take(PC_D * PC_D);
     w.wkvt = take(2 * PC_D * PC_D);
@@ -219,9 +241,12 @@ int attention_backward_impl(const pc_p2v_tensors* p, const pc_p2v_tensors* g, co
     AttnWs w = attn_ws_layout(ws, B, slot_row ? key_rows : B * N);
     const SegInfo si1 = make_seginfo(nullptr, B, 128), si2 = make_seginfo(nullptr, key_rows, 128);
 
-    PC_TRY(launch_transpose(p->out_proj_w, PC_D, PC_D, w.wot, st));
-    PC_TRY(launch_transpose(p->in_proj_w, PC_D, PC_D, w.wqt, st));
-    PC_TRY(launch_transpose(p->in_proj_w + PC_D * PC_D, 2 * PC_D, PC_D, w.wkvt, st));   // [2D,D] -> [D,2D]
+    TransposeBatch tb = {};
+    tb.job[0] = {p->out_proj_w, w.wot, PC_D, PC_D};
+    tb.job[1] = {p->in_proj_w, w.wqt, PC_D, PC_D};
+    tb.job[2] = {p->in_proj_w + PC_D * PC_D, w.wkvt, 2 * PC_D, PC_D};   // [2D,D] -> [D,2D]
+    tb.n = 3;
+    PC_TRY(launch_transpose_batch(tb, st));
 
     // out = ctx Wo^T + bo
     PC_TRY(launch_gemm_nt(nt_plain(dout, PC_D, w.wot, PC_D, nullptr, w.dctx, PC_D, B, PC_D, PC_D), st));
@@ -237,7 +262,9 @@ int attention_backward_impl(const pc_p2v_tensors* p, const pc_p2v_tensors* g, co
                        B, N, w.dq, w.dkv, slot_row, has_pad ? pad_row : -1, has_pad ? w.dkv_pad : nullptr);
     PC_TRY(pc_launch_status());
     if (has_pad) {
-        PC_LAUNCH(colsum_kernel, dim3(2 * PC_D / 32), dim3(32, 32), 0, st, w.dkv_pad, B, w.dkv + (size_t)pad_row * 2 * PC_D);
+        PC_LAUNCH(colsum_partial_kernel, dim3(COLSUM_CHUNKS), dim3(256), 0, st, w.dkv_pad, B, w.pad_part);
+        PC_TRY(pc_launch_status());
+        PC_LAUNCH(colsum_final_kernel, dim3(1), dim3(256), 0, st, w.pad_part, w.dkv + (size_t)pad_row * 2 * PC_D);
         PC_TRY(pc_launch_status());
     }
 

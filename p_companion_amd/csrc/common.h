@@ -172,6 +172,10 @@ struct NtArgs {
 int launch_gemm_nt(const NtArgs& a, hipStream_t st);
 int gemm_nt_tiles(const SegInfo& si);
 
+struct TransposeJob { const float* in; float* out; int rows, cols; };   // out[c][r] = in[r][c]
+struct TransposeBatch { TransposeJob job[4]; int n; };
+int launch_transpose_batch(const TransposeBatch& tb, hipStream_t st);
+
 struct TnArgs {
     // dW[No,Ni] (+)= sum_r Z[r][o] * A[r][i];  db[o] (+)= sum_r Z[r][o]
     const float* Z; int ldz;

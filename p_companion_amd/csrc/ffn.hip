@@ -154,6 +154,34 @@ __global__ void transpose_kernel(const float* in, int rows, int cols, float* out
     }
 }
 
+// several small transposes in ONE launch (blockIdx.z picks the matrix): the backward passes need
+// W^T of 2-3 weights each step and a launch boundary costs more than the transpose itself
+__global__ void transpose_batch_kernel(TransposeBatch tb) {
+    __shared__ float t[32][33];
+    const TransposeJob j = tb.job[blockIdx.z];
+    const int bx = blockIdx.x * 32, by = blockIdx.y * 32;
+    if (bx >= j.cols || by >= j.rows) return;
+    for (int i = threadIdx.y; i < 32; i += 8) {
+        const int r = by + i, c = bx + threadIdx.x;
+        t[i][threadIdx.x] = (r < j.rows && c < j.cols) ? j.in[(size_t)r * j.cols + c] : 0.f;
+    }
+    __syncthreads();
+    for (int i = threadIdx.y; i < 32; i += 8) {
+        const int c = bx + i, r = by + threadIdx.x;
+        if (r < j.rows && c < j.cols) j.out[(size_t)c * j.rows + r] = t[threadIdx.x][i];
+    }
+}
+
+int launch_transpose_batch(const TransposeBatch& tb, hipStream_t st) {
+    int mx = 0, my = 0;
+    for (int i = 0; i < tb.n; i++) {
+        mx = tb.job[i].cols > mx ? tb.job[i].cols : mx;
+        my = tb.job[i].rows > my ? tb.job[i].rows : my;
+    }
+    PC_LAUNCH(transpose_batch_kernel, dim3((mx + 31) / 32, (my + 31) / 32, tb.n), dim3(32, 8), 0, st, tb);
+    return pc_launch_status();
+}
+
 int launch_transpose(const float* in, int rows, int cols, float* out, hipStream_t st) {
     PC_LAUNCH(transpose_kernel, dim3((cols + 31) / 32, (rows + 31) / 32), dim3(32, 8), 0, st, in, rows, cols, out);
     return pc_launch_status();
@@ -285,8 +313,12 @@ static int ffn_backward_impl(const pc_p2v_tensors* p, const pc_p2v_tensors* g, c
     const SegInfo si = make_seginfo(seg, rows, 128);
     FfnWs w = ffn_ws_layout(ws, rows);
 
-    PC_TRY(launch_transpose(p->w5, PC_D, PC_H, w.w5t, st));   // [D,H] -> [H,D]
-    PC_TRY(launch_transpose(p->w3, PC_H, PC_H, w.w3t, st));
+    TransposeBatch tb = {};
+    tb.job[0] = {p->w5, w.w5t, PC_D, PC_H};                   // [D,H] -> [H,D]
+    tb.job[1] = {p->w3, w.w3t, PC_H, PC_H};
+    tb.n = 2;
+    if (dx) tb.job[tb.n++] = {p->w0, w.w0t, PC_H, PC_D};      // [H,D] -> [D,H]
+    PC_TRY(launch_transpose_batch(tb, st));
 
     // dZ2 = (dY W5) * (1 - A2^2)
     NtArgs b1 = nt_plain(dy, PC_D, w.w5t, PC_D, nullptr, w.dz2, PC_H, rows, PC_H, PC_D, si);
@@ -339,7 +371,6 @@ static int ffn_backward_impl(const pc_p2v_tensors* p, const pc_p2v_tensors* g, c
     PC_TRY(launch_gemm_tn(t0, st));
 
     if (dx) {
-        PC_TRY(launch_transpose(p->w0, PC_H, PC_D, w.w0t, st));   // [H,D] -> [D,H]
         NtArgs b3 = nt_plain(w.dz1, PC_H, w.w0t, PC_H, nullptr, dx, PC_D, rows, PC_D, PC_H, si);
         PC_TRY(launch_gemm_nt(b3, st));
     }

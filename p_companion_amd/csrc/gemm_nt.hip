@@ -24,7 +24,6 @@
 // 0-31 take k = 8j..8j+3, lanes 32-63 k = 8j+4..8j+7, identically for A and W) so one b128
 // read feeds four MFMAs.
 #include "common.h"
-#include <stdlib.h>
 
 #define PLD 36          // row stride (floats) of the per-wave epilogue transposition patch
 
@@ -37,7 +36,7 @@ int gemm_nt_tiles(const SegInfo& si) { return si.tile0[PC_MAX_SEG]; }
 // PRO / EPI / STATS are compile-time: a runtime switch per output element costs ~1200 scalar
 // branches per tile and wave (measured: 12 us of a 33 us tile) and the unused fusions' registers.
 template <int NWM, int NWN, int BK, int OCC, bool PRO, int EPI, int STATS>
-__global__ __launch_bounds__(64 * NWM * NWN, OCC) void gemm_nt_kernel(NtArgs a, int ntn, int total_tiles, int dbg) {
+__global__ __launch_bounds__(64 * NWM * NWN, OCC) void gemm_nt_kernel(NtArgs a, int ntn, int total_tiles) {
     constexpr int THREADS = 64 * NWM * NWN;
     constexpr int BM = 64 * NWM, BN = 64 * NWN;
     constexpr int LDS_LD = BK + 4;               // row stride: (BK+4)*4 B = odd multiple of 16 B => conflict-free b128 reads
@@ -154,7 +153,6 @@ __global__ __launch_bounds__(64 * NWM * NWN, OCC) void gemm_nt_kernel(NtArgs a, 
     };
 
     if (tile >= total_tiles) return;
-    if ((dbg & 16) && (blockIdx.x & 256)) { __builtin_amdgcn_s_sleep(100); }   // probe: phase-shift half of the blocks
     tile_geom(tile, row0, row_end, n0, seg);
     make_ptrs(a_source(row0, row_end), n0, aptr, aval, wptr, wval);
     gload(0, aptr, aval, wptr, wval, seg);
@@ -179,8 +177,7 @@ __global__ __launch_bounds__(64 * NWM * NWN, OCC) void gemm_nt_kernel(NtArgs a, 
         for (int kt = 0; kt < nk; kt++) {
             bool loaded = false;
             if (kt + 1 == nk) aux_prefetch();               // older than the prefetch below: its wait never covers it
-            if (dbg & 2) { loaded = true; }
-            else if (kt + 1 < nk) { gload((kt + 1) * BK, aptr, aval, wptr, wval, seg); loaded = true; }
+            if (kt + 1 < nk) { gload((kt + 1) * BK, aptr, aval, wptr, wval, seg); loaded = true; }
             else if (ntile < total_tiles) {
                 make_ptrs(nsrc, nn0, naptr, naval, nwptr, nwval);
                 gload(0, naptr, naval, nwptr, nwval, nseg);
@@ -215,14 +212,13 @@ __global__ __launch_bounds__(64 * NWM * NWN, OCC) void gemm_nt_kernel(NtArgs a, 
                 if (kk + 1 < BK / 8) __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
                 __builtin_amdgcn_sched_group_barrier(0x008, 16, 0);
             }
-            if (loaded && !(dbg & 4)) lstore(cur ^ 1);
-            if (!(dbg & 8)) __syncthreads();
+            if (loaded) lstore(cur ^ 1);
+            __syncthreads();
             cur ^= 1;
         }
 
         // ---- epilogue of `tile`.  Stage `cur` now holds the next tile's first chunk; the other
         // stage is free: each wave transposes its 32x32 sub-tiles through a private 32x36 patch.
-        if (dbg & 1) { if (ntile >= total_tiles) break; zero_acc(); tile = ntile; row0 = nrow0; row_end = nrow_end; n0 = nn0; seg = nseg; aptr = naptr; aval = naval; wptr = nwptr; wval = nwval; continue; }
         float* free_stage = smem + (cur ^ 1) * BUF;
         float* stg = free_stage + w * (32 * PLD);
         const int er = lane >> 3, ec = (lane & 7) * 4;          // staged read: rows er+8i, cols ec..ec+3
@@ -297,7 +293,7 @@ __global__ __launch_bounds__(64 * NWM * NWN, OCC) void gemm_nt_kernel(NtArgs a, 
                             else if (STATS == NT_STAT_BNBWD) { cs1[nt][q] += x; cs2[nt][q] += x * ((ax[q] - mu[q]) * is[q]); }
                         }
                     }
-                    if (rok && !(dbg & 32)) {
+                    if (rok) {
                         if (vec && col + 3 < a.N) {
                             *reinterpret_cast<float4*>(a.C + (size_t)row * a.ldc + col) = make_float4(v[0], v[1], v[2], v[3]);
                         } else {
@@ -358,31 +354,24 @@ static SegInfo retile(const SegInfo& in, int tile_rows) {
 }
 
 template <bool PRO, int EPI, int STATS>
-static void launch_variant(const NtArgs& a, int ntm, int dbg, hipStream_t st) {
-    if ((dbg & 64) && !PRO && STATS == NT_STAT_NONE && a.N > 128) {
-        // probe: 64 rows x 256 columns, 4 waves, BK 16, three workgroups per CU
-        NtArgs b = a;
-        b.seg = retile(a.seg, 64);
-        const int ntn = (a.N + 255) / 256, total = gemm_nt_tiles(b.seg) * ntn;
-        PC_LAUNCH((gemm_nt_kernel<1, 4, 16, 3, false, EPI, NT_STAT_NONE>), dim3(total < 768 ? total : 768), dim3(256), 0, st,
-                  b, ntn, total, dbg);
-    } else if (PRO || a.N > 128 || STATS != NT_STAT_NONE) {
+static void launch_variant(const NtArgs& a, int ntm, hipStream_t st) {
+    if (PRO || a.N > 128 || STATS != NT_STAT_NONE) {
         // 128 rows x 256 columns, 8 waves, one workgroup per CU: A is read once
         const int ntn = (a.N + 255) / 256, total = ntm * ntn;
         PC_LAUNCH((gemm_nt_kernel<2, 4, 32, 2, PRO, EPI, STATS>), dim3(total < 256 ? total : 256), dim3(512), 0, st, a, ntn,
-                  total, dbg);
+                  total);
     } else if (ntm >= 192) {
         // N <= 128: 128x128 tiles, two independent 4-wave workgroups per CU (measured 89 vs 77 TF/s
         // for one 256x128 8-wave workgroup: the second workgroup fills the first one's epilogue)
         PC_LAUNCH((gemm_nt_kernel<2, 2, 32, 2, false, EPI, NT_STAT_NONE>), dim3(ntm < 512 ? ntm : 512), dim3(256), 0, st, a,
-                  1, ntm, dbg);
+                  1, ntm);
     } else {
         // few rows (per-sample projections of the attention block, joint-step layers): 64-row
         // tiles of 2 waves reach 2x the CUs
         NtArgs b = a;
         b.seg = retile(a.seg, 64);
         const int total = gemm_nt_tiles(b.seg);
-        PC_LAUNCH((gemm_nt_kernel<1, 2, 32, 2, false, EPI, NT_STAT_NONE>), dim3(total), dim3(128), 0, st, b, 1, total, dbg);
+        PC_LAUNCH((gemm_nt_kernel<1, 2, 32, 2, false, EPI, NT_STAT_NONE>), dim3(total), dim3(128), 0, st, b, 1, total);
     }
 }
 
@@ -397,19 +386,18 @@ int launch_gemm_nt(const NtArgs& a, hipStream_t st) {
     const bool needs_aux = a.epilogue == NT_EPI_DTANH || a.epilogue == NT_EPI_DTANH_BN || a.epilogue == NT_EPI_DRELU;
     if (needs_aux && !a.aux) return PC_EINVAL;
     if (a.stats != NT_STAT_NONE && (a.N > 256 || !a.stat_sum || !a.stat_aux)) return PC_ESHAPE;
-    static const int dbg = getenv("PC_NT_DBG") ? atoi(getenv("PC_NT_DBG")) : 0;   // developer probe only
     // the fusions the two hot paths use (any other combination is refused)
     const int key = a.prologue * 100 + a.epilogue * 10 + a.stats;
     const int pb = pc_prof_begin(PC_KIND_GEMM_NT, 2.0 * a.M * (double)a.N * a.K, st);
     switch (key) {
-        case 0:   launch_variant<false, NT_EPI_NONE, NT_STAT_NONE>(a, ntm, dbg, st); break;      // plain Linear / dX
-        case 1:   launch_variant<false, NT_EPI_NONE, NT_STAT_SUMSQ>(a, ntm, dbg, st); break;     // Linear0 + BN sums
-        case 110: launch_variant<true, NT_EPI_TANH, NT_STAT_NONE>(a, ntm, dbg, st); break;       // BN+tanh -> Linear3 -> tanh
-        case 10:  launch_variant<false, NT_EPI_TANH, NT_STAT_NONE>(a, ntm, dbg, st); break;
-        case 20:  launch_variant<false, NT_EPI_RELU, NT_STAT_NONE>(a, ntm, dbg, st); break;
-        case 30:  launch_variant<false, NT_EPI_DTANH, NT_STAT_NONE>(a, ntm, dbg, st); break;     // dZ2
-        case 42:  launch_variant<false, NT_EPI_DTANH_BN, NT_STAT_BNBWD>(a, ntm, dbg, st); break; // dZ1 + BN-backward sums
-        case 50:  launch_variant<false, NT_EPI_DRELU, NT_STAT_NONE>(a, ntm, dbg, st); break;
+        case 0:   launch_variant<false, NT_EPI_NONE, NT_STAT_NONE>(a, ntm, st); break;      // plain Linear / dX
+        case 1:   launch_variant<false, NT_EPI_NONE, NT_STAT_SUMSQ>(a, ntm, st); break;     // Linear0 + BN sums
+        case 110: launch_variant<true, NT_EPI_TANH, NT_STAT_NONE>(a, ntm, st); break;       // BN+tanh -> Linear3 -> tanh
+        case 10:  launch_variant<false, NT_EPI_TANH, NT_STAT_NONE>(a, ntm, st); break;
+        case 20:  launch_variant<false, NT_EPI_RELU, NT_STAT_NONE>(a, ntm, st); break;
+        case 30:  launch_variant<false, NT_EPI_DTANH, NT_STAT_NONE>(a, ntm, st); break;     // dZ2
+        case 42:  launch_variant<false, NT_EPI_DTANH_BN, NT_STAT_BNBWD>(a, ntm, st); break; // dZ1 + BN-backward sums
+        case 50:  launch_variant<false, NT_EPI_DRELU, NT_STAT_NONE>(a, ntm, st); break;
         default:  return PC_ESHAPE;
     }
     pc_prof_end(pb, st);
