@@ -102,6 +102,7 @@ def main():
     rank, world, local = pdist.init_from_env("cuda")
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+    local = int(os.environ.get("PC_FORCE_DEVICE", local))
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
 

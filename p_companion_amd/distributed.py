@@ -26,8 +26,11 @@ def init_from_env(device_type="cuda"):
     if world > 1 and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
-        backend = "nccl" if device_type == "cuda" else "gloo"
+        # PC_DIST_BACKEND / PC_FORCE_DEVICE: rehearsal of the N>1 path on a one-GPU box (gloo, every rank
+        # on the same card); the driver's multi-GPU runs use neither
+        backend = os.environ.get("PC_DIST_BACKEND", "nccl" if device_type == "cuda" else "gloo")
         if device_type == "cuda":
+            local = int(os.environ.get("PC_FORCE_DEVICE", local))
             torch.cuda.set_device(local)
         dist.init_process_group(backend=backend, rank=rank, world_size=world)
     return rank, world, local
