@@ -85,6 +85,72 @@ def cpu_baseline(bpg, batch, seconds=15.0):
                       f"pre-gathered batch) on {os.cpu_count()} host cpus, torch {torch.get_num_threads()} threads"}
 
 
+def joint_phase(args, rank, world, dev):
+    """BASELINE configs[2]: 100k products, T types, B pairs per GPU: PCompanion forward + both hinge
+    losses + backward + Adam as pc_joint_train_step / pc_adam_step.  HBM/launch-latency bound
+    (~2.6 KB and ~0.3 MFLOP per triplet): the roofline object reports the gather bandwidth."""
+    from types import SimpleNamespace
+    from p_companion_amd import distributed as pdist
+    from p_companion_amd.data import ComplementaryIndexDataset, ComplementaryIndexLoader, generate_scaled_bpg
+    from p_companion_amd.p_companion import PCompanion
+    from p_companion_amd.product2vec import FusedAdam
+    cfg = SimpleNamespace(PRODUCT_EMB_DIM=128, TYPE_EMB_DIM=64, DROPOUT=0.0, MARGIN=1.0, ALPHA=0.8, NUM_COMP_TYPES=3,
+                          NUM_TYPES=args.types, DEVICE=dev)
+    bpg = generate_scaled_bpg(args.products, min(args.types, 100), seed=0)
+    torch.manual_seed(0)
+    model = PCompanion(cfg, bpg.cuda(dev)["features"]).to(dev).train()       # frozen table: synthetic stand-in for the P2V export
+    opt = FusedAdam(model, lr=1e-3)
+    flat, gflat = model.flatten_parameters()
+    loader = ComplementaryIndexLoader(ComplementaryIndexDataset(bpg, "train"), args.batch, shuffle=True, seed=rank,
+                                      device=dev)
+
+    def batches():
+        while True:
+            for b in loader:
+                if b["query_idx"].numel() == args.batch:
+                    yield b
+
+    it = batches()
+
+    def step(b):
+        losses, _ = model.train_step(b)
+        pdist.all_reduce_mean_(gflat, world)
+        opt.step()
+        return losses
+
+    for _ in range(args.warmup):
+        step(next(it))
+    if world > 1:
+        torch.distributed.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        losses = step(next(it))
+    torch.cuda.synchronize()
+    if world > 1:
+        torch.distributed.barrier()
+    t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=dev)
+    if world > 1:
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+    el = float(t)
+    if rank != 0:
+        return
+    value = world * args.batch * args.steps / el
+    bytes_per = 2600.0
+    out = {"metric": "triplets/sec (P-Companion joint step: fwd + type/item hinge + bwd + Adam)", "value": round(value, 1),
+           "unit": "triplets/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+           "ms_per_step": round(1e3 * el / args.steps, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+           "dtype": "f32", "data": "synthetic",
+           "config": {"workload": f"P-Companion joint step, {args.products} products, {args.types} types, dim=128, "
+                                  f"batch={args.batch}/GPU, K=3 (loader batch construction included)",
+                      "global_batch": world * args.batch, "parallelism": f"dp{world}", "final_loss": round(float(losses[0]), 5)},
+           "roofline": {"bound": "hbm", "achieved": round(bytes_per * value / world / 1e9, 2), "peak": HBM_PEAK_GBS,
+                        "unit": "GB/s", "frac": round(bytes_per * value / world / 1e9 / HBM_PEAK_GBS, 5), "traffic": None,
+                        "note": "2.6 KB gathered per triplet (SURVEY 8d); the step is ~30 launches of a few us each: launch/latency bound"},
+           "cpu_baseline": None}
+    print(json.dumps(out), flush=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -94,6 +160,8 @@ def main():
     ap.add_argument("--types", type=int, default=100)
     ap.add_argument("--batch", type=int, default=4096)
     ap.add_argument("--table", choices=["replicated", "sharded"], default="replicated")
+    ap.add_argument("--phase", choices=["p2v", "joint"], default="p2v",
+                    help="p2v = BASELINE configs[1] (the headline line); joint = configs[2], the P-Companion joint step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     args = ap.parse_args()
@@ -105,6 +173,9 @@ def main():
     local = int(os.environ.get("PC_FORCE_DEVICE", local))
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
+
+    if args.phase == "joint":
+        return joint_phase(args, rank, world, dev)
 
     from types import SimpleNamespace
     from p_companion_amd import ops

@@ -203,6 +203,17 @@ int pc_build_similarity_batch(const int32_t *pair_ids, int batch, const int32_t 
                               int32_t *anchor_idx, int32_t *positive_idx, int32_t *negative_idx,
                               int32_t *neighbor_idx, void *stream);
 
+/* J1 on device: ComplementaryDataset.__getitem__ + collate_fn (data_loader.py:133-157) for `batch`
+ * labelled pairs[b] = (query, target, label in {+1,-1}) (int32 x3): query_idx/query_types/
+ * pos_types/neg_types [B] by the reference's label rules (:148-151), pos_items/neg_items [B,D] =
+ * feat(target) or an N(0,1) filler (torch.randn_like in the reference: input data; here Philox +
+ * Box-Muller keyed by seed/step), target_features [B,D] optional. */
+int pc_build_complementary_batch(const int32_t *pairs, int batch, const float *features,
+                                 const int32_t *type_idx, int n_types, uint64_t seed, uint64_t step,
+                                 int32_t *query_idx, int32_t *query_types, int32_t *pos_types,
+                                 int32_t *neg_types, float *pos_items, float *neg_items,
+                                 float *target_features, void *stream);
+
 /* P2 exact (HOST pointers, host code): SimilarityDataset._get_negative_samples
  * (data_loader.py:27-40) on CPython's `random` stream: MT19937, random.seed(int) key
  * schedule, choice() = _randbelow_with_getrandbits.  Bit-exact negative indices.

@@ -82,6 +82,7 @@ SIGNATURES = {
     "pc_profile_summary": (_i, [_vp, _i, _P(ctypes.c_int), _P(ctypes.c_double), _P(ctypes.c_double)]),
     "pc_build_similarity_batch": (_i, [_vp, _i, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _u64, _u64, _vp, _vp, _vp,
                                        _vp, _vp]),
+    "pc_build_complementary_batch": (_i, [_vp, _i, _vp, _vp, _i, _u64, _u64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "pc_mt_state_bytes": (_sz, []),
     "pc_mt_seed": (_i, [_vp, _u64]),
     "pc_mt_getrandbits": (ctypes.c_uint32, [_vp, _i]),

@@ -171,3 +171,62 @@ extern "C" int pc_build_similarity_batch(const int32_t* pair_ids, int batch, con
     }
     return PC_OK;
 }
+
+// ---------------------------------------------------------------------------------------
+// J1 on device: ComplementaryDataset.__getitem__ + collate_fn (data_loader.py:133-157) for a batch
+// of labelled pairs (query, target, label):
+//   label +1: positive_types = t(target), negative_types = (t(target)+1) % n_types,
+//             positive_items = feat(target), negative_items = N(0,1) filler
+//   label -1: positive_types = 0, negative_types = t(target),
+//             positive_items = N(0,1) filler, negative_items = feat(target)
+// The filler is input DATA (torch.randn_like in the reference's worker): here Philox4x32-10 +
+// Box-Muller keyed by (seed; row, 16-B chunk, step).  One thread per 16-B chunk of a row.
+__device__ __forceinline__ float2 box_muller(uint32_t a, uint32_t b) {
+    const float u1 = ((float)(a >> 8) + 0.5f) * (1.0f / 16777216.0f);      // (0,1)
+    const float u2 = ((float)(b >> 8) + 0.5f) * (1.0f / 16777216.0f);
+    const float r = sqrtf(-2.0f * __logf(u1));
+    float sn, cs;
+    __sincosf(6.283185307179586f * u2, &sn, &cs);
+    return make_float2(r * cs, r * sn);
+}
+
+__global__ void build_complementary_batch_kernel(const int32_t* pairs, int B, const float* features,
+                                                 const int32_t* type_idx, int n_types, uint64_t seed, uint64_t step,
+                                                 int32_t* query_idx, int32_t* query_types, int32_t* pos_types,
+                                                 int32_t* neg_types, float* pos_items, float* neg_items,
+                                                 float* target_features) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= B * (PC_D / 4)) return;
+    const int b = t / (PC_D / 4), c = t % (PC_D / 4);
+    const int q = pairs[3 * b], tg = pairs[3 * b + 1], lab = pairs[3 * b + 2];
+    const float4 f = *reinterpret_cast<const float4*>(features + (size_t)tg * PC_D + 4 * c);
+    Philox rng(seed, step, (uint32_t)t);
+    const float2 n0 = box_muller(rng.next(), rng.next()), n1 = box_muller(rng.next(), rng.next());
+    const float4 fill = make_float4(n0.x, n0.y, n1.x, n1.y);
+    const bool pos = lab == 1;
+    *reinterpret_cast<float4*>(pos_items + (size_t)b * PC_D + 4 * c) = pos ? f : fill;
+    *reinterpret_cast<float4*>(neg_items + (size_t)b * PC_D + 4 * c) = pos ? fill : f;
+    if (target_features) *reinterpret_cast<float4*>(target_features + (size_t)b * PC_D + 4 * c) = f;
+    if (c == 0) {
+        const int tt = type_idx[tg];
+        query_idx[b] = q;
+        query_types[b] = type_idx[q];
+        pos_types[b] = pos ? tt : 0;
+        neg_types[b] = pos ? (tt + 1) % n_types : tt;
+    }
+}
+
+extern "C" int pc_build_complementary_batch(const int32_t* pairs, int batch, const float* features,
+                                            const int32_t* type_idx, int n_types, uint64_t seed, uint64_t step,
+                                            int32_t* query_idx, int32_t* query_types, int32_t* pos_types,
+                                            int32_t* neg_types, float* pos_items, float* neg_items,
+                                            float* target_features, void* stream) {
+    if (!pairs || !features || !type_idx || !query_idx || !query_types || !pos_types || !neg_types || !pos_items ||
+        !neg_items || batch <= 0 || n_types <= 0)
+        return PC_EINVAL;
+    const int total = batch * (PC_D / 4);
+    PC_LAUNCH(build_complementary_batch_kernel, dim3((total + 255) / 256), dim3(256), 0, (hipStream_t)stream, pairs, batch,
+              features, type_idx, n_types, seed, step, query_idx, query_types, pos_types, neg_types, pos_items,
+              neg_items, target_features);
+    return pc_launch_status();
+}

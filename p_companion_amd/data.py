@@ -259,35 +259,25 @@ class ComplementaryIndexLoader:
         self.epoch = 0
         g = dataset.bpg.cuda(device)
         self.features, self.type_idx = g["features"], g["type_idx"]
-        self.gen = torch.Generator(device=device)
-        self.gen.manual_seed(seed)
+        self.step = 0
 
     def __len__(self):
         return (len(self.dataset) + self.batch_size - 1) // self.batch_size
 
-    def make_batch(self, rows):
+    def make_batch(self, rows_dev, rows_host=None):
+        """One HIP launch (pc_build_complementary_batch) builds the whole batch from [B,3] device pairs."""
         from . import ops
-        ds = self.dataset
-        q = torch.from_numpy(np.ascontiguousarray(rows[:, 0])).to(self.device)
-        tgt = torch.from_numpy(np.ascontiguousarray(rows[:, 1])).to(self.device)
-        pos = torch.from_numpy(rows[:, 2] == 1).to(self.device)
-        tt = self.type_idx[tgt.long()]
-        n_types = ds.bpg.n_types
-        feat = ops.gather_rows(self.features, tgt)
-        filler = torch.randn(feat.shape, generator=self.gen, device=self.device)
-        zero = torch.zeros_like(tt)
-        return {
-            "query_idx": q, "query_types": self.type_idx[q.long()].contiguous(),
-            "positive_types": torch.where(pos, tt, zero).view(-1, 1),
-            "negative_types": torch.where(pos, (tt + 1) % n_types, tt).view(-1, 1),
-            "positive_items": torch.where(pos[:, None], feat, filler),
-            "negative_items": torch.where(pos[:, None], filler, feat),
-            "target_features": feat, "label": torch.from_numpy(rows[:, 2].copy()).to(self.device)}
+        batch = ops.build_complementary_batch(rows_dev, self.features, self.type_idx, self.dataset.bpg.n_types,
+                                              self.seed, self.step)
+        self.step += 1
+        batch["label"] = rows_dev[:, 2]
+        return batch
 
     def __iter__(self):
         n = len(self.dataset)
         rs = np.random.Generator(np.random.Philox([self.seed + 7, self.epoch]))
         order = rs.permutation(n) if self.shuffle else np.arange(n)
         self.epoch += 1
+        pairs_dev = torch.from_numpy(np.ascontiguousarray(self.dataset.pairs[order], np.int32)).to(self.device)
         for i in range(len(self)):
-            yield self.make_batch(self.dataset.pairs[order[i * self.batch_size:(i + 1) * self.batch_size]])
+            yield self.make_batch(pairs_dev[i * self.batch_size:(i + 1) * self.batch_size])

@@ -587,3 +587,23 @@ def cosine_rows(x, y):
     out = torch.empty(b * k, dtype=torch.float32, device=x.device)
     check(_lib.lib().pc_cosine_rows(_p(x), _p(y), b, k, _p(out), _stream()), "pc_cosine_rows")
     return out
+
+
+def build_complementary_batch(pairs, features, type_idx, n_types, seed, step, want_targets=True):
+    """pairs [B,3] int32 (query, target, label) on the device -> the joint-step batch dict."""
+    b = pairs.shape[0]
+    _req(pairs, torch.int32, "pairs", (b, 3)); _req(features, torch.float32, "features"); _req(type_idx, torch.int32, "type_idx")
+    dev = pairs.device
+    i32 = lambda: torch.empty(b, dtype=torch.int32, device=dev)
+    f32 = lambda: torch.empty(b, D, dtype=torch.float32, device=dev)
+    out = {"query_idx": i32(), "query_types": i32(), "positive_types": i32(), "negative_types": i32(),
+           "positive_items": f32(), "negative_items": f32()}
+    if want_targets:
+        out["target_features"] = f32()
+    check(_lib.lib().pc_build_complementary_batch(
+        _p(pairs), b, _p(features), _p(type_idx), int(n_types), int(seed), int(step), _p(out["query_idx"]),
+        _p(out["query_types"]), _p(out["positive_types"]), _p(out["negative_types"]), _p(out["positive_items"]),
+        _p(out["negative_items"]), _p(out.get("target_features")), _stream()), "pc_build_complementary_batch")
+    out["positive_types"] = out["positive_types"].view(b, 1)
+    out["negative_types"] = out["negative_types"].view(b, 1)
+    return out

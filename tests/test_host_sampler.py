@@ -22,10 +22,6 @@ def test_stream_golden(golden, CPy, seed):
     assert [r.getrandbits(10) for _ in range(64)] == g[tag + "getrandbits10"].tolist()
     assert [r.getrandbits(32) for _ in range(16)] == g[tag + "getrandbits32"].tolist()
     assert [r.randbelow(1000) for _ in range(64)] == g[tag + "choice1000"].tolist()
-    r.randbelow(1 << 53), r.randbelow(1 << 53)          # not comparable to random(): skip 16 doubles = 32 words
-    r2 = CPy(seed)
-    for _ in range(64 + 16 + 64):
-        pass
     # shuffle after the same prefix as the fixture (64 + 16 + 64 draws, then 16 random() = 32 words)
     r3 = CPy(seed)
     [r3.getrandbits(10) for _ in range(64)]; [r3.getrandbits(32) for _ in range(16)]
