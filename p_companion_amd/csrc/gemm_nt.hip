@@ -10,55 +10,100 @@
 // stream, not around K:
 //   * a workgroup owns 128 rows x the FULL N (up to 256 columns: 8 waves as 2 x 4, each 64x64
 //     = 2x2 v_mfma_f32_32x32x2_f32 accumulators) so A is read from HBM exactly once;
-//   * workgroups are PERSISTENT over row tiles and the K-chunk prefetch runs across tile
-//     boundaries (the first chunk of the next tile -- including its gather indices -- is in
-//     flight during the last chunk of this one), so short K (4-8 chunks) behaves like one
-//     long pipelined loop;
+//   * operands go global -> LDS DIRECTLY (global_load_lds_dwordx4, no VGPR hop and no ds_write):
+//     measured on this loop, 138 TFLOP/s steady state against 104 for register staging
+//     (scripts/microbench/nt_staging.hip).  A wave instruction drops 1 KB = 256/BK whole rows
+//     into an UNPADDED stage; bank conflicts are avoided by an XOR swizzle applied on the global
+//     side (each lane picks which 16-B chunk of its row it fetches).  The DMA is issued from inline
+//     asm and waited for by hand (s_waitcnt vmcnt(0) before the stage's barrier): through the
+//     builtin, the compiler's conservative LDS-alias tracking parks a vmcnt(0) in front of every
+//     ds_read that follows an issue, which serialises the prefetch with the MFMA stream;
+//   * workgroups are PERSISTENT over row tiles and the stage stream runs across tile boundaries
+//     (the first chunk of the next tile -- including its gather indices -- is in flight during
+//     the last chunk of this one); two workgroups share a CU so one's epilogue overlaps the
+//     other's MFMA stream;
 //   * rows of A may be gathered by index straight from the feature table (BPG neighbour
-//     gather, -1 = zero row), tiles never straddle a BatchNorm segment, A can be transformed on
-//     load (BN-apply + tanh) and the epilogue can emit per-tile BatchNorm partial sums;
-//   * the epilogue goes through LDS so that C (and the aux operand of the d-activation
-//     epilogues) move as 16-B per lane, 8 full 128-B row segments per wave-instruction.
-// LDS image: [row][36 floats] (stride 144 B => ds_read_b128 of 16 distinct rows hits 16
-// distinct 16-B slots), double-buffered; operands are fetched with a permuted k order (lanes
-// 0-31 take k = 8j..8j+3, lanes 32-63 k = 8j+4..8j+7, identically for A and W) so one b128
-// read feeds four MFMAs.
+//     gather, -1 = zero row), tiles never straddle a BatchNorm segment, A can be transformed
+//     (BN-apply + tanh, in place in LDS) and the epilogue can emit per-tile BatchNorm partial sums;
+//   * the epilogue goes through per-wave LDS patches so that C (and the aux operand of the
+//     d-activation epilogues) move as 16 B per lane, 8 full 128-B row segments per instruction.
+// Operands are fetched with a permuted k order (lanes 0-31 take k = 8j..8j+3, lanes 32-63
+// k = 8j+4..8j+7, identically for A and W) so one ds_read_b128 feeds four MFMAs.
 #include "common.h"
 
 #define PLD 36          // row stride (floats) of the per-wave epilogue transposition patch
+#define PROWS 16        // rows per patch: half a 32x32 accumulator block
 
 int gemm_nt_tiles(const SegInfo& si) { return si.tile0[PC_MAX_SEG]; }
 
+__device__ __attribute__((aligned(64))) float pc_zero_chunk[16];   // source of every zero-filled 16-B chunk
+
+typedef __attribute__((address_space(3))) void* lptr_t;
+
+// 64 lanes x 16 B from per-lane global addresses to LDS [lds_addr + 16 * lane].  In-order with every
+// other vector-memory operation of the wave (vmcnt), so compiler-placed waits stay correct (at worst
+// they wait for this too); the data is visible after s_waitcnt vmcnt(0) + a workgroup barrier.
+#pragma clang diagnostic push
+#pragma clang diagnostic ignored "-Winline-asm"
+__device__ __forceinline__ void dma16(const float* gsrc, unsigned lds_addr) {
+    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(gsrc), "s"(lds_addr) : "memory", "m0");
+}
+#pragma clang diagnostic pop
+
+// LDS-only hand-off between waves: no global-memory fence (a __syncthreads() would also wait for
+// this wave's outstanding C stores and for the next stage's DMA)
+__device__ __forceinline__ void lds_sync() {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+}
+
 // NWM x NWN waves of 64x64 each: BM = 64*NWM rows, BN = 64*NWN columns.
-//   <2,4> 128x256, 8 waves, one workgroup per CU   (N > 128)
-//   <2,2> 128x128, 4 waves, two workgroups per CU  (N <= 128, many rows)
-//   <1,2>  64x128, 2 waves                         (few rows: more, smaller tiles fill more CUs)
+//   <2,4> 128x256, 8 waves   (N > 128, prologue or statistics)
+//   <2,2> 128x128, 4 waves   (N <= 128, many rows)
+//   <1,2>  64x128, 2 waves   (few rows: more, smaller tiles fill more CUs)
+// WPS = resident waves per SIMD the register budget is set for.
 // PRO / EPI / STATS are compile-time: a runtime switch per output element costs ~1200 scalar
 // branches per tile and wave (measured: 12 us of a 33 us tile) and the unused fusions' registers.
-template <int NWM, int NWN, int BK, int OCC, bool PRO, int EPI, int STATS>
-__global__ __launch_bounds__(64 * NWM * NWN, OCC) void gemm_nt_kernel(NtArgs a, int ntn, int total_tiles) {
-    constexpr int THREADS = 64 * NWM * NWN;
-    constexpr int BM = 64 * NWM, BN = 64 * NWN;
-    constexpr int LDS_LD = BK + 4;               // row stride: (BK+4)*4 B = odd multiple of 16 B => conflict-free b128 reads
-    constexpr int CPR = BK / 4;                  // float4 chunks per row per K-step
-    constexpr int APT = BM * CPR / THREADS;      // float4 of A per thread per chunk, all from one row
-    constexpr int WPT = BN * CPR / THREADS;      // float4 of W per thread per chunk
-    constexpr int TPR_A = CPR / APT, TPR_W = CPR / WPT;
-    constexpr int BUF0 = (BM + BN) * LDS_LD;     // floats per stage: A image then W image
-    constexpr int BUF = BUF0 > (THREADS / 64) * 32 * PLD ? BUF0 : (THREADS / 64) * 32 * PLD;   // also hosts the epilogue patches
-    __shared__ __attribute__((aligned(16))) float smem[2 * BUF];
+template <int NWM, int NWN, int BK, int WPS, bool PRO, int EPI, int STATS>
+__global__ __launch_bounds__(64 * NWM * NWN, WPS) void gemm_nt_kernel(NtArgs a, int ntn, int total_tiles) {
+    constexpr int NW = NWM * NWN, THREADS = 64 * NW;
+    constexpr int BM = 64 * NWM, BN = 64 * NWN, SR = BM + BN;     // stage rows: A image then W image
+    constexpr int CPR = BK / 4;                   // 16-B chunks per stage row
+    constexpr int RB = 64 / BK;                   // stage rows per 256 B (one pass over the 64 banks)
+    constexpr int RPI = 256 / BK;                 // stage rows one wave instruction fills (1 KB)
+    constexpr int NI = SR / RPI / NW;             // DMA instructions per wave and stage
+    constexpr int NIA = BM / RPI / NW;            // ... the first NIA of them fetch rows of A
+    static_assert(SR % (RPI * NW) == 0 && BM % (RPI * NW) == 0, "row blocks must split evenly over the waves");
+    static_assert(!PRO || BM * CPR == THREADS, "in-place prologue: one 16-B chunk per thread");
+    constexpr int PATCH = NW * PROWS * PLD;
+    constexpr int STAGE = SR * BK;                // floats per stage
+    __shared__ __attribute__((aligned(1024))) float stages[2 * STAGE];
+    __shared__ __attribute__((aligned(16))) float patch[PATCH];
+    __shared__ float red[STATS != NT_STAT_NONE ? 2 * NWM * BN : 1];                           // [2 stats][NWM][BN]
+    __shared__ __attribute__((aligned(16))) float pro_ss[PRO ? 2 * PC_MAX_SEG * 256 : 4];   // [seg][scale|shift][K]
 
-    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, wm = w % NWM, wn = w / NWM;
-    const int la_row = tid / TPR_A, la_c = (tid % TPR_A) * APT * 4;       // loader: A row / first float
-    const int lw_row = tid / TPR_W, lw_c = (tid % TPR_W) * WPT * 4;       // loader: W row / first float
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6), wm = w % NWM, wn = w / NWM;     // wave-uniform: SGPRs
     const int nk = (a.K + BK - 1) / BK;
-    constexpr bool pro = PRO;
+    // loader geometry: this lane's row inside a wave instruction's row block, and the chunk of that
+    // row it fetches (slot ^ swizzle; the swizzle of a row is (row / RB) % CPR, the same for every j)
+    const int lrow = lane / CPR;
+    const int lchunk = (lane % CPR) ^ ((((w * RPI) + lrow) / RB) % CPR);
+    const float* const zsrc = pc_zero_chunk;
+
+    if (PRO) {
+        for (int i = tid; i < a.seg.nseg * a.K; i += THREADS) {
+            const int s = i / a.K, k = i - s * a.K;
+            pro_ss[(2 * s) * 256 + k] = a.pscale[i];
+            pro_ss[(2 * s + 1) * 256 + k] = a.pshift[i];
+        }
+    }
 
     // ---- per-tile state ------------------------------------------------------------------
     int tile = blockIdx.x;
+    if (tile >= total_tiles) return;
     int row0 = 0, row_end = 0, n0 = 0, seg = 0;
-    const float* aptr = a.A;  bool aval = false;
-    const float* wptr = a.W;  bool wval = false;
     auto tile_geom = [&](int t, int& r0, int& rend, int& nn0, int& sg) {
         const int tm = t / ntn, tn = t % ntn;
         sg = seg_of_tile(a.seg, tm);
@@ -66,48 +111,34 @@ __global__ __launch_bounds__(64 * NWM * NWN, OCC) void gemm_nt_kernel(NtArgs a, 
         rend = a.seg.start[sg + 1];
         nn0 = tn * BN;
     };
-    // source row of this thread's A row: -1 = zero row (padding slot or past the segment end)
-    auto a_source = [&](int r0, int rend) -> int {
-        const int r = r0 + la_row;
-        if (r >= rend) return -1;
-        return a.gather ? a.gather[r] : r;
-    };
-    auto make_ptrs = [&](int src, int nn0, const float*& ap, bool& av, const float*& wp, bool& wv) {
-        av = src >= 0;
-        ap = a.A + (size_t)(av ? src : 0) * a.lda + la_c;
-        const int n = nn0 + lw_row;
-        wv = n < a.N;
-        wp = a.W + (size_t)(wv ? n : 0) * a.ldw + lw_c;
-    };
-
-    float4 ra[APT], rw[WPT];
-    auto gload = [&](int k0, const float* ap, bool av, const float* wp, bool wv, int sg) {
+    // source rows of this lane's A chunks: -1 = zero row (padding slot or past the segment end)
+    auto a_sources = [&](int r0, int rend, int (&srow)[NIA]) {
 #pragma unroll
-        for (int j = 0; j < APT; j++) {
-            const bool kv = k0 + la_c + 4 * j < a.K;     // K is a multiple of 4: a tail chunk is zero-filled
-            ra[j] = (av && kv) ? *reinterpret_cast<const float4*>(ap + k0 + 4 * j) : make_float4(0.f, 0.f, 0.f, 0.f);
-            if (pro && kv) {
-                const float4 s = *reinterpret_cast<const float4*>(a.pscale + (size_t)sg * a.K + k0 + la_c + 4 * j);
-                const float4 h = *reinterpret_cast<const float4*>(a.pshift + (size_t)sg * a.K + k0 + la_c + 4 * j);
-                ra[j].x = fast_tanh(ra[j].x * s.x + h.x);
-                ra[j].y = fast_tanh(ra[j].y * s.y + h.y);
-                ra[j].z = fast_tanh(ra[j].z * s.z + h.z);
-                ra[j].w = fast_tanh(ra[j].w * s.w + h.w);
-            }
-        }
-#pragma unroll
-        for (int j = 0; j < WPT; j++) {
-            const bool kv = k0 + lw_c + 4 * j < a.K;
-            rw[j] = (wv && kv) ? *reinterpret_cast<const float4*>(wp + k0 + 4 * j) : make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int j = 0; j < NIA; j++) {
+            const int r = r0 + (w + NW * j) * RPI + lrow;
+            srow[j] = r < rend ? (a.gather ? a.gather[r] : r) : -1;
         }
     };
-    auto lstore = [&](int buf) {
-        float* As = smem + buf * BUF;
-        float* Ws = As + BM * LDS_LD;
+    const float* src[NI];          // this lane's source of each DMA instruction (k0 = 0), or null for a zero row
+    auto make_ptrs = [&](const int (&srow)[NIA], int nn0) {
 #pragma unroll
-        for (int j = 0; j < APT; j++) *reinterpret_cast<float4*>(&As[la_row * LDS_LD + la_c + 4 * j]) = ra[j];
+        for (int j = 0; j < NIA; j++)
+            src[j] = srow[j] >= 0 ? a.A + (size_t)srow[j] * a.lda + lchunk * 4 : nullptr;
 #pragma unroll
-        for (int j = 0; j < WPT; j++) *reinterpret_cast<float4*>(&Ws[lw_row * LDS_LD + lw_c + 4 * j]) = rw[j];
+        for (int j = NIA; j < NI; j++) {
+            const int n = nn0 + (w + NW * j) * RPI - BM + lrow;
+            src[j] = n < a.N ? a.W + (size_t)n * a.ldw + lchunk * 4 : nullptr;
+        }
+    };
+    const unsigned lds_w = (unsigned)(uintptr_t)(lptr_t)&stages[0] + w * (RPI * BK * 4);   // this wave's first row block
+    auto issue = [&](int st, int k0) {
+        const bool kin = k0 + lchunk * 4 < a.K;           // K is a multiple of 4: a tail chunk is zero-filled
+        const unsigned dst = lds_w + st * (STAGE * 4);
+#pragma unroll
+        for (int j = 0; j < NI; j++) {
+            const float* p = (src[j] && kin) ? src[j] + k0 : zsrc;
+            dma16(p, dst + j * (NW * RPI * BK * 4));
+        }
     };
 
     f32x16 acc[2][2];
@@ -120,122 +151,106 @@ __global__ __launch_bounds__(64 * NWM * NWN, OCC) void gemm_nt_kernel(NtArgs a, 
                 for (int r = 0; r < 16; r++) acc[i][j][r] = 0.f;
     };
 
-    // aux operand of the d-activation epilogues, prefetched during the tile's LAST K-step in the
-    // layout the staged epilogue reads: [nt][mt][i] -> rows er+8i of sub-tile (mt,nt), cols ec..ec+3
-    constexpr bool HAS_AUX_ANY = EPI == NT_EPI_DTANH || EPI == NT_EPI_DTANH_BN || EPI == NT_EPI_DRELU;
-    constexpr bool HAS_AUX_K = HAS_AUX_ANY && NWM * NWN == 8;      // register budget: the 8-wave kernel only
-    constexpr int NAUX = HAS_AUX_K ? 16 : 1;
-    float4 auxr[NAUX];
-    const bool vec_k = ((a.N | a.ldc) & 3) == 0 && (!a.aux || (a.ldaux & 3) == 0);
-    auto aux_prefetch = [&]() {
-        if (!HAS_AUX_K) return;
+    // fragment addresses: stage row (lane & 31) of the wave's 64-row strip, chunk (2 kk + (lane >> 5)) ^ swizzle
+    const int fr = lane & 31;
+    const int fsw = ((lane >> 5) ^ ((fr / RB) % CPR)) << 2;            // kk = 0; kk > 0 flips bits above it
+    const int fa = (wm * 64 + fr) * BK + fsw, fb = (BM + wn * 64 + fr) * BK + fsw;
+
+    auto compute = [&](const float* cur) {
+        float4 fa0 = *reinterpret_cast<const float4*>(&cur[fa]), fa1 = *reinterpret_cast<const float4*>(&cur[fa + 32 * BK]);
+        float4 fb0 = *reinterpret_cast<const float4*>(&cur[fb]), fb1 = *reinterpret_cast<const float4*>(&cur[fb + 32 * BK]);
 #pragma unroll
-        for (int nt = 0; nt < 2; nt++)
+        for (int kk = 0; kk < BK / 8; kk++) {
+            float4 na0 = fa0, na1 = fa1, nb0 = fb0, nb1 = fb1;
+            if (kk + 1 < BK / 8) {
+                const int x = (kk + 1) << 3;                            // chunk 2(kk+1): XOR into the swizzled offset
+                na0 = *reinterpret_cast<const float4*>(&cur[fa ^ x]);
+                na1 = *reinterpret_cast<const float4*>(&cur[(fa ^ x) + 32 * BK]);
+                nb0 = *reinterpret_cast<const float4*>(&cur[fb ^ x]);
+                nb1 = *reinterpret_cast<const float4*>(&cur[(fb ^ x) + 32 * BK]);
+            }
+            const float av0[4] = {fa0.x, fa0.y, fa0.z, fa0.w}, av1[4] = {fa1.x, fa1.y, fa1.z, fa1.w};
+            const float bv0[4] = {fb0.x, fb0.y, fb0.z, fb0.w}, bv1[4] = {fb1.x, fb1.y, fb1.z, fb1.w};
 #pragma unroll
-            for (int mt = 0; mt < 2; mt++)
-#pragma unroll
-                for (int i = 0; i < 4; i++) {
-                    const int row = row0 + wm * 64 + mt * 32 + (lane >> 3) + 8 * i;
-                    const int col = n0 + wn * 64 + nt * 32 + (lane & 7) * 4;
-                    float4 x4 = make_float4(0.f, 0.f, 0.f, 0.f);
-                    if (row < row_end) {
-                        if (vec_k && col + 3 < a.N) {
-                            x4 = *reinterpret_cast<const float4*>(a.aux + (size_t)row * a.ldaux + col);
-                        } else {
-                            if (col + 0 < a.N) x4.x = a.aux[(size_t)row * a.ldaux + col + 0];
-                            if (col + 1 < a.N) x4.y = a.aux[(size_t)row * a.ldaux + col + 1];
-                            if (col + 2 < a.N) x4.z = a.aux[(size_t)row * a.ldaux + col + 2];
-                            if (col + 3 < a.N) x4.w = a.aux[(size_t)row * a.ldaux + col + 3];
-                        }
-                    }
-                    auxr[HAS_AUX_K ? (nt * 2 + mt) * 4 + i : 0] = x4;
-                }
+            for (int r = 0; r < 4; r++) {
+                acc[0][0] = mfma32(av0[r], bv0[r], acc[0][0]);
+                acc[0][1] = mfma32(av0[r], bv1[r], acc[0][1]);
+                acc[1][0] = mfma32(av1[r], bv0[r], acc[1][0]);
+                acc[1][1] = mfma32(av1[r], bv1[r], acc[1][1]);
+            }
+            fa0 = na0; fa1 = na1; fb0 = nb0; fb1 = nb1;
+            // keep the request one whole block ahead of its use (the scheduler otherwise sinks the
+            // reads to just before the MFMA that consumes them and exposes the LDS latency)
+            if (kk + 1 < BK / 8) __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, 16, 0);
+        }
     };
 
-    if (tile >= total_tiles) return;
+    // BN-apply + tanh on the A image of a landed stage, in place (one 16-B chunk per thread)
+    auto transform = [&](float* cur, int k0, int sg) {
+        const int row = tid / CPR, slot = tid % CPR;
+        const int k = k0 + ((slot ^ ((row / RB) % CPR)) << 2);
+        if (k < a.K) {
+            float4 v = *reinterpret_cast<const float4*>(&cur[tid * 4]);
+            const float4 s = *reinterpret_cast<const float4*>(&pro_ss[(2 * sg) * 256 + k]);
+            const float4 h = *reinterpret_cast<const float4*>(&pro_ss[(2 * sg + 1) * 256 + k]);
+            v.x = fast_tanh(v.x * s.x + h.x);
+            v.y = fast_tanh(v.y * s.y + h.y);
+            v.z = fast_tanh(v.z * s.z + h.z);
+            v.w = fast_tanh(v.w * s.w + h.w);
+            *reinterpret_cast<float4*>(&cur[tid * 4]) = v;
+        }
+    };
+
+    int nsrow[NIA];
+    int ntile = tile, nrow0 = 0, nrow_end = 0, nn0 = 0, nseg = 0;
+    // end of a K-step: this wave's DMA has landed, then every wave is past its reads of the old stage
+    auto stage_sync = [&]() {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+    };
+
     tile_geom(tile, row0, row_end, n0, seg);
-    make_ptrs(a_source(row0, row_end), n0, aptr, aval, wptr, wval);
-    gload(0, aptr, aval, wptr, wval, seg);
-    lstore(0);
-    __syncthreads();
+    a_sources(row0, row_end, nsrow);
+    make_ptrs(nsrow, n0);
+    issue(0, 0);
     zero_acc();
+    stage_sync();
     int cur = 0;
-    const int frag = (lane & 31) * LDS_LD + 4 * (lane >> 5);
 
     while (true) {
-        // next tile's identity (prefetched during the last chunk of this one)
-        const int ntile = tile + gridDim.x;
-        int nrow0 = 0, nrow_end = 0, nn0 = 0, nseg = 0;
-        const float* naptr = a.A; bool naval = false;
-        const float* nwptr = a.W; bool nwval = false;
-        int nsrc = -1;                                        // gather index of the next tile: issued a tile early
+        // next tile's identity; its gather indices are requested a whole tile early
+        ntile = tile + gridDim.x;
         if (ntile < total_tiles) {
             tile_geom(ntile, nrow0, nrow_end, nn0, nseg);
-            nsrc = a_source(nrow0, nrow_end);
+            a_sources(nrow0, nrow_end, nsrow);
         }
-
+        // one K-step: start the DMA of the following chunk (this tile's, or the next tile's first),
+        // then multiply the landed one
         for (int kt = 0; kt < nk; kt++) {
-            bool loaded = false;
-            if (kt + 1 == nk) aux_prefetch();               // older than the prefetch below: its wait never covers it
-            if (kt + 1 < nk) { gload((kt + 1) * BK, aptr, aval, wptr, wval, seg); loaded = true; }
-            else if (ntile < total_tiles) {
-                make_ptrs(nsrc, nn0, naptr, naval, nwptr, nwval);
-                gload(0, naptr, naval, nwptr, nwval, nseg);
-                loaded = true;
-            }
-            const float* As = smem + cur * BUF + wm * 64 * LDS_LD + frag;
-            const float* Ws = smem + cur * BUF + (BM + wn * 64) * LDS_LD + frag;
-            // fragments of k-block kk+1 are requested before the 16 MFMAs of block kk are issued
-            float4 fa0 = *reinterpret_cast<const float4*>(As), fa1 = *reinterpret_cast<const float4*>(As + 32 * LDS_LD);
-            float4 fb0 = *reinterpret_cast<const float4*>(Ws), fb1 = *reinterpret_cast<const float4*>(Ws + 32 * LDS_LD);
-#pragma unroll
-            for (int kk = 0; kk < BK / 8; kk++) {
-                float4 na0 = fa0, na1 = fa1, nb0 = fb0, nb1 = fb1;
-                if (kk + 1 < BK / 8) {
-                    na0 = *reinterpret_cast<const float4*>(As + (kk + 1) * 8);
-                    na1 = *reinterpret_cast<const float4*>(As + 32 * LDS_LD + (kk + 1) * 8);
-                    nb0 = *reinterpret_cast<const float4*>(Ws + (kk + 1) * 8);
-                    nb1 = *reinterpret_cast<const float4*>(Ws + 32 * LDS_LD + (kk + 1) * 8);
-                }
-                const float av0[4] = {fa0.x, fa0.y, fa0.z, fa0.w}, av1[4] = {fa1.x, fa1.y, fa1.z, fa1.w};
-                const float bv0[4] = {fb0.x, fb0.y, fb0.z, fb0.w}, bv1[4] = {fb1.x, fb1.y, fb1.z, fb1.w};
-#pragma unroll
-                for (int r = 0; r < 4; r++) {
-                    acc[0][0] = mfma32(av0[r], bv0[r], acc[0][0]);
-                    acc[0][1] = mfma32(av0[r], bv1[r], acc[0][1]);
-                    acc[1][0] = mfma32(av1[r], bv0[r], acc[1][0]);
-                    acc[1][1] = mfma32(av1[r], bv1[r], acc[1][1]);
-                }
-                fa0 = na0; fa1 = na1; fb0 = nb0; fb1 = nb1;
-                // keep the request one whole block ahead of its use (the scheduler otherwise sinks the
-                // reads to just before the MFMA that consumes them and exposes the LDS latency)
-                if (kk + 1 < BK / 8) __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
-                __builtin_amdgcn_sched_group_barrier(0x008, 16, 0);
-            }
-            if (loaded) lstore(cur ^ 1);
-            __syncthreads();
+            if (kt + 1 < nk) issue(cur ^ 1, (kt + 1) * BK);
+            else if (ntile < total_tiles) { make_ptrs(nsrow, nn0); issue(cur ^ 1, 0); }
+            float* cs = stages + cur * STAGE;
+            if (PRO) { transform(cs, kt * BK, seg); lds_sync(); }
+            compute(cs);
+            stage_sync();
             cur ^= 1;
         }
 
-        // ---- epilogue of `tile`.  Stage `cur` now holds the next tile's first chunk; the other
-        // stage is free: each wave transposes its 32x32 sub-tiles through a private 32x36 patch.
-        float* free_stage = smem + (cur ^ 1) * BUF;
-        float* stg = free_stage + w * (32 * PLD);
+        // ---- epilogue of `tile`: each wave transposes its accumulators, 16 rows x 32 columns at a
+        // time, through a private patch (the stages are busy: the next tile's first chunk is landing)
+        float* stg = patch + w * (PROWS * PLD);
         const int er = lane >> 3, ec = (lane & 7) * 4;          // staged read: rows er+8i, cols ec..ec+3
         const bool vec = ((a.N | a.ldc) & 3) == 0 && (!a.aux || (a.ldaux & 3) == 0);
         constexpr bool HAS_AUX = EPI == NT_EPI_DTANH || EPI == NT_EPI_DTANH_BN || EPI == NT_EPI_DRELU;
-        float cs1[2][4], cs2[2][4];
-#pragma unroll
-        for (int nt = 0; nt < 2; nt++)
-#pragma unroll
-            for (int q = 0; q < 4; q++) { cs1[nt][q] = 0.f; cs2[nt][q] = 0.f; }
 #pragma unroll
         for (int nt = 0; nt < 2; nt++) {
             const int col = n0 + wn * 64 + nt * 32 + ec;
-            float bias[4], es[4], eh[4], mu[4], is[4];
+            float bias[4], es[4], eh[4], mu[4], is[4], cs1[4], cs2[4];
 #pragma unroll
             for (int q = 0; q < 4; q++) {
                 const bool cv = col + q < a.N;
+                cs1[q] = cs2[q] = 0.f;
                 bias[q] = (cv && a.bias) ? a.bias[col + q] : 0.f;
                 es[q] = eh[q] = mu[q] = is[q] = 0.f;
                 if (cv && EPI == NT_EPI_DTANH_BN) {
@@ -250,71 +265,74 @@ __global__ __launch_bounds__(64 * NWM * NWN, OCC) void gemm_nt_kernel(NtArgs a, 
 #pragma unroll
             for (int mt = 0; mt < 2; mt++) {
 #pragma unroll
-                for (int reg = 0; reg < 16; reg++)
-                    stg[((reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)) * PLD + (lane & 31)] = acc[mt][nt][reg];
-                __builtin_amdgcn_wave_barrier();
+                for (int half = 0; half < 2; half++) {
+                    const int rbase = row0 + wm * 64 + mt * 32 + half * 16 + er;
+                    // aux operand first: its latency hides behind the patch round trip
+                    float4 x4[2];
 #pragma unroll
-                for (int i = 0; i < 4; i++) {
-                    const int row = row0 + wm * 64 + mt * 32 + er + 8 * i;
-                    const float4 v4 = *reinterpret_cast<const float4*>(&stg[(er + 8 * i) * PLD + ec]);
-                    float v[4] = {v4.x, v4.y, v4.z, v4.w};
-                    float ax[4] = {0.f, 0.f, 0.f, 0.f};
-                    const bool rok = row < row_end;
-                    if (HAS_AUX_K) {
-                        const float4 x4 = auxr[HAS_AUX_K ? (nt * 2 + mt) * 4 + i : 0];
-                        ax[0] = x4.x; ax[1] = x4.y; ax[2] = x4.z; ax[3] = x4.w;
-                    } else if (rok && HAS_AUX) {
-                        if (vec && col + 3 < a.N) {
-                            const float4 x4 = *reinterpret_cast<const float4*>(a.aux + (size_t)row * a.ldaux + col);
-                            ax[0] = x4.x; ax[1] = x4.y; ax[2] = x4.z; ax[3] = x4.w;
-                        } else {
-#pragma unroll
-                            for (int q = 0; q < 4; q++)
-                                if (col + q < a.N) ax[q] = a.aux[(size_t)row * a.ldaux + col + q];
-                        }
-                    }
-#pragma unroll
-                    for (int q = 0; q < 4; q++) {
-                        float x = v[q] + bias[q];
-                        switch (EPI) {
-                            case NT_EPI_TANH: x = fast_tanh(x); break;
-                            case NT_EPI_RELU: x = x > 0.f ? x : 0.f; break;
-                            case NT_EPI_DTANH: x = x * (1.f - ax[q] * ax[q]); break;
-                            case NT_EPI_DTANH_BN: { const float s = fast_tanh(ax[q] * es[q] + eh[q]); x = x * (1.f - s * s); break; }
-                            case NT_EPI_DRELU: x = ax[q] > 0.f ? x : 0.f; break;
-                            default: break;
-                        }
-                        v[q] = x;
-                        if (rok && col + q < a.N) {
-                            if (STATS == NT_STAT_SUMSQ) {
-                                const float wt = row == a.seg.wrow ? a.seg.wmult : 1.f;   // the row that stands for many
-                                cs1[nt][q] += wt * x; cs2[nt][q] += wt * x * x;
+                    for (int i = 0; i < 2; i++) {
+                        x4[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+                        const int row = rbase + 8 * i;
+                        if (HAS_AUX && row < row_end) {
+                            if (vec && col + 3 < a.N) {
+                                x4[i] = *reinterpret_cast<const float4*>(a.aux + (size_t)row * a.ldaux + col);
+                            } else {
+                                if (col + 0 < a.N) x4[i].x = a.aux[(size_t)row * a.ldaux + col + 0];
+                                if (col + 1 < a.N) x4[i].y = a.aux[(size_t)row * a.ldaux + col + 1];
+                                if (col + 2 < a.N) x4[i].z = a.aux[(size_t)row * a.ldaux + col + 2];
+                                if (col + 3 < a.N) x4[i].w = a.aux[(size_t)row * a.ldaux + col + 3];
                             }
-                            else if (STATS == NT_STAT_BNBWD) { cs1[nt][q] += x; cs2[nt][q] += x * ((ax[q] - mu[q]) * is[q]); }
                         }
                     }
-                    if (rok) {
-                        if (vec && col + 3 < a.N) {
-                            *reinterpret_cast<float4*>(a.C + (size_t)row * a.ldc + col) = make_float4(v[0], v[1], v[2], v[3]);
-                        } else {
 #pragma unroll
-                            for (int q = 0; q < 4; q++)
-                                if (col + q < a.N) a.C[(size_t)row * a.ldc + col + q] = v[q];
+                    for (int q8 = 0; q8 < 8; q8++)
+                        stg[((q8 & 3) + 8 * (q8 >> 2) + 4 * (lane >> 5)) * PLD + (lane & 31)] = acc[mt][nt][half * 8 + q8];
+                    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+                    for (int i = 0; i < 2; i++) {
+                        const int row = rbase + 8 * i;
+                        const float4 v4 = *reinterpret_cast<const float4*>(&stg[(er + 8 * i) * PLD + ec]);
+                        float v[4] = {v4.x, v4.y, v4.z, v4.w};
+                        const float ax[4] = {x4[i].x, x4[i].y, x4[i].z, x4[i].w};
+                        const bool rok = row < row_end;
+#pragma unroll
+                        for (int q = 0; q < 4; q++) {
+                            float x = v[q] + bias[q];
+                            switch (EPI) {
+                                case NT_EPI_TANH: x = fast_tanh(x); break;
+                                case NT_EPI_RELU: x = x > 0.f ? x : 0.f; break;
+                                case NT_EPI_DTANH: x = x * (1.f - ax[q] * ax[q]); break;
+                                case NT_EPI_DTANH_BN: { const float s = fast_tanh(ax[q] * es[q] + eh[q]); x = x * (1.f - s * s); break; }
+                                case NT_EPI_DRELU: x = ax[q] > 0.f ? x : 0.f; break;
+                                default: break;
+                            }
+                            v[q] = x;
+                            if (rok && col + q < a.N) {
+                                if (STATS == NT_STAT_SUMSQ) {
+                                    const float wt = row == a.seg.wrow ? a.seg.wmult : 1.f;   // the row that stands for many
+                                    cs1[q] += wt * x; cs2[q] += wt * x * x;
+                                }
+                                else if (STATS == NT_STAT_BNBWD) { cs1[q] += x; cs2[q] += x * ((ax[q] - mu[q]) * is[q]); }
+                            }
+                        }
+                        if (rok) {
+                            if (vec && col + 3 < a.N) {
+                                *reinterpret_cast<float4*>(a.C + (size_t)row * a.ldc + col) = make_float4(v[0], v[1], v[2], v[3]);
+                            } else {
+#pragma unroll
+                                for (int q = 0; q < 4; q++)
+                                    if (col + q < a.N) a.C[(size_t)row * a.ldc + col + q] = v[q];
+                            }
                         }
                     }
+                    __builtin_amdgcn_wave_barrier();
                 }
-                __builtin_amdgcn_wave_barrier();
             }
-        }
-        if (STATS != NT_STAT_NONE) {
-            // fold the 8 row groups of a wave (lane>>3), then the two M-waves through LDS
-            __syncthreads();                                   // every wave is done with its staging patch
-            float* red = free_stage;                           // [2 stats][NWM][BN]
-#pragma unroll
-            for (int nt = 0; nt < 2; nt++)
+            if (STATS != NT_STAT_NONE) {
+                // fold the 8 row groups of the wave (lane >> 3); the M-waves meet in `red`
 #pragma unroll
                 for (int q = 0; q < 4; q++) {
-                    float s1 = cs1[nt][q], s2 = cs2[nt][q];
+                    float s1 = cs1[q], s2 = cs2[q];
 #pragma unroll
                     for (int o = 8; o <= 32; o <<= 1) { s1 += __shfl_xor(s1, o, 64); s2 += __shfl_xor(s2, o, 64); }
                     if (lane < 8) {
@@ -323,7 +341,10 @@ __global__ __launch_bounds__(64 * NWM * NWN, OCC) void gemm_nt_kernel(NtArgs a, 
                         red[(1 * NWM + wm) * BN + c] = s2;
                     }
                 }
-            __syncthreads();
+            }
+        }
+        if (STATS != NT_STAT_NONE) {
+            lds_sync();                                        // every wave has posted its column sums
             const int tile_m = tile / ntn;
             for (int c = tid; c < BN; c += THREADS)
                 if (n0 + c < a.N) {
@@ -333,12 +354,11 @@ __global__ __launch_bounds__(64 * NWM * NWN, OCC) void gemm_nt_kernel(NtArgs a, 
                     a.stat_sum[(size_t)tile_m * a.N + n0 + c] = s1;
                     a.stat_aux[(size_t)tile_m * a.N + n0 + c] = s2;
                 }
+            // (`red` is written again only after the next tile's K-steps and their barriers)
         }
         if (ntile >= total_tiles) break;
-        __syncthreads();                                       // free stage is written again by the next lstore
         zero_acc();
         tile = ntile; row0 = nrow0; row_end = nrow_end; n0 = nn0; seg = nseg;
-        aptr = naptr; aval = naval; wptr = nwptr; wval = nwval;
     }
 }
 
@@ -356,14 +376,13 @@ static SegInfo retile(const SegInfo& in, int tile_rows) {
 template <bool PRO, int EPI, int STATS>
 static void launch_variant(const NtArgs& a, int ntm, hipStream_t st) {
     if (PRO || a.N > 128 || STATS != NT_STAT_NONE) {
-        // 128 rows x 256 columns, 8 waves, one workgroup per CU: A is read once
+        // 128 rows x 256 columns, 8 waves, two workgroups per CU (66 KB of LDS each): A is read once
         const int ntn = (a.N + 255) / 256, total = ntm * ntn;
-        PC_LAUNCH((gemm_nt_kernel<2, 4, 32, 2, PRO, EPI, STATS>), dim3(total < 256 ? total : 256), dim3(512), 0, st, a, ntn,
+        PC_LAUNCH((gemm_nt_kernel<2, 4, 16, 4, PRO, EPI, STATS>), dim3(total < 512 ? total : 512), dim3(512), 0, st, a, ntn,
                   total);
     } else if (ntm >= 192) {
-        // N <= 128: 128x128 tiles, two independent 4-wave workgroups per CU (measured 89 vs 77 TF/s
-        // for one 256x128 8-wave workgroup: the second workgroup fills the first one's epilogue)
-        PC_LAUNCH((gemm_nt_kernel<2, 2, 32, 2, false, EPI, NT_STAT_NONE>), dim3(ntm < 512 ? ntm : 512), dim3(256), 0, st, a,
+        // N <= 128: 128x128 tiles, 4 waves, three workgroups per CU
+        PC_LAUNCH((gemm_nt_kernel<2, 2, 16, 3, false, EPI, NT_STAT_NONE>), dim3(ntm < 768 ? ntm : 768), dim3(256), 0, st, a,
                   1, ntm);
     } else {
         // few rows (per-sample projections of the attention block, joint-step layers): 64-row
@@ -383,6 +402,7 @@ int launch_gemm_nt(const NtArgs& a, hipStream_t st) {
     const int ntm = gemm_nt_tiles(a.seg);
     if (ntm <= 0) return PC_EINVAL;
     if (a.prologue == NT_PRO_BNTANH && (!a.pscale || !a.pshift)) return PC_EINVAL;
+    if (a.prologue == NT_PRO_BNTANH && a.K > 256) return PC_ESHAPE;      // scale/shift live in LDS
     const bool needs_aux = a.epilogue == NT_EPI_DTANH || a.epilogue == NT_EPI_DTANH_BN || a.epilogue == NT_EPI_DRELU;
     if (needs_aux && !a.aux) return PC_EINVAL;
     if (a.stats != NT_STAT_NONE && (a.N > 256 || !a.stat_sum || !a.stat_aux)) return PC_ESHAPE;
