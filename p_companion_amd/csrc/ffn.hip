@@ -92,10 +92,10 @@ __global__ void bn_eval_coeff_kernel(const float* gamma, const float* beta, cons
     shift_o[j] = beta[j] - running_mean[j] * sc;
 }
 
-// per-tile (sum dz1, sum dz1*xhat) -> dgamma, dbeta (+ per-segment means c1 = dbeta_s/n, c2 = dgamma_s/n)
+// per-tile (sum dz1, sum dz1*h0) -> dgamma, dbeta (+ per-segment means c1 = dbeta_s/n, c2 = dgamma_s/n)
 __global__ __launch_bounds__(FIN_COLS * FIN_LANES) void bn_finalize_bwd_kernel(
-    const float* psum, const float* pdot, SegInfo si, float* dgamma, float* dbeta, int accumulate, float* c1,
-    float* c2) {
+    const float* psum, const float* pdot, SegInfo si, const float* mean, const float* invstd, float* dgamma,
+    float* dbeta, int accumulate, float* c1, float* c2) {
     __shared__ double red[2][FIN_LANES][FIN_COLS];
     const int j = blockIdx.x * FIN_COLS + threadIdx.x, q = threadIdx.y;
     double tg = 0.0, tb = 0.0;
@@ -104,6 +104,8 @@ __global__ __launch_bounds__(FIN_COLS * FIN_LANES) void bn_finalize_bwd_kernel(
         double a = 0.0, b = 0.0;
         fold_partials(psum, pdot, si.tile0[s], si.tile0[s + 1], j, q, red, &a, &b);
         if (q == 0) {
+            // the tiles carry the raw moment sum dz1*h0: sum dz1*xhat = invstd * (sum dz1*h0 - mean * sum dz1)
+            b = (double)invstd[s * PC_H + j] * (b - (double)mean[s * PC_H + j] * a);
             tb += a;
             tg += b;
             c1[s * PC_H + j] = n > 0 ? (float)(a / n) : 0.f;
@@ -335,8 +337,7 @@ static int ffn_backward_impl(const pc_p2v_tensors* p, const pc_p2v_tensors* g, c
     // dZ1 = (dZ2 W3) * (1 - A1^2), A1 = tanh(BN(H0)); plus BN-backward partial sums
     NtArgs b2 = nt_plain(w.dz2, PC_H, w.w3t, PC_H, nullptr, w.dz1, PC_H, rows, PC_H, PC_H, si);
     b2.epilogue = NT_EPI_DTANH_BN; b2.aux = sv->h0; b2.ldaux = PC_H; b2.escale = sv->bn_scale; b2.eshift = sv->bn_shift;
-    b2.stats = NT_STAT_BNBWD; b2.stat_sum = w.stat_a; b2.stat_aux = w.stat_b; b2.mean = sv->bn_mean;
-    b2.invstd = sv->bn_invstd;
+    b2.stats = NT_STAT_BNBWD; b2.stat_sum = w.stat_a; b2.stat_aux = w.stat_b;
     PC_TRY(launch_gemm_nt(b2, st));
 
     // dW3 = dZ2^T A1 (A1 recomputed from H0 in the loader), db3
@@ -347,8 +348,8 @@ static int ffn_backward_impl(const pc_p2v_tensors* p, const pc_p2v_tensors* g, c
     t3.slab_floats = w.slab_floats;
     PC_TRY(launch_gemm_tn(t3, st));
 
-    PC_LAUNCH(bn_finalize_bwd_kernel, dim3(PC_H / FIN_COLS), dim3(FIN_COLS, FIN_LANES), 0, st, w.stat_a, w.stat_b, si, g->gamma,
-                       g->beta, accumulate, w.c1, w.c2);
+    PC_LAUNCH(bn_finalize_bwd_kernel, dim3(PC_H / FIN_COLS), dim3(FIN_COLS, FIN_LANES), 0, st, w.stat_a, w.stat_b, si, sv->bn_mean,
+              sv->bn_invstd, g->gamma, g->beta, accumulate, w.c1, w.c2);
     PC_TRY(pc_launch_status());
 
     // dW0 = dH0^T X (rows gathered again from the table), db0.  Without a dx consumer the BatchNorm

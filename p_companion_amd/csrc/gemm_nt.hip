@@ -243,92 +243,98 @@ __global__ __launch_bounds__(64 * NWM * NWN, WPS) void gemm_nt_kernel(NtArgs a, 
         const int er = lane >> 3, ec = (lane & 7) * 4;          // staged read: rows er+8i, cols ec..ec+3
         const bool vec = ((a.N | a.ldc) & 3) == 0 && (!a.aux || (a.ldaux & 3) == 0);
         constexpr bool HAS_AUX = EPI == NT_EPI_DTANH || EPI == NT_EPI_DTANH_BN || EPI == NT_EPI_DRELU;
-#pragma unroll
-        for (int nt = 0; nt < 2; nt++) {
+        // aux operand (d-activation epilogues): ADEPTH half-patches are in flight ahead of the one being
+        // finished -- with two loads per lane and half-patch the wave would otherwise pay one full
+        // memory latency per half-patch (measured: 19 us of a 32 us tile)
+        constexpr int ADEPTH = HAS_AUX ? (STATS != NT_STAT_NONE ? 1 : 4) : 1;   // (the BN-backward variant has no registers to spare)
+        const bool fast = vec && n0 + BN <= a.N;                 // whole tile inside N: unpredicated 16-B accesses
+        float4 xq[ADEPTH][2];
+        auto aux_load = [&](int h, float4 (&x4)[2]) {
+            const int nt = h >> 2, mt = (h >> 1) & 1, half = h & 1;
             const int col = n0 + wn * 64 + nt * 32 + ec;
-            float bias[4], es[4], eh[4], mu[4], is[4], cs1[4], cs2[4];
 #pragma unroll
-            for (int q = 0; q < 4; q++) {
-                const bool cv = col + q < a.N;
-                cs1[q] = cs2[q] = 0.f;
-                bias[q] = (cv && a.bias) ? a.bias[col + q] : 0.f;
-                es[q] = eh[q] = mu[q] = is[q] = 0.f;
-                if (cv && EPI == NT_EPI_DTANH_BN) {
-                    es[q] = a.escale[(size_t)seg * a.N + col + q];
-                    eh[q] = a.eshift[(size_t)seg * a.N + col + q];
-                }
-                if (cv && STATS == NT_STAT_BNBWD) {
-                    mu[q] = a.mean[(size_t)seg * a.N + col + q];
-                    is[q] = a.invstd[(size_t)seg * a.N + col + q];
+            for (int i = 0; i < 2; i++) {
+                const int row = row0 + wm * 64 + mt * 32 + half * 16 + er + 8 * i;
+                x4[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (fast) {
+                    const int rc = row < row_end ? row : row_end - 1;      // clamped: the value of a dead row is never used
+                    x4[i] = *reinterpret_cast<const float4*>(a.aux + (size_t)rc * a.ldaux + col);
+                } else if (row < row_end) {
+                    if (col + 0 < a.N) x4[i].x = a.aux[(size_t)row * a.ldaux + col + 0];
+                    if (col + 1 < a.N) x4[i].y = a.aux[(size_t)row * a.ldaux + col + 1];
+                    if (col + 2 < a.N) x4[i].z = a.aux[(size_t)row * a.ldaux + col + 2];
+                    if (col + 3 < a.N) x4[i].w = a.aux[(size_t)row * a.ldaux + col + 3];
                 }
             }
+        };
+        if (HAS_AUX) {
 #pragma unroll
-            for (int mt = 0; mt < 2; mt++) {
+            for (int h = 0; h < ADEPTH; h++) aux_load(h, xq[h]);
+        }
+        float bias[4], es[4], eh[4], cs1[4], cs2[4];
 #pragma unroll
-                for (int half = 0; half < 2; half++) {
-                    const int rbase = row0 + wm * 64 + mt * 32 + half * 16 + er;
-                    // aux operand first: its latency hides behind the patch round trip
-                    float4 x4[2];
+        for (int h = 0; h < 8; h++) {
+            const int nt = h >> 2, mt = (h >> 1) & 1, half = h & 1;
+            const int col = n0 + wn * 64 + nt * 32 + ec;
+            if ((h & 3) == 0) {
 #pragma unroll
-                    for (int i = 0; i < 2; i++) {
-                        x4[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-                        const int row = rbase + 8 * i;
-                        if (HAS_AUX && row < row_end) {
-                            if (vec && col + 3 < a.N) {
-                                x4[i] = *reinterpret_cast<const float4*>(a.aux + (size_t)row * a.ldaux + col);
-                            } else {
-                                if (col + 0 < a.N) x4[i].x = a.aux[(size_t)row * a.ldaux + col + 0];
-                                if (col + 1 < a.N) x4[i].y = a.aux[(size_t)row * a.ldaux + col + 1];
-                                if (col + 2 < a.N) x4[i].z = a.aux[(size_t)row * a.ldaux + col + 2];
-                                if (col + 3 < a.N) x4[i].w = a.aux[(size_t)row * a.ldaux + col + 3];
-                            }
-                        }
+                for (int q = 0; q < 4; q++) {
+                    const bool cv = col + q < a.N;
+                    cs1[q] = cs2[q] = 0.f;
+                    bias[q] = (!HAS_AUX && cv && a.bias) ? a.bias[col + q] : 0.f;     // the d-activation epilogues carry no bias
+                    es[q] = eh[q] = 0.f;
+                    if (cv && EPI == NT_EPI_DTANH_BN) {
+                        es[q] = a.escale[(size_t)seg * a.N + col + q];
+                        eh[q] = a.eshift[(size_t)seg * a.N + col + q];
                     }
-#pragma unroll
-                    for (int q8 = 0; q8 < 8; q8++)
-                        stg[((q8 & 3) + 8 * (q8 >> 2) + 4 * (lane >> 5)) * PLD + (lane & 31)] = acc[mt][nt][half * 8 + q8];
-                    __builtin_amdgcn_wave_barrier();
-#pragma unroll
-                    for (int i = 0; i < 2; i++) {
-                        const int row = rbase + 8 * i;
-                        const float4 v4 = *reinterpret_cast<const float4*>(&stg[(er + 8 * i) * PLD + ec]);
-                        float v[4] = {v4.x, v4.y, v4.z, v4.w};
-                        const float ax[4] = {x4[i].x, x4[i].y, x4[i].z, x4[i].w};
-                        const bool rok = row < row_end;
-#pragma unroll
-                        for (int q = 0; q < 4; q++) {
-                            float x = v[q] + bias[q];
-                            switch (EPI) {
-                                case NT_EPI_TANH: x = fast_tanh(x); break;
-                                case NT_EPI_RELU: x = x > 0.f ? x : 0.f; break;
-                                case NT_EPI_DTANH: x = x * (1.f - ax[q] * ax[q]); break;
-                                case NT_EPI_DTANH_BN: { const float s = fast_tanh(ax[q] * es[q] + eh[q]); x = x * (1.f - s * s); break; }
-                                case NT_EPI_DRELU: x = ax[q] > 0.f ? x : 0.f; break;
-                                default: break;
-                            }
-                            v[q] = x;
-                            if (rok && col + q < a.N) {
-                                if (STATS == NT_STAT_SUMSQ) {
-                                    const float wt = row == a.seg.wrow ? a.seg.wmult : 1.f;   // the row that stands for many
-                                    cs1[q] += wt * x; cs2[q] += wt * x * x;
-                                }
-                                else if (STATS == NT_STAT_BNBWD) { cs1[q] += x; cs2[q] += x * ((ax[q] - mu[q]) * is[q]); }
-                            }
-                        }
-                        if (rok) {
-                            if (vec && col + 3 < a.N) {
-                                *reinterpret_cast<float4*>(a.C + (size_t)row * a.ldc + col) = make_float4(v[0], v[1], v[2], v[3]);
-                            } else {
-#pragma unroll
-                                for (int q = 0; q < 4; q++)
-                                    if (col + q < a.N) a.C[(size_t)row * a.ldc + col + q] = v[q];
-                            }
-                        }
-                    }
-                    __builtin_amdgcn_wave_barrier();
                 }
             }
-            if (STATS != NT_STAT_NONE) {
+            const int rbase = row0 + wm * 64 + mt * 32 + half * 16 + er;
+#pragma unroll
+            for (int q8 = 0; q8 < 8; q8++)
+                stg[((q8 & 3) + 8 * (q8 >> 2) + 4 * (lane >> 5)) * PLD + (lane & 31)] = acc[mt][nt][half * 8 + q8];
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int i = 0; i < 2; i++) {
+                const int row = rbase + 8 * i;
+                const float4 v4 = *reinterpret_cast<const float4*>(&stg[(er + 8 * i) * PLD + ec]);
+                float v[4] = {v4.x, v4.y, v4.z, v4.w};
+                const float4 xa = xq[HAS_AUX ? h % ADEPTH : 0][i];
+                const float ax[4] = {xa.x, xa.y, xa.z, xa.w};
+                const bool rok = row < row_end;
+#pragma unroll
+                for (int q = 0; q < 4; q++) {
+                    float x = v[q] + bias[q];
+                    switch (EPI) {
+                        case NT_EPI_TANH: x = fast_tanh(x); break;
+                        case NT_EPI_RELU: x = x > 0.f ? x : 0.f; break;
+                        case NT_EPI_DTANH: x = x * (1.f - ax[q] * ax[q]); break;
+                        case NT_EPI_DTANH_BN: { const float s = fast_tanh(ax[q] * es[q] + eh[q]); x = x * (1.f - s * s); break; }
+                        case NT_EPI_DRELU: x = ax[q] > 0.f ? x : 0.f; break;
+                        default: break;
+                    }
+                    v[q] = x;
+                    if (rok && col + q < a.N) {
+                        if (STATS == NT_STAT_SUMSQ) {
+                            const float wt = row == a.seg.wrow ? a.seg.wmult : 1.f;   // the row that stands for many
+                            cs1[q] += wt * x; cs2[q] += wt * x * x;
+                        }
+                        else if (STATS == NT_STAT_BNBWD) { cs1[q] += x; cs2[q] += x * ax[q]; }      // raw moment: centred in fp64 by the finalize pass
+                    }
+                }
+                if (rok) {
+                    if (fast) {
+                        *reinterpret_cast<float4*>(a.C + (size_t)row * a.ldc + col) = make_float4(v[0], v[1], v[2], v[3]);
+                    } else {
+#pragma unroll
+                        for (int q = 0; q < 4; q++)
+                            if (col + q < a.N) a.C[(size_t)row * a.ldc + col + q] = v[q];
+                    }
+                }
+            }
+            if (HAS_AUX && h + ADEPTH < 8) aux_load(h + ADEPTH, xq[h % ADEPTH]);
+            __builtin_amdgcn_wave_barrier();
+            if (STATS != NT_STAT_NONE && (h & 3) == 3) {
                 // fold the 8 row groups of the wave (lane >> 3); the M-waves meet in `red`
 #pragma unroll
                 for (int q = 0; q < 4; q++) {
@@ -404,7 +410,7 @@ int launch_gemm_nt(const NtArgs& a, hipStream_t st) {
     if (a.prologue == NT_PRO_BNTANH && (!a.pscale || !a.pshift)) return PC_EINVAL;
     if (a.prologue == NT_PRO_BNTANH && a.K > 256) return PC_ESHAPE;      // scale/shift live in LDS
     const bool needs_aux = a.epilogue == NT_EPI_DTANH || a.epilogue == NT_EPI_DTANH_BN || a.epilogue == NT_EPI_DRELU;
-    if (needs_aux && !a.aux) return PC_EINVAL;
+    if (needs_aux && (!a.aux || a.bias)) return PC_EINVAL;
     if (a.stats != NT_STAT_NONE && (a.N > 256 || !a.stat_sum || !a.stat_aux)) return PC_ESHAPE;
     // the fusions the two hot paths use (any other combination is refused)
     const int key = a.prologue * 100 + a.epilogue * 10 + a.stats;
