@@ -50,6 +50,19 @@ __device__ __forceinline__ void dma16(const float* gsrc, unsigned lds_addr) {
 }
 #pragma clang diagnostic pop
 
+// C and aux are streams (written / read once per launch, far larger than the 4 MB L2 of an XCD): moved
+// with the non-temporal hint they do not push W and the A rows in flight out of L2 (measured on the dZ2
+// GEMM: 99 -> 85 us, scripts/microbench/nt_deferred2.hip)
+__device__ __forceinline__ void store_stream(float* p, const float4& v) {
+    typedef float v4f __attribute__((ext_vector_type(4)));
+    __builtin_nontemporal_store(v4f{v.x, v.y, v.z, v.w}, reinterpret_cast<v4f*>(p));
+}
+__device__ __forceinline__ float4 load_stream(const float* p) {
+    typedef float v4f __attribute__((ext_vector_type(4)));
+    const v4f v = __builtin_nontemporal_load(reinterpret_cast<const v4f*>(p));
+    return make_float4(v.x, v.y, v.z, v.w);
+}
+
 // LDS-only hand-off between waves: no global-memory fence (a __syncthreads() would also wait for
 // this wave's outstanding C stores and for the next stage's DMA)
 __device__ __forceinline__ void lds_sync() {
@@ -258,7 +271,7 @@ __global__ __launch_bounds__(64 * NWM * NWN, WPS) void gemm_nt_kernel(NtArgs a, 
                 x4[i] = make_float4(0.f, 0.f, 0.f, 0.f);
                 if (fast) {
                     const int rc = row < row_end ? row : row_end - 1;      // clamped: the value of a dead row is never used
-                    x4[i] = *reinterpret_cast<const float4*>(a.aux + (size_t)rc * a.ldaux + col);
+                    x4[i] = load_stream(a.aux + (size_t)rc * a.ldaux + col);
                 } else if (row < row_end) {
                     if (col + 0 < a.N) x4[i].x = a.aux[(size_t)row * a.ldaux + col + 0];
                     if (col + 1 < a.N) x4[i].y = a.aux[(size_t)row * a.ldaux + col + 1];
@@ -324,7 +337,7 @@ __global__ __launch_bounds__(64 * NWM * NWN, WPS) void gemm_nt_kernel(NtArgs a, 
                 }
                 if (rok) {
                     if (fast) {
-                        *reinterpret_cast<float4*>(a.C + (size_t)row * a.ldc + col) = make_float4(v[0], v[1], v[2], v[3]);
+                        store_stream(a.C + (size_t)row * a.ldc + col, make_float4(v[0], v[1], v[2], v[3]));
                     } else {
 #pragma unroll
                         for (int q = 0; q < 4; q++)
