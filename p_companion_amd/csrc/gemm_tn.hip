@@ -150,116 +150,190 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(TnArgs a, int tiles_i, 
 // once per row tile: 2x the traffic for a 256x256 gradient, and these products sit near the
 // HBM roofline at the fp32 MFMA rate).  Wave grid WO x WI, each wave TO x TI MFMA tiles.
 //   <2,4,4,2> 256x256 (dW3)   <2,4,2,2> 128x256 (dW5)   <4,2,2,2> 256x128 (dW0, dW_kv)
-template <int WO, int WI, int TO, int TI, bool APRO, bool ZPRO>
+// The operands go global -> LDS directly (global_load_lds_dwordx4, see gemm_nt.hip): the stage is
+// [TK rows][NO | NI] row-major exactly as the rows lie in HBM, so one wave instruction drops 1 KB
+// of consecutive row floats and the MFMA fragments are conflict-free ds_read_b32 (32 consecutive
+// floats per half-wave).  The fused loaders run IN PLACE on the landed stage:
+//   APRO  A' = tanh(A * scale_s + shift_s)                       (dW3: A1 recomputed from H0)
+//   ZPRO  Z' = scale_s * (Z - m (c1_s + (H - mean_s) invstd_s c2_s))  (dW0: BatchNorm backward of dZ1,
+//         H = H0 staged beside Z)
+// db is folded from the Z fragments the wi == 0 waves read anyway.
+typedef __attribute__((address_space(3))) void* tn_lptr_t;
+__device__ __attribute__((aligned(64))) float pc_tn_zero_chunk[16];
+#pragma clang diagnostic push
+#pragma clang diagnostic ignored "-Winline-asm"
+__device__ __forceinline__ void tn_dma16(const float* gsrc, unsigned lds_addr) {
+    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(gsrc), "s"(lds_addr) : "memory", "m0");
+}
+#pragma clang diagnostic pop
+__device__ __forceinline__ void tn_lds_sync() {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+}
+
+template <int WO, int WI, int TO, int TI, int TKC, bool APRO, bool ZPRO>
 __global__ __launch_bounds__(512, 2) void gemm_tn8_kernel(TnArgs a, int nsplit, int rows_per_split) {
     constexpr int NO = WO * TO * 32, NI = WI * TI * 32;
-    constexpr int ZP = NO / 64, AP = NI / 64;            // float4 per thread per chunk (Z, A)
-    constexpr int ZT = NO / 4, AT = NI / 4;              // threads per row
-    constexpr int STAGE = TK * (NO + NI);
-    __shared__ __attribute__((aligned(16))) float smem[2 * STAGE];
+    constexpr int ZF = TKC * NO, AF = TKC * NI;                  // floats per stage image
+    constexpr int STAGE = ZF * (ZPRO ? 2 : 1) + AF;              // Z [, H], A
+    constexpr int JZ = ZF / 256 / 8, JA = AF / 256 / 8;          // DMA instructions per wave and image
+    static_assert(ZF % 2048 == 0 && AF % 2048 == 0, "images must split into whole wave instructions over 8 waves");
+    __shared__ __attribute__((aligned(1024))) float smem[2 * STAGE];
 
-    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, wo = w % WO, wi = w / WO;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6), wo = w % WO, wi = w / WO;
     const int split = blockIdx.x;
     const int r_begin = split * rows_per_split;
     const int r_end = min(a.R, r_begin + rows_per_split);
-    const int zrow = tid / ZT, zcol = (tid % ZT) * 4;    // 512/ZT rows per pass
-    const int arow = tid / AT, acol = (tid % AT) * 4;
-    const bool zcol_ok = zcol < a.No, acol_ok = acol < a.Ni;
+    const float* const zsrc0 = pc_tn_zero_chunk;
+    const unsigned lds0 = (unsigned)(uintptr_t)(tn_lptr_t)&smem[0];
 
-    float4 rz[ZP], ra[AP];
-    float4 dbacc = make_float4(0.f, 0.f, 0.f, 0.f);
-    int zseg = -1, aseg = -1;
-    float4 zmu, zis, zsc, zc1, zc2, asc, ash;
-    auto gload = [&](int r0) {
+    // DMA geometry: instruction g = w + 8 j of an image covers its floats [256 g, 256 g + 256)
+    int zr[JZ], zc[JZ], ar[JA], ac[JA];
 #pragma unroll
-        for (int p = 0; p < ZP; p++) {
-            const int r = r0 + zrow + (512 / ZT) * p;
-            const bool rv = r < r_end && zcol_ok;
-            rz[p] = rv ? *reinterpret_cast<const float4*>(a.Z + (size_t)r * a.ldz + zcol) : make_float4(0.f, 0.f, 0.f, 0.f);
-            if (ZPRO && rv) {
-                const int s = seg_of_row(a.seg, r);
-                if (s != zseg) {
-                    const size_t o = (size_t)s * a.No + zcol;
-                    zmu = *reinterpret_cast<const float4*>(a.z_mean + o);
-                    zis = *reinterpret_cast<const float4*>(a.z_invstd + o);
-                    zsc = *reinterpret_cast<const float4*>(a.z_scale + o);
-                    zc1 = *reinterpret_cast<const float4*>(a.z_c1 + o);
-                    zc2 = *reinterpret_cast<const float4*>(a.z_c2 + o);
-                    zseg = s;
-                }
-                const float4 h = *reinterpret_cast<const float4*>(a.zaux + (size_t)r * a.ldzaux + zcol);
-                const float zm = r == a.seg.wrow ? a.seg.wmult : 1.f;
-                rz[p].x = zsc.x * (rz[p].x - zm * (zc1.x + (h.x - zmu.x) * zis.x * zc2.x));
-                rz[p].y = zsc.y * (rz[p].y - zm * (zc1.y + (h.y - zmu.y) * zis.y * zc2.y));
-                rz[p].z = zsc.z * (rz[p].z - zm * (zc1.z + (h.z - zmu.z) * zis.z * zc2.z));
-                rz[p].w = zsc.w * (rz[p].w - zm * (zc1.w + (h.w - zmu.w) * zis.w * zc2.w));
-            }
-            dbacc.x += rz[p].x; dbacc.y += rz[p].y; dbacc.z += rz[p].z; dbacc.w += rz[p].w;
-        }
+    for (int j = 0; j < JZ; j++) { const int f = (w + 8 * j) * 256 + lane * 4; zr[j] = f / NO; zc[j] = f % NO; }
 #pragma unroll
-        for (int p = 0; p < AP; p++) {
-            const int r = r0 + arow + (512 / AT) * p;
-            bool av = r < r_end && acol_ok;
-            int src = r;
-            if (av && a.gather) { src = a.gather[r]; av = src >= 0; }
-            ra[p] = av ? *reinterpret_cast<const float4*>(a.A + (size_t)src * a.lda + acol) : make_float4(0.f, 0.f, 0.f, 0.f);
-            if (APRO && r < r_end && acol_ok) {
-                const int s = seg_of_row(a.seg, r);
-                if (s != aseg) {
-                    asc = *reinterpret_cast<const float4*>(a.pscale + (size_t)s * a.Ni + acol);
-                    ash = *reinterpret_cast<const float4*>(a.pshift + (size_t)s * a.Ni + acol);
-                    aseg = s;
-                }
-                ra[p].x = fast_tanh(ra[p].x * asc.x + ash.x);
-                ra[p].y = fast_tanh(ra[p].y * asc.y + ash.y);
-                ra[p].z = fast_tanh(ra[p].z * asc.z + ash.z);
-                ra[p].w = fast_tanh(ra[p].w * asc.w + ash.w);
-            }
+    for (int j = 0; j < JA; j++) { const int f = (w + 8 * j) * 256 + lane * 4; ar[j] = f / NI; ac[j] = f % NI; }
+    int gidx[JA];                                                // gather indices of the NEXT chunk to issue
+    auto load_gather = [&](int r0) {
+#pragma unroll
+        for (int j = 0; j < JA; j++) {
+            const int r = r0 + ar[j];
+            gidx[j] = (a.gather && r < r_end) ? a.gather[r] : r;
         }
     };
-    auto lstore = [&](int buf) {
-        float* Zs = smem + buf * STAGE;
-        float* As = Zs + TK * NO;
+    auto issue = [&](int st, int r0) {
+        const unsigned base = lds0 + st * (STAGE * 4) + w * 1024;
 #pragma unroll
-        for (int p = 0; p < ZP; p++) *reinterpret_cast<float4*>(&Zs[(zrow + (512 / ZT) * p) * NO + zcol]) = rz[p];
+        for (int j = 0; j < JZ; j++) {
+            const int r = r0 + zr[j];
+            const bool v = r < r_end && zc[j] < a.No;
+            tn_dma16(v ? a.Z + (size_t)r * a.ldz + zc[j] : zsrc0, base + j * 8192);
+            if (ZPRO) tn_dma16(v ? a.zaux + (size_t)r * a.ldzaux + zc[j] : zsrc0, base + ZF * 4 + j * 8192);
+        }
 #pragma unroll
-        for (int p = 0; p < AP; p++) *reinterpret_cast<float4*>(&As[(arow + (512 / AT) * p) * NI + acol]) = ra[p];
+        for (int j = 0; j < JA; j++) {
+            const int r = r0 + ar[j];
+            const bool v = r < r_end && ac[j] < a.Ni && gidx[j] >= 0;
+            tn_dma16(v ? a.A + (size_t)gidx[j] * a.lda + ac[j] : zsrc0, base + (ZPRO ? 2 : 1) * ZF * 4 + j * 8192);
+        }
+    };
+
+    // in-place loaders: thread t owns 4 fixed columns and every (512 / (N/4))-th row of an image
+    constexpr int ZT = NO / 4, AT = NI / 4;
+    const int zrow = tid / ZT, zcol = (tid % ZT) * 4, arow = tid / AT, acol = (tid % AT) * 4;
+    int zseg = -1, aseg = -1;
+    float4 zmu, zis, zsc, zc1, zc2, asc, ash;
+    auto transform = [&](float* stage, int r0) {
+        if (ZPRO && zcol < a.No) {
+            float* Zs = stage;
+            const float* Hs = stage + ZF;
+#pragma unroll
+            for (int p = 0; p < TKC / (512 / ZT); p++) {
+                const int rr = zrow + (512 / ZT) * p, r = r0 + rr;
+                if (r < r_end) {
+                    const int s = seg_of_row(a.seg, r);
+                    if (s != zseg) {
+                        const size_t o = (size_t)s * a.No + zcol;
+                        zmu = *reinterpret_cast<const float4*>(a.z_mean + o);
+                        zis = *reinterpret_cast<const float4*>(a.z_invstd + o);
+                        zsc = *reinterpret_cast<const float4*>(a.z_scale + o);
+                        zc1 = *reinterpret_cast<const float4*>(a.z_c1 + o);
+                        zc2 = *reinterpret_cast<const float4*>(a.z_c2 + o);
+                        zseg = s;
+                    }
+                    float4 z = *reinterpret_cast<const float4*>(&Zs[rr * NO + zcol]);
+                    const float4 h = *reinterpret_cast<const float4*>(&Hs[rr * NO + zcol]);
+                    const float zm = r == a.seg.wrow ? a.seg.wmult : 1.f;
+                    z.x = zsc.x * (z.x - zm * (zc1.x + (h.x - zmu.x) * zis.x * zc2.x));
+                    z.y = zsc.y * (z.y - zm * (zc1.y + (h.y - zmu.y) * zis.y * zc2.y));
+                    z.z = zsc.z * (z.z - zm * (zc1.z + (h.z - zmu.z) * zis.z * zc2.z));
+                    z.w = zsc.w * (z.w - zm * (zc1.w + (h.w - zmu.w) * zis.w * zc2.w));
+                    *reinterpret_cast<float4*>(&Zs[rr * NO + zcol]) = z;
+                }
+            }
+        }
+        if (APRO && acol < a.Ni) {
+            float* As = stage + (ZPRO ? 2 : 1) * ZF;
+#pragma unroll
+            for (int p = 0; p < TKC / (512 / AT); p++) {
+                const int rr = arow + (512 / AT) * p, r = r0 + rr;
+                if (r < r_end) {
+                    const int s = seg_of_row(a.seg, r);
+                    if (s != aseg) {
+                        asc = *reinterpret_cast<const float4*>(a.pscale + (size_t)s * a.Ni + acol);
+                        ash = *reinterpret_cast<const float4*>(a.pshift + (size_t)s * a.Ni + acol);
+                        aseg = s;
+                    }
+                    float4 x = *reinterpret_cast<const float4*>(&As[rr * NI + acol]);
+                    x.x = fast_tanh(x.x * asc.x + ash.x);
+                    x.y = fast_tanh(x.y * asc.y + ash.y);
+                    x.z = fast_tanh(x.z * asc.z + ash.z);
+                    x.w = fast_tanh(x.w * asc.w + ash.w);
+                    *reinterpret_cast<float4*>(&As[rr * NI + acol]) = x;
+                }
+            }
+        }
     };
 
     f32x16 acc[TO][TI];
+    float zsum[TO];
 #pragma unroll
-    for (int i = 0; i < TO; i++)
+    for (int i = 0; i < TO; i++) {
+        zsum[i] = 0.f;
 #pragma unroll
         for (int j = 0; j < TI; j++)
 #pragma unroll
             for (int r = 0; r < 16; r++) acc[i][j][r] = 0.f;
-
-    const int nchunk = (r_end - r_begin + TK - 1) / TK;
-    if (nchunk > 0) {
-        gload(r_begin);
-        lstore(0);
     }
+
+    const int nchunk = (r_end - r_begin + TKC - 1) / TKC;
+    if (nchunk > 0) {
+        load_gather(r_begin);
+        issue(0, r_begin);
+        if (nchunk > 1) load_gather(r_begin + TKC);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     const int fz = (lane >> 5) * NO + wo * (TO * 32) + (lane & 31);
     const int fa = (lane >> 5) * NI + wi * (TI * 32) + (lane & 31);
     for (int c = 0; c < nchunk; c++) {
         const int cur = c & 1;
-        if (c + 1 < nchunk) gload(r_begin + (c + 1) * TK);
-        const float* Zs = smem + cur * STAGE + fz;
-        const float* As = smem + cur * STAGE + TK * NO + fa;
-#pragma unroll
-        for (int k = 0; k < TK; k += 2) {
-            float z[TO], x[TI];
-#pragma unroll
-            for (int i = 0; i < TO; i++) z[i] = Zs[k * NO + 32 * i];
-#pragma unroll
-            for (int j = 0; j < TI; j++) x[j] = As[k * NI + 32 * j];
-#pragma unroll
-            for (int i = 0; i < TO; i++)
-#pragma unroll
-                for (int j = 0; j < TI; j++) acc[i][j] = mfma32(z[i], x[j], acc[i][j]);
+        if (c + 1 < nchunk) {
+            issue(cur ^ 1, r_begin + (c + 1) * TKC);
+            if (c + 2 < nchunk) load_gather(r_begin + (c + 2) * TKC);       // indices a whole chunk ahead of their use
         }
-        if (c + 1 < nchunk) lstore(cur ^ 1);
+        float* stage = smem + cur * STAGE;
+        if (APRO || ZPRO) { transform(stage, r_begin + c * TKC); tn_lds_sync(); }
+        const float* Zs = stage + fz;
+        const float* As = stage + (ZPRO ? 2 : 1) * ZF + fa;
+        // fragments of row pair k+2 are requested before the MFMAs of pair k are issued (the scheduler
+        // otherwise sinks each read to just before its MFMA and exposes the LDS latency 16x per chunk)
+        float z[2][TO], x[2][TI];
+#pragma unroll
+        for (int i = 0; i < TO; i++) z[0][i] = Zs[32 * i];
+#pragma unroll
+        for (int j = 0; j < TI; j++) x[0][j] = As[32 * j];
+#pragma unroll
+        for (int k = 0; k < TKC; k += 2) {
+            const int b = (k >> 1) & 1;
+            if (k + 2 < TKC) {
+#pragma unroll
+                for (int i = 0; i < TO; i++) z[b ^ 1][i] = Zs[(k + 2) * NO + 32 * i];
+#pragma unroll
+                for (int j = 0; j < TI; j++) x[b ^ 1][j] = As[(k + 2) * NI + 32 * j];
+            }
+#pragma unroll
+            for (int i = 0; i < TO; i++) {
+                zsum[i] += z[b][i];
+#pragma unroll
+                for (int j = 0; j < TI; j++) acc[i][j] = mfma32(z[b][i], x[b][j], acc[i][j]);
+            }
+            if (k + 2 < TKC) __builtin_amdgcn_sched_group_barrier(0x100, TO + TI, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, TO * TI, 0);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
     }
 
@@ -275,15 +349,13 @@ __global__ __launch_bounds__(512, 2) void gemm_tn8_kernel(TnArgs a, int nsplit, 
                 if (o < a.No && ci < a.Ni) slab[(size_t)o * a.Ni + ci] = acc[i][j][reg];
             }
         }
-    if (a.db) {
-        float* red = smem;                                // [512/ZT row groups][NO]; all MFMA reads are done
-        *reinterpret_cast<float4*>(&red[zrow * NO + zcol]) = dbacc;
-        __syncthreads();
-        if (tid < NO && tid < a.No) {
-            float s = 0.f;
+    if (a.db && wi == 0) {
+        // lanes l and l+32 hold the even / odd rows of column (l & 31)
 #pragma unroll
-            for (int g = 0; g < 512 / ZT; g++) s += red[g * NO + tid];
-            slab[(size_t)a.No * a.Ni + tid] = s;
+        for (int i = 0; i < TO; i++) {
+            const float s = zsum[i] + __shfl_xor(zsum[i], 32, 64);
+            const int o = wo * (TO * 32) + i * 32 + (lane & 31);
+            if (lane < 32 && o < a.No) slab[(size_t)a.No * a.Ni + o] = s;
         }
     }
 }
@@ -362,9 +434,9 @@ int launch_gemm_tn(const TnArgs& a, hipStream_t st) {
     if (tn_full_tile(a.R, a.No, a.Ni) && !(apro && zpro)) {
 #define TN8(WO, WI, TO, TI)                                                                                   \
     do {                                                                                                      \
-        if (apro) PC_LAUNCH((gemm_tn8_kernel<WO, WI, TO, TI, true, false>), dim3(nsplit), dim3(512), 0, st, a, nsplit, rps);       \
-        else if (zpro) PC_LAUNCH((gemm_tn8_kernel<WO, WI, TO, TI, false, true>), dim3(nsplit), dim3(512), 0, st, a, nsplit, rps);  \
-        else PC_LAUNCH((gemm_tn8_kernel<WO, WI, TO, TI, false, false>), dim3(nsplit), dim3(512), 0, st, a, nsplit, rps);           \
+        if (apro) PC_LAUNCH((gemm_tn8_kernel<WO, WI, TO, TI, 32, true, false>), dim3(nsplit), dim3(512), 0, st, a, nsplit, rps);       \
+        else if (zpro) PC_LAUNCH((gemm_tn8_kernel<WO, WI, TO, TI, 16, false, true>), dim3(nsplit), dim3(512), 0, st, a, nsplit, rps);  \
+        else PC_LAUNCH((gemm_tn8_kernel<WO, WI, TO, TI, 32, false, false>), dim3(nsplit), dim3(512), 0, st, a, nsplit, rps);           \
     } while (0)
         if (a.No > 128 && a.Ni > 128) TN8(2, 4, 4, 2);
         else if (a.No > 128) TN8(4, 2, 2, 2);
