@@ -154,7 +154,7 @@ class SimilarityIndexLoader:
     """
 
     def __init__(self, bpg: IntBPG, batch_size: int, shuffle=True, sampler="philox", seed=0, k_neg=5,
-                 drop_last=False, device="cuda", compact=True):
+                 drop_last=False, device="cuda", compact=True, prefetch=True):
         from . import ops
         self.ops = ops
         self.bpg = bpg
@@ -167,6 +167,9 @@ class SimilarityIndexLoader:
         self.drop_last = drop_last
         self.device = device
         self.compact = compact          # carry the zero-padding rows once (pc_p2v_train_step_compact)
+        # build batch i+1 on a side stream while the consumer trains on batch i (what the reference's
+        # DataLoader workers do on the host, scripts/pretrain_product2vec.py:24-30); same batches either way
+        self.prefetch = prefetch and sampler == "philox" and torch.device(device).type == "cuda"
         self.epoch = 0
         self.step = 0
         self.g = bpg.cuda(device)
@@ -189,7 +192,7 @@ class SimilarityIndexLoader:
             perm = rs.permutation(S) if self.shuffle else np.arange(S, dtype=np.int64)
         perm_dev = torch.from_numpy(perm.astype(np.int32)).to(self.device)
         self.epoch += 1
-        for i in range(len(self)):
+        def make(i):
             lo, hi = i * self.batch_size, min((i + 1) * self.batch_size, S)
             ids = perm[lo:hi]
             n_pad = int(self._deg[ids].max())           # collate_fn pads to the batch maximum
@@ -220,6 +223,31 @@ class SimilarityIndexLoader:
                     batch["neighbor_compact"] = self.ops.compact_neighbors(nb)
             if nbc is not None:
                 batch["neighbor_compact"] = nbc
+            return batch
+
+        n = len(self)
+        if not self.prefetch:
+            for i in range(n):
+                yield make(i)
+            return
+        side = torch.cuda.Stream(self.device)
+        side.wait_stream(torch.cuda.current_stream(self.device))     # the epoch permutation was uploaded there
+        def launch(i):
+            with torch.cuda.stream(side):
+                b = make(i)
+                ev = torch.cuda.Event()
+                ev.record(side)
+            return b, ev
+        nxt = launch(0) if n > 0 else None
+        for i in range(n):
+            batch, ev = nxt
+            nxt = launch(i + 1) if i + 1 < n else None
+            cur = torch.cuda.current_stream(self.device)
+            cur.wait_event(ev)
+            for v in batch.values():
+                for t in (v.values() if isinstance(v, dict) else [v]):
+                    if torch.is_tensor(t):
+                        t.record_stream(cur)        # allocated on the side stream, consumed on this one
             yield batch
 
 
