@@ -1,0 +1,67 @@
+"""Turn one `scripts/profile_round.sh <tag>` run (gpurun_out/<tag>/) into the committed artefacts under profiles/:
+  <tag>_bench.json, <tag>_bench_under_rocprof.json      the bench lines (plain, and under the kernel trace)
+  <tag>_kernel_stats.csv / .json                        rocprofv3 --kernel-trace --stats per-kernel summary
+  <tag>_pmc_traffic.json                                HBM bytes per kernel from the FETCH_SIZE / WRITE_SIZE passes
+PMC units follow /opt/skills/guides/MI355X_MICROARCH.md: both counters are in KiB-like 1 KiB units on this stack
+(value x 1024 = bytes) and FETCH_SIZE under-reports by 2x on gfx950 (doubled here)."""
+import csv, glob, json, os, re, shutil, sqlite3, sys
+from collections import defaultdict
+
+tag = sys.argv[1]
+root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+src = os.path.join(root, "gpurun_out", tag)
+dst = os.path.join(root, "profiles")
+os.makedirs(dst, exist_ok=True)
+for name in ("bench.json", "bench_under_rocprof.json"):
+    if os.path.exists(os.path.join(src, name)):
+        shutil.copy(os.path.join(src, name), os.path.join(dst, f"{tag}_{name}"))
+
+def short(n):
+    n = re.sub(r"\(.*$", "", n)
+    return n.replace("void ", "").strip()
+
+# ---- kernel trace
+dbs = glob.glob(os.path.join(src, "prof", "*_results.db"))
+if dbs:
+    db = sqlite3.connect(dbs[0]); cur = db.cursor()
+    tabs = [r[0] for r in cur.execute("select name from sqlite_master where type='table'")]
+    kd = [t for t in tabs if t.startswith("rocpd_kernel_dispatch")][0]
+    ks = [t for t in tabs if t.startswith("rocpd_info_kernel_symbol")][0]
+    cols = [r[1] for r in cur.execute(f"pragma table_info({ks})")]
+    namecol = "display_name" if "display_name" in cols else "kernel_name"
+    rows = cur.execute(f"select s.{namecol}, count(*), sum(d.end-d.start), avg(d.end-d.start), min(d.end-d.start), max(d.end-d.start) "
+                       f"from {kd} d join {ks} s on d.kernel_id=s.id group by s.{namecol} order by 3 desc").fetchall()
+    tot = sum(r[2] for r in rows)
+    with open(os.path.join(dst, f"{tag}_kernel_stats.csv"), "w", newline="") as f:
+        wr = csv.writer(f); wr.writerow(["Name", "Calls", "TotalDurationNs", "AverageNs", "Percentage", "MinNs", "MaxNs"])
+        for r in rows: wr.writerow([r[0], r[1], r[2], f"{r[3]:.1f}", f"{100*r[2]/tot:.2f}", r[4], r[5]])
+    js = {short(r[0]) if r[0].startswith("void") or "(" in r[0] else r[0]: {"calls": r[1], "avg_us": round(r[3] / 1e3, 2), "share": round(r[2] / tot, 4)} for r in rows}
+    nt = [(r[1], r[2]) for r in rows if "gemm_nt_kernel" in r[0]]; tn = [(r[1], r[2]) for r in rows if "gemm_tn" in r[0]]
+    js["_summary"] = {"total_kernel_us": round(tot / 1e3, 1),
+                      "gemm_nt_avg_us": round(sum(t for _, t in nt) / max(1, sum(c for c, _ in nt)) / 1e3, 2),
+                      "gemm_nt_share": round(sum(t for _, t in nt) / tot, 4),
+                      "gemm_tn_avg_us": round(sum(t for _, t in tn) / max(1, sum(c for c, _ in tn)) / 1e3, 2),
+                      "gemm_tn_share": round(sum(t for _, t in tn) / tot, 4)}
+    json.dump(js, open(os.path.join(dst, f"{tag}_kernel_stats.json"), "w"), indent=1)
+    print("kernel stats:", js["_summary"])
+
+# ---- PMC passes
+def pmc(dirname, counter):
+    out = defaultdict(lambda: [0, 0.0])
+    for fn in glob.glob(os.path.join(src, dirname, "*", "*counter_collection.csv")):
+        for row in csv.DictReader(open(fn)):
+            if row["Counter_Name"] != counter: continue
+            k = short(row["Kernel_Name"])
+            out[k][0] += 1; out[k][1] += float(row["Counter_Value"])
+    return out
+fe, wr_ = pmc("pmc_fetch", "FETCH_SIZE"), pmc("pmc_write", "WRITE_SIZE")
+if fe:
+    res = {}
+    for k, (n, v) in fe.items():
+        w = wr_.get(k, [n, 0.0])
+        res[k] = {"launches": n, "fetch_kib_raw": round(v / n, 1), "fetch_bytes_corrected": round(v / n * 1024 * 2),
+                  "write_bytes": round(w[1] / max(1, w[0]) * 1024)}
+    json.dump(res, open(os.path.join(dst, f"{tag}_pmc_traffic.json"), "w"), indent=1)
+    nt = [v for k, v in res.items() if "gemm_nt_kernel" in k]
+    n = sum(v["launches"] for v in nt)
+    print("gemm_nt HBM bytes/launch:", round(sum((v["fetch_bytes_corrected"] + v["write_bytes"]) * v["launches"] for v in nt) / n))
