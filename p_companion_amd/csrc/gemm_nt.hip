@@ -95,6 +95,10 @@ __global__ __launch_bounds__(64 * NWM * NWN, WPS) void gemm_nt_kernel(NtArgs a, 
     __shared__ __attribute__((aligned(16))) float patch[PATCH];
     __shared__ float red[STATS != NT_STAT_NONE ? 2 * NWM * BN : 1];                           // [2 stats][NWM][BN]
     __shared__ __attribute__((aligned(16))) float pro_ss[PRO ? 2 * PC_MAX_SEG * 256 : 4];   // [seg][scale|shift][K]
+    // DTANH_BN: the per-column BN scale/shift of the epilogue are read from LDS at their use, not held in 8
+    // registers per lane through the whole epilogue (the accumulators leave no room for them)
+    constexpr bool EBN = EPI == NT_EPI_DTANH_BN;
+    __shared__ __attribute__((aligned(16))) float epi_ss[EBN ? 2 * PC_MAX_SEG * 256 : 4];   // [seg][scale|shift][N]
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6), wm = w % NWM, wn = w / NWM;     // wave-uniform: SGPRs
@@ -105,6 +109,13 @@ __global__ __launch_bounds__(64 * NWM * NWN, WPS) void gemm_nt_kernel(NtArgs a, 
     const int lchunk = (lane % CPR) ^ ((((w * RPI) + lrow) / RB) % CPR);
     const float* const zsrc = pc_zero_chunk;
 
+    if (EBN) {
+        for (int i = tid; i < a.seg.nseg * a.N; i += THREADS) {
+            const int s = i / a.N, n = i - s * a.N;
+            epi_ss[(2 * s) * 256 + n] = a.escale[i];
+            epi_ss[(2 * s + 1) * 256 + n] = a.eshift[i];
+        }
+    }
     if (PRO) {
         for (int i = tid; i < a.seg.nseg * a.K; i += THREADS) {
             const int s = i / a.K, k = i - s * a.K;
@@ -284,7 +295,7 @@ __global__ __launch_bounds__(64 * NWM * NWN, WPS) void gemm_nt_kernel(NtArgs a, 
 #pragma unroll
             for (int h = 0; h < ADEPTH; h++) aux_load(h, xq[h]);
         }
-        float bias[4], es[4], eh[4], cs1[4], cs2[4];
+        float bias[4], cs1[4], cs2[4];
 #pragma unroll
         for (int h = 0; h < 8; h++) {
             const int nt = h >> 2, mt = (h >> 1) & 1, half = h & 1;
@@ -295,11 +306,6 @@ __global__ __launch_bounds__(64 * NWM * NWN, WPS) void gemm_nt_kernel(NtArgs a, 
                     const bool cv = col + q < a.N;
                     cs1[q] = cs2[q] = 0.f;
                     bias[q] = (!HAS_AUX && cv && a.bias) ? a.bias[col + q] : 0.f;     // the d-activation epilogues carry no bias
-                    es[q] = eh[q] = 0.f;
-                    if (cv && EPI == NT_EPI_DTANH_BN) {
-                        es[q] = a.escale[(size_t)seg * a.N + col + q];
-                        eh[q] = a.eshift[(size_t)seg * a.N + col + q];
-                    }
                 }
             }
             const int rbase = row0 + wm * 64 + mt * 32 + half * 16 + er;
@@ -315,6 +321,15 @@ __global__ __launch_bounds__(64 * NWM * NWN, WPS) void gemm_nt_kernel(NtArgs a, 
                 const float4 xa = xq[HAS_AUX ? h % ADEPTH : 0][i];
                 const float ax[4] = {xa.x, xa.y, xa.z, xa.w};
                 const bool rok = row < row_end;
+                float es[4] = {0.f, 0.f, 0.f, 0.f}, eh[4] = {0.f, 0.f, 0.f, 0.f};
+                if (EBN) {
+                    int eo = (2 * seg) * 256 + (fast ? col : 0);          // (N <= 256 and the tile spans it when this epilogue runs)
+                    asm volatile("" : "+v"(eo));                          // opaque: re-read here, do not cache in registers
+                    const float4 s4 = *reinterpret_cast<const float4*>(&epi_ss[eo]);
+                    const float4 h4 = *reinterpret_cast<const float4*>(&epi_ss[eo + 256]);
+                    es[0] = s4.x; es[1] = s4.y; es[2] = s4.z; es[3] = s4.w;
+                    eh[0] = h4.x; eh[1] = h4.y; eh[2] = h4.z; eh[3] = h4.w;
+                }
 #pragma unroll
                 for (int q = 0; q < 4; q++) {
                     float x = v[q] + bias[q];
@@ -378,6 +393,11 @@ __global__ __launch_bounds__(64 * NWM * NWN, WPS) void gemm_nt_kernel(NtArgs a, 
         if (ntile >= total_tiles) break;
         zero_acc();
         tile = ntile; row0 = nrow0; row_end = nrow_end; n0 = nn0; seg = nseg;
+        // the DMA source pointers (two registers each) are rebuilt from the row indices rather than kept alive
+        // across the epilogue, which is where the register budget is tightest
+#pragma unroll
+        for (int j = 0; j < NIA; j++) asm volatile("" : "+v"(nsrow[j]));
+        make_ptrs(nsrow, n0);
     }
 }
 
@@ -424,6 +444,7 @@ int launch_gemm_nt(const NtArgs& a, hipStream_t st) {
     if (a.prologue == NT_PRO_BNTANH && a.K > 256) return PC_ESHAPE;      // scale/shift live in LDS
     const bool needs_aux = a.epilogue == NT_EPI_DTANH || a.epilogue == NT_EPI_DTANH_BN || a.epilogue == NT_EPI_DRELU;
     if (needs_aux && (!a.aux || a.bias)) return PC_EINVAL;
+    if (a.epilogue == NT_EPI_DTANH_BN && (a.N > 256 || a.N % 4 || !a.escale || !a.eshift)) return PC_ESHAPE;   // scale/shift live in LDS
     if (a.stats != NT_STAT_NONE && (a.N > 256 || !a.stat_sum || !a.stat_aux)) return PC_ESHAPE;
     // the fusions the two hot paths use (any other combination is refused)
     const int key = a.prologue * 100 + a.epilogue * 10 + a.stats;
