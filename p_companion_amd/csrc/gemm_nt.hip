@@ -401,6 +401,109 @@ __global__ __launch_bounds__(64 * NWM * NWN, WPS) void gemm_nt_kernel(NtArgs a, 
     }
 }
 
+// ---------------------------------------------------------------------------------------
+// Few rows (the per-sample projections of the attention block: M = batch; every layer of the joint
+// step): the product is a few hundred MFLOP and the persistent kernel's K pipeline is pure latency
+// (4 dependent stage round trips for K = 128).  Here a 4-wave workgroup owns 32 rows x up to 128
+// columns, requests the WHOLE K extent of its A rows and of W in one burst of LDS-DMA, waits once,
+// and each wave multiplies its 32x32 block.  K <= 128, N <= 128; no prologue / statistics.
+// Stage rows are KS = 32/64/128 floats (K rounded up), chunks XOR-swizzled as above.
+template <int EPI>
+__global__ __launch_bounds__(256) void gemm_nt_small_kernel(NtArgs a, int ks_log2) {
+    extern __shared__ __attribute__((aligned(1024))) float sm_small[];
+    const int KS = 1 << ks_log2, CPR = KS >> 2;                  // floats / 16-B chunks per stage row
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int tile = blockIdx.x;
+    const int sg = seg_of_tile(a.seg, tile);
+    const int row0 = a.seg.start[sg] + (tile - a.seg.tile0[sg]) * 32, row_end = a.seg.start[sg + 1];
+    auto swz = [&](int r) { return KS == 32 ? (r >> 1) & 7 : r & 15; };
+
+    // ---- one burst: stage rows [0,32) = A rows of the tile, [32,160) = W rows; 1 KB per wave instruction
+    const int rows_per_instr = 256 >> ks_log2, ninstr = (160 * KS) >> 8;
+    const unsigned lds0 = (unsigned)(uintptr_t)(lptr_t)&sm_small[0];
+    for (int g = w; g < ninstr; g += 4) {
+        const int r = g * rows_per_instr + lane / CPR;           // stage row
+        const int chunk = (lane % CPR) ^ swz(r);
+        const float* p = pc_zero_chunk;
+        if (chunk * 4 < a.K) {
+            if (r < 32) {
+                const int gr = row0 + r;
+                const int srow = gr < row_end ? (a.gather ? a.gather[gr] : gr) : -1;
+                if (srow >= 0) p = a.A + (size_t)srow * a.lda + chunk * 4;
+            } else if (r - 32 < a.N) {
+                p = a.W + (size_t)(r - 32) * a.ldw + chunk * 4;
+            }
+        }
+        dma16(p, lds0 + g * 1024);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; r++) acc[r] = 0.f;
+    const int fr = lane & 31, fh = lane >> 5;
+    const float* As = sm_small + fr * KS;
+    const float* Ws = sm_small + (32 + w * 32 + fr) * KS;
+    const int sa = swz(fr), sw = swz(32 + w * 32 + fr);
+    const int nkk = (a.K + 7) >> 3;
+    for (int kk = 0; kk < nkk; kk++) {
+        const int c = 2 * kk + fh;
+        const float4 fa4 = *reinterpret_cast<const float4*>(&As[(c ^ sa) << 2]);
+        const float4 fb4 = *reinterpret_cast<const float4*>(&Ws[(c ^ sw) << 2]);
+        acc = mfma32(fa4.x, fb4.x, acc);
+        acc = mfma32(fa4.y, fb4.y, acc);
+        acc = mfma32(fa4.z, fb4.z, acc);
+        acc = mfma32(fa4.w, fb4.w, acc);
+    }
+    __syncthreads();                                             // the stage becomes the epilogue patches
+
+    float* stg = sm_small + w * (32 * PLD);
+#pragma unroll
+    for (int reg = 0; reg < 16; reg++)
+        stg[((reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)) * PLD + (lane & 31)] = acc[reg];
+    __builtin_amdgcn_wave_barrier();
+    const int er = lane >> 3, ec = (lane & 7) * 4;
+    const int col = w * 32 + ec;
+    const bool vec = ((a.N | a.ldc) & 3) == 0 && (!a.aux || (a.ldaux & 3) == 0);
+    constexpr bool HAS_AUX = EPI == NT_EPI_DTANH || EPI == NT_EPI_DRELU;
+    float bias[4];
+#pragma unroll
+    for (int q = 0; q < 4; q++) bias[q] = (!HAS_AUX && a.bias && col + q < a.N) ? a.bias[col + q] : 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        const int row = row0 + er + 8 * i;
+        if (row >= row_end) continue;
+        const float4 v4 = *reinterpret_cast<const float4*>(&stg[(er + 8 * i) * PLD + ec]);
+        float v[4] = {v4.x, v4.y, v4.z, v4.w}, ax[4] = {0.f, 0.f, 0.f, 0.f};
+        if (HAS_AUX) {
+#pragma unroll
+            for (int q = 0; q < 4; q++)
+                if (col + q < a.N) ax[q] = a.aux[(size_t)row * a.ldaux + col + q];
+        }
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            float x = v[q] + bias[q];
+            switch (EPI) {
+                case NT_EPI_TANH: x = fast_tanh(x); break;
+                case NT_EPI_RELU: x = x > 0.f ? x : 0.f; break;
+                case NT_EPI_DTANH: x = x * (1.f - ax[q] * ax[q]); break;
+                case NT_EPI_DRELU: x = ax[q] > 0.f ? x : 0.f; break;
+                default: break;
+            }
+            v[q] = x;
+        }
+        if (vec && col + 3 < a.N) {
+            *reinterpret_cast<float4*>(a.C + (size_t)row * a.ldc + col) = make_float4(v[0], v[1], v[2], v[3]);
+        } else {
+#pragma unroll
+            for (int q = 0; q < 4; q++)
+                if (col + q < a.N) a.C[(size_t)row * a.ldc + col + q] = v[q];
+        }
+    }
+}
+
 static SegInfo retile(const SegInfo& in, int tile_rows) {
     SegInfo si = in;
     int t = 0;
@@ -423,9 +526,22 @@ static void launch_variant(const NtArgs& a, int ntm, hipStream_t st) {
         // N <= 128: 128x128 tiles, 4 waves, three workgroups per CU
         PC_LAUNCH((gemm_nt_kernel<2, 2, 16, 3, false, EPI, NT_STAT_NONE>), dim3(ntm < 768 ? ntm : 768), dim3(256), 0, st, a,
                   1, ntm);
+    } else if (a.K <= 128 && (EPI == NT_EPI_NONE || EPI == NT_EPI_TANH || EPI == NT_EPI_RELU || EPI == NT_EPI_DTANH ||
+                              EPI == NT_EPI_DRELU)) {
+        // few rows, short K: one LDS-DMA burst per 32-row tile, no K pipeline
+        NtArgs b = a;
+        b.seg = retile(a.seg, 32);
+        const int total = gemm_nt_tiles(b.seg);
+        const int ks_log2 = a.K <= 32 ? 5 : a.K <= 64 ? 6 : 7;
+        constexpr int SEPI = (EPI == NT_EPI_DTANH_BN) ? NT_EPI_NONE : EPI;
+        const size_t lds = (size_t)160 * (1 << ks_log2) * 4 > (size_t)4 * 32 * PLD * 4 ? (size_t)160 * (1 << ks_log2) * 4
+                                                                                   : (size_t)4 * 32 * PLD * 4;
+        static const hipError_t lds_attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt_small_kernel<SEPI>),
+                                                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 128 * 4);
+        (void)lds_attr;                                          // 80 KB of dynamic LDS at KS = 128 (> the 64 KB default cap)
+        PC_LAUNCH((gemm_nt_small_kernel<SEPI>), dim3(total), dim3(256), lds, st, b, ks_log2);
     } else {
-        // few rows (per-sample projections of the attention block, joint-step layers): 64-row
-        // tiles of 2 waves reach 2x the CUs
+        // few rows, long K: 64-row tiles of 2 waves reach 2x the CUs
         NtArgs b = a;
         b.seg = retile(a.seg, 64);
         const int total = gemm_nt_tiles(b.seg);
