@@ -363,6 +363,18 @@ int pc_scatter_rows(float *out, const int32_t *idx, int rows, int width, const f
  * (F.relu of type_transition.py:17 in module mode). */
 int pc_act_backward(const float *dy, const float *y, size_t n, int act, float *dx, void *stream);
 
+/* ---------------------------------------------------------------------------------
+ * Serving: type-filtered top-n retrieval -- the candidate search of
+ * PCompanionInference.recommend (inference.py:90-118): for row r (one predicted complementary
+ * type of one query), scores = proj[r] . features[c] over the products c of type types[r]
+ * (CSR type_rowptr[n_types+1] / type_col, products in node order = bpg.get_products_by_type),
+ * torch.topk(scores, min(n, count)).  out_idx / out_score [rows, n]; missing entries (fewer than
+ * n products of that type, or a type outside [0, n_types)) are -1 / -inf.  1 <= n <= 16.
+ * --------------------------------------------------------------------------------- */
+int pc_retrieve_topk(const float *proj, const int32_t *types, int rows, const int32_t *type_rowptr,
+                     const int32_t *type_col, const float *table, int n_types, int n, int32_t *out_idx,
+                     float *out_score, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -115,3 +115,21 @@ def evaluate_batch(st, query_idx, query_types, positive_items, target_features, 
         res["type_diversity"] = torch.unique(types, dim=1).shape[1] / types.shape[1]
         res["mean_relevance"] = torch.cosine_similarity(proj, positive_items.unsqueeze(1), dim=-1).mean().item()
     return res
+
+
+def recommend(proj, types, type_idx, features, n):
+    """inference.py:90-118 restated with numpy: per (row) predicted type, candidates = products of that
+    type in node order (bpg.get_products_by_type, bpg.py:40-43), similarities = proj @ features[cand].T,
+    torch.topk(similarities, min(n, len(cand))).  Returns lists of (candidate ids, scores) per row."""
+    import numpy as np
+    out = []
+    for r in range(proj.shape[0]):
+        cand = np.nonzero(type_idx == types[r])[0]
+        if cand.size == 0:
+            out.append((np.zeros(0, np.int64), np.zeros(0, np.float32)))
+            continue
+        sims = features[cand].astype(np.float64) @ proj[r].astype(np.float64)
+        k = min(n, cand.size)
+        top = np.argsort(-sims, kind="stable")[:k]
+        out.append((cand[top], sims[top].astype(np.float32)))
+    return out

@@ -104,6 +104,7 @@ SIGNATURES = {
     "pc_topk_rows": (_i, [_vp, _i, _i, _i, _vp, _vp, _vp]),
     "pc_hit_rank": (_i, [_vp, _i, _i, _vp, _vp]),
     "pc_cosine_rows": (_i, [_vp, _vp, _i, _i, _vp, _vp]),
+    "pc_retrieve_topk": (_i, [_vp, _vp, _i, _vp, _vp, _vp, _i, _i, _vp, _vp, _vp]),
     "pc_hadamard_forward": (_i, [_vp, _vp, _i, _i, _vp, _vp]),
     "pc_hadamard_backward": (_i, [_vp, _vp, _vp, _i, _i, _vp, _vp, _vp]),
     "pc_gather_rows": (_i, [_vp, _vp, _i, _i, _vp, _vp]),

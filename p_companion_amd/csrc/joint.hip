@@ -500,3 +500,82 @@ extern "C" int pc_joint_train_step(const pc_joint_tensors* p, const pc_joint_ten
     return pc_joint_backward(p, g, query_idx, query_types, pos_types, neg_types, topk, B, T, K, w.dsv, w.dproj, &sv,
                              ws, ws_bytes, stream);
 }
+
+// ---------------------------------------------------------------------------------------
+// Type-filtered retrieval (inference.py:90-118): for every predicted (query, complementary type)
+// row r, score = proj[r] . features[c] over the products c of that type, top-n by score.  One
+// wavefront per row: proj[r] sits in LDS (broadcast reads), each lane scores its strided candidates
+// (rows of a 1000-product type are L2-resident) and keeps its n best sorted; n rounds of a wave-wide
+// arg-max pop the winners (ties: lower product index, like topk_rows_kernel).
+#define RMAX_N 16
+__global__ __launch_bounds__(256) void retrieve_topk_kernel(const float* proj, const int32_t* types, int rows,
+                                                            const int32_t* type_rowptr, const int32_t* type_col,
+                                                            const float* table, int n_types, int n, int32_t* out_idx,
+                                                            float* out_score) {
+    __shared__ __attribute__((aligned(16))) float q[4][PC_D];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int r = blockIdx.x * 4 + w;
+    if (r < rows) {
+        q[w][lane] = proj[(size_t)r * PC_D + lane];
+        q[w][lane + 64] = proj[(size_t)r * PC_D + lane + 64];
+    }
+    __syncthreads();
+    if (r >= rows) return;
+    const int t = types[r];
+    int c0 = 0, c1 = 0;
+    if (t >= 0 && t < n_types) { c0 = type_rowptr[t]; c1 = type_rowptr[t + 1]; }
+    float v[RMAX_N];
+    int ix[RMAX_N];
+#pragma unroll
+    for (int j = 0; j < RMAX_N; j++) { v[j] = -INFINITY; ix[j] = 0x7fffffff; }
+    for (int c = c0 + lane; c < c1; c += 64) {
+        const int pid = type_col[c];
+        const float4* f = reinterpret_cast<const float4*>(table + (size_t)pid * PC_D);
+        float s = 0.f;
+#pragma unroll 8
+        for (int k = 0; k < PC_D / 4; k++) {
+            const float4 x = f[k];
+            const float4 y = *reinterpret_cast<const float4*>(&q[w][4 * k]);
+            s += x.x * y.x + x.y * y.y + x.z * y.z + x.w * y.w;
+        }
+        float x = s;
+        int xi = pid;
+#pragma unroll
+        for (int j = 0; j < RMAX_N; j++) {
+            if (j < n) {
+                const bool better = x > v[j] || (x == v[j] && xi < ix[j]);
+                if (better) { const float tv = v[j]; const int ti = ix[j]; v[j] = x; ix[j] = xi; x = tv; xi = ti; }
+            }
+        }
+    }
+    for (int k = 0; k < n; k++) {
+        float bv = v[0];
+        int bi = ix[0];
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) {
+            const float ov = __shfl_xor(bv, o, 64);
+            const int oi = __shfl_xor(bi, o, 64);
+            if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
+        }
+        if (ix[0] == bi && bi != 0x7fffffff) {
+#pragma unroll
+            for (int j = 0; j < RMAX_N - 1; j++) { v[j] = v[j + 1]; ix[j] = ix[j + 1]; }
+            v[RMAX_N - 1] = -INFINITY; ix[RMAX_N - 1] = 0x7fffffff;
+        }
+        if (lane == 0) {
+            out_idx[(size_t)r * n + k] = bi == 0x7fffffff ? -1 : bi;
+            out_score[(size_t)r * n + k] = bv;
+        }
+    }
+}
+
+extern "C" int pc_retrieve_topk(const float* proj, const int32_t* types, int rows, const int32_t* type_rowptr,
+                                const int32_t* type_col, const float* table, int n_types, int n, int32_t* out_idx,
+                                float* out_score, void* stream) {
+    if (!proj || !types || !type_rowptr || !type_col || !table || !out_idx || !out_score) return PC_EINVAL;
+    if (rows <= 0 || n_types <= 0) return PC_EINVAL;
+    if (n < 1 || n > RMAX_N) return PC_ESHAPE;
+    PC_LAUNCH(retrieve_topk_kernel, dim3((rows + 3) / 4), dim3(256), 0, (hipStream_t)stream, proj, types, rows,
+              type_rowptr, type_col, table, n_types, n, out_idx, out_score);
+    return pc_launch_status();
+}

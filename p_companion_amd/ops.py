@@ -607,3 +607,20 @@ def build_complementary_batch(pairs, features, type_idx, n_types, seed, step, wa
     out["positive_types"] = out["positive_types"].view(b, 1)
     out["negative_types"] = out["negative_types"].view(b, 1)
     return out
+
+
+def retrieve_topk(proj, types, type_rowptr, type_col, table, n):
+    """pc_retrieve_topk: proj [R,128] fp32, types [R] int32 -> (idx [R,n] int32 product indices, -1 = none;
+    scores [R,n] fp32).  inference.py:90-118 for all rows at once."""
+    proj = _req(proj.reshape(-1, D), torch.float32, "proj")
+    r = proj.shape[0]
+    _req(types, torch.int32, "types", (r,))
+    _req(type_rowptr, torch.int32, "type_rowptr")
+    _req(type_col, torch.int32, "type_col")
+    _req(table, torch.float32, "table")
+    out_idx = torch.empty(r, n, dtype=torch.int32, device=proj.device)
+    out_sc = torch.empty(r, n, dtype=torch.float32, device=proj.device)
+    check(_lib.lib().pc_retrieve_topk(_p(proj), _p(types), r, _p(type_rowptr), _p(type_col), _p(table),
+                                      type_rowptr.numel() - 1, int(n), _p(out_idx), _p(out_sc), _stream()),
+          "pc_retrieve_topk")
+    return out_idx, out_sc

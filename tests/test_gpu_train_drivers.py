@@ -110,3 +110,46 @@ def test_complementary_batch_builder_rules(golden):
     assert abs(f.mean()) < 0.02 and abs(f.std() - 1.0) < 0.02 and abs((f ** 3).mean()) < 0.05
     b2 = ops.build_complementary_batch(torch.from_numpy(rows).cuda(), g["features"], g["type_idx"], bpg.n_types, 11, 6)
     assert not torch.equal(b2["negative_items"], b["negative_items"])            # a new step draws new fillers
+
+
+def test_type_filtered_retrieval_vs_oracle(golden, tmp_path):
+    """PCompanionInference.recommend (inference.py:64-124): model forward, then per predicted type
+    top-n products of that type by <projected embedding, features>.  Candidate search on the GPU
+    (pc_retrieve_topk) against the numpy restatement, on the reference's own 1k-product graph;
+    round trip through a best_model.pth-layout checkpoint."""
+    from p_companion_amd.data import IntBPG
+    from p_companion_amd.inference import PCompanionInference
+    from p_companion_amd.p_companion import PCompanion
+    bpg = IntBPG.from_arrays(golden("g2_bpg1000.npz"))
+    c = cfg(tmp_path, NUM_TYPES=bpg.n_types)
+    torch.manual_seed(3)
+    table = torch.randn(bpg.num_products, 128)
+    model = PCompanion(c, table)
+    path = os.path.join(str(tmp_path), "best_model.pth")
+    torch.save({"epoch": 0, "model_state_dict": {k: v.detach().cpu() for k, v in model.state_dict().items()},
+                "optimizer_state_dict": {}, "metrics": {}}, path)
+    ids = ["P%06d" % i for i in range(bpg.num_products)]
+    inf = PCompanionInference(path, c, bpg, product_ids=ids)
+
+    q = torch.arange(0, 200, dtype=torch.int32)
+    types, idx, sc = inf.recommend_batch(q, 10)
+    out = inf.model({"query_idx": q.cuda(), "query_types": inf.type_idx[q.long().cuda()]})
+    proj = out["projected_embeddings"].reshape(-1, 128).cpu().numpy()
+    tflat = out["complementary_types"].reshape(-1).cpu().numpy()
+    ref = joint_oracle.recommend(proj, tflat, bpg.type_idx, bpg.features, 10)
+    idx, sc = idx.reshape(-1, 10).cpu().numpy(), sc.reshape(-1, 10).cpu().numpy()
+    for r, (rid, rsc) in enumerate(ref):
+        k = len(rid)
+        assert (idx[r, k:] == -1).all()
+        np.testing.assert_allclose(sc[r, :k], rsc, rtol=1e-5, atol=1e-5)
+        assert (idx[r, :k] == rid).all() or np.allclose(np.sort(sc[r, :k]), np.sort(rsc), atol=1e-5)
+        assert (bpg.type_idx[idx[r, :k]] == tflat[r]).all()              # only products of the predicted type
+
+    rec = inf.recommend("P000007", num_recommendations=5)
+    assert rec["complementary_types"] == types[7].tolist()
+    assert len(rec["recommendations"]) == len(rec["scores"]) <= 3
+    assert all(len(x) <= 5 and all(isinstance(p, str) for p in x) for x in rec["recommendations"])
+    with pytest.raises(ValueError):
+        inf.recommend("P999999")
+    with pytest.raises(FileNotFoundError):
+        PCompanionInference(os.path.join(str(tmp_path), "missing.pth"), c, bpg)
