@@ -39,10 +39,24 @@ __global__ __launch_bounds__(256) void attn_core_fwd_kernel(const float* q, cons
     auto row_of = [&](int n) -> size_t {
         return sr_reg ? (size_t)__shfl(my_row, n, 64) : (sr ? (size_t)sr[n] : base + n);
     };
+    // keys are taken AU at a time: the AU row loads of a group are in flight together (one wave per sample
+    // and 16 waves per CU leave the latency of a load-use-load chain exposed otherwise)
+    constexpr int AU = 4;
     float m = -INFINITY;
-    for (int n = 0; n < N; n++) {
-        const float* kvr = kv + row_of(n) * (2 * PC_D);
-        const float2 k2 = *reinterpret_cast<const float2*>(kvr + 2 * lane);
+    int n = 0;
+    for (; n + AU <= N; n += AU) {
+        float2 k2[AU];
+#pragma unroll
+        for (int u = 0; u < AU; u++) k2[u] = *reinterpret_cast<const float2*>(kv + row_of(n + u) * (2 * PC_D) + 2 * lane);
+#pragma unroll
+        for (int u = 0; u < AU; u++) {
+            const float s = group16_sum(qv.x * k2[u].x + qv.y * k2[u].y);
+            if ((lane & 15) == 0) sc[h * N + n + u] = s;
+            m = fmaxf(m, s);
+        }
+    }
+    for (; n < N; n++) {
+        const float2 k2 = *reinterpret_cast<const float2*>(kv + row_of(n) * (2 * PC_D) + 2 * lane);
         const float s = group16_sum(qv.x * k2.x + qv.y * k2.y);
         if ((lane & 15) == 0) sc[h * N + n] = s;
         m = fmaxf(m, s);
@@ -50,10 +64,21 @@ __global__ __launch_bounds__(256) void attn_core_fwd_kernel(const float* q, cons
     __builtin_amdgcn_wave_barrier();
     float sum = 0.f;
     float2 o = make_float2(0.f, 0.f);
-    for (int n = 0; n < N; n++) {
+    for (n = 0; n + AU <= N; n += AU) {
+        float2 v2[AU];
+#pragma unroll
+        for (int u = 0; u < AU; u++) v2[u] = *reinterpret_cast<const float2*>(kv + row_of(n + u) * (2 * PC_D) + PC_D + 2 * lane);
+#pragma unroll
+        for (int u = 0; u < AU; u++) {
+            const float e = expf(sc[h * N + n + u] - m);
+            sum += e;
+            o.x += e * v2[u].x;
+            o.y += e * v2[u].y;
+        }
+    }
+    for (; n < N; n++) {
         const float e = expf(sc[h * N + n] - m);
-        const float* kvr = kv + row_of(n) * (2 * PC_D);
-        const float2 v2 = *reinterpret_cast<const float2*>(kvr + PC_D + 2 * lane);
+        const float2 v2 = *reinterpret_cast<const float2*>(kv + row_of(n) * (2 * PC_D) + PC_D + 2 * lane);
         sum += e;
         o.x += e * v2.x;
         o.y += e * v2.y;
@@ -91,21 +116,40 @@ __global__ __launch_bounds__(256) void attn_core_bwd_kernel(const float* dctx, c
         return sr_reg ? (size_t)__shfl(my_row, n, 64) : (sr ? (size_t)sr[n] : base + n);
     };
     const float* pb = probs + (size_t)b * PC_HEADS * N + h * N;
+    constexpr int AU = 4;                                 // rows in flight per group (see the forward kernel)
     float dsum = 0.f;                                     // sum_n p_n * dp_n  (softmax backward)
-    for (int n = 0; n < N; n++) {
-        const float* kvr = kv + row_of(n) * (2 * PC_D);
-        const float2 v2 = *reinterpret_cast<const float2*>(kvr + PC_D + 2 * lane);
+    int n = 0;
+    for (; n + AU <= N; n += AU) {
+        float2 v2[AU];
+#pragma unroll
+        for (int u = 0; u < AU; u++) v2[u] = *reinterpret_cast<const float2*>(kv + row_of(n + u) * (2 * PC_D) + PC_D + 2 * lane);
+#pragma unroll
+        for (int u = 0; u < AU; u++) {
+            const float dp = group16_sum(g.x * v2[u].x + g.y * v2[u].y);
+            if ((lane & 15) == 0) dps[h * N + n + u] = dp;
+            dsum += pb[n + u] * dp;
+        }
+    }
+    for (; n < N; n++) {
+        const float2 v2 = *reinterpret_cast<const float2*>(kv + row_of(n) * (2 * PC_D) + PC_D + 2 * lane);
         const float dp = group16_sum(g.x * v2.x + g.y * v2.y);
         if ((lane & 15) == 0) dps[h * N + n] = dp;
         dsum += pb[n] * dp;
     }
     __builtin_amdgcn_wave_barrier();
     float2 dqa = make_float2(0.f, 0.f), pk = make_float2(0.f, 0.f), pv = make_float2(0.f, 0.f);
-    for (int n = 0; n < N; n++) {
-        const float p = pb[n];
-        const float ds = p * (dps[h * N + n] - dsum);
-        const size_t row = row_of(n);
-        const float2 k2 = *reinterpret_cast<const float2*>(kv + row * (2 * PC_D) + 2 * lane);
+    for (n = 0; n < N; n += AU) {
+        float2 kk[AU];
+#pragma unroll
+        for (int u = 0; u < AU; u++)
+            kk[u] = n + u < N ? *reinterpret_cast<const float2*>(kv + row_of(n + u) * (2 * PC_D) + 2 * lane) : make_float2(0.f, 0.f);
+#pragma unroll
+        for (int u = 0; u < AU; u++) {
+        if (n + u >= N) break;
+        const float p = pb[n + u];
+        const float ds = p * (dps[h * N + n + u] - dsum);
+        const size_t row = row_of(n + u);
+        const float2 k2 = kk[u];
         dqa.x += ds * k2.x;
         dqa.y += ds * k2.y;
         if (sr && (int)row == pad_row) {                   // wave-uniform: the slot map is per sample
@@ -114,6 +158,7 @@ __global__ __launch_bounds__(256) void attn_core_bwd_kernel(const float* dctx, c
         } else {
             *reinterpret_cast<float2*>(dkv + row * (2 * PC_D) + 2 * lane) = make_float2(ds * qs.x, ds * qs.y);
             *reinterpret_cast<float2*>(dkv + row * (2 * PC_D) + PC_D + 2 * lane) = make_float2(p * g.x, p * g.y);
+        }
         }
     }
     if (dkv_pad) {
