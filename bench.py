@@ -36,6 +36,15 @@ def flops_per_triplet(n):
     return 3 * fwd - 65536 * (n + 7)
 
 
+def nt_algorithmic_bytes(b, nbc):
+    """Compulsory HBM bytes of the 7 persistent gemm_nt_kernel launches of one step:
+    rows R = [anchor B | neighbour rows nbc | positive B | negatives 5B]; per row Linear0 0.5+1 KB (gathered
+    x -> H0), Linear3 1+1 (H0 -> A2), Linear5 1+0.5 (A2 -> Y), dZ2 0.5+1+1 (dY, A2 -> dZ2), dZ1 1+1+1
+    (dZ2, H0 -> dZ1); per neighbour row K|V projection 0.5+1 and dKeys 1+0.5.  Weights are L2-resident."""
+    r = 7 * b + nbc
+    return 1024 * (r * (1.5 + 2.0 + 1.5 + 2.5 + 3.0) + nbc * (1.5 + 1.5))
+
+
 def bytes_per_triplet(n):
     return 512 * (n + 7) + 4 * (n + 7)
 
@@ -51,7 +60,7 @@ def pmc_traffic_per_launch():
         return None
     with open(files[-1]) as f:
         d = json.load(f)
-    nt = [v for k, v in d.items() if "gemm_nt_kernel" in k]
+    nt = [v for k, v in d.items() if "gemm_nt_kernel<" in k and "<1, 2," not in k]      # the persistent family (not the few-row kernels)
     n = sum(v["launches"] for v in nt)
     if not n:
         return None
@@ -252,15 +261,21 @@ def main():
     value = world * args.batch * args.steps / el
     nt = prof.summary("gemm_nt_kernel")
     tn = prof.summary("gemm_tn_kernel")
+    sm = prof.summary("gemm_nt_small_kernel")
+    traffic = pmc_traffic_per_launch()
     achieved = nt["total_flops"] / (nt["total_ms"] * 1e-3) / 1e12 if nt["total_ms"] > 0 else 0.0
     roof = {"bound": "mfma", "kernel": "gemm_nt_kernel", "achieved": round(achieved, 2),
             "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / FP32_MFMA_PEAK_TFLOPS, 4),
-            "traffic": pmc_traffic_per_launch(),
+            "traffic": traffic["hbm_bytes_per_launch"] if traffic else None,
+            "traffic_source": traffic["source"] if traffic else None,
+            "algorithmic_bytes_per_launch": round(nt_algorithmic_bytes(args.batch, real_sum / max(args.steps, 1) + 1) / 7),
             "launches": nt["launches"], "avg_launch_us": round(1e3 * nt["total_ms"] / max(nt["launches"], 1), 2),
             "flops_per_launch": nt["total_flops"] / max(nt["launches"], 1),
             "share_of_step": round(nt["total_ms"] / (el * 1e3), 3),
             "gemm_tn_kernel": {"achieved": round(tn["total_flops"] / max(tn["total_ms"], 1e-9) / 1e9, 2),
                                "launches": tn["launches"], "share_of_step": round(tn["total_ms"] / (el * 1e3), 3)},
+            "gemm_nt_small_kernel": {"launches": sm["launches"], "avg_launch_us": round(1e3 * sm["total_ms"] / max(sm["launches"], 1), 2),
+                                     "share_of_step": round(sm["total_ms"] / (el * 1e3), 3)},
             "whole_step": {"flops_per_triplet": flops_per_triplet(round(n_avg)),
                            "achieved": round(flops_per_triplet(n_avg) * value / world / 1e12, 2),
                            "frac_mfma": round(flops_per_triplet(n_avg) * value / world / 1e12 / FP32_MFMA_PEAK_TFLOPS, 4),

@@ -564,7 +564,9 @@ int launch_gemm_nt(const NtArgs& a, hipStream_t st) {
     if (a.stats != NT_STAT_NONE && (a.N > 256 || !a.stat_sum || !a.stat_aux)) return PC_ESHAPE;
     // the fusions the two hot paths use (any other combination is refused)
     const int key = a.prologue * 100 + a.epilogue * 10 + a.stats;
-    const int pb = pc_prof_begin(PC_KIND_GEMM_NT, 2.0 * a.M * (double)a.N * a.K, st);
+    // few-row launches (latency-bound, a few us each) are booked apart from the persistent kernel family
+    const bool small_m = !(a.prologue == NT_PRO_BNTANH || a.N > 128 || a.stats != NT_STAT_NONE) && ntm < 192;
+    const int pb = pc_prof_begin(small_m ? PC_KIND_GEMM_NT_SMALL : PC_KIND_GEMM_NT, 2.0 * a.M * (double)a.N * a.K, st);
     switch (key) {
         case 0:   launch_variant<false, NT_EPI_NONE, NT_STAT_NONE>(a, ntm, st); break;      // plain Linear / dX
         case 1:   launch_variant<false, NT_EPI_NONE, NT_STAT_SUMSQ>(a, ntm, st); break;     // Linear0 + BN sums

@@ -241,7 +241,7 @@ def adam_step(param, grad, exp_avg, exp_avg_sq, step_count, scalars, lr=1e-3, be
 
 class KernelProfile:
     """HIP-event brackets around the GEMM launches of the fused step (bench.py roofline leg)."""
-    KINDS = {"gemm_nt_kernel": 0, "gemm_tn_kernel": 1}
+    KINDS = {"gemm_nt_kernel": 0, "gemm_tn_kernel": 1, "gemm_nt_small_kernel": 2}
 
     def __init__(self, capacity):
         self.handle = ctypes.c_void_p()

@@ -36,7 +36,7 @@ if dbs:
         wr = csv.writer(f); wr.writerow(["Name", "Calls", "TotalDurationNs", "AverageNs", "Percentage", "MinNs", "MaxNs"])
         for r in rows: wr.writerow([r[0], r[1], r[2], f"{r[3]:.1f}", f"{100*r[2]/tot:.2f}", r[4], r[5]])
     js = {short(r[0]) if r[0].startswith("void") or "(" in r[0] else r[0]: {"calls": r[1], "avg_us": round(r[3] / 1e3, 2), "share": round(r[2] / tot, 4)} for r in rows}
-    nt = [(r[1], r[2]) for r in rows if "gemm_nt_kernel" in r[0]]; tn = [(r[1], r[2]) for r in rows if "gemm_tn" in r[0]]
+    nt = [(r[1], r[2]) for r in rows if "gemm_nt_kernel<" in r[0] or "gemm_nt_kernelI" in r[0]]; tn = [(r[1], r[2]) for r in rows if "gemm_tn" in r[0]]
     js["_summary"] = {"total_kernel_us": round(tot / 1e3, 1),
                       "gemm_nt_avg_us": round(sum(t for _, t in nt) / max(1, sum(c for c, _ in nt)) / 1e3, 2),
                       "gemm_nt_share": round(sum(t for _, t in nt) / tot, 4),
@@ -62,6 +62,6 @@ if fe:
         res[k] = {"launches": n, "fetch_kib_raw": round(v / n, 1), "fetch_bytes_corrected": round(v / n * 1024 * 2),
                   "write_bytes": round(w[1] / max(1, w[0]) * 1024)}
     json.dump(res, open(os.path.join(dst, f"{tag}_pmc_traffic.json"), "w"), indent=1)
-    nt = [v for k, v in res.items() if "gemm_nt_kernel" in k]
+    nt = [v for k, v in res.items() if "gemm_nt_kernel<" in k]
     n = sum(v["launches"] for v in nt)
     print("gemm_nt HBM bytes/launch:", round(sum((v["fetch_bytes_corrected"] + v["write_bytes"]) * v["launches"] for v in nt) / n))
