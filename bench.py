@@ -171,6 +171,9 @@ def main():
     ap.add_argument("--table", choices=["replicated", "sharded"], default="replicated")
     ap.add_argument("--phase", choices=["p2v", "joint"], default="p2v",
                     help="p2v = BASELINE configs[1] (the headline line); joint = configs[2], the P-Companion joint step")
+    ap.add_argument("--sync-bn", action="store_true",
+                    help="N > 1: BatchNorm statistics over all replicas' rows (two 16 KB all-reduces per step) instead of "
+                         "each replica's own batch")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     args = ap.parse_args()
@@ -228,7 +231,8 @@ def main():
             b = {"anchor_idx": remap[o[0]:o[1]].contiguous(), "positive_idx": remap[o[2]:o[3]].contiguous(),
                  "negative_idx": remap[o[3]:o[4]].view(B, K).contiguous(),
                  "neighbor_compact": {"nb_rows": remap[o[1]:o[2]].contiguous(), "slot_row": nbc["slot_row"]}}
-        loss = model.train_step_indexed(tab, b, profile=profile)
+        sync = (lambda t: torch.distributed.all_reduce(t)) if (args.sync_bn and world > 1) else None
+        loss = model.train_step_indexed(tab, b, profile=profile, sync_reduce=sync)
         pdist.all_reduce_mean_(gflat, world)
         opt.step()
         return loss
@@ -288,7 +292,8 @@ def main():
            "config": {"workload": f"Product2Vec GAT pretrain, {args.products} products, {args.types} types, dim=128, "
                                   f"batch={args.batch}/GPU, 5 negatives, neighbours padded to batch max "
                                   f"(avg N={n_avg:.1f})", "global_batch": world * args.batch,
-                      "table": args.table, "parallelism": f"dp{world}", "final_loss": round(float(loss), 5),
+                      "table": args.table, "parallelism": f"dp{world}",
+                      "batchnorm": "cross-replica" if (args.sync_bn and world > 1) else "per-replica", "final_loss": round(float(loss), 5),
                       "padding_slots": "carried once (compact rows): avg %.0f real + 1 shared of %d neighbour slots per step"
                                        % (real_sum / max(args.steps, 1), args.batch * round(n_avg))},
            "roofline": roof}

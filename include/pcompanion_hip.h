@@ -36,6 +36,8 @@ extern "C" {
 #define PC_HEADS 4       /* NUM_ATTENTION_HEADS (config.py:11) */
 #define PC_L 64          /* TYPE_EMB_DIM (config.py:9) */
 #define PC_MAX_SEG 4     /* BatchNorm call groups per launch (anchor, neighbours, positive, negative) */
+/* doubles in one cross-replica BatchNorm exchange buffer: [seg][2][H] sums then [seg] row counts */
+#define PC_BN_SYNC_DOUBLES (PC_MAX_SEG * 2 * 256 + PC_MAX_SEG)
 
 int pc_abi_version(void);
 
@@ -173,6 +175,28 @@ int pc_p2v_train_step_compact(const pc_p2v_tensors *p, const pc_p2v_tensors *g, 
                               const int32_t *slot_row, int batch, int n_nbr, int k_neg, float margin,
                               float *loss, float *d_pos, float *d_neg, float *anchor_emb, void *profile,
                               void *ws, size_t ws_bytes, void *stream);
+
+/* Cross-replica BatchNorm statistics for data-parallel replicas ("all_reduce(sum) of
+ * [2,256] sums + row count, once per BN call"): the same step, cut at the two points where BatchNorm needs
+ * batch-wide sums.  Every replica runs
+ *   phase 0   batch rows + Linear0 + per-segment sums          -> fwd_sums  (this replica)
+ *   [host: all-reduce(SUM) fwd_sums over the replicas, in place]
+ *   phase 1   statistics from fwd_sums (all replicas' rows), rest of the forward, loss, backward up to the
+ *             BatchNorm-backward sums                          -> bwd_local (this replica)
+ *   [host: bwd_global = all-reduce(SUM) of bwd_local, kept beside it]
+ *   phase 2   dgamma/dbeta from bwd_local, BN backward with the means of bwd_global, dW0/db0
+ * Buffers are PC_BN_SYNC_DOUBLES fp64 each ([seg][2][256] sums: forward sum x, sum x^2; backward sum dz,
+ * sum dz*h0; then [seg] row counts), device memory.  The workspace carries the step's state between the
+ * phases and must not be touched in between.  Gradients are those of THIS replica's mean loss under
+ * batch-wide statistics: averaging them over replicas gives the single-device gradient of the concatenated
+ * batch (tested).  Running statistics are updated from the batch-wide values. */
+int pc_p2v_train_step_compact_sync(const pc_p2v_tensors *p, const pc_p2v_tensors *g, const float *table,
+                                   const int32_t *anchor_idx, const int32_t *positive_idx,
+                                   const int32_t *negative_idx, const int32_t *nb_rows, int n_real,
+                                   const int32_t *slot_row, int batch, int n_nbr, int k_neg, float margin,
+                                   float *loss, float *d_pos, float *d_neg, float *anchor_emb, int phase,
+                                   double *fwd_sums, double *bwd_local, const double *bwd_global,
+                                   void *ws, size_t ws_bytes, void *stream);
 int pc_build_similarity_batch_compact(const int32_t *pair_ids, int batch, const int32_t *sim_pairs,
                                       const int32_t *cv_rowptr, const int32_t *cv_col,
                                       const int32_t *sim_rowptr, const int32_t *sim_col,

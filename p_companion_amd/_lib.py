@@ -74,6 +74,8 @@ SIGNATURES = {
                                _vp, _vp, _vp, _vp, _sz, _vp]),
     "pc_p2v_train_step_compact": (_i, [_P(P2VTensors), _P(P2VTensors), _vp, _vp, _vp, _vp, _vp, _i, _vp, _i, _i, _i, _f,
                                        _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "pc_p2v_train_step_compact_sync": (_i, [_P(P2VTensors), _P(P2VTensors), _vp, _vp, _vp, _vp, _vp, _i, _vp, _i, _i, _i,
+                                            _f, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _sz, _vp]),
     "pc_build_similarity_batch_compact": (_i, [_vp, _i, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _u64, _u64, _vp, _vp, _vp,
                                                _vp, _vp, _vp, _vp]),
     "pc_profile_create": (_i, [_i, _P(ctypes.c_void_p)]),

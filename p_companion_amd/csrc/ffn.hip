@@ -44,19 +44,42 @@ __device__ __forceinline__ void fold_partials(const float* p1, const float* p2, 
     __syncthreads();
 }
 
+// Cross-replica BatchNorm: the per-segment sums of THIS replica, in fp64, in the
+// exchange layout sums[PC_BN_SYNC_DOUBLES] = [seg][2][H] sums then [seg] row counts.  The host adds the
+// buffers of all replicas (one all-reduce) and hands the result to the finalize kernels below.
+__global__ __launch_bounds__(FIN_COLS * FIN_LANES) void bn_fold_kernel(const float* p1, const float* p2, SegInfo si,
+                                                                       double* sums) {
+    __shared__ double red[2][FIN_LANES][FIN_COLS];
+    const int j = blockIdx.x * FIN_COLS + threadIdx.x, q = threadIdx.y;
+    for (int s = 0; s < PC_MAX_SEG; s++) {
+        double a = 0.0, b = 0.0;
+        if (s < si.nseg) fold_partials(p1, p2, si.tile0[s], si.tile0[s + 1], j, q, red, &a, &b);
+        if (q == 0) {
+            sums[(2 * s) * PC_H + j] = a;
+            sums[(2 * s + 1) * PC_H + j] = b;
+            if (j == 0) sums[2 * PC_MAX_SEG * PC_H + s] = s < si.nseg ? (double)si.count[s] : 0.0;
+        }
+    }
+}
+
+// gsum: NULL = statistics of this replica (fold the per-tile partials here); else the all-reduced exchange buffer
 __global__ __launch_bounds__(FIN_COLS * FIN_LANES) void bn_finalize_fwd_kernel(
-    const float* psum, const float* psq, SegInfo si, const float* gamma, const float* beta, float* running_mean,
-    float* running_var, int64_t* nbt, int update_running, float* mean_o, float* invstd_o, float* scale_o,
-    float* shift_o) {
+    const float* psum, const float* psq, SegInfo si, const double* gsum, const float* gamma, const float* beta,
+    float* running_mean, float* running_var, int64_t* nbt, int update_running, float* mean_o, float* invstd_o,
+    float* scale_o, float* shift_o) {
     __shared__ double red[2][FIN_LANES][FIN_COLS];
     const int j = blockIdx.x * FIN_COLS + threadIdx.x, q = threadIdx.y;
     float rm = 0.f, rv = 0.f;
     if (q == 0 && update_running) { rm = running_mean[j]; rv = running_var[j]; }
     int nseen = 0;
     for (int s = 0; s < si.nseg; s++) {
-        const int n = si.count[s];                            // logical rows (a weighted row counts wmult times)
+        double n = si.count[s];                               // logical rows (a weighted row counts wmult times)
         double a = 0.0, b = 0.0;
-        fold_partials(psum, psq, si.tile0[s], si.tile0[s + 1], j, q, red, &a, &b);
+        if (gsum) {
+            a = gsum[(2 * s) * PC_H + j]; b = gsum[(2 * s + 1) * PC_H + j]; n = gsum[2 * PC_MAX_SEG * PC_H + s];
+        } else {
+            fold_partials(psum, psq, si.tile0[s], si.tile0[s + 1], j, q, red, &a, &b);
+        }
         if (q == 0 && n > 0) {
             const double m = a / n;
             double var = b / n - m * m;
@@ -69,7 +92,7 @@ __global__ __launch_bounds__(FIN_COLS * FIN_LANES) void bn_finalize_fwd_kernel(
             scale_o[s * PC_H + j] = sc;
             shift_o[s * PC_H + j] = beta[j] - mf * sc;
             if (update_running) {
-                const float unb = n > 1 ? (float)(var * ((double)n / (double)(n - 1))) : vf;
+                const float unb = n > 1 ? (float)(var * (n / (n - 1))) : vf;
                 rm = BN_MOMENTUM * mf + (1.0f - BN_MOMENTUM) * rm;
                 rv = BN_MOMENTUM * unb + (1.0f - BN_MOMENTUM) * rv;
             }
@@ -94,22 +117,30 @@ __global__ void bn_eval_coeff_kernel(const float* gamma, const float* beta, cons
 
 // per-tile (sum dz1, sum dz1*h0) -> dgamma, dbeta (+ per-segment means c1 = dbeta_s/n, c2 = dgamma_s/n)
 __global__ __launch_bounds__(FIN_COLS * FIN_LANES) void bn_finalize_bwd_kernel(
-    const float* psum, const float* pdot, SegInfo si, const float* mean, const float* invstd, float* dgamma,
-    float* dbeta, int accumulate, float* c1, float* c2) {
+    const float* psum, const float* pdot, SegInfo si, const double* lsum, const double* gsum, const float* mean,
+    const float* invstd, float* dgamma, float* dbeta, int accumulate, float* c1, float* c2) {
     __shared__ double red[2][FIN_LANES][FIN_COLS];
     const int j = blockIdx.x * FIN_COLS + threadIdx.x, q = threadIdx.y;
     double tg = 0.0, tb = 0.0;
     for (int s = 0; s < si.nseg; s++) {
-        const int n = si.count[s];                            // logical rows (a weighted row counts wmult times)
+        double n = si.count[s];                               // logical rows (a weighted row counts wmult times)
         double a = 0.0, b = 0.0;
-        fold_partials(psum, pdot, si.tile0[s], si.tile0[s + 1], j, q, red, &a, &b);
+        if (lsum) { a = lsum[(2 * s) * PC_H + j]; b = lsum[(2 * s + 1) * PC_H + j]; }
+        else fold_partials(psum, pdot, si.tile0[s], si.tile0[s + 1], j, q, red, &a, &b);
         if (q == 0) {
             // the tiles carry the raw moment sum dz1*h0: sum dz1*xhat = invstd * (sum dz1*h0 - mean * sum dz1)
-            b = (double)invstd[s * PC_H + j] * (b - (double)mean[s * PC_H + j] * a);
-            tb += a;
+            const double is = (double)invstd[s * PC_H + j], mu = (double)mean[s * PC_H + j];
+            b = is * (b - mu * a);
+            tb += a;                                          // dbeta / dgamma: this replica's rows
             tg += b;
-            c1[s * PC_H + j] = n > 0 ? (float)(a / n) : 0.f;
-            c2[s * PC_H + j] = n > 0 ? (float)(b / n) : 0.f;
+            double ga = a, gb = b;                            // the BN-backward means run over ALL replicas' rows
+            if (gsum) {
+                ga = gsum[(2 * s) * PC_H + j];
+                gb = is * (gsum[(2 * s + 1) * PC_H + j] - mu * ga);
+                n = gsum[2 * PC_MAX_SEG * PC_H + s];
+            }
+            c1[s * PC_H + j] = n > 0 ? (float)(ga / n) : 0.f;
+            c2[s * PC_H + j] = n > 0 ? (float)(gb / n) : 0.f;
         }
     }
     if (q == 0) {
@@ -251,25 +282,35 @@ static NtArgs nt_plain(const float* A, int lda, const float* W, int ldw, const f
     return a;
 }
 
-extern "C" int pc_p2v_ffn_forward_train(const pc_p2v_tensors* p, const float* table, const int32_t* idx, int rows,
-                                        const pc_segments* seg, int update_running, float* y,
-                                        const pc_ffn_saved* sv, void* ws, size_t ws_bytes, void* stream) {
+// part 1: gather + Linear0 + per-tile sums (+ this replica's folded sums into `local_sums` when exchanging);
+// part 2: statistics (from `global_sums` when given) -> BN-tanh -> Linear3 -> tanh -> Linear5
+int ffn_forward_part1(const pc_p2v_tensors* p, const float* table, const int32_t* idx, int rows, const pc_segments* seg,
+                      const pc_ffn_saved* sv, double* local_sums, void* ws, size_t ws_bytes, void* stream) {
     PC_TRY(ffn_check(p, table, rows, seg, ws, ws_bytes));
-    if (!y || !sv || !sv->h0 || !sv->a2 || !sv->bn_mean || !sv->bn_invstd || !sv->bn_scale || !sv->bn_shift)
-        return PC_EINVAL;
-    if (update_running && (!p->running_mean || !p->running_var)) return PC_EINVAL;
+    if (!sv || !sv->h0 || !sv->a2 || !sv->bn_mean || !sv->bn_invstd || !sv->bn_scale || !sv->bn_shift) return PC_EINVAL;
     hipStream_t st = (hipStream_t)stream;
     const SegInfo si = make_seginfo(seg, rows, 128);
     FfnWs w = ffn_ws_layout(ws, rows);
-
     NtArgs g1 = nt_plain(table, PC_D, p->w0, PC_D, p->b0, sv->h0, PC_H, rows, PC_H, PC_D, si);
     g1.gather = idx;
     g1.stats = NT_STAT_SUMSQ; g1.stat_sum = w.stat_a; g1.stat_aux = w.stat_b;
     PC_TRY(launch_gemm_nt(g1, st));
+    if (local_sums) {
+        PC_LAUNCH(bn_fold_kernel, dim3(PC_H / FIN_COLS), dim3(FIN_COLS, FIN_LANES), 0, st, w.stat_a, w.stat_b, si, local_sums);
+        PC_TRY(pc_launch_status());
+    }
+    return PC_OK;
+}
 
-    PC_LAUNCH(bn_finalize_fwd_kernel, dim3(PC_H / FIN_COLS), dim3(FIN_COLS, FIN_LANES), 0, st, w.stat_a, w.stat_b, si, p->gamma,
-                       p->beta, p->running_mean, p->running_var, p->num_batches_tracked, update_running,
-                       sv->bn_mean, sv->bn_invstd, sv->bn_scale, sv->bn_shift);
+int ffn_forward_part2(const pc_p2v_tensors* p, int rows, const pc_segments* seg, int update_running, float* y,
+                      const pc_ffn_saved* sv, const double* global_sums, void* ws, size_t ws_bytes, void* stream) {
+    if (!y || (update_running && (!p->running_mean || !p->running_var))) return PC_EINVAL;
+    hipStream_t st = (hipStream_t)stream;
+    const SegInfo si = make_seginfo(seg, rows, 128);
+    FfnWs w = ffn_ws_layout(ws, rows);
+    PC_LAUNCH(bn_finalize_fwd_kernel, dim3(PC_H / FIN_COLS), dim3(FIN_COLS, FIN_LANES), 0, st, w.stat_a, w.stat_b, si, global_sums,
+              p->gamma, p->beta, p->running_mean, p->running_var, p->num_batches_tracked, update_running,
+              sv->bn_mean, sv->bn_invstd, sv->bn_scale, sv->bn_shift);
     PC_TRY(pc_launch_status());
 
     NtArgs g2 = nt_plain(sv->h0, PC_H, p->w3, PC_H, p->b3, sv->a2, PC_H, rows, PC_H, PC_H, si);
@@ -279,6 +320,14 @@ extern "C" int pc_p2v_ffn_forward_train(const pc_p2v_tensors* p, const float* ta
 
     NtArgs g3 = nt_plain(sv->a2, PC_H, p->w5, PC_H, p->b5, y, PC_D, rows, PC_D, PC_H, si);
     return launch_gemm_nt(g3, st);
+}
+
+extern "C" int pc_p2v_ffn_forward_train(const pc_p2v_tensors* p, const float* table, const int32_t* idx, int rows,
+                                        const pc_segments* seg, int update_running, float* y,
+                                        const pc_ffn_saved* sv, void* ws, size_t ws_bytes, void* stream) {
+    if (!y) return PC_EINVAL;
+    PC_TRY(ffn_forward_part1(p, table, idx, rows, seg, sv, nullptr, ws, ws_bytes, stream));
+    return ffn_forward_part2(p, rows, seg, update_running, y, sv, nullptr, ws, ws_bytes, stream);
 }
 
 extern "C" int pc_p2v_ffn_forward_eval(const pc_p2v_tensors* p, const float* table, const int32_t* idx, int rows,
@@ -304,10 +353,11 @@ extern "C" int pc_p2v_ffn_forward_eval(const pc_p2v_tensors* p, const float* tab
     return launch_gemm_nt(g3, st);
 }
 
-static int ffn_backward_impl(const pc_p2v_tensors* p, const pc_p2v_tensors* g, const float* table,
-                             const int32_t* idx, int rows, const pc_segments* seg, const float* dy,
-                             const pc_ffn_saved* sv, float* dx, int accumulate, void* ws, size_t ws_bytes,
-                             void* stream) {
+// part 1: everything up to the BN-backward partial sums (+ this replica's folded sums into `local_sums`);
+// part 2: dgamma/dbeta (local rows), BN-backward coefficients (from `global_sums` when given), dW0/db0 (/dx)
+int ffn_backward_part1(const pc_p2v_tensors* p, const pc_p2v_tensors* g, const float* table, const int32_t* idx,
+                       int rows, const pc_segments* seg, const float* dy, const pc_ffn_saved* sv, int with_dx,
+                       int accumulate, double* local_sums, void* ws, size_t ws_bytes, void* stream) {
     PC_TRY(ffn_check(p, table, rows, seg, ws, ws_bytes));
     if (!g || !dy || !sv || !sv->h0 || !sv->a2) return PC_EINVAL;
     if (!g->w0 || !g->b0 || !g->gamma || !g->beta || !g->w3 || !g->b3 || !g->w5 || !g->b5) return PC_EINVAL;
@@ -319,7 +369,7 @@ static int ffn_backward_impl(const pc_p2v_tensors* p, const pc_p2v_tensors* g, c
     tb.job[0] = {p->w5, w.w5t, PC_D, PC_H};                   // [D,H] -> [H,D]
     tb.job[1] = {p->w3, w.w3t, PC_H, PC_H};
     tb.n = 2;
-    if (dx) tb.job[tb.n++] = {p->w0, w.w0t, PC_H, PC_D};      // [H,D] -> [D,H]
+    if (with_dx) tb.job[tb.n++] = {p->w0, w.w0t, PC_H, PC_D};      // [H,D] -> [D,H]
     PC_TRY(launch_transpose_batch(tb, st));
 
     // dZ2 = (dY W5) * (1 - A2^2)
@@ -347,9 +397,21 @@ static int ffn_backward_impl(const pc_p2v_tensors* p, const pc_p2v_tensors* g, c
     t3.dW = g->w3; t3.lddw = PC_H; t3.db = g->b3; t3.accumulate = accumulate; t3.slabs = w.slabs;
     t3.slab_floats = w.slab_floats;
     PC_TRY(launch_gemm_tn(t3, st));
+    if (local_sums) {
+        PC_LAUNCH(bn_fold_kernel, dim3(PC_H / FIN_COLS), dim3(FIN_COLS, FIN_LANES), 0, st, w.stat_a, w.stat_b, si, local_sums);
+        PC_TRY(pc_launch_status());
+    }
+    return PC_OK;
+}
 
-    PC_LAUNCH(bn_finalize_bwd_kernel, dim3(PC_H / FIN_COLS), dim3(FIN_COLS, FIN_LANES), 0, st, w.stat_a, w.stat_b, si, sv->bn_mean,
-              sv->bn_invstd, g->gamma, g->beta, accumulate, w.c1, w.c2);
+int ffn_backward_part2(const pc_p2v_tensors* g, const float* table, const int32_t* idx, int rows,
+                       const pc_segments* seg, const pc_ffn_saved* sv, float* dx, int accumulate,
+                       const double* local_sums, const double* global_sums, void* ws, size_t ws_bytes, void* stream) {
+    hipStream_t st = (hipStream_t)stream;
+    const SegInfo si = make_seginfo(seg, rows, 128);
+    FfnWs w = ffn_ws_layout(ws, rows);
+    PC_LAUNCH(bn_finalize_bwd_kernel, dim3(PC_H / FIN_COLS), dim3(FIN_COLS, FIN_LANES), 0, st, w.stat_a, w.stat_b, si, local_sums,
+              global_sums, sv->bn_mean, sv->bn_invstd, g->gamma, g->beta, accumulate, w.c1, w.c2);
     PC_TRY(pc_launch_status());
 
     // dW0 = dH0^T X (rows gathered again from the table), db0.  Without a dx consumer the BatchNorm
@@ -382,5 +444,6 @@ extern "C" int pc_p2v_ffn_backward(const pc_p2v_tensors* p, const pc_p2v_tensors
                                    const int32_t* idx, int rows, const pc_segments* seg, const float* dy,
                                    const pc_ffn_saved* sv, float* dx, int accumulate, void* ws, size_t ws_bytes,
                                    void* stream) {
-    return ffn_backward_impl(p, g, table, idx, rows, seg, dy, sv, dx, accumulate, ws, ws_bytes, stream);
+    PC_TRY(ffn_backward_part1(p, g, table, idx, rows, seg, dy, sv, dx != nullptr, accumulate, nullptr, ws, ws_bytes, stream));
+    return ffn_backward_part2(g, table, idx, rows, seg, sv, dx, accumulate, nullptr, nullptr, ws, ws_bytes, stream);
 }

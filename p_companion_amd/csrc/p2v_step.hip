@@ -62,10 +62,16 @@ __global__ void concat_idx_kernel(const int32_t* a, int na, const int32_t* b, in
     else if (i < na + nb + nc + nd) out[i] = d[i - na - nb - nc];
 }
 
-extern "C" int pc_p2v_ffn_backward(const pc_p2v_tensors* p, const pc_p2v_tensors* g, const float* table,
-                                   const int32_t* idx, int rows, const pc_segments* seg, const float* dy,
-                                   const pc_ffn_saved* sv, float* dx, int accumulate, void* ws, size_t ws_bytes,
-                                   void* stream);
+int ffn_forward_part1(const pc_p2v_tensors* p, const float* table, const int32_t* idx, int rows, const pc_segments* seg,
+                      const pc_ffn_saved* sv, double* local_sums, void* ws, size_t ws_bytes, void* stream);
+int ffn_forward_part2(const pc_p2v_tensors* p, int rows, const pc_segments* seg, int update_running, float* y,
+                      const pc_ffn_saved* sv, const double* global_sums, void* ws, size_t ws_bytes, void* stream);
+int ffn_backward_part1(const pc_p2v_tensors* p, const pc_p2v_tensors* g, const float* table, const int32_t* idx,
+                       int rows, const pc_segments* seg, const float* dy, const pc_ffn_saved* sv, int with_dx,
+                       int accumulate, double* local_sums, void* ws, size_t ws_bytes, void* stream);
+int ffn_backward_part2(const pc_p2v_tensors* g, const float* table, const int32_t* idx, int rows,
+                       const pc_segments* seg, const pc_ffn_saved* sv, float* dx, int accumulate,
+                       const double* local_sums, const double* global_sums, void* ws, size_t ws_bytes, void* stream);
 int attention_forward_impl(const pc_p2v_tensors* p, const float* query, const float* keys, int B, int N,
                            int key_rows, const int32_t* slot_row, float* out, const pc_attn_saved* sv, void* ws,
                            size_t ws_bytes, void* stream);
@@ -81,7 +87,10 @@ static int p2v_step_impl(const pc_p2v_tensors* p, const pc_p2v_tensors* g, const
                          const int32_t* anchor_idx, const int32_t* positive_idx, const int32_t* negative_idx,
                          const int32_t* nb_idx, int nbc, const int32_t* slot_row, int B, int N, int K, float margin,
                          float* loss, float* d_pos, float* d_neg, float* anchor_emb, void* profile, void* ws,
-                         size_t ws_bytes, void* stream) {
+                         size_t ws_bytes, void* stream, int phase = -1, double* fwd_sums = nullptr,
+                         double* bwd_local = nullptr, const double* bwd_global = nullptr) {
+    // phase -1: the whole step with this replica's BatchNorm statistics; 0/1/2: see pc_p2v_train_step_compact_sync
+    const bool p0 = phase <= 0, p1 = phase == -1 || phase == 1, p2 = phase == -1 || phase == 2;
     ProfileScope prof_scope((pc_profile*)profile);
     if (!p || !g || !table || !anchor_idx || !positive_idx || !negative_idx || !loss || !ws) return PC_EINVAL;
     if (B <= 0 || N < 0 || K <= 0 || (N > 0 && !nb_idx) || nbc < 0 || nbc > B * N + 1) return PC_EINVAL;
@@ -103,15 +112,22 @@ static int p2v_step_impl(const pc_p2v_tensors* p, const pc_p2v_tensors* g, const
         seg.nseg = 3; seg.start[0] = rA; seg.start[1] = rP; seg.start[2] = rG; seg.start[3] = R; seg.start[4] = R;
     }
 
-    PC_LAUNCH(concat_idx_kernel, dim3((R + 255) / 256), dim3(256), 0, st, anchor_idx, B, nb_idx, nbc, positive_idx, B,
-              negative_idx, B * K, w.idx_all);
-    PC_TRY(pc_launch_status());
-
     pc_ffn_saved sv;
     sv.h0 = w.h0; sv.a2 = w.a2;
     sv.bn_mean = w.bn; sv.bn_invstd = w.bn + PC_MAX_SEG * PC_H; sv.bn_scale = w.bn + 2 * PC_MAX_SEG * PC_H;
     sv.bn_shift = w.bn + 3 * PC_MAX_SEG * PC_H;
-    PC_TRY(pc_p2v_ffn_forward_train(p, table, w.idx_all, R, &seg, 1, w.y, &sv, w.ffn_ws, w.ffn_bytes, stream));
+    if (p0) {
+        PC_LAUNCH(concat_idx_kernel, dim3((R + 255) / 256), dim3(256), 0, st, anchor_idx, B, nb_idx, nbc, positive_idx, B,
+                  negative_idx, B * K, w.idx_all);
+        PC_TRY(pc_launch_status());
+        PC_TRY(ffn_forward_part1(p, table, w.idx_all, R, &seg, &sv, phase == 0 ? fwd_sums : nullptr, w.ffn_ws, w.ffn_bytes,
+                                 stream));
+        if (phase == 0) return PC_OK;
+    }
+    if (p2 && !p1)
+        return ffn_backward_part2(g, table, w.idx_all, R, &seg, &sv, nullptr, 0, bwd_local, bwd_global, w.ffn_ws,
+                                  w.ffn_bytes, stream);
+    PC_TRY(ffn_forward_part2(p, R, &seg, 1, w.y, &sv, phase == 1 ? fwd_sums : nullptr, w.ffn_ws, w.ffn_bytes, stream));
 
     pc_attn_saved as;
     as.q = w.q; as.kv = w.kv; as.probs = w.probs; as.ctx = w.ctx;
@@ -140,7 +156,10 @@ static int p2v_step_impl(const pc_p2v_tensors* p, const pc_p2v_tensors* g, const
         PC_HIP_TRY(hipMemsetAsync(g->out_proj_w, 0, PC_D * PC_D * 4, st));
         PC_HIP_TRY(hipMemsetAsync(g->out_proj_b, 0, PC_D * 4, st));
     }
-    return pc_p2v_ffn_backward(p, g, table, w.idx_all, R, &seg, w.dy, &sv, nullptr, 0, w.ffn_ws, w.ffn_bytes, stream);
+    PC_TRY(ffn_backward_part1(p, g, table, w.idx_all, R, &seg, w.dy, &sv, 0, 0, phase == 1 ? bwd_local : nullptr, w.ffn_ws,
+                              w.ffn_bytes, stream));
+    if (phase == 1) return PC_OK;
+    return ffn_backward_part2(g, table, w.idx_all, R, &seg, &sv, nullptr, 0, nullptr, nullptr, w.ffn_ws, w.ffn_bytes, stream);
 }
 
 extern "C" int pc_p2v_train_step(const pc_p2v_tensors* p, const pc_p2v_tensors* g, const float* table,
@@ -161,4 +180,19 @@ extern "C" int pc_p2v_train_step_compact(const pc_p2v_tensors* p, const pc_p2v_t
     if (!slot_row || !nb_rows || N <= 0 || n_real < 0 || n_real > B * N) return PC_EINVAL;
     return p2v_step_impl(p, g, table, anchor_idx, positive_idx, negative_idx, nb_rows, n_real + 1, slot_row, B, N, K,
                          margin, loss, d_pos, d_neg, anchor_emb, profile, ws, ws_bytes, stream);
+}
+
+extern "C" int pc_p2v_train_step_compact_sync(const pc_p2v_tensors* p, const pc_p2v_tensors* g, const float* table,
+                                              const int32_t* anchor_idx, const int32_t* positive_idx,
+                                              const int32_t* negative_idx, const int32_t* nb_rows, int n_real,
+                                              const int32_t* slot_row, int B, int N, int K, float margin, float* loss,
+                                              float* d_pos, float* d_neg, float* anchor_emb, int phase,
+                                              double* fwd_sums, double* bwd_local, const double* bwd_global, void* ws,
+                                              size_t ws_bytes, void* stream) {
+    if (!slot_row || !nb_rows || N <= 0 || n_real < 0 || n_real > B * N) return PC_EINVAL;
+    if (phase < 0 || phase > 2 || !fwd_sums || !bwd_local || (phase == 2 && !bwd_global)) return PC_EINVAL;
+    if ((((uintptr_t)fwd_sums | (uintptr_t)bwd_local | (uintptr_t)bwd_global) & 7)) return PC_ESHAPE;
+    return p2v_step_impl(p, g, table, anchor_idx, positive_idx, negative_idx, nb_rows, n_real + 1, slot_row, B, N, K,
+                         margin, loss, d_pos, d_neg, anchor_emb, nullptr, ws, ws_bytes, stream, phase, fwd_sums,
+                         bwd_local, bwd_global);
 }

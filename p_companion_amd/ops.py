@@ -262,9 +262,17 @@ class KernelProfile:
             self.handle = ctypes.c_void_p()
 
 
+BN_SYNC_DOUBLES = PC_MAX_SEG * 2 * H + PC_MAX_SEG
+
+
 def p2v_train_step(params, grads, table, anchor_idx, positive_idx, negative_idx, neighbor_idx, margin,
-                   want_emb=False, profile=None):
-    """One loop-body iteration of Product2Vec.train_model in index form (grads overwritten)."""
+                   want_emb=False, profile=None, sync_reduce=None):
+    """One loop-body iteration of Product2Vec.train_model in index form (grads overwritten).
+
+    sync_reduce: None = BatchNorm statistics of this batch; else a callable `reduce(buf)` that sums a
+    [BN_SYNC_DOUBLES] float64 device tensor over the data-parallel replicas in place (e.g.
+    `lambda t: dist.all_reduce(t)`): the step then runs as pc_p2v_train_step_compact_sync's three phases
+    with batch-wide (cross-replica) BatchNorm statistics.  Compact neighbour layout only."""
     st, dev = p2v_struct(params)
     gst, _ = p2v_struct(grads, with_buffers=False)
     b = anchor_idx.numel()
@@ -288,6 +296,26 @@ def p2v_train_step(params, grads, table, anchor_idx, positive_idx, negative_idx,
         out["anchor_emb"] = torch.empty(b, D, dtype=torch.float32, device=dev)
     nbytes = _lib.lib().pc_p2v_train_step_workspace_bytes(b, n, k)
     ws = workspace(nbytes, dev, "step")
+    if sync_reduce is not None:
+        if not compact:
+            raise ValueError("cross-replica BatchNorm needs the compact neighbour layout")
+        fwd = torch.zeros(BN_SYNC_DOUBLES, dtype=torch.float64, device=dev)
+        bwd_local = torch.zeros(BN_SYNC_DOUBLES, dtype=torch.float64, device=dev)
+        bwd_global = None
+
+        def phase(ph):
+            check(_lib.lib().pc_p2v_train_step_compact_sync(
+                ctypes.byref(st), ctypes.byref(gst), _p(table), _p(anchor_idx), _p(positive_idx), _p(negative_idx),
+                _p(nb_rows), n_real, _p(slot_row), b, n, k, float(margin), _p(out["loss"]), _p(out["d_pos"]),
+                _p(out["d_neg"]), _p(out.get("anchor_emb")), ph, _p(fwd), _p(bwd_local), _p(bwd_global), _p(ws), nbytes,
+                _stream()), "pc_p2v_train_step_compact_sync")
+        phase(0)
+        sync_reduce(fwd)
+        phase(1)
+        bwd_global = bwd_local.clone()
+        sync_reduce(bwd_global)
+        phase(2)
+        return out
     if compact:
         check(_lib.lib().pc_p2v_train_step_compact(
             ctypes.byref(st), ctypes.byref(gst), _p(table), _p(anchor_idx), _p(positive_idx), _p(negative_idx),

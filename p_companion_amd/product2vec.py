@@ -319,16 +319,18 @@ class Product2Vec(nn.Module, _FlatParamsMixin):
         return next(self.parameters()).device
 
     # ------------------------------------------------------------------ P9 loop
-    def train_step_indexed(self, table, batch, profile=None):
+    def train_step_indexed(self, table, batch, profile=None, sync_reduce=None):
         """One loop-body iteration (product2vec.py:130-158 minus optimizer.step) on an index
-        batch.  Gradients land in .grad (flat-buffer views); returns the device loss tensor."""
+        batch.  Gradients land in .grad (flat-buffer views); returns the device loss tensor.
+        sync_reduce: see ops.p2v_train_step (cross-replica BatchNorm statistics for data-parallel runs)."""
         self._check_dropout()
         self.flatten_parameters()
         params = self._tensor_dict()
         grads = {k: p.grad for k, p in self.named_parameters()}
         nbr = batch.get("neighbor_compact", batch.get("neighbor_idx"))      # compact rows when the loader built them
         out = ops.p2v_train_step(params, grads, table, batch["anchor_idx"], batch["positive_idx"],
-                                 batch["negative_idx"], nbr, float(self.config.MARGIN), profile=profile)
+                                 batch["negative_idx"], nbr, float(self.config.MARGIN), profile=profile,
+                                 sync_reduce=sync_reduce)
         return out["loss"]
 
     def train_model(self, train_loader, optimizer, num_epochs=10) -> Dict[str, torch.Tensor]:

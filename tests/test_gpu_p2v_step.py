@@ -180,3 +180,96 @@ def test_compact_builder_matches_dense_builder(golden):
     # slot map reconstructs the dense matrix
     rows = comp["nb_rows"].cpu().numpy()
     assert np.array_equal(rows[comp["slot_row"].cpu().numpy()], nb.cpu().numpy())
+
+
+def test_cross_replica_batchnorm_equals_concatenated_batch():
+    """pc_p2v_train_step_compact_sync: two data-parallel replicas whose BatchNorm sums are added
+    between the phases reproduce the single-device step on the concatenated batch -- loss (mean of the two),
+    gradients (mean of the two) and running statistics.  The two replicas are run here one after the other
+    in one process; `reduce` plays the all-reduce by adding the other replica's buffer."""
+    from p_companion_amd import ops
+    from p_companion_amd.data import generate_scaled_bpg, SimilarityIndexLoader
+    torch.manual_seed(0)
+    bpg = generate_scaled_bpg(4000, 20, seed=3)
+    table = bpg.cuda()["features"]
+    B = 256
+    loader = SimilarityIndexLoader(bpg, 2 * B, seed=5, drop_last=True, compact=False, prefetch=False)
+    big = next(iter(loader))                                   # dense [2B, N] neighbour indices
+    nb = big["neighbor_idx"]
+    halves = []
+    for h in range(2):
+        sl = slice(h * B, (h + 1) * B)
+        halves.append({"anchor_idx": big["anchor_idx"][sl].contiguous(), "positive_idx": big["positive_idx"][sl].contiguous(),
+                       "negative_idx": big["negative_idx"][sl].contiguous(),
+                       "neighbor_compact": ops.compact_neighbors(nb[sl].contiguous())})   # same n_pad on both replicas
+    whole = dict(big, neighbor_compact=ops.compact_neighbors(nb))
+
+    def fresh():
+        sizes = [int(np.prod(s)) for s in ops.P2V_SHAPES]
+        offs = np.concatenate([[0], np.cumsum(sizes)])
+        g = torch.Generator(device="cpu").manual_seed(11)
+        flat = (torch.randn(int(offs[-1]), generator=g) * 0.05).cuda()
+        gflat = torch.zeros_like(flat)
+        params = {k: flat[offs[i]:offs[i + 1]].view(s) for i, (k, s) in enumerate(zip(ops.P2V_KEYS, ops.P2V_SHAPES))}
+        grads = {k: gflat[offs[i]:offs[i + 1]].view(s) for i, (k, s) in enumerate(zip(ops.P2V_KEYS, ops.P2V_SHAPES))}
+        params["ffn.1.weight"].fill_(1.0)
+        params["ffn.1.running_mean"] = torch.zeros(256, device="cuda")
+        params["ffn.1.running_var"] = torch.ones(256, device="cuda")
+        params["ffn.1.num_batches_tracked"] = torch.zeros((), dtype=torch.int64, device="cuda")
+        return params, grads, gflat
+
+    # reference: one device, the concatenated batch
+    p0, g0, gf0 = fresh()
+    out0 = ops.p2v_train_step(p0, g0, table, whole["anchor_idx"], whole["positive_idx"], whole["negative_idx"],
+                              whole["neighbor_compact"], 1.0)
+
+    # two replicas, phases interleaved by hand so that each "all-reduce" sees both contributions
+    import ctypes
+    from p_companion_amd import _lib
+    reps = [fresh() for _ in range(2)]
+    outs, bufs = [], []
+    for r in range(2):
+        bufs.append({k: torch.zeros(ops.BN_SYNC_DOUBLES, dtype=torch.float64, device="cuda") for k in ("fwd", "bl", "bg")})
+    state = []
+    for r, (params, grads, _) in enumerate(reps):
+        st, dev = ops.p2v_struct(params)
+        gst, _ = ops.p2v_struct(grads, with_buffers=False)
+        hb = halves[r]
+        nbc = hb["neighbor_compact"]
+        out = {"loss": torch.empty(1, device="cuda"), "d_pos": torch.empty(B, device="cuda"), "d_neg": torch.empty(B, device="cuda")}
+        n = nbc["slot_row"].shape[1]
+        nbytes = _lib.lib().pc_p2v_train_step_workspace_bytes(B, n, 5)
+        ws = torch.empty(nbytes, dtype=torch.uint8, device="cuda")          # one workspace per replica: it carries the state
+        state.append((st, gst, hb, nbc, out, n, nbytes, ws))
+        outs.append(out)
+
+    def phase(r, ph):
+        st, gst, hb, nbc, out, n, nbytes, ws = state[r]
+        ops.check(_lib.lib().pc_p2v_train_step_compact_sync(
+            ctypes.byref(st), ctypes.byref(gst), ops._p(table), ops._p(hb["anchor_idx"]), ops._p(hb["positive_idx"]),
+            ops._p(hb["negative_idx"]), ops._p(nbc["nb_rows"]), nbc["nb_rows"].numel() - 1, ops._p(nbc["slot_row"]), B, n, 5,
+            1.0, ops._p(out["loss"]), ops._p(out["d_pos"]), ops._p(out["d_neg"]), None, ph, ops._p(bufs[r]["fwd"]),
+            ops._p(bufs[r]["bl"]), ops._p(bufs[r]["bg"]), ops._p(ws), nbytes, ops._stream()), "sync step")
+
+    for r in range(2): phase(r, 0)
+    tot = bufs[0]["fwd"] + bufs[1]["fwd"]
+    for r in range(2): bufs[r]["fwd"].copy_(tot)
+    for r in range(2): phase(r, 1)
+    tot = bufs[0]["bl"] + bufs[1]["bl"]
+    for r in range(2): bufs[r]["bg"].copy_(tot)
+    for r in range(2): phase(r, 2)
+    torch.cuda.synchronize()
+
+    loss_dp = 0.5 * (float(outs[0]["loss"]) + float(outs[1]["loss"]))
+    assert abs(loss_dp - float(out0["loss"])) < 2e-6, (loss_dp, float(out0["loss"]))
+    g_dp = 0.5 * (reps[0][2] + reps[1][2])
+    tol = 2e-6 + 2e-4 * float(gf0.abs().max())
+    assert float((g_dp - gf0).abs().max()) < tol, float((g_dp - gf0).abs().max())
+    for r in range(2):                                         # batch-wide running statistics on every replica
+        assert torch.allclose(reps[r][0]["ffn.1.running_mean"], p0["ffn.1.running_mean"], atol=1e-6)
+        assert torch.allclose(reps[r][0]["ffn.1.running_var"], p0["ffn.1.running_var"], atol=1e-6)
+    # and per-replica statistics are NOT the same thing (the test would be vacuous otherwise)
+    p1, g1, gf1 = fresh()
+    o1 = ops.p2v_train_step(p1, g1, table, halves[0]["anchor_idx"], halves[0]["positive_idx"], halves[0]["negative_idx"],
+                            halves[0]["neighbor_compact"], 1.0)
+    assert float((gf1 - reps[0][2]).abs().max()) > 10 * tol
