@@ -172,14 +172,15 @@ __device__ __forceinline__ void tn_lds_sync() {
     asm volatile("" ::: "memory");
 }
 
-template <int WO, int WI, int TO, int TI, int TKC, bool APRO, bool ZPRO>
+template <int WO, int WI, int TO, int TI, int TKC, int NST, bool APRO, bool ZPRO>
 __global__ __launch_bounds__(512, 2) void gemm_tn8_kernel(TnArgs a, int nsplit, int rows_per_split) {
     constexpr int NO = WO * TO * 32, NI = WI * TI * 32;
     constexpr int ZF = TKC * NO, AF = TKC * NI;                  // floats per stage image
     constexpr int STAGE = ZF * (ZPRO ? 2 : 1) + AF;              // Z [, H], A
     constexpr int JZ = ZF / 256 / 8, JA = AF / 256 / 8;          // DMA instructions per wave and image
     static_assert(ZF % 2048 == 0 && AF % 2048 == 0, "images must split into whole wave instructions over 8 waves");
-    __shared__ __attribute__((aligned(1024))) float smem[2 * STAGE];
+    constexpr int JALL = JZ * (ZPRO ? 2 : 1) + JA;              // DMA instructions per wave and stage
+    __shared__ __attribute__((aligned(1024))) float smem[NST * STAGE];
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6), wo = w % WO, wi = w / WO;
@@ -288,21 +289,27 @@ __global__ __launch_bounds__(512, 2) void gemm_tn8_kernel(TnArgs a, int nsplit, 
             for (int r = 0; r < 16; r++) acc[i][j][r] = 0.f;
     }
 
+    // ring of NST stages: chunk c lives in slot c % NST and NST-1 chunks are in flight ahead of the one being
+    // multiplied.  In-order vmcnt: "chunk c has landed" == at most the (NST-2) * JALL younger DMA instructions
+    // are outstanding; near the end fewer are in flight and the wait is for everything.  (Measured: 4-6 stages of
+    // 16 rows are no faster than 2 of 32 -- these kernels are not waiting for HBM; a row sweep shows a fixed
+    // 28 / 62 us per launch for a 128x256 / 256x256 gradient, i.e. slab write + reduce + ramp, and 107-113
+    // TFLOP/s in the limit of many rows, scripts/tn_rsweep.py.)
     const int nchunk = (r_end - r_begin + TKC - 1) / TKC;
-    if (nchunk > 0) {
-        load_gather(r_begin);
-        issue(0, r_begin);
-        if (nchunk > 1) load_gather(r_begin + TKC);
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < NST - 1; i++)
+        if (i < nchunk) { load_gather(r_begin + i * TKC); issue(i, r_begin + i * TKC); }
+    if (NST - 1 < nchunk) load_gather(r_begin + (NST - 1) * TKC);
     const int fz = (lane >> 5) * NO + wo * (TO * 32) + (lane & 31);
     const int fa = (lane >> 5) * NI + wi * (TI * 32) + (lane & 31);
+    int cur = 0;
     for (int c = 0; c < nchunk; c++) {
-        const int cur = c & 1;
-        if (c + 1 < nchunk) {
-            issue(cur ^ 1, r_begin + (c + 1) * TKC);
-            if (c + 2 < nchunk) load_gather(r_begin + (c + 2) * TKC);       // indices a whole chunk ahead of their use
+        if (c + NST - 1 <= nchunk) { asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NST - 2) * JALL) : "memory"); }
+        else { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+        __syncthreads();                                   // chunk c visible to all; slot of chunk c-1 free again
+        if (c + NST - 1 < nchunk) {
+            issue(cur == 0 ? NST - 1 : cur - 1, r_begin + (c + NST - 1) * TKC);
+            if (c + NST < nchunk) load_gather(r_begin + (c + NST) * TKC);   // indices a whole chunk ahead of their use
         }
         float* stage = smem + cur * STAGE;
         if (APRO || ZPRO) { transform(stage, r_begin + c * TKC); tn_lds_sync(); }
@@ -333,8 +340,7 @@ __global__ __launch_bounds__(512, 2) void gemm_tn8_kernel(TnArgs a, int nsplit, 
             if (k + 2 < TKC) __builtin_amdgcn_sched_group_barrier(0x100, TO + TI, 0);
             __builtin_amdgcn_sched_group_barrier(0x008, TO * TI, 0);
         }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
+        cur = cur + 1 == NST ? 0 : cur + 1;
     }
 
     float* slab = a.slabs + (size_t)split * ((size_t)a.No * a.Ni + a.No);
@@ -434,9 +440,9 @@ int launch_gemm_tn(const TnArgs& a, hipStream_t st) {
     if (tn_full_tile(a.R, a.No, a.Ni) && !(apro && zpro)) {
 #define TN8(WO, WI, TO, TI)                                                                                   \
     do {                                                                                                      \
-        if (apro) PC_LAUNCH((gemm_tn8_kernel<WO, WI, TO, TI, 32, true, false>), dim3(nsplit), dim3(512), 0, st, a, nsplit, rps);       \
-        else if (zpro) PC_LAUNCH((gemm_tn8_kernel<WO, WI, TO, TI, 16, false, true>), dim3(nsplit), dim3(512), 0, st, a, nsplit, rps);  \
-        else PC_LAUNCH((gemm_tn8_kernel<WO, WI, TO, TI, 32, false, false>), dim3(nsplit), dim3(512), 0, st, a, nsplit, rps);           \
+        if (apro) PC_LAUNCH((gemm_tn8_kernel<WO, WI, TO, TI, 32, 2, true, false>), dim3(nsplit), dim3(512), 0, st, a, nsplit, rps);       \
+        else if (zpro) PC_LAUNCH((gemm_tn8_kernel<WO, WI, TO, TI, 16, 3, false, true>), dim3(nsplit), dim3(512), 0, st, a, nsplit, rps);  \
+        else PC_LAUNCH((gemm_tn8_kernel<WO, WI, TO, TI, 32, 2, false, false>), dim3(nsplit), dim3(512), 0, st, a, nsplit, rps);           \
     } while (0)
         if (a.No > 128 && a.Ni > 128) TN8(2, 4, 4, 2);
         else if (a.No > 128) TN8(4, 2, 2, 2);
