@@ -174,6 +174,9 @@ def main():
     ap.add_argument("--sync-bn", action="store_true",
                     help="N > 1: BatchNorm statistics over all replicas' rows (two 16 KB all-reduces per step) instead of "
                          "each replica's own batch")
+    ap.add_argument("--profile-all", action="store_true",
+                    help="HIP-event brackets around every GEMM launch (TN and few-row kernels too), not only the dominant "
+                         "gemm_nt_kernel family: ~60 us/step of event packets")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     args = ap.parse_args()
@@ -217,6 +220,8 @@ def main():
 
     it = batches()
     prof = ops.KernelProfile(capacity=32 * max(args.steps, 1))
+    if not args.profile_all:
+        prof.set_kinds(["gemm_nt_kernel"])
     n_sum = 0
     real_sum = 0
 
@@ -276,10 +281,12 @@ def main():
             "launches": nt["launches"], "avg_launch_us": round(1e3 * nt["total_ms"] / max(nt["launches"], 1), 2),
             "flops_per_launch": nt["total_flops"] / max(nt["launches"], 1),
             "share_of_step": round(nt["total_ms"] / (el * 1e3), 3),
-            "gemm_tn_kernel": {"achieved": round(tn["total_flops"] / max(tn["total_ms"], 1e-9) / 1e9, 2),
-                               "launches": tn["launches"], "share_of_step": round(tn["total_ms"] / (el * 1e3), 3)},
-            "gemm_nt_small_kernel": {"launches": sm["launches"], "avg_launch_us": round(1e3 * sm["total_ms"] / max(sm["launches"], 1), 2),
-                                     "share_of_step": round(sm["total_ms"] / (el * 1e3), 3)},
+            "gemm_tn_kernel": ({"achieved": round(tn["total_flops"] / max(tn["total_ms"], 1e-9) / 1e9, 2),
+                                "launches": tn["launches"], "share_of_step": round(tn["total_ms"] / (el * 1e3), 3)}
+                               if tn["launches"] else None),                     # bracketed with --profile-all only
+            "gemm_nt_small_kernel": ({"launches": sm["launches"],
+                                      "avg_launch_us": round(1e3 * sm["total_ms"] / max(sm["launches"], 1), 2),
+                                      "share_of_step": round(sm["total_ms"] / (el * 1e3), 3)} if sm["launches"] else None),
             "whole_step": {"flops_per_triplet": flops_per_triplet(round(n_avg)),
                            "achieved": round(flops_per_triplet(n_avg) * value / world / 1e12, 2),
                            "frac_mfma": round(flops_per_triplet(n_avg) * value / world / 1e12 / FP32_MFMA_PEAK_TFLOPS, 4),

@@ -211,6 +211,9 @@ int pc_build_similarity_batch_compact(const int32_t *pair_ids, int batch, const 
  * algorithmic FLOPs per kernel kind (0 = gemm_nt_kernel, 1 = gemm_tn_kernel). */
 int pc_profile_create(int capacity, void **out);
 int pc_profile_destroy(void *profile);
+/* Restrict the recorded brackets to the kinds whose bit is set (bit 0 gemm_nt_kernel, bit 1 gemm_tn*,
+ * bit 2 gemm_nt_small_kernel); default all. */
+int pc_profile_set_kinds(void *prof, unsigned kinds);
 int pc_profile_reset(void *profile);
 int pc_profile_summary(void *profile, int kind, int *launches, double *total_ms,
                        double *total_flops);

@@ -81,6 +81,7 @@ SIGNATURES = {
     "pc_profile_create": (_i, [_i, _P(ctypes.c_void_p)]),
     "pc_profile_destroy": (_i, [_vp]),
     "pc_profile_reset": (_i, [_vp]),
+    "pc_profile_set_kinds": (_i, [_vp, ctypes.c_uint]),
     "pc_profile_summary": (_i, [_vp, _i, _P(ctypes.c_int), _P(ctypes.c_double), _P(ctypes.c_double)]),
     "pc_build_similarity_batch": (_i, [_vp, _i, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _u64, _u64, _vp, _vp, _vp,
                                        _vp, _vp]),

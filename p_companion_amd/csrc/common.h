@@ -130,6 +130,7 @@ struct pc_profile {
     int* kind;           // per bracket
     double* flops;       // per bracket: algorithmic FLOPs of the launch
     int capacity, used;
+    unsigned kinds;      // bit k set: brackets of kind k are recorded (default: all)
 };
 enum { PC_KIND_GEMM_NT = 0, PC_KIND_GEMM_TN = 1, PC_KIND_GEMM_NT_SMALL = 2 };   // small: gemm_nt_small_kernel / the 2-wave few-row variant
 extern thread_local pc_profile* pc_tls_profile;

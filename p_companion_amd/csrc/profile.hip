@@ -7,7 +7,7 @@ thread_local pc_profile* pc_tls_profile = nullptr;
 
 int pc_prof_begin(int kind, double flops, hipStream_t st) {
     pc_profile* p = pc_tls_profile;
-    if (!p || p->used >= p->capacity) return -1;
+    if (!p || p->used >= p->capacity || !(p->kinds & (1u << kind))) return -1;
     const int b = p->used++;
     p->kind[b] = kind;
     p->flops[b] = flops;
@@ -29,6 +29,7 @@ extern "C" int pc_profile_create(int capacity, void** out) {
     p->kind = (int*)calloc(capacity, sizeof(int));
     p->flops = (double*)calloc(capacity, sizeof(double));
     p->capacity = capacity;
+    p->kinds = ~0u;
     for (int i = 0; i < 2 * capacity; i++) PC_HIP_TRY(hipEventCreate(&p->ev[i]));
     *out = p;
     return PC_OK;
@@ -39,6 +40,14 @@ extern "C" int pc_profile_destroy(void* prof) {
     if (!p) return PC_EINVAL;
     for (int i = 0; i < 2 * p->capacity; i++) hipEventDestroy(p->ev[i]);
     free(p->ev); free(p->kind); free(p->flops); free(p);
+    return PC_OK;
+}
+
+// Every bracket is two event packets between kernels (a few us each, and the bracketed kernel cannot overlap its
+// neighbours' tails): a caller that only needs one kernel family restricts the brackets to it.
+extern "C" int pc_profile_set_kinds(void* prof, unsigned kinds) {
+    if (!prof) return PC_EINVAL;
+    ((pc_profile*)prof)->kinds = kinds;
     return PC_OK;
 }
 

@@ -190,7 +190,17 @@ class SimilarityIndexLoader:
         else:
             rs = np.random.Generator(np.random.Philox([self.seed, self.epoch]))
             perm = rs.permutation(S) if self.shuffle else np.arange(S, dtype=np.int64)
-        perm_dev = torch.from_numpy(perm.astype(np.int32)).to(self.device)
+        perm_host = torch.from_numpy(perm.astype(np.int32))
+        if torch.device(self.device).type == "cuda":
+            # persistent pinned buffer + non_blocking: a pageable H2D copy (or a fresh pinned allocation) makes the
+            # host wait for all queued GPU work -- one pipeline bubble per epoch
+            if getattr(self, "_perm_pinned", None) is None or self._perm_pinned.numel() != S:
+                self._perm_pinned = torch.empty(S, dtype=torch.int32).pin_memory()
+            self._perm_pinned.copy_(perm_host)
+            perm_dev = torch.empty(S, dtype=torch.int32, device=self.device)
+            perm_dev.copy_(self._perm_pinned, non_blocking=True)
+        else:
+            perm_dev = perm_host.to(self.device)
         self.epoch += 1
         def make(i):
             lo, hi = i * self.batch_size, min((i + 1) * self.batch_size, S)
@@ -230,7 +240,9 @@ class SimilarityIndexLoader:
             for i in range(n):
                 yield make(i)
             return
-        side = torch.cuda.Stream(self.device)
+        if getattr(self, "_side", None) is None:
+            self._side = torch.cuda.Stream(self.device)
+        side = self._side
         side.wait_stream(torch.cuda.current_stream(self.device))     # the epoch permutation was uploaded there
         def launch(i):
             with torch.cuda.stream(side):

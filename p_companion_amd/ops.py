@@ -250,6 +250,13 @@ class KernelProfile:
     def reset(self):
         check(_lib.lib().pc_profile_reset(self.handle), "pc_profile_reset")
 
+    def set_kinds(self, names):
+        """Record only the brackets of these kernel families (each bracket costs two event packets)."""
+        mask = 0
+        for n in names:
+            mask |= 1 << self.KINDS[n]
+        check(_lib.lib().pc_profile_set_kinds(self.handle, mask), "pc_profile_set_kinds")
+
     def summary(self, kind):
         n, ms, fl = ctypes.c_int(), ctypes.c_double(), ctypes.c_double()
         check(_lib.lib().pc_profile_summary(self.handle, self.KINDS[kind], ctypes.byref(n), ctypes.byref(ms),
