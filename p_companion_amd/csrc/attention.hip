@@ -41,7 +41,7 @@ __global__ __launch_bounds__(256) void attn_core_fwd_kernel(const float* q, cons
     };
     // keys are taken AU at a time: the AU row loads of a group are in flight together (one wave per sample
     // and 16 waves per CU leave the latency of a load-use-load chain exposed otherwise)
-    constexpr int AU = 4;
+    constexpr int AU = 8;
     float m = -INFINITY;
     int n = 0;
     for (; n + AU <= N; n += AU) {
@@ -116,7 +116,7 @@ __global__ __launch_bounds__(256) void attn_core_bwd_kernel(const float* dctx, c
         return sr_reg ? (size_t)__shfl(my_row, n, 64) : (sr ? (size_t)sr[n] : base + n);
     };
     const float* pb = probs + (size_t)b * PC_HEADS * N + h * N;
-    constexpr int AU = 4;                                 // rows in flight per group (see the forward kernel)
+    constexpr int AU = 8;                                 // rows in flight per group (see the forward kernel)
     float dsum = 0.f;                                     // sum_n p_n * dp_n  (softmax backward)
     int n = 0;
     for (; n + AU <= N; n += AU) {
