@@ -224,18 +224,22 @@ def main():
         prof.set_kinds(["gemm_nt_kernel"])
     n_sum = 0
     real_sum = 0
+    slot_sum = 0
 
     def step(b, profile=None):
         tab = table
         if sharded is not None:
             nbc = b["neighbor_compact"]
-            ids = torch.cat([b["anchor_idx"], nbc["nb_rows"], b["positive_idx"], b["negative_idx"].reshape(-1)])
+            uq = "weight" in nbc
+            nrows = nbc["nb_rows"][: int(nbc["n_unique"]) + 1] if uq else nbc["nb_rows"]
+            ids = torch.cat([b["anchor_idx"], nrows, b["positive_idx"], b["negative_idx"].reshape(-1)])
             tab, remap = sharded.lookup(ids)
-            B, M1, K = b["anchor_idx"].numel(), nbc["nb_rows"].numel(), b["negative_idx"].shape[1]
+            B, M1, K = b["anchor_idx"].numel(), nrows.numel(), b["negative_idx"].shape[1]
             o = np.cumsum([0, B, M1, B, B * K])
             b = {"anchor_idx": remap[o[0]:o[1]].contiguous(), "positive_idx": remap[o[2]:o[3]].contiguous(),
                  "negative_idx": remap[o[3]:o[4]].view(B, K).contiguous(),
-                 "neighbor_compact": {"nb_rows": remap[o[1]:o[2]].contiguous(), "slot_row": nbc["slot_row"]}}
+                 "neighbor_compact": dict({"nb_rows": remap[o[1]:o[2]].contiguous(), "slot_row": nbc["slot_row"]},
+                                          **({"weight": nbc["weight"], "n_unique": nbc["n_unique"]} if uq else {}))}
         sync = (lambda t: torch.distributed.all_reduce(t)) if (args.sync_bn and world > 1) else None
         loss = model.train_step_indexed(tab, b, profile=profile, sync_reduce=sync)
         pdist.all_reduce_mean_(gflat, world)
@@ -253,7 +257,9 @@ def main():
     for _ in range(args.steps):
         last = next(it)
         n_sum += last["n_pad"]
-        real_sum += last["neighbor_compact"]["nb_rows"].numel() - 1
+        nbc_ = last["neighbor_compact"]
+        real_sum += int(nbc_["n_unique"]) if "weight" in nbc_ else nbc_["nb_rows"].numel() - 1      # rows carried
+        slot_sum += nbc_.get("n_real", nbc_["nb_rows"].numel() - 1)                                   # real slots
         loss = step(last, profile=prof)
     torch.cuda.synchronize()
     if world > 1:
@@ -301,8 +307,10 @@ def main():
                                   f"(avg N={n_avg:.1f})", "global_batch": world * args.batch,
                       "table": args.table, "parallelism": f"dp{world}",
                       "batchnorm": "cross-replica" if (args.sync_bn and world > 1) else "per-replica", "final_loss": round(float(loss), 5),
-                      "padding_slots": "carried once (compact rows): avg %.0f real + 1 shared of %d neighbour slots per step"
-                                       % (real_sum / max(args.steps, 1), args.batch * round(n_avg))},
+                      "neighbour_rows": "identical rows of the neighbour call carried once: avg %.0f distinct products (%.0f "
+                                        "real slots) + 1 shared padding row, of %d neighbour slots per step"
+                                        % (real_sum / max(args.steps, 1), slot_sum / max(args.steps, 1),
+                                           args.batch * round(n_avg))},
            "roofline": roof}
     if not args.no_cpu_baseline and world == 1:
         out["cpu_baseline"] = cpu_baseline(bpg, last, args.cpu_seconds)

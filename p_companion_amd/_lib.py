@@ -29,7 +29,8 @@ class P2VTensors(ctypes.Structure):
 
 class Segments(ctypes.Structure):
     _fields_ = [("nseg", ctypes.c_int), ("start", ctypes.c_int * (PC_MAX_SEG + 1)),
-                ("count", ctypes.c_int * PC_MAX_SEG), ("weighted_row", ctypes.c_int), ("weight", ctypes.c_float)]
+                ("count", ctypes.c_int * PC_MAX_SEG), ("weighted_row", ctypes.c_int), ("weight", ctypes.c_float),
+                ("row_weight", ctypes.c_void_p), ("row_weight_start", ctypes.c_int), ("row_weight_rows", ctypes.c_int)]
 
 
 class FfnSaved(ctypes.Structure):
@@ -74,6 +75,11 @@ SIGNATURES = {
                                _vp, _vp, _vp, _vp, _sz, _vp]),
     "pc_p2v_train_step_compact": (_i, [_P(P2VTensors), _P(P2VTensors), _vp, _vp, _vp, _vp, _vp, _i, _vp, _i, _i, _i, _f,
                                        _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "pc_p2v_train_step_unique": (_i, [_P(P2VTensors), _P(P2VTensors), _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _i, _i, _i, _f,
+                                      _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "pc_build_similarity_batch_unique_scratch_bytes": (_sz, [_i]),
+    "pc_build_similarity_batch_unique": (_i, [_vp, _i, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _u64, _u64, _i, _vp, _vp, _vp,
+                                              _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "pc_p2v_train_step_compact_sync": (_i, [_P(P2VTensors), _P(P2VTensors), _vp, _vp, _vp, _vp, _vp, _i, _vp, _i, _i, _i,
                                             _f, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _sz, _vp]),
     "pc_build_similarity_batch_compact": (_i, [_vp, _i, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _u64, _u64, _vp, _vp, _vp,

@@ -98,7 +98,7 @@ __global__ __launch_bounds__(256) void attn_core_fwd_kernel(const float* q, cons
 __global__ __launch_bounds__(256) void attn_core_bwd_kernel(const float* dctx, const float* q, const float* kv,
                                                             const float* probs, int B, int N, float* dq,
                                                             float* dkv, const int32_t* slot_row, int pad_row,
-                                                            float* dkv_pad) {
+                                                            float* dkv_pad, const float* row_weight) {
     extern __shared__ float sc_all[];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, h = lane >> 4;
     const int b = blockIdx.x * 4 + w;
@@ -155,6 +155,10 @@ __global__ __launch_bounds__(256) void attn_core_bwd_kernel(const float* dctx, c
         if (sr && (int)row == pad_row) {                   // wave-uniform: the slot map is per sample
             pk.x += ds * qs.x; pk.y += ds * qs.y;
             pv.x += p * g.x;   pv.y += p * g.y;
+        } else if (row_weight && row_weight[row] > 1.f) {  // a row shared by several slots (unique-neighbour layout):
+            float* d = dkv + row * (2 * PC_D) + 2 * lane;  // pre-zeroed, contributions added in hardware (order free)
+            unsafeAtomicAdd(d, ds * qs.x);          unsafeAtomicAdd(d + 1, ds * qs.y);
+            unsafeAtomicAdd(d + PC_D, p * g.x);     unsafeAtomicAdd(d + PC_D + 1, p * g.y);
         } else {
             *reinterpret_cast<float2*>(dkv + row * (2 * PC_D) + 2 * lane) = make_float2(ds * qs.x, ds * qs.y);
             *reinterpret_cast<float2*>(dkv + row * (2 * PC_D) + PC_D + 2 * lane) = make_float2(p * g.x, p * g.y);
@@ -166,6 +170,13 @@ __global__ __launch_bounds__(256) void attn_core_bwd_kernel(const float* dctx, c
         *reinterpret_cast<float2*>(dkv_pad + (size_t)b * (2 * PC_D) + PC_D + 2 * lane) = pv;
     }
     *reinterpret_cast<float2*>(dq + (size_t)b * PC_D + 2 * lane) = make_float2(dqa.x * scale, dqa.y * scale);
+}
+
+// rows of dkv that several slots add into start from zero (one wave per row)
+__global__ __launch_bounds__(256) void zero_shared_rows_kernel(float* dkv, const float* row_weight, int rows) {
+    const int r = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (r >= rows || !(row_weight[r] > 1.f)) return;
+    *reinterpret_cast<float4*>(dkv + (size_t)r * (2 * PC_D) + 4 * lane) = make_float4(0.f, 0.f, 0.f, 0.f);
 }
 
 // out[c] = sum_b x[b][c] over B rows of 2D = 256 columns, in two fixed-order stages: COLSUM_CHUNKS
@@ -275,10 +286,12 @@ extern "C" int pc_p2v_attention_forward(const pc_p2v_tensors* p, const float* qu
     return attention_forward_impl(p, query, keys, B, N, B * N, nullptr, out, sv, ws, ws_bytes, stream);
 }
 
+// row_weight (optional, [key_rows]): multiplicity of each key row; rows with weight > 1 are shared by several
+// slots and collect their gradients by hardware float atomics (the only order-free sum of the step)
 int attention_backward_impl(const pc_p2v_tensors* p, const pc_p2v_tensors* g, const float* query, const float* keys,
                             int B, int N, int key_rows, const int32_t* slot_row, int pad_row, const float* dout,
                             const pc_attn_saved* sv, float* dquery, float* dkeys, int accumulate, void* ws,
-                            size_t ws_bytes, void* stream) {
+                            size_t ws_bytes, void* stream, const float* row_weight) {
     PC_TRY(attn_check(p, B, N, key_rows, slot_row, sv, ws, ws_bytes));
     if (!g || !g->in_proj_w || !g->in_proj_b || !g->out_proj_w || !g->out_proj_b) return PC_EINVAL;
     if (!query || !keys || !dout || !dquery || !dkeys) return PC_EINVAL;
@@ -303,8 +316,12 @@ int attention_backward_impl(const pc_p2v_tensors* p, const pc_p2v_tensors* g, co
 
     const size_t lds = (size_t)4 * PC_HEADS * N * sizeof(float);
     const bool has_pad = slot_row && pad_row >= 0;
+    if (row_weight) {
+        PC_LAUNCH(zero_shared_rows_kernel, dim3((key_rows + 3) / 4), dim3(256), 0, st, w.dkv, row_weight, key_rows);
+        PC_TRY(pc_launch_status());
+    }
     PC_LAUNCH(attn_core_bwd_kernel, dim3((B + 3) / 4), dim3(256), lds, st, w.dctx, sv->q, sv->kv, sv->probs,
-                       B, N, w.dq, w.dkv, slot_row, has_pad ? pad_row : -1, has_pad ? w.dkv_pad : nullptr);
+                       B, N, w.dq, w.dkv, slot_row, has_pad ? pad_row : -1, has_pad ? w.dkv_pad : nullptr, row_weight);
     PC_TRY(pc_launch_status());
     if (has_pad) {
         PC_LAUNCH(colsum_partial_kernel, dim3(COLSUM_CHUNKS), dim3(256), 0, st, w.dkv_pad, B, w.pad_part);
@@ -336,5 +353,5 @@ extern "C" int pc_p2v_attention_backward(const pc_p2v_tensors* p, const pc_p2v_t
                                          const pc_attn_saved* sv, float* dquery, float* dkeys, int accumulate,
                                          void* ws, size_t ws_bytes, void* stream) {
     return attention_backward_impl(p, g, query, keys, B, N, B * N, nullptr, -1, dout, sv, dquery, dkeys, accumulate, ws,
-                                   ws_bytes, stream);
+                                   ws_bytes, stream, nullptr);
 }

@@ -42,6 +42,8 @@ struct SegInfo {
     int count[PC_MAX_SEG];       // logical rows per segment (what BatchNorm divides by)
     int wrow;                    // the one row that stands for `wmult` identical rows (-1: none)
     float wmult;
+    const float* roww;           // multiplicities of rows [w0, w0 + wn) (null: none): unique-neighbour layout
+    int w0, wn;
 };
 
 static inline SegInfo make_seginfo(const pc_segments* s, int rows, int tile_rows) {
@@ -51,12 +53,14 @@ static inline SegInfo make_seginfo(const pc_segments* s, int rows, int tile_rows
     si.start[0] = 0;
     si.wrow = -1;
     si.wmult = 1.f;
+    si.roww = nullptr; si.w0 = 0; si.wn = 0;
     if (s) {
         si.nseg = s->nseg;
         for (int i = 0; i <= s->nseg; i++) si.start[i] = s->start[i];
         for (int i = s->nseg + 1; i <= PC_MAX_SEG; i++) si.start[i] = s->start[s->nseg];
         si.wrow = s->weighted_row;
         si.wmult = s->weight;
+        if (s->row_weight && s->row_weight_rows > 0) { si.roww = s->row_weight; si.w0 = s->row_weight_start; si.wn = s->row_weight_rows; }
     }
     for (int i = 0; i < PC_MAX_SEG; i++) {
         const int phys = si.start[i + 1] - si.start[i];
@@ -78,6 +82,8 @@ static inline int seg_valid(const pc_segments* s, int rows) {
     for (int i = 0; i < s->nseg; i++)
         if (s->start[i + 1] < s->start[i] || s->count[i] < 0) return 0;
     if (s->weighted_row >= rows || (s->weighted_row >= 0 && s->weight < 0.f)) return 0;
+    if (s->row_weight && (s->row_weight_start < 0 || s->row_weight_rows < 0 || s->row_weight_start + s->row_weight_rows > rows))
+        return 0;
     return 1;
 }
 
@@ -87,6 +93,12 @@ __device__ __forceinline__ int seg_of_row(const SegInfo& si, int r) {
 #pragma unroll
     for (int i = 1; i < PC_MAX_SEG; i++) s += (i < si.nseg && r >= si.start[i]) ? 1 : 0;
     return s;
+}
+
+// how many identical logical rows physical row r stands for (1 unless the caller said otherwise)
+__device__ __forceinline__ float row_multiplicity(const SegInfo& si, int r) {
+    if (si.roww && (unsigned)(r - si.w0) < (unsigned)si.wn) return si.roww[r - si.w0];
+    return r == si.wrow ? si.wmult : 1.f;
 }
 
 __device__ __forceinline__ int seg_of_tile(const SegInfo& si, int t) {

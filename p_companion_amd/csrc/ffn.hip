@@ -156,7 +156,7 @@ __global__ void bn_bwd_apply_kernel(float* dz, const float* h0, int rows, SegInf
     const int rl = threadIdx.x >> 6;                           // 4 rows per block pass
     for (int r = blockIdx.x * 4 + rl; r < rows; r += gridDim.x * 4) {
         const int s = seg_of_row(si, r);
-        const float m = r == si.wrow ? si.wmult : 1.f;          // sum over the rows this one stands for
+        const float m = row_multiplicity(si, r);                  // sum over the rows this one stands for
         float4 g = *reinterpret_cast<float4*>(dz + (size_t)r * PC_H + c4);
         const float4 h = *reinterpret_cast<const float4*>(h0 + (size_t)r * PC_H + c4);
         const float4 mu = *reinterpret_cast<const float4*>(mean + s * PC_H + c4);

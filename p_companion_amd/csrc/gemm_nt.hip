@@ -344,7 +344,7 @@ __global__ __launch_bounds__(64 * NWM * NWN, WPS) void gemm_nt_kernel(NtArgs a, 
                     v[q] = x;
                     if (rok && col + q < a.N) {
                         if (STATS == NT_STAT_SUMSQ) {
-                            const float wt = row == a.seg.wrow ? a.seg.wmult : 1.f;   // the row that stands for many
+                            const float wt = row_multiplicity(a.seg, row);            // a row may stand for many
                             cs1[q] += wt * x; cs2[q] += wt * x * x;
                         }
                         else if (STATS == NT_STAT_BNBWD) { cs1[q] += x; cs2[q] += x * ax[q]; }      // raw moment: centred in fp64 by the finalize pass

@@ -52,7 +52,7 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(TnArgs a, int tiles_i, 
                     zseg = s;
                 }
                 const float4 h = *reinterpret_cast<const float4*>(a.zaux + (size_t)r * a.ldzaux + o0 + lcol);
-                const float zm = r == a.seg.wrow ? a.seg.wmult : 1.f;
+                const float zm = row_multiplicity(a.seg, r);
                 rz[p].x = zsc.x * (rz[p].x - zm * (zc1.x + (h.x - zmu.x) * zis.x * zc2.x));
                 rz[p].y = zsc.y * (rz[p].y - zm * (zc1.y + (h.y - zmu.y) * zis.y * zc2.y));
                 rz[p].z = zsc.z * (rz[p].z - zm * (zc1.z + (h.z - zmu.z) * zis.z * zc2.z));
@@ -246,7 +246,7 @@ __global__ __launch_bounds__(512, 2) void gemm_tn8_kernel(TnArgs a, int nsplit, 
                     }
                     float4 z = *reinterpret_cast<const float4*>(&Zs[rr * NO + zcol]);
                     const float4 h = *reinterpret_cast<const float4*>(&Hs[rr * NO + zcol]);
-                    const float zm = r == a.seg.wrow ? a.seg.wmult : 1.f;
+                    const float zm = row_multiplicity(a.seg, r);
                     z.x = zsc.x * (z.x - zm * (zc1.x + (h.x - zmu.x) * zis.x * zc2.x));
                     z.y = zsc.y * (z.y - zm * (zc1.y + (h.y - zmu.y) * zis.y * zc2.y));
                     z.z = zsc.z * (z.z - zm * (zc1.z + (h.z - zmu.z) * zis.z * zc2.z));

@@ -141,6 +141,21 @@ def generate_scaled_bpg(num_products=100_000, num_types=100, seed=0, mean_degree
                   similarity_pairs=sim, complementary_pairs=comp, n_types=int(num_types))
 
 
+class _LazyCount:
+    """Device-computed integer read back through pinned memory; int() waits for the copy (normally long done)."""
+
+    def __init__(self, host_tensor, event):
+        self._t, self._ev, self._v = host_tensor, event, None
+
+    def __int__(self):
+        if self._v is None:
+            self._ev.synchronize()
+            self._v = int(self._t[0])
+        return self._v
+
+    __index__ = __int__
+
+
 class SimilarityIndexLoader:
     """Index-form counterpart of DataLoader(SimilarityDataset, shuffle=True, collate_fn)
     (scripts/pretrain_product2vec.py:24-30).  Yields device index batches; the dense feature
@@ -154,7 +169,7 @@ class SimilarityIndexLoader:
     """
 
     def __init__(self, bpg: IntBPG, batch_size: int, shuffle=True, sampler="philox", seed=0, k_neg=5,
-                 drop_last=False, device="cuda", compact=True, prefetch=True):
+                 drop_last=False, device="cuda", compact=True, prefetch=True, unique=True):
         from . import ops
         self.ops = ops
         self.bpg = bpg
@@ -167,6 +182,9 @@ class SimilarityIndexLoader:
         self.drop_last = drop_last
         self.device = device
         self.compact = compact          # carry the zero-padding rows once (pc_p2v_train_step_compact)
+        # ... and every distinct neighbour product once (pc_p2v_train_step_unique): identical rows of one
+        # BatchNorm call are identical all the way through the FFN
+        self.unique = unique and compact and sampler == "philox" and torch.device(device).type == "cuda"
         # build batch i+1 on a side stream while the consumer trains on batch i (what the reference's
         # DataLoader workers do on the host, scripts/pretrain_product2vec.py:24-30); same batches either way
         self.prefetch = prefetch and sampler == "philox" and torch.device(device).type == "cuda"
@@ -209,8 +227,19 @@ class SimilarityIndexLoader:
             nbc = None
             if self.sampler == "philox" and self.compact and n_pad > 0:
                 n_real = int(np.minimum(self._deg[ids], n_pad).sum())
-                a, p, ng, nbc = self.ops.build_similarity_batch_compact(perm_dev[lo:hi], self.g, n_pad, self.k_neg,
-                                                                        self.seed, self.step, n_real)
+                if self.unique:
+                    a, p, ng, nbc = self.ops.build_similarity_batch_unique(perm_dev[lo:hi], self.g, n_pad, self.k_neg,
+                                                                           self.seed, self.step, n_real)
+                    # the row count is needed on the host (kernel grids): fetched through pinned memory behind the
+                    # builder, read when the batch is handed out (a whole step later when prefetching)
+                    host_n = torch.empty(1, dtype=torch.int32).pin_memory()
+                    host_n.copy_(nbc["n_unique"], non_blocking=True)
+                    ev = torch.cuda.Event(); ev.record(torch.cuda.current_stream(self.device))
+                    nbc["n_unique"] = _LazyCount(host_n, ev)
+                    nbc["n_real"] = n_real
+                else:
+                    a, p, ng, nbc = self.ops.build_similarity_batch_compact(perm_dev[lo:hi], self.g, n_pad, self.k_neg,
+                                                                            self.seed, self.step, n_real)
                 nb = None
             elif self.sampler == "philox":
                 a, p, ng, nb = self.ops.build_similarity_batch(perm_dev[lo:hi], self.g, n_pad, self.k_neg,

@@ -284,11 +284,17 @@ def p2v_train_step(params, grads, table, anchor_idx, positive_idx, negative_idx,
     gst, _ = p2v_struct(grads, with_buffers=False)
     b = anchor_idx.numel()
     k = negative_idx.shape[1]
-    compact = isinstance(neighbor_idx, dict)          # {"nb_rows": [M+1], "slot_row": [B,N]}
+    compact = isinstance(neighbor_idx, dict)          # {"nb_rows": [M+1], "slot_row": [B,N]} (+ "weight", "n_unique")
+    unique = compact and "weight" in neighbor_idx
     if compact:
         nb_rows, slot_row = neighbor_idx["nb_rows"], neighbor_idx["slot_row"]
-        n, n_real = slot_row.shape[1], nb_rows.numel() - 1
+        n = slot_row.shape[1]
+        n_real = int(neighbor_idx["n_unique"]) if unique else nb_rows.numel() - 1
         _req(nb_rows, torch.int32, "nb_rows"); _req(slot_row, torch.int32, "slot_row", (b, n))
+        if unique:
+            _req(neighbor_idx["weight"], torch.float32, "weight")
+            if nb_rows.numel() < n_real + 1 or neighbor_idx["weight"].numel() < n_real + 1:
+                raise ValueError("nb_rows / weight shorter than n_unique + 1")
     else:
         n = 0 if neighbor_idx is None else neighbor_idx.shape[1]
     _req(table, torch.float32, "table")
@@ -311,6 +317,13 @@ def p2v_train_step(params, grads, table, anchor_idx, positive_idx, negative_idx,
         bwd_global = None
 
         def phase(ph):
+            if unique:
+                check(_lib.lib().pc_p2v_train_step_unique(
+                    ctypes.byref(st), ctypes.byref(gst), _p(table), _p(anchor_idx), _p(positive_idx), _p(negative_idx),
+                    _p(nb_rows), _p(neighbor_idx["weight"]), n_real, _p(slot_row), b, n, k, float(margin), _p(out["loss"]),
+                    _p(out["d_pos"]), _p(out["d_neg"]), _p(out.get("anchor_emb")), None, ph, _p(fwd), _p(bwd_local),
+                    _p(bwd_global), _p(ws), nbytes, _stream()), "pc_p2v_train_step_unique")
+                return
             check(_lib.lib().pc_p2v_train_step_compact_sync(
                 ctypes.byref(st), ctypes.byref(gst), _p(table), _p(anchor_idx), _p(positive_idx), _p(negative_idx),
                 _p(nb_rows), n_real, _p(slot_row), b, n, k, float(margin), _p(out["loss"]), _p(out["d_pos"]),
@@ -322,6 +335,13 @@ def p2v_train_step(params, grads, table, anchor_idx, positive_idx, negative_idx,
         bwd_global = bwd_local.clone()
         sync_reduce(bwd_global)
         phase(2)
+        return out
+    if unique:
+        check(_lib.lib().pc_p2v_train_step_unique(
+            ctypes.byref(st), ctypes.byref(gst), _p(table), _p(anchor_idx), _p(positive_idx), _p(negative_idx),
+            _p(nb_rows), _p(neighbor_idx["weight"]), n_real, _p(slot_row), b, n, k, float(margin), _p(out["loss"]),
+            _p(out["d_pos"]), _p(out["d_neg"]), _p(out.get("anchor_emb")), profile.handle if profile else None, -1, None,
+            None, None, _p(ws), nbytes, _stream()), "pc_p2v_train_step_unique")
         return out
     if compact:
         check(_lib.lib().pc_p2v_train_step_compact(
@@ -376,6 +396,52 @@ def build_similarity_batch_compact(pair_ids, graph, n_pad, k_neg, seed, step, n_
         _p(graph["sim_col"]), int(graph["n_products"]), n_pad, k_neg, int(seed), int(step), _p(a), _p(p), _p(ng),
         _p(nb_rows), _p(slot_row), _p(row_off), _stream()), "pc_build_similarity_batch_compact")
     return a, p, ng, {"nb_rows": nb_rows, "slot_row": slot_row}
+
+
+_uq_scratch = {}
+
+
+def build_similarity_batch_unique(pair_ids, graph, n_pad, k_neg, seed, step, n_real):
+    """Same batch in the unique-neighbour layout (pc_build_similarity_batch_unique): returns anchor_idx,
+    positive_idx, negative_idx, {"nb_rows": [n_real+1], "weight": [n_real+1] fp32, "slot_row": [B,n_pad],
+    "n_unique": [1] int32 DEVICE tensor}.  Only the first n_unique+1 entries of nb_rows / weight are meaningful;
+    the caller reads n_unique back (the loader does so asynchronously, one batch ahead)."""
+    b = pair_ids.numel()
+    dev = pair_ids.device
+    _req(pair_ids, torch.int32, "pair_ids")
+    npr = int(graph["n_products"])
+    key = (dev, npr)
+    if key not in _uq_scratch:          # per-product counters: zero-filled once, every call leaves them zeroed
+        nbytes = _lib.lib().pc_build_similarity_batch_unique_scratch_bytes(npr)
+        _uq_scratch[key] = torch.zeros(nbytes, dtype=torch.uint8, device=dev)
+    scratch = _uq_scratch[key]
+    a = torch.empty(b, dtype=torch.int32, device=dev)
+    p = torch.empty(b, dtype=torch.int32, device=dev)
+    ng = torch.empty(b, k_neg, dtype=torch.int32, device=dev)
+    nb_rows = torch.empty(n_real + 1, dtype=torch.int32, device=dev)
+    weight = torch.empty(n_real + 1, dtype=torch.float32, device=dev)
+    slot_row = torch.empty(b, n_pad, dtype=torch.int32, device=dev)
+    n_unique = torch.empty(1, dtype=torch.int32, device=dev)
+    check(_lib.lib().pc_build_similarity_batch_unique(
+        _p(pair_ids), b, _p(graph["sim_pairs"]), _p(graph["cv_rowptr"]), _p(graph["cv_col"]), _p(graph["sim_rowptr"]),
+        _p(graph["sim_col"]), npr, n_pad, k_neg, int(seed), int(step), int(n_real), _p(a), _p(p), _p(ng), _p(nb_rows),
+        _p(weight), _p(slot_row), _p(n_unique), _p(scratch), scratch.numel(), _stream()),
+        "pc_build_similarity_batch_unique")
+    return a, p, ng, {"nb_rows": nb_rows, "weight": weight, "slot_row": slot_row, "n_unique": n_unique}
+
+
+def unique_neighbors(neighbor_idx):
+    """Host-side construction of the unique-neighbour layout from a dense [B,N] index matrix (-1 = padding)."""
+    idx = neighbor_idx.cpu().numpy()
+    real = idx >= 0
+    u, inv, cnt = np.unique(idx[real], return_inverse=True, return_counts=True)
+    nb_rows = np.concatenate([u, [-1]]).astype(np.int32)
+    weight = np.concatenate([cnt, [idx.size - int(real.sum())]]).astype(np.float32)
+    slot = np.full(idx.shape, len(u), np.int32)
+    slot[real] = inv.astype(np.int32)
+    dev = neighbor_idx.device
+    return {"nb_rows": torch.from_numpy(nb_rows).to(dev), "weight": torch.from_numpy(weight).to(dev),
+            "slot_row": torch.from_numpy(slot).to(dev), "n_unique": int(len(u))}
 
 
 def compact_neighbors(neighbor_idx):

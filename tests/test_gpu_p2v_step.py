@@ -273,3 +273,75 @@ def test_cross_replica_batchnorm_equals_concatenated_batch():
     o1 = ops.p2v_train_step(p1, g1, table, halves[0]["anchor_idx"], halves[0]["positive_idx"], halves[0]["negative_idx"],
                             halves[0]["neighbor_compact"], 1.0)
     assert float((gf1 - reps[0][2]).abs().max()) > 10 * tol
+
+
+def test_unique_neighbour_layout_equals_dense_and_golden(golden):
+    """pc_p2v_train_step_unique: every distinct neighbour product carried once (multiplicity-weighted BatchNorm,
+    summed slot gradients) gives the dense step's loss and gradients; also against the reference's golden step."""
+    from p_companion_amd import ops
+    from p_companion_amd.data import generate_scaled_bpg, SimilarityIndexLoader
+    bpg = generate_scaled_bpg(3000, 20, seed=4)            # small catalogue: many repeated neighbours
+    table = bpg.cuda()["features"]
+    loader = SimilarityIndexLoader(bpg, 512, seed=2, drop_last=True, compact=False, prefetch=False)
+    batch = next(iter(loader))
+    nb = batch["neighbor_idx"]
+    uq = ops.unique_neighbors(nb)
+    real = int((nb >= 0).sum())
+    assert uq["n_unique"] < 0.8 * real                       # the layout must actually merge rows here
+
+    def fresh():
+        sizes = [int(np.prod(s)) for s in ops.P2V_SHAPES]
+        offs = np.concatenate([[0], np.cumsum(sizes)])
+        g = torch.Generator(device="cpu").manual_seed(5)
+        flat = (torch.randn(int(offs[-1]), generator=g) * 0.05).cuda()
+        gflat = torch.zeros_like(flat)
+        params = {k: flat[offs[i]:offs[i + 1]].view(s) for i, (k, s) in enumerate(zip(ops.P2V_KEYS, ops.P2V_SHAPES))}
+        grads = {k: gflat[offs[i]:offs[i + 1]].view(s) for i, (k, s) in enumerate(zip(ops.P2V_KEYS, ops.P2V_SHAPES))}
+        params["ffn.1.weight"].fill_(1.0)
+        params["ffn.1.running_mean"] = torch.zeros(256, device="cuda")
+        params["ffn.1.running_var"] = torch.ones(256, device="cuda")
+        params["ffn.1.num_batches_tracked"] = torch.zeros((), dtype=torch.int64, device="cuda")
+        return params, grads, gflat
+
+    pd, gd, gfd = fresh()
+    od = ops.p2v_train_step(pd, gd, table, batch["anchor_idx"], batch["positive_idx"], batch["negative_idx"], nb, 1.0,
+                            want_emb=True)
+    pu, gu, gfu = fresh()
+    ou = ops.p2v_train_step(pu, gu, table, batch["anchor_idx"], batch["positive_idx"], batch["negative_idx"], uq, 1.0,
+                            want_emb=True)
+    assert abs(float(od["loss"]) - float(ou["loss"])) < 2e-6
+    assert float((od["anchor_emb"] - ou["anchor_emb"]).abs().max()) < 2e-5
+    tol = 2e-6 + 2e-4 * float(gfd.abs().max())
+    assert float((gfd - gfu).abs().max()) < tol, float((gfd - gfu).abs().max())
+    assert torch.allclose(pd["ffn.1.running_var"], pu["ffn.1.running_var"], atol=1e-6)
+
+    # device builder == host construction (same rows, weights, slot map), and it leaves its counters zeroed
+    g = bpg.cuda()
+    perm = torch.arange(512, dtype=torch.int32, device="cuda")
+    deg = np.minimum(bpg.degree(bpg.similarity_pairs[:512, 0]), 32)
+    n_pad, n_real = int(deg.max()), int(deg.sum())
+    for rep in range(2):                                      # twice: the scratch counters must come back to zero
+        a, p_, ng, u = ops.build_similarity_batch_unique(perm, g, n_pad, 5, 7, 3, n_real)
+        a2, p2, ng2, dense = ops.build_similarity_batch(perm, g, n_pad, 5, 7, 3)
+        ref = ops.unique_neighbors(dense)
+        U = int(u["n_unique"][0])
+        assert U == ref["n_unique"]
+        assert torch.equal(u["nb_rows"][:U + 1], ref["nb_rows"]) and torch.equal(u["weight"][:U + 1], ref["weight"])
+        assert torch.equal(u["slot_row"], ref["slot_row"]) and torch.equal(a, a2) and torch.equal(ng, ng2)
+
+
+
+def test_train_step_unique_golden_b256(golden):
+    """The REFERENCE's golden step (256 samples of its own 1k-product graph, 37 % padding, repeated neighbours)
+    through pc_p2v_train_step_unique: 3 steps, losses / gradients / BN statistics / parameters after Adam."""
+    from p_companion_amd import ops
+    g, st = _load(golden, "g4_p2v_b256.npz")
+    ints = golden("g2_bpg1000.npz")
+    table = torch.from_numpy(ints["features"]).cuda()
+    batch = {k: torch.from_numpy(g[k]).cuda() for k in ("anchor_idx", "positive_idx", "negative_idx")}
+    nb = torch.from_numpy(g["neighbor_idx"]).cuda()
+    uq = ops.unique_neighbors(nb)
+    assert uq["n_unique"] < int((g["neighbor_idx"] >= 0).sum())
+    batch["neighbor_idx"] = uq
+    outs, fg, bn1, after1, final = _run_steps(ops, st, table, batch, 3)
+    _check(g, outs, fg, bn1, final, golden("g4_p2v_b256_params3.npz"))
