@@ -239,7 +239,7 @@ def main():
             b = {"anchor_idx": remap[o[0]:o[1]].contiguous(), "positive_idx": remap[o[2]:o[3]].contiguous(),
                  "negative_idx": remap[o[3]:o[4]].view(B, K).contiguous(),
                  "neighbor_compact": dict({"nb_rows": remap[o[1]:o[2]].contiguous(), "slot_row": nbc["slot_row"]},
-                                          **({"weight": nbc["weight"], "n_unique": nbc["n_unique"]} if uq else {}))}
+                                          **({k: nbc[k] for k in ("weight", "n_unique", "ref_off", "ref_slot")} if uq else {}))}
         sync = (lambda t: torch.distributed.all_reduce(t)) if (args.sync_bn and world > 1) else None
         loss = model.train_step_indexed(tab, b, profile=profile, sync_reduce=sync)
         pdist.all_reduce_mean_(gflat, world)

@@ -187,16 +187,18 @@ int pc_p2v_train_step_compact(const pc_p2v_tensors *p, const pc_p2v_tensors *g, 
  *   nb_rows[n_unique + 1]    the distinct products (ascending) then -1 (the shared padding row)
  *   nb_weight[n_unique + 1]  how many slots each stands for; last entry = number of padding slots
  *   slot_row[B * N]          row of every (sample, slot)
- * (pc_build_similarity_batch_unique builds all three.)  A row's multiplicity weights its BatchNorm sums and
- * the BatchNorm-backward correction; the gradients of the slots that share a row are summed (the attention
- * backward adds them with hardware float atomics: the one order-free sum of the step, ~1e-7 relative run to
- * run).  Loss and gradients equal the dense step's up to fp32 summation order (tested).
+ *   ref_off / ref_slot       the inverse: slots of every row, ascending (see pc_build_similarity_batch_unique)
+ * (pc_build_similarity_batch_unique builds all of them.)  A row's multiplicity weights its BatchNorm sums and
+ * the BatchNorm-backward correction; the gradients of the slots that share a row are summed: the attention
+ * backward forms dK/dV row by row over the row's slots in ascending slot order (it sorts the row's list:
+ * fixed summation order, no float atomics; a row with more than 64 slots is summed in fp64 instead).  Loss and gradients equal the dense step's up to fp32 summation order (tested).
  * phase: -1 = the whole step with this replica's BatchNorm statistics (fwd_sums / bwd_* ignored); 0,1,2 = the
  * cross-replica phases described at pc_p2v_train_step_compact_sync. */
 int pc_p2v_train_step_unique(const pc_p2v_tensors *p, const pc_p2v_tensors *g, const float *table,
                              const int32_t *anchor_idx, const int32_t *positive_idx,
                              const int32_t *negative_idx, const int32_t *nb_rows, const float *nb_weight,
-                             int n_unique, const int32_t *slot_row, int batch, int n_nbr, int k_neg,
+                             int n_unique, const int32_t *slot_row, const int32_t *ref_off,
+                             const int32_t *ref_slot, int batch, int n_nbr, int k_neg,
                              float margin, float *loss, float *d_pos, float *d_neg, float *anchor_emb,
                              void *profile, int phase, double *fwd_sums, double *bwd_local,
                              const double *bwd_global, void *ws, size_t ws_bytes, void *stream);
@@ -232,17 +234,22 @@ int pc_build_similarity_batch_compact(const int32_t *pair_ids, int batch, const 
 
 /* Same batch in the unique-neighbour layout (see pc_p2v_train_step_unique).  n_real = number of real
  * neighbour slots (host-known: sum of the capped degrees), the upper bound of n_unique: nb_rows / nb_weight
- * hold n_real + 1 entries; *n_unique (device int) receives the number of distinct products.  `scratch`:
- * pc_build_similarity_batch_unique_scratch_bytes(n_products) bytes, ZERO-FILLED before the first call and left
- * zeroed by every call (per-product occurrence counters).  Integer work only: deterministic. */
-size_t pc_build_similarity_batch_unique_scratch_bytes(int n_products);
+ * hold n_real + 1 entries; *n_unique (device int) receives the number of distinct products.  Also the inverse
+ * map, for the attention backward: ref_slot[n_real] = the real slots (sample * n_pad + position) grouped by
+ * row -- in arrival order inside a row: the consumer sorts the few entries of a row before it sums --, and
+ * ref_off[n_real + 2] = where each row's slots start (the padding row lists none).  `scratch`:
+ * pc_build_similarity_batch_unique_scratch_bytes(n_products, batch * n_pad) bytes whose first 4 * n_products
+ * bytes are ZERO-FILLED before the first call and left zeroed by every call (per-product occurrence
+ * counters).  Integer work only: deterministic. */
+size_t pc_build_similarity_batch_unique_scratch_bytes(int n_products, int max_slots /* batch * n_pad */);
 int pc_build_similarity_batch_unique(const int32_t *pair_ids, int batch, const int32_t *sim_pairs,
                                      const int32_t *cv_rowptr, const int32_t *cv_col,
                                      const int32_t *sim_rowptr, const int32_t *sim_col, int n_products,
                                      int n_pad, int k_neg, uint64_t seed, uint64_t step, int n_real,
                                      int32_t *anchor_idx, int32_t *positive_idx, int32_t *negative_idx,
                                      int32_t *nb_rows, float *nb_weight, int32_t *slot_row,
-                                     int32_t *n_unique, void *scratch, size_t scratch_bytes, void *stream);
+                                     int32_t *ref_off, int32_t *ref_slot, int32_t *n_unique, void *scratch,
+                                     size_t scratch_bytes, void *stream);
 
 /* Optional measurement aid (bench.py's roofline leg; NULL everywhere else): a pool of HIP
  * events that pc_p2v_train_step records on its stream around each of its GEMM launches.

@@ -75,11 +75,11 @@ SIGNATURES = {
                                _vp, _vp, _vp, _vp, _sz, _vp]),
     "pc_p2v_train_step_compact": (_i, [_P(P2VTensors), _P(P2VTensors), _vp, _vp, _vp, _vp, _vp, _i, _vp, _i, _i, _i, _f,
                                        _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
-    "pc_p2v_train_step_unique": (_i, [_P(P2VTensors), _P(P2VTensors), _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _i, _i, _i, _f,
-                                      _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _sz, _vp]),
-    "pc_build_similarity_batch_unique_scratch_bytes": (_sz, [_i]),
+    "pc_p2v_train_step_unique": (_i, [_P(P2VTensors), _P(P2VTensors), _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _i, _i,
+                                      _i, _f, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "pc_build_similarity_batch_unique_scratch_bytes": (_sz, [_i, _i]),
     "pc_build_similarity_batch_unique": (_i, [_vp, _i, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _u64, _u64, _i, _vp, _vp, _vp,
-                                              _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
+                                              _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "pc_p2v_train_step_compact_sync": (_i, [_P(P2VTensors), _P(P2VTensors), _vp, _vp, _vp, _vp, _vp, _i, _vp, _i, _i, _i,
                                             _f, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _sz, _vp]),
     "pc_build_similarity_batch_compact": (_i, [_vp, _i, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _u64, _u64, _vp, _vp, _vp,

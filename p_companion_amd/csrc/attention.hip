@@ -98,7 +98,7 @@ __global__ __launch_bounds__(256) void attn_core_fwd_kernel(const float* q, cons
 __global__ __launch_bounds__(256) void attn_core_bwd_kernel(const float* dctx, const float* q, const float* kv,
                                                             const float* probs, int B, int N, float* dq,
                                                             float* dkv, const int32_t* slot_row, int pad_row,
-                                                            float* dkv_pad, const float* row_weight) {
+                                                            float* dkv_pad, float* coef) {
     extern __shared__ float sc_all[];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, h = lane >> 4;
     const int b = blockIdx.x * 4 + w;
@@ -155,10 +155,13 @@ __global__ __launch_bounds__(256) void attn_core_bwd_kernel(const float* dctx, c
         if (sr && (int)row == pad_row) {                   // wave-uniform: the slot map is per sample
             pk.x += ds * qs.x; pk.y += ds * qs.y;
             pv.x += p * g.x;   pv.y += p * g.y;
-        } else if (row_weight && row_weight[row] > 1.f) {  // a row shared by several slots (unique-neighbour layout):
-            float* d = dkv + row * (2 * PC_D) + 2 * lane;  // pre-zeroed, contributions added in hardware (order free)
-            unsafeAtomicAdd(d, ds * qs.x);          unsafeAtomicAdd(d + 1, ds * qs.y);
-            unsafeAtomicAdd(d + PC_D, p * g.x);     unsafeAtomicAdd(d + PC_D + 1, p * g.y);
+        } else if (coef) {
+            // unique-neighbour layout: rows are shared between samples, so dK/dV are formed row by row afterwards
+            // (attn_dkv_rows_kernel) from the per-slot softmax coefficients: [slot][ds per head | p per head]
+            if ((lane & 15) == 0) {
+                coef[(base + n + u) * 8 + h] = ds;
+                coef[(base + n + u) * 8 + 4 + h] = p;
+            }
         } else {
             *reinterpret_cast<float2*>(dkv + row * (2 * PC_D) + 2 * lane) = make_float2(ds * qs.x, ds * qs.y);
             *reinterpret_cast<float2*>(dkv + row * (2 * PC_D) + PC_D + 2 * lane) = make_float2(p * g.x, p * g.y);
@@ -172,11 +175,67 @@ __global__ __launch_bounds__(256) void attn_core_bwd_kernel(const float* dctx, c
     *reinterpret_cast<float2*>(dq + (size_t)b * PC_D + 2 * lane) = make_float2(dqa.x * scale, dqa.y * scale);
 }
 
-// rows of dkv that several slots add into start from zero (one wave per row)
-__global__ __launch_bounds__(256) void zero_shared_rows_kernel(float* dkv, const float* row_weight, int rows) {
-    const int r = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
-    if (r >= rows || !(row_weight[r] > 1.f)) return;
-    *reinterpret_cast<float4*>(dkv + (size_t)r * (2 * PC_D) + 4 * lane) = make_float4(0.f, 0.f, 0.f, 0.f);
+// dK_r = sum over the slots (b,n) of row r of ds[b,h,n] * q_b / sqrt(32),  dV_r = sum p[b,h,n] * dctx_b : one wave
+// per row; q / dctx rows of the batch are L2-resident.  The row's slot list arrives in arbitrary order: up to 64
+// entries are sorted in the wave (bitonic, by shuffles) so the fp32 summation order is fixed; a longer list (a
+// product that is a neighbour of more than 64 anchors of the batch) is accumulated in fp64, where the order no
+// longer reaches the rounded fp32 result.
+__global__ __launch_bounds__(256) void attn_dkv_rows_kernel(const float* coef, const float* q, const float* dctx,
+                                                            const int32_t* ref_off, const int32_t* ref_slot, int N,
+                                                            int rows, float* dkv) {
+    const int lane = threadIdx.x & 63, h = lane >> 4;
+    const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= rows) return;
+    const float scale = 0.17677669529663687f;
+    const int lo = ref_off[r], k = ref_off[r + 1] - lo;
+    float2 dk = make_float2(0.f, 0.f), dv = make_float2(0.f, 0.f);
+    if (k <= 64) {
+        int mine = lane < k ? ref_slot[lo + lane] : 0x7fffffff;
+        if (k > 1) {
+#pragma unroll
+            for (int size = 2; size <= 64; size <<= 1)
+#pragma unroll
+                for (int stride = size >> 1; stride >= 1; stride >>= 1) {
+                    const int other = __shfl_xor(mine, stride, 64);
+                    const bool up = (lane & size) == 0, low = (lane & stride) == 0;
+                    mine = (up == low) ? min(mine, other) : max(mine, other);
+                }
+        }
+        for (int i = 0; i < k; i += 4) {
+            float ds[4], p[4];
+            float2 qq[4], gg[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                const int slot = __shfl(mine, min(i + u, k - 1), 64);
+                const int b = slot / N;
+                ds[u] = coef[(size_t)slot * 8 + h];
+                p[u] = coef[(size_t)slot * 8 + 4 + h];
+                qq[u] = *reinterpret_cast<const float2*>(q + (size_t)b * PC_D + 2 * lane);
+                gg[u] = *reinterpret_cast<const float2*>(dctx + (size_t)b * PC_D + 2 * lane);
+            }
+#pragma unroll
+            for (int u = 0; u < 4; u++)
+                if (i + u < k) {
+                    dk.x += ds[u] * (qq[u].x * scale); dk.y += ds[u] * (qq[u].y * scale);
+                    dv.x += p[u] * gg[u].x;            dv.y += p[u] * gg[u].y;
+                }
+        }
+    } else {
+        double kx = 0.0, ky = 0.0, vx = 0.0, vy = 0.0;
+        for (int i = 0; i < k; i++) {
+            const int slot = ref_slot[lo + i];
+            const int b = slot / N;
+            const float ds = coef[(size_t)slot * 8 + h], p = coef[(size_t)slot * 8 + 4 + h];
+            const float2 qq = *reinterpret_cast<const float2*>(q + (size_t)b * PC_D + 2 * lane);
+            const float2 gg = *reinterpret_cast<const float2*>(dctx + (size_t)b * PC_D + 2 * lane);
+            kx += (double)ds * (double)(qq.x * scale); ky += (double)ds * (double)(qq.y * scale);
+            vx += (double)p * (double)gg.x;            vy += (double)p * (double)gg.y;
+        }
+        dk = make_float2((float)kx, (float)ky);
+        dv = make_float2((float)vx, (float)vy);
+    }
+    *reinterpret_cast<float2*>(dkv + (size_t)r * (2 * PC_D) + 2 * lane) = dk;
+    *reinterpret_cast<float2*>(dkv + (size_t)r * (2 * PC_D) + PC_D + 2 * lane) = dv;
 }
 
 // out[c] = sum_b x[b][c] over B rows of 2D = 256 columns, in two fixed-order stages: COLSUM_CHUNKS
@@ -209,12 +268,13 @@ static inline size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
 
 struct AttnWs {
     float *dctx, *dq, *dkv, *dkv_pad, *pad_part;   // backward intermediates
+    float *coef;                                    // [B*N][8] per-slot softmax coefficients (unique-neighbour layout)
     float *wot, *wqt, *wkvt;      // transposed projections
     float *slabs; size_t slab_floats;
     size_t total;
 };
 
-static AttnWs attn_ws_layout(void* base, int B, int key_rows) {
+static AttnWs attn_ws_layout(void* base, int B, int key_rows, int n_slots_per_sample) {
     AttnWs w;
     size_t off = 0;
     auto take = [&](size_t floats) {
@@ -227,6 +287,7 @@ static AttnWs attn_ws_layout(void* base, int B, int key_rows) {
     w.dkv = take((size_t)key_rows * 2 * PC_D);
     w.dkv_pad = take((size_t)B * 2 * PC_D);
     w.pad_part = take((size_t)COLSUM_CHUNKS * 2 * PC_D);
+    w.coef = take((size_t)B * n_slots_per_sample * 8);
     w.wot = take(PC_D * PC_D);
     w.wqt = take(PC_D * PC_D);
     w.wkvt = take(2 * PC_D * PC_D);
@@ -240,7 +301,7 @@ static AttnWs attn_ws_layout(void* base, int B, int key_rows) {
 
 extern "C" size_t pc_p2v_attention_workspace_bytes(int batch, int n_keys) {
     if (batch <= 0 || n_keys <= 0) return 0;
-    return attn_ws_layout(nullptr, batch, batch * n_keys).total;     // dense layout bounds the compact one
+    return attn_ws_layout(nullptr, batch, batch * n_keys, n_keys).total;     // dense layout bounds the compact one
 }
 
 static NtArgs nt_plain(const float* A, int lda, const float* W, int ldw, const float* bias, float* C, int ldc, int M,
@@ -286,17 +347,17 @@ extern "C" int pc_p2v_attention_forward(const pc_p2v_tensors* p, const float* qu
     return attention_forward_impl(p, query, keys, B, N, B * N, nullptr, out, sv, ws, ws_bytes, stream);
 }
 
-// row_weight (optional, [key_rows]): multiplicity of each key row; rows with weight > 1 are shared by several
-// slots and collect their gradients by hardware float atomics (the only order-free sum of the step)
+// ref_off / ref_slot (optional, unique-neighbour layout): the slots of every key row; dK/dV are then formed row
+// by row in a second pass from per-slot softmax coefficients (fixed summation order, no atomics)
 int attention_backward_impl(const pc_p2v_tensors* p, const pc_p2v_tensors* g, const float* query, const float* keys,
                             int B, int N, int key_rows, const int32_t* slot_row, int pad_row, const float* dout,
                             const pc_attn_saved* sv, float* dquery, float* dkeys, int accumulate, void* ws,
-                            size_t ws_bytes, void* stream, const float* row_weight) {
+                            size_t ws_bytes, void* stream, const int32_t* ref_off, const int32_t* ref_slot) {
     PC_TRY(attn_check(p, B, N, key_rows, slot_row, sv, ws, ws_bytes));
     if (!g || !g->in_proj_w || !g->in_proj_b || !g->out_proj_w || !g->out_proj_b) return PC_EINVAL;
     if (!query || !keys || !dout || !dquery || !dkeys) return PC_EINVAL;
     hipStream_t st = (hipStream_t)stream;
-    AttnWs w = attn_ws_layout(ws, B, slot_row ? key_rows : B * N);
+    AttnWs w = attn_ws_layout(ws, B, slot_row ? key_rows : B * N, N);
     const SegInfo si1 = make_seginfo(nullptr, B, 128), si2 = make_seginfo(nullptr, key_rows, 128);
 
     TransposeBatch tb = {};
@@ -316,13 +377,19 @@ int attention_backward_impl(const pc_p2v_tensors* p, const pc_p2v_tensors* g, co
 
     const size_t lds = (size_t)4 * PC_HEADS * N * sizeof(float);
     const bool has_pad = slot_row && pad_row >= 0;
-    if (row_weight) {
-        PC_LAUNCH(zero_shared_rows_kernel, dim3((key_rows + 3) / 4), dim3(256), 0, st, w.dkv, row_weight, key_rows);
-        PC_TRY(pc_launch_status());
-    }
+    const bool by_rows = ref_off && ref_slot && slot_row;
     PC_LAUNCH(attn_core_bwd_kernel, dim3((B + 3) / 4), dim3(256), lds, st, w.dctx, sv->q, sv->kv, sv->probs,
-                       B, N, w.dq, w.dkv, slot_row, has_pad ? pad_row : -1, has_pad ? w.dkv_pad : nullptr, row_weight);
+                       B, N, w.dq, w.dkv, slot_row, has_pad ? pad_row : -1, has_pad ? w.dkv_pad : nullptr,
+                       by_rows ? w.coef : nullptr);
     PC_TRY(pc_launch_status());
+    if (by_rows) {
+        const int real_rows = has_pad ? key_rows - 1 : key_rows;
+        if (real_rows > 0) {
+            PC_LAUNCH(attn_dkv_rows_kernel, dim3((real_rows + 3) / 4), dim3(256), 0, st, w.coef, sv->q, w.dctx, ref_off,
+                      ref_slot, N, real_rows, w.dkv);
+            PC_TRY(pc_launch_status());
+        }
+    }
     if (has_pad) {
         PC_LAUNCH(colsum_partial_kernel, dim3(COLSUM_CHUNKS), dim3(256), 0, st, w.dkv_pad, B, w.pad_part);
         PC_TRY(pc_launch_status());
@@ -353,5 +420,5 @@ extern "C" int pc_p2v_attention_backward(const pc_p2v_tensors* p, const pc_p2v_t
                                          const pc_attn_saved* sv, float* dquery, float* dkeys, int accumulate,
                                          void* ws, size_t ws_bytes, void* stream) {
     return attention_backward_impl(p, g, query, keys, B, N, B * N, nullptr, -1, dout, sv, dquery, dkeys, accumulate, ws,
-                                   ws_bytes, stream, nullptr);
+                                   ws_bytes, stream, nullptr, nullptr);
 }

@@ -78,7 +78,7 @@ int attention_forward_impl(const pc_p2v_tensors* p, const float* query, const fl
 int attention_backward_impl(const pc_p2v_tensors* p, const pc_p2v_tensors* g, const float* query, const float* keys,
                             int B, int N, int key_rows, const int32_t* slot_row, int pad_row, const float* dout,
                             const pc_attn_saved* sv, float* dquery, float* dkeys, int accumulate, void* ws,
-                            size_t ws_bytes, void* stream, const float* row_weight);
+                            size_t ws_bytes, void* stream, const int32_t* ref_off, const int32_t* ref_slot);
 
 // nb_idx: neighbour rows of the step, nbc of them.  Dense layout: nbc = B*N slots in slot order
 // (slot_row NULL).  Compact layout: the M real neighbours then one -1 row (nbc = M + 1), slot_row[B*N]
@@ -89,7 +89,8 @@ static int p2v_step_impl(const pc_p2v_tensors* p, const pc_p2v_tensors* g, const
                          float* loss, float* d_pos, float* d_neg, float* anchor_emb, void* profile, void* ws,
                          size_t ws_bytes, void* stream, int phase = -1, double* fwd_sums = nullptr,
                          double* bwd_local = nullptr, const double* bwd_global = nullptr,
-                         const float* nb_weight = nullptr) {
+                         const float* nb_weight = nullptr, const int32_t* ref_off = nullptr,
+                         const int32_t* ref_slot = nullptr) {
     // nb_weight (unique-neighbour layout): multiplicity of each of the nbc neighbour rows (its last entry = the
     // number of padding slots); replaces the single weighted row of the compact layout
     // phase -1: the whole step with this replica's BatchNorm statistics; 0/1/2: see pc_p2v_train_step_compact_sync
@@ -153,7 +154,7 @@ static int p2v_step_impl(const pc_p2v_tensors* p, const pc_p2v_tensors* g, const
     if (N > 0) {
         PC_TRY(attention_backward_impl(p, g, w.y + (size_t)rA * PC_D, w.y + (size_t)rN * PC_D, B, N, nbc, slot_row,
                                        slot_row ? nbc - 1 : -1, w.demb, &as, w.dy + (size_t)rA * PC_D,
-                                       w.dy + (size_t)rN * PC_D, 0, w.attn_ws, w.attn_bytes, stream, nb_weight));
+                                       w.dy + (size_t)rN * PC_D, 0, w.attn_ws, w.attn_bytes, stream, ref_off, ref_slot));
     } else {
         PC_HIP_TRY(hipMemsetAsync(g->in_proj_w, 0, 3 * PC_D * PC_D * 4, st));
         PC_HIP_TRY(hipMemsetAsync(g->in_proj_b, 0, 3 * PC_D * 4, st));
@@ -202,18 +203,21 @@ extern "C" int pc_p2v_train_step_compact_sync(const pc_p2v_tensors* p, const pc_
 }
 
 // Unique-neighbour layout (see pcompanion_hip.h): nb_rows[n_unique + 1] distinct neighbour products then -1,
-// nb_weight[n_unique + 1] their multiplicities then the number of padding slots, slot_row[B*N] slot -> row.
+// nb_weight[n_unique + 1] their multiplicities then the number of padding slots, slot_row[B*N] slot -> row,
+// ref_off / ref_slot row -> slots.
 extern "C" int pc_p2v_train_step_unique(const pc_p2v_tensors* p, const pc_p2v_tensors* g, const float* table,
                                         const int32_t* anchor_idx, const int32_t* positive_idx,
                                         const int32_t* negative_idx, const int32_t* nb_rows, const float* nb_weight,
-                                        int n_unique, const int32_t* slot_row, int B, int N, int K, float margin,
+                                        int n_unique, const int32_t* slot_row, const int32_t* ref_off,
+                                        const int32_t* ref_slot, int B, int N, int K, float margin,
                                         float* loss, float* d_pos, float* d_neg, float* anchor_emb, void* profile,
                                         int phase, double* fwd_sums, double* bwd_local, const double* bwd_global,
                                         void* ws, size_t ws_bytes, void* stream) {
-    if (!slot_row || !nb_rows || !nb_weight || N <= 0 || n_unique < 0 || n_unique > B * N) return PC_EINVAL;
+    if (!slot_row || !nb_rows || !nb_weight || !ref_off || !ref_slot || N <= 0 || n_unique < 0 || n_unique > B * N)
+        return PC_EINVAL;
     if (phase < -1 || phase > 2) return PC_EINVAL;
     if (phase >= 0 && (!fwd_sums || !bwd_local || (phase == 2 && !bwd_global))) return PC_EINVAL;
     return p2v_step_impl(p, g, table, anchor_idx, positive_idx, negative_idx, nb_rows, n_unique + 1, slot_row, B, N, K,
                          margin, loss, d_pos, d_neg, anchor_emb, profile, ws, ws_bytes, stream, phase, fwd_sums,
-                         bwd_local, bwd_global, nb_weight);
+                         bwd_local, bwd_global, nb_weight, ref_off, ref_slot);
 }

@@ -166,88 +166,108 @@ __global__ void uq_count_kernel(const int32_t* anchor_idx, int B, const int32_t*
     if (j < deg) atomicAdd(&cnt[cv_col[lo + j]], 1);
 }
 
+// per chunk of products: (number present, number of slots) -> blocksum[2 * blk], blocksum[2 * blk + 1]
 __global__ __launch_bounds__(1024) void uq_block_sums_kernel(const int32_t* cnt, int P, int32_t* blocksum) {
-    __shared__ int red[16];
+    __shared__ int red[2][16];
     const int base = blockIdx.x * UQ_CHUNK + threadIdx.x * 4;
-    int s = 0;
+    int s = 0, c = 0;
 #pragma unroll
-    for (int i = 0; i < 4; i++) s += (base + i < P && cnt[base + i] > 0) ? 1 : 0;
+    for (int i = 0; i < 4; i++) { const int v = base + i < P ? cnt[base + i] : 0; s += v > 0 ? 1 : 0; c += v; }
 #pragma unroll
-    for (int o = 32; o >= 1; o >>= 1) s += __shfl_xor(s, o, 64);
-    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    for (int o = 32; o >= 1; o >>= 1) { s += __shfl_xor(s, o, 64); c += __shfl_xor(c, o, 64); }
+    if ((threadIdx.x & 63) == 0) { red[0][threadIdx.x >> 6] = s; red[1][threadIdx.x >> 6] = c; }
     __syncthreads();
     if (threadIdx.x == 0) {
-        int tot = 0;
-        for (int i = 0; i < 16; i++) tot += red[i];
-        blocksum[blockIdx.x] = tot;
+        int ts = 0, tc = 0;
+        for (int i = 0; i < 16; i++) { ts += red[0][i]; tc += red[1][i]; }
+        blocksum[2 * blockIdx.x] = ts;
+        blocksum[2 * blockIdx.x + 1] = tc;
     }
 }
 
 // exclusive scan of up to 4096 block sums in one workgroup; total -> n_unique
 __global__ __launch_bounds__(1024) void uq_scan_sums_kernel(int32_t* blocksum, int nblocks, int32_t* n_unique) {
-    __shared__ int part[1024];
+    __shared__ int part[2][1024];
     const int t = threadIdx.x;
     const int per = (nblocks + 1023) / 1024;
     const int lo = t * per, hi = min(nblocks, lo + per);
-    int s = 0;
-    for (int i = lo; i < hi; i++) s += blocksum[i];
-    part[t] = s;
+    int s = 0, c = 0;
+    for (int i = lo; i < hi; i++) { s += blocksum[2 * i]; c += blocksum[2 * i + 1]; }
+    part[0][t] = s; part[1][t] = c;
     __syncthreads();
     for (int o = 1; o < 1024; o <<= 1) {
-        const int v = t >= o ? part[t - o] : 0;
+        const int v = t >= o ? part[0][t - o] : 0, u = t >= o ? part[1][t - o] : 0;
         __syncthreads();
-        part[t] += v;
+        part[0][t] += v; part[1][t] += u;
         __syncthreads();
     }
-    int run = part[t] - s;
-    for (int i = lo; i < hi; i++) { const int v = blocksum[i]; blocksum[i] = run; run += v; }
-    if (t == 1023) n_unique[0] = part[1023];
+    int run = part[0][t] - s, runc = part[1][t] - c;
+    for (int i = lo; i < hi; i++) {
+        const int v = blocksum[2 * i], u = blocksum[2 * i + 1];
+        blocksum[2 * i] = run; blocksum[2 * i + 1] = runc;
+        run += v; runc += u;
+    }
+    if (t == 1023) n_unique[0] = part[0][1023];
 }
 
+// row of every present product (ascending product order), its multiplicity, and the start of its slot list
 __global__ __launch_bounds__(1024) void uq_assign_kernel(const int32_t* cnt, int P, const int32_t* blockoff, int32_t* rank,
-                                                         int32_t* nb_rows, float* nb_weight) {
-    __shared__ int wsum[16];
+                                                         int32_t* nb_rows, float* nb_weight, int32_t* ref_off,
+                                                         int32_t* cursor) {
+    __shared__ int wsum[2][16];
     const int base = blockIdx.x * UQ_CHUNK + threadIdx.x * 4;
-    int f[4], c[4], s = 0;
+    int f[4], c[4], s = 0, cs = 0;
 #pragma unroll
-    for (int i = 0; i < 4; i++) { c[i] = base + i < P ? cnt[base + i] : 0; f[i] = c[i] > 0; s += f[i]; }
-    // exclusive scan of the per-thread counts: within the wave by shuffles, across the 16 waves through LDS
-    int incl = s;
+    for (int i = 0; i < 4; i++) { c[i] = base + i < P ? cnt[base + i] : 0; f[i] = c[i] > 0; s += f[i]; cs += c[i]; }
+    // exclusive scans of the per-thread counts: within the wave by shuffles, across the 16 waves through LDS
+    int incl = s, inclc = cs;
 #pragma unroll
-    for (int o = 1; o < 64; o <<= 1) { const int v = __shfl_up(incl, o, 64); if ((threadIdx.x & 63) >= o) incl += v; }
-    if ((threadIdx.x & 63) == 63) wsum[threadIdx.x >> 6] = incl;
+    for (int o = 1; o < 64; o <<= 1) {
+        const int v = __shfl_up(incl, o, 64), u = __shfl_up(inclc, o, 64);
+        if ((threadIdx.x & 63) >= o) { incl += v; inclc += u; }
+    }
+    if ((threadIdx.x & 63) == 63) { wsum[0][threadIdx.x >> 6] = incl; wsum[1][threadIdx.x >> 6] = inclc; }
     __syncthreads();
-    int woff = 0;
-    for (int i = 0; i < (int)(threadIdx.x >> 6); i++) woff += wsum[i];
-    int r = blockoff[blockIdx.x] + woff + incl - s;
+    int woff = 0, woffc = 0;
+    for (int i = 0; i < (int)(threadIdx.x >> 6); i++) { woff += wsum[0][i]; woffc += wsum[1][i]; }
+    int r = blockoff[2 * blockIdx.x] + woff + incl - s;
+    int ro = blockoff[2 * blockIdx.x + 1] + woffc + inclc - cs;
 #pragma unroll
     for (int i = 0; i < 4; i++)
-        if (f[i]) { rank[base + i] = r; nb_rows[r] = base + i; nb_weight[r] = (float)c[i]; r++; }
+        if (f[i]) {
+            rank[base + i] = r; nb_rows[r] = base + i; nb_weight[r] = (float)c[i]; ref_off[r] = ro; cursor[r] = 0;
+            r++; ro += c[i];
+        }
 }
 
 __global__ void uq_slots_kernel(const int32_t* anchor_idx, int B, const int32_t* cv_rowptr, const int32_t* cv_col,
                                 int n_pad, const int32_t* rank, const int32_t* n_unique, int n_real, int32_t* cnt,
-                                int32_t* nb_rows, float* nb_weight, int32_t* slot_row) {
+                                int32_t* nb_rows, float* nb_weight, int32_t* slot_row, int32_t* ref_off,
+                                int32_t* cursor, int32_t* ref_slot) {
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= B * n_pad) return;
     const int b = t / n_pad, j = t % n_pad;
     const int a = anchor_idx[b];
     const int lo = cv_rowptr[a], deg = min(cv_rowptr[a + 1] - lo, n_pad);
     const int U = n_unique[0];
+    int row = U;
     if (j < deg) {
         const int pid = cv_col[lo + j];
-        slot_row[t] = rank[pid];
+        row = rank[pid];
         cnt[pid] = 0;                                       // leave the counters zeroed for the next batch
-    } else {
-        slot_row[t] = U;
+        // the row's slot list fills in arrival order (integer atomics); its consumer sorts the handful of
+        // entries of a row before summing, so the result does not depend on that order
+        ref_slot[ref_off[row] + atomicAdd(&cursor[row], 1)] = t;
     }
-    if (t == 0) { nb_rows[U] = -1; nb_weight[U] = (float)(B * n_pad - n_real); }
+    slot_row[t] = row;
+    if (t == 0) { nb_rows[U] = -1; nb_weight[U] = (float)(B * n_pad - n_real); ref_off[U] = n_real; ref_off[U + 1] = n_real; }
 }
 
-extern "C" size_t pc_build_similarity_batch_unique_scratch_bytes(int n_products) {
-    if (n_products <= 0) return 0;
+// layout: cnt[P] | rank[P] | blocksum[2 * nblk] | cursor[S]      (S = slots: an upper bound of the row count)
+extern "C" size_t pc_build_similarity_batch_unique_scratch_bytes(int n_products, int max_slots) {
+    if (n_products <= 0 || max_slots <= 0) return 0;
     const size_t nblk = ((size_t)n_products + UQ_CHUNK - 1) / UQ_CHUNK;
-    return ((size_t)n_products * 2 + nblk) * sizeof(int32_t);
+    return ((size_t)n_products * 2 + 2 * nblk + (size_t)max_slots + 1) * sizeof(int32_t);
 }
 
 extern "C" int pc_build_similarity_batch_unique(const int32_t* pair_ids, int batch, const int32_t* sim_pairs,
@@ -256,29 +276,33 @@ extern "C" int pc_build_similarity_batch_unique(const int32_t* pair_ids, int bat
                                                 int n_pad, int k_neg, uint64_t seed, uint64_t step, int n_real,
                                                 int32_t* anchor_idx, int32_t* positive_idx, int32_t* negative_idx,
                                                 int32_t* nb_rows, float* nb_weight, int32_t* slot_row,
-                                                int32_t* n_unique, void* scratch, size_t scratch_bytes, void* stream) {
+                                                int32_t* ref_off, int32_t* ref_slot, int32_t* n_unique, void* scratch,
+                                                size_t scratch_bytes, void* stream) {
     if (!pair_ids || !sim_pairs || !cv_rowptr || !cv_col || !sim_rowptr || !sim_col || !anchor_idx ||
-        !positive_idx || !negative_idx || !nb_rows || !nb_weight || !slot_row || !n_unique || !scratch)
+        !positive_idx || !negative_idx || !nb_rows || !nb_weight || !slot_row || !ref_off || !ref_slot || !n_unique ||
+        !scratch)
         return PC_EINVAL;
     if (batch <= 0 || n_pad <= 0 || k_neg <= 0 || n_products <= k_neg + 1 || n_real < 0 || n_real > batch * n_pad)
         return PC_EINVAL;
     const int nblk = (n_products + UQ_CHUNK - 1) / UQ_CHUNK;
     if (nblk > 4096) return PC_ESHAPE;                        // 16.7 M products with one scan workgroup
-    if (scratch_bytes < pc_build_similarity_batch_unique_scratch_bytes(n_products)) return PC_EWORKSPACE;
+    const int total = batch * n_pad;
+    if (scratch_bytes < pc_build_similarity_batch_unique_scratch_bytes(n_products, total)) return PC_EWORKSPACE;
     int32_t* cnt = (int32_t*)scratch;
     int32_t* rank = cnt + n_products;
     int32_t* blocksum = rank + n_products;
+    int32_t* cursor = blocksum + 2 * nblk;
     hipStream_t st = (hipStream_t)stream;
     PC_LAUNCH(build_pairs_negatives_kernel, dim3((batch + 127) / 128), dim3(128), 0, st, pair_ids, batch, sim_pairs,
               sim_rowptr, sim_col, n_products, k_neg, seed, step, anchor_idx, positive_idx, negative_idx);
     PC_TRY(pc_launch_status());
-    const int total = batch * n_pad;
     PC_LAUNCH(uq_count_kernel, dim3((total + 255) / 256), dim3(256), 0, st, anchor_idx, batch, cv_rowptr, cv_col, n_pad, cnt);
     PC_LAUNCH(uq_block_sums_kernel, dim3(nblk), dim3(1024), 0, st, cnt, n_products, blocksum);
     PC_LAUNCH(uq_scan_sums_kernel, dim3(1), dim3(1024), 0, st, blocksum, nblk, n_unique);
-    PC_LAUNCH(uq_assign_kernel, dim3(nblk), dim3(1024), 0, st, cnt, n_products, blocksum, rank, nb_rows, nb_weight);
+    PC_LAUNCH(uq_assign_kernel, dim3(nblk), dim3(1024), 0, st, cnt, n_products, blocksum, rank, nb_rows, nb_weight, ref_off,
+              cursor);
     PC_LAUNCH(uq_slots_kernel, dim3((total + 255) / 256), dim3(256), 0, st, anchor_idx, batch, cv_rowptr, cv_col, n_pad,
-              rank, n_unique, n_real, cnt, nb_rows, nb_weight, slot_row);
+              rank, n_unique, n_real, cnt, nb_rows, nb_weight, slot_row, ref_off, cursor, ref_slot);
     return pc_launch_status();
 }
 

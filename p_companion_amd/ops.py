@@ -320,7 +320,8 @@ def p2v_train_step(params, grads, table, anchor_idx, positive_idx, negative_idx,
             if unique:
                 check(_lib.lib().pc_p2v_train_step_unique(
                     ctypes.byref(st), ctypes.byref(gst), _p(table), _p(anchor_idx), _p(positive_idx), _p(negative_idx),
-                    _p(nb_rows), _p(neighbor_idx["weight"]), n_real, _p(slot_row), b, n, k, float(margin), _p(out["loss"]),
+                    _p(nb_rows), _p(neighbor_idx["weight"]), n_real, _p(slot_row), _p(neighbor_idx["ref_off"]),
+                    _p(neighbor_idx["ref_slot"]), b, n, k, float(margin), _p(out["loss"]),
                     _p(out["d_pos"]), _p(out["d_neg"]), _p(out.get("anchor_emb")), None, ph, _p(fwd), _p(bwd_local),
                     _p(bwd_global), _p(ws), nbytes, _stream()), "pc_p2v_train_step_unique")
                 return
@@ -339,7 +340,8 @@ def p2v_train_step(params, grads, table, anchor_idx, positive_idx, negative_idx,
     if unique:
         check(_lib.lib().pc_p2v_train_step_unique(
             ctypes.byref(st), ctypes.byref(gst), _p(table), _p(anchor_idx), _p(positive_idx), _p(negative_idx),
-            _p(nb_rows), _p(neighbor_idx["weight"]), n_real, _p(slot_row), b, n, k, float(margin), _p(out["loss"]),
+            _p(nb_rows), _p(neighbor_idx["weight"]), n_real, _p(slot_row), _p(neighbor_idx["ref_off"]),
+            _p(neighbor_idx["ref_slot"]), b, n, k, float(margin), _p(out["loss"]),
             _p(out["d_pos"]), _p(out["d_neg"]), _p(out.get("anchor_emb")), profile.handle if profile else None, -1, None,
             None, None, _p(ws), nbytes, _stream()), "pc_p2v_train_step_unique")
         return out
@@ -410,10 +412,13 @@ def build_similarity_batch_unique(pair_ids, graph, n_pad, k_neg, seed, step, n_r
     dev = pair_ids.device
     _req(pair_ids, torch.int32, "pair_ids")
     npr = int(graph["n_products"])
+    slots = b * n_pad
     key = (dev, npr)
-    if key not in _uq_scratch:          # per-product counters: zero-filled once, every call leaves them zeroed
-        nbytes = _lib.lib().pc_build_similarity_batch_unique_scratch_bytes(npr)
-        _uq_scratch[key] = torch.zeros(nbytes, dtype=torch.uint8, device=dev)
+    need = _lib.lib().pc_build_similarity_batch_unique_scratch_bytes(npr, slots)
+    if key not in _uq_scratch or _uq_scratch[key].numel() < need:
+        # per-product counters (first 4*P bytes): zero-filled once, every call leaves them zeroed
+        _uq_scratch[key] = torch.zeros(max(need, _lib.lib().pc_build_similarity_batch_unique_scratch_bytes(npr, 2 * slots)),
+                                       dtype=torch.uint8, device=dev)
     scratch = _uq_scratch[key]
     a = torch.empty(b, dtype=torch.int32, device=dev)
     p = torch.empty(b, dtype=torch.int32, device=dev)
@@ -422,12 +427,15 @@ def build_similarity_batch_unique(pair_ids, graph, n_pad, k_neg, seed, step, n_r
     weight = torch.empty(n_real + 1, dtype=torch.float32, device=dev)
     slot_row = torch.empty(b, n_pad, dtype=torch.int32, device=dev)
     n_unique = torch.empty(1, dtype=torch.int32, device=dev)
+    ref_off = torch.empty(n_real + 2, dtype=torch.int32, device=dev)
+    ref_slot = torch.empty(max(n_real, 1), dtype=torch.int32, device=dev)
     check(_lib.lib().pc_build_similarity_batch_unique(
         _p(pair_ids), b, _p(graph["sim_pairs"]), _p(graph["cv_rowptr"]), _p(graph["cv_col"]), _p(graph["sim_rowptr"]),
         _p(graph["sim_col"]), npr, n_pad, k_neg, int(seed), int(step), int(n_real), _p(a), _p(p), _p(ng), _p(nb_rows),
-        _p(weight), _p(slot_row), _p(n_unique), _p(scratch), scratch.numel(), _stream()),
+        _p(weight), _p(slot_row), _p(ref_off), _p(ref_slot), _p(n_unique), _p(scratch), scratch.numel(), _stream()),
         "pc_build_similarity_batch_unique")
-    return a, p, ng, {"nb_rows": nb_rows, "weight": weight, "slot_row": slot_row, "n_unique": n_unique}
+    return a, p, ng, {"nb_rows": nb_rows, "weight": weight, "slot_row": slot_row, "ref_off": ref_off,
+                      "ref_slot": ref_slot, "n_unique": n_unique}
 
 
 def unique_neighbors(neighbor_idx):
@@ -439,9 +447,12 @@ def unique_neighbors(neighbor_idx):
     weight = np.concatenate([cnt, [idx.size - int(real.sum())]]).astype(np.float32)
     slot = np.full(idx.shape, len(u), np.int32)
     slot[real] = inv.astype(np.int32)
+    order = np.argsort(slot.reshape(-1), kind="stable").astype(np.int32)[:int(real.sum())]   # real slots grouped by row
+    ref_off = np.concatenate([[0], np.cumsum(cnt), [int(real.sum())]]).astype(np.int32)      # [U + 2]: padding row lists none
     dev = neighbor_idx.device
     return {"nb_rows": torch.from_numpy(nb_rows).to(dev), "weight": torch.from_numpy(weight).to(dev),
-            "slot_row": torch.from_numpy(slot).to(dev), "n_unique": int(len(u))}
+            "slot_row": torch.from_numpy(slot).to(dev), "ref_off": torch.from_numpy(ref_off).to(dev),
+            "ref_slot": torch.from_numpy(order).to(dev), "n_unique": int(len(u))}
 
 
 def compact_neighbors(neighbor_idx):

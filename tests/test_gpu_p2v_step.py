@@ -328,6 +328,10 @@ def test_unique_neighbour_layout_equals_dense_and_golden(golden):
         assert U == ref["n_unique"]
         assert torch.equal(u["nb_rows"][:U + 1], ref["nb_rows"]) and torch.equal(u["weight"][:U + 1], ref["weight"])
         assert torch.equal(u["slot_row"], ref["slot_row"]) and torch.equal(a, a2) and torch.equal(ng, ng2)
+        assert torch.equal(u["ref_off"][:U + 2], ref["ref_off"])
+        ro, rs, rr = u["ref_off"].cpu().numpy(), u["ref_slot"].cpu().numpy(), ref["ref_slot"].cpu().numpy()
+        for r in range(0, U, 97):                              # same slots per row (arrival order is free)
+            assert sorted(rs[ro[r]:ro[r + 1]].tolist()) == rr[ro[r]:ro[r + 1]].tolist()
 
 
 
