@@ -45,6 +45,13 @@ def nt_algorithmic_bytes(b, nbc):
     return 1024 * (r * (1.5 + 2.0 + 1.5 + 2.5 + 3.0) + nbc * (1.5 + 1.5))
 
 
+def executed_flops_per_step(b, nbc):
+    """FLOPs of the GEMMs one step actually runs: FFN forward + backward without dX of Linear0 over
+    R = 7b + nbc rows (720,896 per row), K|V projection + dKeys + dW_kv over the nbc neighbour rows and the
+    q / out projections with their backward over the b samples (196,608 each)."""
+    return 720896.0 * (7 * b + nbc) + 196608.0 * (nbc + b)
+
+
 def bytes_per_triplet(n):
     return 512 * (n + 7) + 4 * (n + 7)
 
@@ -294,6 +301,10 @@ def main():
                                       "avg_launch_us": round(1e3 * sm["total_ms"] / max(sm["launches"], 1), 2),
                                       "share_of_step": round(sm["total_ms"] / (el * 1e3), 3)} if sm["launches"] else None),
             "whole_step": {"flops_per_triplet": flops_per_triplet(round(n_avg)),
+                           # `achieved` prices the step at the reference's dense formulation (every slot its own
+                           # row); `executed` counts the rows actually multiplied (identical rows carried once)
+                           "executed_flops_per_triplet": round(executed_flops_per_step(args.batch, real_sum / max(args.steps, 1) + 1) / args.batch),
+                           "executed": round(executed_flops_per_step(args.batch, real_sum / max(args.steps, 1) + 1) / args.batch * value / world / 1e12, 2),
                            "achieved": round(flops_per_triplet(n_avg) * value / world / 1e12, 2),
                            "frac_mfma": round(flops_per_triplet(n_avg) * value / world / 1e12 / FP32_MFMA_PEAK_TFLOPS, 4),
                            "gather_bytes_per_triplet": bytes_per_triplet(round(n_avg)),
