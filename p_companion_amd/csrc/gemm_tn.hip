@@ -173,12 +173,21 @@ __device__ __forceinline__ void tn_lds_sync() {
 }
 
 template <int WO, int WI, int TO, int TI, int TKC, int NST, bool APRO, bool ZPRO>
-__global__ __launch_bounds__(512, 2) void gemm_tn8_kernel(TnArgs a, int nsplit, int rows_per_split) {
+__global__ __launch_bounds__(64 * WO * WI, WO * WI / 4) void gemm_tn8_kernel(TnArgs a, int nsplit, int rows_per_split) {
+    constexpr int NWV = WO * WI, THREADS = 64 * NWV;            // 8 waves (2 per SIMD) or 16 (4 per SIMD)
     constexpr int NO = WO * TO * 32, NI = WI * TI * 32;
-    constexpr int ZF = TKC * NO, AF = TKC * NI;                  // floats per stage image
+    // Image rows must not start on the same LDS bank two rows apart in the MFMA's k pair (lanes 0-31 read row k,
+    // lanes 32-63 row k+1, same columns): a 256-wide image is stored with row stride 288 floats (each wave
+    // instruction is one row: it is simply dropped 128 B further), a 128-wide one keeps stride 128 and swaps the
+    // two 32-float halves of every 64 in its ODD rows (the lanes of the second row of an instruction fetch the
+    // other half; the fragment / in-place readers of odd rows flip bit 5 of the column).
+    constexpr int ZRS = NO == 256 ? 288 : NO, ARS = NI == 256 ? 288 : NI;     // row strides
+    constexpr bool ZSW = NO == 128, ASW = NI == 128;                          // odd-row half swap
+    static_assert((NO == 128 || NO == 256) && (NI == 128 || NI == 256), "image widths");
+    constexpr int ZF = TKC * ZRS, AF = TKC * ARS;                // floats per stage image
     constexpr int STAGE = ZF * (ZPRO ? 2 : 1) + AF;              // Z [, H], A
-    constexpr int JZ = ZF / 256 / 8, JA = AF / 256 / 8;          // DMA instructions per wave and image
-    static_assert(ZF % 2048 == 0 && AF % 2048 == 0, "images must split into whole wave instructions over 8 waves");
+    constexpr int JZ = TKC * NO / 256 / NWV, JA = TKC * NI / 256 / NWV;      // DMA instructions per wave and image
+    static_assert((TKC * NO) % (256 * NWV) == 0 && (TKC * NI) % (256 * NWV) == 0, "images must split into whole wave instructions over the waves");
     constexpr int JALL = JZ * (ZPRO ? 2 : 1) + JA;              // DMA instructions per wave and stage
     __shared__ __attribute__((aligned(1024))) float smem[NST * STAGE];
 
@@ -190,12 +199,24 @@ __global__ __launch_bounds__(512, 2) void gemm_tn8_kernel(TnArgs a, int nsplit, 
     const float* const zsrc0 = pc_tn_zero_chunk;
     const unsigned lds0 = (unsigned)(uintptr_t)(tn_lptr_t)&smem[0];
 
-    // DMA geometry: instruction g = w + 8 j of an image covers its floats [256 g, 256 g + 256)
+    // DMA geometry: instruction g = w + NWV j of an image covers its floats [256 g, 256 g + 256)
+    // (zc / ac: the GLOBAL column this lane fetches; zd / ad: byte offset of the instruction inside the image)
     int zr[JZ], zc[JZ], ar[JA], ac[JA];
+    unsigned zd[JZ], ad[JA];
 #pragma unroll
-    for (int j = 0; j < JZ; j++) { const int f = (w + 8 * j) * 256 + lane * 4; zr[j] = f / NO; zc[j] = f % NO; }
+    for (int j = 0; j < JZ; j++) {
+        const int g = w + NWV * j, f = g * 256 + lane * 4;
+        zr[j] = f / NO; zc[j] = f % NO;
+        if (ZSW && (zr[j] & 1)) zc[j] ^= 32;
+        zd[j] = (NO == 256 ? g * ZRS : g * 256) * 4;
+    }
 #pragma unroll
-    for (int j = 0; j < JA; j++) { const int f = (w + 8 * j) * 256 + lane * 4; ar[j] = f / NI; ac[j] = f % NI; }
+    for (int j = 0; j < JA; j++) {
+        const int g = w + NWV * j, f = g * 256 + lane * 4;
+        ar[j] = f / NI; ac[j] = f % NI;
+        if (ASW && (ar[j] & 1)) ac[j] ^= 32;
+        ad[j] = (NI == 256 ? g * ARS : g * 256) * 4;
+    }
     int gidx[JA];                                                // gather indices of the NEXT chunk to issue
     auto load_gather = [&](int r0) {
 #pragma unroll
@@ -205,23 +226,23 @@ __global__ __launch_bounds__(512, 2) void gemm_tn8_kernel(TnArgs a, int nsplit, 
         }
     };
     auto issue = [&](int st, int r0) {
-        const unsigned base = lds0 + st * (STAGE * 4) + w * 1024;
+        const unsigned base = lds0 + st * (STAGE * 4);
 #pragma unroll
         for (int j = 0; j < JZ; j++) {
             const int r = r0 + zr[j];
             const bool v = r < r_end && zc[j] < a.No;
-            tn_dma16(v ? a.Z + (size_t)r * a.ldz + zc[j] : zsrc0, base + j * 8192);
-            if (ZPRO) tn_dma16(v ? a.zaux + (size_t)r * a.ldzaux + zc[j] : zsrc0, base + ZF * 4 + j * 8192);
+            tn_dma16(v ? a.Z + (size_t)r * a.ldz + zc[j] : zsrc0, base + zd[j]);
+            if (ZPRO) tn_dma16(v ? a.zaux + (size_t)r * a.ldzaux + zc[j] : zsrc0, base + ZF * 4 + zd[j]);
         }
 #pragma unroll
         for (int j = 0; j < JA; j++) {
             const int r = r0 + ar[j];
             const bool v = r < r_end && ac[j] < a.Ni && gidx[j] >= 0;
-            tn_dma16(v ? a.A + (size_t)gidx[j] * a.lda + ac[j] : zsrc0, base + (ZPRO ? 2 : 1) * ZF * 4 + j * 8192);
+            tn_dma16(v ? a.A + (size_t)gidx[j] * a.lda + ac[j] : zsrc0, base + (ZPRO ? 2 : 1) * ZF * 4 + ad[j]);
         }
     };
 
-    // in-place loaders: thread t owns 4 fixed columns and every (512 / (N/4))-th row of an image
+    // in-place loaders: thread t owns 4 fixed columns and every (THREADS / (N/4))-th row of an image
     constexpr int ZT = NO / 4, AT = NI / 4;
     const int zrow = tid / ZT, zcol = (tid % ZT) * 4, arow = tid / AT, acol = (tid % AT) * 4;
     int zseg = -1, aseg = -1;
@@ -231,8 +252,8 @@ __global__ __launch_bounds__(512, 2) void gemm_tn8_kernel(TnArgs a, int nsplit, 
             float* Zs = stage;
             const float* Hs = stage + ZF;
 #pragma unroll
-            for (int p = 0; p < TKC / (512 / ZT); p++) {
-                const int rr = zrow + (512 / ZT) * p, r = r0 + rr;
+            for (int p = 0; p < TKC / (THREADS / ZT); p++) {
+                const int rr = zrow + (THREADS / ZT) * p, r = r0 + rr;
                 if (r < r_end) {
                     const int s = seg_of_row(a.seg, r);
                     if (s != zseg) {
@@ -244,22 +265,23 @@ __global__ __launch_bounds__(512, 2) void gemm_tn8_kernel(TnArgs a, int nsplit, 
                         zc2 = *reinterpret_cast<const float4*>(a.z_c2 + o);
                         zseg = s;
                     }
-                    float4 z = *reinterpret_cast<const float4*>(&Zs[rr * NO + zcol]);
-                    const float4 h = *reinterpret_cast<const float4*>(&Hs[rr * NO + zcol]);
+                    const int zp = rr * ZRS + ((ZSW && (rr & 1)) ? zcol ^ 32 : zcol);
+                    float4 z = *reinterpret_cast<const float4*>(&Zs[zp]);
+                    const float4 h = *reinterpret_cast<const float4*>(&Hs[zp]);
                     const float zm = row_multiplicity(a.seg, r);
                     z.x = zsc.x * (z.x - zm * (zc1.x + (h.x - zmu.x) * zis.x * zc2.x));
                     z.y = zsc.y * (z.y - zm * (zc1.y + (h.y - zmu.y) * zis.y * zc2.y));
                     z.z = zsc.z * (z.z - zm * (zc1.z + (h.z - zmu.z) * zis.z * zc2.z));
                     z.w = zsc.w * (z.w - zm * (zc1.w + (h.w - zmu.w) * zis.w * zc2.w));
-                    *reinterpret_cast<float4*>(&Zs[rr * NO + zcol]) = z;
+                    *reinterpret_cast<float4*>(&Zs[zp]) = z;
                 }
             }
         }
         if (APRO && acol < a.Ni) {
             float* As = stage + (ZPRO ? 2 : 1) * ZF;
 #pragma unroll
-            for (int p = 0; p < TKC / (512 / AT); p++) {
-                const int rr = arow + (512 / AT) * p, r = r0 + rr;
+            for (int p = 0; p < TKC / (THREADS / AT); p++) {
+                const int rr = arow + (THREADS / AT) * p, r = r0 + rr;
                 if (r < r_end) {
                     const int s = seg_of_row(a.seg, r);
                     if (s != aseg) {
@@ -267,12 +289,13 @@ __global__ __launch_bounds__(512, 2) void gemm_tn8_kernel(TnArgs a, int nsplit, 
                         ash = *reinterpret_cast<const float4*>(a.pshift + (size_t)s * a.Ni + acol);
                         aseg = s;
                     }
-                    float4 x = *reinterpret_cast<const float4*>(&As[rr * NI + acol]);
+                    const int ap = rr * ARS + ((ASW && (rr & 1)) ? acol ^ 32 : acol);
+                    float4 x = *reinterpret_cast<const float4*>(&As[ap]);
                     x.x = fast_tanh(x.x * asc.x + ash.x);
                     x.y = fast_tanh(x.y * asc.y + ash.y);
                     x.z = fast_tanh(x.z * asc.z + ash.z);
                     x.w = fast_tanh(x.w * asc.w + ash.w);
-                    *reinterpret_cast<float4*>(&As[rr * NI + acol]) = x;
+                    *reinterpret_cast<float4*>(&As[ap]) = x;
                 }
             }
         }
@@ -300,8 +323,13 @@ __global__ __launch_bounds__(512, 2) void gemm_tn8_kernel(TnArgs a, int nsplit, 
     for (int i = 0; i < NST - 1; i++)
         if (i < nchunk) { load_gather(r_begin + i * TKC); issue(i, r_begin + i * TKC); }
     if (NST - 1 < nchunk) load_gather(r_begin + (NST - 1) * TKC);
-    const int fz = (lane >> 5) * NO + wo * (TO * 32) + (lane & 31);
-    const int fa = (lane >> 5) * NI + wi * (TI * 32) + (lane & 31);
+    // lanes 32-63 read the odd row of each pair: in a half-swapped image their columns have bit 5 flipped
+    const int fz = (lane >> 5) * ZRS, fa = (lane >> 5) * ARS;
+    int zo[TO], xo[TI];                                        // this lane's column of each 32-wide block
+#pragma unroll
+    for (int i = 0; i < TO; i++) zo[i] = (wo * (TO * 32) + 32 * i + (lane & 31)) ^ ((ZSW && lane >= 32) ? 32 : 0);
+#pragma unroll
+    for (int j = 0; j < TI; j++) xo[j] = (wi * (TI * 32) + 32 * j + (lane & 31)) ^ ((ASW && lane >= 32) ? 32 : 0);
     int cur = 0;
     for (int c = 0; c < nchunk; c++) {
         if (c + NST - 1 <= nchunk) { asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NST - 2) * JALL) : "memory"); }
@@ -319,26 +347,26 @@ __global__ __launch_bounds__(512, 2) void gemm_tn8_kernel(TnArgs a, int nsplit, 
         // otherwise sinks each read to just before its MFMA and exposes the LDS latency 16x per chunk)
         float z[2][TO], x[2][TI];
 #pragma unroll
-        for (int i = 0; i < TO; i++) z[0][i] = Zs[32 * i];
+        for (int i = 0; i < TO; i++) z[0][i] = Zs[zo[i]];
 #pragma unroll
-        for (int j = 0; j < TI; j++) x[0][j] = As[32 * j];
+        for (int j = 0; j < TI; j++) x[0][j] = As[xo[j]];
 #pragma unroll
         for (int k = 0; k < TKC; k += 2) {
             const int b = (k >> 1) & 1;
             if (k + 2 < TKC) {
 #pragma unroll
-                for (int i = 0; i < TO; i++) z[b ^ 1][i] = Zs[(k + 2) * NO + 32 * i];
+                for (int i = 0; i < TO; i++) z[b ^ 1][i] = Zs[(k + 2) * ZRS + zo[i]];
 #pragma unroll
-                for (int j = 0; j < TI; j++) x[b ^ 1][j] = As[(k + 2) * NI + 32 * j];
+                for (int j = 0; j < TI; j++) x[b ^ 1][j] = As[(k + 2) * ARS + xo[j]];
             }
+            __builtin_amdgcn_sched_barrier(0);          // the requests above stay above the MFMAs below
 #pragma unroll
             for (int i = 0; i < TO; i++) {
                 zsum[i] += z[b][i];
 #pragma unroll
                 for (int j = 0; j < TI; j++) acc[i][j] = mfma32(z[b][i], x[b][j], acc[i][j]);
             }
-            if (k + 2 < TKC) __builtin_amdgcn_sched_group_barrier(0x100, TO + TI, 0);
-            __builtin_amdgcn_sched_group_barrier(0x008, TO * TI, 0);
+            __builtin_amdgcn_sched_barrier(0);
         }
         cur = cur + 1 == NST ? 0 : cur + 1;
     }
@@ -440,9 +468,9 @@ int launch_gemm_tn(const TnArgs& a, hipStream_t st) {
     if (tn_full_tile(a.R, a.No, a.Ni) && !(apro && zpro)) {
 #define TN8(WO, WI, TO, TI)                                                                                   \
     do {                                                                                                      \
-        if (apro) PC_LAUNCH((gemm_tn8_kernel<WO, WI, TO, TI, 32, 2, true, false>), dim3(nsplit), dim3(512), 0, st, a, nsplit, rps);       \
-        else if (zpro) PC_LAUNCH((gemm_tn8_kernel<WO, WI, TO, TI, 16, 3, false, true>), dim3(nsplit), dim3(512), 0, st, a, nsplit, rps);  \
-        else PC_LAUNCH((gemm_tn8_kernel<WO, WI, TO, TI, 32, 2, false, false>), dim3(nsplit), dim3(512), 0, st, a, nsplit, rps);           \
+        if (apro) PC_LAUNCH((gemm_tn8_kernel<WO, WI, TO, TI, 32, 2, true, false>), dim3(nsplit), dim3(64 * WO * WI), 0, st, a, nsplit, rps);       \
+        else if (zpro) PC_LAUNCH((gemm_tn8_kernel<4, 2, 2, 2, 16, 3, false, true>), dim3(nsplit), dim3(512), 0, st, a, nsplit, rps);  \
+        else PC_LAUNCH((gemm_tn8_kernel<WO, WI, TO, TI, 32, 2, false, false>), dim3(nsplit), dim3(64 * WO * WI), 0, st, a, nsplit, rps);           \
     } while (0)
         if (a.No > 128 && a.Ni > 128) TN8(2, 4, 4, 2);
         else if (a.No > 128) TN8(4, 2, 2, 2);
