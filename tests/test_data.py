@@ -57,3 +57,41 @@ def test_complementary_dataset_split_and_labels(golden):
         tt = int(bpg.type_idx[t])
         assert want["positive_types"] == (tt if lab == 1 else 0)
         assert want["negative_types"] == (tt if lab == -1 else (tt + 1) % bpg.n_types)
+
+
+def test_unique_neighbor_layout_host_construction():
+    """ops.unique_neighbors (the host-side mirror of pc_build_similarity_batch_unique): rows = distinct products
+    ascending, weights = multiplicities (+ padding count), slot map and per-row slot lists consistent."""
+    import torch
+    from p_companion_amd import ops
+    rng = np.random.default_rng(0)
+    idx = rng.integers(0, 40, size=(16, 6)).astype(np.int32)
+    idx[rng.random(idx.shape) < 0.3] = -1
+    u = ops.unique_neighbors(torch.from_numpy(idx))
+    U = u["n_unique"]
+    rows, w, slot = u["nb_rows"].numpy(), u["weight"].numpy(), u["slot_row"].numpy()
+    real = idx >= 0
+    assert np.array_equal(rows[:U], np.unique(idx[real])) and rows[U] == -1
+    assert w[:U].sum() == real.sum() and w[U] == (~real).sum()
+    assert np.array_equal(rows[slot][real], idx[real]) and (slot[~real] == U).all()
+    ro, rs = u["ref_off"].numpy(), u["ref_slot"].numpy()
+    assert ro[0] == 0 and ro[U] == ro[U + 1] == real.sum() and len(rs) == real.sum()
+    for r in range(U):
+        s = rs[ro[r]:ro[r + 1]]
+        assert len(s) == w[r] and (np.diff(s) > 0).all() and (slot.reshape(-1)[s] == r).all()
+
+
+def test_recommend_oracle_matches_bruteforce():
+    """oracle.joint_oracle.recommend (restatement of inference.py:90-118) on a toy catalogue."""
+    from oracle import joint_oracle
+    rng = np.random.default_rng(1)
+    feats = rng.standard_normal((50, 128)).astype(np.float32)
+    types = rng.integers(0, 5, 50)
+    proj = rng.standard_normal((4, 128)).astype(np.float32)
+    want = np.array([0, 3, 3, 4])
+    out = joint_oracle.recommend(proj, want, types, feats, 3)
+    for r, (ids, sc) in enumerate(out):
+        cand = np.nonzero(types == want[r])[0]
+        s = feats[cand] @ proj[r]
+        best = cand[np.argsort(-s)[:3]]
+        assert np.array_equal(ids, best) and np.allclose(sc, np.sort(s)[::-1][:3], atol=1e-5)
