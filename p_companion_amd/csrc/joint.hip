@@ -263,8 +263,8 @@ __global__ __launch_bounds__(256) void type_hinge_bwd_kernel(const float* dsims_
     const float cb = c[(size_t)b * PC_L + lane];
     dc[(size_t)b * PC_L + lane] = v0 * ec[(size_t)p * PC_L + lane] + v1 * ec[(size_t)n * PC_L + lane];
     if (v0 != 0.f || v1 != 0.f) {
-        atomicAdd(dec + (size_t)p * PC_L + lane, v0 * cb);
-        atomicAdd(dec + (size_t)n * PC_L + lane, v1 * cb);
+        unsafeAtomicAdd(dec + (size_t)p * PC_L + lane, v0 * cb);
+        unsafeAtomicAdd(dec + (size_t)n * PC_L + lane, v1 * cb);
     }
 }
 

@@ -169,7 +169,7 @@ __global__ void scatter_add_rows_kernel(float* table, const int32_t* idx, int ro
     if (t >= total) return;
     const int r = (int)(t / width), c = (int)(t % width);
     const int dst = idx[r];
-    if (dst >= 0) atomicAdd(table + (size_t)dst * width + c, src[t]);
+    if (dst >= 0) unsafeAtomicAdd(table + (size_t)dst * width + c, src[t]);
 }
 
 // Small tables (the [T,64] type tables at T ~ 100: thousands of source rows collide on a few
@@ -186,12 +186,12 @@ __global__ __launch_bounds__(256) void scatter_add_rows_lds_kernel(float* table,
     const int r0 = blockIdx.x * rows_per_block, r1 = min(rows, r0 + rows_per_block);
     for (int t = r0 * width + threadIdx.x; t < r1 * width; t += blockDim.x) {
         const int dst = idx[t / width];
-        if (dst >= 0) atomicAdd(&priv[dst * width + t % width], src[t]);
+        if (dst >= 0) unsafeAtomicAdd(&priv[dst * width + t % width], src[t]);      // ds_add_f32 (plain atomicAdd would compile to a CAS loop)
     }
     __syncthreads();
     for (int i = threadIdx.x; i < n; i += blockDim.x) {
         const float v = priv[i];
-        if (v != 0.f) atomicAdd(table + i, v);
+        if (v != 0.f) unsafeAtomicAdd(table + i, v);
     }
 }
 
