@@ -181,7 +181,8 @@ int pc_p2v_train_step_compact(const pc_p2v_tensors *p, const pc_p2v_tensors *g, 
                               float *loss, float *d_pos, float *d_neg, float *anchor_emb, void *profile,
                               void *ws, size_t ws_bytes, void *stream);
 
-/* Unique-neighbour layout: the co-view neighbours of a batch repeat (about a third of the real slots of a
+/* The same loop body (product2vec.py:126-159) in the unique-neighbour layout: the co-view neighbours
+ * (bpg.get_neighbors, bpg.py:24-38, gathered per sample by data_loader.py:71-88) of a batch repeat (about a third of the real slots of a
  * 4096-anchor batch over 100 k products); identical table rows are identical FFN rows inside one BatchNorm
  * call, so -- exactly as for the zero-padding rows -- every DISTINCT neighbour product is carried once:
  *   nb_rows[n_unique + 1]    the distinct products (ascending) then -1 (the shared padding row)
@@ -203,7 +204,8 @@ int pc_p2v_train_step_unique(const pc_p2v_tensors *p, const pc_p2v_tensors *g, c
                              void *profile, int phase, double *fwd_sums, double *bwd_local,
                              const double *bwd_global, void *ws, size_t ws_bytes, void *stream);
 
-/* Cross-replica BatchNorm statistics for data-parallel replicas ("all_reduce(sum) of
+/* The same loop body (product2vec.py:126-159; its four BatchNorm1d calls are ffn[1] of :14-21 reached through
+ * :73,:78) with cross-replica BatchNorm statistics for data-parallel replicas ("all_reduce(sum) of
  * [2,256] sums + row count, once per BN call"): the same step, cut at the two points where BatchNorm needs
  * batch-wide sums.  Every replica runs
  *   phase 0   batch rows + Linear0 + per-segment sums          -> fwd_sums  (this replica)
