@@ -132,6 +132,45 @@ __device__ __forceinline__ float group16_sum(float v) {
 __device__ __forceinline__ f32x16 mfma32(float a, float b, f32x16 c) {
     return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
 }
+
+// ---- fp32-grade products on the BF16 matrix cores (16x the fp32 MFMA rate): every fp32 operand value is split
+// into three bf16 pieces, a = a0 + a1 + a2 (8 + 8 + 8 mantissa bits; the first two residuals are exact in fp32),
+// and the six significant cross products a0b0, a0b1, a1b0, a1b1, a0b2, a2b0 are accumulated in fp32 by
+// v_mfma_f32_32x32x16_bf16.  Measured error against an fp64 product: the same as v_mfma_f32_32x32x2_f32's
+// (scripts/microbench/nt_bf16x6.hip: 7.9e-5 vs 9.4e-5 on K = 2048 sums of magnitude 58).
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+struct Split3 { bf16x8 p0, p1, p2; };
+// Pieces by TRUNCATION (top 16 bits of the fp32 pattern): a0 = trunc(a), r1 = a - a0 (exact), a1 = trunc(r1),
+// r2 = r1 - a1 (exact), a2 = trunc(r2): |a - (a0+a1+a2)| < 2^-24 |a|.  Only full-rate VALU instructions
+// (v_and / v_sub / v_perm): the RNE conversion v_cvt_pk_bf16_f32 made the split, not the matrix pipe, the bound.
+__device__ __forceinline__ Split3 split3(const float4& lo, const float4& hi) {
+    const float v[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+    unsigned u0[8], u1[8], u2[8];
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        u0[i] = __float_as_uint(v[i]);
+        const float r1 = v[i] - __uint_as_float(u0[i] & 0xffff0000u);
+        u1[i] = __float_as_uint(r1);
+        const float r2 = r1 - __uint_as_float(u1[i] & 0xffff0000u);
+        u2[i] = __float_as_uint(r2);
+    }
+    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+    u32x4 q0, q1, q2;
+#pragma unroll
+    for (int j = 0; j < 4; j++) {            // dword j = {element 2j+1 (high half), element 2j (low half)}: the high halves of two words
+        q0[j] = __builtin_amdgcn_perm(u0[2 * j + 1], u0[2 * j], 0x07060302u);
+        q1[j] = __builtin_amdgcn_perm(u1[2 * j + 1], u1[2 * j], 0x07060302u);
+        q2[j] = __builtin_amdgcn_perm(u2[2 * j + 1], u2[2 * j], 0x07060302u);
+    }
+    Split3 s;
+    s.p0 = __builtin_bit_cast(bf16x8, q0);
+    s.p1 = __builtin_bit_cast(bf16x8, q1);
+    s.p2 = __builtin_bit_cast(bf16x8, q2);
+    return s;
+}
+__device__ __forceinline__ f32x16 mfma_bf16(const bf16x8& a, const bf16x8& b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+}
 #endif
 
 // ---- optional per-launch timing (bench.py roofline leg): HIP events recorded on the launch

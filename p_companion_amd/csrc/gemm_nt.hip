@@ -180,33 +180,31 @@ __global__ __launch_bounds__(64 * NWM * NWN, WPS) void gemm_nt_kernel(NtArgs a, 
     const int fsw = ((lane >> 5) ^ ((fr / RB) % CPR)) << 2;            // kk = 0; kk > 0 flips bits above it
     const int fa = (wm * 64 + fr) * BK + fsw, fb = (BM + wn * 64 + fr) * BK + fsw;
 
+    // One K-step = one k group of 16: lane (row fr, half lane >> 5) holds k = 8 (lane >> 5) .. + 7 of its rows, i.e. the
+    // two 16-B chunks 2 (lane >> 5), + 1 of the stage row.  A blocks are split once, each W block as it is used;
+    // the six products of every accumulator are issued term by term across the four accumulators (no back-to-back
+    // dependent MFMAs).
+    static_assert(BK == 16 || BK == 32, "k groups of 16");
+    const int gsw = (fr / RB) % CPR;                                        // the row's chunk swizzle
     auto compute = [&](const float* cur) {
-        float4 fa0 = *reinterpret_cast<const float4*>(&cur[fa]), fa1 = *reinterpret_cast<const float4*>(&cur[fa + 32 * BK]);
-        float4 fb0 = *reinterpret_cast<const float4*>(&cur[fb]), fb1 = *reinterpret_cast<const float4*>(&cur[fb + 32 * BK]);
 #pragma unroll
-        for (int kk = 0; kk < BK / 8; kk++) {
-            float4 na0 = fa0, na1 = fa1, nb0 = fb0, nb1 = fb1;
-            if (kk + 1 < BK / 8) {
-                const int x = (kk + 1) << 3;                            // chunk 2(kk+1): XOR into the swizzled offset
-                na0 = *reinterpret_cast<const float4*>(&cur[fa ^ x]);
-                na1 = *reinterpret_cast<const float4*>(&cur[(fa ^ x) + 32 * BK]);
-                nb0 = *reinterpret_cast<const float4*>(&cur[fb ^ x]);
-                nb1 = *reinterpret_cast<const float4*>(&cur[(fb ^ x) + 32 * BK]);
-            }
-            const float av0[4] = {fa0.x, fa0.y, fa0.z, fa0.w}, av1[4] = {fa1.x, fa1.y, fa1.z, fa1.w};
-            const float bv0[4] = {fb0.x, fb0.y, fb0.z, fb0.w}, bv1[4] = {fb1.x, fb1.y, fb1.z, fb1.w};
+        for (int g = 0; g < BK / 16; g++) {
+            const int c0 = (((4 * g + 2 * (lane >> 5)) ^ gsw) << 2), c1 = (((4 * g + 2 * (lane >> 5) + 1) ^ gsw) << 2);
+            const float* ar = cur + (wm * 64 + fr) * BK;
+            const float* br = cur + (BM + wn * 64 + fr) * BK;
+            Split3 sa[2];
 #pragma unroll
-            for (int r = 0; r < 4; r++) {
-                acc[0][0] = mfma32(av0[r], bv0[r], acc[0][0]);
-                acc[0][1] = mfma32(av0[r], bv1[r], acc[0][1]);
-                acc[1][0] = mfma32(av1[r], bv0[r], acc[1][0]);
-                acc[1][1] = mfma32(av1[r], bv1[r], acc[1][1]);
+            for (int i = 0; i < 2; i++)
+                sa[i] = split3(*reinterpret_cast<const float4*>(ar + i * 32 * BK + c0), *reinterpret_cast<const float4*>(ar + i * 32 * BK + c1));
+#pragma unroll
+            for (int j = 0; j < 2; j++) {
+                const Split3 sb = split3(*reinterpret_cast<const float4*>(br + j * 32 * BK + c0), *reinterpret_cast<const float4*>(br + j * 32 * BK + c1));
+#define PC_TERM(PA, PB)                                                   \
+                acc[0][j] = mfma_bf16(sa[0].PA, sb.PB, acc[0][j]);        \
+                acc[1][j] = mfma_bf16(sa[1].PA, sb.PB, acc[1][j]);
+                PC_TERM(p2, p0) PC_TERM(p0, p2) PC_TERM(p1, p1) PC_TERM(p1, p0) PC_TERM(p0, p1) PC_TERM(p0, p0)
             }
-            fa0 = na0; fa1 = na1; fb0 = nb0; fb1 = nb1;
-            // keep the request one whole block ahead of its use (the scheduler otherwise sinks the
-            // reads to just before the MFMA that consumes them and exposes the LDS latency)
-            if (kk + 1 < BK / 8) __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
-            __builtin_amdgcn_sched_group_barrier(0x008, 16, 0);
+#undef PC_TERM
         }
     };
 

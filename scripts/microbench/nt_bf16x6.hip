@@ -20,6 +20,30 @@ __device__ __forceinline__ void dma16(const float* g, unsigned l) {
 }
 
 struct Split { bf16x8 p0, p1, p2; };
+// truncating variant (what the product kernels use: full-rate v_and / v_sub / v_perm only)
+__device__ __forceinline__ Split split8t(const float4& lo, const float4& hi) {
+    const float v[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+    unsigned u0[8], u1[8], u2[8];
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        u0[i] = __float_as_uint(v[i]);
+        const float r1 = v[i] - __uint_as_float(u0[i] & 0xffff0000u);
+        u1[i] = __float_as_uint(r1);
+        const float r2 = r1 - __uint_as_float(u1[i] & 0xffff0000u);
+        u2[i] = __float_as_uint(r2);
+    }
+    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+    u32x4 q0, q1, q2;
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        q0[j] = __builtin_amdgcn_perm(u0[2 * j + 1], u0[2 * j], 0x07060302u);
+        q1[j] = __builtin_amdgcn_perm(u1[2 * j + 1], u1[2 * j], 0x07060302u);
+        q2[j] = __builtin_amdgcn_perm(u2[2 * j + 1], u2[2 * j], 0x07060302u);
+    }
+    Split s;
+    s.p0 = __builtin_bit_cast(bf16x8, q0); s.p1 = __builtin_bit_cast(bf16x8, q1); s.p2 = __builtin_bit_cast(bf16x8, q2);
+    return s;
+}
 __device__ __forceinline__ Split split8(const float4& lo, const float4& hi) {
     const float v[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
     Split s;
@@ -35,6 +59,7 @@ __device__ __forceinline__ Split split8(const float4& lo, const float4& hi) {
 }
 
 // MODE 0: fp32 MFMA (reference)   MODE 1: bf16 x 6 products   MODE 2: bf16 x 3 products (a0b0 + a0b1 + a1b0)
+// MODE 3: bf16 x 6 with the truncating split
 template <int MODE>
 __global__ __launch_bounds__(512, 2) void kern(const float* A, const float* W, float* C, int K) {
     constexpr int STAGE = 384 * BK;
@@ -89,15 +114,20 @@ __global__ __launch_bounds__(512, 2) void kern(const float* A, const float* W, f
                 Split sa[2], sb[2];
 #pragma unroll
                 for (int i = 0; i < 2; i++) {
-                    sa[i] = split8(chunk_at(cur, ra0 + 32 * i, c), chunk_at(cur, ra0 + 32 * i, c + 1));
-                    sb[i] = split8(chunk_at(cur, rb0 + 32 * i, c), chunk_at(cur, rb0 + 32 * i, c + 1));
+                    if (MODE == 3) {
+                        sa[i] = split8t(chunk_at(cur, ra0 + 32 * i, c), chunk_at(cur, ra0 + 32 * i, c + 1));
+                        sb[i] = split8t(chunk_at(cur, rb0 + 32 * i, c), chunk_at(cur, rb0 + 32 * i, c + 1));
+                    } else {
+                        sa[i] = split8(chunk_at(cur, ra0 + 32 * i, c), chunk_at(cur, ra0 + 32 * i, c + 1));
+                        sb[i] = split8(chunk_at(cur, rb0 + 32 * i, c), chunk_at(cur, rb0 + 32 * i, c + 1));
+                    }
                 }
 #pragma unroll
                 for (int i = 0; i < 2; i++)
 #pragma unroll
                     for (int j = 0; j < 2; j++) {
                         f32x16 t = acc[i][j];
-                        if (MODE == 1) {
+                        if (MODE == 1 || MODE == 3) {
                             t = __builtin_amdgcn_mfma_f32_32x32x16_bf16(sa[i].p2, sb[j].p0, t, 0, 0, 0);
                             t = __builtin_amdgcn_mfma_f32_32x32x16_bf16(sa[i].p0, sb[j].p2, t, 0, 0, 0);
                             t = __builtin_amdgcn_mfma_f32_32x32x16_bf16(sa[i].p1, sb[j].p1, t, 0, 0, 0);
@@ -144,22 +174,25 @@ int main() {
     hipMemcpy(A, h, (size_t)M * K * 4, hipMemcpyHostToDevice);
     hipMemcpy(W, h + 31337, 256 * K * 4, hipMemcpyHostToDevice);
     const double fl = 2.0 * M * 256 * K;
+    float t3 = run<3>(A, W, C2, NB, K);
+    float* c3 = (float*)malloc((size_t)4096 * 256 * 4); hipMemcpy(c3, C2, (size_t)4096 * 256 * 4, hipMemcpyDeviceToHost);
     float t0 = run<0>(A, W, C0, NB, K), t1 = run<1>(A, W, C1, NB, K), t2 = run<2>(A, W, C2, NB, K);
+    printf("bf16 x 6, truncating : %8.1f us  %6.1f TFLOP/s fp32-equivalent\n", t3, 2.0 * M * 256 * K / t3 / 1e6);
     printf("fp32 MFMA            : %8.1f us  %6.1f TFLOP/s\n", t0, fl / t0 / 1e6);
     printf("bf16 x 6 (fp32 grade): %8.1f us  %6.1f TFLOP/s fp32-equivalent (%s)\n", t1, fl / t1 / 1e6, hipGetErrorString(hipGetLastError()));
     printf("bf16 x 3             : %8.1f us  %6.1f TFLOP/s fp32-equivalent\n", t2, fl / t2 / 1e6);
     const size_t n = (size_t)4096 * 256;          // compare the first 4096 rows against a double-precision host product
     float *c0 = (float*)malloc(n * 4), *c1 = (float*)malloc(n * 4), *c2 = (float*)malloc(n * 4);
     hipMemcpy(c0, C0, n * 4, hipMemcpyDeviceToHost); hipMemcpy(c1, C1, n * 4, hipMemcpyDeviceToHost); hipMemcpy(c2, C2, n * 4, hipMemcpyDeviceToHost);
-    double e0 = 0, e1 = 0, e2 = 0, ref_max = 0;
+    double e0 = 0, e1 = 0, e2 = 0, e3 = 0, ref_max = 0;
     const float* hw = h + 31337;
     for (int r = 0; r < 64; r++)
         for (int c = 0; c < 256; c++) {
             double s = 0;
             for (int k = 0; k < K; k++) s += (double)h[(size_t)r * K + k] * (double)hw[(size_t)c * K + k];
             ref_max = fmax(ref_max, fabs(s));
-            e0 = fmax(e0, fabs(c0[r * 256 + c] - s)); e1 = fmax(e1, fabs(c1[r * 256 + c] - s)); e2 = fmax(e2, fabs(c2[r * 256 + c] - s));
+            e0 = fmax(e0, fabs(c0[r * 256 + c] - s)); e1 = fmax(e1, fabs(c1[r * 256 + c] - s)); e2 = fmax(e2, fabs(c2[r * 256 + c] - s)); e3 = fmax(e3, fabs(c3[r * 256 + c] - s));
         }
-    printf("max |error| vs fp64 (|ref| up to %.1f): fp32 MFMA %.3g, bf16x6 %.3g, bf16x3 %.3g\n", ref_max, e0, e1, e2);
+    printf("max |error| vs fp64 (|ref| up to %.1f): fp32 MFMA %.3g, bf16x6 %.3g, bf16x6 truncating %.3g, bf16x3 %.3g\n", ref_max, e0, e1, e3, e2);
     return 0;
 }
