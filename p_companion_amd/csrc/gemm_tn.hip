@@ -181,8 +181,11 @@ __global__ __launch_bounds__(64 * WO * WI, WO * WI / 4) void gemm_tn8_kernel(TnA
     // instruction is one row: it is simply dropped 128 B further), a 128-wide one keeps stride 128 and swaps the
     // two 32-float halves of every 64 in its ODD rows (the lanes of the second row of an instruction fetch the
     // other half; the fragment / in-place readers of odd rows flip bit 5 of the column).
-    constexpr int ZRS = NO == 256 ? 288 : NO, ARS = NI == 256 ? 288 : NI;     // row strides
-    constexpr bool ZSW = NO == 128, ASW = NI == 128;                          // odd-row half swap
+    // (bf16 products: lanes 0-31 read rows k .. k+7, lanes 32-63 rows k+8 .. k+15 of a 16-row group; the two
+    // half-waves must sit on different banks: 256-wide images get row stride 260 floats (8 x 260 = 32 mod 64), 128-wide
+    // ones swap the 32-float halves of every 64 in the rows whose bit 3 is set)
+    constexpr int ZRS = NO == 256 ? 260 : NO, ARS = NI == 256 ? 260 : NI;     // row strides
+    constexpr bool ZSW = NO == 128, ASW = NI == 128;                          // half swap of rows with bit 3 set
     static_assert((NO == 128 || NO == 256) && (NI == 128 || NI == 256), "image widths");
     constexpr int ZF = TKC * ZRS, AF = TKC * ARS;                // floats per stage image
     constexpr int STAGE = ZF * (ZPRO ? 2 : 1) + AF;              // Z [, H], A
@@ -207,14 +210,14 @@ __global__ __launch_bounds__(64 * WO * WI, WO * WI / 4) void gemm_tn8_kernel(TnA
     for (int j = 0; j < JZ; j++) {
         const int g = w + NWV * j, f = g * 256 + lane * 4;
         zr[j] = f / NO; zc[j] = f % NO;
-        if (ZSW && (zr[j] & 1)) zc[j] ^= 32;
+        if (ZSW && (zr[j] & 8)) zc[j] ^= 32;
         zd[j] = (NO == 256 ? g * ZRS : g * 256) * 4;
     }
 #pragma unroll
     for (int j = 0; j < JA; j++) {
         const int g = w + NWV * j, f = g * 256 + lane * 4;
         ar[j] = f / NI; ac[j] = f % NI;
-        if (ASW && (ar[j] & 1)) ac[j] ^= 32;
+        if (ASW && (ar[j] & 8)) ac[j] ^= 32;
         ad[j] = (NI == 256 ? g * ARS : g * 256) * 4;
     }
     int gidx[JA];                                                // gather indices of the NEXT chunk to issue
@@ -245,8 +248,8 @@ __global__ __launch_bounds__(64 * WO * WI, WO * WI / 4) void gemm_tn8_kernel(TnA
     // in-place loaders: thread t owns 4 fixed columns and every (THREADS / (N/4))-th row of an image
     constexpr int ZT = NO / 4, AT = NI / 4;
     const int zrow = tid / ZT, zcol = (tid % ZT) * 4, arow = tid / AT, acol = (tid % AT) * 4;
-    int zseg = -1, aseg = -1;
-    float4 zmu, zis, zsc, zc1, zc2, asc, ash;
+    int zseg = -1;
+    float4 zmu, zis, zsc, zc1, zc2;
     auto transform = [&](float* stage, int r0) {
         if (ZPRO && zcol < a.No) {
             float* Zs = stage;
@@ -265,7 +268,7 @@ __global__ __launch_bounds__(64 * WO * WI, WO * WI / 4) void gemm_tn8_kernel(TnA
                         zc2 = *reinterpret_cast<const float4*>(a.z_c2 + o);
                         zseg = s;
                     }
-                    const int zp = rr * ZRS + ((ZSW && (rr & 1)) ? zcol ^ 32 : zcol);
+                    const int zp = rr * ZRS + ((ZSW && (rr & 8)) ? zcol ^ 32 : zcol);
                     float4 z = *reinterpret_cast<const float4*>(&Zs[zp]);
                     const float4 h = *reinterpret_cast<const float4*>(&Hs[zp]);
                     const float zm = row_multiplicity(a.seg, r);
@@ -279,6 +282,9 @@ __global__ __launch_bounds__(64 * WO * WI, WO * WI / 4) void gemm_tn8_kernel(TnA
         }
         if (APRO && acol < a.Ni) {
             float* As = stage + (ZPRO ? 2 : 1) * ZF;
+            // scale / shift are re-fetched per chunk (L1 hits) instead of living in 8 registers across the MFMA phase
+            int aseg = -1;
+            float4 asc, ash;
 #pragma unroll
             for (int p = 0; p < TKC / (THREADS / AT); p++) {
                 const int rr = arow + (THREADS / AT) * p, r = r0 + rr;
@@ -289,7 +295,7 @@ __global__ __launch_bounds__(64 * WO * WI, WO * WI / 4) void gemm_tn8_kernel(TnA
                         ash = *reinterpret_cast<const float4*>(a.pshift + (size_t)s * a.Ni + acol);
                         aseg = s;
                     }
-                    const int ap = rr * ARS + ((ASW && (rr & 1)) ? acol ^ 32 : acol);
+                    const int ap = rr * ARS + ((ASW && (rr & 8)) ? acol ^ 32 : acol);
                     float4 x = *reinterpret_cast<const float4*>(&As[ap]);
                     x.x = fast_tanh(x.x * asc.x + ash.x);
                     x.y = fast_tanh(x.y * asc.y + ash.y);
@@ -324,7 +330,11 @@ __global__ __launch_bounds__(64 * WO * WI, WO * WI / 4) void gemm_tn8_kernel(TnA
         if (i < nchunk) { load_gather(r_begin + i * TKC); issue(i, r_begin + i * TKC); }
     if (NST - 1 < nchunk) load_gather(r_begin + (NST - 1) * TKC);
     // lanes 32-63 read the odd row of each pair: in a half-swapped image their columns have bit 5 flipped
-    const int fz = (lane >> 5) * ZRS, fa = (lane >> 5) * ARS;
+    // bf16 products (see common.h): one MFMA k group = 16 rows; lane (column lane & 31, half lane >> 5) holds the 8
+    // rows 8 (lane >> 5) .. + 7 of its column, read one by one (row stride), split into three bf16 pieces once and
+    // used by TI (Z blocks) / TO (A blocks) accumulators.
+    static_assert(TKC % 16 == 0, "chunks are whole k groups");
+    const int fz = 8 * (lane >> 5) * ZRS, fa = 8 * (lane >> 5) * ARS;
     int zo[TO], xo[TI];                                        // this lane's column of each 32-wide block
 #pragma unroll
     for (int i = 0; i < TO; i++) zo[i] = (wo * (TO * 32) + 32 * i + (lane & 31)) ^ ((ZSW && lane >= 32) ? 32 : 0);
@@ -343,30 +353,29 @@ __global__ __launch_bounds__(64 * WO * WI, WO * WI / 4) void gemm_tn8_kernel(TnA
         if (APRO || ZPRO) { transform(stage, r_begin + c * TKC); tn_lds_sync(); }
         const float* Zs = stage + fz;
         const float* As = stage + (ZPRO ? 2 : 1) * ZF + fa;
-        // fragments of row pair k+2 are requested before the MFMAs of pair k are issued (the scheduler
-        // otherwise sinks each read to just before its MFMA and exposes the LDS latency 16x per chunk)
-        float z[2][TO], x[2][TI];
 #pragma unroll
-        for (int i = 0; i < TO; i++) z[0][i] = Zs[zo[i]];
+        for (int g = 0; g < TKC / 16; g++) {
+            // rows 16 g + 8 (lane >> 5) + t; in a half-swapped 128-wide image the swap follows bit 3 of the row, i.e.
+            // the lane's half when g is even and its complement when... rows 16g+8h+t have bit 3 == h: constant per lane
+            Split3 sx[TI];
 #pragma unroll
-        for (int j = 0; j < TI; j++) x[0][j] = As[xo[j]];
+            for (int j = 0; j < TI; j++) {
+                float v[8];
 #pragma unroll
-        for (int k = 0; k < TKC; k += 2) {
-            const int b = (k >> 1) & 1;
-            if (k + 2 < TKC) {
-#pragma unroll
-                for (int i = 0; i < TO; i++) z[b ^ 1][i] = Zs[(k + 2) * ZRS + zo[i]];
-#pragma unroll
-                for (int j = 0; j < TI; j++) x[b ^ 1][j] = As[(k + 2) * ARS + xo[j]];
+                for (int t = 0; t < 8; t++) v[t] = As[(16 * g + t) * ARS + xo[j]];
+                sx[j] = split3(make_float4(v[0], v[1], v[2], v[3]), make_float4(v[4], v[5], v[6], v[7]));
             }
-            __builtin_amdgcn_sched_barrier(0);          // the requests above stay above the MFMAs below
 #pragma unroll
             for (int i = 0; i < TO; i++) {
-                zsum[i] += z[b][i];
+                float v[8];
 #pragma unroll
-                for (int j = 0; j < TI; j++) acc[i][j] = mfma32(z[b][i], x[b][j], acc[i][j]);
+                for (int t = 0; t < 8; t++) v[t] = Zs[(16 * g + t) * ZRS + zo[i]];
+                zsum[i] += ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]));
+                const Split3 sz = split3(make_float4(v[0], v[1], v[2], v[3]), make_float4(v[4], v[5], v[6], v[7]));
+#define PC_TERM(PZ, PX) _Pragma("unroll") for (int j = 0; j < TI; j++) acc[i][j] = mfma_bf16(sz.PZ, sx[j].PX, acc[i][j]);
+                PC_TERM(p2, p0) PC_TERM(p0, p2) PC_TERM(p1, p1) PC_TERM(p1, p0) PC_TERM(p0, p1) PC_TERM(p0, p0)
+#undef PC_TERM
             }
-            __builtin_amdgcn_sched_barrier(0);
         }
         cur = cur + 1 == NST ? 0 : cur + 1;
     }
