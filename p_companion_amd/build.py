@@ -11,6 +11,7 @@ OBJ = os.path.join(CSRC, "_obj")
 LIB = os.path.join(HERE, "libpcompanion_hip.so")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-Wall", "-Wno-unused-function"]
+FLAGS += os.environ.get("PC_EXTRA_HIPCC_FLAGS", "").split()      # developer builds (e.g. -DPC_NT_TIMING, scripts/nt_phase_times.py)
 
 
 def sources():

@@ -78,6 +78,13 @@ __device__ __forceinline__ void lds_sync() {
 // WPS = resident waves per SIMD the register budget is set for.
 // PRO / EPI / STATS are compile-time: a runtime switch per output element costs ~1200 scalar
 // branches per tile and wave (measured: 12 us of a 33 us tile) and the unused fusions' registers.
+#ifdef PC_NT_TIMING
+__device__ unsigned long long pc_nt_timing[32 * 4];
+extern "C" int pc_debug_nt_timing(unsigned long long* out, int reset) {
+    if (reset) { unsigned long long z[32 * 4] = {}; return (int)hipMemcpyToSymbol(HIP_SYMBOL(pc_nt_timing), z, sizeof(z)); }
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(pc_nt_timing), sizeof(unsigned long long) * 32 * 4);
+}
+#endif
 template <int NWM, int NWN, int BK, int WPS, bool PRO, int EPI, int STATS>
 __global__ __launch_bounds__(64 * NWM * NWN, WPS) void gemm_nt_kernel(NtArgs a, int ntn, int total_tiles) {
     constexpr int NW = NWM * NWN, THREADS = 64 * NW;
@@ -240,7 +247,13 @@ __global__ __launch_bounds__(64 * NWM * NWN, WPS) void gemm_nt_kernel(NtArgs a, 
     stage_sync();
     int cur = 0;
 
+#ifdef PC_NT_TIMING
+    unsigned long long tk = 0, te = 0, tn = 0;
+#endif
     while (true) {
+#ifdef PC_NT_TIMING
+        const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+#endif
         // next tile's identity; its gather indices are requested a whole tile early
         ntile = tile + gridDim.x;
         if (ntile < total_tiles) {
@@ -259,6 +272,9 @@ __global__ __launch_bounds__(64 * NWM * NWN, WPS) void gemm_nt_kernel(NtArgs a, 
             cur ^= 1;
         }
 
+#ifdef PC_NT_TIMING
+        const unsigned long long t1 = __builtin_amdgcn_s_memtime();
+#endif
         // ---- epilogue of `tile`: each wave transposes its accumulators, 16 rows x 32 columns at a
         // time, through a private patch (the stages are busy: the next tile's first chunk is landing)
         float* stg = patch + w * (PROWS * PLD);
@@ -268,7 +284,7 @@ __global__ __launch_bounds__(64 * NWM * NWN, WPS) void gemm_nt_kernel(NtArgs a, 
         // aux operand (d-activation epilogues): ADEPTH half-patches are in flight ahead of the one being
         // finished -- with two loads per lane and half-patch the wave would otherwise pay one full
         // memory latency per half-patch (measured: 19 us of a 32 us tile)
-        constexpr int ADEPTH = HAS_AUX ? (STATS != NT_STAT_NONE ? 1 : 4) : 1;   // (the BN-backward variant has no registers to spare)
+        constexpr int ADEPTH = HAS_AUX ? 4 : 1;
         const bool fast = vec && n0 + BN <= a.N;                 // whole tile inside N: unpredicated 16-B accesses
         float4 xq[ADEPTH][2];
         auto aux_load = [&](int h, float4 (&x4)[2]) {
@@ -388,6 +404,16 @@ __global__ __launch_bounds__(64 * NWM * NWN, WPS) void gemm_nt_kernel(NtArgs a, 
                 }
             // (`red` is written again only after the next tile's K-steps and their barriers)
         }
+#ifdef PC_NT_TIMING
+        {
+            const unsigned long long t2 = __builtin_amdgcn_s_memtime();
+            tk += t1 - t0; te += t2 - t1; tn += 1;
+            if (ntile >= total_tiles && NWM == 2 && NWN == 4 && tid == 0) {
+                const int id = (EPI + 6 * (STATS != 0) + 12 * (PRO ? 1 : 0)) * 4;
+                atomicAdd(&pc_nt_timing[id], tk); atomicAdd(&pc_nt_timing[id + 1], te); atomicAdd(&pc_nt_timing[id + 2], tn); atomicAdd(&pc_nt_timing[id + 3], 1ull);
+            }
+        }
+#endif
         if (ntile >= total_tiles) break;
         zero_acc();
         tile = ntile; row0 = nrow0; row_end = nrow_end; n0 = nn0; seg = nseg;
@@ -518,7 +544,7 @@ static void launch_variant(const NtArgs& a, int ntm, hipStream_t st) {
     if (PRO || a.N > 128 || STATS != NT_STAT_NONE) {
         // 128 rows x 256 columns, 8 waves, two workgroups per CU (66 KB of LDS each): A is read once
         const int ntn = (a.N + 255) / 256, total = ntm * ntn;
-        PC_LAUNCH((gemm_nt_kernel<2, 4, 16, 4, PRO, EPI, STATS>), dim3(total < 512 ? total : 512), dim3(512), 0, st, a, ntn,
+        PC_LAUNCH((gemm_nt_kernel<2, 4, 16, 2, PRO, EPI, STATS>), dim3(total < 256 ? total : 256), dim3(512), 0, st, a, ntn,
                   total);
     } else if (ntm >= 192) {
         // N <= 128: 128x128 tiles, 4 waves, three workgroups per CU

@@ -72,6 +72,25 @@ def test_linear_backward_input(ops):
     close(ops.linear_backward_input(dev(dy), dev(w)), (dy.double() @ w.double()).float(), 2e-5, what="dx")
 
 
+@pytest.mark.parametrize("rows,k,n", [(20000, 256, 256), (30000, 128, 256), (50000, 256, 128)])
+def test_matrix_core_products_are_fp32_grade(ops, rows, k, n):
+    """The persistent NT / full-tile TN kernels evaluate each fp32 product as six bf16 matrix-core products of a
+    three-way split (common.h split3).  Their error against an fp64 product must not exceed what a plain fp32
+    product (torch's fp32 matmul on the same GPU) shows on the same operands."""
+    x, w = dev(rnd(rows, k, seed=21)), dev(rnd(n, k, seed=22, scale=0.1))
+    ref = x.double() @ w.double().T
+    y = ops.linear_forward(x, w, None)
+    e_hip = float((y.double() - ref).abs().max())
+    e_f32 = float(((x @ w.T).double() - ref).abs().max())
+    assert e_hip <= 1.25 * e_f32 + 1e-7, f"NT: {e_hip:.3e} vs fp32 {e_f32:.3e}"
+    dy = dev(rnd(rows, n, seed=23))
+    dw, _ = ops.linear_backward_weight(dy, x, n, k)
+    refw = dy.double().T @ x.double()
+    e_hip = float((dw.double() - refw).abs().max())
+    e_f32 = float(((dy.T @ x).double() - refw).abs().max())
+    assert e_hip <= 1.25 * e_f32 + 1e-6, f"TN: {e_hip:.3e} vs fp32 {e_f32:.3e}"
+
+
 # ------------------------------------------------------------------ P6 FFN
 def _state(seed=11):
     st = p2v_oracle.init_state(seed)
