@@ -544,7 +544,7 @@ static void launch_variant(const NtArgs& a, int ntm, hipStream_t st) {
     if (PRO || a.N > 128 || STATS != NT_STAT_NONE) {
         // 128 rows x 256 columns, 8 waves, two workgroups per CU (66 KB of LDS each): A is read once
         const int ntn = (a.N + 255) / 256, total = ntm * ntn;
-        PC_LAUNCH((gemm_nt_kernel<2, 4, 16, 2, PRO, EPI, STATS>), dim3(total < 256 ? total : 256), dim3(512), 0, st, a, ntn,
+        PC_LAUNCH((gemm_nt_kernel<2, 4, PRO ? 16 : 32, 2, PRO, EPI, STATS>), dim3(total < 256 ? total : 256), dim3(512), 0, st, a, ntn,
                   total);
     } else if (ntm >= 192) {
         // N <= 128: 128x128 tiles, 4 waves, three workgroups per CU
