@@ -121,8 +121,15 @@ def joint_phase(args, rank, world, dev):
     model = PCompanion(cfg, bpg.cuda(dev)["features"]).to(dev).train()       # frozen table: synthetic stand-in for the P2V export
     opt = FusedAdam(model, lr=1e-3)
     flat, gflat = model.flatten_parameters()
+    # one process: the fixed-shape step (pc_joint_train_step + pc_adam_step) is captured once as a HIP graph and
+    # replayed, the loader builds each batch straight into the graph's input buffers.  N > 1 keeps eager launches
+    # (the gradient all-reduce sits between the two calls).
+    graphed = None
+    if world == 1 and not args.no_graph:
+        from p_companion_amd.p_companion import GraphedJointStep
+        graphed = GraphedJointStep(model, opt, args.batch)
     loader = ComplementaryIndexLoader(ComplementaryIndexDataset(bpg, "train"), args.batch, shuffle=True, seed=rank,
-                                      device=dev)
+                                      device=dev, out=graphed.static if graphed else None)
 
     def batches():
         while True:
@@ -133,6 +140,8 @@ def joint_phase(args, rank, world, dev):
     it = batches()
 
     def step(b):
+        if graphed is not None:
+            return graphed(b)[0]
         losses, _ = model.train_step(b)
         pdist.all_reduce_mean_(gflat, world)
         opt.step()
@@ -163,7 +172,8 @@ def joint_phase(args, rank, world, dev):
            "dtype": "f32", "data": "synthetic",
            "config": {"workload": f"P-Companion joint step, {args.products} products, {args.types} types, dim=128, "
                                   f"batch={args.batch}/GPU, K=3 (loader batch construction included)",
-                      "global_batch": world * args.batch, "parallelism": f"dp{world}", "final_loss": round(float(losses[0]), 5)},
+                      "global_batch": world * args.batch, "parallelism": f"dp{world}", "final_loss": round(float(losses[0]), 5),
+                      "launch": "hipGraph replay" if graphed is not None else "eager"},
            "roofline": {"bound": "hbm", "achieved": round(bytes_per * value / world / 1e9, 2), "peak": HBM_PEAK_GBS,
                         "unit": "GB/s", "frac": round(bytes_per * value / world / 1e9 / HBM_PEAK_GBS, 5), "traffic": None,
                         "note": "2.6 KB gathered per triplet (SURVEY 8d); the step is ~30 launches of a few us each: launch/latency bound"},
@@ -189,6 +199,7 @@ def main():
                     help="HIP-event brackets around every GEMM launch (TN and few-row kernels too), not only the dominant "
                          "gemm_nt_kernel family: ~60 us/step of event packets")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-graph", action="store_true", help="joint phase: eager launches instead of the HIP-graph replay")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     args = ap.parse_args()
 

@@ -319,7 +319,10 @@ class ComplementaryIndexDataset:
 class ComplementaryIndexLoader:
     """DataLoader(ComplementaryDataset, collate_fn) in index form (train.py:115-129)."""
 
-    def __init__(self, dataset: ComplementaryIndexDataset, batch_size, shuffle=True, seed=0, device="cuda"):
+    def __init__(self, dataset: ComplementaryIndexDataset, batch_size, shuffle=True, seed=0, device="cuda", out=None):
+        """`out`: fixed device buffers every FULL batch is built into (GraphedJointStep.static); the dict handed out
+        is then the same tensors each time, valid until the next batch is requested."""
+        self.out = out
         self.dataset = dataset
         self.batch_size = int(batch_size)
         self.shuffle = shuffle
@@ -336,8 +339,9 @@ class ComplementaryIndexLoader:
     def make_batch(self, rows_dev, rows_host=None):
         """One HIP launch (pc_build_complementary_batch) builds the whole batch from [B,3] device pairs."""
         from . import ops
+        out = self.out if (self.out is not None and rows_dev.shape[0] == self.batch_size) else None
         batch = ops.build_complementary_batch(rows_dev, self.features, self.type_idx, self.dataset.bpg.n_types,
-                                              self.seed, self.step)
+                                              self.seed, self.step, out=out)
         self.step += 1
         batch["label"] = rows_dev[:, 2]
         return batch

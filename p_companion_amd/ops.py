@@ -701,17 +701,28 @@ def cosine_rows(x, y):
     return out
 
 
-def build_complementary_batch(pairs, features, type_idx, n_types, seed, step, want_targets=True):
-    """pairs [B,3] int32 (query, target, label) on the device -> the joint-step batch dict."""
+def build_complementary_batch(pairs, features, type_idx, n_types, seed, step, want_targets=True, out=None):
+    """pairs [B,3] int32 (query, target, label) on the device -> the joint-step batch dict.  `out`: a dict of
+    preallocated tensors of those shapes to build into (fixed buffers of a graphed step)."""
     b = pairs.shape[0]
     _req(pairs, torch.int32, "pairs", (b, 3)); _req(features, torch.float32, "features"); _req(type_idx, torch.int32, "type_idx")
     dev = pairs.device
     i32 = lambda: torch.empty(b, dtype=torch.int32, device=dev)
     f32 = lambda: torch.empty(b, D, dtype=torch.float32, device=dev)
-    out = {"query_idx": i32(), "query_types": i32(), "positive_types": i32(), "negative_types": i32(),
-           "positive_items": f32(), "negative_items": f32()}
-    if want_targets:
-        out["target_features"] = f32()
+    if out is not None:
+        out = dict(out)
+        for k in ("query_idx", "query_types", "positive_types", "negative_types"):
+            _req(out[k], torch.int32, k)
+            if out[k].numel() != b:
+                raise ValueError("build_complementary_batch: out[%r] has %d elements, batch is %d" % (k, out[k].numel(), b))
+        for k in ("positive_items", "negative_items"):
+            _req(out[k], torch.float32, k, (b, D))
+        want_targets = "target_features" in out
+    else:
+        out = {"query_idx": i32(), "query_types": i32(), "positive_types": i32(), "negative_types": i32(),
+               "positive_items": f32(), "negative_items": f32()}
+        if want_targets:
+            out["target_features"] = f32()
     check(_lib.lib().pc_build_complementary_batch(
         _p(pairs), b, _p(features), _p(type_idx), int(n_types), int(seed), int(step), _p(out["query_idx"]),
         _p(out["query_types"]), _p(out["positive_types"]), _p(out["negative_types"]), _p(out["positive_items"]),

@@ -153,6 +153,67 @@ class PCompanion(nn.Module, _FlatParamsMixin):
         return [(k, sd[k]) for k in self._flat_keys]
 
 
+class GraphedJointStep:
+    """train.py:42-48 (forward, compute_loss, zero_grad, backward, optimizer.step) for a FIXED batch size as one
+    HIP-graph replay.  The fused joint step is ~40 launches of 3-13 us each and is bound by how fast the host can
+    launch them; its shapes and buffers do not depend on the data, so after `warmup` eager steps the launch
+    sequence (pc_joint_train_step + pc_adam_step, every kernel on the capturing stream) is recorded once and
+    replayed.  The batch lives in fixed device buffers (`.static`, the loader can build straight into them:
+    ComplementaryIndexLoader(..., out=step.static)); Adam's step counter and bias corrections live on the device.
+
+    Single process only (a gradient all-reduce between the two calls would have to be captured too): the
+    data-parallel loop keeps the eager calls."""
+
+    def __init__(self, model, optimizer, batch_size, warmup=3):
+        from .product2vec import FusedAdam
+        if not isinstance(optimizer, FusedAdam):
+            raise TypeError("GraphedJointStep replays pc_adam_step: pass a FusedAdam")
+        self.model, self.optimizer = model, optimizer
+        dev = model.query_type_embeddings.weight.device
+        if dev.type != "cuda":
+            raise RuntimeError("GraphedJointStep needs the model on the GPU")
+        b = int(batch_size)
+        i32 = lambda *shape: torch.zeros(*shape, dtype=torch.int32, device=dev)
+        f32 = lambda: torch.zeros(b, ops.D, dtype=torch.float32, device=dev)
+        self.static = {"query_idx": i32(b), "query_types": i32(b), "positive_types": i32(b, 1),
+                       "negative_types": i32(b, 1), "positive_items": f32(), "negative_items": f32()}
+        self.batch_size, self.warmup = b, int(warmup)
+        self.graph = None
+        self._eager_steps = 0
+        self.losses = self.complementary_types = None
+
+    def load(self, batch):
+        """Copy a batch dict into the fixed buffers (a no-op for tensors that already are those buffers)."""
+        for k, dst in self.static.items():
+            src = batch[k]
+            if src.data_ptr() != dst.data_ptr():
+                dst.copy_(src.reshape(dst.shape), non_blocking=True)
+
+    def _eager(self):
+        self.losses, self.complementary_types = self.model.train_step(self.static)
+        self.optimizer.step()
+
+    def __call__(self, batch=None):
+        if batch is not None:
+            if batch["query_idx"].numel() != self.batch_size:
+                raise ValueError("GraphedJointStep: fixed batch size %d" % self.batch_size)
+            self.load(batch)
+        if self.graph is None:
+            if self._eager_steps < self.warmup:
+                self._eager_steps += 1
+                self._eager()
+                return self.losses, self.complementary_types
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph, stream=side):
+                self._eager()
+            torch.cuda.current_stream().wait_stream(side)
+            self.graph = graph
+        self.graph.replay()
+        return self.losses, self.complementary_types
+
+
 class _IdentityIds:
     """product_to_idx for an integer-id table: 'P000123' -> 123 without a 100M-entry dict."""
 

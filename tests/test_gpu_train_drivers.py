@@ -153,3 +153,47 @@ def test_type_filtered_retrieval_vs_oracle(golden, tmp_path):
         inf.recommend("P999999")
     with pytest.raises(FileNotFoundError):
         PCompanionInference(os.path.join(str(tmp_path), "missing.pth"), c, bpg)
+
+
+def test_graphed_joint_step_equals_eager_steps():
+    """GraphedJointStep (HIP-graph replay of pc_joint_train_step + pc_adam_step, loader building into the graph's
+    fixed buffers) against the same steps launched eagerly: same losses, top-k and parameters after 8 steps (the
+    type-table scatter-add uses hardware float atomics, hence a tolerance instead of bit equality)."""
+    from types import SimpleNamespace
+    from p_companion_amd.data import ComplementaryIndexDataset, ComplementaryIndexLoader, generate_scaled_bpg
+    from p_companion_amd.p_companion import GraphedJointStep, PCompanion
+    from p_companion_amd.product2vec import FusedAdam
+    cfg = SimpleNamespace(PRODUCT_EMB_DIM=128, TYPE_EMB_DIM=64, DROPOUT=0.0, MARGIN=1.0, ALPHA=0.8, NUM_COMP_TYPES=3,
+                          NUM_TYPES=40, DEVICE="cuda")
+    bpg = generate_scaled_bpg(3000, 40, seed=3)
+    B = 512
+
+    def make():
+        torch.manual_seed(5)
+        m = PCompanion(cfg, bpg.cuda("cuda")["features"]).to("cuda").train()
+        return m, FusedAdam(m, lr=1e-2)
+
+    m_e, o_e = make()
+    m_g, o_g = make()
+    graphed = GraphedJointStep(m_g, o_g, B, warmup=2)
+    ld_e = ComplementaryIndexLoader(ComplementaryIndexDataset(bpg, "train"), B, shuffle=True, seed=9, device="cuda")
+    ld_g = ComplementaryIndexLoader(ComplementaryIndexDataset(bpg, "train"), B, shuffle=True, seed=9, device="cuda",
+                                    out=graphed.static)
+    steps = 0
+    for be, bg in zip(ld_e, ld_g):
+        if be["query_idx"].numel() != B:
+            continue
+        assert bg["positive_items"].data_ptr() == graphed.static["positive_items"].data_ptr()     # built in place
+        le, te = m_e.train_step(be)
+        o_e.step()
+        lg, tg = graphed(bg)
+        assert torch.equal(te, tg), f"top-k differs at step {steps}"
+        assert torch.allclose(le, lg, rtol=1e-5, atol=1e-6), f"losses differ at step {steps}: {le} vs {lg}"
+        steps += 1
+        if steps == 8:
+            break
+    assert steps == 8 and graphed.graph is not None            # 2 eager warm-up steps, 6 replays
+    for (k, pe), (_, pg) in zip(m_e.named_parameters(), m_g.named_parameters()):
+        assert torch.allclose(pe, pg, rtol=1e-4, atol=1e-6), k
+    with pytest.raises(ValueError):
+        graphed({k: v[:7] for k, v in graphed.static.items()})
