@@ -541,6 +541,16 @@ static SegInfo retile(const SegInfo& in, int tile_rows) {
 
 template <bool PRO, int EPI, int STATS>
 static void launch_variant(const NtArgs& a, int ntm, hipStream_t st) {
+    if (!PRO && a.N > 128 && a.N <= 256 && ntm >= 192) {
+        // many rows, 129..256 columns, no in-place prologue: 128x128 tiles of 4 waves, two column tiles per row tile,
+        // THREE workgroups per CU.  A is fetched twice (the second time mostly from L2 / MALL), but one workgroup's
+        // epilogue -- 30-54 % of a tile's time, during which its waves only move data -- overlaps the K loops of the
+        // other two: dZ1 133 -> 115 us, dZ2 79 -> 70, Linear0 71 -> 67 against the 8-wave full-width tile (step 1.135 ->
+        // 1.115 ms on the same box; two 4-wave workgroups with 256 registers each: no better than the 8-wave tile).
+        PC_LAUNCH((gemm_nt_kernel<2, 2, 16, 3, false, EPI, STATS>), dim3(2 * ntm < 768 ? 2 * ntm : 768), dim3(256), 0, st, a,
+                  2, 2 * ntm);
+        return;
+    }
     if (PRO || a.N > 128 || STATS != NT_STAT_NONE) {
         // 128 rows x 256 columns, 8 waves, two workgroups per CU (66 KB of LDS each): A is read once
         const int ntn = (a.N + 255) / 256, total = ntm * ntn;
