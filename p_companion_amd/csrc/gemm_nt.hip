@@ -136,7 +136,11 @@ __global__ __launch_bounds__(64 * NWM * NWN, WPS) void gemm_nt_kernel(NtArgs a, 
     if (tile >= total_tiles) return;
     int row0 = 0, row_end = 0, n0 = 0, seg = 0;
     auto tile_geom = [&](int t, int& r0, int& rend, int& nn0, int& sg) {
-        const int tm = t / ntn, tn = t % ntn;
+        int tm = t / ntn, tn = t % ntn;
+        // Two column tiles per row tile: workgroups b and b + 8 -- the same XCD, blockIdx round-robins over the 8 XCDs
+        // and the grid is a multiple of 16 -- take the two halves of one row tile, so the second fetch of its A rows is
+        // an L2 hit.  The host pads the tile count to a multiple of 16; a row tile past the end has no rows.
+        if (ntn == 2) { tm = ((t >> 4) << 3) + (t & 7); tn = (t >> 3) & 1; }
         sg = seg_of_tile(a.seg, tm);
         r0 = a.seg.start[sg] + (tm - a.seg.tile0[sg]) * BM;
         rend = a.seg.start[sg + 1];
@@ -393,9 +397,10 @@ __global__ __launch_bounds__(64 * NWM * NWN, WPS) void gemm_nt_kernel(NtArgs a, 
         }
         if (STATS != NT_STAT_NONE) {
             lds_sync();                                        // every wave has posted its column sums
-            const int tile_m = tile / ntn;
+            const int tile_m = ntn == 2 ? ((tile >> 4) << 3) + (tile & 7) : tile / ntn;
+            const bool live = row0 < row_end;                  // (a padding tile of the paired numbering owns no statistics slot)
             for (int c = tid; c < BN; c += THREADS)
-                if (n0 + c < a.N) {
+                if (live && n0 + c < a.N) {
                     float s1 = 0.f, s2 = 0.f;
 #pragma unroll
                     for (int m = 0; m < NWM; m++) { s1 += red[(0 * NWM + m) * BN + c]; s2 += red[(1 * NWM + m) * BN + c]; }
@@ -547,13 +552,15 @@ static void launch_variant(const NtArgs& a, int ntm, hipStream_t st) {
         // epilogue -- 30-54 % of a tile's time, during which its waves only move data -- overlaps the K loops of the
         // other two: dZ1 133 -> 115 us, dZ2 79 -> 70, Linear0 71 -> 67 against the 8-wave full-width tile (step 1.135 ->
         // 1.115 ms on the same box; two 4-wave workgroups with 256 registers each: no better than the 8-wave tile).
-        PC_LAUNCH((gemm_nt_kernel<2, 2, 16, 3, false, EPI, STATS>), dim3(2 * ntm < 768 ? 2 * ntm : 768), dim3(256), 0, st, a,
-                  2, 2 * ntm);
+        const int total = (2 * ntm + 15) & ~15;                  // paired numbering (tile_geom): whole groups of 16
+        PC_LAUNCH((gemm_nt_kernel<2, 2, 16, 3, false, EPI, STATS>), dim3(total < 768 ? total : 768), dim3(256), 0, st, a,
+                  2, total);
         return;
     }
     if (PRO || a.N > 128 || STATS != NT_STAT_NONE) {
         // 128 rows x 256 columns, 8 waves, two workgroups per CU (66 KB of LDS each): A is read once
-        const int ntn = (a.N + 255) / 256, total = ntm * ntn;
+        const int ntn = (a.N + 255) / 256;
+        const int total = ntn == 2 ? ((ntm * 2 + 15) & ~15) : ntm * ntn;      // (two column tiles: paired numbering, tile_geom)
         PC_LAUNCH((gemm_nt_kernel<2, 4, PRO ? 16 : 32, 2, PRO, EPI, STATS>), dim3(total < 256 ? total : 256), dim3(512), 0, st, a, ntn,
                   total);
     } else if (ntm >= 192) {
