@@ -271,6 +271,7 @@ struct AttnWs {
     float *coef;                                    // [B*N][8] per-slot softmax coefficients (unique-neighbour layout)
     float *wot, *wqt, *wkvt;      // transposed projections
     float *slabs; size_t slab_floats;
+    float *slabs_o; size_t slab_o_floats;              // out_proj gradient: grouped with the q-projection gradient
     size_t total;
 };
 
@@ -295,6 +296,8 @@ static AttnWs attn_ws_layout(void* base, int B, int key_rows, int n_slots_per_sa
     size_t s2 = gemm_tn_workspace_floats(B, PC_D, PC_D);
     w.slab_floats = s1 > s2 ? s1 : s2;
     w.slabs = take(w.slab_floats);
+    w.slab_o_floats = gemm_tn_workspace_floats(B, PC_D, PC_D);
+    w.slabs_o = take(w.slab_o_floats);
     w.total = off;
     return w;
 }
@@ -371,9 +374,8 @@ int attention_backward_impl(const pc_p2v_tensors* p, const pc_p2v_tensors* g, co
     PC_TRY(launch_gemm_nt(nt_plain(dout, PC_D, w.wot, PC_D, nullptr, w.dctx, PC_D, B, PC_D, PC_D), st));
     TnArgs to = {};
     to.Z = dout; to.ldz = PC_D; to.A = sv->ctx; to.lda = PC_D; to.R = B; to.No = PC_D; to.Ni = PC_D; to.seg = si1;
-    to.dW = g->out_proj_w; to.lddw = PC_D; to.db = g->out_proj_b; to.accumulate = accumulate; to.slabs = w.slabs;
-    to.slab_floats = w.slab_floats;
-    PC_TRY(launch_gemm_tn(to, st));
+    to.dW = g->out_proj_w; to.lddw = PC_D; to.db = g->out_proj_b; to.accumulate = accumulate; to.slabs = w.slabs_o;
+    to.slab_floats = w.slab_o_floats;                  // (launched below, together with the q-projection gradient)
 
     const size_t lds = (size_t)4 * PC_HEADS * N * sizeof(float);
     const bool has_pad = slot_row && pad_row >= 0;
@@ -403,7 +405,10 @@ int attention_backward_impl(const pc_p2v_tensors* p, const pc_p2v_tensors* g, co
     tq.Z = w.dq; tq.ldz = PC_D; tq.A = query; tq.lda = PC_D; tq.R = B; tq.No = PC_D; tq.Ni = PC_D; tq.seg = si1;
     tq.dW = g->in_proj_w; tq.lddw = PC_D; tq.db = g->in_proj_b; tq.accumulate = accumulate; tq.slabs = w.slabs;
     tq.slab_floats = w.slab_floats;
-    PC_TRY(launch_gemm_tn(tq, st));
+    {   // two few-row products (M = batch), each ~13 us of latency on a quarter of the chip: one launch, one reduce
+        const TnArgs pair[2] = {to, tq};
+        PC_TRY(launch_gemm_tn_group(pair, 2, nullptr, 0, st));
+    }
 
     // [k|v] = keys [Wk;Wv]^T + [bk;bv]
     PC_TRY(launch_gemm_nt(nt_plain(w.dkv, 2 * PC_D, w.wkvt, 2 * PC_D, nullptr, dkeys, PC_D, key_rows, PC_D, 2 * PC_D), st));

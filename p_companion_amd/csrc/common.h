@@ -245,3 +245,18 @@ struct TnArgs {
 };
 int launch_gemm_tn(const TnArgs& a, hipStream_t st);
 size_t gemm_tn_workspace_floats(int R, int No, int Ni);
+// up to PC_TN_GROUP small independent products (disjoint slab regions) as one launch + one reduce; the reduce can
+// take PC_TN_EXTRA further slab sets that other kernels filled (the joint step's type-table scatter-adds)
+#define PC_TN_GROUP 4
+#define PC_TN_EXTRA 2
+#define PC_TN_RGROUP (PC_TN_GROUP + PC_TN_EXTRA)
+struct TnGroup { TnArgs a[PC_TN_GROUP]; int tiles_i[PC_TN_GROUP], nsplit[PC_TN_GROUP], rps[PC_TN_GROUP], block0[PC_TN_GROUP + 1], n; };
+struct TnReduceJob { const float* slabs; int nsplit, n; float* out; int accumulate; };   // out[n] (+)= sum of nsplit slabs of n floats
+struct TnReduceGroup {
+    const float* slabs[PC_TN_RGROUP]; float* dW[PC_TN_RGROUP]; float* db[PC_TN_RGROUP];
+    int nsplit[PC_TN_RGROUP], n_w[PC_TN_RGROUP], n_b[PC_TN_RGROUP], accumulate[PC_TN_RGROUP], block0[PC_TN_RGROUP + 1], n;
+};
+int launch_gemm_tn_group(const TnArgs* args, int n, const TnReduceJob* extra, int n_extra, hipStream_t st);
+int scatter_add_slab_blocks(int table_rows, int rows, int width);
+int launch_scatter_add_slabs(const int32_t* idx, int rows, int width, int table_rows, const float* src, float* slabs,
+                             hipStream_t st);

@@ -15,12 +15,12 @@
 #define TM 128
 #define TK 32
 
-__global__ __launch_bounds__(256, 2) void gemm_tn_kernel(TnArgs a, int tiles_i, int nsplit, int rows_per_split) {
+__device__ __forceinline__ void tn_small_body(const TnArgs& a, int tiles_i, int nsplit, int rows_per_split, int bid) {
     __shared__ __attribute__((aligned(16))) float smem[2][2][TK * TM];
 
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, wo = w >> 1, wi = w & 1;
-    const int split = blockIdx.x % nsplit;
-    const int tile = blockIdx.x / nsplit;
+    const int split = bid % nsplit;
+    const int tile = bid / nsplit;
     const int o0 = (tile / tiles_i) * TM, i0 = (tile % tiles_i) * TM;
     const int r_begin = split * rows_per_split;
     const int r_end = min(a.R, r_begin + rows_per_split);
@@ -141,6 +141,20 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(TnArgs a, int tiles_i, 
             slab[(size_t)a.No * a.Ni + o0 + tid] = s;
         }
     }
+}
+
+__global__ __launch_bounds__(256, 2) void gemm_tn_kernel(TnArgs a, int tiles_i, int nsplit, int rows_per_split) {
+    tn_small_body(a, tiles_i, nsplit, rows_per_split, blockIdx.x);
+}
+
+// Several small, mutually independent gradients in ONE launch (the four Linear layers of the joint step: each alone
+// is 64 workgroups and ~13 us of pure latency): workgroup ranges [block0[j], block0[j+1]) run product j.
+__global__ __launch_bounds__(256, 2) void gemm_tn_group_kernel(TnGroup g) {
+    const int b = blockIdx.x;
+    int j = 0;
+#pragma unroll
+    for (int i = 1; i < PC_TN_GROUP; i++) j += (i < g.n && b >= g.block0[i]) ? 1 : 0;
+    tn_small_body(g.a[j], g.tiles_i[j], g.nsplit[j], g.rps[j], b - g.block0[j]);
 }
 
 // ---------------------------------------------------------------------------------------
@@ -406,10 +420,10 @@ __global__ __launch_bounds__(64 * WO * WI, WO * WI / 4) void gemm_tn8_kernel(TnA
 // out[j] (+)= sum_s slabs[s][j], j over [No*Ni] then [No] (bias).  Eight lanes share one float4 of
 // outputs: lane g sums slabs g, g+8, ... and the eight partial sums fold in a fixed xor order
 // (bitwise reproducible), so a 256x256 gradient keeps ~500 workgroups streaming from HBM.
-__global__ __launch_bounds__(256) void tn_reduce_kernel(const float* slabs, int nsplit, int n_w, int n_b, float* dW,
-                                                        float* db, int accumulate) {
+__device__ __forceinline__ void tn_reduce_body(const float* slabs, int nsplit, int n_w, int n_b, float* dW, float* db,
+                                               int accumulate, int bid) {
     const int total4 = (n_w + (db ? n_b : 0)) / 4;          // n_w, n_b multiples of 4
-    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    const int t = bid * blockDim.x + threadIdx.x;
     const int j4 = t >> 3, g = t & 7;
     if (j4 >= total4) return;                               // whole 8-lane groups leave together
     const size_t stride = (size_t)n_w + n_b;
@@ -434,6 +448,18 @@ __global__ __launch_bounds__(256) void tn_reduce_kernel(const float* slabs, int 
         }
         *reinterpret_cast<float4*>(dst) = s;
     }
+}
+
+__global__ __launch_bounds__(256) void tn_reduce_kernel(const float* slabs, int nsplit, int n_w, int n_b, float* dW,
+                                                        float* db, int accumulate) {
+    tn_reduce_body(slabs, nsplit, n_w, n_b, dW, db, accumulate, blockIdx.x);
+}
+__global__ __launch_bounds__(256) void tn_reduce_group_kernel(TnReduceGroup g) {
+    const int b = blockIdx.x;
+    int j = 0;
+#pragma unroll
+    for (int i = 1; i < PC_TN_RGROUP; i++) j += (i < g.n && b >= g.block0[i]) ? 1 : 0;
+    tn_reduce_body(g.slabs[j], g.nsplit[j], g.n_w[j], g.n_b[j], g.dW[j], g.db[j], g.accumulate[j], b - g.block0[j]);
 }
 
 static bool tn_full_tile(int R, int No, int Ni) {
@@ -494,5 +520,59 @@ int launch_gemm_tn(const TnArgs& a, hipStream_t st) {
     const int threads = (n_w + (a.db ? n_b : 0)) / 4 * 8;
     PC_LAUNCH(tn_reduce_kernel, dim3((threads + 255) / 256), dim3(256), 0, st, a.slabs, nsplit, n_w, n_b,
                        a.dW, a.db, a.accumulate);
+    return pc_launch_status();
+}
+
+// n <= PC_TN_GROUP independent products whose slab regions do not overlap.  Products that qualify for the full-tile
+// kernels (many rows) are launched on their own.
+int launch_gemm_tn_group(const TnArgs* args, int n, const TnReduceJob* extra, int n_extra, hipStream_t st) {
+    if (!args || n < 1 || n > PC_TN_GROUP || n_extra < 0 || n_extra > PC_TN_EXTRA || (n_extra && !extra)) return PC_EINVAL;
+    TnGroup g = {};
+    TnReduceGroup r = {};
+    double flops = 0.0;
+    int blocks = 0, rblocks = 0;
+    for (int i = 0; i < n; i++) {
+        const TnArgs& a = args[i];
+        if (tn_full_tile(a.R, a.No, a.Ni) || a.prologue != NT_PRO_NONE) { PC_TRY(launch_gemm_tn(a, st)); continue; }
+        if (!a.Z || !a.A || !a.dW || !a.slabs || a.R <= 0 || a.No <= 0 || a.Ni <= 0) return PC_EINVAL;
+        if (a.No % 4 || a.Ni % 4 || a.ldz % 4 || a.lda % 4 || a.lddw != a.Ni) return PC_ESHAPE;
+        if (((uintptr_t)a.dW & 15) || (a.db && ((uintptr_t)a.db & 15)) || ((uintptr_t)a.slabs & 15)) return PC_ESHAPE;
+        int nsplit, rps;
+        tn_plan(a.R, a.No, a.Ni, &nsplit, &rps);
+        if ((size_t)nsplit * ((size_t)a.No * a.Ni + a.No) > a.slab_floats) return PC_EWORKSPACE;
+        for (int k = 0; k < g.n; k++) {                          // slab regions must be disjoint
+            const float* lo = g.a[k].slabs; const float* hi = lo + g.a[k].slab_floats;
+            if (a.slabs < hi && lo < a.slabs + a.slab_floats) return PC_EINVAL;
+        }
+        const int tiles_o = (a.No + TM - 1) / TM, tiles_i = (a.Ni + TM - 1) / TM;
+        const int k = g.n++;
+        g.a[k] = a; g.tiles_i[k] = tiles_i; g.nsplit[k] = nsplit; g.rps[k] = rps; g.block0[k] = blocks;
+        blocks += tiles_o * tiles_i * nsplit;
+        const int n_w = a.No * a.Ni, n_b = a.No;
+        r.slabs[k] = a.slabs; r.nsplit[k] = nsplit; r.n_w[k] = n_w; r.n_b[k] = n_b; r.dW[k] = a.dW; r.db[k] = a.db;
+        r.accumulate[k] = a.accumulate; r.block0[k] = rblocks;
+        rblocks += ((n_w + (a.db ? n_b : 0)) / 4 * 8 + 255) / 256;
+        flops += 2.0 * a.R * (double)a.No * a.Ni;
+    }
+    r.n = g.n;
+    for (int i = 0; i < n_extra; i++) {                          // slab sets filled by other kernels
+        const TnReduceJob& e = extra[i];
+        if (!e.slabs || !e.out || e.nsplit < 1 || e.n < 4 || e.n % 4 || ((uintptr_t)e.slabs & 15) || ((uintptr_t)e.out & 15))
+            return PC_EINVAL;
+        const int k = r.n++;
+        r.slabs[k] = e.slabs; r.nsplit[k] = e.nsplit; r.n_w[k] = e.n; r.n_b[k] = 0; r.dW[k] = e.out; r.db[k] = nullptr;
+        r.accumulate[k] = e.accumulate; r.block0[k] = rblocks;
+        rblocks += (e.n / 4 * 8 + 255) / 256;
+    }
+    if (r.n == 0) return PC_OK;
+    for (int k = g.n; k <= PC_TN_GROUP; k++) g.block0[k] = blocks;
+    for (int k = r.n; k <= PC_TN_RGROUP; k++) r.block0[k] = rblocks;
+    if (g.n) {
+        const int pb = pc_prof_begin(PC_KIND_GEMM_TN, flops, st);
+        PC_LAUNCH(gemm_tn_group_kernel, dim3(blocks), dim3(256), 0, st, g);
+        pc_prof_end(pb, st);
+        PC_TRY(pc_launch_status());
+    }
+    PC_LAUNCH(tn_reduce_group_kernel, dim3(rblocks), dim3(256), 0, st, r);
     return pc_launch_status();
 }

@@ -343,7 +343,8 @@ struct JointWs {
     float *typ_wt, *dec_wt, *enc_wt;
     float *sims, *proj, *dproj, *dsv, *partials;      // train_step scratch
     float *h, *c, *pi, *tp;                           // train_step saved activations
-    float *slabs; size_t slab_floats;
+    float* slabs[4]; size_t slab_floats[4];            // one region per weight gradient: they run as one grouped launch
+    float* tslabs[2]; int tblocks[2];                  // per-workgroup private copies of the two type-table gradients
     size_t total;
 };
 
@@ -373,12 +374,12 @@ static JointWs joint_ws_layout(void* base, int B, int T, int K) {
     w.c = take((size_t)B * PC_L);
     w.pi = take((size_t)B * PC_D);
     w.tp = take((size_t)B * K * PC_D);
-    size_t s = gemm_tn_workspace_floats(B * K, PC_D, PC_L);
-    for (size_t f : {gemm_tn_workspace_floats(B, PC_D, PC_D), gemm_tn_workspace_floats(B, PC_L, LH),
-                     gemm_tn_workspace_floats(B, LH, PC_L)})
-        if (f > s) s = f;
-    w.slab_floats = s;
-    w.slabs = take(s);
+    const size_t sf[4] = {gemm_tn_workspace_floats(B, PC_D, PC_D), gemm_tn_workspace_floats(B * K, PC_D, PC_L),
+                          gemm_tn_workspace_floats(B, PC_L, LH), gemm_tn_workspace_floats(B, LH, PC_L)};
+    for (int i = 0; i < 4; i++) { w.slab_floats[i] = sf[i]; w.slabs[i] = take(sf[i]); }
+    w.tblocks[0] = scatter_add_slab_blocks(T, B * K, PC_L);        // E_c rows picked by top-k;  0: table too large, atomics
+    w.tblocks[1] = scatter_add_slab_blocks(T, B, PC_L);            // E_q rows
+    for (int i = 0; i < 2; i++) w.tslabs[i] = take((size_t)(w.tblocks[i] > 0 ? w.tblocks[i] : 0) * T * PC_L + 4);
     w.total = off;
     return w;
 }
@@ -441,46 +442,64 @@ extern "C" int pc_joint_backward(const pc_joint_tensors* p, const pc_joint_tenso
     JointWs w = joint_ws_layout(ws, B, T, K);
     const SegInfo siB = make_seginfo(nullptr, B, 128), siBK = make_seginfo(nullptr, B * K, 128);
 
-    PC_HIP_TRY(hipMemsetAsync(g->query_types, 0, (size_t)T * PC_L * 4, st));
+    // type-table gradients: small tables are summed deterministically from per-workgroup slabs by the grouped
+    // reduce at the end (E_q: overwritten there, no clear needed; E_c also takes the type hinge's atomics)
+    const bool tslab = w.tblocks[0] > 0 && w.tblocks[1] > 0;
+    if (!tslab) PC_HIP_TRY(hipMemsetAsync(g->query_types, 0, (size_t)T * PC_L * 4, st));
     PC_HIP_TRY(hipMemsetAsync(g->comp_types, 0, (size_t)T * PC_L * 4, st));
-    PC_TRY(launch_transpose(p->typ_w, PC_D, PC_L, w.typ_wt, st));   // [D,L] -> [L,D]
-    PC_TRY(launch_transpose(p->dec_w, PC_L, LH, w.dec_wt, st));     // [L,L/2] -> [L/2,L]
-    PC_TRY(launch_transpose(p->enc_w, LH, PC_L, w.enc_wt, st));     // [L/2,L] -> [L,L/2]
+    TransposeBatch tb = {};
+    tb.n = 3;
+    tb.job[0] = {p->typ_w, w.typ_wt, PC_D, PC_L};                    // [D,L] -> [L,D]
+    tb.job[1] = {p->dec_w, w.dec_wt, PC_L, LH};                      // [L,L/2] -> [L/2,L]
+    tb.job[2] = {p->enc_w, w.enc_wt, LH, PC_L};                      // [L/2,L] -> [L,L/2]
+    PC_TRY(launch_transpose_batch(tb, st));
+    // The four weight gradients depend only on buffers that stay untouched to the end of the backward pass: they are
+    // collected here and run as ONE grouped launch + ONE grouped slab reduce after the dX chain (each alone is 64
+    // workgroups and ~13 + 5 us of latency).
+    TnArgs tn[4];
 
     // ---- item branch
     PC_TRY(pc_hadamard_backward(dproj, sv->pi, sv->tp, B, K, w.dpi, w.dtp, stream));
-    TnArgs ti = {};
+    TnArgs& ti = tn[0];
+    ti = {};
     ti.Z = w.dpi; ti.ldz = PC_D; ti.A = p->product_table; ti.lda = PC_D; ti.gather = query_idx; ti.R = B;
     ti.No = PC_D; ti.Ni = PC_D; ti.seg = siB; ti.dW = g->itm_w; ti.lddw = PC_D; ti.db = g->itm_b;
-    ti.slabs = w.slabs; ti.slab_floats = w.slab_floats;
-    PC_TRY(launch_gemm_tn(ti, st));
-    TnArgs tt = {};
+    ti.slabs = w.slabs[0]; ti.slab_floats = w.slab_floats[0];
+    TnArgs& tt = tn[1];
+    tt = {};
     tt.Z = w.dtp; tt.ldz = PC_D; tt.A = p->comp_types; tt.lda = PC_L; tt.gather = topk; tt.R = B * K;
     tt.No = PC_D; tt.Ni = PC_L; tt.seg = siBK; tt.dW = g->typ_w; tt.lddw = PC_L; tt.db = g->typ_b;
-    tt.slabs = w.slabs; tt.slab_floats = w.slab_floats;
-    PC_TRY(launch_gemm_tn(tt, st));
+    tt.slabs = w.slabs[1]; tt.slab_floats = w.slab_floats[1];
     // dE_c[topk] += dtp typ_w     (row-sparse: only the K selected rows per sample)
     PC_TRY(launch_gemm_nt(nt_plain(w.dtp, PC_D, w.typ_wt, PC_D, nullptr, w.dce, PC_L, B * K, PC_L, PC_D), st));
-    PC_TRY(pc_scatter_add_rows_small(g->comp_types, T, topk, B * K, PC_L, w.dce, stream));
+    if (tslab) PC_TRY(launch_scatter_add_slabs(topk, B * K, PC_L, T, w.dce, w.tslabs[0], st));
+    else PC_TRY(pc_scatter_add_rows_small(g->comp_types, T, topk, B * K, PC_L, w.dce, stream));
 
     // ---- type branch (two touched similarity columns per row)
     PC_LAUNCH(type_hinge_bwd_kernel, dim3((B + 3) / 4), dim3(256), 0, st, dsims_val, pos_types, neg_types,
                        sv->c, p->comp_types, B, w.dc, g->comp_types);
     PC_TRY(pc_launch_status());
-    TnArgs td = {};
+    TnArgs& td = tn[2];
+    td = {};
     td.Z = w.dc; td.ldz = PC_L; td.A = sv->h; td.lda = LH; td.R = B; td.No = PC_L; td.Ni = LH; td.seg = siB;
-    td.dW = g->dec_w; td.lddw = LH; td.db = g->dec_b; td.slabs = w.slabs; td.slab_floats = w.slab_floats;
-    PC_TRY(launch_gemm_tn(td, st));
+    td.dW = g->dec_w; td.lddw = LH; td.db = g->dec_b; td.slabs = w.slabs[2]; td.slab_floats = w.slab_floats[2];
     NtArgs dh = nt_plain(w.dc, PC_L, w.dec_wt, PC_L, nullptr, w.dh, LH, B, LH, PC_L);
     dh.epilogue = NT_EPI_DRELU; dh.aux = sv->h; dh.ldaux = LH;
     PC_TRY(launch_gemm_nt(dh, st));
-    TnArgs te = {};
+    TnArgs& te = tn[3];
+    te = {};
     te.Z = w.dh; te.ldz = LH; te.A = p->query_types; te.lda = PC_L; te.gather = query_types; te.R = B;
     te.No = LH; te.Ni = PC_L; te.seg = siB; te.dW = g->enc_w; te.lddw = PC_L; te.db = g->enc_b;
-    te.slabs = w.slabs; te.slab_floats = w.slab_floats;
-    PC_TRY(launch_gemm_tn(te, st));
+    te.slabs = w.slabs[3]; te.slab_floats = w.slab_floats[3];
     PC_TRY(launch_gemm_nt(nt_plain(w.dh, LH, w.enc_wt, LH, nullptr, w.dt, PC_L, B, PC_L, LH), st));
-    return pc_scatter_add_rows_small(g->query_types, T, query_types, B, PC_L, w.dt, stream);
+    if (!tslab) {
+        PC_TRY(pc_scatter_add_rows_small(g->query_types, T, query_types, B, PC_L, w.dt, stream));
+        return launch_gemm_tn_group(tn, 4, nullptr, 0, st);
+    }
+    PC_TRY(launch_scatter_add_slabs(query_types, B, PC_L, T, w.dt, w.tslabs[1], st));
+    const TnReduceJob tj[2] = {{w.tslabs[0], w.tblocks[0], T * PC_L, g->comp_types, 1},
+                               {w.tslabs[1], w.tblocks[1], T * PC_L, g->query_types, 0}};
+    return launch_gemm_tn_group(tn, 4, tj, 2, st);
 }
 
 extern "C" int pc_joint_train_step(const pc_joint_tensors* p, const pc_joint_tensors* g, const int32_t* query_idx,
