@@ -239,6 +239,10 @@ struct TnArgs {
     //   Z' = scale_s * (Z - c1_s - (zaux - mean_s) * invstd_s * c2_s)
     const float* zaux; int ldzaux;
     const float *z_mean, *z_invstd, *z_scale, *z_c1, *z_c2;
+    // Z implicit: row r of Z is the one-hot vector of z_onehot[r] (< 0: a zero row; Z itself is then unused).  The
+    // product is a segmented row sum, dW[t] = sum of the A rows with z_onehot[r] == t: an nn.Embedding gradient over a
+    // small table, through the matrix cores instead of float atomics (few-row kernel only)
+    const int32_t* z_onehot;
     float* dW; int lddw; float* db;                              // db may be null
     int accumulate;                                              // 1: +=, 0: overwrite
     float* slabs; size_t slab_floats;                            // workspace
@@ -247,7 +251,7 @@ int launch_gemm_tn(const TnArgs& a, hipStream_t st);
 size_t gemm_tn_workspace_floats(int R, int No, int Ni);
 // up to PC_TN_GROUP small independent products (disjoint slab regions) as one launch + one reduce; the reduce can
 // take PC_TN_EXTRA further slab sets that other kernels filled (the joint step's type-table scatter-adds)
-#define PC_TN_GROUP 4
+#define PC_TN_GROUP 6
 #define PC_TN_EXTRA 2
 #define PC_TN_RGROUP (PC_TN_GROUP + PC_TN_EXTRA)
 struct TnGroup { TnArgs a[PC_TN_GROUP]; int tiles_i[PC_TN_GROUP], nsplit[PC_TN_GROUP], rps[PC_TN_GROUP], block0[PC_TN_GROUP + 1], n; };

@@ -38,8 +38,13 @@ __device__ __forceinline__ void tn_small_body(const TnArgs& a, int tiles_i, int 
         for (int p = 0; p < 4; p++) {
             const int r = r0 + lrow + 8 * p;
             const bool rv = r < r_end;
-            rz[p] = (rv && zcol_ok) ? *reinterpret_cast<const float4*>(a.Z + (size_t)r * a.ldz + o0 + lcol)
-                                    : make_float4(0.f, 0.f, 0.f, 0.f);
+            if (a.z_onehot) {
+                const int t = rv ? a.z_onehot[r] : -1, c = o0 + lcol;
+                rz[p] = make_float4(t == c ? 1.f : 0.f, t == c + 1 ? 1.f : 0.f, t == c + 2 ? 1.f : 0.f, t == c + 3 ? 1.f : 0.f);
+            } else {
+                rz[p] = (rv && zcol_ok) ? *reinterpret_cast<const float4*>(a.Z + (size_t)r * a.ldz + o0 + lcol)
+                                        : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
             if (a.zaux && rv && zcol_ok) {
                 const int s = seg_of_row(a.seg, r);
                 if (s != zseg) {
@@ -491,8 +496,9 @@ size_t gemm_tn_workspace_floats(int R, int No, int Ni) {
 }
 
 int launch_gemm_tn(const TnArgs& a, hipStream_t st) {
-    if (!a.Z || !a.A || !a.dW || !a.slabs || a.R <= 0 || a.No <= 0 || a.Ni <= 0) return PC_EINVAL;
-    if (a.No % 4 || a.Ni % 4 || a.ldz % 4 || a.lda % 4 || a.lddw != a.Ni) return PC_ESHAPE;
+    if ((!a.Z && !a.z_onehot) || !a.A || !a.dW || !a.slabs || a.R <= 0 || a.No <= 0 || a.Ni <= 0) return PC_EINVAL;
+    if (a.No % 4 || a.Ni % 4 || (a.Z && a.ldz % 4) || a.lda % 4 || a.lddw != a.Ni) return PC_ESHAPE;
+    if (a.z_onehot && (a.zaux || tn_full_tile(a.R, a.No, a.Ni))) return PC_ESHAPE;     // few-row kernel only
     if (((uintptr_t)a.dW & 15) || (a.db && ((uintptr_t)a.db & 15)) || ((uintptr_t)a.slabs & 15)) return PC_ESHAPE;
     int nsplit, rps;
     tn_plan(a.R, a.No, a.Ni, &nsplit, &rps);
@@ -534,8 +540,9 @@ int launch_gemm_tn_group(const TnArgs* args, int n, const TnReduceJob* extra, in
     for (int i = 0; i < n; i++) {
         const TnArgs& a = args[i];
         if (tn_full_tile(a.R, a.No, a.Ni) || a.prologue != NT_PRO_NONE) { PC_TRY(launch_gemm_tn(a, st)); continue; }
-        if (!a.Z || !a.A || !a.dW || !a.slabs || a.R <= 0 || a.No <= 0 || a.Ni <= 0) return PC_EINVAL;
-        if (a.No % 4 || a.Ni % 4 || a.ldz % 4 || a.lda % 4 || a.lddw != a.Ni) return PC_ESHAPE;
+        if ((!a.Z && !a.z_onehot) || !a.A || !a.dW || !a.slabs || a.R <= 0 || a.No <= 0 || a.Ni <= 0) return PC_EINVAL;
+        if (a.No % 4 || a.Ni % 4 || (a.Z && a.ldz % 4) || a.lda % 4 || a.lddw != a.Ni) return PC_ESHAPE;
+        if (a.z_onehot && a.zaux) return PC_EINVAL;
         if (((uintptr_t)a.dW & 15) || (a.db && ((uintptr_t)a.db & 15)) || ((uintptr_t)a.slabs & 15)) return PC_ESHAPE;
         int nsplit, rps;
         tn_plan(a.R, a.No, a.Ni, &nsplit, &rps);

@@ -343,8 +343,9 @@ struct JointWs {
     float *typ_wt, *dec_wt, *enc_wt;
     float *sims, *proj, *dproj, *dsv, *partials;      // train_step scratch
     float *h, *c, *pi, *tp;                           // train_step saved activations
-    float* slabs[4]; size_t slab_floats[4];            // one region per weight gradient: they run as one grouped launch
+    float* slabs[6]; size_t slab_floats[6];            // one region per gradient product: they run as one grouped launch
     float* tslabs[2]; int tblocks[2];                  // per-workgroup private copies of the two type-table gradients
+    int table_mode;                                    // type-table gradients: 2 one-hot products, 1 LDS slabs, 0 atomics
     size_t total;
 };
 
@@ -377,9 +378,28 @@ static JointWs joint_ws_layout(void* base, int B, int T, int K) {
     const size_t sf[4] = {gemm_tn_workspace_floats(B, PC_D, PC_D), gemm_tn_workspace_floats(B * K, PC_D, PC_L),
                           gemm_tn_workspace_floats(B, PC_L, LH), gemm_tn_workspace_floats(B, LH, PC_L)};
     for (int i = 0; i < 4; i++) { w.slab_floats[i] = sf[i]; w.slabs[i] = take(sf[i]); }
-    w.tblocks[0] = scatter_add_slab_blocks(T, B * K, PC_L);        // E_c rows picked by top-k;  0: table too large, atomics
-    w.tblocks[1] = scatter_add_slab_blocks(T, B, PC_L);            // E_q rows
-    for (int i = 0; i < 2; i++) w.tslabs[i] = take((size_t)(w.tblocks[i] > 0 ? w.tblocks[i] : 0) * T * PC_L + 4);
+    // nn.Embedding gradients of the two type tables (rows picked by top-k / by the query types).  Small tables: as
+    // one-hot products dE = onehot(idx)^T x through the few-row TN kernel, in the same grouped launch as the weight
+    // gradients (no atomics, fixed summation order); else per-workgroup LDS copies summed by the grouped reduce; else
+    // (T = 34800: a dense [T,64] product would be 55 GFLOP) hardware float atomics.
+    w.table_mode = (T <= 512 && T % 4 == 0) ? 2 : 0;
+    w.tblocks[0] = w.tblocks[1] = 0;
+    w.tslabs[0] = w.tslabs[1] = nullptr;
+    w.slab_floats[4] = w.slab_floats[5] = 0;
+    w.slabs[4] = w.slabs[5] = nullptr;
+    if (w.table_mode == 2) {
+        w.slab_floats[4] = gemm_tn_workspace_floats(B * K, T, PC_L);
+        w.slab_floats[5] = gemm_tn_workspace_floats(B, T, PC_L);
+        w.slabs[4] = take(w.slab_floats[4]);
+        w.slabs[5] = take(w.slab_floats[5]);
+    } else {
+        w.tblocks[0] = scatter_add_slab_blocks(T, B * K, PC_L);
+        w.tblocks[1] = scatter_add_slab_blocks(T, B, PC_L);
+        if (w.tblocks[0] > 0 && w.tblocks[1] > 0) {
+            w.table_mode = 1;
+            for (int i = 0; i < 2; i++) w.tslabs[i] = take((size_t)w.tblocks[i] * T * PC_L);
+        }
+    }
     w.total = off;
     return w;
 }
@@ -444,8 +464,8 @@ extern "C" int pc_joint_backward(const pc_joint_tensors* p, const pc_joint_tenso
 
     // type-table gradients: small tables are summed deterministically from per-workgroup slabs by the grouped
     // reduce at the end (E_q: overwritten there, no clear needed; E_c also takes the type hinge's atomics)
-    const bool tslab = w.tblocks[0] > 0 && w.tblocks[1] > 0;
-    if (!tslab) PC_HIP_TRY(hipMemsetAsync(g->query_types, 0, (size_t)T * PC_L * 4, st));
+    const bool tslab = w.table_mode == 1;
+    if (w.table_mode == 0) PC_HIP_TRY(hipMemsetAsync(g->query_types, 0, (size_t)T * PC_L * 4, st));
     PC_HIP_TRY(hipMemsetAsync(g->comp_types, 0, (size_t)T * PC_L * 4, st));
     TransposeBatch tb = {};
     tb.n = 3;
@@ -456,7 +476,7 @@ extern "C" int pc_joint_backward(const pc_joint_tensors* p, const pc_joint_tenso
     // The four weight gradients depend only on buffers that stay untouched to the end of the backward pass: they are
     // collected here and run as ONE grouped launch + ONE grouped slab reduce after the dX chain (each alone is 64
     // workgroups and ~13 + 5 us of latency).
-    TnArgs tn[4];
+    TnArgs tn[6];
 
     // ---- item branch
     PC_TRY(pc_hadamard_backward(dproj, sv->pi, sv->tp, B, K, w.dpi, w.dtp, stream));
@@ -473,7 +493,7 @@ extern "C" int pc_joint_backward(const pc_joint_tensors* p, const pc_joint_tenso
     // dE_c[topk] += dtp typ_w     (row-sparse: only the K selected rows per sample)
     PC_TRY(launch_gemm_nt(nt_plain(w.dtp, PC_D, w.typ_wt, PC_D, nullptr, w.dce, PC_L, B * K, PC_L, PC_D), st));
     if (tslab) PC_TRY(launch_scatter_add_slabs(topk, B * K, PC_L, T, w.dce, w.tslabs[0], st));
-    else PC_TRY(pc_scatter_add_rows_small(g->comp_types, T, topk, B * K, PC_L, w.dce, stream));
+    else if (w.table_mode == 0) PC_TRY(pc_scatter_add_rows_small(g->comp_types, T, topk, B * K, PC_L, w.dce, stream));
 
     // ---- type branch (two touched similarity columns per row)
     PC_LAUNCH(type_hinge_bwd_kernel, dim3((B + 3) / 4), dim3(256), 0, st, dsims_val, pos_types, neg_types,
@@ -492,6 +512,20 @@ extern "C" int pc_joint_backward(const pc_joint_tensors* p, const pc_joint_tenso
     te.No = LH; te.Ni = PC_L; te.seg = siB; te.dW = g->enc_w; te.lddw = PC_L; te.db = g->enc_b;
     te.slabs = w.slabs[3]; te.slab_floats = w.slab_floats[3];
     PC_TRY(launch_gemm_nt(nt_plain(w.dh, LH, w.enc_wt, LH, nullptr, w.dt, PC_L, B, PC_L, LH), st));
+    if (w.table_mode == 2) {
+        const SegInfo siT0 = make_seginfo(nullptr, B * K, 128), siT1 = make_seginfo(nullptr, B, 128);
+        TnArgs& tc = tn[4];
+        tc = {};
+        tc.z_onehot = topk; tc.A = w.dce; tc.lda = PC_L; tc.R = B * K; tc.No = T; tc.Ni = PC_L; tc.seg = siT0;
+        tc.dW = g->comp_types; tc.lddw = PC_L; tc.accumulate = 1;      // (+ the type hinge's two rows per sample, above)
+        tc.slabs = w.slabs[4]; tc.slab_floats = w.slab_floats[4];
+        TnArgs& tqy = tn[5];
+        tqy = {};
+        tqy.z_onehot = query_types; tqy.A = w.dt; tqy.lda = PC_L; tqy.R = B; tqy.No = T; tqy.Ni = PC_L; tqy.seg = siT1;
+        tqy.dW = g->query_types; tqy.lddw = PC_L; tqy.accumulate = 0;
+        tqy.slabs = w.slabs[5]; tqy.slab_floats = w.slab_floats[5];
+        return launch_gemm_tn_group(tn, 6, nullptr, 0, st);
+    }
     if (!tslab) {
         PC_TRY(pc_scatter_add_rows_small(g->query_types, T, query_types, B, PC_L, w.dt, stream));
         return launch_gemm_tn_group(tn, 4, nullptr, 0, st);

@@ -211,7 +211,7 @@ __global__ __launch_bounds__(256) void scatter_add_rows_lds_kernel(float* table,
 // Deterministic form for callers with a workspace (the fused joint step): every workgroup writes its private
 // table to its own slab; the caller sums the slabs in fixed order (tn_reduce) -- no global atomics at all
 // (the flush above is 600 k same-address float atomics for a [100,64] table and 12 k source rows: 19 us).
-__global__ __launch_bounds__(256) void scatter_add_rows_slab_kernel(const int32_t* idx, int rows, int width,
+__global__ __launch_bounds__(1024) void scatter_add_rows_slab_kernel(const int32_t* idx, int rows, int width,
                                                                     int table_rows, const float* src,
                                                                     int rows_per_block, float* slabs) {
     extern __shared__ float priv[];
@@ -256,7 +256,8 @@ int launch_scatter_add_slabs(const int32_t* idx, int rows, int width, int table_
     const int blocks = scatter_add_slab_blocks(table_rows, rows, width);
     if (blocks <= 0 || !idx || !src || !slabs) return PC_EINVAL;
     const int rpb = (rows + blocks - 1) / blocks;
-    PC_LAUNCH(scatter_add_rows_slab_kernel, dim3(blocks), dim3(256), (size_t)table_rows * width * sizeof(float), st, idx,
+    // 1024 threads: 128 rows x 64 floats = one pass of 8 elements per thread (the kernel is a chain of memory latencies)
+    PC_LAUNCH(scatter_add_rows_slab_kernel, dim3(blocks), dim3(1024), (size_t)table_rows * width * sizeof(float), st, idx,
               rows, width, table_rows, src, rpb, slabs);
     return pc_launch_status();
 }

@@ -252,3 +252,36 @@ def test_joint_eval_forward_and_topk_ties():
     big = torch.randn(7, 34800, generator=torch.Generator().manual_seed(3))
     got = ops.topk_rows(big.cuda(), 3).cpu().long()
     assert torch.equal(got, torch.topk(big, 3, dim=1).indices)
+
+
+@pytest.mark.parametrize("T", [250, 2000])
+def test_pcompanion_fused_step_table_gradient_paths(T):
+    """The fused step forms the two type-table gradients three ways depending on the table size: as one-hot products
+    through the grouped weight-gradient launch (T <= 512, T % 4 == 0: the golden tests above), from per-workgroup LDS
+    copies summed in fixed order (T = 250), with hardware float atomics (T = 2000).  Each must equal the oracle's
+    autograd gradients (dense IndexBackward semantics of the reference, p_companion.py:60-65,95-103)."""
+    from oracle import joint_oracle
+    from p_companion_amd.p_companion import PCompanion
+    c = cfg(NUM_TYPES=T)
+    gen = torch.Generator().manual_seed(T)
+    P, B = 500, 333
+    table = torch.randn(P, 128, generator=gen)
+    st = joint_oracle.init_state(T + 1, table, T)
+    model = PCompanion(c, table)
+    model.load_state_dict(st)
+    model = model.to(c.DEVICE).train()
+    batch = {"query_idx": torch.randint(0, P, (B,), generator=gen).int(),
+             "query_types": torch.randint(0, T, (B,), generator=gen),
+             "positive_types": torch.randint(0, T, (B, 1), generator=gen),
+             "negative_types": torch.randint(0, T, (B, 1), generator=gen),
+             "positive_items": torch.randn(B, 128, generator=gen),
+             "negative_items": torch.randn(B, 128, generator=gen)}
+    ref = joint_oracle.train_step({k: v.clone() for k, v in st.items()}, batch, joint_oracle.new_moments(st), 1)
+    ls, topk = model.train_step({k: v.cuda() for k, v in batch.items()})
+    assert torch.equal(topk.cpu().long(), ref["out"]["complementary_types"])
+    assert abs(float(ls[0]) - float(ref["loss"])) < 1e-5
+    for k, p in model.named_parameters():
+        if p.requires_grad:
+            want = ref["grads"][k]
+            got = p.grad.cpu()
+            assert torch.allclose(got, want, rtol=1e-4, atol=1e-6 + 1e-5 * float(want.abs().max())), k
