@@ -585,8 +585,18 @@ def joint_train_step(params, grads, query_idx, query_types, pos_types, neg_types
 
 
 # ----------------------------------------------------------------------------- building blocks
+def _pad_cols(t, mult=4):
+    """[..., c] -> [..., ceil(c / mult) * mult] with zero columns (the kernels move 16-byte chunks: contraction and
+    gradient dimensions that are not multiples of 4 -- an odd NUM_TYPES in module mode -- are zero-padded here)."""
+    c = t.shape[-1]
+    return t if c % mult == 0 else torch.nn.functional.pad(t, (0, mult - c % mult)).contiguous()
+
+
 def linear_forward(x, w, b=None, idx=None, act=0, rows=None):
     out_dim, in_dim = w.shape
+    if in_dim % 4:                                   # zero columns add nothing to x . w
+        x, w = _pad_cols(x.reshape(-1, in_dim)), _pad_cols(w)
+        in_dim = w.shape[1]
     _req(x, torch.float32, "x"); _req(w, torch.float32, "weight")
     if b is not None:
         _req(b, torch.float32, "bias", (out_dim,))
@@ -604,6 +614,10 @@ def linear_forward(x, w, b=None, idx=None, act=0, rows=None):
 def linear_backward_input(dy, w):
     out_dim, in_dim = w.shape
     rows = dy.numel() // out_dim
+    if out_dim % 4:                                  # dx = dy . w contracts over out_dim
+        dy = _pad_cols(dy.reshape(rows, out_dim))
+        w = torch.cat([w, w.new_zeros(dy.shape[1] - out_dim, in_dim)])
+        out_dim = dy.shape[1]
     _req(dy, torch.float32, "dy"); _req(w, torch.float32, "weight")
     dx = torch.empty(rows, in_dim, dtype=torch.float32, device=w.device)
     wt = torch.empty(in_dim, out_dim, dtype=torch.float32, device=w.device)
@@ -614,6 +628,10 @@ def linear_backward_input(dy, w):
 
 def linear_backward_weight(dy, x, out_dim, in_dim, idx=None, want_bias=True):
     rows = dy.numel() // out_dim
+    if out_dim % 4 or in_dim % 4:
+        dyp, xp = _pad_cols(dy.reshape(rows, out_dim)), _pad_cols(x.reshape(-1, in_dim))
+        dw, db = linear_backward_weight(dyp, xp, dyp.shape[1], xp.shape[1], idx, want_bias)
+        return dw[:out_dim, :in_dim].contiguous(), (db[:out_dim].contiguous() if db is not None else None)
     _req(dy, torch.float32, "dy"); _req(x, torch.float32, "x")
     if idx is not None:
         _req(idx, torch.int32, "idx", (rows,))

@@ -285,3 +285,17 @@ def test_pcompanion_fused_step_table_gradient_paths(T):
             want = ref["grads"][k]
             got = p.grad.cpu()
             assert torch.allclose(got, want, rtol=1e-4, atol=1e-6 + 1e-5 * float(want.abs().max())), k
+    # module mode (forward / compute_loss / backward through autograd) on the same batch: a NUM_TYPES that is not a
+    # multiple of 4 makes the similarity product's contraction / gradient dimensions odd (zero-padded in ops.py)
+    for p in model.parameters():
+        if p.grad is not None:
+            p.grad.zero_()
+    dev_batch = {k: v.cuda() for k, v in batch.items()}
+    outputs = model(dev_batch)
+    loss = model.compute_loss(dev_batch, outputs)
+    loss.backward()
+    assert abs(float(loss) - float(ref["loss"])) < 1e-5
+    for k, p in model.named_parameters():
+        if p.requires_grad:
+            want = ref["grads"][k]
+            assert torch.allclose(p.grad.cpu(), want, rtol=1e-4, atol=1e-6 + 1e-5 * float(want.abs().max())), "module mode: " + k
