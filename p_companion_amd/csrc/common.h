@@ -223,6 +223,10 @@ struct NtArgs {
 };
 int launch_gemm_nt(const NtArgs& a, hipStream_t st);
 int gemm_nt_tiles(const SegInfo& si);
+// independent few-row products (M < 192 x 128 rows, N <= 128, K <= 128, no prologue / statistics) as one launch
+#define PC_NT_GROUP 4
+struct NtSmallGroup { NtArgs a[PC_NT_GROUP]; int ks_log2[PC_NT_GROUP], block0[PC_NT_GROUP + 1], n; };
+int launch_gemm_nt_group(const NtArgs* args, int n, hipStream_t st);
 
 struct TransposeJob { const float* in; float* out; int rows, cols; };   // out[c][r] = in[r][c]
 struct TransposeBatch { TransposeJob job[4]; int n; };

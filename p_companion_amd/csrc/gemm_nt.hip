@@ -188,8 +188,6 @@ __global__ __launch_bounds__(64 * NWM * NWN, WPS) void gemm_nt_kernel(NtArgs a, 
 
     // fragment addresses: stage row (lane & 31) of the wave's 64-row strip, chunk (2 kk + (lane >> 5)) ^ swizzle
     const int fr = lane & 31;
-    const int fsw = ((lane >> 5) ^ ((fr / RB) % CPR)) << 2;            // kk = 0; kk > 0 flips bits above it
-    const int fa = (wm * 64 + fr) * BK + fsw, fb = (BM + wn * 64 + fr) * BK + fsw;
 
     // One K-step = one k group of 16: lane (row fr, half lane >> 5) holds k = 8 (lane >> 5) .. + 7 of its rows, i.e. the
     // two 16-B chunks 2 (lane >> 5), + 1 of the stage row.  A blocks are split once, each W block as it is used;
@@ -437,13 +435,13 @@ __global__ __launch_bounds__(64 * NWM * NWN, WPS) void gemm_nt_kernel(NtArgs a, 
 // columns, requests the WHOLE K extent of its A rows and of W in one burst of LDS-DMA, waits once,
 // and each wave multiplies its 32x32 block.  K <= 128, N <= 128; no prologue / statistics.
 // Stage rows are KS = 32/64/128 floats (K rounded up), chunks XOR-swizzled as above.
-template <int EPI>
-__global__ __launch_bounds__(256) void gemm_nt_small_kernel(NtArgs a, int ks_log2) {
+// (EPI: a compile-time constant in the single-product kernel, the member's own value in the grouped one -- the
+// kernel is latency-bound, a uniform switch per element costs nothing)
+__device__ __forceinline__ void nt_small_body(const NtArgs& a, int ks_log2, int tile, const int EPI) {
     extern __shared__ __attribute__((aligned(1024))) float sm_small[];
     const int KS = 1 << ks_log2, CPR = KS >> 2;                  // floats / 16-B chunks per stage row
     const int tid = threadIdx.x, lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int tile = blockIdx.x;
     const int sg = seg_of_tile(a.seg, tile);
     const int row0 = a.seg.start[sg] + (tile - a.seg.tile0[sg]) * 32, row_end = a.seg.start[sg + 1];
     auto swz = [&](int r) { return KS == 32 ? (r >> 1) & 7 : r & 15; };
@@ -496,7 +494,7 @@ __global__ __launch_bounds__(256) void gemm_nt_small_kernel(NtArgs a, int ks_log
     const int er = lane >> 3, ec = (lane & 7) * 4;
     const int col = w * 32 + ec;
     const bool vec = ((a.N | a.ldc) & 3) == 0 && (!a.aux || (a.ldaux & 3) == 0);
-    constexpr bool HAS_AUX = EPI == NT_EPI_DTANH || EPI == NT_EPI_DRELU;
+    const bool HAS_AUX = EPI == NT_EPI_DTANH || EPI == NT_EPI_DRELU;
     float bias[4];
 #pragma unroll
     for (int q = 0; q < 4; q++) bias[q] = (!HAS_AUX && a.bias && col + q < a.N) ? a.bias[col + q] : 0.f;
@@ -533,6 +531,21 @@ __global__ __launch_bounds__(256) void gemm_nt_small_kernel(NtArgs a, int ks_log
     }
 }
 
+template <int EPI>
+__global__ __launch_bounds__(256) void gemm_nt_small_kernel(NtArgs a, int ks_log2) {
+    nt_small_body(a, ks_log2, blockIdx.x, EPI);
+}
+
+// Up to PC_NT_GROUP mutually independent few-row products in one launch (the joint step's encoder next to the item
+// projection, dE_c next to the hidden-layer gradient): workgroups [block0[j], block0[j+1]) run product j.
+__global__ __launch_bounds__(256) void gemm_nt_small_group_kernel(NtSmallGroup g) {
+    const int b = blockIdx.x;
+    int j = 0;
+#pragma unroll
+    for (int i = 1; i < PC_NT_GROUP; i++) j += (i < g.n && b >= g.block0[i]) ? 1 : 0;
+    nt_small_body(g.a[j], g.ks_log2[j], b - g.block0[j], g.a[j].epilogue);
+}
+
 static SegInfo retile(const SegInfo& in, int tile_rows) {
     SegInfo si = in;
     int t = 0;
@@ -558,7 +571,7 @@ static void launch_variant(const NtArgs& a, int ntm, hipStream_t st) {
         return;
     }
     if (PRO || a.N > 128 || STATS != NT_STAT_NONE) {
-        // 128 rows x 256 columns, 8 waves, two workgroups per CU (66 KB of LDS each): A is read once
+        // 128 rows x 256 columns, 8 waves with 256 VGPRs, one workgroup per CU: A is read once
         const int ntn = (a.N + 255) / 256;
         const int total = ntn == 2 ? ((ntm * 2 + 15) & ~15) : ntm * ntn;      // (two column tiles: paired numbering, tile_geom)
         PC_LAUNCH((gemm_nt_kernel<2, 4, PRO ? 16 : 32, 2, PRO, EPI, STATS>), dim3(total < 256 ? total : 256), dim3(512), 0, st, a, ntn,
@@ -619,6 +632,50 @@ int launch_gemm_nt(const NtArgs& a, hipStream_t st) {
         case 50:  launch_variant<false, NT_EPI_DRELU, NT_STAT_NONE>(a, ntm, st); break;
         default:  return PC_ESHAPE;
     }
+    pc_prof_end(pb, st);
+    return pc_launch_status();
+}
+
+
+static bool nt_small_ok(const NtArgs& a) {
+    if (!a.A || !a.W || !a.C || a.M <= 0 || a.N <= 0 || a.K <= 0) return false;
+    if (a.K % 4 != 0 || a.lda % 4 != 0 || a.ldw % 4 != 0) return false;
+    if (((uintptr_t)a.A | (uintptr_t)a.W | (uintptr_t)a.C) & 15) return false;
+    if (a.aux && ((uintptr_t)a.aux & 15)) return false;
+    if (a.prologue != NT_PRO_NONE || a.stats != NT_STAT_NONE || a.N > 128 || a.K > 128) return false;
+    const int e = a.epilogue;
+    if (!(e == NT_EPI_NONE || e == NT_EPI_TANH || e == NT_EPI_RELU || e == NT_EPI_DTANH || e == NT_EPI_DRELU)) return false;
+    if ((e == NT_EPI_DTANH || e == NT_EPI_DRELU) && (!a.aux || a.bias)) return false;
+    return gemm_nt_tiles(a.seg) < 192;
+}
+
+// Products that do not fit the few-row kernel are launched on their own.
+int launch_gemm_nt_group(const NtArgs* args, int n, hipStream_t st) {
+    if (!args || n < 1 || n > PC_NT_GROUP) return PC_EINVAL;
+    NtSmallGroup g = {};
+    int blocks = 0;
+    size_t lds = 0;
+    double flops = 0.0;
+    for (int i = 0; i < n; i++) {
+        if (!nt_small_ok(args[i])) { PC_TRY(launch_gemm_nt(args[i], st)); continue; }
+        const int k = g.n++;
+        g.a[k] = args[i];
+        g.a[k].seg = retile(args[i].seg, 32);
+        g.ks_log2[k] = args[i].K <= 32 ? 5 : args[i].K <= 64 ? 6 : 7;
+        g.block0[k] = blocks;
+        blocks += gemm_nt_tiles(g.a[k].seg);
+        const size_t need = (size_t)160 * (1 << g.ks_log2[k]) * 4 > (size_t)4 * 32 * PLD * 4 ? (size_t)160 * (1 << g.ks_log2[k]) * 4
+                                                                                          : (size_t)4 * 32 * PLD * 4;
+        if (need > lds) lds = need;
+        flops += 2.0 * args[i].M * (double)args[i].N * args[i].K;
+    }
+    if (g.n == 0) return PC_OK;
+    for (int k = g.n; k <= PC_NT_GROUP; k++) g.block0[k] = blocks;
+    static const hipError_t lds_attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt_small_group_kernel),
+                                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 128 * 4);
+    (void)lds_attr;
+    const int pb = pc_prof_begin(PC_KIND_GEMM_NT_SMALL, flops, st);
+    PC_LAUNCH(gemm_nt_small_group_kernel, dim3(blocks), dim3(256), lds, st, g);
     pc_prof_end(pb, st);
     return pc_launch_status();
 }

@@ -427,18 +427,21 @@ extern "C" int pc_joint_forward(const pc_joint_tensors* p, const int32_t* query_
     (void)ws; (void)ws_bytes;
     hipStream_t st = (hipStream_t)stream;
     // h = relu(enc(E_q[query_types]))      type_transition.py:17 (dropout p = 0)
-    NtArgs e = nt_plain(p->query_types, PC_L, p->enc_w, PC_L, p->enc_b, sv->h, LH, B, LH, PC_L);
+    // pi = item_projection(E_prod[query_idx])   item_prediction.py:31, p_companion.py:51
+    // (both depend on the batch only: one grouped few-row launch)
+    NtArgs first[2];
+    NtArgs& e = first[0];
+    e = nt_plain(p->query_types, PC_L, p->enc_w, PC_L, p->enc_b, sv->h, LH, B, LH, PC_L);
     e.gather = query_types; e.epilogue = NT_EPI_RELU;
-    PC_TRY(launch_gemm_nt(e, st));
+    NtArgs& ip = first[1];
+    ip = nt_plain(p->product_table, PC_D, p->itm_w, PC_D, p->itm_b, sv->pi, PC_D, B, PC_D, PC_D);
+    ip.gather = query_idx;
+    PC_TRY(launch_gemm_nt_group(first, 2, st));
     // c = dec(h)                            type_transition.py:19
     PC_TRY(launch_gemm_nt(nt_plain(sv->h, LH, p->dec_w, LH, p->dec_b, sv->c, PC_L, B, PC_L, LH), st));
     // sims = c E_c^T                        p_companion.py:60-63
     PC_TRY(launch_gemm_nt(nt_plain(sv->c, PC_L, p->comp_types, PC_L, nullptr, sims, T, B, T, PC_L), st));
     PC_TRY(pc_topk_rows(sims, B, T, K, topk, nullptr, stream));
-    // pi = item_projection(E_prod[query_idx])   item_prediction.py:31, p_companion.py:51
-    NtArgs ip = nt_plain(p->product_table, PC_D, p->itm_w, PC_D, p->itm_b, sv->pi, PC_D, B, PC_D, PC_D);
-    ip.gather = query_idx;
-    PC_TRY(launch_gemm_nt(ip, st));
     // tp = type_projection(E_c[topk])           item_prediction.py:35, p_companion.py:65
     NtArgs tpj = nt_plain(p->comp_types, PC_L, p->typ_w, PC_L, p->typ_b, sv->tp, PC_D, B * K, PC_D, PC_L);
     tpj.gather = topk;
@@ -490,10 +493,9 @@ extern "C" int pc_joint_backward(const pc_joint_tensors* p, const pc_joint_tenso
     tt.Z = w.dtp; tt.ldz = PC_D; tt.A = p->comp_types; tt.lda = PC_L; tt.gather = topk; tt.R = B * K;
     tt.No = PC_D; tt.Ni = PC_L; tt.seg = siBK; tt.dW = g->typ_w; tt.lddw = PC_L; tt.db = g->typ_b;
     tt.slabs = w.slabs[1]; tt.slab_floats = w.slab_floats[1];
-    // dE_c[topk] += dtp typ_w     (row-sparse: only the K selected rows per sample)
-    PC_TRY(launch_gemm_nt(nt_plain(w.dtp, PC_D, w.typ_wt, PC_D, nullptr, w.dce, PC_L, B * K, PC_L, PC_D), st));
-    if (tslab) PC_TRY(launch_scatter_add_slabs(topk, B * K, PC_L, T, w.dce, w.tslabs[0], st));
-    else if (w.table_mode == 0) PC_TRY(pc_scatter_add_rows_small(g->comp_types, T, topk, B * K, PC_L, w.dce, stream));
+    // dE_c[topk] += dtp typ_w     (row-sparse: only the K selected rows per sample): launched below, grouped with dh
+    NtArgs pair[2];
+    pair[0] = nt_plain(w.dtp, PC_D, w.typ_wt, PC_D, nullptr, w.dce, PC_L, B * K, PC_L, PC_D);
 
     // ---- type branch (two touched similarity columns per row)
     PC_LAUNCH(type_hinge_bwd_kernel, dim3((B + 3) / 4), dim3(256), 0, st, dsims_val, pos_types, neg_types,
@@ -503,9 +505,12 @@ extern "C" int pc_joint_backward(const pc_joint_tensors* p, const pc_joint_tenso
     td = {};
     td.Z = w.dc; td.ldz = PC_L; td.A = sv->h; td.lda = LH; td.R = B; td.No = PC_L; td.Ni = LH; td.seg = siB;
     td.dW = g->dec_w; td.lddw = LH; td.db = g->dec_b; td.slabs = w.slabs[2]; td.slab_floats = w.slab_floats[2];
-    NtArgs dh = nt_plain(w.dc, PC_L, w.dec_wt, PC_L, nullptr, w.dh, LH, B, LH, PC_L);
+    NtArgs& dh = pair[1];
+    dh = nt_plain(w.dc, PC_L, w.dec_wt, PC_L, nullptr, w.dh, LH, B, LH, PC_L);
     dh.epilogue = NT_EPI_DRELU; dh.aux = sv->h; dh.ldaux = LH;
-    PC_TRY(launch_gemm_nt(dh, st));
+    PC_TRY(launch_gemm_nt_group(pair, 2, st));
+    if (tslab) PC_TRY(launch_scatter_add_slabs(topk, B * K, PC_L, T, w.dce, w.tslabs[0], st));
+    else if (w.table_mode == 0) PC_TRY(pc_scatter_add_rows_small(g->comp_types, T, topk, B * K, PC_L, w.dce, stream));
     TnArgs& te = tn[3];
     te = {};
     te.Z = w.dh; te.ldz = LH; te.A = p->query_types; te.lda = PC_L; te.gather = query_types; te.R = B;
