@@ -299,3 +299,33 @@ def test_pcompanion_fused_step_table_gradient_paths(T):
         if p.requires_grad:
             want = ref["grads"][k]
             assert torch.allclose(p.grad.cpu(), want, rtol=1e-4, atol=1e-6 + 1e-5 * float(want.abs().max())), "module mode: " + k
+
+
+def test_p2v_forward_shapes_and_missing_neighbours():
+    """product2vec.py:70-81: neighbours that are None or have size(0) == 0 are ignored (the FFN output is returned);
+    :31-46 / :48-68: 1-D, 2-D and 3-D inputs keep their rank; numbers against the oracle in eval mode."""
+    from p_companion_amd.product2vec import Product2Vec
+    st = p2v_oracle.init_state(13)
+    st["ffn.1.running_mean"] = 0.1 * torch.randn(256, generator=torch.Generator().manual_seed(1))
+    st["ffn.1.running_var"] = 0.5 + torch.rand(256, generator=torch.Generator().manual_seed(2))
+    m = Product2Vec(cfg())
+    m.load_state_dict(st)
+    m = m.cuda().eval()
+    g = torch.Generator().manual_seed(3)
+    x, nb = torch.randn(6, 128, generator=g), torch.randn(6, 5, 128, generator=g)
+    with torch.no_grad():
+        base = m(x.cuda())
+        assert torch.equal(base, m(x.cuda(), None))
+        assert torch.equal(base, m(x.cuda(), torch.zeros(0, 5, 128).cuda()))
+        assert torch.equal(base, m.get_initial_embedding(x.cuda()))
+        np.testing.assert_allclose(base.cpu(), p2v_oracle.ffn(x, st, False), atol=5e-6)
+        one = m(x[0].cuda())                                             # a single feature vector (generate_all_embeddings)
+        assert one.shape == (128,)
+        np.testing.assert_allclose(one.cpu(), base[0].cpu(), atol=5e-6)
+        three = m.get_initial_embedding(nb.cuda())                        # [B,N,D] -> [B,N,D]
+        assert three.shape == (6, 5, 128)
+        full = m(x.cuda(), nb.cuda())
+        np.testing.assert_allclose(full.cpu(), p2v_oracle.forward(x, nb, st, False), atol=1e-5)
+        single = m.apply_attention(base[0], three[0])                     # query [D], keys [N,D] -> [D]
+        assert single.shape == (128,)
+        np.testing.assert_allclose(single.cpu(), full[0].cpu(), atol=1e-5)
