@@ -537,6 +537,17 @@ int launch_gemm_tn_group(const TnArgs* args, int n, const TnReduceJob* extra, in
     TnReduceGroup r = {};
     double flops = 0.0;
     int blocks = 0, rblocks = 0;
+    // One round of the chip (2 workgroups of this kernel per CU): when the members' own plans add up to more than
+    // 512 workgroups their splits are thinned in proportion (each then takes more 32-row chunks; fewer slabs).
+    int planned = 0;
+    for (int i = 0; i < n; i++) {
+        const TnArgs& a = args[i];
+        if (tn_full_tile(a.R, a.No, a.Ni) || a.prologue != NT_PRO_NONE || a.R <= 0 || a.No <= 0 || a.Ni <= 0) continue;
+        int ns, rp;
+        tn_plan(a.R, a.No, a.Ni, &ns, &rp);
+        planned += ((a.No + TM - 1) / TM) * ((a.Ni + TM - 1) / TM) * ns;
+    }
+    const double thin = planned > 512 ? 512.0 / planned : 1.0;
     for (int i = 0; i < n; i++) {
         const TnArgs& a = args[i];
         if (tn_full_tile(a.R, a.No, a.Ni) || a.prologue != NT_PRO_NONE) { PC_TRY(launch_gemm_tn(a, st)); continue; }
@@ -546,6 +557,12 @@ int launch_gemm_tn_group(const TnArgs* args, int n, const TnReduceJob* extra, in
         if (((uintptr_t)a.dW & 15) || (a.db && ((uintptr_t)a.db & 15)) || ((uintptr_t)a.slabs & 15)) return PC_ESHAPE;
         int nsplit, rps;
         tn_plan(a.R, a.No, a.Ni, &nsplit, &rps);
+        if (thin < 1.0) {
+            int s2 = (int)(nsplit * thin);
+            if (s2 < 1) s2 = 1;
+            rps = ((a.R + s2 - 1) / s2 + TK - 1) / TK * TK;
+            nsplit = (a.R + rps - 1) / rps;
+        }
         if ((size_t)nsplit * ((size_t)a.No * a.Ni + a.No) > a.slab_floats) return PC_EWORKSPACE;
         for (int k = 0; k < g.n; k++) {                          // slab regions must be disjoint
             const float* lo = g.a[k].slabs; const float* hi = lo + g.a[k].slab_floats;
