@@ -82,6 +82,38 @@ class _TripletLossFunction(torch.autograd.Function):
         return da * g, dp * g, dn * g, None
 
 
+class _FusedDenseLoss(torch.autograd.Function):
+    """The whole loop body of train_model (product2vec.py:132-154: four FFN calls, attention, the hinge) on a DENSE
+    reference batch as one fused HIP step: the batch's rows are laid end to end as a temporary table
+    [anchor B | neighbours B*N | positive B | negatives B*K] addressed by identity indices, so the four calls run as
+    the segments of one launch sequence and forward + backward are a single pc_p2v_train_step (every slot its own
+    row, zero padding rows included, exactly as the reference computes them).  The parameter gradients are formed
+    in forward and handed to autograd in backward (scaled by the incoming gradient)."""
+
+    @staticmethod
+    def forward(ctx, module, anchor, positive, negative, neighbors, *weights):
+        b, k, n = anchor.shape[0], negative.shape[1], neighbors.shape[1]
+        dev = anchor.device
+        table = torch.cat([anchor, neighbors.reshape(-1, ops.D), positive, negative.reshape(-1, ops.D)])
+        key = (b, n, k, dev)
+        idx = module._dense_idx.get(key)
+        if idx is None:
+            ar = lambda lo, cnt: torch.arange(lo, lo + cnt, dtype=torch.int32, device=dev)
+            idx = (ar(0, b), ar(b + b * n, b), ar(2 * b + b * n, b * k).reshape(b, k), ar(b, b * n).reshape(b, n))
+            module._dense_idx.clear()
+            module._dense_idx[key] = idx
+        names = [nm for nm, _ in module.named_parameters()]
+        grads = {nm: torch.empty_like(w) for nm, w in zip(names, weights)}
+        out = ops.p2v_train_step(module._tensor_dict(), grads, table, idx[0], idx[1], idx[2], idx[3],
+                                 float(module.config.MARGIN))
+        ctx.grads = [grads[nm] for nm in names]
+        return out["loss"].reshape(())
+
+    @staticmethod
+    def backward(ctx, g):
+        return (None, None, None, None, None) + tuple(gr * g for gr in ctx.grads)
+
+
 class FusedAdam(torch.optim.Optimizer):
     """torch.optim.Adam semantics (defaults of scripts/pretrain_product2vec.py:34) as ONE HIP
     launch over the module's flat parameter buffer.  Opt-in: any torch optimizer works too."""
@@ -176,6 +208,7 @@ class Product2Vec(nn.Module, _FlatParamsMixin):
                                                num_heads=config.NUM_ATTENTION_HEADS,
                                                dropout=config.DROPOUT, batch_first=True)
         self.last_embedding_table = None
+        self._dense_idx = {}                      # identity index arrays of the fused dense-batch step, by (B, N, K)
 
     # ------------------------------------------------------------------ plumbing
     def _tensor_dict(self):
@@ -347,7 +380,8 @@ class Product2Vec(nn.Module, _FlatParamsMixin):
             self.train()
             total = None
             num_batches = 0
-            for batch in train_loader:
+            from .data import prefetch_to_device
+            for batch in prefetch_to_device(train_loader, device):       # dense batches: next batch's PCIe copy overlaps this step
                 batch = {k: v.to(device) if isinstance(v, torch.Tensor) else v for k, v in batch.items()}
                 if "anchor_idx" in batch:
                     if table is None:
@@ -369,6 +403,17 @@ class Product2Vec(nn.Module, _FlatParamsMixin):
 
     def dense_loss(self, batch):
         """product2vec.py:132-154 on a dense reference batch (anchor/positive/negative[/anchor_neighbors])."""
+        nb = batch.get("anchor_neighbors")
+        a, p, n = batch["anchor"], batch["positive"], batch["negative"]
+        if (self.training and torch.is_grad_enabled() and nb is not None and nb.dim() == 3 and nb.shape[0] == a.shape[0]
+                and nb.shape[1] > 0 and a.dim() == 2 and p.dim() == 2 and n.dim() == 3 and a.shape[0] > 1
+                and not any(t.requires_grad for t in (a, p, n, nb))):
+            # training on device batches: the fused step (same numbers as the four module calls below, one launch
+            # sequence instead of four forward + four backward ones)
+            self._check_dropout()
+            dev = self.ffn[0].weight.device
+            f = lambda t: t.to(device=dev, dtype=torch.float32).contiguous()
+            return _FusedDenseLoss.apply(self, f(a), f(p), f(n), f(nb), *[w for _, w in self.named_parameters()])
         anchor_emb = self(batch["anchor"], batch.get("anchor_neighbors"))
         positive_emb = self(batch["positive"])
         negative_emb = self(batch["negative"])

@@ -37,6 +37,26 @@ def step(hb, copy=True):
     return loss
 
 
+from p_companion_amd.data import prefetch_to_device
+
+
+def overlapped():
+    def gen(count):
+        for i in range(count):
+            yield host[i % 4]
+    for hb in prefetch_to_device(gen(warm), dev):
+        step(hb, False)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for hb in prefetch_to_device(gen(steps), dev):
+        step(hb, False)
+    torch.cuda.synchronize()
+    ms = 1e3 * (time.perf_counter() - t0) / steps
+    print(f"dense path, pinned host batches, next batch's copy on a side stream (train_model's loop): {ms:.3f} ms/step = "
+          f"{B / ms * 1e3 / 1e6:.3f} M triplets/s")
+
+
+overlapped()
 for mode in ("pcie", "resident"):
     batches = host if mode == "pcie" else [{k: v.to(dev) for k, v in hb.items()} for hb in host]
     for i in range(warm):

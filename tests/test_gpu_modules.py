@@ -329,3 +329,41 @@ def test_p2v_forward_shapes_and_missing_neighbours():
         single = m.apply_attention(base[0], three[0])                     # query [D], keys [N,D] -> [D]
         assert single.shape == (128,)
         np.testing.assert_allclose(single.cpu(), full[0].cpu(), atol=1e-5)
+
+
+def test_p2v_dense_loss_fused_path_equals_module_calls(golden):
+    """dense_loss on a device batch takes ONE fused step (_FusedDenseLoss); the reference's loop body spelled out with
+    the module's own calls (four FFN passes, attention, the hinge, autograd) must give the same loss, the same
+    gradients and the same BatchNorm running statistics, on the golden tiny batch and on a ragged random one."""
+    import torch.nn.functional as F
+    from p_companion_amd.product2vec import Product2Vec
+    g = golden("g4_p2v_tiny.npz")
+    c = cfg()
+    gb = {k[6:]: torch.from_numpy(g[k]).cuda() for k in g.files if k.startswith("batch.")}
+    gen = torch.Generator().manual_seed(8)
+    rb = {"anchor": torch.randn(37, 128, generator=gen).cuda(), "positive": torch.randn(37, 128, generator=gen).cuda(),
+          "negative": torch.randn(37, 5, 128, generator=gen).cuda(),
+          "anchor_neighbors": (torch.randn(37, 9, 128, generator=gen) * (torch.rand(37, 9, 1, generator=gen) > 0.3)).cuda()}
+    for batch in (gb, rb):
+        ms = []
+        for fused in (True, False):
+            m = Product2Vec(c)
+            m.load_state_dict(golden_state(g))
+            m = m.to(c.DEVICE).train()
+            if fused:
+                loss = m.dense_loss(batch)
+            else:
+                a = m(batch["anchor"], batch["anchor_neighbors"])
+                p = m(batch["positive"])
+                n = m(batch["negative"])
+                dn = torch.mean(F.pairwise_distance(a.unsqueeze(1).expand(-1, n.size(1), -1), n, p=2), dim=1)
+                loss = F.relu(c.MARGIN - F.pairwise_distance(a, p) + dn).mean()
+            loss.backward()
+            ms.append((m, float(loss)))
+        (mf, lf), (mm, lm) = ms
+        assert abs(lf - lm) < 1e-5
+        for (k, pf), (_, pm) in zip(mf.named_parameters(), mm.named_parameters()):
+            tol = 2e-6 + 2e-4 * float(pm.grad.abs().max())
+            assert torch.allclose(pf.grad, pm.grad, rtol=0, atol=tol), k
+        for k in ("ffn.1.running_mean", "ffn.1.running_var", "ffn.1.num_batches_tracked"):
+            assert torch.allclose(mf.state_dict()[k].float(), mm.state_dict()[k].float(), atol=1e-6), k
