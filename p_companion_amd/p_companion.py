@@ -41,6 +41,59 @@ class _JointLoss(torch.autograd.Function):
         return dense * g, dproj * g, None, None, None, None, None, None, None
 
 
+class _LazyJointForward(torch.autograd.Function):
+    """forward(batch) in training mode as ONE fused launch sequence (pc_joint_forward).  The reference's loop hands
+    the outputs straight to compute_loss, which then takes the fused step and never differentiates through them; if
+    anything else does (a caller's own loss on `projected_embeddings` / `type_similarities`), backward rebuilds the
+    per-op autograd graph of the same forward and differentiates that -- same gradients, paid only when used."""
+
+    @staticmethod
+    def forward(ctx, module, query_idx, query_types, k, *weights):
+        params = module._tensor_dict()
+        params["product_embeddings.weight"] = module.product_embeddings.weight
+        sims, topk, proj, _ = ops.joint_forward(params, query_idx, query_types, k)
+        ctx.module, ctx.args = module, (query_idx, query_types, k)
+        ctx.nw = len(weights)
+        ctx.mark_non_differentiable(topk)
+        return sims, topk, proj
+
+    @staticmethod
+    def backward(ctx, dsims, _dtopk, dproj):
+        module = ctx.module
+        weights = [p for p in module.parameters() if p.requires_grad]
+        with torch.enable_grad():
+            sims, _, proj = module._forward_graph(*ctx.args)
+            outs, gouts = [], []
+            for o, g in ((sims, dsims), (proj, dproj)):
+                if g is not None:
+                    outs.append(o); gouts.append(g.contiguous())
+            grads = torch.autograd.grad(outs, weights, gouts, allow_unused=True)
+        return (None, None, None, None) + tuple(grads)
+
+
+class _FusedJointLoss(torch.autograd.Function):
+    """compute_loss(batch, outputs) when `outputs` is what forward(batch) just returned in training mode: the whole
+    loop body train.py:42-46 is then known, and forward + both hinges + backward run as ONE pc_joint_train_step
+    (type-hinge gradient kept sparse, type-table gradients without a dense [B,T] detour) instead of autograd walking
+    the per-op graph.  The parameter gradients are formed here and handed to autograd in backward."""
+
+    @staticmethod
+    def forward(ctx, module, query_idx, query_types, pos_types, neg_types, pos_items, neg_items, *weights):
+        names = [k for k, p in module.named_parameters() if p.requires_grad]
+        grads = {k: torch.empty_like(w) for k, w in zip(names, weights)}
+        params = module._tensor_dict()
+        params["product_embeddings.weight"] = module.product_embeddings.weight
+        losses, _ = ops.joint_train_step(params, grads, query_idx, query_types, pos_types, neg_types, pos_items, neg_items,
+                                         int(module.config.NUM_COMP_TYPES), float(module.config.MARGIN),
+                                         float(module.config.ALPHA))
+        ctx.grads = [grads[k] for k in names]
+        return losses[0].reshape(())
+
+    @staticmethod
+    def backward(ctx, g):
+        return (None,) * 7 + tuple(torch._foreach_mul(ctx.grads, g))      # one multi-tensor launch
+
+
 class PCompanion(nn.Module, _FlatParamsMixin):
     _flat_keys = ops.JOINT_KEYS
 
@@ -95,6 +148,18 @@ class PCompanion(nn.Module, _FlatParamsMixin):
             sims, topk, proj, _ = ops.joint_forward(self._tensor_dict(), query_indices, query_types, k)
             return {"projected_embeddings": proj, "complementary_types": topk.long(), "type_similarities": sims}
 
+        self._pending = None
+        weights = [p for p in self.parameters() if p.requires_grad]
+        similarities, top_k, projected_embeddings = _LazyJointForward.apply(self, query_indices, query_types, k, *weights)
+        outputs = {"projected_embeddings": projected_embeddings, "complementary_types": top_k.long(),
+                   "type_similarities": similarities}
+        # remembered so that compute_loss(batch, outputs) on exactly this pair can take the fused step
+        self._pending = (outputs, projected_embeddings, similarities, query_indices, query_types,
+                         tuple(p._version for p in self.parameters()))
+        return outputs
+
+    def _forward_graph(self, query_indices, query_types, k):
+        """p_companion.py:45-77 op by op through the autograd Functions (what _LazyJointForward differentiates)."""
         query_embeddings = embedding(self.product_embeddings.weight, query_indices)
         query_type_emb = embedding(self.query_type_embeddings.weight, query_types)
         comp_base = self.type_transition(query_type_emb)
@@ -102,8 +167,7 @@ class PCompanion(nn.Module, _FlatParamsMixin):
         top_k = ops.topk_rows(similarities.detach(), k)                                     # indices: no gradient
         comp_type_embeddings = embedding(self.complementary_type_embeddings.weight, top_k)
         projected_embeddings = self.item_prediction(query_embeddings, comp_type_embeddings)
-        return {"projected_embeddings": projected_embeddings, "complementary_types": top_k.long(),
-                "type_similarities": similarities}
+        return similarities, top_k, projected_embeddings
 
     def _loss(self, batch, outputs, which):
         dev = outputs["type_similarities"].device
@@ -115,6 +179,21 @@ class PCompanion(nn.Module, _FlatParamsMixin):
 
     def compute_loss(self, batch, outputs):
         """Compute combined loss for type transition and item prediction (p_companion.py:79-93)"""
+        pend = getattr(self, "_pending", None)
+        self._pending = None
+        if (pend is not None and outputs is pend[0] and outputs.get("projected_embeddings") is pend[1]
+                and outputs.get("type_similarities") is pend[2] and self.training and torch.is_grad_enabled()
+                and pend[5] == tuple(p._version for p in self.parameters())
+                and not any(isinstance(batch[k], torch.Tensor) and batch[k].requires_grad
+                            for k in ("positive_items", "negative_items"))):
+            # the reference's loop body, recognised: forward(batch) then compute_loss(batch, its outputs), parameters
+            # untouched in between -> one fused step (the autograd graph forward recorded is simply dropped)
+            dev = pend[3].device
+            weights = [p for p in self.parameters() if p.requires_grad]
+            return _FusedJointLoss.apply(
+                self, pend[3], pend[4], self._i32(batch["positive_types"].to(dev)), self._i32(batch["negative_types"].to(dev)),
+                batch["positive_items"].to(dev).float().contiguous(), batch["negative_items"].to(dev).float().contiguous(),
+                *weights)
         return self._loss(batch, outputs, 0)
 
     def _compute_type_loss(self, type_similarities, positive_types, negative_types):

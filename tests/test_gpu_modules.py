@@ -299,6 +299,26 @@ def test_pcompanion_fused_step_table_gradient_paths(T):
         if p.requires_grad:
             want = ref["grads"][k]
             assert torch.allclose(p.grad.cpu(), want, rtol=1e-4, atol=1e-6 + 1e-5 * float(want.abs().max())), "module mode: " + k
+    # a caller's OWN loss on the outputs (not compute_loss): forward ran as one fused launch sequence, so backward has to
+    # rebuild the per-op graph (_LazyJointForward) -- gradients against torch autograd over the oracle's forward
+    for p in model.parameters():
+        if p.grad is not None:
+            p.grad.zero_()
+    outputs = model(dev_batch)
+    own = outputs["projected_embeddings"].square().mean() + 0.3 * outputs["type_similarities"].tanh().mean()
+    own.backward()
+    leaves = {n: st[n].clone().requires_grad_(True) for n in joint_oracle.TRAINABLE}
+    work = dict(st)
+    work.update(leaves)
+    o = joint_oracle.forward(work, batch["query_idx"], batch["query_types"], 3)
+    ref_own = o["projected_embeddings"].square().mean() + 0.3 * o["type_similarities"].tanh().mean()
+    want_all = torch.autograd.grad(ref_own, [leaves[n] for n in joint_oracle.TRAINABLE], allow_unused=True)
+    assert abs(float(own) - float(ref_own)) < 1e-5
+    for n, want in zip(joint_oracle.TRAINABLE, want_all):
+        got = dict(model.named_parameters())[n].grad
+        want = torch.zeros_like(st[n]) if want is None else want
+        got = torch.zeros_like(want) if got is None else got.cpu()
+        assert torch.allclose(got, want, rtol=1e-4, atol=1e-7 + 1e-5 * float(want.abs().max())), "own loss: " + n
 
 
 def test_p2v_forward_shapes_and_missing_neighbours():
