@@ -387,3 +387,27 @@ def test_p2v_dense_loss_fused_path_equals_module_calls(golden):
             assert torch.allclose(pf.grad, pm.grad, rtol=0, atol=tol), k
         for k in ("ffn.1.running_mean", "ffn.1.running_var", "ffn.1.num_batches_tracked"):
             assert torch.allclose(mf.state_dict()[k].float(), mm.state_dict()[k].float(), atol=1e-6), k
+
+
+@pytest.mark.parametrize("k", [1, 3, 4, 6])
+def test_topk_rows_against_torch(k):
+    """pc_topk_rows (p_companion.py:64) for every compile-time / run-time K form, vector and scalar row reads, ties
+    and -inf entries: torch.topk on the CPU is the reference (ties: lower index first, as torch's CPU kernel does for
+    these inputs is NOT guaranteed, so ties are checked by value and by the lowest-index rule directly)."""
+    from p_companion_amd import ops
+    g = torch.Generator().manual_seed(k)
+    for T in (7, 64, 1001, 34800):
+        x = torch.randn(13, T, generator=g)
+        if T > 64:
+            x[:, ::97] = float("-inf")
+            x[3, 5] = x[3, 900] = 9.0                      # a tie for the top value: the lower column wins
+        kk = min(k, T)
+        idx, val = ops.topk_rows(x.cuda(), kk, want_values=True)
+        ref = torch.topk(x, kk, dim=1)
+        assert torch.equal(val.cpu(), ref.values)
+        assert torch.equal(torch.gather(x, 1, idx.cpu().long()), ref.values)
+        if T > 64:
+            assert int(idx[3, 0]) == 5 and (kk < 2 or int(idx[3, 1]) == 900)
+    allneg = torch.full((2, 40), float("-inf"))
+    idx = ops.topk_rows(allneg.cuda(), min(k, 8))
+    assert idx.cpu().tolist() == [list(range(min(k, 8)))] * 2      # lowest indices, as before
