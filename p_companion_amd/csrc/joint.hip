@@ -241,6 +241,55 @@ __global__ __launch_bounds__(256) void joint_loss_kernel(const float* sims, cons
     if (lane == 0) part_item[b] = li;
 }
 
+// The fused training step's version of the four per-sample kernels between the projections and the dX chain --
+// proj = pi * tp (item_prediction.py:38), both hinges (p_companion.py:95-119), d(proj) -> d(pi), d(tp), and the sparse
+// type-hinge backward (dc, dE_c rows) -- as ONE pass, one wave per sample: the gradient scales 1/B and 1/(B K) are
+// constants, so nothing here waits for the mean.  proj itself is never written (nothing else reads it in this step).
+__global__ __launch_bounds__(256) void joint_rowwise_kernel(const float* sims, const float* pi, const float* tp,
+                                                            const int32_t* pos_t, const int32_t* neg_t,
+                                                            const float* pos_items, const float* neg_items,
+                                                            const float* c, const float* ec, int B, int T, int K,
+                                                            float margin, float alpha, float* part_type,
+                                                            float* part_item, float* dpi, float* dtp, float* dc,
+                                                            float* dec) {
+    const int lane = threadIdx.x & 63;
+    const int b = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (b >= B) return;
+    const int p = pos_t[b], n = neg_t[b];
+    const float lt = margin - sims[(size_t)b * T + p] + sims[(size_t)b * T + n];
+    const float gt = lt > 0.f ? (1.0f - alpha) / (float)B : 0.f;
+    const float v0 = -gt, v1 = gt;
+    if (lane == 0) part_type[b] = lt > 0.f ? lt : 0.f;
+    const float cb = c[(size_t)b * PC_L + lane];
+    dc[(size_t)b * PC_L + lane] = v0 * ec[(size_t)p * PC_L + lane] + v1 * ec[(size_t)n * PC_L + lane];
+    if (gt != 0.f) {
+        unsafeAtomicAdd(dec + (size_t)p * PC_L + lane, v0 * cb);
+        unsafeAtomicAdd(dec + (size_t)n * PC_L + lane, v1 * cb);
+    }
+    const float2 a = *reinterpret_cast<const float2*>(pi + (size_t)b * PC_D + 2 * lane);
+    const float2 pp = *reinterpret_cast<const float2*>(pos_items + (size_t)b * PC_D + 2 * lane);
+    const float2 nn = *reinterpret_cast<const float2*>(neg_items + (size_t)b * PC_D + 2 * lane);
+    float li = 0.f;
+    float2 acc = make_float2(0.f, 0.f);
+    for (int k = 0; k < K; k++) {
+        const size_t o = ((size_t)b * K + k) * PC_D + 2 * lane;
+        const float2 t = *reinterpret_cast<const float2*>(tp + o);
+        const float2 x = make_float2(a.x * t.x, a.y * t.y);
+        const float2 dp = make_float2(x.x - pp.x, x.y - pp.y), dn = make_float2(x.x - nn.x, x.y - nn.y);
+        const float np_ = sqrtf(wave_sum(dp.x * dp.x + dp.y * dp.y));
+        const float nn_ = sqrtf(wave_sum(dn.x * dn.x + dn.y * dn.y));
+        const float l = margin - np_ + nn_;
+        li += l > 0.f ? l : 0.f;
+        const float g = l > 0.f ? alpha / ((float)B * (float)K) : 0.f;
+        const float ip = np_ > 0.f ? g / np_ : 0.f, in = nn_ > 0.f ? g / nn_ : 0.f;   // torch.norm: subgradient 0 at 0
+        const float2 d = make_float2(-dp.x * ip + dn.x * in, -dp.y * ip + dn.y * in);
+        acc.x += d.x * t.x; acc.y += d.y * t.y;
+        *reinterpret_cast<float2*>(dtp + o) = make_float2(d.x * a.x, d.y * a.y);
+    }
+    *reinterpret_cast<float2*>(dpi + (size_t)b * PC_D + 2 * lane) = acc;
+    if (lane == 0) part_item[b] = li;
+}
+
 __global__ void joint_loss_reduce_kernel(const float* part_type, const float* part_item, int B, int K, float alpha,
                                          float* losses) {
     __shared__ float r0[256], r1[256];
@@ -446,11 +495,12 @@ static int joint_check(const pc_joint_tensors* p, int B, int T, int K) {
     return PC_OK;
 }
 
-extern "C" int pc_joint_forward(const pc_joint_tensors* p, const int32_t* query_idx, const int32_t* query_types,
-                                int B, int T, int K, float* sims, int32_t* topk, float* proj,
-                                const pc_joint_saved* sv, void* ws, size_t ws_bytes, void* stream) {
+static int joint_forward_impl(const pc_joint_tensors* p, const int32_t* query_idx, const int32_t* query_types,
+                              int B, int T, int K, float* sims, int32_t* topk, float* proj,
+                              const pc_joint_saved* sv, void* ws, size_t ws_bytes, void* stream) {
+    // proj == nullptr: the caller (the fused step) forms proj = pi * tp itself, inside joint_rowwise_kernel
     PC_TRY(joint_check(p, B, T, K));
-    if (!query_idx || !query_types || !sims || !topk || !proj || !sv || !sv->h || !sv->c || !sv->pi || !sv->tp)
+    if (!query_idx || !query_types || !sims || !topk || !sv || !sv->h || !sv->c || !sv->pi || !sv->tp)
         return PC_EINVAL;
     (void)ws; (void)ws_bytes;
     hipStream_t st = (hipStream_t)stream;
@@ -474,20 +524,29 @@ extern "C" int pc_joint_forward(const pc_joint_tensors* p, const int32_t* query_
     NtArgs tpj = nt_plain(p->comp_types, PC_L, p->typ_w, PC_L, p->typ_b, sv->tp, PC_D, B * K, PC_D, PC_L);
     tpj.gather = topk;
     PC_TRY(launch_gemm_nt(tpj, st));
-    return pc_hadamard_forward(sv->pi, sv->tp, B, K, proj, stream);
+    return proj ? pc_hadamard_forward(sv->pi, sv->tp, B, K, proj, stream) : PC_OK;
 }
 
-extern "C" int pc_joint_backward(const pc_joint_tensors* p, const pc_joint_tensors* g, const int32_t* query_idx,
-                                 const int32_t* query_types, const int32_t* pos_types, const int32_t* neg_types,
-                                 const int32_t* topk, int B, int T, int K, const float* dsims_val,
-                                 const float* dproj, const pc_joint_saved* sv, void* ws, size_t ws_bytes,
-                                 void* stream) {
+extern "C" int pc_joint_forward(const pc_joint_tensors* p, const int32_t* query_idx, const int32_t* query_types,
+                                int B, int T, int K, float* sims, int32_t* topk, float* proj,
+                                const pc_joint_saved* sv, void* ws, size_t ws_bytes, void* stream) {
+    if (!proj) return PC_EINVAL;
+    return joint_forward_impl(p, query_idx, query_types, B, T, K, sims, topk, proj, sv, ws, ws_bytes, stream);
+}
+
+// rowwise_done: joint_rowwise_kernel has already produced dpi / dtp / dc and the type hinge's dE_c rows (into a
+// cleared g->comp_types): the table clears, the Hadamard backward and the type-hinge backward are skipped here.
+static int joint_backward_impl(const pc_joint_tensors* p, const pc_joint_tensors* g, const int32_t* query_idx,
+                               const int32_t* query_types, const int32_t* pos_types, const int32_t* neg_types,
+                               const int32_t* topk, int B, int T, int K, const float* dsims_val,
+                               const float* dproj, const pc_joint_saved* sv, void* ws, size_t ws_bytes,
+                               void* stream, bool rowwise_done) {
     PC_TRY(joint_check(p, B, T, K));
     if (!g || !g->enc_w || !g->enc_b || !g->dec_w || !g->dec_b || !g->typ_w || !g->typ_b || !g->itm_w ||
         !g->itm_b || !g->query_types || !g->comp_types)
         return PC_EINVAL;
-    if (!query_idx || !query_types || !pos_types || !neg_types || !topk || !dsims_val || !dproj || !sv || !ws)
-        return PC_EINVAL;
+    if (!query_idx || !query_types || !pos_types || !neg_types || !topk || !sv || !ws) return PC_EINVAL;
+    if (!rowwise_done && (!dsims_val || !dproj)) return PC_EINVAL;
     if (ws_bytes < pc_joint_workspace_bytes(B, T, K)) return PC_EWORKSPACE;
     hipStream_t st = (hipStream_t)stream;
     JointWs w = joint_ws_layout(ws, B, T, K);
@@ -496,8 +555,10 @@ extern "C" int pc_joint_backward(const pc_joint_tensors* p, const pc_joint_tenso
     // type-table gradients: small tables are summed deterministically from per-workgroup slabs by the grouped
     // reduce at the end (E_q: overwritten there, no clear needed; E_c also takes the type hinge's atomics)
     const bool tslab = w.table_mode == 1;
-    if (w.table_mode == 0) PC_HIP_TRY(hipMemsetAsync(g->query_types, 0, (size_t)T * PC_L * 4, st));
-    PC_HIP_TRY(hipMemsetAsync(g->comp_types, 0, (size_t)T * PC_L * 4, st));
+    if (!rowwise_done) {
+        if (w.table_mode == 0) PC_HIP_TRY(hipMemsetAsync(g->query_types, 0, (size_t)T * PC_L * 4, st));
+        PC_HIP_TRY(hipMemsetAsync(g->comp_types, 0, (size_t)T * PC_L * 4, st));
+    }
     TransposeBatch tb = {};
     tb.n = 3;
     tb.job[0] = {p->typ_w, w.typ_wt, PC_D, PC_L};                    // [D,L] -> [L,D]
@@ -510,7 +571,7 @@ extern "C" int pc_joint_backward(const pc_joint_tensors* p, const pc_joint_tenso
     TnArgs tn[6];
 
     // ---- item branch
-    PC_TRY(pc_hadamard_backward(dproj, sv->pi, sv->tp, B, K, w.dpi, w.dtp, stream));
+    if (!rowwise_done) PC_TRY(pc_hadamard_backward(dproj, sv->pi, sv->tp, B, K, w.dpi, w.dtp, stream));
     TnArgs& ti = tn[0];
     ti = {};
     ti.Z = w.dpi; ti.ldz = PC_D; ti.A = p->product_table; ti.lda = PC_D; ti.gather = query_idx; ti.R = B;
@@ -526,9 +587,11 @@ extern "C" int pc_joint_backward(const pc_joint_tensors* p, const pc_joint_tenso
     pair[0] = nt_plain(w.dtp, PC_D, w.typ_wt, PC_D, nullptr, w.dce, PC_L, B * K, PC_L, PC_D);
 
     // ---- type branch (two touched similarity columns per row)
-    PC_LAUNCH(type_hinge_bwd_kernel, dim3((B + 3) / 4), dim3(256), 0, st, dsims_val, pos_types, neg_types,
-                       sv->c, p->comp_types, B, w.dc, g->comp_types);
-    PC_TRY(pc_launch_status());
+    if (!rowwise_done) {
+        PC_LAUNCH(type_hinge_bwd_kernel, dim3((B + 3) / 4), dim3(256), 0, st, dsims_val, pos_types, neg_types,
+                           sv->c, p->comp_types, B, w.dc, g->comp_types);
+        PC_TRY(pc_launch_status());
+    }
     TnArgs& td = tn[2];
     td = {};
     td.Z = w.dc; td.ldz = PC_L; td.A = sv->h; td.lda = LH; td.R = B; td.No = PC_L; td.Ni = LH; td.seg = siB;
@@ -569,22 +632,41 @@ extern "C" int pc_joint_backward(const pc_joint_tensors* p, const pc_joint_tenso
     return launch_gemm_tn_group(tn, 4, tj, 2, st);
 }
 
+extern "C" int pc_joint_backward(const pc_joint_tensors* p, const pc_joint_tensors* g, const int32_t* query_idx,
+                                 const int32_t* query_types, const int32_t* pos_types, const int32_t* neg_types,
+                                 const int32_t* topk, int B, int T, int K, const float* dsims_val,
+                                 const float* dproj, const pc_joint_saved* sv, void* ws, size_t ws_bytes,
+                                 void* stream) {
+    return joint_backward_impl(p, g, query_idx, query_types, pos_types, neg_types, topk, B, T, K, dsims_val, dproj, sv,
+                               ws, ws_bytes, stream, false);
+}
+
 extern "C" int pc_joint_train_step(const pc_joint_tensors* p, const pc_joint_tensors* g, const int32_t* query_idx,
                                    const int32_t* query_types, const int32_t* pos_types, const int32_t* neg_types,
                                    const float* pos_items, const float* neg_items, int B, int T, int K,
                                    float margin, float alpha, float* losses, int32_t* topk, void* ws,
                                    size_t ws_bytes, void* stream) {
     PC_TRY(joint_check(p, B, T, K));
-    if (!ws || !losses || !topk) return PC_EINVAL;
+    if (!ws || !losses || !topk || !g || !g->comp_types || !g->query_types || !pos_types || !neg_types || !pos_items ||
+        !neg_items)
+        return PC_EINVAL;
     if (ws_bytes < pc_joint_workspace_bytes(B, T, K)) return PC_EWORKSPACE;
+    hipStream_t st = (hipStream_t)stream;
     JointWs w = joint_ws_layout(ws, B, T, K);
     pc_joint_saved sv;
     sv.h = w.h; sv.c = w.c; sv.pi = w.pi; sv.tp = w.tp;
-    PC_TRY(pc_joint_forward(p, query_idx, query_types, B, T, K, w.sims, topk, w.proj, &sv, ws, ws_bytes, stream));
-    PC_TRY(pc_joint_loss(w.sims, w.proj, pos_types, neg_types, pos_items, neg_items, B, T, K, margin, alpha, losses,
-                         w.dsv, w.dproj, w.partials, stream));
-    return pc_joint_backward(p, g, query_idx, query_types, pos_types, neg_types, topk, B, T, K, w.dsv, w.dproj, &sv,
-                             ws, ws_bytes, stream);
+    // the table-gradient clears come first: the row-wise pass below already adds the type hinge's rows
+    if (w.table_mode == 0) PC_HIP_TRY(hipMemsetAsync(g->query_types, 0, (size_t)T * PC_L * 4, st));
+    PC_HIP_TRY(hipMemsetAsync(g->comp_types, 0, (size_t)T * PC_L * 4, st));
+    PC_TRY(joint_forward_impl(p, query_idx, query_types, B, T, K, w.sims, topk, nullptr, &sv, ws, ws_bytes, stream));
+    PC_LAUNCH(joint_rowwise_kernel, dim3((B + 3) / 4), dim3(256), 0, st, w.sims, sv.pi, sv.tp, pos_types, neg_types,
+              pos_items, neg_items, sv.c, p->comp_types, B, T, K, margin, alpha, w.partials, w.partials + B, w.dpi, w.dtp,
+              w.dc, g->comp_types);
+    PC_TRY(pc_launch_status());
+    PC_LAUNCH(joint_loss_reduce_kernel, dim3(1), dim3(256), 0, st, w.partials, w.partials + B, B, K, alpha, losses);
+    PC_TRY(pc_launch_status());
+    return joint_backward_impl(p, g, query_idx, query_types, pos_types, neg_types, topk, B, T, K, nullptr, nullptr, &sv,
+                               ws, ws_bytes, stream, true);
 }
 
 // ---------------------------------------------------------------------------------------
