@@ -30,6 +30,8 @@ extern "C" {
 #define PC_EINVAL (-1)   /* null pointer / non-positive size */
 #define PC_ESHAPE (-2)   /* dimension not supported by the kernels (see each function) */
 #define PC_EWORKSPACE (-3)
+#define PC_EBATCHNORM (-4) /* a BatchNorm call group of ONE row in training mode: nn.BatchNorm1d raises
+                             "Expected more than 1 value per channel when training" (product2vec.py:17,39) */
 
 #define PC_D 128         /* PRODUCT_EMB_DIM (config.py:8) */
 #define PC_H 256         /* HIDDEN_SIZE (config.py:10) */
@@ -437,6 +439,14 @@ int pc_scatter_rows(float *out, const int32_t *idx, int rows, int width, const f
 /* dx = dy * act'(y) for a stand-alone activation: act 1 = tanh (1 - y^2), 2 = relu (y > 0)
  * (F.relu of type_transition.py:17 in module mode). */
 int pc_act_backward(const float *dy, const float *y, size_t n, int act, float *dx, void *stream);
+
+/* Index validation.  The reference's lookups raise for an id outside its table (nn.Embedding: IndexError;
+ * product_to_idx: KeyError -- p_companion.py:48-54); here up to `count` <= 4 int32 index arrays idx[a][n[a]] are
+ * checked against [0, hi[a]) (or [-1, hi[a]) where allow_pad[a] != 0: -1 is the collate padding sentinel) in one
+ * launch, and the number of offending entries is ADDED to the device counter *bad.  The caller reads the counter
+ * when it synchronises anyway (PCompanion.raise_index_errors) and raises IndexError. */
+int pc_check_indices(const int32_t *const *idx, const int *n, const int *hi, const int *allow_pad, int count,
+                     int32_t *bad, void *stream);
 
 /* ---------------------------------------------------------------------------------
  * Serving: type-filtered top-n retrieval -- the candidate search of

@@ -14,7 +14,8 @@ PC_MAX_SEG = 4
 D, H, HEADS, L = 128, 256, 4, 64
 
 _ERR = {-1: "PC_EINVAL (null pointer / bad size)", -2: "PC_ESHAPE (unsupported dimension/alignment)",
-        -3: "PC_EWORKSPACE (workspace too small)"}
+        -3: "PC_EWORKSPACE (workspace too small)",
+        -4: "PC_EBATCHNORM (a BatchNorm call group of one row in training mode)"}
 
 
 class HipKernelError(RuntimeError):
@@ -121,6 +122,7 @@ SIGNATURES = {
     "pc_scatter_add_rows_small": (_i, [_vp, _i, _vp, _i, _i, _vp, _vp]),
     "pc_scatter_rows": (_i, [_vp, _vp, _i, _i, _vp, _vp]),
     "pc_act_backward": (_i, [_vp, _vp, _sz, _i, _vp, _vp]),
+    "pc_check_indices": (_i, [_P(ctypes.c_void_p), _P(ctypes.c_int), _P(ctypes.c_int), _P(ctypes.c_int), _i, _vp, _vp]),
 }
 
 _lib = None
@@ -149,6 +151,9 @@ def lib():
 def check(rc, what):
     if rc == 0:
         return
+    if rc == -4:
+        # what nn.BatchNorm1d raises in the reference (torch/nn/functional.py _verify_batch_size)
+        raise ValueError(f"Expected more than 1 value per channel when training, got input size torch.Size([1, {H}])")
     if rc < 0:
         raise HipKernelError(f"{what}: {_ERR.get(rc, rc)}")
     raise HipKernelError(f"{what}: hipError_t {rc}")

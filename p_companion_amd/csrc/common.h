@@ -21,17 +21,22 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
         if (_r != 0) return _r;      \
     } while (0)
 
-// Kernel launch that first drops any stale (sticky) runtime error left by an unrelated earlier
-// call on this thread, so pc_launch_status() reports THIS launch only.
-#define PC_LAUNCH(...)                 \
-    do {                               \
-        (void)hipGetLastError();       \
-        hipLaunchKernelGGL(__VA_ARGS__); \
+// Kernel launch.  A stale (sticky) runtime error left by an unrelated earlier call on this thread is dropped first;
+// the launch's own error, if any, is kept in a thread-local until pc_launch_status() collects it, so a sequence of
+// launches checked once at its end still reports the FIRST failure (a later PC_LAUNCH does not wipe it).
+extern thread_local int pc_tls_launch_err;
+#define PC_LAUNCH(...)                                                           \
+    do {                                                                         \
+        (void)hipGetLastError();                                                 \
+        hipLaunchKernelGGL(__VA_ARGS__);                                         \
+        const hipError_t _le = hipGetLastError();                                \
+        if (_le != hipSuccess && pc_tls_launch_err == 0) pc_tls_launch_err = (int)_le; \
     } while (0)
 
 static inline int pc_launch_status() {
-    hipError_t e = hipGetLastError();
-    return e == hipSuccess ? 0 : (int)e;
+    const int e = pc_tls_launch_err;
+    pc_tls_launch_err = 0;
+    return e;
 }
 
 // Row segments (BatchNorm call groups) passed to kernels BY VALUE.

@@ -1,15 +1,16 @@
-// C[M,N] = prologue(A)[M,K] . W[N,K]^T (+bias) -> epilogue, exact fp32 on the matrix cores.
+// C[M,N] = prologue(A)[M,K] . W[N,K]^T (+bias) -> epilogue: fp32 in, fp32 accumulate, fp32-grade products on the
+// BF16 matrix cores (six v_mfma_f32_32x32x16_bf16 over a three-way bf16 split of both operands, common.h split3);
+// the few-row kernels further down stay on v_mfma_f32_32x32x2_f32.
 //
 // One kernel family serves every "activation x weight^T" product of the two hot paths
 // (nn.Linear forward, and dX = dY . W through a pre-transposed W): product2vec.py:14-21
 // (ffn), nn.MultiheadAttention's in/out projections (:23-28), type_transition.py:11-12,
 // item_prediction.py:11-20, p_companion.py:60-63 (similarities).
 //
-// These are SKINNY products: M = hundreds of thousands of rows, N,K <= 256.  At the fp32
-// MFMA rate they sit within 2x of the HBM roofline, so the kernel is built around the row
-// stream, not around K:
+// These are SKINNY products: M = hundreds of thousands of rows, N,K <= 256: ~43 FLOP per HBM byte, just under the
+// ridge of the six-product bf16 rate (52 FLOP/B), so the kernel is built around the row stream, not around K:
 //   * a workgroup owns 128 rows x the FULL N (up to 256 columns: 8 waves as 2 x 4, each 64x64
-//     = 2x2 v_mfma_f32_32x32x2_f32 accumulators) so A is read from HBM exactly once;
+//     = 2x2 32x32 accumulator blocks) so A is read from HBM exactly once;
 //   * operands go global -> LDS DIRECTLY (global_load_lds_dwordx4, no VGPR hop and no ds_write):
 //     measured on this loop, 138 TFLOP/s steady state against 104 for register staging
 //     (scripts/microbench/nt_staging.hip).  A wave instruction drops 1 KB = 256/BK whole rows

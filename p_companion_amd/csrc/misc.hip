@@ -320,4 +320,37 @@ extern "C" int pc_act_backward(const float* dy, const float* y, size_t n, int ac
     return pc_launch_status();
 }
 
-extern "C" int pc_abi_version(void) { return 1; }
+// ---------------------------------------------------------------------------------------
+// Index validation (the reference's nn.Embedding / dict lookups raise IndexError / KeyError for an id outside the
+// table, p_companion.py:48-54): up to four index arrays against their table sizes in ONE launch; the number of bad
+// entries is ADDED to *bad (a device counter the caller reads when it chooses to synchronise).  Entries of -1 are
+// legal where allow_pad is set (the zero-row sentinel of the collate padding).
+struct IdxJobs { const int32_t* idx[4]; int n[4], hi[4], allow_pad[4], count; };
+__global__ void check_indices_kernel(IdxJobs j, int32_t* bad) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    int wrong = 0;
+#pragma unroll
+    for (int a = 0; a < 4; a++)
+        if (a < j.count && t < j.n[a]) {
+            const int v = j.idx[a][t];
+            if (v >= j.hi[a] || v < (j.allow_pad[a] ? -1 : 0)) wrong++;
+        }
+    if (wrong) atomicAdd(bad, wrong);
+}
+
+extern "C" int pc_check_indices(const int32_t* const* idx, const int* n, const int* hi, const int* allow_pad, int count,
+                                int32_t* bad, void* stream) {
+    if (!idx || !n || !hi || !bad || count < 1 || count > 4) return PC_EINVAL;
+    IdxJobs j = {};
+    int mx = 0;
+    for (int a = 0; a < count; a++) {
+        if (!idx[a] || n[a] <= 0 || hi[a] <= 0) return PC_EINVAL;
+        j.idx[a] = idx[a]; j.n[a] = n[a]; j.hi[a] = hi[a]; j.allow_pad[a] = allow_pad ? allow_pad[a] : 0;
+        mx = n[a] > mx ? n[a] : mx;
+    }
+    j.count = count;
+    PC_LAUNCH(check_indices_kernel, dim3((mx + 255) / 256), dim3(256), 0, (hipStream_t)stream, j, bad);
+    return pc_launch_status();
+}
+
+extern "C" int pc_abi_version(void) { return 2; }

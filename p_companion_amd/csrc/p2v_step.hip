@@ -98,6 +98,9 @@ static int p2v_step_impl(const pc_p2v_tensors* p, const pc_p2v_tensors* g, const
     ProfileScope prof_scope((pc_profile*)profile);
     if (!p || !g || !table || !anchor_idx || !positive_idx || !negative_idx || !loss || !ws) return PC_EINVAL;
     if (B <= 0 || N < 0 || K <= 0 || (N > 0 && !nb_idx) || nbc < 0 || nbc > B * N + 1) return PC_EINVAL;
+    // the anchor and positive calls are [B,128] BatchNorm inputs: the reference raises for a single row in training
+    // mode (torch/nn/functional.py _verify_batch_size); so does a [1,5,128] negative block when K = 1
+    if (B == 1) return PC_EBATCHNORM;
     if (ws_bytes < pc_p2v_train_step_workspace_bytes(B, N, K)) return PC_EWORKSPACE;
     hipStream_t st = (hipStream_t)stream;
     StepWs w = step_ws_layout(ws, B, N, K);

@@ -4,6 +4,7 @@
 #include <stdlib.h>
 
 thread_local pc_profile* pc_tls_profile = nullptr;
+thread_local int pc_tls_launch_err = 0;          // first failed launch since the last pc_launch_status() (common.h)
 
 int pc_prof_begin(int kind, double flops, hipStream_t st) {
     pc_profile* p = pc_tls_profile;

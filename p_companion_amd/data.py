@@ -332,6 +332,10 @@ class ComplementaryIndexLoader:
         g = dataset.bpg.cuda(device)
         self.features, self.type_idx = g["features"], g["type_idx"]
         self.step = 0
+        bpg = dataset.bpg
+        if len(bpg.type_idx) and (int(bpg.type_idx.max()) >= int(bpg.n_types) or int(bpg.type_idx.min()) < 0):
+            raise IndexError(f"type ids of the graph reach {int(bpg.type_idx.max())} but n_types = {bpg.n_types}: the "
+                             "batches' negative types are taken modulo n_types (data_loader.py:150)")
 
     def __len__(self):
         return (len(self.dataset) + self.batch_size - 1) // self.batch_size

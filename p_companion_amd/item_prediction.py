@@ -1,6 +1,6 @@
 """ComplementaryItemPrediction on MI355X -- drop-in for src/models/item_prediction.py.
 item_projection(q)[:, None, :] * type_projection(c)  (item_prediction.py:22-40): two
-fp32-MFMA Linear launches and one Hadamard kernel."""
+Linear launches (pc_linear_forward, see type_transition.py) and one Hadamard kernel."""
 import torch
 import torch.nn as nn
 

@@ -1,7 +1,8 @@
 """Metrics on the device -- drop-in for src/utils/metrics.py (Metrics.evaluate_model runs every
 epoch in train.train and selects the best checkpoint, train.py:55-70).
 
-The similarity product [B*K,128] x [128,B] is the shared fp32-MFMA GEMM, hit@k is a rank kernel
+The similarity product [B*K,128] x [128,B] is the shared NT GEMM (pc_linear_forward: fp32 MFMA for few rows, fp32-grade
+six-product bf16 MFMA for many), hit@k is a rank kernel
 (one wave per row), relevance a cosine kernel; only the final scalar means are read back.
 Reproduces the reference's quirk: ground truth is arange(B*K) against B columns, so rows >= B can
 never hit (metrics.py:95-100)."""

@@ -703,6 +703,20 @@ def act_backward(dy, y, act):
     return dx
 
 
+def check_indices(jobs, bad):
+    """jobs: up to four (int32 index tensor, table rows, allow -1) triples; adds the number of out-of-range entries
+    to the device counter `bad` ([1] int32).  Asynchronous: nothing is read back here."""
+    n = len(jobs)
+    if not 1 <= n <= 4:
+        raise ValueError("1..4 index arrays per launch")
+    _req(bad, torch.int32, "bad", (1,))
+    ptrs = (ctypes.c_void_p * n)(*[_req(t, torch.int32, "idx").data_ptr() for t, _, _ in jobs])
+    cnt = (ctypes.c_int * n)(*[t.numel() for t, _, _ in jobs])
+    hi = (ctypes.c_int * n)(*[int(h) for _, h, _ in jobs])
+    pad = (ctypes.c_int * n)(*[1 if a else 0 for _, _, a in jobs])
+    check(_lib.lib().pc_check_indices(ptrs, cnt, hi, pad, n, _p(bad), _stream()), "pc_check_indices")
+
+
 def hit_rank(sims):
     rows, cols = sims.shape
     _req(sims, torch.float32, "similarities")

@@ -137,6 +137,34 @@ class PCompanion(nn.Module, _FlatParamsMixin):
         if self.training and float(self.config.DROPOUT) != 0.0:
             raise NotImplementedError("DROPOUT != 0 is not implemented in the HIP path; set config.DROPOUT = 0")
 
+    # ------------------------------------------------------------------ index validation
+    def _validate(self, *jobs):
+        """Counts ids outside their tables on the device (pc_check_indices); nothing is read back here.  jobs:
+        (int32 tensor, table rows).  The reference raises at the lookup (p_companion.py:48-54); here the count is
+        collected by raise_index_errors() at a point where the host synchronises anyway (train() does it per epoch)."""
+        dev = self.query_type_embeddings.weight.device
+        bad = getattr(self, "_bad", None)
+        if bad is None or bad.device != dev:
+            bad = self._bad = torch.zeros(1, dtype=torch.int32, device=dev)
+        ops.check_indices([(t, hi, False) for t, hi in jobs], bad)
+
+    def index_errors(self) -> int:
+        """Number of out-of-range product / type ids the device has seen since the last call (synchronises)."""
+        bad = getattr(self, "_bad", None)
+        if bad is None:
+            return 0
+        n = int(bad.item())
+        if n:
+            bad.zero_()
+        return n
+
+    def raise_index_errors(self):
+        n = self.index_errors()
+        if n:
+            raise IndexError(f"{n} product / type ids of the processed batches lie outside the embedding tables "
+                             f"(products: {self.product_embeddings.weight.shape[0]} rows, types: "
+                             f"{self.query_type_embeddings.weight.shape[0]} rows)")
+
     # ------------------------------------------------------------------ reference surface
     def forward(self, batch):
         self._check()
@@ -144,6 +172,8 @@ class PCompanion(nn.Module, _FlatParamsMixin):
         k = int(self.config.NUM_COMP_TYPES)
         query_indices = self._query_indices(batch, dev)
         query_types = self._i32(batch["query_types"].to(dev))
+        self._validate((query_indices, self.product_embeddings.weight.shape[0]),
+                       (query_types, self.query_type_embeddings.weight.shape[0]))
         if not (torch.is_grad_enabled() and self.training):
             sims, topk, proj, _ = ops.joint_forward(self._tensor_dict(), query_indices, query_types, k)
             return {"projected_embeddings": proj, "complementary_types": topk.long(), "type_similarities": sims}
@@ -171,9 +201,11 @@ class PCompanion(nn.Module, _FlatParamsMixin):
 
     def _loss(self, batch, outputs, which):
         dev = outputs["type_similarities"].device
+        pos_t, neg_t = self._i32(batch["positive_types"].to(dev)), self._i32(batch["negative_types"].to(dev))
+        t = outputs["type_similarities"].shape[1]
+        self._validate((pos_t, t), (neg_t, t))
         return _JointLoss.apply(
-            outputs["type_similarities"].contiguous(), outputs["projected_embeddings"].contiguous(),
-            self._i32(batch["positive_types"].to(dev)), self._i32(batch["negative_types"].to(dev)),
+            outputs["type_similarities"].contiguous(), outputs["projected_embeddings"].contiguous(), pos_t, neg_t,
             batch["positive_items"].to(dev).float().contiguous(), batch["negative_items"].to(dev).float().contiguous(),
             float(self.config.MARGIN), float(self.config.ALPHA), which)
 
@@ -190,8 +222,11 @@ class PCompanion(nn.Module, _FlatParamsMixin):
             # untouched in between -> one fused step (the autograd graph forward recorded is simply dropped)
             dev = pend[3].device
             weights = [p for p in self.parameters() if p.requires_grad]
+            pt, nt = self._i32(batch["positive_types"].to(dev)), self._i32(batch["negative_types"].to(dev))
+            t = self.query_type_embeddings.weight.shape[0]
+            self._validate((pt, t), (nt, t))
             return _FusedJointLoss.apply(
-                self, pend[3], pend[4], self._i32(batch["positive_types"].to(dev)), self._i32(batch["negative_types"].to(dev)),
+                self, pend[3], pend[4], pt, nt,
                 batch["positive_items"].to(dev).float().contiguous(), batch["negative_items"].to(dev).float().contiguous(),
                 *weights)
         return self._loss(batch, outputs, 0)
@@ -221,9 +256,12 @@ class PCompanion(nn.Module, _FlatParamsMixin):
         params = self._tensor_dict()
         params["product_embeddings.weight"] = self.product_embeddings.weight
         grads = {k: p.grad for k, p in self.named_parameters() if p.grad is not None}
+        qi, qt = self._query_indices(batch, dev), self._i32(batch["query_types"].to(dev))
+        pt, nt = self._i32(batch["positive_types"].to(dev)), self._i32(batch["negative_types"].to(dev))
+        t = self.query_type_embeddings.weight.shape[0]
+        self._validate((qi, self.product_embeddings.weight.shape[0]), (qt, t), (pt, t), (nt, t))
         return ops.joint_train_step(
-            params, grads, self._query_indices(batch, dev), self._i32(batch["query_types"].to(dev)),
-            self._i32(batch["positive_types"].to(dev)), self._i32(batch["negative_types"].to(dev)),
+            params, grads, qi, qt, pt, nt,
             batch["positive_items"].to(dev).float().contiguous(), batch["negative_items"].to(dev).float().contiguous(),
             int(self.config.NUM_COMP_TYPES), float(self.config.MARGIN), float(self.config.ALPHA))
 

@@ -67,6 +67,32 @@ class _AttentionFunction(torch.autograd.Function):
         return (None, dq, dk) + tuple(grads[k] for k in _ATT_KEYS)
 
 
+class _NoEvalBackward(torch.autograd.Function):
+    """Eval-mode forward (BatchNorm running statistics, no dropout) with gradients enabled.  The reference would
+    differentiate through it (product2vec.py:31-46 has no mode switch in autograd); the HIP path implements the
+    backward of the TRAINING graph only, so the output carries a node that raises when differentiated -- inference
+    code that merely forgot torch.no_grad() keeps working, a fine-tuning / saliency pass fails loudly instead of
+    silently receiving no gradient."""
+
+    @staticmethod
+    def forward(ctx, y, what, *deps):
+        ctx.what = what
+        return y.view_as(y)
+
+    @staticmethod
+    def backward(ctx, g):
+        raise NotImplementedError(
+            f"{ctx.what}: backward through the eval-mode forward is not implemented in the HIP path "
+            "(call .train(), or wrap inference in torch.no_grad())")
+
+
+def _guard_eval(y, what, deps):
+    deps = [d for d in deps if isinstance(d, torch.Tensor) and d.requires_grad]
+    if torch.is_grad_enabled() and deps:
+        return _NoEvalBackward.apply(y, what, *deps)
+    return y
+
+
 class _TripletLossFunction(torch.autograd.Function):
     """The loss expression of train_model (product2vec.py:137-154) as one kernel."""
 
@@ -144,6 +170,70 @@ class FusedAdam(torch.optim.Optimizer):
     def zero_grad(self, set_to_none=False):
         _, gflat = self._ensure()
         gflat.zero_()
+
+    # ------------------------------------------------------------------ checkpoint layout of torch.optim.Adam
+    def _slices(self):
+        """[(index in param_groups[0]['params'], offset, numel, shape)] of the parameters that live in the flat buffer."""
+        self._ensure()
+        pos = {id(p): i for i, p in enumerate(self.param_groups[0]["params"])}
+        out, off = [], 0
+        for _, p in self.module._named_flat():
+            out.append((pos[id(p)], off, p.numel(), tuple(p.shape)))
+            off += p.numel()
+        return out
+
+    def state_dict(self):
+        """The dict torch.optim.Adam.state_dict() would return for the same parameters after the same steps
+        (train.py:66 saves it as 'optimizer_state_dict'): per-parameter 'step' / 'exp_avg' / 'exp_avg_sq' sliced out
+        of the flat moment buffers, parameters without a gradient (the frozen product table, p_companion.py:26-29)
+        hold no state, like in torch.  torch.optim.Adam(model.parameters()).load_state_dict() reads it."""
+        n = len(self.param_groups[0]["params"])
+        group = {"lr": self.param_groups[0]["lr"], "betas": tuple(self.param_groups[0]["betas"]),
+                 "eps": self.param_groups[0]["eps"], "weight_decay": 0, "amsgrad": False, "maximize": False,
+                 "foreach": None, "capturable": False, "differentiable": False, "fused": None,
+                 "decoupled_weight_decay": False, "params": list(range(n))}
+        state = {}
+        steps = int(self.step_count) if self._state_ready else 0
+        if steps > 0:
+            for idx, off, m, shape in self._slices():
+                state[idx] = {"step": torch.tensor(float(steps)),
+                              "exp_avg": self.exp_avg[off:off + m].view(shape).clone(),
+                              "exp_avg_sq": self.exp_avg_sq[off:off + m].view(shape).clone()}
+        return {"state": state, "param_groups": [group]}
+
+    def load_state_dict(self, state_dict):
+        """Accepts torch.optim.Adam's layout (also what state_dict() above emits): a resumed run continues with the
+        saved moments and step count."""
+        groups = state_dict["param_groups"]
+        if len(groups) != 1:
+            raise ValueError("FusedAdam: one parameter group expected")
+        n = len(self.param_groups[0]["params"])
+        if len(groups[0]["params"]) != n:
+            raise ValueError("loaded state dict contains a parameter group that doesn't match the size of optimizer's group")
+        for k in ("lr", "betas", "eps"):
+            if k in groups[0]:
+                self.param_groups[0][k] = tuple(groups[0][k]) if k == "betas" else groups[0][k]
+        if groups[0].get("weight_decay", 0) or groups[0].get("amsgrad", False) or groups[0].get("maximize", False):
+            raise ValueError("FusedAdam implements torch.optim.Adam's defaults only (no weight decay / amsgrad / maximize)")
+        order = {pid: i for i, pid in enumerate(groups[0]["params"])}
+        state = {order[k] if k in order else k: v for k, v in state_dict["state"].items()}
+        slices = self._slices()
+        self.exp_avg.zero_(); self.exp_avg_sq.zero_(); self.step_count.zero_()
+        steps = set()
+        for idx, off, m, shape in slices:
+            st = state.get(idx)
+            if st is None:
+                continue
+            if tuple(st["exp_avg"].shape) != shape:
+                raise ValueError(f"FusedAdam.load_state_dict: parameter {idx} has shape {shape}, state has "
+                                 f"{tuple(st['exp_avg'].shape)}")
+            self.exp_avg[off:off + m].copy_(st["exp_avg"].reshape(-1))
+            self.exp_avg_sq[off:off + m].copy_(st["exp_avg_sq"].reshape(-1))
+            steps.add(int(float(st["step"])))
+        if len(steps) > 1:
+            raise ValueError("FusedAdam keeps ONE step count for all parameters; the state holds %s" % sorted(steps))
+        if steps:
+            self.step_count.fill_(steps.pop())
 
 
 class _FlatParamsMixin:
@@ -253,11 +343,9 @@ class Product2Vec(nn.Module, _FlatParamsMixin):
                 return _FFNFunction.apply(self, x, *self._weights(_FFN_KEYS))
             y, _ = ops.ffn_forward_train(self._tensor_dict(), x, None, x.shape[0], [0], True)
             return y
-        if torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in self.parameters())):
-            # eval-mode backward is not part of the reference's hot path
-            with torch.no_grad():
-                return ops.ffn_forward_eval(self._tensor_dict(), x, None, x.shape[0])
-        return ops.ffn_forward_eval(self._tensor_dict(), x, None, x.shape[0])
+        with torch.no_grad():
+            y = ops.ffn_forward_eval(self._tensor_dict(), x, None, x.shape[0])
+        return _guard_eval(y, "Product2Vec.get_initial_embedding", [x] + list(self._weights(_FFN_KEYS)))
 
     def apply_attention(self, query: torch.Tensor, key_value: torch.Tensor) -> torch.Tensor:
         """Apply attention mechanism with proper reshaping (product2vec.py:48-68)."""
@@ -276,7 +364,10 @@ class Product2Vec(nn.Module, _FlatParamsMixin):
         if torch.is_grad_enabled() and self.training:
             out = _AttentionFunction.apply(self, q2, kv, *self._weights(_ATT_KEYS))
         else:
-            out, _ = ops.attention_forward(self._tensor_dict(), q2, kv)
+            with torch.no_grad():
+                out, _ = ops.attention_forward(self._tensor_dict(), q2, kv)
+            if not self.training:
+                out = _guard_eval(out, "Product2Vec.apply_attention", [q2, kv] + list(self._weights(_ATT_KEYS)))
         out = out.unsqueeze(1)
         if query.size(0) == 1 and query.size(1) == 1:
             out = out.squeeze(0).squeeze(0)

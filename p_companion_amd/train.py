@@ -39,6 +39,26 @@ def pretrain_product2vec(config, similarity_dataset) -> Dict[str, torch.Tensor]:
     return embeddings_dict
 
 
+def _cpu_state(sd):
+    return {"state": {k: {n: (v.detach().cpu() if isinstance(v, torch.Tensor) else v) for n, v in st.items()}
+                      for k, st in sd["state"].items()}, "param_groups": sd["param_groups"]}
+
+
+def _check_ranges(config, loader, model):
+    """The kernels index the [NUM_TYPES,64] tables with the batch's type ids and the product table with its product
+    ids; the reference raises IndexError / KeyError for an id outside them (p_companion.py:48-54).  Checked once
+    here for the index loaders (whose ids come from the graph), per step on the device otherwise (PCompanion.index_errors)."""
+    bpg = getattr(getattr(loader, "dataset", None), "bpg", None)
+    if bpg is None or not hasattr(bpg, "n_types"):
+        return
+    if int(bpg.n_types) > int(config.NUM_TYPES):
+        raise IndexError(f"the graph has {bpg.n_types} types but config.NUM_TYPES = {config.NUM_TYPES}: type ids "
+                         "would index past the type embedding tables")
+    if bpg.num_products > model.product_embeddings.weight.shape[0]:
+        raise IndexError(f"the graph has {bpg.num_products} products but the pretrained table holds "
+                         f"{model.product_embeddings.weight.shape[0]} rows")
+
+
 def train(config, train_loader, val_loader, pretrained_embeddings, fused=True):
     """Train P-Companion model (train.py:16-72): loop, per-epoch Metrics.evaluate_model, best
     hit@10 checkpoint.  fused=True runs the loop body as pc_joint_train_step + one Adam launch;
@@ -47,6 +67,8 @@ def train(config, train_loader, val_loader, pretrained_embeddings, fused=True):
     model = PCompanion(config, pretrained_embeddings).to(config.DEVICE)
     optimizer = FusedAdam(model, lr=config.LEARNING_RATE) if fused else \
         torch.optim.Adam(model.parameters(), lr=config.LEARNING_RATE)
+    for ld in (train_loader, val_loader):
+        _check_ranges(config, ld, model)
     best_hit10 = 0.0
     for epoch in range(config.NUM_EPOCHS):
         model.train()
@@ -68,6 +90,7 @@ def train(config, train_loader, val_loader, pretrained_embeddings, fused=True):
             nb += 1
         if nb:
             logger.info(f"Epoch {epoch + 1}/{config.NUM_EPOCHS}, Loss: {float(total) / nb:.4f}")
+        model.raise_index_errors()                   # ids outside the tables seen by the device this epoch -> IndexError
         metrics = Metrics.evaluate_model(model, val_loader, config.DEVICE)
         for name, value in metrics.items():
             logger.info(f"{name}: {value:.4f}")
@@ -76,9 +99,7 @@ def train(config, train_loader, val_loader, pretrained_embeddings, fused=True):
             os.makedirs(config.MODEL_DIR, exist_ok=True)
             torch.save({"epoch": epoch,
                         "model_state_dict": {k: v.detach().cpu() for k, v in model.state_dict().items()},
-                        "optimizer_state_dict": optimizer.state_dict() if not fused else
-                        {"exp_avg": optimizer.exp_avg.cpu(), "exp_avg_sq": optimizer.exp_avg_sq.cpu(),
-                         "step": int(optimizer.step_count)},
+                        "optimizer_state_dict": _cpu_state(optimizer.state_dict()),      # torch.optim.Adam's layout in both modes
                         "metrics": metrics}, os.path.join(config.MODEL_DIR, "best_model.pth"))
         logger.info(f"Best Hit@10: {best_hit10:.4f}")
     return model

@@ -1,6 +1,7 @@
 """ComplementaryTypeTransition on MI355X -- drop-in for src/models/type_transition.py.
 decoder(dropout(relu(encoder(x)))), Linear 64->32->64 (type_transition.py:11-19), each
-Linear one fp32-MFMA launch (pc_linear_forward) with the ReLU fused in the epilogue."""
+Linear one few-row MFMA launch (pc_linear_forward: v_mfma_f32_32x32x2_f32, exact fp32 products) with the ReLU fused
+in the epilogue."""
 import torch
 import torch.nn as nn
 

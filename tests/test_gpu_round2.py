@@ -1,0 +1,167 @@
+"""Round-2 behaviour of the module surface on the GPU: optimizer checkpoints in torch.optim.Adam's layout
+(train.py:63-70), error conventions of the reference (single-row BatchNorm call, ids outside the tables,
+backward through an eval-mode forward).  Needs an MI355X."""
+from types import SimpleNamespace
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def cfg(**over):
+    c = SimpleNamespace(PRODUCT_EMB_DIM=128, TYPE_EMB_DIM=64, HIDDEN_SIZE=256, NUM_ATTENTION_HEADS=4, DROPOUT=0.0,
+                        MARGIN=1.0, ALPHA=0.8, NUM_COMP_TYPES=3, NUM_TYPES=40, DEVICE=torch.device("cuda"),
+                        LEARNING_RATE=1e-3, BATCH_SIZE=64, PRODUCT2VEC_EPOCHS=1)
+    c.__dict__.update(over)
+    return c
+
+
+def joint_batch(B, P, T, seed=0, dev="cuda"):
+    g = torch.Generator().manual_seed(seed)
+    return {"query_idx": torch.randint(0, P, (B,), generator=g, dtype=torch.int32).to(dev),
+            "query_types": torch.randint(0, T, (B,), generator=g).to(dev),
+            "positive_types": torch.randint(0, T, (B, 1), generator=g).to(dev),
+            "negative_types": torch.randint(0, T, (B, 1), generator=g).to(dev),
+            "positive_items": torch.randn(B, 128, generator=g).to(dev),
+            "negative_items": torch.randn(B, 128, generator=g).to(dev)}
+
+
+def test_fused_adam_state_dict_is_torch_adams_and_resumes():
+    """FusedAdam.state_dict() == what torch.optim.Adam holds after the same steps on the same gradients;
+    load_state_dict() continues a run bit-for-bit; torch.optim.Adam.load_state_dict() reads the file."""
+    from p_companion_amd.p_companion import PCompanion
+    from p_companion_amd.product2vec import FusedAdam
+    c = cfg()
+    g = torch.Generator().manual_seed(1)
+    table = torch.randn(300, 128, generator=g)
+
+    def make():
+        torch.manual_seed(3)
+        return PCompanion(c, table).to("cuda").train()
+
+    m1 = make()
+    o1 = FusedAdam(m1, lr=1e-2)
+    assert o1.state_dict()["state"] == {}                       # like torch before the first step
+    m_t = make()
+    o_t = torch.optim.Adam(m_t.parameters(), lr=1e-2)
+    for s in range(3):
+        b = joint_batch(64, 300, 40, seed=s)
+        m1.train_step(b)
+        o1.step()
+        m_t.train_step(b)                                        # same gradients into .grad of the torch-optimised copy
+        o_t.step()
+    sd, sd_t = o1.state_dict(), o_t.state_dict()
+    assert sorted(sd["state"]) == sorted(sd_t["state"])         # the frozen product table (index 0) holds no state
+    assert 0 not in sd["state"]
+    for k in sd["state"]:
+        assert float(sd["state"][k]["step"]) == float(sd_t["state"][k]["step"]) == 3.0
+        for n in ("exp_avg", "exp_avg_sq"):
+            assert sd["state"][k][n].shape == sd_t["state"][k][n].shape
+            assert torch.allclose(sd["state"][k][n], sd_t["state"][k][n], rtol=1e-5, atol=1e-12), (k, n)
+    assert sd["param_groups"][0]["params"] == sd_t["param_groups"][0]["params"]
+    # torch's optimizer reads the fused optimizer's file ...
+    m_l = make()
+    o_l = torch.optim.Adam(m_l.parameters(), lr=1e-2)
+    o_l.load_state_dict(sd)
+    assert torch.equal(o_l.state_dict()["state"][1]["exp_avg"].cpu(), sd["state"][1]["exp_avg"].cpu())
+    # ... and a resumed fused run continues exactly like the uninterrupted one
+    m2 = make()
+    m2.load_state_dict(m1.state_dict())
+    o2 = FusedAdam(m2, lr=1e-2)
+    o2.load_state_dict(sd_t)                                     # torch's own layout is accepted
+    o2.load_state_dict(sd)
+    b = joint_batch(64, 300, 40, seed=9)
+    m1.train_step(b); o1.step()
+    m2.train_step(b); o2.step()
+    assert int(o2.step_count) == 4
+    for (k, p1), (_, p2) in zip(m1.named_parameters(), m2.named_parameters()):
+        assert torch.allclose(p1, p2, rtol=0, atol=2e-7), k      # (type-table scatter-adds are float atomics: not bitwise)
+
+
+def test_p2v_fused_adam_state_roundtrip():
+    from p_companion_amd.product2vec import FusedAdam, Product2Vec
+    torch.manual_seed(0)
+    m = Product2Vec(cfg()).to("cuda").train()
+    o = FusedAdam(m)
+    g = torch.Generator().manual_seed(0)
+    table = torch.randn(100, 128, generator=g).cuda()
+    b = {"anchor_idx": torch.randint(0, 100, (8,), generator=g, dtype=torch.int32).cuda(),
+         "positive_idx": torch.randint(0, 100, (8,), generator=g, dtype=torch.int32).cuda(),
+         "negative_idx": torch.randint(0, 100, (8, 5), generator=g, dtype=torch.int32).cuda(),
+         "neighbor_idx": torch.randint(-1, 100, (8, 4), generator=g, dtype=torch.int32).cuda()}
+    m.train_step_indexed(table, b)
+    o.step()
+    sd = o.state_dict()
+    assert len(sd["state"]) == 12 and sd["state"][0]["exp_avg"].shape == (256, 128)
+    t = torch.optim.Adam(m.parameters())
+    t.load_state_dict(sd)
+    o2 = FusedAdam(m)
+    o2.load_state_dict(t.state_dict())
+    assert torch.equal(o2.exp_avg, o.exp_avg) and torch.equal(o2.exp_avg_sq, o.exp_avg_sq) and int(o2.step_count) == 1
+
+
+def test_single_row_batch_raises_like_batchnorm():
+    """A batch of ONE triplet: nn.BatchNorm1d raises in training mode (the reference would, product2vec.py:132);
+    so does the fused index step (reachable through a loader with drop_last=False)."""
+    from p_companion_amd.product2vec import Product2Vec
+    m = Product2Vec(cfg()).to("cuda").train()
+    table = torch.randn(50, 128).cuda()
+    b = {"anchor_idx": torch.tensor([3], dtype=torch.int32).cuda(), "positive_idx": torch.tensor([4], dtype=torch.int32).cuda(),
+         "negative_idx": torch.tensor([[5, 6, 7, 8, 9]], dtype=torch.int32).cuda(),
+         "neighbor_idx": torch.tensor([[1, 2, -1]], dtype=torch.int32).cuda()}
+    with pytest.raises(ValueError, match="Expected more than 1 value per channel"):
+        m.train_step_indexed(table, b)
+
+
+def test_eval_mode_forward_works_but_backward_raises():
+    from p_companion_amd.product2vec import Product2Vec
+    m = Product2Vec(cfg()).to("cuda").eval()
+    x = torch.randn(6, 128).cuda()
+    nb = torch.randn(6, 3, 128).cuda()
+    with torch.no_grad():
+        ref = m(x, nb)
+    y = m(x, nb)                                                  # grad enabled, eval mode: inference still works
+    assert torch.equal(y, ref) and y.requires_grad
+    with pytest.raises(NotImplementedError, match="eval-mode"):
+        y.sum().backward()
+    xg = x.clone().requires_grad_(True)
+    with pytest.raises(NotImplementedError):
+        m.get_initial_embedding(xg).sum().backward()
+
+
+def test_out_of_range_ids_are_reported():
+    from p_companion_amd.p_companion import PCompanion
+    c = cfg()
+    m = PCompanion(c, torch.randn(100, 128)).to("cuda").train()
+    b = joint_batch(32, 100, 40)
+    m.train_step(b)
+    assert m.index_errors() == 0
+    out = m(b)
+    m.compute_loss(b, out)
+    m.raise_index_errors()                                        # nothing to report
+    # ids inside int32 but outside the tables: counted, reported as IndexError at the next collection point.
+    # (Only the validation launch is exercised: the step itself is not run on the bad batch.)
+    bad = dict(b)
+    bad["query_types"] = b["query_types"].clone()
+    bad["query_types"][3] = 40
+    bad["query_idx"] = b["query_idx"].clone()
+    bad["query_idx"][0] = 100
+    bad["query_idx"][1] = -1
+    m._validate((bad["query_idx"], 100), (bad["query_types"].to(torch.int32), 40))
+    assert m.index_errors() == 3
+    m._validate((bad["query_idx"], 100))
+    with pytest.raises(IndexError, match="outside the embedding tables"):
+        m.raise_index_errors()
+    m.raise_index_errors()                                        # the counter was cleared
+
+
+def test_train_refuses_a_graph_with_more_types_than_tables(tmp_path):
+    from p_companion_amd.data import ComplementaryIndexDataset, ComplementaryIndexLoader, generate_scaled_bpg
+    from p_companion_amd import train as drivers
+    bpg = generate_scaled_bpg(500, 20, seed=1)
+    c = cfg(NUM_TYPES=10, NUM_EPOCHS=1, MODEL_DIR=str(tmp_path))
+    ld = ComplementaryIndexLoader(ComplementaryIndexDataset(bpg, "train"), 64, device="cuda")
+    with pytest.raises(IndexError, match="NUM_TYPES"):
+        drivers.train(c, ld, ld, torch.from_numpy(bpg.features))
