@@ -301,13 +301,29 @@ class ComplementaryIndexDataset:
                 positive_items = randn, negative_items = feat(tgt)              (:148-153)
     The randn filler items are input data (drawn here from torch's generator on the device)."""
 
-    def __init__(self, bpg: IntBPG, mode="train", seed=0):
+    def __init__(self, bpg: IntBPG, mode="train", seed=0, sampler="philox", rng=None):
+        """sampler='philox' (throughput): each mode draws its own counter-based permutation.
+        sampler='cpython' (parity): the shuffle of data_loader.py:119 is CPython's random.shuffle over the list
+        [complementary pairs (+1) ... similarity pairs (-1)] (:113-116), replayed bit-exactly by the host MT19937
+        restatement (pc_mt_shuffle): after random.seed(seed) the pair order, the split and therefore every integer
+        field of every sample equal the reference's (tests/golden/g9_complementary.npz).  `rng`: an
+        ops.CPythonRandom to draw from instead of a fresh one -- the reference builds its train and val datasets
+        back to back from ONE global stream (train.py:111-112)."""
         self.bpg = bpg
         cp, sp = bpg.complementary_pairs, bpg.similarity_pairs
         pairs = np.concatenate([np.concatenate([cp, np.ones((len(cp), 1), np.int32)], 1),
                                 np.concatenate([sp, -np.ones((len(sp), 1), np.int32)], 1)])
-        rs = np.random.Generator(np.random.Philox([seed, {"train": 0, "val": 1, "test": 2}[mode]]))
-        pairs = pairs[rs.permutation(len(pairs))]       # each mode shuffles independently (:119-126)
+        if sampler == "cpython":
+            if rng is None:
+                from . import ops
+                rng = ops.CPythonRandom(seed)
+            pairs = pairs[rng.shuffle(len(pairs))]
+        elif sampler == "philox":
+            rs = np.random.Generator(np.random.Philox([seed, {"train": 0, "val": 1, "test": 2}[mode]]))
+            pairs = pairs[rs.permutation(len(pairs))]       # each mode shuffles independently (:119-126)
+        else:
+            raise ValueError("sampler must be 'philox' or 'cpython'")
+        self.sampler = sampler
         n = len(pairs)
         lo, hi = {"train": (0, int(0.8 * n)), "val": (int(0.8 * n), int(0.9 * n)), "test": (int(0.9 * n), n)}[mode]
         self.pairs = pairs[lo:hi]

@@ -19,6 +19,10 @@ Vectors:
   g6_joint_t100.npz / g6_joint_t300.npz   P-Companion joint step (fwd, losses, grads, Adam x3)
   g7_collate.npz      collate_fn zero-padding of ragged neighbour lists
   g8_metrics.npz      Metrics.evaluate_model on one fixed batch
+  g9_complementary.npz   ComplementaryDataset: pair order after random.shuffle + the 80/10/10 split for
+                      train / val / test, and the integer fields / item rules of the first 256 samples of each
+
+    PYTHONHASHSEED=0 python tests/golden/make_golden.py g9      # only the named vectors
 """
 import os
 import sys
@@ -387,17 +391,65 @@ def g8():
          metric_names=np.array(sorted(m)), metric_values=np.array([m[k] for k in sorted(m)], np.float64))
 
 
+# --------------------------------------------------------------------------- G9
+def g9(bpg, ints):
+    """ComplementaryDataset (data_loader.py:90-157) on the reference's own graph (= g2): `pairs` after
+    _create_product_pairs' random.shuffle and split, per mode, from a fresh random.seed(s); and for the first 256
+    samples of each mode what __getitem__ returns: the integer fields, and which of positive_items / negative_items
+    IS the target's feature row (the other one is torch.randn_like filler -- input data, not pinned)."""
+    from src.data.data_loader import ComplementaryDataset
+    import logging
+    logging.disable(logging.CRITICAL)
+    cfg = stub_config()
+    feats = torch.from_numpy(ints["features"])
+    out = {}
+    for s in (0, 11):
+        for mode in ("train", "val", "test"):
+            random.seed(s)
+            torch.manual_seed(s)
+            ds = ComplementaryDataset(bpg, cfg, mode)
+            tag = f"s{s}_{mode}_"
+            out[tag + "pairs"] = np.array([[pid2int(q), pid2int(t), lab] for q, t, lab in ds.pairs], np.int32)
+            n = min(256, len(ds))
+            rows = [ds[i] for i in range(n)]
+            out[tag + "query_idx"] = np.array([pid2int(r["query_ids"]) for r in rows], np.int32)
+            for k in ("query_types", "positive_types", "negative_types", "label"):
+                out[tag + k] = np.array([int(r[k].reshape(-1)[0]) for r in rows], np.int32)
+            tgt = out[tag + "pairs"][:n, 1]
+            pos_is = np.array([bool(torch.equal(r["positive_items"], feats[t])) for r, t in zip(rows, tgt)])
+            neg_is = np.array([bool(torch.equal(r["negative_items"], feats[t])) for r, t in zip(rows, tgt)])
+            assert np.all(pos_is ^ neg_is)                       # exactly one of the two is the real row
+            assert all(torch.equal(r["target_features"], feats[t]) for r, t in zip(rows, tgt))
+            out[tag + "positive_is_target"] = pos_is
+        # the type index the dataset builds (set iteration order) is the one g2 stores
+        assert [ds.type_to_idx[t] for t in ints["type_names"]] == list(range(len(ints["type_names"])))
+    out["n_types"] = np.array(len(ds.type_to_idx), np.int32)
+    save("g9_complementary.npz", **out)
+
+
 if __name__ == "__main__":
-    g1()
+    only = set(sys.argv[1:])
+    want = lambda name: not only or name in only
+    if want("g1"):
+        g1()
     gen, bpg = build_bpg(0)
     ints = bpg_to_int(bpg)
     f16 = dict(ints)
-    save("g2_bpg1000.npz", **f16)
-    g3(bpg)
-    g4(bpg, ints)
-    g5()
-    g6(100, 64, 600)
-    g6(300, 64, 700)
-    g7()
-    g8()
+    if want("g2"):
+        save("g2_bpg1000.npz", **f16)
+    if want("g3"):
+        g3(bpg)
+    if want("g4"):
+        g4(bpg, ints)
+    if want("g5"):
+        g5()
+    if want("g6"):
+        g6(100, 64, 600)
+        g6(300, 64, 700)
+    if want("g7"):
+        g7()
+    if want("g8"):
+        g8()
+    if want("g9"):
+        g9(bpg, ints)
     print("done")

@@ -1,5 +1,6 @@
 """Integer BPG, scalable generator, loaders' host logic.  CPU only."""
 import numpy as np
+import pytest
 
 from oracle import data_oracle
 from p_companion_amd.data import ComplementaryIndexDataset, IntBPG, generate_scaled_bpg
@@ -57,6 +58,45 @@ def test_complementary_dataset_split_and_labels(golden):
         tt = int(bpg.type_idx[t])
         assert want["positive_types"] == (tt if lab == 1 else 0)
         assert want["negative_types"] == (tt if lab == -1 else (tt + 1) % bpg.n_types)
+
+
+@pytest.mark.parametrize("seed", [0, 11])
+def test_complementary_dataset_cpython_mode_matches_reference(golden, seed):
+    """J1 parity mode: pair order after the reference's random.shuffle + 80/10/10 split, and the integer fields of
+    the first 256 samples of each mode, against vectors captured from the reference's ComplementaryDataset (G9)."""
+    z = golden("g9_complementary.npz")
+    bpg = IntBPG.from_arrays(golden("g2_bpg1000.npz"))
+    assert bpg.n_types == int(z["n_types"])
+    for mode in ("train", "val", "test"):
+        ds = ComplementaryIndexDataset(bpg, mode, seed=seed, sampler="cpython")
+        want = z[f"s{seed}_{mode}_pairs"]
+        assert np.array_equal(ds.pairs, want), mode
+        n = len(z[f"s{seed}_{mode}_query_idx"])
+        assert np.array_equal(ds.pairs[:n, 0], z[f"s{seed}_{mode}_query_idx"])
+        assert np.array_equal(ds.pairs[:n, 2], z[f"s{seed}_{mode}_label"])
+        # the oracle's label rules against what the reference's __getitem__ returned
+        for i in range(n):
+            q, t, lab = ds.pairs[i]
+            o = data_oracle.complementary_sample_ints(q, t, lab, bpg.type_idx, bpg.n_types)
+            for k in ("query_types", "positive_types", "negative_types"):
+                assert o[k] == int(z[f"s{seed}_{mode}_{k}"][i]), (mode, i, k)
+            assert bool(z[f"s{seed}_{mode}_positive_is_target"][i]) == (lab == 1)
+    # one shared stream, datasets built back to back like train.py:111-112: train is the seed's first shuffle,
+    # val comes from the continued stream (and is therefore NOT the fresh-seed val split)
+    from p_companion_amd import ops
+    rng = ops.CPythonRandom(seed)
+    tr = ComplementaryIndexDataset(bpg, "train", sampler="cpython", rng=rng)
+    va = ComplementaryIndexDataset(bpg, "val", sampler="cpython", rng=rng)
+    assert np.array_equal(tr.pairs, z[f"s{seed}_train_pairs"])
+    assert not np.array_equal(va.pairs, z[f"s{seed}_val_pairs"])
+    import random
+    random.seed(seed)
+    n = len(bpg.complementary_pairs) + len(bpg.similarity_pairs)
+    a = list(range(n)); random.shuffle(a)
+    b = list(range(n)); random.shuffle(b)
+    allp = np.concatenate([np.concatenate([bpg.complementary_pairs, np.ones((len(bpg.complementary_pairs), 1), np.int32)], 1),
+                           np.concatenate([bpg.similarity_pairs, -np.ones((len(bpg.similarity_pairs), 1), np.int32)], 1)])
+    assert np.array_equal(va.pairs, allp[np.array(b)][int(0.8 * n):int(0.9 * n)])
 
 
 def test_unique_neighbor_layout_host_construction():

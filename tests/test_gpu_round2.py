@@ -165,3 +165,28 @@ def test_train_refuses_a_graph_with_more_types_than_tables(tmp_path):
     ld = ComplementaryIndexLoader(ComplementaryIndexDataset(bpg, "train"), 64, device="cuda")
     with pytest.raises(IndexError, match="NUM_TYPES"):
         drivers.train(c, ld, ld, torch.from_numpy(bpg.features))
+
+
+@pytest.mark.parametrize("mode", ["train", "val"])
+def test_complementary_batch_against_reference_golden(golden, mode):
+    """J1 end to end in parity mode: sampler='cpython' pair order + pc_build_complementary_batch on the device against
+    what the reference's ComplementaryDataset.__getitem__ returned for the same random.seed (G9): every integer
+    field bit-exact, the real item row is the target's feature row, the other one is filler."""
+    from p_companion_amd import ops
+    from p_companion_amd.data import ComplementaryIndexDataset, IntBPG
+    z = golden("g9_complementary.npz")
+    bpg = IntBPG.from_arrays(golden("g2_bpg1000.npz"))
+    ds = ComplementaryIndexDataset(bpg, mode, seed=11, sampler="cpython")
+    n = len(z[f"s11_{mode}_query_idx"])
+    rows = torch.from_numpy(np.ascontiguousarray(ds.pairs[:n], np.int32)).cuda()
+    g = bpg.cuda()
+    b = ops.build_complementary_batch(rows, g["features"], g["type_idx"], bpg.n_types, 5, 0)
+    for k, dk in (("query_idx", "query_idx"), ("query_types", "query_types"), ("positive_types", "positive_types"),
+                  ("negative_types", "negative_types")):
+        assert np.array_equal(b[dk].reshape(-1).cpu().numpy(), z[f"s11_{mode}_{k}"]), k
+    pos_is = z[f"s11_{mode}_positive_is_target"]
+    tgt = torch.from_numpy(bpg.features[ds.pairs[:n, 1]]).cuda()
+    is_pos = (b["positive_items"] == tgt).all(1).cpu().numpy()
+    is_neg = (b["negative_items"] == tgt).all(1).cpu().numpy()
+    assert np.array_equal(is_pos, pos_is) and np.array_equal(is_neg, ~pos_is)
+    assert torch.equal(b["target_features"], tgt)
