@@ -1,19 +1,24 @@
 #!/usr/bin/env python3
-"""bench.py -- triplets/sec of the Product2Vec GAT triplet pretrain step on MI355X.
+"""bench.py -- triplets/sec of P-Companion's two embedding-learning hot paths on MI355X
+(BASELINE.json metric: "Product2Vec pretrain + P-Companion joint step").
 
-Workload (BASELINE.json configs[1]): 100k products, 100 types, D=128,
-B=4096 triplets per GPU and step, 5 negatives, neighbours padded to the batch max (<=32),
-synthetic BPG (data='synthetic', random-init weights).  One step = device batch build
-(Philox negative sampling + CSR neighbour rows) + gather + 4 FFN/BatchNorm call groups +
-attention + triplet hinge + full backward + Adam: everything inside the timed region.
+Default run (no flags), one process per GPU:
+  * phase 1 = BASELINE configs[1] -- the headline `value`: 100k products, 100 types, D=128, B=4096 triplets per GPU
+    and step, 5 negatives, neighbours padded to the batch max (<=32), synthetic BPG, random-init weights.  One step =
+    device batch build (Philox negative sampling + CSR neighbour rows) + gather + 4 FFN/BatchNorm call groups +
+    attention + triplet hinge + full backward + Adam, everything inside the timed region.
+  * phase 2 = configs[2] -- object `joint` of the same JSON line: the P-Companion joint step (forward, type + item
+    hinge, backward, Adam over both type tables and the four Linears), B=4096 per GPU, T = --types (100) and, as
+    `joint_num_types_34800`, the reference's own config.py:27 NUM_TYPES.
 
     python bench.py --gpus 1 --steps 50 --warmup 10
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
-Prints ONE JSON line on rank 0 (contract in the task statement) with `roofline` (dominant
-kernel gemm_nt_kernel: algorithmic FLOPs / HIP-event time on the launch stream, against the
-matrix-core peak of the instruction it issues: fp32-grade products as six v_mfma_f32_32x32x16_bf16
-over a three-way bf16 split of the fp32 operands, i.e. the dense bf16 peak / 6) and `cpu_baseline` (the oracle port timed on this box's host cores).
+ONE JSON line on rank 0.  `roofline` is for the dominant kernel family of the headline phase (gemm_nt_kernel):
+algorithmic FLOPs and bytes / HIP-event time on the launch stream; BOTH fractions are printed (matrix cores: fp32-grade
+products as six v_mfma_f32_32x32x16_bf16 over a three-way bf16 split, i.e. dense bf16 peak / 6; HBM: 8 TB/s) and
+`bound` names the roof that is nearer (the larger lower bound on the launch time).  `cpu_baseline` = the oracle port
+timed on this box's host cores (compute-only over >= 20 steps, and end to end with the host loader).
 """
 import argparse
 import json
@@ -60,29 +65,43 @@ def bytes_per_triplet(n):
     return 512 * (n + 7) + 4 * (n + 7)
 
 
-def pmc_traffic_per_launch():
-    """HBM bytes per gemm_nt_kernel launch from the committed rocprofv3 --pmc passes of this same
-    command (profiles/*_pmc_traffic.json: FETCH_SIZE and WRITE_SIZE in separate passes, KiB -> bytes,
-    FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950).  None if no profile is committed:
+def committed_pmc(pattern, match):
+    """HBM bytes per launch of the kernels whose name contains `match`, from the newest committed rocprofv3 --pmc
+    passes of this same command (profiles/<tag>_pmc_traffic*.json: FETCH_SIZE and WRITE_SIZE in separate passes,
+    KiB -> bytes, FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950).  None if no profile is committed:
     PMC counters cannot be collected from inside the bench process."""
     import glob
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_traffic.json")))
+    files = sorted(f for f in glob.glob(os.path.join(ROOT, "profiles", pattern))
+                   if ("joint" in os.path.basename(f)) == ("joint" in pattern))
     if not files:
         return None
     with open(files[-1]) as f:
         d = json.load(f)
-    nt = [v for k, v in d.items() if "gemm_nt_kernel<" in k and "<1, 2," not in k]      # the persistent family (not the few-row kernels)
-    n = sum(v["launches"] for v in nt)
+    sel = [v for k, v in d.items() if match(k)]
+    n = sum(v["launches"] for v in sel)
     if not n:
         return None
-    return {"hbm_bytes_per_launch": round(sum((v["fetch_bytes_corrected"] + v["write_bytes"]) * v["launches"] for v in nt) / n),
+    return {"hbm_bytes_per_launch": round(sum((v["fetch_bytes_corrected"] + v["write_bytes"]) * v["launches"] for v in sel) / n),
             "source": os.path.relpath(files[-1], ROOT)}
 
 
-def cpu_baseline(bpg, batch, seconds=15.0):
-    """The oracle (CPU restatement pinned to the reference's golden vectors) timed on this
-    box's host cores: same workload shape, pre-gathered dense batch, fwd+bwd+Adam."""
+def two_roof(flops, nbytes, seconds, peak_tflops):
+    """Both roofline fractions of one launch: time the matrix cores / HBM would need at their peaks over the measured
+    time; the binding roof is the larger lower bound."""
+    t_mfma = flops / (peak_tflops * 1e12)
+    t_hbm = nbytes / (HBM_PEAK_GBS * 1e9)
+    fm, fh = (t_mfma / seconds, t_hbm / seconds) if seconds > 0 else (0.0, 0.0)
+    return ("mfma" if t_mfma >= t_hbm else "hbm"), fm, fh
+
+
+# ----------------------------------------------------------------------------------------------- CPU legs
+def p2v_cpu_baseline(bpg, batch, min_steps=20, max_seconds=100.0):
+    """The oracle (CPU restatement pinned to the reference's golden vectors) timed on this box's host cores: same
+    workload shape, fwd+bwd+Adam.  compute-only: one pre-gathered dense batch, >= 20 steps; end to end: the host
+    loader in parity mode (exact CPython negative sampler + CSR neighbour rows) + the dense gather of
+    data_loader.py:45-88,171-206 + the step, per batch."""
     from oracle import p2v_oracle
+    from p_companion_amd.data import SimilarityIndexLoader
     st = p2v_oracle.init_state(0)
     feats = torch.from_numpy(bpg.features)
     nbc = batch["neighbor_compact"]
@@ -94,39 +113,85 @@ def cpu_baseline(bpg, batch, seconds=15.0):
     p2v_oracle.train_step(st, dense, 1.0, mom, 1)            # warm-up
     t0 = time.perf_counter()
     n = 0
-    while True:
+    while n < min_steps:
         p2v_oracle.train_step(st, dense, 1.0, mom, n + 2)
         n += 1
-        el = time.perf_counter() - t0
-        if el > seconds or n >= 50:
+        if time.perf_counter() - t0 > max_seconds:
             break
+    el = time.perf_counter() - t0
+    # end to end: a few batches through the host loader
+    ld = SimilarityIndexLoader(bpg, b, shuffle=True, sampler="cpython", seed=0, drop_last=True, device="cpu",
+                               compact=False, prefetch=False, unique=False)
+    it = iter(ld)
+    t1 = time.perf_counter()
+    m = 0
+    while m < 3:
+        hb = next(it)
+        d2 = p2v_oracle.gather_batch(feats, hb["anchor_idx"].numpy(), hb["positive_idx"].numpy(),
+                                     hb["negative_idx"].numpy(), hb["neighbor_idx"].numpy())
+        p2v_oracle.train_step(st, d2, 1.0, mom, n + m + 2)
+        m += 1
+    el2 = time.perf_counter() - t1
     return {"value": b * n / el, "unit": "triplets/s", "cores": torch.get_num_threads(), "kind": "port",
+            "os_cpu_count": os.cpu_count(),
             "sample": f"{n} steps of the same workload (B={b}, N={dense['anchor_neighbors'].shape[1]}, fwd+bwd+Adam, "
-                      f"pre-gathered batch) on {os.cpu_count()} host cpus, torch {torch.get_num_threads()} threads"}
+                      f"pre-gathered batch) on {os.cpu_count()} host cpus, torch {torch.get_num_threads()} threads",
+            "end_to_end": {"value": b * m / el2, "unit": "triplets/s",
+                           "sample": f"{m} batches through the host loader (exact CPython negative sampler, CSR neighbour "
+                                     f"rows, dense gather) + the step"}}
 
 
-def joint_phase(args, rank, world, dev):
-    """BASELINE configs[2]: 100k products, T types, B pairs per GPU: PCompanion forward + both hinge
-    losses + backward + Adam as pc_joint_train_step / pc_adam_step.  HBM/launch-latency bound
-    (~2.6 KB and ~0.3 MFLOP per triplet): the roofline object reports the gather bandwidth."""
+def joint_cpu_baseline(model, batch, cfg, min_steps=20, max_seconds=40.0):
+    """oracle.joint_oracle.train_step on the same batch and the same initial state, on the host cores."""
+    from oracle import joint_oracle
+    st = {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}
+    hb = {k: (v.detach().cpu() if torch.is_tensor(v) else v) for k, v in batch.items()}
+    mom = joint_oracle.new_moments(st)
+    joint_oracle.train_step(st, hb, mom, 1, cfg.MARGIN, cfg.ALPHA, cfg.NUM_COMP_TYPES)
+    t0 = time.perf_counter()
+    n = 0
+    while n < min_steps:
+        joint_oracle.train_step(st, hb, mom, n + 2, cfg.MARGIN, cfg.ALPHA, cfg.NUM_COMP_TYPES)
+        n += 1
+        if time.perf_counter() - t0 > max_seconds:
+            break
+    el = time.perf_counter() - t0
+    b = hb["query_idx"].numel()
+    return {"value": b * n / el, "unit": "triplets/s", "cores": torch.get_num_threads(), "kind": "port",
+            "os_cpu_count": os.cpu_count(),
+            "sample": f"{n} steps of the same batch (B={b}, T={st['query_type_embeddings.weight'].shape[0]}, forward + both "
+                      f"hinges + autograd backward + dense Adam) on {os.cpu_count()} host cpus, torch "
+                      f"{torch.get_num_threads()} threads"}
+
+
+# ----------------------------------------------------------------------------------------------- joint phase
+def joint_algorithmic_bytes(b, t, k=3):
+    """per triplet 512 (query row) + 1024 (pos/neg item rows) + 256 (query-type row) + K*256 (comp-type
+    rows) + ~40 B of indices; per step T*L*4 to stream E_c for the similarities and 28 B per parameter of dense Adam
+    over 2*T*64 + 29,024 parameters."""
+    return b * (512 + 1024 + 256 + k * 256 + 40) + t * 64 * 4 + 28 * (2 * t * 64 + 29024)
+
+
+def run_joint(args, rank, world, dev, types, steps, warmup, want_cpu):
+    """BASELINE configs[2]: 100k products, T types, B pairs per GPU: PCompanion forward + both hinge losses + backward
+    + Adam (pc_joint_train_step + pc_adam_step), loader batch construction included."""
     from types import SimpleNamespace
     from p_companion_amd import distributed as pdist
     from p_companion_amd.data import ComplementaryIndexDataset, ComplementaryIndexLoader, generate_scaled_bpg
-    from p_companion_amd.p_companion import PCompanion
+    from p_companion_amd.p_companion import GraphedJointStep, PCompanion
     from p_companion_amd.product2vec import FusedAdam
     cfg = SimpleNamespace(PRODUCT_EMB_DIM=128, TYPE_EMB_DIM=64, DROPOUT=0.0, MARGIN=1.0, ALPHA=0.8, NUM_COMP_TYPES=3,
-                          NUM_TYPES=args.types, DEVICE=dev)
-    bpg = generate_scaled_bpg(args.products, min(args.types, 100), seed=0)
+                          NUM_TYPES=types, DEVICE=dev)
+    bpg = run_joint.bpg if getattr(run_joint, "bpg", None) is not None else generate_scaled_bpg(args.products, min(args.types, 100), seed=0)
+    run_joint.bpg = bpg
     torch.manual_seed(0)
     model = PCompanion(cfg, bpg.cuda(dev)["features"]).to(dev).train()       # frozen table: synthetic stand-in for the P2V export
     opt = FusedAdam(model, lr=1e-3)
     flat, gflat = model.flatten_parameters()
-    # one process: the fixed-shape step (pc_joint_train_step + pc_adam_step) is captured once as a HIP graph and
-    # replayed, the loader builds each batch straight into the graph's input buffers.  N > 1 keeps eager launches
-    # (the gradient all-reduce sits between the two calls).
+    # one process: the fixed-shape step is captured once as a HIP graph and replayed, the loader builds each batch
+    # straight into the graph's input buffers.  N > 1 keeps eager launches (the gradient all-reduce sits between).
     graphed = None
     if world == 1 and not args.no_graph:
-        from p_companion_amd.p_companion import GraphedJointStep
         graphed = GraphedJointStep(model, opt, args.batch)
     loader = ComplementaryIndexLoader(ComplementaryIndexDataset(bpg, "train"), args.batch, shuffle=True, seed=rank,
                                       device=dev, out=graphed.static if graphed else None)
@@ -147,14 +212,20 @@ def joint_phase(args, rank, world, dev):
         opt.step()
         return losses
 
-    for _ in range(args.warmup):
-        step(next(it))
+    last = None
+    for _ in range(max(warmup, 4)):                   # (the graph is captured after GraphedJointStep's eager warm-up steps)
+        last = next(it)
+        step(last)
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
     if world > 1:
         torch.distributed.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        losses = step(next(it))
+    ev[0].record()
+    for _ in range(steps):
+        last = next(it)
+        losses = step(last)
+    ev[1].record()
     torch.cuda.synchronize()
     if world > 1:
         torch.distributed.barrier()
@@ -163,65 +234,45 @@ def joint_phase(args, rank, world, dev):
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
     el = float(t)
     if rank != 0:
-        return
-    value = world * args.batch * args.steps / el
-    bytes_per = 2600.0
+        return None
+    value = world * args.batch * steps / el
+    dev_ms = ev[0].elapsed_time(ev[1]) / steps               # HIP events on the launch stream, around the timed steps
+    alg = joint_algorithmic_bytes(args.batch, types)
+    pmc = committed_pmc("*_joint_pmc_traffic*.json" if types == args.types else f"*_joint{types}_pmc_traffic*.json",
+                        lambda k: k == "_step_total")
+    achieved = alg / (dev_ms * 1e-3) / 1e9
     out = {"metric": "triplets/sec (P-Companion joint step: fwd + type/item hinge + bwd + Adam)", "value": round(value, 1),
-           "unit": "triplets/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-           "ms_per_step": round(1e3 * el / args.steps, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-           "dtype": "f32", "data": "synthetic",
-           "config": {"workload": f"P-Companion joint step, {args.products} products, {args.types} types, dim=128, "
+           "unit": "triplets/s", "steps": steps, "ms_per_step": round(1e3 * el / steps, 4),
+           "config": {"workload": f"P-Companion joint step, {args.products} products, NUM_TYPES={types}, dim=128, "
                                   f"batch={args.batch}/GPU, K=3 (loader batch construction included)",
                       "global_batch": world * args.batch, "parallelism": f"dp{world}", "final_loss": round(float(losses[0]), 5),
-                      "launch": "hipGraph replay" if graphed is not None else "eager"},
-           "roofline": {"bound": "hbm", "achieved": round(bytes_per * value / world / 1e9, 2), "peak": HBM_PEAK_GBS,
-                        "unit": "GB/s", "frac": round(bytes_per * value / world / 1e9 / HBM_PEAK_GBS, 5), "traffic": None,
-                        "note": "2.6 KB gathered per triplet (SURVEY 8d); the step is ~30 launches of a few us each: launch/latency bound"},
-           "cpu_baseline": None}
-    print(json.dumps(out), flush=True)
+                      "launch": "hipGraph replay" if graphed is not None else "eager",
+                      "kernels_per_step": getattr(model, "last_step_launches", None)},
+           "roofline": {"bound": "hbm", "kernel": "the whole step (one HIP-graph replay): its kernels are a dependent chain",
+                        "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                        "frac": round(achieved / HBM_PEAK_GBS, 5),
+                        "algorithmic_bytes_per_step": alg, "device_ms_per_step": round(dev_ms, 4),
+                        "traffic": pmc["hbm_bytes_per_launch"] if pmc else None,
+                        "traffic_source": pmc["source"] if pmc else None,
+                        "note": "2.6 KB gathered per triplet + T*256 B of E_c + 28 B/parameter of dense Adam per step "
+                                "(SURVEY 8d); launch/latency-bound, not bandwidth-bound"},
+           "cpu_baseline": joint_cpu_baseline(model, last, cfg) if want_cpu else None}
+    return out
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=50)
-    ap.add_argument("--warmup", type=int, default=10)
-    ap.add_argument("--products", type=int, default=100_000)
-    ap.add_argument("--types", type=int, default=100)
-    ap.add_argument("--batch", type=int, default=4096)
-    ap.add_argument("--table", choices=["replicated", "sharded"], default="replicated")
-    ap.add_argument("--phase", choices=["p2v", "joint"], default="p2v",
-                    help="p2v = BASELINE configs[1] (the headline line); joint = configs[2], the P-Companion joint step")
-    ap.add_argument("--sync-bn", action="store_true",
-                    help="N > 1: BatchNorm statistics over all replicas' rows (two 16 KB all-reduces per step) instead of "
-                         "each replica's own batch")
-    ap.add_argument("--profile-all", action="store_true",
-                    help="HIP-event brackets around every GEMM launch (TN and few-row kernels too), not only the dominant "
-                         "gemm_nt_kernel family: ~60 us/step of event packets")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-graph", action="store_true", help="joint phase: eager launches instead of the HIP-graph replay")
-    ap.add_argument("--cpu-seconds", type=float, default=15.0)
-    args = ap.parse_args()
-
-    from p_companion_amd import distributed as pdist
-    rank, world, local = pdist.init_from_env("cuda")
-    if world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
-    local = int(os.environ.get("PC_FORCE_DEVICE", local))
-    torch.cuda.set_device(local)
-    dev = torch.device("cuda", local)
-
-    if args.phase == "joint":
-        return joint_phase(args, rank, world, dev)
-
+# ----------------------------------------------------------------------------------------------- P2V phase
+def run_p2v(args, rank, world, dev, products, steps, warmup, want_cpu, profile_kernels=True):
     from types import SimpleNamespace
+    from p_companion_amd import distributed as pdist
     from p_companion_amd import ops
     from p_companion_amd.data import SimilarityIndexLoader, generate_scaled_bpg
     from p_companion_amd.product2vec import FusedAdam, Product2Vec
 
     cfg = SimpleNamespace(PRODUCT_EMB_DIM=128, TYPE_EMB_DIM=64, HIDDEN_SIZE=256, NUM_ATTENTION_HEADS=4, DROPOUT=0.0,
                           MARGIN=1.0, BATCH_SIZE=args.batch, LEARNING_RATE=1e-3, DEVICE=dev)
-    bpg = generate_scaled_bpg(args.products, args.types, seed=0)
+    bpg = generate_scaled_bpg(products, args.types, seed=0)
+    if products == args.products:
+        run_joint.bpg = bpg                                   # the joint phase trains over the same catalogue
     torch.manual_seed(0)
     model = Product2Vec(cfg).to(dev)
     model.train()
@@ -241,27 +292,15 @@ def main():
                 yield b
 
     it = batches()
-    prof = ops.KernelProfile(capacity=32 * max(args.steps, 1))
+    prof = ops.KernelProfile(capacity=32 * max(steps, 1))
     if not args.profile_all:
         prof.set_kinds(["gemm_nt_kernel"])
-    n_sum = 0
-    real_sum = 0
-    slot_sum = 0
+    n_sum = real_sum = slot_sum = 0
 
     def step(b, profile=None):
         tab = table
         if sharded is not None:
-            nbc = b["neighbor_compact"]
-            uq = "weight" in nbc
-            nrows = nbc["nb_rows"][: int(nbc["n_unique"]) + 1] if uq else nbc["nb_rows"]
-            ids = torch.cat([b["anchor_idx"], nrows, b["positive_idx"], b["negative_idx"].reshape(-1)])
-            tab, remap = sharded.lookup(ids)
-            B, M1, K = b["anchor_idx"].numel(), nrows.numel(), b["negative_idx"].shape[1]
-            o = np.cumsum([0, B, M1, B, B * K])
-            b = {"anchor_idx": remap[o[0]:o[1]].contiguous(), "positive_idx": remap[o[2]:o[3]].contiguous(),
-                 "negative_idx": remap[o[3]:o[4]].view(B, K).contiguous(),
-                 "neighbor_compact": dict({"nb_rows": remap[o[1]:o[2]].contiguous(), "slot_row": nbc["slot_row"]},
-                                          **({k: nbc[k] for k in ("weight", "n_unique", "ref_off", "ref_slot")} if uq else {}))}
+            tab, b = sharded.lookup_batch(b)
         sync = (lambda t: torch.distributed.all_reduce(t)) if (args.sync_bn and world > 1) else None
         loss = model.train_step_indexed(tab, b, profile=profile, sync_reduce=sync)
         pdist.all_reduce_mean_(gflat, world)
@@ -269,85 +308,169 @@ def main():
         return loss
 
     last = None
-    for _ in range(args.warmup):
+    for _ in range(warmup):
         last = next(it)
         step(last)
     if world > 1:
         torch.distributed.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    for _ in range(steps):
         last = next(it)
         n_sum += last["n_pad"]
         nbc_ = last["neighbor_compact"]
         real_sum += int(nbc_["n_unique"]) if "weight" in nbc_ else nbc_["nb_rows"].numel() - 1      # rows carried
         slot_sum += nbc_.get("n_real", nbc_["nb_rows"].numel() - 1)                                   # real slots
-        loss = step(last, profile=prof)
+        loss = step(last, profile=prof if profile_kernels else None)
     torch.cuda.synchronize()
     if world > 1:
         torch.distributed.barrier()
-    el = time.perf_counter() - t0
-    t = torch.tensor([el], dtype=torch.float64, device=dev)
+    t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=dev)
     if world > 1:
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
     el = float(t)
     if rank != 0:
-        return
+        return None
 
-    n_avg = n_sum / max(args.steps, 1)
-    value = world * args.batch * args.steps / el
-    nt = prof.summary("gemm_nt_kernel")
-    tn = prof.summary("gemm_tn_kernel")
-    sm = prof.summary("gemm_nt_small_kernel")
-    traffic = pmc_traffic_per_launch()
-    achieved = nt["total_flops"] / (nt["total_ms"] * 1e-3) / 1e12 if nt["total_ms"] > 0 else 0.0
-    roof = {"bound": "mfma", "kernel": "gemm_nt_kernel", "achieved": round(achieved, 2),
-            "peak": round(NT_PEAK_TFLOPS, 1), "unit": "TFLOP/s", "frac": round(achieved / NT_PEAK_TFLOPS, 4),
-            "peak_note": "fp32 in / fp32 accumulate / fp32-grade result on the bf16 matrix cores: 6 bf16 MFMA products per "
-                         "fp32 product, so peak = 2500 dense bf16 TFLOP/s / 6; `achieved` counts each fp32 product once",
-            "executed_bf16_tflops": round(achieved * BF16_PRODUCTS, 1),
-            "frac_of_fp32_mfma_peak": round(achieved / FP32_MFMA_PEAK_TFLOPS, 4),
+    n_avg = n_sum / max(steps, 1)
+    rows_avg = real_sum / max(steps, 1)
+    slots_avg = slot_sum / max(steps, 1)
+    value = world * args.batch * steps / el
+    res = {"value": value, "ms_per_step": 1e3 * el / steps, "n_avg": n_avg, "final_loss": float(loss),
+           "distinct_neighbour_rows": rows_avg, "real_neighbour_slots": slots_avg,
+           "rows_saved_by_duplicate_neighbours": round(1.0 - (7 * args.batch + rows_avg + 1) / (7 * args.batch + slots_avg + 1), 4)}
+    if profile_kernels:
+        nt = prof.summary("gemm_nt_kernel")
+        tn = prof.summary("gemm_tn_kernel")
+        sm = prof.summary("gemm_nt_small_kernel")
+        traffic = committed_pmc("*_pmc_traffic.json", lambda k: "gemm_nt_kernel<" in k and "<1, 2," not in k)
+        launches = max(nt["launches"], 1)
+        sec = nt["total_ms"] * 1e-3 / launches
+        fl = nt["total_flops"] / launches
+        alg = nt_algorithmic_bytes(args.batch, rows_avg + 1) / 7
+        bound, fm, fh = two_roof(fl, alg, sec, NT_PEAK_TFLOPS)
+        tfl = fl / sec / 1e12 if sec > 0 else 0.0
+        gbs = alg / sec / 1e9 if sec > 0 else 0.0
+        exe = executed_flops_per_step(args.batch, rows_avg + 1)
+        res["roofline"] = {
+            "bound": bound, "kernel": "gemm_nt_kernel",
+            "achieved": round(gbs if bound == "hbm" else tfl, 2), "peak": HBM_PEAK_GBS if bound == "hbm" else round(NT_PEAK_TFLOPS, 1),
+            "unit": "GB/s" if bound == "hbm" else "TFLOP/s", "frac": round(fh if bound == "hbm" else fm, 4),
+            "frac_hbm": round(fh, 4), "achieved_gbs": round(gbs, 1),
+            "frac_mfma": round(fm, 4), "achieved_tflops": round(tfl, 2), "peak_tflops": round(NT_PEAK_TFLOPS, 1),
+            "bound_note": "intensity %.1f FLOP/B vs the ridge %.1f FLOP/B of (2500 dense bf16 TFLOP/s / 6 products) over 8 TB/s: "
+                          "the binding roof is the larger of the two lower bounds on the launch time"
+                          % (fl / alg, NT_PEAK_TFLOPS * 1e3 / HBM_PEAK_GBS),
+            "peak_note": "fp32 in / fp32 accumulate / fp32-grade result on the bf16 matrix cores: 6 bf16 MFMA products per fp32 "
+                         "product, so the matrix peak is 2500 / 6 fp32-equivalent TFLOP/s; `achieved_tflops` counts each fp32 product once",
             "traffic": traffic["hbm_bytes_per_launch"] if traffic else None,
             "traffic_source": traffic["source"] if traffic else None,
-            "algorithmic_bytes_per_launch": round(nt_algorithmic_bytes(args.batch, real_sum / max(args.steps, 1) + 1) / 7),
-            "launches": nt["launches"], "avg_launch_us": round(1e3 * nt["total_ms"] / max(nt["launches"], 1), 2),
-            "flops_per_launch": nt["total_flops"] / max(nt["launches"], 1),
+            "algorithmic_bytes_per_launch": round(alg), "flops_per_launch": fl,
+            "launches": nt["launches"], "avg_launch_us": round(1e6 * sec, 2),
             "share_of_step": round(nt["total_ms"] / (el * 1e3), 3),
-            "gemm_tn_kernel": ({"achieved": round(tn["total_flops"] / max(tn["total_ms"], 1e-9) / 1e9, 2),
+            "gemm_tn_kernel": ({"achieved_tflops": round(tn["total_flops"] / max(tn["total_ms"], 1e-9) / 1e9, 2),
                                 "launches": tn["launches"], "share_of_step": round(tn["total_ms"] / (el * 1e3), 3)}
                                if tn["launches"] else None),                     # bracketed with --profile-all only
             "gemm_nt_small_kernel": ({"launches": sm["launches"],
                                       "avg_launch_us": round(1e3 * sm["total_ms"] / max(sm["launches"], 1), 2),
                                       "share_of_step": round(sm["total_ms"] / (el * 1e3), 3)} if sm["launches"] else None),
-            "whole_step": {"flops_per_triplet": flops_per_triplet(round(n_avg)),
-                           # `achieved` prices the step at the reference's dense formulation (every slot its own
-                           # row); `executed` counts the rows actually multiplied (identical rows carried once)
-                           "executed_flops_per_triplet": round(executed_flops_per_step(args.batch, real_sum / max(args.steps, 1) + 1) / args.batch),
-                           "executed": round(executed_flops_per_step(args.batch, real_sum / max(args.steps, 1) + 1) / args.batch * value / world / 1e12, 2),
-                           "achieved": round(flops_per_triplet(n_avg) * value / world / 1e12, 2),
-                           "frac_mfma": round(flops_per_triplet(n_avg) * value / world / 1e12 / FP32_MFMA_PEAK_TFLOPS, 4),
+            # the whole step is occupancy-, epilogue- and launch-structure-bound, not roofline-bound: reported as what
+            # it executes, against the peaks of the units it uses
+            "whole_step": {"executed_flops_per_triplet": round(exe / args.batch),
+                           "executed_tflops": round(exe / args.batch * value / world / 1e12, 2),
+                           "executed_frac_of_matrix_peak": round(exe / args.batch * value / world / 1e12 / NT_PEAK_TFLOPS, 4),
+                           "reference_equivalent_flops_per_triplet": flops_per_triplet(round(n_avg)),
                            "gather_bytes_per_triplet": bytes_per_triplet(round(n_avg)),
                            "frac_hbm_gather": round(bytes_per_triplet(n_avg) * value / world / 1e9 / HBM_PEAK_GBS, 5)}}
-    out = {"metric": "triplets/sec (Product2Vec pretrain step: gather+fwd+bwd+Adam)", "value": round(value, 1),
-           "unit": "triplets/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-           "ms_per_step": round(1e3 * el / args.steps, 4), "higher_is_better": True, "scaling": "weak",
-           "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+    if want_cpu:
+        res["cpu_baseline"] = p2v_cpu_baseline(bpg, last)
+    prof.close()
+    return res
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--products", type=int, default=100_000)
+    ap.add_argument("--types", type=int, default=100)
+    ap.add_argument("--batch", type=int, default=4096)
+    ap.add_argument("--table", choices=["replicated", "sharded"], default="replicated")
+    ap.add_argument("--phase", choices=["both", "p2v", "joint"], default="both",
+                    help="both (default) = BASELINE's whole metric: configs[1] as the headline value + configs[2] as `joint`")
+    ap.add_argument("--sync-bn", action="store_true",
+                    help="N > 1: BatchNorm statistics over all replicas' rows (two 16 KB all-reduces per step) instead of "
+                         "each replica's own batch")
+    ap.add_argument("--profile-all", action="store_true",
+                    help="HIP-event brackets around every GEMM launch (TN and few-row kernels too), not only the dominant "
+                         "gemm_nt_kernel family: ~60 us/step of event packets")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-graph", action="store_true", help="joint phase: eager launches instead of the HIP-graph replay")
+    ap.add_argument("--large-catalogue", type=int, default=0,
+                    help="also time the P2V step over this many products (e.g. 2000000: few duplicate neighbours to merge)")
+    ap.add_argument("--no-ref-types", action="store_true", help="skip the joint leg at the reference's NUM_TYPES = 34800")
+    args = ap.parse_args()
+
+    from p_companion_amd import distributed as pdist
+    rank, world, local = pdist.init_from_env("cuda")
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+    local = int(os.environ.get("PC_FORCE_DEVICE", local))
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    want_cpu = not args.no_cpu_baseline and world == 1
+
+    p2v = joint = joint_ref = large = None
+    if args.phase in ("both", "p2v"):
+        p2v = run_p2v(args, rank, world, dev, args.products, args.steps, args.warmup, want_cpu)
+        if args.large_catalogue:
+            large = run_p2v(args, rank, world, dev, args.large_catalogue, max(args.steps // 2, 5), args.warmup, False,
+                            profile_kernels=False)
+    if args.phase in ("both", "joint"):
+        joint = run_joint(args, rank, world, dev, args.types, max(args.steps * 4, 100), max(args.warmup, 10), want_cpu)
+        if not args.no_ref_types and args.types != 34800:
+            joint_ref = run_joint(args, rank, world, dev, 34800, max(args.steps, 20), max(args.warmup, 10), False)
+    if rank != 0:
+        return
+
+    common = {"unit": "triplets/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "higher_is_better": True,
+              "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic"}
+    if p2v is None:                                           # --phase joint: the joint step is the line
+        out = dict(common)
+        out.update(joint)
+        out["steps"] = joint["steps"]
+        if joint_ref:
+            out["joint_num_types_34800"] = joint_ref
+        print(json.dumps(out), flush=True)
+        return
+    out = {"metric": "triplets/sec (Product2Vec pretrain step: gather+fwd+bwd+Adam)" +
+                     (" + P-Companion joint step under `joint`" if joint else ""),
+           "value": round(p2v["value"], 1), **common, "ms_per_step": round(p2v["ms_per_step"], 4),
            "dtype_note": "fp32 storage, accumulation and result accuracy; the large GEMMs evaluate each fp32 product as six "
                          "bf16 matrix-core products of a three-way split (error <= the fp32 MFMA's, tests/test_gpu_ops.py)",
            "config": {"workload": f"Product2Vec GAT pretrain, {args.products} products, {args.types} types, dim=128, "
                                   f"batch={args.batch}/GPU, 5 negatives, neighbours padded to batch max "
-                                  f"(avg N={n_avg:.1f})", "global_batch": world * args.batch,
+                                  f"(avg N={p2v['n_avg']:.1f})", "global_batch": world * args.batch,
                       "table": args.table, "parallelism": f"dp{world}",
-                      "batchnorm": "cross-replica" if (args.sync_bn and world > 1) else "per-replica", "final_loss": round(float(loss), 5),
+                      "batchnorm": "cross-replica" if (args.sync_bn and world > 1) else "per-replica",
+                      "final_loss": round(p2v["final_loss"], 5),
                       "neighbour_rows": "identical rows of the neighbour call carried once: avg %.0f distinct products (%.0f "
-                                        "real slots) + 1 shared padding row, of %d neighbour slots per step"
-                                        % (real_sum / max(args.steps, 1), slot_sum / max(args.steps, 1),
-                                           args.batch * round(n_avg))},
-           "roofline": roof}
-    if not args.no_cpu_baseline and world == 1:
-        out["cpu_baseline"] = cpu_baseline(bpg, last, args.cpu_seconds)
-    else:
-        out["cpu_baseline"] = None
+                                        "real slots) + 1 shared padding row, of %d neighbour slots per step; the duplicates "
+                                        "are a property of the catalogue (%.0f %% of all FFN rows saved at %d products; see "
+                                        "`large_catalogue` / DESIGN.md section 7 for 2 M products)"
+                                        % (p2v["distinct_neighbour_rows"], p2v["real_neighbour_slots"],
+                                           args.batch * round(p2v["n_avg"]), 100 * p2v["rows_saved_by_duplicate_neighbours"],
+                                           args.products)},
+           "roofline": p2v.get("roofline"), "cpu_baseline": p2v.get("cpu_baseline")}
+    if large:
+        out["large_catalogue"] = {"products": args.large_catalogue, "value": round(large["value"], 1),
+                                  "ms_per_step": round(large["ms_per_step"], 4),
+                                  "rows_saved_by_duplicate_neighbours": large["rows_saved_by_duplicate_neighbours"]}
+    if joint:
+        out["joint"] = joint
+    if joint_ref:
+        out["joint_num_types_34800"] = joint_ref
     print(json.dumps(out), flush=True)
 
 

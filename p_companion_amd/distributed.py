@@ -64,6 +64,22 @@ class ShardedFeatureTable:
     def shard(full_table, rank, world):
         return full_table[rank::world].contiguous()
 
+    def lookup_batch(self, batch):
+        """Index batch over GLOBAL product ids -> (compact table of the rows this rank needs, the same batch over
+        that table): what the fused step consumes unchanged (unique / compact neighbour layouts)."""
+        nbc = batch["neighbor_compact"]
+        uq = "weight" in nbc
+        nrows = nbc["nb_rows"][: int(nbc["n_unique"]) + 1] if uq else nbc["nb_rows"]
+        ids = torch.cat([batch["anchor_idx"], nrows, batch["positive_idx"], batch["negative_idx"].reshape(-1)])
+        tab, remap = self.lookup(ids)
+        B, M1, K = batch["anchor_idx"].numel(), nrows.numel(), batch["negative_idx"].shape[1]
+        o = np.cumsum([0, B, M1, B, B * K])
+        out = {"anchor_idx": remap[o[0]:o[1]].contiguous(), "positive_idx": remap[o[2]:o[3]].contiguous(),
+               "negative_idx": remap[o[3]:o[4]].view(B, K).contiguous(),
+               "neighbor_compact": dict({"nb_rows": remap[o[1]:o[2]].contiguous(), "slot_row": nbc["slot_row"]},
+                                        **({k: nbc[k] for k in ("weight", "n_unique", "ref_off", "ref_slot")} if uq else {}))}
+        return tab, out
+
     def lookup(self, ids):
         dev = ids.device
         flat = ids.reshape(-1).to(torch.int64)

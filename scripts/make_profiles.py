@@ -12,7 +12,7 @@ root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 src = os.path.join(root, "gpurun_out", tag)
 dst = os.path.join(root, "profiles")
 os.makedirs(dst, exist_ok=True)
-for name in ("bench.json", "bench_under_rocprof.json"):
+for name in ("bench.json", "bench_under_rocprof.json", "bench_joint_under_rocprof.json"):
     if os.path.exists(os.path.join(src, name)):
         shutil.copy(os.path.join(src, name), os.path.join(dst, f"{tag}_{name}"))
 
@@ -21,8 +21,10 @@ def short(n):
     return n.replace("void ", "").strip()
 
 # ---- kernel trace
-dbs = glob.glob(os.path.join(src, "prof", "*_results.db"))
-if dbs:
+def kernel_stats(subdir, suffix):
+    dbs = glob.glob(os.path.join(src, subdir, "*_results.db"))
+    if not dbs:
+        return
     db = sqlite3.connect(dbs[0]); cur = db.cursor()
     tabs = [r[0] for r in cur.execute("select name from sqlite_master where type='table'")]
     kd = [t for t in tabs if t.startswith("rocpd_kernel_dispatch")][0]
@@ -32,7 +34,7 @@ if dbs:
     rows = cur.execute(f"select s.{namecol}, count(*), sum(d.end-d.start), avg(d.end-d.start), min(d.end-d.start), max(d.end-d.start) "
                        f"from {kd} d join {ks} s on d.kernel_id=s.id group by s.{namecol} order by 3 desc").fetchall()
     tot = sum(r[2] for r in rows)
-    with open(os.path.join(dst, f"{tag}_kernel_stats.csv"), "w", newline="") as f:
+    with open(os.path.join(dst, f"{tag}{suffix}_kernel_stats.csv"), "w", newline="") as f:
         wr = csv.writer(f); wr.writerow(["Name", "Calls", "TotalDurationNs", "AverageNs", "Percentage", "MinNs", "MaxNs"])
         for r in rows: wr.writerow([r[0], r[1], r[2], f"{r[3]:.1f}", f"{100*r[2]/tot:.2f}", r[4], r[5]])
     js = {short(r[0]) if r[0].startswith("void") or "(" in r[0] else r[0]: {"calls": r[1], "avg_us": round(r[3] / 1e3, 2), "share": round(r[2] / tot, 4)} for r in rows}
@@ -42,8 +44,18 @@ if dbs:
                       "gemm_nt_share": round(sum(t for _, t in nt) / tot, 4),
                       "gemm_tn_avg_us": round(sum(t for _, t in tn) / max(1, sum(c for c, _ in tn)) / 1e3, 2),
                       "gemm_tn_share": round(sum(t for _, t in tn) / tot, 4)}
-    json.dump(js, open(os.path.join(dst, f"{tag}_kernel_stats.json"), "w"), indent=1)
-    print("kernel stats:", js["_summary"])
+    if suffix == "_joint":
+        # kernels per step of the joint loop: everything launched once per step has the call count of the Adam kernel
+        steps = max([r[1] for r in rows if "adam" in r[0]] or [1])
+        per_step = {short(r[0]): round(r[1] / steps, 2) for r in rows if r[1] >= steps // 2}
+        js["_summary"].update({"steps_traced": steps, "kernel_us_per_step": round(tot / 1e3 / steps, 2),
+                               "launches_per_step": round(sum(r[1] for r in rows if r[1] >= steps // 2) / steps, 2),
+                               "per_step_launch_counts": per_step})
+    json.dump(js, open(os.path.join(dst, f"{tag}{suffix}_kernel_stats.json"), "w"), indent=1)
+    print(f"kernel stats{suffix}:", js["_summary"])
+
+kernel_stats("prof", "")
+kernel_stats("prof_joint", "_joint")
 
 # ---- PMC passes
 def pmc(dirname, counter):
@@ -65,3 +77,19 @@ if fe:
     nt = [v for k, v in res.items() if "gemm_nt_kernel<" in k]
     n = sum(v["launches"] for v in nt)
     print("gemm_nt HBM bytes/launch:", round(sum((v["fetch_bytes_corrected"] + v["write_bytes"]) * v["launches"] for v in nt) / n))
+
+# ---- PMC passes of the joint phase (eager launches): per kernel, and summed over one step (`_step_total`)
+fe, wr_ = pmc("pmc_joint_fetch", "FETCH_SIZE"), pmc("pmc_joint_write", "WRITE_SIZE")
+if fe:
+    res = {}
+    for k, (n, v) in fe.items():
+        w = wr_.get(k, [n, 0.0])
+        res[k] = {"launches": n, "fetch_kib_raw": round(v / n, 1), "fetch_bytes_corrected": round(v / n * 1024 * 2),
+                  "write_bytes": round(w[1] / max(1, w[0]) * 1024)}
+    steps = max([v["launches"] for k, v in res.items() if "adam" in k] or [1])
+    tot_f = sum(v["fetch_bytes_corrected"] * v["launches"] for v in res.values()) / steps
+    tot_w = sum(v["write_bytes"] * v["launches"] for v in res.values()) / steps
+    res["_step_total"] = {"launches": 1, "steps_counted": steps, "fetch_bytes_corrected": round(tot_f), "write_bytes": round(tot_w),
+                          "note": "all kernels of the process (batch builder, step, Adam) summed and divided by the steps run"}
+    json.dump(res, open(os.path.join(dst, f"{tag}_joint_pmc_traffic.json"), "w"), indent=1)
+    print("joint HBM bytes/step:", round(tot_f + tot_w))
