@@ -43,6 +43,19 @@ extern "C" {
 
 int pc_abi_version(void);
 
+/* Training-mode dropout (config.py:12 DROPOUT = 0.1 is live in every reference training step: the attention
+ * probabilities of product2vec.py:23-28 and the hidden layer of type_transition.py:13,17).  ATen's dropout stream
+ * cannot be reproduced, so the mask is the build's own, counter-based and restated in oracle/philox_oracle.py:
+ * element e of the dropped tensor belongs to group e >> 2, the four keep decisions of a group are the four words
+ * of Philox4x32-10(counter = (group, stream, offset lo, offset hi), key = seed); word i keeps element 4*group + i
+ * iff word >= floor(p * 2^32); kept values are multiplied by fp32 1/(1-p).  stream 0 = attention probabilities
+ * [B,HEADS,N] (after the softmax, before the weighted sum: F.multi_head_attention_forward), 1 = hidden layer [B,32].
+ * `offset`: the caller's step counter -- forward and backward of one step pass the same value.  p == 0: off. */
+typedef struct {
+    float p;
+    uint64_t seed, offset;
+} pc_dropout;
+
 /* ---------------------------------------------------------------------------------
  * Product2Vec parameters, reference state_dict layout (product2vec.py:14-29):
  *   ffn.0 Linear(D->H) w0[H,D] b0[H]; ffn.1 BatchNorm1d(H) gamma/beta/running_*[H];
@@ -55,6 +68,8 @@ typedef struct {
     float *in_proj_w, *in_proj_b, *out_proj_w, *out_proj_b;
     float *running_mean, *running_var;
     int64_t *num_batches_tracked;
+    pc_dropout dropout;   /* attention-weight dropout of nn.MultiheadAttention(dropout=config.DROPOUT) in
+                           * training mode (product2vec.py:23-28); all-zero = off (eval, or DROPOUT = 0) */
 } pc_p2v_tensors;
 
 /* Row groups ("segments") of one FFN launch.  The reference calls the FFN once per tensor
@@ -316,6 +331,8 @@ typedef struct {
     float *itm_w, *itm_b;  /* item_prediction.item_projection [D,D], [D]                 */
     float *query_types;    /* query_type_embeddings.weight [T,L]                         */
     float *comp_types;     /* complementary_type_embeddings.weight [T,L]                 */
+    pc_dropout dropout;    /* nn.Dropout on the hidden layer in training mode (type_transition.py:13,17);
+                            * all-zero = off */
 } pc_joint_tensors;
 
 typedef struct {
@@ -439,6 +456,11 @@ int pc_scatter_rows(float *out, const int32_t *idx, int rows, int width, const f
 /* dx = dy * act'(y) for a stand-alone activation: act 1 = tanh (1 - y^2), 2 = relu (y > 0)
  * (F.relu of type_transition.py:17 in module mode). */
 int pc_act_backward(const float *dy, const float *y, size_t n, int act, float *dx, void *stream);
+
+/* nn.Dropout of ComplementaryTypeTransition (type_transition.py:13,17) in training mode on the hidden activations
+ * x[n] (n % 4 == 0, rows of 32): y = x * mask, mask = stream 1 of pc_dropout (0 or 1/(1-p)).  The same call with the
+ * same (seed, offset) is its backward (dx = dy * mask).  In place (y == x) allowed.  0 < p < 1. */
+int pc_dropout_hidden(const float *x, size_t n, const pc_dropout *d, float *y, void *stream);
 
 /* Index validation.  The reference's lookups raise for an id outside its table (nn.Embedding: IndexError;
  * product_to_idx: KeyError -- p_companion.py:48-54); here up to `count` <= 4 int32 index arrays idx[a][n[a]] are

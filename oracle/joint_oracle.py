@@ -40,12 +40,15 @@ def init_state(seed, table, num_types, d=128, l=64):
     return st
 
 
-def forward(st, query_idx, query_types, k=3):
+def forward(st, query_idx, query_types, k=3, hidden_mask=None):
     """p_companion.py:45-77 with integer product ids (the str->idx map of :47-49 is host
-    glue).  Dropout p=0 (type_transition.py:17)."""
+    glue).  hidden_mask [B,32] (optional): nn.Dropout on the hidden layer (type_transition.py:17) as an explicit
+    multiplier (0 or 1/(1-p)); None = dropout off."""
     q = st["product_embeddings.weight"][query_idx.long()]
     t = st["query_type_embeddings.weight"][query_types.long()]
     h = torch.relu(t @ st["type_transition.encoder.weight"].T + st["type_transition.encoder.bias"])
+    if hidden_mask is not None:
+        h = h * hidden_mask
     c = h @ st["type_transition.decoder.weight"].T + st["type_transition.decoder.bias"]
     ec = st["complementary_type_embeddings.weight"]
     sims = c @ ec.T
@@ -82,14 +85,14 @@ def new_moments(st):
     return {k: (torch.zeros_like(st[k]), torch.zeros_like(st[k])) for k in TRAINABLE}
 
 
-def train_step(st, batch, moments, step, margin=1.0, alpha=0.8, k=3, lr=1e-3):
+def train_step(st, batch, moments, step, margin=1.0, alpha=0.8, k=3, lr=1e-3, hidden_mask=None):
     """One iteration of train.train's loop body (train.py:42-48).  Dense Adam: rows of the
     type tables that received zero gradient still move once their moments are non-zero."""
     from .p2v_oracle import adam_step
     leaves = {n: st[n].detach().clone().requires_grad_(True) for n in TRAINABLE}
     work = dict(st)
     work.update(leaves)
-    out = forward(work, batch["query_idx"], batch["query_types"], k)
+    out = forward(work, batch["query_idx"], batch["query_types"], k, hidden_mask=hidden_mask)
     loss, tl, il = compute_loss(out, batch, margin, alpha)
     grads = dict(zip(TRAINABLE, torch.autograd.grad(loss, [leaves[n] for n in TRAINABLE])))
     with torch.no_grad():

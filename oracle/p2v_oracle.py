@@ -74,9 +74,12 @@ def ffn(x, st, training, update_running=True):
     return a2 @ st["ffn.5.weight"].T + st["ffn.5.bias"]
 
 
-def attention(query, keys, st, heads=4):
+def attention(query, keys, st, heads=4, mask=None):
     """apply_attention (product2vec.py:48-68): nn.MultiheadAttention, one query token,
-    keys == values, NO key-padding mask, dropout 0.  query [B,D], keys [B,N,D] -> [B,D]."""
+    keys == values, NO key-padding mask.  query [B,D], keys [B,N,D] -> [B,D].
+    mask [B,heads,N] (optional): the attention-weight dropout of nn.MultiheadAttention(dropout=p) in training mode
+    (F.multi_head_attention_forward: softmax, THEN dropout on the probabilities, then the weighted sum) as an explicit
+    multiplier tensor (0 or 1/(1-p)) -- ATen's own mask stream cannot be reproduced, so the mask is an input here."""
     b, n, d = keys.shape
     hd = d // heads
     w, bias = st["attention.in_proj_weight"], st["attention.in_proj_bias"]
@@ -87,11 +90,13 @@ def attention(query, keys, st, heads=4):
     k = k.view(b, n, heads, hd).transpose(1, 2)           # [B,H,N,hd]
     v = v.view(b, n, heads, hd).transpose(1, 2)
     p = torch.softmax((q * k).sum(-1), dim=-1)            # [B,H,N]
+    if mask is not None:
+        p = p * mask
     o = (p.unsqueeze(-1) * v).sum(2).reshape(b, d)        # heads concatenated
     return o @ st["attention.out_proj.weight"].T + st["attention.out_proj.bias"]
 
 
-def forward(features, neighbors, st, training):
+def forward(features, neighbors, st, training, attn_mask=None):
     """Product2Vec.forward (product2vec.py:70-81) for 2-D features / 3-D neighbours."""
     if features.dim() == 3:
         b, n, d = features.shape
@@ -100,7 +105,7 @@ def forward(features, neighbors, st, training):
     if neighbors is not None and neighbors.shape[0] > 0:
         b, n, d = neighbors.shape
         nb = ffn(neighbors.reshape(-1, d), st, training).reshape(b, n, -1)
-        emb = attention(emb, nb, st)
+        emb = attention(emb, nb, st, mask=attn_mask)
     return emb
 
 
@@ -128,14 +133,14 @@ def adam_step(params, grads, moments, step, lr=1e-3, b1=0.9, b2=0.999, eps=1e-8)
         params[k].addcdiv_(m, denom, value=-lr / bc1)
 
 
-def train_step(st, batch, margin, moments, step, lr=1e-3):
+def train_step(st, batch, margin, moments, step, lr=1e-3, attn_mask=None):
     """One iteration of Product2Vec.train_model's loop body (product2vec.py:126-159).
     batch: anchor [B,D], positive [B,D], negative [B,K,D], anchor_neighbors [B,N,D] or None.
     Mutates st (params, BN buffers) and moments.  Returns a dict of intermediates."""
     leaves = {k: st[k].detach().clone().requires_grad_(True) for k in TRAINABLE}
     work = dict(st)
     work.update(leaves)
-    a = forward(batch["anchor"], batch.get("anchor_neighbors"), work, True)
+    a = forward(batch["anchor"], batch.get("anchor_neighbors"), work, True, attn_mask=attn_mask)
     p = forward(batch["positive"], None, work, True)
     n = forward(batch["negative"], None, work, True)
     loss, d_pos, d_neg = triplet_loss(a, p, n, margin)

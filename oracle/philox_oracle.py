@@ -58,3 +58,33 @@ def build_batch(pair_ids, sim_pairs, cv_rowptr, cv_col, sim_rowptr, sim_col, n_p
         row = cv_col[cv_rowptr[a[b]]:cv_rowptr[a[b] + 1]][:n_pad]
         nb[b, :len(row)] = row
     return a, p, neg, nb
+
+
+# ---------------------------------------------------------------------------------------------------------
+# Dropout masks of the HIP path (csrc/common.h pc_dropout_keep4).  ATen's dropout stream cannot be reproduced
+# (SURVEY.md section 7), so the build draws its own: element e of a dropped tensor belongs to group e >> 2; the four
+# keep decisions of a group are the four words of Philox4x32-10(counter = (group, stream, offset lo, offset hi),
+# key = seed), word i decides element 4 * group + i: KEEP iff word >= floor(p * 2^32); kept values are scaled by
+# 1 / (1 - p) in fp32.  stream 0 = attention probabilities [B, heads, N] (nn.MultiheadAttention(dropout=p),
+# product2vec.py:23-28), stream 1 = the type-transition hidden layer [B, 32] (nn.Dropout, type_transition.py:13,17).
+# `offset` is the module's training-step counter (one fresh mask per forward).
+STREAM_ATTENTION, STREAM_HIDDEN = 0, 1
+
+
+def dropout_threshold(p):
+    return min(int(float(np.float32(p)) * 4294967296.0), 4294967295)
+
+
+def dropout_mask(seed, offset, stream, n_elements, p):
+    """[n_elements] float32 multipliers: 0 for a dropped element, fp32(1 / (1 - p)) for a kept one."""
+    if p <= 0:
+        return np.ones(n_elements, np.float32)
+    thr = dropout_threshold(p)
+    scale = np.float32(1.0) / (np.float32(1.0) - np.float32(p))
+    key = (seed & MASK, (seed >> 32) & MASK)
+    out = np.empty((n_elements + 3) // 4 * 4, np.float32)
+    for g in range(len(out) // 4):
+        w = philox4x32_10((g & MASK, stream, offset & MASK, (offset >> 32) & MASK), key)
+        for i in range(4):
+            out[4 * g + i] = scale if w[i] >= thr else np.float32(0.0)
+    return out[:n_elements]

@@ -22,10 +22,15 @@ class HipKernelError(RuntimeError):
     pass
 
 
+class Dropout(ctypes.Structure):
+    """pc_dropout: p == 0 (the zero-initialised default) = off."""
+    _fields_ = [("p", ctypes.c_float), ("seed", ctypes.c_uint64), ("offset", ctypes.c_uint64)]
+
+
 class P2VTensors(ctypes.Structure):
     _fields_ = [(n, ctypes.c_void_p) for n in (
         "w0", "b0", "gamma", "beta", "w3", "b3", "w5", "b5", "in_proj_w", "in_proj_b", "out_proj_w",
-        "out_proj_b", "running_mean", "running_var", "num_batches_tracked")]
+        "out_proj_b", "running_mean", "running_var", "num_batches_tracked")] + [("dropout", Dropout)]
 
 
 class Segments(ctypes.Structure):
@@ -45,7 +50,7 @@ class AttnSaved(ctypes.Structure):
 class JointTensors(ctypes.Structure):
     _fields_ = [(n, ctypes.c_void_p) for n in (
         "product_table", "enc_w", "enc_b", "dec_w", "dec_b", "typ_w", "typ_b", "itm_w", "itm_b",
-        "query_types", "comp_types")]
+        "query_types", "comp_types")] + [("dropout", Dropout)]
 
 
 class JointSaved(ctypes.Structure):
@@ -122,6 +127,7 @@ SIGNATURES = {
     "pc_scatter_add_rows_small": (_i, [_vp, _i, _vp, _i, _i, _vp, _vp]),
     "pc_scatter_rows": (_i, [_vp, _vp, _i, _i, _vp, _vp]),
     "pc_act_backward": (_i, [_vp, _vp, _sz, _i, _vp, _vp]),
+    "pc_dropout_hidden": (_i, [_vp, _sz, _P(Dropout), _vp, _vp]),
     "pc_check_indices": (_i, [_P(ctypes.c_void_p), _P(ctypes.c_int), _P(ctypes.c_int), _P(ctypes.c_int), _i, _vp, _vp]),
 }
 

@@ -178,6 +178,41 @@ __device__ __forceinline__ f32x16 mfma_bf16(const bf16x8& a, const bf16x8& b, f3
 }
 #endif
 
+// ---- training-mode dropout masks (pc_dropout in the header; restated for the tests by philox_oracle.dropout_mask)
+struct DropCfg {
+    unsigned thr;        // keep iff word >= thr; 0 = dropout off
+    float scale;         // fp32 1 / (1 - p)
+    unsigned k0, k1, c2, c3;
+};
+enum { PC_DROP_STREAM_ATTENTION = 0, PC_DROP_STREAM_HIDDEN = 1 };
+static inline DropCfg make_dropcfg(const pc_dropout& d) {
+    DropCfg c = {};
+    if (d.p > 0.f) {
+        double t = (double)d.p * 4294967296.0;
+        c.thr = t >= 4294967295.0 ? 4294967295u : (unsigned)t;
+        c.scale = 1.0f / (1.0f - d.p);
+        c.k0 = (unsigned)d.seed; c.k1 = (unsigned)(d.seed >> 32);
+        c.c2 = (unsigned)d.offset; c.c3 = (unsigned)(d.offset >> 32);
+    }
+    return c;
+}
+#ifdef __HIPCC__
+// the four multipliers (0 or scale) of elements 4 * group .. 4 * group + 3 of stream `stream`
+__device__ __forceinline__ void pc_dropout_keep4(const DropCfg& c, unsigned group, unsigned stream, float (&m)[4]) {
+    unsigned x0 = group, x1 = stream, x2 = c.c2, x3 = c.c3, k0 = c.k0, k1 = c.k1;
+#pragma unroll
+    for (int r = 0; r < 10; r++) {
+        const unsigned long long p0 = (unsigned long long)0xD2511F53u * x0, p1 = (unsigned long long)0xCD9E8D57u * x2;
+        const unsigned y0 = (unsigned)(p1 >> 32) ^ x1 ^ k0, y1 = (unsigned)p1;
+        const unsigned y2 = (unsigned)(p0 >> 32) ^ x3 ^ k1, y3 = (unsigned)p0;
+        x0 = y0; x1 = y1; x2 = y2; x3 = y3;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+    m[0] = x0 >= c.thr ? c.scale : 0.f; m[1] = x1 >= c.thr ? c.scale : 0.f;
+    m[2] = x2 >= c.thr ? c.scale : 0.f; m[3] = x3 >= c.thr ? c.scale : 0.f;
+}
+#endif
+
 // ---- optional per-launch timing (bench.py roofline leg): HIP events recorded on the launch
 // stream around every gemm_nt / gemm_tn launch of ONE C-ABI call.  The pointer is
 // thread-local and only set for the duration of that call (no persistent global state).

@@ -11,6 +11,7 @@
 #include "common.h"
 
 int launch_transpose(const float* in, int rows, int cols, float* out, hipStream_t st);
+int launch_dropout(const float* x, size_t n, const pc_dropout& d, unsigned stream_id, float* y, hipStream_t st);
 extern "C" int pc_scatter_add_rows_small(float* table, int table_rows, const int32_t* idx, int rows, int width,
                                          const float* src, void* stream);
 
@@ -515,6 +516,8 @@ static int joint_forward_impl(const pc_joint_tensors* p, const int32_t* query_id
     ip = nt_plain(p->product_table, PC_D, p->itm_w, PC_D, p->itm_b, sv->pi, PC_D, B, PC_D, PC_D);
     ip.gather = query_idx;
     PC_TRY(launch_gemm_nt_group(first, 2, st));
+    // h = dropout(h) in training mode        type_transition.py:17 (saved dropped: the decoder gradient needs it so)
+    if (p->dropout.p > 0.f) PC_TRY(launch_dropout(sv->h, (size_t)B * LH, p->dropout, PC_DROP_STREAM_HIDDEN, sv->h, st));
     // c = dec(h)                            type_transition.py:19
     PC_TRY(launch_gemm_nt(nt_plain(sv->h, LH, p->dec_w, LH, p->dec_b, sv->c, PC_L, B, PC_L, LH), st));
     // sims = c E_c^T                        p_companion.py:60-63
@@ -600,6 +603,8 @@ static int joint_backward_impl(const pc_joint_tensors* p, const pc_joint_tensors
     dh = nt_plain(w.dc, PC_L, w.dec_wt, PC_L, nullptr, w.dh, LH, B, LH, PC_L);
     dh.epilogue = NT_EPI_DRELU; dh.aux = sv->h; dh.ldaux = LH;
     PC_TRY(launch_gemm_nt_group(pair, 2, st));
+    // (the d-ReLU epilogue tested the saved, already dropped h: dropped units are 0 there; kept ones still need 1/(1-p))
+    if (p->dropout.p > 0.f) PC_TRY(launch_dropout(w.dh, (size_t)B * LH, p->dropout, PC_DROP_STREAM_HIDDEN, w.dh, st));
     if (tslab) PC_TRY(launch_scatter_add_slabs(topk, B * K, PC_L, T, w.dce, w.tslabs[0], st));
     else if (w.table_mode == 0) PC_TRY(pc_scatter_add_rows_small(g->comp_types, T, topk, B * K, PC_L, w.dce, stream));
     TnArgs& te = tn[3];

@@ -321,6 +321,29 @@ extern "C" int pc_act_backward(const float* dy, const float* y, size_t n, int ac
 }
 
 // ---------------------------------------------------------------------------------------
+// nn.Dropout (type_transition.py:13,17) on a flat fp32 tensor: y[e] = x[e] * m[e], m = the counter-based mask of
+// common.h (0 or 1/(1-p)).  Its own backward (dx = dy * m with the same seed / offset).  One 16-B group per thread.
+__global__ void dropout_kernel(const float* x, size_t n4, DropCfg drop, unsigned stream, float* y) {
+    const size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= n4) return;
+    float m[4];
+    pc_dropout_keep4(drop, (unsigned)g, stream, m);
+    const float4 v = *reinterpret_cast<const float4*>(x + 4 * g);
+    *reinterpret_cast<float4*>(y + 4 * g) = make_float4(v.x * m[0], v.y * m[1], v.z * m[2], v.w * m[3]);
+}
+
+int launch_dropout(const float* x, size_t n, const pc_dropout& d, unsigned stream_id, float* y, hipStream_t st) {
+    if (!x || !y || n == 0 || n % 4 || d.p <= 0.f || d.p >= 1.f) return PC_EINVAL;
+    PC_LAUNCH(dropout_kernel, dim3((unsigned)((n / 4 + 255) / 256)), dim3(256), 0, st, x, n / 4, make_dropcfg(d), stream_id, y);
+    return pc_launch_status();
+}
+
+extern "C" int pc_dropout_hidden(const float* x, size_t n, const pc_dropout* d, float* y, void* stream) {
+    if (!d) return PC_EINVAL;
+    return launch_dropout(x, n, *d, PC_DROP_STREAM_HIDDEN, y, (hipStream_t)stream);
+}
+
+// ---------------------------------------------------------------------------------------
 // Index validation (the reference's nn.Embedding / dict lookups raise IndexError / KeyError for an id outside the
 // table, p_companion.py:48-54): up to four index arrays against their table sizes in ONE launch; the number of bad
 // entries is ADDED to *bad (a device counter the caller reads when it chooses to synchronise).  Entries of -1 are

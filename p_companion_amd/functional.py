@@ -86,3 +86,21 @@ class _Hadamard(torch.autograd.Function):
 
 def hadamard(pi, tp, k):
     return _Hadamard.apply(pi, tp, k)
+
+
+class _DropoutHidden(torch.autograd.Function):
+    """nn.Dropout on the type-transition hidden layer (type_transition.py:17) with the build's counter-based mask;
+    the backward multiplies by the same mask (regenerated from seed / offset)."""
+
+    @staticmethod
+    def forward(ctx, x, dropout):
+        ctx.dropout = dropout
+        return ops.dropout_hidden(_c(x), dropout)
+
+    @staticmethod
+    def backward(ctx, dy):
+        return ops.dropout_hidden(dy.contiguous(), ctx.dropout), None
+
+
+def dropout_hidden(x, dropout):
+    return _DropoutHidden.apply(x, dropout)

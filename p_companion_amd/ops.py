@@ -97,7 +97,18 @@ def p2v_struct(tensors, with_buffers=True):
             if t is not None:
                 _req(t, torch.int64 if "num_batches" in key else torch.float32, key)
                 setattr(st, field, t.data_ptr())
+    _set_dropout(st, tensors.get(DROPOUT_KEY))
     return st, dev
+
+
+DROPOUT_KEY = "__dropout__"      # optional entry of a tensor dict: (p, seed, offset) of the module's training-mode dropout
+
+
+def _set_dropout(st, d):
+    if d is not None and float(d[0]) > 0.0:
+        if not 0.0 < float(d[0]) < 1.0:
+            raise ValueError(f"dropout probability has to be between 0 and 1, but got {d[0]}")
+        st.dropout.p, st.dropout.seed, st.dropout.offset = float(d[0]), int(d[1]), int(d[2])
 
 
 def _new_p2v_grads(device):
@@ -512,6 +523,7 @@ def joint_struct(tensors, table=None):
     if tbl is not None:
         _req(tbl, torch.float32, "product_embeddings.weight")
         st.product_table = tbl.data_ptr()
+    _set_dropout(st, tensors.get(DROPOUT_KEY))
     return st, dev
 
 
@@ -701,6 +713,18 @@ def act_backward(dy, y, act):
     dx = torch.empty_like(dy)
     check(_lib.lib().pc_act_backward(_p(dy), _p(y), dy.numel(), act, _p(dx), _stream()), "pc_act_backward")
     return dx
+
+
+def dropout_hidden(x, dropout):
+    """x * mask for the type-transition hidden layer (pc_dropout_hidden); dropout = (p, seed, offset)."""
+    _req(x, torch.float32, "x")
+    d = _lib.Dropout()
+    d.p, d.seed, d.offset = float(dropout[0]), int(dropout[1]), int(dropout[2])
+    if not 0.0 < d.p < 1.0:
+        raise ValueError(f"dropout probability has to be between 0 and 1, but got {dropout[0]}")
+    y = torch.empty_like(x)
+    check(_lib.lib().pc_dropout_hidden(_p(x), x.numel(), ctypes.byref(d), _p(y), _stream()), "pc_dropout_hidden")
+    return y
 
 
 def check_indices(jobs, bad):

@@ -48,11 +48,11 @@ class _LazyJointForward(torch.autograd.Function):
     per-op autograd graph of the same forward and differentiates that -- same gradients, paid only when used."""
 
     @staticmethod
-    def forward(ctx, module, query_idx, query_types, k, *weights):
-        params = module._tensor_dict()
+    def forward(ctx, module, query_idx, query_types, k, dropout, *weights):
+        params = module._tensor_dict(dropout)
         params["product_embeddings.weight"] = module.product_embeddings.weight
         sims, topk, proj, _ = ops.joint_forward(params, query_idx, query_types, k)
-        ctx.module, ctx.args = module, (query_idx, query_types, k)
+        ctx.module, ctx.args = module, (query_idx, query_types, k, dropout)
         ctx.nw = len(weights)
         ctx.mark_non_differentiable(topk)
         return sims, topk, proj
@@ -68,7 +68,7 @@ class _LazyJointForward(torch.autograd.Function):
                 if g is not None:
                     outs.append(o); gouts.append(g.contiguous())
             grads = torch.autograd.grad(outs, weights, gouts, allow_unused=True)
-        return (None, None, None, None) + tuple(grads)
+        return (None, None, None, None, None) + tuple(grads)
 
 
 class _FusedJointLoss(torch.autograd.Function):
@@ -78,10 +78,10 @@ class _FusedJointLoss(torch.autograd.Function):
     the per-op graph.  The parameter gradients are formed here and handed to autograd in backward."""
 
     @staticmethod
-    def forward(ctx, module, query_idx, query_types, pos_types, neg_types, pos_items, neg_items, *weights):
+    def forward(ctx, module, query_idx, query_types, pos_types, neg_types, pos_items, neg_items, dropout, *weights):
         names = [k for k, p in module.named_parameters() if p.requires_grad]
         grads = {k: torch.empty_like(w) for k, w in zip(names, weights)}
-        params = module._tensor_dict()
+        params = module._tensor_dict(dropout)
         params["product_embeddings.weight"] = module.product_embeddings.weight
         losses, _ = ops.joint_train_step(params, grads, query_idx, query_types, pos_types, neg_types, pos_items, neg_items,
                                          int(module.config.NUM_COMP_TYPES), float(module.config.MARGIN),
@@ -91,7 +91,7 @@ class _FusedJointLoss(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, g):
-        return (None,) * 7 + tuple(torch._foreach_mul(ctx.grads, g))      # one multi-tensor launch
+        return (None,) * 8 + tuple(torch._foreach_mul(ctx.grads, g))      # one multi-tensor launch
 
 
 class PCompanion(nn.Module, _FlatParamsMixin):
@@ -126,16 +126,19 @@ class PCompanion(nn.Module, _FlatParamsMixin):
         return torch.tensor([self.product_to_idx[pid] for pid in batch["query_ids"]],      # KeyError as :48
                             dtype=torch.int32).to(device)
 
-    def _tensor_dict(self):
-        return dict(self.named_parameters())
+    def _tensor_dict(self, dropout=None):
+        d = dict(self.named_parameters())
+        if dropout is not None:
+            d[ops.DROPOUT_KEY] = dropout
+        return d
+
+    def _next_dropout(self):
+        """(p, seed, offset) of this training-mode forward's hidden-layer dropout (type_transition.py:13,17), None = off."""
+        return self.type_transition._next_dropout() if self.training else None
 
     @staticmethod
     def _i32(t):
         return t.reshape(-1).to(torch.int32).contiguous()
-
-    def _check(self):
-        if self.training and float(self.config.DROPOUT) != 0.0:
-            raise NotImplementedError("DROPOUT != 0 is not implemented in the HIP path; set config.DROPOUT = 0")
 
     # ------------------------------------------------------------------ index validation
     def _validate(self, *jobs):
@@ -167,7 +170,6 @@ class PCompanion(nn.Module, _FlatParamsMixin):
 
     # ------------------------------------------------------------------ reference surface
     def forward(self, batch):
-        self._check()
         dev = self.query_type_embeddings.weight.device
         k = int(self.config.NUM_COMP_TYPES)
         query_indices = self._query_indices(batch, dev)
@@ -175,24 +177,26 @@ class PCompanion(nn.Module, _FlatParamsMixin):
         self._validate((query_indices, self.product_embeddings.weight.shape[0]),
                        (query_types, self.query_type_embeddings.weight.shape[0]))
         if not (torch.is_grad_enabled() and self.training):
-            sims, topk, proj, _ = ops.joint_forward(self._tensor_dict(), query_indices, query_types, k)
+            sims, topk, proj, _ = ops.joint_forward(self._tensor_dict(self._next_dropout()), query_indices, query_types, k)
             return {"projected_embeddings": proj, "complementary_types": topk.long(), "type_similarities": sims}
 
         self._pending = None
         weights = [p for p in self.parameters() if p.requires_grad]
-        similarities, top_k, projected_embeddings = _LazyJointForward.apply(self, query_indices, query_types, k, *weights)
+        dropout = self._next_dropout()
+        similarities, top_k, projected_embeddings = _LazyJointForward.apply(self, query_indices, query_types, k, dropout, *weights)
         outputs = {"projected_embeddings": projected_embeddings, "complementary_types": top_k.long(),
                    "type_similarities": similarities}
         # remembered so that compute_loss(batch, outputs) on exactly this pair can take the fused step
         self._pending = (outputs, projected_embeddings, similarities, query_indices, query_types,
-                         tuple(p._version for p in self.parameters()))
+                         tuple(p._version for p in self.parameters()), dropout)
         return outputs
 
-    def _forward_graph(self, query_indices, query_types, k):
-        """p_companion.py:45-77 op by op through the autograd Functions (what _LazyJointForward differentiates)."""
+    def _forward_graph(self, query_indices, query_types, k, dropout=None):
+        """p_companion.py:45-77 op by op through the autograd Functions (what _LazyJointForward differentiates);
+        `dropout`: the (p, seed, offset) the fused forward used, so both see the same hidden-layer mask."""
         query_embeddings = embedding(self.product_embeddings.weight, query_indices)
         query_type_emb = embedding(self.query_type_embeddings.weight, query_types)
-        comp_base = self.type_transition(query_type_emb)
+        comp_base = self.type_transition(query_type_emb, _dropout=dropout)
         similarities = linear(comp_base, self.complementary_type_embeddings.weight)       # c . E_c^T
         top_k = ops.topk_rows(similarities.detach(), k)                                     # indices: no gradient
         comp_type_embeddings = embedding(self.complementary_type_embeddings.weight, top_k)
@@ -228,7 +232,7 @@ class PCompanion(nn.Module, _FlatParamsMixin):
             return _FusedJointLoss.apply(
                 self, pend[3], pend[4], pt, nt,
                 batch["positive_items"].to(dev).float().contiguous(), batch["negative_items"].to(dev).float().contiguous(),
-                *weights)
+                pend[6], *weights)
         return self._loss(batch, outputs, 0)
 
     def _compute_type_loss(self, type_similarities, positive_types, negative_types):
@@ -250,10 +254,9 @@ class PCompanion(nn.Module, _FlatParamsMixin):
     def train_step(self, batch):
         """train.py:42-46 (forward, compute_loss, zero_grad, backward) as one C-ABI call.
         Returns (losses[3] = total/type/item on the device, complementary_types[B,K])."""
-        self._check()
         self.flatten_parameters()
         dev = self.query_type_embeddings.weight.device
-        params = self._tensor_dict()
+        params = self._tensor_dict(self._next_dropout())
         params["product_embeddings.weight"] = self.product_embeddings.weight
         grads = {k: p.grad for k, p in self.named_parameters() if p.grad is not None}
         qi, qt = self._query_indices(batch, dev), self._i32(batch["query_types"].to(dev))

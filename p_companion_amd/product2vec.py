@@ -53,7 +53,8 @@ class _AttentionFunction(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, module, query, keys, *weights):
-        params = module._tensor_dict()
+        ctx.dropout = module._next_dropout()                 # one fresh mask per forward; the backward regenerates it
+        params = module._tensor_dict(ctx.dropout)
         out, sv = ops.attention_forward(params, query, keys)
         ctx.module, ctx.sv = module, sv
         ctx.save_for_backward(query, keys)
@@ -62,7 +63,7 @@ class _AttentionFunction(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dout):
         query, keys = ctx.saved_tensors
-        params = ctx.module._tensor_dict()
+        params = ctx.module._tensor_dict(ctx.dropout)
         grads, dq, dk = ops.attention_backward(params, query, keys, dout.contiguous(), ctx.sv)
         return (None, dq, dk) + tuple(grads[k] for k in _ATT_KEYS)
 
@@ -130,7 +131,7 @@ class _FusedDenseLoss(torch.autograd.Function):
             module._dense_idx[key] = idx
         names = [nm for nm, _ in module.named_parameters()]
         grads = {nm: torch.empty_like(w) for nm, w in zip(names, weights)}
-        out = ops.p2v_train_step(module._tensor_dict(), grads, table, idx[0], idx[1], idx[2], idx[3],
+        out = ops.p2v_train_step(module._tensor_dict(module._next_dropout()), grads, table, idx[0], idx[1], idx[2], idx[3],
                                  float(module.config.MARGIN))
         ctx.grads = [grads[nm] for nm in names]
         return out["loss"].reshape(())
@@ -298,23 +299,34 @@ class Product2Vec(nn.Module, _FlatParamsMixin):
                                                num_heads=config.NUM_ATTENTION_HEADS,
                                                dropout=config.DROPOUT, batch_first=True)
         self.last_embedding_table = None
+        self._dropout_seed, self._dropout_step = None, 0
         self._dense_idx = {}                      # identity index arrays of the fused dense-batch step, by (B, N, K)
 
     # ------------------------------------------------------------------ plumbing
-    def _tensor_dict(self):
+    def _tensor_dict(self, dropout=None):
         d = dict(self.named_parameters())
         d.update(dict(self.named_buffers()))
+        if dropout is not None:
+            d[ops.DROPOUT_KEY] = dropout
         return d
+
+    def _next_dropout(self):
+        """(p, seed, offset) of the attention-weight dropout of this training-mode forward
+        (nn.MultiheadAttention(dropout=config.DROPOUT), product2vec.py:23-28), None when it is off.  The masks are the
+        build's own counter-based stream (include/pcompanion_hip.h pc_dropout) -- ATen's cannot be reproduced, so a
+        run with DROPOUT > 0 matches the reference in distribution, not bit for bit; the seed is drawn once from
+        torch's generator (torch.manual_seed makes runs repeatable), the offset counts forwards."""
+        p = float(getattr(self.config, "DROPOUT", 0.0))
+        if not self.training or p == 0.0:
+            return None
+        if self._dropout_seed is None:
+            self._dropout_seed = int(torch.randint(0, 2 ** 62, (1,)).item())
+        self._dropout_step += 1
+        return (p, self._dropout_seed, self._dropout_step - 1)
 
     def _weights(self, keys):
         d = dict(self.named_parameters())
         return tuple(d[k] for k in keys)
-
-    def _check_dropout(self):
-        if self.training and float(getattr(self.config, "DROPOUT", 0.0)) != 0.0:
-            raise NotImplementedError(
-                "attention-weight dropout (config.DROPOUT != 0) is not implemented in the HIP path; "
-                "set DROPOUT = 0 (ATen's dropout RNG stream cannot be reproduced, SURVEY section 7)")
 
     @staticmethod
     def _dev(t):
@@ -358,14 +370,13 @@ class Product2Vec(nn.Module, _FlatParamsMixin):
         if query.size(1) != 1:
             raise ValueError("the HIP attention kernel handles one query token per sample "
                              "(the only use in product2vec.py:70-81)")
-        self._check_dropout()
         q2 = self._dev(query[:, 0, :])
         kv = self._dev(key_value)
         if torch.is_grad_enabled() and self.training:
             out = _AttentionFunction.apply(self, q2, kv, *self._weights(_ATT_KEYS))
         else:
             with torch.no_grad():
-                out, _ = ops.attention_forward(self._tensor_dict(), q2, kv)
+                out, _ = ops.attention_forward(self._tensor_dict(self._next_dropout()), q2, kv)   # (dropout off in eval)
             if not self.training:
                 out = _guard_eval(out, "Product2Vec.apply_attention", [q2, kv] + list(self._weights(_ATT_KEYS)))
         out = out.unsqueeze(1)
@@ -447,9 +458,8 @@ class Product2Vec(nn.Module, _FlatParamsMixin):
         """One loop-body iteration (product2vec.py:130-158 minus optimizer.step) on an index
         batch.  Gradients land in .grad (flat-buffer views); returns the device loss tensor.
         sync_reduce: see ops.p2v_train_step (cross-replica BatchNorm statistics for data-parallel runs)."""
-        self._check_dropout()
         self.flatten_parameters()
-        params = self._tensor_dict()
+        params = self._tensor_dict(self._next_dropout())
         grads = {k: p.grad for k, p in self.named_parameters()}
         nbr = batch.get("neighbor_compact", batch.get("neighbor_idx"))      # compact rows when the loader built them
         out = ops.p2v_train_step(params, grads, table, batch["anchor_idx"], batch["positive_idx"],
@@ -501,7 +511,6 @@ class Product2Vec(nn.Module, _FlatParamsMixin):
                 and not any(t.requires_grad for t in (a, p, n, nb))):
             # training on device batches: the fused step (same numbers as the four module calls below, one launch
             # sequence instead of four forward + four backward ones)
-            self._check_dropout()
             dev = self.ffn[0].weight.device
             f = lambda t: t.to(device=dev, dtype=torch.float32).contiguous()
             return _FusedDenseLoss.apply(self, f(a), f(p), f(n), f(nb), *[w for _, w in self.named_parameters()])
