@@ -391,6 +391,31 @@ int pc_joint_train_step(const pc_joint_tensors *p, const pc_joint_tensors *g,
                         int num_types, int k, float margin, float alpha, float *losses,
                         int32_t *topk, void *ws, size_t ws_bytes, void *stream);
 
+/* J8 loop body, FUSED (train.py:42-48: forward, compute_loss, zero_grad, backward and -- optionally --
+ * optimizer.step as THREE launches): one kernel over 16-sample tiles computes the whole per-sample part (row gathers,
+ * type transition with dropout, similarities + top-K, item projection, both hinges, the dX chain), one grouped
+ * rows^T x rows launch forms the gradient slabs of the four Linears and of both [T,64] tables (one-hot products; the
+ * type hinge's two dE_c rows per sample ride in the same product: no float atomics, bitwise reproducible), one kernel
+ * sums the slabs in fixed order into g, forms losses[3] = {loss, type, item} and, when exp_avg / exp_avg_sq are given,
+ * applies torch.optim.Adam's update (defaults of train.py:24) to p in the same pass (*step_count is advanced by one).
+ * exp_avg == NULL: gradients only (a data-parallel caller all-reduces g, then pc_adam_step).
+ * T <= 512: as above.  T > 512 (config.py:27 NUM_TYPES = 34800): the similarity row and its top-K are formed once per
+ * DISTINCT query type of the batch (it is a function of the type alone), the [B,T] matrix never exists; the table
+ * gradients use float atomics into the cleared dense g (not bitwise reproducible); needs dropout p == 0.
+ * Ids outside their tables (query_idx vs num_products, the three type arrays vs num_types) are clamped, counted into
+ * *bad_count (may be NULL) and never dereferenced out of bounds -- the reference raises at the lookup
+ * (p_companion.py:48-54), the caller raises when it reads the counter.
+ * pc_joint_fused_supported: 1 iff (num_types, k, dropout p) is served (k <= 4; see above), else use pc_joint_train_step. */
+size_t pc_joint_fused_workspace_bytes(int batch, int num_types, int k);
+int pc_joint_fused_supported(int num_types, int k, float dropout_p);
+int pc_joint_fused_step(const pc_joint_tensors *p, const pc_joint_tensors *g, const pc_joint_tensors *exp_avg,
+                        const pc_joint_tensors *exp_avg_sq, int64_t *step_count, double lr, double beta1,
+                        double beta2, double eps, const int32_t *query_idx, const int32_t *query_types,
+                        const int32_t *pos_types, const int32_t *neg_types, const float *pos_items,
+                        const float *neg_items, int batch, int num_types, int k, int num_products, float margin,
+                        float alpha, float *losses, int32_t *topk, int32_t *bad_count, void *ws, size_t ws_bytes,
+                        void *stream);
+
 /* ---------------------------------------------------------------------------------
  * Building blocks the Python modules compose their autograd from (module / dense mode).
  * --------------------------------------------------------------------------------- */

@@ -112,6 +112,10 @@ SIGNATURES = {
                                _P(JointSaved), _vp, _sz, _vp]),
     "pc_joint_train_step": (_i, [_P(JointTensors), _P(JointTensors), _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _f,
                                  _f, _vp, _vp, _vp, _sz, _vp]),
+    "pc_joint_fused_workspace_bytes": (_sz, [_i, _i, _i]),
+    "pc_joint_fused_supported": (_i, [_i, _i, _f]),
+    "pc_joint_fused_step": (_i, [_P(JointTensors), _P(JointTensors), _P(JointTensors), _P(JointTensors), _vp, _d, _d, _d, _d,
+                                 _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _f, _vp, _vp, _vp, _vp, _sz, _vp]),
     "pc_linear_forward": (_i, [_vp, _vp, _i, _i, _vp, _vp, _i, _i, _vp, _vp]),
     "pc_linear_backward_input": (_i, [_vp, _i, _i, _vp, _i, _i, _vp, _vp, _vp, _vp]),
     "pc_linear_backward_weight_workspace_bytes": (_sz, [_i, _i, _i]),

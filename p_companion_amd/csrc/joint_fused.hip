@@ -1,0 +1,895 @@
+// P-Companion joint step, fused (train.py:42-48): the whole per-sample part of
+// PCompanion.forward + compute_loss + backward (p_companion.py:45-119, type_transition.py:15-20,
+// item_prediction.py:22-40) is ONE kernel over 16-sample tiles; the weight / table gradients are one grouped
+// "rows^T x rows" launch over the row buffers that kernel leaves behind; one more kernel sums their slabs in fixed
+// order, forms the losses and (optionally) applies Adam.  Three launches per step instead of ~20 dependent few-us
+// ones (the step moves ~11 MB: it is bound by kernel boundaries and ramps, not by bandwidth).
+//
+//   joint_tile_kernel   per 16-sample tile, 4 waves, every activation in LDS, weights streamed from L2:
+//       t = E_q[qt], q = E_prod[qi]                                   (row gathers, p_companion.py:51,54)
+//       h = dropout(relu(enc t)), c = dec h                           (type_transition.py:17-19)
+//       sims = c E_c^T, top-K (ties -> lower index), e_k = E_c[top_k] (p_companion.py:60-65)
+//       pi = itm q, tp_k = typ e_k, proj_k = pi * tp_k                (item_prediction.py:31-38)
+//       both hinges and their gradients w.r.t. proj and the two touched similarity columns (p_companion.py:95-119)
+//       dpi, dtp_k, dce_k = dtp_k typ_w, dc, dh = (dc dec_w) relu' dropout', dt = dh enc_w    (the whole dX chain)
+//     products on v_mfma_f32_16x16x4_f32 (exact fp32 fma chains: 16-row tiles fill 256 workgroups at B = 4096)
+//   gemm_tn_group       d itm_w, d typ_w, d dec_w, d enc_w (+ biases) and both [T,64] table gradients as one-hot
+//                       products -- the type hinge's dE_c rows ride in the same product (no float atomics anywhere:
+//                       the step is bitwise reproducible for T <= 512)
+//   joint_finish_kernel slab sums (fixed order) -> .grad, losses, Adam
+// Large tables (T > 512, e.g. config.py:27 NUM_TYPES = 34800): the similarity row depends on the query TYPE only, so
+// it is formed once per distinct query type of the batch (present-type list, sims + per-chunk top-K in one kernel's
+// epilogue, merge) instead of per sample, the [B,T] matrix never exists, and the table gradients fall back to
+// hardware float atomics into the cleared dense gradient (row lists of B*(K+2) + B rows).
+#include "common.h"
+
+#define LH (PC_L / 2)
+#define FK 4          /* top-K capacity of the fused kernel (NUM_COMP_TYPES = 3, config.py:24) */
+#define TS 16         /* samples per tile */
+#define T_SMALL 512   /* largest table the per-tile similarity row (LDS) and the one-hot gradients serve */
+
+typedef float f32x4v __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ f32x4v mfma16(float a, float b, f32x4v c) {
+    return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+}
+
+static inline size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
+
+// ---- 16 x 16 output blocks on v_mfma_f32_16x16x4_f32 ----------------------------------------------------------
+// A operand: LDS rows (row stride lda floats), B operand: global weights.  k runs in chunks of 16; inside a chunk
+// lane (i = lane & 15, h = lane >> 4) owns k = 16 c + 4 h + q, q = 0..3, for BOTH operands (a sum over k does not
+// care about the order, so one 16-B read feeds four MFMAs).  MB row blocks share one B fragment set.
+// NT: B[k][j] = W[(n0 + j) * ldw + k]   (y = x W^T, nn.Linear forward)
+// NN: B[k][j] = W[k * ldw + n0 + j]     (dx = dy W)
+template <int K, int MB, bool NN>
+__device__ __forceinline__ void block_product(const float* As, int lda, int mblocks, const float* W, int ldw, int n0,
+                                              int nvalid, f32x4v (&acc)[MB], int lane) {
+    const int i = lane & 15, h = lane >> 4;
+    constexpr int NC = K / 16;
+    float4 b4[NC];
+    if (NN) {
+#pragma unroll
+        for (int c = 0; c < NC; c++) {
+            const float* w = W + (size_t)(16 * c + 4 * h) * ldw + n0 + i;
+            const bool v = n0 + i < nvalid;
+            b4[c] = v ? make_float4(w[0], w[ldw], w[2 * ldw], w[3 * ldw]) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    } else {
+        const bool v = n0 + i < nvalid;
+        const float* w = W + (size_t)(v ? n0 + i : 0) * ldw + 4 * h;
+#pragma unroll
+        for (int c = 0; c < NC; c++)
+            b4[c] = v ? *reinterpret_cast<const float4*>(w + 16 * c) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+#pragma unroll
+    for (int m = 0; m < MB; m++) {
+        if (m < mblocks) {
+            const float* a = As + (size_t)(16 * m + i) * lda + 4 * h;
+#pragma unroll
+            for (int c = 0; c < NC; c++) {
+                const float4 a4 = *reinterpret_cast<const float4*>(a + 16 * c);
+                acc[m] = mfma16(a4.x, b4[c].x, acc[m]);
+                acc[m] = mfma16(a4.y, b4[c].y, acc[m]);
+                acc[m] = mfma16(a4.z, b4[c].z, acc[m]);
+                acc[m] = mfma16(a4.w, b4[c].w, acc[m]);
+            }
+        }
+    }
+}
+// result element (block m, register r) of lane: row 16 m + 4 (lane >> 4) + r, column n0 + (lane & 15)
+
+struct FusedArgs {
+    const float *table, *enc_w, *enc_b, *dec_w, *dec_b, *typ_w, *typ_b, *itm_w, *itm_b, *eq, *ec;
+    const int32_t *query_idx, *query_types, *pos_types, *neg_types;
+    const float *pos_items, *neg_items;
+    int B, T, K, P;
+    float margin, g_type, g_item;        // g_type = (1 - alpha) / B, g_item = alpha / (B K): the means' constants
+    DropCfg drop;
+    // regime L (T > T_SMALL): top-K per query TYPE, computed beforehand
+    const int32_t* topk_by_type;
+    // outputs
+    int32_t* topk;                        // [B,K]
+    float *part_type, *part_item;         // [B] hinge values (summed by the finish kernel)
+    float *h, *dpi, *dtp, *dc, *dh, *dt;  // row buffers for the gradient products
+    float* ecsrc; int32_t* ecidx;         // [B (K + 2)][64] / [B (K + 2)]: rows added into dE_c[ecidx[r]]
+    int32_t* bad; int64_t* step_count;
+};
+
+// top-K of one LDS row by one wave (ties -> the lower index, like torch.topk / pc_topk_rows)
+__device__ __forceinline__ void wave_topk(const float* row, int T, int K, int lane, int* out_idx) {
+    float v[FK];
+    int ix[FK];
+#pragma unroll
+    for (int j = 0; j < FK; j++) { v[j] = -INFINITY; ix[j] = 0x7fffffff; }
+    for (int t = lane; t < T; t += 64) {
+        float x = row[t];
+        int xi = t;
+#pragma unroll
+        for (int j = 0; j < FK; j++) {
+            if (j < K) {
+                const bool better = x > v[j] || ix[j] == 0x7fffffff;
+                const float tv = better ? v[j] : x;
+                const int ti = better ? ix[j] : xi;
+                v[j] = better ? x : v[j];
+                ix[j] = better ? xi : ix[j];
+                x = tv; xi = ti;
+            }
+        }
+    }
+    for (int r = 0; r < K; r++) {
+        float bv = v[0];
+        int bi = ix[0];
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) {
+            const float ov = __shfl_xor(bv, o, 64);
+            const int oi = __shfl_xor(bi, o, 64);
+            if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
+        }
+        if (ix[0] == bi) {
+#pragma unroll
+            for (int j = 0; j < FK - 1; j++) { v[j] = v[j + 1]; ix[j] = ix[j + 1]; }
+            v[FK - 1] = -INFINITY; ix[FK - 1] = 0x7fffffff;
+        }
+        out_idx[r] = bi;
+    }
+}
+
+#define LD64 68       /* LDS row strides: row length + 4 floats (16-B reads of 16 rows spread over the banks) */
+#define LD32 36
+#define LD128 132
+
+// SIMS_LOCAL: the similarity row and its top-K are computed here (T <= T_SMALL); else read per query type
+template <bool SIMS_LOCAL>
+__global__ __launch_bounds__(256) void joint_tile_kernel(FusedArgs a, int ldsims) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    float* Tin = sm;                       // [16][LD64]   E_q rows
+    float* Hs = Tin + TS * LD64;           // [16][LD32]   hidden (dropped)
+    float* Cs = Hs + TS * LD32;            // [16][LD64]   complementary base
+    float* Qs = Cs + TS * LD64;            // [16][LD128]  product rows
+    float* PIs = Qs + TS * LD128;          // [16][LD128]  item projection -> d(pi)
+    float* ECs = PIs + TS * LD128;         // [16 FK][LD64] selected E_c rows
+    float* TPs = ECs + TS * FK * LD64;     // [16 FK][LD128] type projection -> d(tp)
+    float* DCs = TPs + TS * FK * LD128;    // [16][LD64]
+    float* DHs = DCs + TS * LD64;          // [16][LD32]
+    int* ints = reinterpret_cast<int*>(DHs + TS * LD32);      // [16][8]: qi, qt, pos, neg, topk[4]
+    float* Sims = reinterpret_cast<float*>(ints + TS * 8);    // [16][ldsims]   (SIMS_LOCAL only)
+
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int b0 = blockIdx.x * TS;
+    const int K = a.K;
+    if (blockIdx.x == 0 && tid == 0 && a.step_count) *a.step_count += 1;     // Adam's step (read by the finish kernel)
+
+    // ---- indices of the tile: validated (the reference raises for an id outside its table, p_companion.py:48-54; here
+    // the offence is counted and the id clamped so that nothing is read or written out of bounds)
+    if (tid < TS) {
+        const int b = b0 + tid;
+        int qi = 0, qt = 0, pt = 0, nt = 0, wrong = 0;
+        if (b < a.B) {
+            qi = a.query_idx[b]; qt = a.query_types[b]; pt = a.pos_types[b]; nt = a.neg_types[b];
+            if ((unsigned)qi >= (unsigned)a.P) { wrong++; qi = 0; }
+            if ((unsigned)qt >= (unsigned)a.T) { wrong++; qt = 0; }
+            if ((unsigned)pt >= (unsigned)a.T) { wrong++; pt = 0; }
+            if ((unsigned)nt >= (unsigned)a.T) { wrong++; nt = 0; }
+            if (wrong && a.bad) atomicAdd(a.bad, wrong);
+        }
+        ints[tid * 8 + 0] = qi; ints[tid * 8 + 1] = qt; ints[tid * 8 + 2] = pt; ints[tid * 8 + 3] = nt;
+    }
+    __syncthreads();
+    // ---- row gathers: t = E_q[qt] (16 x 64), q = E_prod[qi] (16 x 128); rows past the batch are zero
+    {
+        const int r = tid >> 4, c4 = (tid & 15) * 4;
+        const bool live = b0 + r < a.B;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (live) v = *reinterpret_cast<const float4*>(a.eq + (size_t)ints[r * 8 + 1] * PC_L + c4);
+        *reinterpret_cast<float4*>(&Tin[r * LD64 + c4]) = v;
+#pragma unroll
+        for (int u = 0; u < 2; u++) {
+            const int e = tid + 256 * u, rr = e >> 5, cc = (e & 31) * 4;
+            float4 x = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (b0 + rr < a.B) x = *reinterpret_cast<const float4*>(a.table + (size_t)ints[rr * 8 + 0] * PC_D + cc);
+            *reinterpret_cast<float4*>(&Qs[rr * LD128 + cc]) = x;
+        }
+    }
+    __syncthreads();
+
+    const int ci = lane & 15, rh = lane >> 4;       // result column inside a block / row group
+    // ---- phase A: h = dropout(relu(enc t + b))  (waves 0, 1: one 16-column block each)   ||   pi blocks 0..3 (waves 2, 3)
+    if (w < 2) {
+        f32x4v acc[1] = {{0.f, 0.f, 0.f, 0.f}};
+        block_product<PC_L, 1, false>(Tin, LD64, 1, a.enc_w, PC_L, 16 * w, LH, acc, lane);
+        const int col = 16 * w + ci;
+        const float bias = a.enc_b[col];
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            const int row = 4 * rh + r;
+            float x = acc[0][r] + bias;
+            x = x > 0.f ? x : 0.f;
+            if (a.drop.thr) {
+                float m[4];
+                pc_dropout_keep4(a.drop, (unsigned)((b0 + row) * (LH / 4) + (col >> 2)), PC_DROP_STREAM_HIDDEN, m);
+                x *= m[col & 3];
+            }
+            Hs[row * LD32 + col] = x;
+            if (b0 + row < a.B) a.h[(size_t)(b0 + row) * LH + col] = x;
+        }
+    }
+    // pi = itm q + b: 8 column blocks; waves 2, 3 take two each now, the remaining four follow in phase B
+    auto pi_block = [&](int nb) {
+        f32x4v acc[1] = {{0.f, 0.f, 0.f, 0.f}};
+        block_product<PC_D, 1, false>(Qs, LD128, 1, a.itm_w, PC_D, 16 * nb, PC_D, acc, lane);
+        const int col = 16 * nb + ci;
+        const float bias = a.itm_b[col];
+#pragma unroll
+        for (int r = 0; r < 4; r++) PIs[(4 * rh + r) * LD128 + col] = acc[0][r] + bias;
+    };
+    if (w >= 2) { pi_block(2 * (w - 2)); pi_block(2 * (w - 2) + 1); }
+    __syncthreads();
+    // ---- phase B: c = dec h + b (4 blocks, one per wave), then pi blocks 4..7
+    {
+        f32x4v acc[1] = {{0.f, 0.f, 0.f, 0.f}};
+        block_product<LH, 1, false>(Hs, LD32, 1, a.dec_w, LH, 16 * w, PC_L, acc, lane);
+        const int col = 16 * w + ci;
+        const float bias = a.dec_b[col];
+#pragma unroll
+        for (int r = 0; r < 4; r++) Cs[(4 * rh + r) * LD64 + col] = acc[0][r] + bias;
+        pi_block(4 + w);
+    }
+    __syncthreads();
+    // ---- phase C / D: similarities over all T types and their top-K -- or the per-type result of the dedup pass
+    if (SIMS_LOCAL) {
+        const int nblk = (a.T + 15) >> 4;
+        for (int nb = w; nb < nblk; nb += 4) {
+            f32x4v acc[1] = {{0.f, 0.f, 0.f, 0.f}};
+            block_product<PC_L, 1, false>(Cs, LD64, 1, a.ec, PC_L, 16 * nb, a.T, acc, lane);
+#pragma unroll
+            for (int r = 0; r < 4; r++) Sims[(4 * rh + r) * ldsims + 16 * nb + ci] = acc[0][r];
+        }
+        __syncthreads();
+        for (int s = w; s < TS; s += 4) {
+            int idx[FK];
+            wave_topk(Sims + s * ldsims, a.T, K, lane, idx);
+            if (lane == 0)
+                for (int k = 0; k < K; k++) ints[s * 8 + 4 + k] = idx[k];
+        }
+    } else {
+        if (tid < TS * FK) {
+            const int s = tid / FK, k = tid % FK;
+            if (k < K) ints[s * 8 + 4 + k] = b0 + s < a.B ? a.topk_by_type[(size_t)ints[s * 8 + 1] * K + k] : 0;
+        }
+    }
+    __syncthreads();
+    // selected rows e_k = E_c[top_k]: 16 K rows of 64 floats, row index s * FK + k (blocks of 16 rows = 4 samples x FK...
+    // the MFMA row blocks below are over ROW ids, any assignment works: row = k * 16 + s keeps one block per k)
+    for (int e = tid; e < TS * K * 16; e += 256) {
+        const int row = e >> 4, c4 = (e & 15) * 4;        // row = k * 16 + s
+        const int s = row & 15, k = row >> 4;
+        const int t = ints[s * 8 + 4 + k];
+        *reinterpret_cast<float4*>(&ECs[row * LD64 + c4]) = *reinterpret_cast<const float4*>(a.ec + (size_t)t * PC_L + c4);
+        if (c4 == 0 && b0 + s < a.B) {
+            a.topk[(size_t)(b0 + s) * K + k] = t;
+            a.ecidx[(size_t)(b0 + s) * K + k] = t;
+        }
+    }
+    __syncthreads();
+    // ---- phase E: tp_k = typ e_k + b: K row blocks x 8 column blocks; a wave takes column blocks w and w + 4
+#pragma unroll
+    for (int u = 0; u < 2; u++) {
+        const int nb = w + 4 * u;
+        f32x4v acc[FK];
+#pragma unroll
+        for (int m = 0; m < FK; m++) acc[m] = f32x4v{0.f, 0.f, 0.f, 0.f};
+        block_product<PC_L, FK, false>(ECs, LD64, K, a.typ_w, PC_L, 16 * nb, PC_D, acc, lane);
+        const int col = 16 * nb + ci;
+        const float bias = a.typ_b[col];
+#pragma unroll
+        for (int m = 0; m < FK; m++)
+            if (m < K)
+#pragma unroll
+                for (int r = 0; r < 4; r++) TPs[(16 * m + 4 * rh + r) * LD128 + col] = acc[m][r] + bias;
+    }
+    __syncthreads();
+    // ---- phase F: per sample (one wave, lane = dims 2 lane, 2 lane + 1): proj_k = pi * tp_k, both hinges, d(proj) -> d(pi),
+    // d(tp_k) (in place), the two-column type hinge -> dc and the two dE_c rows it touches
+    for (int s = w; s < TS; s += 4) {
+        const int b = b0 + s;
+        if (b >= a.B) {                                            // dead row of the last tile: zero operands downstream
+            for (int k = 0; k < K; k++) *reinterpret_cast<float2*>(&TPs[(16 * k + s) * LD128 + 2 * lane]) = make_float2(0.f, 0.f);
+            DCs[s * LD64 + lane] = 0.f;
+            continue;
+        }
+        const int pt = ints[s * 8 + 2], nt = ints[s * 8 + 3];
+        const float cb = Cs[s * LD64 + lane];
+        float sp = 0.f, sn = 0.f;
+        if (SIMS_LOCAL) { sp = Sims[s * ldsims + pt]; sn = Sims[s * ldsims + nt]; }
+        const float ep = a.ec[(size_t)pt * PC_L + lane], en = a.ec[(size_t)nt * PC_L + lane];
+        if (!SIMS_LOCAL) { sp = wave_sum(cb * ep); sn = wave_sum(cb * en); }
+        const float lt = a.margin - sp + sn;
+        const float gt = lt > 0.f ? a.g_type : 0.f;
+        DCs[s * LD64 + lane] = gt * (en - ep);
+        a.dc[(size_t)b * PC_L + lane] = gt * (en - ep);
+        a.ecsrc[((size_t)a.B * K + b) * PC_L + lane] = -gt * cb;               // -> dE_c[pos]
+        a.ecsrc[((size_t)a.B * (K + 1) + b) * PC_L + lane] = gt * cb;          // -> dE_c[neg]
+        const float2 pa = *reinterpret_cast<const float2*>(&PIs[s * LD128 + 2 * lane]);
+        const float2 pp = *reinterpret_cast<const float2*>(a.pos_items + (size_t)b * PC_D + 2 * lane);
+        const float2 nn = *reinterpret_cast<const float2*>(a.neg_items + (size_t)b * PC_D + 2 * lane);
+        float li = 0.f;
+        float2 acc = make_float2(0.f, 0.f);
+        for (int k = 0; k < K; k++) {
+            float* tpp = &TPs[(16 * k + s) * LD128 + 2 * lane];
+            const float2 t = *reinterpret_cast<const float2*>(tpp);
+            const float2 x = make_float2(pa.x * t.x, pa.y * t.y);
+            const float2 dp = make_float2(x.x - pp.x, x.y - pp.y), dn = make_float2(x.x - nn.x, x.y - nn.y);
+            const float np_ = sqrtf(wave_sum(dp.x * dp.x + dp.y * dp.y));
+            const float nn_ = sqrtf(wave_sum(dn.x * dn.x + dn.y * dn.y));
+            const float l = a.margin - np_ + nn_;
+            li += l > 0.f ? l : 0.f;
+            const float g = l > 0.f ? a.g_item : 0.f;
+            const float ip = np_ > 0.f ? g / np_ : 0.f, in = nn_ > 0.f ? g / nn_ : 0.f;   // torch.norm: subgradient 0 at 0
+            const float2 d = make_float2(-dp.x * ip + dn.x * in, -dp.y * ip + dn.y * in);
+            acc.x += d.x * t.x; acc.y += d.y * t.y;
+            const float2 dt2 = make_float2(d.x * pa.x, d.y * pa.y);
+            *reinterpret_cast<float2*>(tpp) = dt2;
+            *reinterpret_cast<float2*>(a.dtp + ((size_t)b * K + k) * PC_D + 2 * lane) = dt2;
+        }
+        *reinterpret_cast<float2*>(a.dpi + (size_t)b * PC_D + 2 * lane) = acc;
+        if (lane == 0) {
+            a.part_type[b] = lt > 0.f ? lt : 0.f;
+            a.part_item[b] = li;
+            a.ecidx[(size_t)a.B * K + b] = pt;
+            a.ecidx[(size_t)a.B * (K + 1) + b] = nt;
+        }
+    }
+    __syncthreads();
+    // ---- phase G: dce_k = dtp_k typ_w (K row blocks x 4 column blocks: wave w takes column block w) -> the dE_c rows of
+    // the selected types; dh = (dc dec_w) relu' dropout' (waves 0, 1)
+    {
+        f32x4v acc[FK];
+#pragma unroll
+        for (int m = 0; m < FK; m++) acc[m] = f32x4v{0.f, 0.f, 0.f, 0.f};
+        block_product<PC_D, FK, true>(TPs, LD128, K, a.typ_w, PC_L, 16 * w, PC_L, acc, lane);
+        const int col = 16 * w + ci;
+#pragma unroll
+        for (int m = 0; m < FK; m++)
+            if (m < K)
+#pragma unroll
+                for (int r = 0; r < 4; r++) {
+                    const int s = 4 * rh + r;
+                    if (b0 + s < a.B) a.ecsrc[((size_t)(b0 + s) * K + m) * PC_L + col] = acc[m][r];
+                }
+    }
+    if (w < 2) {
+        f32x4v acc[1] = {{0.f, 0.f, 0.f, 0.f}};
+        block_product<PC_L, 1, true>(DCs, LD64, 1, a.dec_w, LH, 16 * w, LH, acc, lane);
+        const int col = 16 * w + ci;
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            const int row = 4 * rh + r;
+            // the saved hidden value is the DROPPED one: 0 where relu' = 0 or the unit was dropped; kept units carry 1/(1-p)
+            float x = Hs[row * LD32 + col] > 0.f ? acc[0][r] : 0.f;
+            if (a.drop.thr) x *= a.drop.scale;
+            DHs[row * LD32 + col] = x;
+            if (b0 + row < a.B) a.dh[(size_t)(b0 + row) * LH + col] = x;
+        }
+    }
+    __syncthreads();
+    // ---- phase H: dt = dh enc_w (4 column blocks, one per wave) -> the dE_q rows
+    {
+        f32x4v acc[1] = {{0.f, 0.f, 0.f, 0.f}};
+        block_product<LH, 1, true>(DHs, LD32, 1, a.enc_w, PC_L, 16 * w, PC_L, acc, lane);
+        const int col = 16 * w + ci;
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            const int row = 4 * rh + r;
+            if (b0 + row < a.B) a.dt[(size_t)(b0 + row) * PC_L + col] = acc[0][r];
+        }
+    }
+}
+
+static size_t tile_lds_bytes(int T, bool sims_local) {
+    const int ldsims = sims_local ? ((T + 15) / 16 * 16 + 4) : 0;
+    const size_t floats = (size_t)TS * LD64 + TS * LD32 + TS * LD64 + 2 * TS * LD128 + (size_t)TS * FK * LD64 +
+                          (size_t)TS * FK * LD128 + TS * LD64 + TS * LD32 + TS * 8 + (size_t)TS * ldsims;
+    return floats * sizeof(float);
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Large tables: similarity row and top-K once per DISTINCT query type of the batch (dropout off: c is a function of
+// the type alone).
+//   present_types_kernel   bitmap of the batch's query types -> ascending list ulist[U] (one workgroup)
+//   type_sims_topk_kernel  per (chunk of TC types, tile of 64 listed query types): c for the tile (two small
+//                          products), sims = c E_c[chunk]^T, per query type the chunk's best K   [epilogue top-K:
+//                          the [U,T] similarity matrix is never written]
+//   type_topk_merge_kernel per listed query type: best K of its chunks' candidates -> topk_by_type[type][K]
+#define TC 256
+#define UT 64
+__global__ __launch_bounds__(1024) void present_types_kernel(const int32_t* query_types, int B, int T, int32_t* ulist,
+                                                             int32_t* n_u) {
+    extern __shared__ unsigned bits[];                  // [words] then scan scratch [1024]
+    const int words = (T + 31) >> 5;
+    unsigned* part = bits + words;
+    for (int i = threadIdx.x; i < words; i += 1024) bits[i] = 0u;
+    __syncthreads();
+    for (int b = threadIdx.x; b < B; b += 1024) {
+        const int t = query_types[b];
+        if ((unsigned)t < (unsigned)T) atomicOr(&bits[t >> 5], 1u << (t & 31));
+    }
+    __syncthreads();
+    const int per = (words + 1023) / 1024;
+    const int lo = threadIdx.x * per, hi = min(words, lo + per);
+    int cnt = 0;
+    for (int i = lo; i < hi; i++) cnt += __popc(bits[i]);
+    part[threadIdx.x] = cnt;
+    __syncthreads();
+    for (int o = 1; o < 1024; o <<= 1) {
+        const unsigned v = threadIdx.x >= (unsigned)o ? part[threadIdx.x - o] : 0u;
+        __syncthreads();
+        part[threadIdx.x] += v;
+        __syncthreads();
+    }
+    int pos = (int)part[threadIdx.x] - cnt;
+    for (int i = lo; i < hi; i++) {
+        unsigned m = bits[i];
+        while (m) {
+            const int bit = __ffs(m) - 1;
+            m &= m - 1;
+            ulist[pos++] = 32 * i + bit;
+        }
+    }
+    if (threadIdx.x == 1023) *n_u = (int)part[1023];
+}
+
+struct TypeSimsArgs {
+    const float *enc_w, *enc_b, *dec_w, *dec_b, *eq, *ec;
+    const int32_t *ulist, *n_u;
+    int T, K, nchunks;
+    float* part_val; int32_t* part_idx;     // [U capacity][nchunks][K]
+};
+
+__global__ __launch_bounds__(256) void type_sims_topk_kernel(TypeSimsArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    float* Tin = sm;                        // [64][LD64]
+    float* Hs = Tin + UT * LD64;            // [64][LD32]
+    float* Cs = Hs + UT * LD32;             // [64][LD64]
+    float* Sims = Cs + UT * LD64;           // [64][TC + 4]
+    constexpr int LDS_ = TC + 4;
+    const int nu = *a.n_u;
+    const int u0 = blockIdx.y * UT;
+    if (u0 >= nu) return;
+    const int t0 = blockIdx.x * TC;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, ci = lane & 15, rh = lane >> 4;
+    for (int e = tid; e < UT * 16; e += 256) {
+        const int r = e >> 4, c4 = (e & 15) * 4;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (u0 + r < nu) v = *reinterpret_cast<const float4*>(a.eq + (size_t)a.ulist[u0 + r] * PC_L + c4);
+        *reinterpret_cast<float4*>(&Tin[r * LD64 + c4]) = v;
+    }
+    __syncthreads();
+    // wave w owns the 16 query types [16 w, 16 w + 16) of the tile for the two small layers
+    {
+        const float* At = Tin + 16 * w * LD64;
+#pragma unroll
+        for (int nb = 0; nb < 2; nb++) {
+            f32x4v acc[1] = {{0.f, 0.f, 0.f, 0.f}};
+            block_product<PC_L, 1, false>(At, LD64, 1, a.enc_w, PC_L, 16 * nb, LH, acc, lane);
+            const float bias = a.enc_b[16 * nb + ci];
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                const float x = acc[0][r] + bias;
+                Hs[(16 * w + 4 * rh + r) * LD32 + 16 * nb + ci] = x > 0.f ? x : 0.f;
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int nb = 0; nb < 4; nb++) {
+            f32x4v acc[1] = {{0.f, 0.f, 0.f, 0.f}};
+            block_product<LH, 1, false>(Hs + 16 * w * LD32, LD32, 1, a.dec_w, LH, 16 * nb, PC_L, acc, lane);
+            const float bias = a.dec_b[16 * nb + ci];
+#pragma unroll
+            for (int r = 0; r < 4; r++) Cs[(16 * w + 4 * rh + r) * LD64 + 16 * nb + ci] = acc[0][r] + bias;
+        }
+    }
+    __syncthreads();
+    // sims[64][TC]: 16 column blocks, wave w takes blocks w, w + 4, ...; 4 row blocks share a B fragment set
+    for (int nb = w; nb < TC / 16; nb += 4) {
+        f32x4v acc[4];
+#pragma unroll
+        for (int m = 0; m < 4; m++) acc[m] = f32x4v{0.f, 0.f, 0.f, 0.f};
+        block_product<PC_L, 4, false>(Cs, LD64, 4, a.ec, PC_L, t0 + 16 * nb, a.T, acc, lane);
+#pragma unroll
+        for (int m = 0; m < 4; m++)
+#pragma unroll
+            for (int r = 0; r < 4; r++) Sims[(16 * m + 4 * rh + r) * LDS_ + 16 * nb + ci] = acc[m][r];
+    }
+    __syncthreads();
+    const int nvalid = min(TC, a.T - t0);
+    for (int s = w; s < UT; s += 4) {
+        if (u0 + s >= nu) break;
+        float v[FK];
+        int ix[FK];
+#pragma unroll
+        for (int j = 0; j < FK; j++) { v[j] = -INFINITY; ix[j] = 0x7fffffff; }
+        for (int t = lane; t < nvalid; t += 64) {
+            float x = Sims[s * LDS_ + t];
+            int xi = t0 + t;
+#pragma unroll
+            for (int j = 0; j < FK; j++)
+                if (j < a.K) {
+                    const bool better = x > v[j] || ix[j] == 0x7fffffff;
+                    const float tv = better ? v[j] : x;
+                    const int ti = better ? ix[j] : xi;
+                    v[j] = better ? x : v[j];
+                    ix[j] = better ? xi : ix[j];
+                    x = tv; xi = ti;
+                }
+        }
+        for (int r = 0; r < a.K; r++) {
+            float bv = v[0];
+            int bi = ix[0];
+#pragma unroll
+            for (int o = 32; o >= 1; o >>= 1) {
+                const float ov = __shfl_xor(bv, o, 64);
+                const int oi = __shfl_xor(bi, o, 64);
+                if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
+            }
+            if (ix[0] == bi && bi != 0x7fffffff) {
+#pragma unroll
+                for (int j = 0; j < FK - 1; j++) { v[j] = v[j + 1]; ix[j] = ix[j + 1]; }
+                v[FK - 1] = -INFINITY; ix[FK - 1] = 0x7fffffff;
+            }
+            if (lane == 0) {
+                const size_t o = ((size_t)(u0 + s) * a.nchunks + blockIdx.x) * a.K + r;
+                a.part_val[o] = bv;
+                a.part_idx[o] = bi;
+            }
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void type_topk_merge_kernel(const float* part_val, const int32_t* part_idx,
+                                                              const int32_t* ulist, const int32_t* n_u, int nchunks,
+                                                              int K, int32_t* topk_by_type) {
+    const int lane = threadIdx.x & 63;
+    const int u = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (u >= *n_u) return;
+    const int n = nchunks * K;
+    float v[FK];
+    int ix[FK];
+#pragma unroll
+    for (int j = 0; j < FK; j++) { v[j] = -INFINITY; ix[j] = 0x7fffffff; }
+    for (int t = lane; t < n; t += 64) {
+        float x = part_val[(size_t)u * n + t];
+        int xi = part_idx[(size_t)u * n + t];
+        if (xi == 0x7fffffff) continue;
+#pragma unroll
+        for (int j = 0; j < FK; j++)
+            if (j < K) {
+                const bool better = x > v[j] || (x == v[j] && xi < ix[j]);
+                const float tv = better ? v[j] : x;
+                const int ti = better ? ix[j] : xi;
+                v[j] = better ? x : v[j];
+                ix[j] = better ? xi : ix[j];
+                x = tv; xi = ti;
+            }
+    }
+    const int type = ulist[u];
+    for (int r = 0; r < K; r++) {
+        float bv = v[0];
+        int bi = ix[0];
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) {
+            const float ov = __shfl_xor(bv, o, 64);
+            const int oi = __shfl_xor(bi, o, 64);
+            if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
+        }
+        if (ix[0] == bi) {
+#pragma unroll
+            for (int j = 0; j < FK - 1; j++) { v[j] = v[j + 1]; ix[j] = ix[j + 1]; }
+            v[FK - 1] = -INFINITY; ix[FK - 1] = 0x7fffffff;
+        }
+        if (lane == 0) topk_by_type[(size_t)type * K + r] = bi;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Finish: per parameter tensor, the fixed-order sum of its gradient slabs (written by the grouped rows^T x rows launch)
+// -> .grad; the two loss means; and -- when the caller handed its moments -- torch.optim.Adam's update on the element
+// just reduced.  Jobs with nsplit == 0 have their gradient complete in `grad` already (atomics path of large tables).
+#define FIN_JOBS 12
+struct FinishJob { const float* slabs; size_t stride; int nsplit, n; float *grad, *param, *m, *v; };
+struct FinishArgs {
+    FinishJob job[FIN_JOBS]; int block0[FIN_JOBS + 1], njobs;
+    const float *part_type, *part_item; int B, K; float alpha; float* losses;
+    const int64_t* step_count; double lr, beta1, beta2, eps; int adam;
+};
+
+__global__ __launch_bounds__(256) void joint_finish_kernel(FinishArgs a) {
+    __shared__ float r0[256], r1[256];
+    __shared__ float scal[2];
+    const int b = blockIdx.x;
+    if (b == a.block0[a.njobs]) {                       // the extra workgroup: the two hinge means
+        float x = 0.f, y = 0.f;
+        for (int i = threadIdx.x; i < a.B; i += 256) { x += a.part_type[i]; y += a.part_item[i]; }
+        r0[threadIdx.x] = x; r1[threadIdx.x] = y;
+        __syncthreads();
+        for (int o = 128; o >= 1; o >>= 1) {
+            if (threadIdx.x < o) { r0[threadIdx.x] += r0[threadIdx.x + o]; r1[threadIdx.x] += r1[threadIdx.x + o]; }
+            __syncthreads();
+        }
+        if (threadIdx.x == 0) {
+            const float tl = r0[0] / (float)a.B, il = r1[0] / ((float)a.B * (float)a.K);
+            a.losses[0] = a.alpha * il + (1.0f - a.alpha) * tl;
+            a.losses[1] = tl;
+            a.losses[2] = il;
+        }
+        return;
+    }
+    if (a.adam) {
+        if (threadIdx.x == 0) {                         // torch's single-tensor path: scalars in fp64, rounded at use
+            const int64_t t = *a.step_count;            // (already advanced by the tile kernel of this step)
+            scal[0] = (float)(a.lr / (1.0 - pow(a.beta1, (double)t)));
+            scal[1] = (float)sqrt(1.0 - pow(a.beta2, (double)t));
+        }
+        __syncthreads();
+    }
+    int j = 0;
+#pragma unroll
+    for (int i = 1; i < FIN_JOBS; i++) j += (i < a.njobs && b >= a.block0[i]) ? 1 : 0;
+    const FinishJob& jb = a.job[j];
+    // eight lanes share one float4 of outputs: lane g sums slabs g, g + 8, ...; the partial sums fold in a fixed xor order
+    const int t = (b - a.block0[j]) * 256 + threadIdx.x;
+    const int j4 = t >> 3, g = t & 7;
+    if (j4 * 4 >= jb.n) return;
+    float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (jb.nsplit > 0) {
+        const float* src = jb.slabs + (size_t)j4 * 4;
+#pragma unroll 4
+        for (int k = g; k < jb.nsplit; k += 8) {
+            const float4 v = *reinterpret_cast<const float4*>(src + (size_t)k * jb.stride);
+            s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+        }
+#pragma unroll
+        for (int o = 1; o < 8; o <<= 1) {
+            s.x += __shfl_xor(s.x, o, 64); s.y += __shfl_xor(s.y, o, 64);
+            s.z += __shfl_xor(s.z, o, 64); s.w += __shfl_xor(s.w, o, 64);
+        }
+    } else if (g == 0) {
+        s = *reinterpret_cast<const float4*>(jb.grad + (size_t)j4 * 4);
+    }
+    if (g != 0) return;
+    if (jb.nsplit > 0) *reinterpret_cast<float4*>(jb.grad + (size_t)j4 * 4) = s;
+    if (a.adam) {
+        const float step_size = scal[0], bc2s = scal[1];
+        const float omb1 = (float)(1.0 - a.beta1), beta2 = (float)a.beta2, omb2 = (float)(1.0 - a.beta2), eps = (float)a.eps;
+        float4 pv = *reinterpret_cast<float4*>(jb.param + (size_t)j4 * 4);
+        float4 mv = *reinterpret_cast<float4*>(jb.m + (size_t)j4 * 4);
+        float4 vv = *reinterpret_cast<float4*>(jb.v + (size_t)j4 * 4);
+#define ADAM1(c)                                                         \
+        mv.c = mv.c + (s.c - mv.c) * omb1;                               \
+        vv.c = vv.c * beta2 + omb2 * s.c * s.c;                          \
+        pv.c = pv.c - step_size * (mv.c / (sqrtf(vv.c) / bc2s + eps));
+        ADAM1(x) ADAM1(y) ADAM1(z) ADAM1(w)
+#undef ADAM1
+        *reinterpret_cast<float4*>(jb.param + (size_t)j4 * 4) = pv;
+        *reinterpret_cast<float4*>(jb.m + (size_t)j4 * 4) = mv;
+        *reinterpret_cast<float4*>(jb.v + (size_t)j4 * 4) = vv;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+extern "C" int pc_scatter_add_rows(float* table, const int32_t* idx, int rows, int width, const float* src, void* stream);
+
+struct FusedWs {
+    float *part, *h, *dpi, *dtp, *dc, *dh, *dt, *ecsrc;
+    int32_t *ecidx, *ulist, *n_u, *topk_by_type, *part_idx;
+    float* part_val;
+    float* slabs[6]; size_t slab_floats[6];
+    int nchunks, ucap;
+    bool small;
+    size_t total;
+};
+
+static FusedWs fused_ws_layout(void* base, int B, int T, int K) {
+    FusedWs w;
+    size_t off = 0;
+    auto take = [&](size_t bytes) {
+        void* p = base ? reinterpret_cast<char*>(base) + off : nullptr;
+        off += align256(bytes);
+        return p;
+    };
+    w.small = T <= T_SMALL;
+    w.part = (float*)take((size_t)2 * B * 4);
+    w.h = (float*)take((size_t)B * LH * 4);
+    w.dpi = (float*)take((size_t)B * PC_D * 4);
+    w.dtp = (float*)take((size_t)B * K * PC_D * 4);
+    w.dc = (float*)take((size_t)B * PC_L * 4);
+    w.dh = (float*)take((size_t)B * LH * 4);
+    w.dt = (float*)take((size_t)B * PC_L * 4);
+    w.ecsrc = (float*)take((size_t)B * (K + 2) * PC_L * 4);
+    w.ecidx = (int32_t*)take((size_t)B * (K + 2) * 4);
+    const size_t sf[4] = {gemm_tn_workspace_floats(B, PC_D, PC_D), gemm_tn_workspace_floats(B * K, PC_D, PC_L),
+                          gemm_tn_workspace_floats(B, PC_L, LH), gemm_tn_workspace_floats(B, LH, PC_L)};
+    for (int i = 0; i < 4; i++) { w.slab_floats[i] = sf[i]; w.slabs[i] = (float*)take(sf[i] * 4); }
+    w.slab_floats[4] = w.slab_floats[5] = 0;
+    w.slabs[4] = w.slabs[5] = nullptr;
+    w.nchunks = w.ucap = 0;
+    w.ulist = w.n_u = w.topk_by_type = w.part_idx = nullptr;
+    w.part_val = nullptr;
+    if (w.small) {
+        const int Tp = (T + 3) & ~3;
+        w.slab_floats[4] = gemm_tn_workspace_floats(B * (K + 2), Tp, PC_L);
+        w.slab_floats[5] = gemm_tn_workspace_floats(B, Tp, PC_L);
+        w.slabs[4] = (float*)take(w.slab_floats[4] * 4);
+        w.slabs[5] = (float*)take(w.slab_floats[5] * 4);
+    } else {
+        w.nchunks = (T + TC - 1) / TC;
+        w.ucap = B < T ? B : T;
+        w.ulist = (int32_t*)take((size_t)w.ucap * 4);
+        w.n_u = (int32_t*)take(256);
+        w.topk_by_type = (int32_t*)take((size_t)T * K * 4);
+        w.part_val = (float*)take((size_t)w.ucap * w.nchunks * K * 4);
+        w.part_idx = (int32_t*)take((size_t)w.ucap * w.nchunks * K * 4);
+    }
+    w.total = off;
+    return w;
+}
+
+extern "C" size_t pc_joint_fused_workspace_bytes(int batch, int num_types, int k) {
+    if (batch <= 0 || num_types <= 0 || k <= 0) return 0;
+    return fused_ws_layout(nullptr, batch, num_types, k).total;
+}
+
+extern "C" int pc_joint_fused_supported(int num_types, int k, float dropout_p) {
+    if (k < 1 || k > FK || k > num_types || num_types < 1) return 0;
+    if (num_types > T_SMALL && dropout_p > 0.f) return 0;      // the per-type similarity row needs c = f(type) only
+    if (num_types > T_SMALL && (size_t)((num_types + 31) / 32 + 1024) * 4 > 160 * 1024) return 0;
+    return 1;
+}
+
+static bool tensors_ok(const pc_joint_tensors* t, bool need_table) {
+    return t && (!need_table || t->product_table) && t->enc_w && t->enc_b && t->dec_w && t->dec_b && t->typ_w && t->typ_b &&
+           t->itm_w && t->itm_b && t->query_types && t->comp_types;
+}
+
+extern "C" int pc_joint_fused_step(const pc_joint_tensors* p, const pc_joint_tensors* g, const pc_joint_tensors* exp_avg,
+                                   const pc_joint_tensors* exp_avg_sq, int64_t* step_count, double lr, double beta1,
+                                   double beta2, double eps, const int32_t* query_idx, const int32_t* query_types,
+                                   const int32_t* pos_types, const int32_t* neg_types, const float* pos_items,
+                                   const float* neg_items, int B, int T, int K, int num_products, float margin, float alpha,
+                                   float* losses, int32_t* topk, int32_t* bad_count, void* ws, size_t ws_bytes,
+                                   void* stream) {
+    if (!tensors_ok(p, true) || !tensors_ok(g, false)) return PC_EINVAL;
+    const bool adam = exp_avg != nullptr;
+    if (adam && (!tensors_ok(exp_avg, false) || !tensors_ok(exp_avg_sq, false) || !step_count)) return PC_EINVAL;
+    if (!query_idx || !query_types || !pos_types || !neg_types || !pos_items || !neg_items || !losses || !topk || !ws)
+        return PC_EINVAL;
+    if (B <= 0 || T <= 0 || num_products <= 0) return PC_EINVAL;
+    if (!pc_joint_fused_supported(T, K, p->dropout.p)) return PC_ESHAPE;
+    if (ws_bytes < pc_joint_fused_workspace_bytes(B, T, K)) return PC_EWORKSPACE;
+    hipStream_t st = (hipStream_t)stream;
+    FusedWs w = fused_ws_layout(ws, B, T, K);
+
+    if (!w.small) {
+        // gradients of the two big tables arrive by float atomics: cleared first
+        PC_HIP_TRY(hipMemsetAsync(g->query_types, 0, (size_t)T * PC_L * 4, st));
+        PC_HIP_TRY(hipMemsetAsync(g->comp_types, 0, (size_t)T * PC_L * 4, st));
+        const int words = (T + 31) / 32;
+        PC_LAUNCH(present_types_kernel, dim3(1), dim3(1024), (size_t)(words + 1024) * 4, st, query_types, B, T, w.ulist, w.n_u);
+        TypeSimsArgs ta = {p->enc_w, p->enc_b, p->dec_w, p->dec_b, p->query_types, p->comp_types, w.ulist, w.n_u, T, K,
+                           w.nchunks, w.part_val, w.part_idx};
+        const size_t lds = ((size_t)UT * LD64 * 2 + UT * LD32 + (size_t)UT * (TC + 4)) * 4;
+        static const hipError_t attr0 = hipFuncSetAttribute(reinterpret_cast<const void*>(&type_sims_topk_kernel),
+                                                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)attr0;
+        PC_LAUNCH(type_sims_topk_kernel, dim3(w.nchunks, (w.ucap + UT - 1) / UT), dim3(256), lds, st, ta);
+        PC_LAUNCH(type_topk_merge_kernel, dim3((w.ucap + 3) / 4), dim3(256), 0, st, w.part_val, w.part_idx, w.ulist, w.n_u,
+                  w.nchunks, K, w.topk_by_type);
+        PC_TRY(pc_launch_status());
+    }
+
+    FusedArgs fa = {};
+    fa.table = p->product_table; fa.enc_w = p->enc_w; fa.enc_b = p->enc_b; fa.dec_w = p->dec_w; fa.dec_b = p->dec_b;
+    fa.typ_w = p->typ_w; fa.typ_b = p->typ_b; fa.itm_w = p->itm_w; fa.itm_b = p->itm_b; fa.eq = p->query_types;
+    fa.ec = p->comp_types;
+    fa.query_idx = query_idx; fa.query_types = query_types; fa.pos_types = pos_types; fa.neg_types = neg_types;
+    fa.pos_items = pos_items; fa.neg_items = neg_items;
+    fa.B = B; fa.T = T; fa.K = K; fa.P = num_products;
+    fa.margin = margin; fa.g_type = (1.0f - alpha) / (float)B; fa.g_item = alpha / ((float)B * (float)K);
+    fa.drop = make_dropcfg(p->dropout);
+    fa.topk_by_type = w.topk_by_type;
+    fa.topk = topk; fa.part_type = w.part; fa.part_item = w.part + B;
+    fa.h = w.h; fa.dpi = w.dpi; fa.dtp = w.dtp; fa.dc = w.dc; fa.dh = w.dh; fa.dt = w.dt;
+    fa.ecsrc = w.ecsrc; fa.ecidx = w.ecidx; fa.bad = bad_count; fa.step_count = adam ? step_count : nullptr;
+    const int tiles = (B + TS - 1) / TS;
+    const int ldsims = w.small ? ((T + 15) / 16 * 16 + 4) : 0;
+    const size_t lds = tile_lds_bytes(T, w.small);
+    static const hipError_t attr1 = hipFuncSetAttribute(reinterpret_cast<const void*>(&joint_tile_kernel<true>),
+                                                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    static const hipError_t attr2 = hipFuncSetAttribute(reinterpret_cast<const void*>(&joint_tile_kernel<false>),
+                                                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)attr1; (void)attr2;
+    if (w.small) PC_LAUNCH(joint_tile_kernel<true>, dim3(tiles), dim3(256), lds, st, fa, ldsims);
+    else PC_LAUNCH(joint_tile_kernel<false>, dim3(tiles), dim3(256), lds, st, fa, ldsims);
+    PC_TRY(pc_launch_status());
+
+    // ---- gradient products over the row buffers: one grouped launch, slabs summed by the finish kernel
+    const SegInfo siB = make_seginfo(nullptr, B, 128), siBK = make_seginfo(nullptr, B * K, 128),
+                  siE = make_seginfo(nullptr, B * (K + 2), 128);
+    TnArgs tn[6];
+    TnArgs& ti = tn[0];
+    ti = {};
+    ti.Z = w.dpi; ti.ldz = PC_D; ti.A = p->product_table; ti.lda = PC_D; ti.gather = query_idx; ti.R = B;
+    ti.No = PC_D; ti.Ni = PC_D; ti.seg = siB; ti.dW = g->itm_w; ti.lddw = PC_D; ti.db = g->itm_b;
+    ti.slabs = w.slabs[0]; ti.slab_floats = w.slab_floats[0];
+    TnArgs& tt = tn[1];
+    tt = {};
+    tt.Z = w.dtp; tt.ldz = PC_D; tt.A = p->comp_types; tt.lda = PC_L; tt.gather = topk; tt.R = B * K;
+    tt.No = PC_D; tt.Ni = PC_L; tt.seg = siBK; tt.dW = g->typ_w; tt.lddw = PC_L; tt.db = g->typ_b;
+    tt.slabs = w.slabs[1]; tt.slab_floats = w.slab_floats[1];
+    TnArgs& td = tn[2];
+    td = {};
+    td.Z = w.dc; td.ldz = PC_L; td.A = w.h; td.lda = LH; td.R = B; td.No = PC_L; td.Ni = LH; td.seg = siB;
+    td.dW = g->dec_w; td.lddw = LH; td.db = g->dec_b; td.slabs = w.slabs[2]; td.slab_floats = w.slab_floats[2];
+    TnArgs& te = tn[3];
+    te = {};
+    te.Z = w.dh; te.ldz = LH; te.A = p->query_types; te.lda = PC_L; te.gather = query_types; te.R = B;
+    te.No = LH; te.Ni = PC_L; te.seg = siB; te.dW = g->enc_w; te.lddw = PC_L; te.db = g->enc_b;
+    te.slabs = w.slabs[3]; te.slab_floats = w.slab_floats[3];
+    int nt = 4;
+    const int Tp = (T + 3) & ~3;
+    if (w.small) {
+        TnArgs& tc = tn[4];
+        tc = {};
+        tc.z_onehot = w.ecidx; tc.A = w.ecsrc; tc.lda = PC_L; tc.R = B * (K + 2); tc.No = Tp; tc.Ni = PC_L; tc.seg = siE;
+        tc.dW = g->comp_types; tc.lddw = PC_L; tc.slabs = w.slabs[4]; tc.slab_floats = w.slab_floats[4];
+        TnArgs& tq = tn[5];
+        tq = {};
+        tq.z_onehot = query_types; tq.A = w.dt; tq.lda = PC_L; tq.R = B; tq.No = Tp; tq.Ni = PC_L; tq.seg = siB;
+        tq.dW = g->query_types; tq.lddw = PC_L; tq.slabs = w.slabs[5]; tq.slab_floats = w.slab_floats[5];
+        nt = 6;
+    } else {
+        PC_TRY(pc_scatter_add_rows(g->comp_types, w.ecidx, B * (K + 2), PC_L, w.ecsrc, stream));
+        PC_TRY(pc_scatter_add_rows(g->query_types, query_types, B, PC_L, w.dt, stream));
+    }
+    TnGroupPlan plan;
+    PC_TRY(launch_gemm_tn_group_partials(tn, nt, &plan, st));
+
+    // ---- finish: slab sums -> .grad, the losses, Adam
+    FinishArgs fin = {};
+    float* const gw[6] = {g->itm_w, g->typ_w, g->dec_w, g->enc_w, g->comp_types, g->query_types};
+    float* const gb[6] = {g->itm_b, g->typ_b, g->dec_b, g->enc_b, nullptr, nullptr};
+    float* const pw[6] = {p->itm_w, p->typ_w, p->dec_w, p->enc_w, p->comp_types, p->query_types};
+    float* const pb[6] = {p->itm_b, p->typ_b, p->dec_b, p->enc_b, nullptr, nullptr};
+    float *mw[6] = {}, *mb[6] = {}, *vw[6] = {}, *vb[6] = {};
+    if (adam) {
+        float* const m_[6] = {exp_avg->itm_w, exp_avg->typ_w, exp_avg->dec_w, exp_avg->enc_w, exp_avg->comp_types, exp_avg->query_types};
+        float* const mb_[6] = {exp_avg->itm_b, exp_avg->typ_b, exp_avg->dec_b, exp_avg->enc_b, nullptr, nullptr};
+        float* const v_[6] = {exp_avg_sq->itm_w, exp_avg_sq->typ_w, exp_avg_sq->dec_w, exp_avg_sq->enc_w, exp_avg_sq->comp_types, exp_avg_sq->query_types};
+        float* const vb_[6] = {exp_avg_sq->itm_b, exp_avg_sq->typ_b, exp_avg_sq->dec_b, exp_avg_sq->enc_b, nullptr, nullptr};
+        for (int i = 0; i < 6; i++) { mw[i] = m_[i]; mb[i] = mb_[i]; vw[i] = v_[i]; vb[i] = vb_[i]; }
+    }
+    int blocks = 0, nj = 0;
+    auto add = [&](const float* slabs, size_t stride, int nsplit, int n, float* grad, float* param, float* m, float* v) {
+        FinishJob& j = fin.job[nj];
+        j.slabs = slabs; j.stride = stride; j.nsplit = nsplit; j.n = n; j.grad = grad; j.param = param; j.m = m; j.v = v;
+        fin.block0[nj++] = blocks;
+        blocks += (n / 4 * 8 + 255) / 256;
+    };
+    for (int i = 0; i < nt; i++) {
+        const int n_w = tn[i].No * tn[i].Ni, n_b = tn[i].No;
+        const size_t stride = (size_t)n_w + n_b;
+        const int real_w = i >= 4 ? T * PC_L : n_w;               // (a table padded to a multiple of 4 rows: only T are real)
+        add(plan.slabs[i], stride, plan.nsplit[i], real_w, gw[i], pw[i], mw[i], vw[i]);
+        if (gb[i]) add(plan.slabs[i] + n_w, stride, plan.nsplit[i], n_b, gb[i], pb[i], mb[i], vb[i]);
+    }
+    if (!w.small && adam) {                                        // big tables: gradient complete already, Adam only
+        add(nullptr, 0, 0, T * PC_L, g->comp_types, p->comp_types, exp_avg->comp_types, exp_avg_sq->comp_types);
+        add(nullptr, 0, 0, T * PC_L, g->query_types, p->query_types, exp_avg->query_types, exp_avg_sq->query_types);
+    }
+    fin.njobs = nj;
+    for (int k = nj; k <= FIN_JOBS; k++) fin.block0[k] = blocks;
+    fin.part_type = w.part; fin.part_item = w.part + B; fin.B = B; fin.K = K; fin.alpha = alpha; fin.losses = losses;
+    fin.step_count = step_count; fin.lr = lr; fin.beta1 = beta1; fin.beta2 = beta2; fin.eps = eps; fin.adam = adam ? 1 : 0;
+    PC_LAUNCH(joint_finish_kernel, dim3(blocks + 1), dim3(256), 0, st, fin);
+    return pc_launch_status();
+}

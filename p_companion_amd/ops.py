@@ -596,6 +596,45 @@ def joint_train_step(params, grads, query_idx, query_types, pos_types, neg_types
     return losses, topk
 
 
+def joint_fused_supported(num_types, k, dropout_p=0.0):
+    return bool(_lib.lib().pc_joint_fused_supported(int(num_types), int(k), float(dropout_p)))
+
+
+def joint_fused_step(params, grads, query_idx, query_types, pos_types, neg_types, pos_items, neg_items, k, margin, alpha,
+                     bad=None, adam=None):
+    """pc_joint_fused_step: the joint loop body as three launches.  adam: None (gradients only) or a dict with
+    'exp_avg' / 'exp_avg_sq' (tensor dicts keyed like `params`), 'step_count' ([1] int64), 'lr', 'betas', 'eps': the
+    optimizer update then happens in the last kernel.  Returns (losses[3], complementary_types[B,K])."""
+    st, dev = joint_struct(params)
+    gst, _ = joint_struct(grads, table=params["product_embeddings.weight"])
+    b = query_idx.numel()
+    t = params["query_type_embeddings.weight"].shape[0]
+    for x, nm in ((query_idx, "query_idx"), (query_types, "query_types"), (pos_types, "positive_types"),
+                  (neg_types, "negative_types")):
+        _req(x, torch.int32, nm, (b,))
+    _req(pos_items, torch.float32, "positive_items", (b, D)); _req(neg_items, torch.float32, "negative_items", (b, D))
+    losses = torch.empty(3, dtype=torch.float32, device=dev)
+    topk = torch.empty(b, k, dtype=torch.int32, device=dev)
+    nbytes = _lib.lib().pc_joint_fused_workspace_bytes(b, t, k)
+    ws = workspace(nbytes, dev, "joint_fused")
+    m_ref = v_ref = step = None
+    lr, b1, b2, eps = 0.0, 0.0, 0.0, 0.0
+    if adam is not None:
+        mst, _ = joint_struct(adam["exp_avg"], table=params["product_embeddings.weight"])
+        vst, _ = joint_struct(adam["exp_avg_sq"], table=params["product_embeddings.weight"])
+        m_ref, v_ref = ctypes.byref(mst), ctypes.byref(vst)
+        step = _req(adam["step_count"], torch.int64, "step_count")
+        lr, (b1, b2), eps = float(adam["lr"]), adam["betas"], float(adam["eps"])
+    if bad is not None:
+        _req(bad, torch.int32, "bad", (1,))
+    check(_lib.lib().pc_joint_fused_step(
+        ctypes.byref(st), ctypes.byref(gst), m_ref, v_ref, _p(step), lr, float(b1), float(b2), eps, _p(query_idx),
+        _p(query_types), _p(pos_types), _p(neg_types), _p(pos_items), _p(neg_items), b, t, k,
+        int(params["product_embeddings.weight"].shape[0]), float(margin), float(alpha), _p(losses), _p(topk), _p(bad),
+        _p(ws), nbytes, _stream()), "pc_joint_fused_step")
+    return losses, topk
+
+
 # ----------------------------------------------------------------------------- building blocks
 def _pad_cols(t, mult=4):
     """[..., c] -> [..., ceil(c / mult) * mult] with zero columns (the kernels move 16-byte chunks: contraction and

@@ -83,9 +83,12 @@ class _FusedJointLoss(torch.autograd.Function):
         grads = {k: torch.empty_like(w) for k, w in zip(names, weights)}
         params = module._tensor_dict(dropout)
         params["product_embeddings.weight"] = module.product_embeddings.weight
-        losses, _ = ops.joint_train_step(params, grads, query_idx, query_types, pos_types, neg_types, pos_items, neg_items,
-                                         int(module.config.NUM_COMP_TYPES), float(module.config.MARGIN),
-                                         float(module.config.ALPHA))
+        t, k = module.query_type_embeddings.weight.shape[0], int(module.config.NUM_COMP_TYPES)
+        step = ops.joint_train_step
+        if getattr(module, "use_fused_joint", True) and ops.joint_fused_supported(t, k, dropout[0] if dropout else 0.0):
+            step = ops.joint_fused_step
+        losses, _ = step(params, grads, query_idx, query_types, pos_types, neg_types, pos_items, neg_items, k,
+                         float(module.config.MARGIN), float(module.config.ALPHA))
         ctx.grads = [grads[k] for k in names]
         return losses[0].reshape(())
 
@@ -251,22 +254,41 @@ class PCompanion(nn.Module, _FlatParamsMixin):
                                 negative_items.float().contiguous(), float(self.config.MARGIN), 1.0, 2)
 
     # ------------------------------------------------------------------ fused loop body
-    def train_step(self, batch):
-        """train.py:42-46 (forward, compute_loss, zero_grad, backward) as one C-ABI call.
-        Returns (losses[3] = total/type/item on the device, complementary_types[B,K])."""
+    def train_step(self, batch, optimizer=None):
+        """train.py:42-46 (forward, compute_loss, zero_grad, backward) as one C-ABI call; with `optimizer` (a FusedAdam
+        over this module) also train.py:48 optimizer.step(), applied by the step's last kernel.
+        Returns (losses[3] = total/type/item on the device, complementary_types[B,K]).
+        The fused three-launch form (pc_joint_fused_step) serves K <= 4 and, for T > 512, dropout off; anything else
+        takes the launch-per-op sequence pc_joint_train_step (self.use_fused_joint = False forces it)."""
         self.flatten_parameters()
         dev = self.query_type_embeddings.weight.device
-        params = self._tensor_dict(self._next_dropout())
+        drop = self._next_dropout()
+        params = self._tensor_dict(drop)
         params["product_embeddings.weight"] = self.product_embeddings.weight
         grads = {k: p.grad for k, p in self.named_parameters() if p.grad is not None}
         qi, qt = self._query_indices(batch, dev), self._i32(batch["query_types"].to(dev))
         pt, nt = self._i32(batch["positive_types"].to(dev)), self._i32(batch["negative_types"].to(dev))
+        pos = batch["positive_items"].to(dev).float().contiguous()
+        neg = batch["negative_items"].to(dev).float().contiguous()
         t = self.query_type_embeddings.weight.shape[0]
+        k = int(self.config.NUM_COMP_TYPES)
+        if getattr(self, "use_fused_joint", True) and ops.joint_fused_supported(t, k, drop[0] if drop else 0.0):
+            bad = getattr(self, "_bad", None)
+            if bad is None or bad.device != dev:
+                bad = self._bad = torch.zeros(1, dtype=torch.int32, device=dev)
+            adam = None
+            if optimizer is not None:
+                if not hasattr(optimizer, "fused_state") or optimizer.module is not self:
+                    raise TypeError("train_step(optimizer=...) takes the FusedAdam built over this module")
+                adam = optimizer.fused_state()
+            return ops.joint_fused_step(params, grads, qi, qt, pt, nt, pos, neg, k, float(self.config.MARGIN),
+                                        float(self.config.ALPHA), bad=bad, adam=adam)
         self._validate((qi, self.product_embeddings.weight.shape[0]), (qt, t), (pt, t), (nt, t))
-        return ops.joint_train_step(
-            params, grads, qi, qt, pt, nt,
-            batch["positive_items"].to(dev).float().contiguous(), batch["negative_items"].to(dev).float().contiguous(),
-            int(self.config.NUM_COMP_TYPES), float(self.config.MARGIN), float(self.config.ALPHA))
+        out = ops.joint_train_step(params, grads, qi, qt, pt, nt, pos, neg, k, float(self.config.MARGIN),
+                                   float(self.config.ALPHA))
+        if optimizer is not None:
+            optimizer.step()
+        return out
 
     def _named_flat(self):
         sd = dict(self.named_parameters())
@@ -310,8 +332,7 @@ class GraphedJointStep:
                 dst.copy_(src.reshape(dst.shape), non_blocking=True)
 
     def _eager(self):
-        self.losses, self.complementary_types = self.model.train_step(self.static)
-        self.optimizer.step()
+        self.losses, self.complementary_types = self.model.train_step(self.static, optimizer=self.optimizer)
 
     def __call__(self, batch=None):
         if batch is not None:

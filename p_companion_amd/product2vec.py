@@ -172,6 +172,21 @@ class FusedAdam(torch.optim.Optimizer):
         _, gflat = self._ensure()
         gflat.zero_()
 
+    def fused_state(self):
+        """What a fused training step needs to apply this optimizer's update in its own last kernel
+        (ops.joint_fused_step(adam=...)): per-parameter views of the flat moment buffers, the device step counter and
+        the hyper-parameters.  The caller must NOT call step() for that iteration."""
+        self._ensure()
+        m, v, off = {}, {}, 0
+        for name, p in self.module._named_flat():
+            n = p.numel()
+            m[name] = self.exp_avg[off:off + n].view(p.shape)
+            v[name] = self.exp_avg_sq[off:off + n].view(p.shape)
+            off += n
+        g = self.param_groups[0]
+        return {"exp_avg": m, "exp_avg_sq": v, "step_count": self.step_count, "lr": g["lr"], "betas": g["betas"],
+                "eps": g["eps"]}
+
     # ------------------------------------------------------------------ checkpoint layout of torch.optim.Adam
     def _slices(self):
         """[(index in param_groups[0]['params'], offset, numel, shape)] of the parameters that live in the flat buffer."""

@@ -77,7 +77,7 @@ def train(config, train_loader, val_loader, pretrained_embeddings, fused=True):
         for batch in train_loader:
             batch = {k: v.to(config.DEVICE) if isinstance(v, torch.Tensor) else v for k, v in batch.items()}
             if fused:
-                losses, _ = model.train_step(batch)
+                losses, _ = model.train_step(batch, optimizer=optimizer)      # Adam applied by the step's last kernel
                 loss = losses[0:1]
             else:
                 outputs = model(batch)
@@ -85,7 +85,7 @@ def train(config, train_loader, val_loader, pretrained_embeddings, fused=True):
                 optimizer.zero_grad()
                 loss.backward()
                 loss = loss.detach().reshape(1)
-            optimizer.step()
+                optimizer.step()
             total = loss.clone() if total is None else total + loss
             nb += 1
         if nb:
