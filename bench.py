@@ -222,9 +222,13 @@ def run_joint(args, rank, world, dev, types, steps, warmup, want_cpu):
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     ev[0].record()
-    for _ in range(steps):
+    trace = os.environ.get("PC_BENCH_TRACE")
+    for i in range(steps):
         last = next(it)
         losses = step(last)
+        if trace and i % 5 == 0:                     # debugging aid: localise a device fault (synchronises: not for timing)
+            torch.cuda.synchronize()
+            print(f"[trace] joint T={types} step {i} loader step {loader.step} ok", file=sys.stderr, flush=True)
     ev[1].record()
     torch.cuda.synchronize()
     if world > 1:

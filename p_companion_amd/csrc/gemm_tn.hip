@@ -104,6 +104,10 @@ __device__ __forceinline__ void tn_small_body(const TnArgs& a, int tiles_i, int 
     __syncthreads();
     const int fz = (lane >> 5) * TM + wo * 64 + (lane & 31);
     const int fa = (lane >> 5) * TM + wi * 64 + (lane & 31);
+    // 32x32 blocks of this wave that lie inside [No, Ni] (wave-uniform): a small gradient (the joint step's 64x32 / 32x64
+    // layers, its [T,64] one-hot table products) would otherwise spend most of the tile's MFMAs on zeros
+    const bool vz0 = __builtin_amdgcn_readfirstlane(o0 + wo * 64 < a.No), vz1 = __builtin_amdgcn_readfirstlane(o0 + wo * 64 + 32 < a.No);
+    const bool vx0 = __builtin_amdgcn_readfirstlane(i0 + wi * 64 < a.Ni), vx1 = __builtin_amdgcn_readfirstlane(i0 + wi * 64 + 32 < a.Ni);
     for (int c = 0; c < nchunk; c++) {
         const int cur = c & 1;
         if (c + 1 < nchunk) gload(r_begin + (c + 1) * TK);
@@ -113,10 +117,10 @@ __device__ __forceinline__ void tn_small_body(const TnArgs& a, int tiles_i, int 
         for (int k = 0; k < TK; k += 2) {
             const float z0 = Zs[k * TM], z1 = Zs[k * TM + 32];
             const float x0 = As[k * TM], x1 = As[k * TM + 32];
-            acc[0][0] = mfma32(z0, x0, acc[0][0]);
-            acc[0][1] = mfma32(z0, x1, acc[0][1]);
-            acc[1][0] = mfma32(z1, x0, acc[1][0]);
-            acc[1][1] = mfma32(z1, x1, acc[1][1]);
+            if (vz0 && vx0) acc[0][0] = mfma32(z0, x0, acc[0][0]);
+            if (vz0 && vx1) acc[0][1] = mfma32(z0, x1, acc[0][1]);
+            if (vz1 && vx0) acc[1][0] = mfma32(z1, x0, acc[1][0]);
+            if (vz1 && vx1) acc[1][1] = mfma32(z1, x1, acc[1][1]);
         }
         if (c + 1 < nchunk) lstore(cur ^ 1);
         __syncthreads();

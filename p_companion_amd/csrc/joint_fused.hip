@@ -41,40 +41,53 @@ static inline size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
 // care about the order, so one 16-B read feeds four MFMAs).  MB row blocks share one B fragment set.
 // NT: B[k][j] = W[(n0 + j) * ldw + k]   (y = x W^T, nn.Linear forward)
 // NN: B[k][j] = W[k * ldw + n0 + j]     (dx = dy W)
-template <int K, int MB, bool NN>
-__device__ __forceinline__ void block_product(const float* As, int lda, int mblocks, const float* W, int ldw, int n0,
-                                              int nvalid, f32x4v (&acc)[MB], int lane) {
+// The B fragments of EVERY phase are requested at the top of the kernel (weights do not depend on the tile): the phases
+// then wait for LDS hand-offs only, not for one L2 / HBM round trip each.
+template <int NC> struct BFrag { float4 v[NC]; };
+
+template <int K, bool NN>
+__device__ __forceinline__ BFrag<K / 16> load_b(const float* W, int ldw, int n0, int nvalid, int lane) {
     const int i = lane & 15, h = lane >> 4;
     constexpr int NC = K / 16;
-    float4 b4[NC];
+    BFrag<NC> b;
+    const bool v = n0 + i < nvalid;
     if (NN) {
 #pragma unroll
         for (int c = 0; c < NC; c++) {
-            const float* w = W + (size_t)(16 * c + 4 * h) * ldw + n0 + i;
-            const bool v = n0 + i < nvalid;
-            b4[c] = v ? make_float4(w[0], w[ldw], w[2 * ldw], w[3 * ldw]) : make_float4(0.f, 0.f, 0.f, 0.f);
+            const float* w = W + (size_t)(16 * c + 4 * h) * ldw + (v ? n0 + i : 0);
+            b.v[c] = v ? make_float4(w[0], w[ldw], w[2 * ldw], w[3 * ldw]) : make_float4(0.f, 0.f, 0.f, 0.f);
         }
     } else {
-        const bool v = n0 + i < nvalid;
         const float* w = W + (size_t)(v ? n0 + i : 0) * ldw + 4 * h;
 #pragma unroll
         for (int c = 0; c < NC; c++)
-            b4[c] = v ? *reinterpret_cast<const float4*>(w + 16 * c) : make_float4(0.f, 0.f, 0.f, 0.f);
+            b.v[c] = v ? *reinterpret_cast<const float4*>(w + 16 * c) : make_float4(0.f, 0.f, 0.f, 0.f);
     }
+    return b;
+}
+
+template <int NC, int MB>
+__device__ __forceinline__ void mul_b(const float* As, int lda, int mblocks, const BFrag<NC>& b, f32x4v (&acc)[MB], int lane) {
+    const int i = lane & 15, h = lane >> 4;
 #pragma unroll
-    for (int m = 0; m < MB; m++) {
-        if (m < mblocks) {
-            const float* a = As + (size_t)(16 * m + i) * lda + 4 * h;
+    for (int c = 0; c < NC; c++) {
 #pragma unroll
-            for (int c = 0; c < NC; c++) {
-                const float4 a4 = *reinterpret_cast<const float4*>(a + 16 * c);
-                acc[m] = mfma16(a4.x, b4[c].x, acc[m]);
-                acc[m] = mfma16(a4.y, b4[c].y, acc[m]);
-                acc[m] = mfma16(a4.z, b4[c].z, acc[m]);
-                acc[m] = mfma16(a4.w, b4[c].w, acc[m]);
+        for (int m = 0; m < MB; m++) {
+            if (m < mblocks) {                       // (folds away when the caller passes a compile-time count == MB)
+                const float4 a4 = *reinterpret_cast<const float4*>(As + (size_t)(16 * m + i) * lda + 4 * h + 16 * c);
+                acc[m] = mfma16(a4.x, b.v[c].x, acc[m]);
+                acc[m] = mfma16(a4.y, b.v[c].y, acc[m]);
+                acc[m] = mfma16(a4.z, b.v[c].z, acc[m]);
+                acc[m] = mfma16(a4.w, b.v[c].w, acc[m]);
             }
         }
     }
+}
+template <int K, int MB, bool NN>
+__device__ __forceinline__ void block_product(const float* As, int lda, int mblocks, const float* W, int ldw, int n0,
+                                              int nvalid, f32x4v (&acc)[MB], int lane) {
+    const BFrag<K / 16> b = load_b<K, NN>(W, ldw, n0, nvalid, lane);
+    mul_b<K / 16, MB>(As, lda, mblocks, b, acc, lane);
 }
 // result element (block m, register r) of lane: row 16 m + 4 (lane >> 4) + r, column n0 + (lane & 15)
 
@@ -95,42 +108,80 @@ struct FusedArgs {
     int32_t* bad; int64_t* step_count;
 };
 
-// top-K of one LDS row by one wave (ties -> the lower index, like torch.topk / pc_topk_rows)
-__device__ __forceinline__ void wave_topk(const float* row, int T, int K, int lane, int* out_idx) {
-    float v[FK];
-    int ix[FK];
+// ---- wave-wide reductions on the DPP network (6 VALU instructions; the xor-shuffle form is 6 dependent LDS-crossbar
+// round trips, ~10x the latency -- and this kernel is a chain of latencies).  Fixed order: bitwise reproducible.
+template <int CTRL, int RM>
+__device__ __forceinline__ float dpp_add(float v) {
+    return v + __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, RM, 0xf, true));
+}
+__device__ __forceinline__ float wave_sum_dpp(float v) {
+    v = dpp_add<0x111, 0xf>(v);     // row_shr:1  } inclusive scan inside each row of 16 lanes: lane 15 of a row holds
+    v = dpp_add<0x112, 0xf>(v);     // row_shr:2  } the row total
+    v = dpp_add<0x114, 0xf>(v);     // row_shr:4
+    v = dpp_add<0x118, 0xf>(v);     // row_shr:8
+    v = dpp_add<0x142, 0xa>(v);     // row_bcast:15 into rows 1, 3: lane 31 = rows 0+1, lane 63 = rows 2+3
+    v = dpp_add<0x143, 0xc>(v);     // row_bcast:31 into rows 2, 3: lane 63 = everything
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
+}
+// ---- reductions inside a ROW of 16 lanes (four samples per wave side by side): an inclusive scan on the row_shr network
+// leaves the row total in lane 15 of the row in a FIXED order; every lane of the row then takes that one value (a
+// rotate-and-add all-reduce would give each lane its own association of the 16 terms: the hinge decisions of a sample
+// must not differ between its lanes).
+template <int CTRL>
+__device__ __forceinline__ float dpp_row_add(float v) {
+    return v + __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, true));
+}
+__device__ __forceinline__ float row_bcast15(float v, int g) {
+    const int x = __builtin_bit_cast(int, v);
+    const float t0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(x, 15)), t1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(x, 31));
+    const float t2 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(x, 47)), t3 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(x, 63));
+    return g == 0 ? t0 : g == 1 ? t1 : g == 2 ? t2 : t3;
+}
+__device__ __forceinline__ float row_sum(float v, int g) {
+    v = dpp_row_add<0x111>(v); v = dpp_row_add<0x112>(v); v = dpp_row_add<0x114>(v); v = dpp_row_add<0x118>(v);
+    return row_bcast15(v, g);
+}
+// max of a 64-bit key (hi, lo) over the row: max is idempotent, so the rotate network (row_ror 1, 2, 4, 8) hands every
+// lane of the row the same result directly
+template <int CTRL>
+__device__ __forceinline__ void dpp_row_maxkey(unsigned& hi, unsigned& lo) {
+    const unsigned oh = (unsigned)__builtin_amdgcn_update_dpp((int)hi, (int)hi, CTRL, 0xf, 0xf, false);
+    const unsigned ol = (unsigned)__builtin_amdgcn_update_dpp((int)lo, (int)lo, CTRL, 0xf, 0xf, false);
+    const bool gt = oh > hi || (oh == hi && ol > lo);
+    hi = gt ? oh : hi;
+    lo = gt ? ol : lo;
+}
+__device__ __forceinline__ void row_maxkey(unsigned& hi, unsigned& lo) {
+    dpp_row_maxkey<0x121>(hi, lo); dpp_row_maxkey<0x122>(hi, lo); dpp_row_maxkey<0x124>(hi, lo); dpp_row_maxkey<0x128>(hi, lo);
+}
+// order-preserving map fp32 -> uint32 (larger float <=> larger unsigned); -0.0 < +0.0 here, torch.topk treats them as
+// equal: a similarity of exactly -0.0 against +0.0 is the only case the tie rule could differ in
+__device__ __forceinline__ unsigned ord_f32(float x) {
+    const unsigned u = __float_as_uint(x);
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+
+// top-K of one LDS row of T similarities by the 16 lanes of a row group (descending; ties -> the lower index, like
+// torch.topk / pc_topk_rows): K rounds; in a round every lane scans its strided elements, skipping the earlier
+// winners, and the row takes the maximum key (value, ~index).  out[r] is the same in all 16 lanes.
+template <int KC>
+__device__ __forceinline__ void row_topk(const float* row, int T, int K, int l16, int (&out)[FK]) {
 #pragma unroll
-    for (int j = 0; j < FK; j++) { v[j] = -INFINITY; ix[j] = 0x7fffffff; }
-    for (int t = lane; t < T; t += 64) {
-        float x = row[t];
-        int xi = t;
+    for (int r = 0; r < FK; r++) out[r] = -1;
 #pragma unroll
-        for (int j = 0; j < FK; j++) {
-            if (j < K) {
-                const bool better = x > v[j] || ix[j] == 0x7fffffff;
-                const float tv = better ? v[j] : x;
-                const int ti = better ? ix[j] : xi;
-                v[j] = better ? x : v[j];
-                ix[j] = better ? xi : ix[j];
-                x = tv; xi = ti;
+    for (int r = 0; r < FK; r++) {
+        if (r < (KC ? KC : K)) {
+            unsigned bh = 0u, bl = 0u;                     // (0, 0) is below every real key
+            for (int t = l16; t < T; t += 16) {
+                const unsigned kh = ord_f32(row[t]), kl = ~(unsigned)t;
+                const bool taken = t == out[0] || t == out[1] || t == out[2] || t == out[3];
+                const bool gt = !taken && (kh > bh || (kh == bh && kl > bl));
+                bh = gt ? kh : bh;
+                bl = gt ? kl : bl;
             }
+            row_maxkey(bh, bl);
+            out[r] = (int)~bl;
         }
-    }
-    for (int r = 0; r < K; r++) {
-        float bv = v[0];
-        int bi = ix[0];
-#pragma unroll
-        for (int o = 32; o >= 1; o >>= 1) {
-            const float ov = __shfl_xor(bv, o, 64);
-            const int oi = __shfl_xor(bi, o, 64);
-            if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
-        }
-        if (ix[0] == bi) {
-#pragma unroll
-            for (int j = 0; j < FK - 1; j++) { v[j] = v[j + 1]; ix[j] = ix[j + 1]; }
-            v[FK - 1] = -INFINITY; ix[FK - 1] = 0x7fffffff;
-        }
-        out_idx[r] = bi;
     }
 }
 
@@ -138,15 +189,39 @@ __device__ __forceinline__ void wave_topk(const float* row, int T, int K, int la
 #define LD32 36
 #define LD128 132
 
+// LDS-only hand-off between the phases (no wait for this wave's outstanding global loads / stores)
+__device__ __forceinline__ void phase_sync() {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+}
+
+#ifdef PC_JOINT_TIMING
+// developer build (scripts/joint_phase_times.py): 100 MHz wall-clock stamps of wave 0 of workgroups 0 and 128 at the
+// phase boundaries of the last launch
+__device__ unsigned long long pc_joint_timing[2 * 16];
+extern "C" int pc_debug_joint_timing(unsigned long long* out) {
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(pc_joint_timing), sizeof(unsigned long long) * 32);
+}
+#define PC_STAMP(i)                                                                                      \
+    do {                                                                                                 \
+        if ((blockIdx.x == 0 || blockIdx.x == 128) && tid == 0) pc_joint_timing[(blockIdx.x ? 16 : 0) + (i)] = wall_clock64(); \
+    } while (0)
+#else
+#define PC_STAMP(i) do { } while (0)
+#endif
+
 // SIMS_LOCAL: the similarity row and its top-K are computed here (T <= T_SMALL); else read per query type
-template <bool SIMS_LOCAL>
+// KC: compile-time NUM_COMP_TYPES (3 = config.py:24; the row-block loops then carry no branches and the compiler
+// schedules the LDS reads of a whole phase ahead of its MFMAs), 0 = run-time K <= FK
+template <bool SIMS_LOCAL, int KC>
 __global__ __launch_bounds__(256) void joint_tile_kernel(FusedArgs a, int ldsims) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
     float* Tin = sm;                       // [16][LD64]   E_q rows
     float* Hs = Tin + TS * LD64;           // [16][LD32]   hidden (dropped)
     float* Cs = Hs + TS * LD32;            // [16][LD64]   complementary base
     float* Qs = Cs + TS * LD64;            // [16][LD128]  product rows
-    float* PIs = Qs + TS * LD128;          // [16][LD128]  item projection -> d(pi)
+    float* PIs = Qs + TS * LD128;          // [16][LD128]  item projection
     float* ECs = PIs + TS * LD128;         // [16 FK][LD64] selected E_c rows
     float* TPs = ECs + TS * FK * LD64;     // [16 FK][LD128] type projection -> d(tp)
     float* DCs = TPs + TS * FK * LD128;    // [16][LD64]
@@ -154,9 +229,12 @@ __global__ __launch_bounds__(256) void joint_tile_kernel(FusedArgs a, int ldsims
     int* ints = reinterpret_cast<int*>(DHs + TS * LD32);      // [16][8]: qi, qt, pos, neg, topk[4]
     float* Sims = reinterpret_cast<float*>(ints + TS * 8);    // [16][ldsims]   (SIMS_LOCAL only)
 
-    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int b0 = blockIdx.x * TS;
-    const int K = a.K;
+    const int K = KC ? KC : a.K;
+    constexpr int MBK = KC ? KC : FK;          // row blocks of the K-row products
+    PC_STAMP(0);
     if (blockIdx.x == 0 && tid == 0 && a.step_count) *a.step_count += 1;     // Adam's step (read by the finish kernel)
 
     // ---- indices of the tile: validated (the reference raises for an id outside its table, p_companion.py:48-54; here
@@ -174,35 +252,74 @@ __global__ __launch_bounds__(256) void joint_tile_kernel(FusedArgs a, int ldsims
         }
         ints[tid * 8 + 0] = qi; ints[tid * 8 + 1] = qt; ints[tid * 8 + 2] = pt; ints[tid * 8 + 3] = nt;
     }
-    __syncthreads();
-    // ---- row gathers: t = E_q[qt] (16 x 64), q = E_prod[qi] (16 x 128); rows past the batch are zero
+    // ---- every weight fragment this wave will multiply by, requested now (see load_b)
+    BFrag<4> f_h = {}, f_dh = {}, f_s0 = {}, f_s1 = {};
+    BFrag<8> f_pa = {}, f_pb = {};
+    if (w < 2) { f_h = load_b<PC_L, false>(a.enc_w, PC_L, 16 * w, LH, lane); f_dh = load_b<PC_L, true>(a.dec_w, LH, 16 * w, LH, lane); }
+    else { f_pa = load_b<PC_D, false>(a.itm_w, PC_D, 32 * (w - 2), PC_D, lane); f_pb = load_b<PC_D, false>(a.itm_w, PC_D, 32 * (w - 2) + 16, PC_D, lane); }
+    const BFrag<8> f_pc = load_b<PC_D, false>(a.itm_w, PC_D, 16 * (4 + w), PC_D, lane);
+    const BFrag<2> f_c = load_b<LH, false>(a.dec_w, LH, 16 * w, PC_L, lane);
+    const BFrag<4> f_t0 = load_b<PC_L, false>(a.typ_w, PC_L, 16 * w, PC_D, lane);
+    const BFrag<4> f_t1 = load_b<PC_L, false>(a.typ_w, PC_L, 16 * (w + 4), PC_D, lane);
+    const BFrag<8> f_dce = load_b<PC_D, true>(a.typ_w, PC_L, 16 * w, PC_L, lane);
+    const BFrag<2> f_dt = load_b<LH, true>(a.enc_w, PC_L, 16 * w, PC_L, lane);
+    if (SIMS_LOCAL) {                       // the first two of this wave's E_c column blocks (all of them for T <= 128)
+        f_s0 = load_b<PC_L, false>(a.ec, PC_L, 16 * w, a.T, lane);
+        f_s1 = load_b<PC_L, false>(a.ec, PC_L, 16 * (w + 4), a.T, lane);
+    }
+    const int ci = lane & 15, rh = lane >> 4;       // result column inside a block / row group
+    const float bias_h = w < 2 ? a.enc_b[16 * w + ci] : 0.f, bias_c = a.dec_b[16 * w + ci];
+    const float bias_pa = w >= 2 ? a.itm_b[32 * (w - 2) + ci] : 0.f, bias_pb = w >= 2 ? a.itm_b[32 * (w - 2) + 16 + ci] : 0.f;
+    const float bias_pc = a.itm_b[16 * (4 + w) + ci], bias_t0 = a.typ_b[16 * w + ci], bias_t1 = a.typ_b[16 * (w + 4) + ci];
+    phase_sync();
+    PC_STAMP(1);
+    // ---- row gathers: t = E_q[qt] (16 x 64), q = E_prod[qi] (16 x 128); rows past the batch are zero.  Also the rows of
+    // the loss phase: there a row group of 16 lanes (g = lane >> 4) owns sample 4 w + g, lane l16 its item dims
+    // [4 l16, 4 l16 + 4) and [64 + 4 l16, ...) and dims [4 l16, 4 l16 + 4) of the 64-wide type rows
+    const int g4 = lane >> 4, l16 = lane & 15;
+    const int sF = 4 * w + g4, bF = b0 + sF;
+    const bool liveF = bF < a.B;
+    float4 r_pos[2], r_neg[2], r_ep, r_en;
     {
         const int r = tid >> 4, c4 = (tid & 15) * 4;
-        const bool live = b0 + r < a.B;
         float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (live) v = *reinterpret_cast<const float4*>(a.eq + (size_t)ints[r * 8 + 1] * PC_L + c4);
+        if (b0 + r < a.B) v = *reinterpret_cast<const float4*>(a.eq + (size_t)ints[r * 8 + 1] * PC_L + c4);
+        float4 x[2];
+#pragma unroll
+        for (int u = 0; u < 2; u++) {
+            const int e = tid + 256 * u, rr = e >> 5, cc = (e & 31) * 4;
+            x[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (b0 + rr < a.B) x[u] = *reinterpret_cast<const float4*>(a.table + (size_t)ints[rr * 8 + 0] * PC_D + cc);
+        }
+        {
+            const size_t bb = liveF ? bF : 0;
+#pragma unroll
+            for (int u = 0; u < 2; u++) {
+                r_pos[u] = *reinterpret_cast<const float4*>(a.pos_items + bb * PC_D + 64 * u + 4 * l16);
+                r_neg[u] = *reinterpret_cast<const float4*>(a.neg_items + bb * PC_D + 64 * u + 4 * l16);
+            }
+            r_ep = *reinterpret_cast<const float4*>(a.ec + (size_t)ints[sF * 8 + 2] * PC_L + 4 * l16);
+            r_en = *reinterpret_cast<const float4*>(a.ec + (size_t)ints[sF * 8 + 3] * PC_L + 4 * l16);
+        }
         *reinterpret_cast<float4*>(&Tin[r * LD64 + c4]) = v;
 #pragma unroll
         for (int u = 0; u < 2; u++) {
             const int e = tid + 256 * u, rr = e >> 5, cc = (e & 31) * 4;
-            float4 x = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (b0 + rr < a.B) x = *reinterpret_cast<const float4*>(a.table + (size_t)ints[rr * 8 + 0] * PC_D + cc);
-            *reinterpret_cast<float4*>(&Qs[rr * LD128 + cc]) = x;
+            *reinterpret_cast<float4*>(&Qs[rr * LD128 + cc]) = x[u];
         }
     }
-    __syncthreads();
+    phase_sync();
+    PC_STAMP(2);
 
-    const int ci = lane & 15, rh = lane >> 4;       // result column inside a block / row group
     // ---- phase A: h = dropout(relu(enc t + b))  (waves 0, 1: one 16-column block each)   ||   pi blocks 0..3 (waves 2, 3)
     if (w < 2) {
         f32x4v acc[1] = {{0.f, 0.f, 0.f, 0.f}};
-        block_product<PC_L, 1, false>(Tin, LD64, 1, a.enc_w, PC_L, 16 * w, LH, acc, lane);
+        mul_b<4, 1>(Tin, LD64, 1, f_h, acc, lane);
         const int col = 16 * w + ci;
-        const float bias = a.enc_b[col];
 #pragma unroll
         for (int r = 0; r < 4; r++) {
             const int row = 4 * rh + r;
-            float x = acc[0][r] + bias;
+            float x = acc[0][r] + bias_h;
             x = x > 0.f ? x : 0.f;
             if (a.drop.thr) {
                 float m[4];
@@ -212,44 +329,59 @@ __global__ __launch_bounds__(256) void joint_tile_kernel(FusedArgs a, int ldsims
             Hs[row * LD32 + col] = x;
             if (b0 + row < a.B) a.h[(size_t)(b0 + row) * LH + col] = x;
         }
-    }
-    // pi = itm q + b: 8 column blocks; waves 2, 3 take two each now, the remaining four follow in phase B
-    auto pi_block = [&](int nb) {
-        f32x4v acc[1] = {{0.f, 0.f, 0.f, 0.f}};
-        block_product<PC_D, 1, false>(Qs, LD128, 1, a.itm_w, PC_D, 16 * nb, PC_D, acc, lane);
-        const int col = 16 * nb + ci;
-        const float bias = a.itm_b[col];
+    } else {
+        f32x4v acc0[1] = {{0.f, 0.f, 0.f, 0.f}}, acc1[1] = {{0.f, 0.f, 0.f, 0.f}};
+        mul_b<8, 1>(Qs, LD128, 1, f_pa, acc0, lane);
+        mul_b<8, 1>(Qs, LD128, 1, f_pb, acc1, lane);
 #pragma unroll
-        for (int r = 0; r < 4; r++) PIs[(4 * rh + r) * LD128 + col] = acc[0][r] + bias;
-    };
-    if (w >= 2) { pi_block(2 * (w - 2)); pi_block(2 * (w - 2) + 1); }
-    __syncthreads();
+        for (int r = 0; r < 4; r++) {
+            PIs[(4 * rh + r) * LD128 + 32 * (w - 2) + ci] = acc0[0][r] + bias_pa;
+            PIs[(4 * rh + r) * LD128 + 32 * (w - 2) + 16 + ci] = acc1[0][r] + bias_pb;
+        }
+    }
+    phase_sync();
+    PC_STAMP(3);
     // ---- phase B: c = dec h + b (4 blocks, one per wave), then pi blocks 4..7
     {
-        f32x4v acc[1] = {{0.f, 0.f, 0.f, 0.f}};
-        block_product<LH, 1, false>(Hs, LD32, 1, a.dec_w, LH, 16 * w, PC_L, acc, lane);
-        const int col = 16 * w + ci;
-        const float bias = a.dec_b[col];
+        f32x4v acc[1] = {{0.f, 0.f, 0.f, 0.f}}, accp[1] = {{0.f, 0.f, 0.f, 0.f}};
+        mul_b<2, 1>(Hs, LD32, 1, f_c, acc, lane);
+        mul_b<8, 1>(Qs, LD128, 1, f_pc, accp, lane);
 #pragma unroll
-        for (int r = 0; r < 4; r++) Cs[(4 * rh + r) * LD64 + col] = acc[0][r] + bias;
-        pi_block(4 + w);
+        for (int r = 0; r < 4; r++) {
+            Cs[(4 * rh + r) * LD64 + 16 * w + ci] = acc[0][r] + bias_c;
+            PIs[(4 * rh + r) * LD128 + 16 * (4 + w) + ci] = accp[0][r] + bias_pc;
+        }
     }
-    __syncthreads();
+    phase_sync();
+    PC_STAMP(4);
     // ---- phase C / D: similarities over all T types and their top-K -- or the per-type result of the dedup pass
     if (SIMS_LOCAL) {
         const int nblk = (a.T + 15) >> 4;
-        for (int nb = w; nb < nblk; nb += 4) {
+        {
+            f32x4v acc0[1] = {{0.f, 0.f, 0.f, 0.f}}, acc1[1] = {{0.f, 0.f, 0.f, 0.f}};
+            if (w < nblk) mul_b<4, 1>(Cs, LD64, 1, f_s0, acc0, lane);
+            if (w + 4 < nblk) mul_b<4, 1>(Cs, LD64, 1, f_s1, acc1, lane);
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                if (w < nblk) Sims[(4 * rh + r) * ldsims + 16 * w + ci] = acc0[0][r];
+                if (w + 4 < nblk) Sims[(4 * rh + r) * ldsims + 16 * (w + 4) + ci] = acc1[0][r];
+            }
+        }
+        for (int nb = w + 8; nb < nblk; nb += 4) {
             f32x4v acc[1] = {{0.f, 0.f, 0.f, 0.f}};
             block_product<PC_L, 1, false>(Cs, LD64, 1, a.ec, PC_L, 16 * nb, a.T, acc, lane);
 #pragma unroll
             for (int r = 0; r < 4; r++) Sims[(4 * rh + r) * ldsims + 16 * nb + ci] = acc[0][r];
         }
-        __syncthreads();
-        for (int s = w; s < TS; s += 4) {
+        phase_sync();
+        PC_STAMP(5);
+        {
             int idx[FK];
-            wave_topk(Sims + s * ldsims, a.T, K, lane, idx);
-            if (lane == 0)
-                for (int k = 0; k < K; k++) ints[s * 8 + 4 + k] = idx[k];
+            row_topk<KC>(Sims + sF * ldsims, a.T, K, l16, idx);
+            if (l16 == 0)
+#pragma unroll
+                for (int k = 0; k < FK; k++)
+                    if (k < K) ints[sF * 8 + 4 + k] = idx[k];
         }
     } else {
         if (tid < TS * FK) {
@@ -257,11 +389,11 @@ __global__ __launch_bounds__(256) void joint_tile_kernel(FusedArgs a, int ldsims
             if (k < K) ints[s * 8 + 4 + k] = b0 + s < a.B ? a.topk_by_type[(size_t)ints[s * 8 + 1] * K + k] : 0;
         }
     }
-    __syncthreads();
-    // selected rows e_k = E_c[top_k]: 16 K rows of 64 floats, row index s * FK + k (blocks of 16 rows = 4 samples x FK...
-    // the MFMA row blocks below are over ROW ids, any assignment works: row = k * 16 + s keeps one block per k)
+    phase_sync();
+    PC_STAMP(6);
+    // selected rows e_k = E_c[top_k]: 16 K rows of 64 floats; LDS row = k * 16 + s keeps one MFMA row block per k
     for (int e = tid; e < TS * K * 16; e += 256) {
-        const int row = e >> 4, c4 = (e & 15) * 4;        // row = k * 16 + s
+        const int row = e >> 4, c4 = (e & 15) * 4;
         const int s = row & 15, k = row >> 4;
         const int t = ints[s * 8 + 4 + k];
         *reinterpret_cast<float4*>(&ECs[row * LD64 + c4]) = *reinterpret_cast<const float4*>(a.ec + (size_t)t * PC_L + c4);
@@ -270,86 +402,112 @@ __global__ __launch_bounds__(256) void joint_tile_kernel(FusedArgs a, int ldsims
             a.ecidx[(size_t)(b0 + s) * K + k] = t;
         }
     }
-    __syncthreads();
+    phase_sync();
+    PC_STAMP(7);
     // ---- phase E: tp_k = typ e_k + b: K row blocks x 8 column blocks; a wave takes column blocks w and w + 4
+    {
+        f32x4v acc0[MBK], acc1[MBK];
 #pragma unroll
-    for (int u = 0; u < 2; u++) {
-        const int nb = w + 4 * u;
-        f32x4v acc[FK];
+        for (int m = 0; m < MBK; m++) { acc0[m] = f32x4v{0.f, 0.f, 0.f, 0.f}; acc1[m] = f32x4v{0.f, 0.f, 0.f, 0.f}; }
+        mul_b<4, MBK>(ECs, LD64, K, f_t0, acc0, lane);
+        mul_b<4, MBK>(ECs, LD64, K, f_t1, acc1, lane);
 #pragma unroll
-        for (int m = 0; m < FK; m++) acc[m] = f32x4v{0.f, 0.f, 0.f, 0.f};
-        block_product<PC_L, FK, false>(ECs, LD64, K, a.typ_w, PC_L, 16 * nb, PC_D, acc, lane);
-        const int col = 16 * nb + ci;
-        const float bias = a.typ_b[col];
-#pragma unroll
-        for (int m = 0; m < FK; m++)
+        for (int m = 0; m < MBK; m++)
             if (m < K)
 #pragma unroll
-                for (int r = 0; r < 4; r++) TPs[(16 * m + 4 * rh + r) * LD128 + col] = acc[m][r] + bias;
+                for (int r = 0; r < 4; r++) {
+                    TPs[(16 * m + 4 * rh + r) * LD128 + 16 * w + ci] = acc0[m][r] + bias_t0;
+                    TPs[(16 * m + 4 * rh + r) * LD128 + 16 * (w + 4) + ci] = acc1[m][r] + bias_t1;
+                }
     }
-    __syncthreads();
-    // ---- phase F: per sample (one wave, lane = dims 2 lane, 2 lane + 1): proj_k = pi * tp_k, both hinges, d(proj) -> d(pi),
-    // d(tp_k) (in place), the two-column type hinge -> dc and the two dE_c rows it touches
-    for (int s = w; s < TS; s += 4) {
-        const int b = b0 + s;
-        if (b >= a.B) {                                            // dead row of the last tile: zero operands downstream
-            for (int k = 0; k < K; k++) *reinterpret_cast<float2*>(&TPs[(16 * k + s) * LD128 + 2 * lane]) = make_float2(0.f, 0.f);
-            DCs[s * LD64 + lane] = 0.f;
-            continue;
+    phase_sync();
+    PC_STAMP(8);
+    // ---- phase F: per sample (a row group of 16 lanes each, four samples per wave side by side): proj_k = pi * tp_k, both
+    // hinges, d(proj) -> d(pi), d(tp_k) (in place), the two-column type hinge -> dc and the two dE_c rows it touches
+    {
+        const int pt = ints[sF * 8 + 2], nt = ints[sF * 8 + 3];
+        const float4 cb = *reinterpret_cast<const float4*>(&Cs[sF * LD64 + 4 * l16]);
+        float sp, sn;
+        if (SIMS_LOCAL) { sp = Sims[sF * ldsims + pt]; sn = Sims[sF * ldsims + nt]; }
+        else {
+            sp = row_sum(cb.x * r_ep.x + cb.y * r_ep.y + cb.z * r_ep.z + cb.w * r_ep.w, g4);
+            sn = row_sum(cb.x * r_en.x + cb.y * r_en.y + cb.z * r_en.z + cb.w * r_en.w, g4);
         }
-        const int pt = ints[s * 8 + 2], nt = ints[s * 8 + 3];
-        const float cb = Cs[s * LD64 + lane];
-        float sp = 0.f, sn = 0.f;
-        if (SIMS_LOCAL) { sp = Sims[s * ldsims + pt]; sn = Sims[s * ldsims + nt]; }
-        const float ep = a.ec[(size_t)pt * PC_L + lane], en = a.ec[(size_t)nt * PC_L + lane];
-        if (!SIMS_LOCAL) { sp = wave_sum(cb * ep); sn = wave_sum(cb * en); }
         const float lt = a.margin - sp + sn;
-        const float gt = lt > 0.f ? a.g_type : 0.f;
-        DCs[s * LD64 + lane] = gt * (en - ep);
-        a.dc[(size_t)b * PC_L + lane] = gt * (en - ep);
-        a.ecsrc[((size_t)a.B * K + b) * PC_L + lane] = -gt * cb;               // -> dE_c[pos]
-        a.ecsrc[((size_t)a.B * (K + 1) + b) * PC_L + lane] = gt * cb;          // -> dE_c[neg]
-        const float2 pa = *reinterpret_cast<const float2*>(&PIs[s * LD128 + 2 * lane]);
-        const float2 pp = *reinterpret_cast<const float2*>(a.pos_items + (size_t)b * PC_D + 2 * lane);
-        const float2 nn = *reinterpret_cast<const float2*>(a.neg_items + (size_t)b * PC_D + 2 * lane);
-        float li = 0.f;
-        float2 acc = make_float2(0.f, 0.f);
-        for (int k = 0; k < K; k++) {
-            float* tpp = &TPs[(16 * k + s) * LD128 + 2 * lane];
-            const float2 t = *reinterpret_cast<const float2*>(tpp);
-            const float2 x = make_float2(pa.x * t.x, pa.y * t.y);
-            const float2 dp = make_float2(x.x - pp.x, x.y - pp.y), dn = make_float2(x.x - nn.x, x.y - nn.y);
-            const float np_ = sqrtf(wave_sum(dp.x * dp.x + dp.y * dp.y));
-            const float nn_ = sqrtf(wave_sum(dn.x * dn.x + dn.y * dn.y));
-            const float l = a.margin - np_ + nn_;
-            li += l > 0.f ? l : 0.f;
-            const float g = l > 0.f ? a.g_item : 0.f;
-            const float ip = np_ > 0.f ? g / np_ : 0.f, in = nn_ > 0.f ? g / nn_ : 0.f;   // torch.norm: subgradient 0 at 0
-            const float2 d = make_float2(-dp.x * ip + dn.x * in, -dp.y * ip + dn.y * in);
-            acc.x += d.x * t.x; acc.y += d.y * t.y;
-            const float2 dt2 = make_float2(d.x * pa.x, d.y * pa.y);
-            *reinterpret_cast<float2*>(tpp) = dt2;
-            *reinterpret_cast<float2*>(a.dtp + ((size_t)b * K + k) * PC_D + 2 * lane) = dt2;
+        const float gt = (liveF && lt > 0.f) ? a.g_type : 0.f;
+        const float4 dcv = make_float4(gt * (r_en.x - r_ep.x), gt * (r_en.y - r_ep.y), gt * (r_en.z - r_ep.z), gt * (r_en.w - r_ep.w));
+        *reinterpret_cast<float4*>(&DCs[sF * LD64 + 4 * l16]) = dcv;
+        float4 pa[2];
+#pragma unroll
+        for (int u = 0; u < 2; u++) pa[u] = *reinterpret_cast<const float4*>(&PIs[sF * LD128 + 64 * u + 4 * l16]);
+        float4 t[MBK][2], dp[MBK][2], dn[MBK][2];
+        float np_[MBK], nn_[MBK];
+#pragma unroll
+        for (int k = 0; k < MBK; k++) {
+            np_[k] = nn_[k] = 0.f;
+            if (k < K) {
+#pragma unroll
+                for (int u = 0; u < 2; u++) {
+                    t[k][u] = *reinterpret_cast<const float4*>(&TPs[(16 * k + sF) * LD128 + 64 * u + 4 * l16]);
+                    const float4 x = make_float4(pa[u].x * t[k][u].x, pa[u].y * t[k][u].y, pa[u].z * t[k][u].z, pa[u].w * t[k][u].w);
+                    dp[k][u] = make_float4(x.x - r_pos[u].x, x.y - r_pos[u].y, x.z - r_pos[u].z, x.w - r_pos[u].w);
+                    dn[k][u] = make_float4(x.x - r_neg[u].x, x.y - r_neg[u].y, x.z - r_neg[u].z, x.w - r_neg[u].w);
+                    np_[k] += dp[k][u].x * dp[k][u].x + dp[k][u].y * dp[k][u].y + dp[k][u].z * dp[k][u].z + dp[k][u].w * dp[k][u].w;
+                    nn_[k] += dn[k][u].x * dn[k][u].x + dn[k][u].y * dn[k][u].y + dn[k][u].z * dn[k][u].z + dn[k][u].w * dn[k][u].w;
+                }
+            }
         }
-        *reinterpret_cast<float2*>(a.dpi + (size_t)b * PC_D + 2 * lane) = acc;
-        if (lane == 0) {
-            a.part_type[b] = lt > 0.f ? lt : 0.f;
-            a.part_item[b] = li;
-            a.ecidx[(size_t)a.B * K + b] = pt;
-            a.ecidx[(size_t)a.B * (K + 1) + b] = nt;
+#pragma unroll
+        for (int k = 0; k < MBK; k++)
+            if (k < K) { np_[k] = sqrtf(row_sum(np_[k], g4)); nn_[k] = sqrtf(row_sum(nn_[k], g4)); }
+        float li = 0.f;
+        float4 acc[2] = {make_float4(0.f, 0.f, 0.f, 0.f), make_float4(0.f, 0.f, 0.f, 0.f)};
+#pragma unroll
+        for (int k = 0; k < MBK; k++)
+            if (k < K) {
+                const float l = a.margin - np_[k] + nn_[k];
+                li += l > 0.f ? l : 0.f;
+                const float g = (liveF && l > 0.f) ? a.g_item : 0.f;
+                const float ip = np_[k] > 0.f ? g / np_[k] : 0.f, in = nn_[k] > 0.f ? g / nn_[k] : 0.f;   // torch.norm: subgradient 0 at 0
+#pragma unroll
+                for (int u = 0; u < 2; u++) {
+                    const float4 d = make_float4(-dp[k][u].x * ip + dn[k][u].x * in, -dp[k][u].y * ip + dn[k][u].y * in,
+                                                 -dp[k][u].z * ip + dn[k][u].z * in, -dp[k][u].w * ip + dn[k][u].w * in);
+                    acc[u].x += d.x * t[k][u].x; acc[u].y += d.y * t[k][u].y; acc[u].z += d.z * t[k][u].z; acc[u].w += d.w * t[k][u].w;
+                    const float4 dt4 = make_float4(d.x * pa[u].x, d.y * pa[u].y, d.z * pa[u].z, d.w * pa[u].w);
+                    // (a dead row of the last tile carries g = 0: zero operands for the products downstream)
+                    *reinterpret_cast<float4*>(&TPs[(16 * k + sF) * LD128 + 64 * u + 4 * l16]) = dt4;
+                    if (liveF) *reinterpret_cast<float4*>(a.dtp + ((size_t)bF * K + k) * PC_D + 64 * u + 4 * l16) = dt4;
+                }
+            }
+        if (liveF) {
+            *reinterpret_cast<float4*>(a.dc + (size_t)bF * PC_L + 4 * l16) = dcv;
+            *reinterpret_cast<float4*>(a.ecsrc + ((size_t)a.B * K + bF) * PC_L + 4 * l16) =
+                make_float4(-gt * cb.x, -gt * cb.y, -gt * cb.z, -gt * cb.w);                       // -> dE_c[pos]
+            *reinterpret_cast<float4*>(a.ecsrc + ((size_t)a.B * (K + 1) + bF) * PC_L + 4 * l16) =
+                make_float4(gt * cb.x, gt * cb.y, gt * cb.z, gt * cb.w);                           // -> dE_c[neg]
+#pragma unroll
+            for (int u = 0; u < 2; u++) *reinterpret_cast<float4*>(a.dpi + (size_t)bF * PC_D + 64 * u + 4 * l16) = acc[u];
+            if (l16 == 0) {
+                a.part_type[bF] = lt > 0.f ? lt : 0.f;
+                a.part_item[bF] = li;
+                a.ecidx[(size_t)a.B * K + bF] = pt;
+                a.ecidx[(size_t)a.B * (K + 1) + bF] = nt;
+            }
         }
     }
-    __syncthreads();
+    phase_sync();
+    PC_STAMP(9);
     // ---- phase G: dce_k = dtp_k typ_w (K row blocks x 4 column blocks: wave w takes column block w) -> the dE_c rows of
     // the selected types; dh = (dc dec_w) relu' dropout' (waves 0, 1)
     {
-        f32x4v acc[FK];
+        f32x4v acc[MBK];
 #pragma unroll
-        for (int m = 0; m < FK; m++) acc[m] = f32x4v{0.f, 0.f, 0.f, 0.f};
-        block_product<PC_D, FK, true>(TPs, LD128, K, a.typ_w, PC_L, 16 * w, PC_L, acc, lane);
+        for (int m = 0; m < MBK; m++) acc[m] = f32x4v{0.f, 0.f, 0.f, 0.f};
+        mul_b<8, MBK>(TPs, LD128, K, f_dce, acc, lane);
         const int col = 16 * w + ci;
 #pragma unroll
-        for (int m = 0; m < FK; m++)
+        for (int m = 0; m < MBK; m++)
             if (m < K)
 #pragma unroll
                 for (int r = 0; r < 4; r++) {
@@ -359,7 +517,7 @@ __global__ __launch_bounds__(256) void joint_tile_kernel(FusedArgs a, int ldsims
     }
     if (w < 2) {
         f32x4v acc[1] = {{0.f, 0.f, 0.f, 0.f}};
-        block_product<PC_L, 1, true>(DCs, LD64, 1, a.dec_w, LH, 16 * w, LH, acc, lane);
+        mul_b<4, 1>(DCs, LD64, 1, f_dh, acc, lane);
         const int col = 16 * w + ci;
 #pragma unroll
         for (int r = 0; r < 4; r++) {
@@ -371,11 +529,12 @@ __global__ __launch_bounds__(256) void joint_tile_kernel(FusedArgs a, int ldsims
             if (b0 + row < a.B) a.dh[(size_t)(b0 + row) * LH + col] = x;
         }
     }
-    __syncthreads();
+    phase_sync();
+    PC_STAMP(10);
     // ---- phase H: dt = dh enc_w (4 column blocks, one per wave) -> the dE_q rows
     {
         f32x4v acc[1] = {{0.f, 0.f, 0.f, 0.f}};
-        block_product<LH, 1, true>(DHs, LD32, 1, a.enc_w, PC_L, 16 * w, PC_L, acc, lane);
+        mul_b<2, 1>(DHs, LD32, 1, f_dt, acc, lane);
         const int col = 16 * w + ci;
 #pragma unroll
         for (int r = 0; r < 4; r++) {
@@ -383,6 +542,7 @@ __global__ __launch_bounds__(256) void joint_tile_kernel(FusedArgs a, int ldsims
             if (b0 + row < a.B) a.dt[(size_t)(b0 + row) * PC_L + col] = acc[0][r];
         }
     }
+    PC_STAMP(11);
 }
 
 static size_t tile_lds_bytes(int T, bool sims_local) {
@@ -453,10 +613,13 @@ __global__ __launch_bounds__(256) void type_sims_topk_kernel(TypeSimsArgs a) {
     float* Sims = Cs + UT * LD64;           // [64][TC + 4]
     constexpr int LDS_ = TC + 4;
     const int nu = *a.n_u;
-    const int u0 = blockIdx.y * UT;
-    if (u0 >= nu) return;
     const int t0 = blockIdx.x * TC;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, ci = lane & 15, rh = lane >> 4;
+    // the number of listed query types is known to the device only: a workgroup walks the tiles of 64 of them with stride
+    // gridDim.y (a grid sized for the worst case, one workgroup per possible tile, spends more time dispatching workgroups
+    // that find nothing to do -- each holds 110 KB of LDS -- than the product takes)
+    for (int u0 = blockIdx.y * UT; u0 < nu; u0 += gridDim.y * UT) {
+    __syncthreads();
     for (int e = tid; e < UT * 16; e += 256) {
         const int r = e >> 4, c4 = (e & 15) * 4;
         float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -543,6 +706,7 @@ __global__ __launch_bounds__(256) void type_sims_topk_kernel(TypeSimsArgs a) {
                 a.part_idx[o] = bi;
             }
         }
+    }
     }
 }
 
@@ -637,8 +801,10 @@ __global__ __launch_bounds__(256) void joint_finish_kernel(FinishArgs a) {
     for (int i = 1; i < FIN_JOBS; i++) j += (i < a.njobs && b >= a.block0[i]) ? 1 : 0;
     const FinishJob& jb = a.job[j];
     // eight lanes share one float4 of outputs: lane g sums slabs g, g + 8, ...; the partial sums fold in a fixed xor order
+    // (a job whose gradient is complete already -- nsplit == 0 -- gives every lane its own float4: pure streaming)
     const int t = (b - a.block0[j]) * 256 + threadIdx.x;
-    const int j4 = t >> 3, g = t & 7;
+    const bool direct = jb.nsplit == 0;
+    const int j4 = direct ? t : t >> 3, g = direct ? 0 : t & 7;
     if (j4 * 4 >= jb.n) return;
     float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
     if (jb.nsplit > 0) {
@@ -781,7 +947,8 @@ extern "C" int pc_joint_fused_step(const pc_joint_tensors* p, const pc_joint_ten
         static const hipError_t attr0 = hipFuncSetAttribute(reinterpret_cast<const void*>(&type_sims_topk_kernel),
                                                             hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         (void)attr0;
-        PC_LAUNCH(type_sims_topk_kernel, dim3(w.nchunks, (w.ucap + UT - 1) / UT), dim3(256), lds, st, ta);
+        const int ytiles = (w.ucap + UT - 1) / UT;
+        PC_LAUNCH(type_sims_topk_kernel, dim3(w.nchunks, ytiles < 4 ? ytiles : 4), dim3(256), lds, st, ta);
         PC_LAUNCH(type_topk_merge_kernel, dim3((w.ucap + 3) / 4), dim3(256), 0, st, w.part_val, w.part_idx, w.ulist, w.n_u,
                   w.nchunks, K, w.topk_by_type);
         PC_TRY(pc_launch_status());
@@ -803,13 +970,16 @@ extern "C" int pc_joint_fused_step(const pc_joint_tensors* p, const pc_joint_ten
     const int tiles = (B + TS - 1) / TS;
     const int ldsims = w.small ? ((T + 15) / 16 * 16 + 4) : 0;
     const size_t lds = tile_lds_bytes(T, w.small);
-    static const hipError_t attr1 = hipFuncSetAttribute(reinterpret_cast<const void*>(&joint_tile_kernel<true>),
-                                                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    static const hipError_t attr2 = hipFuncSetAttribute(reinterpret_cast<const void*>(&joint_tile_kernel<false>),
-                                                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    (void)attr1; (void)attr2;
-    if (w.small) PC_LAUNCH(joint_tile_kernel<true>, dim3(tiles), dim3(256), lds, st, fa, ldsims);
-    else PC_LAUNCH(joint_tile_kernel<false>, dim3(tiles), dim3(256), lds, st, fa, ldsims);
+    static const hipError_t attr[4] = {
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&joint_tile_kernel<true, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024),
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&joint_tile_kernel<true, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024),
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&joint_tile_kernel<false, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024),
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&joint_tile_kernel<false, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)};
+    (void)attr;
+    if (w.small && K == 3) PC_LAUNCH((joint_tile_kernel<true, 3>), dim3(tiles), dim3(256), lds, st, fa, ldsims);
+    else if (w.small) PC_LAUNCH((joint_tile_kernel<true, 0>), dim3(tiles), dim3(256), lds, st, fa, ldsims);
+    else if (K == 3) PC_LAUNCH((joint_tile_kernel<false, 3>), dim3(tiles), dim3(256), lds, st, fa, ldsims);
+    else PC_LAUNCH((joint_tile_kernel<false, 0>), dim3(tiles), dim3(256), lds, st, fa, ldsims);
     PC_TRY(pc_launch_status());
 
     // ---- gradient products over the row buffers: one grouped launch, slabs summed by the finish kernel
@@ -873,7 +1043,7 @@ extern "C" int pc_joint_fused_step(const pc_joint_tensors* p, const pc_joint_ten
         FinishJob& j = fin.job[nj];
         j.slabs = slabs; j.stride = stride; j.nsplit = nsplit; j.n = n; j.grad = grad; j.param = param; j.m = m; j.v = v;
         fin.block0[nj++] = blocks;
-        blocks += (n / 4 * 8 + 255) / 256;
+        blocks += nsplit > 0 ? (n / 4 * 8 + 255) / 256 : (n / 4 + 255) / 256;
     };
     for (int i = 0; i < nt; i++) {
         const int n_w = tn[i].No * tn[i].Ni, n_b = tn[i].No;
