@@ -282,13 +282,14 @@ def run_p2v(args, rank, world, dev, products, steps, warmup, want_cpu, profile_k
     model.train()
     opt = FusedAdam(model, lr=cfg.LEARNING_RATE)
     flat, gflat = model.flatten_parameters()
-    loader = SimilarityIndexLoader(bpg, args.batch, shuffle=True, sampler="philox", seed=1 + rank, drop_last=True,
-                                   device=dev)
     table = bpg.cuda(dev)["features"]
     sharded = None
     if args.table == "sharded":
+        # row r on rank r % world; the loader runs the per-batch exchange on its side stream, one batch ahead
         sharded = pdist.ShardedFeatureTable(pdist.ShardedFeatureTable.shard(table, rank, world), bpg.num_products,
                                             rank, world)
+    loader = SimilarityIndexLoader(bpg, args.batch, shuffle=True, sampler="philox", seed=1 + rank, drop_last=True,
+                                   device=dev, sharded=sharded)
 
     def batches():
         while True:
@@ -302,9 +303,7 @@ def run_p2v(args, rank, world, dev, products, steps, warmup, want_cpu, profile_k
     n_sum = real_sum = slot_sum = 0
 
     def step(b, profile=None):
-        tab = table
-        if sharded is not None:
-            tab, b = sharded.lookup_batch(b)
+        tab = b.get("table", table)                       # sharded: the rows this batch's exchange delivered
         sync = (lambda t: torch.distributed.all_reduce(t)) if (args.sync_bn and world > 1) else None
         loss = model.train_step_indexed(tab, b, profile=profile, sync_reduce=sync)
         pdist.all_reduce_mean_(gflat, world)
@@ -333,6 +332,8 @@ def run_p2v(args, rank, world, dev, products, steps, warmup, want_cpu, profile_k
     if world > 1:
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
     el = float(t)
+    if sharded is not None:
+        sharded.raise_if_overflowed()
     if rank != 0:
         return None
 
@@ -342,6 +343,8 @@ def run_p2v(args, rank, world, dev, products, steps, warmup, want_cpu, profile_k
     value = world * args.batch * steps / el
     res = {"value": value, "ms_per_step": 1e3 * el / steps, "n_avg": n_avg, "final_loss": float(loss),
            "distinct_neighbour_rows": rows_avg, "real_neighbour_slots": slots_avg,
+           "sharded_lookup": ({"capacity_rows_per_peer": sharded.capacity, "bytes_per_peer_and_step": sharded.bytes_per_peer,
+                               "host_syncs_per_step": 0} if sharded is not None else None),
            "rows_saved_by_duplicate_neighbours": round(1.0 - (7 * args.batch + rows_avg + 1) / (7 * args.batch + slots_avg + 1), 4)}
     if profile_kernels:
         nt = prof.summary("gemm_nt_kernel")
@@ -386,7 +389,7 @@ def run_p2v(args, rank, world, dev, products, steps, warmup, want_cpu, profile_k
                            "reference_equivalent_flops_per_triplet": flops_per_triplet(round(n_avg)),
                            "gather_bytes_per_triplet": bytes_per_triplet(round(n_avg)),
                            "frac_hbm_gather": round(bytes_per_triplet(n_avg) * value / world / 1e9 / HBM_PEAK_GBS, 5)}}
-    if want_cpu:
+    if want_cpu and sharded is None:                  # (a sharded batch holds indices over its own gathered table)
         res["cpu_baseline"] = p2v_cpu_baseline(bpg, last)
     prof.close()
     return res
@@ -456,7 +459,7 @@ def main():
            "config": {"workload": f"Product2Vec GAT pretrain, {args.products} products, {args.types} types, dim=128, "
                                   f"batch={args.batch}/GPU, 5 negatives, neighbours padded to batch max "
                                   f"(avg N={p2v['n_avg']:.1f})", "global_batch": world * args.batch,
-                      "table": args.table, "parallelism": f"dp{world}",
+                      "table": args.table, "sharded_lookup": p2v.get("sharded_lookup"), "parallelism": f"dp{world}",
                       "batchnorm": "cross-replica" if (args.sync_bn and world > 1) else "per-replica",
                       "final_loss": round(p2v["final_loss"], 5),
                       "neighbour_rows": "identical rows of the neighbour call carried once: avg %.0f distinct products (%.0f "

@@ -482,6 +482,20 @@ int pc_scatter_rows(float *out, const int32_t *idx, int rows, int width, const f
  * (F.relu of type_transition.py:17 in module mode). */
 int pc_act_backward(const float *dy, const float *y, size_t n, int act, float *dx, void *stream);
 
+/* Row-sharded feature table, device-resident request bucketing (north_star: "embedding table row-shards across up
+ * to 8 MI355X with RCCL all-to-all for cross-shard lookups"; the reference's table is one in-process dict,
+ * src/data/bpg.py:4-22, data_loader.py:50-55).  Product r lives on rank r % world as local row r / world.
+ * Up to `count` <= 4 id arrays ids[a][n[a]] (global product ids, < 0 = padding; only the first *n_dev[a] + n_dev_add[a]
+ * entries are live when n_dev[a] != NULL -- the unique-neighbour list's length exists on the device only) become
+ *   send_ids[world][capacity]   per-owner request lists (local row indices; unused slots -1), and
+ *   remap_out[a][n[a]]          the same arrays as indices into the [world][capacity][D] buffer the exchange returns
+ *                               (row = owner * capacity + slot; padding and non-live entries -> -1).
+ * counts[world] receives the bucket sizes; *overflow is incremented for every id that did not fit its bucket (that id
+ * maps to -1).  Nothing is read back to the host: shapes are constant, the two all-to-all rounds need no size exchange. */
+int pc_shard_bucket(const int32_t *const *ids, const int *n, const int32_t *const *n_dev, const int *n_dev_add,
+                    int32_t *const *remap_out, int count, int world, int capacity, int32_t *counts,
+                    int32_t *send_ids, int32_t *overflow, void *stream);
+
 /* nn.Dropout of ComplementaryTypeTransition (type_transition.py:13,17) in training mode on the hidden activations
  * x[n] (n % 4 == 0, rows of 32): y = x * mask, mask = stream 1 of pc_dropout (0 or 1/(1-p)).  The same call with the
  * same (seed, offset) is its backward (dx = dy * mask).  In place (y == x) allowed.  0 < p < 1. */

@@ -321,6 +321,72 @@ extern "C" int pc_act_backward(const float* dy, const float* y, size_t n, int ac
 }
 
 // ---------------------------------------------------------------------------------------
+// Row-sharded feature table: product r lives on rank r % G as local row r / G.  One launch turns
+// the id arrays of a batch into (a) per-owner request lists of FIXED capacity C -- send_ids[G][C], local row indices,
+// unused slots stay -1 -- and (b) the batch's indices over the table the exchange will deliver, row = owner * C + slot
+// of the [G][C][D] receive buffer.  Everything stays on the device: no counts travel to the host, the two all-to-all
+// rounds have constant shapes.  Slots are handed out by wave-aggregated integer atomics (one per wave and owner): the
+// slot ORDER varies run to run, the rows the indices resolve to do not.  A bucket that would exceed C sets *overflow
+// and maps the id to -1 (the caller checks the flag when it synchronises anyway and enlarges C).
+struct ShardJobs { const int32_t* ids[4]; int32_t* out[4]; int n[4]; const int32_t* n_dev[4]; int n_dev_add[4]; int count; };
+__global__ __launch_bounds__(256) void shard_bucket_kernel(ShardJobs j, int G, int C, int32_t* counts, int32_t* send_ids,
+                                                           int32_t* overflow) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    const int lane = threadIdx.x & 63;
+    // which array and position (the arrays are walked as one virtual concatenation of their CAPACITIES)
+    int a = 0, pos = t;
+#pragma unroll
+    for (int i = 0; i < 3; i++)
+        if (a == i && i + 1 < j.count && pos >= j.n[i]) { pos -= j.n[i]; a = i + 1; }
+    const bool inside = a < j.count && pos < j.n[a];
+    int id = -1;
+    if (inside) {
+        const int live = j.n_dev[a] ? min(j.n[a], *j.n_dev[a] + j.n_dev_add[a]) : j.n[a];     // entries past it are scratch
+        if (pos < live) id = j.ids[a][pos];
+    }
+    const int owner = id >= 0 ? id % G : -1;
+    int slot = -1;
+    for (int o = 0; o < G; o++) {                          // wave-uniform loop: one atomic per wave and owner
+        const unsigned long long m = __ballot(owner == o);
+        if (m == 0ull) continue;
+        const int leader = __ffsll((long long)m) - 1;
+        int base = 0;
+        if (lane == leader) base = atomicAdd(&counts[o], __popcll(m));
+        base = __shfl(base, leader, 64);
+        if (owner == o) slot = base + __popcll(m & ((1ull << lane) - 1ull));
+    }
+    if (!inside) return;
+    int r = -1;
+    if (id >= 0) {
+        if (slot < C) { send_ids[(size_t)owner * C + slot] = id / G; r = owner * C + slot; }
+        else atomicAdd(overflow, 1);
+    }
+    j.out[a][pos] = r;
+}
+
+extern "C" int pc_shard_bucket(const int32_t* const* ids, const int* n, const int32_t* const* n_dev, const int* n_dev_add,
+                               int32_t* const* remap_out, int count, int world, int capacity, int32_t* counts,
+                               int32_t* send_ids, int32_t* overflow, void* stream) {
+    if (!ids || !n || !remap_out || !counts || !send_ids || !overflow || count < 1 || count > 4 || world < 1 || capacity < 1)
+        return PC_EINVAL;
+    ShardJobs j = {};
+    long total = 0;
+    for (int a = 0; a < count; a++) {
+        if (!ids[a] || !remap_out[a] || n[a] <= 0) return PC_EINVAL;
+        j.ids[a] = ids[a]; j.out[a] = remap_out[a]; j.n[a] = n[a];
+        j.n_dev[a] = n_dev ? n_dev[a] : nullptr; j.n_dev_add[a] = n_dev_add ? n_dev_add[a] : 0;
+        total += n[a];
+    }
+    j.count = count;
+    hipStream_t st = (hipStream_t)stream;
+    PC_HIP_TRY(hipMemsetAsync(counts, 0, (size_t)world * sizeof(int32_t), st));
+    PC_HIP_TRY(hipMemsetAsync(send_ids, 0xff, (size_t)world * capacity * sizeof(int32_t), st));       // -1 = no request
+    PC_LAUNCH(shard_bucket_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, j, world, capacity, counts,
+              send_ids, overflow);
+    return pc_launch_status();
+}
+
+// ---------------------------------------------------------------------------------------
 // nn.Dropout (type_transition.py:13,17) on a flat fp32 tensor: y[e] = x[e] * m[e], m = the counter-based mask of
 // common.h (0 or 1/(1-p)).  Its own backward (dx = dy * m with the same seed / offset).  One 16-B group per thread.
 __global__ void dropout_kernel(const float* x, size_t n4, DropCfg drop, unsigned stream, float* y) {

@@ -169,7 +169,7 @@ class SimilarityIndexLoader:
     """
 
     def __init__(self, bpg: IntBPG, batch_size: int, shuffle=True, sampler="philox", seed=0, k_neg=5,
-                 drop_last=False, device="cuda", compact=True, prefetch=True, unique=True):
+                 drop_last=False, device="cuda", compact=True, prefetch=True, unique=True, sharded=None):
         from . import ops
         self.ops = ops
         self.bpg = bpg
@@ -190,6 +190,9 @@ class SimilarityIndexLoader:
         self.prefetch = prefetch and sampler == "philox" and torch.device(device).type == "cuda"
         self.epoch = 0
         self.step = 0
+        self.sharded = sharded          # distributed.ShardedFeatureTable: batches then carry their own gathered `table`
+        if sharded is not None and not (compact and sampler == "philox"):
+            raise ValueError("the sharded lookup consumes the compact / unique neighbour layouts of the device sampler")
         self.g = bpg.cuda(device)
         if sampler == "cpython":
             self.rng = ops.CPythonRandom(seed)
@@ -235,6 +238,7 @@ class SimilarityIndexLoader:
                     host_n = torch.empty(1, dtype=torch.int32).pin_memory()
                     host_n.copy_(nbc["n_unique"], non_blocking=True)
                     ev = torch.cuda.Event(); ev.record(torch.cuda.current_stream(self.device))
+                    nbc["n_unique_dev"] = nbc["n_unique"]              # [1] int32 on the device (the sharded lookup reads it there)
                     nbc["n_unique"] = _LazyCount(host_n, ev)
                     nbc["n_real"] = n_real
                 else:
@@ -262,6 +266,11 @@ class SimilarityIndexLoader:
                     batch["neighbor_compact"] = self.ops.compact_neighbors(nb)
             if nbc is not None:
                 batch["neighbor_compact"] = nbc
+            if self.sharded is not None:
+                # row-sharded table: the two all-to-all rounds of this batch's rows run here, on the builder's stream,
+                # one batch ahead of the step that consumes them (they overlap the previous step's kernels)
+                tab, remapped = self.sharded.lookup_batch(batch)
+                batch = dict(remapped, table=tab, n_pad=n_pad)
             return batch
 
         n = len(self)

@@ -45,40 +45,108 @@ def all_reduce_mean_(flat, world):
 
 
 class ShardedFeatureTable:
-    """[P,D] feature table row-sharded cyclically over the ranks of `group`.
+    """[P,D] feature table row-sharded cyclically over the ranks of `group`: product r lives on rank r % G as local row
+    r // G (SURVEY section 8e-1).
 
-    lookup(ids) returns (rows[U,D], remap) with rows[remap[i]] == table[ids[i]] (ids < 0 map
-    to -1: the zero-row sentinel of the collate padding).  `gather_fn(local_table, idx_int32)`
-    performs the owner-side row gather: the HIP kernel on the GPU; the CPU tests inject their
-    own (test infrastructure only -- the product never falls back)."""
+    lookup_batch(batch): the per-step exchange, DEVICE-RESIDENT -- no host synchronisation, constant shapes:
+      1. pc_shard_bucket: the batch's id arrays -> per-owner request lists send_ids[G][C] (fixed capacity C, unused
+         slots -1) and the batch's indices over the [G][C][D] buffer the exchange will return;
+      2. all_to_all of the request lists (C int32 per peer), owner-side HIP row gather, all_to_all of the rows
+         (C x D fp32 per peer);
+      3. the fused step runs unchanged over that buffer.  The table is frozen (p_companion.py:26-29,
+         synthetic_data.py:50-58): no backward exchange.
+    The unique-neighbour layout already carries every distinct neighbour product once; the remaining ids (anchors,
+    positives, negatives) are sent as they are -- at the catalogue sizes sharding is for (>= 10 M products) repeats among
+    a batch's ~37 k of them are < 1 %.  A bucket overflow (a batch whose ids pile up on one owner beyond C) increments
+    a device counter; raise_if_overflowed() reports it where the caller synchronises anyway.
 
-    def __init__(self, local_rows, num_products, rank, world, gather_fn=None, group=None):
+    lookup(ids): general-purpose variant for arbitrary id tensors (tools, tests): de-duplicates, exact sizes, but
+    reads the bucket sizes back to the host.
+
+    `gather_fn(local_table, idx_int32)` / `bucket_fn(...)`: the owner-side row gather and the bucketing -- the HIP
+    kernels on the GPU; the CPU tests inject their own (test infrastructure only -- the product never falls back)."""
+
+    def __init__(self, local_rows, num_products, rank, world, gather_fn=None, group=None, capacity=None, bucket_fn=None):
         self.local = local_rows
         self.P, self.rank, self.world, self.group = int(num_products), rank, world, group
         if gather_fn is None:
             from . import ops
             gather_fn = ops.gather_rows
-        self.gather_fn = gather_fn
+        if bucket_fn is None:
+            from . import ops
+            bucket_fn = ops.shard_bucket
+        self.gather_fn, self.bucket_fn = gather_fn, bucket_fn
+        self.capacity = capacity                 # rows per peer and step; None: sized from the first batch
+        self._bufs = None
+        self.bytes_per_peer = None
 
     @staticmethod
     def shard(full_table, rank, world):
         return full_table[rank::world].contiguous()
 
+    @staticmethod
+    def capacity_for(ids_per_step, world, slack=1.25):
+        """Ids hash uniformly over the owners (r % G of a scattered id set): mean R / G per bucket, standard deviation
+        ~sqrt(R / G); 25 % headroom is > 20 sigma at R ~ 1e5."""
+        return int(ids_per_step) if world == 1 else int(slack * ids_per_step / world) + 1024
+
+    def _buffers(self, n_ids, dev):
+        if self.capacity is None:
+            self.capacity = self.capacity_for(n_ids, self.world)
+        if self._bufs is None or self._bufs["send_ids"].device != dev:
+            G, C = self.world, self.capacity
+            i32 = lambda *s: torch.zeros(*s, dtype=torch.int32, device=dev)
+            self._bufs = {"counts": i32(G), "send_ids": i32(G * C), "overflow": i32(1)}
+            self.bytes_per_peer = {"request_ids": 4 * C, "rows": 4 * C * self.local.shape[1]}
+        return self._bufs
+
     def lookup_batch(self, batch):
-        """Index batch over GLOBAL product ids -> (compact table of the rows this rank needs, the same batch over
-        that table): what the fused step consumes unchanged (unique / compact neighbour layouts)."""
+        """Index batch over GLOBAL product ids -> (table of the rows this rank asked for, [G*C, D]; the same batch over
+        that table).  Unique / compact neighbour layouts; asynchronous."""
         nbc = batch["neighbor_compact"]
         uq = "weight" in nbc
-        nrows = nbc["nb_rows"][: int(nbc["n_unique"]) + 1] if uq else nbc["nb_rows"]
-        ids = torch.cat([batch["anchor_idx"], nrows, batch["positive_idx"], batch["negative_idx"].reshape(-1)])
-        tab, remap = self.lookup(ids)
-        B, M1, K = batch["anchor_idx"].numel(), nrows.numel(), batch["negative_idx"].shape[1]
-        o = np.cumsum([0, B, M1, B, B * K])
-        out = {"anchor_idx": remap[o[0]:o[1]].contiguous(), "positive_idx": remap[o[2]:o[3]].contiguous(),
-               "negative_idx": remap[o[3]:o[4]].view(B, K).contiguous(),
-               "neighbor_compact": dict({"nb_rows": remap[o[1]:o[2]].contiguous(), "slot_row": nbc["slot_row"]},
-                                        **({k: nbc[k] for k in ("weight", "n_unique", "ref_off", "ref_slot")} if uq else {}))}
+        a, p, ng = batch["anchor_idx"], batch["positive_idx"], batch["negative_idx"]
+        dev = a.device
+        B, K = a.numel(), ng.shape[1]
+        nb_rows = nbc["nb_rows"]
+        n_live = nbc.get("n_unique_dev") if uq else None                      # [1] int32 on the device: rows 0..n_unique are live
+        bufs = self._buffers(2 * B + B * K + nb_rows.numel(), dev)
+        G, C = self.world, self.capacity
+        outs = self.bucket_fn([(a, None, 0), (nb_rows, n_live, 1), (p, None, 0), (ng.reshape(-1), None, 0)], G, C,
+                              bufs["counts"], bufs["send_ids"], bufs["overflow"])
+        req = torch.empty_like(bufs["send_ids"])
+        if G > 1:
+            dist.all_to_all_single(req, bufs["send_ids"], group=self.group)       # equal splits: C int32 per peer
+        else:
+            req.copy_(bufs["send_ids"])
+        rows_out = self.gather_fn(self.local, req)                                # -1 -> zero row
+        tab = torch.empty_like(rows_out)
+        if G > 1:
+            dist.all_to_all_single(tab, rows_out, group=self.group)               # C x D fp32 per peer
+        else:
+            tab = rows_out
+        out = {"anchor_idx": outs[0], "positive_idx": outs[2], "negative_idx": outs[3].view(B, K),
+               "neighbor_compact": dict({"nb_rows": outs[1], "slot_row": nbc["slot_row"]},
+                                        **({k: nbc[k] for k in ("weight", "n_unique", "n_unique_dev", "ref_off", "ref_slot", "n_real")
+                                            if k in nbc} if uq else {}))}
+        if "n_pad" in batch:
+            out["n_pad"] = batch["n_pad"]
         return tab, out
+
+    def overflowed(self) -> int:
+        """Ids that did not fit their owner's bucket since the last call (synchronises)."""
+        if self._bufs is None:
+            return 0
+        n = int(self._bufs["overflow"].item())
+        if n:
+            self._bufs["overflow"].zero_()
+        return n
+
+    def raise_if_overflowed(self):
+        n = self.overflowed()
+        if n:
+            raise RuntimeError(f"{n} product ids did not fit the per-peer request capacity {self.capacity} of the sharded "
+                               "lookup: construct ShardedFeatureTable with a larger `capacity`")
 
     def lookup(self, ids):
         dev = ids.device

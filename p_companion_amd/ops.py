@@ -754,6 +754,25 @@ def act_backward(dy, y, act):
     return dx
 
 
+def shard_bucket(arrays, world, capacity, counts, send_ids, overflow):
+    """pc_shard_bucket.  arrays: up to four (ids int32 tensor, live-length device tensor or None, add) triples; returns
+    the remapped index tensors (same shapes).  counts [world], send_ids [world*capacity], overflow [1]: int32 device."""
+    n = len(arrays)
+    if not 1 <= n <= 4:
+        raise ValueError("1..4 id arrays per launch")
+    outs = [torch.empty_like(_req(t, torch.int32, "ids")) for t, _, _ in arrays]
+    _req(counts, torch.int32, "counts", (world,)); _req(send_ids, torch.int32, "send_ids", (world * capacity,))
+    _req(overflow, torch.int32, "overflow", (1,))
+    ptrs = (ctypes.c_void_p * n)(*[t.data_ptr() for t, _, _ in arrays])
+    lens = (ctypes.c_int * n)(*[t.numel() for t, _, _ in arrays])
+    ndev = (ctypes.c_void_p * n)(*[(_req(d, torch.int32, "live length").data_ptr() if d is not None else None) for _, d, _ in arrays])
+    nadd = (ctypes.c_int * n)(*[int(a) for _, _, a in arrays])
+    optrs = (ctypes.c_void_p * n)(*[o.data_ptr() for o in outs])
+    check(_lib.lib().pc_shard_bucket(ptrs, lens, ndev, nadd, optrs, n, int(world), int(capacity), _p(counts), _p(send_ids),
+                                     _p(overflow), _stream()), "pc_shard_bucket")
+    return outs
+
+
 def dropout_hidden(x, dropout):
     """x * mask for the type-transition hidden layer (pc_dropout_hidden); dropout = (p, seed, offset)."""
     _req(x, torch.float32, "x")

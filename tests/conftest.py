@@ -20,3 +20,48 @@ def golden():
     def load(name):
         return np.load(os.path.join(GOLDEN, name))
     return load
+
+
+# ---- world-2 job of tests/test_gpu_sharded.py: two ranks sharing the one card.  The children are started HERE, at
+# session start, before this process makes its first GPU call (a process that has initialised the GPU must not be the
+# one that launches further GPU programs on this pool); the test only collects their results.
+_WORLD2 = {}
+
+
+def pytest_sessionstart(session):
+    markexpr = session.config.getoption("-m") or ""
+    if "gpu" not in markexpr or "not gpu" in markexpr:
+        return
+    import socket
+    import subprocess
+    import tempfile
+    import torch
+    if torch.cuda.device_count() < 1:                  # (counting devices does not initialise the GPU)
+        return
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    d = tempfile.mkdtemp(prefix="pc_world2_")
+    worker = os.path.join(ROOT, "tests", "sharded_world2_worker.py")
+    procs = []
+    for rank in range(2):
+        out = os.path.join(d, f"rank{rank}.json")
+        log = open(os.path.join(d, f"rank{rank}.log"), "w")
+        procs.append((subprocess.Popen([sys.executable, worker, str(rank), str(port), out], stdout=log, stderr=log), out, log))
+    _WORLD2["procs"] = procs
+
+
+@pytest.fixture(scope="session")
+def world2_job():
+    def collect():
+        import json
+        if "procs" not in _WORLD2:
+            pytest.skip("no GPU: the world-2 job was not started")
+        res = []
+        for p, out, log in _WORLD2["procs"]:
+            p.wait(timeout=600)
+            log.close()
+            if os.path.exists(out):
+                res.append(json.load(open(out)))
+            else:
+                res.append({"ok": False, "error": open(log.name).read()[-2000:]})
+        return res
+    return collect

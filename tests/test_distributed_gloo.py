@@ -20,6 +20,28 @@ def _cpu_gather(table, idx):
     return table[idx.long()]
 
 
+def _cpu_bucket(arrays, G, C, counts, send_ids, overflow):
+    """Test-side restatement of pc_shard_bucket's contract (include/pcompanion_hip.h) for CPU tensors."""
+    counts.zero_(); send_ids.fill_(-1)
+    outs = []
+    for ids, n_dev, add in arrays:
+        live = ids.numel() if n_dev is None else min(ids.numel(), int(n_dev) + add)
+        out = torch.full_like(ids, -1)
+        for pos in range(live):
+            i = int(ids[pos])
+            if i < 0:
+                continue
+            o = i % G
+            slot = int(counts[o]); counts[o] += 1
+            if slot < C:
+                send_ids[o * C + slot] = i // G
+                out[pos] = o * C + slot
+            else:
+                overflow += 1
+        outs.append(out)
+    return outs
+
+
 def _worker(rank, world, port, q):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
                       LOCAL_RANK=str(rank))
@@ -40,6 +62,29 @@ def _worker(rank, world, port, q):
     ok = ok and torch.equal(ext[remap.long()], want)
     ok = ok and rows.shape[0] == len(torch.unique(ids[ids >= 0]))            # de-duplicated on the wire
     ok = ok and bool(((remap < 0) == (ids < 0)).all())
+    # the per-step, fixed-capacity form (what the loader runs): request lists of C ids per peer, rows back, the batch's
+    # indices over the [G*C, D] buffer; the unique-neighbour list's live length is a device scalar
+    gb = torch.Generator().manual_seed(200 + rank)
+    B, K = 16, 5
+    nb = torch.sort(torch.randperm(1000, generator=gb)[:40]).values.to(torch.int32)
+    batch = {"anchor_idx": torch.randint(0, 1000, (B,), generator=gb, dtype=torch.int32),
+             "positive_idx": torch.randint(0, 1000, (B,), generator=gb, dtype=torch.int32),
+             "negative_idx": torch.randint(0, 1000, (B, K), generator=gb, dtype=torch.int32),
+             "neighbor_compact": {"nb_rows": torch.cat([nb, torch.tensor([-1, 777, 778], dtype=torch.int32)]),   # 2 scratch entries
+                                  "weight": torch.ones(43), "slot_row": torch.zeros(B, 4, dtype=torch.int32),
+                                  "n_unique": 40, "n_unique_dev": torch.tensor([40], dtype=torch.int32)}}
+    tab2 = pdist.ShardedFeatureTable(pdist.ShardedFeatureTable.shard(full, rank, world), 1000, rank, world,
+                                     gather_fn=lambda t, i: torch.cat([t, torch.zeros(1, 16)])[i.long()], bucket_fn=_cpu_bucket)
+    rows2, rb = tab2.lookup_batch(batch)
+    ok = ok and rows2.shape == (world * tab2.capacity, 16) and tab2.overflowed() == 0
+    ext2 = torch.cat([rows2, torch.zeros(1, 16)])
+    wantf = torch.cat([full, torch.zeros(1, 16)])
+    for k in ("anchor_idx", "positive_idx", "negative_idx"):
+        ok = ok and torch.equal(ext2[rb[k].long()], wantf[batch[k].long()])
+    nbr = rb["neighbor_compact"]["nb_rows"]
+    ok = ok and torch.equal(ext2[nbr[:41].long()], wantf[batch["neighbor_compact"]["nb_rows"][:41].long()])
+    ok = ok and bool((nbr[41:] == -1).all()) and int(nbr[40]) == -1
+    ok = ok and tab2.bytes_per_peer == {"request_ids": 4 * tab2.capacity, "rows": 64 * tab2.capacity}
     grad = torch.full((10,), float(rank + 1))
     pdist.all_reduce_mean_(grad, world)
     ok = ok and torch.allclose(grad, torch.full((10,), (1 + world) / 2))
