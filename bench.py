@@ -192,7 +192,7 @@ def run_joint(args, rank, world, dev, types, steps, warmup, want_cpu):
     # straight into the graph's input buffers.  N > 1 keeps eager launches (the gradient all-reduce sits between).
     graphed = None
     if world == 1 and not args.no_graph:
-        graphed = GraphedJointStep(model, opt, args.batch)
+        graphed = GraphedJointStep(model, opt, args.batch, mode=args.joint_launch)
     loader = ComplementaryIndexLoader(ComplementaryIndexDataset(bpg, "train"), args.batch, shuffle=True, seed=rank,
                                       device=dev, out=graphed.static if graphed else None)
 
@@ -250,8 +250,11 @@ def run_joint(args, rank, world, dev, types, steps, warmup, want_cpu):
            "config": {"workload": f"P-Companion joint step, {args.products} products, NUM_TYPES={types}, dim=128, "
                                   f"batch={args.batch}/GPU, K=3 (loader batch construction included)",
                       "global_batch": world * args.batch, "parallelism": f"dp{world}", "final_loss": round(float(losses[0]), 5),
-                      "launch": "hipGraph replay" if graphed is not None else "eager",
-                      "kernels_per_step": getattr(model, "last_step_launches", None)},
+                      "launch": ({"direct": "fused step, arguments resolved once (one foreign call per step)",
+                                  "graph": "hipGraph replay"}[graphed.mode] if graphed is not None else "eager module calls"),
+                      "kernels_per_step": ("3 (tile kernel, grouped gradient products, finish + Adam) + the batch builder" if types <= 512 else
+                                            "10 (2 clears, present types, sims + chunk top-K, merge, tile kernel, 2 row scatter-adds, "
+                                            "grouped gradient products, finish + Adam) + the batch builder")},
            "roofline": {"bound": "hbm", "kernel": "the whole step (one HIP-graph replay): its kernels are a dependent chain",
                         "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                         "frac": round(achieved / HBM_PEAK_GBS, 5),
@@ -413,7 +416,9 @@ def main():
                     help="HIP-event brackets around every GEMM launch (TN and few-row kernels too), not only the dominant "
                          "gemm_nt_kernel family: ~60 us/step of event packets")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-graph", action="store_true", help="joint phase: eager launches instead of the HIP-graph replay")
+    ap.add_argument("--no-graph", action="store_true", help="joint phase: plain module calls (PCompanion.train_step + optimizer) per step")
+    ap.add_argument("--joint-launch", choices=["auto", "direct", "graph"], default="auto",
+                    help="joint phase, one process: 'direct' = the fused step with its arguments resolved once; 'graph' = HIP-graph replay")
     ap.add_argument("--large-catalogue", type=int, default=0,
                     help="also time the P2V step over this many products (e.g. 2000000: few duplicate neighbours to merge)")
     ap.add_argument("--no-ref-types", action="store_true", help="skip the joint leg at the reference's NUM_TYPES = 34800")

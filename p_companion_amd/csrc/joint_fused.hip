@@ -154,6 +154,21 @@ __device__ __forceinline__ void dpp_row_maxkey(unsigned& hi, unsigned& lo) {
 __device__ __forceinline__ void row_maxkey(unsigned& hi, unsigned& lo) {
     dpp_row_maxkey<0x121>(hi, lo); dpp_row_maxkey<0x122>(hi, lo); dpp_row_maxkey<0x124>(hi, lo); dpp_row_maxkey<0x128>(hi, lo);
 }
+// the same over the whole wave (row_shr scan inside the rows, row_bcast 15 / 31 across them: lane 63 holds the maximum)
+template <int CTRL, int RM>
+__device__ __forceinline__ void dpp_maxkey(unsigned& hi, unsigned& lo) {
+    const unsigned oh = (unsigned)__builtin_amdgcn_update_dpp((int)hi, (int)hi, CTRL, RM, 0xf, false);
+    const unsigned ol = (unsigned)__builtin_amdgcn_update_dpp((int)lo, (int)lo, CTRL, RM, 0xf, false);
+    const bool gt = oh > hi || (oh == hi && ol > lo);
+    hi = gt ? oh : hi;
+    lo = gt ? ol : lo;
+}
+__device__ __forceinline__ void wave_maxkey(unsigned& hi, unsigned& lo) {
+    dpp_maxkey<0x111, 0xf>(hi, lo); dpp_maxkey<0x112, 0xf>(hi, lo); dpp_maxkey<0x114, 0xf>(hi, lo);
+    dpp_maxkey<0x118, 0xf>(hi, lo); dpp_maxkey<0x142, 0xa>(hi, lo); dpp_maxkey<0x143, 0xc>(hi, lo);
+    hi = (unsigned)__builtin_amdgcn_readlane((int)hi, 63);
+    lo = (unsigned)__builtin_amdgcn_readlane((int)lo, 63);
+}
 // order-preserving map fp32 -> uint32 (larger float <=> larger unsigned); -0.0 < +0.0 here, torch.topk treats them as
 // equal: a similarity of exactly -0.0 against +0.0 is the only case the tie rule could differ in
 __device__ __forceinline__ unsigned ord_f32(float x) {
@@ -560,7 +575,7 @@ static size_t tile_lds_bytes(int T, bool sims_local) {
 //                          products), sims = c E_c[chunk]^T, per query type the chunk's best K   [epilogue top-K:
 //                          the [U,T] similarity matrix is never written]
 //   type_topk_merge_kernel per listed query type: best K of its chunks' candidates -> topk_by_type[type][K]
-#define TC 256
+#define TC 320        /* types per chunk: 109 chunks x 2 tiles of listed query types = 218 workgroups at T = 34800: one round of the chip */
 #define UT 64
 __global__ __launch_bounds__(1024) void present_types_kernel(const int32_t* query_types, int B, int T, int32_t* ulist,
                                                              int32_t* n_u) {
@@ -615,9 +630,23 @@ __global__ __launch_bounds__(256) void type_sims_topk_kernel(TypeSimsArgs a) {
     const int nu = *a.n_u;
     const int t0 = blockIdx.x * TC;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, ci = lane & 15, rh = lane >> 4;
+    // every weight fragment this wave multiplies by, requested once: the two small layers and ALL of this chunk's E_c
+    // column blocks (they are the same for every tile of query types the workgroup walks)
+    const BFrag<4> f_e0 = load_b<PC_L, false>(a.enc_w, PC_L, 0, LH, lane), f_e1 = load_b<PC_L, false>(a.enc_w, PC_L, 16, LH, lane);
+    BFrag<2> f_d[4];
+#pragma unroll
+    for (int nb = 0; nb < 4; nb++) f_d[nb] = load_b<LH, false>(a.dec_w, LH, 16 * nb, PC_L, lane);
+    constexpr int NBW = TC / 16 / 4;                       // E_c column blocks per wave
+    BFrag<4> f_s[NBW];
+#pragma unroll
+    for (int q = 0; q < NBW; q++) f_s[q] = load_b<PC_L, false>(a.ec, PC_L, t0 + 16 * (w + 4 * q), a.T, lane);
+    const float bias_e0 = a.enc_b[ci], bias_e1 = a.enc_b[16 + ci];
+    float bias_d[4];
+#pragma unroll
+    for (int nb = 0; nb < 4; nb++) bias_d[nb] = a.dec_b[16 * nb + ci];
     // the number of listed query types is known to the device only: a workgroup walks the tiles of 64 of them with stride
     // gridDim.y (a grid sized for the worst case, one workgroup per possible tile, spends more time dispatching workgroups
-    // that find nothing to do -- each holds 110 KB of LDS -- than the product takes)
+    // that find nothing to do -- each holds > 100 KB of LDS -- than the product takes)
     for (int u0 = blockIdx.y * UT; u0 < nu; u0 += gridDim.y * UT) {
     __syncthreads();
     for (int e = tid; e < UT * 16; e += 256) {
@@ -630,35 +659,34 @@ __global__ __launch_bounds__(256) void type_sims_topk_kernel(TypeSimsArgs a) {
     // wave w owns the 16 query types [16 w, 16 w + 16) of the tile for the two small layers
     {
         const float* At = Tin + 16 * w * LD64;
+        f32x4v a0[1] = {{0.f, 0.f, 0.f, 0.f}}, a1[1] = {{0.f, 0.f, 0.f, 0.f}};
+        mul_b<4, 1>(At, LD64, 1, f_e0, a0, lane);
+        mul_b<4, 1>(At, LD64, 1, f_e1, a1, lane);
 #pragma unroll
-        for (int nb = 0; nb < 2; nb++) {
-            f32x4v acc[1] = {{0.f, 0.f, 0.f, 0.f}};
-            block_product<PC_L, 1, false>(At, LD64, 1, a.enc_w, PC_L, 16 * nb, LH, acc, lane);
-            const float bias = a.enc_b[16 * nb + ci];
-#pragma unroll
-            for (int r = 0; r < 4; r++) {
-                const float x = acc[0][r] + bias;
-                Hs[(16 * w + 4 * rh + r) * LD32 + 16 * nb + ci] = x > 0.f ? x : 0.f;
-            }
+        for (int r = 0; r < 4; r++) {
+            const float x0 = a0[0][r] + bias_e0, x1 = a1[0][r] + bias_e1;
+            Hs[(16 * w + 4 * rh + r) * LD32 + ci] = x0 > 0.f ? x0 : 0.f;
+            Hs[(16 * w + 4 * rh + r) * LD32 + 16 + ci] = x1 > 0.f ? x1 : 0.f;
         }
         __builtin_amdgcn_wave_barrier();
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #pragma unroll
         for (int nb = 0; nb < 4; nb++) {
             f32x4v acc[1] = {{0.f, 0.f, 0.f, 0.f}};
-            block_product<LH, 1, false>(Hs + 16 * w * LD32, LD32, 1, a.dec_w, LH, 16 * nb, PC_L, acc, lane);
-            const float bias = a.dec_b[16 * nb + ci];
+            mul_b<2, 1>(Hs + 16 * w * LD32, LD32, 1, f_d[nb], acc, lane);
 #pragma unroll
-            for (int r = 0; r < 4; r++) Cs[(16 * w + 4 * rh + r) * LD64 + 16 * nb + ci] = acc[0][r] + bias;
+            for (int r = 0; r < 4; r++) Cs[(16 * w + 4 * rh + r) * LD64 + 16 * nb + ci] = acc[0][r] + bias_d[nb];
         }
     }
     __syncthreads();
-    // sims[64][TC]: 16 column blocks, wave w takes blocks w, w + 4, ...; 4 row blocks share a B fragment set
-    for (int nb = w; nb < TC / 16; nb += 4) {
+    // sims[64][TC]: TC / 16 column blocks, wave w takes blocks w, w + 4, ...; 4 row blocks share a B fragment set
+#pragma unroll
+    for (int q = 0; q < NBW; q++) {
+        const int nb = w + 4 * q;
         f32x4v acc[4];
 #pragma unroll
         for (int m = 0; m < 4; m++) acc[m] = f32x4v{0.f, 0.f, 0.f, 0.f};
-        block_product<PC_L, 4, false>(Cs, LD64, 4, a.ec, PC_L, t0 + 16 * nb, a.T, acc, lane);
+        mul_b<4, 4>(Cs, LD64, 4, f_s[q], acc, lane);
 #pragma unroll
         for (int m = 0; m < 4; m++)
 #pragma unroll
@@ -666,92 +694,60 @@ __global__ __launch_bounds__(256) void type_sims_topk_kernel(TypeSimsArgs a) {
     }
     __syncthreads();
     const int nvalid = min(TC, a.T - t0);
-    for (int s = w; s < UT; s += 4) {
-        if (u0 + s >= nu) break;
-        float v[FK];
-        int ix[FK];
-#pragma unroll
-        for (int j = 0; j < FK; j++) { v[j] = -INFINITY; ix[j] = 0x7fffffff; }
-        for (int t = lane; t < nvalid; t += 64) {
-            float x = Sims[s * LDS_ + t];
-            int xi = t0 + t;
-#pragma unroll
-            for (int j = 0; j < FK; j++)
-                if (j < a.K) {
-                    const bool better = x > v[j] || ix[j] == 0x7fffffff;
-                    const float tv = better ? v[j] : x;
-                    const int ti = better ? ix[j] : xi;
-                    v[j] = better ? x : v[j];
-                    ix[j] = better ? xi : ix[j];
-                    x = tv; xi = ti;
+    // the chunk's best K per listed query type: a row group of 16 lanes per type, four types per wave side by side
+    {
+        const int g4 = lane >> 4, l16 = lane & 15;
+        for (int pass = 0; pass < UT / 16; pass++) {
+            const int s = 16 * w + 4 * pass + g4;
+            int idx[FK];
+            row_topk<0>(Sims + s * LDS_, nvalid, a.K, l16, idx);
+            if (l16 == 0 && u0 + s < nu)
+                for (int r = 0; r < a.K; r++) {
+                    const size_t o = ((size_t)(u0 + s) * a.nchunks + blockIdx.x) * a.K + r;
+                    const bool got = idx[r] >= 0;                 // (a tail chunk may hold fewer than K types)
+                    a.part_val[o] = got ? Sims[s * LDS_ + idx[r]] : -INFINITY;
+                    a.part_idx[o] = got ? t0 + idx[r] : 0x7fffffff;
                 }
-        }
-        for (int r = 0; r < a.K; r++) {
-            float bv = v[0];
-            int bi = ix[0];
-#pragma unroll
-            for (int o = 32; o >= 1; o >>= 1) {
-                const float ov = __shfl_xor(bv, o, 64);
-                const int oi = __shfl_xor(bi, o, 64);
-                if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
-            }
-            if (ix[0] == bi && bi != 0x7fffffff) {
-#pragma unroll
-                for (int j = 0; j < FK - 1; j++) { v[j] = v[j + 1]; ix[j] = ix[j + 1]; }
-                v[FK - 1] = -INFINITY; ix[FK - 1] = 0x7fffffff;
-            }
-            if (lane == 0) {
-                const size_t o = ((size_t)(u0 + s) * a.nchunks + blockIdx.x) * a.K + r;
-                a.part_val[o] = bv;
-                a.part_idx[o] = bi;
-            }
         }
     }
     }
 }
 
+// per listed query type: the best K of its nchunks * K candidates (value, index), ties -> the lower index; a row group of
+// 16 lanes per type
 __global__ __launch_bounds__(256) void type_topk_merge_kernel(const float* part_val, const int32_t* part_idx,
                                                               const int32_t* ulist, const int32_t* n_u, int nchunks,
                                                               int K, int32_t* topk_by_type) {
     const int lane = threadIdx.x & 63;
     const int u = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (u >= *n_u) return;
+    if (u >= *n_u) return;                                   // wave-uniform
     const int n = nchunks * K;
-    float v[FK];
-    int ix[FK];
+    // one pass: every lane keeps the best K keys of its strided candidates (the loads are independent: one latency),
+    // then K rounds of a wave max; the winner is retired by its owner
+    unsigned kh[FK], kl[FK];
 #pragma unroll
-    for (int j = 0; j < FK; j++) { v[j] = -INFINITY; ix[j] = 0x7fffffff; }
+    for (int j = 0; j < FK; j++) { kh[j] = 0u; kl[j] = 0u; }
     for (int t = lane; t < n; t += 64) {
-        float x = part_val[(size_t)u * n + t];
-        int xi = part_idx[(size_t)u * n + t];
-        if (xi == 0x7fffffff) continue;
+        const int xi = part_idx[(size_t)u * n + t];
+        unsigned h = xi == 0x7fffffff ? 0u : ord_f32(part_val[(size_t)u * n + t]), l = xi == 0x7fffffff ? 0u : ~(unsigned)xi;
 #pragma unroll
-        for (int j = 0; j < FK; j++)
-            if (j < K) {
-                const bool better = x > v[j] || (x == v[j] && xi < ix[j]);
-                const float tv = better ? v[j] : x;
-                const int ti = better ? ix[j] : xi;
-                v[j] = better ? x : v[j];
-                ix[j] = better ? xi : ix[j];
-                x = tv; xi = ti;
-            }
+        for (int j = 0; j < FK; j++) {                       // insertion into the sorted (descending) list
+            const bool gt = h > kh[j] || (h == kh[j] && l > kl[j]);
+            const unsigned th = gt ? kh[j] : h, tl = gt ? kl[j] : l;
+            kh[j] = gt ? h : kh[j]; kl[j] = gt ? l : kl[j];
+            h = th; l = tl;
+        }
     }
     const int type = ulist[u];
     for (int r = 0; r < K; r++) {
-        float bv = v[0];
-        int bi = ix[0];
+        unsigned bh = kh[0], bl = kl[0];
+        wave_maxkey(bh, bl);
+        if (kh[0] == bh && kl[0] == bl) {                    // pop the owner's head
 #pragma unroll
-        for (int o = 32; o >= 1; o >>= 1) {
-            const float ov = __shfl_xor(bv, o, 64);
-            const int oi = __shfl_xor(bi, o, 64);
-            if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
+            for (int j = 0; j < FK - 1; j++) { kh[j] = kh[j + 1]; kl[j] = kl[j + 1]; }
+            kh[FK - 1] = 0u; kl[FK - 1] = 0u;
         }
-        if (ix[0] == bi) {
-#pragma unroll
-            for (int j = 0; j < FK - 1; j++) { v[j] = v[j + 1]; ix[j] = ix[j + 1]; }
-            v[FK - 1] = -INFINITY; ix[FK - 1] = 0x7fffffff;
-        }
-        if (lane == 0) topk_by_type[(size_t)type * K + r] = bi;
+        if (lane == 0) topk_by_type[(size_t)type * K + r] = (int)~bl;
     }
 }
 

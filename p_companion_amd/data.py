@@ -199,6 +199,11 @@ class SimilarityIndexLoader:
         elif sampler != "philox":
             raise ValueError("sampler must be 'philox' or 'cpython'")
         self._deg = bpg.degree(bpg.similarity_pairs[:, 0])
+        if sharded is not None and sharded.capacity is None:
+            # the request capacity per peer must be the same constant on every rank: sized for the largest possible batch
+            # (anchor + positive + k negatives + a full neighbour list per sample, + the padding row), not for this rank's first one
+            max_ids = self.batch_size * (2 + k_neg + int(self._deg.max() if len(self._deg) else 0)) + 1
+            sharded.capacity = sharded.capacity_for(max_ids, sharded.world)
 
     def __len__(self):
         n = self.bpg.similarity_pairs.shape[0]
@@ -369,6 +374,16 @@ class ComplementaryIndexLoader:
         """One HIP launch (pc_build_complementary_batch) builds the whole batch from [B,3] device pairs."""
         from . import ops
         out = self.out if (self.out is not None and rows_dev.shape[0] == self.batch_size) else None
+        if out is not None and rows_dev.is_cuda:
+            # fixed buffers: one foreign call with the arguments resolved once (the host must stay ahead of a ~70 us step)
+            if getattr(self, "_prepared", None) is None:
+                self._prepared = ops.PreparedComplementaryBuilder(self.features, self.type_idx, self.dataset.bpg.n_types,
+                                                                  self.seed, out)
+                self._static_batch = dict(out)
+            self._prepared(rows_dev, self.step)
+            self.step += 1
+            self._static_batch["label"] = rows_dev[:, 2]
+            return self._static_batch
         batch = ops.build_complementary_batch(rows_dev, self.features, self.type_idx, self.dataset.bpg.n_types,
                                               self.seed, self.step, out=out)
         self.step += 1

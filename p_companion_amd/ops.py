@@ -635,6 +635,80 @@ def joint_fused_step(params, grads, query_idx, query_types, pos_types, neg_types
     return losses, topk
 
 
+class PreparedJointStep:
+    """pc_joint_fused_step with every argument resolved once: the loop body then costs one foreign call (the per-step
+    argument marshalling of joint_fused_step -- ~50 tensor checks, dict and struct building -- is as long as the three
+    kernels themselves).  All buffers are fixed: parameters / gradients / moments (flat-buffer views), the batch
+    tensors, the workspace, the outputs.  dropout: (p, seed) or None; the offset advances with every call."""
+
+    def __init__(self, params, grads, batch, k, margin, alpha, bad=None, adam=None, dropout=None):
+        self._keep = (params, grads, batch, bad, adam)
+        self.st, dev = joint_struct(params)
+        self.gst, _ = joint_struct(grads, table=params["product_embeddings.weight"])
+        qi, qt, pt, nt = (batch[n].reshape(-1) for n in ("query_idx", "query_types", "positive_types", "negative_types"))
+        b = qi.numel()
+        t = params["query_type_embeddings.weight"].shape[0]
+        for x, nm in ((qi, "query_idx"), (qt, "query_types"), (pt, "positive_types"), (nt, "negative_types")):
+            _req(x, torch.int32, nm, (b,))
+        pos, neg = batch["positive_items"], batch["negative_items"]
+        _req(pos, torch.float32, "positive_items", (b, D)); _req(neg, torch.float32, "negative_items", (b, D))
+        self.losses = torch.empty(3, dtype=torch.float32, device=dev)
+        self.topk = torch.empty(b, k, dtype=torch.int32, device=dev)
+        nbytes = _lib.lib().pc_joint_fused_workspace_bytes(b, t, k)
+        self.ws = torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device=dev)
+        m_ref = v_ref = step = None
+        lr = b1 = b2 = eps = 0.0
+        if adam is not None:
+            self.mst, _ = joint_struct(adam["exp_avg"], table=params["product_embeddings.weight"])
+            self.vst, _ = joint_struct(adam["exp_avg_sq"], table=params["product_embeddings.weight"])
+            m_ref, v_ref = ctypes.byref(self.mst), ctypes.byref(self.vst)
+            step = _req(adam["step_count"], torch.int64, "step_count")
+            lr, (b1, b2), eps = float(adam["lr"]), adam["betas"], float(adam["eps"])
+        if bad is not None:
+            _req(bad, torch.int32, "bad", (1,))
+        self.dropout = dropout
+        self.calls = 0
+        if dropout is not None:
+            self.st.dropout.p, self.st.dropout.seed = float(dropout[0]), int(dropout[1])
+        self._fn = _lib.lib().pc_joint_fused_step
+        self._args = [ctypes.byref(self.st), ctypes.byref(self.gst), m_ref, v_ref, _p(step), lr, float(b1), float(b2), eps,
+                      _p(qi), _p(qt), _p(pt), _p(nt), _p(pos), _p(neg), b, t, k,
+                      int(params["product_embeddings.weight"].shape[0]), float(margin), float(alpha), _p(self.losses),
+                      _p(self.topk), _p(bad), _p(self.ws), nbytes]
+        self._idx = (qi, qt, pt, nt)
+
+    def __call__(self, dropout_offset=0):
+        if self.dropout is not None:
+            self.st.dropout.offset = int(dropout_offset)
+        rc = self._fn(*self._args, _stream())
+        if rc:
+            check(rc, "pc_joint_fused_step")
+        self.calls += 1
+        return self.losses, self.topk
+
+
+class PreparedComplementaryBuilder:
+    """pc_build_complementary_batch into FIXED output buffers with the arguments resolved once (see PreparedJointStep)."""
+
+    def __init__(self, features, type_idx, n_types, seed, out):
+        _req(features, torch.float32, "features"); _req(type_idx, torch.int32, "type_idx")
+        self.b = out["query_idx"].numel()
+        for k in ("query_idx", "query_types", "positive_types", "negative_types"):
+            _req(out[k], torch.int32, k)
+        for k in ("positive_items", "negative_items"):
+            _req(out[k], torch.float32, k, (self.b, D))
+        self._keep = (features, type_idx, out)
+        self._fn = _lib.lib().pc_build_complementary_batch
+        self._tail = [_p(out["query_idx"]), _p(out["query_types"]), _p(out["positive_types"]), _p(out["negative_types"]),
+                      _p(out["positive_items"]), _p(out["negative_items"]), _p(out.get("target_features"))]
+        self._head = [_p(features), _p(type_idx), int(n_types), int(seed)]
+
+    def __call__(self, rows_dev, step):
+        rc = self._fn(ctypes.c_void_p(rows_dev.data_ptr()), self.b, *self._head, int(step), *self._tail, _stream())
+        if rc:
+            check(rc, "pc_build_complementary_batch")
+
+
 # ----------------------------------------------------------------------------- building blocks
 def _pad_cols(t, mult=4):
     """[..., c] -> [..., ceil(c / mult) * mult] with zero columns (the kernels move 16-byte chunks: contraction and

@@ -296,20 +296,23 @@ class PCompanion(nn.Module, _FlatParamsMixin):
 
 
 class GraphedJointStep:
-    """train.py:42-48 (forward, compute_loss, zero_grad, backward, optimizer.step) for a FIXED batch size as one
-    HIP-graph replay.  The fused joint step is ~40 launches of 3-13 us each and is bound by how fast the host can
-    launch them; its shapes and buffers do not depend on the data, so after `warmup` eager steps the launch
-    sequence (pc_joint_train_step + pc_adam_step, every kernel on the capturing stream) is recorded once and
-    replayed.  The batch lives in fixed device buffers (`.static`, the loader can build straight into them:
+    """train.py:42-48 (forward, compute_loss, zero_grad, backward, optimizer.step) for a FIXED batch size with the host
+    out of the loop.  The batch lives in fixed device buffers (`.static`; the loader builds straight into them:
     ComplementaryIndexLoader(..., out=step.static)); Adam's step counter and bias corrections live on the device.
+    After `warmup` ordinary steps:
+      mode 'direct' (default where pc_joint_fused_step serves the configuration): the three-launch step with every
+        argument resolved once -- one foreign call per iteration (ops.PreparedJointStep).  Measured on MI355X: the
+        per-node cost of a HIP-graph replay (~5 us) exceeds what a launch costs the device when the host keeps its
+        queue filled, so for 3-12 kernels the direct form is the faster one;
+      mode 'graph': the launch sequence recorded once as a HIP graph and replayed (the launch-per-op sequence of
+        pc_joint_train_step + pc_adam_step is ~25 launches: there the replay wins).
+    Single process only (a gradient all-reduce between backward and Adam would have to be inside): the data-parallel
+    loop calls train_step / all_reduce / optimizer.step."""
 
-    Single process only (a gradient all-reduce between the two calls would have to be captured too): the
-    data-parallel loop keeps the eager calls."""
-
-    def __init__(self, model, optimizer, batch_size, warmup=3):
+    def __init__(self, model, optimizer, batch_size, warmup=3, mode="auto"):
         from .product2vec import FusedAdam
         if not isinstance(optimizer, FusedAdam):
-            raise TypeError("GraphedJointStep replays pc_adam_step: pass a FusedAdam")
+            raise TypeError("GraphedJointStep drives pc_adam_step / the fused step's Adam: pass a FusedAdam")
         self.model, self.optimizer = model, optimizer
         dev = model.query_type_embeddings.weight.device
         if dev.type != "cuda":
@@ -320,7 +323,15 @@ class GraphedJointStep:
         self.static = {"query_idx": i32(b), "query_types": i32(b), "positive_types": i32(b, 1),
                        "negative_types": i32(b, 1), "positive_items": f32(), "negative_items": f32()}
         self.batch_size, self.warmup = b, int(warmup)
-        self.graph = None
+        if mode not in ("auto", "direct", "graph"):
+            raise ValueError("mode: 'auto', 'direct' or 'graph'")
+        p = float(getattr(model.config, "DROPOUT", 0.0))
+        fused_ok = getattr(model, "use_fused_joint", True) and ops.joint_fused_supported(
+            model.query_type_embeddings.weight.shape[0], int(model.config.NUM_COMP_TYPES), p)
+        if mode == "direct" and not fused_ok:
+            raise ValueError("mode 'direct' needs a configuration pc_joint_fused_step serves")
+        self.mode = ("direct" if fused_ok else "graph") if mode == "auto" else mode
+        self.graph = self.prepared = None
         self._eager_steps = 0
         self.losses = self.complementary_types = None
 
@@ -334,16 +345,44 @@ class GraphedJointStep:
     def _eager(self):
         self.losses, self.complementary_types = self.model.train_step(self.static, optimizer=self.optimizer)
 
+    def _prepare(self):
+        m = self.model
+        m.flatten_parameters()
+        params = m._tensor_dict()
+        params["product_embeddings.weight"] = m.product_embeddings.weight
+        grads = {k: q.grad for k, q in m.named_parameters() if q.grad is not None}
+        bad = getattr(m, "_bad", None)
+        tt = m.type_transition
+        p = float(getattr(m.config, "DROPOUT", 0.0))
+        drop = None
+        if p > 0.0:
+            if tt._dropout_seed is None:
+                tt._next_dropout()
+            drop = (p, tt._dropout_seed)
+        self.prepared = ops.PreparedJointStep(params, grads, self.static, int(m.config.NUM_COMP_TYPES), float(m.config.MARGIN),
+                                              float(m.config.ALPHA), bad=bad, adam=self.optimizer.fused_state(), dropout=drop)
+
     def __call__(self, batch=None):
         if batch is not None:
             if batch["query_idx"].numel() != self.batch_size:
                 raise ValueError("GraphedJointStep: fixed batch size %d" % self.batch_size)
             self.load(batch)
+        if self.prepared is not None:
+            tt = self.model.type_transition
+            if not self.model.training:
+                raise RuntimeError("GraphedJointStep: the model left training mode")
+            off = tt._dropout_step
+            tt._dropout_step += 1
+            self.losses, self.complementary_types = self.prepared(off)
+            return self.losses, self.complementary_types
         if self.graph is None:
             if self._eager_steps < self.warmup:
                 self._eager_steps += 1
                 self._eager()
                 return self.losses, self.complementary_types
+            if self.mode == "direct":
+                self._prepare()
+                return self(None)
             side = torch.cuda.Stream()
             side.wait_stream(torch.cuda.current_stream())
             graph = torch.cuda.CUDAGraph()

@@ -121,7 +121,7 @@ def test_sharded_step_world2_on_one_card(world2_job):
     for bit; the bucket capacity and per-peer bytes are the documented ones."""
     results = world2_job()
     assert len(results) == 2
+    assert all(r.get("ok") for r in results), "\n".join(str(r.get("error", r)) for r in results)
     for r in results:
-        assert r.get("ok"), r
         assert r["steps"] == 3 and r["worst"] == 0.0
         assert r["bytes_per_peer"]["rows"] == 512 * r["capacity"]

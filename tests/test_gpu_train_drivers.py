@@ -155,7 +155,8 @@ def test_type_filtered_retrieval_vs_oracle(golden, tmp_path):
         PCompanionInference(os.path.join(str(tmp_path), "missing.pth"), c, bpg)
 
 
-def test_graphed_joint_step_equals_eager_steps():
+@pytest.mark.parametrize("mode", ["direct", "graph"])
+def test_graphed_joint_step_equals_eager_steps(mode):
     """GraphedJointStep (HIP-graph replay of pc_joint_train_step + pc_adam_step, loader building into the graph's
     fixed buffers) against the same steps launched eagerly: the same losses, top-k and parameters after 8 steps, bit
     for bit (pc_joint_fused_step has no float atomics for T <= 512: fixed-order slab sums, one-hot table gradients)."""
@@ -175,7 +176,7 @@ def test_graphed_joint_step_equals_eager_steps():
 
     m_e, o_e = make()
     m_g, o_g = make()
-    graphed = GraphedJointStep(m_g, o_g, B, warmup=2)
+    graphed = GraphedJointStep(m_g, o_g, B, warmup=2, mode=mode)
     ld_e = ComplementaryIndexLoader(ComplementaryIndexDataset(bpg, "train"), B, shuffle=True, seed=9, device="cuda")
     ld_g = ComplementaryIndexLoader(ComplementaryIndexDataset(bpg, "train"), B, shuffle=True, seed=9, device="cuda",
                                     out=graphed.static)
@@ -191,7 +192,8 @@ def test_graphed_joint_step_equals_eager_steps():
         steps += 1
         if steps == 8:
             break
-    assert steps == 8 and graphed.graph is not None            # 2 eager warm-up steps, 6 replays
+    assert steps == 8 and (graphed.graph if mode == "graph" else graphed.prepared) is not None     # 2 warm-up steps, 6 replays / direct calls
+    assert mode == "graph" or graphed.prepared.calls == 6
     for (k, pe), (_, pg) in zip(m_e.named_parameters(), m_g.named_parameters()):
         assert torch.equal(pe, pg), k              # the fused step is bitwise reproducible (T <= 512), replay or eager
     with pytest.raises(ValueError):
