@@ -482,6 +482,18 @@ int pc_scatter_rows(float *out, const int32_t *idx, int rows, int width, const f
  * (F.relu of type_transition.py:17 in module mode). */
 int pc_act_backward(const float *dy, const float *y, size_t n, int act, float *dx, void *stream);
 
+/* Zipf(s = 1) negative sampling (BASELINE configs[4]; an extension: the reference draws its negatives uniformly,
+ * data_loader.py:34).  Replaces negative_idx[batch,k_neg] of an already built batch: candidate = perm[rank - 1]
+ * (perm NULL: product id = rank - 1) with P(rank) ~ 1 / rank over ranks 1..n_products, under the reference's rejection
+ * rules (data_loader.py:33-38: not the anchor, not one of its positives, no repeats).  Integer-only: an octave
+ * [2^j, 2^(j+1)) is chosen by the first j with draw <= octave_cum[j] (n_octaves = floor(log2(n_products)) + 1 cumulative
+ * 32-bit thresholds of the octaves' probability masses, last = 0xFFFFFFFF), a rank in it uniformly (j bits), accepted
+ * with probability 2^j / rank.  Philox4x32-10 keyed by (seed ^ "ZIPF"; sample, step). */
+int pc_sample_negatives_zipf(const int32_t *pair_ids, int batch, const int32_t *sim_pairs,
+                             const int32_t *sim_rowptr, const int32_t *sim_col, int n_products, int k_neg,
+                             uint64_t seed, uint64_t step, const uint32_t *octave_cum, int n_octaves,
+                             const int32_t *perm, int32_t *negative_idx, void *stream);
+
 /* Row-sharded feature table, device-resident request bucketing (north_star: "embedding table row-shards across up
  * to 8 MI355X with RCCL all-to-all for cross-shard lookups"; the reference's table is one in-process dict,
  * src/data/bpg.py:4-22, data_loader.py:50-55).  Product r lives on rank r % world as local row r / world.

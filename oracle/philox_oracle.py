@@ -88,3 +88,37 @@ def dropout_mask(seed, offset, stream, n_elements, p):
         for i in range(4):
             out[4 * g + i] = scale if w[i] >= thr else np.float32(0.0)
     return out[:n_elements]
+
+
+# ---------------------------------------------------------------------------------------------------------
+# Zipf(s = 1) negatives of the HIP path (csrc/sampler.hip zipf_negatives_kernel; BASELINE configs[4] -- an extension,
+# the reference samples uniformly).  Same integer procedure: octave by cumulative 32-bit thresholds, a rank in it by j
+# random bits, accepted with probability 2^j / rank; then the rejection rules of data_loader.py:33-38.
+ZIPF_TAG = 0x5a495046
+
+
+def zipf_negatives(pair_ids, sim_pairs, sim_rowptr, sim_col, n_products, k, seed, step, thresholds, perm=None):
+    thr = [int(x) for x in np.asarray(thresholds).astype(np.uint32)]
+    out = np.zeros((len(pair_ids), k), np.int32)
+    for b, pid in enumerate(pair_ids):
+        a = int(sim_pairs[pid, 0])
+        pos = set(sim_col[sim_rowptr[a]:sim_rowptr[a + 1]].tolist())
+        s = Stream(seed ^ ZIPF_TAG, step, b)
+        got = []
+        while len(got) < k:
+            r0 = s.next()
+            j = 0
+            while j + 1 < len(thr) and r0 > thr[j]:
+                j += 1
+            base = 1 << j
+            kk = base + ((s.next() >> (32 - j)) if j else 0)
+            if kk > n_products:
+                continue
+            r2 = s.next()
+            if r2 * kk >= (base << 32):
+                continue
+            c = int(perm[kk - 1]) if perm is not None else kk - 1
+            if c != a and c not in pos and c not in got:
+                got.append(c)
+        out[b] = got
+    return out

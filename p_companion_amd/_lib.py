@@ -131,6 +131,7 @@ SIGNATURES = {
     "pc_scatter_add_rows_small": (_i, [_vp, _i, _vp, _i, _i, _vp, _vp]),
     "pc_scatter_rows": (_i, [_vp, _vp, _i, _i, _vp, _vp]),
     "pc_act_backward": (_i, [_vp, _vp, _sz, _i, _vp, _vp]),
+    "pc_sample_negatives_zipf": (_i, [_vp, _i, _vp, _vp, _vp, _i, _i, _u64, _u64, _vp, _i, _vp, _vp, _vp]),
     "pc_shard_bucket": (_i, [_P(ctypes.c_void_p), _P(ctypes.c_int), _P(ctypes.c_void_p), _P(ctypes.c_int), _P(ctypes.c_void_p),
                              _i, _i, _i, _vp, _vp, _vp, _vp]),
     "pc_dropout_hidden": (_i, [_vp, _sz, _P(Dropout), _vp, _vp]),

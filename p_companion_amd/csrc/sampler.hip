@@ -332,6 +332,53 @@ extern "C" int pc_build_similarity_batch(const int32_t* pair_ids, int batch, con
 }
 
 // ---------------------------------------------------------------------------------------
+// Zipf(s = 1) negatives (BASELINE configs[4]: "Zipf-skewed negative sampling"; no reference counterpart -- the
+// reference draws uniformly, data_loader.py:34): candidate = perm[k - 1] with P(k) proportional to 1 / k over the
+// popularity ranks k = 1..P, then the SAME rejection rules as data_loader.py:33-38 (not the anchor, not one of its
+// positives, not drawn before).  Integer arithmetic only, so the host restatement (philox_oracle.zipf_negatives) is bit
+// exact: the octaves [2^j, 2^(j+1)) carry nearly equal mass under 1 / k -- an octave is picked by comparing one 32-bit
+// draw with the cumulative thresholds octave_cum[j] (computed once on the host), a rank inside it is proposed
+// uniformly (j random bits) and accepted with probability 2^j / k (r * k < 2^j * 2^32 for a third draw r).
+__global__ void zipf_negatives_kernel(const int32_t* pair_ids, int B, const int32_t* sim_pairs, const int32_t* sim_rowptr,
+                                      const int32_t* sim_col, int n_products, int K, uint64_t seed, uint64_t step,
+                                      const uint32_t* octave_cum, int n_octaves, const int32_t* perm,
+                                      int32_t* negative_idx) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    const int a = sim_pairs[2 * pair_ids[b]];
+    const int lo = sim_rowptr[a], hi = sim_rowptr[a + 1];
+    Philox rng(seed ^ 0x5a495046ull, step, (uint32_t)b);          // its own stream ("ZIPF"), apart from the uniform sampler's
+    int got = 0;
+    while (got < K) {
+        const uint32_t r0 = rng.next();
+        int j = 0;
+        while (j + 1 < n_octaves && r0 > octave_cum[j]) j++;
+        const uint32_t base = 1u << j;
+        const uint32_t k = base + (j ? (rng.next() >> (32 - j)) : 0u);
+        if (k > (uint32_t)n_products) continue;                   // the last octave may be partial
+        const uint32_t r2 = rng.next();
+        if ((uint64_t)r2 * k >= ((uint64_t)base << 32)) continue; // accept with probability 2^j / k
+        const int c = perm ? perm[k - 1] : (int)(k - 1);
+        bool ok = c != a;
+        for (int q = lo; ok && q < hi; q++) ok = sim_col[q] != c;
+        for (int q = 0; ok && q < got; q++) ok = negative_idx[(size_t)b * K + q] != c;
+        if (ok) negative_idx[(size_t)b * K + got++] = c;
+    }
+}
+
+extern "C" int pc_sample_negatives_zipf(const int32_t* pair_ids, int batch, const int32_t* sim_pairs,
+                                        const int32_t* sim_rowptr, const int32_t* sim_col, int n_products, int k_neg,
+                                        uint64_t seed, uint64_t step, const uint32_t* octave_cum, int n_octaves,
+                                        const int32_t* perm, int32_t* negative_idx, void* stream) {
+    if (!pair_ids || !sim_pairs || !sim_rowptr || !sim_col || !octave_cum || !negative_idx) return PC_EINVAL;
+    if (batch <= 0 || k_neg <= 0 || n_products <= k_neg + 1 || n_octaves < 1 || n_octaves > 31) return PC_EINVAL;
+    if ((1ll << (n_octaves - 1)) > (long long)n_products) return PC_EINVAL;      // the last octave must start inside [1, P]
+    PC_LAUNCH(zipf_negatives_kernel, dim3((batch + 127) / 128), dim3(128), 0, (hipStream_t)stream, pair_ids, batch, sim_pairs,
+              sim_rowptr, sim_col, n_products, k_neg, seed, step, octave_cum, n_octaves, perm, negative_idx);
+    return pc_launch_status();
+}
+
+// ---------------------------------------------------------------------------------------
 // J1 on device: ComplementaryDataset.__getitem__ + collate_fn (data_loader.py:133-157) for a batch
 // of labelled pairs (query, target, label):
 //   label +1: positive_types = t(target), negative_types = (t(target)+1) % n_types,

@@ -169,7 +169,8 @@ class SimilarityIndexLoader:
     """
 
     def __init__(self, bpg: IntBPG, batch_size: int, shuffle=True, sampler="philox", seed=0, k_neg=5,
-                 drop_last=False, device="cuda", compact=True, prefetch=True, unique=True, sharded=None):
+                 drop_last=False, device="cuda", compact=True, prefetch=True, unique=True, sharded=None,
+                 negatives="uniform", popularity=None):
         from . import ops
         self.ops = ops
         self.bpg = bpg
@@ -190,6 +191,19 @@ class SimilarityIndexLoader:
         self.prefetch = prefetch and sampler == "philox" and torch.device(device).type == "cuda"
         self.epoch = 0
         self.step = 0
+        # negatives='zipf' (BASELINE configs[4]; an extension, the reference draws uniformly): P(rank) ~ 1 / rank over the
+        # popularity permutation `popularity` ([P] int32 product id per rank; None: product 0 is the most popular),
+        # same rejection rules, device sampler only
+        if negatives not in ("uniform", "zipf"):
+            raise ValueError("negatives: 'uniform' or 'zipf'")
+        if negatives == "zipf" and sampler != "philox":
+            raise ValueError("Zipf negatives come from the device sampler (sampler='philox')")
+        self.negatives = negatives
+        self._zipf = None
+        if negatives == "zipf":
+            thr = ops.zipf_octave_thresholds(bpg.num_products)
+            self._zipf = (torch.from_numpy(thr.view(np.int32).copy()).to(device),
+                          None if popularity is None else torch.as_tensor(np.ascontiguousarray(popularity, np.int32)).to(device))
         self.sharded = sharded          # distributed.ShardedFeatureTable: batches then carry their own gathered `table`
         if sharded is not None and not (compact and sampler == "philox"):
             raise ValueError("the sharded lookup consumes the compact / unique neighbour layouts of the device sampler")
@@ -263,6 +277,9 @@ class SimilarityIndexLoader:
                     nbr[r, :len(nb_)] = nb_
                 up = lambda x: torch.from_numpy(np.ascontiguousarray(x, np.int32)).to(self.device)
                 a, p, ng, nb = up(pairs[:, 0]), up(pairs[:, 1]), up(negs), (up(nbr) if n_pad else None)
+            if self._zipf is not None:
+                self.ops.sample_negatives_zipf(perm_dev[lo:hi], self.g, self.k_neg, self.seed, self.step, self._zipf[0],
+                                               self._zipf[1], out=ng)
             self.step += 1
             batch = {"anchor_idx": a, "positive_idx": p, "negative_idx": ng, "n_pad": n_pad}
             if nb is not None:

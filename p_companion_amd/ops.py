@@ -828,6 +828,37 @@ def act_backward(dy, y, act):
     return dx
 
 
+def zipf_octave_thresholds(n_products):
+    """Cumulative 32-bit thresholds of the octave masses of P(rank) ~ 1 / rank, rank = 1..n_products (host, float64 once;
+    the device and the oracle then compare integers only).  octave j = ranks [2^j, min(2^(j+1), P + 1))."""
+    n_oct = int(n_products).bit_length()
+    mass = []
+    for j in range(n_oct):
+        lo, hi = 1 << j, min((1 << (j + 1)) - 1, int(n_products))
+        if hi - lo < 4096:
+            mass.append(float(np.sum(1.0 / np.arange(lo, hi + 1, dtype=np.float64))))
+        else:                                    # Euler-Maclaurin: sum_{k=lo}^{hi} 1/k, error < 1e-12 for lo >= 4096
+            mass.append(float(np.log(hi / lo) + 0.5 / lo + 0.5 / hi + (1.0 / lo ** 2 - 1.0 / hi ** 2) / 12.0))
+    cum = np.cumsum(mass) / np.sum(mass)
+    thr = np.minimum(np.floor(cum * 4294967296.0), 4294967295.0).astype(np.uint64).astype(np.uint32)
+    thr[-1] = 0xFFFFFFFF
+    return thr
+
+
+def sample_negatives_zipf(pair_ids, graph, k_neg, seed, step, thresholds, perm=None, out=None):
+    """pc_sample_negatives_zipf: returns negative_idx [B,k_neg] (int32, device).  thresholds: uint32 device tensor from
+    zipf_octave_thresholds (viewed as int32 storage)."""
+    b = pair_ids.numel()
+    _req(pair_ids, torch.int32, "pair_ids"); _req(thresholds, torch.int32, "thresholds")
+    if perm is not None:
+        _req(perm, torch.int32, "perm", (int(graph["n_products"]),))
+    ng = out if out is not None else torch.empty(b, k_neg, dtype=torch.int32, device=pair_ids.device)
+    check(_lib.lib().pc_sample_negatives_zipf(_p(pair_ids), b, _p(graph["sim_pairs"]), _p(graph["sim_rowptr"]), _p(graph["sim_col"]),
+                                              int(graph["n_products"]), int(k_neg), int(seed), int(step), _p(thresholds),
+                                              thresholds.numel(), _p(perm), _p(ng), _stream()), "pc_sample_negatives_zipf")
+    return ng
+
+
 def shard_bucket(arrays, world, capacity, counts, send_ids, overflow):
     """pc_shard_bucket.  arrays: up to four (ids int32 tensor, live-length device tensor or None, add) triples; returns
     the remapped index tensors (same shapes).  counts [world], send_ids [world*capacity], overflow [1]: int32 device."""

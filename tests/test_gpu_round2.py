@@ -293,3 +293,49 @@ def test_fused_joint_step_at_reference_num_types():
     touched[b["positive_types"].reshape(-1)] = True
     touched[b["negative_types"].reshape(-1)] = True
     assert float(gf["complementary_type_embeddings.weight"][~touched].abs().max()) == 0.0
+
+
+# ------------------------------------------------------------------ Zipf negatives (BASELINE configs[4])
+def test_zipf_negatives_bit_exact_vs_oracle_and_rules(golden):
+    from oracle import philox_oracle
+    from p_companion_amd import ops
+    from p_companion_amd.data import IntBPG
+    bpg = IntBPG.from_arrays(golden("g2_bpg1000.npz"))
+    g = bpg.cuda()
+    P = bpg.num_products
+    thr = ops.zipf_octave_thresholds(P)
+    thr_d = torch.from_numpy(thr.view(np.int32).copy()).cuda()
+    rs = np.random.default_rng(0)
+    perm = rs.permutation(P).astype(np.int32)
+    pair_ids = torch.arange(0, 300, dtype=torch.int32).cuda()
+    for pm in (None, perm):
+        got = ops.sample_negatives_zipf(pair_ids, g, 5, 77, 3, thr_d, None if pm is None else torch.from_numpy(pm).cuda())
+        want = philox_oracle.zipf_negatives(np.arange(300), bpg.similarity_pairs, bpg.sim_rowptr, bpg.sim_col, P, 5, 77, 3, thr, pm)
+        assert np.array_equal(got.cpu().numpy(), want)
+        for b in range(300):                                     # the reference's rejection rules
+            a = bpg.similarity_pairs[b, 0]
+            pos = set(bpg.sim_col[bpg.sim_rowptr[a]:bpg.sim_rowptr[a + 1]].tolist())
+            row = want[b].tolist()
+            assert a not in row and not (pos & set(row)) and len(set(row)) == 5
+
+
+def test_zipf_negatives_follow_one_over_rank():
+    from p_companion_amd.data import SimilarityIndexLoader, generate_scaled_bpg
+    bpg = generate_scaled_bpg(50000, 100, seed=4)
+    ld = SimilarityIndexLoader(bpg, 4096, seed=9, drop_last=True, negatives="zipf", prefetch=False)
+    cnt = np.zeros(bpg.num_products, np.int64)
+    n = 0
+    for b in ld:
+        np.add.at(cnt, b["negative_idx"].cpu().numpy().reshape(-1), 1)
+        n += 1
+        if n == 12:
+            break
+    total = cnt.sum()
+    h = np.sum(1.0 / np.arange(1, bpg.num_products + 1))
+    # octave masses: ranks [2^j, 2^(j+1)) each carry ~ln 2 / H_P of the draws (product id = rank - 1 here)
+    for j in (0, 3, 6, 9, 12, 15):
+        lo, hi = (1 << j) - 1, min((1 << (j + 1)) - 1, bpg.num_products)
+        want = np.sum(1.0 / np.arange(lo + 1, hi + 1)) / h
+        got = cnt[lo:hi].sum() / total
+        assert abs(got - want) < 0.012, (j, got, want)
+    assert cnt[0] > 10 * max(cnt[1000:1010].mean(), 1)           # the head is heavy
