@@ -70,6 +70,8 @@ typedef struct {
     int64_t *num_batches_tracked;
     pc_dropout dropout;   /* attention-weight dropout of nn.MultiheadAttention(dropout=config.DROPOUT) in
                            * training mode (product2vec.py:23-28); all-zero = off (eval, or DROPOUT = 0) */
+    int dim;              /* D = config.PRODUCT_EMB_DIM (product2vec.py:14-29 take it from the config): 128, or 256
+                           * (BASELINE configs[4]; head dim 64).  0 = 128.  Shapes above with that D; H stays 256. */
 } pc_p2v_tensors;
 
 /* Row groups ("segments") of one FFN launch.  The reference calls the FFN once per tensor
@@ -139,7 +141,8 @@ int pc_p2v_ffn_backward(const pc_p2v_tensors *p, const pc_p2v_tensors *g, const 
 typedef struct {
     float *q, *kv, *probs, *ctx;
 } pc_attn_saved;
-size_t pc_p2v_attention_workspace_bytes(int batch, int n_keys);
+size_t pc_p2v_attention_workspace_bytes(int batch, int n_keys);                       /* D = 128 */
+size_t pc_p2v_attention_workspace_bytes_dim(int batch, int n_keys, int dim);          /* D = 128 or 256 */
 int pc_p2v_attention_forward(const pc_p2v_tensors *p, const float *query, const float *keys,
                              int batch, int n_keys, float *out, const pc_attn_saved *saved,
                              void *ws, size_t ws_bytes, void *stream);
@@ -157,7 +160,10 @@ int pc_p2v_attention_backward(const pc_p2v_tensors *p, const pc_p2v_tensors *g,
  * non-NULL, da/dp/dn = d(loss)/d(.)  (already including the 1/B of the mean). */
 int pc_p2v_triplet_loss(const float *a, const float *p, const float *n, int batch, int k_neg,
                         float margin, float *loss, float *d_pos, float *d_neg, float *da,
-                        float *dp, float *dn, void *stream);
+                        float *dp, float *dn, void *stream);                                   /* D = 128 */
+int pc_p2v_triplet_loss_dim(const float *a, const float *p, const float *n, int batch, int k_neg, int dim,
+                            float margin, float *loss, float *d_pos, float *d_neg, float *da,
+                            float *dp, float *dn, void *stream);                               /* D = 128 or 256 */
 
 /* P10: torch.optim.Adam (scripts/pretrain_product2vec.py:34, train.py:24; defaults beta
  * (0.9,0.999), eps 1e-8), no weight decay / amsgrad, bias-corrected, dense over `n` floats.
@@ -174,7 +180,8 @@ int pc_adam_step(float *param, const float *grad, float *exp_avg, float *exp_avg
  * Outputs: loss[1] (+ d_pos/d_neg[B], anchor_emb[B,D] when non-NULL).  profile: NULL, or a
  * pc_profile_create handle (see below).
  * ws: pc_p2v_train_step_workspace_bytes(B,N,K). */
-size_t pc_p2v_train_step_workspace_bytes(int batch, int n_nbr, int k_neg);
+size_t pc_p2v_train_step_workspace_bytes(int batch, int n_nbr, int k_neg);                  /* D = 128 */
+size_t pc_p2v_train_step_workspace_bytes_dim(int batch, int n_nbr, int k_neg, int dim);     /* D = 128 or 256 (p->dim) */
 int pc_p2v_train_step(const pc_p2v_tensors *p, const pc_p2v_tensors *g, const float *table,
                       const int32_t *anchor_idx, const int32_t *positive_idx,
                       const int32_t *negative_idx, const int32_t *neighbor_idx, int batch,

@@ -30,7 +30,7 @@ class Dropout(ctypes.Structure):
 class P2VTensors(ctypes.Structure):
     _fields_ = [(n, ctypes.c_void_p) for n in (
         "w0", "b0", "gamma", "beta", "w3", "b3", "w5", "b5", "in_proj_w", "in_proj_b", "out_proj_w",
-        "out_proj_b", "running_mean", "running_var", "num_batches_tracked")] + [("dropout", Dropout)]
+        "out_proj_b", "running_mean", "running_var", "num_batches_tracked")] + [("dropout", Dropout), ("dim", ctypes.c_int)]
 
 
 class Segments(ctypes.Structure):
@@ -71,12 +71,15 @@ SIGNATURES = {
     "pc_p2v_ffn_backward": (_i, [_P(P2VTensors), _P(P2VTensors), _vp, _vp, _i, _P(Segments), _vp, _P(FfnSaved),
                                  _vp, _i, _vp, _sz, _vp]),
     "pc_p2v_attention_workspace_bytes": (_sz, [_i, _i]),
+    "pc_p2v_attention_workspace_bytes_dim": (_sz, [_i, _i, _i]),
     "pc_p2v_attention_forward": (_i, [_P(P2VTensors), _vp, _vp, _i, _i, _vp, _P(AttnSaved), _vp, _sz, _vp]),
     "pc_p2v_attention_backward": (_i, [_P(P2VTensors), _P(P2VTensors), _vp, _vp, _i, _i, _vp, _P(AttnSaved), _vp,
                                        _vp, _i, _vp, _sz, _vp]),
     "pc_p2v_triplet_loss": (_i, [_vp, _vp, _vp, _i, _i, _f, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "pc_p2v_triplet_loss_dim": (_i, [_vp, _vp, _vp, _i, _i, _i, _f, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "pc_adam_step": (_i, [_vp, _vp, _vp, _vp, _sz, _vp, _vp, _d, _d, _d, _d, _vp]),
     "pc_p2v_train_step_workspace_bytes": (_sz, [_i, _i, _i]),
+    "pc_p2v_train_step_workspace_bytes_dim": (_sz, [_i, _i, _i, _i]),
     "pc_p2v_train_step": (_i, [_P(P2VTensors), _P(P2VTensors), _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _f, _vp, _vp,
                                _vp, _vp, _vp, _vp, _sz, _vp]),
     "pc_p2v_train_step_compact": (_i, [_P(P2VTensors), _P(P2VTensors), _vp, _vp, _vp, _vp, _vp, _i, _vp, _i, _i, _i, _f,

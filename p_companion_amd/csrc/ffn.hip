@@ -246,9 +246,9 @@ static FfnWs ffn_ws_layout(void* base, int rows) {
     w.stat_b = take((size_t)max_tiles * PC_H);
     w.dz2 = take((size_t)rows * PC_H);
     w.dz1 = take((size_t)rows * PC_H);
-    w.w5t = take(PC_H * PC_D);
+    w.w5t = take(PC_H * 256);                  // [H, D], D <= 256
     w.w3t = take(PC_H * PC_H);
-    w.w0t = take(PC_D * PC_H);
+    w.w0t = take(256 * PC_H);
     w.c1 = take(PC_MAX_SEG * PC_H);
     w.c2 = take(PC_MAX_SEG * PC_H);
     w.coef = take(2 * PC_H);
@@ -265,9 +265,12 @@ extern "C" size_t pc_p2v_ffn_workspace_bytes(int rows) {
     return ffn_ws_layout(nullptr, rows).total;
 }
 
+static inline int p2v_dim(const pc_p2v_tensors* p) { return p && p->dim == 256 ? 256 : PC_D; }
+
 static int ffn_check(const pc_p2v_tensors* p, const float* table, int rows, const pc_segments* seg, void* ws,
                      size_t ws_bytes) {
     if (!p || !table || rows <= 0 || !ws) return PC_EINVAL;
+    if (p->dim != 0 && p->dim != 128 && p->dim != 256) return PC_ESHAPE;
     if (!p->w0 || !p->b0 || !p->gamma || !p->beta || !p->w3 || !p->b3 || !p->w5 || !p->b5) return PC_EINVAL;
     if (!seg_valid(seg, rows)) return PC_EINVAL;
     if (ws_bytes < pc_p2v_ffn_workspace_bytes(rows)) return PC_EWORKSPACE;
@@ -289,9 +292,10 @@ int ffn_forward_part1(const pc_p2v_tensors* p, const float* table, const int32_t
     PC_TRY(ffn_check(p, table, rows, seg, ws, ws_bytes));
     if (!sv || !sv->h0 || !sv->a2 || !sv->bn_mean || !sv->bn_invstd || !sv->bn_scale || !sv->bn_shift) return PC_EINVAL;
     hipStream_t st = (hipStream_t)stream;
+    const int D = p2v_dim(p);
     const SegInfo si = make_seginfo(seg, rows, 128);
     FfnWs w = ffn_ws_layout(ws, rows);
-    NtArgs g1 = nt_plain(table, PC_D, p->w0, PC_D, p->b0, sv->h0, PC_H, rows, PC_H, PC_D, si);
+    NtArgs g1 = nt_plain(table, D, p->w0, D, p->b0, sv->h0, PC_H, rows, PC_H, D, si);
     g1.gather = idx;
     g1.stats = NT_STAT_SUMSQ; g1.stat_sum = w.stat_a; g1.stat_aux = w.stat_b;
     PC_TRY(launch_gemm_nt(g1, st));
@@ -318,7 +322,8 @@ int ffn_forward_part2(const pc_p2v_tensors* p, int rows, const pc_segments* seg,
     g2.epilogue = NT_EPI_TANH;
     PC_TRY(launch_gemm_nt(g2, st));
 
-    NtArgs g3 = nt_plain(sv->a2, PC_H, p->w5, PC_H, p->b5, y, PC_D, rows, PC_D, PC_H, si);
+    const int D = p2v_dim(p);
+    NtArgs g3 = nt_plain(sv->a2, PC_H, p->w5, PC_H, p->b5, y, D, rows, D, PC_H, si);
     return launch_gemm_nt(g3, st);
 }
 
@@ -342,14 +347,15 @@ extern "C" int pc_p2v_ffn_forward_eval(const pc_p2v_tensors* p, const float* tab
     PC_LAUNCH(bn_eval_coeff_kernel, dim3(1), dim3(PC_H), 0, st, p->gamma, p->beta, p->running_mean,
                        p->running_var, w.coef, w.coef + PC_H);
     PC_TRY(pc_launch_status());
-    NtArgs g1 = nt_plain(table, PC_D, p->w0, PC_D, p->b0, h0, PC_H, rows, PC_H, PC_D, si);
+    const int D = p2v_dim(p);
+    NtArgs g1 = nt_plain(table, D, p->w0, D, p->b0, h0, PC_H, rows, PC_H, D, si);
     g1.gather = idx;
     PC_TRY(launch_gemm_nt(g1, st));
     NtArgs g2 = nt_plain(h0, PC_H, p->w3, PC_H, p->b3, a2, PC_H, rows, PC_H, PC_H, si);
     g2.prologue = NT_PRO_BNTANH; g2.pscale = w.coef; g2.pshift = w.coef + PC_H;
     g2.epilogue = NT_EPI_TANH;
     PC_TRY(launch_gemm_nt(g2, st));
-    NtArgs g3 = nt_plain(a2, PC_H, p->w5, PC_H, p->b5, y, PC_D, rows, PC_D, PC_H, si);
+    NtArgs g3 = nt_plain(a2, PC_H, p->w5, PC_H, p->b5, y, D, rows, D, PC_H, si);
     return launch_gemm_nt(g3, st);
 }
 
@@ -365,21 +371,22 @@ int ffn_backward_part1(const pc_p2v_tensors* p, const pc_p2v_tensors* g, const f
     const SegInfo si = make_seginfo(seg, rows, 128);
     FfnWs w = ffn_ws_layout(ws, rows);
 
+    const int D = p2v_dim(p);
     TransposeBatch tb = {};
-    tb.job[0] = {p->w5, w.w5t, PC_D, PC_H};                   // [D,H] -> [H,D]
+    tb.job[0] = {p->w5, w.w5t, D, PC_H};                      // [D,H] -> [H,D]
     tb.job[1] = {p->w3, w.w3t, PC_H, PC_H};
     tb.n = 2;
-    if (with_dx) tb.job[tb.n++] = {p->w0, w.w0t, PC_H, PC_D};      // [H,D] -> [D,H]
+    if (with_dx) tb.job[tb.n++] = {p->w0, w.w0t, PC_H, D};         // [H,D] -> [D,H]
     PC_TRY(launch_transpose_batch(tb, st));
 
     // dZ2 = (dY W5) * (1 - A2^2)
-    NtArgs b1 = nt_plain(dy, PC_D, w.w5t, PC_D, nullptr, w.dz2, PC_H, rows, PC_H, PC_D, si);
+    NtArgs b1 = nt_plain(dy, D, w.w5t, D, nullptr, w.dz2, PC_H, rows, PC_H, D, si);
     b1.epilogue = NT_EPI_DTANH; b1.aux = sv->a2; b1.ldaux = PC_H;
     PC_TRY(launch_gemm_nt(b1, st));
 
     // dW5 = dY^T A2, db5
     TnArgs t5 = {};
-    t5.Z = dy; t5.ldz = PC_D; t5.A = sv->a2; t5.lda = PC_H; t5.R = rows; t5.No = PC_D; t5.Ni = PC_H; t5.seg = si;
+    t5.Z = dy; t5.ldz = D; t5.A = sv->a2; t5.lda = PC_H; t5.R = rows; t5.No = D; t5.Ni = PC_H; t5.seg = si;
     t5.dW = g->w5; t5.lddw = PC_H; t5.db = g->b5; t5.accumulate = accumulate; t5.slabs = w.slabs;
     t5.slab_floats = w.slab_floats;
     PC_TRY(launch_gemm_tn(t5, st));
@@ -416,10 +423,11 @@ int ffn_backward_part2(const pc_p2v_tensors* g, const float* table, const int32_
 
     // dW0 = dH0^T X (rows gathered again from the table), db0.  Without a dx consumer the BatchNorm
     // backward is applied to dZ1 on the fly inside the loader and dH0 never touches HBM.
+    const int D = p2v_dim(g);                                     // (the gradient struct carries the same dim)
     TnArgs t0 = {};
-    t0.Z = w.dz1; t0.ldz = PC_H; t0.A = table; t0.lda = PC_D; t0.gather = idx; t0.R = rows; t0.No = PC_H;
-    t0.Ni = PC_D; t0.seg = si;
-    t0.dW = g->w0; t0.lddw = PC_D; t0.db = g->b0; t0.accumulate = accumulate; t0.slabs = w.slabs;
+    t0.Z = w.dz1; t0.ldz = PC_H; t0.A = table; t0.lda = D; t0.gather = idx; t0.R = rows; t0.No = PC_H;
+    t0.Ni = D; t0.seg = si;
+    t0.dW = g->w0; t0.lddw = D; t0.db = g->b0; t0.accumulate = accumulate; t0.slabs = w.slabs;
     t0.slab_floats = w.slab_floats;
     if (dx) {
         int blocks = (rows + 3) / 4;
@@ -434,7 +442,7 @@ int ffn_backward_part2(const pc_p2v_tensors* g, const float* table, const int32_
     PC_TRY(launch_gemm_tn(t0, st));
 
     if (dx) {
-        NtArgs b3 = nt_plain(w.dz1, PC_H, w.w0t, PC_H, nullptr, dx, PC_D, rows, PC_D, PC_H, si);
+        NtArgs b3 = nt_plain(w.dz1, PC_H, w.w0t, PC_H, nullptr, dx, D, rows, D, PC_H, si);
         PC_TRY(launch_gemm_nt(b3, st));
     }
     return PC_OK;

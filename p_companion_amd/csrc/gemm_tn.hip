@@ -514,6 +514,7 @@ int launch_gemm_tn(const TnArgs& a, hipStream_t st) {
 #define TN8(WO, WI, TO, TI)                                                                                   \
     do {                                                                                                      \
         if (apro) PC_LAUNCH((gemm_tn8_kernel<WO, WI, TO, TI, 32, 2, true, false>), dim3(nsplit), dim3(64 * WO * WI), 0, st, a, nsplit, rps);       \
+        else if (zpro && a.Ni > 128) PC_LAUNCH((gemm_tn8_kernel<2, 4, 4, 2, 16, 3, false, true>), dim3(nsplit), dim3(512), 0, st, a, nsplit, rps);  \
         else if (zpro) PC_LAUNCH((gemm_tn8_kernel<4, 2, 2, 2, 16, 3, false, true>), dim3(nsplit), dim3(512), 0, st, a, nsplit, rps);  \
         else PC_LAUNCH((gemm_tn8_kernel<WO, WI, TO, TI, 32, 2, false, false>), dim3(nsplit), dim3(64 * WO * WI), 0, st, a, nsplit, rps);           \
     } while (0)

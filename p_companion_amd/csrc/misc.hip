@@ -8,25 +8,37 @@
 #define LOSS_MAX_K 8
 #define PAIR_EPS 1e-6f
 
+// lane l owns dims [VW l, VW l + VW), VW = D / 64 (2 at D = 128, 4 at D = 256)
+template <int VW>
 __global__ __launch_bounds__(256) void triplet_loss_kernel(const float* a, const float* p, const float* n, int B,
                                                            int K, float margin, float* d_pos, float* d_neg,
                                                            float* da, float* dp, float* dn) {
+    constexpr int D = 64 * VW;
     const int lane = threadIdx.x & 63;
     const int b = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (b >= B) return;
-    const float2 av = *reinterpret_cast<const float2*>(a + (size_t)b * PC_D + 2 * lane);
-    const float2 pv = *reinterpret_cast<const float2*>(p + (size_t)b * PC_D + 2 * lane);
-    const float2 dpv = make_float2(av.x - pv.x + PAIR_EPS, av.y - pv.y + PAIR_EPS);
-    const float dpos = sqrtf(wave_sum(dpv.x * dpv.x + dpv.y * dpv.y));
-    float2 dnv[LOSS_MAX_K];
+    float av[VW], dpv[VW];
+    float s = 0.f;
+#pragma unroll
+    for (int c = 0; c < VW; c++) {
+        av[c] = a[(size_t)b * D + VW * lane + c];
+        dpv[c] = av[c] - p[(size_t)b * D + VW * lane + c] + PAIR_EPS;
+        s += dpv[c] * dpv[c];
+    }
+    const float dpos = sqrtf(wave_sum(s));
+    float dnv[LOSS_MAX_K][VW];
     float dn_j[LOSS_MAX_K];
     float dneg = 0.f;
 #pragma unroll
     for (int j = 0; j < LOSS_MAX_K; j++) {
         if (j < K) {
-            const float2 nv = *reinterpret_cast<const float2*>(n + ((size_t)b * K + j) * PC_D + 2 * lane);
-            dnv[j] = make_float2(av.x - nv.x + PAIR_EPS, av.y - nv.y + PAIR_EPS);
-            dn_j[j] = sqrtf(wave_sum(dnv[j].x * dnv[j].x + dnv[j].y * dnv[j].y));
+            float t = 0.f;
+#pragma unroll
+            for (int c = 0; c < VW; c++) {
+                dnv[j][c] = av[c] - n[((size_t)b * K + j) * D + VW * lane + c] + PAIR_EPS;
+                t += dnv[j][c] * dnv[j][c];
+            }
+            dn_j[j] = sqrtf(wave_sum(t));
             dneg += dn_j[j];
         }
     }
@@ -37,19 +49,25 @@ __global__ __launch_bounds__(256) void triplet_loss_kernel(const float* a, const
     const float gs = active ? 1.0f / (float)B : 0.f;        // d(mean)/d(l_b)
     // d l / d d+ = -1 ; d l / d d-_j = 1/K
     const float ip = gs / dpos;
-    float2 ga = make_float2(-dpv.x * ip, -dpv.y * ip);
-    *reinterpret_cast<float2*>(dp + (size_t)b * PC_D + 2 * lane) = make_float2(dpv.x * ip, dpv.y * ip);
+    float ga[VW];
+#pragma unroll
+    for (int c = 0; c < VW; c++) {
+        ga[c] = -dpv[c] * ip;
+        dp[(size_t)b * D + VW * lane + c] = dpv[c] * ip;
+    }
 #pragma unroll
     for (int j = 0; j < LOSS_MAX_K; j++) {
         if (j < K) {
             const float in = gs / ((float)K * dn_j[j]);
-            ga.x += dnv[j].x * in;
-            ga.y += dnv[j].y * in;
-            *reinterpret_cast<float2*>(dn + ((size_t)b * K + j) * PC_D + 2 * lane) =
-                make_float2(-dnv[j].x * in, -dnv[j].y * in);
+#pragma unroll
+            for (int c = 0; c < VW; c++) {
+                ga[c] += dnv[j][c] * in;
+                dn[((size_t)b * K + j) * D + VW * lane + c] = -dnv[j][c] * in;
+            }
         }
     }
-    *reinterpret_cast<float2*>(da + (size_t)b * PC_D + 2 * lane) = ga;
+#pragma unroll
+    for (int c = 0; c < VW; c++) da[(size_t)b * D + VW * lane + c] = ga[c];
 }
 
 // loss = mean_b relu(margin - d+ + d-): single block, fixed summation order
@@ -69,18 +87,26 @@ __global__ void hinge_mean_kernel(const float* d_pos, const float* d_neg, int B,
     if (threadIdx.x == 0) *loss = red[0] / (float)B;
 }
 
-extern "C" int pc_p2v_triplet_loss(const float* a, const float* p, const float* n, int batch, int k_neg,
-                                   float margin, float* loss, float* d_pos, float* d_neg, float* da, float* dp,
-                                   float* dn, void* stream) {
+extern "C" int pc_p2v_triplet_loss_dim(const float* a, const float* p, const float* n, int batch, int k_neg, int dim,
+                                       float margin, float* loss, float* d_pos, float* d_neg, float* da, float* dp,
+                                       float* dn, void* stream) {
     if (!a || !p || !n || !loss || !d_pos || !d_neg || batch <= 0) return PC_EINVAL;
-    if (k_neg < 1 || k_neg > LOSS_MAX_K) return PC_ESHAPE;
+    if (k_neg < 1 || k_neg > LOSS_MAX_K || (dim != 128 && dim != 256)) return PC_ESHAPE;
     if (da && (!dp || !dn)) return PC_EINVAL;
     hipStream_t st = (hipStream_t)stream;
-    PC_LAUNCH(triplet_loss_kernel, dim3((batch + 3) / 4), dim3(256), 0, st, a, p, n, batch, k_neg, margin,
-                       d_pos, d_neg, da, dp, dn);
+    if (dim == 128) PC_LAUNCH(triplet_loss_kernel<2>, dim3((batch + 3) / 4), dim3(256), 0, st, a, p, n, batch, k_neg, margin,
+                              d_pos, d_neg, da, dp, dn);
+    else PC_LAUNCH(triplet_loss_kernel<4>, dim3((batch + 3) / 4), dim3(256), 0, st, a, p, n, batch, k_neg, margin,
+                   d_pos, d_neg, da, dp, dn);
     PC_TRY(pc_launch_status());
     PC_LAUNCH(hinge_mean_kernel, dim3(1), dim3(256), 0, st, d_pos, d_neg, batch, margin, loss);
     return pc_launch_status();
+}
+
+extern "C" int pc_p2v_triplet_loss(const float* a, const float* p, const float* n, int batch, int k_neg,
+                                   float margin, float* loss, float* d_pos, float* d_neg, float* da, float* dp,
+                                   float* dn, void* stream) {
+    return pc_p2v_triplet_loss_dim(a, p, n, batch, k_neg, PC_D, margin, loss, d_pos, d_neg, da, dp, dn, stream);
 }
 
 // ---------------------------------------------------------------------------------------

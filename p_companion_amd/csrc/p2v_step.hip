@@ -17,7 +17,7 @@ struct StepWs {
     size_t total;
 };
 
-static StepWs step_ws_layout(void* base, int B, int N, int K) {
+static StepWs step_ws_layout(void* base, int B, int N, int K, int D) {
     StepWs w;
     const size_t R = (size_t)B * (2 + N + K) + 1;          // +1: the shared padding row of the compact layout
     size_t off = 0;
@@ -27,31 +27,38 @@ static StepWs step_ws_layout(void* base, int B, int N, int K) {
         return p;
     };
     w.idx_all = (int32_t*)take(R * 4);
-    w.y = (float*)take(R * PC_D * 4);
+    w.y = (float*)take(R * D * 4);
     w.h0 = (float*)take(R * PC_H * 4);
     w.a2 = (float*)take(R * PC_H * 4);
     w.bn = (float*)take(4 * PC_MAX_SEG * PC_H * 4);
-    w.q = (float*)take((size_t)B * PC_D * 4);
-    w.kv = (float*)take((size_t)B * (N > 0 ? N : 1) * 2 * PC_D * 4);
+    w.q = (float*)take((size_t)B * D * 4);
+    w.kv = (float*)take((size_t)B * (N > 0 ? N : 1) * 2 * D * 4);
     w.probs = (float*)take((size_t)B * PC_HEADS * (N > 0 ? N : 1) * 4);
-    w.ctx = (float*)take((size_t)B * PC_D * 4);
-    w.emb = (float*)take((size_t)B * PC_D * 4);
-    w.dy = (float*)take(R * PC_D * 4);
-    w.demb = (float*)take((size_t)B * PC_D * 4);
+    w.ctx = (float*)take((size_t)B * D * 4);
+    w.emb = (float*)take((size_t)B * D * 4);
+    w.dy = (float*)take(R * D * 4);
+    w.demb = (float*)take((size_t)B * D * 4);
     w.dpos_tmp = (float*)take((size_t)B * 4);
     w.dneg_tmp = (float*)take((size_t)B * 4);
     w.ffn_bytes = pc_p2v_ffn_workspace_bytes((int)R);
     w.ffn_ws = take(w.ffn_bytes);
-    w.attn_bytes = N > 0 ? pc_p2v_attention_workspace_bytes(B, N) : 0;
+    w.attn_bytes = N > 0 ? pc_p2v_attention_workspace_bytes_dim(B, N, D) : 0;
     w.attn_ws = take(w.attn_bytes);
     w.total = off;
     return w;
 }
 
-extern "C" size_t pc_p2v_train_step_workspace_bytes(int batch, int n_nbr, int k_neg) {
-    if (batch <= 0 || n_nbr < 0 || k_neg <= 0) return 0;
-    return step_ws_layout(nullptr, batch, n_nbr, k_neg).total;
+extern "C" size_t pc_p2v_train_step_workspace_bytes_dim(int batch, int n_nbr, int k_neg, int dim) {
+    if (batch <= 0 || n_nbr < 0 || k_neg <= 0 || (dim != 128 && dim != 256)) return 0;
+    return step_ws_layout(nullptr, batch, n_nbr, k_neg, dim).total;
 }
+extern "C" size_t pc_p2v_train_step_workspace_bytes(int batch, int n_nbr, int k_neg) {
+    return pc_p2v_train_step_workspace_bytes_dim(batch, n_nbr, k_neg, PC_D);
+}
+extern "C" size_t pc_p2v_attention_workspace_bytes_dim(int batch, int n_keys, int dim);
+extern "C" int pc_p2v_triplet_loss_dim(const float* a, const float* p, const float* n, int batch, int k_neg, int dim,
+                                       float margin, float* loss, float* d_pos, float* d_neg, float* da, float* dp,
+                                       float* dn, void* stream);
 
 __global__ void concat_idx_kernel(const int32_t* a, int na, const int32_t* b, int nb, const int32_t* c, int nc,
                                   const int32_t* d, int nd, int32_t* out) {
@@ -101,9 +108,11 @@ static int p2v_step_impl(const pc_p2v_tensors* p, const pc_p2v_tensors* g, const
     // the anchor and positive calls are [B,128] BatchNorm inputs: the reference raises for a single row in training
     // mode (torch/nn/functional.py _verify_batch_size); so does a [1,5,128] negative block when K = 1
     if (B == 1) return PC_EBATCHNORM;
-    if (ws_bytes < pc_p2v_train_step_workspace_bytes(B, N, K)) return PC_EWORKSPACE;
+    if (p->dim != 0 && p->dim != 128 && p->dim != 256) return PC_ESHAPE;
+    const int D = p->dim == 256 ? 256 : PC_D;
+    if (ws_bytes < pc_p2v_train_step_workspace_bytes_dim(B, N, K, D)) return PC_EWORKSPACE;
     hipStream_t st = (hipStream_t)stream;
-    StepWs w = step_ws_layout(ws, B, N, K);
+    StepWs w = step_ws_layout(ws, B, N, K, D);
     const int R = 2 * B + nbc + B * K;
     const int rA = 0, rN = B, rP = B + nbc, rG = rP + B;
 
@@ -141,28 +150,28 @@ static int p2v_step_impl(const pc_p2v_tensors* p, const pc_p2v_tensors* g, const
     as.q = w.q; as.kv = w.kv; as.probs = w.probs; as.ctx = w.ctx;
     const float* emb = w.y;                     // anchor embedding = FFN output when there are no neighbours
     if (N > 0) {
-        PC_TRY(attention_forward_impl(p, w.y + (size_t)rA * PC_D, w.y + (size_t)rN * PC_D, B, N, nbc, slot_row, w.emb,
+        PC_TRY(attention_forward_impl(p, w.y + (size_t)rA * D, w.y + (size_t)rN * D, B, N, nbc, slot_row, w.emb,
                                       &as, w.attn_ws, w.attn_bytes, stream));
         emb = w.emb;
     }
 
     float* dp_out = d_pos ? d_pos : w.dpos_tmp;
     float* dn_out = d_neg ? d_neg : w.dneg_tmp;
-    float* demb = N > 0 ? w.demb : w.dy + (size_t)rA * PC_D;
-    PC_TRY(pc_p2v_triplet_loss(emb, w.y + (size_t)rP * PC_D, w.y + (size_t)rG * PC_D, B, K, margin, loss, dp_out,
-                               dn_out, demb, w.dy + (size_t)rP * PC_D, w.dy + (size_t)rG * PC_D, stream));
+    float* demb = N > 0 ? w.demb : w.dy + (size_t)rA * D;
+    PC_TRY(pc_p2v_triplet_loss_dim(emb, w.y + (size_t)rP * D, w.y + (size_t)rG * D, B, K, D, margin, loss, dp_out,
+                               dn_out, demb, w.dy + (size_t)rP * D, w.dy + (size_t)rG * D, stream));
     if (anchor_emb)
-        PC_HIP_TRY(hipMemcpyAsync(anchor_emb, emb, (size_t)B * PC_D * 4, hipMemcpyDeviceToDevice, st));
+        PC_HIP_TRY(hipMemcpyAsync(anchor_emb, emb, (size_t)B * D * 4, hipMemcpyDeviceToDevice, st));
 
     if (N > 0) {
-        PC_TRY(attention_backward_impl(p, g, w.y + (size_t)rA * PC_D, w.y + (size_t)rN * PC_D, B, N, nbc, slot_row,
-                                       slot_row ? nbc - 1 : -1, w.demb, &as, w.dy + (size_t)rA * PC_D,
-                                       w.dy + (size_t)rN * PC_D, 0, w.attn_ws, w.attn_bytes, stream, ref_off, ref_slot));
+        PC_TRY(attention_backward_impl(p, g, w.y + (size_t)rA * D, w.y + (size_t)rN * D, B, N, nbc, slot_row,
+                                       slot_row ? nbc - 1 : -1, w.demb, &as, w.dy + (size_t)rA * D,
+                                       w.dy + (size_t)rN * D, 0, w.attn_ws, w.attn_bytes, stream, ref_off, ref_slot));
     } else {
-        PC_HIP_TRY(hipMemsetAsync(g->in_proj_w, 0, 3 * PC_D * PC_D * 4, st));
-        PC_HIP_TRY(hipMemsetAsync(g->in_proj_b, 0, 3 * PC_D * 4, st));
-        PC_HIP_TRY(hipMemsetAsync(g->out_proj_w, 0, PC_D * PC_D * 4, st));
-        PC_HIP_TRY(hipMemsetAsync(g->out_proj_b, 0, PC_D * 4, st));
+        PC_HIP_TRY(hipMemsetAsync(g->in_proj_w, 0, 3 * D * D * 4, st));
+        PC_HIP_TRY(hipMemsetAsync(g->in_proj_b, 0, 3 * D * 4, st));
+        PC_HIP_TRY(hipMemsetAsync(g->out_proj_w, 0, D * D * 4, st));
+        PC_HIP_TRY(hipMemsetAsync(g->out_proj_b, 0, D * 4, st));
     }
     PC_TRY(ffn_backward_part1(p, g, table, w.idx_all, R, &seg, w.dy, &sv, 0, 0, phase == 1 ? bwd_local : nullptr, w.ffn_ws,
                               w.ffn_bytes, stream));

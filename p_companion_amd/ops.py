@@ -83,11 +83,26 @@ def make_segments(starts, rows):
     return s
 
 
+def p2v_shapes(d=D):
+    """Parameter shapes of product2vec.py:14-29 for PRODUCT_EMB_DIM = d (128, or 256: BASELINE configs[4]); HIDDEN_SIZE
+    stays 256."""
+    return ((H, d), (H,), (H,), (H,), (H, H), (H,), (d, H), (d,), (3 * d, d), (3 * d,), (d, d), (d,))
+
+
+def p2v_dim(tensors):
+    d = int(tensors["ffn.0.weight"].shape[1])
+    if d not in (128, 256):
+        raise ValueError(f"the gfx950 kernels are built for PRODUCT_EMB_DIM 128 or 256, got {d}")
+    return d
+
+
 def p2v_struct(tensors, with_buffers=True):
     """tensors: mapping reference-state_dict-key -> tensor (parameters or gradients)."""
     st = P2VTensors()
     dev = None
-    for key, field, shape in zip(P2V_KEYS, P2V_FIELDS, P2V_SHAPES):
+    d = p2v_dim(tensors)
+    st.dim = d
+    for key, field, shape in zip(P2V_KEYS, P2V_FIELDS, p2v_shapes(d)):
         t = _req(tensors[key], torch.float32, key, shape)
         dev = t.device
         setattr(st, field, t.data_ptr())
@@ -111,8 +126,8 @@ def _set_dropout(st, d):
         st.dropout.p, st.dropout.seed, st.dropout.offset = float(d[0]), int(d[1]), int(d[2])
 
 
-def _new_p2v_grads(device):
-    return {k: torch.empty(s, dtype=torch.float32, device=device) for k, s in zip(P2V_KEYS, P2V_SHAPES)}
+def _new_p2v_grads(device, d=D):
+    return {k: torch.empty(s, dtype=torch.float32, device=device) for k, s in zip(P2V_KEYS, p2v_shapes(d))}
 
 
 # ----------------------------------------------------------------------------- P6
@@ -124,7 +139,7 @@ def ffn_forward_train(params, table, idx, rows, seg_starts, update_running=True)
     if idx is not None:
         _req(idx, torch.int32, "idx", (rows,))
     seg = make_segments(seg_starts, rows)
-    y = torch.empty(rows, D, dtype=torch.float32, device=dev)
+    y = torch.empty(rows, st.dim, dtype=torch.float32, device=dev)
     sv = {"h0": torch.empty(rows, H, dtype=torch.float32, device=dev),
           "a2": torch.empty(rows, H, dtype=torch.float32, device=dev),
           "bn": torch.empty(4, PC_MAX_SEG, H, dtype=torch.float32, device=dev),
@@ -150,7 +165,7 @@ def ffn_forward_eval(params, table, idx, rows):
     _req(table, torch.float32, "table")
     if idx is not None:
         _req(idx, torch.int32, "idx", (rows,))
-    y = torch.empty(rows, D, dtype=torch.float32, device=dev)
+    y = torch.empty(rows, st.dim, dtype=torch.float32, device=dev)
     nbytes = _lib.lib().pc_p2v_ffn_workspace_bytes(rows)
     ws = workspace(nbytes, dev)
     check(_lib.lib().pc_p2v_ffn_forward_eval(ctypes.byref(st), _p(table), _p(idx), rows, _p(y), _p(ws), nbytes,
@@ -161,13 +176,14 @@ def ffn_forward_eval(params, table, idx, rows):
 def ffn_backward(params, table, idx, dy, sv, need_dx=False, grads=None, accumulate=False):
     st, dev = p2v_struct(params)
     rows = sv["rows"]
-    _req(dy, torch.float32, "dy", (rows, D))
+    d = st.dim
+    _req(dy, torch.float32, "dy", (rows, d))
     if grads is None:
-        grads = _new_p2v_grads(dev)
+        grads = _new_p2v_grads(dev, d)
         accumulate = False
     gst, _ = p2v_struct(grads, with_buffers=False)
     seg = make_segments(sv["seg_starts"], rows)
-    dx = torch.empty(rows, D, dtype=torch.float32, device=dev) if need_dx else None
+    dx = torch.empty(rows, d, dtype=torch.float32, device=dev) if need_dx else None
     nbytes = _lib.lib().pc_p2v_ffn_workspace_bytes(rows)
     ws = workspace(nbytes, dev)
     check(_lib.lib().pc_p2v_ffn_backward(ctypes.byref(st), ctypes.byref(gst), _p(table), _p(idx), rows,
@@ -187,14 +203,15 @@ def attention_forward(params, query, keys):
     """query [B,D], keys [B,N,D] -> out [B,D], saved."""
     st, dev = p2v_struct(params)
     b, n, _ = keys.shape
-    _req(query, torch.float32, "query", (b, D))
-    _req(keys, torch.float32, "keys", (b, n, D))
-    out = torch.empty(b, D, dtype=torch.float32, device=dev)
-    sv = {"q": torch.empty(b, D, dtype=torch.float32, device=dev),
-          "kv": torch.empty(b * n, 2 * D, dtype=torch.float32, device=dev),
+    d = st.dim
+    _req(query, torch.float32, "query", (b, d))
+    _req(keys, torch.float32, "keys", (b, n, d))
+    out = torch.empty(b, d, dtype=torch.float32, device=dev)
+    sv = {"q": torch.empty(b, d, dtype=torch.float32, device=dev),
+          "kv": torch.empty(b * n, 2 * d, dtype=torch.float32, device=dev),
           "probs": torch.empty(b, HEADS, n, dtype=torch.float32, device=dev),
-          "ctx": torch.empty(b, D, dtype=torch.float32, device=dev)}
-    nbytes = _lib.lib().pc_p2v_attention_workspace_bytes(b, n)
+          "ctx": torch.empty(b, d, dtype=torch.float32, device=dev)}
+    nbytes = _lib.lib().pc_p2v_attention_workspace_bytes_dim(b, n, d)
     ws = workspace(nbytes, dev)
     check(_lib.lib().pc_p2v_attention_forward(ctypes.byref(st), _p(query), _p(keys), b, n, _p(out),
                                               ctypes.byref(_attn_saved(sv)), _p(ws), nbytes, _stream()),
@@ -205,14 +222,15 @@ def attention_forward(params, query, keys):
 def attention_backward(params, query, keys, dout, sv, grads=None, accumulate=False):
     st, dev = p2v_struct(params)
     b, n, _ = keys.shape
-    _req(dout, torch.float32, "dout", (b, D))
+    d = st.dim
+    _req(dout, torch.float32, "dout", (b, d))
     if grads is None:
-        grads = _new_p2v_grads(dev)
+        grads = _new_p2v_grads(dev, d)
         accumulate = False
     gst, _ = p2v_struct(grads, with_buffers=False)
-    dq = torch.empty(b, D, dtype=torch.float32, device=dev)
-    dk = torch.empty(b, n, D, dtype=torch.float32, device=dev)
-    nbytes = _lib.lib().pc_p2v_attention_workspace_bytes(b, n)
+    dq = torch.empty(b, d, dtype=torch.float32, device=dev)
+    dk = torch.empty(b, n, d, dtype=torch.float32, device=dev)
+    nbytes = _lib.lib().pc_p2v_attention_workspace_bytes_dim(b, n, d)
     ws = workspace(nbytes, dev)
     check(_lib.lib().pc_p2v_attention_backward(ctypes.byref(st), ctypes.byref(gst), _p(query), _p(keys), b, n,
                                                _p(dout), ctypes.byref(_attn_saved(sv)), _p(dq), _p(dk),
@@ -224,18 +242,20 @@ def attention_backward(params, query, keys, dout, sv, grads=None, accumulate=Fal
 # ----------------------------------------------------------------------------- P9 / P10
 def triplet_loss(a, p, n, margin, need_grad=True):
     """a,p [B,D]; n [B,K,D].  Returns dict(loss[1], d_pos[B], d_neg[B], da, dp, dn)."""
-    b, k, _ = n.shape
-    _req(a, torch.float32, "anchor_emb", (b, D)); _req(p, torch.float32, "positive_emb", (b, D))
-    _req(n, torch.float32, "negative_emb", (b, k, D))
+    b, k, d = n.shape
+    if d not in (128, 256):
+        raise ValueError(f"embedding width {d}: the gfx950 kernels serve 128 and 256")
+    _req(a, torch.float32, "anchor_emb", (b, d)); _req(p, torch.float32, "positive_emb", (b, d))
+    _req(n, torch.float32, "negative_emb", (b, k, d))
     dev = a.device
     out = {"loss": torch.empty(1, dtype=torch.float32, device=dev),
            "d_pos": torch.empty(b, dtype=torch.float32, device=dev),
            "d_neg": torch.empty(b, dtype=torch.float32, device=dev)}
     if need_grad:
         out.update(da=torch.empty_like(a), dp=torch.empty_like(p), dn=torch.empty_like(n))
-    check(_lib.lib().pc_p2v_triplet_loss(_p(a), _p(p), _p(n), b, k, float(margin), _p(out["loss"]),
-                                         _p(out["d_pos"]), _p(out["d_neg"]), _p(out.get("da")), _p(out.get("dp")),
-                                         _p(out.get("dn")), _stream()), "pc_p2v_triplet_loss")
+    check(_lib.lib().pc_p2v_triplet_loss_dim(_p(a), _p(p), _p(n), b, k, d, float(margin), _p(out["loss"]),
+                                             _p(out["d_pos"]), _p(out["d_neg"]), _p(out.get("da")), _p(out.get("dp")),
+                                             _p(out.get("dn")), _stream()), "pc_p2v_triplet_loss_dim")
     return out
 
 
@@ -316,9 +336,11 @@ def p2v_train_step(params, grads, table, anchor_idx, positive_idx, negative_idx,
     out = {"loss": torch.empty(1, dtype=torch.float32, device=dev),
            "d_pos": torch.empty(b, dtype=torch.float32, device=dev),
            "d_neg": torch.empty(b, dtype=torch.float32, device=dev)}
+    if table.shape[1] != st.dim:
+        raise ValueError(f"feature table width {table.shape[1]} != PRODUCT_EMB_DIM {st.dim} of the parameters")
     if want_emb:
-        out["anchor_emb"] = torch.empty(b, D, dtype=torch.float32, device=dev)
-    nbytes = _lib.lib().pc_p2v_train_step_workspace_bytes(b, n, k)
+        out["anchor_emb"] = torch.empty(b, st.dim, dtype=torch.float32, device=dev)
+    nbytes = _lib.lib().pc_p2v_train_step_workspace_bytes_dim(b, n, k, st.dim)
     ws = workspace(nbytes, dev, "step")
     if sync_reduce is not None:
         if not compact:

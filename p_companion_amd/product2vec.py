@@ -121,7 +121,8 @@ class _FusedDenseLoss(torch.autograd.Function):
     def forward(ctx, module, anchor, positive, negative, neighbors, *weights):
         b, k, n = anchor.shape[0], negative.shape[1], neighbors.shape[1]
         dev = anchor.device
-        table = torch.cat([anchor, neighbors.reshape(-1, ops.D), positive, negative.reshape(-1, ops.D)])
+        d = anchor.shape[1]
+        table = torch.cat([anchor, neighbors.reshape(-1, d), positive, negative.reshape(-1, d)])
         key = (b, n, k, dev)
         idx = module._dense_idx.get(key)
         if idx is None:
@@ -298,9 +299,10 @@ class Product2Vec(nn.Module, _FlatParamsMixin):
     def __init__(self, config):
         super().__init__()
         self.config = config
-        if (config.PRODUCT_EMB_DIM, config.HIDDEN_SIZE, config.NUM_ATTENTION_HEADS) != (ops.D, ops.H, ops.HEADS):
-            raise ValueError("the gfx950 kernels are built for PRODUCT_EMB_DIM=128, HIDDEN_SIZE=256, "
-                             "NUM_ATTENTION_HEADS=4 (config.py:8-11)")
+        if config.PRODUCT_EMB_DIM not in (128, 256) or (config.HIDDEN_SIZE, config.NUM_ATTENTION_HEADS) != (ops.H, ops.HEADS):
+            raise ValueError("the gfx950 kernels are built for PRODUCT_EMB_DIM = 128 (config.py:8) or 256 (BASELINE "
+                             "configs[4]), HIDDEN_SIZE = 256, NUM_ATTENTION_HEADS = 4 (config.py:10-11)")
+        self.dim = int(config.PRODUCT_EMB_DIM)
         # parameter containers only -- same construction order as product2vec.py:14-29, so
         # torch.manual_seed(s) yields the reference's initial weights
         self.ffn = nn.Sequential(
@@ -436,7 +438,7 @@ class Product2Vec(nn.Module, _FlatParamsMixin):
             nb = cv_col[(starts[:, None] + np.arange(d)[None, :]).reshape(-1)]
             nb_idx = torch.from_numpy(np.ascontiguousarray(nb, np.int32)).to(x.device)
             node_idx = torch.from_numpy(nodes.astype(np.int32)).to(x.device)
-            keys = ops.gather_rows(e1, nb_idx).view(len(nodes), int(d), ops.D)
+            keys = ops.gather_rows(e1, nb_idx).view(len(nodes), int(d), self.dim)
             query = ops.gather_rows(e2, node_idx)
             upd, _ = ops.attention_forward(params, query, keys)
             ops.scatter_rows(out, node_idx, upd)
