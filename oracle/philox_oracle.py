@@ -111,12 +111,12 @@ def zipf_negatives(pair_ids, sim_pairs, sim_rowptr, sim_col, n_products, k, seed
             while j + 1 < len(thr) and r0 > thr[j]:
                 j += 1
             base = 1 << j
-            kk = base + ((s.next() >> (32 - j)) if j else 0)
-            if kk > n_products:
-                continue
-            r2 = s.next()
-            if r2 * kk >= (base << 32):
-                continue
+            while True:                                   # inside the chosen octave until a rank is accepted
+                kk = base + ((s.next() >> (32 - j)) if j else 0)
+                if kk > n_products:
+                    continue
+                if s.next() * kk < (base << 32):
+                    break
             c = int(perm[kk - 1]) if perm is not None else kk - 1
             if c != a and c not in pos and c not in got:
                 got.append(c)

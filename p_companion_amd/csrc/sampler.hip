@@ -354,10 +354,13 @@ __global__ void zipf_negatives_kernel(const int32_t* pair_ids, int B, const int3
         int j = 0;
         while (j + 1 < n_octaves && r0 > octave_cum[j]) j++;
         const uint32_t base = 1u << j;
-        const uint32_t k = base + (j ? (rng.next() >> (32 - j)) : 0u);
-        if (k > (uint32_t)n_products) continue;                   // the last octave may be partial
-        const uint32_t r2 = rng.next();
-        if ((uint64_t)r2 * k >= ((uint64_t)base << 32)) continue; // accept with probability 2^j / k
+        uint32_t k;
+        while (true) {                                            // inside the chosen octave until a rank is accepted
+            k = base + (j ? (rng.next() >> (32 - j)) : 0u);
+            if (k > (uint32_t)n_products) continue;               // the last octave may be partial
+            const uint32_t r2 = rng.next();
+            if ((uint64_t)r2 * k < ((uint64_t)base << 32)) break; // accept with probability 2^j / k
+        }
         const int c = perm ? perm[k - 1] : (int)(k - 1);
         bool ok = c != a;
         for (int q = lo; ok && q < hi; q++) ok = sim_col[q] != c;

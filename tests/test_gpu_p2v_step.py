@@ -99,6 +99,26 @@ def test_train_step_golden_b256(golden):
     _check(g, outs, fg, bn1, final, golden("g4_p2v_b256_params3.npz"))
 
 
+def test_train_step_features_scaled_1e4_vs_oracle(golden):
+    """The golden B = 256 batch with its features scaled by 1e4 (operands far from unit scale through Linear0 and its
+    weight gradient; BatchNorm brings the rest back): loss within the north_star's 1e-4 of the oracle, gradients close."""
+    from p_companion_amd import ops
+    g, st = _load(golden, "g4_p2v_b256.npz")
+    ints = golden("g2_bpg1000.npz")
+    feats = torch.from_numpy(ints["features"]) * 1e4
+    batch = {k: torch.from_numpy(g[k]) for k in ("anchor_idx", "positive_idx", "negative_idx", "neighbor_idx")}
+    outs, fg, bn1, after1, final = _run_steps(ops, st, feats.cuda(), {k: v.cuda() for k, v in batch.items()}, 1)
+    ost = {k: v.clone() for k, v in st.items()}
+    dense = p2v_oracle.gather_batch(feats, batch["anchor_idx"], batch["positive_idx"], batch["negative_idx"], batch["neighbor_idx"])
+    ref = p2v_oracle.train_step(ost, dense, 1.0, p2v_oracle.new_moments(ost), 1)
+    assert abs(float(outs[0]["loss"]) - float(ref["loss"])) < 1e-4
+    for k in p2v_oracle.TRAINABLE:
+        if k == "ffn.0.bias":
+            continue
+        r = ref["grads"][k]
+        np.testing.assert_allclose(fg[k], r, atol=3e-6 + 3e-4 * float(r.abs().max()), err_msg=k)
+
+
 def test_train_step_no_neighbors_vs_oracle():
     """anchor_neighbors absent (data_loader.py:67-69): embedding = plain FFN, 3 BatchNorm calls,
     attention parameters receive no gradient."""
