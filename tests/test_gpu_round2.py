@@ -326,9 +326,11 @@ def test_zipf_negatives_follow_one_over_rank():
     cnt = np.zeros(bpg.num_products, np.int64)
     n = 0
     for b in ld:
-        np.add.at(cnt, b["negative_idx"].cpu().numpy().reshape(-1), 1)
+        # the FIRST negative of a sample is one draw of the distribution (the later ones exclude the earlier: the "no
+        # repeats" rule of data_loader.py:36 thins the head)
+        np.add.at(cnt, b["negative_idx"][:, 0].cpu().numpy().reshape(-1), 1)
         n += 1
-        if n == 12:
+        if n == 40:
             break
     total = cnt.sum()
     h = np.sum(1.0 / np.arange(1, bpg.num_products + 1))
@@ -337,5 +339,5 @@ def test_zipf_negatives_follow_one_over_rank():
         lo, hi = (1 << j) - 1, min((1 << (j + 1)) - 1, bpg.num_products)
         want = np.sum(1.0 / np.arange(lo + 1, hi + 1)) / h
         got = cnt[lo:hi].sum() / total
-        assert abs(got - want) < 0.012, (j, got, want)
+        assert abs(got - want) < 0.006, (j, got, want)
     assert cnt[0] > 10 * max(cnt[1000:1010].mean(), 1)           # the head is heavy
