@@ -752,6 +752,203 @@ __global__ __launch_bounds__(256) void type_topk_merge_kernel(const float* part_
 }
 
 // ---------------------------------------------------------------------------------------------------------------
+// Gradient products of the step, right-sized: every weight / table gradient is a "rows^T x rows" product over the
+// row buffers the tile kernel left (d itm_w = dpi^T q, d typ_w = dtp^T e, d dec_w = dc^T h, d enc_w = dh^T t, and the two
+// [T,64] tables as one-hot products, the type hinge's two rows per sample included).  The generic 128 x 128-tile kernel
+// spends most of its MFMAs on zeros here (64 x 32, 32 x 64, T x 64 outputs); this one walks 16-sample subtiles with
+// 16 x 16 x 4 blocks sized to each product, accumulates a workgroup's share of the batch in registers and writes ONE
+// slab per workgroup (summed in fixed order by the finish kernel).
+//   C[i][o] = sum_s X[s][i] Z[s][o]: the lane's four results are four consecutive i of one o -> one 16-B store at
+//   slab[o * Ni + i].  Operands come from LDS row-major images (row stride = width + 16 floats: the four sample rows one
+//   MFMA touches sit 16 banks apart).
+#define WG_S 32            /* samples per workgroup (two subtiles) */
+#define WLD128 144
+#define WLD64 80
+#define WLD32 48
+struct WgradArgs {
+    const float *table, *eq, *ec;                         // gather sources: product rows, E_q, E_c
+    const int32_t *query_idx, *query_types, *topk;        // [B], [B], [B,K]
+    const float *dpi, *dtp, *dc, *h, *dh, *dt, *ecsrc;    // row buffers (see FusedArgs)
+    const int32_t* ecidx;                                 // [B (K + 2)]
+    int B, T, K;
+    float* slabs; int slab_floats;                        // per workgroup: itm_w | itm_b | typ_w | typ_b | dec_w | dec_b | enc_w | enc_b | E_c | E_q
+};
+__host__ __device__ inline int wg_off_itm_w() { return 0; }
+__host__ __device__ inline int wg_off_itm_b() { return PC_D * PC_D; }
+__host__ __device__ inline int wg_off_typ_w() { return wg_off_itm_b() + PC_D; }
+__host__ __device__ inline int wg_off_typ_b() { return wg_off_typ_w() + PC_D * PC_L; }
+__host__ __device__ inline int wg_off_dec_w() { return wg_off_typ_b() + PC_D; }
+__host__ __device__ inline int wg_off_dec_b() { return wg_off_dec_w() + PC_L * LH; }
+__host__ __device__ inline int wg_off_enc_w() { return wg_off_dec_b() + PC_L; }
+__host__ __device__ inline int wg_off_enc_b() { return wg_off_enc_w() + LH * PC_L; }
+__host__ __device__ inline int wg_off_ec() { return wg_off_enc_b() + LH; }
+__host__ __device__ inline int wg_off_eq(int T) { return wg_off_ec() + T * PC_L; }
+__host__ __device__ inline int wg_slab_floats(int T) { return wg_off_eq(T) + T * PC_L; }
+
+// NTW: 16-type column blocks of a table product per wave (T <= 128: 4; T <= 512: 16)
+template <int NTW, int KC>
+__global__ __launch_bounds__(512) void joint_wgrad_kernel(WgradArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    float* DPI = sm;                          // [16][WLD128]
+    float* Q = DPI + 16 * WLD128;             // [16][WLD128]
+    float* DTP = Q + 16 * WLD128;             // [16 FK][WLD128]   rows b * K + k
+    float* E = DTP + 16 * FK * WLD128;        // [16 FK][WLD64]
+    float* DC = E + 16 * FK * WLD64;          // [16][WLD64]
+    float* Hh = DC + 16 * WLD64;              // [16][WLD32]
+    float* DH = Hh + 16 * WLD32;              // [16][WLD32]
+    float* Tq = DH + 16 * WLD32;              // [16][WLD64]
+    float* ES = Tq + 16 * WLD64;              // [16 (FK + 2)][WLD64]  dE_c source rows: 16 K selected-type rows, 16 + 16 hinge rows
+    float* DT = ES + 16 * (FK + 2) * WLD64;   // [16][WLD64]
+    int* idx = reinterpret_cast<int*>(DT + 16 * WLD64);     // [16 (FK + 2)] E_c destinations, then [16] E_q destinations
+    const int K = KC ? KC : a.K;
+    const int tid = threadIdx.x, lane = tid & 63, i16 = lane & 15, h = lane >> 4;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int ntb = (a.T + 15) >> 4;                                    // 16-type column blocks of the tables
+    constexpr int MBK = KC ? KC : FK;
+
+    f32x4v c_itm[8], c_typ[4], c_dec, c_enc, c_ec[NTW], c_eq[NTW];
+#pragma unroll
+    for (int i = 0; i < 8; i++) c_itm[i] = f32x4v{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int i = 0; i < 4; i++) c_typ[i] = f32x4v{0.f, 0.f, 0.f, 0.f};
+    c_dec = f32x4v{0.f, 0.f, 0.f, 0.f}; c_enc = f32x4v{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int i = 0; i < NTW; i++) { c_ec[i] = f32x4v{0.f, 0.f, 0.f, 0.f}; c_eq[i] = f32x4v{0.f, 0.f, 0.f, 0.f}; }
+    float bsum = 0.f;                          // bias column owned by this thread (tid < 352)
+
+    for (int sub = 0; sub < WG_S / 16; sub++) {
+        const int b0 = blockIdx.x * WG_S + sub * 16;
+        if (b0 >= a.B) break;                                           // workgroup-uniform
+        __syncthreads();
+        // ---- stage the subtile: rows past the batch are zero
+        auto rowf4 = [&](float* dst, int ld, const float* src, int width4, int rows, int first_row, int row_limit) {
+            for (int e = tid; e < rows * width4; e += 512) {
+                const int r = e / width4, c4 = (e % width4) * 4;
+                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (first_row + r < row_limit) v = *reinterpret_cast<const float4*>(src + (size_t)(first_row + r) * (width4 * 4) + c4);
+                *reinterpret_cast<float4*>(&dst[r * ld + c4]) = v;
+            }
+        };
+        rowf4(DPI, WLD128, a.dpi, 32, 16, b0, a.B);
+        rowf4(DTP, WLD128, a.dtp, 32, 16 * K, b0 * K, a.B * K);
+        rowf4(DC, WLD64, a.dc, 16, 16, b0, a.B);
+        rowf4(Hh, WLD32, a.h, 8, 16, b0, a.B);
+        rowf4(DH, WLD32, a.dh, 8, 16, b0, a.B);
+        rowf4(DT, WLD64, a.dt, 16, 16, b0, a.B);
+        rowf4(ES, WLD64, a.ecsrc, 16, 16 * K, b0 * K, a.B * K);
+        rowf4(ES + 16 * K * WLD64, WLD64, a.ecsrc + (size_t)a.B * K * PC_L, 16, 16, b0, a.B);
+        rowf4(ES + 16 * (K + 1) * WLD64, WLD64, a.ecsrc + (size_t)a.B * (K + 1) * PC_L, 16, 16, b0, a.B);
+        for (int e = tid; e < 16 * 32; e += 512) {                     // q = E_prod[query_idx]
+            const int r = e >> 5, c4 = (e & 31) * 4;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (b0 + r < a.B) v = *reinterpret_cast<const float4*>(a.table + (size_t)a.query_idx[b0 + r] * PC_D + c4);
+            *reinterpret_cast<float4*>(&Q[r * WLD128 + c4]) = v;
+        }
+        for (int e = tid; e < 16 * K * 16; e += 512) {                 // e = E_c[topk]
+            const int r = e >> 4, c4 = (e & 15) * 4;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (b0 * K + r < a.B * K) v = *reinterpret_cast<const float4*>(a.ec + (size_t)a.topk[(size_t)b0 * K + r] * PC_L + c4);
+            *reinterpret_cast<float4*>(&E[r * WLD64 + c4]) = v;
+        }
+        for (int e = tid; e < 16 * 16; e += 512) {                     // t = E_q[query_types]
+            const int r = e >> 4, c4 = (e & 15) * 4;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (b0 + r < a.B) v = *reinterpret_cast<const float4*>(a.eq + (size_t)a.query_types[b0 + r] * PC_L + c4);
+            *reinterpret_cast<float4*>(&Tq[r * WLD64 + c4]) = v;
+        }
+        if (tid < 16 * (K + 2)) {
+            // destinations of the dE_c source rows, in the rows' order: [16 K selected | 16 pos | 16 neg]; -1 = no row
+            int r = tid, v = -1;
+            if (r < 16 * K) { if (b0 * K + r < a.B * K) v = a.ecidx[(size_t)b0 * K + r]; }
+            else if (r < 16 * (K + 1)) { if (b0 + r - 16 * K < a.B) v = a.ecidx[(size_t)a.B * K + b0 + r - 16 * K]; }
+            else if (b0 + r - 16 * (K + 1) < a.B) v = a.ecidx[(size_t)a.B * (K + 1) + b0 + r - 16 * (K + 1)];
+            idx[r] = v;
+        } else if (tid >= 448 && tid < 464) {
+            const int r = tid - 448;
+            idx[16 * (FK + 2) + r] = b0 + r < a.B ? a.query_types[b0 + r] : -1;
+        }
+        __syncthreads();
+        // ---- biases: column sums of the Z images
+        if (tid < 128) { for (int r = 0; r < 16; r++) bsum += DPI[r * WLD128 + tid]; }
+        else if (tid < 256) { for (int r = 0; r < 16 * K; r++) bsum += DTP[r * WLD128 + tid - 128]; }
+        else if (tid < 320) { for (int r = 0; r < 16; r++) bsum += DC[r * WLD64 + tid - 256]; }
+        else if (tid < 352) { for (int r = 0; r < 16; r++) bsum += DH[r * WLD32 + tid - 320]; }
+        // ---- d itm_w^T: wave w owns input block w (16 of the 128 q dims) x all 8 output blocks
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const float av = Q[(4 * q + h) * WLD128 + 16 * w + i16];
+#pragma unroll
+            for (int ob = 0; ob < 8; ob++) c_itm[ob] = mfma16(av, DPI[(4 * q + h) * WLD128 + 16 * ob + i16], c_itm[ob]);
+        }
+        // ---- d typ_w^T: input block w & 3 (of 4) x output blocks 4 (w >> 2) .. + 3; 16 K rows
+        for (int q = 0; q < 4 * MBK; q++) {
+            if (q < 4 * K) {
+                const float av = E[(4 * q + h) * WLD64 + 16 * (w & 3) + i16];
+#pragma unroll
+                for (int ob = 0; ob < 4; ob++)
+                    c_typ[ob] = mfma16(av, DTP[(4 * q + h) * WLD128 + 16 * (4 * (w >> 2) + ob) + i16], c_typ[ob]);
+            }
+        }
+        // ---- d dec_w^T [32 in][64 out]: input block w & 1, output block w >> 1;  d enc_w^T [64 in][32 out]: w & 3, w >> 2
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            c_dec = mfma16(Hh[(4 * q + h) * WLD32 + 16 * (w & 1) + i16], DC[(4 * q + h) * WLD64 + 16 * (w >> 1) + i16], c_dec);
+            c_enc = mfma16(Tq[(4 * q + h) * WLD64 + 16 * (w & 3) + i16], DH[(4 * q + h) * WLD32 + 16 * (w >> 2) + i16], c_enc);
+        }
+        // ---- table gradients, transposed: C[j][t] = sum_r src[r][j] [idx[r] == t]; wave: dims block w & 3, type blocks
+        // (w >> 2) + 2 n
+        for (int q = 0; q < 4 * (MBK + 2); q++) {
+            if (q < 4 * (K + 2)) {
+                const float av = ES[(4 * q + h) * WLD64 + 16 * (w & 3) + i16];
+                const int d = idx[4 * q + h];
+#pragma unroll
+                for (int n = 0; n < NTW; n++) {
+                    const int tb = (w >> 2) + 2 * n;
+                    if (tb < ntb) c_ec[n] = mfma16(av, d == 16 * tb + i16 ? 1.f : 0.f, c_ec[n]);
+                }
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const float av = DT[(4 * q + h) * WLD64 + 16 * (w & 3) + i16];
+            const int d = idx[16 * (FK + 2) + 4 * q + h];
+#pragma unroll
+            for (int n = 0; n < NTW; n++) {
+                const int tb = (w >> 2) + 2 * n;
+                if (tb < ntb) c_eq[n] = mfma16(av, d == 16 * tb + i16 ? 1.f : 0.f, c_eq[n]);
+            }
+        }
+    }
+    // ---- the workgroup's slab: result register r of a block = input index 4 h + r (+ block), column = output index
+    float* slab = a.slabs + (size_t)blockIdx.x * a.slab_floats;
+    auto st4 = [&](float* dst, const f32x4v& v) { *reinterpret_cast<float4*>(dst) = make_float4(v[0], v[1], v[2], v[3]); };
+#pragma unroll
+    for (int ob = 0; ob < 8; ob++) st4(slab + wg_off_itm_w() + (size_t)(16 * ob + i16) * PC_D + 16 * w + 4 * h, c_itm[ob]);
+#pragma unroll
+    for (int ob = 0; ob < 4; ob++)
+        st4(slab + wg_off_typ_w() + (size_t)(16 * (4 * (w >> 2) + ob) + i16) * PC_L + 16 * (w & 3) + 4 * h, c_typ[ob]);
+    st4(slab + wg_off_dec_w() + (size_t)(16 * (w >> 1) + i16) * LH + 16 * (w & 1) + 4 * h, c_dec);
+    st4(slab + wg_off_enc_w() + (size_t)(16 * (w >> 2) + i16) * PC_L + 16 * (w & 3) + 4 * h, c_enc);
+#pragma unroll
+    for (int n = 0; n < NTW; n++) {
+        const int t = 16 * ((w >> 2) + 2 * n) + i16;
+        if (t < a.T) {
+            st4(slab + wg_off_ec() + (size_t)t * PC_L + 16 * (w & 3) + 4 * h, c_ec[n]);
+            st4(slab + wg_off_eq(a.T) + (size_t)t * PC_L + 16 * (w & 3) + 4 * h, c_eq[n]);
+        }
+    }
+    if (tid < 128) slab[wg_off_itm_b() + tid] = bsum;
+    else if (tid < 256) slab[wg_off_typ_b() + tid - 128] = bsum;
+    else if (tid < 320) slab[wg_off_dec_b() + tid - 256] = bsum;
+    else if (tid < 352) slab[wg_off_enc_b() + tid - 320] = bsum;
+}
+
+static size_t wgrad_lds_bytes() {
+    return ((size_t)2 * 16 * WLD128 + 16 * FK * WLD128 + 16 * FK * WLD64 + 16 * WLD64 + 2 * 16 * WLD32 + 16 * WLD64 +
+            16 * (FK + 2) * WLD64 + 16 * WLD64 + 16 * (FK + 2) + 16) * 4;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
 // Finish: per parameter tensor, the fixed-order sum of its gradient slabs (written by the grouped rows^T x rows launch)
 // -> .grad; the two loss means; and -- when the caller handed its moments -- torch.optim.Adam's update on the element
 // just reduced.  Jobs with nsplit == 0 have their gradient complete in `grad` already (atomics path of large tables).
@@ -845,7 +1042,7 @@ struct FusedWs {
     float *part, *h, *dpi, *dtp, *dc, *dh, *dt, *ecsrc;
     int32_t *ecidx, *ulist, *n_u, *topk_by_type, *part_idx;
     float* part_val;
-    float* slabs[6]; size_t slab_floats[6];
+    float* wslabs; int wg_blocks, wslab_floats;      // joint_wgrad_kernel: one slab per workgroup
     int nchunks, ucap;
     bool small;
     size_t total;
@@ -869,20 +1066,13 @@ static FusedWs fused_ws_layout(void* base, int B, int T, int K) {
     w.dt = (float*)take((size_t)B * PC_L * 4);
     w.ecsrc = (float*)take((size_t)B * (K + 2) * PC_L * 4);
     w.ecidx = (int32_t*)take((size_t)B * (K + 2) * 4);
-    const size_t sf[4] = {gemm_tn_workspace_floats(B, PC_D, PC_D), gemm_tn_workspace_floats(B * K, PC_D, PC_L),
-                          gemm_tn_workspace_floats(B, PC_L, LH), gemm_tn_workspace_floats(B, LH, PC_L)};
-    for (int i = 0; i < 4; i++) { w.slab_floats[i] = sf[i]; w.slabs[i] = (float*)take(sf[i] * 4); }
-    w.slab_floats[4] = w.slab_floats[5] = 0;
-    w.slabs[4] = w.slabs[5] = nullptr;
+    w.wg_blocks = (B + WG_S - 1) / WG_S;
+    w.wslab_floats = wg_slab_floats(w.small ? T : 0);      // (large tables: their gradients go by row scatter-add)
+    w.wslabs = (float*)take((size_t)w.wg_blocks * w.wslab_floats * 4);
     w.nchunks = w.ucap = 0;
     w.ulist = w.n_u = w.topk_by_type = w.part_idx = nullptr;
     w.part_val = nullptr;
     if (w.small) {
-        const int Tp = (T + 3) & ~3;
-        w.slab_floats[4] = gemm_tn_workspace_floats(B * (K + 2), Tp, PC_L);
-        w.slab_floats[5] = gemm_tn_workspace_floats(B, Tp, PC_L);
-        w.slabs[4] = (float*)take(w.slab_floats[4] * 4);
-        w.slabs[5] = (float*)take(w.slab_floats[5] * 4);
     } else {
         w.nchunks = (T + TC - 1) / TC;
         w.ucap = B < T ? B : T;
@@ -978,62 +1168,36 @@ extern "C" int pc_joint_fused_step(const pc_joint_tensors* p, const pc_joint_ten
     else PC_LAUNCH((joint_tile_kernel<false, 0>), dim3(tiles), dim3(256), lds, st, fa, ldsims);
     PC_TRY(pc_launch_status());
 
-    // ---- gradient products over the row buffers: one grouped launch, slabs summed by the finish kernel
-    const SegInfo siB = make_seginfo(nullptr, B, 128), siBK = make_seginfo(nullptr, B * K, 128),
-                  siE = make_seginfo(nullptr, B * (K + 2), 128);
-    TnArgs tn[6];
-    TnArgs& ti = tn[0];
-    ti = {};
-    ti.Z = w.dpi; ti.ldz = PC_D; ti.A = p->product_table; ti.lda = PC_D; ti.gather = query_idx; ti.R = B;
-    ti.No = PC_D; ti.Ni = PC_D; ti.seg = siB; ti.dW = g->itm_w; ti.lddw = PC_D; ti.db = g->itm_b;
-    ti.slabs = w.slabs[0]; ti.slab_floats = w.slab_floats[0];
-    TnArgs& tt = tn[1];
-    tt = {};
-    tt.Z = w.dtp; tt.ldz = PC_D; tt.A = p->comp_types; tt.lda = PC_L; tt.gather = topk; tt.R = B * K;
-    tt.No = PC_D; tt.Ni = PC_L; tt.seg = siBK; tt.dW = g->typ_w; tt.lddw = PC_L; tt.db = g->typ_b;
-    tt.slabs = w.slabs[1]; tt.slab_floats = w.slab_floats[1];
-    TnArgs& td = tn[2];
-    td = {};
-    td.Z = w.dc; td.ldz = PC_L; td.A = w.h; td.lda = LH; td.R = B; td.No = PC_L; td.Ni = LH; td.seg = siB;
-    td.dW = g->dec_w; td.lddw = LH; td.db = g->dec_b; td.slabs = w.slabs[2]; td.slab_floats = w.slab_floats[2];
-    TnArgs& te = tn[3];
-    te = {};
-    te.Z = w.dh; te.ldz = LH; te.A = p->query_types; te.lda = PC_L; te.gather = query_types; te.R = B;
-    te.No = LH; te.Ni = PC_L; te.seg = siB; te.dW = g->enc_w; te.lddw = PC_L; te.db = g->enc_b;
-    te.slabs = w.slabs[3]; te.slab_floats = w.slab_floats[3];
-    int nt = 4;
-    const int Tp = (T + 3) & ~3;
-    if (w.small) {
-        TnArgs& tc = tn[4];
-        tc = {};
-        tc.z_onehot = w.ecidx; tc.A = w.ecsrc; tc.lda = PC_L; tc.R = B * (K + 2); tc.No = Tp; tc.Ni = PC_L; tc.seg = siE;
-        tc.dW = g->comp_types; tc.lddw = PC_L; tc.slabs = w.slabs[4]; tc.slab_floats = w.slab_floats[4];
-        TnArgs& tq = tn[5];
-        tq = {};
-        tq.z_onehot = query_types; tq.A = w.dt; tq.lda = PC_L; tq.R = B; tq.No = Tp; tq.Ni = PC_L; tq.seg = siB;
-        tq.dW = g->query_types; tq.lddw = PC_L; tq.slabs = w.slabs[5]; tq.slab_floats = w.slab_floats[5];
-        nt = 6;
-    } else {
+    // ---- gradient products over the row buffers: one launch, one slab per workgroup, summed by the finish kernel
+    WgradArgs wa = {};
+    wa.table = p->product_table; wa.eq = p->query_types; wa.ec = p->comp_types;
+    wa.query_idx = query_idx; wa.query_types = query_types; wa.topk = topk;
+    wa.dpi = w.dpi; wa.dtp = w.dtp; wa.dc = w.dc; wa.h = w.h; wa.dh = w.dh; wa.dt = w.dt; wa.ecsrc = w.ecsrc; wa.ecidx = w.ecidx;
+    wa.B = B; wa.T = w.small ? T : 0; wa.K = K; wa.slabs = w.wslabs; wa.slab_floats = w.wslab_floats;
+    {
+        static const hipError_t wattr[4] = {
+            hipFuncSetAttribute(reinterpret_cast<const void*>(&joint_wgrad_kernel<4, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024),
+            hipFuncSetAttribute(reinterpret_cast<const void*>(&joint_wgrad_kernel<4, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024),
+            hipFuncSetAttribute(reinterpret_cast<const void*>(&joint_wgrad_kernel<16, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024),
+            hipFuncSetAttribute(reinterpret_cast<const void*>(&joint_wgrad_kernel<16, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)};
+        (void)wattr;
+        const size_t wl = wgrad_lds_bytes();
+        const bool few = wa.T <= 128;
+        if (few && K == 3) PC_LAUNCH((joint_wgrad_kernel<4, 3>), dim3(w.wg_blocks), dim3(512), wl, st, wa);
+        else if (few) PC_LAUNCH((joint_wgrad_kernel<4, 0>), dim3(w.wg_blocks), dim3(512), wl, st, wa);
+        else if (K == 3) PC_LAUNCH((joint_wgrad_kernel<16, 3>), dim3(w.wg_blocks), dim3(512), wl, st, wa);
+        else PC_LAUNCH((joint_wgrad_kernel<16, 0>), dim3(w.wg_blocks), dim3(512), wl, st, wa);
+        PC_TRY(pc_launch_status());
+    }
+    if (!w.small) {
+        // the query_idx / query_types / topk gathers of the kernel above use the caller's raw ids: they were validated
+        // (and any offender counted) by the tile kernel
         PC_TRY(pc_scatter_add_rows(g->comp_types, w.ecidx, B * (K + 2), PC_L, w.ecsrc, stream));
         PC_TRY(pc_scatter_add_rows(g->query_types, query_types, B, PC_L, w.dt, stream));
     }
-    TnGroupPlan plan;
-    PC_TRY(launch_gemm_tn_group_partials(tn, nt, &plan, st));
 
     // ---- finish: slab sums -> .grad, the losses, Adam
     FinishArgs fin = {};
-    float* const gw[6] = {g->itm_w, g->typ_w, g->dec_w, g->enc_w, g->comp_types, g->query_types};
-    float* const gb[6] = {g->itm_b, g->typ_b, g->dec_b, g->enc_b, nullptr, nullptr};
-    float* const pw[6] = {p->itm_w, p->typ_w, p->dec_w, p->enc_w, p->comp_types, p->query_types};
-    float* const pb[6] = {p->itm_b, p->typ_b, p->dec_b, p->enc_b, nullptr, nullptr};
-    float *mw[6] = {}, *mb[6] = {}, *vw[6] = {}, *vb[6] = {};
-    if (adam) {
-        float* const m_[6] = {exp_avg->itm_w, exp_avg->typ_w, exp_avg->dec_w, exp_avg->enc_w, exp_avg->comp_types, exp_avg->query_types};
-        float* const mb_[6] = {exp_avg->itm_b, exp_avg->typ_b, exp_avg->dec_b, exp_avg->enc_b, nullptr, nullptr};
-        float* const v_[6] = {exp_avg_sq->itm_w, exp_avg_sq->typ_w, exp_avg_sq->dec_w, exp_avg_sq->enc_w, exp_avg_sq->comp_types, exp_avg_sq->query_types};
-        float* const vb_[6] = {exp_avg_sq->itm_b, exp_avg_sq->typ_b, exp_avg_sq->dec_b, exp_avg_sq->enc_b, nullptr, nullptr};
-        for (int i = 0; i < 6; i++) { mw[i] = m_[i]; mb[i] = mb_[i]; vw[i] = v_[i]; vb[i] = vb_[i]; }
-    }
     int blocks = 0, nj = 0;
     auto add = [&](const float* slabs, size_t stride, int nsplit, int n, float* grad, float* param, float* m, float* v) {
         FinishJob& j = fin.job[nj];
@@ -1041,16 +1205,26 @@ extern "C" int pc_joint_fused_step(const pc_joint_tensors* p, const pc_joint_ten
         fin.block0[nj++] = blocks;
         blocks += nsplit > 0 ? (n / 4 * 8 + 255) / 256 : (n / 4 + 255) / 256;
     };
-    for (int i = 0; i < nt; i++) {
-        const int n_w = tn[i].No * tn[i].Ni, n_b = tn[i].No;
-        const size_t stride = (size_t)n_w + n_b;
-        const int real_w = i >= 4 ? T * PC_L : n_w;               // (a table padded to a multiple of 4 rows: only T are real)
-        add(plan.slabs[i], stride, plan.nsplit[i], real_w, gw[i], pw[i], mw[i], vw[i]);
-        if (gb[i]) add(plan.slabs[i] + n_w, stride, plan.nsplit[i], n_b, gb[i], pb[i], mb[i], vb[i]);
-    }
-    if (!w.small && adam) {                                        // big tables: gradient complete already, Adam only
-        add(nullptr, 0, 0, T * PC_L, g->comp_types, p->comp_types, exp_avg->comp_types, exp_avg_sq->comp_types);
-        add(nullptr, 0, 0, T * PC_L, g->query_types, p->query_types, exp_avg->query_types, exp_avg_sq->query_types);
+    {
+        const int Tt = wa.T;
+        const int off[10] = {wg_off_itm_w(), wg_off_itm_b(), wg_off_typ_w(), wg_off_typ_b(), wg_off_dec_w(), wg_off_dec_b(),
+                             wg_off_enc_w(), wg_off_enc_b(), wg_off_ec(), wg_off_eq(Tt)};
+        const int cnt[10] = {PC_D * PC_D, PC_D, PC_D * PC_L, PC_D, PC_L * LH, PC_L, LH * PC_L, LH, Tt * PC_L, Tt * PC_L};
+        float* const gq[10] = {g->itm_w, g->itm_b, g->typ_w, g->typ_b, g->dec_w, g->dec_b, g->enc_w, g->enc_b, g->comp_types, g->query_types};
+        float* const pq[10] = {p->itm_w, p->itm_b, p->typ_w, p->typ_b, p->dec_w, p->dec_b, p->enc_w, p->enc_b, p->comp_types, p->query_types};
+        float *mq[10] = {}, *vq[10] = {};
+        if (adam) {
+            float* const m_[10] = {exp_avg->itm_w, exp_avg->itm_b, exp_avg->typ_w, exp_avg->typ_b, exp_avg->dec_w, exp_avg->dec_b,
+                                   exp_avg->enc_w, exp_avg->enc_b, exp_avg->comp_types, exp_avg->query_types};
+            float* const v_[10] = {exp_avg_sq->itm_w, exp_avg_sq->itm_b, exp_avg_sq->typ_w, exp_avg_sq->typ_b, exp_avg_sq->dec_w,
+                                   exp_avg_sq->dec_b, exp_avg_sq->enc_w, exp_avg_sq->enc_b, exp_avg_sq->comp_types, exp_avg_sq->query_types};
+            for (int i = 0; i < 10; i++) { mq[i] = m_[i]; vq[i] = v_[i]; }
+        }
+        for (int i = 0; i < 10; i++) {
+            if (cnt[i] > 0) add(w.wslabs + off[i], (size_t)w.wslab_floats, w.wg_blocks, cnt[i], gq[i], pq[i], mq[i], vq[i]);
+            else if (adam)                                             // big tables: gradient complete already, Adam only
+                add(nullptr, 0, 0, T * PC_L, gq[i], pq[i], mq[i], vq[i]);
+        }
     }
     fin.njobs = nj;
     for (int k = nj; k <= FIN_JOBS; k++) fin.block0[k] = blocks;

@@ -46,7 +46,7 @@ def kernel_stats(subdir, suffix):
                       "gemm_tn_share": round(sum(t for _, t in tn) / tot, 4)}
     if suffix == "_joint":
         # kernels per step of the joint loop: everything launched once per step has the call count of the Adam kernel
-        steps = max([r[1] for r in rows if "adam" in r[0]] or [1])
+        steps = max([r[1] for r in rows if "adam" in r[0] or "joint_finish" in r[0]] or [1])
         per_step = {short(r[0]): round(r[1] / steps, 2) for r in rows if r[1] >= steps // 2}
         js["_summary"].update({"steps_traced": steps, "kernel_us_per_step": round(tot / 1e3 / steps, 2),
                                "launches_per_step": round(sum(r[1] for r in rows if r[1] >= steps // 2) / steps, 2),
@@ -86,7 +86,7 @@ if fe:
         w = wr_.get(k, [n, 0.0])
         res[k] = {"launches": n, "fetch_kib_raw": round(v / n, 1), "fetch_bytes_corrected": round(v / n * 1024 * 2),
                   "write_bytes": round(w[1] / max(1, w[0]) * 1024)}
-    steps = max([v["launches"] for k, v in res.items() if "adam" in k] or [1])
+    steps = max([v["launches"] for k, v in res.items() if "adam" in k or "joint_finish" in k] or [1])
     tot_f = sum(v["fetch_bytes_corrected"] * v["launches"] for v in res.values()) / steps
     tot_w = sum(v["write_bytes"] * v["launches"] for v in res.values()) / steps
     res["_step_total"] = {"launches": 1, "steps_counted": steps, "fetch_bytes_corrected": round(tot_f), "write_bytes": round(tot_w),
