@@ -305,10 +305,6 @@ struct TnReduceGroup {
     int nsplit[PC_TN_RGROUP], n_w[PC_TN_RGROUP], n_b[PC_TN_RGROUP], accumulate[PC_TN_RGROUP], block0[PC_TN_RGROUP + 1], n;
 };
 int launch_gemm_tn_group(const TnArgs* args, int n, const TnReduceJob* extra, int n_extra, hipStream_t st);
-// the grouped launch WITHOUT its slab reduce: the caller's own kernel sums the nsplit[i] slabs of member i (each
-// No*Ni + No floats: weight part then bias part) in fixed order (the fused joint step folds Adam into that pass)
-struct TnGroupPlan { const float* slabs[PC_TN_GROUP]; int nsplit[PC_TN_GROUP]; };
-int launch_gemm_tn_group_partials(const TnArgs* args, int n, TnGroupPlan* plan, hipStream_t st);
 int scatter_add_slab_blocks(int table_rows, int rows, int width);
 int launch_scatter_add_slabs(const int32_t* idx, int rows, int width, int table_rows, const float* src, float* slabs,
                              hipStream_t st);

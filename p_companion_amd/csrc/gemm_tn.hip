@@ -606,43 +606,3 @@ int launch_gemm_tn_group(const TnArgs* args, int n, const TnReduceJob* extra, in
     return pc_launch_status();
 }
 
-// Same grouped launch, slabs only (see common.h).  Every member runs through the 128x128-tile body.
-int launch_gemm_tn_group_partials(const TnArgs* args, int n, TnGroupPlan* plan, hipStream_t st) {
-    if (!args || !plan || n < 1 || n > PC_TN_GROUP) return PC_EINVAL;
-    TnGroup g = {};
-    double flops = 0.0;
-    int blocks = 0, planned = 0;
-    for (int i = 0; i < n; i++) {
-        const TnArgs& a = args[i];
-        if ((!a.Z && !a.z_onehot) || !a.A || !a.slabs || a.R <= 0 || a.No <= 0 || a.Ni <= 0) return PC_EINVAL;
-        if (a.No % 4 || a.Ni % 4 || (a.Z && a.ldz % 4) || a.lda % 4 || a.prologue != NT_PRO_NONE || a.zaux) return PC_ESHAPE;
-        if ((uintptr_t)a.slabs & 15) return PC_ESHAPE;
-        int ns, rp;
-        tn_plan(a.R, a.No, a.Ni, &ns, &rp);
-        planned += ((a.No + TM - 1) / TM) * ((a.Ni + TM - 1) / TM) * ns;
-    }
-    const double thin = planned > 512 ? 512.0 / planned : 1.0;        // one round of the chip (2 workgroups per CU)
-    for (int i = 0; i < n; i++) {
-        const TnArgs& a = args[i];
-        int nsplit, rps;
-        tn_plan(a.R, a.No, a.Ni, &nsplit, &rps);
-        if (thin < 1.0) {
-            int s2 = (int)(nsplit * thin);
-            if (s2 < 1) s2 = 1;
-            rps = ((a.R + s2 - 1) / s2 + TK - 1) / TK * TK;
-            nsplit = (a.R + rps - 1) / rps;
-        }
-        if ((size_t)nsplit * ((size_t)a.No * a.Ni + a.No) > a.slab_floats) return PC_EWORKSPACE;
-        const int tiles_o = (a.No + TM - 1) / TM, tiles_i = (a.Ni + TM - 1) / TM;
-        g.a[i] = a; g.tiles_i[i] = tiles_i; g.nsplit[i] = nsplit; g.rps[i] = rps; g.block0[i] = blocks;
-        blocks += tiles_o * tiles_i * nsplit;
-        plan->slabs[i] = a.slabs; plan->nsplit[i] = nsplit;
-        flops += 2.0 * a.R * (double)a.No * a.Ni;
-    }
-    g.n = n;
-    for (int k = n; k <= PC_TN_GROUP; k++) g.block0[k] = blocks;
-    const int pb = pc_prof_begin(PC_KIND_GEMM_TN, flops, st);
-    PC_LAUNCH(gemm_tn_group_kernel, dim3(blocks), dim3(256), 0, st, g);
-    pc_prof_end(pb, st);
-    return pc_launch_status();
-}

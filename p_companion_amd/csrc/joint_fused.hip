@@ -13,9 +13,10 @@
 //       both hinges and their gradients w.r.t. proj and the two touched similarity columns (p_companion.py:95-119)
 //       dpi, dtp_k, dce_k = dtp_k typ_w, dc, dh = (dc dec_w) relu' dropout', dt = dh enc_w    (the whole dX chain)
 //     products on v_mfma_f32_16x16x4_f32 (exact fp32 fma chains: 16-row tiles fill 256 workgroups at B = 4096)
-//   gemm_tn_group       d itm_w, d typ_w, d dec_w, d enc_w (+ biases) and both [T,64] table gradients as one-hot
-//                       products -- the type hinge's dE_c rows ride in the same product (no float atomics anywhere:
-//                       the step is bitwise reproducible for T <= 512)
+//   joint_wgrad_kernel  d itm_w, d typ_w, d dec_w, d enc_w (+ biases) and both [T,64] table gradients as one-hot
+//                       products over the same 16-sample subtiles, blocks sized to each product -- the type hinge's
+//                       dE_c rows ride in the table product (no float atomics anywhere: the step is bitwise
+//                       reproducible for T <= 512); one slab per workgroup
 //   joint_finish_kernel slab sums (fixed order) -> .grad, losses, Adam
 // Large tables (T > 512, e.g. config.py:27 NUM_TYPES = 34800): the similarity row depends on the query TYPE only, so
 // it is formed once per distinct query type of the batch (present-type list, sims + per-chunk top-K in one kernel's
@@ -761,7 +762,8 @@ __global__ __launch_bounds__(256) void type_topk_merge_kernel(const float* part_
 //   C[i][o] = sum_s X[s][i] Z[s][o]: the lane's four results are four consecutive i of one o -> one 16-B store at
 //   slab[o * Ni + i].  Operands come from LDS row-major images (row stride = width + 16 floats: the four sample rows one
 //   MFMA touches sit 16 banks apart).
-#define WG_S 32            /* samples per workgroup (two subtiles) */
+#define WG_S 16            /* samples per workgroup (one 16-sample subtile: 256 workgroups at B = 4096; two subtiles per
+                              workgroup halve the slab bytes but leave half the CUs idle: 34 vs 2x us, measured) */
 #define WLD128 144
 #define WLD64 80
 #define WLD32 48
@@ -874,13 +876,14 @@ __global__ __launch_bounds__(512) void joint_wgrad_kernel(WgradArgs a) {
         else if (tid < 320) { for (int r = 0; r < 16; r++) bsum += DC[r * WLD64 + tid - 256]; }
         else if (tid < 352) { for (int r = 0; r < 16; r++) bsum += DH[r * WLD32 + tid - 320]; }
         // ---- d itm_w^T: wave w owns input block w (16 of the 128 q dims) x all 8 output blocks
-#pragma unroll
+#pragma unroll 2
         for (int q = 0; q < 4; q++) {
             const float av = Q[(4 * q + h) * WLD128 + 16 * w + i16];
 #pragma unroll
             for (int ob = 0; ob < 8; ob++) c_itm[ob] = mfma16(av, DPI[(4 * q + h) * WLD128 + 16 * ob + i16], c_itm[ob]);
         }
         // ---- d typ_w^T: input block w & 3 (of 4) x output blocks 4 (w >> 2) .. + 3; 16 K rows
+#pragma unroll 2
         for (int q = 0; q < 4 * MBK; q++) {
             if (q < 4 * K) {
                 const float av = E[(4 * q + h) * WLD64 + 16 * (w & 3) + i16];
@@ -890,13 +893,14 @@ __global__ __launch_bounds__(512) void joint_wgrad_kernel(WgradArgs a) {
             }
         }
         // ---- d dec_w^T [32 in][64 out]: input block w & 1, output block w >> 1;  d enc_w^T [64 in][32 out]: w & 3, w >> 2
-#pragma unroll
+#pragma unroll 1
         for (int q = 0; q < 4; q++) {
             c_dec = mfma16(Hh[(4 * q + h) * WLD32 + 16 * (w & 1) + i16], DC[(4 * q + h) * WLD64 + 16 * (w >> 1) + i16], c_dec);
             c_enc = mfma16(Tq[(4 * q + h) * WLD64 + 16 * (w & 3) + i16], DH[(4 * q + h) * WLD32 + 16 * (w >> 2) + i16], c_enc);
         }
         // ---- table gradients, transposed: C[j][t] = sum_r src[r][j] [idx[r] == t]; wave: dims block w & 3, type blocks
         // (w >> 2) + 2 n
+#pragma unroll 1
         for (int q = 0; q < 4 * (MBK + 2); q++) {
             if (q < 4 * (K + 2)) {
                 const float av = ES[(4 * q + h) * WLD64 + 16 * (w & 3) + i16];
@@ -908,7 +912,7 @@ __global__ __launch_bounds__(512) void joint_wgrad_kernel(WgradArgs a) {
                 }
             }
         }
-#pragma unroll
+#pragma unroll 1
         for (int q = 0; q < 4; q++) {
             const float av = DT[(4 * q + h) * WLD64 + 16 * (w & 3) + i16];
             const int d = idx[16 * (FK + 2) + 4 * q + h];
