@@ -255,7 +255,7 @@ def run_joint(args, rank, world, dev, types, steps, warmup, want_cpu):
                       "kernels_per_step": ("3 (tile kernel, grouped gradient products, finish + Adam) + the batch builder" if types <= 512 else
                                             "10 (2 clears, present types, sims + chunk top-K, merge, tile kernel, 2 row scatter-adds, "
                                             "grouped gradient products, finish + Adam) + the batch builder")},
-           "roofline": {"bound": "hbm", "kernel": "the whole step (one HIP-graph replay): its kernels are a dependent chain",
+           "roofline": {"bound": "hbm", "kernel": "the whole step (batch builder + the fused step's kernels: a dependent chain)",
                         "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                         "frac": round(achieved / HBM_PEAK_GBS, 5),
                         "algorithmic_bytes_per_step": alg, "device_ms_per_step": round(dev_ms, 4),
