@@ -192,9 +192,14 @@ def run_joint(args, rank, world, dev, types, steps, warmup, want_cpu):
     # straight into the graph's input buffers.  N > 1 keeps eager launches (the gradient all-reduce sits between).
     graphed = None
     if world == 1 and not args.no_graph:
-        graphed = GraphedJointStep(model, opt, args.batch, mode=args.joint_launch)
+        graphed = GraphedJointStep(model, opt, args.batch, mode="auto" if args.joint_launch == "epoch" else args.joint_launch)
+    # 'epoch': train.py:36-57's loop over the epoch's batches as one foreign call (pc_joint_train_epoch) -- the same steps,
+    # enqueued from C back to back; falls back to one call per step where the fused step does not serve the configuration
+    by_epoch = graphed is not None and args.joint_launch == "epoch" and graphed.mode == "direct"
+    # direct mode: the loader hands its batches over unbuilt and the step's first kernel builds them (same values)
     loader = ComplementaryIndexLoader(ComplementaryIndexDataset(bpg, "train"), args.batch, shuffle=True, seed=rank,
-                                      device=dev, out=graphed.static if graphed else None)
+                                      device=dev, out=graphed.static if graphed else None,
+                                      deferred=graphed is not None and graphed.mode == "direct")
 
     def batches():
         while True:
@@ -223,13 +228,19 @@ def run_joint(args, rank, world, dev, types, steps, warmup, want_cpu):
     t0 = time.perf_counter()
     ev[0].record()
     trace = os.environ.get("PC_BENCH_TRACE")
-    for i in range(steps):
+    done = 0
+    while by_epoch and done < steps:
+        ep = graphed.run_epoch(loader, drop_last=True, max_steps=steps - done)
+        done += int(ep.shape[0])
+        losses = ep[-1]
+    for i in range(0 if not by_epoch else steps, steps):
         last = next(it)
         losses = step(last)
         if trace and i % 5 == 0:                     # debugging aid: localise a device fault (synchronises: not for timing)
             torch.cuda.synchronize()
             print(f"[trace] joint T={types} step {i} loader step {loader.step} ok", file=sys.stderr, flush=True)
     ev[1].record()
+    host_ms = 1e3 * (time.perf_counter() - t0) / steps       # time the host needed to ENQUEUE a step (>= device time: host-bound)
     torch.cuda.synchronize()
     if world > 1:
         torch.distributed.barrier()
@@ -247,14 +258,18 @@ def run_joint(args, rank, world, dev, types, steps, warmup, want_cpu):
     achieved = alg / (dev_ms * 1e-3) / 1e9
     out = {"metric": "triplets/sec (P-Companion joint step: fwd + type/item hinge + bwd + Adam)", "value": round(value, 1),
            "unit": "triplets/s", "steps": steps, "ms_per_step": round(1e3 * el / steps, 4),
+           "host_enqueue_ms_per_step": round(host_ms, 4),
            "config": {"workload": f"P-Companion joint step, {args.products} products, NUM_TYPES={types}, dim=128, "
                                   f"batch={args.batch}/GPU, K=3 (loader batch construction included)",
                       "global_batch": world * args.batch, "parallelism": f"dp{world}", "final_loss": round(float(losses[0]), 5),
-                      "launch": ({"direct": "fused step, arguments resolved once (one foreign call per step)",
+                      "launch": ("pc_joint_train_epoch: the epoch's steps enqueued by one foreign call" if by_epoch else
+                                 {"direct": "fused step, arguments resolved once (one foreign call per step)",
                                   "graph": "hipGraph replay"}[graphed.mode] if graphed is not None else "eager module calls"),
-                      "kernels_per_step": ("3 (tile kernel, grouped gradient products, finish + Adam) + the batch builder" if types <= 512 else
-                                            "10 (2 clears, present types, sims + chunk top-K, merge, tile kernel, 2 row scatter-adds, "
-                                            "grouped gradient products, finish + Adam) + the batch builder")},
+                      "kernels_per_step": ("2 (tile kernel: batch construction, forward, losses, backward and the tile's gradient slab; finish: slab "
+                                            "sums + Adam)" if types <= 128 else
+                                            "4 (batch builder, tile kernel, gradient products, finish + Adam)" if types <= 512 else
+                                            "10 (batch builder, 2 clears, present types, sims + chunk top-K, merge, tile kernel incl. the "
+                                            "weight-gradient slabs, 2 row scatter-adds, finish + Adam)")},
            "roofline": {"bound": "hbm", "kernel": "the whole step (batch builder + the fused step's kernels: a dependent chain)",
                         "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                         "frac": round(achieved / HBM_PEAK_GBS, 5),
@@ -417,7 +432,7 @@ def main():
                          "gemm_nt_kernel family: ~60 us/step of event packets")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true", help="joint phase: plain module calls (PCompanion.train_step + optimizer) per step")
-    ap.add_argument("--joint-launch", choices=["auto", "direct", "graph"], default="auto",
+    ap.add_argument("--joint-launch", choices=["epoch", "auto", "direct", "graph"], default="epoch",
                     help="joint phase, one process: 'direct' = the fused step with its arguments resolved once; 'graph' = HIP-graph replay")
     ap.add_argument("--large-catalogue", type=int, default=0,
                     help="also time the P2V step over this many products (e.g. 2000000: few duplicate neighbours to merge)")

@@ -423,6 +423,37 @@ int pc_joint_fused_step(const pc_joint_tensors *p, const pc_joint_tensors *g, co
                         float alpha, float *losses, int32_t *topk, int32_t *bad_count, void *ws, size_t ws_bytes,
                         void *stream);
 
+/* The loader's batch construction (pc_build_complementary_batch, data_loader.py:133-157) and the fused step as ONE call
+ * over `batch` labelled pairs[b] = (query, target, label): query_idx .. neg_items are OUTPUT buffers here -- after the call
+ * they hold the batch exactly as pc_build_complementary_batch(pairs, ..., seed, step) writes it (same filler bits), for
+ * whoever reads the batch afterwards (metrics, logging).  num_types <= 128: the first kernel of the step derives the ids and
+ * the item rows itself (one launch and a 4 MB round trip less); larger tables: the builder's launch, then the step.
+ * `features` [num_products, 128] is the table the dataset serves item rows from (train.py:115: the exported Product2Vec
+ * embeddings), `type_idx` [num_products] the products' type ids, `n_types` the dataset's modulus for the negative type. */
+int pc_joint_fused_step_pairs(const pc_joint_tensors *p, const pc_joint_tensors *g, const pc_joint_tensors *exp_avg,
+                              const pc_joint_tensors *exp_avg_sq, int64_t *step_count, double lr, double beta1,
+                              double beta2, double eps, const int32_t *pairs, const float *features,
+                              const int32_t *type_idx, int n_types, uint64_t seed, uint64_t step,
+                              int32_t *query_idx, int32_t *query_types, int32_t *pos_types, int32_t *neg_types,
+                              float *pos_items, float *neg_items, int batch, int num_types, int k, int num_products,
+                              float margin, float alpha, float *losses, int32_t *topk, int32_t *bad_count, void *ws,
+                              size_t ws_bytes, void *stream);
+
+/* train.py:36-57 train_epoch (for batch in loader: forward, loss, zero_grad, backward, optimizer.step) over `n_pairs`
+ * labelled pairs in epoch order on the device, as ONE call: full batches of `batch` pairs, then (unless drop_last) the
+ * ragged rest, each through pc_joint_fused_step_pairs with the loader's step counter first_step + i and the dropout
+ * offset p->dropout.offset + i.  losses_out[3 * i ..] = {loss, type, item} of step i, on the device (the reference's
+ * loss.item() per step is one device round trip per batch).  The batch buffers (sized for `batch`) hold the last batch
+ * afterwards; ws as for pc_joint_fused_step at `batch`.  exp_avg / exp_avg_sq are required. */
+int pc_joint_train_epoch(const pc_joint_tensors *p, const pc_joint_tensors *g, const pc_joint_tensors *exp_avg,
+                         const pc_joint_tensors *exp_avg_sq, int64_t *step_count, double lr, double beta1,
+                         double beta2, double eps, const int32_t *pairs, int64_t n_pairs, const float *features,
+                         const int32_t *type_idx, int n_types, uint64_t seed, uint64_t first_step,
+                         int32_t *query_idx, int32_t *query_types, int32_t *pos_types, int32_t *neg_types,
+                         float *pos_items, float *neg_items, int batch, int drop_last, int num_types, int k,
+                         int num_products, float margin, float alpha, float *losses_out, int32_t *topk,
+                         int32_t *bad_count, void *ws, size_t ws_bytes, void *stream);
+
 /* ---------------------------------------------------------------------------------
  * Building blocks the Python modules compose their autograd from (module / dense mode).
  * --------------------------------------------------------------------------------- */

@@ -119,6 +119,12 @@ SIGNATURES = {
     "pc_joint_fused_supported": (_i, [_i, _i, _f]),
     "pc_joint_fused_step": (_i, [_P(JointTensors), _P(JointTensors), _P(JointTensors), _P(JointTensors), _vp, _d, _d, _d, _d,
                                  _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _f, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "pc_joint_fused_step_pairs": (_i, [_P(JointTensors), _P(JointTensors), _P(JointTensors), _P(JointTensors), _vp, _d, _d, _d, _d,
+                                       _vp, _vp, _vp, _i, _u64, _u64, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _f,
+                                       _vp, _vp, _vp, _vp, _sz, _vp]),
+    "pc_joint_train_epoch": (_i, [_P(JointTensors), _P(JointTensors), _P(JointTensors), _P(JointTensors), _vp, _d, _d, _d, _d,
+                                  _vp, _i64, _vp, _vp, _i, _u64, _u64, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _f,
+                                  _vp, _vp, _vp, _vp, _sz, _vp]),
     "pc_linear_forward": (_i, [_vp, _vp, _i, _i, _vp, _vp, _i, _i, _vp, _vp]),
     "pc_linear_backward_input": (_i, [_vp, _i, _i, _vp, _i, _i, _vp, _vp, _vp, _vp]),
     "pc_linear_backward_weight_workspace_bytes": (_sz, [_i, _i, _i]),

@@ -211,6 +211,41 @@ __device__ __forceinline__ void pc_dropout_keep4(const DropCfg& c, unsigned grou
     m[0] = x0 >= c.thr ? c.scale : 0.f; m[1] = x1 >= c.thr ? c.scale : 0.f;
     m[2] = x2 >= c.thr ? c.scale : 0.f; m[3] = x3 >= c.thr ? c.scale : 0.f;
 }
+// torch.optim.Adam's single-tensor update of one element (train.py:24 defaults; step_size = lr / (1 - beta1^t),
+// bc2s = sqrt(1 - beta2^t), both rounded from fp64).  ONE definition with contraction off, so that the stand-alone Adam
+// kernel and the fused step's finish kernel round identically whatever code surrounds them.
+__device__ __forceinline__ void pc_adam_update(float& p, float& m, float& v, float g, float step_size, float bc2s,
+                                               float omb1, float beta2, float omb2, float eps) {
+#pragma clang fp contract(off)
+    m = m + (g - m) * omb1;
+    v = v * beta2 + (omb2 * g) * g;
+    p = p - step_size * (m / (sqrtf(v) / bc2s + eps));
+}
+// The N(0,1) filler rows of the complementary batch (data_loader.py:148-151: torch.randn_like in the reference's worker
+// -- input DATA): chunk t = 32 b + c (16-B chunk c of row b) takes the first Philox4x32-10 block of the stream
+// (seed; sample t, step) through Box-Muller.  One definition for the batch builder and for the fused step that builds
+// its batch itself, so that both produce the same bits.
+__device__ __forceinline__ float2 pc_box_muller(uint32_t a, uint32_t b) {
+    const float u1 = ((float)(a >> 8) + 0.5f) * (1.0f / 16777216.0f);      // (0,1)
+    const float u2 = ((float)(b >> 8) + 0.5f) * (1.0f / 16777216.0f);
+    const float r = sqrtf(-2.0f * __logf(u1));
+    float sn, cs;
+    __sincosf(6.283185307179586f * u2, &sn, &cs);
+    return make_float2(r * cs, r * sn);
+}
+__device__ __forceinline__ float4 pc_filler_chunk(uint64_t seed, uint64_t step, uint32_t t) {
+    uint32_t x0 = 0u, x1 = t, x2 = (uint32_t)step, x3 = (uint32_t)(step >> 32), k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
+#pragma unroll
+    for (int r = 0; r < 10; r++) {
+        const uint64_t p0 = (uint64_t)0xD2511F53u * x0, p1 = (uint64_t)0xCD9E8D57u * x2;
+        const uint32_t y0 = (uint32_t)(p1 >> 32) ^ x1 ^ k0, y1 = (uint32_t)p1;
+        const uint32_t y2 = (uint32_t)(p0 >> 32) ^ x3 ^ k1, y3 = (uint32_t)p0;
+        x0 = y0; x1 = y1; x2 = y2; x3 = y3;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+    const float2 n0 = pc_box_muller(x0, x1), n1 = pc_box_muller(x2, x3);
+    return make_float4(n0.x, n0.y, n1.x, n1.y);
+}
 #endif
 
 // ---- optional per-launch timing (bench.py roofline leg): HIP events recorded on the launch

@@ -107,6 +107,11 @@ struct FusedArgs {
     float *h, *dpi, *dtp, *dc, *dh, *dt;  // row buffers for the gradient products
     float* ecsrc; int32_t* ecidx;         // [B (K + 2)][64] / [B (K + 2)]: rows added into dE_c[ecidx[r]]
     int32_t* bad; int64_t* step_count;
+    float* slabs; int slab_floats;        // WGRAD: one gradient slab per workgroup (layout: wg_off_*)
+    // PAIRS: the batch is built here from labelled pairs (data_loader.py:133-157, see pc_build_complementary_batch);
+    // query_idx .. neg_items above are then OUTPUTS (the batch as the loader would have handed it), written on the way
+    const int32_t* pairs; const float* features; const int32_t* type_idx; int n_types_mod; uint64_t bseed, bstep;
+    int32_t *o_qidx, *o_qt, *o_pt, *o_nt; float *o_pos, *o_neg;
 };
 
 // ---- wave-wide reductions on the DPP network (6 VALU instructions; the xor-shuffle form is 6 dependent LDS-crossbar
@@ -201,6 +206,19 @@ __device__ __forceinline__ void row_topk(const float* row, int T, int K, int l16
     }
 }
 
+// per-workgroup gradient slab: itm_w | itm_b | typ_w | typ_b | dec_w | dec_b | enc_w | enc_b | E_c | E_q
+__host__ __device__ inline int wg_off_itm_w() { return 0; }
+__host__ __device__ inline int wg_off_itm_b() { return PC_D * PC_D; }
+__host__ __device__ inline int wg_off_typ_w() { return wg_off_itm_b() + PC_D; }
+__host__ __device__ inline int wg_off_typ_b() { return wg_off_typ_w() + PC_D * PC_L; }
+__host__ __device__ inline int wg_off_dec_w() { return wg_off_typ_b() + PC_D; }
+__host__ __device__ inline int wg_off_dec_b() { return wg_off_dec_w() + PC_L * LH; }
+__host__ __device__ inline int wg_off_enc_w() { return wg_off_dec_b() + PC_L; }
+__host__ __device__ inline int wg_off_enc_b() { return wg_off_enc_w() + LH * PC_L; }
+__host__ __device__ inline int wg_off_ec() { return wg_off_enc_b() + LH; }
+__host__ __device__ inline int wg_off_eq(int T) { return wg_off_ec() + T * PC_L; }
+__host__ __device__ inline int wg_slab_floats(int T) { return wg_off_eq(T) + T * PC_L; }
+
 #define LD64 68       /* LDS row strides: row length + 4 floats (16-B reads of 16 rows spread over the banks) */
 #define LD32 36
 #define LD128 132
@@ -230,8 +248,13 @@ extern "C" int pc_debug_joint_timing(unsigned long long* out) {
 // SIMS_LOCAL: the similarity row and its top-K are computed here (T <= T_SMALL); else read per query type
 // KC: compile-time NUM_COMP_TYPES (3 = config.py:24; the row-block loops then carry no branches and the compiler
 // schedules the LDS reads of a whole phase ahead of its MFMAs), 0 = run-time K <= FK
-template <bool SIMS_LOCAL, int KC>
+// WGRAD: the tile's share of every weight gradient (and, with SIMS_LOCAL and T <= 128, of both table gradients as
+// one-hot products) is formed HERE from the operands the phases left in LDS and written as the workgroup's slab: the
+// row buffers never travel to HBM and back and the step is one launch shorter.  Samples of a product run in the order
+// s = q + 4 h (lane group h of MFMA q): with row strides = 4 mod 64 banks the four rows of one MFMA sit 16 banks apart.
+template <bool SIMS_LOCAL, int KC, bool WGRAD, bool PAIRS = false>
 __global__ __launch_bounds__(256) void joint_tile_kernel(FusedArgs a, int ldsims) {
+    constexpr bool TABLES = WGRAD && SIMS_LOCAL;       // table gradients in this kernel
     extern __shared__ __attribute__((aligned(16))) float sm[];
     float* Tin = sm;                       // [16][LD64]   E_q rows
     float* Hs = Tin + TS * LD64;           // [16][LD32]   hidden (dropped)
@@ -244,6 +267,9 @@ __global__ __launch_bounds__(256) void joint_tile_kernel(FusedArgs a, int ldsims
     float* DHs = DCs + TS * LD64;          // [16][LD32]
     int* ints = reinterpret_cast<int*>(DHs + TS * LD32);      // [16][8]: qi, qt, pos, neg, topk[4]
     float* Sims = reinterpret_cast<float*>(ints + TS * 8);    // [16][ldsims]   (SIMS_LOCAL only)
+    float* ES = Sims + (SIMS_LOCAL ? TS * ldsims : 0);        // TABLES: [16 (K + 2)][LD64] dE_c source rows (row block k: the
+                                                              // selected types' rows, K: -> pos type, K + 1: -> neg type)
+    float* DTs = ES + TS * (FK + 2) * LD64;                   // TABLES: [16][LD64] dE_q source rows
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -257,9 +283,20 @@ __global__ __launch_bounds__(256) void joint_tile_kernel(FusedArgs a, int ldsims
     // the offence is counted and the id clamped so that nothing is read or written out of bounds)
     if (tid < TS) {
         const int b = b0 + tid;
-        int qi = 0, qt = 0, pt = 0, nt = 0, wrong = 0;
+        int qi = 0, qt = 0, pt = 0, nt = 0, wrong = 0, tg = 0, lab = 1;
         if (b < a.B) {
-            qi = a.query_idx[b]; qt = a.query_types[b]; pt = a.pos_types[b]; nt = a.neg_types[b];
+            if (PAIRS) {
+                qi = a.pairs[3 * b]; tg = a.pairs[3 * b + 1]; lab = a.pairs[3 * b + 2];
+                if ((unsigned)qi >= (unsigned)a.P) { wrong++; qi = 0; }
+                if ((unsigned)tg >= (unsigned)a.P) { wrong++; tg = 0; }
+                const int tt = a.type_idx[tg];
+                qt = a.type_idx[qi];
+                pt = lab == 1 ? tt : 0;
+                nt = lab == 1 ? (tt + 1) % a.n_types_mod : tt;
+                a.o_qidx[b] = qi; a.o_qt[b] = qt; a.o_pt[b] = pt; a.o_nt[b] = nt;
+            } else {
+                qi = a.query_idx[b]; qt = a.query_types[b]; pt = a.pos_types[b]; nt = a.neg_types[b];
+            }
             if ((unsigned)qi >= (unsigned)a.P) { wrong++; qi = 0; }
             if ((unsigned)qt >= (unsigned)a.T) { wrong++; qt = 0; }
             if ((unsigned)pt >= (unsigned)a.T) { wrong++; pt = 0; }
@@ -267,6 +304,7 @@ __global__ __launch_bounds__(256) void joint_tile_kernel(FusedArgs a, int ldsims
             if (wrong && a.bad) atomicAdd(a.bad, wrong);
         }
         ints[tid * 8 + 0] = qi; ints[tid * 8 + 1] = qt; ints[tid * 8 + 2] = pt; ints[tid * 8 + 3] = nt;
+        if (PAIRS) { ints[tid * 8 + 4] = tg; ints[tid * 8 + 5] = lab; }      // (the top-K slots: free until phase D)
     }
     // ---- every weight fragment this wave will multiply by, requested now (see load_b)
     BFrag<4> f_h = {}, f_dh = {}, f_s0 = {}, f_s1 = {};
@@ -309,10 +347,27 @@ __global__ __launch_bounds__(256) void joint_tile_kernel(FusedArgs a, int ldsims
         }
         {
             const size_t bb = liveF ? bF : 0;
+            if (PAIRS) {
+                // positive / negative item rows: the target's feature row and an N(0,1) filler, by the pair's label
+                const int tg = ints[sF * 8 + 4];
+                const bool pos = ints[sF * 8 + 5] == 1;
 #pragma unroll
-            for (int u = 0; u < 2; u++) {
-                r_pos[u] = *reinterpret_cast<const float4*>(a.pos_items + bb * PC_D + 64 * u + 4 * l16);
-                r_neg[u] = *reinterpret_cast<const float4*>(a.neg_items + bb * PC_D + 64 * u + 4 * l16);
+                for (int u = 0; u < 2; u++) {
+                    const float4 f = *reinterpret_cast<const float4*>(a.features + (size_t)tg * PC_D + 64 * u + 4 * l16);
+                    const float4 fill = pc_filler_chunk(a.bseed, a.bstep, (uint32_t)(bb * (PC_D / 4) + 16 * u + l16));
+                    r_pos[u] = pos ? f : fill;
+                    r_neg[u] = pos ? fill : f;
+                    if (liveF) {
+                        *reinterpret_cast<float4*>(a.o_pos + bb * PC_D + 64 * u + 4 * l16) = r_pos[u];
+                        *reinterpret_cast<float4*>(a.o_neg + bb * PC_D + 64 * u + 4 * l16) = r_neg[u];
+                    }
+                }
+            } else {
+#pragma unroll
+                for (int u = 0; u < 2; u++) {
+                    r_pos[u] = *reinterpret_cast<const float4*>(a.pos_items + bb * PC_D + 64 * u + 4 * l16);
+                    r_neg[u] = *reinterpret_cast<const float4*>(a.neg_items + bb * PC_D + 64 * u + 4 * l16);
+                }
             }
             r_ep = *reinterpret_cast<const float4*>(a.ec + (size_t)ints[sF * 8 + 2] * PC_L + 4 * l16);
             r_en = *reinterpret_cast<const float4*>(a.ec + (size_t)ints[sF * 8 + 3] * PC_L + 4 * l16);
@@ -343,7 +398,7 @@ __global__ __launch_bounds__(256) void joint_tile_kernel(FusedArgs a, int ldsims
                 x *= m[col & 3];
             }
             Hs[row * LD32 + col] = x;
-            if (b0 + row < a.B) a.h[(size_t)(b0 + row) * LH + col] = x;
+            if (!WGRAD && b0 + row < a.B) a.h[(size_t)(b0 + row) * LH + col] = x;
         }
     } else {
         f32x4v acc0[1] = {{0.f, 0.f, 0.f, 0.f}}, acc1[1] = {{0.f, 0.f, 0.f, 0.f}};
@@ -415,7 +470,7 @@ __global__ __launch_bounds__(256) void joint_tile_kernel(FusedArgs a, int ldsims
         *reinterpret_cast<float4*>(&ECs[row * LD64 + c4]) = *reinterpret_cast<const float4*>(a.ec + (size_t)t * PC_L + c4);
         if (c4 == 0 && b0 + s < a.B) {
             a.topk[(size_t)(b0 + s) * K + k] = t;
-            a.ecidx[(size_t)(b0 + s) * K + k] = t;
+            if (!TABLES) a.ecidx[(size_t)(b0 + s) * K + k] = t;
         }
     }
     phase_sync();
@@ -493,22 +548,36 @@ __global__ __launch_bounds__(256) void joint_tile_kernel(FusedArgs a, int ldsims
                     const float4 dt4 = make_float4(d.x * pa[u].x, d.y * pa[u].y, d.z * pa[u].z, d.w * pa[u].w);
                     // (a dead row of the last tile carries g = 0: zero operands for the products downstream)
                     *reinterpret_cast<float4*>(&TPs[(16 * k + sF) * LD128 + 64 * u + 4 * l16]) = dt4;
-                    if (liveF) *reinterpret_cast<float4*>(a.dtp + ((size_t)bF * K + k) * PC_D + 64 * u + 4 * l16) = dt4;
+                    if (!WGRAD && liveF) *reinterpret_cast<float4*>(a.dtp + ((size_t)bF * K + k) * PC_D + 64 * u + 4 * l16) = dt4;
                 }
             }
-        if (liveF) {
-            *reinterpret_cast<float4*>(a.dc + (size_t)bF * PC_L + 4 * l16) = dcv;
-            *reinterpret_cast<float4*>(a.ecsrc + ((size_t)a.B * K + bF) * PC_L + 4 * l16) =
-                make_float4(-gt * cb.x, -gt * cb.y, -gt * cb.z, -gt * cb.w);                       // -> dE_c[pos]
-            *reinterpret_cast<float4*>(a.ecsrc + ((size_t)a.B * (K + 1) + bF) * PC_L + 4 * l16) =
-                make_float4(gt * cb.x, gt * cb.y, gt * cb.z, gt * cb.w);                           // -> dE_c[neg]
+        const float4 hp = make_float4(-gt * cb.x, -gt * cb.y, -gt * cb.z, -gt * cb.w);          // -> dE_c[pos]
+        const float4 hn = make_float4(gt * cb.x, gt * cb.y, gt * cb.z, gt * cb.w);              // -> dE_c[neg]
+        if (WGRAD) {                                   // d(pi) over pi (this lane's own elements); dead rows carry zeros
 #pragma unroll
-            for (int u = 0; u < 2; u++) *reinterpret_cast<float4*>(a.dpi + (size_t)bF * PC_D + 64 * u + 4 * l16) = acc[u];
+            for (int u = 0; u < 2; u++) *reinterpret_cast<float4*>(&PIs[sF * LD128 + 64 * u + 4 * l16]) = acc[u];
+        }
+        if (TABLES) {
+            *reinterpret_cast<float4*>(&ES[(16 * K + sF) * LD64 + 4 * l16]) = hp;
+            *reinterpret_cast<float4*>(&ES[(16 * (K + 1) + sF) * LD64 + 4 * l16]) = hn;
+        }
+        if (liveF) {
+            if (!WGRAD) {
+                *reinterpret_cast<float4*>(a.dc + (size_t)bF * PC_L + 4 * l16) = dcv;
+#pragma unroll
+                for (int u = 0; u < 2; u++) *reinterpret_cast<float4*>(a.dpi + (size_t)bF * PC_D + 64 * u + 4 * l16) = acc[u];
+            }
+            if (!TABLES) {
+                *reinterpret_cast<float4*>(a.ecsrc + ((size_t)a.B * K + bF) * PC_L + 4 * l16) = hp;
+                *reinterpret_cast<float4*>(a.ecsrc + ((size_t)a.B * (K + 1) + bF) * PC_L + 4 * l16) = hn;
+            }
             if (l16 == 0) {
                 a.part_type[bF] = lt > 0.f ? lt : 0.f;
                 a.part_item[bF] = li;
-                a.ecidx[(size_t)a.B * K + bF] = pt;
-                a.ecidx[(size_t)a.B * (K + 1) + bF] = nt;
+                if (!TABLES) {
+                    a.ecidx[(size_t)a.B * K + bF] = pt;
+                    a.ecidx[(size_t)a.B * (K + 1) + bF] = nt;
+                }
             }
         }
     }
@@ -528,7 +597,8 @@ __global__ __launch_bounds__(256) void joint_tile_kernel(FusedArgs a, int ldsims
 #pragma unroll
                 for (int r = 0; r < 4; r++) {
                     const int s = 4 * rh + r;
-                    if (b0 + s < a.B) a.ecsrc[((size_t)(b0 + s) * K + m) * PC_L + col] = acc[m][r];
+                    if (TABLES) ES[(16 * m + s) * LD64 + col] = acc[m][r];
+                    else if (b0 + s < a.B) a.ecsrc[((size_t)(b0 + s) * K + m) * PC_L + col] = acc[m][r];
                 }
     }
     if (w < 2) {
@@ -542,7 +612,7 @@ __global__ __launch_bounds__(256) void joint_tile_kernel(FusedArgs a, int ldsims
             float x = Hs[row * LD32 + col] > 0.f ? acc[0][r] : 0.f;
             if (a.drop.thr) x *= a.drop.scale;
             DHs[row * LD32 + col] = x;
-            if (b0 + row < a.B) a.dh[(size_t)(b0 + row) * LH + col] = x;
+            if (!WGRAD && b0 + row < a.B) a.dh[(size_t)(b0 + row) * LH + col] = x;
         }
     }
     phase_sync();
@@ -555,16 +625,149 @@ __global__ __launch_bounds__(256) void joint_tile_kernel(FusedArgs a, int ldsims
 #pragma unroll
         for (int r = 0; r < 4; r++) {
             const int row = 4 * rh + r;
-            if (b0 + row < a.B) a.dt[(size_t)(b0 + row) * PC_L + col] = acc[0][r];
+            if (TABLES) DTs[row * LD64 + col] = acc[0][r];
+            else if (b0 + row < a.B) a.dt[(size_t)(b0 + row) * PC_L + col] = acc[0][r];
         }
     }
     PC_STAMP(11);
+    if (WGRAD) {
+        // ---- the tile's gradient products C[i][o] = sum_s X[s][i] Z[s][o] on 16 x 16 x 4 blocks: the lane's four results
+        // are four consecutive i of one o -> one 16-B store at slab[o * Ni + i] (summed over the workgroups in fixed order by
+        // the finish kernel).  Every operand is in LDS; rows of samples past the batch carry zero Z.
+        phase_sync();
+        float* slab = a.slabs + (size_t)blockIdx.x * a.slab_floats;
+        const int i16 = lane & 15, h4 = lane >> 4;
+        auto st4 = [&](float* dst, const f32x4v& v) { *reinterpret_cast<float4*>(dst) = make_float4(v[0], v[1], v[2], v[3]); };
+        {   // biases: column sums of d(pi), d(tp), dc, dh
+            float bs = 0.f;
+            if (tid < 128) {
+#pragma unroll
+                for (int r = 0; r < TS; r++) bs += PIs[r * LD128 + tid];
+                slab[wg_off_itm_b() + tid] = bs;
+            } else {
+                for (int r = 0; r < TS * K; r++) bs += TPs[r * LD128 + tid - 128];
+                slab[wg_off_typ_b() + tid - 128] = bs;
+            }
+            bs = 0.f;
+            if (tid < 64) {
+#pragma unroll
+                for (int r = 0; r < TS; r++) bs += DCs[r * LD64 + tid];
+                slab[wg_off_dec_b() + tid] = bs;
+            } else if (tid < 96) {
+#pragma unroll
+                for (int r = 0; r < TS; r++) bs += DHs[r * LD32 + tid - 64];
+                slab[wg_off_enc_b() + tid - 64] = bs;
+            }
+        }
+        PC_STAMP(12);
+        // d itm_w[o][i] = sum_s d(pi)[s][o] q[s][i]: wave w owns input blocks w and w + 4 x all 8 output blocks
+#pragma unroll 1
+        for (int pass = 0; pass < 2; pass++) {
+            const int ib = w + 4 * pass;
+            f32x4v c[8];
+#pragma unroll
+            for (int ob = 0; ob < 8; ob++) c[ob] = f32x4v{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                const int sr = q + 4 * h4;
+                const float av = Qs[sr * LD128 + 16 * ib + i16];
+#pragma unroll
+                for (int ob = 0; ob < 8; ob++) c[ob] = mfma16(av, PIs[sr * LD128 + 16 * ob + i16], c[ob]);
+            }
+#pragma unroll
+            for (int ob = 0; ob < 8; ob++) st4(slab + wg_off_itm_w() + (size_t)(16 * ob + i16) * PC_D + 16 * ib + 4 * h4, c[ob]);
+        }
+        PC_STAMP(13);
+        // d typ_w[o][i] = sum_{s,k} d(tp)[s,k][o] e[s,k][i]: input block w (of 4) x 8 output blocks, 16 K rows
+        {
+            f32x4v c[8];
+#pragma unroll
+            for (int ob = 0; ob < 8; ob++) c[ob] = f32x4v{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int k = 0; k < MBK; k++) {
+                if (k < K) {
+#pragma unroll
+                    for (int q = 0; q < 4; q++) {
+                        const int row = 16 * k + q + 4 * h4;
+                        const float av = ECs[row * LD64 + 16 * w + i16];
+#pragma unroll
+                        for (int ob = 0; ob < 8; ob++) c[ob] = mfma16(av, TPs[row * LD128 + 16 * ob + i16], c[ob]);
+                    }
+                }
+            }
+#pragma unroll
+            for (int ob = 0; ob < 8; ob++) st4(slab + wg_off_typ_w() + (size_t)(16 * ob + i16) * PC_L + 16 * w + 4 * h4, c[ob]);
+        }
+        // d dec_w[o][i] = sum_s dc[s][o] h[s][i] ([64][32]: output block w x 2 input blocks);
+        // d enc_w[o][i] = sum_s dh[s][o] t[s][i] ([32][64]: input block w x 2 output blocks)
+        {
+            f32x4v cd[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}}, ce[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                const int sr = q + 4 * h4;
+                const float zd = DCs[sr * LD64 + 16 * w + i16], xt = Tin[sr * LD64 + 16 * w + i16];
+#pragma unroll
+                for (int j = 0; j < 2; j++) {
+                    cd[j] = mfma16(Hs[sr * LD32 + 16 * j + i16], zd, cd[j]);
+                    ce[j] = mfma16(xt, DHs[sr * LD32 + 16 * j + i16], ce[j]);
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < 2; j++) {
+                st4(slab + wg_off_dec_w() + (size_t)(16 * w + i16) * LH + 16 * j + 4 * h4, cd[j]);
+                st4(slab + wg_off_enc_w() + (size_t)(16 * j + i16) * PC_L + 16 * w + 4 * h4, ce[j]);
+            }
+        }
+        PC_STAMP(14);
+        if (TABLES) {
+            // table gradients, transposed, as one-hot products: C[j][t] = sum_r src[r][j] [idx[r] == t]; wave w owns the
+            // dims block w, all (<= 8) type blocks.  E_c: 16 (K + 2) source rows; E_q: the 16 d(t) rows.
+            // (all 8 blocks unconditionally: a run-time block count turns every MFMA into its own branch target and the
+            // accumulators into copies between them -- 60 us instead of 3, measured)
+            f32x4v c[8];
+#pragma unroll
+            for (int n = 0; n < 8; n++) c[n] = f32x4v{0.f, 0.f, 0.f, 0.f};
+#pragma unroll 1
+            for (int rb = 0; rb < K + 2; rb++) {
+#pragma unroll
+                for (int q = 0; q < 4; q++) {
+                    const int sr = q + 4 * h4;
+                    const float av = ES[(16 * rb + sr) * LD64 + 16 * w + i16];
+                    const int d = ints[sr * 8 + (rb < K ? 4 + rb : 2 + rb - K)];
+#pragma unroll
+                    for (int n = 0; n < 8; n++) c[n] = mfma16(av, d == 16 * n + i16 ? 1.f : 0.f, c[n]);
+                }
+            }
+#pragma unroll
+            for (int n = 0; n < 8; n++) {
+                const int t = 16 * n + i16;
+                if (t < a.T) st4(slab + wg_off_ec() + (size_t)t * PC_L + 16 * w + 4 * h4, c[n]);
+                c[n] = f32x4v{0.f, 0.f, 0.f, 0.f};
+            }
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                const int sr = q + 4 * h4;
+                const float av = DTs[sr * LD64 + 16 * w + i16];
+                const int d = ints[sr * 8 + 1];
+#pragma unroll
+                for (int n = 0; n < 8; n++) c[n] = mfma16(av, d == 16 * n + i16 ? 1.f : 0.f, c[n]);
+            }
+#pragma unroll
+            for (int n = 0; n < 8; n++) {
+                const int t = 16 * n + i16;
+                if (t < a.T) st4(slab + wg_off_eq(a.T) + (size_t)t * PC_L + 16 * w + 4 * h4, c[n]);
+            }
+        }
+        PC_STAMP(15);
+    }
 }
 
-static size_t tile_lds_bytes(int T, bool sims_local) {
+#define T_WGRAD 128   /* largest table whose one-hot gradient blocks (8 per wave and table) the tile kernel carries itself */
+static size_t tile_lds_bytes(int T, bool sims_local, bool tables) {
     const int ldsims = sims_local ? ((T + 15) / 16 * 16 + 4) : 0;
     const size_t floats = (size_t)TS * LD64 + TS * LD32 + TS * LD64 + 2 * TS * LD128 + (size_t)TS * FK * LD64 +
-                          (size_t)TS * FK * LD128 + TS * LD64 + TS * LD32 + TS * 8 + (size_t)TS * ldsims;
+                          (size_t)TS * FK * LD128 + TS * LD64 + TS * LD32 + TS * 8 + (size_t)TS * ldsims +
+                          (tables ? (size_t)TS * (FK + 2) * LD64 + TS * LD64 : 0);
     return floats * sizeof(float);
 }
 
@@ -762,6 +965,7 @@ __global__ __launch_bounds__(256) void type_topk_merge_kernel(const float* part_
 //   C[i][o] = sum_s X[s][i] Z[s][o]: the lane's four results are four consecutive i of one o -> one 16-B store at
 //   slab[o * Ni + i].  Operands come from LDS row-major images (row stride = width + 16 floats: the four sample rows one
 //   MFMA touches sit 16 banks apart).
+static_assert(TS == 16, "one gradient slab per 16-sample tile");
 #define WG_S 16            /* samples per workgroup (one 16-sample subtile: 256 workgroups at B = 4096; two subtiles per
                               workgroup halve the slab bytes but leave half the CUs idle: 34 vs 2x us, measured) */
 #define WLD128 144
@@ -775,18 +979,6 @@ struct WgradArgs {
     int B, T, K;
     float* slabs; int slab_floats;                        // per workgroup: itm_w | itm_b | typ_w | typ_b | dec_w | dec_b | enc_w | enc_b | E_c | E_q
 };
-__host__ __device__ inline int wg_off_itm_w() { return 0; }
-__host__ __device__ inline int wg_off_itm_b() { return PC_D * PC_D; }
-__host__ __device__ inline int wg_off_typ_w() { return wg_off_itm_b() + PC_D; }
-__host__ __device__ inline int wg_off_typ_b() { return wg_off_typ_w() + PC_D * PC_L; }
-__host__ __device__ inline int wg_off_dec_w() { return wg_off_typ_b() + PC_D; }
-__host__ __device__ inline int wg_off_dec_b() { return wg_off_dec_w() + PC_L * LH; }
-__host__ __device__ inline int wg_off_enc_w() { return wg_off_dec_b() + PC_L; }
-__host__ __device__ inline int wg_off_enc_b() { return wg_off_enc_w() + LH * PC_L; }
-__host__ __device__ inline int wg_off_ec() { return wg_off_enc_b() + LH; }
-__host__ __device__ inline int wg_off_eq(int T) { return wg_off_ec() + T * PC_L; }
-__host__ __device__ inline int wg_slab_floats(int T) { return wg_off_eq(T) + T * PC_L; }
-
 // NTW: 16-type column blocks of a table product per wave (T <= 128: 4; T <= 512: 16)
 template <int NTW, int KC>
 __global__ __launch_bounds__(512) void joint_wgrad_kernel(WgradArgs a) {
@@ -1004,10 +1196,26 @@ __global__ __launch_bounds__(256) void joint_finish_kernel(FinishArgs a) {
     const int j4 = direct ? t : t >> 3, g = direct ? 0 : t & 7;
     if (j4 * 4 >= jb.n) return;
     float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+    // Adam's operands are requested before the slab walk (they do not depend on it)
+    float4 pv = make_float4(0.f, 0.f, 0.f, 0.f), mv = pv, vv = pv;
+    if (a.adam && g == 0) {
+        pv = *reinterpret_cast<const float4*>(jb.param + (size_t)j4 * 4);
+        mv = *reinterpret_cast<const float4*>(jb.m + (size_t)j4 * 4);
+        vv = *reinterpret_cast<const float4*>(jb.v + (size_t)j4 * 4);
+    }
     if (jb.nsplit > 0) {
+        // 16 slab reads in flight per lane: the walk is a chain of memory latencies (32 dependent-free loads per lane at 256
+        // slabs; four at a time took 16 us for 43 MB that sit in the last-level cache), the order of the additions is fixed
         const float* src = jb.slabs + (size_t)j4 * 4;
-#pragma unroll 4
-        for (int k = g; k < jb.nsplit; k += 8) {
+        int k = g;
+        for (; k + 8 * 15 < jb.nsplit; k += 8 * 16) {
+            float4 v[16];
+#pragma unroll
+            for (int u = 0; u < 16; u++) v[u] = *reinterpret_cast<const float4*>(src + (size_t)(k + 8 * u) * jb.stride);
+#pragma unroll
+            for (int u = 0; u < 16; u++) { s.x += v[u].x; s.y += v[u].y; s.z += v[u].z; s.w += v[u].w; }
+        }
+        for (; k < jb.nsplit; k += 8) {
             const float4 v = *reinterpret_cast<const float4*>(src + (size_t)k * jb.stride);
             s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
         }
@@ -1024,13 +1232,7 @@ __global__ __launch_bounds__(256) void joint_finish_kernel(FinishArgs a) {
     if (a.adam) {
         const float step_size = scal[0], bc2s = scal[1];
         const float omb1 = (float)(1.0 - a.beta1), beta2 = (float)a.beta2, omb2 = (float)(1.0 - a.beta2), eps = (float)a.eps;
-        float4 pv = *reinterpret_cast<float4*>(jb.param + (size_t)j4 * 4);
-        float4 mv = *reinterpret_cast<float4*>(jb.m + (size_t)j4 * 4);
-        float4 vv = *reinterpret_cast<float4*>(jb.v + (size_t)j4 * 4);
-#define ADAM1(c)                                                         \
-        mv.c = mv.c + (s.c - mv.c) * omb1;                               \
-        vv.c = vv.c * beta2 + omb2 * s.c * s.c;                          \
-        pv.c = pv.c - step_size * (mv.c / (sqrtf(vv.c) / bc2s + eps));
+#define ADAM1(c) pc_adam_update(pv.c, mv.c, vv.c, s.c, step_size, bc2s, omb1, beta2, omb2, eps);
         ADAM1(x) ADAM1(y) ADAM1(z) ADAM1(w)
 #undef ADAM1
         *reinterpret_cast<float4*>(jb.param + (size_t)j4 * 4) = pv;
@@ -1107,13 +1309,21 @@ static bool tensors_ok(const pc_joint_tensors* t, bool need_table) {
            t->itm_w && t->itm_b && t->query_types && t->comp_types;
 }
 
-extern "C" int pc_joint_fused_step(const pc_joint_tensors* p, const pc_joint_tensors* g, const pc_joint_tensors* exp_avg,
-                                   const pc_joint_tensors* exp_avg_sq, int64_t* step_count, double lr, double beta1,
-                                   double beta2, double eps, const int32_t* query_idx, const int32_t* query_types,
-                                   const int32_t* pos_types, const int32_t* neg_types, const float* pos_items,
-                                   const float* neg_items, int B, int T, int K, int num_products, float margin, float alpha,
-                                   float* losses, int32_t* topk, int32_t* bad_count, void* ws, size_t ws_bytes,
-                                   void* stream) {
+extern "C" int pc_build_complementary_batch(const int32_t* pairs, int batch, const float* features,
+                                            const int32_t* type_idx, int n_types, uint64_t seed, uint64_t step,
+                                            int32_t* query_idx, int32_t* query_types, int32_t* pos_types,
+                                            int32_t* neg_types, float* pos_items, float* neg_items,
+                                            float* target_features, void* stream);
+
+struct PairsSrc { const int32_t* pairs; const float* features; const int32_t* type_idx; int n_types; uint64_t seed, step; };
+
+static int fused_step_impl(const pc_joint_tensors* p, const pc_joint_tensors* g, const pc_joint_tensors* exp_avg,
+                           const pc_joint_tensors* exp_avg_sq, int64_t* step_count, double lr, double beta1,
+                           double beta2, double eps, const PairsSrc* src, const int32_t* query_idx, const int32_t* query_types,
+                           const int32_t* pos_types, const int32_t* neg_types, const float* pos_items,
+                           const float* neg_items, int B, int T, int K, int num_products, float margin, float alpha,
+                           float* losses, int32_t* topk, int32_t* bad_count, void* ws, size_t ws_bytes,
+                           void* stream) {
     if (!tensors_ok(p, true) || !tensors_ok(g, false)) return PC_EINVAL;
     const bool adam = exp_avg != nullptr;
     if (adam && (!tensors_ok(exp_avg, false) || !tensors_ok(exp_avg_sq, false) || !step_count)) return PC_EINVAL;
@@ -1124,6 +1334,14 @@ extern "C" int pc_joint_fused_step(const pc_joint_tensors* p, const pc_joint_ten
     if (ws_bytes < pc_joint_fused_workspace_bytes(B, T, K)) return PC_EWORKSPACE;
     hipStream_t st = (hipStream_t)stream;
     FusedWs w = fused_ws_layout(ws, B, T, K);
+    // the batch from labelled pairs: inside the tile kernel where that kernel is the step's first consumer of the batch
+    // (T <= 128); otherwise by the builder's own launch, then the step as usual
+    const bool pairs_in_tile = src && w.small && T <= T_WGRAD;
+    if (src && !pairs_in_tile)
+        PC_TRY(pc_build_complementary_batch(src->pairs, B, src->features, src->type_idx, src->n_types, src->seed, src->step,
+                                            const_cast<int32_t*>(query_idx), const_cast<int32_t*>(query_types),
+                                            const_cast<int32_t*>(pos_types), const_cast<int32_t*>(neg_types),
+                                            const_cast<float*>(pos_items), const_cast<float*>(neg_items), nullptr, stream));
 
     if (!w.small) {
         // gradients of the two big tables arrive by float atomics: cleared first
@@ -1157,19 +1375,43 @@ extern "C" int pc_joint_fused_step(const pc_joint_tensors* p, const pc_joint_ten
     fa.topk = topk; fa.part_type = w.part; fa.part_item = w.part + B;
     fa.h = w.h; fa.dpi = w.dpi; fa.dtp = w.dtp; fa.dc = w.dc; fa.dh = w.dh; fa.dt = w.dt;
     fa.ecsrc = w.ecsrc; fa.ecidx = w.ecidx; fa.bad = bad_count; fa.step_count = adam ? step_count : nullptr;
-    const int tiles = (B + TS - 1) / TS;
+    fa.slabs = w.wslabs; fa.slab_floats = w.wslab_floats;
+    if (pairs_in_tile) {
+        fa.pairs = src->pairs; fa.features = src->features; fa.type_idx = src->type_idx; fa.n_types_mod = src->n_types;
+        fa.bseed = src->seed; fa.bstep = src->step;
+        fa.o_qidx = const_cast<int32_t*>(query_idx); fa.o_qt = const_cast<int32_t*>(query_types);
+        fa.o_pt = const_cast<int32_t*>(pos_types); fa.o_nt = const_cast<int32_t*>(neg_types);
+        fa.o_pos = const_cast<float*>(pos_items); fa.o_neg = const_cast<float*>(neg_items);
+    }
+    const int tiles = (B + TS - 1) / TS;                          // == w.wg_blocks (WG_S == TS): one slab per tile
     const int ldsims = w.small ? ((T + 15) / 16 * 16 + 4) : 0;
-    const size_t lds = tile_lds_bytes(T, w.small);
-    static const hipError_t attr[4] = {
-        hipFuncSetAttribute(reinterpret_cast<const void*>(&joint_tile_kernel<true, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024),
-        hipFuncSetAttribute(reinterpret_cast<const void*>(&joint_tile_kernel<true, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024),
-        hipFuncSetAttribute(reinterpret_cast<const void*>(&joint_tile_kernel<false, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024),
-        hipFuncSetAttribute(reinterpret_cast<const void*>(&joint_tile_kernel<false, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)};
+    // where the gradient products run: inside the tile kernel (T <= 128: tables included; T > 512: weights only, the table
+    // rows go by scatter-add) or, for 128 < T <= 512, in joint_wgrad_kernel over the row buffers
+    const bool wgrad_in_tile = !w.small || T <= T_WGRAD;
+    const size_t lds = tile_lds_bytes(T, w.small, w.small && wgrad_in_tile);
+    static const hipError_t attr[8] = {
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&joint_tile_kernel<true, 3, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024),
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&joint_tile_kernel<true, 0, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024),
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&joint_tile_kernel<true, 3, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024),
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&joint_tile_kernel<true, 0, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024),
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&joint_tile_kernel<true, 3, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024),
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&joint_tile_kernel<true, 0, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024),
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&joint_tile_kernel<false, 3, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024),
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&joint_tile_kernel<false, 0, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)};
     (void)attr;
-    if (w.small && K == 3) PC_LAUNCH((joint_tile_kernel<true, 3>), dim3(tiles), dim3(256), lds, st, fa, ldsims);
-    else if (w.small) PC_LAUNCH((joint_tile_kernel<true, 0>), dim3(tiles), dim3(256), lds, st, fa, ldsims);
-    else if (K == 3) PC_LAUNCH((joint_tile_kernel<false, 3>), dim3(tiles), dim3(256), lds, st, fa, ldsims);
-    else PC_LAUNCH((joint_tile_kernel<false, 0>), dim3(tiles), dim3(256), lds, st, fa, ldsims);
+    if (pairs_in_tile) {
+        if (K == 3) PC_LAUNCH((joint_tile_kernel<true, 3, true, true>), dim3(tiles), dim3(256), lds, st, fa, ldsims);
+        else PC_LAUNCH((joint_tile_kernel<true, 0, true, true>), dim3(tiles), dim3(256), lds, st, fa, ldsims);
+    } else if (w.small && wgrad_in_tile) {
+        if (K == 3) PC_LAUNCH((joint_tile_kernel<true, 3, true>), dim3(tiles), dim3(256), lds, st, fa, ldsims);
+        else PC_LAUNCH((joint_tile_kernel<true, 0, true>), dim3(tiles), dim3(256), lds, st, fa, ldsims);
+    } else if (w.small) {
+        if (K == 3) PC_LAUNCH((joint_tile_kernel<true, 3, false>), dim3(tiles), dim3(256), lds, st, fa, ldsims);
+        else PC_LAUNCH((joint_tile_kernel<true, 0, false>), dim3(tiles), dim3(256), lds, st, fa, ldsims);
+    } else {
+        if (K == 3) PC_LAUNCH((joint_tile_kernel<false, 3, true>), dim3(tiles), dim3(256), lds, st, fa, ldsims);
+        else PC_LAUNCH((joint_tile_kernel<false, 0, true>), dim3(tiles), dim3(256), lds, st, fa, ldsims);
+    }
     PC_TRY(pc_launch_status());
 
     // ---- gradient products over the row buffers: one launch, one slab per workgroup, summed by the finish kernel
@@ -1178,7 +1420,7 @@ extern "C" int pc_joint_fused_step(const pc_joint_tensors* p, const pc_joint_ten
     wa.query_idx = query_idx; wa.query_types = query_types; wa.topk = topk;
     wa.dpi = w.dpi; wa.dtp = w.dtp; wa.dc = w.dc; wa.h = w.h; wa.dh = w.dh; wa.dt = w.dt; wa.ecsrc = w.ecsrc; wa.ecidx = w.ecidx;
     wa.B = B; wa.T = w.small ? T : 0; wa.K = K; wa.slabs = w.wslabs; wa.slab_floats = w.wslab_floats;
-    {
+    if (!wgrad_in_tile) {
         static const hipError_t wattr[4] = {
             hipFuncSetAttribute(reinterpret_cast<const void*>(&joint_wgrad_kernel<4, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024),
             hipFuncSetAttribute(reinterpret_cast<const void*>(&joint_wgrad_kernel<4, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024),
@@ -1236,4 +1478,63 @@ extern "C" int pc_joint_fused_step(const pc_joint_tensors* p, const pc_joint_ten
     fin.step_count = step_count; fin.lr = lr; fin.beta1 = beta1; fin.beta2 = beta2; fin.eps = eps; fin.adam = adam ? 1 : 0;
     PC_LAUNCH(joint_finish_kernel, dim3(blocks + 1), dim3(256), 0, st, fin);
     return pc_launch_status();
+}
+
+extern "C" int pc_joint_fused_step(const pc_joint_tensors* p, const pc_joint_tensors* g, const pc_joint_tensors* exp_avg,
+                                   const pc_joint_tensors* exp_avg_sq, int64_t* step_count, double lr, double beta1,
+                                   double beta2, double eps, const int32_t* query_idx, const int32_t* query_types,
+                                   const int32_t* pos_types, const int32_t* neg_types, const float* pos_items,
+                                   const float* neg_items, int B, int T, int K, int num_products, float margin, float alpha,
+                                   float* losses, int32_t* topk, int32_t* bad_count, void* ws, size_t ws_bytes,
+                                   void* stream) {
+    return fused_step_impl(p, g, exp_avg, exp_avg_sq, step_count, lr, beta1, beta2, eps, nullptr, query_idx, query_types,
+                           pos_types, neg_types, pos_items, neg_items, B, T, K, num_products, margin, alpha, losses, topk,
+                           bad_count, ws, ws_bytes, stream);
+}
+
+extern "C" int pc_joint_fused_step_pairs(const pc_joint_tensors* p, const pc_joint_tensors* g, const pc_joint_tensors* exp_avg,
+                                         const pc_joint_tensors* exp_avg_sq, int64_t* step_count, double lr, double beta1,
+                                         double beta2, double eps, const int32_t* pairs, const float* features,
+                                         const int32_t* type_idx, int n_types, uint64_t seed, uint64_t step,
+                                         int32_t* query_idx, int32_t* query_types, int32_t* pos_types, int32_t* neg_types,
+                                         float* pos_items, float* neg_items, int B, int T, int K, int num_products,
+                                         float margin, float alpha, float* losses, int32_t* topk, int32_t* bad_count,
+                                         void* ws, size_t ws_bytes, void* stream) {
+    if (!pairs || !features || !type_idx || n_types <= 0) return PC_EINVAL;
+    const PairsSrc src = {pairs, features, type_idx, n_types, seed, step};
+    return fused_step_impl(p, g, exp_avg, exp_avg_sq, step_count, lr, beta1, beta2, eps, &src, query_idx, query_types,
+                           pos_types, neg_types, pos_items, neg_items, B, T, K, num_products, margin, alpha, losses, topk,
+                           bad_count, ws, ws_bytes, stream);
+}
+
+// train.py:36-57 (train_epoch: for batch in loader: forward, loss, zero_grad, backward, optimizer.step) for `n_pairs`
+// labelled pairs already in epoch order on the device: full batches of `batch` pairs, then -- unless drop_last -- the
+// ragged rest.  The host enqueues the launches back to back from this one call (a Python loop body costs more than the
+// step's kernels run); losses_out[i] = {loss, type, item} of step i stays on the device (the reference's per-step
+// loss.item() is a device round trip per batch: read losses_out once per epoch instead).  The batch buffers hold the
+// LAST batch afterwards.  Dropout offsets and the loader's step counter advance by one per step from the given values.
+extern "C" int pc_joint_train_epoch(const pc_joint_tensors* p, const pc_joint_tensors* g, const pc_joint_tensors* exp_avg,
+                                    const pc_joint_tensors* exp_avg_sq, int64_t* step_count, double lr, double beta1,
+                                    double beta2, double eps, const int32_t* pairs, int64_t n_pairs, const float* features,
+                                    const int32_t* type_idx, int n_types, uint64_t seed, uint64_t first_step,
+                                    int32_t* query_idx, int32_t* query_types, int32_t* pos_types, int32_t* neg_types,
+                                    float* pos_items, float* neg_items, int B, int drop_last, int T, int K, int num_products,
+                                    float margin, float alpha, float* losses_out, int32_t* topk, int32_t* bad_count,
+                                    void* ws, size_t ws_bytes, void* stream) {
+    if (!p || !pairs || !features || !type_idx || n_types <= 0 || n_pairs < 0 || B <= 0 || !losses_out) return PC_EINVAL;
+    if (!exp_avg || !exp_avg_sq) return PC_EINVAL;               // an epoch without the optimizer step trains nothing
+    pc_joint_tensors pl = *p;
+    int64_t done = 0;
+    for (int64_t i = 0; done < n_pairs; i++) {
+        const int64_t left = n_pairs - done;
+        const int b = left >= B ? B : (int)left;
+        if (b < B && drop_last) break;
+        const PairsSrc src = {pairs + 3 * done, features, type_idx, n_types, seed, first_step + (uint64_t)i};
+        pl.dropout.offset = p->dropout.offset + (uint64_t)i;
+        PC_TRY(fused_step_impl(&pl, g, exp_avg, exp_avg_sq, step_count, lr, beta1, beta2, eps, &src, query_idx, query_types,
+                               pos_types, neg_types, pos_items, neg_items, b, T, K, num_products, margin, alpha,
+                               losses_out + 3 * i, topk, bad_count, ws, ws_bytes, stream));
+        done += b;
+    }
+    return PC_OK;
 }

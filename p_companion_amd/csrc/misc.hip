@@ -131,19 +131,17 @@ __global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, 
         const float4 gv = *reinterpret_cast<const float4*>(g + i4);
         float4 mv = *reinterpret_cast<float4*>(m + i4);
         float4 vv = *reinterpret_cast<float4*>(v + i4);
-#define ADAM1(c)                                                         \
-        mv.c = mv.c + (gv.c - mv.c) * omb1;                              \
-        vv.c = vv.c * beta2 + omb2 * gv.c * gv.c;                        \
-        pv.c = pv.c - step_size * (mv.c / (sqrtf(vv.c) / bc2s + eps));
+#define ADAM1(c) pc_adam_update(pv.c, mv.c, vv.c, gv.c, step_size, bc2s, omb1, beta2, omb2, eps);
         ADAM1(x) ADAM1(y) ADAM1(z) ADAM1(w)
+#undef ADAM1
         *reinterpret_cast<float4*>(p + i4) = pv;
         *reinterpret_cast<float4*>(m + i4) = mv;
         *reinterpret_cast<float4*>(v + i4) = vv;
     } else {
         for (size_t i = i4; i < n; i++) {
-            float mm = m[i] + (g[i] - m[i]) * omb1;
-            float vv = v[i] * beta2 + omb2 * g[i] * g[i];
-            p[i] = p[i] - step_size * (mm / (sqrtf(vv) / bc2s + eps));
+            float pp = p[i], mm = m[i], vv = v[i];
+            pc_adam_update(pp, mm, vv, g[i], step_size, bc2s, omb1, beta2, omb2, eps);
+            p[i] = pp;
             m[i] = mm;
             v[i] = vv;
         }

@@ -389,16 +389,7 @@ extern "C" int pc_sample_negatives_zipf(const int32_t* pair_ids, int batch, cons
 //   label -1: positive_types = 0, negative_types = t(target),
 //             positive_items = N(0,1) filler, negative_items = feat(target)
 // The filler is input DATA (torch.randn_like in the reference's worker): here Philox4x32-10 +
-// Box-Muller keyed by (seed; row, 16-B chunk, step).  One thread per 16-B chunk of a row.
-__device__ __forceinline__ float2 box_muller(uint32_t a, uint32_t b) {
-    const float u1 = ((float)(a >> 8) + 0.5f) * (1.0f / 16777216.0f);      // (0,1)
-    const float u2 = ((float)(b >> 8) + 0.5f) * (1.0f / 16777216.0f);
-    const float r = sqrtf(-2.0f * __logf(u1));
-    float sn, cs;
-    __sincosf(6.283185307179586f * u2, &sn, &cs);
-    return make_float2(r * cs, r * sn);
-}
-
+// Box-Muller keyed by (seed; row, 16-B chunk, step) (common.h pc_filler_chunk).  One thread per 16-B chunk of a row.
 __global__ void build_complementary_batch_kernel(const int32_t* pairs, int B, const float* features,
                                                  const int32_t* type_idx, int n_types, uint64_t seed, uint64_t step,
                                                  int32_t* query_idx, int32_t* query_types, int32_t* pos_types,
@@ -409,9 +400,7 @@ __global__ void build_complementary_batch_kernel(const int32_t* pairs, int B, co
     const int b = t / (PC_D / 4), c = t % (PC_D / 4);
     const int q = pairs[3 * b], tg = pairs[3 * b + 1], lab = pairs[3 * b + 2];
     const float4 f = *reinterpret_cast<const float4*>(features + (size_t)tg * PC_D + 4 * c);
-    Philox rng(seed, step, (uint32_t)t);
-    const float2 n0 = box_muller(rng.next(), rng.next()), n1 = box_muller(rng.next(), rng.next());
-    const float4 fill = make_float4(n0.x, n0.y, n1.x, n1.y);
+    const float4 fill = pc_filler_chunk(seed, step, (uint32_t)t);
     const bool pos = lab == 1;
     *reinterpret_cast<float4*>(pos_items + (size_t)b * PC_D + 4 * c) = pos ? f : fill;
     *reinterpret_cast<float4*>(neg_items + (size_t)b * PC_D + 4 * c) = pos ? fill : f;

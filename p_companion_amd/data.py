@@ -228,8 +228,28 @@ class SimilarityIndexLoader:
         if self.sampler == "cpython":
             perm = self.rng.shuffle(S) if self.shuffle else np.arange(S, dtype=np.int64)
         else:
-            rs = np.random.Generator(np.random.Philox([self.seed, self.epoch]))
-            perm = rs.permutation(S) if self.shuffle else np.arange(S, dtype=np.int64)
+            # the next epoch's permutation (a few ms of host work at 275 k pairs: several steps' worth, and the host runs
+            # only one batch ahead of the device) is drawn by a host thread while this epoch trains (torch.randperm
+            # releases the GIL)
+            import threading
+
+            def draw(epoch):
+                if not self.shuffle:
+                    return np.arange(S, dtype=np.int64)
+                g = torch.Generator()
+                g.manual_seed(int(self.seed) * 1000003 + epoch)
+                return torch.randperm(S, generator=g).numpy()
+
+            nxt = getattr(self, "_next_perm", None)
+            if nxt is not None and nxt[0] == self.epoch and nxt[3] == S:
+                nxt[1].join()
+                perm = nxt[2][0]
+            else:
+                perm = draw(self.epoch)
+            box, e = [None], self.epoch + 1
+            th = threading.Thread(target=lambda: box.__setitem__(0, draw(e)), daemon=True)
+            th.start()
+            self._next_perm = (e, th, box, S)
         perm_host = torch.from_numpy(perm.astype(np.int32))
         if torch.device(self.device).type == "cuda":
             # persistent pinned buffer + non_blocking: a pageable H2D copy (or a fresh pinned allocation) makes the
@@ -366,10 +386,16 @@ class ComplementaryIndexDataset:
 class ComplementaryIndexLoader:
     """DataLoader(ComplementaryDataset, collate_fn) in index form (train.py:115-129)."""
 
-    def __init__(self, dataset: ComplementaryIndexDataset, batch_size, shuffle=True, seed=0, device="cuda", out=None):
+    def __init__(self, dataset: ComplementaryIndexDataset, batch_size, shuffle=True, seed=0, device="cuda", out=None,
+                 deferred=False):
         """`out`: fixed device buffers every FULL batch is built into (GraphedJointStep.static); the dict handed out
-        is then the same tensors each time, valid until the next batch is requested."""
+        is then the same tensors each time, valid until the next batch is requested.
+        `deferred` (needs `out`): a full batch is handed out UNBUILT -- the dict carries the labelled pairs under
+        "_deferred" and GraphedJointStep builds the batch inside its first kernel (pc_joint_fused_step_pairs: same values,
+        one launch and a 4 MB round trip less); the tensors of the dict hold the batch AFTER the step.  Anything else that
+        wants the batch first calls `materialize(batch)`."""
         self.out = out
+        self.deferred = bool(deferred) and out is not None
         self.dataset = dataset
         self.batch_size = int(batch_size)
         self.shuffle = shuffle
@@ -397,7 +423,11 @@ class ComplementaryIndexLoader:
                 self._prepared = ops.PreparedComplementaryBuilder(self.features, self.type_idx, self.dataset.bpg.n_types,
                                                                   self.seed, out)
                 self._static_batch = dict(out)
-            self._prepared(rows_dev, self.step)
+                self._source = (self.features, self.type_idx, int(self.dataset.bpg.n_types), int(self.seed))
+            if self.deferred:
+                self._static_batch["_deferred"] = (self, rows_dev, self.step)
+            else:
+                self._prepared(rows_dev, self.step)
             self.step += 1
             self._static_batch["label"] = rows_dev[:, 2]
             return self._static_batch
@@ -407,12 +437,32 @@ class ComplementaryIndexLoader:
         batch["label"] = rows_dev[:, 2]
         return batch
 
-    def __iter__(self):
-        n = len(self.dataset)
-        rs = np.random.Generator(np.random.Philox([self.seed + 7, self.epoch]))
-        order = rs.permutation(n) if self.shuffle else np.arange(n)
+    def materialize(self, batch):
+        """Build a deferred batch now (the builder's own launch); a batch that is built already passes through."""
+        d = batch.pop("_deferred", None) if isinstance(batch, dict) else None
+        if d is not None:
+            self._prepared(d[1], d[2])
+        return batch
+
+    def epoch_pairs(self):
+        """The next epoch's labelled pairs [n,3] in batch order on the device (what __iter__ slices its batches from;
+        GraphedJointStep.run_epoch hands them to pc_joint_train_epoch whole)."""
+        # shuffled ON THE DEVICE (randperm + one row gather, ~50 us): a host permutation of 580 k pairs takes longer than the
+        # 141 steps of that epoch run, and the loop would wait for it at every epoch boundary.  Deterministic in (seed, epoch)
+        # per device type.
+        if getattr(self, "_pairs_all", None) is None:
+            self._pairs_all = torch.from_numpy(np.ascontiguousarray(self.dataset.pairs, np.int32)).to(self.device)
+        e = self.epoch
         self.epoch += 1
-        pairs_dev = torch.from_numpy(np.ascontiguousarray(self.dataset.pairs[order], np.int32)).to(self.device)
+        if not self.shuffle:
+            return self._pairs_all
+        g = torch.Generator(device=self._pairs_all.device)
+        g.manual_seed((int(self.seed) + 7) * 1000003 + e)
+        order = torch.randperm(self._pairs_all.shape[0], device=self._pairs_all.device, generator=g)
+        return self._pairs_all.index_select(0, order)
+
+    def __iter__(self):
+        pairs_dev = self.epoch_pairs()
         for i in range(len(self)):
             yield self.make_batch(pairs_dev[i * self.batch_size:(i + 1) * self.batch_size])
 

@@ -698,6 +698,8 @@ class PreparedJointStep:
                       int(params["product_embeddings.weight"].shape[0]), float(margin), float(alpha), _p(self.losses),
                       _p(self.topk), _p(bad), _p(self.ws), nbytes]
         self._idx = (qi, qt, pt, nt)
+        self._pairs_fn = _lib.lib().pc_joint_fused_step_pairs
+        self._pairs_src = None
 
     def __call__(self, dropout_offset=0):
         if self.dropout is not None:
@@ -707,6 +709,52 @@ class PreparedJointStep:
             check(rc, "pc_joint_fused_step")
         self.calls += 1
         return self.losses, self.topk
+
+    def from_pairs(self, rows_dev, source, step, dropout_offset=0):
+        """The loader's batch construction and the step as one call (pc_joint_fused_step_pairs): `rows_dev` [B,3] int32
+        labelled pairs, `source` = (features, type_idx, n_types, seed) of the dataset, `step` the loader's batch counter.
+        The batch tensors this object was prepared with are OUTPUTS here: they hold the batch afterwards."""
+        if self._pairs_src is None or self._pairs_src[0] is not source:
+            features, type_idx, n_types, seed = source
+            _req(features, torch.float32, "features", (self._args[18], D)); _req(type_idx, torch.int32, "type_idx", (self._args[18],))
+            self._pairs_src = (source, [_p(features), _p(type_idx), int(n_types), int(seed)])
+        _req(rows_dev, torch.int32, "pairs", (self._args[15], 3))
+        if self.dropout is not None:
+            self.st.dropout.offset = int(dropout_offset)
+        rc = self._pairs_fn(*self._args[:9], ctypes.c_void_p(rows_dev.data_ptr()), *self._pairs_src[1], int(step),
+                            *self._args[9:], _stream())
+        if rc:
+            check(rc, "pc_joint_fused_step_pairs")
+        self.calls += 1
+        return self.losses, self.topk
+
+
+def _prepared_run_epoch(self, pairs_dev, source, first_step, drop_last=False, dropout_offset=0):
+    """train.py:36-57 over `pairs_dev` [n,3] (epoch order, on the device) as one foreign call (pc_joint_train_epoch).
+    Returns the per-step losses [n_steps,3] (device) and the number of steps."""
+    if self._args[2] is None:
+        raise ValueError("run_epoch needs the optimizer state (PreparedJointStep(adam=...))")
+    features, type_idx, n_types, seed = source
+    _req(features, torch.float32, "features", (self._args[18], D)); _req(type_idx, torch.int32, "type_idx", (self._args[18],))
+    n = int(pairs_dev.shape[0])
+    _req(pairs_dev, torch.int32, "pairs", (n, 3))
+    b = self._args[15]
+    steps = n // b if drop_last else (n + b - 1) // b
+    losses = torch.empty(max(steps, 1), 3, dtype=torch.float32, device=pairs_dev.device)
+    if self.dropout is not None:
+        self.st.dropout.offset = int(dropout_offset)
+    a = self._args
+    rc = _lib.lib().pc_joint_train_epoch(*a[:9], _p(pairs_dev), n, _p(features), _p(type_idx), int(n_types), int(seed),
+                                         int(first_step), *a[9:16], int(bool(drop_last)), *a[16:21], _p(losses), *a[22:],
+                                         _stream())
+    if rc:
+        check(rc, "pc_joint_train_epoch")
+    self.calls += steps
+    self._keep_epoch = (pairs_dev, features, type_idx)
+    return losses[:steps], steps
+
+
+PreparedJointStep.run_epoch = _prepared_run_epoch
 
 
 class PreparedComplementaryBuilder:

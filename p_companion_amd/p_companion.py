@@ -363,9 +363,14 @@ class GraphedJointStep:
                                               float(m.config.ALPHA), bad=bad, adam=self.optimizer.fused_state(), dropout=drop)
 
     def __call__(self, batch=None):
+        deferred = None
         if batch is not None:
             if batch["query_idx"].numel() != self.batch_size:
                 raise ValueError("GraphedJointStep: fixed batch size %d" % self.batch_size)
+            deferred = batch.get("_deferred") if isinstance(batch, dict) else None
+            if deferred is not None and (self.prepared is None or batch["query_idx"].data_ptr() != self.static["query_idx"].data_ptr()):
+                deferred[0].materialize(batch)           # (warm-up steps / graph mode / foreign buffers: the builder's own launch)
+                deferred = None
             self.load(batch)
         if self.prepared is not None:
             tt = self.model.type_transition
@@ -373,7 +378,13 @@ class GraphedJointStep:
                 raise RuntimeError("GraphedJointStep: the model left training mode")
             off = tt._dropout_step
             tt._dropout_step += 1
-            self.losses, self.complementary_types = self.prepared(off)
+            if deferred is not None:
+                # ComplementaryIndexLoader(..., out=self.static, deferred=True): the batch is built by the step's first kernel
+                batch.pop("_deferred", None)
+                loader, rows_dev, step = deferred
+                self.losses, self.complementary_types = self.prepared.from_pairs(rows_dev, loader._source, step, off)
+            else:
+                self.losses, self.complementary_types = self.prepared(off)
             return self.losses, self.complementary_types
         if self.graph is None:
             if self._eager_steps < self.warmup:
@@ -392,6 +403,38 @@ class GraphedJointStep:
             self.graph = graph
         self.graph.replay()
         return self.losses, self.complementary_types
+
+
+def _graphed_run_epoch(self, loader, drop_last=False, max_steps=None):
+    """train.py:36-57 train_epoch over one epoch of `loader` (a ComplementaryIndexLoader built with out=self.static) as ONE
+    foreign call (pc_joint_train_epoch): the host enqueues every step's launches back to back, nothing is read back per
+    step.  Returns the per-step losses [steps, 3] = (loss, type, item) on the device; `.mean(0)` is the epoch's average
+    (train.py:50-57).  Same values, bit for bit, as iterating the loader and calling self(batch)."""
+    if self.mode != "direct":
+        raise ValueError("run_epoch needs mode 'direct' (a configuration pc_joint_fused_step serves)")
+    if not self.model.training:
+        raise RuntimeError("GraphedJointStep: the model left training mode")
+    if loader.batch_size != self.batch_size or loader.out is None or \
+            loader.out["query_idx"].data_ptr() != self.static["query_idx"].data_ptr():
+        raise ValueError("run_epoch: build the loader with batch_size=%d and out=step.static" % self.batch_size)
+    if self.prepared is None:
+        self.model.flatten_parameters()
+        self.optimizer.fused_state()
+        self._prepare()
+    pairs = loader.epoch_pairs()
+    if max_steps is not None:
+        pairs = pairs[:int(max_steps) * self.batch_size]
+    if getattr(loader, "_source", None) is None:
+        loader._source = (loader.features, loader.type_idx, int(loader.dataset.bpg.n_types), int(loader.seed))
+    tt = self.model.type_transition
+    losses, steps = self.prepared.run_epoch(pairs, loader._source, loader.step, drop_last=drop_last, dropout_offset=tt._dropout_step)
+    tt._dropout_step += steps
+    loader.step += steps
+    self.losses, self.complementary_types = (losses[-1] if steps else None), self.prepared.topk
+    return losses
+
+
+GraphedJointStep.run_epoch = _graphed_run_epoch
 
 
 class _IdentityIds:

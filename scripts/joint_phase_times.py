@@ -28,9 +28,9 @@ for _ in range(10):
 torch.cuda.synchronize()
 buf = (ctypes.c_ulonglong * 32)()
 fn(buf)
-names = ["ids+weight requests", "row gathers", "A: h || pi 0-3", "B: c, pi 4-7", "C: sims", "D: top-k", "gather E_c rows", "E: tp", "F: per-sample losses", "G: dce, dh", "H: dt"]
+names = ["ids+weight requests", "row gathers", "A: h || pi 0-3", "B: c, pi 4-7", "C: sims", "D: top-k", "gather E_c rows", "E: tp", "F: per-sample losses", "G: dce, dh", "H: dt", "W: hand-off + bias sums", "W: d itm_w", "W: d typ_w, d dec_w, d enc_w", "W: tables"]
 for wg in (0, 1):
-    t = [buf[16 * wg + i] for i in range(12)]
-    print(f"workgroup {0 if wg == 0 else 128}: total {(t[11] - t[0]) / 100:.2f} us")
+    t = [buf[16 * wg + i] for i in range(16)]
+    print(f"workgroup {0 if wg == 0 else 128}: total {(t[15] - t[0]) / 100:.2f} us")
     for i, n in enumerate(names):
         print(f"   {n:28s} {(t[i + 1] - t[i]) / 100:7.2f} us")

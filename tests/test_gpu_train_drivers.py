@@ -200,6 +200,105 @@ def test_graphed_joint_step_equals_eager_steps(mode):
         graphed({k: v[:7] for k, v in graphed.static.items()})
 
 
+@pytest.mark.parametrize("types,dropout", [(40, 0.0), (40, 0.1), (300, 0.0)])
+def test_deferred_batches_built_inside_the_step(types, dropout):
+    """ComplementaryIndexLoader(deferred=True) + GraphedJointStep: the batch is built by the step's first kernel
+    (pc_joint_fused_step_pairs; T <= 128) or by the builder's launch inside the same call (larger tables).  Against the
+    loader that builds first: the same losses, top-k and parameters bit for bit, and after each step the fixed buffers
+    hold exactly the batch the builder writes (ids, type ids, feature rows and the N(0,1) filler bits)."""
+    from types import SimpleNamespace
+    from p_companion_amd.data import ComplementaryIndexDataset, ComplementaryIndexLoader, generate_scaled_bpg
+    from p_companion_amd.p_companion import GraphedJointStep, PCompanion
+    from p_companion_amd.product2vec import FusedAdam
+    cfg = SimpleNamespace(PRODUCT_EMB_DIM=128, TYPE_EMB_DIM=64, DROPOUT=dropout, MARGIN=1.0, ALPHA=0.8, NUM_COMP_TYPES=3,
+                          NUM_TYPES=types, DEVICE="cuda")
+    bpg = generate_scaled_bpg(3000, 40, seed=3)
+    B = 500                                                       # (not a multiple of the 16-sample tile)
+
+    def make():
+        torch.manual_seed(5)
+        m = PCompanion(cfg, bpg.cuda("cuda")["features"]).to("cuda").train()
+        m.type_transition._dropout_seed = 1234
+        return m, FusedAdam(m, lr=1e-2)
+
+    m_a, o_a = make()
+    m_b, o_b = make()
+    g_a = GraphedJointStep(m_a, o_a, B, warmup=1, mode="direct")
+    g_b = GraphedJointStep(m_b, o_b, B, warmup=1, mode="direct")
+    ld_a = ComplementaryIndexLoader(ComplementaryIndexDataset(bpg, "train"), B, shuffle=True, seed=9, device="cuda", out=g_a.static)
+    ld_b = ComplementaryIndexLoader(ComplementaryIndexDataset(bpg, "train"), B, shuffle=True, seed=9, device="cuda", out=g_b.static,
+                                    deferred=True)
+    steps = 0
+    for ba, bb in zip(ld_a, ld_b):
+        if ba["query_idx"].numel() != B:
+            continue
+        assert "_deferred" in bb and "_deferred" not in ba
+        la, ta = g_a(ba)
+        lb, tb = g_b(bb)
+        assert "_deferred" not in bb
+        assert torch.equal(ta, tb) and torch.equal(la, lb), (steps, la, lb)
+        for k in ("query_idx", "query_types", "positive_types", "negative_types", "positive_items", "negative_items"):
+            assert torch.equal(g_a.static[k], g_b.static[k]), (steps, k)
+        steps += 1
+        if steps == 5:
+            break
+    assert steps == 5 and g_b.prepared.calls == 4
+    for (k, pa), (_, pb) in zip(m_a.named_parameters(), m_b.named_parameters()):
+        assert torch.equal(pa, pb), k
+    # a deferred batch handed to anything else is built on request
+    it = iter(ld_b)
+    nb = next(it)
+    assert "_deferred" in nb
+    ld_b.materialize(nb)
+    assert "_deferred" not in nb and bool((nb["query_types"] == bpg.cuda("cuda")["type_idx"][nb["query_idx"].long()]).all())
+
+
+@pytest.mark.parametrize("types,dropout", [(40, 0.1), (600, 0.0)])
+def test_run_epoch_equals_the_loop_over_the_loader(types, dropout):
+    """GraphedJointStep.run_epoch (pc_joint_train_epoch: train.py:36-57 as one foreign call, ragged last batch included)
+    against iterating the same loader and stepping batch by batch: per-step losses and the parameters after the epoch,
+    bit for bit (T <= 512) / to fp32 atomics' order (T = 600: the large-table path)."""
+    from types import SimpleNamespace
+    from p_companion_amd.data import ComplementaryIndexDataset, ComplementaryIndexLoader, generate_scaled_bpg
+    from p_companion_amd.p_companion import GraphedJointStep, PCompanion
+    from p_companion_amd.product2vec import FusedAdam
+    cfg = SimpleNamespace(PRODUCT_EMB_DIM=128, TYPE_EMB_DIM=64, DROPOUT=dropout, MARGIN=1.0, ALPHA=0.8, NUM_COMP_TYPES=3,
+                          NUM_TYPES=types, DEVICE="cuda")
+    bpg = generate_scaled_bpg(1500, 40, seed=3)
+    B = 448
+
+    def make(deferred):
+        torch.manual_seed(5)
+        m = PCompanion(cfg, bpg.cuda("cuda")["features"]).to("cuda").train()
+        m.type_transition._dropout_seed = 77
+        o = FusedAdam(m, lr=1e-2)
+        g = GraphedJointStep(m, o, B, warmup=0, mode="direct")
+        ld = ComplementaryIndexLoader(ComplementaryIndexDataset(bpg, "train"), B, shuffle=True, seed=2, device="cuda",
+                                      out=g.static, deferred=deferred)
+        return m, o, g, ld
+
+    m_a, o_a, g_a, ld_a = make(False)
+    m_b, o_b, g_b, ld_b = make(True)
+    n = len(ld_a.dataset)
+    ref = []
+    for batch in ld_a:                                            # the plain loop: full batches through the fixed buffers,
+        if batch["query_idx"].numel() == B:                       # the ragged last one through train_step
+            ref.append(g_a(batch)[0].clone())
+        else:
+            ref.append(m_a.train_step(batch, optimizer=o_a)[0].clone())
+    got = g_b.run_epoch(ld_b)
+    assert got.shape == (len(ref), 3) and len(ref) == (n + B - 1) // B and n % B != 0
+    exact = types <= 512
+    for i, r in enumerate(ref):
+        assert torch.equal(got[i], r) if exact else torch.allclose(got[i], r, rtol=1e-5, atol=1e-6), (i, got[i], r)
+    for (k, pa), (_, pb) in zip(m_a.named_parameters(), m_b.named_parameters()):
+        assert torch.equal(pa, pb) if exact else torch.allclose(pa, pb, rtol=1e-4, atol=1e-6), k
+    assert int(o_a.step_count) == int(o_b.step_count) == len(ref) and ld_a.step == ld_b.step == len(ref)
+    # a second epoch continues the counters (loader step, dropout offset, Adam step)
+    got2 = g_b.run_epoch(ld_b, drop_last=True)
+    assert got2.shape[0] == n // B and int(o_b.step_count) == len(ref) + n // B and torch.isfinite(got2).all()
+
+
 def test_train_model_dense_host_batches_prefetched(golden):
     """train_model (product2vec.py:113-170) over DENSE HOST batches in the reference's collate format: the loop
     prefetches batch i+1 to the device on a side stream while batch i trains (data.prefetch_to_device) and runs the
