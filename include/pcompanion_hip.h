@@ -104,6 +104,8 @@ typedef struct {
     float *bn_invstd; /* [nseg,H] 1/sqrt(biased var + 1e-5)                              */
     float *bn_scale;  /* [nseg,H] gamma*invstd                                           */
     float *bn_shift;  /* [nseg,H] beta - mean*gamma*invstd                               */
+    float *a1;        /* [R,H] tanh(BN(h0)), OPTIONAL (NULL: recomputed from h0 where needed): when given, the
+                       * forward writes it on the way (its Linear3 forms it anyway) and the backward's dW3 reads it */
 } pc_ffn_saved;
 
 /* P6: Product2Vec.get_initial_embedding, training mode (product2vec.py:31-46; ffn :14-21).

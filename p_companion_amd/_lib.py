@@ -40,7 +40,7 @@ class Segments(ctypes.Structure):
 
 
 class FfnSaved(ctypes.Structure):
-    _fields_ = [(n, ctypes.c_void_p) for n in ("h0", "a2", "bn_mean", "bn_invstd", "bn_scale", "bn_shift")]
+    _fields_ = [(n, ctypes.c_void_p) for n in ("h0", "a2", "bn_mean", "bn_invstd", "bn_scale", "bn_shift", "a1")]
 
 
 class AttnSaved(ctypes.Structure):

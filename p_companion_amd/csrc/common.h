@@ -291,6 +291,7 @@ struct NtArgs {
     int M, N, K;
     SegInfo seg;
     int prologue; const float* pscale; const float* pshift;     // [nseg][K]
+    float* pro_out; int ldpo;                                   // NT_PRO_BNTANH: the transformed A rows are also written here [M,K] (or null)
     int epilogue; const float* aux; int ldaux;
     const float* escale; const float* eshift;                    // [nseg][N]
     int stats; float* stat_sum; float* stat_aux;                 // [ntiles][N] each

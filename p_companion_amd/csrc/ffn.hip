@@ -319,6 +319,7 @@ int ffn_forward_part2(const pc_p2v_tensors* p, int rows, const pc_segments* seg,
 
     NtArgs g2 = nt_plain(sv->h0, PC_H, p->w3, PC_H, p->b3, sv->a2, PC_H, rows, PC_H, PC_H, si);
     g2.prologue = NT_PRO_BNTANH; g2.pscale = sv->bn_scale; g2.pshift = sv->bn_shift;
+    g2.pro_out = sv->a1; g2.ldpo = PC_H;               // A1 = tanh(BN(H0)) leaves the kernel that forms it anyway (dW3 reads it)
     g2.epilogue = NT_EPI_TANH;
     PC_TRY(launch_gemm_nt(g2, st));
 
@@ -397,10 +398,11 @@ int ffn_backward_part1(const pc_p2v_tensors* p, const pc_p2v_tensors* g, const f
     b2.stats = NT_STAT_BNBWD; b2.stat_sum = w.stat_a; b2.stat_aux = w.stat_b;
     PC_TRY(launch_gemm_nt(b2, st));
 
-    // dW3 = dZ2^T A1 (A1 recomputed from H0 in the loader), db3
+    // dW3 = dZ2^T A1, db3 (A1 as the forward saved it; without the optional buffer it is recomputed from H0 in the loader:
+    // the in-place tanh(BN(.)) on every landed stage made this the longest kernel of the step, 123 us)
     TnArgs t3 = {};
-    t3.Z = w.dz2; t3.ldz = PC_H; t3.A = sv->h0; t3.lda = PC_H; t3.R = rows; t3.No = PC_H; t3.Ni = PC_H; t3.seg = si;
-    t3.prologue = NT_PRO_BNTANH; t3.pscale = sv->bn_scale; t3.pshift = sv->bn_shift;
+    t3.Z = w.dz2; t3.ldz = PC_H; t3.A = sv->a1 ? sv->a1 : sv->h0; t3.lda = PC_H; t3.R = rows; t3.No = PC_H; t3.Ni = PC_H; t3.seg = si;
+    if (!sv->a1) { t3.prologue = NT_PRO_BNTANH; t3.pscale = sv->bn_scale; t3.pshift = sv->bn_shift; }
     t3.dW = g->w3; t3.lddw = PC_H; t3.db = g->b3; t3.accumulate = accumulate; t3.slabs = w.slabs;
     t3.slab_floats = w.slab_floats;
     PC_TRY(launch_gemm_tn(t3, st));

@@ -58,6 +58,16 @@ __device__ __forceinline__ void store_stream(float* p, const float4& v) {
     typedef float v4f __attribute__((ext_vector_type(4)));
     __builtin_nontemporal_store(v4f{v.x, v.y, v.z, v.w}, reinterpret_cast<v4f*>(p));
 }
+// The same store from inline asm (no compiler-placed wait around it).  Loads and stores do NOT retire in order with respect
+// to each other on this hardware: "DMA, store, s_waitcnt vmcnt(1)" let a K-step end with its DMA still in flight (run-to-run
+// different results, measured).  The rows a K-step transforms are therefore stored at the TOP of the next K-step, ahead of
+// its DMA: the step's closing vmcnt(0) then waits for a store that has had a whole K-step to complete.
+__device__ __attribute__((aligned(16))) float pc_store_sink[4];
+__device__ __forceinline__ void store_stream_asm(float* p, const float4& v) {
+    typedef float v4f __attribute__((ext_vector_type(4)));
+    const v4f x = {v.x, v.y, v.z, v.w};
+    asm volatile("global_store_dwordx4 %0, %1, off nt" ::"v"(p), "v"(x) : "memory");
+}
 __device__ __forceinline__ float4 load_stream(const float* p) {
     typedef float v4f __attribute__((ext_vector_type(4)));
     const v4f v = __builtin_nontemporal_load(reinterpret_cast<const v4f*>(p));
@@ -218,12 +228,15 @@ __global__ __launch_bounds__(64 * NWM * NWN, WPS) void gemm_nt_kernel(NtArgs a, 
         }
     };
 
+    float* pend_p = pc_store_sink;                   // pro_out: the chunk transformed in the previous K-step, not yet stored
+    float4 pend_v = make_float4(0.f, 0.f, 0.f, 0.f);
     // BN-apply + tanh on the A image of a landed stage, in place (one 16-B chunk per thread)
     auto transform = [&](float* cur, int k0, int sg) {
         const int row = tid / CPR, slot = tid % CPR;
         const int k = k0 + ((slot ^ ((row / RB) % CPR)) << 2);
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
         if (k < a.K) {
-            float4 v = *reinterpret_cast<const float4*>(&cur[tid * 4]);
+            v = *reinterpret_cast<const float4*>(&cur[tid * 4]);
             const float4 s = *reinterpret_cast<const float4*>(&pro_ss[(2 * sg) * 256 + k]);
             const float4 h = *reinterpret_cast<const float4*>(&pro_ss[(2 * sg + 1) * 256 + k]);
             v.x = fast_tanh(v.x * s.x + h.x);
@@ -231,6 +244,11 @@ __global__ __launch_bounds__(64 * NWM * NWN, WPS) void gemm_nt_kernel(NtArgs a, 
             v.z = fast_tanh(v.z * s.z + h.z);
             v.w = fast_tanh(v.w * s.w + h.w);
             *reinterpret_cast<float4*>(&cur[tid * 4]) = v;
+        }
+        if (a.pro_out) {                               // (wave-uniform) the transformed rows, for the weight gradient that follows
+            const bool live = k < a.K && row0 + row < row_end;
+            pend_p = live ? a.pro_out + (size_t)(row0 + row) * a.ldpo + k : pc_store_sink;
+            pend_v = v;
         }
     };
 
@@ -266,6 +284,7 @@ __global__ __launch_bounds__(64 * NWM * NWN, WPS) void gemm_nt_kernel(NtArgs a, 
         // one K-step: start the DMA of the following chunk (this tile's, or the next tile's first),
         // then multiply the landed one
         for (int kt = 0; kt < nk; kt++) {
+            if (PRO && a.pro_out && kt > 0) store_stream_asm(pend_p, pend_v);
             if (kt + 1 < nk) issue(cur ^ 1, (kt + 1) * BK);
             else if (ntile < total_tiles) { make_ptrs(nsrow, nn0); issue(cur ^ 1, 0); }
             float* cs = stages + cur * STAGE;
@@ -274,6 +293,7 @@ __global__ __launch_bounds__(64 * NWM * NWN, WPS) void gemm_nt_kernel(NtArgs a, 
             stage_sync();
             cur ^= 1;
         }
+        if (PRO && a.pro_out) store_stream_asm(pend_p, pend_v);       // the last K-step's rows
 
 #ifdef PC_NT_TIMING
         const unsigned long long t1 = __builtin_amdgcn_s_memtime();

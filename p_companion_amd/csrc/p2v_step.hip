@@ -9,7 +9,7 @@ static inline size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
 
 struct StepWs {
     int32_t* idx_all;
-    float *y, *h0, *a2, *bn;     // bn: mean, invstd, scale, shift  [4][MAX_SEG][H]
+    float *y, *h0, *a2, *a1, *bn;     // bn: mean, invstd, scale, shift  [4][MAX_SEG][H]
     float *q, *kv, *probs, *ctx, *emb;
     float *dy, *demb, *dpos_tmp, *dneg_tmp;
     void* ffn_ws; size_t ffn_bytes;
@@ -30,6 +30,7 @@ static StepWs step_ws_layout(void* base, int B, int N, int K, int D) {
     w.y = (float*)take(R * D * 4);
     w.h0 = (float*)take(R * PC_H * 4);
     w.a2 = (float*)take(R * PC_H * 4);
+    w.a1 = (float*)take(R * PC_H * 4);
     w.bn = (float*)take(4 * PC_MAX_SEG * PC_H * 4);
     w.q = (float*)take((size_t)B * D * 4);
     w.kv = (float*)take((size_t)B * (N > 0 ? N : 1) * 2 * D * 4);
@@ -130,7 +131,7 @@ static int p2v_step_impl(const pc_p2v_tensors* p, const pc_p2v_tensors* g, const
     }
 
     pc_ffn_saved sv;
-    sv.h0 = w.h0; sv.a2 = w.a2;
+    sv.h0 = w.h0; sv.a2 = w.a2; sv.a1 = w.a1;
     sv.bn_mean = w.bn; sv.bn_invstd = w.bn + PC_MAX_SEG * PC_H; sv.bn_scale = w.bn + 2 * PC_MAX_SEG * PC_H;
     sv.bn_shift = w.bn + 3 * PC_MAX_SEG * PC_H;
     if (p0) {

@@ -142,6 +142,7 @@ def ffn_forward_train(params, table, idx, rows, seg_starts, update_running=True)
     y = torch.empty(rows, st.dim, dtype=torch.float32, device=dev)
     sv = {"h0": torch.empty(rows, H, dtype=torch.float32, device=dev),
           "a2": torch.empty(rows, H, dtype=torch.float32, device=dev),
+          "a1": torch.empty(rows, H, dtype=torch.float32, device=dev),      # tanh(BN(h0)): written by Linear3's kernel, read by dW3
           "bn": torch.empty(4, PC_MAX_SEG, H, dtype=torch.float32, device=dev),
           "seg_starts": list(seg_starts), "rows": rows}
     nbytes = _lib.lib().pc_p2v_ffn_workspace_bytes(rows)
@@ -155,6 +156,7 @@ def ffn_forward_train(params, table, idx, rows, seg_starts, update_running=True)
 def _ffn_saved(sv):
     s = FfnSaved()
     s.h0, s.a2 = sv["h0"].data_ptr(), sv["a2"].data_ptr()
+    s.a1 = sv["a1"].data_ptr() if sv.get("a1") is not None else None
     bn = sv["bn"]
     s.bn_mean, s.bn_invstd, s.bn_scale, s.bn_shift = (bn[i].data_ptr() for i in range(4))
     return s

@@ -70,11 +70,24 @@ def train(config, train_loader, val_loader, pretrained_embeddings, fused=True):
     for ld in (train_loader, val_loader):
         _check_ranges(config, ld, model)
     best_hit10 = 0.0
+    # the index loader of this package on the GPU: train.py:36-57's loop over an epoch runs as ONE foreign call
+    # (GraphedJointStep.run_epoch -> pc_joint_train_epoch; same steps, same values as the loop below)
+    epoch_runner = None
+    if fused and isinstance(train_loader, ComplementaryIndexLoader) and torch.device(config.DEVICE).type == "cuda" and \
+            train_loader.out is None and len(train_loader.dataset) >= train_loader.batch_size:
+        from .p_companion import GraphedJointStep
+        step = GraphedJointStep(model, optimizer, train_loader.batch_size, warmup=0, mode="auto")
+        if step.mode == "direct":
+            train_loader.out, train_loader._prepared = step.static, None
+            epoch_runner = step
     for epoch in range(config.NUM_EPOCHS):
         model.train()
         total = None
         nb = 0
-        for batch in train_loader:
+        if epoch_runner is not None:
+            per_step = epoch_runner.run_epoch(train_loader)
+            total, nb = per_step[:, 0].sum().reshape(1), int(per_step.shape[0])
+        for batch in (train_loader if epoch_runner is None else ()):
             batch = {k: v.to(config.DEVICE) if isinstance(v, torch.Tensor) else v for k, v in batch.items()}
             if fused:
                 losses, _ = model.train_step(batch, optimizer=optimizer)      # Adam applied by the step's last kernel
