@@ -48,10 +48,11 @@ def flops_per_triplet(n):
 def nt_algorithmic_bytes(b, nbc):
     """Compulsory HBM bytes of the 7 persistent gemm_nt_kernel launches of one step:
     rows R = [anchor B | neighbour rows nbc | positive B | negatives 5B]; per row Linear0 0.5+1 KB (gathered
-    x -> H0), Linear3 1+1 (H0 -> A2), Linear5 1+0.5 (A2 -> Y), dZ2 0.5+1+1 (dY, A2 -> dZ2), dZ1 1+1+1
-    (dZ2, H0 -> dZ1); per neighbour row K|V projection 0.5+1 and dKeys 1+0.5.  Weights are L2-resident."""
+    x -> H0), Linear3 1+1+1 (H0 -> A2, and A1 = tanh(BN(H0)) saved for dW3), Linear5 1+0.5 (A2 -> Y), dZ2 0.5+1+1
+    (dY, A2 -> dZ2), dZ1 1+1+1 (dZ2, H0 -> dZ1); per neighbour row K|V projection 0.5+1 and dKeys 1+0.5.  Weights are
+    L2-resident."""
     r = 7 * b + nbc
-    return 1024 * (r * (1.5 + 2.0 + 1.5 + 2.5 + 3.0) + nbc * (1.5 + 1.5))
+    return 1024 * (r * (1.5 + 3.0 + 1.5 + 2.5 + 3.0) + nbc * (1.5 + 1.5))
 
 
 def executed_flops_per_step(b, nbc):
