@@ -194,9 +194,16 @@ def run_joint(args, rank, world, dev, types, steps, warmup, want_cpu):
     graphed = None
     if world == 1 and not args.no_graph:
         graphed = GraphedJointStep(model, opt, args.batch, mode="auto" if args.joint_launch == "epoch" else args.joint_launch)
+    elif not args.no_graph:
+        # one process per GPU: the fused step writes gradients only, the flat gradient buffer is averaged over the replicas
+        # (one all-reduce of 29 k weights + both type tables), then the Adam launch
+        try:
+            graphed = GraphedJointStep(model, opt, args.batch, mode="direct", grad_hook=lambda g: pdist.all_reduce_mean_(g, world))
+        except ValueError:
+            graphed = None
     # 'epoch': train.py:36-57's loop over the epoch's batches as one foreign call (pc_joint_train_epoch) -- the same steps,
     # enqueued from C back to back; falls back to one call per step where the fused step does not serve the configuration
-    by_epoch = graphed is not None and args.joint_launch == "epoch" and graphed.mode == "direct"
+    by_epoch = world == 1 and graphed is not None and args.joint_launch == "epoch" and graphed.mode == "direct"
     # direct mode: the loader hands its batches over unbuilt and the step's first kernel builds them (same values)
     loader = ComplementaryIndexLoader(ComplementaryIndexDataset(bpg, "train"), args.batch, shuffle=True, seed=rank,
                                       device=dev, out=graphed.static if graphed else None,
@@ -264,7 +271,8 @@ def run_joint(args, rank, world, dev, types, steps, warmup, want_cpu):
                                   f"batch={args.batch}/GPU, K=3 (loader batch construction included)",
                       "global_batch": world * args.batch, "parallelism": f"dp{world}", "final_loss": round(float(losses[0]), 5),
                       "launch": ("pc_joint_train_epoch: the epoch's steps enqueued by one foreign call" if by_epoch else
-                                 {"direct": "fused step, arguments resolved once (one foreign call per step)",
+                                 {"direct": "fused step, arguments resolved once (one foreign call per step)" +
+                                            ("; gradients only, then all-reduce of the flat gradient buffer and the Adam launch" if world > 1 else ""),
                                   "graph": "hipGraph replay"}[graphed.mode] if graphed is not None else "eager module calls"),
                       "kernels_per_step": ("2 (tile kernel: batch construction, forward, losses, backward and the tile's gradient slab; finish: slab "
                                             "sums + Adam)" if types <= 128 else

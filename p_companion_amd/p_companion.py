@@ -306,10 +306,11 @@ class GraphedJointStep:
         queue filled, so for 3-12 kernels the direct form is the faster one;
       mode 'graph': the launch sequence recorded once as a HIP graph and replayed (the launch-per-op sequence of
         pc_joint_train_step + pc_adam_step is ~25 launches: there the replay wins).
-    Single process only (a gradient all-reduce between backward and Adam would have to be inside): the data-parallel
-    loop calls train_step / all_reduce / optimizer.step."""
+    Data-parallel replicas pass `grad_hook` (e.g. lambda g: distributed.all_reduce_mean_(g, world)): mode 'direct' then
+    runs the fused step WITHOUT its Adam (gradients only), calls grad_hook(flat gradient buffer) and optimizer.step();
+    'graph' and run_epoch are single-process forms (a collective would have to sit inside the captured sequence)."""
 
-    def __init__(self, model, optimizer, batch_size, warmup=3, mode="auto"):
+    def __init__(self, model, optimizer, batch_size, warmup=3, mode="auto", grad_hook=None):
         from .product2vec import FusedAdam
         if not isinstance(optimizer, FusedAdam):
             raise TypeError("GraphedJointStep drives pc_adam_step / the fused step's Adam: pass a FusedAdam")
@@ -331,6 +332,9 @@ class GraphedJointStep:
         if mode == "direct" and not fused_ok:
             raise ValueError("mode 'direct' needs a configuration pc_joint_fused_step serves")
         self.mode = ("direct" if fused_ok else "graph") if mode == "auto" else mode
+        self.grad_hook = grad_hook
+        if grad_hook is not None and self.mode != "direct":
+            raise ValueError("grad_hook needs mode 'direct' (a configuration pc_joint_fused_step serves)")
         self.graph = self.prepared = None
         self._eager_steps = 0
         self.losses = self.complementary_types = None
@@ -343,6 +347,11 @@ class GraphedJointStep:
                 dst.copy_(src.reshape(dst.shape), non_blocking=True)
 
     def _eager(self):
+        if self.grad_hook is not None:
+            self.losses, self.complementary_types = self.model.train_step(self.static)
+            self.grad_hook(self.model.flatten_parameters()[1])
+            self.optimizer.step()
+            return
         self.losses, self.complementary_types = self.model.train_step(self.static, optimizer=self.optimizer)
 
     def _prepare(self):
@@ -360,7 +369,9 @@ class GraphedJointStep:
                 tt._next_dropout()
             drop = (p, tt._dropout_seed)
         self.prepared = ops.PreparedJointStep(params, grads, self.static, int(m.config.NUM_COMP_TYPES), float(m.config.MARGIN),
-                                              float(m.config.ALPHA), bad=bad, adam=self.optimizer.fused_state(), dropout=drop)
+                                              float(m.config.ALPHA), bad=bad, dropout=drop,
+                                              adam=self.optimizer.fused_state() if self.grad_hook is None else None)
+        self._gflat = m.flatten_parameters()[1]
 
     def __call__(self, batch=None):
         deferred = None
@@ -385,6 +396,9 @@ class GraphedJointStep:
                 self.losses, self.complementary_types = self.prepared.from_pairs(rows_dev, loader._source, step, off)
             else:
                 self.losses, self.complementary_types = self.prepared(off)
+            if self.grad_hook is not None:                 # data-parallel: gradients only above; average, then Adam
+                self.grad_hook(self._gflat)
+                self.optimizer.step()
             return self.losses, self.complementary_types
         if self.graph is None:
             if self._eager_steps < self.warmup:
@@ -410,8 +424,8 @@ def _graphed_run_epoch(self, loader, drop_last=False, max_steps=None):
     foreign call (pc_joint_train_epoch): the host enqueues every step's launches back to back, nothing is read back per
     step.  Returns the per-step losses [steps, 3] = (loss, type, item) on the device; `.mean(0)` is the epoch's average
     (train.py:50-57).  Same values, bit for bit, as iterating the loader and calling self(batch)."""
-    if self.mode != "direct":
-        raise ValueError("run_epoch needs mode 'direct' (a configuration pc_joint_fused_step serves)")
+    if self.mode != "direct" or self.grad_hook is not None:
+        raise ValueError("run_epoch needs mode 'direct' without a grad_hook (single process; a configuration pc_joint_fused_step serves)")
     if not self.model.training:
         raise RuntimeError("GraphedJointStep: the model left training mode")
     if loader.batch_size != self.batch_size or loader.out is None or \

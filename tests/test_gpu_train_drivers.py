@@ -299,6 +299,46 @@ def test_run_epoch_equals_the_loop_over_the_loader(types, dropout):
     assert got2.shape[0] == n // B and int(o_b.step_count) == len(ref) + n // B and torch.isfinite(got2).all()
 
 
+def test_graphed_joint_step_with_grad_hook_equals_fused_adam():
+    """The data-parallel form (fused step without its Adam -> grad_hook(flat gradients) -> optimizer.step()) with an identity
+    hook against the single-process form (Adam inside the finish kernel): same bits (pc_adam_update is one definition)."""
+    from types import SimpleNamespace
+    from p_companion_amd.data import ComplementaryIndexDataset, ComplementaryIndexLoader, generate_scaled_bpg
+    from p_companion_amd.p_companion import GraphedJointStep, PCompanion
+    from p_companion_amd.product2vec import FusedAdam
+    cfg = SimpleNamespace(PRODUCT_EMB_DIM=128, TYPE_EMB_DIM=64, DROPOUT=0.0, MARGIN=1.0, ALPHA=0.8, NUM_COMP_TYPES=3,
+                          NUM_TYPES=40, DEVICE="cuda")
+    bpg = generate_scaled_bpg(2000, 40, seed=3)
+    B, seen = 256, []
+
+    def make(hook):
+        torch.manual_seed(5)
+        m = PCompanion(cfg, bpg.cuda("cuda")["features"]).to("cuda").train()
+        o = FusedAdam(m, lr=1e-2)
+        g = GraphedJointStep(m, o, B, warmup=1, mode="direct", grad_hook=hook)
+        ld = ComplementaryIndexLoader(ComplementaryIndexDataset(bpg, "train"), B, shuffle=True, seed=4, device="cuda",
+                                      out=g.static, deferred=True)
+        return m, o, g, ld
+
+    m_a, o_a, g_a, ld_a = make(None)
+    m_b, o_b, g_b, ld_b = make(lambda gflat: seen.append(gflat.numel()))
+    n = 0
+    for ba, bb in zip(ld_a, ld_b):
+        if ba["query_idx"].numel() != B:
+            continue
+        la, _ = g_a(ba)
+        lb, _ = g_b(bb)
+        assert torch.equal(la, lb), (n, la, lb)
+        n += 1
+        if n == 5:
+            break
+    assert len(seen) == 5 and int(o_a.step_count) == int(o_b.step_count) == 5
+    for (k, pa), (_, pb) in zip(m_a.named_parameters(), m_b.named_parameters()):
+        assert torch.equal(pa, pb), k
+    with pytest.raises(ValueError):
+        g_b.run_epoch(ld_b)
+
+
 def test_train_model_dense_host_batches_prefetched(golden):
     """train_model (product2vec.py:113-170) over DENSE HOST batches in the reference's collate format: the loop
     prefetches batch i+1 to the device on a side stream while batch i trains (data.prefetch_to_device) and runs the
