@@ -78,9 +78,12 @@ if fe:
     n = sum(v["launches"] for v in nt)
     print("gemm_nt HBM bytes/launch:", round(sum((v["fetch_bytes_corrected"] + v["write_bytes"]) * v["launches"] for v in nt) / n))
 
-# ---- PMC passes of the joint phase (eager launches): per kernel, and summed over one step (`_step_total`)
-fe, wr_ = pmc("pmc_joint_fetch", "FETCH_SIZE"), pmc("pmc_joint_write", "WRITE_SIZE")
-if fe:
+# ---- PMC passes of the joint phase: per kernel, and summed over one step (`_step_total`); the same for the run at the
+# reference's NUM_TYPES = 34800 (profiles/<tag>_joint34800_pmc_traffic.json, read by bench.py for that configuration)
+for dirs, out_name in ((("pmc_joint_fetch", "pmc_joint_write"), "joint"), (("pmc_joint34800_fetch", "pmc_joint34800_write"), "joint34800")):
+    fe, wr_ = pmc(dirs[0], "FETCH_SIZE"), pmc(dirs[1], "WRITE_SIZE")
+    if not fe:
+        continue
     res = {}
     for k, (n, v) in fe.items():
         w = wr_.get(k, [n, 0.0])
@@ -90,6 +93,6 @@ if fe:
     tot_f = sum(v["fetch_bytes_corrected"] * v["launches"] for v in res.values()) / steps
     tot_w = sum(v["write_bytes"] * v["launches"] for v in res.values()) / steps
     res["_step_total"] = {"launches": 1, "steps_counted": steps, "fetch_bytes_corrected": round(tot_f), "write_bytes": round(tot_w),
-                          "note": "all kernels of the process (batch builder, step, Adam) summed and divided by the steps run"}
-    json.dump(res, open(os.path.join(dst, f"{tag}_joint_pmc_traffic.json"), "w"), indent=1)
-    print("joint HBM bytes/step:", round(tot_f + tot_w))
+                          "note": "all kernels of the process (batch construction, step, Adam) summed and divided by the steps run"}
+    json.dump(res, open(os.path.join(dst, f"{tag}_{out_name}_pmc_traffic.json"), "w"), indent=1)
+    print(out_name, "HBM bytes/step:", round(tot_f + tot_w))

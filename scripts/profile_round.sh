@@ -22,5 +22,7 @@ rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -- python3 $R/b
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -- python3 $R/bench.py --phase p2v --steps 5 --warmup 2 --no-cpu-baseline > /dev/null 2> $OUT/pmc_write.err
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_joint_fetch -- python3 $R/bench.py --phase joint --steps 5 --warmup 2 --no-cpu-baseline --no-ref-types > /dev/null 2> $OUT/pmc_joint_fetch.err
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_joint_write -- python3 $R/bench.py --phase joint --steps 5 --warmup 2 --no-cpu-baseline --no-ref-types > /dev/null 2> $OUT/pmc_joint_write.err
+rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_joint34800_fetch -- python3 $R/bench.py --phase joint --types 34800 --steps 5 --warmup 2 --no-cpu-baseline --no-ref-types > /dev/null 2> $OUT/pmc_joint34800_fetch.err
+rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_joint34800_write -- python3 $R/bench.py --phase joint --types 34800 --steps 5 --warmup 2 --no-cpu-baseline --no-ref-types > /dev/null 2> $OUT/pmc_joint34800_write.err
 fi
 if [ -z "$NO_BENCH" ]; then cat $OUT/bench.json; fi
