@@ -28,6 +28,7 @@
 #define FK 4          /* top-K capacity of the fused kernel (NUM_COMP_TYPES = 3, config.py:24) */
 #define TS 16         /* samples per tile */
 #define T_SMALL 512   /* largest table the per-tile similarity row (LDS) and the one-hot gradients serve */
+#define T_WGRAD 128   /* largest table whose one-hot gradient blocks (8 per wave and table) the tile kernel carries itself */
 
 typedef float f32x4v __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ f32x4v mfma16(float a, float b, f32x4v c) {
@@ -279,6 +280,27 @@ __global__ __launch_bounds__(256) void joint_tile_kernel(FusedArgs a, int ldsims
     PC_STAMP(0);
     if (blockIdx.x == 0 && tid == 0 && a.step_count) *a.step_count += 1;     // Adam's step (read by the finish kernel)
 
+    // ---- every weight fragment this wave will multiply by, requested now (see load_b)
+    BFrag<4> f_h = {}, f_dh = {}, f_s0 = {}, f_s1 = {};
+    BFrag<8> f_pa = {}, f_pb = {};
+    if (w < 2) { f_h = load_b<PC_L, false>(a.enc_w, PC_L, 16 * w, LH, lane); f_dh = load_b<PC_L, true>(a.dec_w, LH, 16 * w, LH, lane); }
+    else { f_pa = load_b<PC_D, false>(a.itm_w, PC_D, 32 * (w - 2), PC_D, lane); f_pb = load_b<PC_D, false>(a.itm_w, PC_D, 32 * (w - 2) + 16, PC_D, lane); }
+    const BFrag<8> f_pc = load_b<PC_D, false>(a.itm_w, PC_D, 16 * (4 + w), PC_D, lane);
+    const BFrag<2> f_c = load_b<LH, false>(a.dec_w, LH, 16 * w, PC_L, lane);
+    const BFrag<4> f_t0 = load_b<PC_L, false>(a.typ_w, PC_L, 16 * w, PC_D, lane);
+    const BFrag<4> f_t1 = load_b<PC_L, false>(a.typ_w, PC_L, 16 * (w + 4), PC_D, lane);
+    const BFrag<8> f_dce = load_b<PC_D, true>(a.typ_w, PC_L, 16 * w, PC_L, lane);
+    const BFrag<2> f_dt = load_b<LH, true>(a.enc_w, PC_L, 16 * w, PC_L, lane);
+    if (SIMS_LOCAL) {                       // the first two of this wave's E_c column blocks (all of them for T <= 128)
+        f_s0 = load_b<PC_L, false>(a.ec, PC_L, 16 * w, a.T, lane);
+        f_s1 = load_b<PC_L, false>(a.ec, PC_L, 16 * (w + 4), a.T, lane);
+    }
+    const int ci = lane & 15, rh = lane >> 4;       // result column inside a block / row group
+    const float bias_h = w < 2 ? a.enc_b[16 * w + ci] : 0.f, bias_c = a.dec_b[16 * w + ci];
+    const float bias_pa = w >= 2 ? a.itm_b[32 * (w - 2) + ci] : 0.f, bias_pb = w >= 2 ? a.itm_b[32 * (w - 2) + 16 + ci] : 0.f;
+    const float bias_pc = a.itm_b[16 * (4 + w) + ci], bias_t0 = a.typ_b[16 * w + ci], bias_t1 = a.typ_b[16 * (w + 4) + ci];
+    // (the ids come AFTER the weight requests in program order: their two or three dependent round trips -- pairs -> type ids
+    // -> LDS -- then run beside the ~60 fragment loads of the same wave instead of ahead of them)
     // ---- indices of the tile: validated (the reference raises for an id outside its table, p_companion.py:48-54; here
     // the offence is counted and the id clamped so that nothing is read or written out of bounds)
     if (tid < TS) {
@@ -306,25 +328,6 @@ __global__ __launch_bounds__(256) void joint_tile_kernel(FusedArgs a, int ldsims
         ints[tid * 8 + 0] = qi; ints[tid * 8 + 1] = qt; ints[tid * 8 + 2] = pt; ints[tid * 8 + 3] = nt;
         if (PAIRS) { ints[tid * 8 + 4] = tg; ints[tid * 8 + 5] = lab; }      // (the top-K slots: free until phase D)
     }
-    // ---- every weight fragment this wave will multiply by, requested now (see load_b)
-    BFrag<4> f_h = {}, f_dh = {}, f_s0 = {}, f_s1 = {};
-    BFrag<8> f_pa = {}, f_pb = {};
-    if (w < 2) { f_h = load_b<PC_L, false>(a.enc_w, PC_L, 16 * w, LH, lane); f_dh = load_b<PC_L, true>(a.dec_w, LH, 16 * w, LH, lane); }
-    else { f_pa = load_b<PC_D, false>(a.itm_w, PC_D, 32 * (w - 2), PC_D, lane); f_pb = load_b<PC_D, false>(a.itm_w, PC_D, 32 * (w - 2) + 16, PC_D, lane); }
-    const BFrag<8> f_pc = load_b<PC_D, false>(a.itm_w, PC_D, 16 * (4 + w), PC_D, lane);
-    const BFrag<2> f_c = load_b<LH, false>(a.dec_w, LH, 16 * w, PC_L, lane);
-    const BFrag<4> f_t0 = load_b<PC_L, false>(a.typ_w, PC_L, 16 * w, PC_D, lane);
-    const BFrag<4> f_t1 = load_b<PC_L, false>(a.typ_w, PC_L, 16 * (w + 4), PC_D, lane);
-    const BFrag<8> f_dce = load_b<PC_D, true>(a.typ_w, PC_L, 16 * w, PC_L, lane);
-    const BFrag<2> f_dt = load_b<LH, true>(a.enc_w, PC_L, 16 * w, PC_L, lane);
-    if (SIMS_LOCAL) {                       // the first two of this wave's E_c column blocks (all of them for T <= 128)
-        f_s0 = load_b<PC_L, false>(a.ec, PC_L, 16 * w, a.T, lane);
-        f_s1 = load_b<PC_L, false>(a.ec, PC_L, 16 * (w + 4), a.T, lane);
-    }
-    const int ci = lane & 15, rh = lane >> 4;       // result column inside a block / row group
-    const float bias_h = w < 2 ? a.enc_b[16 * w + ci] : 0.f, bias_c = a.dec_b[16 * w + ci];
-    const float bias_pa = w >= 2 ? a.itm_b[32 * (w - 2) + ci] : 0.f, bias_pb = w >= 2 ? a.itm_b[32 * (w - 2) + 16 + ci] : 0.f;
-    const float bias_pc = a.itm_b[16 * (4 + w) + ci], bias_t0 = a.typ_b[16 * w + ci], bias_t1 = a.typ_b[16 * (w + 4) + ci];
     phase_sync();
     PC_STAMP(1);
     // ---- row gathers: t = E_q[qt] (16 x 64), q = E_prod[qi] (16 x 128); rows past the batch are zero.  Also the rows of
@@ -355,8 +358,9 @@ __global__ __launch_bounds__(256) void joint_tile_kernel(FusedArgs a, int ldsims
                 for (int u = 0; u < 2; u++) {
                     const float4 f = *reinterpret_cast<const float4*>(a.features + (size_t)tg * PC_D + 64 * u + 4 * l16);
                     const float4 fill = pc_filler_chunk(a.bseed, a.bstep, (uint32_t)(bb * (PC_D / 4) + 16 * u + l16));
-                    r_pos[u] = pos ? f : fill;
-                    r_neg[u] = pos ? fill : f;
+                    // (component-wise selects: `pos ? f : fill` on the structs becomes an indexed stack array)
+                    r_pos[u] = make_float4(pos ? f.x : fill.x, pos ? f.y : fill.y, pos ? f.z : fill.z, pos ? f.w : fill.w);
+                    r_neg[u] = make_float4(pos ? fill.x : f.x, pos ? fill.y : f.y, pos ? fill.z : f.z, pos ? fill.w : f.w);
                     if (liveF) {
                         *reinterpret_cast<float4*>(a.o_pos + bb * PC_D + 64 * u + 4 * l16) = r_pos[u];
                         *reinterpret_cast<float4*>(a.o_neg + bb * PC_D + 64 * u + 4 * l16) = r_neg[u];
@@ -723,7 +727,8 @@ __global__ __launch_bounds__(256) void joint_tile_kernel(FusedArgs a, int ldsims
             // table gradients, transposed, as one-hot products: C[j][t] = sum_r src[r][j] [idx[r] == t]; wave w owns the
             // dims block w, all (<= 8) type blocks.  E_c: 16 (K + 2) source rows; E_q: the 16 d(t) rows.
             // (all 8 blocks unconditionally: a run-time block count turns every MFMA into its own branch target and the
-            // accumulators into copies between them -- 60 us instead of 3, measured)
+            // accumulators into copies between them -- 60 us instead of 3, measured.  Also measured: the two slabs built in
+            // LDS by row-wise ds_add_f32, one wave per type, and copied out -- 10.8 us against 5.4 for these 188 MFMAs.)
             f32x4v c[8];
 #pragma unroll
             for (int n = 0; n < 8; n++) c[n] = f32x4v{0.f, 0.f, 0.f, 0.f};
@@ -762,7 +767,6 @@ __global__ __launch_bounds__(256) void joint_tile_kernel(FusedArgs a, int ldsims
     }
 }
 
-#define T_WGRAD 128   /* largest table whose one-hot gradient blocks (8 per wave and table) the tile kernel carries itself */
 static size_t tile_lds_bytes(int T, bool sims_local, bool tables) {
     const int ldsims = sims_local ? ((T + 15) / 16 * 16 + 4) : 0;
     const size_t floats = (size_t)TS * LD64 + TS * LD32 + TS * LD64 + 2 * TS * LD128 + (size_t)TS * FK * LD64 +
