@@ -223,35 +223,71 @@ class SimilarityIndexLoader:
         n = self.bpg.similarity_pairs.shape[0]
         return n // self.batch_size if self.drop_last else (n + self.batch_size - 1) // self.batch_size
 
+    def _epoch_plan(self, S):
+        """Throughput mode: this epoch's order of the similarity pairs, drawn ON THE DEVICE (deterministic in (seed, epoch)),
+        and per batch the padded neighbour count and the number of real neighbour slots -- the two integers the host needs
+        to size a batch.  The plan of epoch e + 1 is launched on a side stream when epoch e starts, so that neither the
+        draw (4 ms on the host at 275 k pairs: four steps' worth, with the host only one batch ahead of the device) nor its
+        read-back is ever waited for.  Returns (perm [S] int32 on the device, plan [n_batches, 2] int64 on the host)."""
+        dev = torch.device(self.device)
+        n, B = len(self), self.batch_size
+
+        def launch(epoch):
+            g = torch.Generator(device=dev)
+            g.manual_seed(int(self.seed) * 1000003 + epoch)
+            order = torch.randperm(S, device=dev, generator=g) if self.shuffle else torch.arange(S, device=dev)
+            d = self._deg_dev[order]
+            d = d[:n * B] if n * B <= S else torch.nn.functional.pad(d, (0, n * B - S))
+            d = d.view(n, B)
+            st = torch.stack([d.max(1).values, d.sum(1)], 1)
+            return order.to(torch.int32), st
+
+        if getattr(self, "_deg_dev", None) is None:
+            self._deg_dev = torch.from_numpy(np.ascontiguousarray(self._deg, np.int64)).to(dev)
+        if dev.type != "cuda":
+            perm, st = launch(self.epoch)
+            return perm, st
+        if getattr(self, "_plan_stream", None) is None:
+            self._plan_stream = torch.cuda.Stream(dev)
+        cur = torch.cuda.current_stream(dev)
+
+        def prefetch(epoch):
+            self._plan_stream.wait_stream(cur)                   # (_deg_dev and the allocator's blocks come from there)
+            with torch.cuda.stream(self._plan_stream):
+                perm, st = launch(epoch)
+                # two persistent pinned buffers, alternating (a fresh pinned allocation per epoch is a slow driver call)
+                bufs = getattr(self, "_plan_host", None)
+                if bufs is None or bufs[0].shape[0] != n:
+                    bufs = self._plan_host = [torch.empty(n, 2, dtype=torch.int64).pin_memory() for _ in range(2)]
+                host = bufs[epoch & 1]
+                host.copy_(st, non_blocking=True)
+                ev = torch.cuda.Event()
+                ev.record(self._plan_stream)
+            return epoch, S, perm, host, ev
+
+        nxt = getattr(self, "_next_plan", None)
+        if nxt is None or nxt[0] != self.epoch or nxt[1] != S:
+            nxt = prefetch(self.epoch)
+        _, _, perm, host, ev = nxt
+        ev.synchronize()
+        cur.wait_event(ev)
+        perm.record_stream(cur)
+        if getattr(self, "_side", None) is not None:
+            perm.record_stream(self._side)
+        self._next_plan = prefetch(self.epoch + 1)
+        return perm, host
+
     def __iter__(self):
         S = self.bpg.similarity_pairs.shape[0]
         if self.sampler == "cpython":
             perm = self.rng.shuffle(S) if self.shuffle else np.arange(S, dtype=np.int64)
         else:
-            # the next epoch's permutation (a few ms of host work at 275 k pairs: several steps' worth, and the host runs
-            # only one batch ahead of the device) is drawn by a host thread while this epoch trains (torch.randperm
-            # releases the GIL)
-            import threading
-
-            def draw(epoch):
-                if not self.shuffle:
-                    return np.arange(S, dtype=np.int64)
-                g = torch.Generator()
-                g.manual_seed(int(self.seed) * 1000003 + epoch)
-                return torch.randperm(S, generator=g).numpy()
-
-            nxt = getattr(self, "_next_perm", None)
-            if nxt is not None and nxt[0] == self.epoch and nxt[3] == S:
-                nxt[1].join()
-                perm = nxt[2][0]
-            else:
-                perm = draw(self.epoch)
-            box, e = [None], self.epoch + 1
-            th = threading.Thread(target=lambda: box.__setitem__(0, draw(e)), daemon=True)
-            th.start()
-            self._next_perm = (e, th, box, S)
-        perm_host = torch.from_numpy(perm.astype(np.int32))
-        if torch.device(self.device).type == "cuda":
+            perm = None                                   # (philox: the order lives on the device only)
+        plan = None
+        if perm is None:
+            perm_dev, plan = self._epoch_plan(S)
+        elif torch.device(self.device).type == "cuda":
+            perm_host = torch.from_numpy(perm.astype(np.int32))
             # persistent pinned buffer + non_blocking: a pageable H2D copy (or a fresh pinned allocation) makes the
             # host wait for all queued GPU work -- one pipeline bubble per epoch
             if getattr(self, "_perm_pinned", None) is None or self._perm_pinned.numel() != S:
@@ -260,15 +296,18 @@ class SimilarityIndexLoader:
             perm_dev = torch.empty(S, dtype=torch.int32, device=self.device)
             perm_dev.copy_(self._perm_pinned, non_blocking=True)
         else:
-            perm_dev = perm_host.to(self.device)
+            perm_dev = torch.from_numpy(perm.astype(np.int32)).to(self.device)
         self.epoch += 1
         def make(i):
             lo, hi = i * self.batch_size, min((i + 1) * self.batch_size, S)
-            ids = perm[lo:hi]
-            n_pad = int(self._deg[ids].max())           # collate_fn pads to the batch maximum
+            if plan is not None:
+                n_pad, n_real_plan = int(plan[i, 0]), int(plan[i, 1])
+            else:
+                ids = perm[lo:hi]
+                n_pad = int(self._deg[ids].max())           # collate_fn pads to the batch maximum
             nbc = None
             if self.sampler == "philox" and self.compact and n_pad > 0:
-                n_real = int(np.minimum(self._deg[ids], n_pad).sum())
+                n_real = n_real_plan if plan is not None else int(np.minimum(self._deg[ids], n_pad).sum())
                 if self.unique:
                     a, p, ng, nbc = self.ops.build_similarity_batch_unique(perm_dev[lo:hi], self.g, n_pad, self.k_neg,
                                                                            self.seed, self.step, n_real)
@@ -335,7 +374,10 @@ class SimilarityIndexLoader:
             batch, ev = nxt
             nxt = launch(i + 1) if i + 1 < n else None
             cur = torch.cuda.current_stream(self.device)
-            cur.wait_event(ev)
+            # the builder ran a step ago: normally its event has completed, and then nothing needs to be queued (a
+            # cross-stream wait costs the consuming stream a barrier packet, ~10-40 us in front of every step's first kernel)
+            if not ev.query():
+                cur.wait_event(ev)
             for v in batch.values():
                 for t in (v.values() if isinstance(v, dict) else [v]):
                     if torch.is_tensor(t):
