@@ -135,3 +135,47 @@ def test_recommend_oracle_matches_bruteforce():
         s = feats[cand] @ proj[r]
         best = cand[np.argsort(-s)[:3]]
         assert np.array_equal(ids, best) and np.allclose(sc, np.sort(s)[::-1][:3], atol=1e-5)
+
+
+def test_epoch_plans_are_permutations_deterministic_in_seed_and_epoch():
+    """Host logic of the two index loaders' epoch turnover (CPU device: same code, CPU generator).  SimilarityIndexLoader:
+    the order is a permutation of the pairs, the plan carries per batch the largest neighbour count and the number of real
+    slots, both are functions of (seed, epoch) only.  ComplementaryIndexLoader.epoch_pairs: a row permutation of the
+    dataset's labelled pairs, advancing the epoch counter."""
+    import torch
+    from p_companion_amd.data import ComplementaryIndexLoader, SimilarityIndexLoader
+    bpg = generate_scaled_bpg(600, 12, seed=4)
+    S = bpg.similarity_pairs.shape[0]
+    B = 64
+
+    def plan(seed, epoch, drop_last):
+        ld = SimilarityIndexLoader.__new__(SimilarityIndexLoader)           # (the constructor uploads the graph for the device sampler)
+        ld.bpg, ld.batch_size, ld.shuffle, ld.seed, ld.drop_last, ld.device, ld.epoch = bpg, B, True, seed, drop_last, "cpu", epoch
+        ld._deg = bpg.degree(bpg.similarity_pairs[:, 0])
+        return ld._epoch_plan(S)
+
+    for drop_last in (True, False):
+        perm, st = plan(3, 0, drop_last)
+        perm2, st2 = plan(3, 0, drop_last)
+        assert torch.equal(perm, perm2) and torch.equal(st, st2)
+        assert sorted(perm.tolist()) == list(range(S))
+        assert not torch.equal(perm, plan(3, 1, drop_last)[0]) and not torch.equal(perm, plan(4, 0, drop_last)[0])
+        deg = bpg.degree(bpg.similarity_pairs[:, 0])[perm.numpy()]
+        n = S // B if drop_last else (S + B - 1) // B
+        assert st.shape == (n, 2)
+        for i in range(n):
+            d = deg[i * B:(i + 1) * B]
+            assert int(st[i, 0]) == int(d.max()) and int(st[i, 1]) == int(d.sum())
+
+    ds = ComplementaryIndexDataset(bpg, "train")
+    ld = ComplementaryIndexLoader.__new__(ComplementaryIndexLoader)
+    ld.dataset, ld.batch_size, ld.shuffle, ld.seed, ld.device, ld.epoch = ds, B, True, 5, "cpu", 0
+    e0 = ld.epoch_pairs()
+    e1 = ld.epoch_pairs()
+    assert ld.epoch == 2 and e0.shape == (len(ds), 3) and e0.dtype == torch.int32 and not torch.equal(e0, e1)
+    as_rows = lambda t: sorted(map(tuple, t.tolist()))
+    assert as_rows(e0) == as_rows(e1) == sorted(map(tuple, np.asarray(ds.pairs, np.int32).tolist()))
+    ld.epoch = 0
+    assert torch.equal(ld.epoch_pairs(), e0)
+    ld.shuffle = False
+    assert torch.equal(ld.epoch_pairs(), torch.from_numpy(np.ascontiguousarray(ds.pairs, np.int32)))
