@@ -270,7 +270,7 @@ __global__ __launch_bounds__(256) void joint_tile_kernel(FusedArgs a, int ldsims
     float* Sims = reinterpret_cast<float*>(ints + TS * 8);    // [16][ldsims]   (SIMS_LOCAL only)
     float* ES = Sims + (SIMS_LOCAL ? TS * ldsims : 0);        // TABLES: [16 (K + 2)][LD64] dE_c source rows (row block k: the
                                                               // selected types' rows, K: -> pos type, K + 1: -> neg type)
-    float* DTs = ES + TS * (FK + 2) * LD64;                   // TABLES: [16][LD64] dE_q source rows
+    float* DTs = ES + TS * (FK + 2) * LD64;                   // TABLES: [16][LD64] dE_q source rows (then the destination ids, 16 (FK + 3) ints)
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -724,44 +724,85 @@ __global__ __launch_bounds__(256) void joint_tile_kernel(FusedArgs a, int ldsims
         }
         PC_STAMP(14);
         if (TABLES) {
-            // table gradients, transposed, as one-hot products: C[j][t] = sum_r src[r][j] [idx[r] == t]; wave w owns the
-            // dims block w, all (<= 8) type blocks.  E_c: 16 (K + 2) source rows; E_q: the 16 d(t) rows.
-            // (all 8 blocks unconditionally: a run-time block count turns every MFMA into its own branch target and the
-            // accumulators into copies between them -- 60 us instead of 3, measured.  Also measured: the two slabs built in
-            // LDS by row-wise ds_add_f32, one wave per type, and copied out -- 10.8 us against 5.4 for these 188 MFMAs.)
-            f32x4v c[8];
+            // table gradients, transposed, as one-hot products C[j][t] = sum_r src[r][j] [dst[r] == t] on the BF16 matrix
+            // cores, exactly: a source value is the sum of its three bf16 pieces (common.h split3), the one-hot operand is
+            // 0 / 1, so every product is exact and the fp32 accumulator adds pieces of source rows in the matrix unit's
+            // fixed order (bitwise reproducible).  One v_mfma_f32_32x32x16_bf16 covers 16 source rows -- one row block:
+            // 5 + 1 k steps of 3 MFMAs per 32 x 32 block instead of 24 steps of v_mfma_f32_16x16x4_f32 per 16 x 16 block
+            // (188 MFMAs per wave, 5.4 us -> 36 MFMAs).  Wave w: dims block w & 1, type blocks 2 (w >> 1), + 1 (T <= 128).
+            // [Also measured for this phase: a run-time block count with the fp32 blocks -- every MFMA its own branch target,
+            // 60 us; both slabs built in LDS by row-wise ds_add_f32, one wave per type, then copied out -- 10.8 us.]
+            int* dsts = reinterpret_cast<int*>(DTs + TS * LD64);      // destination type of source row R = 16 rb + s; E_q's after them
+            if (tid < TS * (FK + 2)) {
+                const int rb = tid >> 4, sd = tid & 15;
+                dsts[tid] = tid < TS * (K + 2) ? ints[sd * 8 + (rb < K ? 4 + rb : 2 + rb - K)] : -1;
+            } else if (tid < TS * (FK + 3)) {
+                dsts[tid] = ints[(tid - TS * (FK + 2)) * 8 + 1];
+            }
+            phase_sync();
+            const int fr = lane & 31, fh = lane >> 5, jb = w & 1, tb0 = 2 * (w >> 1);
+            typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+            // this lane's operand fragments of one k step: 8 consecutive source rows 8 fh .. + 7 of the row block
+            auto src_frag = [&](const float* rows) {
+                float v[8];
 #pragma unroll
-            for (int n = 0; n < 8; n++) c[n] = f32x4v{0.f, 0.f, 0.f, 0.f};
-#pragma unroll 1
-            for (int rb = 0; rb < K + 2; rb++) {
+                for (int q = 0; q < 8; q++) v[q] = rows[(8 * fh + q) * LD64 + 32 * jb + fr];
+                return split3(make_float4(v[0], v[1], v[2], v[3]), make_float4(v[4], v[5], v[6], v[7]));
+            };
+            auto onehot_frag = [&](const int* d, int t) {
+                const int4 lo = *reinterpret_cast<const int4*>(d + 8 * fh), hi = *reinterpret_cast<const int4*>(d + 8 * fh + 4);
+                u32x4 q;                                               // bf16 1.0 = 0x3f80; element 2i low half, 2i + 1 high half
+                q[0] = (lo.x == t ? 0x3f80u : 0u) | (lo.y == t ? 0x3f800000u : 0u);
+                q[1] = (lo.z == t ? 0x3f80u : 0u) | (lo.w == t ? 0x3f800000u : 0u);
+                q[2] = (hi.x == t ? 0x3f80u : 0u) | (hi.y == t ? 0x3f800000u : 0u);
+                q[3] = (hi.z == t ? 0x3f80u : 0u) | (hi.w == t ? 0x3f800000u : 0u);
+                return __builtin_bit_cast(bf16x8, q);
+            };
+            auto store_blocks = [&](float* dst, const f32x16 (&c)[2]) {
 #pragma unroll
-                for (int q = 0; q < 4; q++) {
-                    const int sr = q + 4 * h4;
-                    const float av = ES[(16 * rb + sr) * LD64 + 16 * w + i16];
-                    const int d = ints[sr * 8 + (rb < K ? 4 + rb : 2 + rb - K)];
+                for (int u = 0; u < 2; u++) {
+                    const int t = 32 * (tb0 + u) + fr;
+                    if (t < a.T)
 #pragma unroll
-                    for (int n = 0; n < 8; n++) c[n] = mfma16(av, d == 16 * n + i16 ? 1.f : 0.f, c[n]);
+                        for (int g = 0; g < 4; g++)                    // registers 4 g .. + 3: dims 8 g + 4 fh .. + 3 of the block
+                            *reinterpret_cast<float4*>(dst + (size_t)t * PC_L + 32 * jb + 8 * g + 4 * fh) =
+                                make_float4(c[u][4 * g], c[u][4 * g + 1], c[u][4 * g + 2], c[u][4 * g + 3]);
+                }
+            };
+            f32x16 c[2];
+#pragma unroll
+            for (int u = 0; u < 2; u++)
+#pragma unroll
+                for (int r = 0; r < 16; r++) c[u][r] = 0.f;
+#pragma unroll
+            for (int rb = 0; rb < MBK + 2; rb++) {
+                if (rb < K + 2) {
+                    const Split3 sa = src_frag(ES + 16 * rb * LD64);
+#pragma unroll
+                    for (int u = 0; u < 2; u++) {
+                        const bf16x8 oh = onehot_frag(dsts + 16 * rb, 32 * (tb0 + u) + fr);
+                        c[u] = mfma_bf16(sa.p2, oh, c[u]);
+                        c[u] = mfma_bf16(sa.p1, oh, c[u]);
+                        c[u] = mfma_bf16(sa.p0, oh, c[u]);
+                    }
                 }
             }
+            store_blocks(slab + wg_off_ec(), c);
 #pragma unroll
-            for (int n = 0; n < 8; n++) {
-                const int t = 16 * n + i16;
-                if (t < a.T) st4(slab + wg_off_ec() + (size_t)t * PC_L + 16 * w + 4 * h4, c[n]);
-                c[n] = f32x4v{0.f, 0.f, 0.f, 0.f};
+            for (int u = 0; u < 2; u++)
+#pragma unroll
+                for (int r = 0; r < 16; r++) c[u][r] = 0.f;
+            {
+                const Split3 sa = src_frag(DTs);
+#pragma unroll
+                for (int u = 0; u < 2; u++) {
+                    const bf16x8 oh = onehot_frag(dsts + TS * (FK + 2), 32 * (tb0 + u) + fr);
+                    c[u] = mfma_bf16(sa.p2, oh, c[u]);
+                    c[u] = mfma_bf16(sa.p1, oh, c[u]);
+                    c[u] = mfma_bf16(sa.p0, oh, c[u]);
+                }
             }
-#pragma unroll
-            for (int q = 0; q < 4; q++) {
-                const int sr = q + 4 * h4;
-                const float av = DTs[sr * LD64 + 16 * w + i16];
-                const int d = ints[sr * 8 + 1];
-#pragma unroll
-                for (int n = 0; n < 8; n++) c[n] = mfma16(av, d == 16 * n + i16 ? 1.f : 0.f, c[n]);
-            }
-#pragma unroll
-            for (int n = 0; n < 8; n++) {
-                const int t = 16 * n + i16;
-                if (t < a.T) st4(slab + wg_off_eq(a.T) + (size_t)t * PC_L + 16 * w + 4 * h4, c[n]);
-            }
+            store_blocks(slab + wg_off_eq(a.T), c);
         }
         PC_STAMP(15);
     }
@@ -771,7 +812,7 @@ static size_t tile_lds_bytes(int T, bool sims_local, bool tables) {
     const int ldsims = sims_local ? ((T + 15) / 16 * 16 + 4) : 0;
     const size_t floats = (size_t)TS * LD64 + TS * LD32 + TS * LD64 + 2 * TS * LD128 + (size_t)TS * FK * LD64 +
                           (size_t)TS * FK * LD128 + TS * LD64 + TS * LD32 + TS * 8 + (size_t)TS * ldsims +
-                          (tables ? (size_t)TS * (FK + 2) * LD64 + TS * LD64 : 0);
+                          (tables ? (size_t)TS * (FK + 2) * LD64 + TS * LD64 + TS * (FK + 3) : 0);
     return floats * sizeof(float);
 }
 
