@@ -41,6 +41,9 @@ extern "C" {
 /* doubles in one cross-replica BatchNorm exchange buffer: [seg][2][H] sums then [seg] row counts */
 #define PC_BN_SYNC_DOUBLES (PC_MAX_SEG * 2 * 256 + PC_MAX_SEG)
 
+/* 3: pc_ffn_saved gained the optional `a1` member (round 2; a caller built against version 2 passes a shorter struct);
+ * 2: pc_p2v_tensors / pc_joint_tensors gained `dropout` (and `dim`). */
+#define PC_ABI_VERSION 3
 int pc_abi_version(void);
 
 /* Training-mode dropout (config.py:12 DROPOUT = 0.1 is live in every reference training step: the attention
