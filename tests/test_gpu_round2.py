@@ -228,6 +228,36 @@ def test_fused_joint_step_equals_launch_per_op_step_and_oracle(T, B):
         assert float((gf[k].cpu() - g).abs().max()) <= 1e-6 + 1e-4 * float(g.abs().max()), k
 
 
+@pytest.mark.parametrize("K", [1, 2, 4])
+@pytest.mark.parametrize("T,B", [(40, 1), (40, 23), (100, 16), (300, 50), (700, 33)])
+def test_fused_joint_step_other_k_and_tiny_batches(K, T, B):
+    """NUM_COMP_TYPES other than the reference's 3 (the run-time-K instantiations of the tile / gradient kernels) and
+    batches of a single partial tile, in all three table regimes (T <= 128: gradient products in the tile kernel;
+    <= 512: the gradient-product kernel; above: per-query-type similarity rows) against the oracle: loss, top-K
+    (bit-exact), every gradient; and the Adam update applied by the finish kernel against the oracle's."""
+    from oracle import joint_oracle
+    from p_companion_amd.product2vec import FusedAdam
+    m = _pc(T, NUM_COMP_TYPES=K)
+    opt = FusedAdam(m, lr=1e-3)
+    st0 = {k: v.detach().cpu().clone() for k, v in m.state_dict().items()}
+    b = joint_batch(B, 300, T, seed=7 * T + K)
+    lf, tf = m.train_step(b, optimizer=opt)
+    assert tf.shape == (B, K)
+    hb = {k: v.cpu() for k, v in b.items()}
+    st = {k: v.clone() for k, v in st0.items()}
+    ref = joint_oracle.train_step(st, hb, joint_oracle.new_moments(st0), 1, k=K)
+    assert abs(float(lf[0]) - float(ref["loss"])) < 1e-5
+    assert np.array_equal(tf.cpu().numpy(), ref["out"]["complementary_types"].numpy())
+    for k, p in m.named_parameters():
+        if p.grad is not None:
+            g = ref["grads"][k]
+            assert float((p.grad.cpu() - g).abs().max()) <= 1e-6 + 1e-4 * float(g.abs().max()), k
+            # one Adam step (|update| <= lr = 1e-3); an element whose gradient is ~1e-8 = eps may move differently for a
+            # 1e-10 difference in that gradient, so: nearly all elements agree closely, none by more than the step itself
+            d = (p.detach().cpu() - st[k]).abs()
+            assert float((d <= 2e-5).float().mean()) >= 0.99 and float(d.max()) <= 2.1e-3, k
+
+
 def test_fused_joint_step_is_bitwise_reproducible_and_adam_in_kernel():
     """T <= 512: no float atomic anywhere in the step -> run-to-run bit equality of every gradient; the Adam update
     applied by the finish kernel == pc_adam_step on those gradients (same arithmetic, same order)."""
