@@ -299,6 +299,44 @@ def test_run_epoch_equals_the_loop_over_the_loader(types, dropout):
     assert got2.shape[0] == n // B and int(o_b.step_count) == len(ref) + n // B and torch.isfinite(got2).all()
 
 
+def test_pairs_path_clamps_and_counts_ids_outside_the_tables():
+    """pc_joint_fused_step_pairs validates what it derives from the pairs: a query / target id outside the product table is
+    clamped and counted (never dereferenced), the step stays finite, and the model raises when the counter is read."""
+    from types import SimpleNamespace
+    from p_companion_amd.data import ComplementaryIndexDataset, ComplementaryIndexLoader, generate_scaled_bpg
+    from p_companion_amd.p_companion import GraphedJointStep, PCompanion
+    from p_companion_amd.product2vec import FusedAdam
+    cfg = SimpleNamespace(PRODUCT_EMB_DIM=128, TYPE_EMB_DIM=64, DROPOUT=0.0, MARGIN=1.0, ALPHA=0.8, NUM_COMP_TYPES=3,
+                          NUM_TYPES=40, DEVICE="cuda")
+    bpg = generate_scaled_bpg(2000, 40, seed=3)
+    B = 128
+    torch.manual_seed(5)
+    m = PCompanion(cfg, bpg.cuda("cuda")["features"]).to("cuda").train()
+    o = FusedAdam(m, lr=1e-2)
+    g = GraphedJointStep(m, o, B, warmup=1, mode="direct")
+    ld = ComplementaryIndexLoader(ComplementaryIndexDataset(bpg, "train"), B, shuffle=True, seed=4, device="cuda",
+                                  out=g.static, deferred=True)
+    it = iter(ld)
+    g(next(it))                                                   # eager warm-up step (builds its batch itself)
+    g(next(it))                                                   # first prepared step
+    assert m.index_errors() == 0
+    batch = next(it)
+    loader, rows, step = batch["_deferred"]
+    rows = rows.clone()
+    rows[5, 0] = 2000                                             # query id == num_products
+    rows[9, 1] = -3                                               # negative target id
+    batch["_deferred"] = (loader, rows, step)
+    losses, _ = g(batch)
+    assert torch.isfinite(losses).all()
+    with pytest.raises(IndexError):
+        m.raise_index_errors()                                    # (reads and clears the device counter)
+    rows[5, 0], rows[9, 1] = 0, 1
+    rows[0, 0] = 5000
+    batch["_deferred"] = (loader, rows, step + 1)
+    g(batch)
+    assert m.index_errors() == 1
+
+
 def test_graphed_joint_step_with_grad_hook_equals_fused_adam():
     """The data-parallel form (fused step without its Adam -> grad_hook(flat gradients) -> optimizer.step()) with an identity
     hook against the single-process form (Adam inside the finish kernel): same bits (pc_adam_update is one definition)."""
