@@ -200,8 +200,8 @@ def test_graphed_joint_step_equals_eager_steps(mode):
         graphed({k: v[:7] for k, v in graphed.static.items()})
 
 
-@pytest.mark.parametrize("types,dropout", [(40, 0.0), (40, 0.1), (300, 0.0)])
-def test_deferred_batches_built_inside_the_step(types, dropout):
+@pytest.mark.parametrize("types,dropout,k", [(40, 0.0, 3), (40, 0.1, 3), (300, 0.0, 3), (100, 0.0, 2), (128, 0.1, 4)])
+def test_deferred_batches_built_inside_the_step(types, dropout, k):
     """ComplementaryIndexLoader(deferred=True) + GraphedJointStep: the batch is built by the step's first kernel
     (pc_joint_fused_step_pairs; T <= 128) or by the builder's launch inside the same call (larger tables).  Against the
     loader that builds first: the same losses, top-k and parameters bit for bit, and after each step the fixed buffers
@@ -210,7 +210,7 @@ def test_deferred_batches_built_inside_the_step(types, dropout):
     from p_companion_amd.data import ComplementaryIndexDataset, ComplementaryIndexLoader, generate_scaled_bpg
     from p_companion_amd.p_companion import GraphedJointStep, PCompanion
     from p_companion_amd.product2vec import FusedAdam
-    cfg = SimpleNamespace(PRODUCT_EMB_DIM=128, TYPE_EMB_DIM=64, DROPOUT=dropout, MARGIN=1.0, ALPHA=0.8, NUM_COMP_TYPES=3,
+    cfg = SimpleNamespace(PRODUCT_EMB_DIM=128, TYPE_EMB_DIM=64, DROPOUT=dropout, MARGIN=1.0, ALPHA=0.8, NUM_COMP_TYPES=k,
                           NUM_TYPES=types, DEVICE="cuda")
     bpg = generate_scaled_bpg(3000, 40, seed=3)
     B = 500                                                       # (not a multiple of the 16-sample tile)
