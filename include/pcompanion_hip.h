@@ -404,12 +404,14 @@ int pc_joint_train_step(const pc_joint_tensors *p, const pc_joint_tensors *g,
                         int32_t *topk, void *ws, size_t ws_bytes, void *stream);
 
 /* J8 loop body, FUSED (train.py:42-48: forward, compute_loss, zero_grad, backward and -- optionally --
- * optimizer.step as THREE launches): one kernel over 16-sample tiles computes the whole per-sample part (row gathers,
- * type transition with dropout, similarities + top-K, item projection, both hinges, the dX chain), one grouped
- * rows^T x rows launch forms the gradient slabs of the four Linears and of both [T,64] tables (one-hot products; the
- * type hinge's two dE_c rows per sample ride in the same product: no float atomics, bitwise reproducible), one kernel
- * sums the slabs in fixed order into g, forms losses[3] = {loss, type, item} and, when exp_avg / exp_avg_sq are given,
- * applies torch.optim.Adam's update (defaults of train.py:24) to p in the same pass (*step_count is advanced by one).
+ * optimizer.step as TWO launches at num_types <= 128): one kernel over 16-sample tiles computes the whole per-sample
+ * part (row gathers, type transition with dropout, similarities + top-K, item projection, both hinges, the dX chain)
+ * and, from the operands it holds in LDS, the tile's share of the gradients of the four Linears and of both [T,64] tables
+ * (one-hot products; the type hinge's two dE_c rows per sample ride in the same product: no float atomics, bitwise
+ * reproducible) as one slab per tile; one kernel sums the slabs in fixed order into g, forms losses[3] = {loss, type,
+ * item} and, when exp_avg / exp_avg_sq are given, applies torch.optim.Adam's update (defaults of train.py:24) to p in the
+ * same pass (*step_count is advanced by one).  128 < num_types <= 512: the gradient products run as their own kernel
+ * over row buffers (three launches).
  * exp_avg == NULL: gradients only (a data-parallel caller all-reduces g, then pc_adam_step).
  * T <= 512: as above.  T > 512 (config.py:27 NUM_TYPES = 34800): the similarity row and its top-K are formed once per
  * DISTINCT query type of the batch (it is a function of the type alone), the [B,T] matrix never exists; the table

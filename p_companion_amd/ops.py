@@ -626,7 +626,7 @@ def joint_fused_supported(num_types, k, dropout_p=0.0):
 
 def joint_fused_step(params, grads, query_idx, query_types, pos_types, neg_types, pos_items, neg_items, k, margin, alpha,
                      bad=None, adam=None):
-    """pc_joint_fused_step: the joint loop body as three launches.  adam: None (gradients only) or a dict with
+    """pc_joint_fused_step: the joint loop body as two launches (T <= 128; the gradient products get their own kernel up to 512).  adam: None (gradients only) or a dict with
     'exp_avg' / 'exp_avg_sq' (tensor dicts keyed like `params`), 'step_count' ([1] int64), 'lr', 'betas', 'eps': the
     optimizer update then happens in the last kernel.  Returns (losses[3], complementary_types[B,K])."""
     st, dev = joint_struct(params)

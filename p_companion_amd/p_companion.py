@@ -258,7 +258,7 @@ class PCompanion(nn.Module, _FlatParamsMixin):
         """train.py:42-46 (forward, compute_loss, zero_grad, backward) as one C-ABI call; with `optimizer` (a FusedAdam
         over this module) also train.py:48 optimizer.step(), applied by the step's last kernel.
         Returns (losses[3] = total/type/item on the device, complementary_types[B,K]).
-        The fused three-launch form (pc_joint_fused_step) serves K <= 4 and, for T > 512, dropout off; anything else
+        The fused form (pc_joint_fused_step: two launches at T <= 128) serves K <= 4 and, for T > 512, dropout off; anything else
         takes the launch-per-op sequence pc_joint_train_step (self.use_fused_joint = False forces it)."""
         self.flatten_parameters()
         dev = self.query_type_embeddings.weight.device
@@ -300,7 +300,7 @@ class GraphedJointStep:
     out of the loop.  The batch lives in fixed device buffers (`.static`; the loader builds straight into them:
     ComplementaryIndexLoader(..., out=step.static)); Adam's step counter and bias corrections live on the device.
     After `warmup` ordinary steps:
-      mode 'direct' (default where pc_joint_fused_step serves the configuration): the three-launch step with every
+      mode 'direct' (default where pc_joint_fused_step serves the configuration): the fused step with every
         argument resolved once -- one foreign call per iteration (ops.PreparedJointStep).  Measured on MI355X: the
         per-node cost of a HIP-graph replay (~5 us) exceeds what a launch costs the device when the host keeps its
         queue filled, so for 3-12 kernels the direct form is the faster one;
