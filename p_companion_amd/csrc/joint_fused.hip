@@ -107,6 +107,7 @@ struct FusedArgs {
     float *part_type, *part_item;         // [B] hinge values (summed by the finish kernel)
     float *h, *dpi, *dtp, *dc, *dh, *dt;  // row buffers for the gradient products
     float* ecsrc; int32_t* ecidx;         // [B (K + 2)][64] / [B (K + 2)]: rows added into dE_c[ecidx[r]]
+    int32_t* cids;                        // [2][B] validated (clamped) query_idx / query_types for the kernels that follow
     int32_t* bad; int64_t* step_count;
     float* slabs; int slab_floats;        // WGRAD: one gradient slab per workgroup (layout: wg_off_*)
     // PAIRS: the batch is built here from labelled pairs (data_loader.py:133-157, see pc_build_complementary_batch);
@@ -326,6 +327,7 @@ __global__ __launch_bounds__(256) void joint_tile_kernel(FusedArgs a, int ldsims
             if (wrong && a.bad) atomicAdd(a.bad, wrong);
         }
         ints[tid * 8 + 0] = qi; ints[tid * 8 + 1] = qt; ints[tid * 8 + 2] = pt; ints[tid * 8 + 3] = nt;
+        if (!TABLES && b < a.B) { a.cids[b] = qi; a.cids[a.B + b] = qt; }    // (gradient-product / scatter kernels gather by these)
         if (PAIRS) { ints[tid * 8 + 4] = tg; ints[tid * 8 + 5] = lab; }      // (the top-K slots: free until phase D)
     }
     phase_sync();
@@ -461,7 +463,12 @@ __global__ __launch_bounds__(256) void joint_tile_kernel(FusedArgs a, int ldsims
     } else {
         if (tid < TS * FK) {
             const int s = tid / FK, k = tid % FK;
-            if (k < K) ints[s * 8 + 4 + k] = b0 + s < a.B ? a.topk_by_type[(size_t)ints[s * 8 + 1] * K + k] : 0;
+            if (k < K) {
+                // (a query type that was out of range and clamped may have no entry in the per-type table: whatever is read
+                // there is forced into the table before it is used as a row id)
+                const int t = b0 + s < a.B ? a.topk_by_type[(size_t)ints[s * 8 + 1] * K + k] : 0;
+                ints[s * 8 + 4 + k] = (unsigned)t < (unsigned)a.T ? t : 0;
+            }
         }
     }
     phase_sync();
@@ -1287,11 +1294,43 @@ __global__ __launch_bounds__(256) void joint_finish_kernel(FinishArgs a) {
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-extern "C" int pc_scatter_add_rows(float* table, const int32_t* idx, int rows, int width, const float* src, void* stream);
+// Large tables: table[idx[r]][0..63] += src[r][0..63] for TWO row lists in one launch (the dE_c rows of the selected / hinge
+// types and the dE_q rows), destination-partitioned over the XCDs: workgroup b serves the destination rows with
+// idx % 8 == b % 8 only (workgroups are dealt to the 8 XCDs round-robin), so all float atomics on one table row come from
+// one XCD and resolve in that XCD's L2.  With a few live types in a large table (config.py:27 NUM_TYPES = 34800 over 20-100
+// live types) thousands of source rows land on the same hundred rows: issued from every XCD at once those atomics are
+// device-scope read-modify-writes on the same lines (33 us for 20 k rows, measured).  A workgroup's four waves walk the
+// source rows r = slot, slot + 32, ... (slot = b / 8) 64 candidates at a time and add the matching ones, one row per step
+// across the wave's lanes.  (Also measured: no atomics at all -- destination row t owned by workgroup t % 256, which adds its
+// source rows in fixed order into an LDS slice and stores it, clears included: bitwise reproducible, but a hot destination
+// is one workgroup's serial chain: 121 us against 33 + 12 here.)
+struct ScatterList { float* table; const int32_t* idx; const float* src; int rows; };
+
+__global__ __launch_bounds__(256) void scatter_add_rows_xcd_kernel(ScatterList l0, ScatterList l1) {
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, nslot = gridDim.x >> 3;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+#pragma unroll
+    for (int li = 0; li < 2; li++) {
+        const ScatterList& l = li ? l1 : l0;
+        // wave w of slot s takes the candidate rows (s + nslot * (w + 4 i)), i = 0, 1, ...
+        for (int base = slot + nslot * w; base < l.rows; base += nslot * 4 * 64) {
+            const int r = base + nslot * 4 * lane;
+            const int d = r < l.rows ? l.idx[r] : -1;
+            unsigned long long m = __ballot(d >= 0 && (d & 7) == xcd);
+            while (m) {
+                const int j = __ffsll((long long)m) - 1;
+                m &= m - 1;
+                const int rj = base + nslot * 4 * j;
+                const int dj = __shfl(d, j, 64);
+                unsafeAtomicAdd(l.table + (size_t)dj * PC_L + lane, l.src[(size_t)rj * PC_L + lane]);
+            }
+        }
+    }
+}
 
 struct FusedWs {
     float *part, *h, *dpi, *dtp, *dc, *dh, *dt, *ecsrc;
-    int32_t *ecidx, *ulist, *n_u, *topk_by_type, *part_idx;
+    int32_t *ecidx, *cids, *ulist, *n_u, *topk_by_type, *part_idx;
     float* part_val;
     float* wslabs; int wg_blocks, wslab_floats;      // joint_wgrad_kernel: one slab per workgroup
     int nchunks, ucap;
@@ -1317,6 +1356,7 @@ static FusedWs fused_ws_layout(void* base, int B, int T, int K) {
     w.dt = (float*)take((size_t)B * PC_L * 4);
     w.ecsrc = (float*)take((size_t)B * (K + 2) * PC_L * 4);
     w.ecidx = (int32_t*)take((size_t)B * (K + 2) * 4);
+    w.cids = (int32_t*)take((size_t)2 * B * 4);
     w.wg_blocks = (B + WG_S - 1) / WG_S;
     w.wslab_floats = wg_slab_floats(w.small ? T : 0);      // (large tables: their gradients go by row scatter-add)
     w.wslabs = (float*)take((size_t)w.wg_blocks * w.wslab_floats * 4);
@@ -1419,7 +1459,7 @@ static int fused_step_impl(const pc_joint_tensors* p, const pc_joint_tensors* g,
     fa.topk_by_type = w.topk_by_type;
     fa.topk = topk; fa.part_type = w.part; fa.part_item = w.part + B;
     fa.h = w.h; fa.dpi = w.dpi; fa.dtp = w.dtp; fa.dc = w.dc; fa.dh = w.dh; fa.dt = w.dt;
-    fa.ecsrc = w.ecsrc; fa.ecidx = w.ecidx; fa.bad = bad_count; fa.step_count = adam ? step_count : nullptr;
+    fa.ecsrc = w.ecsrc; fa.ecidx = w.ecidx; fa.cids = w.cids; fa.bad = bad_count; fa.step_count = adam ? step_count : nullptr;
     fa.slabs = w.wslabs; fa.slab_floats = w.wslab_floats;
     if (pairs_in_tile) {
         fa.pairs = src->pairs; fa.features = src->features; fa.type_idx = src->type_idx; fa.n_types_mod = src->n_types;
@@ -1462,7 +1502,7 @@ static int fused_step_impl(const pc_joint_tensors* p, const pc_joint_tensors* g,
     // ---- gradient products over the row buffers: one launch, one slab per workgroup, summed by the finish kernel
     WgradArgs wa = {};
     wa.table = p->product_table; wa.eq = p->query_types; wa.ec = p->comp_types;
-    wa.query_idx = query_idx; wa.query_types = query_types; wa.topk = topk;
+    wa.query_idx = w.cids; wa.query_types = w.cids + B; wa.topk = topk;      // (validated by the tile kernel)
     wa.dpi = w.dpi; wa.dtp = w.dtp; wa.dc = w.dc; wa.h = w.h; wa.dh = w.dh; wa.dt = w.dt; wa.ecsrc = w.ecsrc; wa.ecidx = w.ecidx;
     wa.B = B; wa.T = w.small ? T : 0; wa.K = K; wa.slabs = w.wslabs; wa.slab_floats = w.wslab_floats;
     if (!wgrad_in_tile) {
@@ -1481,10 +1521,9 @@ static int fused_step_impl(const pc_joint_tensors* p, const pc_joint_tensors* g,
         PC_TRY(pc_launch_status());
     }
     if (!w.small) {
-        // the query_idx / query_types / topk gathers of the kernel above use the caller's raw ids: they were validated
-        // (and any offender counted) by the tile kernel
-        PC_TRY(pc_scatter_add_rows(g->comp_types, w.ecidx, B * (K + 2), PC_L, w.ecsrc, stream));
-        PC_TRY(pc_scatter_add_rows(g->query_types, query_types, B, PC_L, w.dt, stream));
+        const ScatterList lc = {g->comp_types, w.ecidx, w.ecsrc, B * (K + 2)}, lq = {g->query_types, w.cids + B, w.dt, B};
+        PC_LAUNCH(scatter_add_rows_xcd_kernel, dim3(256), dim3(256), 0, st, lc, lq);
+        PC_TRY(pc_launch_status());
     }
 
     // ---- finish: slab sums -> .grad, the losses, Adam

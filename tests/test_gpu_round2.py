@@ -285,10 +285,11 @@ def test_fused_joint_step_is_bitwise_reproducible_and_adam_in_kernel():
     assert torch.equal(g1, m1._gflat)
 
 
-def test_fused_joint_step_clamps_and_counts_bad_ids():
-    m = _pc(40)
+@pytest.mark.parametrize("T", [40, 300, 700])
+def test_fused_joint_step_clamps_and_counts_bad_ids(T):
+    m = _pc(T)
     b = joint_batch(48, 300, 40, seed=5)
-    b["query_types"][7] = 41
+    b["query_types"][7] = T + 1
     b["query_idx"][3] = 300
     b["negative_types"][11, 0] = -2
     losses, topk = m.train_step(b)                               # no out-of-bounds access: ids clamped in the kernel
