@@ -1031,7 +1031,7 @@ struct WgradArgs {
     int B, T, K;
     float* slabs; int slab_floats;                        // per workgroup: itm_w | itm_b | typ_w | typ_b | dec_w | dec_b | enc_w | enc_b | E_c | E_q
 };
-// NTW: 16-type column blocks of a table product per wave (T <= 128: 4; T <= 512: 16)
+// NTW: 16-type column blocks of a table product per wave (16 serves T <= 512; T <= 128 never comes here)
 template <int NTW, int KC>
 __global__ __launch_bounds__(512) void joint_wgrad_kernel(WgradArgs a) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
@@ -1506,17 +1506,13 @@ static int fused_step_impl(const pc_joint_tensors* p, const pc_joint_tensors* g,
     wa.dpi = w.dpi; wa.dtp = w.dtp; wa.dc = w.dc; wa.h = w.h; wa.dh = w.dh; wa.dt = w.dt; wa.ecsrc = w.ecsrc; wa.ecidx = w.ecidx;
     wa.B = B; wa.T = w.small ? T : 0; wa.K = K; wa.slabs = w.wslabs; wa.slab_floats = w.wslab_floats;
     if (!wgrad_in_tile) {
-        static const hipError_t wattr[4] = {
-            hipFuncSetAttribute(reinterpret_cast<const void*>(&joint_wgrad_kernel<4, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024),
-            hipFuncSetAttribute(reinterpret_cast<const void*>(&joint_wgrad_kernel<4, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024),
+        // (only 128 < T <= 512 comes here: 16 type blocks per wave and table)
+        static const hipError_t wattr[2] = {
             hipFuncSetAttribute(reinterpret_cast<const void*>(&joint_wgrad_kernel<16, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024),
             hipFuncSetAttribute(reinterpret_cast<const void*>(&joint_wgrad_kernel<16, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)};
         (void)wattr;
         const size_t wl = wgrad_lds_bytes();
-        const bool few = wa.T <= 128;
-        if (few && K == 3) PC_LAUNCH((joint_wgrad_kernel<4, 3>), dim3(w.wg_blocks), dim3(512), wl, st, wa);
-        else if (few) PC_LAUNCH((joint_wgrad_kernel<4, 0>), dim3(w.wg_blocks), dim3(512), wl, st, wa);
-        else if (K == 3) PC_LAUNCH((joint_wgrad_kernel<16, 3>), dim3(w.wg_blocks), dim3(512), wl, st, wa);
+        if (K == 3) PC_LAUNCH((joint_wgrad_kernel<16, 3>), dim3(w.wg_blocks), dim3(512), wl, st, wa);
         else PC_LAUNCH((joint_wgrad_kernel<16, 0>), dim3(w.wg_blocks), dim3(512), wl, st, wa);
         PC_TRY(pc_launch_status());
     }
