@@ -169,7 +169,11 @@ __global__ __launch_bounds__(64 * NWM * NWN, WPS) void gemm_nt_kernel(NtArgs a, 
     auto make_ptrs = [&](const int (&srow)[NIA], int nn0) {
 #pragma unroll
         for (int j = 0; j < NIA; j++)
+#ifdef PC_EXP_DMA_L2
+            src[j] = srow[j] >= 0 ? a.A + (size_t)(srow[j] & 127) * a.lda + lchunk * 4 : nullptr;
+#else
             src[j] = srow[j] >= 0 ? a.A + (size_t)srow[j] * a.lda + lchunk * 4 : nullptr;
+#endif
 #pragma unroll
         for (int j = NIA; j < NI; j++) {
             const int n = nn0 + (w + NW * j) * RPI - BM + lrow;
@@ -212,16 +216,38 @@ __global__ __launch_bounds__(64 * NWM * NWN, WPS) void gemm_nt_kernel(NtArgs a, 
             const int c0 = (((4 * g + 2 * (lane >> 5)) ^ gsw) << 2), c1 = (((4 * g + 2 * (lane >> 5) + 1) ^ gsw) << 2);
             const float* ar = cur + (wm * 64 + fr) * BK;
             const float* br = cur + (BM + wn * 64 + fr) * BK;
+            // developer builds (scripts/dev/nt_decompose.sh; WRONG results, right instruction mix): what each part of the
+            // loop costs.  -DPC_EXP_NO_SPLIT fragments used unsplit, -DPC_EXP_NO_LDSREAD fragments from loop-invariant
+            // registers, -DPC_EXP_NO_MFMA products replaced by a register keep-alive, -DPC_EXP_NO_DMA only the first
+            // stage is ever fetched, -DPC_EXP_DMA_L2 the A rows come from 128 hot rows
+#if defined(PC_EXP_NO_LDSREAD)
+#define PC_FRAG(PTR, OFF) make_float4(__int_as_float(a.M), __int_as_float(a.N), __int_as_float(a.K), __int_as_float(a.lda))
+#else
+#define PC_FRAG(PTR, OFF) (*reinterpret_cast<const float4*>((PTR) + (OFF)))
+#endif
+#if defined(PC_EXP_NO_SPLIT) || defined(PC_EXP_NO_LDSREAD)
+#define PC_SPLIT(LO, HI) Split3{__builtin_bit_cast(bf16x8, LO), __builtin_bit_cast(bf16x8, HI), __builtin_bit_cast(bf16x8, LO)}
+#else
+#define PC_SPLIT(LO, HI) split3(LO, HI)
+#endif
+#if defined(PC_EXP_NO_MFMA)
+#define PC_MFMA(A, B, C) ([&]() { asm volatile("" ::"v"(A), "v"(B)); return C; }())
+#else
+#define PC_MFMA(A, B, C) mfma_bf16(A, B, C)
+#endif
             Split3 sa[2];
 #pragma unroll
-            for (int i = 0; i < 2; i++)
-                sa[i] = split3(*reinterpret_cast<const float4*>(ar + i * 32 * BK + c0), *reinterpret_cast<const float4*>(ar + i * 32 * BK + c1));
+            for (int i = 0; i < 2; i++) {
+                const float4 lo = PC_FRAG(ar + i * 32 * BK, c0), hi = PC_FRAG(ar + i * 32 * BK, c1);
+                sa[i] = PC_SPLIT(lo, hi);
+            }
 #pragma unroll
             for (int j = 0; j < 2; j++) {
-                const Split3 sb = split3(*reinterpret_cast<const float4*>(br + j * 32 * BK + c0), *reinterpret_cast<const float4*>(br + j * 32 * BK + c1));
+                const float4 wlo = PC_FRAG(br + j * 32 * BK, c0), whi = PC_FRAG(br + j * 32 * BK, c1);
+                const Split3 sb = PC_SPLIT(wlo, whi);
 #define PC_TERM(PA, PB)                                                   \
-                acc[0][j] = mfma_bf16(sa[0].PA, sb.PB, acc[0][j]);        \
-                acc[1][j] = mfma_bf16(sa[1].PA, sb.PB, acc[1][j]);
+                acc[0][j] = PC_MFMA(sa[0].PA, sb.PB, acc[0][j]);          \
+                acc[1][j] = PC_MFMA(sa[1].PA, sb.PB, acc[1][j]);
                 PC_TERM(p2, p0) PC_TERM(p0, p2) PC_TERM(p1, p1) PC_TERM(p1, p0) PC_TERM(p0, p1) PC_TERM(p0, p0)
             }
 #undef PC_TERM
@@ -285,8 +311,10 @@ __global__ __launch_bounds__(64 * NWM * NWN, WPS) void gemm_nt_kernel(NtArgs a, 
         // then multiply the landed one
         for (int kt = 0; kt < nk; kt++) {
             if (PRO && a.pro_out && kt > 0) store_stream_asm(pend_p, pend_v);
+#ifndef PC_EXP_NO_DMA
             if (kt + 1 < nk) issue(cur ^ 1, (kt + 1) * BK);
             else if (ntile < total_tiles) { make_ptrs(nsrow, nn0); issue(cur ^ 1, 0); }
+#endif
             float* cs = stages + cur * STAGE;
             if (PRO) { transform(cs, kt * BK, seg); lds_sync(); }
             compute(cs);
