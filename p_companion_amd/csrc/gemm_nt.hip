@@ -145,6 +145,10 @@ __global__ __launch_bounds__(64 * NWM * NWN, WPS) void gemm_nt_kernel(NtArgs a, 
     // ---- per-tile state ------------------------------------------------------------------
     int tile = blockIdx.x;
     if (tile >= total_tiles) return;
+#ifdef PC_EXP_STAGGER
+    // developer experiment: the co-resident workgroups of a CU (b, b + 256, b + 512) start PC_EXP_STAGGER us apart
+    for (int i = 0; i < ((blockIdx.x >> 8) % 3) * PC_EXP_STAGGER * 4; i++) __builtin_amdgcn_s_sleep(8);    // ~0.25 us each
+#endif
     int row0 = 0, row_end = 0, n0 = 0, seg = 0;
     auto tile_geom = [&](int t, int& r0, int& rend, int& nn0, int& sg) {
         int tm = t / ntn, tn = t % ntn;
@@ -219,7 +223,8 @@ __global__ __launch_bounds__(64 * NWM * NWN, WPS) void gemm_nt_kernel(NtArgs a, 
             // developer builds (scripts/dev/nt_decompose.sh; WRONG results, right instruction mix): what each part of the
             // loop costs.  -DPC_EXP_NO_SPLIT fragments used unsplit, -DPC_EXP_NO_LDSREAD fragments from loop-invariant
             // registers, -DPC_EXP_NO_MFMA products replaced by a register keep-alive, -DPC_EXP_NO_DMA only the first
-            // stage is ever fetched, -DPC_EXP_DMA_L2 the A rows come from 128 hot rows
+            // stage is ever fetched, -DPC_EXP_DMA_L2 the A rows come from 128 hot rows, -DPC_EXP_STAGGER=us the three
+            // co-resident workgroups of a CU start that many microseconds apart
 #if defined(PC_EXP_NO_LDSREAD)
 #define PC_FRAG(PTR, OFF) make_float4(__int_as_float(a.M), __int_as_float(a.N), __int_as_float(a.K), __int_as_float(a.lda))
 #else
