@@ -1306,12 +1306,23 @@ __global__ __launch_bounds__(256) void joint_finish_kernel(FinishArgs a) {
 // is one workgroup's serial chain: 121 us against 33 + 12 here.)
 struct ScatterList { float* table; const int32_t* idx; const float* src; int rows; };
 
+#define SC_SLOTS 64        /* distinct destinations a workgroup aggregates in LDS before it touches the table */
 __global__ __launch_bounds__(256) void scatter_add_rows_xcd_kernel(ScatterList l0, ScatterList l1) {
+    // rows with the same destination are first added up in LDS (a workgroup sees ~80 source rows over a dozen destinations
+    // when few types are live), then each distinct destination costs ONE row of float atomics
+    __shared__ float tab[SC_SLOTS * PC_L];
+    __shared__ int keys[SC_SLOTS];
+    __shared__ int nkeys;
     const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, nslot = gridDim.x >> 3;
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-#pragma unroll
+#pragma unroll 1
     for (int li = 0; li < 2; li++) {
         const ScatterList& l = li ? l1 : l0;
+        __syncthreads();
+        for (int e = threadIdx.x; e < SC_SLOTS * PC_L; e += 256) tab[e] = 0.f;
+        if (threadIdx.x < SC_SLOTS) keys[threadIdx.x] = -1;
+        if (threadIdx.x == 0) nkeys = 0;
+        __syncthreads();
         // wave w of slot s takes the candidate rows (s + nslot * (w + 4 i)), i = 0, 1, ...
         for (int base = slot + nslot * w; base < l.rows; base += nslot * 4 * 64) {
             const int r = base + nslot * 4 * lane;
@@ -1322,9 +1333,27 @@ __global__ __launch_bounds__(256) void scatter_add_rows_xcd_kernel(ScatterList l
                 m &= m - 1;
                 const int rj = base + nslot * 4 * j;
                 const int dj = __shfl(d, j, 64);
-                unsafeAtomicAdd(l.table + (size_t)dj * PC_L + lane, l.src[(size_t)rj * PC_L + lane]);
+                const float v = l.src[(size_t)rj * PC_L + lane];
+                // the destination's slot: known already, or a new one (two waves may each open one for the same destination
+                // at the same moment: both are flushed), or -- table full -- straight to the table
+                unsigned long long hit = __ballot(keys[lane] == dj);
+                int sl = hit ? __ffsll((long long)hit) - 1 : -1;
+                if (sl < 0) {
+                    int got = 0;
+                    if (lane == 0) {
+                        got = atomicAdd(&nkeys, 1);
+                        if (got < SC_SLOTS) keys[got] = dj;
+                    }
+                    got = __shfl(got, 0, 64);
+                    sl = got < SC_SLOTS ? got : -1;
+                }
+                if (sl >= 0) unsafeAtomicAdd(&tab[sl * PC_L + lane], v);          // ds_add_f32
+                else unsafeAtomicAdd(l.table + (size_t)dj * PC_L + lane, v);
             }
         }
+        __syncthreads();
+        const int nk = nkeys < SC_SLOTS ? nkeys : SC_SLOTS;
+        for (int sl = w; sl < nk; sl += 4) unsafeAtomicAdd(l.table + (size_t)keys[sl] * PC_L + lane, tab[sl * PC_L + lane]);
     }
 }
 
