@@ -278,8 +278,8 @@ def run_joint(args, rank, world, dev, types, steps, warmup, want_cpu):
                       "kernels_per_step": ("2 (tile kernel: batch construction, forward, losses, backward and the tile's gradient slab; finish: slab "
                                             "sums + Adam)" if types <= 128 else
                                             "4 (batch builder, tile kernel, gradient products, finish + Adam)" if types <= 512 else
-                                            "10 (batch builder, 2 clears, present types, sims + chunk top-K, merge, tile kernel incl. the "
-                                            "weight-gradient slabs, 2 row scatter-adds, finish + Adam)")},
+                                            "7 (clear, present types, sims + chunk top-K, merge, tile kernel incl. batch construction and the "
+                                            "weight-gradient slabs, table-gradient scatter-add, finish + Adam)")},
            "roofline": {"bound": "hbm", "kernel": "the whole step (batch builder + the fused step's kernels: a dependent chain)",
                         "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                         "frac": round(achieved / HBM_PEAK_GBS, 5),

@@ -433,8 +433,8 @@ int pc_joint_fused_step(const pc_joint_tensors *p, const pc_joint_tensors *g, co
 /* The loader's batch construction (pc_build_complementary_batch, data_loader.py:133-157) and the fused step as ONE call
  * over `batch` labelled pairs[b] = (query, target, label): query_idx .. neg_items are OUTPUT buffers here -- after the call
  * they hold the batch exactly as pc_build_complementary_batch(pairs, ..., seed, step) writes it (same filler bits), for
- * whoever reads the batch afterwards (metrics, logging).  num_types <= 128: the first kernel of the step derives the ids and
- * the item rows itself (one launch and a 4 MB round trip less); larger tables: the builder's launch, then the step.
+ * whoever reads the batch afterwards (metrics, logging).  num_types <= 128 or > 512: the step's own kernels derive the ids
+ * and the item rows (one launch and a 4 MB round trip less); 128 < num_types <= 512: the builder's launch, then the step.
  * `features` [num_products, 128] is the table the dataset serves item rows from (train.py:115: the exported Product2Vec
  * embeddings), `type_idx` [num_products] the products' type ids, `n_types` the dataset's modulus for the negative type. */
 int pc_joint_fused_step_pairs(const pc_joint_tensors *p, const pc_joint_tensors *g, const pc_joint_tensors *exp_avg,

@@ -833,16 +833,30 @@ static size_t tile_lds_bytes(int T, bool sims_local, bool tables) {
 //   type_topk_merge_kernel per listed query type: best K of its chunks' candidates -> topk_by_type[type][K]
 #define TC 320        /* types per chunk: 109 chunks x 2 tiles of listed query types = 218 workgroups at T = 34800: one round of the chip */
 #define UT 64
+// pairs (optional): the batch is not built yet -- the query type of sample b is type_idx[pairs[3 b]] (data_loader.py:146)
 __global__ __launch_bounds__(1024) void present_types_kernel(const int32_t* query_types, int B, int T, int32_t* ulist,
-                                                             int32_t* n_u) {
+                                                             int32_t* n_u, const int32_t* pairs, const int32_t* type_idx,
+                                                             int P) {
     extern __shared__ unsigned bits[];                  // [words] then scan scratch [1024]
     const int words = (T + 31) >> 5;
     unsigned* part = bits + words;
     for (int i = threadIdx.x; i < words; i += 1024) bits[i] = 0u;
     __syncthreads();
-    for (int b = threadIdx.x; b < B; b += 1024) {
-        const int t = query_types[b];
-        if ((unsigned)t < (unsigned)T) atomicOr(&bits[t >> 5], 1u << (t & 31));
+    for (int b0 = threadIdx.x; b0 < B; b0 += 4 * 1024) {          // four samples per thread and round: their two dependent loads overlap
+        int t[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const int b = b0 + 1024 * u;
+            t[u] = b < B ? (pairs ? pairs[3 * b] : query_types[b]) : -1;
+        }
+        if (pairs) {
+#pragma unroll
+            for (int u = 0; u < 4; u++)
+                if (b0 + 1024 * u < B) t[u] = type_idx[(unsigned)t[u] < (unsigned)P ? t[u] : 0];
+        }
+#pragma unroll
+        for (int u = 0; u < 4; u++)
+            if ((unsigned)t[u] < (unsigned)T) atomicOr(&bits[t[u] >> 5], 1u << (t[u] & 31));
     }
     __syncthreads();
     const int per = (words + 1023) / 1024;
@@ -1448,9 +1462,9 @@ static int fused_step_impl(const pc_joint_tensors* p, const pc_joint_tensors* g,
     if (ws_bytes < pc_joint_fused_workspace_bytes(B, T, K)) return PC_EWORKSPACE;
     hipStream_t st = (hipStream_t)stream;
     FusedWs w = fused_ws_layout(ws, B, T, K);
-    // the batch from labelled pairs: inside the tile kernel where that kernel is the step's first consumer of the batch
-    // (T <= 128); otherwise by the builder's own launch, then the step as usual
-    const bool pairs_in_tile = src && w.small && T <= T_WGRAD;
+    // the batch from labelled pairs: inside the tile kernel (T <= 128, and T > 512 where present_types_kernel takes the query
+    // types from the pairs as well); for 128 < T <= 512 by the builder's own launch, then the step as usual
+    const bool pairs_in_tile = src && (!w.small || T <= T_WGRAD);
     if (src && !pairs_in_tile)
         PC_TRY(pc_build_complementary_batch(src->pairs, B, src->features, src->type_idx, src->n_types, src->seed, src->step,
                                             const_cast<int32_t*>(query_idx), const_cast<int32_t*>(query_types),
@@ -1459,10 +1473,15 @@ static int fused_step_impl(const pc_joint_tensors* p, const pc_joint_tensors* g,
 
     if (!w.small) {
         // gradients of the two big tables arrive by float atomics: cleared first
-        PC_HIP_TRY(hipMemsetAsync(g->query_types, 0, (size_t)T * PC_L * 4, st));
-        PC_HIP_TRY(hipMemsetAsync(g->comp_types, 0, (size_t)T * PC_L * 4, st));
+        if (g->comp_types == g->query_types + (size_t)T * PC_L) {          // (adjacent in a flat gradient buffer: one fill)
+            PC_HIP_TRY(hipMemsetAsync(g->query_types, 0, (size_t)2 * T * PC_L * 4, st));
+        } else {
+            PC_HIP_TRY(hipMemsetAsync(g->query_types, 0, (size_t)T * PC_L * 4, st));
+            PC_HIP_TRY(hipMemsetAsync(g->comp_types, 0, (size_t)T * PC_L * 4, st));
+        }
         const int words = (T + 31) / 32;
-        PC_LAUNCH(present_types_kernel, dim3(1), dim3(1024), (size_t)(words + 1024) * 4, st, query_types, B, T, w.ulist, w.n_u);
+        PC_LAUNCH(present_types_kernel, dim3(1), dim3(1024), (size_t)(words + 1024) * 4, st, query_types, B, T, w.ulist, w.n_u,
+                  pairs_in_tile ? src->pairs : nullptr, pairs_in_tile ? src->type_idx : nullptr, num_products);
         TypeSimsArgs ta = {p->enc_w, p->enc_b, p->dec_w, p->dec_b, p->query_types, p->comp_types, w.ulist, w.n_u, T, K,
                            w.nchunks, w.part_val, w.part_idx};
         const size_t lds = ((size_t)UT * LD64 * 2 + UT * LD32 + (size_t)UT * (TC + 4)) * 4;
@@ -1503,7 +1522,9 @@ static int fused_step_impl(const pc_joint_tensors* p, const pc_joint_tensors* g,
     // rows go by scatter-add) or, for 128 < T <= 512, in joint_wgrad_kernel over the row buffers
     const bool wgrad_in_tile = !w.small || T <= T_WGRAD;
     const size_t lds = tile_lds_bytes(T, w.small, w.small && wgrad_in_tile);
-    static const hipError_t attr[8] = {
+    static const hipError_t attr[10] = {
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&joint_tile_kernel<false, 3, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024),
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&joint_tile_kernel<false, 0, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024),
         hipFuncSetAttribute(reinterpret_cast<const void*>(&joint_tile_kernel<true, 3, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024),
         hipFuncSetAttribute(reinterpret_cast<const void*>(&joint_tile_kernel<true, 0, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024),
         hipFuncSetAttribute(reinterpret_cast<const void*>(&joint_tile_kernel<true, 3, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024),
@@ -1513,9 +1534,12 @@ static int fused_step_impl(const pc_joint_tensors* p, const pc_joint_tensors* g,
         hipFuncSetAttribute(reinterpret_cast<const void*>(&joint_tile_kernel<false, 3, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024),
         hipFuncSetAttribute(reinterpret_cast<const void*>(&joint_tile_kernel<false, 0, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)};
     (void)attr;
-    if (pairs_in_tile) {
+    if (pairs_in_tile && w.small) {
         if (K == 3) PC_LAUNCH((joint_tile_kernel<true, 3, true, true>), dim3(tiles), dim3(256), lds, st, fa, ldsims);
         else PC_LAUNCH((joint_tile_kernel<true, 0, true, true>), dim3(tiles), dim3(256), lds, st, fa, ldsims);
+    } else if (pairs_in_tile) {
+        if (K == 3) PC_LAUNCH((joint_tile_kernel<false, 3, true, true>), dim3(tiles), dim3(256), lds, st, fa, ldsims);
+        else PC_LAUNCH((joint_tile_kernel<false, 0, true, true>), dim3(tiles), dim3(256), lds, st, fa, ldsims);
     } else if (w.small && wgrad_in_tile) {
         if (K == 3) PC_LAUNCH((joint_tile_kernel<true, 3, true>), dim3(tiles), dim3(256), lds, st, fa, ldsims);
         else PC_LAUNCH((joint_tile_kernel<true, 0, true>), dim3(tiles), dim3(256), lds, st, fa, ldsims);
