@@ -368,10 +368,12 @@ __global__ __launch_bounds__(64 * WO * WI, WO * WI / 4) void gemm_tn8_kernel(TnA
         if (c + NST - 1 <= nchunk) { asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NST - 2) * JALL) : "memory"); }
         else { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
         __syncthreads();                                   // chunk c visible to all; slot of chunk c-1 free again
+#ifndef PC_EXP_NO_DMA
         if (c + NST - 1 < nchunk) {
             issue(cur == 0 ? NST - 1 : cur - 1, r_begin + (c + NST - 1) * TKC);
             if (c + NST < nchunk) load_gather(r_begin + (c + NST) * TKC);   // indices a whole chunk ahead of their use
         }
+#endif
         float* stage = smem + cur * STAGE;
         if (APRO || ZPRO) { transform(stage, r_begin + c * TKC); tn_lds_sync(); }
         const float* Zs = stage + fz;
@@ -380,22 +382,39 @@ __global__ __launch_bounds__(64 * WO * WI, WO * WI / 4) void gemm_tn8_kernel(TnA
         for (int g = 0; g < TKC / 16; g++) {
             // rows 16 g + 8 (lane >> 5) + t; in a half-swapped 128-wide image the swap follows bit 3 of the row, i.e.
             // the lane's half when g is even and its complement when... rows 16g+8h+t have bit 3 == h: constant per lane
+            // developer builds (scripts/dev/nt_decompose.sh, KERNELS=tn; WRONG results): -DPC_EXP_NO_SPLIT, -DPC_EXP_NO_LDSREAD,
+            // -DPC_EXP_NO_MFMA, -DPC_EXP_NO_DMA as in gemm_nt.hip; -DPC_EXP_NO_SLAB skips the slab store
+#if defined(PC_EXP_NO_LDSREAD)
+#define PC_TNV(PTR, OFF) __int_as_float(a.R + t)
+#else
+#define PC_TNV(PTR, OFF) (PTR)[OFF]
+#endif
+#if defined(PC_EXP_NO_SPLIT) || defined(PC_EXP_NO_LDSREAD)
+#define PC_TNSPLIT(LO, HI) Split3{__builtin_bit_cast(bf16x8, LO), __builtin_bit_cast(bf16x8, HI), __builtin_bit_cast(bf16x8, LO)}
+#else
+#define PC_TNSPLIT(LO, HI) split3(LO, HI)
+#endif
+#if defined(PC_EXP_NO_MFMA)
+#define PC_TNMFMA(A, B, C) ([&]() { asm volatile("" ::"v"(A), "v"(B)); return C; }())
+#else
+#define PC_TNMFMA(A, B, C) mfma_bf16(A, B, C)
+#endif
             Split3 sx[TI];
 #pragma unroll
             for (int j = 0; j < TI; j++) {
                 float v[8];
 #pragma unroll
-                for (int t = 0; t < 8; t++) v[t] = As[(16 * g + t) * ARS + xo[j]];
-                sx[j] = split3(make_float4(v[0], v[1], v[2], v[3]), make_float4(v[4], v[5], v[6], v[7]));
+                for (int t = 0; t < 8; t++) v[t] = PC_TNV(As, (16 * g + t) * ARS + xo[j]);
+                sx[j] = PC_TNSPLIT(make_float4(v[0], v[1], v[2], v[3]), make_float4(v[4], v[5], v[6], v[7]));
             }
 #pragma unroll
             for (int i = 0; i < TO; i++) {
                 float v[8];
 #pragma unroll
-                for (int t = 0; t < 8; t++) v[t] = Zs[(16 * g + t) * ZRS + zo[i]];
+                for (int t = 0; t < 8; t++) v[t] = PC_TNV(Zs, (16 * g + t) * ZRS + zo[i]);
                 zsum[i] += ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]));
-                const Split3 sz = split3(make_float4(v[0], v[1], v[2], v[3]), make_float4(v[4], v[5], v[6], v[7]));
-#define PC_TERM(PZ, PX) _Pragma("unroll") for (int j = 0; j < TI; j++) acc[i][j] = mfma_bf16(sz.PZ, sx[j].PX, acc[i][j]);
+                const Split3 sz = PC_TNSPLIT(make_float4(v[0], v[1], v[2], v[3]), make_float4(v[4], v[5], v[6], v[7]));
+#define PC_TERM(PZ, PX) _Pragma("unroll") for (int j = 0; j < TI; j++) acc[i][j] = PC_TNMFMA(sz.PZ, sx[j].PX, acc[i][j]);
                 PC_TERM(p2, p0) PC_TERM(p0, p2) PC_TERM(p1, p1) PC_TERM(p1, p0) PC_TERM(p0, p1) PC_TERM(p0, p0)
 #undef PC_TERM
             }
@@ -412,7 +431,11 @@ __global__ __launch_bounds__(64 * WO * WI, WO * WI / 4) void gemm_tn8_kernel(TnA
 #pragma unroll
             for (int reg = 0; reg < 16; reg++) {
                 const int o = wo * (TO * 32) + i * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5);
+#ifdef PC_EXP_NO_SLAB
+                if (o < a.No && ci < a.Ni && acc[i][j][reg] == 12345.678f) slab[(size_t)o * a.Ni + ci] = acc[i][j][reg];
+#else
                 if (o < a.No && ci < a.Ni) slab[(size_t)o * a.Ni + ci] = acc[i][j][reg];
+#endif
             }
         }
     if (a.db && wi == 0) {

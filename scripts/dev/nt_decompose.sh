@@ -9,7 +9,7 @@ mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 for K in ${KNOBS:-BASE NO_SPLIT NO_LDSREAD NO_MFMA NO_DMA DMA_L2}; do
   TAG=$(echo $K | sed 's/ -DPC_EXP_/+/g')
-  touch $R/p_companion_amd/csrc/gemm_nt.hip
+  touch $R/p_companion_amd/csrc/gemm_nt.hip $R/p_companion_amd/csrc/gemm_tn.hip
   if [ "$K" = "BASE" ]; then FL=""; else FL="-DPC_EXP_$K"; fi
   (cd $R && PC_EXTRA_HIPCC_FLAGS="$FL" python3 -m p_companion_amd.build > /tmp/build_decomp.log 2>&1)
   rm -rf /tmp/prof_decomp
@@ -21,8 +21,8 @@ c = sqlite3.connect(f[0])
 tabs = [r[0] for r in c.execute("select name from sqlite_master where type='table'")]
 kd = [t for t in tabs if 'kernel_dispatch' in t][0]
 ks = [t for t in tabs if 'kernel_symbol' in t][0]
-for n, cnt, avg in c.execute(f"select s.kernel_name,count(*),avg(d.end-d.start)/1e3 from {kd} d join {ks} s on d.kernel_id=s.id where s.kernel_name like '%gemm_nt_kernel%' group by s.kernel_name"):
-    print(sys.argv[1], n[18:52], cnt, round(avg, 1))
+for n, cnt, avg in c.execute(f"select s.kernel_name,count(*),avg(d.end-d.start)/1e3 from {kd} d join {ks} s on d.kernel_id=s.id where s.kernel_name like '%gemm_nt_kernel%' or s.kernel_name like '%gemm_tn8%' or s.kernel_name like '%tn_reduce_kernel%' group by s.kernel_name"):
+    print(sys.argv[1], n[4:52].replace(' ', ''), cnt, round(avg, 1))
 PY
   echo "done $TAG"
 done
