@@ -405,7 +405,19 @@ int ffn_backward_part1(const pc_p2v_tensors* p, const pc_p2v_tensors* g, const f
     if (!sv->a1) { t3.prologue = NT_PRO_BNTANH; t3.pscale = sv->bn_scale; t3.pshift = sv->bn_shift; }
     t3.dW = g->w3; t3.lddw = PC_H; t3.db = g->b3; t3.accumulate = accumulate; t3.slabs = w.slabs;
     t3.slab_floats = w.slab_floats;
-    PC_TRY(launch_gemm_tn(t3, st));
+    if (sv->a1) {
+        // as two 128 x 256 halves of the output rows: the 256 x 256 tile needs 8 blocks per wave at 256 registers (six splits
+        // and a spill per 48 MFMAs: 102 us); the half-size kernel runs 44 us per half (scripts/dev/nt_decompose.sh; same box,
+        // whole step: 1.068 -> 1.062 ms)
+        for (int half = 0; half < 2; half++) {
+            TnArgs th = t3;
+            th.Z = w.dz2 + half * (PC_H / 2); th.No = PC_H / 2;
+            th.dW = g->w3 + (size_t)half * (PC_H / 2) * PC_H; th.db = g->b3 + half * (PC_H / 2);
+            PC_TRY(launch_gemm_tn(th, st));
+        }
+    } else {
+        PC_TRY(launch_gemm_tn(t3, st));
+    }
     if (local_sums) {
         PC_LAUNCH(bn_fold_kernel, dim3(PC_H / FIN_COLS), dim3(FIN_COLS, FIN_LANES), 0, st, w.stat_a, w.stat_b, si, local_sums);
         PC_TRY(pc_launch_status());
