@@ -20,9 +20,9 @@ rows = [
     ("gemm_nt_kernel<2, 2, 16, 3, false, 0, 0>", "Linear5 / K|V projection / dKeys (3 launches, mean)", (R + 2 * nbc) / 3, 2 * D * H, 4 * (D + H)),
     ("gemm_nt_kernel<2, 2, 16, 3, false, 3, 0>", "dZ2 = dY W5 * tanh' (aux A2)", R, 2 * D * H, 4 * (D + H + H)),
     ("gemm_nt_kernel<2, 2, 16, 3, false, 4, 2>", "dZ1 = dZ2 W3 * tanh'(BN) + BN-bwd sums (aux H0)", R, 2 * H * H, 4 * (H + H + H)),
-    ("gemm_tn8_kernel<2, 4, 4, 2, 32, 2, false, false>", "dW3 = dZ2^T A1", R, 2 * H * H, 4 * (H + H)),
+    ("gemm_tn8_kernel<2, 4, 4, 2, 32, 2, false, false>", "dW3 = dZ2^T A1 (whole 256 x 256 tile: builds before the split into halves)", R, 2 * H * H, 4 * (H + H)),
     ("gemm_tn8_kernel<4, 2, 2, 2, 16, 3, false, true>", "dW0 = BNbwd(dZ1)^T x (aux H0, gathered x)", R, 2 * D * H, 4 * (H + H + D)),
-    ("gemm_tn8_kernel<2, 4, 2, 2, 32, 2, false, false>", "dW5 = dY^T A2", R, 2 * D * H, 4 * (D + H)),
+    ("gemm_tn8_kernel<2, 4, 2, 2, 32, 2, false, false>", "dW5 = dY^T A2 and the two halves of dW3 = dZ2^T A1 (mean of 3)", R, 2 * D * H, 4 * (D + H + (H - D) * 2 / 3)),
     ("gemm_tn8_kernel<4, 2, 2, 2, 32, 2, false, false>", "dW_kv = dKV^T keys", nbc, 2 * D * H, 4 * (D + H)),
 ]
 steps = None
