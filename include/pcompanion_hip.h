@@ -43,7 +43,7 @@ extern "C" {
 
 /* 3: pc_ffn_saved gained the optional `a1` member (round 2; a caller built against version 2 passes a shorter struct);
  * 2: pc_p2v_tensors / pc_joint_tensors gained `dropout` (and `dim`). */
-#define PC_ABI_VERSION 3
+#define PC_ABI_VERSION 4
 int pc_abi_version(void);
 
 /* Training-mode dropout (config.py:12 DROPOUT = 0.1 is live in every reference training step: the attention
@@ -139,12 +139,16 @@ int pc_p2v_ffn_backward(const pc_p2v_tensors *p, const pc_p2v_tensors *g, const 
                         size_t ws_bytes, void *stream);
 
 /* P7: Product2Vec.apply_attention -> nn.MultiheadAttention(128, 4 heads), ONE query token
- * per sample, keys == values == neighbour embeddings, no key-padding mask, dropout 0
+ * per sample, keys == values == neighbour embeddings, no key-padding mask, attention-weight dropout p->dropout
  * (product2vec.py:48-68).  query[B,D], keys[B*N,D] -> out[B,D].
- * Saved for backward: q[B,D] (projected, unscaled), kv[B*N,2D] (K | V), probs[B,HEADS,N],
- * ctx[B,D] (pre-out_proj).  ws: pc_p2v_attention_workspace_bytes(B,N). */
+ * With ONE query token the K and V projections of the key rows are absorbed into the per-sample side (exact algebra,
+ * csrc/attention.hip): score = (Wk_h^T q_h / sqrt(hd)) . key + const, ctx_h = Wv_h (sum_n pm_n key_n) + bv_h sum_n pm_n;
+ * no [B*N, 2D] K|V buffer exists.
+ * Saved for backward: q[B,D] (projected, unscaled), qt[B,HEADS,D] (Wk_h^T q_h), probs[B,HEADS,N] (before dropout),
+ * c[B,HEADS,D] (sum_n pm_n key_n), sp[B,HEADS] (sum_n pm_n), ctx[B,D] (pre-out_proj).
+ * ws: pc_p2v_attention_workspace_bytes(B,N). */
 typedef struct {
-    float *q, *kv, *probs, *ctx;
+    float *q, *qt, *probs, *c, *sp, *ctx;
 } pc_attn_saved;
 size_t pc_p2v_attention_workspace_bytes(int batch, int n_keys);                       /* D = 128 */
 size_t pc_p2v_attention_workspace_bytes_dim(int batch, int n_keys, int dim);          /* D = 128 or 256 */

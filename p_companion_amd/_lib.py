@@ -44,7 +44,7 @@ class FfnSaved(ctypes.Structure):
 
 
 class AttnSaved(ctypes.Structure):
-    _fields_ = [(n, ctypes.c_void_p) for n in ("q", "kv", "probs", "ctx")]
+    _fields_ = [(n, ctypes.c_void_p) for n in ("q", "qt", "probs", "c", "sp", "ctx")]
 
 
 class JointTensors(ctypes.Structure):

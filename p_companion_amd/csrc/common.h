@@ -296,6 +296,9 @@ struct NtArgs {
     const float* escale; const float* eshift;                    // [nseg][N]
     int stats; float* stat_sum; float* stat_aux;                 // [ntiles][N] each
     const float* mean; const float* invstd;                      // [nseg][N] for NT_STAT_BNBWD
+    // few-row kernel only: the bias of row m is scaled by brs[m * ldbrs] (null: 1).  The value projection of the
+    // absorbed attention: ctx_h = Wv_h c_h + bv_h * sum_n(p_n m_n), where the sum is 1 only without dropout
+    const float* brs; int ldbrs;
 };
 int launch_gemm_nt(const NtArgs& a, hipStream_t st);
 int gemm_nt_tiles(const SegInfo& si);
@@ -305,7 +308,10 @@ struct NtSmallGroup { NtArgs a[PC_NT_GROUP]; int ks_log2[PC_NT_GROUP], block0[PC
 int launch_gemm_nt_group(const NtArgs* args, int n, hipStream_t st);
 
 struct TransposeJob { const float* in; float* out; int rows, cols; };   // out[c][r] = in[r][c]
-struct TransposeBatch { TransposeJob job[4]; int n; };
+#define PC_TRANSPOSE_JOBS 8
+// zero / nzero (optional): floats the launch also clears (the key-bias gradient of the absorbed attention is exactly 0;
+// a separate fill would be one more launch boundary)
+struct TransposeBatch { TransposeJob job[PC_TRANSPOSE_JOBS]; int n; float* zero; int nzero; };
 int launch_transpose_batch(const TransposeBatch& tb, hipStream_t st);
 
 struct TnArgs {
@@ -327,20 +333,30 @@ struct TnArgs {
     int accumulate;                                              // 1: +=, 0: overwrite
     float* slabs; size_t slab_floats;                            // workspace
 };
-int launch_gemm_tn(const TnArgs& a, hipStream_t st);
+// Deferred slab sums: with a TnDefer the product launches append their reduce job to the list instead of launching
+// tn_reduce themselves, and ONE tn_reduce_group launch folds every weight gradient of the step (the products' slab
+// regions must then be distinct and stay untouched until launch_tn_reduce_deferred).  Five reduce launches of ~9 us
+// per Product2Vec step became one.
+struct TnDefer;
+int launch_gemm_tn(const TnArgs& a, hipStream_t st, TnDefer* defer = nullptr);
 size_t gemm_tn_workspace_floats(int R, int No, int Ni);
 // up to PC_TN_GROUP small independent products (disjoint slab regions) as one launch + one reduce; the reduce can
 // take PC_TN_EXTRA further slab sets that other kernels filled (the joint step's type-table scatter-adds)
-#define PC_TN_GROUP 6
+#define PC_TN_GROUP 10
 #define PC_TN_EXTRA 2
-#define PC_TN_RGROUP (PC_TN_GROUP + PC_TN_EXTRA)
+#define PC_TN_RGROUP (PC_TN_GROUP + PC_TN_EXTRA + 4)      // + the four large FFN gradients when a step's reduces are deferred
 struct TnGroup { TnArgs a[PC_TN_GROUP]; int tiles_i[PC_TN_GROUP], nsplit[PC_TN_GROUP], rps[PC_TN_GROUP], block0[PC_TN_GROUP + 1], n; };
 struct TnReduceJob { const float* slabs; int nsplit, n; float* out; int accumulate; };   // out[n] (+)= sum of nsplit slabs of n floats
 struct TnReduceGroup {
     const float* slabs[PC_TN_RGROUP]; float* dW[PC_TN_RGROUP]; float* db[PC_TN_RGROUP];
     int nsplit[PC_TN_RGROUP], n_w[PC_TN_RGROUP], n_b[PC_TN_RGROUP], accumulate[PC_TN_RGROUP], block0[PC_TN_RGROUP + 1], n;
 };
-int launch_gemm_tn_group(const TnArgs* args, int n, const TnReduceJob* extra, int n_extra, hipStream_t st);
+struct TnDefer { TnReduceGroup r; int rblocks; };
+static_assert(sizeof(TnGroup) <= 4096, "kernel argument segment");
+int launch_gemm_tn_group(const TnArgs* args, int n, const TnReduceJob* extra, int n_extra, hipStream_t st,
+                         TnDefer* defer = nullptr);
+int launch_tn_reduce_deferred(TnDefer* d, hipStream_t st);
+static inline void tn_defer_init(TnDefer* d) { d->r = TnReduceGroup{}; d->rblocks = 0; }
 int scatter_add_slab_blocks(int table_rows, int rows, int width);
 int launch_scatter_add_slabs(const int32_t* idx, int rows, int width, int table_rows, const float* src, float* slabs,
                              hipStream_t st);

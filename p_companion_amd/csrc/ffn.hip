@@ -193,6 +193,8 @@ __global__ void transpose_batch_kernel(TransposeBatch tb) {
     __shared__ float t[32][33];
     const TransposeJob j = tb.job[blockIdx.z];
     const int bx = blockIdx.x * 32, by = blockIdx.y * 32;
+    if (tb.zero && blockIdx.x + blockIdx.y + blockIdx.z == 0)
+        for (int i = threadIdx.y * 32 + threadIdx.x; i < tb.nzero; i += 256) tb.zero[i] = 0.f;
     if (bx >= j.cols || by >= j.rows) return;
     for (int i = threadIdx.y; i < 32; i += 8) {
         const int r = by + i, c = bx + threadIdx.x;
@@ -229,7 +231,9 @@ struct FfnWs {
     float *w5t, *w3t, *w0t;     // transposed weights
     float *c1, *c2;             // [MAX_SEG][H]
     float *coef;                // eval: scale, shift [2][H]
-    float *slabs; size_t slab_floats;
+    // one region per weight gradient (dW5, the two halves of dW3, dW0): their slab sums are folded by ONE launch at the
+    // end of the step (TnDefer), so no region may be reused in between
+    float *slabs[4]; size_t slab_floats;
     size_t total;
 };
 
@@ -255,7 +259,7 @@ static FfnWs ffn_ws_layout(void* base, int rows) {
     w.slab_floats = gemm_tn_workspace_floats(rows, PC_H, PC_H);
     for (size_t f : {gemm_tn_workspace_floats(rows, PC_D, PC_H), gemm_tn_workspace_floats(rows, PC_H, PC_D)})
         if (f > w.slab_floats) w.slab_floats = f;
-    w.slabs = take(w.slab_floats);
+    for (int i = 0; i < 4; i++) w.slabs[i] = take(w.slab_floats);
     w.total = off;
     return w;
 }
@@ -362,23 +366,39 @@ extern "C" int pc_p2v_ffn_forward_eval(const pc_p2v_tensors* p, const float* tab
 
 // part 1: everything up to the BN-backward partial sums (+ this replica's folded sums into `local_sums`);
 // part 2: dgamma/dbeta (local rows), BN-backward coefficients (from `global_sums` when given), dW0/db0 (/dx)
+// the transposed weights the backward multiplies by (W5^T, W3^T, and W0^T for a dx consumer) as jobs of a transpose launch
+int ffn_transposes(const pc_p2v_tensors* p, void* ws, int rows, int with_dx, TransposeBatch* tb) {
+    FfnWs w = ffn_ws_layout(ws, rows);
+    const int D = p2v_dim(p);
+    if (tb->n + 2 + (with_dx ? 1 : 0) > PC_TRANSPOSE_JOBS) return PC_EINVAL;
+    tb->job[tb->n++] = {p->w5, w.w5t, D, PC_H};                      // [D,H] -> [H,D]
+    tb->job[tb->n++] = {p->w3, w.w3t, PC_H, PC_H};
+    if (with_dx) tb->job[tb->n++] = {p->w0, w.w0t, PC_H, D};         // [H,D] -> [D,H]
+    return PC_OK;
+}
+
+// transposed != 0: ffn_transposes' products are in the workspace already (the fused step forms every transposed weight
+// of the step in one launch).  defer (optional): the slab sums join the caller's list instead of being launched here.
 int ffn_backward_part1(const pc_p2v_tensors* p, const pc_p2v_tensors* g, const float* table, const int32_t* idx,
                        int rows, const pc_segments* seg, const float* dy, const pc_ffn_saved* sv, int with_dx,
-                       int accumulate, double* local_sums, void* ws, size_t ws_bytes, void* stream) {
+                       int accumulate, double* local_sums, void* ws, size_t ws_bytes, void* stream, int transposed,
+                       TnDefer* defer) {
     PC_TRY(ffn_check(p, table, rows, seg, ws, ws_bytes));
     if (!g || !dy || !sv || !sv->h0 || !sv->a2) return PC_EINVAL;
     if (!g->w0 || !g->b0 || !g->gamma || !g->beta || !g->w3 || !g->b3 || !g->w5 || !g->b5) return PC_EINVAL;
     hipStream_t st = (hipStream_t)stream;
     const SegInfo si = make_seginfo(seg, rows, 128);
     FfnWs w = ffn_ws_layout(ws, rows);
+    TnDefer own;
+    tn_defer_init(&own);
+    TnDefer* df = defer ? defer : &own;
 
     const int D = p2v_dim(p);
-    TransposeBatch tb = {};
-    tb.job[0] = {p->w5, w.w5t, D, PC_H};                      // [D,H] -> [H,D]
-    tb.job[1] = {p->w3, w.w3t, PC_H, PC_H};
-    tb.n = 2;
-    if (with_dx) tb.job[tb.n++] = {p->w0, w.w0t, PC_H, D};         // [H,D] -> [D,H]
-    PC_TRY(launch_transpose_batch(tb, st));
+    if (!transposed) {
+        TransposeBatch tb = {};
+        PC_TRY(ffn_transposes(p, ws, rows, with_dx, &tb));
+        PC_TRY(launch_transpose_batch(tb, st));
+    }
 
     // dZ2 = (dY W5) * (1 - A2^2)
     NtArgs b1 = nt_plain(dy, D, w.w5t, D, nullptr, w.dz2, PC_H, rows, PC_H, D, si);
@@ -388,9 +408,9 @@ int ffn_backward_part1(const pc_p2v_tensors* p, const pc_p2v_tensors* g, const f
     // dW5 = dY^T A2, db5
     TnArgs t5 = {};
     t5.Z = dy; t5.ldz = D; t5.A = sv->a2; t5.lda = PC_H; t5.R = rows; t5.No = D; t5.Ni = PC_H; t5.seg = si;
-    t5.dW = g->w5; t5.lddw = PC_H; t5.db = g->b5; t5.accumulate = accumulate; t5.slabs = w.slabs;
+    t5.dW = g->w5; t5.lddw = PC_H; t5.db = g->b5; t5.accumulate = accumulate; t5.slabs = w.slabs[0];
     t5.slab_floats = w.slab_floats;
-    PC_TRY(launch_gemm_tn(t5, st));
+    PC_TRY(launch_gemm_tn(t5, st, df));
 
     // dZ1 = (dZ2 W3) * (1 - A1^2), A1 = tanh(BN(H0)); plus BN-backward partial sums
     NtArgs b2 = nt_plain(w.dz2, PC_H, w.w3t, PC_H, nullptr, w.dz1, PC_H, rows, PC_H, PC_H, si);
@@ -403,7 +423,7 @@ int ffn_backward_part1(const pc_p2v_tensors* p, const pc_p2v_tensors* g, const f
     TnArgs t3 = {};
     t3.Z = w.dz2; t3.ldz = PC_H; t3.A = sv->a1 ? sv->a1 : sv->h0; t3.lda = PC_H; t3.R = rows; t3.No = PC_H; t3.Ni = PC_H; t3.seg = si;
     if (!sv->a1) { t3.prologue = NT_PRO_BNTANH; t3.pscale = sv->bn_scale; t3.pshift = sv->bn_shift; }
-    t3.dW = g->w3; t3.lddw = PC_H; t3.db = g->b3; t3.accumulate = accumulate; t3.slabs = w.slabs;
+    t3.dW = g->w3; t3.lddw = PC_H; t3.db = g->b3; t3.accumulate = accumulate; t3.slabs = w.slabs[1];
     t3.slab_floats = w.slab_floats;
     if (sv->a1) {
         // as two 128 x 256 halves of the output rows: the 256 x 256 tile needs 8 blocks per wave at 256 registers (six splits
@@ -413,21 +433,24 @@ int ffn_backward_part1(const pc_p2v_tensors* p, const pc_p2v_tensors* g, const f
             TnArgs th = t3;
             th.Z = w.dz2 + half * (PC_H / 2); th.No = PC_H / 2;
             th.dW = g->w3 + (size_t)half * (PC_H / 2) * PC_H; th.db = g->b3 + half * (PC_H / 2);
-            PC_TRY(launch_gemm_tn(th, st));
+            th.slabs = w.slabs[1 + half];
+            PC_TRY(launch_gemm_tn(th, st, df));
         }
     } else {
-        PC_TRY(launch_gemm_tn(t3, st));
+        PC_TRY(launch_gemm_tn(t3, st, df));
     }
     if (local_sums) {
         PC_LAUNCH(bn_fold_kernel, dim3(PC_H / FIN_COLS), dim3(FIN_COLS, FIN_LANES), 0, st, w.stat_a, w.stat_b, si, local_sums);
         PC_TRY(pc_launch_status());
     }
+    if (!defer) PC_TRY(launch_tn_reduce_deferred(&own, st));
     return PC_OK;
 }
 
 int ffn_backward_part2(const pc_p2v_tensors* g, const float* table, const int32_t* idx, int rows,
                        const pc_segments* seg, const pc_ffn_saved* sv, float* dx, int accumulate,
-                       const double* local_sums, const double* global_sums, void* ws, size_t ws_bytes, void* stream) {
+                       const double* local_sums, const double* global_sums, void* ws, size_t ws_bytes, void* stream,
+                       TnDefer* defer) {
     hipStream_t st = (hipStream_t)stream;
     const SegInfo si = make_seginfo(seg, rows, 128);
     FfnWs w = ffn_ws_layout(ws, rows);
@@ -441,7 +464,7 @@ int ffn_backward_part2(const pc_p2v_tensors* g, const float* table, const int32_
     TnArgs t0 = {};
     t0.Z = w.dz1; t0.ldz = PC_H; t0.A = table; t0.lda = D; t0.gather = idx; t0.R = rows; t0.No = PC_H;
     t0.Ni = D; t0.seg = si;
-    t0.dW = g->w0; t0.lddw = D; t0.db = g->b0; t0.accumulate = accumulate; t0.slabs = w.slabs;
+    t0.dW = g->w0; t0.lddw = D; t0.db = g->b0; t0.accumulate = accumulate; t0.slabs = w.slabs[3];
     t0.slab_floats = w.slab_floats;
     if (dx) {
         int blocks = (rows + 3) / 4;
@@ -453,7 +476,7 @@ int ffn_backward_part2(const pc_p2v_tensors* g, const float* table, const int32_
         t0.zaux = sv->h0; t0.ldzaux = PC_H;
         t0.z_mean = sv->bn_mean; t0.z_invstd = sv->bn_invstd; t0.z_scale = sv->bn_scale; t0.z_c1 = w.c1; t0.z_c2 = w.c2;
     }
-    PC_TRY(launch_gemm_tn(t0, st));
+    PC_TRY(launch_gemm_tn(t0, st, defer));
 
     if (dx) {
         NtArgs b3 = nt_plain(w.dz1, PC_H, w.w0t, PC_H, nullptr, dx, D, rows, D, PC_H, si);
@@ -466,6 +489,9 @@ extern "C" int pc_p2v_ffn_backward(const pc_p2v_tensors* p, const pc_p2v_tensors
                                    const int32_t* idx, int rows, const pc_segments* seg, const float* dy,
                                    const pc_ffn_saved* sv, float* dx, int accumulate, void* ws, size_t ws_bytes,
                                    void* stream) {
-    PC_TRY(ffn_backward_part1(p, g, table, idx, rows, seg, dy, sv, dx != nullptr, accumulate, nullptr, ws, ws_bytes, stream));
-    return ffn_backward_part2(g, table, idx, rows, seg, sv, dx, accumulate, nullptr, nullptr, ws, ws_bytes, stream);
+    TnDefer df;
+    tn_defer_init(&df);
+    PC_TRY(ffn_backward_part1(p, g, table, idx, rows, seg, dy, sv, dx != nullptr, accumulate, nullptr, ws, ws_bytes, stream, 0, &df));
+    PC_TRY(ffn_backward_part2(g, table, idx, rows, seg, sv, dx, accumulate, nullptr, nullptr, ws, ws_bytes, stream, &df));
+    return launch_tn_reduce_deferred(&df, (hipStream_t)stream);
 }

@@ -563,9 +563,10 @@ __device__ __forceinline__ void nt_small_body(const NtArgs& a, int ks_log2, int 
             for (int q = 0; q < 4; q++)
                 if (col + q < a.N) ax[q] = a.aux[(size_t)row * a.ldaux + col + q];
         }
+        const float rs = a.brs ? a.brs[(size_t)row * a.ldbrs] : 1.f;
 #pragma unroll
         for (int q = 0; q < 4; q++) {
-            float x = v[q] + bias[q];
+            float x = v[q] + (a.brs ? bias[q] * rs : bias[q]);
             switch (EPI) {
                 case NT_EPI_TANH: x = fast_tanh(x); break;
                 case NT_EPI_RELU: x = x > 0.f ? x : 0.f; break;
@@ -657,12 +658,14 @@ static void launch_variant(const NtArgs& a, int ntm, hipStream_t st) {
     }
 }
 
+static bool nt_small_ok(const NtArgs& a);
 int launch_gemm_nt(const NtArgs& a, hipStream_t st) {
     if (!a.A || !a.W || !a.C || a.M <= 0 || a.N <= 0 || a.K <= 0) return PC_EINVAL;
     if (a.K % 4 != 0 || a.lda % 4 != 0 || a.ldw % 4 != 0) return PC_ESHAPE;
     if (((uintptr_t)a.A | (uintptr_t)a.W | (uintptr_t)a.C) & 15) return PC_ESHAPE;
     if (a.aux && ((uintptr_t)a.aux & 15)) return PC_ESHAPE;
     const int ntm = gemm_nt_tiles(a.seg);
+    if (a.brs && !nt_small_ok(a)) return PC_ESHAPE;               // per-row bias scale: few-row kernel only
     if (ntm <= 0) return PC_EINVAL;
     if (a.prologue == NT_PRO_BNTANH && (!a.pscale || !a.pshift)) return PC_EINVAL;
     if (a.prologue == NT_PRO_BNTANH && a.K > 256) return PC_ESHAPE;      // scale/shift live in LDS

@@ -516,13 +516,39 @@ static void tn_plan(int R, int No, int Ni, int* nsplit, int* rows_per_split) {
     *rows_per_split = rps;
 }
 
+// An upper bound of the plan's slab count that is MONOTONE in R: workspaces are laid out for the largest row count a
+// call may see and used with the actual one, and the plan itself is not monotone (R = 8192 splits 256 ways, R = 19969
+// only 209 ways because rows_per_split is rounded up to whole chunks).
 size_t gemm_tn_workspace_floats(int R, int No, int Ni) {
-    int s, rps;
-    tn_plan(R, No, Ni, &s, &rps);
+    const int tiles = ((No + TM - 1) / TM) * ((Ni + TM - 1) / TM);
+    int cap = (512 + tiles - 1) / tiles;
+    if (No <= 256 && Ni <= 256 && (No > 128 || Ni > 128) && No % 64 == 0 && Ni % 64 == 0 && cap < 256) cap = 256;
+    int s = (R + 63) / 64;
+    if (s > cap) s = cap;
+    if (s < 1) s = 1;
     return (size_t)s * ((size_t)No * Ni + No);
 }
 
-int launch_gemm_tn(const TnArgs& a, hipStream_t st) {
+// appends one slab sum to a deferred list; the slab regions of a list must be pairwise disjoint (they are all read
+// by the one reduce launch at the end)
+static int tn_defer_push(TnDefer* d, const float* slabs, size_t slab_floats, int nsplit, int n_w, int n_b, float* dW,
+                         float* db, int accumulate) {
+    if (d->r.n >= PC_TN_RGROUP) return PC_EINVAL;
+    const size_t used = (size_t)nsplit * ((size_t)n_w + n_b);
+    if (used > slab_floats) return PC_EWORKSPACE;
+    for (int k = 0; k < d->r.n; k++) {
+        const float* lo = d->r.slabs[k];
+        const float* hi = lo + (size_t)d->r.nsplit[k] * ((size_t)d->r.n_w[k] + d->r.n_b[k]);
+        if (slabs < hi && lo < slabs + used) return PC_EINVAL;
+    }
+    const int k = d->r.n++;
+    d->r.slabs[k] = slabs; d->r.nsplit[k] = nsplit; d->r.n_w[k] = n_w; d->r.n_b[k] = n_b; d->r.dW[k] = dW; d->r.db[k] = db;
+    d->r.accumulate[k] = accumulate; d->r.block0[k] = d->rblocks;
+    d->rblocks += ((n_w + (db ? n_b : 0)) / 4 * 8 + 255) / 256;
+    return PC_OK;
+}
+
+int launch_gemm_tn(const TnArgs& a, hipStream_t st, TnDefer* defer) {
     if ((!a.Z && !a.z_onehot) || !a.A || !a.dW || !a.slabs || a.R <= 0 || a.No <= 0 || a.Ni <= 0) return PC_EINVAL;
     if (a.No % 4 || a.Ni % 4 || (a.Z && a.ldz % 4) || a.lda % 4 || a.lddw != a.Ni) return PC_ESHAPE;
     if (a.z_onehot && (a.zaux || tn_full_tile(a.R, a.No, a.Ni))) return PC_ESHAPE;     // few-row kernel only
@@ -552,14 +578,24 @@ int launch_gemm_tn(const TnArgs& a, hipStream_t st) {
     PC_TRY(pc_launch_status());
     const int n_w = a.No * a.Ni, n_b = a.No;
     const int threads = (n_w + (a.db ? n_b : 0)) / 4 * 8;
+    if (defer) return tn_defer_push(defer, a.slabs, a.slab_floats, nsplit, n_w, n_b, a.dW, a.db, a.accumulate);
     PC_LAUNCH(tn_reduce_kernel, dim3((threads + 255) / 256), dim3(256), 0, st, a.slabs, nsplit, n_w, n_b,
                        a.dW, a.db, a.accumulate);
     return pc_launch_status();
 }
 
+int launch_tn_reduce_deferred(TnDefer* d, hipStream_t st) {
+    if (!d) return PC_EINVAL;
+    if (d->r.n == 0) return PC_OK;
+    for (int k = d->r.n; k <= PC_TN_RGROUP; k++) d->r.block0[k] = d->rblocks;
+    PC_LAUNCH(tn_reduce_group_kernel, dim3(d->rblocks), dim3(256), 0, st, d->r);
+    tn_defer_init(d);
+    return pc_launch_status();
+}
+
 // n <= PC_TN_GROUP independent products whose slab regions do not overlap.  Products that qualify for the full-tile
 // kernels (many rows) are launched on their own.
-int launch_gemm_tn_group(const TnArgs* args, int n, const TnReduceJob* extra, int n_extra, hipStream_t st) {
+int launch_gemm_tn_group(const TnArgs* args, int n, const TnReduceJob* extra, int n_extra, hipStream_t st, TnDefer* defer) {
     if (!args || n < 1 || n > PC_TN_GROUP || n_extra < 0 || n_extra > PC_TN_EXTRA || (n_extra && !extra)) return PC_EINVAL;
     TnGroup g = {};
     TnReduceGroup r = {};
@@ -578,7 +614,7 @@ int launch_gemm_tn_group(const TnArgs* args, int n, const TnReduceJob* extra, in
     const double thin = planned > 512 ? 512.0 / planned : 1.0;
     for (int i = 0; i < n; i++) {
         const TnArgs& a = args[i];
-        if (tn_full_tile(a.R, a.No, a.Ni) || a.prologue != NT_PRO_NONE) { PC_TRY(launch_gemm_tn(a, st)); continue; }
+        if (tn_full_tile(a.R, a.No, a.Ni) || a.prologue != NT_PRO_NONE) { PC_TRY(launch_gemm_tn(a, st, defer)); continue; }
         if ((!a.Z && !a.z_onehot) || !a.A || !a.dW || !a.slabs || a.R <= 0 || a.No <= 0 || a.Ni <= 0) return PC_EINVAL;
         if (a.No % 4 || a.Ni % 4 || (a.Z && a.ldz % 4) || a.lda % 4 || a.lddw != a.Ni) return PC_ESHAPE;
         if (a.z_onehot && a.zaux) return PC_EINVAL;
@@ -624,6 +660,12 @@ int launch_gemm_tn_group(const TnArgs* args, int n, const TnReduceJob* extra, in
         PC_LAUNCH(gemm_tn_group_kernel, dim3(blocks), dim3(256), 0, st, g);
         pc_prof_end(pb, st);
         PC_TRY(pc_launch_status());
+    }
+    if (defer) {
+        for (int k = 0; k < r.n; k++)
+            PC_TRY(tn_defer_push(defer, r.slabs[k], (size_t)r.nsplit[k] * ((size_t)r.n_w[k] + r.n_b[k]), r.nsplit[k], r.n_w[k],
+                                 r.n_b[k], r.dW[k], r.db[k], r.accumulate[k]));
+        return PC_OK;
     }
     PC_LAUNCH(tn_reduce_group_kernel, dim3(rblocks), dim3(256), 0, st, r);
     return pc_launch_status();

@@ -466,4 +466,4 @@ extern "C" int pc_check_indices(const int32_t* const* idx, const int* n, const i
     return pc_launch_status();
 }
 
-extern "C" int pc_abi_version(void) { return 3; }
+extern "C" int pc_abi_version(void) { return PC_ABI_VERSION; }

@@ -10,7 +10,7 @@ static inline size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
 struct StepWs {
     int32_t* idx_all;
     float *y, *h0, *a2, *a1, *bn;     // bn: mean, invstd, scale, shift  [4][MAX_SEG][H]
-    float *q, *kv, *probs, *ctx, *emb;
+    float *q, *qt, *probs, *c, *sp, *ctx, *emb;
     float *dy, *demb, *dpos_tmp, *dneg_tmp;
     void* ffn_ws; size_t ffn_bytes;
     void* attn_ws; size_t attn_bytes;
@@ -33,7 +33,9 @@ static StepWs step_ws_layout(void* base, int B, int N, int K, int D) {
     w.a1 = (float*)take(R * PC_H * 4);
     w.bn = (float*)take(4 * PC_MAX_SEG * PC_H * 4);
     w.q = (float*)take((size_t)B * D * 4);
-    w.kv = (float*)take((size_t)B * (N > 0 ? N : 1) * 2 * D * 4);
+    w.qt = (float*)take((size_t)B * PC_HEADS * D * 4);
+    w.c = (float*)take((size_t)B * PC_HEADS * D * 4);
+    w.sp = (float*)take((size_t)B * PC_HEADS * 4);
     w.probs = (float*)take((size_t)B * PC_HEADS * (N > 0 ? N : 1) * 4);
     w.ctx = (float*)take((size_t)B * D * 4);
     w.emb = (float*)take((size_t)B * D * 4);
@@ -76,17 +78,22 @@ int ffn_forward_part2(const pc_p2v_tensors* p, int rows, const pc_segments* seg,
                       const pc_ffn_saved* sv, const double* global_sums, void* ws, size_t ws_bytes, void* stream);
 int ffn_backward_part1(const pc_p2v_tensors* p, const pc_p2v_tensors* g, const float* table, const int32_t* idx,
                        int rows, const pc_segments* seg, const float* dy, const pc_ffn_saved* sv, int with_dx,
-                       int accumulate, double* local_sums, void* ws, size_t ws_bytes, void* stream);
+                       int accumulate, double* local_sums, void* ws, size_t ws_bytes, void* stream, int transposed,
+                       TnDefer* defer);
 int ffn_backward_part2(const pc_p2v_tensors* g, const float* table, const int32_t* idx, int rows,
                        const pc_segments* seg, const pc_ffn_saved* sv, float* dx, int accumulate,
-                       const double* local_sums, const double* global_sums, void* ws, size_t ws_bytes, void* stream);
+                       const double* local_sums, const double* global_sums, void* ws, size_t ws_bytes, void* stream,
+                       TnDefer* defer);
+int ffn_transposes(const pc_p2v_tensors* p, void* ws, int rows, int with_dx, TransposeBatch* tb);
+int attention_transposes(const pc_p2v_tensors* p, void* ws, int B, int N, int key_rows, TransposeBatch* tb, float* zero_bk);
 int attention_forward_impl(const pc_p2v_tensors* p, const float* query, const float* keys, int B, int N,
                            int key_rows, const int32_t* slot_row, float* out, const pc_attn_saved* sv, void* ws,
-                           size_t ws_bytes, void* stream);
+                           size_t ws_bytes, void* stream, int transposed);
 int attention_backward_impl(const pc_p2v_tensors* p, const pc_p2v_tensors* g, const float* query, const float* keys,
                             int B, int N, int key_rows, const int32_t* slot_row, int pad_row, const float* dout,
                             const pc_attn_saved* sv, float* dquery, float* dkeys, int accumulate, void* ws,
-                            size_t ws_bytes, void* stream, const int32_t* ref_off, const int32_t* ref_slot);
+                            size_t ws_bytes, void* stream, const int32_t* ref_off, const int32_t* ref_slot,
+                            int transposed, TnDefer* defer);
 
 // nb_idx: neighbour rows of the step, nbc of them.  Dense layout: nbc = B*N slots in slot order
 // (slot_row NULL).  Compact layout: the M real neighbours then one -1 row (nbc = M + 1), slot_row[B*N]
@@ -144,15 +151,23 @@ static int p2v_step_impl(const pc_p2v_tensors* p, const pc_p2v_tensors* g, const
     }
     if (p2 && !p1)
         return ffn_backward_part2(g, table, w.idx_all, R, &seg, &sv, nullptr, 0, bwd_local, bwd_global, w.ffn_ws,
-                                  w.ffn_bytes, stream);
+                                  w.ffn_bytes, stream, nullptr);
+    // every transposed weight of the step (attention: Wo^T, Wq^T, [Wk;Wv]^T; FFN backward: W5^T, W3^T) in ONE launch,
+    // which also clears the key-bias gradient (exactly 0, see attention.hip)
+    {
+        TransposeBatch tb = {};
+        PC_TRY(ffn_transposes(p, w.ffn_ws, R, 0, &tb));
+        if (N > 0) PC_TRY(attention_transposes(p, w.attn_ws, B, N, slot_row ? nbc : B * N, &tb, g->in_proj_b + D));
+        PC_TRY(launch_transpose_batch(tb, st));
+    }
     PC_TRY(ffn_forward_part2(p, R, &seg, 1, w.y, &sv, phase == 1 ? fwd_sums : nullptr, w.ffn_ws, w.ffn_bytes, stream));
 
     pc_attn_saved as;
-    as.q = w.q; as.kv = w.kv; as.probs = w.probs; as.ctx = w.ctx;
+    as.q = w.q; as.qt = w.qt; as.probs = w.probs; as.c = w.c; as.sp = w.sp; as.ctx = w.ctx;
     const float* emb = w.y;                     // anchor embedding = FFN output when there are no neighbours
     if (N > 0) {
         PC_TRY(attention_forward_impl(p, w.y + (size_t)rA * D, w.y + (size_t)rN * D, B, N, nbc, slot_row, w.emb,
-                                      &as, w.attn_ws, w.attn_bytes, stream));
+                                      &as, w.attn_ws, w.attn_bytes, stream, 1));
         emb = w.emb;
     }
 
@@ -164,10 +179,14 @@ static int p2v_step_impl(const pc_p2v_tensors* p, const pc_p2v_tensors* g, const
     if (anchor_emb)
         PC_HIP_TRY(hipMemcpyAsync(anchor_emb, emb, (size_t)B * D * 4, hipMemcpyDeviceToDevice, st));
 
+    // the slab sums of ALL weight gradients of the step (attention: 10 few-row products, FFN: dW5, dW3 x 2, dW0) fold in
+    // one launch at the end of the call
+    TnDefer df;
+    tn_defer_init(&df);
     if (N > 0) {
         PC_TRY(attention_backward_impl(p, g, w.y + (size_t)rA * D, w.y + (size_t)rN * D, B, N, nbc, slot_row,
                                        slot_row ? nbc - 1 : -1, w.demb, &as, w.dy + (size_t)rA * D,
-                                       w.dy + (size_t)rN * D, 0, w.attn_ws, w.attn_bytes, stream, ref_off, ref_slot));
+                                       w.dy + (size_t)rN * D, 0, w.attn_ws, w.attn_bytes, stream, ref_off, ref_slot, 1, &df));
     } else {
         PC_HIP_TRY(hipMemsetAsync(g->in_proj_w, 0, 3 * D * D * 4, st));
         PC_HIP_TRY(hipMemsetAsync(g->in_proj_b, 0, 3 * D * 4, st));
@@ -175,9 +194,10 @@ static int p2v_step_impl(const pc_p2v_tensors* p, const pc_p2v_tensors* g, const
         PC_HIP_TRY(hipMemsetAsync(g->out_proj_b, 0, D * 4, st));
     }
     PC_TRY(ffn_backward_part1(p, g, table, w.idx_all, R, &seg, w.dy, &sv, 0, 0, phase == 1 ? bwd_local : nullptr, w.ffn_ws,
-                              w.ffn_bytes, stream));
-    if (phase == 1) return PC_OK;
-    return ffn_backward_part2(g, table, w.idx_all, R, &seg, &sv, nullptr, 0, nullptr, nullptr, w.ffn_ws, w.ffn_bytes, stream);
+                              w.ffn_bytes, stream, 1, &df));
+    if (phase == 1) return launch_tn_reduce_deferred(&df, st);
+    PC_TRY(ffn_backward_part2(g, table, w.idx_all, R, &seg, &sv, nullptr, 0, nullptr, nullptr, w.ffn_ws, w.ffn_bytes, stream, &df));
+    return launch_tn_reduce_deferred(&df, st);
 }
 
 extern "C" int pc_p2v_train_step(const pc_p2v_tensors* p, const pc_p2v_tensors* g, const float* table,

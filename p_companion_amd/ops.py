@@ -197,7 +197,7 @@ def ffn_backward(params, table, idx, dy, sv, need_dx=False, grads=None, accumula
 # ----------------------------------------------------------------------------- P7
 def _attn_saved(sv):
     s = AttnSaved()
-    s.q, s.kv, s.probs, s.ctx = (sv[k].data_ptr() for k in ("q", "kv", "probs", "ctx"))
+    s.q, s.qt, s.probs, s.c, s.sp, s.ctx = (sv[k].data_ptr() for k in ("q", "qt", "probs", "c", "sp", "ctx"))
     return s
 
 
@@ -210,7 +210,9 @@ def attention_forward(params, query, keys):
     _req(keys, torch.float32, "keys", (b, n, d))
     out = torch.empty(b, d, dtype=torch.float32, device=dev)
     sv = {"q": torch.empty(b, d, dtype=torch.float32, device=dev),
-          "kv": torch.empty(b * n, 2 * d, dtype=torch.float32, device=dev),
+          "qt": torch.empty(b, HEADS, d, dtype=torch.float32, device=dev),      # Wk_h^T q_h: the key projection, absorbed
+          "c": torch.empty(b, HEADS, d, dtype=torch.float32, device=dev),       # sum_n pm_n key_n per head (value projection follows)
+          "sp": torch.empty(b, HEADS, dtype=torch.float32, device=dev),
           "probs": torch.empty(b, HEADS, n, dtype=torch.float32, device=dev),
           "ctx": torch.empty(b, d, dtype=torch.float32, device=dev)}
     nbytes = _lib.lib().pc_p2v_attention_workspace_bytes_dim(b, n, d)

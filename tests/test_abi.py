@@ -28,7 +28,7 @@ def test_library_exports_every_declared_symbol():
     L = ctypes.CDLL(_lib.LIB_PATH)
     for name in header_functions():
         assert hasattr(L, name), f"{name} declared in the header but not exported"
-    assert L.pc_abi_version() == 3
+    assert L.pc_abi_version() == 4
 
 
 def test_ctypes_table_matches_header():
