@@ -45,6 +45,15 @@ extern "C" {
  * 2: pc_p2v_tensors / pc_joint_tensors gained `dropout` (and `dim`). */
 #define PC_ABI_VERSION 4
 int pc_abi_version(void);
+/* Bitmask of the developer knobs this library was compiled with (0 = a production build).  PC_FLAG_EXP_*: a part of a
+ * GEMM loop is compiled out to price it (scripts/dev/nt_decompose.sh) -- WRONG numbers by design; *_TIMING: in-kernel
+ * clock reads.  Checked by tests/test_abi.py and __graft_entry__.build(). */
+enum {
+    PC_FLAG_EXP_NO_MFMA = 1, PC_FLAG_EXP_NO_SPLIT = 2, PC_FLAG_EXP_NO_LDSREAD = 4, PC_FLAG_EXP_NO_DMA = 8,
+    PC_FLAG_EXP_NO_SLAB = 16, PC_FLAG_EXP_STAGGER = 32, PC_FLAG_EXP_DMA_L2 = 64, PC_FLAG_NT_TIMING = 128,
+    PC_FLAG_JOINT_TIMING = 256
+};
+unsigned pc_build_flags(void);
 
 /* Training-mode dropout (config.py:12 DROPOUT = 0.1 is live in every reference training step: the attention
  * probabilities of product2vec.py:23-28 and the hidden layer of type_transition.py:13,17).  ATen's dropout stream
@@ -541,7 +550,26 @@ int pc_act_backward(const float *dy, const float *y, size_t n, int act, float *d
 int pc_sample_negatives_zipf(const int32_t *pair_ids, int batch, const int32_t *sim_pairs,
                              const int32_t *sim_rowptr, const int32_t *sim_col, int n_products, int k_neg,
                              uint64_t seed, uint64_t step, const uint32_t *octave_cum, int n_octaves,
-                             const int32_t *perm, int32_t *negative_idx, void *stream);
+                             const int32_t *perm, int32_t *negative_idx, int32_t *failed, void *stream);
+/* (`failed`, optional device int32: += 1 for every sample that ran out of its 4096 proposals -- an anchor whose positives
+ * cover the head of the popularity order, or one with fewer than k_neg eligible products; such a sample's remaining
+ * negatives are the first eligible products in rank order, -1 when none is left.  Every wave terminates.) */
+
+/* The epoch order of DataLoader(shuffle=True) (scripts/pretrain_product2vec.py:24-30, train.py:115-121) as a keyed
+ * bijection: out[i] = perm_{seed,epoch}(i), i in [0, n) -- a six-round balanced Feistel network over the even number of
+ * bits covering n, cycle-walked into [0, n).  No sort, no storage, deterministic in (seed, epoch); restated in
+ * oracle/philox_oracle.py::epoch_permutation.  (The reference's order comes from torch's CPU generator and cannot be
+ * bit-matched; parity mode replays CPython's random.shuffle on the host instead: pc_mt_shuffle.) */
+int pc_epoch_permutation(int n, uint64_t seed, uint64_t epoch, int32_t *out, void *stream);
+/* out[i][0:width] = rows[perm_{seed,epoch}(i)][0:width] (int32 rows, e.g. the labelled pairs [n,3] of
+ * ComplementaryDataset, data_loader.py:113-126): one epoch's shuffled order in one launch.  out != rows. */
+int pc_shuffle_rows_i32(const int32_t *rows, int n, int width, uint64_t seed, uint64_t epoch, int32_t *out,
+                        void *stream);
+/* collate_fn pads every neighbour list to the batch maximum (data_loader.py:186-198), so the host needs two integers per
+ * batch to size it: plan[b] = (max, sum) of deg[order[i]] over positions i in [b*batch, (b+1)*batch), i < n
+ * (order NULL: the identity).  plan: device int64 [n_batches][2]. */
+int pc_epoch_plan(const int32_t *order, const int32_t *deg, int n, int batch, int n_batches, int64_t *plan,
+                  void *stream);
 
 /* Row-sharded feature table, device-resident request bucketing (north_star: "embedding table row-shards across up
  * to 8 MI355X with RCCL all-to-all for cross-shard lookups"; the reference's table is one in-process dict,

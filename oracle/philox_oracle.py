@@ -122,3 +122,55 @@ def zipf_negatives(pair_ids, sim_pairs, sim_rowptr, sim_col, n_products, k, seed
                 got.append(c)
         out[b] = got
     return out
+
+
+# ---------------------------------------------------------------------------------------------------------
+# The loaders' epoch order on the device (csrc/sampler.hip epoch_permutation_kernel; replaces torch.randperm): a keyed
+# six-round balanced Feistel bijection over 2^k >= n (k even), cycle-walked into [0, n).  No reference counterpart
+# (DataLoader(shuffle=True) draws from torch's CPU generator, scripts/pretrain_product2vec.py:24-30): pinned only
+# against this restatement and by the bijection property.
+M64 = (1 << 64) - 1
+
+
+def _splitmix64(x):
+    x = (x + 0x9E3779B97F4A7C15) & M64
+    z = x
+    z = ((z ^ (z >> 30)) * 0xBF58476D1CE4E5B9) & M64
+    z = ((z ^ (z >> 27)) * 0x94D049BB133111EB) & M64
+    return x, z ^ (z >> 31)
+
+
+def feistel_keys(n, seed, epoch):
+    bits = 2
+    while bits < 62 and (1 << bits) < n:
+        bits += 2
+    x = (seed * 0xD1342543DE82EF95 + epoch * 0x2545F4914F6CDD1D + 0x1234567) & M64
+    keys = []
+    for _ in range(6):
+        x, z = _splitmix64(x)
+        keys.append(z >> 32)
+    return bits // 2, keys
+
+
+def epoch_permutation(n, seed, epoch):
+    half, keys = feistel_keys(n, seed, epoch)
+    mask = np.uint64((1 << half) - 1)
+    M32 = np.uint64(0xFFFFFFFF)
+
+    def apply(x):
+        L, R = x >> np.uint64(half), x & mask
+        for k in keys:
+            v = (R * np.uint64(0xCC9E2D51) + np.uint64(k)) & M32
+            v ^= v >> np.uint64(15); v = (v * np.uint64(0x85EBCA6B)) & M32
+            v ^= v >> np.uint64(13); v = (v * np.uint64(0xC2B2AE35)) & M32
+            v ^= v >> np.uint64(16)
+            L, R = R, L ^ (v & mask)
+        return (L << np.uint64(half)) | R
+
+    x = apply(np.arange(n, dtype=np.uint64))
+    while True:
+        out = x >= np.uint64(n)
+        if not out.any():
+            break
+        x[out] = apply(x[out])
+    return x.astype(np.int32)

@@ -65,6 +65,7 @@ _P = ctypes.POINTER
 # (tests/test_abi.py parses the header and checks this table and the .so against it).
 SIGNATURES = {
     "pc_abi_version": (_i, []),
+    "pc_build_flags": (ctypes.c_uint, []),
     "pc_p2v_ffn_workspace_bytes": (_sz, [_i]),
     "pc_p2v_ffn_forward_train": (_i, [_P(P2VTensors), _vp, _vp, _i, _P(Segments), _i, _vp, _P(FfnSaved), _vp, _sz, _vp]),
     "pc_p2v_ffn_forward_eval": (_i, [_P(P2VTensors), _vp, _vp, _i, _vp, _vp, _sz, _vp]),
@@ -140,7 +141,10 @@ SIGNATURES = {
     "pc_scatter_add_rows_small": (_i, [_vp, _i, _vp, _i, _i, _vp, _vp]),
     "pc_scatter_rows": (_i, [_vp, _vp, _i, _i, _vp, _vp]),
     "pc_act_backward": (_i, [_vp, _vp, _sz, _i, _vp, _vp]),
-    "pc_sample_negatives_zipf": (_i, [_vp, _i, _vp, _vp, _vp, _i, _i, _u64, _u64, _vp, _i, _vp, _vp, _vp]),
+    "pc_sample_negatives_zipf": (_i, [_vp, _i, _vp, _vp, _vp, _i, _i, _u64, _u64, _vp, _i, _vp, _vp, _vp, _vp]),
+    "pc_epoch_permutation": (_i, [_i, _u64, _u64, _vp, _vp]),
+    "pc_shuffle_rows_i32": (_i, [_vp, _i, _i, _u64, _u64, _vp, _vp]),
+    "pc_epoch_plan": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp]),
     "pc_shard_bucket": (_i, [_P(ctypes.c_void_p), _P(ctypes.c_int), _P(ctypes.c_void_p), _P(ctypes.c_int), _P(ctypes.c_void_p),
                              _i, _i, _i, _vp, _vp, _vp, _vp]),
     "pc_dropout_hidden": (_i, [_vp, _sz, _P(Dropout), _vp, _vp]),

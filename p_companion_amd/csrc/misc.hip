@@ -467,3 +467,40 @@ extern "C" int pc_check_indices(const int32_t* const* idx, const int* n, const i
 }
 
 extern "C" int pc_abi_version(void) { return PC_ABI_VERSION; }
+
+// Developer knobs compiled into THIS translation unit's build (build.py passes PC_EXTRA_HIPCC_FLAGS to every file, so
+// one unit sees them all).  The PC_EXP_* defines remove a part of a GEMM loop to price it -- such a build computes
+// WRONG numbers by design -- and the *_TIMING defines add clock reads and atomics.  A production build returns 0;
+// tests/test_abi.py and __graft_entry__.build() assert it, so a knob build can never be tested or benchmarked as the
+// product.
+extern "C" unsigned pc_build_flags(void) {
+    unsigned f = 0;
+#ifdef PC_EXP_NO_MFMA
+    f |= PC_FLAG_EXP_NO_MFMA;
+#endif
+#ifdef PC_EXP_NO_SPLIT
+    f |= PC_FLAG_EXP_NO_SPLIT;
+#endif
+#ifdef PC_EXP_NO_LDSREAD
+    f |= PC_FLAG_EXP_NO_LDSREAD;
+#endif
+#ifdef PC_EXP_NO_DMA
+    f |= PC_FLAG_EXP_NO_DMA;
+#endif
+#ifdef PC_EXP_NO_SLAB
+    f |= PC_FLAG_EXP_NO_SLAB;
+#endif
+#ifdef PC_EXP_STAGGER
+    f |= PC_FLAG_EXP_STAGGER;
+#endif
+#ifdef PC_EXP_DMA_L2
+    f |= PC_FLAG_EXP_DMA_L2;
+#endif
+#ifdef PC_NT_TIMING
+    f |= PC_FLAG_NT_TIMING;
+#endif
+#ifdef PC_JOINT_TIMING
+    f |= PC_FLAG_JOINT_TIMING;
+#endif
+    return f;
+}

@@ -339,17 +339,34 @@ extern "C" int pc_build_similarity_batch(const int32_t* pair_ids, int batch, con
 // exact: the octaves [2^j, 2^(j+1)) carry nearly equal mass under 1 / k -- an octave is picked by comparing one 32-bit
 // draw with the cumulative thresholds octave_cum[j] (computed once on the host), a rank inside it is proposed
 // uniformly (j random bits) and accepted with probability 2^j / k (r * k < 2^j * 2^32 for a third draw r).
+#define PC_ZIPF_MAX_TRIES 4096
 __global__ void zipf_negatives_kernel(const int32_t* pair_ids, int B, const int32_t* sim_pairs, const int32_t* sim_rowptr,
                                       const int32_t* sim_col, int n_products, int K, uint64_t seed, uint64_t step,
                                       const uint32_t* octave_cum, int n_octaves, const int32_t* perm,
-                                      int32_t* negative_idx) {
+                                      int32_t* negative_idx, int32_t* failed) {
     const int b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= B) return;
     const int a = sim_pairs[2 * pair_ids[b]];
     const int lo = sim_rowptr[a], hi = sim_rowptr[a + 1];
     Philox rng(seed ^ 0x5a495046ull, step, (uint32_t)b);          // its own stream ("ZIPF"), apart from the uniform sampler's
     int got = 0;
+    // Every wave must leave: an anchor whose positives cover the head of the popularity order accepts rarely, and one with
+    // fewer than K eligible products never.  After PC_ZIPF_MAX_TRIES proposals the remaining negatives are the first
+    // eligible products in rank order (deterministic; counted in `failed` so that the caller can tell), -1 if none is left.
+    int tries = 0;
     while (got < K) {
+        if (++tries > PC_ZIPF_MAX_TRIES) {
+            if (failed && got < K) atomicAdd(failed, 1);
+            for (int k1 = 0; got < K && k1 < n_products; k1++) {
+                const int c = perm ? perm[k1] : k1;
+                bool ok = c != a;
+                for (int q = lo; ok && q < hi; q++) ok = sim_col[q] != c;
+                for (int q = 0; ok && q < got; q++) ok = negative_idx[(size_t)b * K + q] != c;
+                if (ok) negative_idx[(size_t)b * K + got++] = c;
+            }
+            while (got < K) negative_idx[(size_t)b * K + got++] = -1;
+            break;
+        }
         const uint32_t r0 = rng.next();
         int j = 0;
         while (j + 1 < n_octaves && r0 > octave_cum[j]) j++;
@@ -357,7 +374,7 @@ __global__ void zipf_negatives_kernel(const int32_t* pair_ids, int B, const int3
         uint32_t k;
         while (true) {                                            // inside the chosen octave until a rank is accepted
             k = base + (j ? (rng.next() >> (32 - j)) : 0u);
-            if (k > (uint32_t)n_products) continue;               // the last octave may be partial
+            if (k > (uint32_t)n_products) continue;               // the last octave may be partial (it starts inside [1, P]: the host checks)
             const uint32_t r2 = rng.next();
             if ((uint64_t)r2 * k < ((uint64_t)base << 32)) break; // accept with probability 2^j / k
         }
@@ -372,12 +389,12 @@ __global__ void zipf_negatives_kernel(const int32_t* pair_ids, int B, const int3
 extern "C" int pc_sample_negatives_zipf(const int32_t* pair_ids, int batch, const int32_t* sim_pairs,
                                         const int32_t* sim_rowptr, const int32_t* sim_col, int n_products, int k_neg,
                                         uint64_t seed, uint64_t step, const uint32_t* octave_cum, int n_octaves,
-                                        const int32_t* perm, int32_t* negative_idx, void* stream) {
+                                        const int32_t* perm, int32_t* negative_idx, int32_t* failed, void* stream) {
     if (!pair_ids || !sim_pairs || !sim_rowptr || !sim_col || !octave_cum || !negative_idx) return PC_EINVAL;
     if (batch <= 0 || k_neg <= 0 || n_products <= k_neg + 1 || n_octaves < 1 || n_octaves > 31) return PC_EINVAL;
     if ((1ll << (n_octaves - 1)) > (long long)n_products) return PC_EINVAL;      // the last octave must start inside [1, P]
     PC_LAUNCH(zipf_negatives_kernel, dim3((batch + 127) / 128), dim3(128), 0, (hipStream_t)stream, pair_ids, batch, sim_pairs,
-              sim_rowptr, sim_col, n_products, k_neg, seed, step, octave_cum, n_octaves, perm, negative_idx);
+              sim_rowptr, sim_col, n_products, k_neg, seed, step, octave_cum, n_octaves, perm, negative_idx, failed);
     return pc_launch_status();
 }
 
@@ -426,5 +443,108 @@ extern "C" int pc_build_complementary_batch(const int32_t* pairs, int batch, con
     PC_LAUNCH(build_complementary_batch_kernel, dim3((total + 255) / 256), dim3(256), 0, (hipStream_t)stream, pairs, batch,
               features, type_idx, n_types, seed, step, query_idx, query_types, pos_types, neg_types, pos_items,
               neg_items, target_features);
+    return pc_launch_status();
+}
+
+
+// ---------------------------------------------------------------------------------------
+// The epoch order of the loaders (DataLoader(shuffle=True): scripts/pretrain_product2vec.py:24-30, train.py:115-121)
+// without a sort and without storage: a keyed bijection of [0, 2^k) (balanced Feistel network, six rounds, k = the even
+// number of bits covering n) cycle-walked into [0, n) -- position i maps through the network until the value is < n.
+// Deterministic in (seed, epoch), integer arithmetic only (restated for the tests by philox_oracle.epoch_permutation), and
+// it replaces torch.randperm, whose radix / merge sort kernels were the last third-party kernels on the loader path.
+struct FeistelKeys { uint32_t k[6]; int half; };     // half = k / 2 bits per side
+static inline uint64_t pc_splitmix64(uint64_t& x) {
+    uint64_t z = (x += 0x9E3779B97F4A7C15ull);
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+static FeistelKeys feistel_keys(uint64_t n, uint64_t seed, uint64_t epoch) {
+    FeistelKeys f;
+    int bits = 2;
+    while (bits < 62 && (1ull << bits) < n) bits += 2;
+    f.half = bits / 2;
+    uint64_t x = seed * 0xD1342543DE82EF95ull + epoch * 0x2545F4914F6CDD1Dull + 0x1234567ull;
+    for (int r = 0; r < 6; r++) f.k[r] = (uint32_t)(pc_splitmix64(x) >> 32);
+    return f;
+}
+__device__ __forceinline__ uint32_t feistel_apply(uint32_t x, const FeistelKeys& f) {
+    const uint32_t mask = (1u << f.half) - 1u;
+    uint32_t L = x >> f.half, R = x & mask;
+#pragma unroll
+    for (int r = 0; r < 6; r++) {
+        uint32_t v = R * 0xCC9E2D51u + f.k[r];
+        v ^= v >> 15; v *= 0x85EBCA6Bu; v ^= v >> 13; v *= 0xC2B2AE35u; v ^= v >> 16;
+        const uint32_t t = L ^ (v & mask);
+        L = R; R = t;
+    }
+    return (L << f.half) | R;
+}
+__device__ __forceinline__ uint32_t epoch_perm_at(uint32_t i, uint32_t n, const FeistelKeys& f) {
+    uint32_t x = feistel_apply(i, f);
+    while (x >= n) x = feistel_apply(x, f);          // the cycle of i returns to [0, n): at most 4 n / n expected steps
+    return x;
+}
+
+__global__ void epoch_permutation_kernel(uint32_t n, FeistelKeys f, int32_t* out) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = (int32_t)epoch_perm_at(i, n, f);
+}
+
+extern "C" int pc_epoch_permutation(int n, uint64_t seed, uint64_t epoch, int32_t* out, void* stream) {
+    if (n <= 0 || !out) return PC_EINVAL;
+    const FeistelKeys f = feistel_keys((uint64_t)n, seed, epoch);
+    PC_LAUNCH(epoch_permutation_kernel, dim3(((unsigned)n + 255) / 256), dim3(256), 0, (hipStream_t)stream, (uint32_t)n, f, out);
+    return pc_launch_status();
+}
+
+// out[i][:] = rows[perm(i)][:], width int32 per row (the labelled pairs [n,3] of the complementary loader): the shuffled
+// epoch in one launch
+__global__ void shuffle_rows_kernel(const int32_t* rows, uint32_t n, int width, FeistelKeys f, int32_t* out) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t s = epoch_perm_at(i, n, f);
+    for (int c = 0; c < width; c++) out[(size_t)i * width + c] = rows[(size_t)s * width + c];
+}
+
+extern "C" int pc_shuffle_rows_i32(const int32_t* rows, int n, int width, uint64_t seed, uint64_t epoch, int32_t* out,
+                                   void* stream) {
+    if (n <= 0 || width <= 0 || !rows || !out || rows == out) return PC_EINVAL;
+    const FeistelKeys f = feistel_keys((uint64_t)n, seed, epoch);
+    PC_LAUNCH(shuffle_rows_kernel, dim3(((unsigned)n + 255) / 256), dim3(256), 0, (hipStream_t)stream, rows, (uint32_t)n, width, f, out);
+    return pc_launch_status();
+}
+
+// The two integers per batch the host needs to size it (collate_fn pads the neighbour lists to the batch maximum,
+// data_loader.py:186-198): plan[b] = (max, sum) of deg[order[i]] over the batch's positions i in [b B, (b+1) B), i < n.
+// order == NULL: the identity (shuffle = False).  One workgroup per batch.
+__global__ __launch_bounds__(256) void epoch_plan_kernel(const int32_t* order, const int32_t* deg, int n, int B, long long* plan) {
+    __shared__ int smx[256];
+    __shared__ long long ssm[256];
+    const int b = blockIdx.x;
+    int mx = 0;
+    long long sm = 0;
+    for (int i = b * B + threadIdx.x; i < (b + 1) * B && i < n; i += 256) {
+        const int d = deg[order ? order[i] : i];
+        mx = max(mx, d);
+        sm += d;
+    }
+    smx[threadIdx.x] = mx; ssm[threadIdx.x] = sm;
+    __syncthreads();
+    for (int o = 128; o >= 1; o >>= 1) {
+        if ((int)threadIdx.x < o) {
+            smx[threadIdx.x] = max(smx[threadIdx.x], smx[threadIdx.x + o]);
+            ssm[threadIdx.x] += ssm[threadIdx.x + o];
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) { plan[2 * b] = smx[0]; plan[2 * b + 1] = ssm[0]; }
+}
+
+extern "C" int pc_epoch_plan(const int32_t* order, const int32_t* deg, int n, int batch, int n_batches, int64_t* plan,
+                             void* stream) {
+    if (!deg || !plan || n <= 0 || batch <= 0 || n_batches <= 0) return PC_EINVAL;
+    PC_LAUNCH(epoch_plan_kernel, dim3(n_batches), dim3(256), 0, (hipStream_t)stream, order, deg, n, batch, (long long*)plan);
     return pc_launch_status();
 }

@@ -217,7 +217,14 @@ class SimilarityIndexLoader:
             # the request capacity per peer must be the same constant on every rank: sized for the largest possible batch
             # (anchor + positive + k negatives + a full neighbour list per sample, + the padding row), not for this rank's first one
             max_ids = self.batch_size * (2 + k_neg + int(self._deg.max() if len(self._deg) else 0)) + 1
-            sharded.capacity = sharded.capacity_for(max_ids, sharded.world)
+            sharded.agree_capacity(sharded.capacity_for(max_ids, sharded.world))     # MAX over the ranks: a split size of the exchange
+        if negatives == "zipf":
+            # the rejection sampler needs k_neg eligible products for every anchor (not itself, not one of its positives)
+            max_pos = int(np.diff(bpg.sim_rowptr).max()) if len(bpg.sim_rowptr) > 1 else 0
+            if max_pos + k_neg + 1 > bpg.num_products:
+                raise ValueError(f"Zipf negatives: an anchor has {max_pos} positives, so fewer than k_neg = {k_neg} of the "
+                                 f"{bpg.num_products} products are eligible")
+            self._zipf_failed = torch.zeros(1, dtype=torch.int32, device=device)
 
     def __len__(self):
         n = self.bpg.similarity_pairs.shape[0]
@@ -233,17 +240,25 @@ class SimilarityIndexLoader:
         n, B = len(self), self.batch_size
 
         def launch(epoch):
-            g = torch.Generator(device=dev)
+            if dev.type == "cuda":
+                # two launches of the library's own kernels (a keyed Feistel bijection + a per-batch max / sum): no
+                # torch.randperm, i.e. no ATen / rocprim sort kernels on the loader path
+                order = self.ops.epoch_permutation(S, int(self.seed) * 1000003 + 17, epoch, dev) if self.shuffle else None
+                st = self.ops.epoch_plan(order, self._deg_dev, S, B, n)
+                if order is None:
+                    order = torch.arange(S, device=dev, dtype=torch.int32)
+                return order, st
+            g = torch.Generator(device=dev)                      # host loader (CPU tests): plain torch on the host
             g.manual_seed(int(self.seed) * 1000003 + epoch)
             order = torch.randperm(S, device=dev, generator=g) if self.shuffle else torch.arange(S, device=dev)
-            d = self._deg_dev[order]
+            d = self._deg_dev.to(torch.int64)[order]
             d = d[:n * B] if n * B <= S else torch.nn.functional.pad(d, (0, n * B - S))
             d = d.view(n, B)
             st = torch.stack([d.max(1).values, d.sum(1)], 1)
             return order.to(torch.int32), st
 
         if getattr(self, "_deg_dev", None) is None:
-            self._deg_dev = torch.from_numpy(np.ascontiguousarray(self._deg, np.int64)).to(dev)
+            self._deg_dev = torch.from_numpy(np.ascontiguousarray(self._deg, np.int32)).to(dev)
         if dev.type != "cuda":
             perm, st = launch(self.epoch)
             return perm, st
@@ -338,7 +353,7 @@ class SimilarityIndexLoader:
                 a, p, ng, nb = up(pairs[:, 0]), up(pairs[:, 1]), up(negs), (up(nbr) if n_pad else None)
             if self._zipf is not None:
                 self.ops.sample_negatives_zipf(perm_dev[lo:hi], self.g, self.k_neg, self.seed, self.step, self._zipf[0],
-                                               self._zipf[1], out=ng)
+                                               self._zipf[1], out=ng, failed=self._zipf_failed)
             self.step += 1
             batch = {"anchor_idx": a, "positive_idx": p, "negative_idx": ng, "n_pad": n_pad}
             if nb is not None:
@@ -358,6 +373,7 @@ class SimilarityIndexLoader:
         if not self.prefetch:
             for i in range(n):
                 yield make(i)
+            self._end_of_epoch_checks()
             return
         if getattr(self, "_side", None) is None:
             self._side = torch.cuda.Stream(self.device)
@@ -383,6 +399,50 @@ class SimilarityIndexLoader:
                     if torch.is_tensor(t):
                         t.record_stream(cur)        # allocated on the side stream, consumed on this one
             yield batch
+        self._end_of_epoch_checks()
+
+    def _end_of_epoch_checks(self, wait=False):
+        """Device-side error counters, read WITHOUT stalling the pipeline: at the end of an epoch the counters are copied to
+        pinned memory behind the epoch's last builder; the copy of the epoch before is examined (it completed long ago).
+        A sharded lookup whose request bucket overflowed trained on zero rows for the ids that did not fit, and a Zipf
+        sampler that ran out of proposals completed its negatives in rank order -- both raise instead of continuing
+        silently, at most one epoch late.  check_errors() (wait=True) synchronises and reports at once."""
+        counters = []
+        if self.sharded is not None and self.sharded._bufs is not None:
+            counters.append(("overflow", self.sharded._bufs["overflow"]))
+        zf = getattr(self, "_zipf_failed", None)
+        if zf is not None:
+            counters.append(("zipf", zf))
+        pend = getattr(self, "_err_pending", None)
+        self._err_pending = None
+        if counters and torch.device(self.device).type == "cuda":
+            host = torch.empty(len(counters), dtype=torch.int32).pin_memory()
+            for i, (_, t) in enumerate(counters):
+                host[i:i + 1].copy_(t, non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record(torch.cuda.current_stream(self.device))
+            self._err_pending = ([n for n, _ in counters], host, ev)
+        elif counters:
+            pend = ([n for n, _ in counters], torch.cat([t.reshape(1).cpu() for _, t in counters]), None)
+        if wait and self._err_pending is not None:
+            pend, self._err_pending = self._err_pending, None
+        if pend is None:
+            return
+        names, host, ev = pend
+        if ev is not None:
+            ev.synchronize()
+        for nm, v in zip(names, host.tolist()):
+            if v and nm == "overflow":
+                raise RuntimeError(f"{v} product ids did not fit the per-peer request capacity {self.sharded.capacity} of the "
+                                   "sharded lookup (they were trained as zero rows): construct ShardedFeatureTable with a "
+                                   "larger `capacity`")
+            if v and nm == "zipf":
+                raise RuntimeError(f"Zipf negative sampler: {v} samples ran out of proposals (their negatives were completed "
+                                   "in rank order): the anchors' positives cover the head of the popularity order")
+
+    def check_errors(self):
+        """Synchronising form of the per-epoch check (end of training, tests)."""
+        self._end_of_epoch_checks(wait=True)
 
 
 class ComplementaryIndexDataset:
@@ -489,7 +549,7 @@ class ComplementaryIndexLoader:
     def epoch_pairs(self):
         """The next epoch's labelled pairs [n,3] in batch order on the device (what __iter__ slices its batches from;
         GraphedJointStep.run_epoch hands them to pc_joint_train_epoch whole)."""
-        # shuffled ON THE DEVICE (randperm + one row gather, ~50 us): a host permutation of 580 k pairs takes longer than the
+        # shuffled ON THE DEVICE (pc_shuffle_rows_i32, one launch): a host permutation of 580 k pairs takes longer than the
         # 141 steps of that epoch run, and the loop would wait for it at every epoch boundary.  Deterministic in (seed, epoch)
         # per device type.
         if getattr(self, "_pairs_all", None) is None:
@@ -498,7 +558,10 @@ class ComplementaryIndexLoader:
         self.epoch += 1
         if not self.shuffle:
             return self._pairs_all
-        g = torch.Generator(device=self._pairs_all.device)
+        if self._pairs_all.is_cuda:
+            from . import ops
+            return ops.shuffle_rows_i32(self._pairs_all, (int(self.seed) + 7) * 1000003, e)     # one launch of the library's own kernel
+        g = torch.Generator(device=self._pairs_all.device)           # host loader (CPU tests)
         g.manual_seed((int(self.seed) + 7) * 1000003 + e)
         order = torch.randperm(self._pairs_all.shape[0], device=self._pairs_all.device, generator=g)
         return self._pairs_all.index_select(0, order)

@@ -90,9 +90,22 @@ class ShardedFeatureTable:
         ~sqrt(R / G); 25 % headroom is > 20 sigma at R ~ 1e5."""
         return int(ids_per_step) if world == 1 else int(slack * ids_per_step / world) + 1024
 
+    def agree_capacity(self, capacity):
+        """The per-peer request capacity is a split size of two all_to_all_single calls: it MUST be the same number on
+        every rank.  Ranks may hold different graphs or batch sizes, so the value each rank derived locally is
+        all-reduced (MAX) over the group once, at construction time (one tiny host-visible collective)."""
+        capacity = int(capacity)
+        if self.world > 1 and dist.is_initialized():
+            dev = self.local.device if dist.get_backend(self.group) != "gloo" else torch.device("cpu")
+            t = torch.tensor([capacity], dtype=torch.int64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX, group=self.group)
+            capacity = int(t.item())
+        self.capacity = capacity
+        return capacity
+
     def _buffers(self, n_ids, dev):
         if self.capacity is None:
-            self.capacity = self.capacity_for(n_ids, self.world)
+            self.agree_capacity(self.capacity_for(n_ids, self.world))
         if self._bufs is None or self._bufs["send_ids"].device != dev:
             G, C = self.world, self.capacity
             i32 = lambda *s: torch.zeros(*s, dtype=torch.int32, device=dev)

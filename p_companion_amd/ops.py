@@ -705,6 +705,13 @@ class PreparedJointStep:
         self._pairs_fn = _lib.lib().pc_joint_fused_step_pairs
         self._pairs_src = None
 
+    def set_hyper(self, lr, betas, eps):
+        """The optimizer's hyper-parameters are plain doubles among the resolved arguments: refreshed from
+        optimizer.param_groups by the caller before a step / an epoch, so that an LR scheduler or a load_state_dict()
+        after preparation reaches the fused update exactly as it reaches the eager path."""
+        if self._args[2] is not None:
+            self._args[5], self._args[6], self._args[7], self._args[8] = float(lr), float(betas[0]), float(betas[1]), float(eps)
+
     def __call__(self, dropout_offset=0):
         if self.dropout is not None:
             self.st.dropout.offset = int(dropout_offset)
@@ -919,9 +926,37 @@ def zipf_octave_thresholds(n_products):
     return thr
 
 
-def sample_negatives_zipf(pair_ids, graph, k_neg, seed, step, thresholds, perm=None, out=None):
+def epoch_permutation(n, seed, epoch, device):
+    """pc_epoch_permutation: the epoch's order of n dataset positions, int32 [n] on the device (keyed Feistel bijection,
+    cycle-walked: no sort kernels, no torch.randperm)."""
+    out = torch.empty(int(n), dtype=torch.int32, device=device)
+    check(_lib.lib().pc_epoch_permutation(int(n), int(seed) & (2 ** 64 - 1), int(epoch), _p(out), _stream()), "pc_epoch_permutation")
+    return out
+
+
+def shuffle_rows_i32(rows, seed, epoch):
+    """pc_shuffle_rows_i32: rows [n,w] int32 -> the rows in the epoch's order (a new tensor)."""
+    _req(rows, torch.int32, "rows")
+    n, w = rows.shape
+    out = torch.empty_like(rows)
+    check(_lib.lib().pc_shuffle_rows_i32(_p(rows), n, w, int(seed) & (2 ** 64 - 1), int(epoch), _p(out), _stream()), "pc_shuffle_rows_i32")
+    return out
+
+
+def epoch_plan(order, deg, n, batch, n_batches):
+    """pc_epoch_plan: per batch (padded neighbour count, real neighbour slots) -> int64 [n_batches,2] on the device."""
+    _req(deg, torch.int32, "deg")
+    if order is not None:
+        _req(order, torch.int32, "order")
+    plan = torch.empty(n_batches, 2, dtype=torch.int64, device=deg.device)
+    check(_lib.lib().pc_epoch_plan(_p(order), _p(deg), int(n), int(batch), int(n_batches), _p(plan), _stream()), "pc_epoch_plan")
+    return plan
+
+
+def sample_negatives_zipf(pair_ids, graph, k_neg, seed, step, thresholds, perm=None, out=None, failed=None):
     """pc_sample_negatives_zipf: returns negative_idx [B,k_neg] (int32, device).  thresholds: uint32 device tensor from
-    zipf_octave_thresholds (viewed as int32 storage)."""
+    zipf_octave_thresholds (viewed as int32 storage).  failed: optional int32 [1] device counter of samples that ran out
+    of proposals (see the header)."""
     b = pair_ids.numel()
     _req(pair_ids, torch.int32, "pair_ids"); _req(thresholds, torch.int32, "thresholds")
     if perm is not None:
@@ -929,7 +964,7 @@ def sample_negatives_zipf(pair_ids, graph, k_neg, seed, step, thresholds, perm=N
     ng = out if out is not None else torch.empty(b, k_neg, dtype=torch.int32, device=pair_ids.device)
     check(_lib.lib().pc_sample_negatives_zipf(_p(pair_ids), b, _p(graph["sim_pairs"]), _p(graph["sim_rowptr"]), _p(graph["sim_col"]),
                                               int(graph["n_products"]), int(k_neg), int(seed), int(step), _p(thresholds),
-                                              thresholds.numel(), _p(perm), _p(ng), _stream()), "pc_sample_negatives_zipf")
+                                              thresholds.numel(), _p(perm), _p(ng), _p(failed), _stream()), "pc_sample_negatives_zipf")
     return ng
 
 

@@ -148,11 +148,17 @@ class PCompanion(nn.Module, _FlatParamsMixin):
         """Counts ids outside their tables on the device (pc_check_indices); nothing is read back here.  jobs:
         (int32 tensor, table rows).  The reference raises at the lookup (p_companion.py:48-54); here the count is
         collected by raise_index_errors() at a point where the host synchronises anyway (train() does it per epoch)."""
+        ops.check_indices([(t, hi, False) for t, hi in jobs], self._bad_counter())
+
+    def _bad_counter(self):
+        """The device counter of out-of-range ids (created on first use; every path that hands ids to a kernel -- _validate,
+        train_step, GraphedJointStep's prepared step and epoch runner -- goes through here, so raise_index_errors() can
+        always fire)."""
         dev = self.query_type_embeddings.weight.device
         bad = getattr(self, "_bad", None)
         if bad is None or bad.device != dev:
             bad = self._bad = torch.zeros(1, dtype=torch.int32, device=dev)
-        ops.check_indices([(t, hi, False) for t, hi in jobs], bad)
+        return bad
 
     def index_errors(self) -> int:
         """Number of out-of-range product / type ids the device has seen since the last call (synchronises)."""
@@ -273,9 +279,7 @@ class PCompanion(nn.Module, _FlatParamsMixin):
         t = self.query_type_embeddings.weight.shape[0]
         k = int(self.config.NUM_COMP_TYPES)
         if getattr(self, "use_fused_joint", True) and ops.joint_fused_supported(t, k, drop[0] if drop else 0.0):
-            bad = getattr(self, "_bad", None)
-            if bad is None or bad.device != dev:
-                bad = self._bad = torch.zeros(1, dtype=torch.int32, device=dev)
+            bad = self._bad_counter()
             adam = None
             if optimizer is not None:
                 if not hasattr(optimizer, "fused_state") or optimizer.module is not self:
@@ -360,7 +364,7 @@ class GraphedJointStep:
         params = m._tensor_dict()
         params["product_embeddings.weight"] = m.product_embeddings.weight
         grads = {k: q.grad for k, q in m.named_parameters() if q.grad is not None}
-        bad = getattr(m, "_bad", None)
+        bad = m._bad_counter()                     # (never None: the kernel clamps AND counts ids outside the tables)
         tt = m.type_transition
         p = float(getattr(m.config, "DROPOUT", 0.0))
         drop = None
@@ -372,6 +376,10 @@ class GraphedJointStep:
                                               float(m.config.ALPHA), bad=bad, dropout=drop,
                                               adam=self.optimizer.fused_state() if self.grad_hook is None else None)
         self._gflat = m.flatten_parameters()[1]
+
+    def _refresh_hyper(self):
+        g = self.optimizer.param_groups[0]
+        self.prepared.set_hyper(g["lr"], g["betas"], g["eps"])
 
     def __call__(self, batch=None):
         deferred = None
@@ -389,6 +397,7 @@ class GraphedJointStep:
                 raise RuntimeError("GraphedJointStep: the model left training mode")
             off = tt._dropout_step
             tt._dropout_step += 1
+            self._refresh_hyper()
             if deferred is not None:
                 # ComplementaryIndexLoader(..., out=self.static, deferred=True): the batch is built by the step's first kernel
                 batch.pop("_deferred", None)
@@ -441,6 +450,7 @@ def _graphed_run_epoch(self, loader, drop_last=False, max_steps=None):
     if getattr(loader, "_source", None) is None:
         loader._source = (loader.features, loader.type_idx, int(loader.dataset.bpg.n_types), int(loader.seed))
     tt = self.model.type_transition
+    self._refresh_hyper()
     losses, steps = self.prepared.run_epoch(pairs, loader._source, loader.step, drop_last=drop_last, dropout_offset=tt._dropout_step)
     tt._dropout_step += steps
     loader.step += steps

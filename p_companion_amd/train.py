@@ -73,6 +73,7 @@ def train(config, train_loader, val_loader, pretrained_embeddings, fused=True):
     # the index loader of this package on the GPU: train.py:36-57's loop over an epoch runs as ONE foreign call
     # (GraphedJointStep.run_epoch -> pc_joint_train_epoch; same steps, same values as the loop below)
     epoch_runner = None
+    loader_out = (train_loader.out, getattr(train_loader, "_prepared", None)) if isinstance(train_loader, ComplementaryIndexLoader) else None
     if fused and isinstance(train_loader, ComplementaryIndexLoader) and torch.device(config.DEVICE).type == "cuda" and \
             train_loader.out is None and len(train_loader.dataset) >= train_loader.batch_size:
         from .p_companion import GraphedJointStep
@@ -115,6 +116,9 @@ def train(config, train_loader, val_loader, pretrained_embeddings, fused=True):
                         "optimizer_state_dict": _cpu_state(optimizer.state_dict()),      # torch.optim.Adam's layout in both modes
                         "metrics": metrics}, os.path.join(config.MODEL_DIR, "best_model.pth"))
         logger.info(f"Best Hit@10: {best_hit10:.4f}")
+    if epoch_runner is not None:                     # the caller's loader leaves as it came (its batches no longer alias the step's buffers)
+        train_loader.out, train_loader._prepared = loader_out
+        train_loader._static_batch = None
     return model
 
 

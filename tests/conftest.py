@@ -28,9 +28,10 @@ def golden():
 _WORLD2 = {}
 
 
-def pytest_sessionstart(session):
-    markexpr = session.config.getoption("-m") or ""
-    if "gpu" not in markexpr or "not gpu" in markexpr:
+def pytest_collection_finish(session):
+    """Runs after collection and BEFORE any test (hence before this process's first GPU call): the children are started
+    only when the world-2 test is among the selected items (a run narrowed with -k / a node id leaves no orphans)."""
+    if not any(item.name.startswith("test_sharded_step_world2_on_one_card") for item in session.items):
         return
     import socket
     import subprocess
@@ -47,6 +48,21 @@ def pytest_sessionstart(session):
         log = open(os.path.join(d, f"rank{rank}.log"), "w")
         procs.append((subprocess.Popen([sys.executable, worker, str(rank), str(port), out], stdout=log, stderr=log), out, log))
     _WORLD2["procs"] = procs
+
+
+def pytest_sessionfinish(session, exitstatus):
+    """Children that are still running (the test that collects them failed early, was interrupted, ...) are ended by
+    their exact PIDs and their logs closed."""
+    for p, _, log in _WORLD2.pop("procs", []):
+        if p.poll() is None:
+            p.terminate()
+            try:
+                p.wait(timeout=20)
+            except Exception:
+                p.kill()
+                p.wait(timeout=20)
+        if not log.closed:
+            log.close()
 
 
 @pytest.fixture(scope="session")

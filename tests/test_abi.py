@@ -29,6 +29,7 @@ def test_library_exports_every_declared_symbol():
     for name in header_functions():
         assert hasattr(L, name), f"{name} declared in the header but not exported"
     assert L.pc_abi_version() == 4
+    assert L.pc_build_flags() == 0, "a developer-knob build (PC_EXP_* / *_TIMING) is not the product"
 
 
 def test_ctypes_table_matches_header():
