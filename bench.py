@@ -46,21 +46,26 @@ def flops_per_triplet(n):
     return 3 * fwd - 65536 * (n + 7)
 
 
+NT_LAUNCHES_PER_STEP = 6
+
+
 def nt_algorithmic_bytes(b, nbc):
-    """Compulsory HBM bytes of the 7 persistent gemm_nt_kernel launches of one step:
+    """Compulsory HBM bytes of the 6 persistent gemm_nt_kernel launches of one step:
     rows R = [anchor B | neighbour rows nbc | positive B | negatives 5B]; per row Linear0 0.5+1 KB (gathered
     x -> H0), Linear3 1+1+1 (H0 -> A2, and A1 = tanh(BN(H0)) saved for dW3), Linear5 1+0.5 (A2 -> Y), dZ2 0.5+1+1
-    (dY, A2 -> dZ2), dZ1 1+1+1 (dZ2, H0 -> dZ1); per neighbour row K|V projection 0.5+1 and dKeys 1+0.5.  Weights are
-    L2-resident."""
+    (dY, A2 -> dZ2), dZ1 1+1+1 (dZ2, H0 -> dZ1); per neighbour row dKeys 1+0.5 ([dK|dV] -> dY).  Weights are
+    L2-resident.  (Round 2 had a seventh launch, the K|V projection of the neighbour rows: absorbed into the
+    single-query attention in round 3.)"""
     r = 7 * b + nbc
-    return 1024 * (r * (1.5 + 3.0 + 1.5 + 2.5 + 3.0) + nbc * (1.5 + 1.5))
+    return 1024 * (r * (1.5 + 3.0 + 1.5 + 2.5 + 3.0) + nbc * 1.5)
 
 
 def executed_flops_per_step(b, nbc):
     """FLOPs of the GEMMs one step actually runs: FFN forward + backward without dX of Linear0 over
-    R = 7b + nbc rows (720,896 per row), K|V projection + dKeys + dW_kv over the nbc neighbour rows and the
-    q / out projections with their backward over the b samples (196,608 each)."""
-    return 720896.0 * (7 * b + nbc) + 196608.0 * (nbc + b)
+    R = 7b + nbc rows (720,896 per row), dKeys over the nbc neighbour rows (65,536 each) and, per sample, the q / out
+    projections with their backward (196,608) plus the per-head products of the absorbed K and V projections
+    (Wk_h^T q_h, Wv_h c_h, their two input gradients and two weight gradients: 6 x 32,768)."""
+    return 720896.0 * (7 * b + nbc) + 65536.0 * nbc + 393216.0 * b
 
 
 def bytes_per_triplet(n):
@@ -288,12 +293,14 @@ def run_joint(args, rank, world, dev, types, steps, warmup, want_cpu):
                         "traffic_source": pmc["source"] if pmc else None,
                         "note": "2.6 KB gathered per triplet + T*256 B of E_c + 28 B/parameter of dense Adam per step "
                                 "(SURVEY 8d); launch/latency-bound, not bandwidth-bound"},
-           "cpu_baseline": joint_cpu_baseline(model, last, cfg) if want_cpu else None}
+           # (T = 34800: ~1 s per oracle step -- dense [B,T] similarities and dense Adam over both tables -- bounded to ~20 s)
+           "cpu_baseline": (joint_cpu_baseline(model, last, cfg, min_steps=20 if types <= 1000 else 8,
+                                               max_seconds=40.0 if types <= 1000 else 20.0) if want_cpu else None)}
     return out
 
 
 # ----------------------------------------------------------------------------------------------- P2V phase
-def run_p2v(args, rank, world, dev, products, steps, warmup, want_cpu, profile_kernels=True):
+def run_p2v(args, rank, world, dev, products, steps, warmup, want_cpu, profile_kernels=True, sustained=False):
     from types import SimpleNamespace
     from p_companion_amd import distributed as pdist
     from p_companion_amd import ops
@@ -389,7 +396,7 @@ def run_p2v(args, rank, world, dev, products, steps, warmup, want_cpu, profile_k
         launches = max(nt["launches"], 1)
         sec = nt["total_ms"] * 1e-3 / launches
         fl = nt["total_flops"] / launches
-        alg = nt_algorithmic_bytes(args.batch, rows_avg + 1) / 7
+        alg = nt_algorithmic_bytes(args.batch, rows_avg + 1) / NT_LAUNCHES_PER_STEP
         bound, fm, fh = two_roof(fl, alg, sec, NT_PEAK_TFLOPS)
         tfl = fl / sec / 1e12 if sec > 0 else 0.0
         gbs = alg / sec / 1e9 if sec > 0 else 0.0
@@ -427,6 +434,32 @@ def run_p2v(args, rank, world, dev, products, steps, warmup, want_cpu, profile_k
                            "reference_equivalent_flops_per_triplet": flops_per_triplet(round(n_avg)),
                            "gather_bytes_per_triplet": bytes_per_triplet(round(n_avg)),
                            "frac_hbm_gather": round(bytes_per_triplet(n_avg) * value / world / 1e9 / HBM_PEAK_GBS, 5)}}
+    if sustained:
+        # The driver's flags make the headline region short (20 steps = 22 ms) and it never crosses a loader epoch boundary
+        # (every 67 steps).  This leg is the same loop, un-bracketed, over >= 300 steps after >= 20 warm-up steps, three
+        # times: min / median / max of the per-repeat ms_per_step.
+        reps = []
+        steps_s = max(300, int(np.ceil(3.2 * len(loader))))        # >= 3 epoch boundaries inside every repeat
+        for _ in range(20):
+            step(next(it))
+        for _rep in range(3):
+            if world > 1:
+                torch.distributed.barrier()
+            torch.cuda.synchronize()
+            ts = time.perf_counter()
+            for _ in range(steps_s):
+                step(next(it))
+            torch.cuda.synchronize()
+            if world > 1:
+                torch.distributed.barrier()
+            tt = torch.tensor([time.perf_counter() - ts], dtype=torch.float64, device=dev)
+            if world > 1:
+                torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
+            reps.append(1e3 * float(tt) / steps_s)
+        reps.sort()
+        res["sustained"] = {"steps": steps_s, "warmup": 20, "repeats": 3, "epoch_boundaries_per_repeat": steps_s // max(len(loader), 1),
+                            "ms_per_step": {"min": round(reps[0], 4), "median": round(reps[1], 4), "max": round(reps[2], 4)},
+                            "value_median": round(world * args.batch / (reps[1] * 1e-3), 1), "unit": "triplets/s"}
     if want_cpu and sharded is None:                  # (a sharded batch holds indices over its own gathered table)
         res["cpu_baseline"] = p2v_cpu_baseline(bpg, last)
     prof.close()
@@ -457,6 +490,7 @@ def main():
     ap.add_argument("--large-catalogue", type=int, default=0,
                     help="also time the P2V step over this many products (e.g. 2000000: few duplicate neighbours to merge)")
     ap.add_argument("--no-ref-types", action="store_true", help="skip the joint leg at the reference's NUM_TYPES = 34800")
+    ap.add_argument("--no-sustained", action="store_true", help="skip the `sustained` leg (3 x >= 300 P2V steps across epoch boundaries)")
     args = ap.parse_args()
 
     from p_companion_amd import distributed as pdist
@@ -470,14 +504,14 @@ def main():
 
     p2v = joint = joint_ref = large = None
     if args.phase in ("both", "p2v"):
-        p2v = run_p2v(args, rank, world, dev, args.products, args.steps, args.warmup, want_cpu)
+        p2v = run_p2v(args, rank, world, dev, args.products, args.steps, args.warmup, want_cpu, sustained=not args.no_sustained)
         if args.large_catalogue:
             large = run_p2v(args, rank, world, dev, args.large_catalogue, max(args.steps // 2, 5), args.warmup, False,
                             profile_kernels=False)
     if args.phase in ("both", "joint"):
         joint = run_joint(args, rank, world, dev, args.types, max(args.steps * 4, 100), max(args.warmup, 10), want_cpu)
         if not args.no_ref_types and args.types != 34800:
-            joint_ref = run_joint(args, rank, world, dev, 34800, max(args.steps, 20), max(args.warmup, 10), False)
+            joint_ref = run_joint(args, rank, world, dev, 34800, max(args.steps, 20), max(args.warmup, 10), want_cpu)
     if rank != 0:
         return
 
@@ -510,6 +544,7 @@ def main():
                                         % (p2v["distinct_neighbour_rows"], p2v["real_neighbour_slots"],
                                            args.batch * round(p2v["n_avg"]), 100 * p2v["rows_saved_by_duplicate_neighbours"],
                                            args.products)},
+           "sustained": p2v.get("sustained"),
            "roofline": p2v.get("roofline"), "cpu_baseline": p2v.get("cpu_baseline")}
     if large:
         out["large_catalogue"] = {"products": args.large_catalogue, "value": round(large["value"], 1),

@@ -306,6 +306,29 @@ int gemm_nt_tiles(const SegInfo& si);
 #define PC_NT_GROUP 4
 struct NtSmallGroup { NtArgs a[PC_NT_GROUP]; int ks_log2[PC_NT_GROUP], block0[PC_NT_GROUP + 1], n; };
 int launch_gemm_nt_group(const NtArgs* args, int n, hipStream_t st);
+// two few-row products over the same 32-row tiles in ONE launch (gemm_nt.hip: the attention block's projection chains)
+enum { NT_MODE_PLAIN = 0, NT_MODE_KHEAD = 1, NT_MODE_AHEAD = 2 };
+// rider (optional): loss = mean_b relu(margin - d+ + d-) (product2vec.py:154) by ONE extra workgroup of the chain launch that
+// follows the triplet-loss kernel in the fused step (a launch of its own costs ~4.5 us of latency for 16 KB of work)
+struct HingeMeanJob { const float* d_pos; const float* d_neg; int B; float margin; float* loss; };
+int launch_gemm_nt_chain(const NtArgs* args, const int* modes, int n, hipStream_t st, const HingeMeanJob* rider = nullptr);
+#ifdef __HIPCC__
+// single workgroup of 256 threads, fixed summation order
+__device__ __forceinline__ void hinge_mean_body(const HingeMeanJob& j, float* red /* [256] LDS */) {
+    float s = 0.f;
+    for (int b = threadIdx.x; b < j.B; b += 256) {
+        const float l = j.margin - j.d_pos[b] + j.d_neg[b];
+        s += l > 0.f ? l : 0.f;
+    }
+    red[threadIdx.x] = s;
+    __syncthreads();
+    for (int o = 128; o >= 1; o >>= 1) {
+        if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) *j.loss = red[0] / (float)j.B;
+}
+#endif
 
 struct TransposeJob { const float* in; float* out; int rows, cols; };   // out[c][r] = in[r][c]
 #define PC_TRANSPOSE_JOBS 8

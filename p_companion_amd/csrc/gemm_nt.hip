@@ -482,6 +482,19 @@ __global__ __launch_bounds__(64 * NWM * NWN, WPS) void gemm_nt_kernel(NtArgs a, 
     }
 }
 
+#ifdef PC_CHAIN_TIMING
+// developer build: shader-clock stamps of workgroup 0 / thread 0 at the phases of the few-row bodies (scripts/dev/chain_phase_times.py)
+__device__ unsigned long long pc_chain_timing[64];
+__device__ int pc_chain_slot;
+extern "C" int pc_debug_chain_timing(unsigned long long* out, int reset) {
+    if (reset) { unsigned long long z[64] = {}; int zs = 0; (void)hipMemcpyToSymbol(HIP_SYMBOL(pc_chain_slot), &zs, sizeof(int)); return (int)hipMemcpyToSymbol(HIP_SYMBOL(pc_chain_timing), z, sizeof(z)); }
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(pc_chain_timing), sizeof(unsigned long long) * 64);
+}
+#define PC_CT() do { if (blockIdx.x == 0 && threadIdx.x == 0 && pc_chain_slot < 64) pc_chain_timing[pc_chain_slot++] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define PC_CT() do { } while (0)
+#endif
+
 // ---------------------------------------------------------------------------------------
 // Few rows (the per-sample projections of the attention block: M = batch; every layer of the joint
 // step): the product is a few hundred MFLOP and the persistent kernel's K pipeline is pure latency
@@ -518,8 +531,10 @@ __device__ __forceinline__ void nt_small_body(const NtArgs& a, int ks_log2, int 
         }
         dma16(p, lds0 + g * 1024);
     }
+    PC_CT();
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
+    PC_CT();
 
     f32x16 acc;
 #pragma unroll
@@ -539,6 +554,7 @@ __device__ __forceinline__ void nt_small_body(const NtArgs& a, int ks_log2, int 
         acc = mfma32(fa4.w, fb4.w, acc);
     }
     __syncthreads();                                             // the stage becomes the epilogue patches
+    PC_CT();
 
     float* stg = sm_small + w * (32 * PLD);
 #pragma unroll
@@ -599,6 +615,194 @@ __global__ __launch_bounds__(256) void gemm_nt_small_group_kernel(NtSmallGroup g
 #pragma unroll
     for (int i = 1; i < PC_NT_GROUP; i++) j += (i < g.n && b >= g.block0[i]) ? 1 : 0;
     nt_small_body(g.a[j], g.ks_log2[j], b - g.block0[j], g.a[j].epilogue);
+}
+
+static SegInfo retile_plain(int M) {
+    SegInfo si = make_seginfo(nullptr, M, 32);
+    return si;
+}
+
+// ---------------------------------------------------------------------------------------
+// Chains of few-row products over the SAME 32-row tile (the attention block of Product2Vec at D = 128, M = batch):
+//   forward   q = e_a Wq^T + bq  ->  qt_h = q_h Wk_h            |  ctx_h = c_h Wv_h^T + bv_h sp_h  ->  out = ctx Wo^T + bo
+//   backward  dctx = dout Wo     ->  dc_h = dctx_h Wv_h          |  dq_h = dqt_h Wk_h^T             ->  dquery = dq Wq
+// Each pair was two launches of ~10 us of pure latency (plus the boundary between them); a workgroup owns its 32 rows in
+// both products, so the second one follows in the same kernel: its A rows are the C rows this workgroup has just stored
+// (s_waitcnt vmcnt(0) + barrier: the stores are complete, the rows come back through the CU's own L1 / L2).
+// The per-head block products run one head per wave:
+//   KHEAD  C[r][h*128 + d] = sum_{j<32} A[r][32h + j] W[d][32h + j]     (A 32 x 128, W 128 x 128 staged like a plain
+//          product; wave h multiplies its head's 32 k's against all four column blocks; ldc = 512)
+//   AHEAD  C[r][32h + j]   = sum_{d<128} A[r][h*128 + d] W[32h + j][d]  (+ bias[32h + j] * brs[r][h]; A is four staged
+//          32 x 128 images, one per head; wave h takes image h and its own 32 output columns)
+struct NtChain { NtArgs a[2]; int mode[2], epi[2], n, tiles; HingeMeanJob rider; };
+
+// The burst goes global -> registers -> LDS here (every lane up to 32 independent 16-B loads in flight, then the
+// swizzled ds_write_b128s): measured with in-kernel clocks (scripts/dev/chain_phase_times.py), a 4-wave workgroup issuing its
+// 20-32 LDS-DMA instructions per wave spent 4-12 us in the issue -- the DMA path holds only a few requests per wave in
+// flight, which the persistent kernels hide behind twelve waves per CU and this one-shot burst cannot.
+__device__ __forceinline__ void nt_head_body(const NtArgs& a, int tile, int mode) {
+    extern __shared__ __attribute__((aligned(1024))) float sm_small[];
+    constexpr int KS = 128;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int row0 = tile * 32, row_end = a.M;
+    const int arows = mode == NT_MODE_AHEAD ? 128 : 32;          // staged A rows (AHEAD: image h at rows [32h, 32h + 32))
+    {
+        constexpr int MAXC = 32;                                 // 16-B chunks per thread: (arows + 128) * 32 / 256 = 20 or 32
+        const int nchunk = (arows + 128) >> 3;
+        float4 buf[MAXC];
+#pragma unroll
+        for (int i = 0; i < MAXC; i++) {
+            buf[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (i < nchunk) {
+                const int id = tid + 256 * i, r = id >> 5, cc = id & 31;   // stage row, 16-B chunk of the row
+                const float* p = nullptr;
+                if (r < arows) {
+                    const int gr = row0 + (r & 31);
+                    if (gr < row_end) p = a.A + (size_t)gr * a.lda + (mode == NT_MODE_AHEAD ? (r >> 5) * 128 : 0) + cc * 4;
+                } else {
+                    p = a.W + (size_t)(r - arows) * a.ldw + cc * 4;
+                }
+                if (p) buf[i] = *reinterpret_cast<const float4*>(p);
+            }
+        }
+        PC_CT();
+#pragma unroll
+        for (int i = 0; i < MAXC; i++)
+            if (i < nchunk) {
+                const int id = tid + 256 * i, r = id >> 5, cc = id & 31;
+                *reinterpret_cast<float4*>(&sm_small[r * KS + ((cc ^ (r & 15)) << 2)]) = buf[i];
+            }
+    }
+    __syncthreads();
+    PC_CT();
+
+    const int fr = lane & 31, fh = lane >> 5;
+    const int er = lane >> 3, ec = (lane & 7) * 4;
+    const int nblk = mode == NT_MODE_KHEAD ? 4 : 1;
+    f32x16 acc[4];
+#pragma unroll
+    for (int nb = 0; nb < 4; nb++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) acc[nb][r] = 0.f;
+    if (mode == NT_MODE_KHEAD) {
+        const float* As = sm_small + fr * KS;
+        const int sa = fr & 15;
+#pragma unroll
+        for (int kk = 0; kk < 4; kk++) {
+            const int c = 2 * (4 * w + kk) + fh;
+            const float4 fa4 = *reinterpret_cast<const float4*>(&As[(c ^ sa) << 2]);
+#pragma unroll
+            for (int nb = 0; nb < 4; nb++) {
+                const int wr = 32 + nb * 32 + fr;
+                const float4 fb4 = *reinterpret_cast<const float4*>(&sm_small[wr * KS + ((c ^ (wr & 15)) << 2)]);
+                acc[nb] = mfma32(fa4.x, fb4.x, acc[nb]);
+                acc[nb] = mfma32(fa4.y, fb4.y, acc[nb]);
+                acc[nb] = mfma32(fa4.z, fb4.z, acc[nb]);
+                acc[nb] = mfma32(fa4.w, fb4.w, acc[nb]);
+            }
+        }
+    } else {
+        // PLAIN: every wave reads the one A image; AHEAD: wave h reads image h.  Two accumulators (even / odd k groups)
+        // halve the dependent MFMA chain
+        const int ar = (mode == NT_MODE_AHEAD ? w * 32 : 0) + fr, wr = arows + w * 32 + fr;
+        const float* As = sm_small + ar * KS;
+        const float* Ws = sm_small + wr * KS;
+        const int sa = ar & 15, sw = wr & 15;
+#pragma unroll
+        for (int kk = 0; kk < 16; kk++) {
+            const int c = 2 * kk + fh;
+            const float4 fa4 = *reinterpret_cast<const float4*>(&As[(c ^ sa) << 2]);
+            const float4 fb4 = *reinterpret_cast<const float4*>(&Ws[(c ^ sw) << 2]);
+            acc[kk & 1] = mfma32(fa4.x, fb4.x, acc[kk & 1]);
+            acc[kk & 1] = mfma32(fa4.y, fb4.y, acc[kk & 1]);
+            acc[kk & 1] = mfma32(fa4.z, fb4.z, acc[kk & 1]);
+            acc[kk & 1] = mfma32(fa4.w, fb4.w, acc[kk & 1]);
+        }
+#pragma unroll
+        for (int r = 0; r < 16; r++) acc[0][r] += acc[1][r];
+    }
+    __syncthreads();                                             // the stage becomes the epilogue patches
+    PC_CT();
+    float* stg = sm_small + w * (32 * PLD);
+#pragma unroll
+    for (int nb = 0; nb < 4; nb++) {
+        if (nb >= nblk) break;
+#pragma unroll
+        for (int reg = 0; reg < 16; reg++)
+            stg[((reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)) * PLD + (lane & 31)] = acc[nb][reg];
+        __builtin_amdgcn_wave_barrier();
+        const int col = mode == NT_MODE_KHEAD ? w * 128 + nb * 32 + ec : w * 32 + ec;
+        float bias[4] = {0.f, 0.f, 0.f, 0.f};
+        if (mode != NT_MODE_KHEAD && a.bias) {
+#pragma unroll
+            for (int q = 0; q < 4; q++) bias[q] = a.bias[col + q];
+        }
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            const int row = row0 + er + 8 * i;
+            if (row >= row_end) continue;
+            float4 v4 = *reinterpret_cast<const float4*>(&stg[(er + 8 * i) * PLD + ec]);
+            const float rs = (mode == NT_MODE_AHEAD && a.brs) ? a.brs[(size_t)row * a.ldbrs + w] : 1.f;
+            v4.x += bias[0] * rs; v4.y += bias[1] * rs; v4.z += bias[2] * rs; v4.w += bias[3] * rs;
+            *reinterpret_cast<float4*>(a.C + (size_t)row * a.ldc + col) = v4;
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
+__global__ __launch_bounds__(256) void gemm_nt_chain_kernel(NtChain c) {
+    if ((int)blockIdx.x >= c.tiles) {                            // the rider's workgroup (see HingeMeanJob)
+        extern __shared__ __attribute__((aligned(1024))) float sm_small[];
+        hinge_mean_body(c.rider, sm_small);
+        return;
+    }
+    PC_CT();
+    for (int s = 0; s < c.n; s++) {
+        PC_CT();
+        if (s) {                                                 // this workgroup's C rows of stage s - 1 are stage s's A rows
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+        }
+        PC_CT();
+        nt_head_body(c.a[s], blockIdx.x, c.mode[s]);
+    }
+}
+
+// D = 128 attention chains only: every stage M rows (the same M), K = N = 128 per plain stage / head structure above.
+int launch_gemm_nt_chain(const NtArgs* args, const int* modes, int n, hipStream_t st, const HingeMeanJob* rider) {
+    if (!args || !modes || n < 1 || n > 2) return PC_EINVAL;
+    NtChain c = {};
+    c.n = n;
+    double flops = 0.0;
+    for (int i = 0; i < n; i++) {
+        const NtArgs& a = args[i];
+        if (!a.A || !a.W || !a.C || a.M <= 0 || a.M != args[0].M) return PC_EINVAL;
+        if (a.gather || a.prologue != NT_PRO_NONE || a.stats != NT_STAT_NONE || a.epilogue != NT_EPI_NONE) return PC_ESHAPE;
+        if (a.lda % 4 || a.ldw % 4 || a.ldc % 4 || (((uintptr_t)a.A | (uintptr_t)a.W | (uintptr_t)a.C) & 15)) return PC_ESHAPE;
+        if (modes[i] == NT_MODE_PLAIN) { if (a.N != 128 || a.K != 128 || a.brs) return PC_ESHAPE; flops += 2.0 * a.M * 128 * 128; }
+        else if (modes[i] == NT_MODE_KHEAD) { if (a.N != 512 || a.K != 128 || a.bias) return PC_ESHAPE; flops += 2.0 * a.M * 512 * 32; }
+        else if (modes[i] == NT_MODE_AHEAD) { if (a.N != 128 || a.K != 512) return PC_ESHAPE; flops += 2.0 * a.M * 128 * 128; }
+        else return PC_EINVAL;
+        c.a[i] = a;
+        c.a[i].seg = retile_plain(a.M);
+        c.mode[i] = modes[i];
+        c.epi[i] = NT_EPI_NONE;
+    }
+    const int tiles = (args[0].M + 31) / 32;
+    c.tiles = tiles;
+    if (rider) {
+        if (!rider->d_pos || !rider->d_neg || !rider->loss || rider->B <= 0) return PC_EINVAL;
+        c.rider = *rider;
+    }
+    const size_t lds = (size_t)256 * 128 * 4;                    // AHEAD: 128 A-image rows + 128 W rows of 512 B
+    static const hipError_t lds_attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt_chain_kernel),
+                                                           hipFuncAttributeMaxDynamicSharedMemorySize, 256 * 128 * 4);
+    (void)lds_attr;
+    const int pb = pc_prof_begin(PC_KIND_GEMM_NT_SMALL, flops, st);
+    PC_LAUNCH(gemm_nt_chain_kernel, dim3(tiles + (rider ? 1 : 0)), dim3(256), lds, st, c);
+    pc_prof_end(pb, st);
+    return pc_launch_status();
 }
 
 static SegInfo retile(const SegInfo& in, int tile_rows) {

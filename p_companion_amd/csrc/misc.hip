@@ -71,25 +71,14 @@ __global__ __launch_bounds__(256) void triplet_loss_kernel(const float* a, const
 }
 
 // loss = mean_b relu(margin - d+ + d-): single block, fixed summation order
-__global__ void hinge_mean_kernel(const float* d_pos, const float* d_neg, int B, float margin, float* loss) {
+__global__ void hinge_mean_kernel(HingeMeanJob j) {
     __shared__ float red[256];
-    float s = 0.f;
-    for (int b = threadIdx.x; b < B; b += 256) {
-        const float l = margin - d_pos[b] + d_neg[b];
-        s += l > 0.f ? l : 0.f;
-    }
-    red[threadIdx.x] = s;
-    __syncthreads();
-    for (int o = 128; o >= 1; o >>= 1) {
-        if (threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
-        __syncthreads();
-    }
-    if (threadIdx.x == 0) *loss = red[0] / (float)B;
+    hinge_mean_body(j, red);
 }
 
-extern "C" int pc_p2v_triplet_loss_dim(const float* a, const float* p, const float* n, int batch, int k_neg, int dim,
-                                       float margin, float* loss, float* d_pos, float* d_neg, float* da, float* dp,
-                                       float* dn, void* stream) {
+// with_mean == 0: the caller folds the mean into a later launch (HingeMeanJob rider of launch_gemm_nt_chain)
+int triplet_loss_launch(const float* a, const float* p, const float* n, int batch, int k_neg, int dim, float margin,
+                        float* loss, float* d_pos, float* d_neg, float* da, float* dp, float* dn, void* stream, int with_mean) {
     if (!a || !p || !n || !loss || !d_pos || !d_neg || batch <= 0) return PC_EINVAL;
     if (k_neg < 1 || k_neg > LOSS_MAX_K || (dim != 128 && dim != 256)) return PC_ESHAPE;
     if (da && (!dp || !dn)) return PC_EINVAL;
@@ -99,8 +88,16 @@ extern "C" int pc_p2v_triplet_loss_dim(const float* a, const float* p, const flo
     else PC_LAUNCH(triplet_loss_kernel<4>, dim3((batch + 3) / 4), dim3(256), 0, st, a, p, n, batch, k_neg, margin,
                    d_pos, d_neg, da, dp, dn);
     PC_TRY(pc_launch_status());
-    PC_LAUNCH(hinge_mean_kernel, dim3(1), dim3(256), 0, st, d_pos, d_neg, batch, margin, loss);
+    if (!with_mean) return PC_OK;
+    const HingeMeanJob j = {d_pos, d_neg, batch, margin, loss};
+    PC_LAUNCH(hinge_mean_kernel, dim3(1), dim3(256), 0, st, j);
     return pc_launch_status();
+}
+
+extern "C" int pc_p2v_triplet_loss_dim(const float* a, const float* p, const float* n, int batch, int k_neg, int dim,
+                                       float margin, float* loss, float* d_pos, float* d_neg, float* da, float* dp,
+                                       float* dn, void* stream) {
+    return triplet_loss_launch(a, p, n, batch, k_neg, dim, margin, loss, d_pos, d_neg, da, dp, dn, stream, 1);
 }
 
 extern "C" int pc_p2v_triplet_loss(const float* a, const float* p, const float* n, int batch, int k_neg,
@@ -501,6 +498,9 @@ extern "C" unsigned pc_build_flags(void) {
 #endif
 #ifdef PC_JOINT_TIMING
     f |= PC_FLAG_JOINT_TIMING;
+#endif
+#ifdef PC_CHAIN_TIMING
+    f |= PC_FLAG_CHAIN_TIMING;
 #endif
     return f;
 }

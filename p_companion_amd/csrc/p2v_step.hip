@@ -93,7 +93,9 @@ int attention_backward_impl(const pc_p2v_tensors* p, const pc_p2v_tensors* g, co
                             int B, int N, int key_rows, const int32_t* slot_row, int pad_row, const float* dout,
                             const pc_attn_saved* sv, float* dquery, float* dkeys, int accumulate, void* ws,
                             size_t ws_bytes, void* stream, const int32_t* ref_off, const int32_t* ref_slot,
-                            int transposed, TnDefer* defer);
+                            int transposed, TnDefer* defer, const HingeMeanJob* rider);
+int triplet_loss_launch(const float* a, const float* p, const float* n, int batch, int k_neg, int dim, float margin,
+                        float* loss, float* d_pos, float* d_neg, float* da, float* dp, float* dn, void* stream, int with_mean);
 
 // nb_idx: neighbour rows of the step, nbc of them.  Dense layout: nbc = B*N slots in slot order
 // (slot_row NULL).  Compact layout: the M real neighbours then one -1 row (nbc = M + 1), slot_row[B*N]
@@ -174,8 +176,11 @@ static int p2v_step_impl(const pc_p2v_tensors* p, const pc_p2v_tensors* g, const
     float* dp_out = d_pos ? d_pos : w.dpos_tmp;
     float* dn_out = d_neg ? d_neg : w.dneg_tmp;
     float* demb = N > 0 ? w.demb : w.dy + (size_t)rA * D;
-    PC_TRY(pc_p2v_triplet_loss_dim(emb, w.y + (size_t)rP * D, w.y + (size_t)rG * D, B, K, D, margin, loss, dp_out,
-                               dn_out, demb, w.dy + (size_t)rP * D, w.dy + (size_t)rG * D, stream));
+    // the hinge mean rides on the first launch of the attention backward (D = 128 with neighbours); nothing in the step reads it
+    const bool mean_rides = N > 0 && D == 128;
+    PC_TRY(triplet_loss_launch(emb, w.y + (size_t)rP * D, w.y + (size_t)rG * D, B, K, D, margin, loss, dp_out,
+                               dn_out, demb, w.dy + (size_t)rP * D, w.dy + (size_t)rG * D, stream, mean_rides ? 0 : 1));
+    const HingeMeanJob hm = {dp_out, dn_out, B, margin, loss};
     if (anchor_emb)
         PC_HIP_TRY(hipMemcpyAsync(anchor_emb, emb, (size_t)B * D * 4, hipMemcpyDeviceToDevice, st));
 
@@ -186,7 +191,8 @@ static int p2v_step_impl(const pc_p2v_tensors* p, const pc_p2v_tensors* g, const
     if (N > 0) {
         PC_TRY(attention_backward_impl(p, g, w.y + (size_t)rA * D, w.y + (size_t)rN * D, B, N, nbc, slot_row,
                                        slot_row ? nbc - 1 : -1, w.demb, &as, w.dy + (size_t)rA * D,
-                                       w.dy + (size_t)rN * D, 0, w.attn_ws, w.attn_bytes, stream, ref_off, ref_slot, 1, &df));
+                                       w.dy + (size_t)rN * D, 0, w.attn_ws, w.attn_bytes, stream, ref_off, ref_slot, 1, &df,
+                                       mean_rides ? &hm : nullptr));
     } else {
         PC_HIP_TRY(hipMemsetAsync(g->in_proj_w, 0, 3 * D * D * 4, st));
         PC_HIP_TRY(hipMemsetAsync(g->in_proj_b, 0, 3 * D * 4, st));

@@ -12,14 +12,14 @@ int pc_prof_begin(int kind, double flops, hipStream_t st) {
     const int b = p->used++;
     p->kind[b] = kind;
     p->flops[b] = flops;
-    hipEventRecord(p->ev[2 * b], st);
+    (void)hipEventRecord(p->ev[2 * b], st);
     return b;
 }
 
 void pc_prof_end(int bracket, hipStream_t st) {
     pc_profile* p = pc_tls_profile;
     if (!p || bracket < 0) return;
-    hipEventRecord(p->ev[2 * bracket + 1], st);
+    (void)hipEventRecord(p->ev[2 * bracket + 1], st);
 }
 
 extern "C" int pc_profile_create(int capacity, void** out) {
@@ -39,7 +39,7 @@ extern "C" int pc_profile_create(int capacity, void** out) {
 extern "C" int pc_profile_destroy(void* prof) {
     pc_profile* p = (pc_profile*)prof;
     if (!p) return PC_EINVAL;
-    for (int i = 0; i < 2 * p->capacity; i++) hipEventDestroy(p->ev[i]);
+    for (int i = 0; i < 2 * p->capacity; i++) (void)hipEventDestroy(p->ev[i]);
     free(p->ev); free(p->kind); free(p->flops); free(p);
     return PC_OK;
 }

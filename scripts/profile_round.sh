@@ -7,7 +7,7 @@
 # NO_BENCH=1 skips the plain default bench line (the first step).
 # Kernel trace and the two PMC counters are separate rocprofv3 passes (never --pmc with a trace of the HIP/HSA domains).
 set -e
-TAG=${1:-r02}
+TAG=${1:-r03}
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$R/gpurun_out/$TAG
 mkdir -p $OUT
@@ -15,14 +15,14 @@ cd /tmp && export TMPDIR=/tmp
 if [ -z "$NO_BENCH" ]; then
 python3 $R/bench.py > $OUT/bench.json 2> $OUT/bench.err
 fi
-rocprofv3 --kernel-trace --stats -d $OUT/prof -o $TAG -- python3 $R/bench.py --phase p2v --steps 30 --warmup 5 --no-cpu-baseline > $OUT/bench_under_rocprof.json 2> $OUT/rocprof.err
-rocprofv3 --kernel-trace --stats -d $OUT/prof_joint -o ${TAG}_joint -- python3 $R/bench.py --phase joint --steps 25 --warmup 5 --no-cpu-baseline --no-ref-types > $OUT/bench_joint_under_rocprof.json 2> $OUT/rocprof_joint.err
+rocprofv3 --kernel-trace --stats -d $OUT/prof -o $TAG -- python3 $R/bench.py --phase p2v --steps 30 --warmup 5 --no-cpu-baseline --no-sustained > $OUT/bench_under_rocprof.json 2> $OUT/rocprof.err
+rocprofv3 --kernel-trace --stats -d $OUT/prof_joint -o ${TAG}_joint -- python3 $R/bench.py --phase joint --steps 25 --warmup 5 --no-cpu-baseline --no-sustained --no-ref-types > $OUT/bench_joint_under_rocprof.json 2> $OUT/rocprof_joint.err
 if [ -z "$NO_PMC" ]; then
-rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -- python3 $R/bench.py --phase p2v --steps 5 --warmup 2 --no-cpu-baseline > /dev/null 2> $OUT/pmc_fetch.err
-rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -- python3 $R/bench.py --phase p2v --steps 5 --warmup 2 --no-cpu-baseline > /dev/null 2> $OUT/pmc_write.err
-rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_joint_fetch -- python3 $R/bench.py --phase joint --steps 5 --warmup 2 --no-cpu-baseline --no-ref-types > /dev/null 2> $OUT/pmc_joint_fetch.err
-rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_joint_write -- python3 $R/bench.py --phase joint --steps 5 --warmup 2 --no-cpu-baseline --no-ref-types > /dev/null 2> $OUT/pmc_joint_write.err
-rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_joint34800_fetch -- python3 $R/bench.py --phase joint --types 34800 --steps 5 --warmup 2 --no-cpu-baseline --no-ref-types > /dev/null 2> $OUT/pmc_joint34800_fetch.err
-rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_joint34800_write -- python3 $R/bench.py --phase joint --types 34800 --steps 5 --warmup 2 --no-cpu-baseline --no-ref-types > /dev/null 2> $OUT/pmc_joint34800_write.err
+rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -- python3 $R/bench.py --phase p2v --steps 5 --warmup 2 --no-cpu-baseline --no-sustained > /dev/null 2> $OUT/pmc_fetch.err
+rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -- python3 $R/bench.py --phase p2v --steps 5 --warmup 2 --no-cpu-baseline --no-sustained > /dev/null 2> $OUT/pmc_write.err
+rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_joint_fetch -- python3 $R/bench.py --phase joint --steps 5 --warmup 2 --no-cpu-baseline --no-sustained --no-ref-types > /dev/null 2> $OUT/pmc_joint_fetch.err
+rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_joint_write -- python3 $R/bench.py --phase joint --steps 5 --warmup 2 --no-cpu-baseline --no-sustained --no-ref-types > /dev/null 2> $OUT/pmc_joint_write.err
+rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_joint34800_fetch -- python3 $R/bench.py --phase joint --types 34800 --steps 5 --warmup 2 --no-cpu-baseline --no-sustained --no-ref-types > /dev/null 2> $OUT/pmc_joint34800_fetch.err
+rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_joint34800_write -- python3 $R/bench.py --phase joint --types 34800 --steps 5 --warmup 2 --no-cpu-baseline --no-sustained --no-ref-types > /dev/null 2> $OUT/pmc_joint34800_write.err
 fi
 if [ -z "$NO_BENCH" ]; then cat $OUT/bench.json; fi
