@@ -555,6 +555,42 @@ int pc_sample_negatives_zipf(const int32_t *pair_ids, int batch, const int32_t *
  * cover the head of the popularity order, or one with fewer than k_neg eligible products; such a sample's remaining
  * negatives are the first eligible products in rank order, -1 when none is left.  Every wave terminates.) */
 
+/* ---- The synthetic catalogue generated ON THE DEVICE (csrc/generator.hip): SyntheticDataGenerator
+ * (src/data/synthetic_data.py:11-153) restated per source node like data.generate_scaled_bpg, but as kernels that write
+ * straight into HBM -- BASELINE configs[3]/[4] (10 M / 100 M products) cannot exist as host numpy arrays.  Every array is a
+ * pure function of (seed, product id) through Philox4x32-10, so a rank generates exactly its rows of the feature table
+ * (rows first, first + stride, ...: the cyclic shard r % world of SURVEY 8e) and the replicated graph arrays are identical
+ * on every rank.  Distributions: type uniform (synthetic_data.py:35-46); features N(0,1)^dim + 1.0 on the category's 20-dim
+ * block (:50-52); co-view out-degree Poisson(2 mean (1 - u)) capped, targets uniform, different-category targets kept with
+ * probability 2/3 (:107-108), distinct per row; similarity = co-view & purchase-after-view (0.2) & not co-purchase (0.075
+ * same category / 0.15) (:110-121); complementary = Poisson(comp_mean) targets, same-category kept 0.5, not co-viewed
+ * (:122-127).  Call order: pc_gen_degrees -> pc_exclusive_scan_i32 (cv_rowptr) -> pc_gen_coview -> scan (sim_rowptr) ->
+ * pc_gen_similarity; pc_gen_complementary(count) -> scan -> pc_gen_complementary(pairs). */
+int pc_gen_types(int64_t n_products, int num_types, uint64_t seed, int32_t *type_idx, void *stream);
+/* features[k][0:dim] = the feature row of product first + k * stride, k < n_local; dim >= 100, dim % 4 == 0 */
+int pc_gen_features(int64_t first, int64_t stride, int64_t n_local, int dim, int num_types, uint64_t seed,
+                    float *features, void *stream);
+/* deg[P]: co-view out-degrees; comp_cand[P] (optional): complementary candidates per product.  degree_cap <= 64 */
+int pc_gen_degrees(int64_t n_products, double mean_degree, int degree_cap, double comp_mean, uint64_t seed,
+                   int32_t *deg, int32_t *comp_cand, void *stream);
+size_t pc_scan_scratch_bytes(int64_t n);
+/* out[i] = sum_{j<i} in[j] for i = 0..n (out has n + 1 entries); total_out (optional): device int64 = out[n] unrounded
+ * (check it against 2^31 on the host: the offsets are int32) */
+int pc_exclusive_scan_i32(const int32_t *in, int64_t n, int32_t *out, int64_t *total_out, void *scratch,
+                          size_t scratch_bytes, void *stream);
+/* cv_col[cv_rowptr[i] + j] = j-th co-view target of product i, bit 31 = "this edge is a similarity pair" (cleared by
+ * pc_gen_similarity); sim_count[i] = number of such edges */
+int pc_gen_coview(int64_t n_products, int num_types, uint64_t seed, const int32_t *cv_rowptr, int32_t *cv_col,
+                  int32_t *sim_count, void *stream);
+/* sim_pairs[S][2] in source order, sim_col[S] (= the positives' CSR with sim_rowptr), pair_deg[S] (optional): co-view
+ * degree of each pair's anchor (what the loader pads to, data_loader.py:186-198) */
+int pc_gen_similarity(int64_t n_products, const int32_t *cv_rowptr, int32_t *cv_col, const int32_t *sim_rowptr,
+                      int32_t *sim_pairs, int32_t *sim_col, int32_t *pair_deg, void *stream);
+/* count != NULL: count[i] = complementary pairs of product i; comp_pairs != NULL: pairs written at comp_rowptr[i] */
+int pc_gen_complementary(int64_t n_products, int num_types, uint64_t seed, const int32_t *comp_cand,
+                         const int32_t *cv_rowptr, const int32_t *cv_col, int32_t *count,
+                         const int32_t *comp_rowptr, int32_t *comp_pairs, void *stream);
+
 /* The epoch order of DataLoader(shuffle=True) (scripts/pretrain_product2vec.py:24-30, train.py:115-121) as a keyed
  * bijection: out[i] = perm_{seed,epoch}(i), i in [0, n) -- a six-round balanced Feistel network over the even number of
  * bits covering n, cycle-walked into [0, n).  No sort, no storage, deterministic in (seed, epoch); restated in

@@ -143,6 +143,14 @@ SIGNATURES = {
     "pc_act_backward": (_i, [_vp, _vp, _sz, _i, _vp, _vp]),
     "pc_sample_negatives_zipf": (_i, [_vp, _i, _vp, _vp, _vp, _i, _i, _u64, _u64, _vp, _i, _vp, _vp, _vp, _vp]),
     "pc_epoch_permutation": (_i, [_i, _u64, _u64, _vp, _vp]),
+    "pc_gen_types": (_i, [_i64, _i, _u64, _vp, _vp]),
+    "pc_gen_features": (_i, [_i64, _i64, _i64, _i, _i, _u64, _vp, _vp]),
+    "pc_gen_degrees": (_i, [_i64, ctypes.c_double, _i, ctypes.c_double, _u64, _vp, _vp, _vp]),
+    "pc_scan_scratch_bytes": (_sz, [_i64]),
+    "pc_exclusive_scan_i32": (_i, [_vp, _i64, _vp, _vp, _vp, _sz, _vp]),
+    "pc_gen_coview": (_i, [_i64, _i, _u64, _vp, _vp, _vp, _vp]),
+    "pc_gen_similarity": (_i, [_i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "pc_gen_complementary": (_i, [_i64, _i, _u64, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "pc_shuffle_rows_i32": (_i, [_vp, _i, _i, _u64, _u64, _vp, _vp]),
     "pc_epoch_plan": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp]),
     "pc_shard_bucket": (_i, [_P(ctypes.c_void_p), _P(ctypes.c_int), _P(ctypes.c_void_p), _P(ctypes.c_int), _P(ctypes.c_void_p),

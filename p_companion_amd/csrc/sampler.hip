@@ -8,42 +8,6 @@
 // Philox4x32-10 stream keyed by (seed; sample, step), so every sample draws independently.
 #include "common.h"
 
-struct Philox {
-    uint32_t c[4], k[2], out[4];
-    int have;
-    __device__ Philox(uint64_t seed, uint64_t step, uint32_t sample) {
-        k[0] = (uint32_t)seed; k[1] = (uint32_t)(seed >> 32);
-        c[0] = 0; c[1] = sample; c[2] = (uint32_t)step; c[3] = (uint32_t)(step >> 32);
-        have = 0;
-    }
-    __device__ void block() {
-        uint32_t x0 = c[0], x1 = c[1], x2 = c[2], x3 = c[3], k0 = k[0], k1 = k[1];
-#pragma unroll
-        for (int r = 0; r < 10; r++) {
-            const uint64_t p0 = (uint64_t)0xD2511F53u * x0, p1 = (uint64_t)0xCD9E8D57u * x2;
-            const uint32_t y0 = (uint32_t)(p1 >> 32) ^ x1 ^ k0, y1 = (uint32_t)p1;
-            const uint32_t y2 = (uint32_t)(p0 >> 32) ^ x3 ^ k1, y3 = (uint32_t)p0;
-            x0 = y0; x1 = y1; x2 = y2; x3 = y3;
-            k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
-        }
-        out[0] = x0; out[1] = x1; out[2] = x2; out[3] = x3;
-        c[0]++;                      // draw-block counter
-        have = 4;
-    }
-    __device__ uint32_t next() {
-        if (have == 0) block();
-        return out[4 - have--];
-    }
-    // unbiased integer in [0, n): top bit_length(n) bits, redraw while >= n (the rule of
-    // CPython's _randbelow_with_getrandbits, applied to this stream)
-    __device__ uint32_t below(uint32_t n) {
-        const int bits = 32 - __clz(n);
-        uint32_t r = next() >> (32 - bits);
-        while (r >= n) r = next() >> (32 - bits);
-        return r;
-    }
-};
-
 __global__ void build_pairs_negatives_kernel(const int32_t* pair_ids, int B, const int32_t* sim_pairs,
                                              const int32_t* sim_rowptr, const int32_t* sim_col, int n_products,
                                              int K, uint64_t seed, uint64_t step, int32_t* anchor_idx,

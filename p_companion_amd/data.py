@@ -141,6 +141,63 @@ def generate_scaled_bpg(num_products=100_000, num_types=100, seed=0, mean_degree
                   similarity_pairs=sim, complementary_pairs=comp, n_types=int(num_types))
 
 
+class DeviceBPG:
+    """The integer BPG with every array RESIDENT IN HBM, generated there (ops.generate_catalogue -> csrc/generator.hip):
+    BASELINE configs[3]/[4] -- 10 M and 100 M products -- cannot be built as host numpy arrays (generate_scaled_bpg's
+    np.unique over src * P + tgt alone needs tens of GB of host memory and minutes).  Same attribute surface as IntBPG for
+    the device paths (the throughput loaders, the fused steps, bench.py); host-side consumers (the CPython parity
+    sampler, the CPU baseline) take an IntBPG.
+
+    rank / world: this process holds rows rank, rank + world, ... of the feature table (the cyclic shard of SURVEY 8e);
+    the graph arrays are replicated -- they are a pure function of (seed, product id), identical on every rank."""
+
+    def __init__(self, arrays, n_types, dim, rank=0, world=1, seed=0):
+        self.arrays = arrays
+        self.n_types = int(n_types)
+        self.dim = int(dim)
+        self.rank, self.world, self.seed = int(rank), int(world), int(seed)
+        self.num_products = int(arrays["n_products"])
+        self.max_degree = int(arrays["max_degree"])
+
+    # --- the few IntBPG attributes the device paths read
+    @property
+    def n_similarity_pairs(self):
+        return int(self.arrays["sim_pairs"].shape[0])
+
+    def cuda(self, device="cuda"):
+        a = self.arrays
+        g = {k: a[k] for k in ("type_idx", "cv_rowptr", "cv_col", "sim_pairs", "sim_rowptr", "sim_col")}
+        g["n_products"] = self.num_products
+        if "features" in a:
+            g["features"] = a["features"]
+        return g
+
+    def nbytes(self):
+        return sum(v.numel() * v.element_size() for v in self.arrays.values() if torch.is_tensor(v))
+
+    def to_host(self):
+        """IntBPG copy (small catalogues only: tests, the CPU baseline)."""
+        a = self.arrays
+        if self.world != 1:
+            raise ValueError("to_host(): generate with world = 1 (the whole feature table)")
+        c = lambda k: a[k].cpu().numpy()
+        per_cat = max(self.n_types // 5, 1)
+        ti = c("type_idx")
+        return IntBPG(features=c("features"), type_idx=ti, category=np.minimum(ti // per_cat, 4).astype(np.int32),
+                      cv_rowptr=c("cv_rowptr"), cv_col=c("cv_col"), similarity_pairs=c("sim_pairs"),
+                      complementary_pairs=(c("comp_pairs") if "comp_pairs" in a else np.zeros((0, 2), np.int32)),
+                      n_types=self.n_types, sim_rowptr=c("sim_rowptr"), sim_col=c("sim_col"))
+
+
+def generate_device_bpg(num_products=100_000, num_types=100, seed=0, mean_degree=16.0, degree_cap=32, dim=128,
+                        device="cuda", rank=0, world=1, with_complementary=True) -> DeviceBPG:
+    """generate_scaled_bpg's distributions, drawn on the device straight into HBM (see DeviceBPG)."""
+    from . import ops
+    arrays = ops.generate_catalogue(num_products, num_types, seed, mean_degree, degree_cap, dim, device, rank=rank,
+                                    world=world, with_complementary=with_complementary)
+    return DeviceBPG(arrays, num_types, dim, rank=rank, world=world, seed=seed)
+
+
 class _LazyCount:
     """Device-computed integer read back through pinned memory; int() waits for the copy (normally long done)."""
 
@@ -212,22 +269,37 @@ class SimilarityIndexLoader:
             self.rng = ops.CPythonRandom(seed)
         elif sampler != "philox":
             raise ValueError("sampler must be 'philox' or 'cpython'")
-        self._deg = bpg.degree(bpg.similarity_pairs[:, 0])
+        self._on_device = isinstance(bpg, DeviceBPG)          # graph generated in HBM: no host copy of anything
+        if self._on_device:
+            if sampler != "philox" or torch.device(device).type != "cuda":
+                raise ValueError("a DeviceBPG feeds the device sampler (sampler='philox', device='cuda')")
+            self._n_pairs = bpg.n_similarity_pairs
+            self._deg = None
+            self._deg_dev = bpg.arrays["pair_deg"]
+            self._max_deg = bpg.max_degree
+            if unique and bpg.num_products > 4_000_000:
+                # the unique-row layout scans a per-product counter array every batch (O(P): 1.2 GB of traffic at 100 M
+                # products) to merge duplicate neighbours that a catalogue this size does not have (2 % at 2 M products)
+                self.unique = False
+        else:
+            self._n_pairs = int(bpg.similarity_pairs.shape[0])
+            self._deg = bpg.degree(bpg.similarity_pairs[:, 0])
+            self._max_deg = int(self._deg.max() if len(self._deg) else 0)
         if sharded is not None and sharded.capacity is None:
             # the request capacity per peer must be the same constant on every rank: sized for the largest possible batch
             # (anchor + positive + k negatives + a full neighbour list per sample, + the padding row), not for this rank's first one
-            max_ids = self.batch_size * (2 + k_neg + int(self._deg.max() if len(self._deg) else 0)) + 1
+            max_ids = self.batch_size * (2 + k_neg + self._max_deg) + 1
             sharded.agree_capacity(sharded.capacity_for(max_ids, sharded.world))     # MAX over the ranks: a split size of the exchange
         if negatives == "zipf":
             # the rejection sampler needs k_neg eligible products for every anchor (not itself, not one of its positives)
-            max_pos = int(np.diff(bpg.sim_rowptr).max()) if len(bpg.sim_rowptr) > 1 else 0
+            max_pos = self._max_deg if self._on_device else (int(np.diff(bpg.sim_rowptr).max()) if len(bpg.sim_rowptr) > 1 else 0)
             if max_pos + k_neg + 1 > bpg.num_products:
                 raise ValueError(f"Zipf negatives: an anchor has {max_pos} positives, so fewer than k_neg = {k_neg} of the "
                                  f"{bpg.num_products} products are eligible")
             self._zipf_failed = torch.zeros(1, dtype=torch.int32, device=device)
 
     def __len__(self):
-        n = self.bpg.similarity_pairs.shape[0]
+        n = self._n_pairs
         return n // self.batch_size if self.drop_last else (n + self.batch_size - 1) // self.batch_size
 
     def _epoch_plan(self, S):
@@ -293,7 +365,7 @@ class SimilarityIndexLoader:
         return perm, host
 
     def __iter__(self):
-        S = self.bpg.similarity_pairs.shape[0]
+        S = self._n_pairs
         if self.sampler == "cpython":
             perm = self.rng.shuffle(S) if self.shuffle else np.arange(S, dtype=np.int64)
         else:

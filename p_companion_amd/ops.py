@@ -926,6 +926,64 @@ def zipf_octave_thresholds(n_products):
     return thr
 
 
+def exclusive_scan_i32(counts):
+    """pc_exclusive_scan_i32: int32 [n] on the device -> (offsets int32 [n + 1], total as a Python int; raises when the
+    total does not fit the int32 offsets)."""
+    _req(counts, torch.int32, "counts")
+    n = counts.numel()
+    out = torch.empty(n + 1, dtype=torch.int32, device=counts.device)
+    total = torch.zeros(1, dtype=torch.int64, device=counts.device)
+    nbytes = _lib.lib().pc_scan_scratch_bytes(n)
+    scratch = torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device=counts.device)
+    check(_lib.lib().pc_exclusive_scan_i32(_p(counts), n, _p(out), _p(total), _p(scratch), nbytes, _stream()),
+          "pc_exclusive_scan_i32")
+    t = int(total.item())
+    if t >= 2 ** 31:
+        raise OverflowError(f"{t} entries do not fit int32 offsets")
+    return out, t
+
+
+def generate_catalogue(num_products, num_types, seed, mean_degree, degree_cap, dim, device, rank=0, world=1,
+                       comp_mean=4.5, with_complementary=True, with_features=True):
+    """csrc/generator.hip end to end; returns a dict of device tensors (see data.DeviceBPG)."""
+    L = _lib.lib()
+    P = int(num_products)
+    dev = torch.device(device)
+    i32 = lambda *s: torch.empty(*s, dtype=torch.int32, device=dev)
+    out = {"n_products": P}
+    type_idx = i32(P)
+    check(L.pc_gen_types(P, int(num_types), int(seed), _p(type_idx), _stream()), "pc_gen_types")
+    out["type_idx"] = type_idx
+    if with_features:
+        n_local = (P - rank + world - 1) // world
+        feats = torch.empty(n_local, dim, dtype=torch.float32, device=dev)
+        check(L.pc_gen_features(rank, world, n_local, int(dim), int(num_types), int(seed), _p(feats), _stream()), "pc_gen_features")
+        out["features"] = feats
+    deg, cand = i32(P), (i32(P) if with_complementary else None)
+    check(L.pc_gen_degrees(P, float(mean_degree), int(degree_cap), float(comp_mean), int(seed), _p(deg), _p(cand), _stream()),
+          "pc_gen_degrees")
+    cv_rowptr, n_edges = exclusive_scan_i32(deg)
+    cv_col, sim_count = i32(max(n_edges, 1)), i32(P)
+    check(L.pc_gen_coview(P, int(num_types), int(seed), _p(cv_rowptr), _p(cv_col), _p(sim_count), _stream()), "pc_gen_coview")
+    sim_rowptr, n_sim = exclusive_scan_i32(sim_count)
+    sim_pairs, sim_col, pair_deg = i32(max(n_sim, 1), 2), i32(max(n_sim, 1)), i32(max(n_sim, 1))
+    check(L.pc_gen_similarity(P, _p(cv_rowptr), _p(cv_col), _p(sim_rowptr), _p(sim_pairs), _p(sim_col), _p(pair_deg), _stream()),
+          "pc_gen_similarity")
+    out.update(cv_rowptr=cv_rowptr, cv_col=cv_col[:n_edges], sim_rowptr=sim_rowptr, sim_pairs=sim_pairs[:n_sim],
+               sim_col=sim_col[:n_sim], pair_deg=pair_deg[:n_sim], max_degree=int(degree_cap))
+    del deg, sim_count
+    if with_complementary:
+        cnt = i32(P)
+        check(L.pc_gen_complementary(P, int(num_types), int(seed), _p(cand), _p(cv_rowptr), _p(cv_col), _p(cnt), None, None,
+                                     _stream()), "pc_gen_complementary")
+        comp_rowptr, n_comp = exclusive_scan_i32(cnt)
+        comp = i32(max(n_comp, 1), 2)
+        check(L.pc_gen_complementary(P, int(num_types), int(seed), _p(cand), _p(cv_rowptr), _p(cv_col), None, _p(comp_rowptr),
+                                     _p(comp), _stream()), "pc_gen_complementary")
+        out["comp_pairs"] = comp[:n_comp]
+    return out
+
+
 def epoch_permutation(n, seed, epoch, device):
     """pc_epoch_permutation: the epoch's order of n dataset positions, int32 [n] on the device (keyed Feistel bijection,
     cycle-walked: no sort kernels, no torch.randperm)."""

@@ -152,6 +152,7 @@ def test_epoch_plans_are_permutations_deterministic_in_seed_and_epoch():
         ld = SimilarityIndexLoader.__new__(SimilarityIndexLoader)           # (the constructor uploads the graph for the device sampler)
         ld.bpg, ld.batch_size, ld.shuffle, ld.seed, ld.drop_last, ld.device, ld.epoch = bpg, B, True, seed, drop_last, "cpu", epoch
         ld._deg = bpg.degree(bpg.similarity_pairs[:, 0])
+        ld._n_pairs = S
         return ld._epoch_plan(S)
 
     for drop_last in (True, False):
