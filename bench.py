@@ -40,36 +40,40 @@ PROFILE_EVERY = 5          # timed steps between two steps whose gemm_nt launche
 HBM_PEAK_GBS = 8000.0
 
 
-def flops_per_triplet(n):
-    """fwd 328,192*N + 1,900,544; fwd+bwd = 3*fwd - 65,536*(N+7)."""
-    fwd = 328192 * n + 1900544
-    return 3 * fwd - 65536 * (n + 7)
+def flops_per_triplet(n, dim=128):
+    """SURVEY.md section 8(d), every padded slot its own row: at dim = 128 fwd 328,192*N + 1,900,544 and fwd+bwd =
+    3*fwd - 65,536*(N+7) (no input gradient of Linear0)."""
+    ffn_row = 2 * (dim * 256 + 256 * 256 + 256 * dim)
+    fwd = ffn_row * (n + 7) + 4 * dim * dim * n + 4 * dim * dim + 4 * dim * n
+    return 3 * fwd - 2 * dim * 256 * (n + 7)
 
 
 NT_LAUNCHES_PER_STEP = 6
 
 
-def nt_algorithmic_bytes(b, nbc):
+def nt_algorithmic_bytes(b, nbc, dim=128):
     """Compulsory HBM bytes of the 6 persistent gemm_nt_kernel launches of one step:
-    rows R = [anchor B | neighbour rows nbc | positive B | negatives 5B]; per row Linear0 0.5+1 KB (gathered
-    x -> H0), Linear3 1+1+1 (H0 -> A2, and A1 = tanh(BN(H0)) saved for dW3), Linear5 1+0.5 (A2 -> Y), dZ2 0.5+1+1
-    (dY, A2 -> dZ2), dZ1 1+1+1 (dZ2, H0 -> dZ1); per neighbour row dKeys 1+0.5 ([dK|dV] -> dY).  Weights are
-    L2-resident.  (Round 2 had a seventh launch, the K|V projection of the neighbour rows: absorbed into the
-    single-query attention in round 3.)"""
+    rows R = [anchor B | neighbour rows nbc | positive B | negatives 5B]; per row (d = dim * 4 bytes, 1 KB = a 256-wide
+    hidden row) Linear0 d + 1 KB (gathered x -> H0), Linear3 1+1+1 (H0 -> A2, and A1 = tanh(BN(H0)) saved for dW3),
+    Linear5 1 KB + d (A2 -> Y), dZ2 d+1+1 (dY, A2 -> dZ2), dZ1 1+1+1 (dZ2, H0 -> dZ1); per neighbour row dKeys 2d + d
+    ([dK|dV] -> dY).  Weights are L2-resident.  (Round 2 had a seventh launch, the K|V projection of the neighbour rows:
+    absorbed into the single-query attention in round 3.)"""
     r = 7 * b + nbc
-    return 1024 * (r * (1.5 + 3.0 + 1.5 + 2.5 + 3.0) + nbc * 1.5)
+    d = dim * 4
+    return r * ((d + 1024) + 3072 + (1024 + d) + (d + 2048) + 3072) + nbc * 3 * d
 
 
-def executed_flops_per_step(b, nbc):
-    """FLOPs of the GEMMs one step actually runs: FFN forward + backward without dX of Linear0 over
-    R = 7b + nbc rows (720,896 per row), dKeys over the nbc neighbour rows (65,536 each) and, per sample, the q / out
-    projections with their backward (196,608) plus the per-head products of the absorbed K and V projections
-    (Wk_h^T q_h, Wv_h c_h, their two input gradients and two weight gradients: 6 x 32,768)."""
-    return 720896.0 * (7 * b + nbc) + 65536.0 * nbc + 393216.0 * b
+def executed_flops_per_step(b, nbc, dim=128):
+    """FLOPs of the GEMMs one step actually runs: FFN forward + backward without dX of Linear0 over R = 7b + nbc rows
+    (Linear0 / dW0: 2*dim*256 each, Linear3 / dZ1 / dW3: 2*256*256 each, Linear5 / dZ2 / dW5: 2*256*dim each), dKeys over the
+    nbc neighbour rows (2 * 2dim * dim) and, per sample, the q / out projections with their backward (6 * 2 dim^2) plus
+    the per-head products of the absorbed K and V projections (6 * 2 dim^2 / ... one dim x dim product each)."""
+    ffn = 2 * (2 * dim * 256) + 3 * (2 * 256 * 256) + 3 * (2 * 256 * dim)
+    return float(ffn) * (7 * b + nbc) + 4.0 * dim * dim * nbc + 24.0 * dim * dim * b
 
 
-def bytes_per_triplet(n):
-    return 512 * (n + 7) + 4 * (n + 7)
+def bytes_per_triplet(n, dim=128):
+    return 4 * dim * (n + 7) + 4 * (n + 7)
 
 
 def committed_pmc(pattern, match):
@@ -205,6 +209,8 @@ def run_joint(args, rank, world, dev, types, steps, warmup, want_cpu):
         # (one all-reduce of 29 k weights + both type tables), then the Adam launch
         try:
             graphed = GraphedJointStep(model, opt, args.batch, mode="direct", grad_hook=lambda g: pdist.all_reduce_mean_(g, world))
+            # (T > 512: the two [T,64] table gradients travel as row lists, the 29 k dense weights as one all-reduce)
+            graphed.grad_hook = pdist.joint_grad_hook(model, graphed, world)
         except ValueError:
             graphed = None
     # 'epoch': train.py:36-57's loop over the epoch's batches as one foreign call (pc_joint_train_epoch) -- the same steps,
@@ -283,8 +289,8 @@ def run_joint(args, rank, world, dev, types, steps, warmup, want_cpu):
                       "kernels_per_step": ("2 (tile kernel: batch construction, forward, losses, backward and the tile's gradient slab; finish: slab "
                                             "sums + Adam)" if types <= 128 else
                                             "4 (batch builder, tile kernel, gradient products, finish + Adam)" if types <= 512 else
-                                            "7 (clear, present types, sims + chunk top-K, merge, tile kernel incl. batch construction and the "
-                                            "weight-gradient slabs, table-gradient scatter-add, finish + Adam)")},
+                                            "9 (clear, present types, sims + chunk top-K, merge, tile kernel incl. batch construction and the "
+                                            "weight-gradient slabs, touched-row lists, per-workgroup partial tables, fixed-order table sums, finish + Adam)")},
            "roofline": {"bound": "hbm", "kernel": "the whole step (batch builder + the fused step's kernels: a dependent chain)",
                         "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                         "frac": round(achieved / HBM_PEAK_GBS, 5),
@@ -307,10 +313,24 @@ def run_p2v(args, rank, world, dev, products, steps, warmup, want_cpu, profile_k
     from p_companion_amd.data import SimilarityIndexLoader, generate_scaled_bpg
     from p_companion_amd.product2vec import FusedAdam, Product2Vec
 
-    cfg = SimpleNamespace(PRODUCT_EMB_DIM=128, TYPE_EMB_DIM=64, HIDDEN_SIZE=256, NUM_ATTENTION_HEADS=4, DROPOUT=0.0,
+    from p_companion_amd.data import generate_device_bpg
+    dim = args.dim
+    cfg = SimpleNamespace(PRODUCT_EMB_DIM=dim, TYPE_EMB_DIM=64, HIDDEN_SIZE=256, NUM_ATTENTION_HEADS=4, DROPOUT=0.0,
                           MARGIN=1.0, BATCH_SIZE=args.batch, LEARNING_RATE=1e-3, DEVICE=dev)
-    bpg = generate_scaled_bpg(products, args.types, seed=0)
-    if products == args.products:
+    # the catalogue: host restatement (numpy; what the CPU baseline also reads) up to 2 M products, otherwise generated IN
+    # HBM by csrc/generator.hip (configs[3]/[4]: 10 M / 100 M products cannot exist as host arrays); a sharded table is
+    # then generated shard by shard (rows rank::world), never as a whole
+    on_device = args.generator == "device" or (args.generator == "auto" and products > 2_000_000)
+    t_gen = time.perf_counter()
+    if on_device:
+        shard = args.table == "sharded"
+        bpg = generate_device_bpg(products, args.types, seed=0, dim=dim, device=dev, rank=rank if shard else 0,
+                                  world=world if shard else 1, with_complementary=False)
+        torch.cuda.synchronize()
+    else:
+        bpg = generate_scaled_bpg(products, args.types, seed=0, dim=dim)
+    t_gen = time.perf_counter() - t_gen
+    if products == args.products and not on_device:
         run_joint.bpg = bpg                                   # the joint phase trains over the same catalogue
     torch.manual_seed(0)
     model = Product2Vec(cfg).to(dev)
@@ -321,10 +341,10 @@ def run_p2v(args, rank, world, dev, products, steps, warmup, want_cpu, profile_k
     sharded = None
     if args.table == "sharded":
         # row r on rank r % world; the loader runs the per-batch exchange on its side stream, one batch ahead
-        sharded = pdist.ShardedFeatureTable(pdist.ShardedFeatureTable.shard(table, rank, world), bpg.num_products,
-                                            rank, world)
+        local = table if on_device else pdist.ShardedFeatureTable.shard(table, rank, world)
+        sharded = pdist.ShardedFeatureTable(local, bpg.num_products, rank, world)
     loader = SimilarityIndexLoader(bpg, args.batch, shuffle=True, sampler="philox", seed=1 + rank, drop_last=True,
-                                   device=dev, sharded=sharded)
+                                   device=dev, sharded=sharded, negatives=args.negatives)
 
     def batches():
         while True:
@@ -396,11 +416,11 @@ def run_p2v(args, rank, world, dev, products, steps, warmup, want_cpu, profile_k
         launches = max(nt["launches"], 1)
         sec = nt["total_ms"] * 1e-3 / launches
         fl = nt["total_flops"] / launches
-        alg = nt_algorithmic_bytes(args.batch, rows_avg + 1) / NT_LAUNCHES_PER_STEP
+        alg = nt_algorithmic_bytes(args.batch, rows_avg + 1, dim) / NT_LAUNCHES_PER_STEP
         bound, fm, fh = two_roof(fl, alg, sec, NT_PEAK_TFLOPS)
         tfl = fl / sec / 1e12 if sec > 0 else 0.0
         gbs = alg / sec / 1e9 if sec > 0 else 0.0
-        exe = executed_flops_per_step(args.batch, rows_avg + 1)
+        exe = executed_flops_per_step(args.batch, rows_avg + 1, dim)
         res["roofline"] = {
             "bound": bound, "kernel": "gemm_nt_kernel",
             "achieved": round(gbs if bound == "hbm" else tfl, 2), "peak": HBM_PEAK_GBS if bound == "hbm" else round(NT_PEAK_TFLOPS, 1),
@@ -431,15 +451,15 @@ def run_p2v(args, rank, world, dev, products, steps, warmup, want_cpu, profile_k
             "whole_step": {"executed_flops_per_triplet": round(exe / args.batch),
                            "executed_tflops": round(exe / args.batch * value / world / 1e12, 2),
                            "executed_frac_of_matrix_peak": round(exe / args.batch * value / world / 1e12 / NT_PEAK_TFLOPS, 4),
-                           "reference_equivalent_flops_per_triplet": flops_per_triplet(round(n_avg)),
-                           "gather_bytes_per_triplet": bytes_per_triplet(round(n_avg)),
-                           "frac_hbm_gather": round(bytes_per_triplet(n_avg) * value / world / 1e9 / HBM_PEAK_GBS, 5)}}
+                           "reference_equivalent_flops_per_triplet": flops_per_triplet(round(n_avg), dim),
+                           "gather_bytes_per_triplet": bytes_per_triplet(round(n_avg), dim),
+                           "frac_hbm_gather": round(bytes_per_triplet(n_avg, dim) * value / world / 1e9 / HBM_PEAK_GBS, 5)}}
     if sustained:
         # The driver's flags make the headline region short (20 steps = 22 ms) and it never crosses a loader epoch boundary
         # (every 67 steps).  This leg is the same loop, un-bracketed, over >= 300 steps after >= 20 warm-up steps, three
         # times: min / median / max of the per-repeat ms_per_step.
         reps = []
-        steps_s = max(300, int(np.ceil(3.2 * len(loader))))        # >= 3 epoch boundaries inside every repeat
+        steps_s = min(max(300, int(np.ceil(3.2 * len(loader)))), 1000)   # >= 3 epoch boundaries inside every repeat (configs[1]: 67 steps per epoch)
         for _ in range(20):
             step(next(it))
         for _rep in range(3):
@@ -460,7 +480,12 @@ def run_p2v(args, rank, world, dev, products, steps, warmup, want_cpu, profile_k
         res["sustained"] = {"steps": steps_s, "warmup": 20, "repeats": 3, "epoch_boundaries_per_repeat": steps_s // max(len(loader), 1),
                             "ms_per_step": {"min": round(reps[0], 4), "median": round(reps[1], 4), "max": round(reps[2], 4)},
                             "value_median": round(world * args.batch / (reps[1] * 1e-3), 1), "unit": "triplets/s"}
-    if want_cpu and sharded is None:                  # (a sharded batch holds indices over its own gathered table)
+    res["catalogue"] = {"products": products, "dim": dim, "generator": "device (csrc/generator.hip)" if on_device else "host (numpy)",
+                        "seconds": round(t_gen, 3), "negatives": args.negatives,
+                        "neighbour_layout": "unique rows" if loader.unique else "compact (every real slot its own row)",
+                        "hbm_bytes": bpg.nbytes() if on_device else None,
+                        "similarity_pairs": len(loader) * args.batch}
+    if want_cpu and sharded is None and not on_device and dim == 128:    # (the oracle reads host arrays; a sharded batch indexes its own gathered table)
         res["cpu_baseline"] = p2v_cpu_baseline(bpg, last)
     prof.close()
     return res
@@ -475,6 +500,10 @@ def main():
     ap.add_argument("--types", type=int, default=100)
     ap.add_argument("--batch", type=int, default=4096)
     ap.add_argument("--table", choices=["replicated", "sharded"], default="replicated")
+    ap.add_argument("--dim", type=int, default=128, choices=[128, 256], help="PRODUCT_EMB_DIM (256: BASELINE configs[4])")
+    ap.add_argument("--negatives", choices=["uniform", "zipf"], default="uniform", help="zipf: configs[4] (P(rank) ~ 1/rank, product 0 the most popular)")
+    ap.add_argument("--generator", choices=["auto", "host", "device"], default="auto",
+                    help="where the synthetic catalogue is drawn: host numpy (<= 2 M products) or straight into HBM")
     ap.add_argument("--phase", choices=["both", "p2v", "joint"], default="both",
                     help="both (default) = BASELINE's whole metric: configs[1] as the headline value + configs[2] as `joint`")
     ap.add_argument("--sync-bn", action="store_true",
@@ -531,7 +560,7 @@ def main():
            "host_enqueue_ms_per_step": p2v.get("host_enqueue_ms_per_step"),
            "dtype_note": "fp32 storage, accumulation and result accuracy; the large GEMMs evaluate each fp32 product as six "
                          "bf16 matrix-core products of a three-way split (error <= the fp32 MFMA's, tests/test_gpu_ops.py)",
-           "config": {"workload": f"Product2Vec GAT pretrain, {args.products} products, {args.types} types, dim=128, "
+           "config": {"workload": f"Product2Vec GAT pretrain, {args.products} products, {args.types} types, dim={args.dim}, "
                                   f"batch={args.batch}/GPU, 5 negatives, neighbours padded to batch max "
                                   f"(avg N={p2v['n_avg']:.1f})", "global_batch": world * args.batch,
                       "table": args.table, "sharded_lookup": p2v.get("sharded_lookup"), "parallelism": f"dp{world}",
@@ -544,7 +573,7 @@ def main():
                                         % (p2v["distinct_neighbour_rows"], p2v["real_neighbour_slots"],
                                            args.batch * round(p2v["n_avg"]), 100 * p2v["rows_saved_by_duplicate_neighbours"],
                                            args.products)},
-           "sustained": p2v.get("sustained"),
+           "sustained": p2v.get("sustained"), "catalogue": p2v.get("catalogue"),
            "roofline": p2v.get("roofline"), "cpu_baseline": p2v.get("cpu_baseline")}
     if large:
         out["large_catalogue"] = {"products": args.large_catalogue, "value": round(large["value"], 1),

@@ -428,13 +428,22 @@ int pc_joint_train_step(const pc_joint_tensors *p, const pc_joint_tensors *g,
  * exp_avg == NULL: gradients only (a data-parallel caller all-reduces g, then pc_adam_step).
  * T <= 512: as above.  T > 512 (config.py:27 NUM_TYPES = 34800): the similarity row and its top-K are formed once per
  * DISTINCT query type of the batch (it is a function of the type alone), the [B,T] matrix never exists; the table
- * gradients use float atomics into the cleared dense g (not bitwise reproducible); needs dropout p == 0.
+ * gradients are fixed-order sums over the touched rows (per-workgroup partial tables in LDS, added in source order, then a
+ * fixed-order fold: bitwise reproducible) while a table has <= 512 touched rows in the batch -- the reference's catalogue
+ * has 20 live types, the benchmark's 100 -- and float atomics into the cleared dense g beyond that; needs dropout p == 0.
  * Ids outside their tables (query_idx vs num_products, the three type arrays vs num_types) are clamped, counted into
  * *bad_count (may be NULL) and never dereferenced out of bounds -- the reference raises at the lookup
  * (p_companion.py:48-54), the caller raises when it reads the counter.
  * pc_joint_fused_supported: 1 iff (num_types, k, dropout p) is served (k <= 4; see above), else use pc_joint_train_step. */
 size_t pc_joint_fused_workspace_bytes(int batch, int num_types, int k);
 int pc_joint_fused_supported(int num_types, int k, float dropout_p);
+/* After a fused step at num_types > 512: the touched rows of the two [T,64] table gradients -- ascending distinct row ids
+ * rows_comp / rows_query and their counts n_touched (device int32[2]) -- as pointers INTO `ws` (valid until the next step
+ * on it).  The row list a data-parallel job exchanges instead of the dense tables (north_star: "reduce-scatter for the
+ * sparse grads"; src/models/p_companion.py:36-43 + train.py:46-48): 17.8 MB of dense tables at T = 34800 against
+ * 260 B per touched row. */
+int pc_joint_fused_touched(void *ws, size_t ws_bytes, int batch, int num_types, int k, const int32_t **rows_comp,
+                           const int32_t **rows_query, const int32_t **n_touched);
 int pc_joint_fused_step(const pc_joint_tensors *p, const pc_joint_tensors *g, const pc_joint_tensors *exp_avg,
                         const pc_joint_tensors *exp_avg_sq, int64_t *step_count, double lr, double beta1,
                         double beta2, double eps, const int32_t *query_idx, const int32_t *query_types,

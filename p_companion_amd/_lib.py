@@ -118,6 +118,7 @@ SIGNATURES = {
                                  _f, _vp, _vp, _vp, _sz, _vp]),
     "pc_joint_fused_workspace_bytes": (_sz, [_i, _i, _i]),
     "pc_joint_fused_supported": (_i, [_i, _i, _f]),
+    "pc_joint_fused_touched": (_i, [_vp, _sz, _i, _i, _i, _P(ctypes.c_void_p), _P(ctypes.c_void_p), _P(ctypes.c_void_p)]),
     "pc_joint_fused_step": (_i, [_P(JointTensors), _P(JointTensors), _P(JointTensors), _P(JointTensors), _vp, _d, _d, _d, _d,
                                  _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _f, _vp, _vp, _vp, _vp, _sz, _vp]),
     "pc_joint_fused_step_pairs": (_i, [_P(JointTensors), _P(JointTensors), _P(JointTensors), _P(JointTensors), _vp, _d, _d, _d, _d,

@@ -342,8 +342,9 @@ struct NtArgs {
 int launch_gemm_nt(const NtArgs& a, hipStream_t st);
 int gemm_nt_tiles(const SegInfo& si);
 // independent few-row products (M < 192 x 128 rows, N <= 128, K <= 128, no prologue / statistics) as one launch
-#define PC_NT_GROUP 4
+#define PC_NT_GROUP 8
 struct NtSmallGroup { NtArgs a[PC_NT_GROUP]; int ks_log2[PC_NT_GROUP], block0[PC_NT_GROUP + 1], n; };
+static_assert(sizeof(NtSmallGroup) <= 4096, "kernel argument segment");
 int launch_gemm_nt_group(const NtArgs* args, int n, hipStream_t st);
 // two few-row products over the same 32-row tiles in ONE launch (gemm_nt.hip: the attention block's projection chains)
 enum { NT_MODE_PLAIN = 0, NT_MODE_KHEAD = 1, NT_MODE_AHEAD = 2 };

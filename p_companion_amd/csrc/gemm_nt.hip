@@ -880,7 +880,7 @@ int launch_gemm_nt(const NtArgs& a, hipStream_t st) {
     // the fusions the two hot paths use (any other combination is refused)
     const int key = a.prologue * 100 + a.epilogue * 10 + a.stats;
     // few-row launches (latency-bound, a few us each) are booked apart from the persistent kernel family
-    const bool small_m = !(a.prologue == NT_PRO_BNTANH || a.N > 128 || a.stats != NT_STAT_NONE) && ntm < 192;
+    const bool small_m = ntm < 192;                        // (M < 24.5 k rows: the attention block's per-sample products at any width)
     const int pb = pc_prof_begin(small_m ? PC_KIND_GEMM_NT_SMALL : PC_KIND_GEMM_NT, 2.0 * a.M * (double)a.N * a.K, st);
     switch (key) {
         case 0:   launch_variant<false, NT_EPI_NONE, NT_STAT_NONE>(a, ntm, st); break;      // plain Linear / dX

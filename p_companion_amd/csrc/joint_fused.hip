@@ -1371,9 +1371,148 @@ __global__ __launch_bounds__(256) void scatter_add_rows_xcd_kernel(ScatterList l
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Large tables, DETERMINISTIC gradients (round 3; the atomics above remain the path for more than TG_CAP distinct rows):
+// the reference's NUM_TYPES = 34800 (config.py:27) is a big table of which a batch touches few rows (20 live types at the
+// reference's catalogue, 100 at the benchmark's).
+//   touched_types_kernel   one workgroup: bitmaps of the destination rows of both lists -> ascending lists ulist_c / ulist_q
+//                          and the inverse maps pos_c / pos_q (row -> index in its list)
+//   table_partials_kernel  256 workgroups, each a contiguous chunk of the source rows: chunk staged in LDS, rows added IN
+//                          SOURCE ORDER into an LDS table indexed by pos (destination u belongs to wave u % 4: one adder
+//                          per destination), the table's n_u rows written as the workgroup's slab
+//   table_reduce_kernel    table[ulist[u]] = sum of the 256 slabs in fixed order
+// No float atomic anywhere: the step is bitwise reproducible at any T.  The ascending lists also ARE the row lists of the
+// data-parallel exchange (pc_joint_fused_touched: SURVEY 8e-4, "reduce-scatter for the sparse grads").
+#define TG_CAP 512          /* distinct touched rows per table on the deterministic path: 512 x 64 floats = 128 KB of LDS */
+#define TG_WGS 256
+#define TG_CHUNK 64         /* source rows a workgroup stages at a time (16 KB) */
+
+__global__ __launch_bounds__(1024) void touched_types_kernel(const int32_t* idx_c, int n_c, const int32_t* idx_q, int n_q, int T,
+                                                             int32_t* ulist_c, int32_t* pos_c, int32_t* ulist_q,
+                                                             int32_t* pos_q, int32_t* n_touch) {
+    extern __shared__ unsigned bits[];                  // [words] then scan scratch [1024]
+    const int words = (T + 31) >> 5;
+    unsigned* part = bits + words;
+#pragma unroll 1
+    for (int li = 0; li < 2; li++) {
+        const int32_t* idx = li ? idx_q : idx_c;
+        const int n = li ? n_q : n_c;
+        int32_t* ulist = li ? ulist_q : ulist_c;
+        int32_t* pos = li ? pos_q : pos_c;
+        __syncthreads();
+        for (int i = threadIdx.x; i < words; i += 1024) bits[i] = 0u;
+        __syncthreads();
+        for (int r = threadIdx.x; r < n; r += 1024) {
+            const int t = idx[r];
+            if ((unsigned)t < (unsigned)T) atomicOr(&bits[t >> 5], 1u << (t & 31));      // (integer: the result is the set)
+        }
+        __syncthreads();
+        const int per = (words + 1023) / 1024;
+        const int lo = threadIdx.x * per, hi = min(words, lo + per);
+        int cnt = 0;
+        for (int i = lo; i < hi; i++) cnt += __popc(bits[i]);
+        part[threadIdx.x] = cnt;
+        __syncthreads();
+        for (int o = 1; o < 1024; o <<= 1) {
+            const unsigned v = threadIdx.x >= (unsigned)o ? part[threadIdx.x - o] : 0u;
+            __syncthreads();
+            part[threadIdx.x] += v;
+            __syncthreads();
+        }
+        int p = (int)part[threadIdx.x] - cnt;
+        for (int i = lo; i < hi; i++) {
+            unsigned m = bits[i];
+            while (m) {
+                const int bit = __ffs(m) - 1;
+                m &= m - 1;
+                pos[32 * i + bit] = p;
+                ulist[p++] = 32 * i + bit;
+            }
+        }
+        if (threadIdx.x == 1023) n_touch[li] = (int)part[1023];
+    }
+}
+
+struct TableList { float* table; const int32_t* idx; const float* src; int rows; const int32_t* pos; float* slabs; };
+
+__global__ __launch_bounds__(256) void table_partials_kernel(TableList l0, TableList l1, const int32_t* n_touch, int T) {
+    extern __shared__ __attribute__((aligned(16))) float tg_lds[];
+    float* tab = tg_lds;                                 // [TG_CAP][64]
+    float* rowsb = tg_lds + TG_CAP * PC_L;               // [TG_CHUNK][64]
+    int* dst = reinterpret_cast<int*>(rowsb + TG_CHUNK * PC_L);   // [TG_CHUNK]
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+#pragma unroll 1
+    for (int li = 0; li < 2; li++) {
+        const TableList& l = li ? l1 : l0;
+        const int nu = n_touch[li];
+        const int per = (l.rows + TG_WGS - 1) / TG_WGS;
+        const int lo = blockIdx.x * per, hi = min(l.rows, lo + per);
+        if (nu > TG_CAP) {
+            // more distinct rows than the LDS table holds: the row adds go to the (cleared) table by float atomics
+            for (int r = lo + w; r < hi; r += 4) {
+                const int d = l.idx[r];
+                if ((unsigned)d < (unsigned)T) unsafeAtomicAdd(l.table + (size_t)d * PC_L + lane, l.src[(size_t)r * PC_L + lane]);
+            }
+            continue;
+        }
+        __syncthreads();
+        for (int e = threadIdx.x; e < nu * PC_L; e += 256) tab[e] = 0.f;
+        for (int c0 = lo; c0 < hi; c0 += TG_CHUNK) {
+            const int nr = min(TG_CHUNK, hi - c0);
+            __syncthreads();
+            for (int e = threadIdx.x; e < nr * (PC_L / 4); e += 256)
+                *reinterpret_cast<float4*>(&rowsb[e * 4]) = *reinterpret_cast<const float4*>(l.src + (size_t)c0 * PC_L + e * 4);
+            if ((int)threadIdx.x < nr) {
+                const int d = l.idx[c0 + threadIdx.x];
+                dst[threadIdx.x] = (unsigned)d < (unsigned)T ? l.pos[d] : -1;
+            }
+            __syncthreads();
+            // destination u is wave (u % 4)'s: that wave adds u's rows in source order, nobody else touches tab[u]
+            for (int i = 0; i < nr; i++) {
+                const int u = dst[i];
+                if (u >= 0 && (u & 3) == w) tab[u * PC_L + lane] += rowsb[i * PC_L + lane];
+            }
+        }
+        __syncthreads();
+        float* slab = l.slabs + (size_t)blockIdx.x * TG_CAP * PC_L;
+        for (int e = threadIdx.x; e < nu * (PC_L / 4); e += 256)
+            *reinterpret_cast<float4*>(slab + e * 4) = *reinterpret_cast<const float4*>(&tab[e * 4]);
+    }
+}
+
+// table[ulist[u]][:] = sum_w slabs[w][u][:], w ascending in eight interleaved lanes then a fixed xor fold (as tn_reduce)
+__global__ __launch_bounds__(256) void table_reduce_kernel(TableList l0, TableList l1, const int32_t* ulist0, const int32_t* ulist1,
+                                                           const int32_t* n_touch) {
+    const int per_list = TG_CAP * (PC_L / 4) * 8 / 256;          // workgroups per list
+    const int li = (int)blockIdx.x >= per_list ? 1 : 0;
+    const TableList& l = li ? l1 : l0;
+    const int32_t* ulist = li ? ulist1 : ulist0;
+    const int nu = n_touch[li];
+    if (nu > TG_CAP) return;
+    const int t = ((int)blockIdx.x - li * per_list) * 256 + threadIdx.x;
+    const int j4 = t >> 3, g = t & 7;                     // float4 index inside [TG_CAP][64], slab lane
+    const int u = j4 / (PC_L / 4);
+    if (u >= nu) return;                                  // (whole 8-lane groups leave together)
+    const float* src = l.slabs + (size_t)j4 * 4;
+    float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll 4
+    for (int k = g; k < TG_WGS; k += 8) {
+        const float4 v = *reinterpret_cast<const float4*>(src + (size_t)k * TG_CAP * PC_L);
+        s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+    }
+#pragma unroll
+    for (int o = 1; o < 8; o <<= 1) {
+        s.x += __shfl_xor(s.x, o, 64); s.y += __shfl_xor(s.y, o, 64);
+        s.z += __shfl_xor(s.z, o, 64); s.w += __shfl_xor(s.w, o, 64);
+    }
+    if (g == 0) *reinterpret_cast<float4*>(l.table + (size_t)ulist[u] * PC_L + (j4 % (PC_L / 4)) * 4) = s;
+}
+
 struct FusedWs {
     float *part, *h, *dpi, *dtp, *dc, *dh, *dt, *ecsrc;
     int32_t *ecidx, *cids, *ulist, *n_u, *topk_by_type, *part_idx;
+    int32_t *tl_c, *tp_c, *tl_q, *tp_q, *n_touch;       // touched rows of the two big tables: ascending lists, row -> list position
+    float *tslab_c, *tslab_q;                           // [TG_WGS][TG_CAP][64] each
     float* part_val;
     float* wslabs; int wg_blocks, wslab_floats;      // joint_wgrad_kernel: one slab per workgroup
     int nchunks, ucap;
@@ -1405,9 +1544,19 @@ static FusedWs fused_ws_layout(void* base, int B, int T, int K) {
     w.wslabs = (float*)take((size_t)w.wg_blocks * w.wslab_floats * 4);
     w.nchunks = w.ucap = 0;
     w.ulist = w.n_u = w.topk_by_type = w.part_idx = nullptr;
+    w.tl_c = w.tp_c = w.tl_q = w.tp_q = w.n_touch = nullptr;
+    w.tslab_c = w.tslab_q = nullptr;
     w.part_val = nullptr;
     if (w.small) {
     } else {
+        const int nc = B * (K + 2);
+        w.tl_c = (int32_t*)take((size_t)(nc < T ? nc : T) * 4);
+        w.tp_c = (int32_t*)take((size_t)T * 4);
+        w.tl_q = (int32_t*)take((size_t)(B < T ? B : T) * 4);
+        w.tp_q = (int32_t*)take((size_t)T * 4);
+        w.n_touch = (int32_t*)take(256);
+        w.tslab_c = (float*)take((size_t)TG_WGS * TG_CAP * PC_L * 4);
+        w.tslab_q = (float*)take((size_t)TG_WGS * TG_CAP * PC_L * 4);
         w.nchunks = (T + TC - 1) / TC;
         w.ucap = B < T ? B : T;
         w.ulist = (int32_t*)take((size_t)w.ucap * 4);
@@ -1423,6 +1572,19 @@ static FusedWs fused_ws_layout(void* base, int B, int T, int K) {
 extern "C" size_t pc_joint_fused_workspace_bytes(int batch, int num_types, int k) {
     if (batch <= 0 || num_types <= 0 || k <= 0) return 0;
     return fused_ws_layout(nullptr, batch, num_types, k).total;
+}
+
+// The touched rows of the two [T,64] tables after a fused step at T > 512 (pointers INTO the workspace; valid until the next
+// step on it): ascending distinct row ids and their counts (device int32[2]: complementary table, query table).  This is the
+// row list a data-parallel job exchanges instead of the dense tables.
+extern "C" int pc_joint_fused_touched(void* ws, size_t ws_bytes, int batch, int num_types, int k, const int32_t** rows_comp,
+                                      const int32_t** rows_query, const int32_t** n_touched) {
+    if (!ws || batch <= 0 || num_types <= 0 || k <= 0 || !rows_comp || !rows_query || !n_touched) return PC_EINVAL;
+    if (ws_bytes < pc_joint_fused_workspace_bytes(batch, num_types, k)) return PC_EWORKSPACE;
+    FusedWs w = fused_ws_layout(ws, batch, num_types, k);
+    if (w.small) return PC_ESHAPE;                       // T <= 512: the tables travel densely (51 KB at T = 100)
+    *rows_comp = w.tl_c; *rows_query = w.tl_q; *n_touched = w.n_touch;
+    return PC_OK;
 }
 
 extern "C" int pc_joint_fused_supported(int num_types, int k, float dropout_p) {
@@ -1570,8 +1732,18 @@ static int fused_step_impl(const pc_joint_tensors* p, const pc_joint_tensors* g,
         PC_TRY(pc_launch_status());
     }
     if (!w.small) {
-        const ScatterList lc = {g->comp_types, w.ecidx, w.ecsrc, B * (K + 2)}, lq = {g->query_types, w.cids + B, w.dt, B};
-        PC_LAUNCH(scatter_add_rows_xcd_kernel, dim3(256), dim3(256), 0, st, lc, lq);
+        // table gradients: fixed-order sums over the touched rows (no float atomics while a table has <= TG_CAP touched rows)
+        const int words = (T + 31) / 32;
+        PC_LAUNCH(touched_types_kernel, dim3(1), dim3(1024), (size_t)(words + 1024) * 4, st, w.ecidx, B * (K + 2), w.cids + B, B, T,
+                  w.tl_c, w.tp_c, w.tl_q, w.tp_q, w.n_touch);
+        const TableList lc = {g->comp_types, w.ecidx, w.ecsrc, B * (K + 2), w.tp_c, w.tslab_c};
+        const TableList lq = {g->query_types, w.cids + B, w.dt, B, w.tp_q, w.tslab_q};
+        const size_t tlds = ((size_t)TG_CAP * PC_L + (size_t)TG_CHUNK * PC_L + TG_CHUNK) * 4;
+        static const hipError_t tattr = hipFuncSetAttribute(reinterpret_cast<const void*>(&table_partials_kernel),
+                                                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)tattr;
+        PC_LAUNCH(table_partials_kernel, dim3(TG_WGS), dim3(256), tlds, st, lc, lq, w.n_touch, T);
+        PC_LAUNCH(table_reduce_kernel, dim3(2 * (TG_CAP * (PC_L / 4) * 8 / 256)), dim3(256), 0, st, lc, lq, w.tl_c, w.tl_q, w.n_touch);
         PC_TRY(pc_launch_status());
     }
 

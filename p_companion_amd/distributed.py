@@ -193,3 +193,112 @@ class ShardedFeatureTable:
         remap = torch.full_like(flat, -1)
         remap[valid] = pos[inv]
         return rows_in, remap.to(torch.int32).reshape(ids.shape)
+
+
+class TableRowExchange:
+    """Data-parallel exchange of the gradients of P-Companion's two [NUM_TYPES, 64] embedding tables as ROW LISTS
+    (north_star: "reduce-scatter for the sparse grads"; src/models/p_companion.py:36-43 + train.py:46-48).
+
+    The reference's autograd materialises dense [T,64] gradients of which a batch touches few rows (20 live types at its
+    own catalogue, 100 at the benchmark's; at most B (K + 3) rows).  A dense all-reduce moves 2 x T x 256 B per step --
+    17.8 MB at config.py:27's T = 34800 -- where the touched rows are n x 260 B (26 KB at 100 live types).  Per step:
+      1. every rank's fused step has left ascending lists of its touched rows (pc_joint_fused_touched) and the locally
+         summed rows in its dense gradient tables;
+      2. all_gather of the two counts (one int64[2] message), then of the row ids and of the rows, padded to the largest
+         count (constant shapes per call: no variable-size collective);
+      3. every rank clears its own touched rows and adds the G lists IN RANK ORDER, each scaled by 1/G: a fixed summation
+         order, so all ranks hold bit-identical mean gradients (ids are distinct inside a list: no atomics contend).
+    The remaining 29 k dense weights travel as one all-reduce of their flat segment.
+
+    gather_fn(table, ids) / assign_fn(table, ids, rows) / add_fn(table, ids, rows): the HIP row movers on the GPU
+    (ops.gather_rows / scatter_rows / scatter_add_rows); the CPU tests inject torch equivalents (test infrastructure only)."""
+
+    def __init__(self, world, group=None, gather_fn=None, assign_fn=None, add_fn=None):
+        self.world, self.group = int(world), group
+        if gather_fn is None:
+            from . import ops
+            gather_fn, assign_fn, add_fn = ops.gather_rows, ops.scatter_rows, ops.scatter_add_rows
+        self.gather_fn, self.assign_fn, self.add_fn = gather_fn, assign_fn, add_fn
+        self.last_bytes = None
+
+    @staticmethod
+    def merge(table_grad, lists, world, assign_fn, add_fn, own_ids):
+        """table_grad [T,L]: this rank's dense table gradient; lists = [(ids_r, rows_r)] in RANK ORDER; own_ids: the rows this
+        rank touched (cleared first).  Leaves the mean over the ranks in table_grad."""
+        if own_ids.numel():
+            assign_fn(table_grad, own_ids, torch.zeros(own_ids.numel(), table_grad.shape[1], dtype=table_grad.dtype,
+                                                       device=table_grad.device))
+        inv = 1.0 / world
+        for ids, rows in lists:
+            if ids.numel():
+                add_fn(table_grad, ids, rows * inv)
+        return table_grad
+
+    def __call__(self, tables, touched):
+        """tables: [grad_comp [T,L], grad_query [T,L]]; touched: [ids_comp, ids_query] (int32, exact length, ascending)."""
+        G = self.world
+        dev = tables[0].device
+        n_loc = torch.tensor([int(t.numel()) for t in touched], dtype=torch.int64, device=dev)
+        counts = torch.empty(G, 2, dtype=torch.int64, device=dev)
+        if G > 1:
+            dist.all_gather_into_tensor(counts.view(-1), n_loc, group=self.group)
+        else:
+            counts[0] = n_loc
+        counts = counts.cpu()                                   # (the one host-visible read of the exchange)
+        sent = 0
+        for ti, (tab, ids) in enumerate(zip(tables, touched)):
+            cap = int(counts[:, ti].max())
+            if cap == 0:
+                continue
+            L = tab.shape[1]
+            ids_pad = torch.full((cap,), -1, dtype=torch.int32, device=dev)
+            rows_pad = torch.zeros(cap, L, dtype=tab.dtype, device=dev)
+            n = int(ids.numel())
+            if n:
+                ids_pad[:n] = ids
+                rows_pad[:n] = self.gather_fn(tab, ids)
+            all_ids = torch.empty(G, cap, dtype=torch.int32, device=dev)
+            all_rows = torch.empty(G, cap, L, dtype=tab.dtype, device=dev)
+            if G > 1:
+                dist.all_gather_into_tensor(all_ids.view(-1), ids_pad, group=self.group)
+                dist.all_gather_into_tensor(all_rows.view(-1), rows_pad.view(-1), group=self.group)
+            else:
+                all_ids[0], all_rows[0] = ids_pad, rows_pad
+            lists = [(all_ids[r, :int(counts[r, ti])].contiguous(), all_rows[r, :int(counts[r, ti])].contiguous()) for r in range(G)]
+            self.merge(tab, lists, G, self.assign_fn, self.add_fn, ids)
+            sent += cap * (4 + 4 * L)
+        self.last_bytes = {"row_lists_per_rank": sent, "dense_tables": sum(t.numel() * 4 for t in tables)}
+        return tables
+
+
+def joint_grad_hook(model, step, world, group=None):
+    """The data-parallel gradient exchange of the joint step as GraphedJointStep's grad_hook: T <= 512 -- one all-reduce of
+    the flat gradient buffer (both tables are 51 KB at T = 100); T > 512 -- the 29 k dense weights as one all-reduce of
+    their flat segment and the two [T,64] tables as row lists (TableRowExchange)."""
+    T = model.query_type_embeddings.weight.shape[0]
+    if T <= 512 or world == 1:
+        return lambda gflat: all_reduce_mean_(gflat, world)
+    from . import ops
+    ex = TableRowExchange(world, group)
+    names = [k for k, _ in model._named_flat()]
+    tab_names = ("query_type_embeddings.weight", "complementary_type_embeddings.weight")
+
+    def hook(gflat):
+        params = dict(model.named_parameters())
+        gq, gc = params[tab_names[0]].grad, params[tab_names[1]].grad
+        off, lo = 0, None                                       # the dense weights: the maximal runs of the flat buffer between tables
+        for k in names + [None]:
+            if k is None or k in tab_names:
+                if lo is not None:
+                    all_reduce_mean_(gflat[lo:off], world)       # (ops.JOINT_KEYS puts all eight Linear tensors first: one call)
+                    lo = None
+            elif lo is None:
+                lo = off
+            if k is not None:
+                off += params[k].numel()
+        rc, rq, nt = ops.joint_fused_touched(step.prepared.ws, step.batch_size, T, int(model.config.NUM_COMP_TYPES))
+        n_c, n_q = (int(v) for v in nt.tolist())
+        ex([gc, gq], [rc[:n_c], rq[:n_q]])
+        step.last_exchange_bytes = ex.last_bytes
+        return gflat
+    return hook

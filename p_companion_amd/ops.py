@@ -661,6 +661,21 @@ def joint_fused_step(params, grads, query_idx, query_types, pos_types, neg_types
     return losses, topk
 
 
+def joint_fused_touched(ws, b, t, k):
+    """pc_joint_fused_touched: (rows_comp, rows_query, n_touched) -- int32 device tensors aliasing the fused step's
+    workspace `ws` (a uint8 tensor): ascending touched rows of the two [T,64] tables (capacity-sized; the first
+    n_touched[0] / n_touched[1] entries are live) after a step at T > 512."""
+    rc, rq, nt = ctypes.c_void_p(), ctypes.c_void_p(), ctypes.c_void_p()
+    check(_lib.lib().pc_joint_fused_touched(_p(ws), ws.numel(), int(b), int(t), int(k), ctypes.byref(rc), ctypes.byref(rq),
+                                            ctypes.byref(nt)), "pc_joint_fused_touched")
+    base = ws.data_ptr()
+
+    def view(ptr, n):
+        off = ptr.value - base
+        return ws[off:off + 4 * n].view(torch.int32)
+    return view(rc, min(b * (k + 2), t)), view(rq, min(b, t)), view(nt, 2)
+
+
 class PreparedJointStep:
     """pc_joint_fused_step with every argument resolved once: the loop body then costs one foreign call (the per-step
     argument marshalling of joint_fused_step -- ~50 tensor checks, dict and struct building -- is as long as the three

@@ -12,7 +12,7 @@ root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 src = os.path.join(root, "gpurun_out", tag)
 dst = os.path.join(root, "profiles")
 os.makedirs(dst, exist_ok=True)
-for name in ("bench.json", "bench_under_rocprof.json", "bench_joint_under_rocprof.json"):
+for name in ("bench.json", "bench_under_rocprof.json", "bench_joint_under_rocprof.json", "bench_big.json", "bench_big_under_rocprof.json"):
     if os.path.exists(os.path.join(src, name)):
         shutil.copy(os.path.join(src, name), os.path.join(dst, f"{tag}_{name}"))
 
@@ -56,6 +56,7 @@ def kernel_stats(subdir, suffix):
 
 kernel_stats("prof", "")
 kernel_stats("prof_joint", "_joint")
+kernel_stats("prof_big", "_big")
 
 # ---- PMC passes
 def pmc(dirname, counter):
@@ -96,3 +97,33 @@ for dirs, out_name in ((("pmc_joint_fetch", "pmc_joint_write"), "joint"), (("pmc
                           "note": "all kernels of the process (batch construction, step, Adam) summed and divided by the steps run"}
     json.dump(res, open(os.path.join(dst, f"{tag}_{out_name}_pmc_traffic.json"), "w"), indent=1)
     print(out_name, "HBM bytes/step:", round(tot_f + tot_w))
+
+
+# ---- BASELINE configs[4] on one GPU (BIG=1): per-kernel HBM traffic and L2 hit rates, Zipf vs uniform negatives
+def pmc_multi(dirname, counters):
+    out = defaultdict(lambda: defaultdict(float))
+    cnt = defaultdict(int)
+    for fn in glob.glob(os.path.join(src, dirname, "*", "*counter_collection.csv")):
+        for row in csv.DictReader(open(fn)):
+            if row["Counter_Name"] not in counters: continue
+            k = short(row["Kernel_Name"])
+            out[k][row["Counter_Name"]] += float(row["Counter_Value"])
+            if row["Counter_Name"] == counters[0]: cnt[k] += 1
+    return out, cnt
+fe, wr_ = pmc("pmc_big_fetch", "FETCH_SIZE"), pmc("pmc_big_write", "WRITE_SIZE")
+if fe:
+    l2, l2n = pmc_multi("pmc_big_l2", ["TCC_HIT_sum", "TCC_MISS_sum"])
+    feu = pmc("pmc_bigu_fetch", "FETCH_SIZE")
+    l2u, _ = pmc_multi("pmc_bigu_l2", ["TCC_HIT_sum", "TCC_MISS_sum"])
+    res = {}
+    for k, (n, v) in fe.items():
+        w = wr_.get(k, [n, 0.0])
+        hit = lambda d: (round(d[k]["TCC_HIT_sum"] / max(1.0, d[k]["TCC_HIT_sum"] + d[k]["TCC_MISS_sum"]), 4) if k in d else None)
+        res[k] = {"launches": n, "fetch_bytes_corrected": round(v / n * 1024 * 2), "write_bytes": round(w[1] / max(1, w[0]) * 1024),
+                  "l2_hit_rate": hit(l2),
+                  "uniform_negatives": {"fetch_bytes_corrected": round(feu[k][1] / max(1, feu[k][0]) * 1024 * 2) if k in feu else None,
+                                        "l2_hit_rate": hit(l2u)}}
+    json.dump(res, open(os.path.join(dst, f"{tag}_big_pmc_traffic.json"), "w"), indent=1)
+    for k, v in res.items():
+        if "gemm_nt_kernel" in k or "gemm_tn8" in k:
+            print("big:", k[:60], v)

@@ -26,3 +26,17 @@ rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_joint34800_fetch -- p
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_joint34800_write -- python3 $R/bench.py --phase joint --types 34800 --steps 5 --warmup 2 --no-cpu-baseline --no-sustained --no-ref-types > /dev/null 2> $OUT/pmc_joint34800_write.err
 fi
 if [ -z "$NO_BENCH" ]; then cat $OUT/bench.json; fi
+# BIG=1: BASELINE configs[4] on ONE GPU (100 M products x 256, Zipf negatives; the catalogue is generated in HBM): kernel
+# trace + the HBM-traffic counters + the L2 hit counters of the same command (the hot-row cache question)
+if [ -n "$BIG" ]; then
+BIGARGS="--phase p2v --products 100000000 --dim 256 --negatives zipf --no-cpu-baseline --no-sustained"
+python3 $R/bench.py $BIGARGS --steps 30 --warmup 10 > $OUT/bench_big.json 2> $OUT/bench_big.err
+rocprofv3 --kernel-trace --stats -d $OUT/prof_big -o ${TAG}_big -- python3 $R/bench.py $BIGARGS --steps 20 --warmup 5 > $OUT/bench_big_under_rocprof.json 2> $OUT/rocprof_big.err
+rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_big_fetch -- python3 $R/bench.py $BIGARGS --steps 5 --warmup 2 > /dev/null 2> $OUT/pmc_big_fetch.err
+rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_big_write -- python3 $R/bench.py $BIGARGS --steps 5 --warmup 2 > /dev/null 2> $OUT/pmc_big_write.err
+rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum --output-format csv -d $OUT/pmc_big_l2 -- python3 $R/bench.py $BIGARGS --steps 5 --warmup 2 > /dev/null 2> $OUT/pmc_big_l2.err
+# the same three counter passes with UNIFORM negatives: what the Zipf head changes
+BIGU="--phase p2v --products 100000000 --dim 256 --negatives uniform --no-cpu-baseline --no-sustained"
+rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_bigu_fetch -- python3 $R/bench.py $BIGU --steps 5 --warmup 2 > /dev/null 2> $OUT/pmc_bigu_fetch.err
+rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum --output-format csv -d $OUT/pmc_bigu_l2 -- python3 $R/bench.py $BIGU --steps 5 --warmup 2 > /dev/null 2> $OUT/pmc_bigu_l2.err
+fi

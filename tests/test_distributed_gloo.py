@@ -116,3 +116,66 @@ def test_sharded_lookup_single_rank():
     rows, remap = tab.lookup(ids)
     ext = torch.cat([rows, torch.zeros(1, 4)])
     assert torch.equal(ext[remap.long()], torch.cat([full, torch.zeros(1, 4)])[ids.long()])
+
+
+# ------------------------------------------------------------------ row-list exchange of the type-table gradients
+def _joint_half_batch(rank, B, P, T_live, seed=0):
+    g = torch.Generator().manual_seed(seed)
+    full = {"query_idx": torch.randint(0, P, (2 * B,), generator=g, dtype=torch.int32),
+            "query_types": torch.randint(0, T_live, (2 * B,), generator=g),
+            "positive_types": torch.randint(0, T_live, (2 * B, 1), generator=g),
+            "negative_types": torch.randint(0, T_live, (2 * B, 1), generator=g),
+            "positive_items": torch.randn(2 * B, 128, generator=g), "negative_items": torch.randn(2 * B, 128, generator=g)}
+    half = {k: v[rank * B:(rank + 1) * B] for k, v in full.items()}
+    return full, half
+
+
+def _exchange_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    from oracle import joint_oracle
+    from p_companion_amd import distributed as pdist
+    pdist.init_from_env("cpu")
+    T, P, B = 3000, 200, 48
+    gt = torch.Generator().manual_seed(1)
+    st = joint_oracle.init_state(3, torch.randn(P, 128, generator=gt), T)
+    full, half = _joint_half_batch(rank, B, P, 25, seed=5)
+    loc = joint_oracle.train_step({k: v.clone() for k, v in st.items()}, half, joint_oracle.new_moments(st), 1)
+    ref = joint_oracle.train_step({k: v.clone() for k, v in st.items()}, full, joint_oracle.new_moments(st), 1)
+    names = ("complementary_type_embeddings.weight", "query_type_embeddings.weight")
+    tables = [loc["grads"][n].clone() for n in names]
+    touched = [torch.nonzero(t.abs().amax(1) > 0).reshape(-1).to(torch.int32) for t in tables]       # ascending, as the kernel lists them
+    ex = pdist.TableRowExchange(world, gather_fn=lambda t, i: t[i.long()],
+                                assign_fn=lambda t, i, r: t.index_copy_(0, i.long(), r),
+                                add_fn=lambda t, i, r: t.index_add_(0, i.long(), r))
+    ex(tables, touched)
+    ok = True
+    for n, t in zip(names, tables):
+        # the mean over the two ranks' B-sample means = the gradient of the 2B-sample mean
+        ok = ok and float((t - ref["grads"][n]).abs().max()) <= 1e-7 + 1e-5 * float(ref["grads"][n].abs().max())
+        ok = ok and bool((t[ref["grads"][n].abs().amax(1) == 0] == 0).all())          # untouched rows stay exactly zero
+    # all ranks hold bit-identical tables (fixed summation order: rank 0's list, then rank 1's)
+    both = [torch.empty_like(tables[0]) for _ in range(world)]
+    dist.all_gather(both, tables[0])
+    ok = ok and torch.equal(both[0], both[1])
+    ok = ok and ex.last_bytes["row_lists_per_rank"] < ex.last_bytes["dense_tables"] // 20
+    q.put((rank, bool(ok)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(180)
+def test_type_table_row_list_exchange_world2_equals_the_concatenated_batch():
+    """Two ranks, each with the oracle's gradients of its half batch (T = 3000 > 512, 25 live types): after the row-list
+    exchange both hold the gradients of the single-process step on the concatenated batch; far fewer bytes than the
+    dense tables."""
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_exchange_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=150) for _ in range(world))
+    for p in procs:
+        p.join(30)
+    assert res == {0: True, 1: True}

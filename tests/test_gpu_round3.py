@@ -258,3 +258,78 @@ def test_attention_saves_no_kv_buffer_and_matches_the_oracle_with_bias():
     # the key-bias gradient is analytically zero: the reference holds rounding noise there, this path an exact 0
     assert float(grads["attention.in_proj_bias"][D:2 * D].abs().max()) == 0.0
     assert float(pr["attention.in_proj_bias"].grad[D:2 * D].abs().max()) < 1e-5
+
+
+# ------------------------------------------------------------------ big tables: deterministic gradients + row lists
+def _pc_big(T, P=2000, seed=3):
+    from p_companion_amd.p_companion import PCompanion
+    g = torch.Generator().manual_seed(seed)
+    table = torch.randn(P, 128, generator=g)
+    torch.manual_seed(seed + 1)
+    return PCompanion(cfg(NUM_TYPES=T), table).to("cuda").train()
+
+
+@pytest.mark.parametrize("T,live", [(34800, 100), (34800, 20), (2000, 60)])
+def test_fused_joint_step_is_bitwise_reproducible_at_the_reference_num_types(T, live):
+    """config.py:27 NUM_TYPES = 34800 (and any T > 512 with <= 512 touched rows per table): the table gradients are
+    fixed-order sums -- two runs of the same step from the same state give bit-identical gradients of all ten tensors,
+    and the in-kernel Adam update is bit-identical too.  (Round 2: float atomics above T = 512.)"""
+    from p_companion_amd.product2vec import FusedAdam
+    B = 4096
+    m1, m2 = _pc_big(T), _pc_big(T)
+    o1, o2 = FusedAdam(m1, lr=1e-2), FusedAdam(m2, lr=1e-2)
+    for s in range(3):
+        b = joint_batch(B, 2000, live, seed=70 + s)
+        l1, t1 = m1.train_step(b, optimizer=o1)
+        l2, t2 = m2.train_step(b, optimizer=o2)
+        assert torch.equal(l1, l2) and torch.equal(t1, t2)
+        assert torch.equal(m1._gflat, m2._gflat), s
+        for (k, p1), (_, p2) in zip(m1.named_parameters(), m2.named_parameters()):
+            assert torch.equal(p1, p2), (s, k)
+    b = joint_batch(B, 2000, live, seed=99)
+    m1.train_step(b)
+    g1 = m1._gflat.clone()
+    for _ in range(3):
+        m1.train_step(b)
+        assert torch.equal(g1, m1._gflat)
+
+
+def test_touched_row_lists_and_the_row_list_exchange_on_the_gpu():
+    """pc_joint_fused_touched lists exactly the rows of the two [T,64] tables that received a gradient (ascending); two
+    replicas' lists merged by TableRowExchange.merge with the HIP row movers reproduce the step on the concatenated batch."""
+    from p_companion_amd import distributed as pdist
+    from p_companion_amd import ops
+    from p_companion_amd.p_companion import GraphedJointStep
+    from p_companion_amd.product2vec import FusedAdam
+    T, B, K = 34800, 512, 3
+    names = ("complementary_type_embeddings.weight", "query_type_embeddings.weight")
+    full = joint_batch(2 * B, 2000, 60, seed=4)
+    reps, lists = [], []
+    for r in range(2):
+        m = _pc_big(T)
+        step = GraphedJointStep(m, FusedAdam(m), B, warmup=0, mode="direct", grad_hook=lambda g: g)   # gradients only
+        half = {k: v[r * B:(r + 1) * B].contiguous() for k, v in full.items()}
+        step(half)
+        rc, rq, nt = ops.joint_fused_touched(step.prepared.ws, B, T, K)
+        n_c, n_q = (int(v) for v in nt.tolist())
+        params = dict(m.named_parameters())
+        per_table = []
+        for nm, ids in ((names[0], rc[:n_c]), (names[1], rq[:n_q])):
+            g = params[nm].grad
+            nz = torch.nonzero(g.abs().amax(1) > 0).reshape(-1).to(torch.int32)
+            # (a touched row can sum to exactly zero only by accident; the list must cover every non-zero row, ascending)
+            assert torch.equal(torch.sort(ids).values, ids) and len(torch.unique(ids)) == ids.numel()
+            assert bool(torch.isin(nz, ids).all()) and ids.numel() <= nz.numel() + 2
+            per_table.append((ids.clone(), ops.gather_rows(g, ids)))
+        reps.append((m, params))
+        lists.append(per_table)
+    ref = _pc_big(T)
+    ref.train_step(full)
+    rparams = dict(ref.named_parameters())
+    for ti, nm in enumerate(names):
+        for r in range(2):
+            g = reps[r][1][nm].grad
+            pdist.TableRowExchange.merge(g, [lists[0][ti], lists[1][ti]], 2, ops.scatter_rows, ops.scatter_add_rows, lists[r][ti][0])
+        assert torch.equal(reps[0][1][nm].grad, reps[1][1][nm].grad)                       # both replicas: the same bits
+        want = rparams[nm].grad
+        assert float((reps[0][1][nm].grad - want).abs().max()) <= 1e-7 + 1e-5 * float(want.abs().max()), nm
