@@ -53,12 +53,27 @@ def _stream():
 _ws_cache = {}
 
 
+def _default_alloc(n, dtype, device, zero=False):
+    return (torch.zeros if zero else torch.empty)(int(n), dtype=dtype, device=device)
+
+
+# Every device buffer the kernels WRITE through this package's own allocations -- workspaces (slabs included), the flat
+# parameter / gradient / moment buffers, the fixed batch and output buffers of the prepared steps -- comes from this hook.
+# tests/test_gpu_soak.py swaps in an allocator that brackets each buffer with sentinel-filled guard bands and checks them
+# after hundreds of thousands of steps; production code never touches it.
+_allocator = _default_alloc
+
+
+def alloc(n, dtype, device, zero=False):
+    return _allocator(n, dtype, device, zero)
+
+
 def workspace(nbytes, device, tag="ws"):
     """Grow-only scratch buffer per (device, stream, tag); contents never outlive a call."""
-    key = (device.index, torch.cuda.current_stream(device).cuda_stream, tag)
+    key = (device.index, torch.cuda.current_stream(device).cuda_stream, tag, _allocator)
     buf = _ws_cache.get(key)
     if buf is None or buf.numel() < nbytes:
-        buf = torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device=device)
+        buf = alloc(max(int(nbytes), 256), torch.uint8, device)
         _ws_cache[key] = buf
     return buf
 
@@ -337,9 +352,7 @@ def p2v_train_step(params, grads, table, anchor_idx, positive_idx, negative_idx,
     _req(negative_idx, torch.int32, "negative_idx", (b, k))
     if n and not compact:
         _req(neighbor_idx, torch.int32, "neighbor_idx", (b, n))
-    out = {"loss": torch.empty(1, dtype=torch.float32, device=dev),
-           "d_pos": torch.empty(b, dtype=torch.float32, device=dev),
-           "d_neg": torch.empty(b, dtype=torch.float32, device=dev)}
+    out = {"loss": alloc(1, torch.float32, dev), "d_pos": alloc(b, torch.float32, dev), "d_neg": alloc(b, torch.float32, dev)}
     if table.shape[1] != st.dim:
         raise ValueError(f"feature table width {table.shape[1]} != PRODUCT_EMB_DIM {st.dim} of the parameters")
     if want_emb:
@@ -693,10 +706,10 @@ class PreparedJointStep:
             _req(x, torch.int32, nm, (b,))
         pos, neg = batch["positive_items"], batch["negative_items"]
         _req(pos, torch.float32, "positive_items", (b, D)); _req(neg, torch.float32, "negative_items", (b, D))
-        self.losses = torch.empty(3, dtype=torch.float32, device=dev)
-        self.topk = torch.empty(b, k, dtype=torch.int32, device=dev)
+        self.losses = alloc(3, torch.float32, dev)
+        self.topk = alloc(b * k, torch.int32, dev).view(b, k)
         nbytes = _lib.lib().pc_joint_fused_workspace_bytes(b, t, k)
-        self.ws = torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device=dev)
+        self.ws = alloc(max(int(nbytes), 256), torch.uint8, dev)
         m_ref = v_ref = step = None
         lr = b1 = b2 = eps = 0.0
         if adam is not None:

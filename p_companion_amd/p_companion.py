@@ -13,6 +13,7 @@ parameter containers only.  Two ways in:
 """
 from typing import Dict
 
+import numpy as np
 import torch
 import torch.nn as nn
 
@@ -323,8 +324,8 @@ class GraphedJointStep:
         if dev.type != "cuda":
             raise RuntimeError("GraphedJointStep needs the model on the GPU")
         b = int(batch_size)
-        i32 = lambda *shape: torch.zeros(*shape, dtype=torch.int32, device=dev)
-        f32 = lambda: torch.zeros(b, ops.D, dtype=torch.float32, device=dev)
+        i32 = lambda *shape: ops.alloc(int(np.prod(shape)), torch.int32, dev, zero=True).view(*shape)
+        f32 = lambda: ops.alloc(b * ops.D, torch.float32, dev, zero=True).view(b, ops.D)
         self.static = {"query_idx": i32(b), "query_types": i32(b), "positive_types": i32(b, 1),
                        "negative_types": i32(b, 1), "positive_items": f32(), "negative_items": f32()}
         self.batch_size, self.warmup = b, int(warmup)

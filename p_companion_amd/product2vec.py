@@ -155,8 +155,8 @@ class FusedAdam(torch.optim.Optimizer):
         flat, gflat = self.module.flatten_parameters()
         if not self._state_ready or self.exp_avg.data_ptr() == 0 or self.exp_avg.numel() != flat.numel() \
                 or self.exp_avg.device != flat.device:
-            self.exp_avg = torch.zeros_like(flat)
-            self.exp_avg_sq = torch.zeros_like(flat)
+            self.exp_avg = ops.alloc(flat.numel(), torch.float32, flat.device, zero=True)
+            self.exp_avg_sq = ops.alloc(flat.numel(), torch.float32, flat.device, zero=True)
             self.step_count = torch.zeros(1, dtype=torch.int64, device=flat.device)
             self.scalars = torch.zeros(2, dtype=torch.float32, device=flat.device)
             self._state_ready = True
@@ -278,8 +278,8 @@ class _FlatParamsMixin:
         if not ok:
             dev = items[0][1].device
             n = sum(p.numel() for _, p in items)
-            flat = torch.empty(n, dtype=torch.float32, device=dev)
-            gflat = torch.zeros(n, dtype=torch.float32, device=dev)
+            flat = ops.alloc(n, torch.float32, dev)
+            gflat = ops.alloc(n, torch.float32, dev, zero=True)
             off = 0
             for _, p in items:
                 m = p.numel()
