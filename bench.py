@@ -344,7 +344,7 @@ def run_p2v(args, rank, world, dev, products, steps, warmup, want_cpu, profile_k
         local = table if on_device else pdist.ShardedFeatureTable.shard(table, rank, world)
         sharded = pdist.ShardedFeatureTable(local, bpg.num_products, rank, world)
     loader = SimilarityIndexLoader(bpg, args.batch, shuffle=True, sampler="philox", seed=1 + rank, drop_last=True,
-                                   device=dev, sharded=sharded, negatives=args.negatives)
+                                   device=dev, sharded=sharded, negatives=args.negatives, reuse_buffers=True)
 
     def batches():
         while True:

@@ -227,7 +227,7 @@ class SimilarityIndexLoader:
 
     def __init__(self, bpg: IntBPG, batch_size: int, shuffle=True, sampler="philox", seed=0, k_neg=5,
                  drop_last=False, device="cuda", compact=True, prefetch=True, unique=True, sharded=None,
-                 negatives="uniform", popularity=None):
+                 negatives="uniform", popularity=None, reuse_buffers=False):
         from . import ops
         self.ops = ops
         self.bpg = bpg
@@ -248,6 +248,12 @@ class SimilarityIndexLoader:
         self.prefetch = prefetch and sampler == "philox" and torch.device(device).type == "cuda"
         self.epoch = 0
         self.step = 0
+        # reuse_buffers (training loops: train_model, bench.py): batches are built into a RING of preallocated buffers instead
+        # of fresh tensors (ops.BatchBuffers: no allocation and, above all, no cross-stream free per step).  A batch handed out
+        # stays valid until RING - 2 further batches have been requested: a loop that consumes each batch before asking for
+        # the next may use it; code that keeps batches (tests collecting an epoch) must not.
+        self.reuse_buffers = bool(reuse_buffers)
+        self._ring, self._ring_done = None, None
         # negatives='zipf' (BASELINE configs[4]; an extension, the reference draws uniformly): P(rank) ~ 1 / rank over the
         # popularity permutation `popularity` ([P] int32 product id per rank; None: product 0 is the most popular),
         # same rejection rules, device sampler only
@@ -358,6 +364,7 @@ class SimilarityIndexLoader:
         _, _, perm, host, ev = nxt
         ev.synchronize()
         cur.wait_event(ev)
+        self._last_plan_ev = ev
         perm.record_stream(cur)
         if getattr(self, "_side", None) is not None:
             perm.record_stream(self._side)
@@ -385,6 +392,9 @@ class SimilarityIndexLoader:
         else:
             perm_dev = torch.from_numpy(perm.astype(np.int32)).to(self.device)
         self.epoch += 1
+        ring_ok = self.reuse_buffers and self.prefetch and self.sampler == "philox" and self.compact and self.sharded is None
+        base = getattr(self, "_ring_base", 0)
+
         def make(i):
             lo, hi = i * self.batch_size, min((i + 1) * self.batch_size, S)
             if plan is not None:
@@ -395,12 +405,14 @@ class SimilarityIndexLoader:
             nbc = None
             if self.sampler == "philox" and self.compact and n_pad > 0:
                 n_real = n_real_plan if plan is not None else int(np.minimum(self._deg[ids], n_pad).sum())
+                slot = self._ring_slot(base + i) if ring_ok else None
+                out = slot.views(hi - lo, n_pad, n_real, self.unique) if slot is not None else None
                 if self.unique:
                     a, p, ng, nbc = self.ops.build_similarity_batch_unique(perm_dev[lo:hi], self.g, n_pad, self.k_neg,
-                                                                           self.seed, self.step, n_real)
+                                                                           self.seed, self.step, n_real, out=out)
                     # the row count is needed on the host (kernel grids): fetched through pinned memory behind the
                     # builder, read when the batch is handed out (a whole step later when prefetching)
-                    host_n = torch.empty(1, dtype=torch.int32).pin_memory()
+                    host_n = slot.host_n if slot is not None else torch.empty(1, dtype=torch.int32).pin_memory()
                     host_n.copy_(nbc["n_unique"], non_blocking=True)
                     ev = torch.cuda.Event(); ev.record(torch.cuda.current_stream(self.device))
                     nbc["n_unique_dev"] = nbc["n_unique"]              # [1] int32 on the device (the sharded lookup reads it there)
@@ -408,7 +420,7 @@ class SimilarityIndexLoader:
                     nbc["n_real"] = n_real
                 else:
                     a, p, ng, nbc = self.ops.build_similarity_batch_compact(perm_dev[lo:hi], self.g, n_pad, self.k_neg,
-                                                                            self.seed, self.step, n_real)
+                                                                            self.seed, self.step, n_real, out=out)
                 nb = None
             elif self.sampler == "philox":
                 a, p, ng, nb = self.ops.build_similarity_batch(perm_dev[lo:hi], self.g, n_pad, self.k_neg,
@@ -450,28 +462,71 @@ class SimilarityIndexLoader:
         if getattr(self, "_side", None) is None:
             self._side = torch.cuda.Stream(self.device)
         side = self._side
-        side.wait_stream(torch.cuda.current_stream(self.device))     # the epoch permutation was uploaded there
+        base = getattr(self, "_ring_base", 0)                 # hand-outs of earlier epochs: the ring's sequence runs across epochs
+        clean = getattr(self, "_ring_clean", True)              # False: the previous epoch's iterator was abandoned mid-way
+        self._ring_clean = False
+        if not clean and self._ring_done is not None:
+            self._ring_done = [None] * self.RING
+        if ring_ok and clean and getattr(self, "_last_plan_ev", None) is not None and plan is not None:
+            # the builders need this epoch's permutation (plan stream), not the training stream's backlog: waiting for
+            # that would drain the pipeline at every epoch boundary; the ring's own events order the buffer reuse
+            side.wait_event(self._last_plan_ev)
+        else:
+            side.wait_stream(torch.cuda.current_stream(self.device))     # the epoch permutation was uploaded there
         def launch(i):
             with torch.cuda.stream(side):
                 b = make(i)
                 ev = torch.cuda.Event()
                 ev.record(side)
             return b, ev
-        nxt = launch(0) if n > 0 else None
+        # TWO batches ahead: the builder of batch i + 2 is queued when batch i is handed out, so that its event has completed
+        # by the time the batch is asked for (the host runs about one step ahead of the device: one batch ahead, the event
+        # was pending about every other time and the wait below cost the training stream a barrier packet per step)
+        depth = max(1, int(getattr(self, "prefetch_depth", 4 if ring_ok else 2)))
+        from collections import deque
+        ahead = deque(launch(j) for j in range(min(depth, n)))
         for i in range(n):
-            batch, ev = nxt
-            nxt = launch(i + 1) if i + 1 < n else None
+            batch, ev = ahead.popleft()
             cur = torch.cuda.current_stream(self.device)
+            if ring_ok:
+                # everything the training stream has queued so far -- the steps over batches < i -- precedes this event; the
+                # builder that reuses a slot waits for the event recorded RING - depth hand-outs earlier (one event record
+                # per step on the training stream instead of one per freed tensor)
+                done = torch.cuda.Event()
+                done.record(cur)
+                self._ring_done[(base + i) % len(self._ring_done)] = done
+            if i + depth < n:
+                ahead.append(launch(i + depth))
             # the builder ran a step ago: normally its event has completed, and then nothing needs to be queued (a
             # cross-stream wait costs the consuming stream a barrier packet, ~10-40 us in front of every step's first kernel)
             if not ev.query():
-                cur.wait_event(ev)
-            for v in batch.values():
-                for t in (v.values() if isinstance(v, dict) else [v]):
-                    if torch.is_tensor(t):
-                        t.record_stream(cur)        # allocated on the side stream, consumed on this one
+                # The HOST waits for the builder, not the training stream: a cross-stream wait is a barrier packet in front
+                # of the step's first kernel (measured: a 67 us hole at every step boundary, scripts/dev/fixed_batch_probe.py),
+                # while the host runs far ahead of the device (0.3 ms of enqueue work per ~1 ms step) and loses nothing by
+                # blocking for a builder that was queued two steps ago.
+                ev.synchronize()
+            if not ring_ok:
+                for v in batch.values():
+                    for t in (v.values() if isinstance(v, dict) else [v]):
+                        if torch.is_tensor(t):
+                            t.record_stream(cur)        # allocated on the side stream, consumed on this one
             yield batch
+        self._ring_base = base + n
+        self._ring_clean = True
         self._end_of_epoch_checks()
+
+    RING = 16
+
+    def _ring_slot(self, i):
+        """Slot i % RING of the buffer ring, safe to overwrite: builder i runs `depth` hand-outs ahead; the slot last held
+        batch i - RING, whose step was queued before hand-out i - RING + 1 -- the builder's stream waits for that event."""
+        if self._ring is None:
+            self._ring = [self.ops.BatchBuffers(self.batch_size, self._max_deg, self.k_neg, self.device) for _ in range(self.RING)]
+            self._ring_done = [None] * self.RING
+        ev = self._ring_done[(i - self.RING + 1) % self.RING] if i >= self.RING else None
+        if ev is not None:
+            torch.cuda.current_stream(self.device).wait_event(ev)      # (the builder's stream: make() runs under it)
+        return self._ring[i % self.RING]
 
     def _end_of_epoch_checks(self, wait=False):
         """Device-side error counters, read WITHOUT stalling the pipeline: at the end of an epoch the counters are copied to

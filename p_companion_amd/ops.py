@@ -430,19 +430,50 @@ def build_similarity_batch(pair_ids, graph, n_pad, k_neg, seed, step):
     return a, p, ng, nb
 
 
-def build_similarity_batch_compact(pair_ids, graph, n_pad, k_neg, seed, step, n_real):
+class BatchBuffers:
+    """One slot of a loader's ring of batch buffers, sized for the largest batch (B samples, n_max neighbour slots each):
+    the builders write into views of it (`out=`), so a steady-state step allocates nothing and -- the point -- frees
+    nothing: every tensor that is allocated on the builder's stream, used on the training stream and then freed costs
+    the TRAINING stream an event-record packet at the free (torch's allocator does that for record_stream'ed blocks);
+    nine such tensors per batch were a 40-70 us hole at every step boundary (scripts/dev/fixed_batch_probe.py)."""
+
+    def __init__(self, b, n_max, k_neg, device):
+        i32 = lambda n: torch.empty(n, dtype=torch.int32, device=device)
+        slots = b * max(n_max, 1)
+        self.b, self.n_max, self.k = b, n_max, k_neg
+        self.a, self.p, self.ng = i32(b), i32(b), i32(b * k_neg)
+        self.nb_rows, self.ref_off, self.ref_slot, self.slot_row = i32(slots + 2), i32(slots + 3), i32(slots + 1), i32(slots)
+        self.weight = torch.empty(slots + 2, dtype=torch.float32, device=device)
+        self.n_unique, self.row_off = i32(1), i32(b + 1)
+        self.host_n = torch.empty(1, dtype=torch.int32).pin_memory()
+
+    def views(self, b, n_pad, n_real, unique):
+        if b > self.b or n_pad > self.n_max or n_real > self.b * max(self.n_max, 1):
+            raise ValueError("batch larger than the ring's buffers")
+        v = {"a": self.a[:b], "p": self.p[:b], "ng": self.ng[:b * self.k].view(b, self.k), "nb_rows": self.nb_rows[:n_real + 1],
+             "slot_row": self.slot_row[:b * n_pad].view(b, n_pad), "row_off": self.row_off[:b + 1]}
+        if unique:
+            v.update(weight=self.weight[:n_real + 1], ref_off=self.ref_off[:n_real + 2], ref_slot=self.ref_slot[:max(n_real, 1)],
+                     n_unique=self.n_unique)
+        return v
+
+
+def build_similarity_batch_compact(pair_ids, graph, n_pad, k_neg, seed, step, n_real, out=None):
     """Same batch with the neighbour rows compacted (pc_build_similarity_batch_compact): returns
     anchor_idx, positive_idx, negative_idx, {"nb_rows": [n_real+1], "slot_row": [B,n_pad]}.  n_real =
     sum of the batch's (capped) co-view degrees, known to the host loader."""
     b = pair_ids.numel()
     dev = pair_ids.device
     _req(pair_ids, torch.int32, "pair_ids")
-    a = torch.empty(b, dtype=torch.int32, device=dev)
-    p = torch.empty(b, dtype=torch.int32, device=dev)
-    ng = torch.empty(b, k_neg, dtype=torch.int32, device=dev)
-    nb_rows = torch.empty(n_real + 1, dtype=torch.int32, device=dev)
-    slot_row = torch.empty(b, n_pad, dtype=torch.int32, device=dev)
-    row_off = torch.empty(b + 1, dtype=torch.int32, device=dev)
+    if out is not None:
+        a, p, ng, nb_rows, slot_row, row_off = (out[k] for k in ("a", "p", "ng", "nb_rows", "slot_row", "row_off"))
+    else:
+        a = torch.empty(b, dtype=torch.int32, device=dev)
+        p = torch.empty(b, dtype=torch.int32, device=dev)
+        ng = torch.empty(b, k_neg, dtype=torch.int32, device=dev)
+        nb_rows = torch.empty(n_real + 1, dtype=torch.int32, device=dev)
+        slot_row = torch.empty(b, n_pad, dtype=torch.int32, device=dev)
+        row_off = torch.empty(b + 1, dtype=torch.int32, device=dev)
     check(_lib.lib().pc_build_similarity_batch_compact(
         _p(pair_ids), b, _p(graph["sim_pairs"]), _p(graph["cv_rowptr"]), _p(graph["cv_col"]), _p(graph["sim_rowptr"]),
         _p(graph["sim_col"]), int(graph["n_products"]), n_pad, k_neg, int(seed), int(step), _p(a), _p(p), _p(ng),
@@ -453,7 +484,7 @@ def build_similarity_batch_compact(pair_ids, graph, n_pad, k_neg, seed, step, n_
 _uq_scratch = {}
 
 
-def build_similarity_batch_unique(pair_ids, graph, n_pad, k_neg, seed, step, n_real):
+def build_similarity_batch_unique(pair_ids, graph, n_pad, k_neg, seed, step, n_real, out=None):
     """Same batch in the unique-neighbour layout (pc_build_similarity_batch_unique): returns anchor_idx,
     positive_idx, negative_idx, {"nb_rows": [n_real+1], "weight": [n_real+1] fp32, "slot_row": [B,n_pad],
     "n_unique": [1] int32 DEVICE tensor}.  Only the first n_unique+1 entries of nb_rows / weight are meaningful;
@@ -470,15 +501,19 @@ def build_similarity_batch_unique(pair_ids, graph, n_pad, k_neg, seed, step, n_r
         _uq_scratch[key] = torch.zeros(max(need, _lib.lib().pc_build_similarity_batch_unique_scratch_bytes(npr, 2 * slots)),
                                        dtype=torch.uint8, device=dev)
     scratch = _uq_scratch[key]
-    a = torch.empty(b, dtype=torch.int32, device=dev)
-    p = torch.empty(b, dtype=torch.int32, device=dev)
-    ng = torch.empty(b, k_neg, dtype=torch.int32, device=dev)
-    nb_rows = torch.empty(n_real + 1, dtype=torch.int32, device=dev)
-    weight = torch.empty(n_real + 1, dtype=torch.float32, device=dev)
-    slot_row = torch.empty(b, n_pad, dtype=torch.int32, device=dev)
-    n_unique = torch.empty(1, dtype=torch.int32, device=dev)
-    ref_off = torch.empty(n_real + 2, dtype=torch.int32, device=dev)
-    ref_slot = torch.empty(max(n_real, 1), dtype=torch.int32, device=dev)
+    if out is not None:
+        a, p, ng, nb_rows, weight, slot_row, n_unique, ref_off, ref_slot = (
+            out[k] for k in ("a", "p", "ng", "nb_rows", "weight", "slot_row", "n_unique", "ref_off", "ref_slot"))
+    else:
+        a = torch.empty(b, dtype=torch.int32, device=dev)
+        p = torch.empty(b, dtype=torch.int32, device=dev)
+        ng = torch.empty(b, k_neg, dtype=torch.int32, device=dev)
+        nb_rows = torch.empty(n_real + 1, dtype=torch.int32, device=dev)
+        weight = torch.empty(n_real + 1, dtype=torch.float32, device=dev)
+        slot_row = torch.empty(b, n_pad, dtype=torch.int32, device=dev)
+        n_unique = torch.empty(1, dtype=torch.int32, device=dev)
+        ref_off = torch.empty(n_real + 2, dtype=torch.int32, device=dev)
+        ref_slot = torch.empty(max(n_real, 1), dtype=torch.int32, device=dev)
     check(_lib.lib().pc_build_similarity_batch_unique(
         _p(pair_ids), b, _p(graph["sim_pairs"]), _p(graph["cv_rowptr"]), _p(graph["cv_col"]), _p(graph["sim_rowptr"]),
         _p(graph["sim_col"]), npr, n_pad, k_neg, int(seed), int(step), int(n_real), _p(a), _p(p), _p(ng), _p(nb_rows),

@@ -22,7 +22,7 @@ def pretrain_product2vec(config, similarity_dataset) -> Dict[str, torch.Tensor]:
     logger = logging.getLogger(__name__)
     if isinstance(similarity_dataset, IntBPG):
         loader = SimilarityIndexLoader(similarity_dataset, config.BATCH_SIZE, shuffle=True, sampler="philox",
-                                       device=config.DEVICE)
+                                       device=config.DEVICE, reuse_buffers=True)     # (train_model consumes each batch before the next)
     else:
         loader = similarity_dataset
     model = Product2Vec(config).to(config.DEVICE)
