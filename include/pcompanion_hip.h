@@ -390,6 +390,10 @@ int pc_joint_loss(const float *sims, const float *proj, const int32_t *pos_types
                   const int32_t *neg_types, const float *pos_items, const float *neg_items,
                   int batch, int num_types, int k, float margin, float alpha, float *losses,
                   float *dsims_val, float *dproj, float *partials, void *stream);
+int pc_joint_loss_dim(const float *sims, const float *proj, const int32_t *pos_types, const int32_t *neg_types,
+                      const float *pos_items, const float *neg_items, int batch, int num_types, int k, int dim,
+                      float margin, float alpha, float *losses, float *dsims_val, float *dproj, float *partials,
+                      void *stream);                                                   /* PRODUCT_EMB_DIM 128 or 256 */
 
 /* Dense form of the sparse type-hinge gradient, for callers whose autograd graph needs
  * d(loss)/d(type_similarities) as a [B,T] tensor (what p_companion.py:96-97's advanced
@@ -515,13 +519,17 @@ int pc_topk_rows(const float *sims, int batch, int num_types, int k, int32_t *id
  *   (metrics.py:44-60).  D = 128. */
 int pc_hit_rank(const float *sims, int rows, int cols, int32_t *rank, void *stream);
 int pc_cosine_rows(const float *x, const float *y, int batch, int k, float *out, void *stream);
+int pc_cosine_rows_dim(const float *x, const float *y, int batch, int k, int dim, float *out, void *stream);
 
 /* item_prediction.py:38: proj[b,k,:] = pi[b,:] * tp[b*K+k,:] and its backward
  * (dpi[b] = sum_k dproj[b,k]*tp[b,k]; dtp[b,k] = dproj[b,k]*pi[b]).  D = 128. */
 int pc_hadamard_forward(const float *pi, const float *tp, int batch, int k, float *proj,
                         void *stream);
+int pc_hadamard_forward_dim(const float *pi, const float *tp, int batch, int k, int dim, float *proj, void *stream);   /* PRODUCT_EMB_DIM 128 or 256 (item_prediction.py:11-20 takes it from config) */
 int pc_hadamard_backward(const float *dproj, const float *pi, const float *tp, int batch, int k,
                          float *dpi, float *dtp, void *stream);
+int pc_hadamard_backward_dim(const float *dproj, const float *pi, const float *tp, int batch, int k, int dim,
+                             float *dpi, float *dtp, void *stream);
 
 /* ---------------------------------------------------------------------------------
  * Row movers used by the sharded-table exchange and the modules.
@@ -654,6 +662,9 @@ int pc_check_indices(const int32_t *const *idx, const int *n, const int *hi, con
 int pc_retrieve_topk(const float *proj, const int32_t *types, int rows, const int32_t *type_rowptr,
                      const int32_t *type_col, const float *table, int n_types, int n, int32_t *out_idx,
                      float *out_score, void *stream);
+int pc_retrieve_topk_dim(const float *proj, const int32_t *types, int rows, const int32_t *type_rowptr,
+                        const int32_t *type_col, const float *table, int n_types, int n, int dim, int32_t *out_idx,
+                        float *out_score, void *stream);
 
 #ifdef __cplusplus
 }

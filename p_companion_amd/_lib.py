@@ -111,6 +111,7 @@ SIGNATURES = {
     "pc_joint_workspace_bytes": (_sz, [_i, _i, _i]),
     "pc_joint_forward": (_i, [_P(JointTensors), _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _P(JointSaved), _vp, _sz, _vp]),
     "pc_joint_loss": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _f, _f, _vp, _vp, _vp, _vp, _vp]),
+    "pc_joint_loss_dim": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _f, _vp, _vp, _vp, _vp, _vp]),
     "pc_expand_type_grad": (_i, [_vp, _vp, _vp, _i, _i, _vp, _vp]),
     "pc_joint_backward": (_i, [_P(JointTensors), _P(JointTensors), _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp,
                                _P(JointSaved), _vp, _sz, _vp]),
@@ -134,9 +135,13 @@ SIGNATURES = {
     "pc_topk_rows": (_i, [_vp, _i, _i, _i, _vp, _vp, _vp]),
     "pc_hit_rank": (_i, [_vp, _i, _i, _vp, _vp]),
     "pc_cosine_rows": (_i, [_vp, _vp, _i, _i, _vp, _vp]),
+    "pc_cosine_rows_dim": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp]),
     "pc_retrieve_topk": (_i, [_vp, _vp, _i, _vp, _vp, _vp, _i, _i, _vp, _vp, _vp]),
+    "pc_retrieve_topk_dim": (_i, [_vp, _vp, _i, _vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp]),
     "pc_hadamard_forward": (_i, [_vp, _vp, _i, _i, _vp, _vp]),
+    "pc_hadamard_forward_dim": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp]),
     "pc_hadamard_backward": (_i, [_vp, _vp, _vp, _i, _i, _vp, _vp, _vp]),
+    "pc_hadamard_backward_dim": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp]),
     "pc_gather_rows": (_i, [_vp, _vp, _i, _i, _vp, _vp]),
     "pc_scatter_add_rows": (_i, [_vp, _vp, _i, _i, _vp, _vp]),
     "pc_scatter_add_rows_small": (_i, [_vp, _i, _vp, _i, _i, _vp, _vp]),

@@ -155,49 +155,71 @@ extern "C" int pc_topk_rows(const float* sims, int batch, int num_types, int k, 
 }
 
 // proj[b,k,:] = pi[b,:] * tp[b*K+k,:]   (item_prediction.py:38)
-__global__ void hadamard_fwd_kernel(const float* pi, const float* tp, int B, int K, float* proj) {
+__global__ void hadamard_fwd_kernel(const float* pi, const float* tp, int B, int K, int D, float* proj) {
     const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;      // float4 index
-    const size_t total = (size_t)B * K * (PC_D / 4);
+    const size_t total = (size_t)B * K * (D / 4);
     if (t >= total) return;
-    const size_t row = t / (PC_D / 4);
-    const int c = (int)(t % (PC_D / 4));
-    const float4 a = *reinterpret_cast<const float4*>(pi + (row / K) * PC_D + c * 4);
+    const size_t row = t / (D / 4);
+    const int c = (int)(t % (D / 4));
+    const float4 a = *reinterpret_cast<const float4*>(pi + (row / K) * D + c * 4);
     const float4 x = *reinterpret_cast<const float4*>(tp + t * 4);
     *reinterpret_cast<float4*>(proj + t * 4) = make_float4(a.x * x.x, a.y * x.y, a.z * x.z, a.w * x.w);
 }
 
 // dpi[b] = sum_k dproj[b,k]*tp[b,k] ; dtp[b,k] = dproj[b,k]*pi[b] : one wave per sample
+// (PRODUCT_EMB_DIM = 128 or 256: a lane owns dims (2 lane, 2 lane + 1) of every 128-dim chunk, NCH = D / 128 chunks)
+template <int NCH>
 __global__ __launch_bounds__(256) void hadamard_bwd_kernel(const float* dproj, const float* pi, const float* tp,
                                                            int B, int K, float* dpi, float* dtp) {
+    constexpr int D = 128 * NCH;
     const int lane = threadIdx.x & 63;
     const int b = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (b >= B) return;
-    const float2 a = *reinterpret_cast<const float2*>(pi + (size_t)b * PC_D + 2 * lane);
-    float2 acc = make_float2(0.f, 0.f);
-    for (int k = 0; k < K; k++) {
-        const size_t o = ((size_t)b * K + k) * PC_D + 2 * lane;
-        const float2 g = *reinterpret_cast<const float2*>(dproj + o);
-        const float2 x = *reinterpret_cast<const float2*>(tp + o);
-        acc.x += g.x * x.x; acc.y += g.y * x.y;
-        *reinterpret_cast<float2*>(dtp + o) = make_float2(g.x * a.x, g.y * a.y);
+    float2 a[NCH], acc[NCH];
+#pragma unroll
+    for (int ch = 0; ch < NCH; ch++) {
+        a[ch] = *reinterpret_cast<const float2*>(pi + (size_t)b * D + 128 * ch + 2 * lane);
+        acc[ch] = make_float2(0.f, 0.f);
     }
-    *reinterpret_cast<float2*>(dpi + (size_t)b * PC_D + 2 * lane) = acc;
+    for (int k = 0; k < K; k++) {
+#pragma unroll
+        for (int ch = 0; ch < NCH; ch++) {
+            const size_t o = ((size_t)b * K + k) * D + 128 * ch + 2 * lane;
+            const float2 g = *reinterpret_cast<const float2*>(dproj + o);
+            const float2 x = *reinterpret_cast<const float2*>(tp + o);
+            acc[ch].x += g.x * x.x; acc[ch].y += g.y * x.y;
+            *reinterpret_cast<float2*>(dtp + o) = make_float2(g.x * a[ch].x, g.y * a[ch].y);
+        }
+    }
+#pragma unroll
+    for (int ch = 0; ch < NCH; ch++) *reinterpret_cast<float2*>(dpi + (size_t)b * D + 128 * ch + 2 * lane) = acc[ch];
 }
 
-extern "C" int pc_hadamard_forward(const float* pi, const float* tp, int batch, int k, float* proj, void* stream) {
+extern "C" int pc_hadamard_forward_dim(const float* pi, const float* tp, int batch, int k, int dim, float* proj, void* stream) {
     if (!pi || !tp || !proj || batch <= 0 || k <= 0) return PC_EINVAL;
-    const size_t total = (size_t)batch * k * (PC_D / 4);
+    if (dim != 128 && dim != 256) return PC_ESHAPE;
+    const size_t total = (size_t)batch * k * (dim / 4);
     PC_LAUNCH(hadamard_fwd_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
-                       pi, tp, batch, k, proj);
+                       pi, tp, batch, k, dim, proj);
     return pc_launch_status();
 }
+extern "C" int pc_hadamard_forward(const float* pi, const float* tp, int batch, int k, float* proj, void* stream) {
+    return pc_hadamard_forward_dim(pi, tp, batch, k, PC_D, proj, stream);
+}
 
+extern "C" int pc_hadamard_backward_dim(const float* dproj, const float* pi, const float* tp, int batch, int k, int dim,
+                                        float* dpi, float* dtp, void* stream) {
+    if (!dproj || !pi || !tp || !dpi || !dtp || batch <= 0 || k <= 0) return PC_EINVAL;
+    if (dim != 128 && dim != 256) return PC_ESHAPE;
+    if (dim == 128) PC_LAUNCH(hadamard_bwd_kernel<1>, dim3((batch + 3) / 4), dim3(256), 0, (hipStream_t)stream, dproj, pi, tp,
+                              batch, k, dpi, dtp);
+    else PC_LAUNCH(hadamard_bwd_kernel<2>, dim3((batch + 3) / 4), dim3(256), 0, (hipStream_t)stream, dproj, pi, tp,
+                   batch, k, dpi, dtp);
+    return pc_launch_status();
+}
 extern "C" int pc_hadamard_backward(const float* dproj, const float* pi, const float* tp, int batch, int k,
                                     float* dpi, float* dtp, void* stream) {
-    if (!dproj || !pi || !tp || !dpi || !dtp || batch <= 0 || k <= 0) return PC_EINVAL;
-    PC_LAUNCH(hadamard_bwd_kernel, dim3((batch + 3) / 4), dim3(256), 0, (hipStream_t)stream, dproj, pi, tp,
-                       batch, k, dpi, dtp);
-    return pc_launch_status();
+    return pc_hadamard_backward_dim(dproj, pi, tp, batch, k, PC_D, dpi, dtp, stream);
 }
 
 // ---------------------------------------------------------------------------------------
@@ -205,11 +227,13 @@ extern "C" int pc_hadamard_backward(const float* dproj, const float* pi, const f
 //   type_b = clamp(margin - S[b,pos] + S[b,neg], 0)
 //   item_bk = clamp(margin - ||proj_bk - pos_item_b|| + ||proj_bk - neg_item_b||, 0)   (torch.norm: no eps)
 //   loss = alpha * mean_{b,k} item + (1-alpha) * mean_b type
+template <int NCH>
 __global__ __launch_bounds__(256) void joint_loss_kernel(const float* sims, const float* proj,
                                                          const int32_t* pos_t, const int32_t* neg_t,
                                                          const float* pos_items, const float* neg_items, int B,
                                                          int T, int K, float margin, float alpha, float* part_type,
                                                          float* part_item, float* dsims_val, float* dproj) {
+    constexpr int D = 128 * NCH;
     const int lane = threadIdx.x & 63;
     const int b = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (b >= B) return;
@@ -222,21 +246,33 @@ __global__ __launch_bounds__(256) void joint_loss_kernel(const float* sims, cons
             dsims_val[2 * b + 1] = g;
         }
     }
-    const float2 pp = *reinterpret_cast<const float2*>(pos_items + (size_t)b * PC_D + 2 * lane);
-    const float2 nn = *reinterpret_cast<const float2*>(neg_items + (size_t)b * PC_D + 2 * lane);
+    float2 pp[NCH], nn[NCH];
+#pragma unroll
+    for (int ch = 0; ch < NCH; ch++) {
+        pp[ch] = *reinterpret_cast<const float2*>(pos_items + (size_t)b * D + 128 * ch + 2 * lane);
+        nn[ch] = *reinterpret_cast<const float2*>(neg_items + (size_t)b * D + 128 * ch + 2 * lane);
+    }
     float li = 0.f;
     for (int k = 0; k < K; k++) {
-        const size_t o = ((size_t)b * K + k) * PC_D + 2 * lane;
-        const float2 x = *reinterpret_cast<const float2*>(proj + o);
-        const float2 dp = make_float2(x.x - pp.x, x.y - pp.y), dn = make_float2(x.x - nn.x, x.y - nn.y);
-        const float np_ = sqrtf(wave_sum(dp.x * dp.x + dp.y * dp.y));
-        const float nn_ = sqrtf(wave_sum(dn.x * dn.x + dn.y * dn.y));
+        float2 dp[NCH], dn[NCH];
+        float sp_ = 0.f, sn_ = 0.f;
+#pragma unroll
+        for (int ch = 0; ch < NCH; ch++) {
+            const float2 x = *reinterpret_cast<const float2*>(proj + ((size_t)b * K + k) * D + 128 * ch + 2 * lane);
+            dp[ch] = make_float2(x.x - pp[ch].x, x.y - pp[ch].y); dn[ch] = make_float2(x.x - nn[ch].x, x.y - nn[ch].y);
+            sp_ += dp[ch].x * dp[ch].x + dp[ch].y * dp[ch].y; sn_ += dn[ch].x * dn[ch].x + dn[ch].y * dn[ch].y;
+        }
+        const float np_ = sqrtf(wave_sum(sp_));
+        const float nn_ = sqrtf(wave_sum(sn_));
         const float l = margin - np_ + nn_;
         li += l > 0.f ? l : 0.f;
         if (dproj) {
             const float g = l > 0.f ? alpha / ((float)B * (float)K) : 0.f;
             const float ip = np_ > 0.f ? g / np_ : 0.f, in = nn_ > 0.f ? g / nn_ : 0.f;   // torch.norm: subgradient 0 at 0
-            *reinterpret_cast<float2*>(dproj + o) = make_float2(-dp.x * ip + dn.x * in, -dp.y * ip + dn.y * in);
+#pragma unroll
+            for (int ch = 0; ch < NCH; ch++)
+                *reinterpret_cast<float2*>(dproj + ((size_t)b * K + k) * D + 128 * ch + 2 * lane) =
+                    make_float2(-dp[ch].x * ip + dn[ch].x * in, -dp[ch].y * ip + dn[ch].y * in);
         }
     }
     if (lane == 0) part_item[b] = li;
@@ -310,21 +346,30 @@ __global__ void joint_loss_reduce_kernel(const float* part_type, const float* pa
     }
 }
 
-extern "C" int pc_joint_loss(const float* sims, const float* proj, const int32_t* pos_types,
-                             const int32_t* neg_types, const float* pos_items, const float* neg_items, int batch,
-                             int num_types, int k, float margin, float alpha, float* losses, float* dsims_val,
-                             float* dproj, float* partials, void* stream) {
+extern "C" int pc_joint_loss_dim(const float* sims, const float* proj, const int32_t* pos_types,
+                                 const int32_t* neg_types, const float* pos_items, const float* neg_items, int batch,
+                                 int num_types, int k, int dim, float margin, float alpha, float* losses, float* dsims_val,
+                                 float* dproj, float* partials, void* stream) {
     if (!sims || !proj || !pos_types || !neg_types || !pos_items || !neg_items || !losses || !partials)
         return PC_EINVAL;
     if (batch <= 0 || num_types <= 0 || k <= 0) return PC_EINVAL;
+    if (dim != 128 && dim != 256) return PC_ESHAPE;
     hipStream_t st = (hipStream_t)stream;
-    PC_LAUNCH(joint_loss_kernel, dim3((batch + 3) / 4), dim3(256), 0, st, sims, proj, pos_types, neg_types,
-                       pos_items, neg_items, batch, num_types, k, margin, alpha, partials, partials + batch,
-                       dsims_val, dproj);
+    if (dim == 128) PC_LAUNCH(joint_loss_kernel<1>, dim3((batch + 3) / 4), dim3(256), 0, st, sims, proj, pos_types, neg_types,
+                              pos_items, neg_items, batch, num_types, k, margin, alpha, partials, partials + batch, dsims_val, dproj);
+    else PC_LAUNCH(joint_loss_kernel<2>, dim3((batch + 3) / 4), dim3(256), 0, st, sims, proj, pos_types, neg_types,
+                   pos_items, neg_items, batch, num_types, k, margin, alpha, partials, partials + batch, dsims_val, dproj);
     PC_TRY(pc_launch_status());
     PC_LAUNCH(joint_loss_reduce_kernel, dim3(1), dim3(256), 0, st, partials, partials + batch, batch, k,
                        alpha, losses);
     return pc_launch_status();
+}
+extern "C" int pc_joint_loss(const float* sims, const float* proj, const int32_t* pos_types,
+                             const int32_t* neg_types, const float* pos_items, const float* neg_items, int batch,
+                             int num_types, int k, float margin, float alpha, float* losses, float* dsims_val,
+                             float* dproj, float* partials, void* stream) {
+    return pc_joint_loss_dim(sims, proj, pos_types, neg_types, pos_items, neg_items, batch, num_types, k, PC_D, margin, alpha,
+                             losses, dsims_val, dproj, partials, stream);
 }
 
 // Sparse backward of sims = c E_c^T restricted to the two touched columns per row:
@@ -398,21 +443,33 @@ extern "C" int pc_hit_rank(const float* sims, int rows, int cols, int32_t* rank,
 }
 
 //   mean_relevance (metrics.py:44-60): cos[b,k] = <x_bk, y_b> / (max(|x_bk|,eps) * max(|y_b|,eps)), eps 1e-8
+template <int NCH>
 __global__ __launch_bounds__(256) void cosine_rows_kernel(const float* x, const float* y, int B, int K, float* out) {
+    constexpr int D = 128 * NCH;
     const int lane = threadIdx.x & 63;
     const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (r >= B * K) return;
-    const float2 a = *reinterpret_cast<const float2*>(x + (size_t)r * PC_D + 2 * lane);
-    const float2 b = *reinterpret_cast<const float2*>(y + (size_t)(r / K) * PC_D + 2 * lane);
-    const float dot = wave_sum(a.x * b.x + a.y * b.y);
-    const float na = sqrtf(wave_sum(a.x * a.x + a.y * a.y)), nb = sqrtf(wave_sum(b.x * b.x + b.y * b.y));
+    float d_ = 0.f, a_ = 0.f, b_ = 0.f;
+#pragma unroll
+    for (int ch = 0; ch < NCH; ch++) {
+        const float2 a = *reinterpret_cast<const float2*>(x + (size_t)r * D + 128 * ch + 2 * lane);
+        const float2 b = *reinterpret_cast<const float2*>(y + (size_t)(r / K) * D + 128 * ch + 2 * lane);
+        d_ += a.x * b.x + a.y * b.y; a_ += a.x * a.x + a.y * a.y; b_ += b.x * b.x + b.y * b.y;
+    }
+    const float dot = wave_sum(d_);
+    const float na = sqrtf(wave_sum(a_)), nb = sqrtf(wave_sum(b_));
     if (lane == 0) out[r] = dot / (fmaxf(na, 1e-8f) * fmaxf(nb, 1e-8f));
 }
 
-extern "C" int pc_cosine_rows(const float* x, const float* y, int batch, int k, float* out, void* stream) {
+extern "C" int pc_cosine_rows_dim(const float* x, const float* y, int batch, int k, int dim, float* out, void* stream) {
     if (!x || !y || !out || batch <= 0 || k <= 0) return PC_EINVAL;
-    PC_LAUNCH(cosine_rows_kernel, dim3((batch * k + 3) / 4), dim3(256), 0, (hipStream_t)stream, x, y, batch, k, out);
+    if (dim != 128 && dim != 256) return PC_ESHAPE;
+    if (dim == 128) PC_LAUNCH(cosine_rows_kernel<1>, dim3((batch * k + 3) / 4), dim3(256), 0, (hipStream_t)stream, x, y, batch, k, out);
+    else PC_LAUNCH(cosine_rows_kernel<2>, dim3((batch * k + 3) / 4), dim3(256), 0, (hipStream_t)stream, x, y, batch, k, out);
     return pc_launch_status();
+}
+extern "C" int pc_cosine_rows(const float* x, const float* y, int batch, int k, float* out, void* stream) {
+    return pc_cosine_rows_dim(x, y, batch, k, PC_D, out, stream);
 }
 
 // ---------------------------------------------------------------------------------------
@@ -684,14 +741,12 @@ extern "C" int pc_joint_train_step(const pc_joint_tensors* p, const pc_joint_ten
 __global__ __launch_bounds__(256) void retrieve_topk_kernel(const float* proj, const int32_t* types, int rows,
                                                             const int32_t* type_rowptr, const int32_t* type_col,
                                                             const float* table, int n_types, int n, int32_t* out_idx,
-                                                            float* out_score) {
-    __shared__ __attribute__((aligned(16))) float q[4][PC_D];
+                                                            float* out_score, int D) {
+    __shared__ __attribute__((aligned(16))) float q[4][256];          // PRODUCT_EMB_DIM 128 or 256
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int r = blockIdx.x * 4 + w;
-    if (r < rows) {
-        q[w][lane] = proj[(size_t)r * PC_D + lane];
-        q[w][lane + 64] = proj[(size_t)r * PC_D + lane + 64];
-    }
+    if (r < rows)
+        for (int d = lane; d < D; d += 64) q[w][d] = proj[(size_t)r * D + d];
     __syncthreads();
     if (r >= rows) return;
     const int t = types[r];
@@ -703,10 +758,10 @@ __global__ __launch_bounds__(256) void retrieve_topk_kernel(const float* proj, c
     for (int j = 0; j < RMAX_N; j++) { v[j] = -INFINITY; ix[j] = 0x7fffffff; }
     for (int c = c0 + lane; c < c1; c += 64) {
         const int pid = type_col[c];
-        const float4* f = reinterpret_cast<const float4*>(table + (size_t)pid * PC_D);
+        const float4* f = reinterpret_cast<const float4*>(table + (size_t)pid * D);
         float s = 0.f;
 #pragma unroll 8
-        for (int k = 0; k < PC_D / 4; k++) {
+        for (int k = 0; k < D / 4; k++) {
             const float4 x = f[k];
             const float4 y = *reinterpret_cast<const float4*>(&q[w][4 * k]);
             s += x.x * y.x + x.y * y.y + x.z * y.z + x.w * y.w;
@@ -742,13 +797,18 @@ __global__ __launch_bounds__(256) void retrieve_topk_kernel(const float* proj, c
     }
 }
 
+extern "C" int pc_retrieve_topk_dim(const float* proj, const int32_t* types, int rows, const int32_t* type_rowptr,
+                                    const int32_t* type_col, const float* table, int n_types, int n, int dim, int32_t* out_idx,
+                                    float* out_score, void* stream) {
+    if (!proj || !types || !type_rowptr || !type_col || !table || !out_idx || !out_score) return PC_EINVAL;
+    if (rows <= 0 || n_types <= 0) return PC_EINVAL;
+    if (n < 1 || n > RMAX_N || (dim != 128 && dim != 256)) return PC_ESHAPE;
+    PC_LAUNCH(retrieve_topk_kernel, dim3((rows + 3) / 4), dim3(256), 0, (hipStream_t)stream, proj, types, rows,
+              type_rowptr, type_col, table, n_types, n, out_idx, out_score, dim);
+    return pc_launch_status();
+}
 extern "C" int pc_retrieve_topk(const float* proj, const int32_t* types, int rows, const int32_t* type_rowptr,
                                 const int32_t* type_col, const float* table, int n_types, int n, int32_t* out_idx,
                                 float* out_score, void* stream) {
-    if (!proj || !types || !type_rowptr || !type_col || !table || !out_idx || !out_score) return PC_EINVAL;
-    if (rows <= 0 || n_types <= 0) return PC_EINVAL;
-    if (n < 1 || n > RMAX_N) return PC_ESHAPE;
-    PC_LAUNCH(retrieve_topk_kernel, dim3((rows + 3) / 4), dim3(256), 0, (hipStream_t)stream, proj, types, rows,
-              type_rowptr, type_col, table, n_types, n, out_idx, out_score);
-    return pc_launch_status();
+    return pc_retrieve_topk_dim(proj, types, rows, type_rowptr, type_col, table, n_types, n, PC_D, out_idx, out_score, stream);
 }

@@ -72,7 +72,7 @@ class PCompanionInference:
         out = self.model(batch)
         types = out["complementary_types"]
         b, k = types.shape
-        idx, sc = ops.retrieve_topk(out["projected_embeddings"].contiguous().reshape(b * k, ops.D),
+        idx, sc = ops.retrieve_topk(out["projected_embeddings"].contiguous().reshape(b * k, -1),
                                     types.to(torch.int32).reshape(-1).contiguous(), self.type_rowptr, self.type_col,
                                     self.features, int(num_recommendations))
         return types, idx.reshape(b, k, -1), sc.reshape(b, k, -1)

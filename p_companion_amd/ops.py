@@ -624,20 +624,27 @@ def joint_forward(params, query_idx, query_types, k):
     return sims, topk, proj, sv
 
 
+def _width(d):
+    """PRODUCT_EMB_DIM of the row-wise joint kernels (item_prediction.py:11-20, p_companion.py:105-119 take it from config)."""
+    if int(d) not in (128, 256):
+        raise ValueError(f"embedding width {d}: the gfx950 kernels serve PRODUCT_EMB_DIM 128 and 256")
+    return int(d)
+
+
 def joint_loss(sims, proj, pos_types, neg_types, pos_items, neg_items, margin, alpha, need_grad=True):
     b, t = sims.shape
-    k = proj.shape[1]
+    k, d = proj.shape[1], _width(proj.shape[2])
     dev = sims.device
-    _req(sims, torch.float32, "type_similarities"); _req(proj, torch.float32, "projected_embeddings", (b, k, D))
+    _req(sims, torch.float32, "type_similarities"); _req(proj, torch.float32, "projected_embeddings", (b, k, d))
     _req(pos_types, torch.int32, "positive_types", (b,)); _req(neg_types, torch.int32, "negative_types", (b,))
-    _req(pos_items, torch.float32, "positive_items", (b, D)); _req(neg_items, torch.float32, "negative_items", (b, D))
+    _req(pos_items, torch.float32, "positive_items", (b, d)); _req(neg_items, torch.float32, "negative_items", (b, d))
     losses = torch.empty(3, dtype=torch.float32, device=dev)
     dsv = torch.empty(b, 2, dtype=torch.float32, device=dev) if need_grad else None
     dproj = torch.empty_like(proj) if need_grad else None
     partials = torch.empty(2 * b, dtype=torch.float32, device=dev)
-    check(_lib.lib().pc_joint_loss(_p(sims), _p(proj), _p(pos_types), _p(neg_types), _p(pos_items), _p(neg_items),
-                                   b, t, k, float(margin), float(alpha), _p(losses), _p(dsv), _p(dproj),
-                                   _p(partials), _stream()), "pc_joint_loss")
+    check(_lib.lib().pc_joint_loss_dim(_p(sims), _p(proj), _p(pos_types), _p(neg_types), _p(pos_items), _p(neg_items),
+                                       b, t, k, d, float(margin), float(alpha), _p(losses), _p(dsv), _p(dproj),
+                                       _p(partials), _stream()), "pc_joint_loss_dim")
     return losses, dsv, dproj
 
 
@@ -924,20 +931,21 @@ def topk_rows(sims, k, want_values=False):
 
 
 def hadamard_forward(pi, tp, k):
-    b = pi.shape[0]
-    _req(pi, torch.float32, "pi", (b, D)); _req(tp, torch.float32, "tp", (b * k, D))
-    proj = torch.empty(b, k, D, dtype=torch.float32, device=pi.device)
-    check(_lib.lib().pc_hadamard_forward(_p(pi), _p(tp), b, k, _p(proj), _stream()), "pc_hadamard_forward")
+    b, d = pi.shape[0], _width(pi.shape[1])
+    _req(pi, torch.float32, "pi", (b, d)); _req(tp, torch.float32, "tp", (b * k, d))
+    proj = torch.empty(b, k, d, dtype=torch.float32, device=pi.device)
+    check(_lib.lib().pc_hadamard_forward_dim(_p(pi), _p(tp), b, k, d, _p(proj), _stream()), "pc_hadamard_forward_dim")
     return proj
 
 
 def hadamard_backward(dproj, pi, tp):
-    b, k, _ = dproj.shape
-    _req(dproj, torch.float32, "dproj", (b, k, D))
-    dpi = torch.empty(b, D, dtype=torch.float32, device=pi.device)
-    dtp = torch.empty(b * k, D, dtype=torch.float32, device=pi.device)
-    check(_lib.lib().pc_hadamard_backward(_p(dproj), _p(pi), _p(tp), b, k, _p(dpi), _p(dtp), _stream()),
-          "pc_hadamard_backward")
+    b, k, d = dproj.shape
+    _width(d)
+    _req(dproj, torch.float32, "dproj", (b, k, d))
+    dpi = torch.empty(b, d, dtype=torch.float32, device=pi.device)
+    dtp = torch.empty(b * k, d, dtype=torch.float32, device=pi.device)
+    check(_lib.lib().pc_hadamard_backward_dim(_p(dproj), _p(pi), _p(tp), b, k, d, _p(dpi), _p(dtp), _stream()),
+          "pc_hadamard_backward_dim")
     return dpi, dtp
 
 
@@ -1143,10 +1151,11 @@ def hit_rank(sims):
 
 
 def cosine_rows(x, y):
-    b, k, _ = x.shape
-    _req(x, torch.float32, "predictions", (b, k, D)); _req(y, torch.float32, "ground_truth", (b, D))
+    b, k, d = x.shape
+    _width(d)
+    _req(x, torch.float32, "predictions", (b, k, d)); _req(y, torch.float32, "ground_truth", (b, d))
     out = torch.empty(b * k, dtype=torch.float32, device=x.device)
-    check(_lib.lib().pc_cosine_rows(_p(x), _p(y), b, k, _p(out), _stream()), "pc_cosine_rows")
+    check(_lib.lib().pc_cosine_rows_dim(_p(x), _p(y), b, k, d, _p(out), _stream()), "pc_cosine_rows_dim")
     return out
 
 
@@ -1184,7 +1193,8 @@ def build_complementary_batch(pairs, features, type_idx, n_types, seed, step, wa
 def retrieve_topk(proj, types, type_rowptr, type_col, table, n):
     """pc_retrieve_topk: proj [R,128] fp32, types [R] int32 -> (idx [R,n] int32 product indices, -1 = none;
     scores [R,n] fp32).  inference.py:90-118 for all rows at once."""
-    proj = _req(proj.reshape(-1, D), torch.float32, "proj")
+    d = _width(table.shape[1])
+    proj = _req(proj.reshape(-1, d), torch.float32, "proj")
     r = proj.shape[0]
     _req(types, torch.int32, "types", (r,))
     _req(type_rowptr, torch.int32, "type_rowptr")
@@ -1192,7 +1202,7 @@ def retrieve_topk(proj, types, type_rowptr, type_col, table, n):
     _req(table, torch.float32, "table")
     out_idx = torch.empty(r, n, dtype=torch.int32, device=proj.device)
     out_sc = torch.empty(r, n, dtype=torch.float32, device=proj.device)
-    check(_lib.lib().pc_retrieve_topk(_p(proj), _p(types), r, _p(type_rowptr), _p(type_col), _p(table),
-                                      type_rowptr.numel() - 1, int(n), _p(out_idx), _p(out_sc), _stream()),
-          "pc_retrieve_topk")
+    check(_lib.lib().pc_retrieve_topk_dim(_p(proj), _p(types), r, _p(type_rowptr), _p(type_col), _p(table),
+                                          type_rowptr.numel() - 1, int(n), d, _p(out_idx), _p(out_sc), _stream()),
+          "pc_retrieve_topk_dim")
     return out_idx, out_sc

@@ -104,8 +104,14 @@ class PCompanion(nn.Module, _FlatParamsMixin):
     def __init__(self, config, pretrained_embeddings):
         super().__init__()
         self.config = config
-        if (config.PRODUCT_EMB_DIM, config.TYPE_EMB_DIM) != (ops.D, ops.L):
-            raise ValueError("the gfx950 kernels are built for PRODUCT_EMB_DIM=128, TYPE_EMB_DIM=64")
+        if config.PRODUCT_EMB_DIM not in (128, 256) or config.TYPE_EMB_DIM != ops.L:
+            raise ValueError("the gfx950 kernels are built for PRODUCT_EMB_DIM = 128 (config.py:8) or 256 (BASELINE "
+                             "configs[4]) and TYPE_EMB_DIM = 64 (config.py:9)")
+        # PRODUCT_EMB_DIM = 256 (the reference takes every dimension from config: p_companion.py:26-43, item_prediction.py:11-20):
+        # the per-op module path (pc_linear_*, pc_topk_rows, pc_hadamard_*_dim, pc_joint_loss_dim, autograd between them);
+        # the fused single-pass kernels are built for 128
+        self.dim = int(config.PRODUCT_EMB_DIM)
+        self.use_fused_joint = self.dim == ops.D
 
         if isinstance(pretrained_embeddings, torch.Tensor):
             # index-mode extension: row i is product i ("P%06d" % i)
@@ -186,6 +192,12 @@ class PCompanion(nn.Module, _FlatParamsMixin):
         query_types = self._i32(batch["query_types"].to(dev))
         self._validate((query_indices, self.product_embeddings.weight.shape[0]),
                        (query_types, self.query_type_embeddings.weight.shape[0]))
+        if self.dim != ops.D:
+            self._pending = None
+            train = torch.is_grad_enabled() and self.training
+            with torch.set_grad_enabled(train):
+                sims, topk, proj = self._forward_graph(query_indices, query_types, k, self._next_dropout() if self.training else None)
+            return {"projected_embeddings": proj, "complementary_types": topk.long(), "type_similarities": sims}
         if not (torch.is_grad_enabled() and self.training):
             sims, topk, proj, _ = ops.joint_forward(self._tensor_dict(self._next_dropout()), query_indices, query_types, k)
             return {"projected_embeddings": proj, "complementary_types": topk.long(), "type_similarities": sims}
@@ -247,8 +259,8 @@ class PCompanion(nn.Module, _FlatParamsMixin):
 
     def _compute_type_loss(self, type_similarities, positive_types, negative_types):
         b = type_similarities.shape[0]
-        z = torch.zeros(b, ops.D, device=type_similarities.device)
-        proj = torch.zeros(b, 1, ops.D, device=type_similarities.device)
+        z = torch.zeros(b, self.dim, device=type_similarities.device)
+        proj = torch.zeros(b, 1, self.dim, device=type_similarities.device)
         return _JointLoss.apply(type_similarities.contiguous(), proj, self._i32(positive_types),
                                 self._i32(negative_types), z, z, float(self.config.MARGIN), 0.0, 1)
 
@@ -267,6 +279,21 @@ class PCompanion(nn.Module, _FlatParamsMixin):
         Returns (losses[3] = total/type/item on the device, complementary_types[B,K]).
         The fused form (pc_joint_fused_step: two launches at T <= 128) serves K <= 4 and, for T > 512, dropout off; anything else
         takes the launch-per-op sequence pc_joint_train_step (self.use_fused_joint = False forces it)."""
+        if self.dim != ops.D:
+            # PRODUCT_EMB_DIM = 256: the reference's loop body through the per-op path (train.py:42-48)
+            self.flatten_parameters()
+            for p in self.parameters():
+                if p.grad is not None:
+                    p.grad.zero_()
+            outputs = self(batch)
+            loss = self.compute_loss(batch, outputs)
+            loss.backward()
+            with torch.no_grad():
+                lt = self._loss(batch, outputs, 1)
+                li = self._loss(batch, outputs, 2)
+            if optimizer is not None:
+                optimizer.step()
+            return torch.stack([loss.detach(), lt, li]), outputs["complementary_types"].to(torch.int32)
         self.flatten_parameters()
         dev = self.query_type_embeddings.weight.device
         drop = self._next_dropout()

@@ -133,3 +133,59 @@ def test_product2vec_module_dim256_fused_step_vs_oracle(B, N, P):
     st_e = {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}
     ref_e = p2v_oracle.forward(table[:16], table[:48].view(16, 3, D), st_e, False)
     close(e, ref_e, 3e-5, "eval forward")
+
+
+# ------------------------------------------------------------------ the joint step at PRODUCT_EMB_DIM = 256
+def test_joint_step_dim256_matches_the_oracle():
+    """p_companion.py:26-43 / item_prediction.py:11-20 take PRODUCT_EMB_DIM from config: at 256 (BASELINE configs[4]) the
+    joint step runs through the per-op module path (pc_linear_*, pc_topk_rows, pc_hadamard_*_dim, pc_joint_loss_dim) --
+    forward outputs, the three losses, top-k (bit-exact), every gradient and the parameters after one Adam step against
+    the oracle; metrics and retrieval accept the 256-wide rows."""
+    from types import SimpleNamespace
+    from oracle import joint_oracle
+    from p_companion_amd import ops
+    from p_companion_amd.p_companion import PCompanion
+    from p_companion_amd.product2vec import FusedAdam
+    D, T, P, B, K = 256, 60, 500, 96, 3
+    cfg = SimpleNamespace(PRODUCT_EMB_DIM=D, TYPE_EMB_DIM=64, HIDDEN_SIZE=256, NUM_ATTENTION_HEADS=4, DROPOUT=0.0, MARGIN=1.0,
+                          ALPHA=0.8, NUM_COMP_TYPES=K, NUM_TYPES=T, DEVICE=torch.device("cuda"), LEARNING_RATE=1e-3)
+    g = torch.Generator().manual_seed(0)
+    table = torch.randn(P, D, generator=g)
+    torch.manual_seed(1)
+    m = PCompanion(cfg, table).to("cuda").train()
+    assert not m.use_fused_joint
+    st0 = {k: v.detach().cpu().clone() for k, v in m.state_dict().items()}
+    b = {"query_idx": torch.randint(0, P, (B,), generator=g, dtype=torch.int32).cuda(),
+         "query_types": torch.randint(0, T, (B,), generator=g).cuda(),
+         "positive_types": torch.randint(0, T, (B, 1), generator=g).cuda(),
+         "negative_types": torch.randint(0, T, (B, 1), generator=g).cuda(),
+         "positive_items": torch.randn(B, D, generator=g).cuda(), "negative_items": torch.randn(B, D, generator=g).cuda()}
+    hb = {k: v.cpu() for k, v in b.items()}
+    st = {k: v.clone() for k, v in st0.items()}
+    ref = joint_oracle.train_step(st, hb, joint_oracle.new_moments(st0), 1)
+    # the reference's loop body, module surface
+    out = m(b)
+    assert out["projected_embeddings"].shape == (B, K, D)
+    assert np.array_equal(out["complementary_types"].cpu().numpy(), ref["out"]["complementary_types"].numpy())
+    assert float((out["type_similarities"].detach().cpu() - ref["out"]["type_similarities"]).abs().max()) < 2e-5
+    assert float((out["projected_embeddings"].detach().cpu() - ref["out"]["projected_embeddings"]).abs().max()) < 2e-4
+    loss = m.compute_loss(b, out)
+    assert abs(float(loss) - float(ref["loss"])) < 1e-4
+    # the fused-interface loop body (train_step + optimizer)
+    opt = FusedAdam(m, lr=1e-3)
+    losses, topk = m.train_step(b, optimizer=opt)
+    assert abs(float(losses[0]) - float(ref["loss"])) < 1e-4
+    assert abs(float(losses[1]) - float(ref["type_loss"])) < 1e-4 and abs(float(losses[2]) - float(ref["item_loss"])) < 1e-4
+    assert np.array_equal(topk.cpu().numpy(), ref["out"]["complementary_types"].numpy())
+    for k, p in m.named_parameters():
+        if p.grad is None:
+            continue
+        gr = ref["grads"][k]
+        assert float((p.grad.cpu() - gr).abs().max()) <= 2e-6 + 2e-4 * float(gr.abs().max()), k
+        d = (p.detach().cpu() - st[k]).abs()
+        assert float((d <= 2e-5).float().mean()) >= 0.99 and float(d.max()) <= 2.1e-3, k
+    # metrics / retrieval kernels at the 256-wide rows
+    x = torch.randn(B, K, D, generator=g).cuda(); y = torch.randn(B, D, generator=g).cuda()
+    cos = ops.cosine_rows(x, y).view(B, K).cpu()
+    want = torch.nn.functional.cosine_similarity(x.cpu(), y.cpu()[:, None, :], dim=-1)
+    assert float((cos - want).abs().max()) < 1e-5
