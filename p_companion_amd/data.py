@@ -394,8 +394,12 @@ class SimilarityIndexLoader:
         self.epoch += 1
         ring_ok = self.reuse_buffers and self.prefetch and self.sampler == "philox" and self.compact and self.sharded is None
         base = getattr(self, "_ring_base", 0)
+        # the sampler's step counter of batch i of this epoch: a function of (epoch, i) alone -- not of how many builders
+        # were queued ahead when an epoch was abandoned (prefetch depth 2 or 4)
+        step0 = (self.epoch - 1) * len(self)
 
         def make(i):
+            self.step = step0 + i
             lo, hi = i * self.batch_size, min((i + 1) * self.batch_size, S)
             if plan is not None:
                 n_pad, n_real_plan = int(plan[i, 0]), int(plan[i, 1])

@@ -333,3 +333,40 @@ def test_touched_row_lists_and_the_row_list_exchange_on_the_gpu():
         assert torch.equal(reps[0][1][nm].grad, reps[1][1][nm].grad)                       # both replicas: the same bits
         want = rparams[nm].grad
         assert float((reps[0][1][nm].grad - want).abs().max()) <= 1e-7 + 1e-5 * float(want.abs().max()), nm
+
+
+# ------------------------------------------------------------------ the loader's buffer ring
+@pytest.mark.parametrize("unique", [True, False])
+def test_loader_buffer_ring_hands_out_the_same_batches(unique):
+    """reuse_buffers=True (what bench.py and train_model's driver use): batches built into a ring of preallocated buffers,
+    consumed one at a time, are bit-identical to the freshly allocated ones over several epochs (epoch boundaries, a ragged
+    last batch, the abandoned-iterator path), and training on them gives bit-identical parameters."""
+    from p_companion_amd.data import SimilarityIndexLoader, generate_scaled_bpg
+    from p_companion_amd.product2vec import FusedAdam, Product2Vec
+    bpg = generate_scaled_bpg(8000, 40, seed=3)
+    table = bpg.cuda()["features"]
+    mk = lambda ring: SimilarityIndexLoader(bpg, 512, seed=5, drop_last=False, device="cuda", unique=unique, reuse_buffers=ring)
+    a, b = mk(True), mk(False)
+    torch.manual_seed(0)
+    ma, mb = Product2Vec(cfg()).to("cuda").train(), Product2Vec(cfg()).to("cuda").train()
+    mb.load_state_dict(ma.state_dict())
+    oa, ob = FusedAdam(ma, lr=1e-3), FusedAdam(mb, lr=1e-3)
+    n = 0
+    for epoch in range(3):
+        for i, (x, y) in enumerate(zip(a, b)):
+            for k in ("anchor_idx", "positive_idx", "negative_idx"):
+                assert torch.equal(x[k], y[k]), (epoch, i, k)
+            nx, ny = x["neighbor_compact"], y["neighbor_compact"]
+            assert torch.equal(nx["slot_row"], ny["slot_row"])
+            nu = int(nx["n_unique"]) if unique else nx["nb_rows"].numel() - 1
+            assert torch.equal(nx["nb_rows"][:nu + 1], ny["nb_rows"][:nu + 1])
+            if x["anchor_idx"].numel() >= 2:
+                la, lb = ma.train_step_indexed(table, x), mb.train_step_indexed(table, y)
+                oa.step(); ob.step()
+                assert torch.equal(la, lb)
+            n += 1
+            if epoch == 1 and i == 3:
+                break                                             # abandon this epoch's iterators mid-way
+    assert n > 20
+    for (k, p), (_, q) in zip(ma.named_parameters(), mb.named_parameters()):
+        assert torch.equal(p, q), k
