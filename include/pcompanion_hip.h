@@ -190,6 +190,12 @@ int pc_p2v_triplet_loss_dim(const float *a, const float *p, const float *n, int 
 int pc_adam_step(float *param, const float *grad, float *exp_avg, float *exp_avg_sq, size_t n,
                  int64_t *step_count, float *scalars, double lr, double beta1, double beta2,
                  double eps, void *stream);
+/* The same update as ONE launch when the caller knows the step number t (>= 1) on the host -- an optimizer that owns every
+ * increment of its counter: the bias corrections are formed per workgroup by the same fp64 expressions (same bits as
+ * pc_adam_step), *step_count (may be NULL) is left = t. */
+int pc_adam_step_at(float *param, const float *grad, float *exp_avg, float *exp_avg_sq, size_t n,
+                    int64_t *step_count, int64_t t, double lr, double beta1, double beta2, double eps,
+                    void *stream);
 
 /* P9 whole: one iteration of Product2Vec.train_model's loop body (product2vec.py:126-159)
  * in index form: gather -> 4 FFN calls -> attention -> loss -> backward -> grads in `g`

@@ -79,6 +79,7 @@ SIGNATURES = {
     "pc_p2v_triplet_loss": (_i, [_vp, _vp, _vp, _i, _i, _f, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "pc_p2v_triplet_loss_dim": (_i, [_vp, _vp, _vp, _i, _i, _i, _f, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "pc_adam_step": (_i, [_vp, _vp, _vp, _vp, _sz, _vp, _vp, _d, _d, _d, _d, _vp]),
+    "pc_adam_step_at": (_i, [_vp, _vp, _vp, _vp, _sz, _vp, _i64, _d, _d, _d, _d, _vp]),
     "pc_p2v_train_step_workspace_bytes": (_sz, [_i, _i, _i]),
     "pc_p2v_train_step_workspace_bytes_dim": (_sz, [_i, _i, _i, _i]),
     "pc_p2v_train_step": (_i, [_P(P2VTensors), _P(P2VTensors), _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _f, _vp, _vp,

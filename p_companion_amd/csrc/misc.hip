@@ -145,6 +145,57 @@ __global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, 
     }
 }
 
+// The same update with the step number t known to the HOST (an optimizer that owns every increment of its counter): the
+// scalars are formed per workgroup by the same fp64 expressions as adam_prep_kernel (same bits), nothing reads the device
+// counter, so one launch does what pc_adam_step needs two for; block 0 leaves *step_count = t for whoever reads it later.
+__global__ void adam_at_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                               float* __restrict__ v, size_t n, int64_t* step_count, long long t, double lr, double beta1,
+                               double beta2, float omb1, float beta2f, float omb2, float eps) {
+    __shared__ float sc[2];
+    if (threadIdx.x == 0) {
+        const double bc1 = 1.0 - pow(beta1, (double)t);
+        const double bc2 = 1.0 - pow(beta2, (double)t);
+        sc[0] = (float)(lr / bc1);
+        sc[1] = (float)sqrt(bc2);
+        if (blockIdx.x == 0 && step_count) *step_count = t;
+    }
+    __syncthreads();
+    const float step_size = sc[0], bc2s = sc[1];
+    const size_t i4 = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+    if (i4 + 3 < n) {
+        float4 pv = *reinterpret_cast<float4*>(p + i4);
+        const float4 gv = *reinterpret_cast<const float4*>(g + i4);
+        float4 mv = *reinterpret_cast<float4*>(m + i4);
+        float4 vv = *reinterpret_cast<float4*>(v + i4);
+#define ADAM1(c) pc_adam_update(pv.c, mv.c, vv.c, gv.c, step_size, bc2s, omb1, beta2f, omb2, eps);
+        ADAM1(x) ADAM1(y) ADAM1(z) ADAM1(w)
+#undef ADAM1
+        *reinterpret_cast<float4*>(p + i4) = pv;
+        *reinterpret_cast<float4*>(m + i4) = mv;
+        *reinterpret_cast<float4*>(v + i4) = vv;
+    } else {
+        for (size_t i = i4; i < n; i++) {
+            float pp = p[i], mm = m[i], vv = v[i];
+            pc_adam_update(pp, mm, vv, g[i], step_size, bc2s, omb1, beta2f, omb2, eps);
+            p[i] = pp;
+            m[i] = mm;
+            v[i] = vv;
+        }
+    }
+}
+
+extern "C" int pc_adam_step_at(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, size_t n,
+                               int64_t* step_count, int64_t t, double lr, double beta1, double beta2, double eps,
+                               void* stream) {
+    if (!param || !grad || !exp_avg || !exp_avg_sq || n == 0 || t < 1) return PC_EINVAL;
+    if (((uintptr_t)param | (uintptr_t)grad | (uintptr_t)exp_avg | (uintptr_t)exp_avg_sq) & 15) return PC_ESHAPE;
+    const size_t threads = (n + 3) / 4;
+    PC_LAUNCH(adam_at_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, (hipStream_t)stream, param, grad, exp_avg,
+              exp_avg_sq, n, step_count, (long long)t, lr, beta1, beta2, (float)(1.0 - beta1), (float)beta2, (float)(1.0 - beta2),
+              (float)eps);
+    return pc_launch_status();
+}
+
 extern "C" int pc_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, size_t n,
                             int64_t* step_count, float* scalars, double lr, double beta1, double beta2,
                             double eps, void* stream) {

@@ -63,13 +63,46 @@ extern "C" int pc_p2v_triplet_loss_dim(const float* a, const float* p, const flo
                                        float margin, float* loss, float* d_pos, float* d_neg, float* da, float* dp,
                                        float* dn, void* stream);
 
-__global__ void concat_idx_kernel(const int32_t* a, int na, const int32_t* b, int nb, const int32_t* c, int nc,
-                                  const int32_t* d, int nd, int32_t* out) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+__device__ __forceinline__ void concat_idx_body(const int32_t* a, int na, const int32_t* b, int nb, const int32_t* c, int nc,
+                                                const int32_t* d, int nd, int32_t* out, int i) {
     if (i < na) out[i] = a[i];
     else if (i < na + nb) out[i] = b[i - na];
     else if (i < na + nb + nc) out[i] = c[i - na - nb];
     else if (i < na + nb + nc + nd) out[i] = d[i - na - nb - nc];
+}
+__global__ void concat_idx_kernel(const int32_t* a, int na, const int32_t* b, int nb, const int32_t* c, int nc,
+                                  const int32_t* d, int nd, int32_t* out) {
+    concat_idx_body(a, na, b, nb, c, nc, d, nd, out, blockIdx.x * blockDim.x + threadIdx.x);
+}
+
+// The step's first launch: the row-index concatenation AND every transposed weight of the step (workgroups
+// [0, concat_blocks) concatenate, the rest are 32 x 32 transpose tiles, tiles_x x tiles_y per job) -- the two were separate
+// launches of ~5 us each, i.e. of pure launch latency.
+__global__ __launch_bounds__(256) void p2v_prologue_kernel(const int32_t* a, int na, const int32_t* b, int nb, const int32_t* c, int nc,
+                                                           const int32_t* d, int nd, int32_t* out, int concat_blocks,
+                                                           TransposeBatch tb, int tiles_x, int tiles_y) {
+    __shared__ float t[32][33];
+    if ((int)blockIdx.x < concat_blocks) {
+        concat_idx_body(a, na, b, nb, c, nc, d, nd, out, blockIdx.x * 256 + threadIdx.x);
+        return;
+    }
+    const int tile = (int)blockIdx.x - concat_blocks;
+    const int jz = tile / (tiles_x * tiles_y), rem = tile % (tiles_x * tiles_y);
+    const TransposeJob j = tb.job[jz];
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    if (tb.zero && tile == 0)
+        for (int i = threadIdx.x; i < tb.nzero; i += 256) tb.zero[i] = 0.f;
+    const int bx = (rem % tiles_x) * 32, by = (rem / tiles_x) * 32;
+    if (bx >= j.cols || by >= j.rows) return;
+    for (int i = ty; i < 32; i += 8) {
+        const int r = by + i, cc = bx + tx;
+        t[i][tx] = (r < j.rows && cc < j.cols) ? j.in[(size_t)r * j.cols + cc] : 0.f;
+    }
+    __syncthreads();
+    for (int i = ty; i < 32; i += 8) {
+        const int cc = bx + i, r = by + tx;
+        if (r < j.rows && cc < j.cols) j.out[(size_t)cc * j.rows + r] = t[tx][i];
+    }
 }
 
 int ffn_forward_part1(const pc_p2v_tensors* p, const float* table, const int32_t* idx, int rows, const pc_segments* seg,
@@ -143,9 +176,25 @@ static int p2v_step_impl(const pc_p2v_tensors* p, const pc_p2v_tensors* g, const
     sv.h0 = w.h0; sv.a2 = w.a2; sv.a1 = w.a1;
     sv.bn_mean = w.bn; sv.bn_invstd = w.bn + PC_MAX_SEG * PC_H; sv.bn_scale = w.bn + 2 * PC_MAX_SEG * PC_H;
     sv.bn_shift = w.bn + 3 * PC_MAX_SEG * PC_H;
+    // every transposed weight of the step (attention: Wo^T, Wq^T, [Wk;Wv]^T; FFN backward: W5^T, W3^T): one launch, which also
+    // clears the key-bias gradient (exactly 0, see attention.hip); in the unsplit step it is the SAME launch as the row-index
+    // concatenation
+    TransposeBatch tb = {};
+    if (p1) {
+        PC_TRY(ffn_transposes(p, w.ffn_ws, R, 0, &tb));
+        if (N > 0) PC_TRY(attention_transposes(p, w.attn_ws, B, N, slot_row ? nbc : B * N, &tb, g->in_proj_b + D));
+    }
     if (p0) {
-        PC_LAUNCH(concat_idx_kernel, dim3((R + 255) / 256), dim3(256), 0, st, anchor_idx, B, nb_idx, nbc, positive_idx, B,
-                  negative_idx, B * K, w.idx_all);
+        if (phase == -1) {
+            int mx = 0, my = 0;
+            for (int i = 0; i < tb.n; i++) { mx = tb.job[i].cols > mx ? tb.job[i].cols : mx; my = tb.job[i].rows > my ? tb.job[i].rows : my; }
+            const int tiles_x = (mx + 31) / 32, tiles_y = (my + 31) / 32, cb = (R + 255) / 256;
+            PC_LAUNCH(p2v_prologue_kernel, dim3(cb + tiles_x * tiles_y * tb.n), dim3(256), 0, st, anchor_idx, B, nb_idx, nbc,
+                      positive_idx, B, negative_idx, B * K, w.idx_all, cb, tb, tiles_x, tiles_y);
+        } else {
+            PC_LAUNCH(concat_idx_kernel, dim3((R + 255) / 256), dim3(256), 0, st, anchor_idx, B, nb_idx, nbc, positive_idx, B,
+                      negative_idx, B * K, w.idx_all);
+        }
         PC_TRY(pc_launch_status());
         PC_TRY(ffn_forward_part1(p, table, w.idx_all, R, &seg, &sv, phase == 0 ? fwd_sums : nullptr, w.ffn_ws, w.ffn_bytes,
                                  stream));
@@ -154,14 +203,7 @@ static int p2v_step_impl(const pc_p2v_tensors* p, const pc_p2v_tensors* g, const
     if (p2 && !p1)
         return ffn_backward_part2(g, table, w.idx_all, R, &seg, &sv, nullptr, 0, bwd_local, bwd_global, w.ffn_ws,
                                   w.ffn_bytes, stream, nullptr);
-    // every transposed weight of the step (attention: Wo^T, Wq^T, [Wk;Wv]^T; FFN backward: W5^T, W3^T) in ONE launch,
-    // which also clears the key-bias gradient (exactly 0, see attention.hip)
-    {
-        TransposeBatch tb = {};
-        PC_TRY(ffn_transposes(p, w.ffn_ws, R, 0, &tb));
-        if (N > 0) PC_TRY(attention_transposes(p, w.attn_ws, B, N, slot_row ? nbc : B * N, &tb, g->in_proj_b + D));
-        PC_TRY(launch_transpose_batch(tb, st));
-    }
+    if (phase == 1) PC_TRY(launch_transpose_batch(tb, st));      // (the split step: phase 0 ran the concatenation alone)
     PC_TRY(ffn_forward_part2(p, R, &seg, 1, w.y, &sv, phase == 1 ? fwd_sums : nullptr, w.ffn_ws, w.ffn_bytes, stream));
 
     pc_attn_saved as;

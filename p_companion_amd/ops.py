@@ -289,6 +289,18 @@ def adam_step(param, grad, exp_avg, exp_avg_sq, step_count, scalars, lr=1e-3, be
                                   float(lr), float(betas[0]), float(betas[1]), float(eps), _stream()), "pc_adam_step")
 
 
+def adam_step_at(param, grad, exp_avg, exp_avg_sq, step_count, t, lr=1e-3, betas=(0.9, 0.999), eps=1e-8):
+    """pc_adam_step_at: the update of step number t (host-known) as one launch; step_count (device int64 [1]) is left = t."""
+    n = param.numel()
+    for x, nm in ((param, "param"), (grad, "grad"), (exp_avg, "exp_avg"), (exp_avg_sq, "exp_avg_sq")):
+        _req(x, torch.float32, nm)
+        if x.numel() != n:
+            raise ValueError("adam_step_at: size mismatch")
+    _req(step_count, torch.int64, "step_count")
+    check(_lib.lib().pc_adam_step_at(_p(param), _p(grad), _p(exp_avg), _p(exp_avg_sq), n, _p(step_count), int(t), float(lr),
+                                     float(betas[0]), float(betas[1]), float(eps), _stream()), "pc_adam_step_at")
+
+
 class KernelProfile:
     """HIP-event brackets around the GEMM launches of the fused step (bench.py roofline leg)."""
     KINDS = {"gemm_nt_kernel": 0, "gemm_tn_kernel": 1, "gemm_nt_small_kernel": 2}

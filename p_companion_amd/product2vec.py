@@ -160,12 +160,21 @@ class FusedAdam(torch.optim.Optimizer):
             self.step_count = torch.zeros(1, dtype=torch.int64, device=flat.device)
             self.scalars = torch.zeros(2, dtype=torch.float32, device=flat.device)
             self._state_ready = True
+            # the step number as the HOST knows it: valid while every increment of the device counter went through step()
+            # (then the update is ONE launch, pc_adam_step_at); None once a fused step advanced the counter itself
+            # (fused_state()) -- the two-launch form then reads the device counter
+            self._host_step = 0
         return flat, gflat
 
     @torch.no_grad()
     def step(self, closure=None):
         flat, gflat = self._ensure()
         g = self.param_groups[0]
+        if self._host_step is not None:
+            self._host_step += 1
+            ops.adam_step_at(flat, gflat, self.exp_avg, self.exp_avg_sq, self.step_count, self._host_step, g["lr"],
+                             g["betas"], g["eps"])
+            return
         ops.adam_step(flat, gflat, self.exp_avg, self.exp_avg_sq, self.step_count, self.scalars, g["lr"],
                       g["betas"], g["eps"])
 
@@ -178,6 +187,7 @@ class FusedAdam(torch.optim.Optimizer):
         (ops.joint_fused_step(adam=...)): per-parameter views of the flat moment buffers, the device step counter and
         the hyper-parameters.  The caller must NOT call step() for that iteration."""
         self._ensure()
+        self._host_step = None                    # (the fused step advances the device counter: the host no longer knows it)
         m, v, off = {}, {}, 0
         for name, p in self.module._named_flat():
             n = p.numel()
@@ -235,7 +245,7 @@ class FusedAdam(torch.optim.Optimizer):
         order = {pid: i for i, pid in enumerate(groups[0]["params"])}
         state = {order[k] if k in order else k: v for k, v in state_dict["state"].items()}
         slices = self._slices()
-        self.exp_avg.zero_(); self.exp_avg_sq.zero_(); self.step_count.zero_()
+        self.exp_avg.zero_(); self.exp_avg_sq.zero_()
         steps = set()
         for idx, off, m, shape in slices:
             st = state.get(idx)
@@ -249,8 +259,9 @@ class FusedAdam(torch.optim.Optimizer):
             steps.add(int(float(st["step"])))
         if len(steps) > 1:
             raise ValueError("FusedAdam keeps ONE step count for all parameters; the state holds %s" % sorted(steps))
-        if steps:
-            self.step_count.fill_(steps.pop())
+        loaded = steps.pop() if steps else 0
+        self.step_count.fill_(loaded)
+        self._host_step = loaded
 
 
 class _FlatParamsMixin:
