@@ -8,11 +8,10 @@
 // Philox4x32-10 stream keyed by (seed; sample, step), so every sample draws independently.
 #include "common.h"
 
-__global__ void build_pairs_negatives_kernel(const int32_t* pair_ids, int B, const int32_t* sim_pairs,
-                                             const int32_t* sim_rowptr, const int32_t* sim_col, int n_products,
-                                             int K, uint64_t seed, uint64_t step, int32_t* anchor_idx,
-                                             int32_t* positive_idx, int32_t* negative_idx) {
-    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+__device__ __forceinline__ void pairs_negatives_body(const int32_t* pair_ids, int B, const int32_t* sim_pairs,
+                                                     const int32_t* sim_rowptr, const int32_t* sim_col, int n_products,
+                                                     int K, uint64_t seed, uint64_t step, int32_t* anchor_idx,
+                                                     int32_t* positive_idx, int32_t* negative_idx, int b) {
     if (b >= B) return;
     const int pid = pair_ids[b];
     const int a = sim_pairs[2 * pid], pos = sim_pairs[2 * pid + 1];
@@ -28,6 +27,14 @@ __global__ void build_pairs_negatives_kernel(const int32_t* pair_ids, int B, con
         for (int j = 0; ok && j < got; j++) ok = negative_idx[(size_t)b * K + j] != c;
         if (ok) negative_idx[(size_t)b * K + got++] = c;
     }
+}
+
+__global__ void build_pairs_negatives_kernel(const int32_t* pair_ids, int B, const int32_t* sim_pairs,
+                                             const int32_t* sim_rowptr, const int32_t* sim_col, int n_products,
+                                             int K, uint64_t seed, uint64_t step, int32_t* anchor_idx,
+                                             int32_t* positive_idx, int32_t* negative_idx) {
+    pairs_negatives_body(pair_ids, B, sim_pairs, sim_rowptr, sim_col, n_products, K, seed, step, anchor_idx, positive_idx,
+                         negative_idx, blockIdx.x * blockDim.x + threadIdx.x);
 }
 
 __global__ void build_neighbors_kernel(const int32_t* anchor_idx, int B, const int32_t* cv_rowptr,
@@ -120,14 +127,30 @@ extern "C" int pc_build_similarity_batch_compact(const int32_t* pair_ids, int ba
 //   cnt[P]   occurrences (zero between calls: this sequence clears what it touched)
 //   rank[P]  row of a present product
 #define UQ_CHUNK 4096
-__global__ void uq_count_kernel(const int32_t* anchor_idx, int B, const int32_t* cv_rowptr, const int32_t* cv_col,
-                                int n_pad, int32_t* cnt) {
-    const int t = blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= B * n_pad) return;
-    const int b = t / n_pad, j = t % n_pad;
-    const int a = anchor_idx[b];
-    const int lo = cv_rowptr[a], deg = min(cv_rowptr[a + 1] - lo, n_pad);
-    if (j < deg) atomicAdd(&cnt[cv_col[lo + j]], 1);
+// The negatives sampler and the occurrence count are independent (the count reads the anchors straight from the pair list):
+// ONE launch, workgroups [0, pair_blocks) of 128 threads sample, the rest count (two slots per thread) -- a launch of its own
+// costs ~4.5 us of latency, and every builder launch shares the chip with the training stream's persistent kernels.
+__global__ __launch_bounds__(128) void uq_pairs_count_kernel(const int32_t* pair_ids, int B, const int32_t* sim_pairs,
+                                                             const int32_t* sim_rowptr, const int32_t* sim_col, int n_products,
+                                                             int K, uint64_t seed, uint64_t step, int32_t* anchor_idx,
+                                                             int32_t* positive_idx, int32_t* negative_idx, int pair_blocks,
+                                                             const int32_t* cv_rowptr, const int32_t* cv_col, int n_pad,
+                                                             int32_t* cnt) {
+    if ((int)blockIdx.x < pair_blocks) {
+        pairs_negatives_body(pair_ids, B, sim_pairs, sim_rowptr, sim_col, n_products, K, seed, step, anchor_idx, positive_idx,
+                             negative_idx, blockIdx.x * 128 + threadIdx.x);
+        return;
+    }
+    const int t0 = (((int)blockIdx.x - pair_blocks) * 128 + threadIdx.x) * 2;
+#pragma unroll
+    for (int u = 0; u < 2; u++) {
+        const int t = t0 + u;
+        if (t >= B * n_pad) return;
+        const int b = t / n_pad, j = t % n_pad;
+        const int a = sim_pairs[2 * pair_ids[b]];
+        const int lo = cv_rowptr[a], deg = min(cv_rowptr[a + 1] - lo, n_pad);
+        if (j < deg) atomicAdd(&cnt[cv_col[lo + j]], 1);
+    }
 }
 
 // per chunk of products: (number present, number of slots) -> blocksum[2 * blk], blocksum[2 * blk + 1]
@@ -149,36 +172,29 @@ __global__ __launch_bounds__(1024) void uq_block_sums_kernel(const int32_t* cnt,
     }
 }
 
-// exclusive scan of up to 4096 block sums in one workgroup; total -> n_unique
-__global__ __launch_bounds__(1024) void uq_scan_sums_kernel(int32_t* blocksum, int nblocks, int32_t* n_unique) {
-    __shared__ int part[2][1024];
-    const int t = threadIdx.x;
-    const int per = (nblocks + 1023) / 1024;
-    const int lo = t * per, hi = min(nblocks, lo + per);
-    int s = 0, c = 0;
-    for (int i = lo; i < hi; i++) { s += blocksum[2 * i]; c += blocksum[2 * i + 1]; }
-    part[0][t] = s; part[1][t] = c;
-    __syncthreads();
-    for (int o = 1; o < 1024; o <<= 1) {
-        const int v = t >= o ? part[0][t - o] : 0, u = t >= o ? part[1][t - o] : 0;
-        __syncthreads();
-        part[0][t] += v; part[1][t] += u;
-        __syncthreads();
-    }
-    int run = part[0][t] - s, runc = part[1][t] - c;
-    for (int i = lo; i < hi; i++) {
-        const int v = blocksum[2 * i], u = blocksum[2 * i + 1];
-        blocksum[2 * i] = run; blocksum[2 * i + 1] = runc;
-        run += v; runc += u;
-    }
-    if (t == 1023) n_unique[0] = part[0][1023];
-}
-
 // row of every present product (ascending product order), its multiplicity, and the start of its slot list
-__global__ __launch_bounds__(1024) void uq_assign_kernel(const int32_t* cnt, int P, const int32_t* blockoff, int32_t* rank,
+// blocksum: the per-chunk sums of uq_block_sums_kernel (NOT scanned): every workgroup adds up its predecessors' sums itself
+// (25 chunks at 100 k products; a scan launch of its own cost more than these few loads); the last one writes n_unique
+__global__ __launch_bounds__(1024) void uq_assign_kernel(const int32_t* cnt, int P, const int32_t* blocksum, int32_t* rank,
                                                          int32_t* nb_rows, float* nb_weight, int32_t* ref_off,
-                                                         int32_t* cursor) {
+                                                         int32_t* cursor, int32_t* n_unique) {
     __shared__ int wsum[2][16];
+    __shared__ int boff[2];
+    {
+        int ps = 0, pc = 0;
+        for (int i = threadIdx.x; i < (int)blockIdx.x; i += 1024) { ps += blocksum[2 * i]; pc += blocksum[2 * i + 1]; }
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) { ps += __shfl_xor(ps, o, 64); pc += __shfl_xor(pc, o, 64); }
+        if ((threadIdx.x & 63) == 0) { wsum[0][threadIdx.x >> 6] = ps; wsum[1][threadIdx.x >> 6] = pc; }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            int a = 0, b = 0;
+            for (int i = 0; i < 16; i++) { a += wsum[0][i]; b += wsum[1][i]; }
+            boff[0] = a; boff[1] = b;
+            if (blockIdx.x == gridDim.x - 1) n_unique[0] = a + blocksum[2 * blockIdx.x];
+        }
+        __syncthreads();
+    }
     const int base = blockIdx.x * UQ_CHUNK + threadIdx.x * 4;
     int f[4], c[4], s = 0, cs = 0;
 #pragma unroll
@@ -190,12 +206,12 @@ __global__ __launch_bounds__(1024) void uq_assign_kernel(const int32_t* cnt, int
         const int v = __shfl_up(incl, o, 64), u = __shfl_up(inclc, o, 64);
         if ((threadIdx.x & 63) >= o) { incl += v; inclc += u; }
     }
-    if ((threadIdx.x & 63) == 63) { wsum[0][threadIdx.x >> 6] = incl; wsum[1][threadIdx.x >> 6] = inclc; }
+    if ((threadIdx.x & 63) == 63) { wsum[0][threadIdx.x >> 6] = incl; wsum[1][threadIdx.x >> 6] = inclc; }     // (reused: the barrier above)
     __syncthreads();
     int woff = 0, woffc = 0;
     for (int i = 0; i < (int)(threadIdx.x >> 6); i++) { woff += wsum[0][i]; woffc += wsum[1][i]; }
-    int r = blockoff[2 * blockIdx.x] + woff + incl - s;
-    int ro = blockoff[2 * blockIdx.x + 1] + woffc + inclc - cs;
+    int r = boff[0] + woff + incl - s;
+    int ro = boff[1] + woffc + inclc - cs;
 #pragma unroll
     for (int i = 0; i < 4; i++)
         if (f[i]) {
@@ -257,14 +273,15 @@ extern "C" int pc_build_similarity_batch_unique(const int32_t* pair_ids, int bat
     int32_t* blocksum = rank + n_products;
     int32_t* cursor = blocksum + 2 * nblk;
     hipStream_t st = (hipStream_t)stream;
-    PC_LAUNCH(build_pairs_negatives_kernel, dim3((batch + 127) / 128), dim3(128), 0, st, pair_ids, batch, sim_pairs,
-              sim_rowptr, sim_col, n_products, k_neg, seed, step, anchor_idx, positive_idx, negative_idx);
+    // four launches (round 2: six): sampler ∥ occurrence count, per-chunk sums, row assignment (own prefix of the sums), slots
+    const int pair_blocks = (batch + 127) / 128;
+    PC_LAUNCH(uq_pairs_count_kernel, dim3(pair_blocks + (total + 255) / 256), dim3(128), 0, st, pair_ids, batch, sim_pairs,
+              sim_rowptr, sim_col, n_products, k_neg, seed, step, anchor_idx, positive_idx, negative_idx, pair_blocks, cv_rowptr,
+              cv_col, n_pad, cnt);
     PC_TRY(pc_launch_status());
-    PC_LAUNCH(uq_count_kernel, dim3((total + 255) / 256), dim3(256), 0, st, anchor_idx, batch, cv_rowptr, cv_col, n_pad, cnt);
     PC_LAUNCH(uq_block_sums_kernel, dim3(nblk), dim3(1024), 0, st, cnt, n_products, blocksum);
-    PC_LAUNCH(uq_scan_sums_kernel, dim3(1), dim3(1024), 0, st, blocksum, nblk, n_unique);
     PC_LAUNCH(uq_assign_kernel, dim3(nblk), dim3(1024), 0, st, cnt, n_products, blocksum, rank, nb_rows, nb_weight, ref_off,
-              cursor);
+              cursor, n_unique);
     PC_LAUNCH(uq_slots_kernel, dim3((total + 255) / 256), dim3(256), 0, st, anchor_idx, batch, cv_rowptr, cv_col, n_pad,
               rank, n_unique, n_real, cnt, nb_rows, nb_weight, slot_row, ref_off, cursor, ref_slot);
     return pc_launch_status();
