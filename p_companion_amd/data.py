@@ -471,8 +471,8 @@ class SimilarityIndexLoader:
         base = getattr(self, "_ring_base", 0)                 # hand-outs of earlier epochs: the ring's sequence runs across epochs
         clean = getattr(self, "_ring_clean", True)              # False: the previous epoch's iterator was abandoned mid-way
         self._ring_clean = False
-        if not clean and self._ring_done is not None:
-            self._ring_done = [None] * self.RING
+        if not clean:
+            self._ring_done = None
         if ring_ok and clean and getattr(self, "_last_plan_ev", None) is not None and plan is not None:
             # the builders need this epoch's permutation (plan stream), not the training stream's backlog: waiting for
             # that would drain the pipeline at every epoch boundary; the ring's own events order the buffer reuse
@@ -494,13 +494,15 @@ class SimilarityIndexLoader:
         for i in range(n):
             batch, ev = ahead.popleft()
             cur = torch.cuda.current_stream(self.device)
-            if ring_ok:
-                # everything the training stream has queued so far -- the steps over batches < i -- precedes this event; the
-                # builder that reuses a slot waits for the event recorded RING - depth hand-outs earlier (one event record
-                # per step on the training stream instead of one per freed tensor)
+            if ring_ok and (base + i) % self.RING_EVERY == 0:
+                # everything the training stream has queued so far -- the steps over batches < i -- precedes this event.  A
+                # builder that reuses a slot waits for the LATEST such event: it covers the slot's previous batch as long as
+                # RING >= depth + RING_EVERY, and still leaves the builder `depth` steps of lead.  One event record per
+                # RING_EVERY steps on the training stream (each is a ~14 us hole in front of the step's first kernel)
+                # instead of one per freed tensor.
                 done = torch.cuda.Event()
                 done.record(cur)
-                self._ring_done[(base + i) % len(self._ring_done)] = done
+                self._ring_done = done
             if i + depth < n:
                 ahead.append(launch(i + depth))
             # the builder ran a step ago: normally its event has completed, and then nothing needs to be queued (a
@@ -522,16 +524,17 @@ class SimilarityIndexLoader:
         self._end_of_epoch_checks()
 
     RING = 16
+    RING_EVERY = 4
 
     def _ring_slot(self, i):
-        """Slot i % RING of the buffer ring, safe to overwrite: builder i runs `depth` hand-outs ahead; the slot last held
-        batch i - RING, whose step was queued before hand-out i - RING + 1 -- the builder's stream waits for that event."""
+        """Slot i % RING of the buffer ring, safe to overwrite: builder i runs `depth` (4) hand-outs ahead; the slot last held
+        batch i - RING, whose step was queued before hand-out i - RING + 1; the latest recorded event is that of a hand-out
+        >= i - depth - RING_EVERY + 1 >= i - RING + 1 -- the builder's stream waits for it."""
         if self._ring is None:
             self._ring = [self.ops.BatchBuffers(self.batch_size, self._max_deg, self.k_neg, self.device) for _ in range(self.RING)]
-            self._ring_done = [None] * self.RING
-        ev = self._ring_done[(i - self.RING + 1) % self.RING] if i >= self.RING else None
-        if ev is not None:
-            torch.cuda.current_stream(self.device).wait_event(ev)      # (the builder's stream: make() runs under it)
+            self._ring_done = None
+        if self._ring_done is not None and i >= self.RING:
+            torch.cuda.current_stream(self.device).wait_event(self._ring_done)      # (the builder's stream: make() runs under it)
         return self._ring[i % self.RING]
 
     def _end_of_epoch_checks(self, wait=False):
