@@ -2,7 +2,7 @@
 import csv, sys
 tag = sys.argv[1]
 rows = list(csv.DictReader(open(f"/root/repo/profiles/{tag}_kernel_stats.csv")))
-steps = max(int(r["Calls"]) for r in rows if r["Name"].startswith("adam_kernel"))
+steps = max(int(r["Calls"]) for r in rows if r["Name"].startswith(("adam_kernel", "adam_at_kernel")))
 tot = 0.0
 for r in rows:
     c = int(r["Calls"])
