@@ -353,20 +353,23 @@ enum { NT_MODE_PLAIN = 0, NT_MODE_KHEAD = 1, NT_MODE_AHEAD = 2 };
 struct HingeMeanJob { const float* d_pos; const float* d_neg; int B; float margin; float* loss; };
 int launch_gemm_nt_chain(const NtArgs* args, const int* modes, int n, hipStream_t st, const HingeMeanJob* rider = nullptr);
 #ifdef __HIPCC__
-// single workgroup of 256 threads, fixed summation order
+// one workgroup of >= 256 threads (the first 256 add, in the same fixed order whatever the workgroup size; the others only
+// take part in the barriers)
 __device__ __forceinline__ void hinge_mean_body(const HingeMeanJob& j, float* red /* [256] LDS */) {
+    const int t = threadIdx.x;
     float s = 0.f;
-    for (int b = threadIdx.x; b < j.B; b += 256) {
-        const float l = j.margin - j.d_pos[b] + j.d_neg[b];
-        s += l > 0.f ? l : 0.f;
-    }
-    red[threadIdx.x] = s;
+    if (t < 256)
+        for (int b = t; b < j.B; b += 256) {
+            const float l = j.margin - j.d_pos[b] + j.d_neg[b];
+            s += l > 0.f ? l : 0.f;
+        }
+    if (t < 256) red[t] = s;
     __syncthreads();
     for (int o = 128; o >= 1; o >>= 1) {
-        if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+        if (t < o) red[t] += red[t + o];
         __syncthreads();
     }
-    if (threadIdx.x == 0) *j.loss = red[0] / (float)j.B;
+    if (t == 0) *j.loss = red[0] / (float)j.B;
 }
 #endif
 
