@@ -888,6 +888,9 @@ struct TypeSimsArgs {
     const int32_t *ulist, *n_u;
     int T, K, nchunks;
     float* part_val; int32_t* part_idx;     // [U capacity][nchunks][K]
+    // rider: workgroups with blockIdx.x >= nchunks clear the two dense table gradients (17.8 MB at T = 34800) while the others
+    // multiply -- the fill was a launch of its own (hipMemsetAsync: ~10 us with its boundary) in front of the step
+    float* zero[2]; size_t nzero[2]; int zcols;
 };
 
 __global__ __launch_bounds__(256) void type_sims_topk_kernel(TypeSimsArgs a) {
@@ -897,6 +900,16 @@ __global__ __launch_bounds__(256) void type_sims_topk_kernel(TypeSimsArgs a) {
     float* Cs = Hs + UT * LD32;             // [64][LD64]
     float* Sims = Cs + UT * LD64;           // [64][TC + 4]
     constexpr int LDS_ = TC + 4;
+    if ((int)blockIdx.x >= a.nchunks) {
+        const size_t wg = ((size_t)blockIdx.x - a.nchunks) * gridDim.y + blockIdx.y, nwg = (size_t)a.zcols * gridDim.y;
+        for (int i = 0; i < 2; i++) {
+            if (!a.zero[i]) continue;
+            const size_t n4 = a.nzero[i] / 4;                   // (T * 64 floats: a multiple of 4, 16-byte aligned)
+            for (size_t e = wg * 256 + threadIdx.x; e < n4; e += nwg * 256)
+                reinterpret_cast<float4*>(a.zero[i])[e] = make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+        return;
+    }
     const int nu = *a.n_u;
     const int t0 = blockIdx.x * TC;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, ci = lane & 15, rh = lane >> 4;
@@ -1375,7 +1388,7 @@ __global__ __launch_bounds__(256) void scatter_add_rows_xcd_kernel(ScatterList l
 // Large tables, DETERMINISTIC gradients (round 3; the atomics above remain the path for more than TG_CAP distinct rows):
 // the reference's NUM_TYPES = 34800 (config.py:27) is a big table of which a batch touches few rows (20 live types at the
 // reference's catalogue, 100 at the benchmark's).
-//   touched_types_kernel   one workgroup: bitmaps of the destination rows of both lists -> ascending lists ulist_c / ulist_q
+//   touched_types_kernel   one workgroup per list: bitmap of the destination rows of both lists -> ascending lists ulist_c / ulist_q
 //                          and the inverse maps pos_c / pos_q (row -> index in its list)
 //   table_partials_kernel  256 workgroups, each a contiguous chunk of the source rows: chunk staged in LDS, rows added IN
 //                          SOURCE ORDER into an LDS table indexed by pos (destination u belongs to wave u % 4: one adder
@@ -1393,8 +1406,8 @@ __global__ __launch_bounds__(1024) void touched_types_kernel(const int32_t* idx_
     extern __shared__ unsigned bits[];                  // [words] then scan scratch [1024]
     const int words = (T + 31) >> 5;
     unsigned* part = bits + words;
-#pragma unroll 1
-    for (int li = 0; li < 2; li++) {
+    {
+        const int li = blockIdx.x;                          // one workgroup per list
         const int32_t* idx = li ? idx_q : idx_c;
         const int n = li ? n_q : n_c;
         int32_t* ulist = li ? ulist_q : ulist_c;
@@ -1634,24 +1647,21 @@ static int fused_step_impl(const pc_joint_tensors* p, const pc_joint_tensors* g,
                                             const_cast<float*>(pos_items), const_cast<float*>(neg_items), nullptr, stream));
 
     if (!w.small) {
-        // gradients of the two big tables arrive by float atomics: cleared first
-        if (g->comp_types == g->query_types + (size_t)T * PC_L) {          // (adjacent in a flat gradient buffer: one fill)
-            PC_HIP_TRY(hipMemsetAsync(g->query_types, 0, (size_t)2 * T * PC_L * 4, st));
-        } else {
-            PC_HIP_TRY(hipMemsetAsync(g->query_types, 0, (size_t)T * PC_L * 4, st));
-            PC_HIP_TRY(hipMemsetAsync(g->comp_types, 0, (size_t)T * PC_L * 4, st));
-        }
+        // the dense gradients of the two big tables hold zeros outside the touched rows (and receive float atomics beyond
+        // TG_CAP touched rows): cleared by rider workgroups of the similarity launch below
         const int words = (T + 31) / 32;
         PC_LAUNCH(present_types_kernel, dim3(1), dim3(1024), (size_t)(words + 1024) * 4, st, query_types, B, T, w.ulist, w.n_u,
                   pairs_in_tile ? src->pairs : nullptr, pairs_in_tile ? src->type_idx : nullptr, num_products);
         TypeSimsArgs ta = {p->enc_w, p->enc_b, p->dec_w, p->dec_b, p->query_types, p->comp_types, w.ulist, w.n_u, T, K,
                            w.nchunks, w.part_val, w.part_idx};
+        ta.zero[0] = g->query_types; ta.nzero[0] = (size_t)T * PC_L; ta.zero[1] = g->comp_types; ta.nzero[1] = (size_t)T * PC_L;
+        ta.zcols = 32;
         const size_t lds = ((size_t)UT * LD64 * 2 + UT * LD32 + (size_t)UT * (TC + 4)) * 4;
         static const hipError_t attr0 = hipFuncSetAttribute(reinterpret_cast<const void*>(&type_sims_topk_kernel),
                                                             hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         (void)attr0;
         const int ytiles = (w.ucap + UT - 1) / UT;
-        PC_LAUNCH(type_sims_topk_kernel, dim3(w.nchunks, ytiles < 4 ? ytiles : 4), dim3(256), lds, st, ta);
+        PC_LAUNCH(type_sims_topk_kernel, dim3(w.nchunks + ta.zcols, ytiles < 4 ? ytiles : 4), dim3(256), lds, st, ta);
         PC_LAUNCH(type_topk_merge_kernel, dim3((w.ucap + 3) / 4), dim3(256), 0, st, w.part_val, w.part_idx, w.ulist, w.n_u,
                   w.nchunks, K, w.topk_by_type);
         PC_TRY(pc_launch_status());
@@ -1734,7 +1744,7 @@ static int fused_step_impl(const pc_joint_tensors* p, const pc_joint_tensors* g,
     if (!w.small) {
         // table gradients: fixed-order sums over the touched rows (no float atomics while a table has <= TG_CAP touched rows)
         const int words = (T + 31) / 32;
-        PC_LAUNCH(touched_types_kernel, dim3(1), dim3(1024), (size_t)(words + 1024) * 4, st, w.ecidx, B * (K + 2), w.cids + B, B, T,
+        PC_LAUNCH(touched_types_kernel, dim3(2), dim3(1024), (size_t)(words + 1024) * 4, st, w.ecidx, B * (K + 2), w.cids + B, B, T,
                   w.tl_c, w.tp_c, w.tl_q, w.tp_q, w.n_touch);
         const TableList lc = {g->comp_types, w.ecidx, w.ecsrc, B * (K + 2), w.tp_c, w.tslab_c};
         const TableList lq = {g->query_types, w.cids + B, w.dt, B, w.tp_q, w.tslab_q};
