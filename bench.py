@@ -205,7 +205,8 @@ def run_joint(args, rank, world, dev, types, steps, warmup, want_cpu):
     # one process: the fixed-shape step is captured once as a HIP graph and replayed, the loader builds each batch
     # straight into the graph's input buffers.  N > 1 keeps eager launches (the gradient all-reduce sits between).
     graphed = None
-    if world == 1 and not args.no_graph:
+    multi = pdist.collectives_on(world)                  # (world > 1, or the one-rank RCCL rehearsal PC_DIST_FORCE=1)
+    if not multi and not args.no_graph:
         graphed = GraphedJointStep(model, opt, args.batch, mode="auto" if args.joint_launch == "epoch" else args.joint_launch)
     elif not args.no_graph:
         # one process per GPU: the fused step writes gradients only, the flat gradient buffer is averaged over the replicas
@@ -218,7 +219,7 @@ def run_joint(args, rank, world, dev, types, steps, warmup, want_cpu):
             graphed = None
     # 'epoch': train.py:36-57's loop over the epoch's batches as one foreign call (pc_joint_train_epoch) -- the same steps,
     # enqueued from C back to back; falls back to one call per step where the fused step does not serve the configuration
-    by_epoch = world == 1 and graphed is not None and args.joint_launch == "epoch" and graphed.mode == "direct"
+    by_epoch = not multi and graphed is not None and args.joint_launch == "epoch" and graphed.mode == "direct"
     # direct mode: the loader hands its batches over unbuilt and the step's first kernel builds them (same values)
     loader = ComplementaryIndexLoader(ComplementaryIndexDataset(bpg, "train"), args.batch, shuffle=True, seed=rank,
                                       device=dev, out=graphed.static if graphed else None,
@@ -245,7 +246,7 @@ def run_joint(args, rank, world, dev, types, steps, warmup, want_cpu):
         last = next(it)
         step(last)
     ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
-    if world > 1:
+    if multi:
         torch.distributed.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -265,10 +266,10 @@ def run_joint(args, rank, world, dev, types, steps, warmup, want_cpu):
     ev[1].record()
     host_ms = 1e3 * (time.perf_counter() - t0) / steps       # time the host needed to ENQUEUE a step (>= device time: host-bound)
     torch.cuda.synchronize()
-    if world > 1:
+    if multi:
         torch.distributed.barrier()
     t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=dev)
-    if world > 1:
+    if multi:
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
     el = float(t)
     if rank != 0:
@@ -287,7 +288,7 @@ def run_joint(args, rank, world, dev, types, steps, warmup, want_cpu):
                       "global_batch": world * args.batch, "parallelism": f"dp{world}", "final_loss": round(float(losses[0]), 5),
                       "launch": ("pc_joint_train_epoch: the epoch's steps enqueued by one foreign call" if by_epoch else
                                  {"direct": "fused step, arguments resolved once (one foreign call per step)" +
-                                            ("; gradients only, then all-reduce of the flat gradient buffer and the Adam launch" if world > 1 else ""),
+                                            ("; gradients only, then all-reduce of the flat gradient buffer and the Adam launch" if multi else ""),
                                   "graph": "hipGraph replay"}[graphed.mode] if graphed is not None else "eager module calls"),
                       "kernels_per_step": ("2 (tile kernel: batch construction, forward, losses, backward and the tile's gradient slab; finish: slab "
                                             "sums + Adam)" if types <= 128 else
@@ -317,6 +318,7 @@ def run_p2v(args, rank, world, dev, products, steps, warmup, want_cpu, profile_k
     from p_companion_amd.product2vec import FusedAdam, Product2Vec
 
     from p_companion_amd.data import generate_device_bpg
+    multi = pdist.collectives_on(world)                  # (world > 1, or the one-rank RCCL rehearsal PC_DIST_FORCE=1)
     dim = args.dim
     cfg = SimpleNamespace(PRODUCT_EMB_DIM=dim, TYPE_EMB_DIM=64, HIDDEN_SIZE=256, NUM_ATTENTION_HEADS=4, DROPOUT=0.0,
                           MARGIN=1.0, BATCH_SIZE=args.batch, LEARNING_RATE=1e-3, DEVICE=dev)
@@ -362,7 +364,7 @@ def run_p2v(args, rank, world, dev, products, steps, warmup, want_cpu, profile_k
 
     def step(b, profile=None):
         tab = b.get("table", table)                       # sharded: the rows this batch's exchange delivered
-        sync = (lambda t: torch.distributed.all_reduce(t)) if (args.sync_bn and world > 1) else None
+        sync = (lambda t: torch.distributed.all_reduce(t)) if (args.sync_bn and multi) else None
         loss = model.train_step_indexed(tab, b, profile=profile, sync_reduce=sync)
         pdist.all_reduce_mean_(gflat, world)
         opt.step()
@@ -372,7 +374,7 @@ def run_p2v(args, rank, world, dev, products, steps, warmup, want_cpu, profile_k
     for _ in range(warmup):
         last = next(it)
         step(last)
-    if world > 1:
+    if multi:
         torch.distributed.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -390,10 +392,10 @@ def run_p2v(args, rank, world, dev, products, steps, warmup, want_cpu, profile_k
         loss = step(last, profile=prof if bracket else None)
     host_ms = 1e3 * (time.perf_counter() - t0) / max(steps, 1)      # the host's time to enqueue a step (incl. its waits)
     torch.cuda.synchronize()
-    if world > 1:
+    if multi:
         torch.distributed.barrier()
     t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=dev)
-    if world > 1:
+    if multi:
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
     el = float(t)
     if sharded is not None:
@@ -466,17 +468,17 @@ def run_p2v(args, rank, world, dev, products, steps, warmup, want_cpu, profile_k
         for _ in range(20):
             step(next(it))
         for _rep in range(3):
-            if world > 1:
+            if multi:
                 torch.distributed.barrier()
             torch.cuda.synchronize()
             ts = time.perf_counter()
             for _ in range(steps_s):
                 step(next(it))
             torch.cuda.synchronize()
-            if world > 1:
+            if multi:
                 torch.distributed.barrier()
             tt = torch.tensor([time.perf_counter() - ts], dtype=torch.float64, device=dev)
-            if world > 1:
+            if multi:
                 torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
             reps.append(1e3 * float(tt) / steps_s)
         reps.sort()
@@ -567,7 +569,7 @@ def main():
                                   f"batch={args.batch}/GPU, 5 negatives, neighbours padded to batch max "
                                   f"(avg N={p2v['n_avg']:.1f})", "global_batch": world * args.batch,
                       "table": args.table, "sharded_lookup": p2v.get("sharded_lookup"), "parallelism": f"dp{world}",
-                      "batchnorm": "cross-replica" if (args.sync_bn and world > 1) else "per-replica",
+                      "batchnorm": "cross-replica" if (args.sync_bn and pdist.collectives_on(world)) else "per-replica",
                       "final_loss": round(p2v["final_loss"], 5),
                       "neighbour_rows": "identical rows of the neighbour call carried once: avg %.0f distinct products (%.0f "
                                         "real slots) + 1 shared padding row, of %d neighbour slots per step; the duplicates "

@@ -51,7 +51,7 @@ int pc_abi_version(void);
 enum {
     PC_FLAG_EXP_NO_MFMA = 1, PC_FLAG_EXP_NO_SPLIT = 2, PC_FLAG_EXP_NO_LDSREAD = 4, PC_FLAG_EXP_NO_DMA = 8,
     PC_FLAG_EXP_NO_SLAB = 16, PC_FLAG_EXP_STAGGER = 32, PC_FLAG_EXP_DMA_L2 = 64, PC_FLAG_NT_TIMING = 128,
-    PC_FLAG_JOINT_TIMING = 256, PC_FLAG_CHAIN_TIMING = 512
+    PC_FLAG_JOINT_TIMING = 256, PC_FLAG_CHAIN_TIMING = 512, PC_FLAG_EXP_NO_BARRIER = 1024, PC_FLAG_EXP_NO_VMWAIT = 2048
 };
 unsigned pc_build_flags(void);
 

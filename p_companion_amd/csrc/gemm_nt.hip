@@ -286,9 +286,15 @@ __global__ __launch_bounds__(64 * NWM * NWN, WPS) void gemm_nt_kernel(NtArgs a, 
     int nsrow[NIA];
     int ntile = tile, nrow0 = 0, nrow_end = 0, nn0 = 0, nseg = 0;
     // end of a K-step: this wave's DMA has landed, then every wave is past its reads of the old stage
+    // (developer builds, wrong results: -DPC_EXP_NO_BARRIER the K-steps of a workgroup's waves run unsynchronised,
+    // -DPC_EXP_NO_VMWAIT no wave waits for its stage requests)
     auto stage_sync = [&]() {
+#ifndef PC_EXP_NO_VMWAIT
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+#ifndef PC_EXP_NO_BARRIER
         __syncthreads();
+#endif
     };
 
     tile_geom(tile, row0, row_end, n0, seg);
@@ -465,7 +471,7 @@ __global__ __launch_bounds__(64 * NWM * NWN, WPS) void gemm_nt_kernel(NtArgs a, 
         {
             const unsigned long long t2 = __builtin_amdgcn_s_memtime();
             tk += t1 - t0; te += t2 - t1; tn += 1;
-            if (ntile >= total_tiles && NWM == 2 && NWN == 4 && tid == 0) {
+            if (ntile >= total_tiles && NWM == 2 && tid == 0) {
                 const int id = (EPI + 6 * (STATS != 0) + 12 * (PRO ? 1 : 0)) * 4;
                 atomicAdd(&pc_nt_timing[id], tk); atomicAdd(&pc_nt_timing[id + 1], te); atomicAdd(&pc_nt_timing[id + 2], tn); atomicAdd(&pc_nt_timing[id + 3], 1ull);
             }

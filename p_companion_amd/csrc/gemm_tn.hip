@@ -365,9 +365,14 @@ __global__ __launch_bounds__(64 * WO * WI, WO * WI / 4) void gemm_tn8_kernel(TnA
     for (int j = 0; j < TI; j++) xo[j] = (wi * (TI * 32) + 32 * j + (lane & 31)) ^ ((ASW && lane >= 32) ? 32 : 0);
     int cur = 0;
     for (int c = 0; c < nchunk; c++) {
+#ifndef PC_EXP_NO_VMWAIT
         if (c + NST - 1 <= nchunk) { asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NST - 2) * JALL) : "memory"); }
         else { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
-        __syncthreads();                                   // chunk c visible to all; slot of chunk c-1 free again
+#endif
+#ifndef PC_EXP_NO_BARRIER
+        __syncthreads();
+#endif
+                                          // chunk c visible to all; slot of chunk c-1 free again
 #ifndef PC_EXP_NO_DMA
         if (c + NST - 1 < nchunk) {
             issue(cur == 0 ? NST - 1 : cur - 1, r_begin + (c + NST - 1) * TKC);

@@ -544,6 +544,12 @@ extern "C" unsigned pc_build_flags(void) {
 #ifdef PC_EXP_DMA_L2
     f |= PC_FLAG_EXP_DMA_L2;
 #endif
+#ifdef PC_EXP_NO_BARRIER
+    f |= PC_FLAG_EXP_NO_BARRIER;
+#endif
+#ifdef PC_EXP_NO_VMWAIT
+    f |= PC_FLAG_EXP_NO_VMWAIT;
+#endif
 #ifdef PC_NT_TIMING
     f |= PC_FLAG_NT_TIMING;
 #endif

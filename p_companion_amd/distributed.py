@@ -18,12 +18,19 @@ import torch
 import torch.distributed as dist
 
 
+def collectives_on(world):
+    """True when the exchange steps go through torch.distributed: always for world > 1; for world == 1 only in the one-rank
+    rehearsal (PC_DIST_FORCE=1), which drives the whole N > 1 code path -- process group, every collective call with its
+    dtypes and shapes, the gradient hooks -- over RCCL on a one-GPU box (tests/test_gpu_rccl.py)."""
+    return world > 1 or os.environ.get("PC_DIST_FORCE", "0") == "1"
+
+
 def init_from_env(device_type="cuda"):
     """Reads RANK / WORLD_SIZE / LOCAL_RANK / MASTER_* (torch.distributed.run)."""
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1 and not dist.is_initialized():
+    if collectives_on(world) and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         # PC_DIST_BACKEND / PC_FORCE_DEVICE: rehearsal of the N>1 path on a one-GPU box (gloo, every rank
@@ -38,7 +45,7 @@ def init_from_env(device_type="cuda"):
 
 def all_reduce_mean_(flat, world):
     """Dense-gradient exchange: one bucket (the whole flat gradient buffer)."""
-    if world > 1:
+    if collectives_on(world):
         dist.all_reduce(flat, op=dist.ReduceOp.SUM)
         flat.mul_(1.0 / world)
     return flat
@@ -95,7 +102,7 @@ class ShardedFeatureTable:
         every rank.  Ranks may hold different graphs or batch sizes, so the value each rank derived locally is
         all-reduced (MAX) over the group once, at construction time (one tiny host-visible collective)."""
         capacity = int(capacity)
-        if self.world > 1 and dist.is_initialized():
+        if collectives_on(self.world) and dist.is_initialized():
             dev = self.local.device if dist.get_backend(self.group) != "gloo" else torch.device("cpu")
             t = torch.tensor([capacity], dtype=torch.int64, device=dev)
             dist.all_reduce(t, op=dist.ReduceOp.MAX, group=self.group)
@@ -128,13 +135,13 @@ class ShardedFeatureTable:
         outs = self.bucket_fn([(a, None, 0), (nb_rows, n_live, 1), (p, None, 0), (ng.reshape(-1), None, 0)], G, C,
                               bufs["counts"], bufs["send_ids"], bufs["overflow"])
         req = torch.empty_like(bufs["send_ids"])
-        if G > 1:
+        if collectives_on(G):
             dist.all_to_all_single(req, bufs["send_ids"], group=self.group)       # equal splits: C int32 per peer
         else:
             req.copy_(bufs["send_ids"])
         rows_out = self.gather_fn(self.local, req)                                # -1 -> zero row
         tab = torch.empty_like(rows_out)
-        if G > 1:
+        if collectives_on(G):
             dist.all_to_all_single(tab, rows_out, group=self.group)               # C x D fp32 per peer
         else:
             tab = rows_out
@@ -171,19 +178,19 @@ class ShardedFeatureTable:
         send_ids = (uniq[order] // self.world).to(torch.int32)
         send_counts = torch.bincount(owner, minlength=self.world)
         recv_counts = torch.empty_like(send_counts)
-        if self.world > 1:
+        if collectives_on(self.world):
             dist.all_to_all_single(recv_counts, send_counts, group=self.group)
         else:
             recv_counts.copy_(send_counts)
         sc, rc = send_counts.tolist(), recv_counts.tolist()
         req = torch.empty(sum(rc), dtype=torch.int32, device=dev)
-        if self.world > 1:
+        if collectives_on(self.world):
             dist.all_to_all_single(req, send_ids, rc, sc, group=self.group)
         else:
             req.copy_(send_ids)
         rows_out = self.gather_fn(self.local, req) if req.numel() else self.local.new_zeros((0, self.local.shape[1]))
         rows_in = torch.empty(uniq.numel(), self.local.shape[1], dtype=self.local.dtype, device=dev)
-        if self.world > 1:
+        if collectives_on(self.world):
             dist.all_to_all_single(rows_in, rows_out, sc, rc, group=self.group)
         else:
             rows_in.copy_(rows_out)
@@ -240,7 +247,7 @@ class TableRowExchange:
         dev = tables[0].device
         n_loc = torch.tensor([int(t.numel()) for t in touched], dtype=torch.int64, device=dev)
         counts = torch.empty(G, 2, dtype=torch.int64, device=dev)
-        if G > 1:
+        if collectives_on(G):
             dist.all_gather_into_tensor(counts.view(-1), n_loc, group=self.group)
         else:
             counts[0] = n_loc
@@ -259,7 +266,7 @@ class TableRowExchange:
                 rows_pad[:n] = self.gather_fn(tab, ids)
             all_ids = torch.empty(G, cap, dtype=torch.int32, device=dev)
             all_rows = torch.empty(G, cap, L, dtype=tab.dtype, device=dev)
-            if G > 1:
+            if collectives_on(G):
                 dist.all_gather_into_tensor(all_ids.view(-1), ids_pad, group=self.group)
                 dist.all_gather_into_tensor(all_rows.view(-1), rows_pad.view(-1), group=self.group)
             else:
@@ -276,7 +283,7 @@ def joint_grad_hook(model, step, world, group=None):
     the flat gradient buffer (both tables are 51 KB at T = 100); T > 512 -- the 29 k dense weights as one all-reduce of
     their flat segment and the two [T,64] tables as row lists (TableRowExchange)."""
     T = model.query_type_embeddings.weight.shape[0]
-    if T <= 512 or world == 1:
+    if T <= 512 or not collectives_on(world):
         return lambda gflat: all_reduce_mean_(gflat, world)
     from . import ops
     ex = TableRowExchange(world, group)
@@ -284,6 +291,10 @@ def joint_grad_hook(model, step, world, group=None):
     tab_names = ("query_type_embeddings.weight", "complementary_type_embeddings.weight")
 
     def hook(gflat):
+        if step.prepared is None:
+            # GraphedJointStep's eager warm-up steps (the launch-per-op path keeps no touched-row lists): the dense exchange,
+            # same mean, 2 x T x 256 B more on the wire for those few steps
+            return all_reduce_mean_(gflat, world)
         params = dict(model.named_parameters())
         gq, gc = params[tab_names[0]].grad, params[tab_names[1]].grad
         off, lo = 0, None                                       # the dense weights: the maximal runs of the flat buffer between tables

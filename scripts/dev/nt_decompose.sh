@@ -13,7 +13,7 @@ for K in ${KNOBS:-BASE NO_SPLIT NO_LDSREAD NO_MFMA NO_DMA DMA_L2}; do
   if [ "$K" = "BASE" ]; then FL=""; else FL="-DPC_EXP_$K"; fi
   (cd $R && PC_EXTRA_HIPCC_FLAGS="$FL" python3 -m p_companion_amd.build > /tmp/build_decomp.log 2>&1)
   rm -rf /tmp/prof_decomp
-  rocprofv3 --kernel-trace --stats -d /tmp/prof_decomp -o t -- python3 $R/bench.py --phase p2v --steps 12 --warmup 3 --no-cpu-baseline > /tmp/b_decomp.json 2> /tmp/b_decomp.err
+  rocprofv3 --kernel-trace --stats -d /tmp/prof_decomp -o t -- python3 $R/bench.py --phase p2v --steps 12 --warmup 3 --no-cpu-baseline --no-sustained > /tmp/b_decomp.json 2> /tmp/b_decomp.err
   python3 - "$TAG" >> $OUT/summary.txt <<'PY'
 import sqlite3, glob, sys
 f = glob.glob('/tmp/prof_decomp/*.db') + glob.glob('/tmp/prof_decomp/*/*.db')

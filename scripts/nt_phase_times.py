@@ -10,7 +10,7 @@ lib = _lib.lib()
 fn = lib.pc_debug_nt_timing
 fn.argtypes = [ctypes.POINTER(ctypes.c_ulonglong), ctypes.c_int]
 fn.restype = ctypes.c_int
-sys.argv = ["bench.py", "--steps", "20", "--warmup", "5", "--no-cpu-baseline"]
+sys.argv = ["bench.py", "--steps", "20", "--warmup", "5", "--no-cpu-baseline", "--no-sustained", "--phase", "p2v"]
 import runpy
 buf = (ctypes.c_ulonglong * 128)()
 torch.cuda.init()

@@ -1,0 +1,91 @@
+"""The N > 1 code path over RCCL on the one GPU this suite has: a ONE-RANK 'nccl' process group with every exchange
+forced through torch.distributed (PC_DIST_FORCE=1).  The world-2 semantics of the exchanges are covered on gloo
+(tests/test_distributed_gloo.py, tests/test_gpu_sharded.py); what this adds is that every collective call of the path --
+its dtypes, shapes, devices, split lists -- is one RCCL accepts, and that bench.py's multi-rank branches (gradient hooks,
+barrier + max-over-ranks timing, the sharded-lookup loader) run end to end on that backend.  Needs an MI355X."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _env():
+    env = dict(os.environ, PC_DIST_FORCE="1", WORLD_SIZE="1", RANK="0", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1",
+               MASTER_PORT=str(_free_port()), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env.pop("PC_DIST_BACKEND", None)
+    return env
+
+
+def _bench(*flags):
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--no-cpu-baseline", "--no-sustained", *flags],
+                         env=_env(), capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-3000:]
+    return json.loads(out.stdout.strip().splitlines()[-1])
+
+
+@pytest.mark.timeout(900)
+def test_bench_multi_rank_branches_run_over_rccl():
+    """Product2Vec: flat-gradient all-reduce per step, barrier + MAX all-reduce of the timing; joint step: direct mode with the
+    gradient hook at T = 100 (one all-reduce) and T = 34800 (dense segment all-reduce + row-list all-gathers)."""
+    line = _bench("--steps", "10", "--warmup", "3")
+    assert line["n_gpus"] == 1 and line["value"] > 1e6 and line["config"]["parallelism"] == "dp1"
+    j, jr = line["joint"], line["joint_num_types_34800"]
+    assert "all-reduce" in j["config"]["launch"] and j["value"] > 1e6
+    assert jr["value"] > 1e6 and jr["config"]["final_loss"] == jr["config"]["final_loss"]        # (not NaN)
+
+
+@pytest.mark.timeout(900)
+def test_bench_sharded_lookup_and_cross_replica_batchnorm_run_over_rccl():
+    """--table sharded: the loader's two constant-shape all_to_all rounds per batch (int32 requests, fp32 rows) and the
+    capacity agreement (MAX all-reduce of an int64); --sync-bn: the three-phase step with the statistics all-reduce."""
+    line = _bench("--phase", "p2v", "--table", "sharded", "--sync-bn", "--steps", "10", "--warmup", "3")
+    assert line["config"]["table"] == "sharded" and line["config"]["batchnorm"] == "cross-replica"
+    assert line["config"]["sharded_lookup"] and line["value"] > 5e5
+
+
+def _worker_exchanges():
+    """(subprocess body) the general-purpose lookup with split lists and the row-list exchange, against their no-collective forms"""
+    import torch.distributed as dist
+    from p_companion_amd import distributed as pdist, ops
+    rank, world, local = pdist.init_from_env("cuda")
+    assert dist.is_initialized() and dist.get_backend() == "nccl" and world == 1
+    dev = torch.device("cuda", local)
+    g = torch.Generator().manual_seed(0)
+    table = torch.randn(5000, 128, generator=g).to(dev)
+    sh = pdist.ShardedFeatureTable(table, 5000, 0, 1)
+    ids = torch.randint(-1, 5000, (64, 7), generator=g).to(dev)
+    rows, remap = sh.lookup(ids)
+    ref = torch.where((ids >= 0)[..., None], table[ids.clamp(min=0)], torch.zeros((), device=dev))
+    got = torch.where((remap >= 0)[..., None], rows[remap.clamp(min=0)], torch.zeros((), device=dev))
+    assert torch.equal(got.view_as(ref), ref)
+    T = 2000
+    ex = pdist.TableRowExchange(1)
+    tabs = [torch.zeros(T, 64, device=dev), torch.zeros(T, 64, device=dev)]
+    touched = [torch.unique(torch.randint(0, T, (300,), generator=g)).to(torch.int32).to(dev) for _ in range(2)]
+    want = []
+    for t, ids_ in zip(tabs, touched):
+        t[ids_.long()] = torch.randn(ids_.numel(), 64, generator=g).to(dev)
+        want.append(t.clone())
+    ex(tabs, touched)
+    assert all(torch.equal(a, b) for a, b in zip(tabs, want)) and ex.last_bytes["row_lists_per_rank"] > 0
+    dist.destroy_process_group()
+    print("exchanges ok")
+
+
+def test_lookup_and_row_list_exchange_over_rccl():
+    out = subprocess.run([sys.executable, "-c", "import tests.test_gpu_rccl as t; t._worker_exchanges()"], env=_env(),
+                         capture_output=True, text=True, timeout=300, cwd=ROOT)
+    assert out.returncode == 0 and "exchanges ok" in out.stdout, out.stderr[-3000:]
