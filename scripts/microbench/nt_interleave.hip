@@ -10,6 +10,7 @@
 //      read and split (compiler's order)
 //   2  = 1 with sched_group_barrier: one MFMA, then 8 VALU, ...
 //   3  = 1 with the dot2c split of 112 VALU (sched_group_barrier: one MFMA, 5 VALU)
+//   6  the 24 MFMAs alone; 7  the reads and splits alone
 //   4  = 0, 5 = 1 with the accumulators in AGPRs (inline-asm MFMA: the compiler cannot move those, so the stream is as written)
 // Output: cycles per K-step per wave and per SIMD.
 #include <hip/hip_runtime.h>
@@ -99,7 +100,19 @@ __global__ __launch_bounds__(256, WPS) void kern(const float* in, float* out, in
 #pragma unroll
             for (int r = 0; r < 16; r++) acc[i][j][r] = 0.f;
     const unsigned long long t0 = __builtin_amdgcn_s_memtime();
-    if (MODE == 0 || MODE == 4) {
+    if (MODE == 6) {                      // the 24 MFMAs alone, on fragments split once
+        const Frags f = load_split<false>(stage[0], wm, wn, lane);
+        for (int it = 0; it < iters; it++) {
+            mfmas<false>(f, acc);
+            asm volatile("" ::: "memory");
+        }
+    } else if (MODE == 7) {               // reads + splits alone (the pieces are kept alive by an empty asm)
+        for (int it = 0; it < iters; it++) {
+            const Frags f = load_split<false>(stage[it & 1], wm, wn, lane);
+            asm volatile("" ::"v"(f.a[0].p0), "v"(f.a[0].p1), "v"(f.a[0].p2), "v"(f.a[1].p0), "v"(f.a[1].p1), "v"(f.a[1].p2),
+                         "v"(f.b[0].p0), "v"(f.b[0].p1), "v"(f.b[0].p2), "v"(f.b[1].p0), "v"(f.b[1].p1), "v"(f.b[1].p2));
+        }
+    } else if (MODE == 0 || MODE == 4) {
         for (int it = 0; it < iters; it++) {
             const Frags f = load_split<false>(stage[it & 1], wm, wn, lane);
             mfmas<MODE == 4>(f, acc);
@@ -173,6 +186,7 @@ int main() {
     run<1, 1>(in, out, cyc, iters);
     run<2, 2>(in, out, cyc, iters);
     run<2, 1>(in, out, cyc, iters);
+    run<6, 3>(in, out, cyc, iters);
     run<3, 2>(in, out, cyc, iters);
     run<3, 1>(in, out, cyc, iters);
     run<4, 3>(in, out, cyc, iters);
@@ -180,12 +194,15 @@ int main() {
     run<4, 1>(in, out, cyc, iters);
     run<5, 2>(in, out, cyc, iters);
     run<5, 1>(in, out, cyc, iters);
+    run<6, 3>(in, out, cyc, iters);
+    run<6, 1>(in, out, cyc, iters);
+    run<7, 3>(in, out, cyc, iters);
+    run<7, 1>(in, out, cyc, iters);
     // is the wall the chip's power / current limit?  Fewer busy CUs (blocks b, b + 8, ... share an XCD; 64 blocks = 8 per XCD),
     // and all-zero operands (less switching): per-CU rate and the clock (ticks per ns) should both go up
-    run<0, 3>(in, out, cyc, iters, 64);
-    run<0, 3>(in, out, cyc, iters, 16);
     hipMemset(in, 0, 2 * 256 * BK * 4);
     run<0, 3>(in, out, cyc, iters);
     run<2, 1>(in, out, cyc, iters);
+    run<6, 3>(in, out, cyc, iters);
     return 0;
 }
