@@ -10,7 +10,8 @@ cd /tmp && export TMPDIR=/tmp
 for K in ${KNOBS:-BASE NO_SPLIT NO_LDSREAD NO_MFMA NO_DMA DMA_L2}; do
   TAG=$(echo $K | sed 's/ -DPC_EXP_/+/g')
   touch $R/p_companion_amd/csrc/gemm_nt.hip $R/p_companion_amd/csrc/gemm_tn.hip
-  if [ "$K" = "BASE" ]; then FL=""; else FL="-DPC_EXP_$K"; fi
+  # (several knobs in one build: comma-separated, e.g. KNOBS="DMA_L2,STAGGER=8")
+  if [ "$K" = "BASE" ]; then FL=""; else FL="-DPC_EXP_${K//,/ -DPC_EXP_}"; fi
   (cd $R && PC_EXTRA_HIPCC_FLAGS="$FL" python3 -m p_companion_amd.build > /tmp/build_decomp.log 2>&1)
   rm -rf /tmp/prof_decomp
   rocprofv3 --kernel-trace --stats -d /tmp/prof_decomp -o t -- python3 $R/bench.py --phase p2v --steps 12 --warmup 3 --no-cpu-baseline --no-sustained > /tmp/b_decomp.json 2> /tmp/b_decomp.err

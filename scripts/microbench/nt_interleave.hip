@@ -87,7 +87,8 @@ __device__ __forceinline__ void mfmas(const Frags& f, f32x16 (&acc)[2][2]) {
 }
 
 template <int MODE, int WPS>
-__global__ __launch_bounds__(256, WPS) void kern(const float* in, float* out, int iters, unsigned long long* cyc) {
+__global__ __launch_bounds__(256, WPS) void kern(const float* in, float* out, int iters, unsigned long long* cyc, int active_mod) {
+    if (active_mod > 1 && ((blockIdx.x >> 3) % active_mod) != 0) { if (threadIdx.x == 0) cyc[blockIdx.x] = 0; return; }   // (whole groups of 8: one per XCD)
     __shared__ __attribute__((aligned(1024))) float stage[2][256 * BK];
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, wm = w & 1, wn = w >> 1;
     for (int i = tid; i < 2 * 256 * BK; i += 256) (&stage[0][0])[i] = in[i];
@@ -146,7 +147,7 @@ __global__ __launch_bounds__(256, WPS) void kern(const float* in, float* out, in
 }
 
 template <int MODE, int WPS>
-static void run(const float* in, float* out, unsigned long long* cyc, int iters, int cus = 256) {
+static void run(const float* in, float* out, unsigned long long* cyc, int iters, int cus = 256, int active_mod = 1) {
     const int grid = cus * WPS;
     std::vector<unsigned long long> h(grid);
     double best = 1e30;
@@ -155,18 +156,20 @@ static void run(const float* in, float* out, unsigned long long* cyc, int iters,
     hipEventCreate(&e0); hipEventCreate(&e1);
     for (int rep = 0; rep < 3; rep++) {
         hipEventRecord(e0);
-        hipLaunchKernelGGL((kern<MODE, WPS>), dim3(grid), dim3(256), 0, 0, in, out, iters, cyc);
+        hipLaunchKernelGGL((kern<MODE, WPS>), dim3(grid), dim3(256), 0, 0, in, out, iters, cyc, active_mod);
         hipEventRecord(e1);
         hipEventSynchronize(e1);
         hipEventElapsedTime(&ms, e0, e1);
         hipMemcpy(h.data(), cyc, grid * 8, hipMemcpyDeviceToHost);
         double m = 0;
-        for (auto v : h) m += (double)v;
-        m /= grid;
+        int live = 0;
+        for (auto v : h) { m += (double)v; live += v != 0; }
+        m /= live;
         if (m < best) best = m;
     }
     // s_memtime ticks at 100 MHz on this part: convert through the event time
-    const double tflops = 2.0 * 128 * 128 * BK * (double)iters * grid / (ms * 1e-3) / 1e12;
+    const double tflops = 2.0 * 128 * 128 * BK * (double)iters * grid / active_mod / (ms * 1e-3) / 1e12;
+    if (active_mod > 1) printf("every %d-th group of 8 workgroups computes, the others exit: ", active_mod);
     printf("CUs %3d  mode %d  waves/SIMD %d  %8.1f memtime ticks/iter  %7.3f ms  %6.1f TFLOP/s-equivalent (fp32-grade), %6.1f us per 16 K-steps\n",
            cus, MODE, WPS, best / iters, ms, tflops, ms * 1e3 / iters * 16);
 }
@@ -198,6 +201,11 @@ int main() {
     run<6, 1>(in, out, cyc, iters);
     run<7, 3>(in, out, cyc, iters);
     run<7, 1>(in, out, cyc, iters);
+    // chip-wide budget or per-CU limit?  One workgroup per CU, the MFMAs alone, on every CU / on every second / fourth CU's worth
+    run<6, 1>(in, out, cyc, iters, 256, 2);
+    run<6, 1>(in, out, cyc, iters, 256, 4);
+    run<0, 1>(in, out, cyc, iters, 256, 2);
+    run<0, 1>(in, out, cyc, iters, 256, 4);
     // is the wall the chip's power / current limit?  Fewer busy CUs (blocks b, b + 8, ... share an XCD; 64 blocks = 8 per XCD),
     // and all-zero operands (less switching): per-CU rate and the clock (ticks per ns) should both go up
     hipMemset(in, 0, 2 * 256 * BK * 4);
