@@ -417,12 +417,22 @@ struct TnReduceGroup {
     const float* slabs[PC_TN_RGROUP]; float* dW[PC_TN_RGROUP]; float* db[PC_TN_RGROUP];
     int nsplit[PC_TN_RGROUP], n_w[PC_TN_RGROUP], n_b[PC_TN_RGROUP], accumulate[PC_TN_RGROUP], block0[PC_TN_RGROUP + 1], n;
 };
-struct TnDefer { TnReduceGroup r; int rblocks; };
+// A second queue for the few launches of the fused Product2Vec step that nothing on the main queue waits for until much
+// later: the attention block's ten few-row weight gradients (24 us, needed by the slab reduce at the end of the step) beside
+// the key-row gradient product and dZ2, and the BatchNorm-backward finalize (12 us, 8 workgroups, needed by dW0) beside the two
+// dW3 halves.  Fork = event on the main queue + wait on the side queue; join = the reverse.  The stream and its events belong
+// to the library (one set per device, created on first use); work on the side queue only ever touches workspace buffers whose
+// next reader on the main queue sits behind the join.
+struct PcFork { hipStream_t side; hipEvent_t fork[2]; hipEvent_t join[2]; int pending; };
+PcFork* pc_fork_get();                                       // null: no side queue (creation failed): everything stays on the main queue
+int pc_fork_begin(PcFork* f, int i, hipStream_t main_st);    // the side queue continues behind everything enqueued on main so far
+int pc_fork_join(PcFork* f, int i, hipStream_t main_st);     // main continues behind everything enqueued on the side queue so far
+struct TnDefer { TnReduceGroup r; int rblocks; PcFork* fork; int bn_finalized; };
 static_assert(sizeof(TnGroup) <= 4096, "kernel argument segment");
 int launch_gemm_tn_group(const TnArgs* args, int n, const TnReduceJob* extra, int n_extra, hipStream_t st,
                          TnDefer* defer = nullptr);
 int launch_tn_reduce_deferred(TnDefer* d, hipStream_t st);
-static inline void tn_defer_init(TnDefer* d) { d->r = TnReduceGroup{}; d->rblocks = 0; }
+static inline void tn_defer_init(TnDefer* d) { d->r = TnReduceGroup{}; d->rblocks = 0; d->fork = nullptr; d->bn_finalized = 0; }
 int scatter_add_slab_blocks(int table_rows, int rows, int width);
 int launch_scatter_add_slabs(const int32_t* idx, int rows, int width, int table_rows, const float* src, float* slabs,
                              hipStream_t st);

@@ -417,6 +417,14 @@ int ffn_backward_part1(const pc_p2v_tensors* p, const pc_p2v_tensors* g, const f
     b2.epilogue = NT_EPI_DTANH_BN; b2.aux = sv->h0; b2.ldaux = PC_H; b2.escale = sv->bn_scale; b2.eshift = sv->bn_shift;
     b2.stats = NT_STAT_BNBWD; b2.stat_sum = w.stat_a; b2.stat_aux = w.stat_b;
     PC_TRY(launch_gemm_nt(b2, st));
+    if (df->fork && !local_sums) {
+        // the BatchNorm-backward finalize (8 workgroups, 12 us; only dW0 reads c1 / c2) on the side queue, beside dW3
+        PC_TRY(pc_fork_begin(df->fork, 1, st));
+        PC_LAUNCH(bn_finalize_bwd_kernel, dim3(PC_H / FIN_COLS), dim3(FIN_COLS, FIN_LANES), 0, df->fork->side, w.stat_a, w.stat_b, si,
+                  nullptr, nullptr, sv->bn_mean, sv->bn_invstd, g->gamma, g->beta, accumulate, w.c1, w.c2);
+        PC_TRY(pc_launch_status());
+        df->bn_finalized = 1;
+    }
 
     // dW3 = dZ2^T A1, db3 (A1 as the forward saved it; without the optional buffer it is recomputed from H0 in the loader:
     // the in-place tanh(BN(.)) on every landed stage made this the longest kernel of the step, 123 us)
@@ -454,9 +462,14 @@ int ffn_backward_part2(const pc_p2v_tensors* g, const float* table, const int32_
     hipStream_t st = (hipStream_t)stream;
     const SegInfo si = make_seginfo(seg, rows, 128);
     FfnWs w = ffn_ws_layout(ws, rows);
-    PC_LAUNCH(bn_finalize_bwd_kernel, dim3(PC_H / FIN_COLS), dim3(FIN_COLS, FIN_LANES), 0, st, w.stat_a, w.stat_b, si, local_sums,
-              global_sums, sv->bn_mean, sv->bn_invstd, g->gamma, g->beta, accumulate, w.c1, w.c2);
-    PC_TRY(pc_launch_status());
+    if (defer && defer->bn_finalized) {
+        if (local_sums || global_sums) return PC_EINVAL;
+        PC_TRY(pc_fork_join(defer->fork, 0, st));              // part 1 ran the finalize on the side queue
+    } else {
+        PC_LAUNCH(bn_finalize_bwd_kernel, dim3(PC_H / FIN_COLS), dim3(FIN_COLS, FIN_LANES), 0, st, w.stat_a, w.stat_b, si, local_sums,
+                  global_sums, sv->bn_mean, sv->bn_invstd, g->gamma, g->beta, accumulate, w.c1, w.c2);
+        PC_TRY(pc_launch_status());
+    }
 
     // dW0 = dH0^T X (rows gathered again from the table), db0.  Without a dx consumer the BatchNorm
     // backward is applied to dZ1 on the fly inside the loader and dH0 never touches HBM.

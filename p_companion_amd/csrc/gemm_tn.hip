@@ -589,8 +589,39 @@ int launch_gemm_tn(const TnArgs& a, hipStream_t st, TnDefer* defer) {
     return pc_launch_status();
 }
 
+PcFork* pc_fork_get() {
+    static PcFork forks[16];
+    static int state[16];                                        // 0 = not tried, 1 = ready, -1 = unavailable
+    int dev = 0;
+    static const bool off = getenv("PC_NO_FORK") != nullptr;     // (A/B measurement: everything on the main queue)
+    if (off || hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return nullptr;
+    if (state[dev] == 0) {
+        PcFork& f = forks[dev];
+        bool ok = hipStreamCreateWithFlags(&f.side, hipStreamNonBlocking) == hipSuccess;
+        for (int i = 0; ok && i < 2; i++)
+            ok = hipEventCreateWithFlags(&f.fork[i], hipEventDisableTiming) == hipSuccess &&
+                 hipEventCreateWithFlags(&f.join[i], hipEventDisableTiming) == hipSuccess;
+        f.pending = 0;
+        state[dev] = ok ? 1 : -1;
+    }
+    return state[dev] == 1 ? &forks[dev] : nullptr;
+}
+int pc_fork_begin(PcFork* f, int i, hipStream_t main_st) {
+    PC_HIP_TRY(hipEventRecord(f->fork[i], main_st));
+    PC_HIP_TRY(hipStreamWaitEvent(f->side, f->fork[i], 0));
+    f->pending = 1;
+    return PC_OK;
+}
+int pc_fork_join(PcFork* f, int i, hipStream_t main_st) {
+    PC_HIP_TRY(hipEventRecord(f->join[i], f->side));
+    PC_HIP_TRY(hipStreamWaitEvent(main_st, f->join[i], 0));
+    f->pending = 0;
+    return PC_OK;
+}
+
 int launch_tn_reduce_deferred(TnDefer* d, hipStream_t st) {
     if (!d) return PC_EINVAL;
+    if (d->fork && d->fork->pending) PC_TRY(pc_fork_join(d->fork, 1, st));      // side-queue products: their slabs are summed here
     if (d->r.n == 0) return PC_OK;
     for (int k = d->r.n; k <= PC_TN_RGROUP; k++) d->r.block0[k] = d->rblocks;
     PC_LAUNCH(tn_reduce_group_kernel, dim3(d->rblocks), dim3(256), 0, st, d->r);
