@@ -423,10 +423,13 @@ struct TnReduceGroup {
 // dW3 halves.  Fork = event on the main queue + wait on the side queue; join = the reverse.  The stream and its events belong
 // to the library (one set per device, created on first use); work on the side queue only ever touches workspace buffers whose
 // next reader on the main queue sits behind the join.
-struct PcFork { hipStream_t side; hipEvent_t fork[2]; hipEvent_t join[2]; int pending; };
+#define PC_FORK_EVENTS 3
+struct PcFork { hipStream_t side; hipEvent_t fork[PC_FORK_EVENTS]; hipEvent_t join[PC_FORK_EVENTS]; int pending; };
 PcFork* pc_fork_get();                                       // null: no side queue (creation failed): everything stays on the main queue
 int pc_fork_begin(PcFork* f, int i, hipStream_t main_st);    // the side queue continues behind everything enqueued on main so far
-int pc_fork_join(PcFork* f, int i, hipStream_t main_st);     // main continues behind everything enqueued on the side queue so far
+int pc_fork_mark(PcFork* f, int i);                          // a point on the side queue ...
+int pc_fork_wait(PcFork* f, int i, hipStream_t main_st);     // ... behind which main continues (the side queue may go on)
+int pc_fork_join(PcFork* f, int i, hipStream_t main_st);     // mark + wait, and nothing is pending afterwards
 struct TnDefer { TnReduceGroup r; int rblocks; PcFork* fork; int bn_finalized; };
 static_assert(sizeof(TnGroup) <= 4096, "kernel argument segment");
 int launch_gemm_tn_group(const TnArgs* args, int n, const TnReduceJob* extra, int n_extra, hipStream_t st,

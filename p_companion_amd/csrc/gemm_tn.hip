@@ -598,7 +598,7 @@ PcFork* pc_fork_get() {
     if (state[dev] == 0) {
         PcFork& f = forks[dev];
         bool ok = hipStreamCreateWithFlags(&f.side, hipStreamNonBlocking) == hipSuccess;
-        for (int i = 0; ok && i < 2; i++)
+        for (int i = 0; ok && i < PC_FORK_EVENTS; i++)
             ok = hipEventCreateWithFlags(&f.fork[i], hipEventDisableTiming) == hipSuccess &&
                  hipEventCreateWithFlags(&f.join[i], hipEventDisableTiming) == hipSuccess;
         f.pending = 0;
@@ -612,9 +612,17 @@ int pc_fork_begin(PcFork* f, int i, hipStream_t main_st) {
     f->pending = 1;
     return PC_OK;
 }
-int pc_fork_join(PcFork* f, int i, hipStream_t main_st) {
+int pc_fork_mark(PcFork* f, int i) {
     PC_HIP_TRY(hipEventRecord(f->join[i], f->side));
+    return PC_OK;
+}
+int pc_fork_wait(PcFork* f, int i, hipStream_t main_st) {
     PC_HIP_TRY(hipStreamWaitEvent(main_st, f->join[i], 0));
+    return PC_OK;
+}
+int pc_fork_join(PcFork* f, int i, hipStream_t main_st) {
+    PC_TRY(pc_fork_mark(f, i));
+    PC_TRY(pc_fork_wait(f, i, main_st));
     f->pending = 0;
     return PC_OK;
 }
