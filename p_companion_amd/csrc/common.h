@@ -421,11 +421,11 @@ struct TnReduceGroup {
 // later: the attention block's ten few-row weight gradients (24 us, needed by the slab reduce at the end of the step) beside
 // the key-row gradient product and dZ2, and the BatchNorm-backward finalize (12 us, 8 workgroups, needed by dW0) beside the two
 // dW3 halves.  Fork = event on the main queue + wait on the side queue; join = the reverse.  The stream and its events belong
-// to the library (one set per device, created on first use); work on the side queue only ever touches workspace buffers whose
+// to the library (one set per device and main queue, created on first use); work on the side queue only ever touches workspace buffers whose
 // next reader on the main queue sits behind the join.
 #define PC_FORK_EVENTS 3
 struct PcFork { hipStream_t side; hipEvent_t fork[PC_FORK_EVENTS]; hipEvent_t join[PC_FORK_EVENTS]; int pending; };
-PcFork* pc_fork_get();                                       // null: no side queue (creation failed): everything stays on the main queue
+PcFork* pc_fork_get(hipStream_t main_st);                    // null: no side queue (creation failed): everything stays on the main queue
 int pc_fork_begin(PcFork* f, int i, hipStream_t main_st);    // the side queue continues behind everything enqueued on main so far
 int pc_fork_mark(PcFork* f, int i);                          // a point on the side queue ...
 int pc_fork_wait(PcFork* f, int i, hipStream_t main_st);     // ... behind which main continues (the side queue may go on)

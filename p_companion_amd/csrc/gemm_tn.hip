@@ -10,6 +10,7 @@
 // 32 lanes), staged [32 rows][128] in LDS and consumed by v_mfma_f32_32x32x2_f32 with the
 // ROW index as the MFMA k: lane l reads element [k0 + (l>>5)][tile + (l&31)] -- 32
 // consecutive floats per half-wave, conflict-free ds_read_b32.
+#include <mutex>
 #include "common.h"
 
 #define TM 128
@@ -589,22 +590,33 @@ int launch_gemm_tn(const TnArgs& a, hipStream_t st, TnDefer* defer) {
     return pc_launch_status();
 }
 
-PcFork* pc_fork_get() {
-    static PcFork forks[16];
-    static int state[16];                                        // 0 = not tried, 1 = ready, -1 = unavailable
-    int dev = 0;
+// One side queue per (device, main queue): two host threads stepping two models on two streams of one device each get their
+// own.  A small fixed table; when it is full (or creation fails) the caller gets null and stays on its main queue.
+PcFork* pc_fork_get(hipStream_t main_st) {
+    struct Slot { int dev; hipStream_t main_st; int state; PcFork f; };      // state: 0 free, 1 ready, -1 unavailable
+    static Slot slots[32];
+    static std::mutex mu;
     static const bool off = getenv("PC_NO_FORK") != nullptr;     // (A/B measurement: everything on the main queue)
-    if (off || hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return nullptr;
-    if (state[dev] == 0) {
-        PcFork& f = forks[dev];
+    int dev = 0;
+    if (off || hipGetDevice(&dev) != hipSuccess) return nullptr;
+    std::lock_guard<std::mutex> lock(mu);
+    Slot* s = nullptr;
+    for (Slot& c : slots) {
+        if (c.state != 0 && c.dev == dev && c.main_st == main_st) { s = &c; break; }
+        if (c.state == 0 && !s) s = &c;
+    }
+    if (!s) return nullptr;
+    if (s->state == 0) {
+        s->dev = dev; s->main_st = main_st;
+        PcFork& f = s->f;
         bool ok = hipStreamCreateWithFlags(&f.side, hipStreamNonBlocking) == hipSuccess;
         for (int i = 0; ok && i < PC_FORK_EVENTS; i++)
             ok = hipEventCreateWithFlags(&f.fork[i], hipEventDisableTiming) == hipSuccess &&
                  hipEventCreateWithFlags(&f.join[i], hipEventDisableTiming) == hipSuccess;
         f.pending = 0;
-        state[dev] = ok ? 1 : -1;
+        s->state = ok ? 1 : -1;
     }
-    return state[dev] == 1 ? &forks[dev] : nullptr;
+    return s->state == 1 ? &s->f : nullptr;
 }
 int pc_fork_begin(PcFork* f, int i, hipStream_t main_st) {
     PC_HIP_TRY(hipEventRecord(f->fork[i], main_st));

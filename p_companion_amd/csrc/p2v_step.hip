@@ -230,7 +230,7 @@ static int p2v_step_impl(const pc_p2v_tensors* p, const pc_p2v_tensors* g, const
     // one launch at the end of the call
     TnDefer df;
     tn_defer_init(&df);
-    if (phase == -1) df.fork = pc_fork_get();              // (the unsplit step: two small launches leave the main queue, common.h PcFork)
+    if (phase == -1) df.fork = pc_fork_get(st);              // (the unsplit step: two small launches leave the main queue, common.h PcFork)
     if (N > 0) {
         PC_TRY(attention_backward_impl(p, g, w.y + (size_t)rA * D, w.y + (size_t)rN * D, B, N, nbc, slot_row,
                                        slot_row ? nbc - 1 : -1, w.demb, &as, w.dy + (size_t)rA * D,
