@@ -599,6 +599,8 @@ PcFork* pc_fork_get(hipStream_t main_st) {
     static const bool off = getenv("PC_NO_FORK") != nullptr;     // (A/B measurement: everything on the main queue)
     int dev = 0;
     if (off || hipGetDevice(&dev) != hipSuccess) return nullptr;
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;     // a stream being captured into a graph keeps the step on itself
+    if (hipStreamIsCapturing(main_st, &cap) != hipSuccess || cap != hipStreamCaptureStatusNone) return nullptr;
     std::lock_guard<std::mutex> lock(mu);
     Slot* s = nullptr;
     for (Slot& c : slots) {

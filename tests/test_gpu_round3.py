@@ -417,3 +417,31 @@ def test_side_queue_fork_changes_no_bit():
         assert r.returncode == 0, r.stderr[-2000:]
         outs.append([l for l in r.stdout.splitlines() if l.startswith("digest")][-1])
     assert outs[0] == outs[1] == outs[2]
+
+
+def test_fused_p2v_step_under_stream_capture_stays_on_one_queue():
+    """A stream that is being captured keeps the fused step on itself (no side queue inside a capture): the captured step,
+    replayed, gives the eager step's loss and gradients bit for bit."""
+    from p_companion_amd.data import SimilarityIndexLoader, generate_scaled_bpg
+    from p_companion_amd.product2vec import Product2Vec
+    bpg = generate_scaled_bpg(20_000, 100, seed=4)
+    table = bpg.cuda()["features"]
+    torch.manual_seed(0)
+    m = Product2Vec(cfg()).to("cuda").train()
+    b = next(iter(SimilarityIndexLoader(bpg, 512, seed=1, drop_last=True, device="cuda")))
+    loss_e = m.train_step_indexed(table, b).clone()
+    grad_e = m.flatten_parameters()[1].clone()
+    m.ffn[1].running_mean.zero_(); m.ffn[1].running_var.fill_(1.0); m.ffn[1].num_batches_tracked.zero_()
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.stream(side):
+        m.train_step_indexed(table, b)                            # (workspaces for this stream exist before the capture)
+        m.ffn[1].running_mean.zero_(); m.ffn[1].running_var.fill_(1.0); m.ffn[1].num_batches_tracked.zero_()
+        with torch.cuda.graph(g, stream=side):
+            loss_c = m.train_step_indexed(table, b)
+    torch.cuda.current_stream().wait_stream(side)
+    m.flatten_parameters()[1].zero_()
+    g.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(loss_c, loss_e) and torch.equal(m.flatten_parameters()[1], grad_e)
