@@ -506,7 +506,7 @@ extern "C" int pc_debug_chain_timing(unsigned long long* out, int reset) {
 // step): the product is a few hundred MFLOP and the persistent kernel's K pipeline is pure latency
 // (4 dependent stage round trips for K = 128).  Here a 4-wave workgroup owns 32 rows x up to 128
 // columns, requests the WHOLE K extent of its A rows and of W in one burst of LDS-DMA, waits once,
-// and each wave multiplies its 32x32 block.  K <= 128, N <= 128; no prologue / statistics.
+// and each wave multiplies its 32x32 block.  K <= 128 (256: two bursts), N <= 128; no prologue / statistics.
 // Stage rows are KS = 32/64/128 floats (K rounded up), chunks XOR-swizzled as above.
 // (EPI: a compile-time constant in the single-product kernel, the member's own value in the grouped one -- the
 // kernel is latency-bound, a uniform switch per element costs nothing)
@@ -519,29 +519,11 @@ __device__ __forceinline__ void nt_small_body(const NtArgs& a, int ks_log2, int 
     const int row0 = a.seg.start[sg] + (tile - a.seg.tile0[sg]) * 32, row_end = a.seg.start[sg + 1];
     auto swz = [&](int r) { return KS == 32 ? (r >> 1) & 7 : r & 15; };
 
-    // ---- one burst: stage rows [0,32) = A rows of the tile, [32,160) = W rows; 1 KB per wave instruction
+    // ---- one burst per 128 k's (K <= 128: one): stage rows [0,32) = A rows of the tile, [32,160) = W rows; 1 KB per wave
+    // instruction.  K in (128, 256] -- the per-head products of the attention block at D = 256 -- runs two bursts over the same
+    // stage, the accumulators carry over
     const int rows_per_instr = 256 >> ks_log2, ninstr = (160 * KS) >> 8;
     const unsigned lds0 = (unsigned)(uintptr_t)(lptr_t)&sm_small[0];
-    for (int g = w; g < ninstr; g += 4) {
-        const int r = g * rows_per_instr + lane / CPR;           // stage row
-        const int chunk = (lane % CPR) ^ swz(r);
-        const float* p = pc_zero_chunk;
-        if (chunk * 4 < a.K) {
-            if (r < 32) {
-                const int gr = row0 + r;
-                const int srow = gr < row_end ? (a.gather ? a.gather[gr] : gr) : -1;
-                if (srow >= 0) p = a.A + (size_t)srow * a.lda + chunk * 4;
-            } else if (r - 32 < a.N) {
-                p = a.W + (size_t)(r - 32) * a.ldw + chunk * 4;
-            }
-        }
-        dma16(p, lds0 + g * 1024);
-    }
-    PC_CT();
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    PC_CT();
-
     f32x16 acc;
 #pragma unroll
     for (int r = 0; r < 16; r++) acc[r] = 0.f;
@@ -549,15 +531,38 @@ __device__ __forceinline__ void nt_small_body(const NtArgs& a, int ks_log2, int 
     const float* As = sm_small + fr * KS;
     const float* Ws = sm_small + (32 + w * 32 + fr) * KS;
     const int sa = swz(fr), sw = swz(32 + w * 32 + fr);
-    const int nkk = (a.K + 7) >> 3;
-    for (int kk = 0; kk < nkk; kk++) {
-        const int c = 2 * kk + fh;
-        const float4 fa4 = *reinterpret_cast<const float4*>(&As[(c ^ sa) << 2]);
-        const float4 fb4 = *reinterpret_cast<const float4*>(&Ws[(c ^ sw) << 2]);
-        acc = mfma32(fa4.x, fb4.x, acc);
-        acc = mfma32(fa4.y, fb4.y, acc);
-        acc = mfma32(fa4.z, fb4.z, acc);
-        acc = mfma32(fa4.w, fb4.w, acc);
+    for (int k0 = 0; k0 < a.K; k0 += 128) {
+        if (k0) __syncthreads();                                 // every wave is past its reads of the previous 128 k's
+        for (int g = w; g < ninstr; g += 4) {
+            const int r = g * rows_per_instr + lane / CPR;       // stage row
+            const int chunk = (lane % CPR) ^ swz(r);
+            const float* p = pc_zero_chunk;
+            if (k0 + chunk * 4 < a.K) {
+                if (r < 32) {
+                    const int gr = row0 + r;
+                    const int srow = gr < row_end ? (a.gather ? a.gather[gr] : gr) : -1;
+                    if (srow >= 0) p = a.A + (size_t)srow * a.lda + k0 + chunk * 4;
+                } else if (r - 32 < a.N) {
+                    p = a.W + (size_t)(r - 32) * a.ldw + k0 + chunk * 4;
+                }
+            }
+            dma16(p, lds0 + g * 1024);
+        }
+        PC_CT();
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        PC_CT();
+        const int kleft = a.K - k0;
+        const int nkk = ((kleft < 128 ? kleft : 128) + 7) >> 3;
+        for (int kk = 0; kk < nkk; kk++) {
+            const int c = 2 * kk + fh;
+            const float4 fa4 = *reinterpret_cast<const float4*>(&As[(c ^ sa) << 2]);
+            const float4 fb4 = *reinterpret_cast<const float4*>(&Ws[(c ^ sw) << 2]);
+            acc = mfma32(fa4.x, fb4.x, acc);
+            acc = mfma32(fa4.y, fb4.y, acc);
+            acc = mfma32(fa4.z, fb4.z, acc);
+            acc = mfma32(fa4.w, fb4.w, acc);
+        }
     }
     __syncthreads();                                             // the stage becomes the epilogue patches
     PC_CT();
@@ -845,9 +850,9 @@ static void launch_variant(const NtArgs& a, int ntm, hipStream_t st) {
         // N <= 128: 128x128 tiles, 4 waves, three workgroups per CU
         PC_LAUNCH((gemm_nt_kernel<2, 2, 16, 3, false, EPI, NT_STAT_NONE>), dim3(ntm < 768 ? ntm : 768), dim3(256), 0, st, a,
                   1, ntm);
-    } else if (a.K <= 128 && (EPI == NT_EPI_NONE || EPI == NT_EPI_TANH || EPI == NT_EPI_RELU || EPI == NT_EPI_DTANH ||
+    } else if (a.K <= 256 && (EPI == NT_EPI_NONE || EPI == NT_EPI_TANH || EPI == NT_EPI_RELU || EPI == NT_EPI_DTANH ||
                               EPI == NT_EPI_DRELU)) {
-        // few rows, short K: one LDS-DMA burst per 32-row tile, no K pipeline
+        // few rows, short K: one LDS-DMA burst per 32-row tile and 128 k's, no K pipeline
         NtArgs b = a;
         b.seg = retile(a.seg, 32);
         const int total = gemm_nt_tiles(b.seg);
@@ -909,7 +914,7 @@ static bool nt_small_ok(const NtArgs& a) {
     if (a.K % 4 != 0 || a.lda % 4 != 0 || a.ldw % 4 != 0) return false;
     if (((uintptr_t)a.A | (uintptr_t)a.W | (uintptr_t)a.C) & 15) return false;
     if (a.aux && ((uintptr_t)a.aux & 15)) return false;
-    if (a.prologue != NT_PRO_NONE || a.stats != NT_STAT_NONE || a.N > 128 || a.K > 128) return false;
+    if (a.prologue != NT_PRO_NONE || a.stats != NT_STAT_NONE || a.N > 128 || a.K > 256) return false;   // (K > 128: two bursts)
     const int e = a.epilogue;
     if (!(e == NT_EPI_NONE || e == NT_EPI_TANH || e == NT_EPI_RELU || e == NT_EPI_DTANH || e == NT_EPI_DRELU)) return false;
     if ((e == NT_EPI_DTANH || e == NT_EPI_DRELU) && (!a.aux || a.bias)) return false;
