@@ -346,7 +346,8 @@ __global__ __launch_bounds__(64 * NWM * NWN, WPS) void gemm_nt_kernel(NtArgs a, 
         // aux operand (d-activation epilogues): ADEPTH half-patches are in flight ahead of the one being
         // finished -- with two loads per lane and half-patch the wave would otherwise pay one full
         // memory latency per half-patch (measured: 19 us of a 32 us tile)
-        constexpr int ADEPTH = HAS_AUX ? 4 : 1;
+        // (three with the statistics epilogue: the fourth pair of aux registers was what spilled there -- 8 B of scratch)
+        constexpr int ADEPTH = HAS_AUX ? (STATS != NT_STAT_NONE ? 3 : 4) : 1;
         const bool fast = vec && n0 + BN <= a.N;                 // whole tile inside N: unpredicated 16-B accesses
         float4 xq[ADEPTH][2];
         auto aux_load = [&](int h, float4 (&x4)[2]) {
