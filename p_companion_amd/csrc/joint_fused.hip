@@ -833,6 +833,24 @@ static size_t tile_lds_bytes(int T, bool sims_local, bool tables) {
 //   type_topk_merge_kernel per listed query type: best K of its chunks' candidates -> topk_by_type[type][K]
 #define TC 320        /* types per chunk: 109 chunks x 2 tiles of listed query types = 218 workgroups at T = 34800: one round of the chip */
 #define UT 64
+// inclusive prefix sum over the 1024 threads of a workgroup: shuffles inside each wave, the 16 wave totals through LDS -- two
+// barriers (the Hillis-Steele form over LDS this replaces took twenty: 3 us of a 10 us single-workgroup kernel)
+__device__ __forceinline__ int block_scan_1024(int v, unsigned* wsum /* [16] LDS */) {
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const int u = __shfl_up(v, o, 64);
+        if (lane >= o) v += u;
+    }
+    __syncthreads();                                    // (wsum may still be read from a previous call)
+    if (lane == 63) wsum[w] = (unsigned)v;
+    __syncthreads();
+    int base = 0;
+#pragma unroll
+    for (int i = 0; i < 16; i++) base += i < w ? (int)wsum[i] : 0;
+    return v + base;
+}
+
 // pairs (optional): the batch is not built yet -- the query type of sample b is type_idx[pairs[3 b]] (data_loader.py:146)
 __global__ __launch_bounds__(1024) void present_types_kernel(const int32_t* query_types, int B, int T, int32_t* ulist,
                                                              int32_t* n_u, const int32_t* pairs, const int32_t* type_idx,
@@ -863,15 +881,8 @@ __global__ __launch_bounds__(1024) void present_types_kernel(const int32_t* quer
     const int lo = threadIdx.x * per, hi = min(words, lo + per);
     int cnt = 0;
     for (int i = lo; i < hi; i++) cnt += __popc(bits[i]);
-    part[threadIdx.x] = cnt;
-    __syncthreads();
-    for (int o = 1; o < 1024; o <<= 1) {
-        const unsigned v = threadIdx.x >= (unsigned)o ? part[threadIdx.x - o] : 0u;
-        __syncthreads();
-        part[threadIdx.x] += v;
-        __syncthreads();
-    }
-    int pos = (int)part[threadIdx.x] - cnt;
+    const int incl = block_scan_1024(cnt, part);
+    int pos = incl - cnt;
     for (int i = lo; i < hi; i++) {
         unsigned m = bits[i];
         while (m) {
@@ -880,7 +891,7 @@ __global__ __launch_bounds__(1024) void present_types_kernel(const int32_t* quer
             ulist[pos++] = 32 * i + bit;
         }
     }
-    if (threadIdx.x == 1023) *n_u = (int)part[1023];
+    if (threadIdx.x == 1023) *n_u = incl;
 }
 
 struct TypeSimsArgs {
@@ -1424,15 +1435,8 @@ __global__ __launch_bounds__(1024) void touched_types_kernel(const int32_t* idx_
         const int lo = threadIdx.x * per, hi = min(words, lo + per);
         int cnt = 0;
         for (int i = lo; i < hi; i++) cnt += __popc(bits[i]);
-        part[threadIdx.x] = cnt;
-        __syncthreads();
-        for (int o = 1; o < 1024; o <<= 1) {
-            const unsigned v = threadIdx.x >= (unsigned)o ? part[threadIdx.x - o] : 0u;
-            __syncthreads();
-            part[threadIdx.x] += v;
-            __syncthreads();
-        }
-        int p = (int)part[threadIdx.x] - cnt;
+        const int incl = block_scan_1024(cnt, part);
+        int p = incl - cnt;
         for (int i = lo; i < hi; i++) {
             unsigned m = bits[i];
             while (m) {
@@ -1442,7 +1446,7 @@ __global__ __launch_bounds__(1024) void touched_types_kernel(const int32_t* idx_
                 ulist[p++] = 32 * i + bit;
             }
         }
-        if (threadIdx.x == 1023) n_touch[li] = (int)part[1023];
+        if (threadIdx.x == 1023) n_touch[li] = incl;
     }
 }
 
