@@ -174,6 +174,72 @@ static void run(const float* in, float* out, unsigned long long* cyc, int iters,
            cus, MODE, WPS, best / iters, ms, tflops, ms * 1e3 / iters * 16);
 }
 
+// ---- a 64 x 128 wave tile (2 x 4 blocks): six operand splits per eight block products instead of eight (the stage holds 128 A
+// rows and 256 W rows; four waves as 2 x 2 own a 128 x 256 output tile).  Same reads-then-MFMAs order as mode 0.
+template <int WPS>
+__global__ __launch_bounds__(256, WPS) void kern_wide(const float* in, float* out, int iters, unsigned long long* cyc) {
+    __shared__ __attribute__((aligned(1024))) float stage[2][384 * BK];
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, wm = w & 1, wn = w >> 1;
+    for (int i = tid; i < 2 * 384 * BK; i += 256) (&stage[0][0])[i] = in[i % (2 * 256 * BK)];
+    __syncthreads();
+    f32x16 acc[2][4];
+#pragma unroll
+    for (int i = 0; i < 2; i++)
+#pragma unroll
+        for (int j = 0; j < 4; j++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) acc[i][j][r] = 0.f;
+    const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+    const int fr = lane & 31, gsw = (fr / 4) % 4;
+    const int c0 = ((2 * (lane >> 5)) ^ gsw) << 2, c1 = ((2 * (lane >> 5) + 1) ^ gsw) << 2;
+    for (int it = 0; it < iters; it++) {
+        const float* st = stage[it & 1];
+        const float* ar = st + (wm * 64 + fr) * BK;
+        const float* br = st + (128 + wn * 128 + fr) * BK;
+        Split3 sa[2];
+#pragma unroll
+        for (int i = 0; i < 2; i++) {
+            const float4 lo = *reinterpret_cast<const float4*>(ar + i * 32 * BK + c0), hi = *reinterpret_cast<const float4*>(ar + i * 32 * BK + c1);
+            sa[i] = split3(lo, hi);
+        }
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const float4 lo = *reinterpret_cast<const float4*>(br + j * 32 * BK + c0), hi = *reinterpret_cast<const float4*>(br + j * 32 * BK + c1);
+            const Split3 sb = split3(lo, hi);
+#define T(PA, PB) acc[0][j] = mfma_bf16(sa[0].PA, sb.PB, acc[0][j]); acc[1][j] = mfma_bf16(sa[1].PA, sb.PB, acc[1][j]);
+            T(p2, p0) T(p0, p2) T(p1, p1) T(p1, p0) T(p0, p1) T(p0, p0)
+#undef T
+        }
+    }
+    const unsigned long long t1 = __builtin_amdgcn_s_memtime();
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < 2; i++)
+#pragma unroll
+        for (int j = 0; j < 4; j++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) s += acc[i][j][r];
+    out[blockIdx.x * 256 + tid] = s;
+    if (tid == 0) cyc[blockIdx.x] = t1 - t0;
+}
+
+template <int WPS>
+static void run_wide(const float* in, float* out, unsigned long long* cyc, int iters) {
+    const int grid = 256 * WPS;
+    float ms = 0.f;
+    hipEvent_t e0, e1;
+    hipEventCreate(&e0); hipEventCreate(&e1);
+    for (int rep = 0; rep < 3; rep++) {
+        hipEventRecord(e0);
+        hipLaunchKernelGGL((kern_wide<WPS>), dim3(grid), dim3(256), 0, 0, in, out, iters, cyc);
+        hipEventRecord(e1);
+        hipEventSynchronize(e1);
+        hipEventElapsedTime(&ms, e0, e1);
+    }
+    const double tflops = 2.0 * 128 * 256 * BK * (double)iters * grid / (ms * 1e-3) / 1e12;
+    printf("64x128 wave tiles (6 splits per 48 MFMAs)  waves/SIMD %d  %7.3f ms  %6.1f TFLOP/s-equivalent (fp32-grade)\n", WPS, ms, tflops);
+}
+
 int main() {
     float *in, *out;
     unsigned long long* cyc;
@@ -201,6 +267,8 @@ int main() {
     run<6, 1>(in, out, cyc, iters);
     run<7, 3>(in, out, cyc, iters);
     run<7, 1>(in, out, cyc, iters);
+    run_wide<2>(in, out, cyc, iters);
+    run_wide<1>(in, out, cyc, iters);
     // chip-wide budget or per-CU limit?  One workgroup per CU, the MFMAs alone, on every CU / on every second / fourth CU's worth
     run<6, 1>(in, out, cyc, iters, 256, 2);
     run<6, 1>(in, out, cyc, iters, 256, 4);
