@@ -459,6 +459,12 @@ def run_p2v(args, rank, world, dev, products, steps, warmup, want_cpu, profile_k
                            "reference_equivalent_flops_per_triplet": flops_per_triplet(round(n_avg), dim),
                            "gather_bytes_per_triplet": bytes_per_triplet(round(n_avg), dim),
                            "frac_hbm_gather": round(bytes_per_triplet(n_avg, dim) * value / world / 1e9 / HBM_PEAK_GBS, 5)}}
+    if want_cpu and last is not None:
+        # `last` is a set of views into one slot of the loader's buffer ring (reuse_buffers=True); the sustained leg below
+        # rebuilds that slot many times over, with other row counts.  The CPU baseline is timed on THIS batch: keep a copy.
+        cl = lambda v: v.clone() if torch.is_tensor(v) else v
+        last = {k: ({kk: (int(vv) if kk == "n_unique" else cl(vv)) for kk, vv in v.items()} if isinstance(v, dict) else cl(v))
+                for k, v in last.items()}
     if sustained:
         # The driver's flags make the headline region short (20 steps = 22 ms) and it never crosses a loader epoch boundary
         # (every 67 steps).  This leg is the same loop, un-bracketed, over >= 300 steps after >= 20 warm-up steps, three

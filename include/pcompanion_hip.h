@@ -10,11 +10,30 @@
  * Conventions:
  *   - raw DEVICE pointers + explicit sizes; fp32 data, int32 indices, row-major, dense;
  *   - `stream` is a hipStream_t passed as void* (the caller's current stream); every call
- *     is asynchronous w.r.t. the host and never synchronises, allocates or frees;
+ *     is asynchronous w.r.t. the host and never synchronises, allocates or frees DEVICE MEMORY;
  *   - caller-allocated outputs and workspace (pc_*_workspace_bytes queries);
  *   - return: 0 ok, <0 invalid argument (PC_E*), >0 a hipError_t; nothing throws;
- *   - no global mutable state: re-entrant across streams and devices.
+ *   - re-entrant across host threads, streams and devices: two threads may step two models on two
+ *     streams of one device concurrently (tests/test_gpu_round4.py runs exactly that, bit-equal to serial).
  *   Exceptions are the two host-side helpers (pc_mt_*), which take HOST pointers.
+ *
+ * Library-owned device state (the ONE exception to "no global state"; ABI 5 states what ABI 4 did silently):
+ *   the unsplit fused Product2Vec step -- pc_p2v_train_step, pc_p2v_train_step_compact, and
+ *   pc_p2v_train_step_unique with phase = -1 -- moves three small launches that nothing on `stream` waits
+ *   for until later in the step (the attention block's dq chain and its ten few-row weight gradients, the
+ *   BatchNorm-backward finalize) onto a SIDE QUEUE: one non-blocking hipStream_t + six timing-disabled
+ *   hipEvent_t per (device, calling stream), created on the first such call on that stream (a process-wide
+ *   table of 32 entries behind a mutex; when it is full, or creation fails, the step stays on `stream`).
+ *   Fork and join are events: when the call returns, everything it enqueued -- on either queue -- is ordered
+ *   before whatever the caller enqueues on `stream` next, so a caller that synchronises `stream` or records an
+ *   event on it sees no difference; results are bit-identical either way (tested).  On an error return the
+ *   side queue is joined into `stream` first (no work is left behind that could outlive the caller's buffers).
+ *   Not used: on a stream that is being captured into a graph; by any other entry point; when switched off.
+ *     pc_set_option(PC_OPT_SIDE_QUEUE, 0 / 1)   process-wide switch (default 1); takes effect at the next step
+ *     pc_release_device_state()                 destroys every side queue and its events (call with no pc_*
+ *                                               call in flight and the streams drained, e.g. before
+ *                                               hipDeviceReset or at interpreter exit); they are re-created on demand
+ *   No environment variable is read anywhere in the library.
  */
 #ifndef PCOMPANION_HIP_H
 #define PCOMPANION_HIP_H
@@ -43,8 +62,18 @@ extern "C" {
 
 /* 3: pc_ffn_saved gained the optional `a1` member (round 2; a caller built against version 2 passes a shorter struct);
  * 2: pc_p2v_tensors / pc_joint_tensors gained `dropout` (and `dim`). */
-#define PC_ABI_VERSION 4
+/* 5: pc_set_option / pc_get_option / pc_release_device_state (the side queue of the fused Product2Vec step is part of the
+ *    contract; the PC_NO_FORK environment variable of version 4 is gone). */
+#define PC_ABI_VERSION 5
 int pc_abi_version(void);
+/* Process-wide options.  PC_OPT_SIDE_QUEUE: 1 (default) = the unsplit fused Product2Vec step may use its side queue
+ * (see "Library-owned device state" above), 0 = every launch stays on the caller's stream.  Unknown option / value:
+ * PC_EINVAL.  Thread-safe. */
+enum { PC_OPT_SIDE_QUEUE = 1 };
+int pc_set_option(int option, int value);
+int pc_get_option(int option, int* value);
+/* Destroys the library-owned device state (side queues and their events) of every device; 0 or a hipError_t. */
+int pc_release_device_state(void);
 /* Bitmask of the developer knobs this library was compiled with (0 = a production build).  PC_FLAG_EXP_*: a part of a
  * GEMM loop is compiled out to price it (scripts/dev/nt_decompose.sh) -- WRONG numbers by design; *_TIMING: in-kernel
  * clock reads.  Checked by tests/test_abi.py and __graft_entry__.build(). */

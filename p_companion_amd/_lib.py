@@ -61,11 +61,16 @@ _vp, _i, _sz, _f, _d, _u64, _i64 = (ctypes.c_void_p, ctypes.c_int, ctypes.c_size
                                     ctypes.c_double, ctypes.c_uint64, ctypes.c_int64)
 _P = ctypes.POINTER
 
+PC_OPT_SIDE_QUEUE = 1      # pc_set_option: the fused Product2Vec step's side queue (include/pcompanion_hip.h)
+
 # name -> (restype, argtypes).  Must list every symbol include/pcompanion_hip.h declares
 # (tests/test_abi.py parses the header and checks this table and the .so against it).
 SIGNATURES = {
     "pc_abi_version": (_i, []),
     "pc_build_flags": (ctypes.c_uint, []),
+    "pc_set_option": (_i, [_i, _i]),
+    "pc_get_option": (_i, [_i, ctypes.POINTER(ctypes.c_int)]),
+    "pc_release_device_state": (_i, []),
     "pc_p2v_ffn_workspace_bytes": (_sz, [_i]),
     "pc_p2v_ffn_forward_train": (_i, [_P(P2VTensors), _vp, _vp, _i, _P(Segments), _i, _vp, _P(FfnSaved), _vp, _sz, _vp]),
     "pc_p2v_ffn_forward_eval": (_i, [_P(P2VTensors), _vp, _vp, _i, _vp, _vp, _sz, _vp]),

@@ -10,6 +10,7 @@
 // 32 lanes), staged [32 rows][128] in LDS and consumed by v_mfma_f32_32x32x2_f32 with the
 // ROW index as the MFMA k: lane l reads element [k0 + (l>>5)][tile + (l&31)] -- 32
 // consecutive floats per half-wave, conflict-free ds_read_b32.
+#include <atomic>
 #include <mutex>
 #include "common.h"
 
@@ -592,18 +593,50 @@ int launch_gemm_tn(const TnArgs& a, hipStream_t st, TnDefer* defer) {
 
 // One side queue per (device, main queue): two host threads stepping two models on two streams of one device each get their
 // own.  A small fixed table; when it is full (or creation fails) the caller gets null and stays on its main queue.
+// This table is the library's ONLY device state (include/pcompanion_hip.h "Library-owned device state"): created lazily by
+// the unsplit fused Product2Vec step while PC_OPT_SIDE_QUEUE is on, destroyed by pc_release_device_state().
+namespace {
+struct ForkSlot { int dev; hipStream_t main_st; int state; PcFork f; };      // state: 0 free, 1 ready, -1 unavailable
+ForkSlot g_fork_slots[32];
+std::mutex g_fork_mu;
+std::atomic<int> g_opt_side_queue{1};
+}
+
+extern "C" int pc_set_option(int option, int value) {
+    if (option != PC_OPT_SIDE_QUEUE || (value != 0 && value != 1)) return PC_EINVAL;
+    g_opt_side_queue.store(value, std::memory_order_relaxed);
+    return PC_OK;
+}
+extern "C" int pc_get_option(int option, int* value) {
+    if (option != PC_OPT_SIDE_QUEUE || !value) return PC_EINVAL;
+    *value = g_opt_side_queue.load(std::memory_order_relaxed);
+    return PC_OK;
+}
+extern "C" int pc_release_device_state(void) {
+    std::lock_guard<std::mutex> lock(g_fork_mu);
+    int cur = 0, rc = PC_OK;
+    const bool have_cur = hipGetDevice(&cur) == hipSuccess;
+    for (ForkSlot& c : g_fork_slots) {
+        if (c.state == 1) {
+            if (hipSetDevice(c.dev) != hipSuccess) { rc = (int)hipErrorInvalidDevice; continue; }
+            (void)hipStreamSynchronize(c.f.side);                 // (nothing is pending between two steps: returns at once)
+            for (int i = 0; i < PC_FORK_EVENTS; i++) { (void)hipEventDestroy(c.f.fork[i]); (void)hipEventDestroy(c.f.join[i]); }
+            (void)hipStreamDestroy(c.f.side);
+        }
+        c = ForkSlot{};
+    }
+    if (have_cur) (void)hipSetDevice(cur);
+    return rc;
+}
+
 PcFork* pc_fork_get(hipStream_t main_st) {
-    struct Slot { int dev; hipStream_t main_st; int state; PcFork f; };      // state: 0 free, 1 ready, -1 unavailable
-    static Slot slots[32];
-    static std::mutex mu;
-    static const bool off = getenv("PC_NO_FORK") != nullptr;     // (A/B measurement: everything on the main queue)
     int dev = 0;
-    if (off || hipGetDevice(&dev) != hipSuccess) return nullptr;
+    if (!g_opt_side_queue.load(std::memory_order_relaxed) || hipGetDevice(&dev) != hipSuccess) return nullptr;
     hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;     // a stream being captured into a graph keeps the step on itself
     if (hipStreamIsCapturing(main_st, &cap) != hipSuccess || cap != hipStreamCaptureStatusNone) return nullptr;
-    std::lock_guard<std::mutex> lock(mu);
-    Slot* s = nullptr;
-    for (Slot& c : slots) {
+    std::lock_guard<std::mutex> lock(g_fork_mu);
+    ForkSlot* s = nullptr;
+    for (ForkSlot& c : g_fork_slots) {
         if (c.state != 0 && c.dev == dev && c.main_st == main_st) { s = &c; break; }
         if (c.state == 0 && !s) s = &c;
     }

@@ -231,6 +231,13 @@ static int p2v_step_impl(const pc_p2v_tensors* p, const pc_p2v_tensors* g, const
     TnDefer df;
     tn_defer_init(&df);
     if (phase == -1) df.fork = pc_fork_get(st);              // (the unsplit step: two small launches leave the main queue, common.h PcFork)
+    // an error return below must not leave work on the side queue that nothing orders before the caller's next use (or
+    // free) of the workspace and gradient buffers: join it into the main queue on the way out (a no-op after the normal
+    // end of the step, whose reduce launch has joined already)
+    struct ForkGuard {
+        PcFork* f; hipStream_t st;
+        ~ForkGuard() { if (f && f->pending) (void)pc_fork_join(f, 1, st); }
+    } fork_guard{df.fork, st};
     if (N > 0) {
         PC_TRY(attention_backward_impl(p, g, w.y + (size_t)rA * D, w.y + (size_t)rN * D, B, N, nbc, slot_row,
                                        slot_row ? nbc - 1 : -1, w.demb, &as, w.dy + (size_t)rA * D,

@@ -14,7 +14,7 @@ __device__ __forceinline__ void pairs_negatives_body(const int32_t* pair_ids, in
                                                      int32_t* positive_idx, int32_t* negative_idx, int b) {
     if (b >= B) return;
     const int pid = pair_ids[b];
-    const int a = sim_pairs[2 * pid], pos = sim_pairs[2 * pid + 1];
+    const int a = sim_pairs[2 * (size_t)pid], pos = sim_pairs[2 * (size_t)pid + 1];      // (pair counts reach 2^30 at 100 M+ products)
     anchor_idx[b] = a;
     positive_idx[b] = pos;
     const int lo = sim_rowptr[a], hi = sim_rowptr[a + 1];
@@ -163,7 +163,7 @@ __global__ __launch_bounds__(128) void uq_pairs_count_kernel(const int32_t* pair
         const int t = t0 + u;
         if (t >= B * n_pad) return;
         const int b = t / n_pad, j = t % n_pad;
-        const int a = sim_pairs[2 * pair_ids[b]];
+        const int a = sim_pairs[2 * (size_t)pair_ids[b]];
         const int lo = cv_rowptr[a], deg = min(cv_rowptr[a + 1] - lo, n_pad);
         if (j < deg) atomicAdd(&cnt[cv_col[lo + j]], 1);
     }
@@ -343,7 +343,7 @@ __global__ void zipf_negatives_kernel(const int32_t* pair_ids, int B, const int3
                                       int32_t* negative_idx, int32_t* failed) {
     const int b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= B) return;
-    const int a = sim_pairs[2 * pair_ids[b]];
+    const int a = sim_pairs[2 * (size_t)pair_ids[b]];
     const int lo = sim_rowptr[a], hi = sim_rowptr[a + 1];
     Philox rng(seed ^ 0x5a495046ull, step, (uint32_t)b);          // its own stream ("ZIPF"), apart from the uniform sampler's
     int got = 0;
@@ -522,7 +522,8 @@ __global__ __launch_bounds__(256) void epoch_plan_kernel(const int32_t* order, c
     const int b = blockIdx.x;
     int mx = 0;
     long long sm = 0;
-    for (int i = b * B + threadIdx.x; i < (b + 1) * B && i < n; i += 256) {
+    const long long i_end = min((long long)(b + 1) * B, (long long)n);      // ((b + 1) * B overflows an int for n near 2^31)
+    for (long long i = (long long)b * B + threadIdx.x; i < i_end; i += 256) {
         const int d = deg[order ? order[i] : i];
         mx = max(mx, d);
         sm += d;

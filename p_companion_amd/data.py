@@ -250,8 +250,11 @@ class SimilarityIndexLoader:
         self.step = 0
         # reuse_buffers (training loops: train_model, bench.py): batches are built into a RING of preallocated buffers instead
         # of fresh tensors (ops.BatchBuffers: no allocation and, above all, no cross-stream free per step).  A batch handed out
-        # stays valid until RING - 2 further batches have been requested: a loop that consumes each batch before asking for
-        # the next may use it; code that keeps batches (tests collecting an epoch) must not.
+        # stays valid until RING - depth - RING_EVERY + 1 (= 9 with the defaults: the builder of hand-out j + RING is queued at
+        # hand-out j + RING - depth and waits only for the latest ring event, which may be RING_EVERY - 1 hand-outs old)
+        # further batches have been requested, PROVIDED it is consumed on the stream that is current when it is handed out
+        # (the ring's events are recorded there): a loop that consumes each batch before asking for the next may use it;
+        # code that keeps batches (tests collecting an epoch) must not.
         self.reuse_buffers = bool(reuse_buffers)
         self._ring, self._ring_done = None, None
         # negatives='zipf' (BASELINE configs[4]; an extension, the reference draws uniformly): P(rank) ~ 1 / rank over the
@@ -489,6 +492,9 @@ class SimilarityIndexLoader:
         # by the time the batch is asked for (the host runs about one step ahead of the device: one batch ahead, the event
         # was pending about every other time and the wait below cost the training stream a barrier packet per step)
         depth = max(1, int(getattr(self, "prefetch_depth", 4 if ring_ok else 2)))
+        if ring_ok and self.RING < depth + self.RING_EVERY:
+            raise ValueError(f"prefetch_depth = {depth}: the buffer ring ({self.RING} slots, one event per {self.RING_EVERY} hand-outs) "
+                             f"covers at most {self.RING - self.RING_EVERY} batches in flight")
         from collections import deque
         ahead = deque(launch(j) for j in range(min(depth, n)))
         for i in range(n):

@@ -1046,6 +1046,8 @@ def generate_catalogue(num_products, num_types, seed, mean_degree, degree_cap, d
     check(L.pc_gen_degrees(P, float(mean_degree), int(degree_cap), float(comp_mean), int(seed), _p(deg), _p(cand), _stream()),
           "pc_gen_degrees")
     cv_rowptr, n_edges = exclusive_scan_i32(deg)
+    # (offsets and ids are int32: exclusive_scan_i32 raises when a total reaches 2^31; the kernels index the two-int pair
+    # array with size_t, so pair counts up to that limit are safe -- 100 M products: 1.6e9 edges, 275 M pairs)
     cv_col, sim_count = i32(max(n_edges, 1)), i32(P)
     check(L.pc_gen_coview(P, int(num_types), int(seed), _p(cv_rowptr), _p(cv_col), _p(sim_count), _stream()), "pc_gen_coview")
     sim_rowptr, n_sim = exclusive_scan_i32(sim_count)

@@ -164,12 +164,20 @@ class FusedAdam(torch.optim.Optimizer):
             # (then the update is ONE launch, pc_adam_step_at); None once a fused step advanced the counter itself
             # (fused_state()) -- the two-launch form then reads the device counter
             self._host_step = 0
+            self._device_counter_only = False     # True once the device counter has been advanced behind the host's back
         return flat, gflat
 
     @torch.no_grad()
     def step(self, closure=None):
         flat, gflat = self._ensure()
         g = self.param_groups[0]
+        if self._host_step is not None and flat.is_cuda and torch.cuda.is_current_stream_capturing():
+            # a step that is being CAPTURED (GraphedJointStep mode 'graph' records optimizer.step() inside torch.cuda.graph)
+            # must not bake the host's step number into the graph as a kernel argument: every replay would run Adam with
+            # the capture-time bias corrections.  The device-counter form (pc_adam_step) is replay-safe; the host stops
+            # counting for good (replays advance the device counter without passing through here).
+            self._host_step = None
+            self._device_counter_only = True
         if self._host_step is not None:
             self._host_step += 1
             ops.adam_step_at(flat, gflat, self.exp_avg, self.exp_avg_sq, self.step_count, self._host_step, g["lr"],
@@ -188,6 +196,7 @@ class FusedAdam(torch.optim.Optimizer):
         the hyper-parameters.  The caller must NOT call step() for that iteration."""
         self._ensure()
         self._host_step = None                    # (the fused step advances the device counter: the host no longer knows it)
+        self._device_counter_only = True
         m, v, off = {}, {}, 0
         for name, p in self.module._named_flat():
             n = p.numel()
@@ -261,7 +270,9 @@ class FusedAdam(torch.optim.Optimizer):
             raise ValueError("FusedAdam keeps ONE step count for all parameters; the state holds %s" % sorted(steps))
         loaded = steps.pop() if steps else 0
         self.step_count.fill_(loaded)
-        self._host_step = loaded
+        # a prepared fused step (fused_state()) or a captured graph keeps advancing the DEVICE counter: the host's copy would
+        # drift from it after the next such step, so it stays out of the picture once that has happened
+        self._host_step = None if self._device_counter_only else loaded
 
 
 class _FlatParamsMixin:

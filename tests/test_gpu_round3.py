@@ -3,6 +3,8 @@ the epoch runner's error / hyper-parameter conventions, the fused joint step aga
 NUM_TYPES (config.py:27), and the absorbed attention's saved tensors.  Needs an MI355X."""
 from types import SimpleNamespace
 
+import ctypes
+
 import numpy as np
 import pytest
 import torch
@@ -372,9 +374,9 @@ def test_loader_buffer_ring_hands_out_the_same_batches(unique):
         assert torch.equal(p, q), k
 
 
-def _fork_worker():
-    """(subprocess body) 60 steps of the fused Product2Vec step through the throughput loader; prints a digest of the
-    parameters, the BatchNorm statistics and the losses."""
+def _fork_digest():
+    """60 steps of the fused Product2Vec step through the throughput loader -> a digest of the parameters, the BatchNorm
+    statistics and the losses."""
     import hashlib
     from p_companion_amd.data import SimilarityIndexLoader, generate_scaled_bpg
     from p_companion_amd.product2vec import FusedAdam, Product2Vec
@@ -395,27 +397,29 @@ def _fork_worker():
     torch.cuda.synchronize()
     h.update(m.flatten_parameters()[0].detach().cpu().numpy().tobytes())
     h.update(m.ffn[1].running_var.cpu().numpy().tobytes())
-    print("digest", h.hexdigest())
+    return h.hexdigest()
 
 
 def test_side_queue_fork_changes_no_bit():
     """The fused step runs the attention block's few-row weight gradients and the BatchNorm-backward finalize on the
-    library's side queue (csrc/common.h PcFork).  Same digest of 60 steps' losses, parameters and running statistics with the
-    fork and with everything on the main queue (PC_NO_FORK=1, read once per process: hence subprocesses)."""
-    import os
-    import subprocess
-    import sys
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    library's side queue (csrc/common.h PcFork; include/pcompanion_hip.h "Library-owned device state").  Same digest of 60
+    steps' losses, parameters and running statistics with the side queue, with everything on the caller's stream
+    (pc_set_option(PC_OPT_SIDE_QUEUE, 0)), and again with it after pc_release_device_state() destroyed and the next step
+    re-created it."""
+    from p_companion_amd import _lib
+    L = _lib.lib()
+    v = ctypes.c_int(-1)
+    assert L.pc_get_option(_lib.PC_OPT_SIDE_QUEUE, ctypes.byref(v)) == 0 and v.value == 1      # the default
+    assert L.pc_set_option(99, 1) == -1 and L.pc_set_option(_lib.PC_OPT_SIDE_QUEUE, 2) == -1
     outs = []
-    for nofork in (False, True, False):
-        env = dict(os.environ)
-        env.pop("PC_NO_FORK", None)
-        if nofork:
-            env["PC_NO_FORK"] = "1"
-        r = subprocess.run([sys.executable, "-c", "import tests.test_gpu_round3 as t; t._fork_worker()"], env=env, cwd=root,
-                           capture_output=True, text=True, timeout=300)
-        assert r.returncode == 0, r.stderr[-2000:]
-        outs.append([l for l in r.stdout.splitlines() if l.startswith("digest")][-1])
+    try:
+        for on in (1, 0, 1):
+            assert L.pc_set_option(_lib.PC_OPT_SIDE_QUEUE, on) == 0
+            outs.append(_fork_digest())
+            torch.cuda.synchronize()
+            assert L.pc_release_device_state() == 0
+    finally:
+        L.pc_set_option(_lib.PC_OPT_SIDE_QUEUE, 1)
     assert outs[0] == outs[1] == outs[2]
 
 
