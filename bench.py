@@ -76,24 +76,30 @@ def bytes_per_triplet(n, dim=128):
     return 4 * dim * (n + 7) + 4 * (n + 7)
 
 
-def committed_pmc(pattern, match):
-    """HBM bytes per launch of the kernels whose name contains `match`, from the newest committed rocprofv3 --pmc
-    passes of this same command (profiles/<tag>_pmc_traffic*.json: FETCH_SIZE and WRITE_SIZE in separate passes,
-    KiB -> bytes, FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950).  None if no profile is committed:
-    PMC counters cannot be collected from inside the bench process."""
-    import glob
-    files = sorted(f for f in glob.glob(os.path.join(ROOT, "profiles", pattern))
-                   if ("joint" in os.path.basename(f)) == ("joint" in pattern))
+def committed_pmc(kind, match):
+    """HBM bytes per launch of the kernels whose name `match` accepts, from the newest committed rocprofv3 --pmc passes of
+    the SAME workload (profiles/<round tag>[_<kind>]_pmc_traffic.json: FETCH_SIZE and WRITE_SIZE in separate passes,
+    KiB -> bytes, FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950).  kind: "" = configs[1] (100 k products),
+    "joint" / "joint34800" = the joint step at T = 100 / 34800, "cfg3" = 10 M products through the sharded lookup, "big" =
+    configs[4] (100 M x 256, Zipf).  None if no profile of that kind is committed (PMC counters cannot be collected from
+    inside the bench process) -- a leg never borrows another workload's traffic."""
+    import re
+    pat = re.compile(r"^(r\d+[a-z0-9]*)_(?:(joint34800|joint|big|cfg3)_)?pmc_traffic\.json$")
+    files = []
+    for f in sorted(os.listdir(os.path.join(ROOT, "profiles"))) if os.path.isdir(os.path.join(ROOT, "profiles")) else []:
+        m = pat.match(f)
+        if m and (m.group(2) or "") == kind:
+            files.append(f)
     if not files:
         return None
-    with open(files[-1]) as f:
+    with open(os.path.join(ROOT, "profiles", files[-1])) as f:
         d = json.load(f)
     sel = [v for k, v in d.items() if match(k)]
     n = sum(v["launches"] for v in sel)
     if not n:
         return None
     return {"hbm_bytes_per_launch": round(sum((v["fetch_bytes_corrected"] + v["write_bytes"]) * v["launches"] for v in sel) / n),
-            "source": os.path.relpath(files[-1], ROOT)}
+            "source": os.path.join("profiles", files[-1])}
 
 
 def two_roof(flops, nbytes, seconds, peak_tflops):
@@ -183,7 +189,7 @@ def joint_algorithmic_bytes(b, t, k=3):
     return b * (512 + 1024 + 256 + k * 256 + 40) + t * 64 * 4 + 28 * (2 * t * 64 + 29024)
 
 
-def run_joint(args, rank, world, dev, types, steps, warmup, want_cpu):
+def run_joint(args, rank, world, dev, types, steps, warmup, want_cpu, dropout=0.0):
     """BASELINE configs[2]: 100k products, T types, B pairs per GPU: PCompanion forward + both hinge losses + backward
     + Adam (pc_joint_train_step + pc_adam_step), loader batch construction included."""
     from types import SimpleNamespace
@@ -191,7 +197,7 @@ def run_joint(args, rank, world, dev, types, steps, warmup, want_cpu):
     from p_companion_amd.data import ComplementaryIndexDataset, ComplementaryIndexLoader, generate_scaled_bpg
     from p_companion_amd.p_companion import GraphedJointStep, PCompanion
     from p_companion_amd.product2vec import FusedAdam
-    cfg = SimpleNamespace(PRODUCT_EMB_DIM=128, TYPE_EMB_DIM=64, DROPOUT=0.0, MARGIN=1.0, ALPHA=0.8, NUM_COMP_TYPES=3,
+    cfg = SimpleNamespace(PRODUCT_EMB_DIM=128, TYPE_EMB_DIM=64, DROPOUT=float(dropout), MARGIN=1.0, ALPHA=0.8, NUM_COMP_TYPES=3,
                           NUM_TYPES=types, DEVICE=dev)
     # configs[2] is quoted on the 100 k catalogue; the complementary-pair dataset is built from host arrays, so a catalogue that
     # only exists in HBM (--products > 2 M: configs[3]/[4] of the Product2Vec phase) is not what this phase trains over
@@ -277,8 +283,9 @@ def run_joint(args, rank, world, dev, types, steps, warmup, want_cpu):
     value = world * args.batch * steps / el
     dev_ms = ev[0].elapsed_time(ev[1]) / steps               # HIP events on the launch stream, around the timed steps
     alg = joint_algorithmic_bytes(args.batch, types)
-    pmc = committed_pmc("*_joint_pmc_traffic*.json" if types == args.types else f"*_joint{types}_pmc_traffic*.json",
-                        lambda k: k == "_step_total")
+    # (the committed counter passes are DROPOUT = 0 runs of T = 100 and T = 34800: other legs carry no traffic figure)
+    pmc = (committed_pmc("joint" if types == 100 else f"joint{types}", lambda k: k == "_step_total")
+           if dropout == 0.0 and types in (100, 34800) else None)
     achieved = alg / (dev_ms * 1e-3) / 1e9
     out = {"metric": "triplets/sec (P-Companion joint step: fwd + type/item hinge + bwd + Adam)", "value": round(value, 1),
            "unit": "triplets/s", "steps": steps, "ms_per_step": round(1e3 * el / steps, 4),
@@ -286,11 +293,13 @@ def run_joint(args, rank, world, dev, types, steps, warmup, want_cpu):
            "config": {"workload": f"P-Companion joint step, {jproducts} products, NUM_TYPES={types}, dim=128, "
                                   f"batch={args.batch}/GPU, K=3 (loader batch construction included)",
                       "global_batch": world * args.batch, "parallelism": f"dp{world}", "final_loss": round(float(losses[0]), 5),
+                      "dropout": float(dropout),
                       "launch": ("pc_joint_train_epoch: the epoch's steps enqueued by one foreign call" if by_epoch else
                                  {"direct": "fused step, arguments resolved once (one foreign call per step)" +
                                             ("; gradients only, then all-reduce of the flat gradient buffer and the Adam launch" if multi else ""),
                                   "graph": "hipGraph replay"}[graphed.mode] if graphed is not None else "eager module calls"),
-                      "kernels_per_step": ("2 (tile kernel: batch construction, forward, losses, backward and the tile's gradient slab; finish: slab "
+                      "kernels_per_step": ("the launch-per-op sequence (pc_joint_train_step + pc_adam_step, ~25 launches)" if graphed is None or graphed.mode == "graph" else
+                                           "2 (tile kernel: batch construction, forward, losses, backward and the tile's gradient slab; finish: slab "
                                             "sums + Adam)" if types <= 128 else
                                             "4 (batch builder, tile kernel, gradient products, finish + Adam)" if types <= 512 else
                                             "8 (present types, sims + chunk top-K with the table-gradient clear riding, merge, tile kernel incl. batch construction and the "
@@ -310,7 +319,10 @@ def run_joint(args, rank, world, dev, types, steps, warmup, want_cpu):
 
 
 # ----------------------------------------------------------------------------------------------- P2V phase
-def run_p2v(args, rank, world, dev, products, steps, warmup, want_cpu, profile_kernels=True, sustained=False):
+def run_p2v(args, rank, world, dev, products, steps, warmup, want_cpu, profile_kernels=True, sustained=False, dim=None,
+            negatives=None, table_mode=None, dropout=0.0, pmc_kind=""):
+    """One Product2Vec leg.  dim / negatives / table_mode default to the command line's; dropout = config.py:12's DROPOUT of
+    the attention probabilities (0.0: the parity setting, every golden test; 0.1: the reference as shipped)."""
     from types import SimpleNamespace
     from p_companion_amd import distributed as pdist
     from p_companion_amd import ops
@@ -319,8 +331,10 @@ def run_p2v(args, rank, world, dev, products, steps, warmup, want_cpu, profile_k
 
     from p_companion_amd.data import generate_device_bpg
     multi = pdist.collectives_on(world)                  # (world > 1, or the one-rank RCCL rehearsal PC_DIST_FORCE=1)
-    dim = args.dim
-    cfg = SimpleNamespace(PRODUCT_EMB_DIM=dim, TYPE_EMB_DIM=64, HIDDEN_SIZE=256, NUM_ATTENTION_HEADS=4, DROPOUT=0.0,
+    dim = args.dim if dim is None else dim
+    negatives = args.negatives if negatives is None else negatives
+    table_mode = args.table if table_mode is None else table_mode
+    cfg = SimpleNamespace(PRODUCT_EMB_DIM=dim, TYPE_EMB_DIM=64, HIDDEN_SIZE=256, NUM_ATTENTION_HEADS=4, DROPOUT=float(dropout),
                           MARGIN=1.0, BATCH_SIZE=args.batch, LEARNING_RATE=1e-3, DEVICE=dev)
     # the catalogue: host restatement (numpy; what the CPU baseline also reads) up to 2 M products, otherwise generated IN
     # HBM by csrc/generator.hip (configs[3]/[4]: 10 M / 100 M products cannot exist as host arrays); a sharded table is
@@ -328,7 +342,7 @@ def run_p2v(args, rank, world, dev, products, steps, warmup, want_cpu, profile_k
     on_device = args.generator == "device" or (args.generator == "auto" and products > 2_000_000)
     t_gen = time.perf_counter()
     if on_device:
-        shard = args.table == "sharded"
+        shard = table_mode == "sharded"
         bpg = generate_device_bpg(products, args.types, seed=0, dim=dim, device=dev, rank=rank if shard else 0,
                                   world=world if shard else 1, with_complementary=False)
         torch.cuda.synchronize()
@@ -344,12 +358,12 @@ def run_p2v(args, rank, world, dev, products, steps, warmup, want_cpu, profile_k
     flat, gflat = model.flatten_parameters()
     table = bpg.cuda(dev)["features"]
     sharded = None
-    if args.table == "sharded":
+    if table_mode == "sharded":
         # row r on rank r % world; the loader runs the per-batch exchange on its side stream, one batch ahead
         local = table if on_device else pdist.ShardedFeatureTable.shard(table, rank, world)
         sharded = pdist.ShardedFeatureTable(local, bpg.num_products, rank, world)
     loader = SimilarityIndexLoader(bpg, args.batch, shuffle=True, sampler="philox", seed=1 + rank, drop_last=True,
-                                   device=dev, sharded=sharded, negatives=args.negatives, reuse_buffers=True)
+                                   device=dev, sharded=sharded, negatives=negatives, reuse_buffers=True)
 
     def batches():
         while True:
@@ -417,7 +431,7 @@ def run_p2v(args, rank, world, dev, products, steps, warmup, want_cpu, profile_k
         nt = prof.summary("gemm_nt_kernel")
         tn = prof.summary("gemm_tn_kernel")
         sm = prof.summary("gemm_nt_small_kernel")
-        traffic = committed_pmc("*_pmc_traffic.json", lambda k: "gemm_nt_kernel<" in k and "<1, 2," not in k)
+        traffic = committed_pmc(pmc_kind, lambda k: "gemm_nt_kernel<" in k and "<1, 2," not in k)
         launches = max(nt["launches"], 1)
         sec = nt["total_ms"] * 1e-3 / launches
         fl = nt["total_flops"] / launches
@@ -492,7 +506,7 @@ def run_p2v(args, rank, world, dev, products, steps, warmup, want_cpu, profile_k
                             "ms_per_step": {"min": round(reps[0], 4), "median": round(reps[1], 4), "max": round(reps[2], 4)},
                             "value_median": round(world * args.batch / (reps[1] * 1e-3), 1), "unit": "triplets/s"}
     res["catalogue"] = {"products": products, "dim": dim, "generator": "device (csrc/generator.hip)" if on_device else "host (numpy)",
-                        "seconds": round(t_gen, 3), "negatives": args.negatives,
+                        "seconds": round(t_gen, 3), "negatives": negatives, "table": table_mode, "dropout": float(dropout),
                         "neighbour_layout": "unique rows" if loader.unique else "compact (every real slot its own row)",
                         "hbm_bytes": bpg.nbytes() if on_device else None,
                         "similarity_pairs": len(loader) * args.batch}
@@ -500,6 +514,74 @@ def run_p2v(args, rank, world, dev, products, steps, warmup, want_cpu, profile_k
         res["cpu_baseline"] = p2v_cpu_baseline(bpg, last)
     prof.close()
     return res
+
+
+def self_launch(n, argv):
+    """`python bench.py --gpus N` without a launcher: start N ranks of this script (one process per GPU, RANK / LOCAL_RANK /
+    WORLD_SIZE / MASTER_* in their environment, exactly what torch.distributed.run would set), relay rank 0's JSON line and
+    exit with the worst child's code.  Runs BEFORE anything touches the GPU in this process: it only counts devices
+    (torch.cuda.device_count() does not initialise HIP) and waits for its children."""
+    import socket
+    import subprocess
+    ndev = torch.cuda.device_count()
+    forced = os.environ.get("PC_FORCE_DEVICE")               # (rehearsal: every rank on one card, with PC_DIST_BACKEND=gloo)
+    if ndev < n and forced is None:
+        print(f"bench.py: --gpus {n} needs {n} visible GPUs, this node shows {ndev} (one process per GPU; set "
+              "PC_FORCE_DEVICE + PC_DIST_BACKEND=gloo only to rehearse the N-rank code path on one card)", file=sys.stderr)
+        return 2
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), PC_BENCH_SELF_LAUNCHED="1")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
+    import threading
+    chunks = []
+    rd = threading.Thread(target=lambda: chunks.append(procs[0].stdout.read()), daemon=True)
+    rd.start()
+    worst, live = 0, set(range(n))
+    while live:
+        for r in sorted(live):
+            rc = procs[r].poll()
+            if rc is None:
+                continue
+            live.discard(r)
+            if rc != 0:
+                worst = worst or rc
+                for o in sorted(live):                           # a rank died: its peers would sit in a collective until the
+                    procs[o].kill()                              # backend's timeout -- end exactly these children, by handle
+        if live:
+            time.sleep(0.05)
+    rd.join(10.0)
+    sys.stdout.write(b"".join(chunks).decode())
+    sys.stdout.flush()
+    return 1 if worst else 0
+
+
+def rccl_info(world, dev):
+    """What the driver needs to SEE N ranks: backend, world size and the ranks an all_gather over the process group returned."""
+    import torch.distributed as dist
+    from p_companion_amd import distributed as pdist
+    if not (pdist.collectives_on(world) and dist.is_initialized()):
+        return None
+    backend = dist.get_backend()
+    t = torch.tensor([dist.get_rank()], dtype=torch.int64, device=dev if backend != "gloo" else "cpu")
+    seen = torch.empty(world, dtype=torch.int64, device=t.device)
+    dist.all_gather_into_tensor(seen, t)
+    return {"backend": backend + (" (RCCL over xGMI)" if backend == "nccl" else ""), "world": world,
+            "ranks_seen": sorted(int(v) for v in seen.tolist()), "launcher": "self" if os.environ.get("PC_BENCH_SELF_LAUNCHED") else "torch.distributed.run"}
+
+
+def leg(res, keys=("value", "ms_per_step", "host_enqueue_ms_per_step", "final_loss", "catalogue", "roofline", "sharded_lookup")):
+    """A secondary Product2Vec leg of the line: its own value / ms_per_step / roofline, nothing borrowed from the headline."""
+    out = {"unit": "triplets/s"}
+    for k in keys:
+        if res.get(k) is not None:
+            out[k] = round(res[k], 4 if k != "value" else 1) if isinstance(res[k], float) else res[k]
+    return out
 
 
 def main():
@@ -517,6 +599,9 @@ def main():
                     help="where the synthetic catalogue is drawn: host numpy (<= 2 M products) or straight into HBM")
     ap.add_argument("--phase", choices=["both", "p2v", "joint"], default="both",
                     help="both (default) = BASELINE's whole metric: configs[1] as the headline value + configs[2] as `joint`")
+    ap.add_argument("--dropout", type=float, default=0.0,
+                    help="DROPOUT of the headline legs (config.py:12 ships 0.1; 0.0 is the parity setting of every golden test). "
+                         "The default line carries the 0.1 legs beside the 0.0 ones either way")
     ap.add_argument("--sync-bn", action="store_true",
                     help="N > 1: BatchNorm statistics over all replicas' rows (two 16 KB all-reduces per step) instead of "
                          "each replica's own batch")
@@ -529,40 +614,89 @@ def main():
                     help="joint phase, one process: 'direct' = the fused step with its arguments resolved once; 'graph' = HIP-graph replay")
     ap.add_argument("--large-catalogue", type=int, default=0,
                     help="also time the P2V step over this many products (e.g. 2000000: few duplicate neighbours to merge)")
+    ap.add_argument("--no-large", action="store_true",
+                    help="skip the `large_catalogue` legs (BASELINE configs[3]: 10 M products through the row-sharded lookup; "
+                         "configs[4]: 100 M products x 256, Zipf negatives; both generated in HBM)")
+    ap.add_argument("--no-dropout-legs", action="store_true", help="skip the legs at the reference's shipped DROPOUT = 0.1 (config.py:12)")
     ap.add_argument("--no-ref-types", action="store_true", help="skip the joint leg at the reference's NUM_TYPES = 34800")
     ap.add_argument("--no-sustained", action="store_true", help="skip the `sustained` leg (3 x >= 300 P2V steps across epoch boundaries)")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(self_launch(args.gpus, sys.argv[1:]))           # (nothing has touched the GPU in this process)
+
     from p_companion_amd import distributed as pdist
     rank, world, local = pdist.init_from_env("cuda")
     if world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     local = int(os.environ.get("PC_FORCE_DEVICE", local))
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     want_cpu = not args.no_cpu_baseline and world == 1
+    plain = args.products == 100_000 and args.dim == 128 and args.table == "replicated" and args.negatives == "uniform"
+    rccl = rccl_info(world, dev)
 
     p2v = joint = joint_ref = large = None
+    extra = {}
     if args.phase in ("both", "p2v"):
-        p2v = run_p2v(args, rank, world, dev, args.products, args.steps, args.warmup, want_cpu, sustained=not args.no_sustained)
+        p2v = run_p2v(args, rank, world, dev, args.products, args.steps, args.warmup, want_cpu, sustained=not args.no_sustained,
+                      dropout=args.dropout, pmc_kind="" if plain else ("big" if args.products == 100_000_000 else "cfg3" if args.products == 10_000_000 else "none"))
         if args.large_catalogue:
             large = run_p2v(args, rank, world, dev, args.large_catalogue, max(args.steps // 2, 5), args.warmup, False,
                             profile_kernels=False)
+        if plain and not args.no_dropout_legs and args.dropout == 0.0:
+            r = run_p2v(args, rank, world, dev, args.products, max(args.steps, 30), args.warmup, False, dropout=0.1, pmc_kind="none")
+            if rank == 0:
+                extra["p2v_dropout_0p1"] = leg(r)
     if args.phase in ("both", "joint"):
-        joint = run_joint(args, rank, world, dev, args.types, max(args.steps * 4, 100), max(args.warmup, 10), want_cpu)
+        joint = run_joint(args, rank, world, dev, args.types, max(args.steps * 4, 100), max(args.warmup, 10), want_cpu, dropout=args.dropout)
+        if not args.no_dropout_legs and args.dropout == 0.0:
+            extra["joint_dropout_0p1"] = run_joint(args, rank, world, dev, args.types, max(args.steps * 4, 100), max(args.warmup, 10),
+                                                   False, dropout=0.1)
         if not args.no_ref_types and args.types != 34800:
-            joint_ref = run_joint(args, rank, world, dev, 34800, max(args.steps, 20), max(args.warmup, 10), want_cpu)
+            joint_ref = run_joint(args, rank, world, dev, 34800, max(args.steps, 20), max(args.warmup, 10), want_cpu, dropout=args.dropout)
+            if not args.no_dropout_legs and args.dropout == 0.0:
+                extra["joint_num_types_34800_dropout_0p1"] = run_joint(args, rank, world, dev, 34800, max(args.steps, 20),
+                                                                       max(args.warmup, 10), False, dropout=0.1)
+    if args.phase in ("both", "p2v") and plain and not args.no_large:
+        # BASELINE configs[3] / [4] at their real sizes, catalogue generated in HBM (this rank's shard of the table when N > 1).
+        # One GPU holds configs[4] whole (102 GB of 288); the smaller catalogues are released first.
+        run_joint.bpg = None
+        import gc
+        gc.collect()
+        torch.cuda.empty_cache()
+        lc = {}
+        r = run_p2v(args, rank, world, dev, 10_000_000, 30, 10, False, dim=128, negatives="uniform", table_mode="sharded", pmc_kind="cfg3")
+        if rank == 0:
+            lc["config3"] = dict(leg(r), workload=f"BASELINE configs[3]: 10 M products, dim=128, table row-sharded over {world} GPU(s) "
+                                                  f"(pc_shard_bucket + two constant-shape all-to-all rounds + pc_gather_rows per batch), batch={args.batch}/GPU")
+        del r
+        gc.collect()
+        torch.cuda.empty_cache()
+        r = run_p2v(args, rank, world, dev, 100_000_000, 30, 10, False, dim=256, negatives="zipf",
+                    table_mode="sharded" if world > 1 else "replicated", pmc_kind="big")
+        if rank == 0:
+            lc["config4"] = dict(leg(r), workload=f"BASELINE configs[4]: 100 M products, dim=256, Zipf(1) negatives, "
+                                                  + (f"table row-sharded over {world} GPUs" if world > 1 else "whole table (102 GB) on one GPU")
+                                                  + f", batch={args.batch}/GPU; hot-row cache measured unnecessary (DESIGN.md section 7)")
+        del r
+        gc.collect()
+        torch.cuda.empty_cache()
+        extra["large_catalogue"] = lc
     if rank != 0:
         return
 
     common = {"unit": "triplets/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "higher_is_better": True,
               "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic"}
+    if rccl:
+        common["rccl"] = rccl
     if p2v is None:                                           # --phase joint: the joint step is the line
         out = dict(common)
         out.update(joint)
         out["steps"] = joint["steps"]
         if joint_ref:
             out["joint_num_types_34800"] = joint_ref
+        out.update(extra)
         print(json.dumps(out), flush=True)
         return
     out = {"metric": "triplets/sec (Product2Vec pretrain step: gather+fwd+bwd+Adam)" +
@@ -574,26 +708,31 @@ def main():
            "config": {"workload": f"Product2Vec GAT pretrain, {args.products} products, {args.types} types, dim={args.dim}, "
                                   f"batch={args.batch}/GPU, 5 negatives, neighbours padded to batch max "
                                   f"(avg N={p2v['n_avg']:.1f})", "global_batch": world * args.batch,
+                      "dropout": args.dropout,
+                      "dropout_note": "DROPOUT = 0.0 is the parity setting (ATen's mask stream cannot be reproduced: every golden-vector "
+                                      "test runs at 0); the reference ships config.py:12 DROPOUT = 0.1 -- legs `p2v_dropout_0p1`, "
+                                      "`joint_dropout_0p1`, `joint_num_types_34800_dropout_0p1` of this line run that setting",
                       "table": args.table, "sharded_lookup": p2v.get("sharded_lookup"), "parallelism": f"dp{world}",
                       "batchnorm": "cross-replica" if (args.sync_bn and pdist.collectives_on(world)) else "per-replica",
                       "final_loss": round(p2v["final_loss"], 5),
                       "neighbour_rows": "identical rows of the neighbour call carried once: avg %.0f distinct products (%.0f "
                                         "real slots) + 1 shared padding row, of %d neighbour slots per step; the duplicates "
-                                        "are a property of the catalogue (%.0f %% of all FFN rows saved at %d products; see "
-                                        "`large_catalogue` / DESIGN.md section 7 for 2 M products)"
+                                        "are a property of the catalogue (%.0f %% of all FFN rows saved at %d products; none to "
+                                        "speak of at 10 M / 100 M products: `large_catalogue` of this line)"
                                         % (p2v["distinct_neighbour_rows"], p2v["real_neighbour_slots"],
                                            args.batch * round(p2v["n_avg"]), 100 * p2v["rows_saved_by_duplicate_neighbours"],
                                            args.products)},
            "sustained": p2v.get("sustained"), "catalogue": p2v.get("catalogue"),
            "roofline": p2v.get("roofline"), "cpu_baseline": p2v.get("cpu_baseline")}
     if large:
-        out["large_catalogue"] = {"products": args.large_catalogue, "value": round(large["value"], 1),
-                                  "ms_per_step": round(large["ms_per_step"], 4),
-                                  "rows_saved_by_duplicate_neighbours": large["rows_saved_by_duplicate_neighbours"]}
+        out["large_catalogue_extra"] = {"products": args.large_catalogue, "value": round(large["value"], 1),
+                                        "ms_per_step": round(large["ms_per_step"], 4),
+                                        "rows_saved_by_duplicate_neighbours": large["rows_saved_by_duplicate_neighbours"]}
     if joint:
         out["joint"] = joint
     if joint_ref:
         out["joint_num_types_34800"] = joint_ref
+    out.update(extra)
     print(json.dumps(out), flush=True)
 
 

@@ -100,8 +100,9 @@ struct FusedArgs {
     int B, T, K, P;
     float margin, g_type, g_item;        // g_type = (1 - alpha) / B, g_item = alpha / (B K): the means' constants
     DropCfg drop;
-    // regime L (T > T_SMALL): top-K per query TYPE, computed beforehand
-    const int32_t* topk_by_type;
+    // regime L (T > T_SMALL): top-K per query TYPE, computed beforehand -- or, with hidden-layer dropout (c then differs from
+    // sample to sample), per SAMPLE: topk_per_sample != 0, the same table indexed by the sample
+    const int32_t* topk_by_type; int topk_per_sample;
     // outputs
     int32_t* topk;                        // [B,K]
     float *part_type, *part_item;         // [B] hinge values (summed by the finish kernel)
@@ -466,7 +467,7 @@ __global__ __launch_bounds__(256) void joint_tile_kernel(FusedArgs a, int ldsims
             if (k < K) {
                 // (a query type that was out of range and clamped may have no entry in the per-type table: whatever is read
                 // there is forced into the table before it is used as a row id)
-                const int t = b0 + s < a.B ? a.topk_by_type[(size_t)ints[s * 8 + 1] * K + k] : 0;
+                const int t = b0 + s < a.B ? a.topk_by_type[(size_t)(a.topk_per_sample ? b0 + s : ints[s * 8 + 1]) * K + k] : 0;
                 ints[s * 8 + 4 + k] = (unsigned)t < (unsigned)a.T ? t : 0;
             }
         }
@@ -1009,12 +1010,13 @@ __global__ __launch_bounds__(256) void type_sims_topk_kernel(TypeSimsArgs a) {
 
 // per listed query type: the best K of its nchunks * K candidates (value, index), ties -> the lower index; a row group of
 // 16 lanes per type
+// (ulist == NULL: the rows are the batch's SAMPLES, n_rows of them, and row u's result goes to topk_by_type[u])
 __global__ __launch_bounds__(256) void type_topk_merge_kernel(const float* part_val, const int32_t* part_idx,
-                                                              const int32_t* ulist, const int32_t* n_u, int nchunks,
+                                                              const int32_t* ulist, const int32_t* n_u, int n_rows, int nchunks,
                                                               int K, int32_t* topk_by_type) {
     const int lane = threadIdx.x & 63;
     const int u = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (u >= *n_u) return;                                   // wave-uniform
+    if (u >= (ulist ? *n_u : n_rows)) return;                // wave-uniform
     const int n = nchunks * K;
     // one pass: every lane keeps the best K keys of its strided candidates (the loads are independent: one latency),
     // then K rounds of a wave max; the winner is retired by its owner
@@ -1032,7 +1034,7 @@ __global__ __launch_bounds__(256) void type_topk_merge_kernel(const float* part_
             h = th; l = tl;
         }
     }
-    const int type = ulist[u];
+    const int type = ulist ? ulist[u] : u;
     for (int r = 0; r < K; r++) {
         unsigned bh = kh[0], bl = kl[0];
         wave_maxkey(bh, bl);
@@ -1042,6 +1044,194 @@ __global__ __launch_bounds__(256) void type_topk_merge_kernel(const float* part_
             kh[FK - 1] = 0u; kl[FK - 1] = 0u;
         }
         if (lane == 0) topk_by_type[(size_t)type * K + r] = (int)~bl;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Large tables WITH hidden-layer dropout (the reference as shipped: config.py:12 DROPOUT = 0.1, config.py:27 NUM_TYPES = 34800;
+// type_transition.py:13-19): c = dec(mask_b (*) relu(enc t)) differs from sample to sample, so the similarity row and its
+// top-K exist per SAMPLE -- the [B,64] x [64,T] product of p_companion.py:60-63 (18 GFLOP at B = 4096), never written:
+//   sample_c_kernel          c[b] for every sample (two small layers, the step's own dropout mask: the tile kernel that follows
+//                            regenerates the same bits) -> c [B,64]
+//   sample_sims_topk_kernel  per chunk of TC types (its E_c fragments resident in registers), walking tiles of SUT samples:
+//                            sims = c E_c[chunk]^T on 16 x 16 x 4 fp32 MFMAs into LDS, the chunk's best K per sample in the
+//                            epilogue (one insertion pass per lane + K row maxima); three workgroups per CU, so one's top-K
+//                            pass (VALU / DPP) runs beside the others' products (matrix pipe)
+//   type_topk_merge_kernel   (rows = samples) best K of each sample's chunk candidates -> topk[b][K]
+struct SampleCArgs {
+    const float *enc_w, *enc_b, *dec_w, *dec_b, *eq;
+    const int32_t *query_types, *pairs, *type_idx;
+    int B, T, P;
+    DropCfg drop;
+    float* c;
+};
+
+__global__ __launch_bounds__(256) void sample_c_kernel(SampleCArgs a) {
+    __shared__ __attribute__((aligned(16))) float Tin[UT * LD64];
+    __shared__ __attribute__((aligned(16))) float Hs[UT * LD32];
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, ci = lane & 15, rh = lane >> 4;
+    const int b0 = blockIdx.x * UT;
+    const BFrag<4> f_e0 = load_b<PC_L, false>(a.enc_w, PC_L, 0, LH, lane), f_e1 = load_b<PC_L, false>(a.enc_w, PC_L, 16, LH, lane);
+    BFrag<2> f_d[4];
+#pragma unroll
+    for (int nb = 0; nb < 4; nb++) f_d[nb] = load_b<LH, false>(a.dec_w, LH, 16 * nb, PC_L, lane);
+    const float bias_e0 = a.enc_b[ci], bias_e1 = a.enc_b[16 + ci];
+    float bias_d[4];
+#pragma unroll
+    for (int nb = 0; nb < 4; nb++) bias_d[nb] = a.dec_b[16 * nb + ci];
+    for (int e = tid; e < UT * 16; e += 256) {
+        const int r = e >> 4, c4 = (e & 15) * 4, b = b0 + r;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (b < a.B) {
+            // the query type as the tile kernel will validate it (an id outside its table is counted there and clamped to 0)
+            int qt;
+            if (a.pairs) { const int qi = a.pairs[3 * b]; qt = a.type_idx[(unsigned)qi < (unsigned)a.P ? qi : 0]; }
+            else qt = a.query_types[b];
+            if ((unsigned)qt >= (unsigned)a.T) qt = 0;
+            v = *reinterpret_cast<const float4*>(a.eq + (size_t)qt * PC_L + c4);
+        }
+        *reinterpret_cast<float4*>(&Tin[r * LD64 + c4]) = v;
+    }
+    __syncthreads();
+    // wave w owns samples [16 w, 16 w + 16) of the tile through both layers (no workgroup barrier in between)
+    const float* At = Tin + 16 * w * LD64;
+    f32x4v a0[1] = {{0.f, 0.f, 0.f, 0.f}}, a1[1] = {{0.f, 0.f, 0.f, 0.f}};
+    mul_b<4, 1>(At, LD64, 1, f_e0, a0, lane);
+    mul_b<4, 1>(At, LD64, 1, f_e1, a1, lane);
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+        const int row = 16 * w + 4 * rh + r;
+        float x0 = a0[0][r] + bias_e0, x1 = a1[0][r] + bias_e1;
+        x0 = x0 > 0.f ? x0 : 0.f;
+        x1 = x1 > 0.f ? x1 : 0.f;
+        if (a.drop.thr) {                                         // the mask of joint_tile_kernel's phase A, element for element
+            float m[4];
+            pc_dropout_keep4(a.drop, (unsigned)((b0 + row) * (LH / 4) + (ci >> 2)), PC_DROP_STREAM_HIDDEN, m);
+            x0 *= m[ci & 3];
+            pc_dropout_keep4(a.drop, (unsigned)((b0 + row) * (LH / 4) + ((16 + ci) >> 2)), PC_DROP_STREAM_HIDDEN, m);
+            x1 *= m[ci & 3];
+        }
+        Hs[row * LD32 + ci] = x0;
+        Hs[row * LD32 + 16 + ci] = x1;
+    }
+    __builtin_amdgcn_wave_barrier();
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+    for (int nb = 0; nb < 4; nb++) {
+        f32x4v acc[1] = {{0.f, 0.f, 0.f, 0.f}};
+        mul_b<2, 1>(Hs + 16 * w * LD32, LD32, 1, f_d[nb], acc, lane);
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            const int b = b0 + 16 * w + 4 * rh + r;
+            if (b < a.B) a.c[(size_t)b * PC_L + 16 * nb + ci] = acc[0][r] + bias_d[nb];
+        }
+    }
+}
+
+// inverse of ord_f32
+__device__ __forceinline__ float unord_f32(unsigned k) {
+    return __uint_as_float((k & 0x80000000u) ? (k ^ 0x80000000u) : ~k);
+}
+
+// top-K of one LDS row of n values by the 16 lanes of a row group, ONE pass over the row: every lane keeps the best FK keys
+// (value, ~index) of its strided elements in a sorted register list, then K rounds of a row maximum whose owner retires
+// its head.  Same order as row_topk (descending, ties -> the lower index); (0, 0) = none (fewer than K values).
+__device__ __forceinline__ void row_topk_ins(const float* row, int n, int K, int l16, unsigned (&oh)[FK], unsigned (&ol)[FK]) {
+    unsigned kh[FK], kl[FK];
+#pragma unroll
+    for (int j = 0; j < FK; j++) { kh[j] = 0u; kl[j] = 0u; oh[j] = 0u; ol[j] = 0u; }
+    for (int t = l16; t < n; t += 16) {
+        unsigned h = ord_f32(row[t]), l = ~(unsigned)t;
+#pragma unroll
+        for (int j = 0; j < FK; j++) {
+            const bool gt = h > kh[j] || (h == kh[j] && l > kl[j]);
+            const unsigned th = gt ? kh[j] : h, tl = gt ? kl[j] : l;
+            kh[j] = gt ? h : kh[j]; kl[j] = gt ? l : kl[j];
+            h = th; l = tl;
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < FK; r++) {
+        if (r < K) {
+            unsigned bh = kh[0], bl = kl[0];
+            row_maxkey(bh, bl);
+            if (kh[0] == bh && kl[0] == bl) {                      // (keys are distinct: exactly one lane owns the winner)
+#pragma unroll
+                for (int j = 0; j < FK - 1; j++) { kh[j] = kh[j + 1]; kl[j] = kl[j + 1]; }
+                kh[FK - 1] = 0u; kl[FK - 1] = 0u;
+            }
+            oh[r] = bh; ol[r] = bl;
+        }
+    }
+}
+
+#define SUT 32        /* samples per tile of sample_sims_topk_kernel: 50 KB of LDS, three workgroups per CU */
+struct SampleSimsArgs {
+    const float *c, *ec;
+    int B, T, K, nchunks;
+    float* part_val; int32_t* part_idx;     // [B][nchunks][K]
+    float* zero[2]; size_t nzero[2]; int zcols;      // rider: see TypeSimsArgs
+};
+
+__global__ __launch_bounds__(256, 3) void sample_sims_topk_kernel(SampleSimsArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    float* Cs = sm;                         // [SUT][LD64]
+    float* Sims = Cs + SUT * LD64;          // [SUT][TC + 4]
+    constexpr int LDS_ = TC + 4;
+    if ((int)blockIdx.x >= a.nchunks) {
+        const size_t wg = ((size_t)blockIdx.x - a.nchunks) * gridDim.y + blockIdx.y, nwg = (size_t)a.zcols * gridDim.y;
+        for (int i = 0; i < 2; i++) {
+            if (!a.zero[i]) continue;
+            const size_t n4 = a.nzero[i] / 4;
+            for (size_t e = wg * 256 + threadIdx.x; e < n4; e += nwg * 256)
+                reinterpret_cast<float4*>(a.zero[i])[e] = make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+        return;
+    }
+    const int t0 = blockIdx.x * TC;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, ci = lane & 15, rh = lane >> 4;
+    constexpr int NBW = TC / 16 / 4;                       // E_c column blocks per wave, resident for the whole kernel
+    BFrag<4> f_s[NBW];
+#pragma unroll
+    for (int q = 0; q < NBW; q++) f_s[q] = load_b<PC_L, false>(a.ec, PC_L, t0 + 16 * (w + 4 * q), a.T, lane);
+    const int nvalid = min(TC, a.T - t0);
+    const int g4 = lane >> 4, l16 = lane & 15;
+    for (int u0 = blockIdx.y * SUT; u0 < a.B; u0 += gridDim.y * SUT) {
+        __syncthreads();                                   // (the previous tile's top-K pass has left Sims / Cs)
+        for (int e = tid; e < SUT * 16; e += 256) {
+            const int r = e >> 4, c4 = (e & 15) * 4;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (u0 + r < a.B) v = *reinterpret_cast<const float4*>(a.c + (size_t)(u0 + r) * PC_L + c4);
+            *reinterpret_cast<float4*>(&Cs[r * LD64 + c4]) = v;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < NBW; q++) {
+            const int nb = w + 4 * q;
+            f32x4v acc[SUT / 16];
+#pragma unroll
+            for (int m = 0; m < SUT / 16; m++) acc[m] = f32x4v{0.f, 0.f, 0.f, 0.f};
+            mul_b<4, SUT / 16>(Cs, LD64, SUT / 16, f_s[q], acc, lane);
+#pragma unroll
+            for (int m = 0; m < SUT / 16; m++)
+#pragma unroll
+                for (int r = 0; r < 4; r++) Sims[(16 * m + 4 * rh + r) * LDS_ + 16 * nb + ci] = acc[m][r];
+        }
+        __syncthreads();
+        // a row group of 16 lanes per sample, four samples per wave side by side: SUT / 16 passes
+#pragma unroll 1
+        for (int pass = 0; pass < SUT / 16; pass++) {
+            const int s = 4 * (w + 4 * pass) + g4;
+            unsigned kh[FK], kl[FK];
+            row_topk_ins(Sims + s * LDS_, nvalid, a.K, l16, kh, kl);
+            if (l16 == 0 && u0 + s < a.B)
+                for (int r = 0; r < a.K; r++) {
+                    const size_t o = ((size_t)(u0 + s) * a.nchunks + blockIdx.x) * a.K + r;
+                    const bool got = (kh[r] | kl[r]) != 0u;        // (a tail chunk may hold fewer than K types)
+                    a.part_val[o] = got ? unord_f32(kh[r]) : -INFINITY;
+                    a.part_idx[o] = got ? t0 + (int)~kl[r] : 0x7fffffff;
+                }
+        }
     }
 }
 
@@ -1531,6 +1721,7 @@ struct FusedWs {
     int32_t *tl_c, *tp_c, *tl_q, *tp_q, *n_touch;       // touched rows of the two big tables: ascending lists, row -> list position
     float *tslab_c, *tslab_q;                           // [TG_WGS][TG_CAP][64] each
     float* part_val;
+    float* csamp;                                       // [B][64]: c per sample (large tables with hidden-layer dropout)
     float* wslabs; int wg_blocks, wslab_floats;      // joint_wgrad_kernel: one slab per workgroup
     int nchunks, ucap;
     bool small;
@@ -1564,6 +1755,7 @@ static FusedWs fused_ws_layout(void* base, int B, int T, int K) {
     w.tl_c = w.tp_c = w.tl_q = w.tp_q = w.n_touch = nullptr;
     w.tslab_c = w.tslab_q = nullptr;
     w.part_val = nullptr;
+    w.csamp = nullptr;
     if (w.small) {
     } else {
         const int nc = B * (K + 2);
@@ -1578,9 +1770,11 @@ static FusedWs fused_ws_layout(void* base, int B, int T, int K) {
         w.ucap = B < T ? B : T;
         w.ulist = (int32_t*)take((size_t)w.ucap * 4);
         w.n_u = (int32_t*)take(256);
-        w.topk_by_type = (int32_t*)take((size_t)T * K * 4);
-        w.part_val = (float*)take((size_t)w.ucap * w.nchunks * K * 4);
-        w.part_idx = (int32_t*)take((size_t)w.ucap * w.nchunks * K * 4);
+        // (sized for either regime: rows = distinct query types without dropout, = the B samples with it)
+        w.topk_by_type = (int32_t*)take((size_t)(T > B ? T : B) * K * 4);
+        w.part_val = (float*)take((size_t)B * w.nchunks * K * 4);
+        w.part_idx = (int32_t*)take((size_t)B * w.nchunks * K * 4);
+        w.csamp = (float*)take((size_t)B * PC_L * 4);
     }
     w.total = off;
     return w;
@@ -1606,7 +1800,8 @@ extern "C" int pc_joint_fused_touched(void* ws, size_t ws_bytes, int batch, int 
 
 extern "C" int pc_joint_fused_supported(int num_types, int k, float dropout_p) {
     if (k < 1 || k > FK || k > num_types || num_types < 1) return 0;
-    if (num_types > T_SMALL && dropout_p > 0.f) return 0;      // the per-type similarity row needs c = f(type) only
+    if (!(dropout_p >= 0.f && dropout_p < 1.f)) return 0;
+    // (T > T_SMALL with dropout: the similarity row per SAMPLE instead of per distinct query type, round 4)
     if (num_types > T_SMALL && (size_t)((num_types + 31) / 32 + 1024) * 4 > 160 * 1024) return 0;
     return 1;
 }
@@ -1650,7 +1845,27 @@ static int fused_step_impl(const pc_joint_tensors* p, const pc_joint_tensors* g,
                                             const_cast<int32_t*>(pos_types), const_cast<int32_t*>(neg_types),
                                             const_cast<float*>(pos_items), const_cast<float*>(neg_items), nullptr, stream));
 
-    if (!w.small) {
+    const bool per_sample = !w.small && p->dropout.p > 0.f;      // hidden-layer dropout: c is a function of the SAMPLE
+    if (per_sample) {
+        SampleCArgs ca = {p->enc_w, p->enc_b, p->dec_w, p->dec_b, p->query_types, query_types,
+                          pairs_in_tile ? src->pairs : nullptr, pairs_in_tile ? src->type_idx : nullptr, B, T, num_products,
+                          make_dropcfg(p->dropout), w.csamp};
+        PC_LAUNCH(sample_c_kernel, dim3((B + UT - 1) / UT), dim3(256), 0, st, ca);
+        SampleSimsArgs sa = {};
+        sa.c = w.csamp; sa.ec = p->comp_types; sa.B = B; sa.T = T; sa.K = K; sa.nchunks = w.nchunks;
+        sa.part_val = w.part_val; sa.part_idx = w.part_idx;
+        sa.zero[0] = g->query_types; sa.nzero[0] = (size_t)T * PC_L; sa.zero[1] = g->comp_types; sa.nzero[1] = (size_t)T * PC_L;
+        sa.zcols = 8;
+        const size_t lds = ((size_t)SUT * LD64 + (size_t)SUT * (TC + 4)) * 4;
+        const int tiles_s = (B + SUT - 1) / SUT;
+        // three workgroups per CU: y so that chunks x y fills 768 slots (each workgroup then walks its share of the sample tiles)
+        int gy = (768 - sa.zcols) / (w.nchunks > 0 ? w.nchunks : 1);
+        gy = gy < 1 ? 1 : gy > tiles_s ? tiles_s : gy;
+        PC_LAUNCH(sample_sims_topk_kernel, dim3(w.nchunks + sa.zcols, gy), dim3(256), lds, st, sa);
+        PC_LAUNCH(type_topk_merge_kernel, dim3((B + 3) / 4), dim3(256), 0, st, w.part_val, w.part_idx, nullptr, nullptr, B,
+                  w.nchunks, K, w.topk_by_type);
+        PC_TRY(pc_launch_status());
+    } else if (!w.small) {
         // the dense gradients of the two big tables hold zeros outside the touched rows (and receive float atomics beyond
         // TG_CAP touched rows): cleared by rider workgroups of the similarity launch below
         const int words = (T + 31) / 32;
@@ -1666,7 +1881,7 @@ static int fused_step_impl(const pc_joint_tensors* p, const pc_joint_tensors* g,
         (void)attr0;
         const int ytiles = (w.ucap + UT - 1) / UT;
         PC_LAUNCH(type_sims_topk_kernel, dim3(w.nchunks + ta.zcols, ytiles < 4 ? ytiles : 4), dim3(256), lds, st, ta);
-        PC_LAUNCH(type_topk_merge_kernel, dim3((w.ucap + 3) / 4), dim3(256), 0, st, w.part_val, w.part_idx, w.ulist, w.n_u,
+        PC_LAUNCH(type_topk_merge_kernel, dim3((w.ucap + 3) / 4), dim3(256), 0, st, w.part_val, w.part_idx, w.ulist, w.n_u, 0,
                   w.nchunks, K, w.topk_by_type);
         PC_TRY(pc_launch_status());
     }
@@ -1680,7 +1895,7 @@ static int fused_step_impl(const pc_joint_tensors* p, const pc_joint_tensors* g,
     fa.B = B; fa.T = T; fa.K = K; fa.P = num_products;
     fa.margin = margin; fa.g_type = (1.0f - alpha) / (float)B; fa.g_item = alpha / ((float)B * (float)K);
     fa.drop = make_dropcfg(p->dropout);
-    fa.topk_by_type = w.topk_by_type;
+    fa.topk_by_type = w.topk_by_type; fa.topk_per_sample = per_sample ? 1 : 0;
     fa.topk = topk; fa.part_type = w.part; fa.part_item = w.part + B;
     fa.h = w.h; fa.dpi = w.dpi; fa.dtp = w.dtp; fa.dc = w.dc; fa.dh = w.dh; fa.dt = w.dt;
     fa.ecsrc = w.ecsrc; fa.ecidx = w.ecidx; fa.cids = w.cids; fa.bad = bad_count; fa.step_count = adam ? step_count : nullptr;

@@ -506,7 +506,7 @@ def build_similarity_batch_unique(pair_ids, graph, n_pad, k_neg, seed, step, n_r
     _req(pair_ids, torch.int32, "pair_ids")
     npr = int(graph["n_products"])
     slots = b * n_pad
-    key = (dev, npr)
+    key = (dev, npr, torch.cuda.current_stream(dev).cuda_stream)      # (per stream: two loaders over one graph must not share counters)
     need = _lib.lib().pc_build_similarity_batch_unique_scratch_bytes(npr, slots)
     if key not in _uq_scratch or _uq_scratch[key].numel() < need:
         # per-product counters (first 4*P bytes): zero-filled once, every call leaves them zeroed

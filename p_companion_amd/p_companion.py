@@ -277,8 +277,9 @@ class PCompanion(nn.Module, _FlatParamsMixin):
         """train.py:42-46 (forward, compute_loss, zero_grad, backward) as one C-ABI call; with `optimizer` (a FusedAdam
         over this module) also train.py:48 optimizer.step(), applied by the step's last kernel.
         Returns (losses[3] = total/type/item on the device, complementary_types[B,K]).
-        The fused form (pc_joint_fused_step: two launches at T <= 128) serves K <= 4 and, for T > 512, dropout off; anything else
-        takes the launch-per-op sequence pc_joint_train_step (self.use_fused_joint = False forces it)."""
+        The fused form (pc_joint_fused_step: two launches at T <= 128) serves K <= 4 (T > 512 with dropout: the similarity row
+        per sample instead of per distinct query type); anything else takes the launch-per-op sequence pc_joint_train_step
+        (self.use_fused_joint = False forces it)."""
         if self.dim != ops.D:
             # PRODUCT_EMB_DIM = 256: the reference's loop body through the per-op path (train.py:42-48)
             self.flatten_parameters()

@@ -40,7 +40,8 @@ def _bench(*flags):
 def test_bench_multi_rank_branches_run_over_rccl():
     """Product2Vec: flat-gradient all-reduce per step, barrier + MAX all-reduce of the timing; joint step: direct mode with the
     gradient hook at T = 100 (one all-reduce) and T = 34800 (dense segment all-reduce + row-list all-gathers)."""
-    line = _bench("--steps", "10", "--warmup", "3")
+    line = _bench("--steps", "10", "--warmup", "3", "--no-large")
+    assert line["rccl"]["backend"].startswith("nccl") and line["rccl"]["ranks_seen"] == [0] and line["rccl"]["world"] == 1
     assert line["n_gpus"] == 1 and line["value"] > 1e6 and line["config"]["parallelism"] == "dp1"
     j, jr = line["joint"], line["joint_num_types_34800"]
     assert "all-reduce" in j["config"]["launch"] and j["value"] > 1e6

@@ -200,7 +200,7 @@ def test_graphed_joint_step_equals_eager_steps(mode):
         graphed({k: v[:7] for k, v in graphed.static.items()})
 
 
-@pytest.mark.parametrize("types,dropout,k", [(40, 0.0, 3), (40, 0.1, 3), (300, 0.0, 3), (100, 0.0, 2), (128, 0.1, 4)])
+@pytest.mark.parametrize("types,dropout,k", [(40, 0.0, 3), (40, 0.1, 3), (300, 0.0, 3), (100, 0.0, 2), (128, 0.1, 4), (600, 0.1, 3), (900, 0.25, 2)])
 def test_deferred_batches_built_inside_the_step(types, dropout, k):
     """ComplementaryIndexLoader(deferred=True) + GraphedJointStep: the batch is built by the step's first kernel
     (pc_joint_fused_step_pairs; T <= 128) or by the builder's launch inside the same call (larger tables).  Against the
@@ -253,7 +253,7 @@ def test_deferred_batches_built_inside_the_step(types, dropout, k):
     assert "_deferred" not in nb and bool((nb["query_types"] == bpg.cuda("cuda")["type_idx"][nb["query_idx"].long()]).all())
 
 
-@pytest.mark.parametrize("types,dropout", [(40, 0.1), (600, 0.0)])
+@pytest.mark.parametrize("types,dropout", [(40, 0.1), (600, 0.0), (600, 0.1)])
 def test_run_epoch_equals_the_loop_over_the_loader(types, dropout):
     """GraphedJointStep.run_epoch (pc_joint_train_epoch: train.py:36-57 as one foreign call, ragged last batch included)
     against iterating the same loader and stepping batch by batch: per-step losses and the parameters after the epoch,
