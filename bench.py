@@ -48,11 +48,8 @@ def flops_per_triplet(n, dim=128):
     return 3 * fwd - 2 * dim * 256 * (n + 7)
 
 
-NT_LAUNCHES_PER_STEP = 6
-
-
 def nt_algorithmic_bytes(b, nbc, dim=128):
-    """Compulsory HBM bytes of the 6 persistent gemm_nt_kernel launches of one step:
+    """Compulsory HBM bytes of the six persistent gemm_nt_kernel products of one step:
     rows R = [anchor B | neighbour rows nbc | positive B | negatives 5B]; per row (d = dim * 4 bytes, 1 KB = a 256-wide
     hidden row) Linear0 d + 1 KB (gathered x -> H0), Linear3 1+1+1 (H0 -> A2, and A1 = tanh(BN(H0)) saved for dW3),
     Linear5 1 KB + d (A2 -> Y), dZ2 d+1+1 (dY, A2 -> dZ2), dZ1 1+1+1 (dZ2, H0 -> dZ1); per neighbour row dKeys 2d + d
@@ -435,7 +432,9 @@ def run_p2v(args, rank, world, dev, products, steps, warmup, want_cpu, profile_k
         launches = max(nt["launches"], 1)
         sec = nt["total_ms"] * 1e-3 / launches
         fl = nt["total_flops"] / launches
-        alg = nt_algorithmic_bytes(args.batch, rows_avg + 1, dim) / NT_LAUNCHES_PER_STEP
+        # bytes of the family per STEP over its launches per step as counted (six products; the two backward ones may run as two
+        # launches each -- the positives' / negatives' rows early on a side queue: eight launches of the same bytes)
+        alg = nt_algorithmic_bytes(args.batch, rows_avg + 1, dim) / (launches / max(profiled_steps, 1))
         bound, fm, fh = two_roof(fl, alg, sec, NT_PEAK_TFLOPS)
         tfl = fl / sec / 1e12 if sec > 0 else 0.0
         gbs = alg / sec / 1e9 if sec > 0 else 0.0
@@ -454,7 +453,8 @@ def run_p2v(args, rank, world, dev, products, steps, warmup, want_cpu, profile_k
             "traffic": traffic["hbm_bytes_per_launch"] if traffic else None,
             "traffic_source": traffic["source"] if traffic else None,
             "algorithmic_bytes_per_launch": round(alg), "flops_per_launch": fl,
-            "launches": nt["launches"], "avg_launch_us": round(1e6 * sec, 2),
+            "launches": nt["launches"], "launches_per_step": round(launches / max(profiled_steps, 1), 2), "avg_launch_us": round(1e6 * sec, 2),
+            "family_us_per_step": round(1e3 * nt["total_ms"] / max(profiled_steps, 1), 1),
             "bracketed_steps": profiled_steps,              # (every PROFILE_EVERY-th timed step carries the HIP-event brackets)
             "share_of_step": round(nt["total_ms"] / max(profiled_steps, 1) / (el * 1e3 / steps), 3),
             "gemm_tn_kernel": ({"achieved_tflops": round(tn["total_flops"] / max(tn["total_ms"], 1e-9) / 1e9, 2),

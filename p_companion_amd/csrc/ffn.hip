@@ -62,44 +62,74 @@ __global__ __launch_bounds__(FIN_COLS * FIN_LANES) void bn_fold_kernel(const flo
     }
 }
 
-// gsum: NULL = statistics of this replica (fold the per-tile partials here); else the all-reduced exchange buffer
-__global__ __launch_bounds__(FIN_COLS * FIN_LANES) void bn_finalize_fwd_kernel(
+// gsum: NULL = statistics of this replica (fold the per-tile partials here); else the all-reduced exchange buffer.
+// Block = (FINF_COLS columns, FIN_LANES tile lanes, PC_MAX_SEG segments), grid = H / FINF_COLS: the four segments' folds run
+// side by side (round 3 walked them one after the other, two barriers each, in 8 workgroups: 12.6 us on the critical path
+// between Linear0 and Linear3); one thread per column then applies the four running-statistic updates in call order.
+// Per (segment, column) the arithmetic is fold_partials' own -- same lanes, same chains, same final order: same bits.
+#define FINF_COLS 8
+__global__ __launch_bounds__(FINF_COLS * FIN_LANES * PC_MAX_SEG) void bn_finalize_fwd_kernel(
     const float* psum, const float* psq, SegInfo si, const double* gsum, const float* gamma, const float* beta,
     float* running_mean, float* running_var, int64_t* nbt, int update_running, float* mean_o, float* invstd_o,
     float* scale_o, float* shift_o) {
-    __shared__ double red[2][FIN_LANES][FIN_COLS];
-    const int j = blockIdx.x * FIN_COLS + threadIdx.x, q = threadIdx.y;
-    float rm = 0.f, rv = 0.f;
-    if (q == 0 && update_running) { rm = running_mean[j]; rv = running_var[j]; }
-    int nseen = 0;
-    for (int s = 0; s < si.nseg; s++) {
-        double n = si.count[s];                               // logical rows (a weighted row counts wmult times)
-        double a = 0.0, b = 0.0;
-        if (gsum) {
-            a = gsum[(2 * s) * PC_H + j]; b = gsum[(2 * s + 1) * PC_H + j]; n = gsum[2 * PC_MAX_SEG * PC_H + s];
-        } else {
-            fold_partials(psum, psq, si.tile0[s], si.tile0[s + 1], j, q, red, &a, &b);
+    __shared__ double red[PC_MAX_SEG][2][FIN_LANES][FINF_COLS];
+    __shared__ float st_m[PC_MAX_SEG][FINF_COLS], st_u[PC_MAX_SEG][FINF_COLS];
+    __shared__ int st_ok[PC_MAX_SEG][FINF_COLS];
+    const int c = threadIdx.x, q = threadIdx.y, s = threadIdx.z;
+    const int j = blockIdx.x * FINF_COLS + c;
+    const bool live = s < si.nseg;
+    if (live && !gsum) {
+        const int t0 = si.tile0[s], t1 = si.tile0[s + 1];
+        double a = 0.0, b = 0.0, a1 = 0.0, b1 = 0.0;
+        int t = t0 + q;
+        for (; t + FIN_LANES < t1; t += 2 * FIN_LANES) {
+            a += (double)psum[(size_t)t * PC_H + j];                b += (double)psq[(size_t)t * PC_H + j];
+            a1 += (double)psum[(size_t)(t + FIN_LANES) * PC_H + j]; b1 += (double)psq[(size_t)(t + FIN_LANES) * PC_H + j];
         }
-        if (q == 0 && n > 0) {
-            const double m = a / n;
-            double var = b / n - m * m;
-            if (var < 0.0) var = 0.0;
-            const float mf = (float)m, vf = (float)var;
-            const float is = 1.0f / sqrtf(vf + BN_EPS);
-            const float sc = gamma[j] * is;
-            mean_o[s * PC_H + j] = mf;
-            invstd_o[s * PC_H + j] = is;
-            scale_o[s * PC_H + j] = sc;
-            shift_o[s * PC_H + j] = beta[j] - mf * sc;
-            if (update_running) {
-                const float unb = n > 1 ? (float)(var * (n / (n - 1))) : vf;
-                rm = BN_MOMENTUM * mf + (1.0f - BN_MOMENTUM) * rm;
-                rv = BN_MOMENTUM * unb + (1.0f - BN_MOMENTUM) * rv;
-            }
-            nseen++;
-        }
+        if (t < t1) { a += (double)psum[(size_t)t * PC_H + j]; b += (double)psq[(size_t)t * PC_H + j]; }
+        red[s][0][q][c] = a + a1;
+        red[s][1][q][c] = b + b1;
     }
-    if (q == 0 && update_running) {
+    __syncthreads();
+    if (q == 0) {
+        int ok = 0;
+        if (live) {
+            double n = si.count[s];                               // logical rows (a weighted row counts wmult times)
+            double a = 0.0, b = 0.0;
+            if (gsum) {
+                a = gsum[(2 * s) * PC_H + j]; b = gsum[(2 * s + 1) * PC_H + j]; n = gsum[2 * PC_MAX_SEG * PC_H + s];
+            } else {
+#pragma unroll 8
+                for (int i = 0; i < FIN_LANES; i++) { a += red[s][0][i][c]; b += red[s][1][i][c]; }
+            }
+            if (n > 0) {
+                const double m = a / n;
+                double var = b / n - m * m;
+                if (var < 0.0) var = 0.0;
+                const float mf = (float)m, vf = (float)var;
+                const float is = 1.0f / sqrtf(vf + BN_EPS);
+                const float sc = gamma[j] * is;
+                mean_o[s * PC_H + j] = mf;
+                invstd_o[s * PC_H + j] = is;
+                scale_o[s * PC_H + j] = sc;
+                shift_o[s * PC_H + j] = beta[j] - mf * sc;
+                st_m[s][c] = mf;
+                st_u[s][c] = n > 1 ? (float)(var * (n / (n - 1))) : vf;
+                ok = 1;
+            }
+        }
+        st_ok[s][c] = ok;
+    }
+    __syncthreads();
+    if (q == 0 && s == 0 && update_running) {
+        float rm = running_mean[j], rv = running_var[j];
+        int nseen = 0;
+        for (int k = 0; k < si.nseg; k++)
+            if (st_ok[k][c]) {
+                rm = BN_MOMENTUM * st_m[k][c] + (1.0f - BN_MOMENTUM) * rm;
+                rv = BN_MOMENTUM * st_u[k][c] + (1.0f - BN_MOMENTUM) * rv;
+                nseen++;
+            }
         running_mean[j] = rm;
         running_var[j] = rv;
         if (j == 0 && nbt) *nbt += nseen;
@@ -316,7 +346,7 @@ int ffn_forward_part2(const pc_p2v_tensors* p, int rows, const pc_segments* seg,
     hipStream_t st = (hipStream_t)stream;
     const SegInfo si = make_seginfo(seg, rows, 128);
     FfnWs w = ffn_ws_layout(ws, rows);
-    PC_LAUNCH(bn_finalize_fwd_kernel, dim3(PC_H / FIN_COLS), dim3(FIN_COLS, FIN_LANES), 0, st, w.stat_a, w.stat_b, si, global_sums,
+    PC_LAUNCH(bn_finalize_fwd_kernel, dim3(PC_H / FINF_COLS), dim3(FINF_COLS, FIN_LANES, PC_MAX_SEG), 0, st, w.stat_a, w.stat_b, si, global_sums,
               p->gamma, p->beta, p->running_mean, p->running_var, p->num_batches_tracked, update_running,
               sv->bn_mean, sv->bn_invstd, sv->bn_scale, sv->bn_shift);
     PC_TRY(pc_launch_status());

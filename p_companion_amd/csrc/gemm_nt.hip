@@ -171,17 +171,22 @@ __global__ __launch_bounds__(64 * NWM * NWN, WPS) void gemm_nt_kernel(NtArgs a, 
     };
     const float* src[NI];          // this lane's source of each DMA instruction (k0 = 0), or null for a zero row
     auto make_ptrs = [&](const int (&srow)[NIA], int nn0) {
+        // (the chunk offset is made opaque here: otherwise the loop-invariant 64-bit sums a.A + 4 lchunk / a.W + 4 lchunk are
+        // hoisted into VGPR pairs that live through the K loops and the epilogue -- the one spill of the Linear0 + statistics
+        // variant; rebuilt per tile they cost two 64-bit adds)
+        int lchunk_ = lchunk;
+        asm volatile("" : "+v"(lchunk_));
 #pragma unroll
         for (int j = 0; j < NIA; j++)
 #ifdef PC_EXP_DMA_L2
-            src[j] = srow[j] >= 0 ? a.A + (size_t)(srow[j] & 127) * a.lda + lchunk * 4 : nullptr;
+            src[j] = srow[j] >= 0 ? a.A + (size_t)(srow[j] & 127) * a.lda + lchunk_ * 4 : nullptr;
 #else
-            src[j] = srow[j] >= 0 ? a.A + (size_t)srow[j] * a.lda + lchunk * 4 : nullptr;
+            src[j] = srow[j] >= 0 ? a.A + (size_t)srow[j] * a.lda + lchunk_ * 4 : nullptr;
 #endif
 #pragma unroll
         for (int j = NIA; j < NI; j++) {
             const int n = nn0 + (w + NW * j) * RPI - BM + lrow;
-            src[j] = n < a.N ? a.W + (size_t)n * a.ldw + lchunk * 4 : nullptr;
+            src[j] = n < a.N ? a.W + (size_t)n * a.ldw + lchunk_ * 4 : nullptr;
         }
     };
     const unsigned lds_w = (unsigned)(uintptr_t)(lptr_t)&stages[0] + w * (RPI * BK * 4);   // this wave's first row block
