@@ -1165,6 +1165,66 @@ __device__ __forceinline__ void row_topk_ins(const float* row, int n, int K, int
     }
 }
 
+// The same selection at a fifth of the instructions (the first version of sample_sims_topk_kernel spent twice the matrix
+// pipe's time in row_topk_ins: ~52 VALU instructions per element): ONE 32-bit key per element -- the order-preserving image
+// of the value with its low 9 bits replaced by 511 - index -- so a lane keeps its best FOUR keys with v_max_u32 + three
+// v_med3_u32 per element and the row's best four fall out of four single-register row maxima.  Truncated keys order
+// elements exactly unless two of the first K + 1 agree in their upper 23 bits (values within 512 ulp of each other, or true
+// ties): then -- and for K > 3 -- the caller falls back to row_topk_ins.  Proof of exactness otherwise: an element outside
+// the four has a truncated value <= the fourth's < the third's, hence a true value below the third's.  n <= 512.
+__device__ __forceinline__ unsigned umed3(unsigned a, unsigned b, unsigned c) {
+    unsigned r;
+    asm("v_med3_u32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
+template <int CTRL>
+__device__ __forceinline__ unsigned dpp_row_umax(unsigned v) {
+    const unsigned o = (unsigned)__builtin_amdgcn_update_dpp((int)v, (int)v, CTRL, 0xf, 0xf, false);
+    return o > v ? o : v;
+}
+__device__ __forceinline__ bool row_topk_trunc(const float* row, int n, int K, int l16, unsigned (&oh)[FK], unsigned (&ol)[FK]) {
+    unsigned a = 0u, b = 0u, c = 0u, d = 0u;
+    if (n == TC) {
+        // a full chunk: the 20 LDS reads of the lane issued ahead of the compare chain (the rolled loop waits out one LDS
+        // latency per element)
+        float x[TC / 16];
+#pragma unroll
+        for (int i = 0; i < TC / 16; i++) x[i] = row[l16 + 16 * i];
+#pragma unroll
+        for (int i = 0; i < TC / 16; i++) {
+            const unsigned k = (ord_f32(x[i]) & ~511u) | (511u - (unsigned)(l16 + 16 * i));
+            d = umed3(c, d, k); c = umed3(b, c, k); b = umed3(a, b, k); a = a > k ? a : k;
+        }
+    } else {
+        for (int t = l16; t < n; t += 16) {
+            const unsigned k = (ord_f32(row[t]) & ~511u) | (511u - (unsigned)t);
+            d = umed3(c, d, k); c = umed3(b, c, k); b = umed3(a, b, k); a = a > k ? a : k;
+        }
+    }
+    unsigned top[4];
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+        unsigned m = a;                                        // row maximum on the rotate network: every lane gets it
+        m = dpp_row_umax<0x121>(m); m = dpp_row_umax<0x122>(m); m = dpp_row_umax<0x124>(m); m = dpp_row_umax<0x128>(m);
+        top[r] = m;
+        if (a == m) { a = b; b = c; c = d; d = 0u; }           // (keys carry their index: one owner)
+    }
+    bool exact = K <= 3;
+#pragma unroll
+    for (int r = 0; r < 3; r++)
+        if (r < K && top[r + 1] != 0u && (top[r] >> 9) == (top[r + 1] >> 9)) exact = false;
+#pragma unroll
+    for (int r = 0; r < FK; r++) {
+        oh[r] = 0u; ol[r] = 0u;
+        if (r < 3 && r < K && top[r] != 0u) {
+            const unsigned idx = 511u - (top[r] & 511u);
+            oh[r] = ord_f32(row[idx]);                          // the exact value back from LDS
+            ol[r] = ~idx;
+        }
+    }
+    return exact;
+}
+
 #define SUT 32        /* samples per tile of sample_sims_topk_kernel: 50 KB of LDS, three workgroups per CU */
 struct SampleSimsArgs {
     const float *c, *ec;
@@ -1223,7 +1283,8 @@ __global__ __launch_bounds__(256, 3) void sample_sims_topk_kernel(SampleSimsArgs
         for (int pass = 0; pass < SUT / 16; pass++) {
             const int s = 4 * (w + 4 * pass) + g4;
             unsigned kh[FK], kl[FK];
-            row_topk_ins(Sims + s * LDS_, nvalid, a.K, l16, kh, kl);
+            const bool exact = row_topk_trunc(Sims + s * LDS_, nvalid, a.K, l16, kh, kl);
+            if (__ballot(!exact)) row_topk_ins(Sims + s * LDS_, nvalid, a.K, l16, kh, kl);   // (wave-uniform; near-ties only)
             if (l16 == 0 && u0 + s < a.B)
                 for (int r = 0; r < a.K; r++) {
                     const size_t o = ((size_t)(u0 + s) * a.nchunks + blockIdx.x) * a.K + r;
@@ -1246,6 +1307,7 @@ __global__ __launch_bounds__(256, 3) void sample_sims_topk_kernel(SampleSimsArgs
 //   slab[o * Ni + i].  Operands come from LDS row-major images (row stride = width + 16 floats: the four sample rows one
 //   MFMA touches sit 16 banks apart).
 static_assert(TS == 16, "one gradient slab per 16-sample tile");
+static_assert(TC <= 512, "row_topk_trunc packs the index of a chunk's element into 9 bits");
 #define WG_S 16            /* samples per workgroup (one 16-sample subtile: 256 workgroups at B = 4096; two subtiles per
                               workgroup halve the slab bytes but leave half the CUs idle: 34 vs 2x us, measured) */
 #define WLD128 144

@@ -340,3 +340,34 @@ def test_fused_joint_step_at_reference_num_types_with_dropout_against_the_oracle
     assert torch.equal(l2, lf) and torch.equal(t2, tf)
     for (kk, a_), (_, b_) in zip(m.named_parameters(), m2.named_parameters()):
         assert torch.equal(a_, b_), kk
+
+
+@pytest.mark.parametrize("k", [1, 3, 4])
+def test_per_sample_topk_resolves_ties_like_the_dense_path(k):
+    """sample_sims_topk_kernel selects with truncated 32-bit keys and falls back to the exact two-word keys when two of a row's
+    leading candidates agree in their upper bits.  A complementary table made of 12 distinct rows repeated over T = 2000 types
+    makes EVERY similarity row a field of exact ties (each value ~167 times): the selected types must be the lowest indices of
+    the best groups, in order -- what pc_topk_rows (tie rule of torch.topk) returns on the oracle's similarity matrix."""
+    from oracle import joint_oracle, philox_oracle
+    from p_companion_amd import ops
+    from p_companion_amd.p_companion import PCompanion
+    from tests.test_gpu_round3 import joint_batch
+    T, P, B, p = 2000, 300, 200, 0.1
+    g = torch.Generator().manual_seed(3)
+    table = torch.randn(P, 128, generator=g)
+    torch.manual_seed(4)
+    m = PCompanion(cfg(NUM_TYPES=T, DROPOUT=p, NUM_COMP_TYPES=k), table).to("cuda").train()
+    with torch.no_grad():
+        base = torch.randn(12, 64, generator=g)
+        m.complementary_type_embeddings.weight.copy_(base[torch.arange(T) % 12].cuda())
+    st0 = {kk: v.detach().cpu().clone() for kk, v in m.state_dict().items()}
+    b = joint_batch(B, P, 50, seed=2)
+    tt = m.type_transition
+    tt._dropout_seed, tt._dropout_step = 99, 0
+    hmask = torch.from_numpy(philox_oracle.dropout_mask(99, 0, philox_oracle.STREAM_HIDDEN, B * 32, p)).view(B, 32)
+    _, tf = m.train_step(b)
+    ref = joint_oracle.forward(st0, b["query_idx"].cpu(), b["query_types"].cpu(), k, hidden_mask=hmask)
+    want = ops.topk_rows(ref["type_similarities"].contiguous().cuda(), k).cpu().numpy()
+    got = tf.cpu().numpy()
+    assert np.array_equal(got, want), f"{(got != want).any(1).sum()} of {B} rows differ"
+    assert (got < 12 * k + 12).all()                               # the winners are the first members of their groups
