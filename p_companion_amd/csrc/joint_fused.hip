@@ -1050,35 +1050,60 @@ __global__ __launch_bounds__(256) void type_topk_merge_kernel(const float* part_
 // ---------------------------------------------------------------------------------------------------------------
 // Large tables WITH hidden-layer dropout (the reference as shipped: config.py:12 DROPOUT = 0.1, config.py:27 NUM_TYPES = 34800;
 // type_transition.py:13-19): c = dec(mask_b (*) relu(enc t)) differs from sample to sample, so the similarity row and its
-// top-K exist per SAMPLE -- the [B,64] x [64,T] product of p_companion.py:60-63 (18 GFLOP at B = 4096), never written:
-//   sample_c_kernel          c[b] for every sample (two small layers, the step's own dropout mask: the tile kernel that follows
-//                            regenerates the same bits) -> c [B,64]
-//   sample_sims_topk_kernel  per chunk of TC types (its E_c fragments resident in registers), walking tiles of SUT samples:
-//                            sims = c E_c[chunk]^T on 16 x 16 x 4 fp32 MFMAs into LDS, the chunk's best K per sample in the
-//                            epilogue (one insertion pass per lane + K row maxima); three workgroups per CU, so one's top-K
-//                            pass (VALU / DPP) runs beside the others' products (matrix pipe)
+// top-K exist per SAMPLE -- the [B,64] x [64,T] product of p_companion.py:60-63 (18 GFLOP at B = 4096), never written.
+// The row is only used to SELECT the K types (the hinges read their two similarities from c and the E_c rows themselves), so
+// it is formed through the 32-wide hidden layer instead of the 64-wide c:  sims[b][t] = E_c[t] . (dec_w hd_b + dec_b)
+//   = G[t] . hd_b + g0[t]   with  G = E_c dec_w [T,32],  g0 = E_c dec_b [T]  (142 MFLOP, once per step), hd_b the dropped hidden
+// row -- half the multiply-adds of c E_c^T.  (Another association of the same fp32 sums: like the reference's own BLAS order,
+// it can only move a selection between two types whose similarities agree to rounding.)
+//   sample_hidden_kernel     workgroups [0, nb_s): hd[b] for every sample (the step's own dropout mask: the tile kernel that
+//                            follows regenerates the same bits) -> hd [B,32];  workgroups [nb_s, ...): G and g0
+//   sample_sims_topk_kernel  per chunk of TC types (its G fragments resident in registers), walking tiles of SUT samples:
+//                            sims = hd G[chunk]^T + g0 on 16 x 16 x 4 fp32 MFMAs into LDS, the chunk's best K per sample in the
+//                            epilogue; three workgroups per CU, so one's top-K pass (VALU / DPP) runs beside the others'
+//                            products (matrix pipe); the next tile's hd rows are requested a tile ahead
 //   type_topk_merge_kernel   (rows = samples) best K of each sample's chunk candidates -> topk[b][K]
-struct SampleCArgs {
-    const float *enc_w, *enc_b, *dec_w, *dec_b, *eq;
+struct SampleHArgs {
+    const float *enc_w, *enc_b, *dec_w, *dec_b, *eq, *ec;
     const int32_t *query_types, *pairs, *type_idx;
-    int B, T, P;
+    int B, T, P, nb_s;
     DropCfg drop;
-    float* c;
+    float *hd, *G, *g0;
 };
 
-__global__ __launch_bounds__(256) void sample_c_kernel(SampleCArgs a) {
+__global__ __launch_bounds__(256) void sample_hidden_kernel(SampleHArgs a) {
     __shared__ __attribute__((aligned(16))) float Tin[UT * LD64];
-    __shared__ __attribute__((aligned(16))) float Hs[UT * LD32];
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, ci = lane & 15, rh = lane >> 4;
+    if ((int)blockIdx.x >= a.nb_s) {
+        // ---- G[t][j] = sum_d E_c[t][d] dec_w[d][j], g0[t] = sum_d E_c[t][d] dec_b[d] for 64 types
+        const int t0 = ((int)blockIdx.x - a.nb_s) * UT;
+        const BFrag<4> f_g0 = load_b<PC_L, true>(a.dec_w, LH, 0, LH, lane), f_g1 = load_b<PC_L, true>(a.dec_w, LH, 16, LH, lane);
+        for (int e = tid; e < UT * 16; e += 256) {
+            const int r = e >> 4, c4 = (e & 15) * 4;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (t0 + r < a.T) v = *reinterpret_cast<const float4*>(a.ec + (size_t)(t0 + r) * PC_L + c4);
+            *reinterpret_cast<float4*>(&Tin[r * LD64 + c4]) = v;
+        }
+        __syncthreads();
+        const float* At = Tin + 16 * w * LD64;
+        f32x4v a0[1] = {{0.f, 0.f, 0.f, 0.f}}, a1[1] = {{0.f, 0.f, 0.f, 0.f}};
+        mul_b<4, 1>(At, LD64, 1, f_g0, a0, lane);
+        mul_b<4, 1>(At, LD64, 1, f_g1, a1, lane);
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            const int t = t0 + 16 * w + 4 * rh + r;
+            if (t < a.T) { a.G[(size_t)t * LH + ci] = a0[0][r]; a.G[(size_t)t * LH + 16 + ci] = a1[0][r]; }
+        }
+        if (tid < UT && t0 + tid < a.T) {
+            float s = 0.f;
+            for (int d = 0; d < PC_L; d++) s += Tin[tid * LD64 + d] * a.dec_b[d];
+            a.g0[t0 + tid] = s;
+        }
+        return;
+    }
     const int b0 = blockIdx.x * UT;
     const BFrag<4> f_e0 = load_b<PC_L, false>(a.enc_w, PC_L, 0, LH, lane), f_e1 = load_b<PC_L, false>(a.enc_w, PC_L, 16, LH, lane);
-    BFrag<2> f_d[4];
-#pragma unroll
-    for (int nb = 0; nb < 4; nb++) f_d[nb] = load_b<LH, false>(a.dec_w, LH, 16 * nb, PC_L, lane);
     const float bias_e0 = a.enc_b[ci], bias_e1 = a.enc_b[16 + ci];
-    float bias_d[4];
-#pragma unroll
-    for (int nb = 0; nb < 4; nb++) bias_d[nb] = a.dec_b[16 * nb + ci];
     for (int e = tid; e < UT * 16; e += 256) {
         const int r = e >> 4, c4 = (e & 15) * 4, b = b0 + r;
         float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -1093,38 +1118,25 @@ __global__ __launch_bounds__(256) void sample_c_kernel(SampleCArgs a) {
         *reinterpret_cast<float4*>(&Tin[r * LD64 + c4]) = v;
     }
     __syncthreads();
-    // wave w owns samples [16 w, 16 w + 16) of the tile through both layers (no workgroup barrier in between)
+    // wave w owns samples [16 w, 16 w + 16) of the tile
     const float* At = Tin + 16 * w * LD64;
     f32x4v a0[1] = {{0.f, 0.f, 0.f, 0.f}}, a1[1] = {{0.f, 0.f, 0.f, 0.f}};
     mul_b<4, 1>(At, LD64, 1, f_e0, a0, lane);
     mul_b<4, 1>(At, LD64, 1, f_e1, a1, lane);
 #pragma unroll
     for (int r = 0; r < 4; r++) {
-        const int row = 16 * w + 4 * rh + r;
+        const int b = b0 + 16 * w + 4 * rh + r;
         float x0 = a0[0][r] + bias_e0, x1 = a1[0][r] + bias_e1;
         x0 = x0 > 0.f ? x0 : 0.f;
         x1 = x1 > 0.f ? x1 : 0.f;
         if (a.drop.thr) {                                         // the mask of joint_tile_kernel's phase A, element for element
             float m[4];
-            pc_dropout_keep4(a.drop, (unsigned)((b0 + row) * (LH / 4) + (ci >> 2)), PC_DROP_STREAM_HIDDEN, m);
+            pc_dropout_keep4(a.drop, (unsigned)(b * (LH / 4) + (ci >> 2)), PC_DROP_STREAM_HIDDEN, m);
             x0 *= m[ci & 3];
-            pc_dropout_keep4(a.drop, (unsigned)((b0 + row) * (LH / 4) + ((16 + ci) >> 2)), PC_DROP_STREAM_HIDDEN, m);
+            pc_dropout_keep4(a.drop, (unsigned)(b * (LH / 4) + ((16 + ci) >> 2)), PC_DROP_STREAM_HIDDEN, m);
             x1 *= m[ci & 3];
         }
-        Hs[row * LD32 + ci] = x0;
-        Hs[row * LD32 + 16 + ci] = x1;
-    }
-    __builtin_amdgcn_wave_barrier();
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-#pragma unroll
-    for (int nb = 0; nb < 4; nb++) {
-        f32x4v acc[1] = {{0.f, 0.f, 0.f, 0.f}};
-        mul_b<2, 1>(Hs + 16 * w * LD32, LD32, 1, f_d[nb], acc, lane);
-#pragma unroll
-        for (int r = 0; r < 4; r++) {
-            const int b = b0 + 16 * w + 4 * rh + r;
-            if (b < a.B) a.c[(size_t)b * PC_L + 16 * nb + ci] = acc[0][r] + bias_d[nb];
-        }
+        if (b < a.B) { a.hd[(size_t)b * LH + ci] = x0; a.hd[(size_t)b * LH + 16 + ci] = x1; }
     }
 }
 
@@ -1182,16 +1194,17 @@ __device__ __forceinline__ unsigned dpp_row_umax(unsigned v) {
     const unsigned o = (unsigned)__builtin_amdgcn_update_dpp((int)v, (int)v, CTRL, 0xf, 0xf, false);
     return o > v ? o : v;
 }
+template <int FULL>
 __device__ __forceinline__ bool row_topk_trunc(const float* row, int n, int K, int l16, unsigned (&oh)[FK], unsigned (&ol)[FK]) {
     unsigned a = 0u, b = 0u, c = 0u, d = 0u;
-    if (n == TC) {
-        // a full chunk: the 20 LDS reads of the lane issued ahead of the compare chain (the rolled loop waits out one LDS
+    if (n == FULL) {
+        // a full chunk: the FULL / 16 LDS reads of the lane issued ahead of the compare chain (the rolled loop waits out one LDS
         // latency per element)
-        float x[TC / 16];
+        float x[FULL / 16];
 #pragma unroll
-        for (int i = 0; i < TC / 16; i++) x[i] = row[l16 + 16 * i];
+        for (int i = 0; i < FULL / 16; i++) x[i] = row[l16 + 16 * i];
 #pragma unroll
-        for (int i = 0; i < TC / 16; i++) {
+        for (int i = 0; i < FULL / 16; i++) {
             const unsigned k = (ord_f32(x[i]) & ~511u) | (511u - (unsigned)(l16 + 16 * i));
             d = umed3(c, d, k); c = umed3(b, c, k); b = umed3(a, b, k); a = a > k ? a : k;
         }
@@ -1225,19 +1238,25 @@ __device__ __forceinline__ bool row_topk_trunc(const float* row, int n, int K, i
     return exact;
 }
 
-#define SUT 32        /* samples per tile of sample_sims_topk_kernel: 50 KB of LDS, three workgroups per CU */
+#define SUT 32        /* samples per tile of sample_sims_topk_kernel */
+#ifndef PC_STC
+#define PC_STC 256    /* types per chunk of sample_sims_topk_kernel: 38 KB of LDS and 118 VGPRs, FOUR workgroups per CU
+                         (320 with three: 0.315 against 0.301 ms per step at T = 34800, B = 4096, alternating runs on one box) */
+#endif
+#define STC PC_STC
+#define SWPS (STC <= 256 ? 4 : 3)   /* workgroups per CU: LDS = SUT (36 + STC + 4) floats */
 struct SampleSimsArgs {
-    const float *c, *ec;
+    const float *hd, *G, *g0;
     int B, T, K, nchunks;
     float* part_val; int32_t* part_idx;     // [B][nchunks][K]
     float* zero[2]; size_t nzero[2]; int zcols;      // rider: see TypeSimsArgs
 };
 
-__global__ __launch_bounds__(256, 3) void sample_sims_topk_kernel(SampleSimsArgs a) {
+__global__ __launch_bounds__(256, SWPS) void sample_sims_topk_kernel(SampleSimsArgs a) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
-    float* Cs = sm;                         // [SUT][LD64]
-    float* Sims = Cs + SUT * LD64;          // [SUT][TC + 4]
-    constexpr int LDS_ = TC + 4;
+    float* Hd = sm;                         // [SUT][LD32]
+    float* Sims = Hd + SUT * LD32;          // [SUT][STC + 4]
+    constexpr int LDS_ = STC + 4;
     if ((int)blockIdx.x >= a.nchunks) {
         const size_t wg = ((size_t)blockIdx.x - a.nchunks) * gridDim.y + blockIdx.y, nwg = (size_t)a.zcols * gridDim.y;
         for (int i = 0; i < 2; i++) {
@@ -1248,22 +1267,30 @@ __global__ __launch_bounds__(256, 3) void sample_sims_topk_kernel(SampleSimsArgs
         }
         return;
     }
-    const int t0 = blockIdx.x * TC;
+    const int t0 = blockIdx.x * STC;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, ci = lane & 15, rh = lane >> 4;
-    constexpr int NBW = TC / 16 / 4;                       // E_c column blocks per wave, resident for the whole kernel
-    BFrag<4> f_s[NBW];
+    constexpr int NBW = STC / 16 / 4;                       // G column blocks per wave, resident for the whole kernel
+    BFrag<2> f_s[NBW];
+    float g0v[NBW];
 #pragma unroll
-    for (int q = 0; q < NBW; q++) f_s[q] = load_b<PC_L, false>(a.ec, PC_L, t0 + 16 * (w + 4 * q), a.T, lane);
-    const int nvalid = min(TC, a.T - t0);
+    for (int q = 0; q < NBW; q++) {
+        const int t = t0 + 16 * (w + 4 * q) + ci;
+        f_s[q] = load_b<LH, false>(a.G, LH, t0 + 16 * (w + 4 * q), a.T, lane);
+        g0v[q] = t < a.T ? a.g0[t] : 0.f;
+    }
+    const int nvalid = min(STC, a.T - t0);
     const int g4 = lane >> 4, l16 = lane & 15;
-    for (int u0 = blockIdx.y * SUT; u0 < a.B; u0 += gridDim.y * SUT) {
-        __syncthreads();                                   // (the previous tile's top-K pass has left Sims / Cs)
-        for (int e = tid; e < SUT * 16; e += 256) {
-            const int r = e >> 4, c4 = (e & 15) * 4;
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (u0 + r < a.B) v = *reinterpret_cast<const float4*>(a.c + (size_t)(u0 + r) * PC_L + c4);
-            *reinterpret_cast<float4*>(&Cs[r * LD64 + c4]) = v;
-        }
+    // this thread's 16-B piece of a tile's hd rows (SUT x 32 floats = one float4 per thread), requested a tile ahead
+    const int pr = tid >> 3, pc4 = (tid & 7) * 4;
+    auto fetch = [&](int u0) {
+        return u0 + pr < a.B ? *reinterpret_cast<const float4*>(a.hd + (size_t)(u0 + pr) * LH + pc4) : make_float4(0.f, 0.f, 0.f, 0.f);
+    };
+    const int ustep = gridDim.y * SUT;
+    float4 nxt = fetch(blockIdx.y * SUT);
+    for (int u0 = blockIdx.y * SUT; u0 < a.B; u0 += ustep) {
+        __syncthreads();                                   // (the previous tile's top-K pass has left Sims / Hd)
+        *reinterpret_cast<float4*>(&Hd[pr * LD32 + pc4]) = nxt;
+        if (u0 + ustep < a.B) nxt = fetch(u0 + ustep);
         __syncthreads();
 #pragma unroll
         for (int q = 0; q < NBW; q++) {
@@ -1271,11 +1298,11 @@ __global__ __launch_bounds__(256, 3) void sample_sims_topk_kernel(SampleSimsArgs
             f32x4v acc[SUT / 16];
 #pragma unroll
             for (int m = 0; m < SUT / 16; m++) acc[m] = f32x4v{0.f, 0.f, 0.f, 0.f};
-            mul_b<4, SUT / 16>(Cs, LD64, SUT / 16, f_s[q], acc, lane);
+            mul_b<2, SUT / 16>(Hd, LD32, SUT / 16, f_s[q], acc, lane);
 #pragma unroll
             for (int m = 0; m < SUT / 16; m++)
 #pragma unroll
-                for (int r = 0; r < 4; r++) Sims[(16 * m + 4 * rh + r) * LDS_ + 16 * nb + ci] = acc[m][r];
+                for (int r = 0; r < 4; r++) Sims[(16 * m + 4 * rh + r) * LDS_ + 16 * nb + ci] = acc[m][r] + g0v[q];
         }
         __syncthreads();
         // a row group of 16 lanes per sample, four samples per wave side by side: SUT / 16 passes
@@ -1283,7 +1310,7 @@ __global__ __launch_bounds__(256, 3) void sample_sims_topk_kernel(SampleSimsArgs
         for (int pass = 0; pass < SUT / 16; pass++) {
             const int s = 4 * (w + 4 * pass) + g4;
             unsigned kh[FK], kl[FK];
-            const bool exact = row_topk_trunc(Sims + s * LDS_, nvalid, a.K, l16, kh, kl);
+            const bool exact = row_topk_trunc<STC>(Sims + s * LDS_, nvalid, a.K, l16, kh, kl);
             if (__ballot(!exact)) row_topk_ins(Sims + s * LDS_, nvalid, a.K, l16, kh, kl);   // (wave-uniform; near-ties only)
             if (l16 == 0 && u0 + s < a.B)
                 for (int r = 0; r < a.K; r++) {
@@ -1307,7 +1334,7 @@ __global__ __launch_bounds__(256, 3) void sample_sims_topk_kernel(SampleSimsArgs
 //   slab[o * Ni + i].  Operands come from LDS row-major images (row stride = width + 16 floats: the four sample rows one
 //   MFMA touches sit 16 banks apart).
 static_assert(TS == 16, "one gradient slab per 16-sample tile");
-static_assert(TC <= 512, "row_topk_trunc packs the index of a chunk's element into 9 bits");
+static_assert(PC_STC <= 512 && PC_STC % 64 == 0, "row_topk_trunc packs the index of a chunk's element into 9 bits");
 #define WG_S 16            /* samples per workgroup (one 16-sample subtile: 256 workgroups at B = 4096; two subtiles per
                               workgroup halve the slab bytes but leave half the CUs idle: 34 vs 2x us, measured) */
 #define WLD128 144
@@ -1783,9 +1810,9 @@ struct FusedWs {
     int32_t *tl_c, *tp_c, *tl_q, *tp_q, *n_touch;       // touched rows of the two big tables: ascending lists, row -> list position
     float *tslab_c, *tslab_q;                           // [TG_WGS][TG_CAP][64] each
     float* part_val;
-    float* csamp;                                       // [B][64]: c per sample (large tables with hidden-layer dropout)
+    float *csamp, *gmat, *g0;                           // large tables with hidden-layer dropout: hd [B][32], G = E_c dec_w [T][32], g0 = E_c dec_b [T]
     float* wslabs; int wg_blocks, wslab_floats;      // joint_wgrad_kernel: one slab per workgroup
-    int nchunks, ucap;
+    int nchunks, nchunks_s, ucap;      // chunks of the per-type / per-sample similarity kernels
     bool small;
     size_t total;
 };
@@ -1812,12 +1839,12 @@ static FusedWs fused_ws_layout(void* base, int B, int T, int K) {
     w.wg_blocks = (B + WG_S - 1) / WG_S;
     w.wslab_floats = wg_slab_floats(w.small ? T : 0);      // (large tables: their gradients go by row scatter-add)
     w.wslabs = (float*)take((size_t)w.wg_blocks * w.wslab_floats * 4);
-    w.nchunks = w.ucap = 0;
+    w.nchunks = w.nchunks_s = w.ucap = 0;
     w.ulist = w.n_u = w.topk_by_type = w.part_idx = nullptr;
     w.tl_c = w.tp_c = w.tl_q = w.tp_q = w.n_touch = nullptr;
     w.tslab_c = w.tslab_q = nullptr;
     w.part_val = nullptr;
-    w.csamp = nullptr;
+    w.csamp = w.gmat = w.g0 = nullptr;
     if (w.small) {
     } else {
         const int nc = B * (K + 2);
@@ -1829,14 +1856,18 @@ static FusedWs fused_ws_layout(void* base, int B, int T, int K) {
         w.tslab_c = (float*)take((size_t)TG_WGS * TG_CAP * PC_L * 4);
         w.tslab_q = (float*)take((size_t)TG_WGS * TG_CAP * PC_L * 4);
         w.nchunks = (T + TC - 1) / TC;
+        w.nchunks_s = (T + PC_STC - 1) / PC_STC;
         w.ucap = B < T ? B : T;
         w.ulist = (int32_t*)take((size_t)w.ucap * 4);
         w.n_u = (int32_t*)take(256);
         // (sized for either regime: rows = distinct query types without dropout, = the B samples with it)
         w.topk_by_type = (int32_t*)take((size_t)(T > B ? T : B) * K * 4);
-        w.part_val = (float*)take((size_t)B * w.nchunks * K * 4);
-        w.part_idx = (int32_t*)take((size_t)B * w.nchunks * K * 4);
-        w.csamp = (float*)take((size_t)B * PC_L * 4);
+        const int ncmax = w.nchunks > w.nchunks_s ? w.nchunks : w.nchunks_s;
+        w.part_val = (float*)take((size_t)B * ncmax * K * 4);
+        w.part_idx = (int32_t*)take((size_t)B * ncmax * K * 4);
+        w.csamp = (float*)take((size_t)B * LH * 4);                // hd: the dropped hidden rows
+        w.gmat = (float*)take((size_t)T * LH * 4);
+        w.g0 = (float*)take((size_t)T * 4);
     }
     w.total = off;
     return w;
@@ -1909,23 +1940,23 @@ static int fused_step_impl(const pc_joint_tensors* p, const pc_joint_tensors* g,
 
     const bool per_sample = !w.small && p->dropout.p > 0.f;      // hidden-layer dropout: c is a function of the SAMPLE
     if (per_sample) {
-        SampleCArgs ca = {p->enc_w, p->enc_b, p->dec_w, p->dec_b, p->query_types, query_types,
+        SampleHArgs ca = {p->enc_w, p->enc_b, p->dec_w, p->dec_b, p->query_types, p->comp_types, query_types,
                           pairs_in_tile ? src->pairs : nullptr, pairs_in_tile ? src->type_idx : nullptr, B, T, num_products,
-                          make_dropcfg(p->dropout), w.csamp};
-        PC_LAUNCH(sample_c_kernel, dim3((B + UT - 1) / UT), dim3(256), 0, st, ca);
+                          (B + UT - 1) / UT, make_dropcfg(p->dropout), w.csamp, w.gmat, w.g0};
+        PC_LAUNCH(sample_hidden_kernel, dim3(ca.nb_s + (T + UT - 1) / UT), dim3(256), 0, st, ca);
         SampleSimsArgs sa = {};
-        sa.c = w.csamp; sa.ec = p->comp_types; sa.B = B; sa.T = T; sa.K = K; sa.nchunks = w.nchunks;
+        sa.hd = w.csamp; sa.G = w.gmat; sa.g0 = w.g0; sa.B = B; sa.T = T; sa.K = K; sa.nchunks = w.nchunks_s;
         sa.part_val = w.part_val; sa.part_idx = w.part_idx;
         sa.zero[0] = g->query_types; sa.nzero[0] = (size_t)T * PC_L; sa.zero[1] = g->comp_types; sa.nzero[1] = (size_t)T * PC_L;
         sa.zcols = 8;
-        const size_t lds = ((size_t)SUT * LD64 + (size_t)SUT * (TC + 4)) * 4;
+        const size_t lds = ((size_t)SUT * LD32 + (size_t)SUT * (STC + 4)) * 4;
         const int tiles_s = (B + SUT - 1) / SUT;
-        // three workgroups per CU: y so that chunks x y fills 768 slots (each workgroup then walks its share of the sample tiles)
-        int gy = (768 - sa.zcols) / (w.nchunks > 0 ? w.nchunks : 1);
+        // SWPS workgroups per CU: y so that chunks x y fills the chip's slots (each workgroup then walks its share of the sample tiles)
+        int gy = (256 * SWPS - sa.zcols) / (sa.nchunks > 0 ? sa.nchunks : 1);
         gy = gy < 1 ? 1 : gy > tiles_s ? tiles_s : gy;
-        PC_LAUNCH(sample_sims_topk_kernel, dim3(w.nchunks + sa.zcols, gy), dim3(256), lds, st, sa);
+        PC_LAUNCH(sample_sims_topk_kernel, dim3(sa.nchunks + sa.zcols, gy), dim3(256), lds, st, sa);
         PC_LAUNCH(type_topk_merge_kernel, dim3((B + 3) / 4), dim3(256), 0, st, w.part_val, w.part_idx, nullptr, nullptr, B,
-                  w.nchunks, K, w.topk_by_type);
+                  sa.nchunks, K, w.topk_by_type);
         PC_TRY(pc_launch_status());
     } else if (!w.small) {
         // the dense gradients of the two big tables hold zeros outside the touched rows (and receive float atomics beyond
