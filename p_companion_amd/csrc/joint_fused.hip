@@ -209,6 +209,110 @@ __device__ __forceinline__ void row_topk(const float* row, int T, int K, int l16
     }
 }
 
+// inverse of ord_f32
+__device__ __forceinline__ float unord_f32(unsigned k) {
+    return __uint_as_float((k & 0x80000000u) ? (k ^ 0x80000000u) : ~k);
+}
+
+// top-K of one LDS row of n values by the 16 lanes of a row group, ONE pass over the row: every lane keeps the best FK keys
+// (value, ~index) of its strided elements in a sorted register list, then K rounds of a row maximum whose owner retires
+// its head.  Same order as row_topk (descending, ties -> the lower index); (0, 0) = none (fewer than K values).
+__device__ __forceinline__ void row_topk_ins(const float* row, int n, int K, int l16, unsigned (&oh)[FK], unsigned (&ol)[FK]) {
+    unsigned kh[FK], kl[FK];
+#pragma unroll
+    for (int j = 0; j < FK; j++) { kh[j] = 0u; kl[j] = 0u; oh[j] = 0u; ol[j] = 0u; }
+    for (int t = l16; t < n; t += 16) {
+        unsigned h = ord_f32(row[t]), l = ~(unsigned)t;
+#pragma unroll
+        for (int j = 0; j < FK; j++) {
+            const bool gt = h > kh[j] || (h == kh[j] && l > kl[j]);
+            const unsigned th = gt ? kh[j] : h, tl = gt ? kl[j] : l;
+            kh[j] = gt ? h : kh[j]; kl[j] = gt ? l : kl[j];
+            h = th; l = tl;
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < FK; r++) {
+        if (r < K) {
+            unsigned bh = kh[0], bl = kl[0];
+            row_maxkey(bh, bl);
+            if (kh[0] == bh && kl[0] == bl) {                      // (keys are distinct: exactly one lane owns the winner)
+#pragma unroll
+                for (int j = 0; j < FK - 1; j++) { kh[j] = kh[j + 1]; kl[j] = kl[j + 1]; }
+                kh[FK - 1] = 0u; kl[FK - 1] = 0u;
+            }
+            oh[r] = bh; ol[r] = bl;
+        }
+    }
+}
+
+// The same selection at a fifth of the instructions (the first version of sample_sims_topk_kernel spent twice the matrix
+// pipe's time in row_topk_ins: ~52 VALU instructions per element): ONE 32-bit key per element -- the order-preserving image
+// of the value with its low 9 bits replaced by 511 - index -- so a lane keeps its best FOUR keys with v_max_u32 + three
+// v_med3_u32 per element and the row's best four fall out of four single-register row maxima.  Truncated keys order
+// elements exactly unless two of the first K + 1 agree in their upper 23 bits (values within 512 ulp of each other, or true
+// ties): then -- and for K > 3 -- the caller falls back to row_topk_ins.  Proof of exactness otherwise: an element outside
+// the four has a truncated value <= the fourth's < the third's, hence a true value below the third's.  n <= 512.
+__device__ __forceinline__ unsigned umed3(unsigned a, unsigned b, unsigned c) {
+    unsigned r;
+    asm("v_med3_u32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
+template <int CTRL>
+__device__ __forceinline__ unsigned dpp_row_umax(unsigned v) {
+    const unsigned o = (unsigned)__builtin_amdgcn_update_dpp((int)v, (int)v, CTRL, 0xf, 0xf, false);
+    return o > v ? o : v;
+}
+template <int FULL>
+__device__ __forceinline__ bool row_topk_trunc(const float* row, int n, int K, int l16, unsigned (&oh)[FK], unsigned (&ol)[FK]) {
+    unsigned a = 0u, b = 0u, c = 0u, d = 0u;
+    if (FULL > 0 && n == FULL) {
+        // a full chunk: the FULL / 16 LDS reads of the lane issued ahead of the compare chain (the rolled loop waits out one LDS
+        // latency per element)
+        float x[FULL > 0 ? FULL / 16 : 1];
+#pragma unroll
+        for (int i = 0; i < FULL / 16; i++) x[i] = row[l16 + 16 * i];
+#pragma unroll
+        for (int i = 0; i < FULL / 16; i++) {
+            const unsigned k = (ord_f32(x[i]) & ~511u) | (511u - (unsigned)(l16 + 16 * i));
+            d = umed3(c, d, k); c = umed3(b, c, k); b = umed3(a, b, k); a = a > k ? a : k;
+        }
+    } else {
+        for (int t = l16; t < n; t += 64) {                    // four reads in flight per round; a key of 0 changes nothing
+            float x[4];
+#pragma unroll
+            for (int j = 0; j < 4; j++) x[j] = t + 16 * j < n ? row[t + 16 * j] : 0.f;
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const unsigned k = t + 16 * j < n ? ((ord_f32(x[j]) & ~511u) | (511u - (unsigned)(t + 16 * j))) : 0u;
+                d = umed3(c, d, k); c = umed3(b, c, k); b = umed3(a, b, k); a = a > k ? a : k;
+            }
+        }
+    }
+    unsigned top[4];
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+        unsigned m = a;                                        // row maximum on the rotate network: every lane gets it
+        m = dpp_row_umax<0x121>(m); m = dpp_row_umax<0x122>(m); m = dpp_row_umax<0x124>(m); m = dpp_row_umax<0x128>(m);
+        top[r] = m;
+        if (a == m) { a = b; b = c; c = d; d = 0u; }           // (keys carry their index: one owner)
+    }
+    bool exact = K <= 3;
+#pragma unroll
+    for (int r = 0; r < 3; r++)
+        if (r < K && top[r + 1] != 0u && (top[r] >> 9) == (top[r + 1] >> 9)) exact = false;
+#pragma unroll
+    for (int r = 0; r < FK; r++) {
+        oh[r] = 0u; ol[r] = 0u;
+        if (r < 3 && r < K && top[r] != 0u) {
+            const unsigned idx = 511u - (top[r] & 511u);
+            oh[r] = ord_f32(row[idx]);                          // the exact value back from LDS
+            ol[r] = ~idx;
+        }
+    }
+    return exact;
+}
+
 // per-workgroup gradient slab: itm_w | itm_b | typ_w | typ_b | dec_w | dec_b | enc_w | enc_b | E_c | E_q
 __host__ __device__ inline int wg_off_itm_w() { return 0; }
 __host__ __device__ inline int wg_off_itm_b() { return PC_D * PC_D; }
@@ -454,8 +558,15 @@ __global__ __launch_bounds__(256) void joint_tile_kernel(FusedArgs a, int ldsims
         phase_sync();
         PC_STAMP(5);
         {
+            // (one-word truncated keys; exact two-word fallback on near-ties and for K = 4: see row_topk_trunc)
             int idx[FK];
-            row_topk<KC>(Sims + sF * ldsims, a.T, K, l16, idx);
+            {
+                unsigned kh[FK], kl[FK];
+                const bool exact = row_topk_trunc<0>(Sims + sF * ldsims, a.T, K, l16, kh, kl);
+                if (__ballot(!exact)) row_topk_ins(Sims + sF * ldsims, a.T, K, l16, kh, kl);
+#pragma unroll
+                for (int r = 0; r < FK; r++) idx[r] = (kh[r] | kl[r]) != 0u ? (int)~kl[r] : -1;
+            }
             if (l16 == 0)
 #pragma unroll
                 for (int k = 0; k < FK; k++)
@@ -1138,104 +1249,6 @@ __global__ __launch_bounds__(256) void sample_hidden_kernel(SampleHArgs a) {
         }
         if (b < a.B) { a.hd[(size_t)b * LH + ci] = x0; a.hd[(size_t)b * LH + 16 + ci] = x1; }
     }
-}
-
-// inverse of ord_f32
-__device__ __forceinline__ float unord_f32(unsigned k) {
-    return __uint_as_float((k & 0x80000000u) ? (k ^ 0x80000000u) : ~k);
-}
-
-// top-K of one LDS row of n values by the 16 lanes of a row group, ONE pass over the row: every lane keeps the best FK keys
-// (value, ~index) of its strided elements in a sorted register list, then K rounds of a row maximum whose owner retires
-// its head.  Same order as row_topk (descending, ties -> the lower index); (0, 0) = none (fewer than K values).
-__device__ __forceinline__ void row_topk_ins(const float* row, int n, int K, int l16, unsigned (&oh)[FK], unsigned (&ol)[FK]) {
-    unsigned kh[FK], kl[FK];
-#pragma unroll
-    for (int j = 0; j < FK; j++) { kh[j] = 0u; kl[j] = 0u; oh[j] = 0u; ol[j] = 0u; }
-    for (int t = l16; t < n; t += 16) {
-        unsigned h = ord_f32(row[t]), l = ~(unsigned)t;
-#pragma unroll
-        for (int j = 0; j < FK; j++) {
-            const bool gt = h > kh[j] || (h == kh[j] && l > kl[j]);
-            const unsigned th = gt ? kh[j] : h, tl = gt ? kl[j] : l;
-            kh[j] = gt ? h : kh[j]; kl[j] = gt ? l : kl[j];
-            h = th; l = tl;
-        }
-    }
-#pragma unroll
-    for (int r = 0; r < FK; r++) {
-        if (r < K) {
-            unsigned bh = kh[0], bl = kl[0];
-            row_maxkey(bh, bl);
-            if (kh[0] == bh && kl[0] == bl) {                      // (keys are distinct: exactly one lane owns the winner)
-#pragma unroll
-                for (int j = 0; j < FK - 1; j++) { kh[j] = kh[j + 1]; kl[j] = kl[j + 1]; }
-                kh[FK - 1] = 0u; kl[FK - 1] = 0u;
-            }
-            oh[r] = bh; ol[r] = bl;
-        }
-    }
-}
-
-// The same selection at a fifth of the instructions (the first version of sample_sims_topk_kernel spent twice the matrix
-// pipe's time in row_topk_ins: ~52 VALU instructions per element): ONE 32-bit key per element -- the order-preserving image
-// of the value with its low 9 bits replaced by 511 - index -- so a lane keeps its best FOUR keys with v_max_u32 + three
-// v_med3_u32 per element and the row's best four fall out of four single-register row maxima.  Truncated keys order
-// elements exactly unless two of the first K + 1 agree in their upper 23 bits (values within 512 ulp of each other, or true
-// ties): then -- and for K > 3 -- the caller falls back to row_topk_ins.  Proof of exactness otherwise: an element outside
-// the four has a truncated value <= the fourth's < the third's, hence a true value below the third's.  n <= 512.
-__device__ __forceinline__ unsigned umed3(unsigned a, unsigned b, unsigned c) {
-    unsigned r;
-    asm("v_med3_u32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
-    return r;
-}
-template <int CTRL>
-__device__ __forceinline__ unsigned dpp_row_umax(unsigned v) {
-    const unsigned o = (unsigned)__builtin_amdgcn_update_dpp((int)v, (int)v, CTRL, 0xf, 0xf, false);
-    return o > v ? o : v;
-}
-template <int FULL>
-__device__ __forceinline__ bool row_topk_trunc(const float* row, int n, int K, int l16, unsigned (&oh)[FK], unsigned (&ol)[FK]) {
-    unsigned a = 0u, b = 0u, c = 0u, d = 0u;
-    if (n == FULL) {
-        // a full chunk: the FULL / 16 LDS reads of the lane issued ahead of the compare chain (the rolled loop waits out one LDS
-        // latency per element)
-        float x[FULL / 16];
-#pragma unroll
-        for (int i = 0; i < FULL / 16; i++) x[i] = row[l16 + 16 * i];
-#pragma unroll
-        for (int i = 0; i < FULL / 16; i++) {
-            const unsigned k = (ord_f32(x[i]) & ~511u) | (511u - (unsigned)(l16 + 16 * i));
-            d = umed3(c, d, k); c = umed3(b, c, k); b = umed3(a, b, k); a = a > k ? a : k;
-        }
-    } else {
-        for (int t = l16; t < n; t += 16) {
-            const unsigned k = (ord_f32(row[t]) & ~511u) | (511u - (unsigned)t);
-            d = umed3(c, d, k); c = umed3(b, c, k); b = umed3(a, b, k); a = a > k ? a : k;
-        }
-    }
-    unsigned top[4];
-#pragma unroll
-    for (int r = 0; r < 4; r++) {
-        unsigned m = a;                                        // row maximum on the rotate network: every lane gets it
-        m = dpp_row_umax<0x121>(m); m = dpp_row_umax<0x122>(m); m = dpp_row_umax<0x124>(m); m = dpp_row_umax<0x128>(m);
-        top[r] = m;
-        if (a == m) { a = b; b = c; c = d; d = 0u; }           // (keys carry their index: one owner)
-    }
-    bool exact = K <= 3;
-#pragma unroll
-    for (int r = 0; r < 3; r++)
-        if (r < K && top[r + 1] != 0u && (top[r] >> 9) == (top[r + 1] >> 9)) exact = false;
-#pragma unroll
-    for (int r = 0; r < FK; r++) {
-        oh[r] = 0u; ol[r] = 0u;
-        if (r < 3 && r < K && top[r] != 0u) {
-            const unsigned idx = 511u - (top[r] & 511u);
-            oh[r] = ord_f32(row[idx]);                          // the exact value back from LDS
-            ol[r] = ~idx;
-        }
-    }
-    return exact;
 }
 
 #define SUT 32        /* samples per tile of sample_sims_topk_kernel */
