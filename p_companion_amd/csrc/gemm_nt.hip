@@ -31,6 +31,7 @@
 // Operands are fetched with a permuted k order (lanes 0-31 take k = 8j..8j+3, lanes 32-63
 // k = 8j+4..8j+7, identically for A and W) so one ds_read_b128 feeds four MFMAs.
 #include "common.h"
+#include "mfma16.h"
 
 #define PLD 36          // row stride (floats) of the per-wave epilogue transposition patch
 #define PROWS 16        // rows per patch: half a 32x32 accumulator block
@@ -786,6 +787,121 @@ __global__ __launch_bounds__(256) void gemm_nt_chain_kernel(NtChain c) {
     }
 }
 
+// The same two chains on 16-row tiles and v_mfma_f32_16x16x4_f32 (round 4): 256 workgroups at B = 4096 instead of 128 (the
+// 32-row bodies above were bound by the matrix pipes of the half of the chip that held a tile: 2.7 us of MFMA per body),
+// the weight fragments of BOTH stages requested at kernel entry straight from L2 into registers (no LDS image of W: 64 KB of
+// staging per stage gone), and the first stage's result handed to the second through LDS (it is also stored: q, ctx, dctx and dq
+// are read again later in the step) instead of through a store / vmcnt(0) / reload round trip.
+//   AHEAD_FIRST = false:  PLAIN -> KHEAD   (q -> qt, dctx -> dc)
+//   AHEAD_FIRST = true:   AHEAD -> PLAIN   (c -> ctx -> out, dqt -> dq -> dquery)
+#define CH_LDA 132          /* LDS row strides: width + 4 floats */
+#define CH_LDA4 516
+template <bool AHEAD_FIRST>
+__global__ __launch_bounds__(256) void gemm_nt_chain16_kernel(NtChain c) {
+    __shared__ __attribute__((aligned(16))) float sA[16 * (AHEAD_FIRST ? CH_LDA4 : CH_LDA)];
+    __shared__ __attribute__((aligned(16))) float sS[16 * CH_LDA];
+    if ((int)blockIdx.x >= c.tiles) {                            // the rider's workgroup (see HingeMeanJob)
+        __shared__ float red[256];
+        hinge_mean_body(c.rider, red);
+        return;
+    }
+    const int tid = threadIdx.x, lane = tid & 63, ci = lane & 15, rh = lane >> 4;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const NtArgs& a0 = c.a[0];
+    const NtArgs& a1 = c.a[1];
+    const int row0 = blockIdx.x * 16, M = a0.M;
+    auto lds_sync = [&]() {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+    };
+    // a PLAIN stage over the 16 x 128 LDS tile `src`: wave w owns the column blocks 2 w, 2 w + 1
+    auto plain = [&](const NtArgs& a, const BFrag<8> (&f)[2], const float* src, float* keep) {
+#pragma unroll
+        for (int j = 0; j < 2; j++) {
+            f32x4v acc[1] = {{0.f, 0.f, 0.f, 0.f}};
+            mul_b<8, 1>(src, CH_LDA, 1, f[j], acc, lane);
+            const int col = 16 * (2 * w + j) + ci;
+            const float bias = a.bias ? a.bias[col] : 0.f;
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                const int row = 4 * rh + r;
+                const float v = acc[0][r] + bias;
+                if (keep) keep[row * CH_LDA + col] = v;
+                if (row0 + row < M) a.C[(size_t)(row0 + row) * a.ldc + col] = v;
+            }
+        }
+    };
+    if (!AHEAD_FIRST) {
+        BFrag<8> fp[2];
+        BFrag<2> fk[8];
+#pragma unroll
+        for (int j = 0; j < 2; j++) fp[j] = load_b<128, false>(a0.W, a0.ldw, 16 * (2 * w + j), 128, lane);
+#pragma unroll
+        for (int nb = 0; nb < 8; nb++) fk[nb] = load_b<32, false>(a1.W + 32 * w, a1.ldw, 16 * nb, 128, lane);
+#pragma unroll
+        for (int u = 0; u < 2; u++) {
+            const int e = tid + 256 * u, r = e >> 5, c4 = (e & 31) * 4;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (row0 + r < M) v = *reinterpret_cast<const float4*>(a0.A + (size_t)(row0 + r) * a0.lda + c4);
+            *reinterpret_cast<float4*>(&sA[r * CH_LDA + c4]) = v;
+        }
+        lds_sync();
+        plain(a0, fp, sA, sS);
+        lds_sync();
+        // KHEAD: wave h multiplies its head's 32 k's against all eight column blocks; C[r][128 h + d]
+#pragma unroll
+        for (int nb = 0; nb < 8; nb++) {
+            f32x4v acc[1] = {{0.f, 0.f, 0.f, 0.f}};
+            mul_b<2, 1>(sS + 32 * w, CH_LDA, 1, fk[nb], acc, lane);
+            const int col = 128 * w + 16 * nb + ci;
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                const int row = 4 * rh + r;
+                if (row0 + row < M) a1.C[(size_t)(row0 + row) * a1.ldc + col] = acc[0][r];
+            }
+        }
+    } else {
+        BFrag<8> fa[2], fp[2];
+#pragma unroll
+        for (int j = 0; j < 2; j++) fa[j] = load_b<128, false>(a0.W, a0.ldw, 32 * w + 16 * j, 128, lane);
+#pragma unroll
+        for (int j = 0; j < 2; j++) fp[j] = load_b<128, false>(a1.W, a1.ldw, 16 * (2 * w + j), 128, lane);
+        float4 x[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+            const int e = tid + 256 * u, r = e >> 7, c4 = (e & 127) * 4;
+            x[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (row0 + r < M) x[u] = *reinterpret_cast<const float4*>(a0.A + (size_t)(row0 + r) * a0.lda + c4);
+        }
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+            const int e = tid + 256 * u, r = e >> 7, c4 = (e & 127) * 4;
+            *reinterpret_cast<float4*>(&sA[r * CH_LDA4 + c4]) = x[u];
+        }
+        lds_sync();
+        // AHEAD: wave h takes image h (columns [128 h, 128 h + 128) of the tile) and its own 32 output columns
+#pragma unroll
+        for (int j = 0; j < 2; j++) {
+            f32x4v acc[1] = {{0.f, 0.f, 0.f, 0.f}};
+            mul_b<8, 1>(sA + 128 * w, CH_LDA4, 1, fa[j], acc, lane);
+            const int col = 32 * w + 16 * j + ci;
+            const float bias = a0.bias ? a0.bias[col] : 0.f;
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                const int row = 4 * rh + r;
+                const bool live = row0 + row < M;
+                const float rs = (a0.brs && live) ? a0.brs[(size_t)(row0 + row) * a0.ldbrs + w] : 1.f;
+                const float v = acc[0][r] + bias * rs;
+                sS[row * CH_LDA + col] = v;
+                if (live) a0.C[(size_t)(row0 + row) * a0.ldc + col] = v;
+            }
+        }
+        lds_sync();
+        plain(a1, fp, sS, nullptr);
+    }
+}
+
 // D = 128 attention chains only: every stage M rows (the same M), K = N = 128 per plain stage / head structure above.
 int launch_gemm_nt_chain(const NtArgs* args, const int* modes, int n, hipStream_t st, const HingeMeanJob* rider) {
     if (!args || !modes || n < 1 || n > 2) return PC_EINVAL;
@@ -811,6 +927,16 @@ int launch_gemm_nt_chain(const NtArgs* args, const int* modes, int n, hipStream_
     if (rider) {
         if (!rider->d_pos || !rider->d_neg || !rider->loss || rider->B <= 0) return PC_EINVAL;
         c.rider = *rider;
+    }
+    if (n == 2 && ((modes[0] == NT_MODE_PLAIN && modes[1] == NT_MODE_KHEAD) || (modes[0] == NT_MODE_AHEAD && modes[1] == NT_MODE_PLAIN)) &&
+        !args[1].brs && !(modes[0] == NT_MODE_PLAIN && args[0].brs)) {
+        // the two chains of the attention block: 16-row tiles
+        c.tiles = (args[0].M + 15) / 16;
+        const int pb16 = pc_prof_begin(PC_KIND_GEMM_NT_SMALL, flops, st);
+        if (modes[0] == NT_MODE_PLAIN) PC_LAUNCH(gemm_nt_chain16_kernel<false>, dim3(c.tiles + (rider ? 1 : 0)), dim3(256), 0, st, c);
+        else PC_LAUNCH(gemm_nt_chain16_kernel<true>, dim3(c.tiles + (rider ? 1 : 0)), dim3(256), 0, st, c);
+        pc_prof_end(pb16, st);
+        return pc_launch_status();
     }
     const size_t lds = (size_t)256 * 128 * 4;                    // AHEAD: 128 A-image rows + 128 W rows of 512 B
     static const hipError_t lds_attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt_chain_kernel),

@@ -12,7 +12,8 @@ root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 src = os.path.join(root, "gpurun_out", tag)
 dst = os.path.join(root, "profiles")
 os.makedirs(dst, exist_ok=True)
-for name in ("bench.json", "bench_under_rocprof.json", "bench_joint_under_rocprof.json", "bench_big.json", "bench_big_under_rocprof.json"):
+for name in ("bench.json", "bench_under_rocprof.json", "bench_joint_under_rocprof.json", "bench_big.json", "bench_big_under_rocprof.json",
+             "bench_cfg3_under_rocprof.json", "bench_joint34800d_under_rocprof.json"):
     if os.path.exists(os.path.join(src, name)):
         shutil.copy(os.path.join(src, name), os.path.join(dst, f"{tag}_{name}"))
 
@@ -44,7 +45,7 @@ def kernel_stats(subdir, suffix):
                       "gemm_nt_share": round(sum(t for _, t in nt) / tot, 4),
                       "gemm_tn_avg_us": round(sum(t for _, t in tn) / max(1, sum(c for c, _ in tn)) / 1e3, 2),
                       "gemm_tn_share": round(sum(t for _, t in tn) / tot, 4)}
-    if suffix == "_joint":
+    if suffix.startswith("_joint"):
         # kernels per step of the joint loop: everything launched once per step has the call count of the Adam kernel
         steps = max([r[1] for r in rows if "adam" in r[0] or "joint_finish" in r[0]] or [1])
         per_step = {short(r[0]): round(r[1] / steps, 2) for r in rows if r[1] >= steps // 2}
@@ -57,6 +58,8 @@ def kernel_stats(subdir, suffix):
 kernel_stats("prof", "")
 kernel_stats("prof_joint", "_joint")
 kernel_stats("prof_big", "_big")
+kernel_stats("prof_cfg3", "_cfg3")
+kernel_stats("prof_joint34800d", "_joint34800d")
 
 # ---- PMC passes
 def pmc(dirname, counter):
@@ -127,3 +130,16 @@ if fe:
     for k, v in res.items():
         if "gemm_nt_kernel" in k or "gemm_tn8" in k:
             print("big:", k[:60], v)
+
+
+# ---- BASELINE configs[3] on one GPU (CFG3=1): per-kernel HBM traffic of the 10 M-product sharded chain
+fe, wr_ = pmc("pmc_cfg3_fetch", "FETCH_SIZE"), pmc("pmc_cfg3_write", "WRITE_SIZE")
+if fe:
+    res = {}
+    for k, (n, v) in fe.items():
+        w = wr_.get(k, [n, 0.0])
+        res[k] = {"launches": n, "fetch_bytes_corrected": round(v / n * 1024 * 2), "write_bytes": round(w[1] / max(1, w[0]) * 1024)}
+    json.dump(res, open(os.path.join(dst, f"{tag}_cfg3_pmc_traffic.json"), "w"), indent=1)
+    nt = [v for k, v in res.items() if "gemm_nt_kernel<" in k]
+    n = sum(v["launches"] for v in nt)
+    print("cfg3 gemm_nt HBM bytes/launch:", round(sum((v["fetch_bytes_corrected"] + v["write_bytes"]) * v["launches"] for v in nt) / max(n, 1)))
