@@ -36,7 +36,7 @@ FP32_MFMA_PEAK_TFLOPS = 157.3     # /opt/skills/guides/MI355X_MICROARCH.md, Peak
 BF16_MFMA_PEAK_TFLOPS = 2500.0    # same guide, dense bf16 (no sparsity)
 BF16_PRODUCTS = 6                 # common.h split3: x = p0 + p1 + p2 (bf16 each), x*y ~ the six products of weight <= 2
 NT_PEAK_TFLOPS = BF16_MFMA_PEAK_TFLOPS / BF16_PRODUCTS     # 416.7 fp32-equivalent TFLOP/s
-PROFILE_EVERY = 10         # timed steps between two steps whose gemm_nt launches carry HIP-event brackets (each bracketed step pays ~60 us of event packets)
+PROFILE_EVERY = 20         # timed steps between two steps whose gemm_nt launches carry HIP-event brackets (each bracketed step pays ~60 us of event packets)
 HBM_PEAK_GBS = 8000.0
 
 

@@ -816,13 +816,15 @@ __global__ __launch_bounds__(256) void gemm_nt_chain16_kernel(NtChain c) {
         asm volatile("" ::: "memory");
     };
     // a PLAIN stage over the 16 x 128 LDS tile `src`: wave w owns the column blocks 2 w, 2 w + 1
-    auto plain = [&](const NtArgs& a, const BFrag<8> (&f)[2], const float* src, float* keep) {
+    // (biases and per-row bias scales are requested at entry with the weight fragments: a load in an epilogue is one more
+    // L2 round trip on the critical path of a kernel that is nothing but such round trips)
+    auto plain = [&](const NtArgs& a, const BFrag<8> (&f)[2], const float (&bias2)[2], const float* src, float* keep) {
 #pragma unroll
         for (int j = 0; j < 2; j++) {
             f32x4v acc[1] = {{0.f, 0.f, 0.f, 0.f}};
             mul_b<8, 1>(src, CH_LDA, 1, f[j], acc, lane);
             const int col = 16 * (2 * w + j) + ci;
-            const float bias = a.bias ? a.bias[col] : 0.f;
+            const float bias = bias2[j];
 #pragma unroll
             for (int r = 0; r < 4; r++) {
                 const int row = 4 * rh + r;
@@ -839,6 +841,7 @@ __global__ __launch_bounds__(256) void gemm_nt_chain16_kernel(NtChain c) {
         for (int j = 0; j < 2; j++) fp[j] = load_b<128, false>(a0.W, a0.ldw, 16 * (2 * w + j), 128, lane);
 #pragma unroll
         for (int nb = 0; nb < 8; nb++) fk[nb] = load_b<32, false>(a1.W + 32 * w, a1.ldw, 16 * nb, 128, lane);
+        const float bp[2] = {a0.bias ? a0.bias[16 * (2 * w) + ci] : 0.f, a0.bias ? a0.bias[16 * (2 * w + 1) + ci] : 0.f};
 #pragma unroll
         for (int u = 0; u < 2; u++) {
             const int e = tid + 256 * u, r = e >> 5, c4 = (e & 31) * 4;
@@ -847,7 +850,7 @@ __global__ __launch_bounds__(256) void gemm_nt_chain16_kernel(NtChain c) {
             *reinterpret_cast<float4*>(&sA[r * CH_LDA + c4]) = v;
         }
         lds_sync();
-        plain(a0, fp, sA, sS);
+        plain(a0, fp, bp, sA, sS);
         lds_sync();
         // KHEAD: wave h multiplies its head's 32 k's against all eight column blocks; C[r][128 h + d]
 #pragma unroll
@@ -867,6 +870,12 @@ __global__ __launch_bounds__(256) void gemm_nt_chain16_kernel(NtChain c) {
         for (int j = 0; j < 2; j++) fa[j] = load_b<128, false>(a0.W, a0.ldw, 32 * w + 16 * j, 128, lane);
 #pragma unroll
         for (int j = 0; j < 2; j++) fp[j] = load_b<128, false>(a1.W, a1.ldw, 16 * (2 * w + j), 128, lane);
+        const float bp[2] = {a1.bias ? a1.bias[16 * (2 * w) + ci] : 0.f, a1.bias ? a1.bias[16 * (2 * w + 1) + ci] : 0.f};
+        const float ba[2] = {a0.bias ? a0.bias[32 * w + ci] : 0.f, a0.bias ? a0.bias[32 * w + 16 + ci] : 0.f};
+        float rs4[4];
+#pragma unroll
+        for (int r = 0; r < 4; r++)
+            rs4[r] = (a0.brs && row0 + 4 * rh + r < M) ? a0.brs[(size_t)(row0 + 4 * rh + r) * a0.ldbrs + w] : 1.f;
         float4 x[8];
 #pragma unroll
         for (int u = 0; u < 8; u++) {
@@ -886,19 +895,18 @@ __global__ __launch_bounds__(256) void gemm_nt_chain16_kernel(NtChain c) {
             f32x4v acc[1] = {{0.f, 0.f, 0.f, 0.f}};
             mul_b<8, 1>(sA + 128 * w, CH_LDA4, 1, fa[j], acc, lane);
             const int col = 32 * w + 16 * j + ci;
-            const float bias = a0.bias ? a0.bias[col] : 0.f;
+            const float bias = ba[j];
 #pragma unroll
             for (int r = 0; r < 4; r++) {
                 const int row = 4 * rh + r;
                 const bool live = row0 + row < M;
-                const float rs = (a0.brs && live) ? a0.brs[(size_t)(row0 + row) * a0.ldbrs + w] : 1.f;
-                const float v = acc[0][r] + bias * rs;
+                const float v = acc[0][r] + bias * rs4[r];
                 sS[row * CH_LDA + col] = v;
                 if (live) a0.C[(size_t)(row0 + row) * a0.ldc + col] = v;
             }
         }
         lds_sync();
-        plain(a1, fp, sS, nullptr);
+        plain(a1, fp, bp, sS, nullptr);
     }
 }
 
