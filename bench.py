@@ -385,22 +385,29 @@ def run_p2v(args, rank, world, dev, products, steps, warmup, want_cpu, profile_k
     for _ in range(warmup):
         last = next(it)
         step(last)
+    # HIP-event brackets around the dominant kernel family cost the stream ~5 us per bracket side (a marker packet each):
+    # every PROFILE_EVERY-th step of the timed region carries them, the others run as a caller's loop does
+    profiled_steps = 0
+    # (the host asks the loader for batch i + 1 right BEHIND step i's launches, not in front of step i + 1's: the loader's
+    # builders run four batches ahead on their own stream either way; what moves is ~0.1 ms of host work out of the gap
+    # between the opening synchronize and the region's first launch -- 5 us per step of a 20-step region)
+    nxt = next(it)
     if multi:
         torch.distributed.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    # HIP-event brackets around the dominant kernel family cost the stream ~5 us per bracket side (a marker packet each):
-    # every PROFILE_EVERY-th step of the timed region carries them, the others run as a caller's loop does
-    profiled_steps = 0
     for i in range(steps):
-        last = next(it)
+        last = nxt
         n_sum += last["n_pad"]
         nbc_ = last["neighbor_compact"]
         real_sum += int(nbc_["n_unique"]) if "weight" in nbc_ else nbc_["nb_rows"].numel() - 1      # rows carried
         slot_sum += nbc_.get("n_real", nbc_["nb_rows"].numel() - 1)                                   # real slots
-        bracket = profile_kernels and (args.profile_all or i % PROFILE_EVERY == 0)
+        # (not the region's first step: its launches follow the opening synchronize with an empty queue behind them)
+        bracket = profile_kernels and (args.profile_all or i % PROFILE_EVERY == min(PROFILE_EVERY // 2, steps - 1))
         profiled_steps += 1 if bracket else 0
         loss = step(last, profile=prof if bracket else None)
+        if i + 1 < steps:
+            nxt = next(it)
     host_ms = 1e3 * (time.perf_counter() - t0) / max(steps, 1)      # the host's time to enqueue a step (incl. its waits)
     torch.cuda.synchronize()
     if multi:
