@@ -405,6 +405,7 @@ struct TnArgs {
 // per Product2Vec step became one.
 struct TnDefer;
 int launch_gemm_tn(const TnArgs& a, hipStream_t st, TnDefer* defer = nullptr);
+int launch_gemm_tn_halves(const TnArgs& a, float* slabs0, float* slabs1, size_t slab_floats, hipStream_t st, TnDefer* defer);
 size_t gemm_tn_workspace_floats(int R, int No, int Ni);
 // up to PC_TN_GROUP small independent products (disjoint slab regions) as one launch + one reduce; the reduce can
 // take PC_TN_EXTRA further slab sets that other kernels filled (the joint step's type-table scatter-adds)

@@ -63,11 +63,11 @@ __global__ __launch_bounds__(FIN_COLS * FIN_LANES) void bn_fold_kernel(const flo
 }
 
 // gsum: NULL = statistics of this replica (fold the per-tile partials here); else the all-reduced exchange buffer.
-// Block = (FINF_COLS columns, FIN_LANES tile lanes, PC_MAX_SEG segments), grid = H / FINF_COLS: the four segments' folds run
+// Block = (FINF_COLS columns, FIN_LANES tile lanes, PC_MAX_SEG segments), grid = H / FINF_COLS = 64: the four segments' folds run
 // side by side (round 3 walked them one after the other, two barriers each, in 8 workgroups: 12.6 us on the critical path
 // between Linear0 and Linear3); one thread per column then applies the four running-statistic updates in call order.
 // Per (segment, column) the arithmetic is fold_partials' own -- same lanes, same chains, same final order: same bits.
-#define FINF_COLS 8
+#define FINF_COLS 4      /* 512-thread workgroups: a 1024-thread one waits for a whole CU's wave slots when the loader's kernels share the chip (configs[4]: 115 us instead of 9 under the profiler) */
 __global__ __launch_bounds__(FINF_COLS * FIN_LANES * PC_MAX_SEG) void bn_finalize_fwd_kernel(
     const float* psum, const float* psq, SegInfo si, const double* gsum, const float* gamma, const float* beta,
     float* running_mean, float* running_var, int64_t* nbt, int update_running, float* mean_o, float* invstd_o,
@@ -467,12 +467,17 @@ int ffn_backward_part1(const pc_p2v_tensors* p, const pc_p2v_tensors* g, const f
         // as two 128 x 256 halves of the output rows: the 256 x 256 tile needs 8 blocks per wave at 256 registers (six splits
         // and a spill per 48 MFMAs: 102 us); the half-size kernel runs 44 us per half (scripts/dev/nt_decompose.sh; same box,
         // whole step: 1.068 -> 1.062 ms)
-        for (int half = 0; half < 2; half++) {
-            TnArgs th = t3;
-            th.Z = w.dz2 + half * (PC_H / 2); th.No = PC_H / 2;
-            th.dW = g->w3 + (size_t)half * (PC_H / 2) * PC_H; th.db = g->b3 + half * (PC_H / 2);
-            th.slabs = w.slabs[1 + half];
-            PC_TRY(launch_gemm_tn(th, st, df));
+        // (round 4: many rows -- the two halves as ONE launch of 2 x 128 row slices: A1 comes from HBM once, half the slabs)
+        if (rows >= 8192 && (size_t)128 * ((size_t)128 * PC_H + 128) <= w.slab_floats) {
+            PC_TRY(launch_gemm_tn_halves(t3, w.slabs[1], w.slabs[2], w.slab_floats, st, df));
+        } else {
+            for (int half = 0; half < 2; half++) {
+                TnArgs th = t3;
+                th.Z = w.dz2 + half * (PC_H / 2); th.No = PC_H / 2;
+                th.dW = g->w3 + (size_t)half * (PC_H / 2) * PC_H; th.db = g->b3 + half * (PC_H / 2);
+                th.slabs = w.slabs[1 + half];
+                PC_TRY(launch_gemm_tn(th, st, df));
+            }
         }
     } else {
         PC_TRY(launch_gemm_tn(t3, st, df));

@@ -197,8 +197,13 @@ __device__ __forceinline__ void tn_lds_sync() {
     asm volatile("" ::: "memory");
 }
 
+// halves == 2 (round 4: dW3): ONE launch computes the two NO-wide halves of a 2 NO-wide gradient over nsplit row slices each.
+// Workgroups b and b + 8 -- the same XCD: blockIdx round-robins over the eight -- take the two halves of ONE row slice, so the
+// second fetch of the slice's A rows is an L2 hit (two launches of 256 slices each read A twice from HBM and wrote twice the
+// slabs).  Half h reads Z + h * NO columns and writes its slabs at a.slabs + h * slab_half_off.
 template <int WO, int WI, int TO, int TI, int TKC, int NST, bool APRO, bool ZPRO>
-__global__ __launch_bounds__(64 * WO * WI, WO * WI / 4) void gemm_tn8_kernel(TnArgs a, int nsplit, int rows_per_split) {
+__global__ __launch_bounds__(64 * WO * WI, WO * WI / 4) void gemm_tn8_kernel(TnArgs a, int nsplit, int rows_per_split, int halves,
+                                                                             size_t slab_half_off) {
     constexpr int NWV = WO * WI, THREADS = 64 * NWV;            // 8 waves (2 per SIMD) or 16 (4 per SIMD)
     constexpr int NO = WO * TO * 32, NI = WI * TI * 32;
     // Image rows must not start on the same LDS bank two rows apart in the MFMA's k pair (lanes 0-31 read row k,
@@ -221,7 +226,13 @@ __global__ __launch_bounds__(64 * WO * WI, WO * WI / 4) void gemm_tn8_kernel(TnA
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6), wo = w % WO, wi = w / WO;
-    const int split = blockIdx.x;
+    const int half = halves == 2 ? ((int)blockIdx.x >> 3) & 1 : 0;
+    const int split = halves == 2 ? (((int)blockIdx.x >> 4) << 3) + ((int)blockIdx.x & 7) : (int)blockIdx.x;
+    if (halves == 2) {                                           // (uniform: scalar adds on the kernel arguments)
+        a.Z += half * (WO * TO * 32);
+        a.slabs += half * slab_half_off;
+        if (a.db) a.db += half * (WO * TO * 32);
+    }
     const int r_begin = split * rows_per_split;
     const int r_end = min(a.R, r_begin + rows_per_split);
     const float* const zsrc0 = pc_tn_zero_chunk;
@@ -569,10 +580,10 @@ int launch_gemm_tn(const TnArgs& a, hipStream_t st, TnDefer* defer) {
     if (tn_full_tile(a.R, a.No, a.Ni) && !(apro && zpro)) {
 #define TN8(WO, WI, TO, TI)                                                                                   \
     do {                                                                                                      \
-        if (apro) PC_LAUNCH((gemm_tn8_kernel<WO, WI, TO, TI, 32, 2, true, false>), dim3(nsplit), dim3(64 * WO * WI), 0, st, a, nsplit, rps);       \
-        else if (zpro && a.Ni > 128) PC_LAUNCH((gemm_tn8_kernel<2, 4, 4, 2, 16, 3, false, true>), dim3(nsplit), dim3(512), 0, st, a, nsplit, rps);  \
-        else if (zpro) PC_LAUNCH((gemm_tn8_kernel<4, 2, 2, 2, 16, 3, false, true>), dim3(nsplit), dim3(512), 0, st, a, nsplit, rps);  \
-        else PC_LAUNCH((gemm_tn8_kernel<WO, WI, TO, TI, 32, 2, false, false>), dim3(nsplit), dim3(64 * WO * WI), 0, st, a, nsplit, rps);           \
+        if (apro) PC_LAUNCH((gemm_tn8_kernel<WO, WI, TO, TI, 32, 2, true, false>), dim3(nsplit), dim3(64 * WO * WI), 0, st, a, nsplit, rps, 1, (size_t)0);       \
+        else if (zpro && a.Ni > 128) PC_LAUNCH((gemm_tn8_kernel<2, 4, 4, 2, 16, 3, false, true>), dim3(nsplit), dim3(512), 0, st, a, nsplit, rps, 1, (size_t)0);  \
+        else if (zpro) PC_LAUNCH((gemm_tn8_kernel<4, 2, 2, 2, 16, 3, false, true>), dim3(nsplit), dim3(512), 0, st, a, nsplit, rps, 1, (size_t)0);  \
+        else PC_LAUNCH((gemm_tn8_kernel<WO, WI, TO, TI, 32, 2, false, false>), dim3(nsplit), dim3(64 * WO * WI), 0, st, a, nsplit, rps, 1, (size_t)0);           \
     } while (0)
         if (a.No > 128 && a.Ni > 128) TN8(2, 4, 4, 2);
         else if (a.No > 128) TN8(4, 2, 2, 2);
@@ -589,6 +600,32 @@ int launch_gemm_tn(const TnArgs& a, hipStream_t st, TnDefer* defer) {
     PC_LAUNCH(tn_reduce_kernel, dim3((threads + 255) / 256), dim3(256), 0, st, a.slabs, nsplit, n_w, n_b,
                        a.dW, a.db, a.accumulate);
     return pc_launch_status();
+}
+
+// dW[2 x 128, 256] = Z[:, 0:256]^T A as ONE launch of 2 x 128 row slices (see gemm_tn8_kernel, halves == 2); slabs0 / slabs1: the two
+// halves' slab regions (each >= 128 x (128 x 256 + 128) floats), reduced as two jobs of the caller's deferred list
+int launch_gemm_tn_halves(const TnArgs& a, float* slabs0, float* slabs1, size_t slab_floats, hipStream_t st, TnDefer* defer) {
+    if (!a.Z || !a.A || !a.dW || !slabs0 || !slabs1 || !defer || a.R <= 0) return PC_EINVAL;
+    if (a.No != 256 || a.Ni != 256 || a.ldz % 4 || a.lda % 4 || a.lddw != a.Ni || a.prologue != NT_PRO_NONE || a.zaux || a.z_onehot || a.gather)
+        return PC_ESHAPE;
+    if (slabs1 < slabs0) return PC_EINVAL;
+    const int nsplit = 128;
+    int rps = (a.R + nsplit - 1) / nsplit;
+    rps = (rps + 31) / 32 * 32;                                  // whole 32-row chunks
+    const int used = (a.R + rps - 1) / rps;                      // (<= 128: trailing slices own no rows and write zero slabs)
+    const size_t per = (size_t)128 * a.Ni + 128;
+    if ((size_t)nsplit * per > slab_floats) return PC_EWORKSPACE;
+    (void)used;
+    TnArgs h = a;
+    h.No = 128; h.slabs = slabs0; h.slab_floats = slab_floats;
+    const int pb = pc_prof_begin(PC_KIND_GEMM_TN, 2.0 * a.R * (double)a.No * a.Ni, st);
+    PC_LAUNCH((gemm_tn8_kernel<2, 4, 2, 2, 32, 2, false, false>), dim3(2 * nsplit), dim3(512), 0, st, h, nsplit, rps, 2,
+              (size_t)(slabs1 - slabs0));
+    pc_prof_end(pb, st);
+    PC_TRY(pc_launch_status());
+    PC_TRY(tn_defer_push(defer, slabs0, slab_floats, nsplit, 128 * a.Ni, 128, a.dW, a.db, a.accumulate));
+    return tn_defer_push(defer, slabs1, slab_floats, nsplit, 128 * a.Ni, 128, a.dW + (size_t)128 * a.Ni, a.db ? a.db + 128 : nullptr,
+                         a.accumulate);
 }
 
 // One side queue per (device, main queue): two host threads stepping two models on two streams of one device each get their
