@@ -1641,7 +1641,7 @@ __global__ __launch_bounds__(256) void scatter_add_rows_xcd_kernel(ScatterList l
 // data-parallel exchange (pc_joint_fused_touched: SURVEY 8e-4, "reduce-scatter for the sparse grads").
 #define TG_CAP 512          /* distinct touched rows per table on the deterministic path: 512 x 64 floats = 128 KB of LDS */
 #define TG_WGS 256
-#define TG_CHUNK 64         /* source rows a workgroup stages at a time (16 KB) */
+#define TG_CHUNK 96         /* source rows a workgroup stages at a time (24 KB: a workgroup's whole share of either list at B = 4096, K = 3) */
 
 __global__ __launch_bounds__(1024) void touched_types_kernel(const int32_t* idx_c, int n_c, const int32_t* idx_q, int n_q, int T,
                                                              int32_t* ulist_c, int32_t* pos_c, int32_t* ulist_q,
@@ -1690,10 +1690,11 @@ __global__ __launch_bounds__(256) void table_partials_kernel(TableList l0, Table
     float* rowsb = tg_lds + TG_CAP * PC_L;               // [TG_CHUNK][64]
     int* dst = reinterpret_cast<int*>(rowsb + TG_CHUNK * PC_L);   // [TG_CHUNK]
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int nus[2] = {n_touch[0], n_touch[1]};         // (both counts in one round trip: the kernel is a chain of them)
 #pragma unroll 1
     for (int li = 0; li < 2; li++) {
         const TableList& l = li ? l1 : l0;
-        const int nu = n_touch[li];
+        const int nu = nus[li];
         const int per = (l.rows + TG_WGS - 1) / TG_WGS;
         const int lo = blockIdx.x * per, hi = min(l.rows, lo + per);
         if (nu > TG_CAP) {
@@ -1708,13 +1709,27 @@ __global__ __launch_bounds__(256) void table_partials_kernel(TableList l0, Table
         for (int e = threadIdx.x; e < nu * PC_L; e += 256) tab[e] = 0.f;
         for (int c0 = lo; c0 < hi; c0 += TG_CHUNK) {
             const int nr = min(TG_CHUNK, hi - c0);
-            __syncthreads();
-            for (int e = threadIdx.x; e < nr * (PC_L / 4); e += 256)
-                *reinterpret_cast<float4*>(&rowsb[e * 4]) = *reinterpret_cast<const float4*>(l.src + (size_t)c0 * PC_L + e * 4);
+            // the chunk's rows and its destinations are requested together (rows into registers; idx -> pos is two dependent
+            // loads): one wait instead of three in a row
+            constexpr int RPT = TG_CHUNK * (PC_L / 4) / 256;            // float4 per thread
+            float4 rv[RPT];
+#pragma unroll
+            for (int u = 0; u < RPT; u++) {
+                const int e = threadIdx.x + 256 * u;
+                rv[u] = e < nr * (PC_L / 4) ? *reinterpret_cast<const float4*>(l.src + (size_t)c0 * PC_L + e * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+            int dv = -1;
             if ((int)threadIdx.x < nr) {
                 const int d = l.idx[c0 + threadIdx.x];
-                dst[threadIdx.x] = (unsigned)d < (unsigned)T ? l.pos[d] : -1;
+                dv = (unsigned)d < (unsigned)T ? l.pos[d] : -1;
             }
+            __syncthreads();                                         // (the previous chunk's adds have left rowsb / dst)
+#pragma unroll
+            for (int u = 0; u < RPT; u++) {
+                const int e = threadIdx.x + 256 * u;
+                if (e < nr * (PC_L / 4)) *reinterpret_cast<float4*>(&rowsb[e * 4]) = rv[u];
+            }
+            if ((int)threadIdx.x < nr) dst[threadIdx.x] = dv;
             __syncthreads();
             // destination u is wave (u % 4)'s: that wave adds u's rows in source order, nobody else touches tab[u]
             for (int i = 0; i < nr; i++) {
