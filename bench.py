@@ -582,8 +582,25 @@ def rccl_info(world, dev):
             "ranks_seen": sorted(int(v) for v in seen.tolist()), "launcher": "self" if os.environ.get("PC_BENCH_SELF_LAUNCHED") else "torch.distributed.run"}
 
 
+def guarded(name, fn, world):
+    """A SECONDARY leg must not take the headline down with it (an allocation that does not fit a smaller card, say): its
+    failure is reported in its place.  One process only: at N > 1 a rank that skipped a leg's collectives would hang its
+    peers, so there the exception propagates (and the launcher ends the job)."""
+    if world > 1:
+        return fn()
+    try:
+        return fn()
+    except Exception as e:                                      # noqa: BLE001 -- reported, not swallowed
+        import traceback
+        traceback.print_exc(file=sys.stderr)
+        torch.cuda.synchronize()
+        return {"error": f"{type(e).__name__}: {e}"[:400], "leg": name}
+
+
 def leg(res, keys=("value", "ms_per_step", "host_enqueue_ms_per_step", "final_loss", "catalogue", "roofline", "sharded_lookup")):
     """A secondary Product2Vec leg of the line: its own value / ms_per_step / roofline, nothing borrowed from the headline."""
+    if res is None or "error" in res:
+        return res
     out = {"unit": "triplets/s"}
     for k in keys:
         if res.get(k) is not None:
@@ -652,19 +669,21 @@ def main():
             large = run_p2v(args, rank, world, dev, args.large_catalogue, max(args.steps // 2, 5), args.warmup, False,
                             profile_kernels=False)
         if plain and not args.no_dropout_legs and args.dropout == 0.0:
-            r = run_p2v(args, rank, world, dev, args.products, max(args.steps, 30), args.warmup, False, dropout=0.1, pmc_kind="none")
+            r = guarded("p2v_dropout_0p1", lambda: run_p2v(args, rank, world, dev, args.products, max(args.steps, 30), args.warmup, False,
+                                                           dropout=0.1, pmc_kind="none"), world)
             if rank == 0:
                 extra["p2v_dropout_0p1"] = leg(r)
     if args.phase in ("both", "joint"):
         joint = run_joint(args, rank, world, dev, args.types, max(args.steps * 4, 100), max(args.warmup, 10), want_cpu, dropout=args.dropout)
         if not args.no_dropout_legs and args.dropout == 0.0:
-            extra["joint_dropout_0p1"] = run_joint(args, rank, world, dev, args.types, max(args.steps * 4, 100), max(args.warmup, 10),
-                                                   False, dropout=0.1)
+            extra["joint_dropout_0p1"] = guarded("joint_dropout_0p1", lambda: run_joint(args, rank, world, dev, args.types, max(args.steps * 4, 100),
+                                                                                         max(args.warmup, 10), False, dropout=0.1), world)
         if not args.no_ref_types and args.types != 34800:
             joint_ref = run_joint(args, rank, world, dev, 34800, max(args.steps, 20), max(args.warmup, 10), want_cpu, dropout=args.dropout)
             if not args.no_dropout_legs and args.dropout == 0.0:
-                extra["joint_num_types_34800_dropout_0p1"] = run_joint(args, rank, world, dev, 34800, max(args.steps, 20),
-                                                                       max(args.warmup, 10), False, dropout=0.1)
+                extra["joint_num_types_34800_dropout_0p1"] = guarded(
+                    "joint_num_types_34800_dropout_0p1",
+                    lambda: run_joint(args, rank, world, dev, 34800, max(args.steps, 20), max(args.warmup, 10), False, dropout=0.1), world)
     if args.phase in ("both", "p2v") and plain and not args.no_large:
         # BASELINE configs[3] / [4] at their real sizes, catalogue generated in HBM (this rank's shard of the table when N > 1).
         # One GPU holds configs[4] whole (102 GB of 288); the smaller catalogues are released first.
@@ -673,15 +692,16 @@ def main():
         gc.collect()
         torch.cuda.empty_cache()
         lc = {}
-        r = run_p2v(args, rank, world, dev, 10_000_000, 30, 10, False, dim=128, negatives="uniform", table_mode="sharded", pmc_kind="cfg3")
+        r = guarded("config3", lambda: run_p2v(args, rank, world, dev, 10_000_000, 30, 10, False, dim=128, negatives="uniform",
+                                               table_mode="sharded", pmc_kind="cfg3"), world)
         if rank == 0:
             lc["config3"] = dict(leg(r), workload=f"BASELINE configs[3]: 10 M products, dim=128, table row-sharded over {world} GPU(s) "
                                                   f"(pc_shard_bucket + two constant-shape all-to-all rounds + pc_gather_rows per batch), batch={args.batch}/GPU")
         del r
         gc.collect()
         torch.cuda.empty_cache()
-        r = run_p2v(args, rank, world, dev, 100_000_000, 30, 10, False, dim=256, negatives="zipf",
-                    table_mode="sharded" if world > 1 else "replicated", pmc_kind="big")
+        r = guarded("config4", lambda: run_p2v(args, rank, world, dev, 100_000_000, 30, 10, False, dim=256, negatives="zipf",
+                                               table_mode="sharded" if world > 1 else "replicated", pmc_kind="big"), world)
         if rank == 0:
             lc["config4"] = dict(leg(r), workload=f"BASELINE configs[4]: 100 M products, dim=256, Zipf(1) negatives, "
                                                   + (f"table row-sharded over {world} GPUs" if world > 1 else "whole table (102 GB) on one GPU")

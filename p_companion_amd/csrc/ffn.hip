@@ -44,6 +44,36 @@ __device__ __forceinline__ void fold_partials(const float* p1, const float* p2, 
     __syncthreads();
 }
 
+// The same fold by 8 tile lanes per column (256-thread workgroups: 32 adjacent columns per tile row as above, four loads in
+// flight per lane).  The backward finalize runs on the side queue BESIDE the weight-gradient launches: a 1024-thread workgroup
+// needs a whole CU's worth of free wave slots and, since dW3 became one launch (round 4), found them only when that launch
+// drained (80-110 us of "duration" in the kernel trace: dW0, which waits for it, started that much later); four waves fit
+// anywhere.
+#define FINB_LANES 8
+__device__ __forceinline__ void fold_partials8(const float* p1, const float* p2, int t0, int t1, int j, int q,
+                                               double (*red)[FINB_LANES][FIN_COLS], double* o1, double* o2) {
+    double a[4] = {0.0, 0.0, 0.0, 0.0}, b[4] = {0.0, 0.0, 0.0, 0.0};
+    int t = t0 + q;
+    for (; t + 3 * FINB_LANES < t1; t += 4 * FINB_LANES) {
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            a[u] += (double)p1[(size_t)(t + u * FINB_LANES) * PC_H + j];
+            b[u] += (double)p2[(size_t)(t + u * FINB_LANES) * PC_H + j];
+        }
+    }
+    for (; t < t1; t += FINB_LANES) { a[0] += (double)p1[(size_t)t * PC_H + j]; b[0] += (double)p2[(size_t)t * PC_H + j]; }
+    red[0][q][threadIdx.x] = (a[0] + a[1]) + (a[2] + a[3]);
+    red[1][q][threadIdx.x] = (b[0] + b[1]) + (b[2] + b[3]);
+    __syncthreads();
+    if (q == 0) {
+        double s1 = 0.0, s2 = 0.0;
+#pragma unroll
+        for (int i = 0; i < FINB_LANES; i++) { s1 += red[0][i][threadIdx.x]; s2 += red[1][i][threadIdx.x]; }
+        *o1 = s1; *o2 = s2;
+    }
+    __syncthreads();
+}
+
 // Cross-replica BatchNorm: the per-segment sums of THIS replica, in fp64, in the
 // exchange layout sums[PC_BN_SYNC_DOUBLES] = [seg][2][H] sums then [seg] row counts.  The host adds the
 // buffers of all replicas (one all-reduce) and hands the result to the finalize kernels below.
@@ -63,73 +93,46 @@ __global__ __launch_bounds__(FIN_COLS * FIN_LANES) void bn_fold_kernel(const flo
 }
 
 // gsum: NULL = statistics of this replica (fold the per-tile partials here); else the all-reduced exchange buffer.
-// Block = (FINF_COLS columns, FIN_LANES tile lanes, PC_MAX_SEG segments), grid = H / FINF_COLS = 64: the four segments' folds run
-// side by side (round 3 walked them one after the other, two barriers each, in 8 workgroups: 12.6 us on the critical path
-// between Linear0 and Linear3); one thread per column then applies the four running-statistic updates in call order.
-// Per (segment, column) the arithmetic is fold_partials' own -- same lanes, same chains, same final order: same bits.
-#define FINF_COLS 4      /* 512-thread workgroups: a 1024-thread one waits for a whole CU's wave slots when the loader's kernels share the chip (configs[4]: 115 us instead of 9 under the profiler) */
-__global__ __launch_bounds__(FINF_COLS * FIN_LANES * PC_MAX_SEG) void bn_finalize_fwd_kernel(
+// (Round 4 tried the four segments side by side in 32-64 narrower workgroups -- 4-8 columns each: 12.6 -> 9.0 us at configs[1], but
+// a wave then touches 16 tile rows per load instead of 2, and beside configs[4]'s loader kernels (random reads over 114 GB: the
+// TLB is theirs) every one of those is a miss: 115-144 us there under the profiler.  Back to 32 adjacent columns per tile row.)
+__global__ __launch_bounds__(FIN_COLS * FIN_LANES) void bn_finalize_fwd_kernel(
     const float* psum, const float* psq, SegInfo si, const double* gsum, const float* gamma, const float* beta,
     float* running_mean, float* running_var, int64_t* nbt, int update_running, float* mean_o, float* invstd_o,
     float* scale_o, float* shift_o) {
-    __shared__ double red[PC_MAX_SEG][2][FIN_LANES][FINF_COLS];
-    __shared__ float st_m[PC_MAX_SEG][FINF_COLS], st_u[PC_MAX_SEG][FINF_COLS];
-    __shared__ int st_ok[PC_MAX_SEG][FINF_COLS];
-    const int c = threadIdx.x, q = threadIdx.y, s = threadIdx.z;
-    const int j = blockIdx.x * FINF_COLS + c;
-    const bool live = s < si.nseg;
-    if (live && !gsum) {
-        const int t0 = si.tile0[s], t1 = si.tile0[s + 1];
-        double a = 0.0, b = 0.0, a1 = 0.0, b1 = 0.0;
-        int t = t0 + q;
-        for (; t + FIN_LANES < t1; t += 2 * FIN_LANES) {
-            a += (double)psum[(size_t)t * PC_H + j];                b += (double)psq[(size_t)t * PC_H + j];
-            a1 += (double)psum[(size_t)(t + FIN_LANES) * PC_H + j]; b1 += (double)psq[(size_t)(t + FIN_LANES) * PC_H + j];
+    __shared__ double red[2][FIN_LANES][FIN_COLS];
+    const int j = blockIdx.x * FIN_COLS + threadIdx.x, q = threadIdx.y;
+    float rm = 0.f, rv = 0.f;
+    if (q == 0 && update_running) { rm = running_mean[j]; rv = running_var[j]; }
+    int nseen = 0;
+    for (int s = 0; s < si.nseg; s++) {
+        double n = si.count[s];                               // logical rows (a weighted row counts wmult times)
+        double a = 0.0, b = 0.0;
+        if (gsum) {
+            a = gsum[(2 * s) * PC_H + j]; b = gsum[(2 * s + 1) * PC_H + j]; n = gsum[2 * PC_MAX_SEG * PC_H + s];
+        } else {
+            fold_partials(psum, psq, si.tile0[s], si.tile0[s + 1], j, q, red, &a, &b);
         }
-        if (t < t1) { a += (double)psum[(size_t)t * PC_H + j]; b += (double)psq[(size_t)t * PC_H + j]; }
-        red[s][0][q][c] = a + a1;
-        red[s][1][q][c] = b + b1;
-    }
-    __syncthreads();
-    if (q == 0) {
-        int ok = 0;
-        if (live) {
-            double n = si.count[s];                               // logical rows (a weighted row counts wmult times)
-            double a = 0.0, b = 0.0;
-            if (gsum) {
-                a = gsum[(2 * s) * PC_H + j]; b = gsum[(2 * s + 1) * PC_H + j]; n = gsum[2 * PC_MAX_SEG * PC_H + s];
-            } else {
-#pragma unroll 8
-                for (int i = 0; i < FIN_LANES; i++) { a += red[s][0][i][c]; b += red[s][1][i][c]; }
+        if (q == 0 && n > 0) {
+            const double m = a / n;
+            double var = b / n - m * m;
+            if (var < 0.0) var = 0.0;
+            const float mf = (float)m, vf = (float)var;
+            const float is = 1.0f / sqrtf(vf + BN_EPS);
+            const float sc = gamma[j] * is;
+            mean_o[s * PC_H + j] = mf;
+            invstd_o[s * PC_H + j] = is;
+            scale_o[s * PC_H + j] = sc;
+            shift_o[s * PC_H + j] = beta[j] - mf * sc;
+            if (update_running) {
+                const float unb = n > 1 ? (float)(var * (n / (n - 1))) : vf;
+                rm = BN_MOMENTUM * mf + (1.0f - BN_MOMENTUM) * rm;
+                rv = BN_MOMENTUM * unb + (1.0f - BN_MOMENTUM) * rv;
             }
-            if (n > 0) {
-                const double m = a / n;
-                double var = b / n - m * m;
-                if (var < 0.0) var = 0.0;
-                const float mf = (float)m, vf = (float)var;
-                const float is = 1.0f / sqrtf(vf + BN_EPS);
-                const float sc = gamma[j] * is;
-                mean_o[s * PC_H + j] = mf;
-                invstd_o[s * PC_H + j] = is;
-                scale_o[s * PC_H + j] = sc;
-                shift_o[s * PC_H + j] = beta[j] - mf * sc;
-                st_m[s][c] = mf;
-                st_u[s][c] = n > 1 ? (float)(var * (n / (n - 1))) : vf;
-                ok = 1;
-            }
+            nseen++;
         }
-        st_ok[s][c] = ok;
     }
-    __syncthreads();
-    if (q == 0 && s == 0 && update_running) {
-        float rm = running_mean[j], rv = running_var[j];
-        int nseen = 0;
-        for (int k = 0; k < si.nseg; k++)
-            if (st_ok[k][c]) {
-                rm = BN_MOMENTUM * st_m[k][c] + (1.0f - BN_MOMENTUM) * rm;
-                rv = BN_MOMENTUM * st_u[k][c] + (1.0f - BN_MOMENTUM) * rv;
-                nseen++;
-            }
+    if (q == 0 && update_running) {
         running_mean[j] = rm;
         running_var[j] = rv;
         if (j == 0 && nbt) *nbt += nseen;
@@ -146,17 +149,17 @@ __global__ void bn_eval_coeff_kernel(const float* gamma, const float* beta, cons
 }
 
 // per-tile (sum dz1, sum dz1*h0) -> dgamma, dbeta (+ per-segment means c1 = dbeta_s/n, c2 = dgamma_s/n)
-__global__ __launch_bounds__(FIN_COLS * FIN_LANES) void bn_finalize_bwd_kernel(
+__global__ __launch_bounds__(FIN_COLS * FINB_LANES) void bn_finalize_bwd_kernel(
     const float* psum, const float* pdot, SegInfo si, const double* lsum, const double* gsum, const float* mean,
     const float* invstd, float* dgamma, float* dbeta, int accumulate, float* c1, float* c2) {
-    __shared__ double red[2][FIN_LANES][FIN_COLS];
+    __shared__ double red[2][FINB_LANES][FIN_COLS];
     const int j = blockIdx.x * FIN_COLS + threadIdx.x, q = threadIdx.y;
     double tg = 0.0, tb = 0.0;
     for (int s = 0; s < si.nseg; s++) {
         double n = si.count[s];                               // logical rows (a weighted row counts wmult times)
         double a = 0.0, b = 0.0;
         if (lsum) { a = lsum[(2 * s) * PC_H + j]; b = lsum[(2 * s + 1) * PC_H + j]; }
-        else fold_partials(psum, pdot, si.tile0[s], si.tile0[s + 1], j, q, red, &a, &b);
+        else fold_partials8(psum, pdot, si.tile0[s], si.tile0[s + 1], j, q, red, &a, &b);
         if (q == 0) {
             // the tiles carry the raw moment sum dz1*h0: sum dz1*xhat = invstd * (sum dz1*h0 - mean * sum dz1)
             const double is = (double)invstd[s * PC_H + j], mu = (double)mean[s * PC_H + j];
@@ -346,7 +349,7 @@ int ffn_forward_part2(const pc_p2v_tensors* p, int rows, const pc_segments* seg,
     hipStream_t st = (hipStream_t)stream;
     const SegInfo si = make_seginfo(seg, rows, 128);
     FfnWs w = ffn_ws_layout(ws, rows);
-    PC_LAUNCH(bn_finalize_fwd_kernel, dim3(PC_H / FINF_COLS), dim3(FINF_COLS, FIN_LANES, PC_MAX_SEG), 0, st, w.stat_a, w.stat_b, si, global_sums,
+    PC_LAUNCH(bn_finalize_fwd_kernel, dim3(PC_H / FIN_COLS), dim3(FIN_COLS, FIN_LANES), 0, st, w.stat_a, w.stat_b, si, global_sums,
               p->gamma, p->beta, p->running_mean, p->running_var, p->num_batches_tracked, update_running,
               sv->bn_mean, sv->bn_invstd, sv->bn_scale, sv->bn_shift);
     PC_TRY(pc_launch_status());
@@ -450,7 +453,7 @@ int ffn_backward_part1(const pc_p2v_tensors* p, const pc_p2v_tensors* g, const f
     if (df->fork && !local_sums) {
         // the BatchNorm-backward finalize (8 workgroups, 12 us; only dW0 reads c1 / c2) on the side queue, beside dW3
         PC_TRY(pc_fork_begin(df->fork, 1, st));
-        PC_LAUNCH(bn_finalize_bwd_kernel, dim3(PC_H / FIN_COLS), dim3(FIN_COLS, FIN_LANES), 0, df->fork->side, w.stat_a, w.stat_b, si,
+        PC_LAUNCH(bn_finalize_bwd_kernel, dim3(PC_H / FIN_COLS), dim3(FIN_COLS, FINB_LANES), 0, df->fork->side, w.stat_a, w.stat_b, si,
                   nullptr, nullptr, sv->bn_mean, sv->bn_invstd, g->gamma, g->beta, accumulate, w.c1, w.c2);
         PC_TRY(pc_launch_status());
         df->bn_finalized = 1;
@@ -501,7 +504,7 @@ int ffn_backward_part2(const pc_p2v_tensors* g, const float* table, const int32_
         if (local_sums || global_sums) return PC_EINVAL;
         PC_TRY(pc_fork_join(defer->fork, 0, st));              // part 1 ran the finalize on the side queue
     } else {
-        PC_LAUNCH(bn_finalize_bwd_kernel, dim3(PC_H / FIN_COLS), dim3(FIN_COLS, FIN_LANES), 0, st, w.stat_a, w.stat_b, si, local_sums,
+        PC_LAUNCH(bn_finalize_bwd_kernel, dim3(PC_H / FIN_COLS), dim3(FIN_COLS, FINB_LANES), 0, st, w.stat_a, w.stat_b, si, local_sums,
                   global_sums, sv->bn_mean, sv->bn_invstd, g->gamma, g->beta, accumulate, w.c1, w.c2);
         PC_TRY(pc_launch_status());
     }
