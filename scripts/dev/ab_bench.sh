@@ -13,7 +13,7 @@ for i in $(seq 1 $ROUNDS); do
     python3 - <<PY
 import json
 d=json.load(open("$OUT/${v}_$i.json"))
-print("$v $i", d["ms_per_step"], d["sustained"]["ms_per_step"], d["roofline"]["avg_launch_us"], flush=True)
+print("$v $i", d["ms_per_step"], (d.get("sustained") or {}).get("ms_per_step"), d["roofline"]["avg_launch_us"], flush=True)
 PY
   done
 done
