@@ -39,7 +39,11 @@ def init_from_env(device_type="cuda"):
         if device_type == "cuda":
             local = int(os.environ.get("PC_FORCE_DEVICE", local))
             torch.cuda.set_device(local)
-        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+        # (a bounded collective timeout: a rank that died inside a step must end the job, not park its peers for the backend's
+        # default half hour)
+        import datetime
+        dist.init_process_group(backend=backend, rank=rank, world_size=world,
+                                timeout=datetime.timedelta(seconds=int(os.environ.get("PC_DIST_TIMEOUT_S", "600"))))
     return rank, world, local
 
 
