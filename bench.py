@@ -563,7 +563,10 @@ def self_launch(n, argv):
         if live:
             time.sleep(0.05)
     rd.join(10.0)
-    sys.stdout.write(b"".join(chunks).decode())
+    # rank 0's JSON line goes to stdout alone; anything else a library printed there (gloo announces its connections on stdout)
+    # is passed on to stderr
+    for ln in b"".join(chunks).decode(errors="replace").splitlines():
+        (sys.stdout if ln.startswith("{") else sys.stderr).write(ln + "\n")
     sys.stdout.flush()
     return 1 if worst else 0
 
