@@ -910,7 +910,140 @@ __global__ __launch_bounds__(256) void gemm_nt_chain16_kernel(NtChain c) {
     }
 }
 
-// D = 128 attention chains only: every stage M rows (the same M), K = N = 128 per plain stage / head structure above.
+// The same chains at PRODUCT_EMB_DIM = 256 (BASELINE configs[4]; head dim 64): the attention block's per-sample products ran as
+// eight grouped few-row launches of ~20 us there.  A product's weight fragments (K = 256: 64 VGPRs per 16-column block) no
+// longer fit the register file all at once, so a wave streams its column blocks from L2 one ahead of the block being multiplied;
+// LDS: the 16 x 1024 input tile of the AHEAD stage (66 KB) + the 16 x 256 hand-over tile.
+#define CH_LDB 260          /* 256-wide LDS rows */
+#define CH_LDB4 1028        /* 1024-wide */
+template <bool AHEAD_FIRST>
+__global__ __launch_bounds__(256) void gemm_nt_chain16_d256_kernel(NtChain c) {
+    extern __shared__ __attribute__((aligned(16))) float ch_lds[];
+    float* sS = ch_lds;                                          // [16][CH_LDB]
+    float* sA = ch_lds + 16 * CH_LDB;                            // [16][CH_LDB4] or [16][CH_LDB]
+    if ((int)blockIdx.x >= c.tiles) {
+        hinge_mean_body(c.rider, ch_lds);
+        return;
+    }
+    const int tid = threadIdx.x, lane = tid & 63, ci = lane & 15, rh = lane >> 4;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const NtArgs& a0 = c.a[0];
+    const NtArgs& a1 = c.a[1];
+    const int row0 = blockIdx.x * 16, M = a0.M;
+    auto lds_sync = [&]() {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+    };
+    // PLAIN over the 16 x 256 LDS tile `src`: wave w owns the column blocks 4 w .. 4 w + 3, fragments one block ahead
+    // (two blocks' fragments in flight: 128 VGPRs; the biases with them)
+    auto plain = [&](const NtArgs& a, const float* src, float* keep) {
+        BFrag<16> f[2];
+        float bias4[4];
+#pragma unroll
+        for (int j = 0; j < 2; j++) f[j] = load_b<256, false>(a.W, a.ldw, 16 * (4 * w + j), 256, lane);
+#pragma unroll
+        for (int j = 0; j < 4; j++) bias4[j] = a.bias ? a.bias[16 * (4 * w + j) + ci] : 0.f;
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const int col = 16 * (4 * w + j) + ci;
+            f32x4v acc[1] = {{0.f, 0.f, 0.f, 0.f}};
+            mul_b<16, 1>(src, CH_LDB, 1, f[j & 1], acc, lane);
+            if (j + 2 < 4) f[j & 1] = load_b<256, false>(a.W, a.ldw, 16 * (4 * w + j + 2), 256, lane);
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                const int row = 4 * rh + r;
+                const float v = acc[0][r] + bias4[j];
+                if (keep) keep[row * CH_LDB + col] = v;
+                if (row0 + row < M) a.C[(size_t)(row0 + row) * a.ldc + col] = v;
+            }
+        }
+    };
+    if (!AHEAD_FIRST) {
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const int e = tid + 256 * u, r = e >> 6, c4 = (e & 63) * 4;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (row0 + r < M) v = *reinterpret_cast<const float4*>(a0.A + (size_t)(row0 + r) * a0.lda + c4);
+            *reinterpret_cast<float4*>(&sA[r * CH_LDB + c4]) = v;
+        }
+        lds_sync();
+        plain(a0, sA, sS);
+        lds_sync();
+        // KHEAD: wave h multiplies its head's 64 k's against all sixteen column blocks; C[r][256 h + d]
+        // (requested BEFORE the first stage's epilogue would be better still; here: groups of four blocks, two groups in flight)
+        BFrag<4> fk[2][4];
+#pragma unroll
+        for (int q = 0; q < 2; q++)
+#pragma unroll
+            for (int u = 0; u < 4; u++) fk[q][u] = load_b<64, false>(a1.W + 64 * w, a1.ldw, 16 * (4 * q + u), 256, lane);
+#pragma unroll
+        for (int gq = 0; gq < 4; gq++) {
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                const int nb = 4 * gq + u;
+                f32x4v acc[1] = {{0.f, 0.f, 0.f, 0.f}};
+                mul_b<4, 1>(sS + 64 * w, CH_LDB, 1, fk[gq & 1][u], acc, lane);
+                const int col = 256 * w + 16 * nb + ci;
+#pragma unroll
+                for (int r = 0; r < 4; r++) {
+                    const int row = 4 * rh + r;
+                    if (row0 + row < M) a1.C[(size_t)(row0 + row) * a1.ldc + col] = acc[0][r];
+                }
+            }
+            if (gq + 2 < 4) {
+#pragma unroll
+                for (int u = 0; u < 4; u++) fk[gq & 1][u] = load_b<64, false>(a1.W + 64 * w, a1.ldw, 16 * (4 * (gq + 2) + u), 256, lane);
+            }
+        }
+    } else {
+        float rs4[4];
+#pragma unroll
+        for (int r = 0; r < 4; r++)
+            rs4[r] = (a0.brs && row0 + 4 * rh + r < M) ? a0.brs[(size_t)(row0 + 4 * rh + r) * a0.ldbrs + w] : 1.f;
+        BFrag<16> f[2];
+#pragma unroll
+        for (int j = 0; j < 2; j++) f[j] = load_b<256, false>(a0.W, a0.ldw, 64 * w + 16 * j, 256, lane);
+        float ba4[4];
+#pragma unroll
+        for (int j = 0; j < 4; j++) ba4[j] = a0.bias ? a0.bias[64 * w + 16 * j + ci] : 0.f;
+#pragma unroll
+        for (int half = 0; half < 2; half++) {
+            float4 x[8];
+#pragma unroll
+            for (int u = 0; u < 8; u++) {
+                const int e = tid + 256 * (8 * half + u), r = e >> 8, c4 = (e & 255) * 4;
+                x[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (row0 + r < M) x[u] = *reinterpret_cast<const float4*>(a0.A + (size_t)(row0 + r) * a0.lda + c4);
+            }
+#pragma unroll
+            for (int u = 0; u < 8; u++) {
+                const int e = tid + 256 * (8 * half + u), r = e >> 8, c4 = (e & 255) * 4;
+                *reinterpret_cast<float4*>(&sA[r * CH_LDB4 + c4]) = x[u];
+            }
+        }
+        lds_sync();
+        // AHEAD: wave h takes image h (columns [256 h, 256 h + 256) of the tile) and its own 64 output columns
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const int col = 64 * w + 16 * j + ci;
+            f32x4v acc[1] = {{0.f, 0.f, 0.f, 0.f}};
+            mul_b<16, 1>(sA + 256 * w, CH_LDB4, 1, f[j & 1], acc, lane);
+            if (j + 2 < 4) f[j & 1] = load_b<256, false>(a0.W, a0.ldw, 64 * w + 16 * (j + 2), 256, lane);
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                const int row = 4 * rh + r;
+                const float v = acc[0][r] + ba4[j] * rs4[r];
+                sS[row * CH_LDB + col] = v;
+                if (row0 + row < M) a0.C[(size_t)(row0 + row) * a0.ldc + col] = v;
+            }
+        }
+        lds_sync();
+        plain(a1, sS, nullptr);
+    }
+}
+
+// The attention chains: every stage M rows (the same M); D = 128 or 256: K = N = D per plain stage / head structure above.
 int launch_gemm_nt_chain(const NtArgs* args, const int* modes, int n, hipStream_t st, const HingeMeanJob* rider) {
     if (!args || !modes || n < 1 || n > 2) return PC_EINVAL;
     NtChain c = {};
@@ -921,6 +1054,17 @@ int launch_gemm_nt_chain(const NtArgs* args, const int* modes, int n, hipStream_
         if (!a.A || !a.W || !a.C || a.M <= 0 || a.M != args[0].M) return PC_EINVAL;
         if (a.gather || a.prologue != NT_PRO_NONE || a.stats != NT_STAT_NONE || a.epilogue != NT_EPI_NONE) return PC_ESHAPE;
         if (a.lda % 4 || a.ldw % 4 || a.ldc % 4 || (((uintptr_t)a.A | (uintptr_t)a.W | (uintptr_t)a.C) & 15)) return PC_ESHAPE;
+        if (args[0].N == 256 || args[0].K == 1024) {                 // the D = 256 chains (16-row tiles only)
+            if (modes[i] == NT_MODE_PLAIN) { if (a.N != 256 || a.K != 256 || a.brs) return PC_ESHAPE; flops += 2.0 * a.M * 256 * 256; }
+            else if (modes[i] == NT_MODE_KHEAD) { if (a.N != 1024 || a.K != 256 || a.bias) return PC_ESHAPE; flops += 2.0 * a.M * 1024 * 64; }
+            else if (modes[i] == NT_MODE_AHEAD) { if (a.N != 256 || a.K != 1024) return PC_ESHAPE; flops += 2.0 * a.M * 256 * 256; }
+            else return PC_EINVAL;
+            c.a[i] = a;
+            c.a[i].seg = retile_plain(a.M);
+            c.mode[i] = modes[i];
+            c.epi[i] = NT_EPI_NONE;
+            continue;
+        }
         if (modes[i] == NT_MODE_PLAIN) { if (a.N != 128 || a.K != 128 || a.brs) return PC_ESHAPE; flops += 2.0 * a.M * 128 * 128; }
         else if (modes[i] == NT_MODE_KHEAD) { if (a.N != 512 || a.K != 128 || a.bias) return PC_ESHAPE; flops += 2.0 * a.M * 512 * 32; }
         else if (modes[i] == NT_MODE_AHEAD) { if (a.N != 128 || a.K != 512) return PC_ESHAPE; flops += 2.0 * a.M * 128 * 128; }
@@ -936,8 +1080,27 @@ int launch_gemm_nt_chain(const NtArgs* args, const int* modes, int n, hipStream_
         if (!rider->d_pos || !rider->d_neg || !rider->loss || rider->B <= 0) return PC_EINVAL;
         c.rider = *rider;
     }
-    if (n == 2 && ((modes[0] == NT_MODE_PLAIN && modes[1] == NT_MODE_KHEAD) || (modes[0] == NT_MODE_AHEAD && modes[1] == NT_MODE_PLAIN)) &&
-        !args[1].brs && !(modes[0] == NT_MODE_PLAIN && args[0].brs)) {
+    const bool two = n == 2 && ((modes[0] == NT_MODE_PLAIN && modes[1] == NT_MODE_KHEAD) || (modes[0] == NT_MODE_AHEAD && modes[1] == NT_MODE_PLAIN)) &&
+                     !args[1].brs && !(modes[0] == NT_MODE_PLAIN && args[0].brs);
+    if (args[0].N == 256 || args[0].K == 1024) {
+        if (!two) return PC_ESHAPE;
+        c.tiles = (args[0].M + 15) / 16;
+        if (rider) {
+            if (!rider->d_pos || !rider->d_neg || !rider->loss || rider->B <= 0) return PC_EINVAL;
+            c.rider = *rider;
+        }
+        const size_t lds16 = (size_t)16 * (CH_LDB + (modes[0] == NT_MODE_AHEAD ? CH_LDB4 : CH_LDB)) * 4;
+        static const hipError_t a16[2] = {
+            hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt_chain16_d256_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024),
+            hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt_chain16_d256_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024)};
+        (void)a16;
+        const int pbd = pc_prof_begin(PC_KIND_GEMM_NT_SMALL, flops, st);
+        if (modes[0] == NT_MODE_PLAIN) PC_LAUNCH(gemm_nt_chain16_d256_kernel<false>, dim3(c.tiles + (rider ? 1 : 0)), dim3(256), lds16, st, c);
+        else PC_LAUNCH(gemm_nt_chain16_d256_kernel<true>, dim3(c.tiles + (rider ? 1 : 0)), dim3(256), lds16, st, c);
+        pc_prof_end(pbd, st);
+        return pc_launch_status();
+    }
+    if (two) {
         // the two chains of the attention block: 16-row tiles
         c.tiles = (args[0].M + 15) / 16;
         const int pb16 = pc_prof_begin(PC_KIND_GEMM_NT_SMALL, flops, st);
