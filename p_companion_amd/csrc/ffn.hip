@@ -443,7 +443,14 @@ int ffn_backward_part1(const pc_p2v_tensors* p, const pc_p2v_tensors* g, const f
     t5.Z = dy; t5.ldz = D; t5.A = sv->a2; t5.lda = PC_H; t5.R = rows; t5.No = D; t5.Ni = PC_H; t5.seg = si;
     t5.dW = g->w5; t5.lddw = PC_H; t5.db = g->b5; t5.accumulate = accumulate; t5.slabs = w.slabs[0];
     t5.slab_floats = w.slab_floats;
-    PC_TRY(launch_gemm_tn(t5, st, df));
+    if (D == 256 && rows >= 8192 && (size_t)2 * 128 * ((size_t)128 * PC_H + 128) <= w.slab_floats) {
+        // PRODUCT_EMB_DIM = 256: dW5 is a 256 x 256 gradient like dW3 -- the paired half-slice launch instead of the full tile
+        // (eight accumulator blocks per wave at 256 registers: 32 B of scratch, 133 us at configs[4])
+        const size_t half = (size_t)128 * ((size_t)128 * PC_H + 128);
+        PC_TRY(launch_gemm_tn_halves(t5, w.slabs[0], w.slabs[0] + half, half, st, df));
+    } else {
+        PC_TRY(launch_gemm_tn(t5, st, df));
+    }
 
     // dZ1 = (dZ2 W3) * (1 - A1^2), A1 = tanh(BN(H0)); plus BN-backward partial sums
     NtArgs b2 = nt_plain(w.dz2, PC_H, w.w3t, PC_H, nullptr, w.dz1, PC_H, rows, PC_H, PC_H, si);
