@@ -19,13 +19,34 @@ __device__ __forceinline__ void pairs_negatives_body(const int32_t* pair_ids, in
     positive_idx[b] = pos;
     const int lo = sim_rowptr[a], hi = sim_rowptr[a + 1];
     Philox rng(seed, step, (uint32_t)b);
+    // the anchor's positives (<= 8 of them: nearly always) and the negatives drawn so far live in registers: the loop used to
+    // re-read both from global memory for every candidate -- a chain of dependent L2 round trips per draw (same draws, same
+    // decisions: the stream and the rejection rules are untouched)
+    constexpr int NPOS = 8, NNEG = 8;
+    int pos_r[NPOS], neg_r[NNEG];
+#pragma unroll
+    for (int j = 0; j < NPOS; j++) pos_r[j] = lo + j < hi ? sim_col[lo + j] : -1;
+#pragma unroll
+    for (int j = 0; j < NNEG; j++) neg_r[j] = -1;
     int got = 0;
     while (got < K) {
         const int c = (int)rng.below((uint32_t)n_products);
         bool ok = c != a;
-        for (int j = lo; ok && j < hi; j++) ok = sim_col[j] != c;
-        for (int j = 0; ok && j < got; j++) ok = negative_idx[(size_t)b * K + j] != c;
-        if (ok) negative_idx[(size_t)b * K + got++] = c;
+#pragma unroll
+        for (int j = 0; j < NPOS; j++) ok = ok && pos_r[j] != c;
+        for (int j = lo + NPOS; ok && j < hi; j++) ok = sim_col[j] != c;
+        if (K <= NNEG) {
+#pragma unroll
+            for (int j = 0; j < NNEG; j++) ok = ok && neg_r[j] != c;
+        } else {
+            for (int j = 0; ok && j < got; j++) ok = negative_idx[(size_t)b * K + j] != c;
+        }
+        if (ok) {
+            negative_idx[(size_t)b * K + got] = c;
+#pragma unroll
+            for (int j = 0; j < NNEG; j++) neg_r[j] = j == got ? c : neg_r[j];
+            got++;
+        }
     }
 }
 
