@@ -1193,11 +1193,12 @@ __global__ __launch_bounds__(256) void sample_hidden_kernel(SampleHArgs a) {
 
 #define SUT 32        /* samples per tile of sample_sims_topk_kernel */
 #ifndef PC_STC
-#define PC_STC 256    /* types per chunk of sample_sims_topk_kernel: 38 KB of LDS and 118 VGPRs, FOUR workgroups per CU
+#define PC_STC 256    /* types per chunk of sample_sims_topk_kernel: 39 KB of LDS and < 128 VGPRs, FOUR workgroups per CU
                          (320 with three: 0.315 against 0.301 ms per step at T = 34800, B = 4096, alternating runs on one box) */
 #endif
 #define STC PC_STC
-#define SWPS (STC <= 256 ? 4 : 3)   /* workgroups per CU: LDS = SUT (36 + STC + 4) floats */
+#define SWPS (STC <= 256 ? 4 : 3)   /* workgroups per CU: LDS = SUT (48 + STC + 4) floats */
+#define HPL (SUT * LH)              /* bf16 elements of one piece plane of a tile's hd rows */
 struct SampleSimsArgs {
     const float *hd, *G, *g0;
     int B, T, K, nchunks;
@@ -1205,10 +1206,38 @@ struct SampleSimsArgs {
     float* zero[2]; size_t nzero[2]; int zcols;      // rider: see TypeSimsArgs
 };
 
+// The product runs as fp32-grade sums on the BF16 matrix cores (common.h split3: three bf16 pieces per operand, the six
+// significant piece products smallest first in the fp32 accumulator -- the same form, and the same error against an fp64
+// product, as the large Product2Vec GEMMs): the contraction is LH = 32 wide, so ONE v_mfma_f32_16x16x32_bf16 covers a 16 x 16
+// block's whole K and six of them (6 x 16 clocks) replace the eight v_mfma_f32_16x16x4_f32 of the first version (8 x 32
+// clocks).  The hd rows of a tile are split ONCE, by the thread that fetched them (one float4 each), and staged as three
+// bf16 piece planes; the chunk's G fragments are split once per workgroup and stay in registers.
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ f32x4v mfma16_bf16(const bf16x8& a, const bf16x8& b, f32x4v c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+}
+// the three pieces of four values (split3's arithmetic): piece p as two dwords = four bf16 in element order
+__device__ __forceinline__ void split3_4(const float4& x, uint2 (&q)[3]) {
+    const float v[4] = {x.x, x.y, x.z, x.w};
+    unsigned u0[4], u1[4], u2[4];
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        u0[i] = __float_as_uint(v[i]);
+        const float r1 = v[i] - __uint_as_float(u0[i] & 0xffff0000u);
+        u1[i] = __float_as_uint(r1);
+        const float r2 = r1 - __uint_as_float(u1[i] & 0xffff0000u);
+        u2[i] = __float_as_uint(r2);
+    }
+    q[0] = make_uint2(__builtin_amdgcn_perm(u0[1], u0[0], 0x07060302u), __builtin_amdgcn_perm(u0[3], u0[2], 0x07060302u));
+    q[1] = make_uint2(__builtin_amdgcn_perm(u1[1], u1[0], 0x07060302u), __builtin_amdgcn_perm(u1[3], u1[2], 0x07060302u));
+    q[2] = make_uint2(__builtin_amdgcn_perm(u2[1], u2[0], 0x07060302u), __builtin_amdgcn_perm(u2[3], u2[2], 0x07060302u));
+}
+
 __global__ __launch_bounds__(256, SWPS) void sample_sims_topk_kernel(SampleSimsArgs a) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
-    float* Hd = sm;                         // [SUT][LD32]
-    float* Sims = Hd + SUT * LD32;          // [SUT][STC + 4]
+    __bf16* Hp = reinterpret_cast<__bf16*>(sm);              // [3 pieces][SUT][LH] bf16: lane (i, h) of an A fragment reads
+                                                             // the 16 B at row i, k = 8 h of a plane (1 KB per 16 rows, dense)
+    float* Sims = sm + 3 * HPL / 2;                          // [SUT][STC + 4]
     constexpr int LDS_ = STC + 4;
     if ((int)blockIdx.x >= a.nchunks) {
         const size_t wg = ((size_t)blockIdx.x - a.nchunks) * gridDim.y + blockIdx.y, nwg = (size_t)a.zcols * gridDim.y;
@@ -1223,12 +1252,17 @@ __global__ __launch_bounds__(256, SWPS) void sample_sims_topk_kernel(SampleSimsA
     const int t0 = blockIdx.x * STC;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, ci = lane & 15, rh = lane >> 4;
     constexpr int NBW = STC / 16 / 4;                       // G column blocks per wave, resident for the whole kernel
-    BFrag<2> f_s[NBW];
+    Split3 f_s[NBW];                                        // lane (j = ci, h = rh): G[t0 + 16 nb + j][8 h .. 8 h + 7] in three pieces
     float g0v[NBW];
 #pragma unroll
     for (int q = 0; q < NBW; q++) {
         const int t = t0 + 16 * (w + 4 * q) + ci;
-        f_s[q] = load_b<LH, false>(a.G, LH, t0 + 16 * (w + 4 * q), a.T, lane);
+        float4 lo = make_float4(0.f, 0.f, 0.f, 0.f), hi = lo;
+        if (t < a.T) {
+            lo = *reinterpret_cast<const float4*>(a.G + (size_t)t * LH + 8 * rh);
+            hi = *reinterpret_cast<const float4*>(a.G + (size_t)t * LH + 8 * rh + 4);
+        }
+        f_s[q] = split3(lo, hi);
         g0v[q] = t < a.T ? a.g0[t] : 0.f;
     }
     const int nvalid = min(STC, a.T - t0);
@@ -1241,21 +1275,41 @@ __global__ __launch_bounds__(256, SWPS) void sample_sims_topk_kernel(SampleSimsA
     const int ustep = gridDim.y * SUT;
     float4 nxt = fetch(blockIdx.y * SUT);
     for (int u0 = blockIdx.y * SUT; u0 < a.B; u0 += ustep) {
-        __syncthreads();                                   // (the previous tile's top-K pass has left Sims / Hd)
-        *reinterpret_cast<float4*>(&Hd[pr * LD32 + pc4]) = nxt;
+        __syncthreads();                                   // (the previous tile's top-K pass has left Sims / Hp)
+        {
+            uint2 pq[3];
+            split3_4(nxt, pq);
+#pragma unroll
+            for (int p3 = 0; p3 < 3; p3++) *reinterpret_cast<uint2*>(Hp + p3 * HPL + pr * LH + pc4) = pq[p3];
+        }
         if (u0 + ustep < a.B) nxt = fetch(u0 + ustep);
         __syncthreads();
-#pragma unroll
-        for (int q = 0; q < NBW; q++) {
-            const int nb = w + 4 * q;
-            f32x4v acc[SUT / 16];
-#pragma unroll
-            for (int m = 0; m < SUT / 16; m++) acc[m] = f32x4v{0.f, 0.f, 0.f, 0.f};
-            mul_b<2, SUT / 16>(Hd, LD32, SUT / 16, f_s[q], acc, lane);
+        {
+            bf16x8 ap[SUT / 16][3];                        // lane (i = ci, h = rh): hd[16 m + i][8 h .. 8 h + 7], piece p
 #pragma unroll
             for (int m = 0; m < SUT / 16; m++)
 #pragma unroll
-                for (int r = 0; r < 4; r++) Sims[(16 * m + 4 * rh + r) * LDS_ + 16 * nb + ci] = acc[m][r] + g0v[q];
+                for (int p3 = 0; p3 < 3; p3++)
+                    ap[m][p3] = *reinterpret_cast<const bf16x8*>(Hp + p3 * HPL + (16 * m + ci) * LH + 8 * rh);
+            f32x4v acc[NBW][SUT / 16];
+#pragma unroll
+            for (int q = 0; q < NBW; q++)
+#pragma unroll
+                for (int m = 0; m < SUT / 16; m++) acc[q][m] = f32x4v{0.f, 0.f, 0.f, 0.f};
+            // term by term over the NBW x SUT / 16 independent accumulators (no back-to-back dependent MFMAs), smallest first
+#define PC_SS_TERM(PA, QB)                                                                              \
+            _Pragma("unroll") for (int q = 0; q < NBW; q++)                                             \
+                _Pragma("unroll") for (int m = 0; m < SUT / 16; m++) acc[q][m] = mfma16_bf16(ap[m][PA], f_s[q].QB, acc[q][m]);
+            PC_SS_TERM(2, p0) PC_SS_TERM(0, p2) PC_SS_TERM(1, p1) PC_SS_TERM(1, p0) PC_SS_TERM(0, p1) PC_SS_TERM(0, p0)
+#undef PC_SS_TERM
+#pragma unroll
+            for (int q = 0; q < NBW; q++) {
+                const int nb = w + 4 * q;
+#pragma unroll
+                for (int m = 0; m < SUT / 16; m++)
+#pragma unroll
+                    for (int r = 0; r < 4; r++) Sims[(16 * m + 4 * rh + r) * LDS_ + 16 * nb + ci] = acc[q][m][r] + g0v[q];
+            }
         }
         __syncthreads();
         // a row group of 16 lanes per sample, four samples per wave side by side: SUT / 16 passes
@@ -1917,7 +1971,7 @@ static int fused_step_impl(const pc_joint_tensors* p, const pc_joint_tensors* g,
         sa.part_val = w.part_val; sa.part_idx = w.part_idx;
         sa.zero[0] = g->query_types; sa.nzero[0] = (size_t)T * PC_L; sa.zero[1] = g->comp_types; sa.nzero[1] = (size_t)T * PC_L;
         sa.zcols = 8;
-        const size_t lds = ((size_t)SUT * LD32 + (size_t)SUT * (STC + 4)) * 4;
+        const size_t lds = ((size_t)3 * HPL / 2 + (size_t)SUT * (STC + 4)) * 4;
         const int tiles_s = (B + SUT - 1) / SUT;
         // SWPS workgroups per CU: y so that chunks x y fills the chip's slots (each workgroup then walks its share of the sample tiles)
         int gy = (256 * SWPS - sa.zcols) / (sa.nchunks > 0 ? sa.nchunks : 1);
