@@ -198,10 +198,16 @@ __device__ __forceinline__ unsigned umed3(unsigned a, unsigned b, unsigned c) {
     asm("v_med3_u32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
     return r;
 }
-template <int CTRL>
-__device__ __forceinline__ unsigned dpp_row_umax(unsigned v) {
-    const unsigned o = (unsigned)__builtin_amdgcn_update_dpp((int)v, (int)v, CTRL, 0xf, 0xf, false);
-    return o > v ? o : v;
+// max over a row of 16 lanes, every lane gets it: four v_max_u32 with the rotated operand read through DPP (the builtin form
+// compiles to a v_mov_dpp and a separate maximum each).  The wait states a DPP read of a VGPR the previous VALU instruction
+// wrote needs are spelled out: the hazard recogniser does not look inside inline asm.
+__device__ __forceinline__ unsigned row16_umax(unsigned v) {
+    asm("s_nop 1\n\tv_max_u32_dpp %0, %0, %0 row_ror:1 row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1\n\tv_max_u32_dpp %0, %0, %0 row_ror:2 row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1\n\tv_max_u32_dpp %0, %0, %0 row_ror:4 row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1\n\tv_max_u32_dpp %0, %0, %0 row_ror:8 row_mask:0xf bank_mask:0xf\n\ts_nop 1"
+        : "+v"(v));
+    return v;
 }
 template <int FULL>
 __device__ __forceinline__ bool row_topk_trunc(const float* row, int n, int K, int l16, unsigned (&oh)[FK], unsigned (&ol)[FK]) {
@@ -232,10 +238,9 @@ __device__ __forceinline__ bool row_topk_trunc(const float* row, int n, int K, i
     unsigned top[4];
 #pragma unroll
     for (int r = 0; r < 4; r++) {
-        unsigned m = a;                                        // row maximum on the rotate network: every lane gets it
-        m = dpp_row_umax<0x121>(m); m = dpp_row_umax<0x122>(m); m = dpp_row_umax<0x124>(m); m = dpp_row_umax<0x128>(m);
-        top[r] = m;
-        if (a == m) { a = b; b = c; c = d; d = 0u; }           // (keys carry their index: one owner)
+        top[r] = row16_umax(a);                                // row maximum on the rotate network: every lane gets it
+        const bool own = a == top[r];                          // (keys carry their index: one owner retires its head)
+        a = own ? b : a; b = own ? c : b; c = own ? d : c; d = own ? 0u : d;
     }
     bool exact = K <= 3;
 #pragma unroll
@@ -246,6 +251,63 @@ __device__ __forceinline__ bool row_topk_trunc(const float* row, int n, int K, i
         oh[r] = 0u; ol[r] = 0u;
         if (r < 3 && r < K && top[r] != 0u) {
             const unsigned idx = 511u - (top[r] & 511u);
+            oh[r] = ord_f32(row[idx]);                          // the exact value back from LDS
+            ol[r] = ~idx;
+        }
+    }
+    return exact;
+}
+
+// The same selection on FLOAT keys (full chunks of sample_sims_topk_kernel: 142 M elements per step at B = 4096, T = 34800, where
+// the selection, not the matrix pipe, sets the kernel's time): the key is the value's own bit pattern with its low 9 bits replaced by
+// 511 - index -- still a float, and truncation towards zero is monotone for both signs, so v_max_f32 / v_med3_f32 order the keys as
+// the unsigned image did and the three instructions of ord_f32 per element are gone (6 VALU per element instead of 10).  Same
+// exactness rule and the same fallback: two of the first K + 1 that agree in their upper 23 bits (near-ties, exact ties, rows of
+// zeros -- whose keys are denormals: the kernels run with fp32 denormals preserved) send the wave to row_topk_ins.  An infinite
+// similarity (a diverged model) would form a NaN key: the selection is then arbitrary but in range.  -INFINITY = no element.
+// max over a row of 16 lanes, every lane gets it: four v_max_f32 with the rotated operand read through DPP (the builtin form compiles
+// to v_mov_dpp + a canonicalising v_max + v_max each: three instructions where one does).  The wait states a DPP read of a VGPR the
+// previous VALU instruction wrote needs are spelled out: the hazard recogniser does not look inside inline asm.
+__device__ __forceinline__ float row16_fmax(float v) {
+    asm("s_nop 1\n\tv_max_f32_dpp %0, %0, %0 row_ror:1 row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1\n\tv_max_f32_dpp %0, %0, %0 row_ror:2 row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1\n\tv_max_f32_dpp %0, %0, %0 row_ror:4 row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1\n\tv_max_f32_dpp %0, %0, %0 row_ror:8 row_mask:0xf bank_mask:0xf\n\ts_nop 1"
+        : "+v"(v));
+    return v;
+}
+template <int FULL>
+__device__ __forceinline__ bool row_topk_truncf(const float* row, int K, int l16, unsigned (&oh)[FK], unsigned (&ol)[FK]) {
+    static_assert(FULL >= 16 && FULL <= 512 && (FULL & (FULL - 1)) == 0, "full power-of-two chunks of at most 512 elements");
+    float a = -INFINITY, b = -INFINITY, c = -INFINITY, d = -INFINITY;
+    float x[FULL / 16];
+#pragma unroll
+    for (int i = 0; i < FULL / 16; i++) x[i] = row[l16 + 16 * i];
+    const unsigned lanec = 15u - (unsigned)l16;                 // 511 - (l16 + 16 i) = ((31 - i) << 4) | (15 - l16)
+#pragma unroll
+    for (int i = 0; i < FULL / 16; i++) {
+        const float k = __uint_as_float(((__float_as_uint(x[i]) & ~511u) | lanec) | ((31u - (unsigned)i) << 4));
+        // (the running maximum from inline asm: fmaxf would first canonicalise k -- one more instruction per element)
+        d = __builtin_amdgcn_fmed3f(c, d, k); c = __builtin_amdgcn_fmed3f(b, c, k); b = __builtin_amdgcn_fmed3f(a, b, k);
+        asm("v_max_f32 %0, %1, %2" : "=v"(a) : "v"(a), "v"(k));
+    }
+    unsigned top[4];
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+        top[r] = __float_as_uint(row16_fmax(a));               // row maximum on the rotate network: every lane gets it
+        const bool own = __float_as_uint(a) == top[r];         // (keys carry their index: one owner retires its head)
+        a = own ? b : a; b = own ? c : b; c = own ? d : c; d = own ? -INFINITY : d;
+    }
+    constexpr unsigned NONE = 0xff800000u;
+    bool exact = K <= 3;
+#pragma unroll
+    for (int r = 0; r < 3; r++)
+        if (r < K && top[r + 1] != NONE && (top[r] >> 9) == (top[r + 1] >> 9)) exact = false;
+#pragma unroll
+    for (int r = 0; r < FK; r++) {
+        oh[r] = 0u; ol[r] = 0u;
+        if (r < 3 && r < K && top[r] != NONE) {
+            const unsigned idx = (511u - (top[r] & 511u)) & (unsigned)(FULL - 1);   // (in range whatever the key: FULL is a power of two)
             oh[r] = ord_f32(row[idx]);                          // the exact value back from LDS
             ol[r] = ~idx;
         }
@@ -1317,7 +1379,9 @@ __global__ __launch_bounds__(256, SWPS) void sample_sims_topk_kernel(SampleSimsA
         for (int pass = 0; pass < SUT / 16; pass++) {
             const int s = 4 * (w + 4 * pass) + g4;
             unsigned kh[FK], kl[FK];
-            const bool exact = row_topk_trunc<STC>(Sims + s * LDS_, nvalid, a.K, l16, kh, kl);
+            bool exact;
+            if ((STC & (STC - 1)) == 0 && nvalid == STC) exact = row_topk_truncf<STC>(Sims + s * LDS_, a.K, l16, kh, kl);
+            else exact = row_topk_trunc<STC>(Sims + s * LDS_, nvalid, a.K, l16, kh, kl);      // (the tail chunk)
             if (__ballot(!exact)) row_topk_ins(Sims + s * LDS_, nvalid, a.K, l16, kh, kl);   // (wave-uniform; near-ties only)
             if (l16 == 0 && u0 + s < a.B)
                 for (int r = 0; r < a.K; r++) {
