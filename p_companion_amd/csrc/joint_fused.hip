@@ -1377,7 +1377,9 @@ __global__ __launch_bounds__(256, SWPS) void sample_sims_topk_kernel(SampleSimsA
         // a row group of 16 lanes per sample, four samples per wave side by side: SUT / 16 passes
 #pragma unroll 1
         for (int pass = 0; pass < SUT / 16; pass++) {
-            const int s = 4 * (w + 4 * pass) + g4;
+            // (the four row groups of a wave read rows FOUR apart: 4 x (STC + 4) floats = 16 banks mod 64, so the 64 lanes of a
+            // read hit 64 banks; consecutive rows sit 4 banks apart and collided four ways)
+            const int s = 16 * pass + 4 * g4 + w;
             unsigned kh[FK], kl[FK];
             bool exact;
             if ((STC & (STC - 1)) == 0 && nvalid == STC) exact = row_topk_truncf<STC>(Sims + s * LDS_, a.K, l16, kh, kl);
