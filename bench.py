@@ -186,7 +186,10 @@ def joint_algorithmic_bytes(b, t, k=3):
     return b * (512 + 1024 + 256 + k * 256 + 40) + t * 64 * 4 + 28 * (2 * t * 64 + 29024)
 
 
-def run_joint(args, rank, world, dev, types, steps, warmup, want_cpu, dropout=0.0):
+EXCHANGE = {"ex": None}      # the replicas' gradient exchange (distributed.make_exchange), set once in main() when N > 1
+
+
+def run_joint(args, rank, world, dev, types, steps, warmup, want_cpu, dropout=0.0, exchange=None):
     """BASELINE configs[2]: 100k products, T types, B pairs per GPU: PCompanion forward + both hinge losses + backward
     + Adam (pc_joint_train_step + pc_adam_step), loader batch construction included."""
     from types import SimpleNamespace
@@ -194,6 +197,7 @@ def run_joint(args, rank, world, dev, types, steps, warmup, want_cpu, dropout=0.
     from p_companion_amd.data import ComplementaryIndexDataset, ComplementaryIndexLoader, generate_scaled_bpg
     from p_companion_amd.p_companion import GraphedJointStep, PCompanion
     from p_companion_amd.product2vec import FusedAdam
+    exchange = EXCHANGE["ex"] if exchange is None else exchange
     cfg = SimpleNamespace(PRODUCT_EMB_DIM=128, TYPE_EMB_DIM=64, DROPOUT=float(dropout), MARGIN=1.0, ALPHA=0.8, NUM_COMP_TYPES=3,
                           NUM_TYPES=types, DEVICE=dev)
     # configs[2] is quoted on the 100 k catalogue; the complementary-pair dataset is built from host arrays, so a catalogue that
@@ -212,17 +216,24 @@ def run_joint(args, rank, world, dev, types, steps, warmup, want_cpu, dropout=0.
     if not multi and not args.no_graph:
         graphed = GraphedJointStep(model, opt, args.batch, mode="auto" if args.joint_launch == "epoch" else args.joint_launch)
     elif not args.no_graph:
-        # one process per GPU: the fused step writes gradients only, the flat gradient buffer is averaged over the replicas
-        # (one all-reduce of 29 k weights + both type tables), then the Adam launch
+        # one process per GPU: the fused step writes gradients only, the flat gradient buffer (29 k weights + both type tables)
+        # is averaged over the replicas, then the Adam launch.  --exchange native (default): the library's exchange slot --
+        # ncclAllReduce(ncclAvg) on its own RCCL communicator, issued from the step's own call (pc_joint_train_epoch_dp: the
+        # replica's whole epoch as one foreign call); hook: a Python grad_hook per step (T > 512: the two [T,64] table gradients
+        # as row lists with one host-visible read per step, the 29 k dense weights as one all-reduce)
         try:
-            graphed = GraphedJointStep(model, opt, args.batch, mode="direct", grad_hook=lambda g: pdist.all_reduce_mean_(g, world))
-            # (T > 512: the two [T,64] table gradients travel as row lists, the 29 k dense weights as one all-reduce)
-            graphed.grad_hook = pdist.joint_grad_hook(model, graphed, world)
+            if exchange is not None:
+                graphed = GraphedJointStep(model, opt, args.batch, mode="direct", exchange=exchange)
+                exchange.register(gflat)
+            else:
+                graphed = GraphedJointStep(model, opt, args.batch, mode="direct", grad_hook=lambda g: pdist.all_reduce_mean_(g, world))
+                graphed.grad_hook = pdist.joint_grad_hook(model, graphed, world)
         except ValueError:
             graphed = None
-    # 'epoch': train.py:36-57's loop over the epoch's batches as one foreign call (pc_joint_train_epoch) -- the same steps,
+    # 'epoch': train.py:36-57's loop over the epoch's batches as one foreign call (pc_joint_train_epoch / _dp) -- the same steps,
     # enqueued from C back to back; falls back to one call per step where the fused step does not serve the configuration
-    by_epoch = not multi and graphed is not None and args.joint_launch == "epoch" and graphed.mode == "direct"
+    by_epoch = (graphed is not None and args.joint_launch == "epoch" and graphed.mode == "direct"
+                and (not multi or graphed.exchange is not None))
     # direct mode: the loader hands its batches over unbuilt and the step's first kernel builds them (same values)
     loader = ComplementaryIndexLoader(ComplementaryIndexDataset(bpg, "train"), args.batch, shuffle=True, seed=rank,
                                       device=dev, out=graphed.static if graphed else None,
@@ -240,8 +251,12 @@ def run_joint(args, rank, world, dev, types, steps, warmup, want_cpu, dropout=0.
         if graphed is not None:
             return graphed(b)[0]
         losses, _ = model.train_step(b)
-        pdist.all_reduce_mean_(gflat, world)
-        opt.step()
+        if exchange is not None:
+            exchange.register(gflat)
+            opt.step(exchange=exchange)
+        else:
+            pdist.all_reduce_mean_(gflat, world)
+            opt.step()
         return losses
 
     last = None
@@ -291,7 +306,10 @@ def run_joint(args, rank, world, dev, types, steps, warmup, want_cpu, dropout=0.
                                   f"batch={args.batch}/GPU, K=3 (loader batch construction included)",
                       "global_batch": world * args.batch, "parallelism": f"dp{world}", "final_loss": round(float(losses[0]), 5),
                       "dropout": float(dropout),
-                      "launch": ("pc_joint_train_epoch: the epoch's steps enqueued by one foreign call" if by_epoch else
+                      "exchange": (getattr(exchange, "kind", None) if multi and graphed is not None and graphed.exchange is not None else
+                                   "python grad_hook per step (torch.distributed)" if multi else None),
+                      "launch": (("pc_joint_train_epoch_dp: the replica's epoch (fused step without Adam, exchange slot, Adam) enqueued by one foreign call"
+                                  if multi else "pc_joint_train_epoch: the epoch's steps enqueued by one foreign call") if by_epoch else
                                  {"direct": "fused step, arguments resolved once (one foreign call per step)" +
                                             ("; gradients only, then all-reduce of the flat gradient buffer and the Adam launch" if multi else ""),
                                   "graph": "hipGraph replay"}[graphed.mode] if graphed is not None else "eager module calls"),
@@ -317,7 +335,7 @@ def run_joint(args, rank, world, dev, types, steps, warmup, want_cpu, dropout=0.
 
 # ----------------------------------------------------------------------------------------------- P2V phase
 def run_p2v(args, rank, world, dev, products, steps, warmup, want_cpu, profile_kernels=True, sustained=False, dim=None,
-            negatives=None, table_mode=None, dropout=0.0, pmc_kind=""):
+            negatives=None, table_mode=None, dropout=0.0, pmc_kind="", exchange=None):
     """One Product2Vec leg.  dim / negatives / table_mode default to the command line's; dropout = config.py:12's DROPOUT of
     the attention probabilities (0.0: the parity setting, every golden test; 0.1: the reference as shipped)."""
     from types import SimpleNamespace
@@ -328,6 +346,7 @@ def run_p2v(args, rank, world, dev, products, steps, warmup, want_cpu, profile_k
 
     from p_companion_amd.data import generate_device_bpg
     multi = pdist.collectives_on(world)                  # (world > 1, or the one-rank RCCL rehearsal PC_DIST_FORCE=1)
+    exchange = EXCHANGE["ex"] if exchange is None else exchange
     dim = args.dim if dim is None else dim
     negatives = args.negatives if negatives is None else negatives
     table_mode = args.table if table_mode is None else table_mode
@@ -353,6 +372,8 @@ def run_p2v(args, rank, world, dev, products, steps, warmup, want_cpu, profile_k
     model.train()
     opt = FusedAdam(model, lr=cfg.LEARNING_RATE)
     flat, gflat = model.flatten_parameters()
+    if exchange is not None:
+        exchange.register(gflat)
     table = bpg.cuda(dev)["features"]
     sharded = None
     if table_mode == "sharded":
@@ -377,8 +398,11 @@ def run_p2v(args, rank, world, dev, products, steps, warmup, want_cpu, profile_k
         tab = b.get("table", table)                       # sharded: the rows this batch's exchange delivered
         sync = (lambda t: torch.distributed.all_reduce(t)) if (args.sync_bn and multi) else None
         loss = model.train_step_indexed(tab, b, profile=profile, sync_reduce=sync)
-        pdist.all_reduce_mean_(gflat, world)
-        opt.step()
+        if exchange is not None:
+            opt.step(exchange=exchange)                   # pc_exchange_adam: the replicas' mean gradient + Adam, one foreign call
+        else:
+            pdist.all_reduce_mean_(gflat, world)
+            opt.step()
         return loss
 
     last = None
@@ -586,18 +610,32 @@ def rccl_info(world, dev):
 
 
 def guarded(name, fn, world):
-    """A SECONDARY leg must not take the headline down with it (an allocation that does not fit a smaller card, say): its
-    failure is reported in its place.  One process only: at N > 1 a rank that skipped a leg's collectives would hang its
-    peers, so there the exception propagates (and the launcher ends the job)."""
-    if world > 1:
-        return fn()
+    """A SECONDARY leg must not take the headline down with it (an allocation that does not fit a smaller card, a path no
+    multi-GPU box has exercised yet): its failure is reported in its place.  At N > 1 the ranks agree on the outcome (MIN
+    all-reduce of an ok flag): a failure every rank hits alike -- same code, same shapes -- is reported by all of them and the
+    line still goes out; a failure on SOME ranks only leaves the others inside the leg's collectives, which the process
+    group's bounded timeout ends (then the launcher ends the job: nothing can report that case)."""
+    err = None
+    res = None
     try:
-        return fn()
+        res = fn()
     except Exception as e:                                      # noqa: BLE001 -- reported, not swallowed
         import traceback
         traceback.print_exc(file=sys.stderr)
-        torch.cuda.synchronize()
-        return {"error": f"{type(e).__name__}: {e}"[:400], "leg": name}
+        err = f"{type(e).__name__}: {e}"[:400]
+        try:
+            torch.cuda.synchronize()
+        except Exception:                                       # noqa: BLE001
+            pass
+    if world > 1:
+        import torch.distributed as dist
+        flag = torch.tensor([0 if err else 1], dtype=torch.int32, device="cpu" if dist.get_backend() == "gloo" else torch.device("cuda", torch.cuda.current_device()))
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        if int(flag.item()) == 0 and err is None:
+            err = "failed on another rank"
+    if err:
+        return {"error": err, "leg": name}
+    return res
 
 
 def leg(res, keys=("value", "ms_per_step", "host_enqueue_ms_per_step", "final_loss", "catalogue", "roofline", "sharded_lookup")):
@@ -641,6 +679,9 @@ def main():
                     help="joint phase, one process: 'direct' = the fused step with its arguments resolved once; 'graph' = HIP-graph replay")
     ap.add_argument("--large-catalogue", type=int, default=0,
                     help="also time the P2V step over this many products (e.g. 2000000: few duplicate neighbours to merge)")
+    ap.add_argument("--exchange", choices=["native", "hook"], default="native",
+                    help="N > 1: the gradient exchange through the library's exchange slot (its own RCCL communicator, issued from the "
+                         "step's call) or from Python hooks per step (torch.distributed; the joint step's [T,64] tables as row lists)")
     ap.add_argument("--no-large", action="store_true",
                     help="skip the `large_catalogue` legs (BASELINE configs[3]: 10 M products through the row-sharded lookup; "
                          "configs[4]: 100 M products x 256, Zipf negatives; both generated in HBM)")
@@ -662,6 +703,15 @@ def main():
     want_cpu = not args.no_cpu_baseline and world == 1
     plain = args.products == 100_000 and args.dim == 128 and args.table == "replicated" and args.negatives == "uniform"
     rccl = rccl_info(world, dev)
+    if pdist.collectives_on(world) and args.exchange != "hook":
+        # the replicas' gradient exchange through the library's slot: its own RCCL communicator ('native'; verified by one
+        # all-reduce of a known vector and agreed over the ranks, else the host-driven form takes over) -- gloo rehearsals get
+        # torch.distributed behind the same slot
+        EXCHANGE["ex"] = pdist.make_exchange(world, rank=rank, kind="auto", device=dev)
+        if rccl is not None:
+            rccl["exchange"] = EXCHANGE["ex"].kind
+    elif rccl is not None:
+        rccl["exchange"] = "python hooks (torch.distributed), --exchange hook"
 
     p2v = joint = joint_ref = large = None
     extra = {}
@@ -677,12 +727,16 @@ def main():
             if rank == 0:
                 extra["p2v_dropout_0p1"] = leg(r)
     if args.phase in ("both", "joint"):
-        joint = run_joint(args, rank, world, dev, args.types, max(args.steps * 4, 100), max(args.warmup, 10), want_cpu, dropout=args.dropout)
+        # (with the Product2Vec phase in front, the joint legs are secondary to the headline value: guarded like the others)
+        first = (lambda name, fn: fn()) if args.phase == "joint" else (lambda name, fn: guarded(name, fn, world))
+        joint = first("joint", lambda: run_joint(args, rank, world, dev, args.types, max(args.steps * 4, 100), max(args.warmup, 10), want_cpu,
+                                                 dropout=args.dropout))
         if not args.no_dropout_legs and args.dropout == 0.0:
             extra["joint_dropout_0p1"] = guarded("joint_dropout_0p1", lambda: run_joint(args, rank, world, dev, args.types, max(args.steps * 4, 100),
                                                                                          max(args.warmup, 10), False, dropout=0.1), world)
         if not args.no_ref_types and args.types != 34800:
-            joint_ref = run_joint(args, rank, world, dev, 34800, max(args.steps, 20), max(args.warmup, 10), want_cpu, dropout=args.dropout)
+            joint_ref = guarded("joint_num_types_34800", lambda: run_joint(args, rank, world, dev, 34800, max(args.steps, 20), max(args.warmup, 10),
+                                                                           want_cpu, dropout=args.dropout), world)
             if not args.no_dropout_legs and args.dropout == 0.0:
                 extra["joint_num_types_34800_dropout_0p1"] = guarded(
                     "joint_num_types_34800_dropout_0p1",

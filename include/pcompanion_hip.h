@@ -51,6 +51,7 @@ extern "C" {
 #define PC_EWORKSPACE (-3)
 #define PC_EBATCHNORM (-4) /* a BatchNorm call group of ONE row in training mode: nn.BatchNorm1d raises
                              "Expected more than 1 value per channel when training" (product2vec.py:17,39) */
+#define PC_ECOMM (-5)    /* the RCCL library could not be loaded, or a communicator call failed (pc_rccl_last_error) */
 
 #define PC_D 128         /* PRODUCT_EMB_DIM (config.py:8) */
 #define PC_H 256         /* HIDDEN_SIZE (config.py:10) */
@@ -64,7 +65,10 @@ extern "C" {
  * 2: pc_p2v_tensors / pc_joint_tensors gained `dropout` (and `dim`). */
 /* 5: pc_set_option / pc_get_option / pc_release_device_state (the side queue of the fused Product2Vec step is part of the
  *    contract; the PC_NO_FORK environment variable of version 4 is gone). */
-#define PC_ABI_VERSION 5
+/* 6: the data-parallel exchange slot (pc_exchange_fn, pc_exchange_adam, pc_joint_train_epoch_dp) and the library's own RCCL
+ *    communicator behind it (pc_rccl_*): the gradient exchange of a replica is issued from the step's own call, on the step's
+ *    stream, not from a host-language hook per step. */
+#define PC_ABI_VERSION 6
 int pc_abi_version(void);
 /* Process-wide options.  PC_OPT_SIDE_QUEUE: 1 (default) = the unsplit fused Product2Vec step may use its side queue
  * (see "Library-owned device state" above), 0 = every launch stays on the caller's stream.  Unknown option / value:
@@ -524,6 +528,64 @@ int pc_joint_train_epoch(const pc_joint_tensors *p, const pc_joint_tensors *g, c
                          float *pos_items, float *neg_items, int batch, int drop_last, int num_types, int k,
                          int num_products, float margin, float alpha, float *losses_out, int32_t *topk,
                          int32_t *bad_count, void *ws, size_t ws_bytes, void *stream);
+
+/* ---------------------------------------------------------------------------------
+ * Data-parallel replicas (the reference is single-process: train.py:46-48 is loss.backward(); optimizer.step()
+ * with nothing between -- a replica of a data-parallel job averages the gradients there).  ABI 6.
+ *
+ * pc_exchange_fn: called between a step's last gradient kernel and its Adam launch, ON THE STEP'S STREAM: it must leave in
+ * grad[0 .. n) the mean over the replicas of what it found there, ordered on `stream` like a kernel (enqueue only; a host
+ * implementation may block).  Returns 0, or an error code the step's call then returns.  Every replica must make the same
+ * sequence of calls (same n): the entry points below call it exactly once per step.
+ * pc_rccl_allreduce_mean is the native implementation: ncclAllReduce(ncclAvg) of RCCL over xGMI on the library's own
+ * communicator, enqueued on `stream` -- no host round trip, no host-language call per step.
+ * --------------------------------------------------------------------------------- */
+typedef int (*pc_exchange_fn)(void *ctx, float *grad, size_t n, void *stream);
+
+/* exchange(ctx, grad, n, stream) -- skipped when exchange is NULL -- then torch.optim.Adam's update over the flat
+ * buffers as pc_adam_step_at(t) when the caller knows the step number (t >= 1), as pc_adam_step (device counter;
+ * `scalars` required) when t == 0: loss.backward() is behind, optimizer.step() of a replica as ONE call
+ * (scripts/pretrain_product2vec.py:34 + product2vec.py:157-158; train.py:47-48). */
+int pc_exchange_adam(pc_exchange_fn exchange, void *exchange_ctx, float *param, float *grad, float *exp_avg,
+                     float *exp_avg_sq, size_t n, int64_t *step_count, int64_t t, float *scalars, double lr,
+                     double beta1, double beta2, double eps, void *stream);
+
+/* pc_joint_train_epoch for a replica: every step is the fused step WITHOUT its Adam (gradients only), the exchange, then
+ * Adam over the flat buffers -- train.py:36-57 with the replicas' mean gradient, all steps of the epoch enqueued by this one
+ * call.  p / g must be views INTO param_flat / grad_flat (the [num_types,64] tables included: at num_types > 512 their dense
+ * gradients hold zeros outside the touched rows, so the flat mean is the mean of the dense gradients the reference's autograd
+ * would form).  t_first: the Adam step number of the epoch's first step (>= 1), or 0 = read the device counter
+ * (adam_scalars: device float[2], required then).  Every replica must run the same number of steps (same n_pairs, batch,
+ * drop_last): the exchange is a collective.  exchange == NULL: a single process (no exchange; same bits as
+ * pc_joint_train_epoch, tested). */
+int pc_joint_train_epoch_dp(const pc_joint_tensors *p, const pc_joint_tensors *g, float *param_flat, float *grad_flat,
+                            float *exp_avg_flat, float *exp_avg_sq_flat, size_t n_flat, int64_t *step_count,
+                            int64_t t_first, float *adam_scalars, double lr, double beta1, double beta2, double eps,
+                            pc_exchange_fn exchange, void *exchange_ctx, const int32_t *pairs, int64_t n_pairs,
+                            const float *features, const int32_t *type_idx, int n_types, uint64_t seed,
+                            uint64_t first_step, int32_t *query_idx, int32_t *query_types, int32_t *pos_types,
+                            int32_t *neg_types, float *pos_items, float *neg_items, int batch, int drop_last,
+                            int num_types, int k, int num_products, float margin, float alpha, float *losses_out,
+                            int32_t *topk, int32_t *bad_count, void *ws, size_t ws_bytes, void *stream);
+
+/* The library's own RCCL communicator (librccl.so.1 is resolved at run time with dlopen -- the copy the process has
+ * loaded already, e.g. torch's, else the system's; the library has no link-time dependency on it).
+ *   pc_rccl_available()          1 if the RCCL entry points could be resolved, else 0
+ *   pc_rccl_unique_id(out)       ncclGetUniqueId into 128 HOST bytes (one rank calls it and hands the bytes to the others
+ *                                by whatever channel the job has: torch.distributed.broadcast in p_companion_amd/distributed.py)
+ *   pc_rccl_comm_create(...)     ncclCommInitRank on the calling thread's current HIP device: a collective over the
+ *                                `world` ranks; *comm_out is the handle (the `ctx` of pc_rccl_allreduce_mean)
+ *   pc_rccl_comm_destroy(comm)   ncclCommDestroy (streams drained by the caller)
+ *   pc_rccl_allreduce_mean       a pc_exchange_fn: in-place ncclAllReduce(ncclFloat32, ncclAvg) of grad[0 .. n) on `stream`;
+ *                                every rank receives the same bits
+ *   pc_rccl_last_error()         text of the calling thread's last PC_ECOMM (static storage; "" if none)
+ * Returns PC_OK, PC_EINVAL, or PC_ECOMM. */
+int pc_rccl_available(void);
+int pc_rccl_unique_id(void *out_128_bytes);
+int pc_rccl_comm_create(const void *unique_id_128_bytes, int rank, int world, void **comm_out);
+int pc_rccl_comm_destroy(void *comm);
+int pc_rccl_allreduce_mean(void *comm, float *grad, size_t n, void *stream);
+const char *pc_rccl_last_error(void);
 
 /* ---------------------------------------------------------------------------------
  * Building blocks the Python modules compose their autograd from (module / dense mode).

@@ -15,7 +15,8 @@ D, H, HEADS, L = 128, 256, 4, 64
 
 _ERR = {-1: "PC_EINVAL (null pointer / bad size)", -2: "PC_ESHAPE (unsupported dimension/alignment)",
         -3: "PC_EWORKSPACE (workspace too small)",
-        -4: "PC_EBATCHNORM (a BatchNorm call group of one row in training mode)"}
+        -4: "PC_EBATCHNORM (a BatchNorm call group of one row in training mode)",
+        -5: "PC_ECOMM (RCCL could not be loaded, or a communicator call failed)"}
 
 
 class HipKernelError(RuntimeError):
@@ -134,6 +135,17 @@ SIGNATURES = {
     "pc_joint_train_epoch": (_i, [_P(JointTensors), _P(JointTensors), _P(JointTensors), _P(JointTensors), _vp, _d, _d, _d, _d,
                                   _vp, _i64, _vp, _vp, _i, _u64, _u64, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _f,
                                   _vp, _vp, _vp, _vp, _sz, _vp]),
+    # ABI 6: the data-parallel exchange slot (a pc_exchange_fn travels as a plain address) and the library's RCCL communicator
+    "pc_exchange_adam": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp, _i64, _vp, _d, _d, _d, _d, _vp]),
+    "pc_joint_train_epoch_dp": (_i, [_P(JointTensors), _P(JointTensors), _vp, _vp, _vp, _vp, _sz, _vp, _i64, _vp, _d, _d, _d, _d,
+                                     _vp, _vp, _vp, _i64, _vp, _vp, _i, _u64, _u64, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i,
+                                     _i, _f, _f, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "pc_rccl_available": (_i, []),
+    "pc_rccl_unique_id": (_i, [_vp]),
+    "pc_rccl_comm_create": (_i, [_vp, _i, _i, _P(ctypes.c_void_p)]),
+    "pc_rccl_comm_destroy": (_i, [_vp]),
+    "pc_rccl_allreduce_mean": (_i, [_vp, _vp, _sz, _vp]),
+    "pc_rccl_last_error": (ctypes.c_char_p, []),
     "pc_linear_forward": (_i, [_vp, _vp, _i, _i, _vp, _vp, _i, _i, _vp, _vp]),
     "pc_linear_backward_input": (_i, [_vp, _i, _i, _vp, _i, _i, _vp, _vp, _vp, _vp]),
     "pc_linear_backward_weight_workspace_bytes": (_sz, [_i, _i, _i]),
@@ -200,6 +212,8 @@ def check(rc, what):
     if rc == -4:
         # what nn.BatchNorm1d raises in the reference (torch/nn/functional.py _verify_batch_size)
         raise ValueError(f"Expected more than 1 value per channel when training, got input size torch.Size([1, {H}])")
+    if rc == -5:
+        raise HipKernelError(f"{what}: {_ERR[rc]}: {lib().pc_rccl_last_error().decode(errors='replace')}")
     if rc < 0:
         raise HipKernelError(f"{what}: {_ERR.get(rc, rc)}")
     raise HipKernelError(f"{what}: hipError_t {rc}")

@@ -2253,3 +2253,46 @@ extern "C" int pc_joint_train_epoch(const pc_joint_tensors* p, const pc_joint_te
     }
     return PC_OK;
 }
+
+// The same epoch for a REPLICA of a data-parallel job (ABI 6): per step the fused step without its Adam (gradients only), the
+// exchange slot -- pc_rccl_allreduce_mean on the library's own RCCL communicator, or whatever the caller supplies -- on the
+// step's stream, then Adam over the flat buffers.  The gradient exchange sits where train.py:46-48 has nothing
+// (loss.backward(); optimizer.step()): issued from this call, between two kernel launches, not from a host-language hook per
+// step (the step is ~2 kernel latencies long).
+extern "C" int pc_joint_train_epoch_dp(const pc_joint_tensors* p, const pc_joint_tensors* g, float* param_flat, float* grad_flat,
+                                       float* exp_avg_flat, float* exp_avg_sq_flat, size_t n_flat, int64_t* step_count,
+                                       int64_t t_first, float* adam_scalars, double lr, double beta1, double beta2, double eps,
+                                       pc_exchange_fn exchange, void* exchange_ctx, const int32_t* pairs, int64_t n_pairs,
+                                       const float* features, const int32_t* type_idx, int n_types, uint64_t seed,
+                                       uint64_t first_step, int32_t* query_idx, int32_t* query_types, int32_t* pos_types,
+                                       int32_t* neg_types, float* pos_items, float* neg_items, int B, int drop_last, int T, int K,
+                                       int num_products, float margin, float alpha, float* losses_out, int32_t* topk,
+                                       int32_t* bad_count, void* ws, size_t ws_bytes, void* stream) {
+    if (!p || !g || !pairs || !features || !type_idx || n_types <= 0 || n_pairs < 0 || B <= 0 || !losses_out) return PC_EINVAL;
+    if (!param_flat || !grad_flat || !exp_avg_flat || !exp_avg_sq_flat || n_flat == 0 || t_first < 0) return PC_EINVAL;
+    if (t_first == 0 && (!step_count || !adam_scalars)) return PC_EINVAL;
+    // p / g are views into the flat buffers: what the exchange averages and Adam updates must be what the step reads and writes
+    const float* const gp[10] = {g->itm_w, g->itm_b, g->typ_w, g->typ_b, g->dec_w, g->dec_b, g->enc_w, g->enc_b, g->comp_types, g->query_types};
+    const float* const pp[10] = {p->itm_w, p->itm_b, p->typ_w, p->typ_b, p->dec_w, p->dec_b, p->enc_w, p->enc_b, p->comp_types, p->query_types};
+    for (int i = 0; i < 10; i++) {
+        if (!gp[i] || !pp[i]) return PC_EINVAL;
+        if (gp[i] < grad_flat || gp[i] >= grad_flat + n_flat || pp[i] < param_flat || pp[i] >= param_flat + n_flat) return PC_EINVAL;
+        if (gp[i] - grad_flat != pp[i] - param_flat) return PC_EINVAL;
+    }
+    pc_joint_tensors pl = *p;
+    int64_t done = 0;
+    for (int64_t i = 0; done < n_pairs; i++) {
+        const int64_t left = n_pairs - done;
+        const int b = left >= B ? B : (int)left;
+        if (b < B && drop_last) break;
+        const PairsSrc src = {pairs + 3 * done, features, type_idx, n_types, seed, first_step + (uint64_t)i};
+        pl.dropout.offset = p->dropout.offset + (uint64_t)i;
+        PC_TRY(fused_step_impl(&pl, g, nullptr, nullptr, nullptr, lr, beta1, beta2, eps, &src, query_idx, query_types, pos_types,
+                               neg_types, pos_items, neg_items, b, T, K, num_products, margin, alpha, losses_out + 3 * i, topk,
+                               bad_count, ws, ws_bytes, stream));
+        PC_TRY(pc_exchange_adam(exchange, exchange_ctx, param_flat, grad_flat, exp_avg_flat, exp_avg_sq_flat, n_flat, step_count,
+                                t_first > 0 ? t_first + i : 0, adam_scalars, lr, beta1, beta2, eps, stream));
+        done += b;
+    }
+    return PC_OK;
+}

@@ -55,6 +55,68 @@ def all_reduce_mean_(flat, world):
     return flat
 
 
+def make_exchange(world, rank=None, group=None, kind="auto", device=None):
+    """The gradient exchange of a data-parallel replica as an ops.Exchange for the library's exchange slot
+    (pc_exchange_adam, pc_joint_train_epoch_dp): issued from the step's own foreign call on the step's stream.
+      'rccl'     the library's own RCCL communicator (ncclAllReduce with ncclAvg over xGMI): one rank draws the unique id,
+                 torch.distributed broadcasts its 128 bytes, every rank joins (ncclCommInitRank) on its current device;
+      'callback' torch.distributed.all_reduce behind a Python trampoline (what the gloo tests use; it blocks the host);
+      'auto'     'rccl' when the process group's backend is nccl and the RCCL entry points resolve, else 'callback'.
+    None when no collective runs (world == 1 outside the one-rank rehearsal).  After construction 'rccl' is verified with one
+    all-reduce of a known vector; a failure on ANY rank (agreed by a MIN all-reduce over the process group) falls back to
+    'callback' on all of them."""
+    if not collectives_on(world):
+        return None
+    from . import ops
+    rank = dist.get_rank(group) if rank is None else rank
+    backend = dist.get_backend(group)
+    dev = torch.device("cuda", torch.cuda.current_device()) if device is None else device
+
+    def callback():
+        def fn(ptr, n, stream):
+            # the slot hands over a raw device address; the replicas' flat gradient buffers are registered by address
+            t = fn.tensors.get(ptr)
+            if t is None or t.numel() != n:
+                raise RuntimeError("callback exchange: unknown gradient buffer %#x (register it with exchange.register(t))" % ptr)
+            dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+            t.mul_(1.0 / world)
+        fn.tensors = {}
+        ex = ops.CallbackExchange(fn, kind=f"torch.distributed.all_reduce ({backend}) behind a Python trampoline")
+        ex.register = lambda t: fn.tensors.__setitem__(t.data_ptr(), t)
+        return ex
+
+    want = kind
+    if kind == "auto":
+        want = "rccl" if backend == "nccl" and ops.rccl_available() else "callback"
+    if want == "callback":
+        return callback()
+    if want != "rccl":
+        raise ValueError("make_exchange: kind 'auto', 'rccl' or 'callback'")
+    ok, ex = 1, None
+    try:
+        id_t = torch.zeros(128, dtype=torch.uint8, device=dev if backend == "nccl" else "cpu")
+        if rank == 0:
+            id_t.copy_(torch.frombuffer(bytearray(ops.RcclExchange.unique_id()), dtype=torch.uint8))
+        dist.broadcast(id_t, src=0, group=group)
+        ex = ops.RcclExchange(bytes(id_t.cpu().numpy().tobytes()), rank, world)
+        probe = torch.full((1024,), float(rank + 1), dtype=torch.float32, device=dev)
+        ex.all_reduce_mean_(probe)
+        torch.cuda.synchronize()
+        ok = int(bool(torch.allclose(probe, torch.full_like(probe, (world + 1) / 2.0), rtol=1e-6, atol=0)))
+    except Exception as e:                                   # noqa: BLE001 -- any failure means: the host-driven exchange
+        import sys
+        print(f"[p_companion_amd] rank {rank}: native RCCL exchange unavailable ({e}); using torch.distributed", file=sys.stderr, flush=True)
+        ok = 0
+    flag = torch.tensor([ok], dtype=torch.int32, device=dev if backend == "nccl" else "cpu")
+    dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=group)
+    if int(flag.item()) == 1:
+        ex.register = lambda t: None
+        return ex
+    if kind == "rccl":
+        raise RuntimeError("make_exchange(kind='rccl'): the native exchange failed its check on some rank")
+    return callback()
+
+
 class ShardedFeatureTable:
     """[P,D] feature table row-sharded cyclically over the ranks of `group`: product r lives on rank r % G as local row
     r // G (SURVEY section 8e-1).

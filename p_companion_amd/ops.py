@@ -301,6 +301,102 @@ def adam_step_at(param, grad, exp_avg, exp_avg_sq, step_count, t, lr=1e-3, betas
                                      float(betas[0]), float(betas[1]), float(eps), _stream()), "pc_adam_step_at")
 
 
+# ----------------------------------------------------------------------------- data-parallel exchange slot (ABI 6)
+# A pc_exchange_fn travels through ctypes as a plain address (fn) with its context (ctx): the native one is the library's own
+# pc_rccl_allreduce_mean over its own RCCL communicator -- no Python between a step's gradient kernels and its Adam launch;
+# CallbackExchange wraps a Python callable for backends RCCL does not serve (gloo in the tests).
+EXCHANGE_FN = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p)
+
+
+class Exchange:
+    fn = None       # ctypes.c_void_p: address of a pc_exchange_fn
+    ctx = None      # ctypes.c_void_p
+
+    def all_reduce_mean_(self, t):
+        """The exchange applied to a device tensor, in place, on the current stream (what a step's call does through the slot)."""
+        _req(t, torch.float32, "grad")
+        rc = EXCHANGE_FN(self.fn.value)(self.ctx, _p(t), t.numel(), _stream())
+        check(rc, "pc_exchange_fn")
+        return t
+
+
+def rccl_available():
+    return bool(_lib.lib().pc_rccl_available())
+
+
+class RcclExchange(Exchange):
+    """ncclAllReduce(ncclAvg) on the library's own RCCL communicator (pc_rccl_*).  One rank draws the unique id
+    (RcclExchange.unique_id()), every rank constructs with the same 128 bytes -- a collective (ncclCommInitRank) on the
+    current device."""
+
+    @staticmethod
+    def unique_id():
+        buf = ctypes.create_string_buffer(128)
+        check(_lib.lib().pc_rccl_unique_id(buf), "pc_rccl_unique_id")
+        return buf.raw
+
+    def __init__(self, unique_id, rank, world):
+        if len(unique_id) != 128:
+            raise ValueError("RcclExchange: a 128-byte ncclUniqueId")
+        L = _lib.lib()
+        h = ctypes.c_void_p()
+        check(L.pc_rccl_comm_create(ctypes.c_char_p(bytes(unique_id)), int(rank), int(world), ctypes.byref(h)), "pc_rccl_comm_create")
+        self.ctx = h
+        self.fn = ctypes.cast(L.pc_rccl_allreduce_mean, ctypes.c_void_p)
+        self.rank, self.world = int(rank), int(world)
+        self.kind = "rccl (library-owned communicator, ncclAvg)"
+
+    def close(self):
+        if self.ctx is not None and self.ctx.value:
+            torch.cuda.synchronize()
+            check(_lib.lib().pc_rccl_comm_destroy(self.ctx), "pc_rccl_comm_destroy")
+            self.ctx = None
+
+
+class CallbackExchange(Exchange):
+    """A Python callable behind the slot: pyfn(ptr, n, stream) must leave the mean over the replicas in the n floats at
+    device address ptr, ordered on the stream (it may block).  An exception inside is reported as PC_ECOMM and re-raised by
+    the wrapper that made the call."""
+
+    def __init__(self, pyfn, kind="python callback"):
+        self.error = None
+
+        def tramp(_ctx, grad, n, stream):
+            try:
+                pyfn(int(grad or 0), int(n), int(stream or 0))
+                return 0
+            except BaseException as e:                # noqa: BLE001 -- nothing may unwind through the C frames
+                self.error = e
+                return -5
+
+        self._tramp = EXCHANGE_FN(tramp)              # (kept alive with the object: the C side holds a bare address)
+        self.fn = ctypes.cast(self._tramp, ctypes.c_void_p)
+        self.ctx = ctypes.c_void_p(0)
+        self.kind = kind
+
+    def reraise(self):
+        e, self.error = self.error, None
+        if e is not None:
+            raise e
+
+
+def exchange_adam(exchange, param, grad, exp_avg, exp_avg_sq, step_count, t, scalars, lr=1e-3, betas=(0.9, 0.999), eps=1e-8):
+    """pc_exchange_adam: the replicas' mean gradient (exchange may be None: single process), then Adam -- optimizer.step() of a
+    replica as one foreign call.  t >= 1: the host-known step number; t == 0: the device counter (scalars required)."""
+    n = param.numel()
+    for x, nm in ((param, "param"), (grad, "grad"), (exp_avg, "exp_avg"), (exp_avg_sq, "exp_avg_sq")):
+        _req(x, torch.float32, nm)
+        if x.numel() != n:
+            raise ValueError("exchange_adam: size mismatch")
+    _req(step_count, torch.int64, "step_count")
+    rc = _lib.lib().pc_exchange_adam(exchange.fn if exchange is not None else None, exchange.ctx if exchange is not None else None,
+                                     _p(param), _p(grad), _p(exp_avg), _p(exp_avg_sq), n, _p(step_count), int(t), _p(scalars),
+                                     float(lr), float(betas[0]), float(betas[1]), float(eps), _stream())
+    if rc and isinstance(exchange, CallbackExchange):
+        exchange.reraise()
+    check(rc, "pc_exchange_adam")
+
+
 class KernelProfile:
     """HIP-event brackets around the GEMM launches of the fused step (bench.py roofline leg)."""
     KINDS = {"gemm_nt_kernel": 0, "gemm_tn_kernel": 1, "gemm_nt_small_kernel": 2}
@@ -786,13 +882,15 @@ class PreparedJointStep:
         self._idx = (qi, qt, pt, nt)
         self._pairs_fn = _lib.lib().pc_joint_fused_step_pairs
         self._pairs_src = None
+        self._hyper = (1e-3, 0.9, 0.999, 1e-8)
 
     def set_hyper(self, lr, betas, eps):
         """The optimizer's hyper-parameters are plain doubles among the resolved arguments: refreshed from
         optimizer.param_groups by the caller before a step / an epoch, so that an LR scheduler or a load_state_dict()
         after preparation reaches the fused update exactly as it reaches the eager path."""
+        self._hyper = (float(lr), float(betas[0]), float(betas[1]), float(eps))       # (run_epoch_dp: Adam over the flat buffers)
         if self._args[2] is not None:
-            self._args[5], self._args[6], self._args[7], self._args[8] = float(lr), float(betas[0]), float(betas[1]), float(eps)
+            self._args[5], self._args[6], self._args[7], self._args[8] = self._hyper
 
     def __call__(self, dropout_offset=0):
         if self.dropout is not None:
@@ -848,6 +946,46 @@ def _prepared_run_epoch(self, pairs_dev, source, first_step, drop_last=False, dr
 
 
 PreparedJointStep.run_epoch = _prepared_run_epoch
+
+
+def _prepared_run_epoch_dp(self, pairs_dev, source, first_step, flat, gflat, exp_avg, exp_avg_sq, step_count, t_first, scalars,
+                           exchange, drop_last=True, dropout_offset=0):
+    """pc_joint_train_epoch_dp: the epoch of a data-parallel REPLICA as one foreign call -- per step the fused step without its
+    Adam, the exchange slot (ops.RcclExchange / CallbackExchange / None) and Adam over the flat buffers.  The object must have
+    been prepared WITHOUT adam (gradients only) over parameters / gradients that are views of flat / gflat."""
+    if self._args[2] is not None:
+        raise ValueError("run_epoch_dp: prepare the step without adam= (the epoch applies Adam over the flat buffers itself)")
+    features, type_idx, n_types, seed = source
+    _req(features, torch.float32, "features", (self._args[18], D)); _req(type_idx, torch.int32, "type_idx", (self._args[18],))
+    n = int(pairs_dev.shape[0])
+    _req(pairs_dev, torch.int32, "pairs", (n, 3))
+    nf = flat.numel()
+    for x, nm in ((flat, "param_flat"), (gflat, "grad_flat"), (exp_avg, "exp_avg"), (exp_avg_sq, "exp_avg_sq")):
+        _req(x, torch.float32, nm, (nf,))
+    _req(step_count, torch.int64, "step_count")
+    b = self._args[15]
+    steps = n // b if drop_last else (n + b - 1) // b
+    losses = torch.empty(max(steps, 1), 3, dtype=torch.float32, device=pairs_dev.device)
+    if self.dropout is not None:
+        self.st.dropout.offset = int(dropout_offset)
+    a = self._args
+    rc = _lib.lib().pc_joint_train_epoch_dp(a[0], a[1], _p(flat), _p(gflat), _p(exp_avg), _p(exp_avg_sq), nf, _p(step_count),
+                                            int(t_first), _p(scalars), float(self._hyper[0]), float(self._hyper[1]),
+                                            float(self._hyper[2]), float(self._hyper[3]),
+                                            exchange.fn if exchange is not None else None,
+                                            exchange.ctx if exchange is not None else None,
+                                            _p(pairs_dev), n, _p(features), _p(type_idx), int(n_types), int(seed), int(first_step),
+                                            *a[9:16], int(bool(drop_last)), *a[16:21], _p(losses), *a[22:], _stream())
+    if rc and isinstance(exchange, CallbackExchange):
+        exchange.reraise()
+    if rc:
+        check(rc, "pc_joint_train_epoch_dp")
+    self.calls += steps
+    self._keep_epoch = (pairs_dev, features, type_idx, flat, gflat, exp_avg, exp_avg_sq, step_count, scalars, exchange)
+    return losses[:steps], steps
+
+
+PreparedJointStep.run_epoch_dp = _prepared_run_epoch_dp
 
 
 class PreparedComplementaryBuilder:

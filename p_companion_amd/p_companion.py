@@ -339,11 +339,15 @@ class GraphedJointStep:
         queue filled, so for 3-12 kernels the direct form is the faster one;
       mode 'graph': the launch sequence recorded once as a HIP graph and replayed (the launch-per-op sequence of
         pc_joint_train_step + pc_adam_step is ~25 launches: there the replay wins).
-    Data-parallel replicas pass `grad_hook` (e.g. lambda g: distributed.all_reduce_mean_(g, world)): mode 'direct' then
-    runs the fused step WITHOUT its Adam (gradients only), calls grad_hook(flat gradient buffer) and optimizer.step();
-    'graph' and run_epoch are single-process forms (a collective would have to sit inside the captured sequence)."""
+    Data-parallel replicas pass `exchange` (an ops.Exchange: distributed.make_exchange(world) -- ncclAllReduce(ncclAvg) on the
+    library's own RCCL communicator): mode 'direct' then runs the fused step WITHOUT its Adam (gradients only) and
+    pc_exchange_adam (the exchange on the step's stream, then Adam) -- two foreign calls per step and no Python between the
+    kernels; run_epoch is pc_joint_train_epoch_dp, the whole epoch of the replica in one call.  `grad_hook` (a Python callable
+    on the flat gradient buffer, e.g. distributed.joint_grad_hook: the row-list exchange of the [T,64] tables at T > 512) is the
+    host-driven form: fused step, grad_hook, optimizer.step() per iteration; no run_epoch.  'graph' is a single-process form (a
+    collective would have to sit inside the captured sequence)."""
 
-    def __init__(self, model, optimizer, batch_size, warmup=3, mode="auto", grad_hook=None):
+    def __init__(self, model, optimizer, batch_size, warmup=3, mode="auto", grad_hook=None, exchange=None):
         from .product2vec import FusedAdam
         if not isinstance(optimizer, FusedAdam):
             raise TypeError("GraphedJointStep drives pc_adam_step / the fused step's Adam: pass a FusedAdam")
@@ -366,8 +370,11 @@ class GraphedJointStep:
             raise ValueError("mode 'direct' needs a configuration pc_joint_fused_step serves")
         self.mode = ("direct" if fused_ok else "graph") if mode == "auto" else mode
         self.grad_hook = grad_hook
-        if grad_hook is not None and self.mode != "direct":
-            raise ValueError("grad_hook needs mode 'direct' (a configuration pc_joint_fused_step serves)")
+        self.exchange = exchange
+        if grad_hook is not None and exchange is not None:
+            raise ValueError("grad_hook OR exchange")
+        if (grad_hook is not None or exchange is not None) and self.mode != "direct":
+            raise ValueError("grad_hook / exchange need mode 'direct' (a configuration pc_joint_fused_step serves)")
         self.graph = self.prepared = None
         self._eager_steps = 0
         self.losses = self.complementary_types = None
@@ -380,10 +387,11 @@ class GraphedJointStep:
                 dst.copy_(src.reshape(dst.shape), non_blocking=True)
 
     def _eager(self):
-        if self.grad_hook is not None:
+        if self.grad_hook is not None or self.exchange is not None:
             self.losses, self.complementary_types = self.model.train_step(self.static)
-            self.grad_hook(self.model.flatten_parameters()[1])
-            self.optimizer.step()
+            if self.grad_hook is not None:
+                self.grad_hook(self.model.flatten_parameters()[1])
+            self.optimizer.step(exchange=self.exchange)
             return
         self.losses, self.complementary_types = self.model.train_step(self.static, optimizer=self.optimizer)
 
@@ -403,7 +411,7 @@ class GraphedJointStep:
             drop = (p, tt._dropout_seed)
         self.prepared = ops.PreparedJointStep(params, grads, self.static, int(m.config.NUM_COMP_TYPES), float(m.config.MARGIN),
                                               float(m.config.ALPHA), bad=bad, dropout=drop,
-                                              adam=self.optimizer.fused_state() if self.grad_hook is None else None)
+                                              adam=self.optimizer.fused_state() if self.grad_hook is None and self.exchange is None else None)
         self._gflat = m.flatten_parameters()[1]
 
     def _refresh_hyper(self):
@@ -437,6 +445,8 @@ class GraphedJointStep:
             if self.grad_hook is not None:                 # data-parallel: gradients only above; average, then Adam
                 self.grad_hook(self._gflat)
                 self.optimizer.step()
+            elif self.exchange is not None:                # the same from one foreign call (pc_exchange_adam), no host hook
+                self.optimizer.step(exchange=self.exchange)
             return self.losses, self.complementary_types
         if self.graph is None:
             if self._eager_steps < self.warmup:
@@ -463,7 +473,8 @@ def _graphed_run_epoch(self, loader, drop_last=False, max_steps=None):
     step.  Returns the per-step losses [steps, 3] = (loss, type, item) on the device; `.mean(0)` is the epoch's average
     (train.py:50-57).  Same values, bit for bit, as iterating the loader and calling self(batch)."""
     if self.mode != "direct" or self.grad_hook is not None:
-        raise ValueError("run_epoch needs mode 'direct' without a grad_hook (single process; a configuration pc_joint_fused_step serves)")
+        raise ValueError("run_epoch needs mode 'direct' without a grad_hook (a configuration pc_joint_fused_step serves; "
+                         "replicas pass exchange=)")
     if not self.model.training:
         raise RuntimeError("GraphedJointStep: the model left training mode")
     if loader.batch_size != self.batch_size or loader.out is None or \
@@ -471,7 +482,8 @@ def _graphed_run_epoch(self, loader, drop_last=False, max_steps=None):
         raise ValueError("run_epoch: build the loader with batch_size=%d and out=step.static" % self.batch_size)
     if self.prepared is None:
         self.model.flatten_parameters()
-        self.optimizer.fused_state()
+        if self.exchange is None:
+            self.optimizer.fused_state()
         self._prepare()
     pairs = loader.epoch_pairs()
     if max_steps is not None:
@@ -480,7 +492,15 @@ def _graphed_run_epoch(self, loader, drop_last=False, max_steps=None):
         loader._source = (loader.features, loader.type_idx, int(loader.dataset.bpg.n_types), int(loader.seed))
     tt = self.model.type_transition
     self._refresh_hyper()
-    losses, steps = self.prepared.run_epoch(pairs, loader._source, loader.step, drop_last=drop_last, dropout_offset=tt._dropout_step)
+    if self.exchange is not None:
+        # a replica: fused step without Adam, the exchange slot, Adam over the flat buffers -- per step, all from one call
+        flat, gflat = self.model.flatten_parameters()
+        m, v, step_count, scalars, t_first = self.optimizer.epoch_state()
+        losses, steps = self.prepared.run_epoch_dp(pairs, loader._source, loader.step, flat, gflat, m, v, step_count, t_first,
+                                                   scalars, self.exchange, drop_last=drop_last, dropout_offset=tt._dropout_step)
+        self.optimizer.advance(steps)
+    else:
+        losses, steps = self.prepared.run_epoch(pairs, loader._source, loader.step, drop_last=drop_last, dropout_offset=tt._dropout_step)
     tt._dropout_step += steps
     loader.step += steps
     self.losses, self.complementary_types = (losses[-1] if steps else None), self.prepared.topk

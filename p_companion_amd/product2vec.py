@@ -168,7 +168,9 @@ class FusedAdam(torch.optim.Optimizer):
         return flat, gflat
 
     @torch.no_grad()
-    def step(self, closure=None):
+    def step(self, closure=None, exchange=None):
+        """exchange (ops.Exchange, optional): a data-parallel replica's gradient exchange, issued from the same foreign call as
+        the update (pc_exchange_adam) -- the flat gradient buffer holds the replicas' mean afterwards."""
         flat, gflat = self._ensure()
         g = self.param_groups[0]
         if self._host_step is not None and flat.is_cuda and torch.cuda.is_current_stream_capturing():
@@ -180,11 +182,31 @@ class FusedAdam(torch.optim.Optimizer):
             self._device_counter_only = True
         if self._host_step is not None:
             self._host_step += 1
+            if exchange is not None:
+                ops.exchange_adam(exchange, flat, gflat, self.exp_avg, self.exp_avg_sq, self.step_count, self._host_step,
+                                  self.scalars, g["lr"], g["betas"], g["eps"])
+                return
             ops.adam_step_at(flat, gflat, self.exp_avg, self.exp_avg_sq, self.step_count, self._host_step, g["lr"],
                              g["betas"], g["eps"])
             return
+        if exchange is not None:
+            ops.exchange_adam(exchange, flat, gflat, self.exp_avg, self.exp_avg_sq, self.step_count, 0, self.scalars, g["lr"],
+                              g["betas"], g["eps"])
+            return
         ops.adam_step(flat, gflat, self.exp_avg, self.exp_avg_sq, self.step_count, self.scalars, g["lr"],
                       g["betas"], g["eps"])
+
+    def epoch_state(self):
+        """What an epoch-in-one-call of a replica (ops.PreparedJointStep.run_epoch_dp) needs: the flat moment buffers, the device
+        step counter, the scratch scalars and t_first -- the Adam step number of the epoch's first step when the host knows it,
+        else 0 (the device counter decides).  Report the steps the call ran with advance()."""
+        self._ensure()
+        t_first = self._host_step + 1 if self._host_step is not None else 0
+        return self.exp_avg, self.exp_avg_sq, self.step_count, self.scalars, t_first
+
+    def advance(self, steps):
+        if self._host_step is not None:
+            self._host_step += int(steps)
 
     def zero_grad(self, set_to_none=False):
         _, gflat = self._ensure()

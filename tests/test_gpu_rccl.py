@@ -37,14 +37,23 @@ def _bench(*flags):
 
 
 @pytest.mark.timeout(900)
-def test_bench_multi_rank_branches_run_over_rccl():
-    """Product2Vec: flat-gradient all-reduce per step, barrier + MAX all-reduce of the timing; joint step: direct mode with the
-    gradient hook at T = 100 (one all-reduce) and T = 34800 (dense segment all-reduce + row-list all-gathers)."""
-    line = _bench("--steps", "10", "--warmup", "3", "--no-large")
+@pytest.mark.parametrize("exchange", ["native", "hook"])
+def test_bench_multi_rank_branches_run_over_rccl(exchange):
+    """Product2Vec: the flat-gradient exchange per step, barrier + MAX all-reduce of the timing; joint step at T = 100 and
+    T = 34800.  native: the library's exchange slot over its own RCCL communicator (pc_exchange_adam per Product2Vec step,
+    pc_joint_train_epoch_dp for the joint epochs); hook: torch.distributed from Python per step (T = 34800: dense segment
+    all-reduce + row-list all-gathers)."""
+    line = _bench("--steps", "10", "--warmup", "3", "--no-large", "--no-dropout-legs", "--exchange", exchange)
     assert line["rccl"]["backend"].startswith("nccl") and line["rccl"]["ranks_seen"] == [0] and line["rccl"]["world"] == 1
     assert line["n_gpus"] == 1 and line["value"] > 1e6 and line["config"]["parallelism"] == "dp1"
     j, jr = line["joint"], line["joint_num_types_34800"]
-    assert "all-reduce" in j["config"]["launch"] and j["value"] > 1e6
+    if exchange == "native":
+        assert line["rccl"]["exchange"].startswith("rccl"), line["rccl"]
+        assert "pc_joint_train_epoch_dp" in j["config"]["launch"] and j["config"]["exchange"].startswith("rccl")
+        assert "pc_joint_train_epoch_dp" in jr["config"]["launch"]
+    else:
+        assert "all-reduce" in j["config"]["launch"] and "hook" in line["rccl"]["exchange"]
+    assert j["value"] > 1e6
     assert jr["value"] > 1e6 and jr["config"]["final_loss"] == jr["config"]["final_loss"]        # (not NaN)
 
 
