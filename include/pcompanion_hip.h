@@ -15,7 +15,8 @@
  *   - return: 0 ok, <0 invalid argument (PC_E*), >0 a hipError_t; nothing throws;
  *   - re-entrant across host threads, streams and devices: two threads may step two models on two
  *     streams of one device concurrently (tests/test_gpu_round4.py runs exactly that, bit-equal to serial).
- *   Exceptions are the two host-side helpers (pc_mt_*), which take HOST pointers.
+ *   Exceptions: the host-side helpers (pc_mt_*, pc_rccl_unique_id) take HOST pointers; pc_rccl_comm_create / _destroy are
+ *   RCCL's communicator setup (they block until every rank has arrived and RCCL allocates its own buffers).
  *
  * Library-owned device state (the ONE exception to "no global state"; ABI 5 states what ABI 4 did silently):
  *   the unsplit fused Product2Vec step -- pc_p2v_train_step, pc_p2v_train_step_compact, and
