@@ -681,7 +681,11 @@ PcFork* pc_fork_get(hipStream_t main_st) {
     if (s->state == 0) {
         s->dev = dev; s->main_st = main_st;
         PcFork& f = s->f;
-        bool ok = hipStreamCreateWithFlags(&f.side, hipStreamNonBlocking) == hipSuccess;
+        // (the side queue runs at the calling stream's priority: its launches are part of the caller's step)
+        int prio = 0;
+        bool ok = (hipStreamGetPriority(main_st, &prio) == hipSuccess
+                       ? hipStreamCreateWithPriority(&f.side, hipStreamNonBlocking, prio)
+                       : hipStreamCreateWithFlags(&f.side, hipStreamNonBlocking)) == hipSuccess;
         for (int i = 0; ok && i < PC_FORK_EVENTS; i++)
             ok = hipEventCreateWithFlags(&f.fork[i], hipEventDisableTiming) == hipSuccess &&
                  hipEventCreateWithFlags(&f.join[i], hipEventDisableTiming) == hipSuccess;
