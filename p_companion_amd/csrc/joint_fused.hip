@@ -1778,9 +1778,13 @@ __global__ __launch_bounds__(1024) void touched_types_kernel(const int32_t* idx_
         __syncthreads();
         for (int i = threadIdx.x; i < words; i += 1024) bits[i] = 0u;
         __syncthreads();
-        for (int r = threadIdx.x; r < n; r += 1024) {
-            const int t = idx[r];
-            if ((unsigned)t < (unsigned)T) atomicOr(&bits[t >> 5], 1u << (t & 31));      // (integer: the result is the set)
+        for (int r0 = threadIdx.x; r0 < n; r0 += 8 * 1024) {     // (eight ids in flight per thread: the loop was a chain of L2 round trips)
+            int t[8];
+#pragma unroll
+            for (int u = 0; u < 8; u++) t[u] = r0 + 1024 * u < n ? idx[r0 + 1024 * u] : -1;
+#pragma unroll
+            for (int u = 0; u < 8; u++)
+                if ((unsigned)t[u] < (unsigned)T) atomicOr(&bits[t[u] >> 5], 1u << (t[u] & 31));      // (integer: the result is the set)
         }
         __syncthreads();
         const int per = (words + 1023) / 1024;
@@ -1819,9 +1823,20 @@ __global__ __launch_bounds__(256) void table_partials_kernel(TableList l0, Table
         const int lo = blockIdx.x * per, hi = min(l.rows, lo + per);
         if (nu > TG_CAP) {
             // more distinct rows than the LDS table holds: the row adds go to the (cleared) table by float atomics
-            for (int r = lo + w; r < hi; r += 4) {
-                const int d = l.idx[r];
-                if ((unsigned)d < (unsigned)T) unsafeAtomicAdd(l.table + (size_t)d * PC_L + lane, l.src[(size_t)r * PC_L + lane]);
+            // (eight rows' destinations and values requested together: one row per trip was a chain of dependent L2 round trips --
+            // twenty per wave at B = 4096, K = 3 -- and this kernel's whole 30 us)
+            for (int r0 = lo + w; r0 < hi; r0 += 32) {
+                int d[8];
+                float v[8];
+#pragma unroll
+                for (int u = 0; u < 8; u++) {
+                    const int r = r0 + 4 * u;
+                    d[u] = r < hi ? l.idx[r] : -1;
+                    v[u] = r < hi ? l.src[(size_t)r * PC_L + lane] : 0.f;
+                }
+#pragma unroll
+                for (int u = 0; u < 8; u++)
+                    if ((unsigned)d[u] < (unsigned)T) unsafeAtomicAdd(l.table + (size_t)d[u] * PC_L + lane, v[u]);
             }
             continue;
         }

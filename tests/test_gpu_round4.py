@@ -160,7 +160,10 @@ def test_bench_self_launches_its_ranks():
     assert out.returncode == 0, out.stderr[-3000:]
     line = json.loads(out.stdout.strip().splitlines()[-1])
     assert line["n_gpus"] == 2 and line["config"]["global_batch"] == 1024 and line["config"]["parallelism"] == "dp2"
-    assert line["rccl"] == {"backend": "gloo", "world": 2, "ranks_seen": [0, 1], "launcher": "self"}
+    rccl = dict(line["rccl"])
+    exchange = rccl.pop("exchange")                     # (ABI 6: the gradient exchange through the library's slot; gloo behind it here)
+    assert rccl == {"backend": "gloo", "world": 2, "ranks_seen": [0, 1], "launcher": "self"} and "gloo" in exchange
+    assert "pc_joint_train_epoch_dp" in line["joint"]["config"]["launch"]
     assert line["value"] > 0 and line["joint"]["value"] > 0 and line["joint"]["config"]["parallelism"] == "dp2"
     # more ranks than GPUs, not a rehearsal: refused with a message, before any rank starts
     env.pop("PC_FORCE_DEVICE")
