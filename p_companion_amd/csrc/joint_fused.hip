@@ -258,63 +258,6 @@ __device__ __forceinline__ bool row_topk_trunc(const float* row, int n, int K, i
     return exact;
 }
 
-// The same selection on FLOAT keys (full chunks of sample_sims_topk_kernel: 142 M elements per step at B = 4096, T = 34800, where
-// the selection, not the matrix pipe, sets the kernel's time): the key is the value's own bit pattern with its low 9 bits replaced by
-// 511 - index -- still a float, and truncation towards zero is monotone for both signs, so v_max_f32 / v_med3_f32 order the keys as
-// the unsigned image did and the three instructions of ord_f32 per element are gone (6 VALU per element instead of 10).  Same
-// exactness rule and the same fallback: two of the first K + 1 that agree in their upper 23 bits (near-ties, exact ties, rows of
-// zeros -- whose keys are denormals: the kernels run with fp32 denormals preserved) send the wave to row_topk_ins.  An infinite
-// similarity (a diverged model) would form a NaN key: the selection is then arbitrary but in range.  -INFINITY = no element.
-// max over a row of 16 lanes, every lane gets it: four v_max_f32 with the rotated operand read through DPP (the builtin form compiles
-// to v_mov_dpp + a canonicalising v_max + v_max each: three instructions where one does).  The wait states a DPP read of a VGPR the
-// previous VALU instruction wrote needs are spelled out: the hazard recogniser does not look inside inline asm.
-__device__ __forceinline__ float row16_fmax(float v) {
-    asm("s_nop 1\n\tv_max_f32_dpp %0, %0, %0 row_ror:1 row_mask:0xf bank_mask:0xf\n\t"
-        "s_nop 1\n\tv_max_f32_dpp %0, %0, %0 row_ror:2 row_mask:0xf bank_mask:0xf\n\t"
-        "s_nop 1\n\tv_max_f32_dpp %0, %0, %0 row_ror:4 row_mask:0xf bank_mask:0xf\n\t"
-        "s_nop 1\n\tv_max_f32_dpp %0, %0, %0 row_ror:8 row_mask:0xf bank_mask:0xf\n\ts_nop 1"
-        : "+v"(v));
-    return v;
-}
-template <int FULL>
-__device__ __forceinline__ bool row_topk_truncf(const float* row, int K, int l16, unsigned (&oh)[FK], unsigned (&ol)[FK]) {
-    static_assert(FULL >= 16 && FULL <= 512 && (FULL & (FULL - 1)) == 0, "full power-of-two chunks of at most 512 elements");
-    float a = -INFINITY, b = -INFINITY, c = -INFINITY, d = -INFINITY;
-    float x[FULL / 16];
-#pragma unroll
-    for (int i = 0; i < FULL / 16; i++) x[i] = row[l16 + 16 * i];
-    const unsigned lanec = 15u - (unsigned)l16;                 // 511 - (l16 + 16 i) = ((31 - i) << 4) | (15 - l16)
-#pragma unroll
-    for (int i = 0; i < FULL / 16; i++) {
-        const float k = __uint_as_float(((__float_as_uint(x[i]) & ~511u) | lanec) | ((31u - (unsigned)i) << 4));
-        // (the running maximum from inline asm: fmaxf would first canonicalise k -- one more instruction per element)
-        d = __builtin_amdgcn_fmed3f(c, d, k); c = __builtin_amdgcn_fmed3f(b, c, k); b = __builtin_amdgcn_fmed3f(a, b, k);
-        asm("v_max_f32 %0, %1, %2" : "=v"(a) : "v"(a), "v"(k));
-    }
-    unsigned top[4];
-#pragma unroll
-    for (int r = 0; r < 4; r++) {
-        top[r] = __float_as_uint(row16_fmax(a));               // row maximum on the rotate network: every lane gets it
-        const bool own = __float_as_uint(a) == top[r];         // (keys carry their index: one owner retires its head)
-        a = own ? b : a; b = own ? c : b; c = own ? d : c; d = own ? -INFINITY : d;
-    }
-    constexpr unsigned NONE = 0xff800000u;
-    bool exact = K <= 3;
-#pragma unroll
-    for (int r = 0; r < 3; r++)
-        if (r < K && top[r + 1] != NONE && (top[r] >> 9) == (top[r + 1] >> 9)) exact = false;
-#pragma unroll
-    for (int r = 0; r < FK; r++) {
-        oh[r] = 0u; ol[r] = 0u;
-        if (r < 3 && r < K && top[r] != NONE) {
-            const unsigned idx = (511u - (top[r] & 511u)) & (unsigned)(FULL - 1);   // (in range whatever the key: FULL is a power of two)
-            oh[r] = ord_f32(row[idx]);                          // the exact value back from LDS
-            ol[r] = ~idx;
-        }
-    }
-    return exact;
-}
-
 // per-workgroup gradient slab: itm_w | itm_b | typ_w | typ_b | dec_w | dec_b | enc_w | enc_b | E_c | E_q
 __host__ __device__ inline int wg_off_itm_w() { return 0; }
 __host__ __device__ inline int wg_off_itm_b() { return PC_D * PC_D; }
@@ -1171,11 +1114,11 @@ __global__ __launch_bounds__(256) void type_topk_merge_kernel(const float* part_
 // it can only move a selection between two types whose similarities agree to rounding.)
 //   sample_hidden_kernel     workgroups [0, nb_s): hd[b] for every sample (the step's own dropout mask: the tile kernel that
 //                            follows regenerates the same bits) -> hd [B,32];  workgroups [nb_s, ...): G and g0
-//   sample_sims_topk_kernel  per chunk of TC types (its G fragments resident in registers), walking tiles of SUT samples:
-//                            sims = hd G[chunk]^T + g0 on 16 x 16 x 4 fp32 MFMAs into LDS, the chunk's best K per sample in the
-//                            epilogue; three workgroups per CU, so one's top-K pass (VALU / DPP) runs beside the others'
-//                            products (matrix pipe); the next tile's hd rows are requested a tile ahead
-//   type_topk_merge_kernel   (rows = samples) best K of each sample's chunk candidates -> topk[b][K]
+//   sample_sims_max_kernel   per chunk of 256 types (its G fragments resident in registers), walking tiles of SUT samples:
+//                            sims = hd G[chunk]^T + g0 as fp32-grade products on the bf16 matrix cores, and of those only the MAXIMUM
+//                            of every 64-type sub-chunk per sample -> cmax [B][T / 64] (no LDS image of the similarities)
+//   sample_topk_refine_kernel  per sample: the K sub-chunks with the largest maxima hold the K best types; their 64 similarities
+//                            each are formed again (lane = type) and selected exactly -> topk[b][K]
 struct SampleHArgs {
     const float *enc_w, *enc_b, *dec_w, *dec_b, *eq, *ec;
     const int32_t *query_types, *pairs, *type_idx;
@@ -1253,18 +1196,15 @@ __global__ __launch_bounds__(256) void sample_hidden_kernel(SampleHArgs a) {
     }
 }
 
-#define SUT 32        /* samples per tile of sample_sims_topk_kernel */
-#ifndef PC_STC
-#define PC_STC 256    /* types per chunk of sample_sims_topk_kernel: 39 KB of LDS and < 128 VGPRs, FOUR workgroups per CU
-                         (320 with three: 0.315 against 0.301 ms per step at T = 34800, B = 4096, alternating runs on one box) */
-#endif
+#define SUT 32        /* samples per tile of sample_sims_max_kernel */
+#define PC_STC 256    /* types per chunk of sample_sims_max_kernel: four waves x one 64-type sub-chunk, < 128 VGPRs, FOUR workgroups per CU */
 #define STC PC_STC
-#define SWPS (STC <= 256 ? 4 : 3)   /* workgroups per CU: LDS = SUT (48 + STC + 4) floats */
+#define SWPS 4
 #define HPL (SUT * LH)              /* bf16 elements of one piece plane of a tile's hd rows */
 struct SampleSimsArgs {
     const float *hd, *G, *g0;
     int B, T, K, nchunks;
-    float* part_val; int32_t* part_idx;     // [B][nchunks][K]
+    float* part_val;                        // cmax [B][4 nchunks]: the sub-chunk maxima
     float* zero[2]; size_t nzero[2]; int zcols;      // rider: see TypeSimsArgs
 };
 
@@ -1295,12 +1235,18 @@ __device__ __forceinline__ void split3_4(const float4& x, uint2 (&q)[3]) {
     q[2] = make_uint2(__builtin_amdgcn_perm(u2[1], u2[0], 0x07060302u), __builtin_amdgcn_perm(u2[3], u2[2], 0x07060302u));
 }
 
-__global__ __launch_bounds__(256, SWPS) void sample_sims_topk_kernel(SampleSimsArgs a) {
-    extern __shared__ __attribute__((aligned(16))) float sm[];
-    __bf16* Hp = reinterpret_cast<__bf16*>(sm);              // [3 pieces][SUT][LH] bf16: lane (i, h) of an A fragment reads
-                                                             // the 16 B at row i, k = 8 h of a plane (1 KB per 16 rows, dense)
-    float* Sims = sm + 3 * HPL / 2;                          // [SUT][STC + 4]
-    constexpr int LDS_ = STC + 4;
+// Pass 1 of 2: the MAXIMUM of every 64-type sub-chunk per sample -- cmax[b][sub] -- and nothing else.  The K best types of a sample
+// lie in the K sub-chunks with the largest maxima (an element of the top K is >= the K-th best overall >= the K-th largest
+// sub-chunk maximum, and so is the maximum of its own sub-chunk), so the exact selection -- indices, ties, two-word keys -- only has
+// to look at K x 64 of the T similarities of a sample (pass 2, sample_topk_refine_kernel); the 142 M elements of a step each cost
+// HALF a VALU instruction here (v_max3_f32 over the lane's four column blocks, then one 16-lane row maximum per sample) where keeping
+// a sorted top-4 with indices per 16-lane row cost 15 per element all told (the first form of this kernel: 126 us at B = 4096,
+// T = 34800, of which 87 the selection).  A wave owns the four column blocks of ONE sub-chunk (types [64 sub, 64 sub + 64)): its
+// results never meet another wave's -- no LDS image of the similarities, no barrier between product and selection.  The accumulators
+// start at g0[t] (-inf for the tail chunk's types >= T: zero G fragments leave it there).
+__global__ __launch_bounds__(256, SWPS) void sample_sims_max_kernel(SampleSimsArgs a) {
+    __shared__ __attribute__((aligned(16))) __bf16 Hp[3 * HPL];   // [3 pieces][SUT][LH] bf16: lane (i, h) of an A fragment reads
+                                                                  // the 16 B at row i, k = 8 h of a plane (1 KB per 16 rows, dense)
     if ((int)blockIdx.x >= a.nchunks) {
         const size_t wg = ((size_t)blockIdx.x - a.nchunks) * gridDim.y + blockIdx.y, nwg = (size_t)a.zcols * gridDim.y;
         for (int i = 0; i < 2; i++) {
@@ -1313,22 +1259,22 @@ __global__ __launch_bounds__(256, SWPS) void sample_sims_topk_kernel(SampleSimsA
     }
     const int t0 = blockIdx.x * STC;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, ci = lane & 15, rh = lane >> 4;
-    constexpr int NBW = STC / 16 / 4;                       // G column blocks per wave, resident for the whole kernel
-    Split3 f_s[NBW];                                        // lane (j = ci, h = rh): G[t0 + 16 nb + j][8 h .. 8 h + 7] in three pieces
+    constexpr int NBW = STC / 16 / 4;                       // column blocks per wave: NBW x 16 = 64 types = one sub-chunk
+    static_assert(NBW == 4 && SUT == 32, "a wave owns one 64-type sub-chunk of a 32-sample tile: eight (sample) slots per lane");
+    const int sub = 4 * blockIdx.x + w, nsub = 4 * a.nchunks;
+    Split3 f_s[NBW];                                        // lane (j = ci, h = rh): G[64 sub + 16 q + j][8 h .. 8 h + 7] in three pieces
     float g0v[NBW];
 #pragma unroll
     for (int q = 0; q < NBW; q++) {
-        const int t = t0 + 16 * (w + 4 * q) + ci;
+        const int t = t0 + 64 * w + 16 * q + ci;
         float4 lo = make_float4(0.f, 0.f, 0.f, 0.f), hi = lo;
         if (t < a.T) {
             lo = *reinterpret_cast<const float4*>(a.G + (size_t)t * LH + 8 * rh);
             hi = *reinterpret_cast<const float4*>(a.G + (size_t)t * LH + 8 * rh + 4);
         }
         f_s[q] = split3(lo, hi);
-        g0v[q] = t < a.T ? a.g0[t] : 0.f;
+        g0v[q] = t < a.T ? a.g0[t] : -INFINITY;
     }
-    const int nvalid = min(STC, a.T - t0);
-    const int g4 = lane >> 4, l16 = lane & 15;
     // this thread's 16-B piece of a tile's hd rows (SUT x 32 floats = one float4 per thread), requested a tile ahead
     const int pr = tid >> 3, pc4 = (tid & 7) * 4;
     auto fetch = [&](int u0) {
@@ -1337,7 +1283,7 @@ __global__ __launch_bounds__(256, SWPS) void sample_sims_topk_kernel(SampleSimsA
     const int ustep = gridDim.y * SUT;
     float4 nxt = fetch(blockIdx.y * SUT);
     for (int u0 = blockIdx.y * SUT; u0 < a.B; u0 += ustep) {
-        __syncthreads();                                   // (the previous tile's top-K pass has left Sims / Hp)
+        __syncthreads();                                   // (the previous tile's fragments have been read)
         {
             uint2 pq[3];
             split3_4(nxt, pq);
@@ -1346,53 +1292,133 @@ __global__ __launch_bounds__(256, SWPS) void sample_sims_topk_kernel(SampleSimsA
         }
         if (u0 + ustep < a.B) nxt = fetch(u0 + ustep);
         __syncthreads();
-        {
-            bf16x8 ap[SUT / 16][3];                        // lane (i = ci, h = rh): hd[16 m + i][8 h .. 8 h + 7], piece p
+        bf16x8 ap[SUT / 16][3];                            // lane (i = ci, h = rh): hd[16 m + i][8 h .. 8 h + 7], piece p
 #pragma unroll
-            for (int m = 0; m < SUT / 16; m++)
+        for (int m = 0; m < SUT / 16; m++)
 #pragma unroll
-                for (int p3 = 0; p3 < 3; p3++)
-                    ap[m][p3] = *reinterpret_cast<const bf16x8*>(Hp + p3 * HPL + (16 * m + ci) * LH + 8 * rh);
-            f32x4v acc[NBW][SUT / 16];
+            for (int p3 = 0; p3 < 3; p3++)
+                ap[m][p3] = *reinterpret_cast<const bf16x8*>(Hp + p3 * HPL + (16 * m + ci) * LH + 8 * rh);
+        f32x4v acc[NBW][SUT / 16];
 #pragma unroll
-            for (int q = 0; q < NBW; q++)
+        for (int q = 0; q < NBW; q++)
 #pragma unroll
-                for (int m = 0; m < SUT / 16; m++) acc[q][m] = f32x4v{0.f, 0.f, 0.f, 0.f};
-            // term by term over the NBW x SUT / 16 independent accumulators (no back-to-back dependent MFMAs), smallest first
+            for (int m = 0; m < SUT / 16; m++) acc[q][m] = f32x4v{g0v[q], g0v[q], g0v[q], g0v[q]};
+        // term by term over the NBW x SUT / 16 independent accumulators (no back-to-back dependent MFMAs), smallest first
 #define PC_SS_TERM(PA, QB)                                                                              \
-            _Pragma("unroll") for (int q = 0; q < NBW; q++)                                             \
-                _Pragma("unroll") for (int m = 0; m < SUT / 16; m++) acc[q][m] = mfma16_bf16(ap[m][PA], f_s[q].QB, acc[q][m]);
-            PC_SS_TERM(2, p0) PC_SS_TERM(0, p2) PC_SS_TERM(1, p1) PC_SS_TERM(1, p0) PC_SS_TERM(0, p1) PC_SS_TERM(0, p0)
+        _Pragma("unroll") for (int q = 0; q < NBW; q++)                                                 \
+            _Pragma("unroll") for (int m = 0; m < SUT / 16; m++) acc[q][m] = mfma16_bf16(ap[m][PA], f_s[q].QB, acc[q][m]);
+        PC_SS_TERM(2, p0) PC_SS_TERM(0, p2) PC_SS_TERM(1, p1) PC_SS_TERM(1, p0) PC_SS_TERM(0, p1) PC_SS_TERM(0, p0)
 #undef PC_SS_TERM
+        // slot s = 4 m + r of a lane is sample 16 m + 4 rh + r: the maximum over the lane's four column blocks ...
+        // (one asm block per row block, opened by the wait states a VALU read of a matrix-core result needs -- 11 after an 8-pass
+        // MFMA: the hazard recogniser does not look inside inline asm, and without them the maxima were read before they were
+        // written: a selection that changed from run to run)
+        float v[8];
 #pragma unroll
-            for (int q = 0; q < NBW; q++) {
-                const int nb = w + 4 * q;
+        for (int m = 0; m < SUT / 16; m++)
+            asm("s_nop 15\n\t"
+                "v_max3_f32 %0, %4, %8, %12\n\tv_max3_f32 %1, %5, %9, %13\n\tv_max3_f32 %2, %6, %10, %14\n\tv_max3_f32 %3, %7, %11, %15\n\t"
+                "v_max_f32 %0, %0, %16\n\tv_max_f32 %1, %1, %17\n\tv_max_f32 %2, %2, %18\n\tv_max_f32 %3, %3, %19"
+                : "=&v"(v[4 * m]), "=&v"(v[4 * m + 1]), "=&v"(v[4 * m + 2]), "=&v"(v[4 * m + 3])
+                : "v"(acc[0][m][0]), "v"(acc[0][m][1]), "v"(acc[0][m][2]), "v"(acc[0][m][3]),
+                  "v"(acc[1][m][0]), "v"(acc[1][m][1]), "v"(acc[1][m][2]), "v"(acc[1][m][3]),
+                  "v"(acc[2][m][0]), "v"(acc[2][m][1]), "v"(acc[2][m][2]), "v"(acc[2][m][3]),
+                  "v"(acc[3][m][0]), "v"(acc[3][m][1]), "v"(acc[3][m][2]), "v"(acc[3][m][3]));
+        // ... and over the sixteen lanes of the row group (the sub-chunk's other 60 types): eight independent rotate-and-maximum
+        // chains interleaved, so a DPP read never follows the write of its register by fewer than the two wait states it needs
+#define PC_SS_ROR(CTRL)                                                                                                        \
+        asm("s_nop 1\n\t"                                                                                                      \
+            "v_max_f32_dpp %0, %0, %0 " CTRL " row_mask:0xf bank_mask:0xf\n\tv_max_f32_dpp %1, %1, %1 " CTRL " row_mask:0xf bank_mask:0xf\n\t" \
+            "v_max_f32_dpp %2, %2, %2 " CTRL " row_mask:0xf bank_mask:0xf\n\tv_max_f32_dpp %3, %3, %3 " CTRL " row_mask:0xf bank_mask:0xf\n\t" \
+            "v_max_f32_dpp %4, %4, %4 " CTRL " row_mask:0xf bank_mask:0xf\n\tv_max_f32_dpp %5, %5, %5 " CTRL " row_mask:0xf bank_mask:0xf\n\t" \
+            "v_max_f32_dpp %6, %6, %6 " CTRL " row_mask:0xf bank_mask:0xf\n\tv_max_f32_dpp %7, %7, %7 " CTRL " row_mask:0xf bank_mask:0xf\n\t" \
+            "s_nop 1"                                                                                                          \
+            : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(v[4]), "+v"(v[5]), "+v"(v[6]), "+v"(v[7]));
+        PC_SS_ROR("row_ror:1") PC_SS_ROR("row_ror:2") PC_SS_ROR("row_ror:4") PC_SS_ROR("row_ror:8")
+#undef PC_SS_ROR
+        // lane ci < 8 of a row group stores slot ci
+        float pick = v[0];
 #pragma unroll
-                for (int m = 0; m < SUT / 16; m++)
+        for (int sidx = 1; sidx < 8; sidx++) pick = ci == sidx ? v[sidx] : pick;
+        const int smp = u0 + 16 * (ci >> 2) + 4 * rh + (ci & 3);
+        if (ci < 8 && smp < a.B) a.part_val[(size_t)smp * nsub + sub] = pick;
+    }
+}
+
+// Pass 2 of 2: one wave per sample.  tau = the K-th largest of the sample's sub-chunk maxima; every sub-chunk whose maximum reaches
+// tau (exactly K of them unless maxima tie; a margin of 2^-15 relative lets in a sub-chunk whose maximum is a rounding-level tie
+// with tau -- the maxima come from the matrix cores' summation order, the values below from an fp32 fma chain) has its 64
+// similarities formed again, lane = type, and the exact selection -- two-word keys (value, ~index): descending, ties -> the lower
+// index, like torch.topk / pc_topk_rows -- runs over those.  100 MFLOP and 100 MB of L2 reads per step at B = 4096, K = 3.
+__global__ __launch_bounds__(256) void sample_topk_refine_kernel(const float* cmax, int nsub, const float* hd, const float* G,
+                                                                 const float* g0, int B, int T, int K, int32_t* topk) {
+    const int lane = threadIdx.x & 63;
+    const int b = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (b >= B) return;                                      // wave-uniform
+    const float* row = cmax + (size_t)b * nsub;
+    float m0 = -INFINITY, m1 = -INFINITY, m2 = -INFINITY, m3 = -INFINITY;      // the lane's four largest maxima, descending
+    for (int i = lane; i < nsub; i += 64) {
+        const float x = row[i];
+        m3 = __builtin_amdgcn_fmed3f(m2, m3, x); m2 = __builtin_amdgcn_fmed3f(m1, m2, x); m1 = __builtin_amdgcn_fmed3f(m0, m1, x);
+        m0 = fmaxf(m0, x);
+    }
+    float tau = -INFINITY;
+    for (int r = 0; r < K; r++) {
+        float m = m0;
 #pragma unroll
-                    for (int r = 0; r < 4; r++) Sims[(16 * m + 4 * rh + r) * LDS_ + 16 * nb + ci] = acc[q][m][r] + g0v[q];
+        for (int o = 32; o >= 1; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+        tau = m;
+        const bool own = m0 == m;                            // (equal maxima in two lanes retire together: tau can only come out lower)
+        m0 = own ? m1 : m0; m1 = own ? m2 : m1; m2 = own ? m3 : m2; m3 = own ? -INFINITY : m3;
+    }
+    const float thr = tau > -INFINITY ? tau - (3.0517578125e-5f * fabsf(tau) + 1e-30f) : -INFINITY;
+    float h[LH];
+#pragma unroll
+    for (int k4 = 0; k4 < LH / 4; k4++) {
+        const float4 t4 = *reinterpret_cast<const float4*>(hd + (size_t)b * LH + 4 * k4);
+        h[4 * k4] = t4.x; h[4 * k4 + 1] = t4.y; h[4 * k4 + 2] = t4.z; h[4 * k4 + 3] = t4.w;
+    }
+    unsigned kh[FK], kl[FK];
+#pragma unroll
+    for (int j = 0; j < FK; j++) { kh[j] = 0u; kl[j] = 0u; }
+    for (int i0 = 0; i0 < nsub; i0 += 64) {
+        const float x = i0 + lane < nsub ? row[i0 + lane] : -INFINITY;
+        unsigned long long mask = __ballot(i0 + lane < nsub && x >= thr);
+        while (mask) {                                       // wave-uniform: K trips in all (more on tied maxima)
+            const int j = __ffsll((long long)mask) - 1;
+            mask &= mask - 1;
+            const int t = 64 * (i0 + j) + lane;
+            if (t < T) {
+                const float4* g4 = reinterpret_cast<const float4*>(G + (size_t)t * LH);
+                float4 gv[LH / 4];
+#pragma unroll
+                for (int k4 = 0; k4 < LH / 4; k4++) gv[k4] = g4[k4];
+                float sacc = 0.f;
+#pragma unroll
+                for (int k4 = 0; k4 < LH / 4; k4++) {
+                    sacc = fmaf(gv[k4].x, h[4 * k4], sacc); sacc = fmaf(gv[k4].y, h[4 * k4 + 1], sacc);
+                    sacc = fmaf(gv[k4].z, h[4 * k4 + 2], sacc); sacc = fmaf(gv[k4].w, h[4 * k4 + 3], sacc);
+                }
+                unsigned hk = ord_f32(sacc + g0[t]), lk = ~(unsigned)t;
+#pragma unroll
+                for (int q = 0; q < FK; q++) {               // insertion into the sorted (descending) list
+                    const bool gt = hk > kh[q] || (hk == kh[q] && lk > kl[q]);
+                    const unsigned th = gt ? kh[q] : hk, tl = gt ? kl[q] : lk;
+                    kh[q] = gt ? hk : kh[q]; kl[q] = gt ? lk : kl[q];
+                    hk = th; lk = tl;
+                }
             }
         }
-        __syncthreads();
-        // a row group of 16 lanes per sample, four samples per wave side by side: SUT / 16 passes
-#pragma unroll 1
-        for (int pass = 0; pass < SUT / 16; pass++) {
-            // (the four row groups of a wave read rows FOUR apart: 4 x (STC + 4) floats = 16 banks mod 64, so the 64 lanes of a
-            // read hit 64 banks; consecutive rows sit 4 banks apart and collided four ways)
-            const int s = 16 * pass + 4 * g4 + w;
-            unsigned kh[FK], kl[FK];
-            bool exact;
-            if ((STC & (STC - 1)) == 0 && nvalid == STC) exact = row_topk_truncf<STC>(Sims + s * LDS_, a.K, l16, kh, kl);
-            else exact = row_topk_trunc<STC>(Sims + s * LDS_, nvalid, a.K, l16, kh, kl);      // (the tail chunk)
-            if (__ballot(!exact)) row_topk_ins(Sims + s * LDS_, nvalid, a.K, l16, kh, kl);   // (wave-uniform; near-ties only)
-            if (l16 == 0 && u0 + s < a.B)
-                for (int r = 0; r < a.K; r++) {
-                    const size_t o = ((size_t)(u0 + s) * a.nchunks + blockIdx.x) * a.K + r;
-                    const bool got = (kh[r] | kl[r]) != 0u;        // (a tail chunk may hold fewer than K types)
-                    a.part_val[o] = got ? unord_f32(kh[r]) : -INFINITY;
-                    a.part_idx[o] = got ? t0 + (int)~kl[r] : 0x7fffffff;
-                }
+    }
+    for (int r = 0; r < K; r++) {
+        unsigned bh = kh[0], bl = kl[0];
+        wave_maxkey(bh, bl);
+        if (kh[0] == bh && kl[0] == bl) {                    // pop the owner's head
+#pragma unroll
+            for (int j = 0; j < FK - 1; j++) { kh[j] = kh[j + 1]; kl[j] = kl[j + 1]; }
+            kh[FK - 1] = 0u; kl[FK - 1] = 0u;
         }
+        if (lane == 0) topk[(size_t)b * K + r] = (int)~bl;
     }
 }
 
@@ -1407,7 +1433,6 @@ __global__ __launch_bounds__(256, SWPS) void sample_sims_topk_kernel(SampleSimsA
 //   slab[o * Ni + i].  Operands come from LDS row-major images (row stride = width + 16 floats: the four sample rows one
 //   MFMA touches sit 16 banks apart).
 static_assert(TS == 16, "one gradient slab per 16-sample tile");
-static_assert(PC_STC <= 512 && PC_STC % 64 == 0, "row_topk_trunc packs the index of a chunk's element into 9 bits");
 #define WG_S 16            /* samples per workgroup (one 16-sample subtile: 256 workgroups at B = 4096; two subtiles per
                               workgroup halve the slab bytes but leave half the CUs idle: 34 vs 2x us, measured) */
 #define WLD128 144
@@ -1966,7 +1991,9 @@ static FusedWs fused_ws_layout(void* base, int B, int T, int K) {
         // (sized for either regime: rows = distinct query types without dropout, = the B samples with it)
         w.topk_by_type = (int32_t*)take((size_t)(T > B ? T : B) * K * 4);
         const int ncmax = w.nchunks > w.nchunks_s ? w.nchunks : w.nchunks_s;
-        w.part_val = (float*)take((size_t)B * ncmax * K * 4);
+        // (with dropout the same buffer holds cmax [B][4 nchunks_s]: the sub-chunk maxima of sample_sims_max_kernel)
+        const size_t pv = (size_t)ncmax * K > (size_t)4 * w.nchunks_s ? (size_t)ncmax * K : (size_t)4 * w.nchunks_s;
+        w.part_val = (float*)take((size_t)B * pv * 4);
         w.part_idx = (int32_t*)take((size_t)B * ncmax * K * 4);
         w.csamp = (float*)take((size_t)B * LH * 4);                // hd: the dropped hidden rows
         w.gmat = (float*)take((size_t)T * LH * 4);
@@ -2049,17 +2076,17 @@ static int fused_step_impl(const pc_joint_tensors* p, const pc_joint_tensors* g,
         PC_LAUNCH(sample_hidden_kernel, dim3(ca.nb_s + (T + UT - 1) / UT), dim3(256), 0, st, ca);
         SampleSimsArgs sa = {};
         sa.hd = w.csamp; sa.G = w.gmat; sa.g0 = w.g0; sa.B = B; sa.T = T; sa.K = K; sa.nchunks = w.nchunks_s;
-        sa.part_val = w.part_val; sa.part_idx = w.part_idx;
+        sa.part_val = w.part_val;
         sa.zero[0] = g->query_types; sa.nzero[0] = (size_t)T * PC_L; sa.zero[1] = g->comp_types; sa.nzero[1] = (size_t)T * PC_L;
         sa.zcols = 8;
-        const size_t lds = ((size_t)3 * HPL / 2 + (size_t)SUT * (STC + 4)) * 4;
         const int tiles_s = (B + SUT - 1) / SUT;
         // SWPS workgroups per CU: y so that chunks x y fills the chip's slots (each workgroup then walks its share of the sample tiles)
         int gy = (256 * SWPS - sa.zcols) / (sa.nchunks > 0 ? sa.nchunks : 1);
         gy = gy < 1 ? 1 : gy > tiles_s ? tiles_s : gy;
-        PC_LAUNCH(sample_sims_topk_kernel, dim3(sa.nchunks + sa.zcols, gy), dim3(256), lds, st, sa);
-        PC_LAUNCH(type_topk_merge_kernel, dim3((B + 3) / 4), dim3(256), 0, st, w.part_val, w.part_idx, nullptr, nullptr, B,
-                  sa.nchunks, K, w.topk_by_type);
+        // pass 1: the maximum of every 64-type sub-chunk per sample; pass 2: the exact top K over each sample's K best sub-chunks
+        PC_LAUNCH(sample_sims_max_kernel, dim3(sa.nchunks + sa.zcols, gy), dim3(256), 0, st, sa);
+        PC_LAUNCH(sample_topk_refine_kernel, dim3((B + 3) / 4), dim3(256), 0, st, w.part_val, 4 * sa.nchunks, w.csamp, w.gmat, w.g0, B, T,
+                  K, w.topk_by_type);
         PC_TRY(pc_launch_status());
     } else if (!w.small) {
         // the dense gradients of the two big tables hold zeros outside the touched rows (and receive float atomics beyond
