@@ -1372,12 +1372,11 @@ __global__ __launch_bounds__(256) void sample_topk_refine_kernel(const float* cm
         m0 = own ? m1 : m0; m1 = own ? m2 : m1; m2 = own ? m3 : m2; m3 = own ? -INFINITY : m3;
     }
     const float thr = tau > -INFINITY ? tau - (3.0517578125e-5f * fabsf(tau) + 1e-30f) : -INFINITY;
-    float h[LH];
-#pragma unroll
-    for (int k4 = 0; k4 < LH / 4; k4++) {
-        const float4 t4 = *reinterpret_cast<const float4*>(hd + (size_t)b * LH + 4 * k4);
-        h[4 * k4] = t4.x; h[4 * k4 + 1] = t4.y; h[4 * k4 + 2] = t4.z; h[4 * k4 + 3] = t4.w;
-    }
+    // A sub-chunk's 64 rows of G are 8 KB in a row: the wave reads them as eight dense 1 KB requests -- request j, lane l: the 16 B
+    // at float4 index 64 j + l, i.e. columns [4 (l & 7), 4 (l & 7) + 4) of row 8 j + (l >> 3) -- instead of every lane walking its
+    // own 128-B row (64 cache lines per request).  The eight lanes of a row add their four-column partials in a fixed tree.
+    const int kq = lane & 7;
+    const float4 h4 = *reinterpret_cast<const float4*>(hd + (size_t)b * LH + 4 * kq);
     unsigned kh[FK], kl[FK];
 #pragma unroll
     for (int j = 0; j < FK; j++) { kh[j] = 0u; kl[j] = 0u; }
@@ -1385,21 +1384,28 @@ __global__ __launch_bounds__(256) void sample_topk_refine_kernel(const float* cm
         const float x = i0 + lane < nsub ? row[i0 + lane] : -INFINITY;
         unsigned long long mask = __ballot(i0 + lane < nsub && x >= thr);
         while (mask) {                                       // wave-uniform: K trips in all (more on tied maxima)
-            const int j = __ffsll((long long)mask) - 1;
+            const int j0 = __ffsll((long long)mask) - 1;
             mask &= mask - 1;
-            const int t = 64 * (i0 + j) + lane;
-            if (t < T) {
-                const float4* g4 = reinterpret_cast<const float4*>(G + (size_t)t * LH);
-                float4 gv[LH / 4];
+            const int tb = 64 * (i0 + j0);                   // first type of the sub-chunk
+            float4 gv[8];
 #pragma unroll
-                for (int k4 = 0; k4 < LH / 4; k4++) gv[k4] = g4[k4];
-                float sacc = 0.f;
+            for (int j = 0; j < 8; j++) {
+                const int t = tb + 8 * j + (lane >> 3);
+                gv[j] = t < T ? *(reinterpret_cast<const float4*>(G + (size_t)tb * LH) + 64 * j + lane) : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+            const int tmine = tb + 8 * kq + (lane >> 3);     // the row this lane enters into its list: request kq's
+            const float g0m = tmine < T ? g0[tmine] : 0.f;
+            float mine = 0.f;
 #pragma unroll
-                for (int k4 = 0; k4 < LH / 4; k4++) {
-                    sacc = fmaf(gv[k4].x, h[4 * k4], sacc); sacc = fmaf(gv[k4].y, h[4 * k4 + 1], sacc);
-                    sacc = fmaf(gv[k4].z, h[4 * k4 + 2], sacc); sacc = fmaf(gv[k4].w, h[4 * k4 + 3], sacc);
-                }
-                unsigned hk = ord_f32(sacc + g0[t]), lk = ~(unsigned)t;
+            for (int j = 0; j < 8; j++) {
+                float part = fmaf(gv[j].w, h4.w, fmaf(gv[j].z, h4.z, fmaf(gv[j].y, h4.y, gv[j].x * h4.x)));
+                part += __shfl_xor(part, 1, 64);
+                part += __shfl_xor(part, 2, 64);
+                part += __shfl_xor(part, 4, 64);
+                mine = kq == j ? part : mine;
+            }
+            if (tmine < T) {
+                unsigned hk = ord_f32(mine + g0m), lk = ~(unsigned)tmine;
 #pragma unroll
                 for (int q = 0; q < FK; q++) {               // insertion into the sorted (descending) list
                     const bool gt = hk > kh[q] || (hk == kh[q] && lk > kl[q]);
