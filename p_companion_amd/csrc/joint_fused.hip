@@ -149,11 +149,6 @@ __device__ __forceinline__ void row_topk(const float* row, int T, int K, int l16
     }
 }
 
-// inverse of ord_f32
-__device__ __forceinline__ float unord_f32(unsigned k) {
-    return __uint_as_float((k & 0x80000000u) ? (k ^ 0x80000000u) : ~k);
-}
-
 // top-K of one LDS row of n values by the 16 lanes of a row group, ONE pass over the row: every lane keeps the best FK keys
 // (value, ~index) of its strided elements in a sorted register list, then K rounds of a row maximum whose owner retires
 // its head.  Same order as row_topk (descending, ties -> the lower index); (0, 0) = none (fewer than K values).
@@ -186,7 +181,7 @@ __device__ __forceinline__ void row_topk_ins(const float* row, int n, int K, int
     }
 }
 
-// The same selection at a fifth of the instructions (the first version of sample_sims_topk_kernel spent twice the matrix
+// The same selection at a fifth of the instructions (a first per-sample similarity kernel spent twice the matrix
 // pipe's time in row_topk_ins: ~52 VALU instructions per element): ONE 32-bit key per element -- the order-preserving image
 // of the value with its low 9 bits replaced by 511 - index -- so a lane keeps its best FOUR keys with v_max_u32 + three
 // v_med3_u32 per element and the row's best four fall out of four single-register row maxima.  Truncated keys order
@@ -209,30 +204,16 @@ __device__ __forceinline__ unsigned row16_umax(unsigned v) {
         : "+v"(v));
     return v;
 }
-template <int FULL>
 __device__ __forceinline__ bool row_topk_trunc(const float* row, int n, int K, int l16, unsigned (&oh)[FK], unsigned (&ol)[FK]) {
     unsigned a = 0u, b = 0u, c = 0u, d = 0u;
-    if (FULL > 0 && n == FULL) {
-        // a full chunk: the FULL / 16 LDS reads of the lane issued ahead of the compare chain (the rolled loop waits out one LDS
-        // latency per element)
-        float x[FULL > 0 ? FULL / 16 : 1];
+    for (int t = l16; t < n; t += 64) {                        // four reads in flight per round; a key of 0 changes nothing
+        float x[4];
 #pragma unroll
-        for (int i = 0; i < FULL / 16; i++) x[i] = row[l16 + 16 * i];
+        for (int j = 0; j < 4; j++) x[j] = t + 16 * j < n ? row[t + 16 * j] : 0.f;
 #pragma unroll
-        for (int i = 0; i < FULL / 16; i++) {
-            const unsigned k = (ord_f32(x[i]) & ~511u) | (511u - (unsigned)(l16 + 16 * i));
+        for (int j = 0; j < 4; j++) {
+            const unsigned k = t + 16 * j < n ? ((ord_f32(x[j]) & ~511u) | (511u - (unsigned)(t + 16 * j))) : 0u;
             d = umed3(c, d, k); c = umed3(b, c, k); b = umed3(a, b, k); a = a > k ? a : k;
-        }
-    } else {
-        for (int t = l16; t < n; t += 64) {                    // four reads in flight per round; a key of 0 changes nothing
-            float x[4];
-#pragma unroll
-            for (int j = 0; j < 4; j++) x[j] = t + 16 * j < n ? row[t + 16 * j] : 0.f;
-#pragma unroll
-            for (int j = 0; j < 4; j++) {
-                const unsigned k = t + 16 * j < n ? ((ord_f32(x[j]) & ~511u) | (511u - (unsigned)(t + 16 * j))) : 0u;
-                d = umed3(c, d, k); c = umed3(b, c, k); b = umed3(a, b, k); a = a > k ? a : k;
-            }
         }
     }
     unsigned top[4];
@@ -507,7 +488,7 @@ __global__ __launch_bounds__(256) void joint_tile_kernel(FusedArgs a, int ldsims
             int idx[FK];
             {
                 unsigned kh[FK], kl[FK];
-                const bool exact = row_topk_trunc<0>(Sims + sF * ldsims, a.T, K, l16, kh, kl);
+                const bool exact = row_topk_trunc(Sims + sF * ldsims, a.T, K, l16, kh, kl);
                 if (__ballot(!exact)) row_topk_ins(Sims + sF * ldsims, a.T, K, l16, kh, kl);
 #pragma unroll
                 for (int r = 0; r < FK; r++) idx[r] = (kh[r] | kl[r]) != 0u ? (int)~kl[r] : -1;
@@ -884,11 +865,9 @@ static size_t tile_lds_bytes(int T, bool sims_local, bool tables) {
 // Large tables: similarity row and top-K once per DISTINCT query type of the batch (dropout off: c is a function of
 // the type alone).
 //   present_types_kernel   bitmap of the batch's query types -> ascending list ulist[U] (one workgroup)
-//   type_sims_topk_kernel  per (chunk of TC types, tile of 64 listed query types): c for the tile (two small
-//                          products), sims = c E_c[chunk]^T, per query type the chunk's best K   [epilogue top-K:
-//                          the [U,T] similarity matrix is never written]
-//   type_topk_merge_kernel per listed query type: best K of its chunks' candidates -> topk_by_type[type][K]
-#define TC 320        /* types per chunk: 109 chunks x 2 tiles of listed query types = 218 workgroups at T = 34800: one round of the chip */
+// then the three kernels of the per-sample form below with rows = the U listed types instead of the B samples
+// (sample_hidden_kernel without a mask, sample_sims_max_kernel, sample_topk_refine_kernel -> topk_by_type[type][K]); U lives on
+// the device, so the grids are sized for min(B, T) rows and the workgroups past U leave at once.
 #define UT 64
 // inclusive prefix sum over the 1024 threads of a workgroup: shuffles inside each wave, the 16 wave totals through LDS -- two
 // barriers (the Hillis-Steele form over LDS this replaces took twenty: 3 us of a 10 us single-workgroup kernel)
@@ -951,161 +930,10 @@ __global__ __launch_bounds__(1024) void present_types_kernel(const int32_t* quer
     if (threadIdx.x == 1023) *n_u = incl;
 }
 
-struct TypeSimsArgs {
-    const float *enc_w, *enc_b, *dec_w, *dec_b, *eq, *ec;
-    const int32_t *ulist, *n_u;
-    int T, K, nchunks;
-    float* part_val; int32_t* part_idx;     // [U capacity][nchunks][K]
-    // rider: workgroups with blockIdx.x >= nchunks clear the two dense table gradients (17.8 MB at T = 34800) while the others
-    // multiply -- the fill was a launch of its own (hipMemsetAsync: ~10 us with its boundary) in front of the step
-    float* zero[2]; size_t nzero[2]; int zcols;
-};
-
-__global__ __launch_bounds__(256) void type_sims_topk_kernel(TypeSimsArgs a) {
-    extern __shared__ __attribute__((aligned(16))) float sm[];
-    float* Tin = sm;                        // [64][LD64]
-    float* Hs = Tin + UT * LD64;            // [64][LD32]
-    float* Cs = Hs + UT * LD32;             // [64][LD64]
-    float* Sims = Cs + UT * LD64;           // [64][TC + 4]
-    constexpr int LDS_ = TC + 4;
-    if ((int)blockIdx.x >= a.nchunks) {
-        const size_t wg = ((size_t)blockIdx.x - a.nchunks) * gridDim.y + blockIdx.y, nwg = (size_t)a.zcols * gridDim.y;
-        for (int i = 0; i < 2; i++) {
-            if (!a.zero[i]) continue;
-            const size_t n4 = a.nzero[i] / 4;                   // (T * 64 floats: a multiple of 4, 16-byte aligned)
-            for (size_t e = wg * 256 + threadIdx.x; e < n4; e += nwg * 256)
-                reinterpret_cast<float4*>(a.zero[i])[e] = make_float4(0.f, 0.f, 0.f, 0.f);
-        }
-        return;
-    }
-    const int nu = *a.n_u;
-    const int t0 = blockIdx.x * TC;
-    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, ci = lane & 15, rh = lane >> 4;
-    // every weight fragment this wave multiplies by, requested once: the two small layers and ALL of this chunk's E_c
-    // column blocks (they are the same for every tile of query types the workgroup walks)
-    const BFrag<4> f_e0 = load_b<PC_L, false>(a.enc_w, PC_L, 0, LH, lane), f_e1 = load_b<PC_L, false>(a.enc_w, PC_L, 16, LH, lane);
-    BFrag<2> f_d[4];
-#pragma unroll
-    for (int nb = 0; nb < 4; nb++) f_d[nb] = load_b<LH, false>(a.dec_w, LH, 16 * nb, PC_L, lane);
-    constexpr int NBW = TC / 16 / 4;                       // E_c column blocks per wave
-    BFrag<4> f_s[NBW];
-#pragma unroll
-    for (int q = 0; q < NBW; q++) f_s[q] = load_b<PC_L, false>(a.ec, PC_L, t0 + 16 * (w + 4 * q), a.T, lane);
-    const float bias_e0 = a.enc_b[ci], bias_e1 = a.enc_b[16 + ci];
-    float bias_d[4];
-#pragma unroll
-    for (int nb = 0; nb < 4; nb++) bias_d[nb] = a.dec_b[16 * nb + ci];
-    // the number of listed query types is known to the device only: a workgroup walks the tiles of 64 of them with stride
-    // gridDim.y (a grid sized for the worst case, one workgroup per possible tile, spends more time dispatching workgroups
-    // that find nothing to do -- each holds > 100 KB of LDS -- than the product takes)
-    for (int u0 = blockIdx.y * UT; u0 < nu; u0 += gridDim.y * UT) {
-    __syncthreads();
-    for (int e = tid; e < UT * 16; e += 256) {
-        const int r = e >> 4, c4 = (e & 15) * 4;
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (u0 + r < nu) v = *reinterpret_cast<const float4*>(a.eq + (size_t)a.ulist[u0 + r] * PC_L + c4);
-        *reinterpret_cast<float4*>(&Tin[r * LD64 + c4]) = v;
-    }
-    __syncthreads();
-    // wave w owns the 16 query types [16 w, 16 w + 16) of the tile for the two small layers
-    {
-        const float* At = Tin + 16 * w * LD64;
-        f32x4v a0[1] = {{0.f, 0.f, 0.f, 0.f}}, a1[1] = {{0.f, 0.f, 0.f, 0.f}};
-        mul_b<4, 1>(At, LD64, 1, f_e0, a0, lane);
-        mul_b<4, 1>(At, LD64, 1, f_e1, a1, lane);
-#pragma unroll
-        for (int r = 0; r < 4; r++) {
-            const float x0 = a0[0][r] + bias_e0, x1 = a1[0][r] + bias_e1;
-            Hs[(16 * w + 4 * rh + r) * LD32 + ci] = x0 > 0.f ? x0 : 0.f;
-            Hs[(16 * w + 4 * rh + r) * LD32 + 16 + ci] = x1 > 0.f ? x1 : 0.f;
-        }
-        __builtin_amdgcn_wave_barrier();
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-#pragma unroll
-        for (int nb = 0; nb < 4; nb++) {
-            f32x4v acc[1] = {{0.f, 0.f, 0.f, 0.f}};
-            mul_b<2, 1>(Hs + 16 * w * LD32, LD32, 1, f_d[nb], acc, lane);
-#pragma unroll
-            for (int r = 0; r < 4; r++) Cs[(16 * w + 4 * rh + r) * LD64 + 16 * nb + ci] = acc[0][r] + bias_d[nb];
-        }
-    }
-    __syncthreads();
-    // sims[64][TC]: TC / 16 column blocks, wave w takes blocks w, w + 4, ...; 4 row blocks share a B fragment set
-#pragma unroll
-    for (int q = 0; q < NBW; q++) {
-        const int nb = w + 4 * q;
-        f32x4v acc[4];
-#pragma unroll
-        for (int m = 0; m < 4; m++) acc[m] = f32x4v{0.f, 0.f, 0.f, 0.f};
-        mul_b<4, 4>(Cs, LD64, 4, f_s[q], acc, lane);
-#pragma unroll
-        for (int m = 0; m < 4; m++)
-#pragma unroll
-            for (int r = 0; r < 4; r++) Sims[(16 * m + 4 * rh + r) * LDS_ + 16 * nb + ci] = acc[m][r];
-    }
-    __syncthreads();
-    const int nvalid = min(TC, a.T - t0);
-    // the chunk's best K per listed query type: a row group of 16 lanes per type, four types per wave side by side
-    {
-        const int g4 = lane >> 4, l16 = lane & 15;
-        for (int pass = 0; pass < UT / 16; pass++) {
-            const int s = 16 * w + 4 * pass + g4;
-            int idx[FK];
-            row_topk<0>(Sims + s * LDS_, nvalid, a.K, l16, idx);
-            if (l16 == 0 && u0 + s < nu)
-                for (int r = 0; r < a.K; r++) {
-                    const size_t o = ((size_t)(u0 + s) * a.nchunks + blockIdx.x) * a.K + r;
-                    const bool got = idx[r] >= 0;                 // (a tail chunk may hold fewer than K types)
-                    a.part_val[o] = got ? Sims[s * LDS_ + idx[r]] : -INFINITY;
-                    a.part_idx[o] = got ? t0 + idx[r] : 0x7fffffff;
-                }
-        }
-    }
-    }
-}
-
-// per listed query type: the best K of its nchunks * K candidates (value, index), ties -> the lower index; a row group of
-// 16 lanes per type
-// (ulist == NULL: the rows are the batch's SAMPLES, n_rows of them, and row u's result goes to topk_by_type[u])
-__global__ __launch_bounds__(256) void type_topk_merge_kernel(const float* part_val, const int32_t* part_idx,
-                                                              const int32_t* ulist, const int32_t* n_u, int n_rows, int nchunks,
-                                                              int K, int32_t* topk_by_type) {
-    const int lane = threadIdx.x & 63;
-    const int u = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (u >= (ulist ? *n_u : n_rows)) return;                // wave-uniform
-    const int n = nchunks * K;
-    // one pass: every lane keeps the best K keys of its strided candidates (the loads are independent: one latency),
-    // then K rounds of a wave max; the winner is retired by its owner
-    unsigned kh[FK], kl[FK];
-#pragma unroll
-    for (int j = 0; j < FK; j++) { kh[j] = 0u; kl[j] = 0u; }
-    for (int t = lane; t < n; t += 64) {
-        const int xi = part_idx[(size_t)u * n + t];
-        unsigned h = xi == 0x7fffffff ? 0u : ord_f32(part_val[(size_t)u * n + t]), l = xi == 0x7fffffff ? 0u : ~(unsigned)xi;
-#pragma unroll
-        for (int j = 0; j < FK; j++) {                       // insertion into the sorted (descending) list
-            const bool gt = h > kh[j] || (h == kh[j] && l > kl[j]);
-            const unsigned th = gt ? kh[j] : h, tl = gt ? kl[j] : l;
-            kh[j] = gt ? h : kh[j]; kl[j] = gt ? l : kl[j];
-            h = th; l = tl;
-        }
-    }
-    const int type = ulist ? ulist[u] : u;
-    for (int r = 0; r < K; r++) {
-        unsigned bh = kh[0], bl = kl[0];
-        wave_maxkey(bh, bl);
-        if (kh[0] == bh && kl[0] == bl) {                    // pop the owner's head
-#pragma unroll
-            for (int j = 0; j < FK - 1; j++) { kh[j] = kh[j + 1]; kl[j] = kl[j + 1]; }
-            kh[FK - 1] = 0u; kl[FK - 1] = 0u;
-        }
-        if (lane == 0) topk_by_type[(size_t)type * K + r] = (int)~bl;
-    }
-}
-
 // ---------------------------------------------------------------------------------------------------------------
-// Large tables WITH hidden-layer dropout (the reference as shipped: config.py:12 DROPOUT = 0.1, config.py:27 NUM_TYPES = 34800;
-// type_transition.py:13-19): c = dec(mask_b (*) relu(enc t)) differs from sample to sample, so the similarity row and its
+// Large tables: the similarity row and its top-K per ROW -- a row is a distinct query type of the batch without dropout (above)
+// and a SAMPLE with hidden-layer dropout (the reference as shipped: config.py:12 DROPOUT = 0.1, config.py:27 NUM_TYPES = 34800;
+// type_transition.py:13-19): c = dec(mask_b (*) relu(enc t)) then differs from sample to sample, so the similarity row and its
 // top-K exist per SAMPLE -- the [B,64] x [64,T] product of p_companion.py:60-63 (18 GFLOP at B = 4096), never written.
 // The row is only used to SELECT the K types (the hinges read their two similarities from c and the E_c rows themselves), so
 // it is formed through the 32-wide hidden layer instead of the 64-wide c:  sims[b][t] = E_c[t] . (dec_w hd_b + dec_b)
@@ -1125,6 +953,7 @@ struct SampleHArgs {
     int B, T, P, nb_s;
     DropCfg drop;
     float *hd, *G, *g0;
+    const int32_t *ulist, *n_rows;          // rows = listed query types (dropout off): row b is type ulist[b], b < *n_rows; else NULL
 };
 
 __global__ __launch_bounds__(256) void sample_hidden_kernel(SampleHArgs a) {
@@ -1158,15 +987,18 @@ __global__ __launch_bounds__(256) void sample_hidden_kernel(SampleHArgs a) {
         return;
     }
     const int b0 = blockIdx.x * UT;
+    const int nrows = a.n_rows ? *a.n_rows : a.B;
+    if (b0 >= nrows) return;
     const BFrag<4> f_e0 = load_b<PC_L, false>(a.enc_w, PC_L, 0, LH, lane), f_e1 = load_b<PC_L, false>(a.enc_w, PC_L, 16, LH, lane);
     const float bias_e0 = a.enc_b[ci], bias_e1 = a.enc_b[16 + ci];
     for (int e = tid; e < UT * 16; e += 256) {
         const int r = e >> 4, c4 = (e & 15) * 4, b = b0 + r;
         float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (b < a.B) {
+        if (b < nrows) {
             // the query type as the tile kernel will validate it (an id outside its table is counted there and clamped to 0)
             int qt;
-            if (a.pairs) { const int qi = a.pairs[3 * b]; qt = a.type_idx[(unsigned)qi < (unsigned)a.P ? qi : 0]; }
+            if (a.ulist) qt = a.ulist[b];
+            else if (a.pairs) { const int qi = a.pairs[3 * b]; qt = a.type_idx[(unsigned)qi < (unsigned)a.P ? qi : 0]; }
             else qt = a.query_types[b];
             if ((unsigned)qt >= (unsigned)a.T) qt = 0;
             v = *reinterpret_cast<const float4*>(a.eq + (size_t)qt * PC_L + c4);
@@ -1192,7 +1024,7 @@ __global__ __launch_bounds__(256) void sample_hidden_kernel(SampleHArgs a) {
             pc_dropout_keep4(a.drop, (unsigned)(b * (LH / 4) + ((16 + ci) >> 2)), PC_DROP_STREAM_HIDDEN, m);
             x1 *= m[ci & 3];
         }
-        if (b < a.B) { a.hd[(size_t)b * LH + ci] = x0; a.hd[(size_t)b * LH + 16 + ci] = x1; }
+        if (b < nrows) { a.hd[(size_t)b * LH + ci] = x0; a.hd[(size_t)b * LH + 16 + ci] = x1; }
     }
 }
 
@@ -1204,7 +1036,8 @@ __global__ __launch_bounds__(256) void sample_hidden_kernel(SampleHArgs a) {
 struct SampleSimsArgs {
     const float *hd, *G, *g0;
     int B, T, K, nchunks;
-    float* part_val;                        // cmax [B][4 nchunks]: the sub-chunk maxima
+    float* part_val;                        // cmax [rows][4 nchunks]: the sub-chunk maxima
+    const int32_t* n_rows;                  // device row count (listed query types), or NULL: B rows
     float* zero[2]; size_t nzero[2]; int zcols;      // rider: see TypeSimsArgs
 };
 
@@ -1257,6 +1090,8 @@ __global__ __launch_bounds__(256, SWPS) void sample_sims_max_kernel(SampleSimsAr
         }
         return;
     }
+    const int nrows = a.n_rows ? *a.n_rows : a.B;
+    if ((int)blockIdx.y * SUT >= nrows) return;             // (rows = listed types: the grid is sized for their capacity)
     const int t0 = blockIdx.x * STC;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, ci = lane & 15, rh = lane >> 4;
     constexpr int NBW = STC / 16 / 4;                       // column blocks per wave: NBW x 16 = 64 types = one sub-chunk
@@ -1278,11 +1113,11 @@ __global__ __launch_bounds__(256, SWPS) void sample_sims_max_kernel(SampleSimsAr
     // this thread's 16-B piece of a tile's hd rows (SUT x 32 floats = one float4 per thread), requested a tile ahead
     const int pr = tid >> 3, pc4 = (tid & 7) * 4;
     auto fetch = [&](int u0) {
-        return u0 + pr < a.B ? *reinterpret_cast<const float4*>(a.hd + (size_t)(u0 + pr) * LH + pc4) : make_float4(0.f, 0.f, 0.f, 0.f);
+        return u0 + pr < nrows ? *reinterpret_cast<const float4*>(a.hd + (size_t)(u0 + pr) * LH + pc4) : make_float4(0.f, 0.f, 0.f, 0.f);
     };
     const int ustep = gridDim.y * SUT;
     float4 nxt = fetch(blockIdx.y * SUT);
-    for (int u0 = blockIdx.y * SUT; u0 < a.B; u0 += ustep) {
+    for (int u0 = blockIdx.y * SUT; u0 < nrows; u0 += ustep) {
         __syncthreads();                                   // (the previous tile's fragments have been read)
         {
             uint2 pq[3];
@@ -1290,7 +1125,7 @@ __global__ __launch_bounds__(256, SWPS) void sample_sims_max_kernel(SampleSimsAr
 #pragma unroll
             for (int p3 = 0; p3 < 3; p3++) *reinterpret_cast<uint2*>(Hp + p3 * HPL + pr * LH + pc4) = pq[p3];
         }
-        if (u0 + ustep < a.B) nxt = fetch(u0 + ustep);
+        if (u0 + ustep < nrows) nxt = fetch(u0 + ustep);
         __syncthreads();
         bf16x8 ap[SUT / 16][3];                            // lane (i = ci, h = rh): hd[16 m + i][8 h .. 8 h + 7], piece p
 #pragma unroll
@@ -1341,7 +1176,7 @@ __global__ __launch_bounds__(256, SWPS) void sample_sims_max_kernel(SampleSimsAr
 #pragma unroll
         for (int sidx = 1; sidx < 8; sidx++) pick = ci == sidx ? v[sidx] : pick;
         const int smp = u0 + 16 * (ci >> 2) + 4 * rh + (ci & 3);
-        if (ci < 8 && smp < a.B) a.part_val[(size_t)smp * nsub + sub] = pick;
+        if (ci < 8 && smp < nrows) a.part_val[(size_t)smp * nsub + sub] = pick;
     }
 }
 
@@ -1351,10 +1186,12 @@ __global__ __launch_bounds__(256, SWPS) void sample_sims_max_kernel(SampleSimsAr
 // similarities formed again, lane = type, and the exact selection -- two-word keys (value, ~index): descending, ties -> the lower
 // index, like torch.topk / pc_topk_rows -- runs over those.  100 MFLOP and 100 MB of L2 reads per step at B = 4096, K = 3.
 __global__ __launch_bounds__(256) void sample_topk_refine_kernel(const float* cmax, int nsub, const float* hd, const float* G,
-                                                                 const float* g0, int B, int T, int K, int32_t* topk) {
+                                                                 const float* g0, int B, int T, int K, int32_t* topk,
+                                                                 const int32_t* ulist, const int32_t* n_rows) {
     const int lane = threadIdx.x & 63;
     const int b = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (b >= B) return;                                      // wave-uniform
+    if (b >= (n_rows ? *n_rows : B)) return;                 // wave-uniform
+    const int orow = ulist ? ulist[b] : b;                   // rows = listed query types: the result is filed under the type
     const float* row = cmax + (size_t)b * nsub;
     float m0 = -INFINITY, m1 = -INFINITY, m2 = -INFINITY, m3 = -INFINITY;      // the lane's four largest maxima, descending
     for (int i = lane; i < nsub; i += 64) {
@@ -1424,7 +1261,7 @@ __global__ __launch_bounds__(256) void sample_topk_refine_kernel(const float* cm
             for (int j = 0; j < FK - 1; j++) { kh[j] = kh[j + 1]; kl[j] = kl[j + 1]; }
             kh[FK - 1] = 0u; kl[FK - 1] = 0u;
         }
-        if (lane == 0) topk[(size_t)b * K + r] = (int)~bl;
+        if (lane == 0) topk[(size_t)orow * K + r] = (int)~bl;
     }
 }
 
@@ -1940,13 +1777,13 @@ __global__ __launch_bounds__(256) void table_reduce_kernel(TableList l0, TableLi
 
 struct FusedWs {
     float *part, *h, *dpi, *dtp, *dc, *dh, *dt, *ecsrc;
-    int32_t *ecidx, *cids, *ulist, *n_u, *topk_by_type, *part_idx;
+    int32_t *ecidx, *cids, *ulist, *n_u, *topk_by_type;
     int32_t *tl_c, *tp_c, *tl_q, *tp_q, *n_touch;       // touched rows of the two big tables: ascending lists, row -> list position
     float *tslab_c, *tslab_q;                           // [TG_WGS][TG_CAP][64] each
     float* part_val;
     float *csamp, *gmat, *g0;                           // large tables with hidden-layer dropout: hd [B][32], G = E_c dec_w [T][32], g0 = E_c dec_b [T]
     float* wslabs; int wg_blocks, wslab_floats;      // joint_wgrad_kernel: one slab per workgroup
-    int nchunks, nchunks_s, ucap;      // chunks of the per-type / per-sample similarity kernels
+    int nchunks_s, ucap;               // chunks of the similarity kernels; capacity of the distinct-query-type list
     bool small;
     size_t total;
 };
@@ -1973,8 +1810,8 @@ static FusedWs fused_ws_layout(void* base, int B, int T, int K) {
     w.wg_blocks = (B + WG_S - 1) / WG_S;
     w.wslab_floats = wg_slab_floats(w.small ? T : 0);      // (large tables: their gradients go by row scatter-add)
     w.wslabs = (float*)take((size_t)w.wg_blocks * w.wslab_floats * 4);
-    w.nchunks = w.nchunks_s = w.ucap = 0;
-    w.ulist = w.n_u = w.topk_by_type = w.part_idx = nullptr;
+    w.nchunks_s = w.ucap = 0;
+    w.ulist = w.n_u = w.topk_by_type = nullptr;
     w.tl_c = w.tp_c = w.tl_q = w.tp_q = w.n_touch = nullptr;
     w.tslab_c = w.tslab_q = nullptr;
     w.part_val = nullptr;
@@ -1989,18 +1826,13 @@ static FusedWs fused_ws_layout(void* base, int B, int T, int K) {
         w.n_touch = (int32_t*)take(256);
         w.tslab_c = (float*)take((size_t)TG_WGS * TG_CAP * PC_L * 4);
         w.tslab_q = (float*)take((size_t)TG_WGS * TG_CAP * PC_L * 4);
-        w.nchunks = (T + TC - 1) / TC;
         w.nchunks_s = (T + PC_STC - 1) / PC_STC;
         w.ucap = B < T ? B : T;
         w.ulist = (int32_t*)take((size_t)w.ucap * 4);
         w.n_u = (int32_t*)take(256);
         // (sized for either regime: rows = distinct query types without dropout, = the B samples with it)
         w.topk_by_type = (int32_t*)take((size_t)(T > B ? T : B) * K * 4);
-        const int ncmax = w.nchunks > w.nchunks_s ? w.nchunks : w.nchunks_s;
-        // (with dropout the same buffer holds cmax [B][4 nchunks_s]: the sub-chunk maxima of sample_sims_max_kernel)
-        const size_t pv = (size_t)ncmax * K > (size_t)4 * w.nchunks_s ? (size_t)ncmax * K : (size_t)4 * w.nchunks_s;
-        w.part_val = (float*)take((size_t)B * pv * 4);
-        w.part_idx = (int32_t*)take((size_t)B * ncmax * K * 4);
+        w.part_val = (float*)take((size_t)B * 4 * w.nchunks_s * 4);   // cmax [rows <= B][4 nchunks_s]: the sub-chunk maxima of sample_sims_max_kernel
         w.csamp = (float*)take((size_t)B * LH * 4);                // hd: the dropped hidden rows
         w.gmat = (float*)take((size_t)T * LH * 4);
         w.g0 = (float*)take((size_t)T * 4);
@@ -2075,43 +1907,36 @@ static int fused_step_impl(const pc_joint_tensors* p, const pc_joint_tensors* g,
                                             const_cast<float*>(pos_items), const_cast<float*>(neg_items), nullptr, stream));
 
     const bool per_sample = !w.small && p->dropout.p > 0.f;      // hidden-layer dropout: c is a function of the SAMPLE
-    if (per_sample) {
+    if (!w.small) {
+        // rows of the similarity product: the B samples (dropout), else the U distinct query types of the batch -- U is a device
+        // scalar, the launches are sized for its capacity min(B, T) and the workgroups past U leave at once
+        const int rows_cap = per_sample ? B : w.ucap;
+        const int32_t* ulist = per_sample ? nullptr : w.ulist;
+        const int32_t* n_rows = per_sample ? nullptr : w.n_u;
+        if (!per_sample) {
+            const int words = (T + 31) / 32;
+            PC_LAUNCH(present_types_kernel, dim3(1), dim3(1024), (size_t)(words + 1024) * 4, st, query_types, B, T, w.ulist, w.n_u,
+                      pairs_in_tile ? src->pairs : nullptr, pairs_in_tile ? src->type_idx : nullptr, num_products);
+        }
         SampleHArgs ca = {p->enc_w, p->enc_b, p->dec_w, p->dec_b, p->query_types, p->comp_types, query_types,
                           pairs_in_tile ? src->pairs : nullptr, pairs_in_tile ? src->type_idx : nullptr, B, T, num_products,
-                          (B + UT - 1) / UT, make_dropcfg(p->dropout), w.csamp, w.gmat, w.g0};
+                          (rows_cap + UT - 1) / UT, make_dropcfg(p->dropout), w.csamp, w.gmat, w.g0, ulist, n_rows};
         PC_LAUNCH(sample_hidden_kernel, dim3(ca.nb_s + (T + UT - 1) / UT), dim3(256), 0, st, ca);
         SampleSimsArgs sa = {};
         sa.hd = w.csamp; sa.G = w.gmat; sa.g0 = w.g0; sa.B = B; sa.T = T; sa.K = K; sa.nchunks = w.nchunks_s;
-        sa.part_val = w.part_val;
+        sa.part_val = w.part_val; sa.n_rows = n_rows;
+        // the dense gradients of the two big tables hold zeros outside the touched rows (and receive float atomics beyond
+        // TG_CAP touched rows): cleared by rider workgroups of this launch
         sa.zero[0] = g->query_types; sa.nzero[0] = (size_t)T * PC_L; sa.zero[1] = g->comp_types; sa.nzero[1] = (size_t)T * PC_L;
         sa.zcols = 8;
-        const int tiles_s = (B + SUT - 1) / SUT;
-        // SWPS workgroups per CU: y so that chunks x y fills the chip's slots (each workgroup then walks its share of the sample tiles)
+        const int tiles_s = (rows_cap + SUT - 1) / SUT;
+        // SWPS workgroups per CU: y so that chunks x y fills the chip's slots (each workgroup then walks its share of the row tiles)
         int gy = (256 * SWPS - sa.zcols) / (sa.nchunks > 0 ? sa.nchunks : 1);
         gy = gy < 1 ? 1 : gy > tiles_s ? tiles_s : gy;
-        // pass 1: the maximum of every 64-type sub-chunk per sample; pass 2: the exact top K over each sample's K best sub-chunks
+        // pass 1: the maximum of every 64-type sub-chunk per row; pass 2: the exact top K over each row's K best sub-chunks
         PC_LAUNCH(sample_sims_max_kernel, dim3(sa.nchunks + sa.zcols, gy), dim3(256), 0, st, sa);
-        PC_LAUNCH(sample_topk_refine_kernel, dim3((B + 3) / 4), dim3(256), 0, st, w.part_val, 4 * sa.nchunks, w.csamp, w.gmat, w.g0, B, T,
-                  K, w.topk_by_type);
-        PC_TRY(pc_launch_status());
-    } else if (!w.small) {
-        // the dense gradients of the two big tables hold zeros outside the touched rows (and receive float atomics beyond
-        // TG_CAP touched rows): cleared by rider workgroups of the similarity launch below
-        const int words = (T + 31) / 32;
-        PC_LAUNCH(present_types_kernel, dim3(1), dim3(1024), (size_t)(words + 1024) * 4, st, query_types, B, T, w.ulist, w.n_u,
-                  pairs_in_tile ? src->pairs : nullptr, pairs_in_tile ? src->type_idx : nullptr, num_products);
-        TypeSimsArgs ta = {p->enc_w, p->enc_b, p->dec_w, p->dec_b, p->query_types, p->comp_types, w.ulist, w.n_u, T, K,
-                           w.nchunks, w.part_val, w.part_idx};
-        ta.zero[0] = g->query_types; ta.nzero[0] = (size_t)T * PC_L; ta.zero[1] = g->comp_types; ta.nzero[1] = (size_t)T * PC_L;
-        ta.zcols = 32;
-        const size_t lds = ((size_t)UT * LD64 * 2 + UT * LD32 + (size_t)UT * (TC + 4)) * 4;
-        static const hipError_t attr0 = hipFuncSetAttribute(reinterpret_cast<const void*>(&type_sims_topk_kernel),
-                                                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        (void)attr0;
-        const int ytiles = (w.ucap + UT - 1) / UT;
-        PC_LAUNCH(type_sims_topk_kernel, dim3(w.nchunks + ta.zcols, ytiles < 4 ? ytiles : 4), dim3(256), lds, st, ta);
-        PC_LAUNCH(type_topk_merge_kernel, dim3((w.ucap + 3) / 4), dim3(256), 0, st, w.part_val, w.part_idx, w.ulist, w.n_u, 0,
-                  w.nchunks, K, w.topk_by_type);
+        PC_LAUNCH(sample_topk_refine_kernel, dim3((rows_cap + 3) / 4), dim3(256), 0, st, w.part_val, 4 * sa.nchunks, w.csamp, w.gmat, w.g0,
+                  B, T, K, w.topk_by_type, ulist, n_rows);
         PC_TRY(pc_launch_status());
     }
 
