@@ -954,7 +954,9 @@ struct SampleHArgs {
     DropCfg drop;
     float *hd, *G, *g0;
     const int32_t *ulist, *n_rows;          // rows = listed query types (dropout off): row b is type ulist[b], b < *n_rows; else NULL
+    float* gnmax;                           // [T / 64 rounded up]: max |G[t]| per 64-type sub-chunk
 };
+static_assert(UT == 64, "a G workgroup of sample_hidden_kernel is one 64-type sub-chunk of sample_sims_max_kernel");
 
 __global__ __launch_bounds__(256) void sample_hidden_kernel(SampleHArgs a) {
     __shared__ __attribute__((aligned(16))) float Tin[UT * LD64];
@@ -984,6 +986,17 @@ __global__ __launch_bounds__(256) void sample_hidden_kernel(SampleHArgs a) {
             for (int d = 0; d < PC_L; d++) s += Tin[tid * LD64 + d] * a.dec_b[d];
             a.g0[t0 + tid] = s;
         }
+        // gnmax[sub] = the largest |G[t]|_2 of this workgroup's 64 types (= one sub-chunk of the similarity kernels): what bounds the
+        // error of the two-piece products of sample_sims_max_kernel for that sub-chunk (Cauchy-Schwarz, see sample_topk_refine_kernel)
+        float nmax = 0.f;
+#pragma unroll
+        for (int r = 0; r < 4; r++) nmax = fmaxf(nmax, group16_sum(a0[0][r] * a0[0][r] + a1[0][r] * a1[0][r]));
+        nmax = fmaxf(nmax, __shfl_xor(nmax, 16, 64));
+        nmax = fmaxf(nmax, __shfl_xor(nmax, 32, 64));
+        __syncthreads();                                   // (Tin is read no more: its first floats carry the four waves' maxima)
+        if (lane == 0) Tin[w] = nmax;
+        __syncthreads();
+        if (tid == 0) a.gnmax[t0 / UT] = sqrtf(fmaxf(fmaxf(Tin[0], Tin[1]), fmaxf(Tin[2], Tin[3])));
         return;
     }
     const int b0 = blockIdx.x * UT;
@@ -1041,31 +1054,30 @@ struct SampleSimsArgs {
     float* zero[2]; size_t nzero[2]; int zcols;      // rider: see TypeSimsArgs
 };
 
-// The product runs as fp32-grade sums on the BF16 matrix cores (common.h split3: three bf16 pieces per operand, the six
-// significant piece products smallest first in the fp32 accumulator -- the same form, and the same error against an fp64
-// product, as the large Product2Vec GEMMs): the contraction is LH = 32 wide, so ONE v_mfma_f32_16x16x32_bf16 covers a 16 x 16
-// block's whole K and six of them (6 x 16 clocks) replace the eight v_mfma_f32_16x16x4_f32 of the first version (8 x 32
-// clocks).  The hd rows of a tile are split ONCE, by the thread that fetched them (one float4 each), and staged as three
-// bf16 piece planes; the chunk's G fragments are split once per workgroup and stay in registers.
+// The product runs on the BF16 matrix cores: the contraction is LH = 32 wide, so ONE v_mfma_f32_16x16x32_bf16 covers a 16 x 16
+// block's whole K.  Pass 1 only has to find the sub-chunks that CAN hold a row's best types, so it multiplies TWO bf16 pieces per
+// operand (x = p0 + p1 + r, |r| < 2^-14 |x|: pieces by truncation, common.h split3's first two) in three products, p0 q1 + p1 q0 +
+// p0 q0, smallest first: |sum - exact| <= 3 * 2^-14 |G[t]| |hd_r| (Cauchy-Schwarz over the 32 terms; the fp32 accumulation of the 96
+// piece products adds < 2^-17 of the same), which pass 2 -- fp32 values -- turns into its candidate margin (PC_SS_EPS).  (The fp32-grade six-product form took
+// 48 MFMAs per wave and tile, 23 us of the kernel's 42 at B = 4096, T = 34800; the first version's eight v_mfma_f32_16x16x4_f32 per
+// block 8 x 32 clocks against 3 x 16.)  The hd rows of a tile are split ONCE, by the thread that fetched them (one float4 each), and
+// staged as two bf16 piece planes; the chunk's G fragments are split once per workgroup and stay in registers.
+#define PC_SS_EPS 2.5e-4f      /* > 3 * 2^-14 + 2^-17 + 2^-19 = 1.93e-4: bound of |pass-1 value - pass-2 value| / (|G[t]| |hd_r|), with a quarter to spare */
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ f32x4v mfma16_bf16(const bf16x8& a, const bf16x8& b, f32x4v c) {
     return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
 }
-// the three pieces of four values (split3's arithmetic): piece p as two dwords = four bf16 in element order
-__device__ __forceinline__ void split3_4(const float4& x, uint2 (&q)[3]) {
+// the first two pieces of four values (split3's arithmetic): piece p as two dwords = four bf16 in element order
+__device__ __forceinline__ void split2_4(const float4& x, uint2 (&q)[2]) {
     const float v[4] = {x.x, x.y, x.z, x.w};
-    unsigned u0[4], u1[4], u2[4];
+    unsigned u0[4], u1[4];
 #pragma unroll
     for (int i = 0; i < 4; i++) {
         u0[i] = __float_as_uint(v[i]);
-        const float r1 = v[i] - __uint_as_float(u0[i] & 0xffff0000u);
-        u1[i] = __float_as_uint(r1);
-        const float r2 = r1 - __uint_as_float(u1[i] & 0xffff0000u);
-        u2[i] = __float_as_uint(r2);
+        u1[i] = __float_as_uint(v[i] - __uint_as_float(u0[i] & 0xffff0000u));
     }
     q[0] = make_uint2(__builtin_amdgcn_perm(u0[1], u0[0], 0x07060302u), __builtin_amdgcn_perm(u0[3], u0[2], 0x07060302u));
     q[1] = make_uint2(__builtin_amdgcn_perm(u1[1], u1[0], 0x07060302u), __builtin_amdgcn_perm(u1[3], u1[2], 0x07060302u));
-    q[2] = make_uint2(__builtin_amdgcn_perm(u2[1], u2[0], 0x07060302u), __builtin_amdgcn_perm(u2[3], u2[2], 0x07060302u));
 }
 
 // Pass 1 of 2: the MAXIMUM of every 64-type sub-chunk per sample -- cmax[b][sub] -- and nothing else.  The K best types of a sample
@@ -1078,7 +1090,7 @@ __device__ __forceinline__ void split3_4(const float4& x, uint2 (&q)[3]) {
 // results never meet another wave's -- no LDS image of the similarities, no barrier between product and selection.  The accumulators
 // start at g0[t] (-inf for the tail chunk's types >= T: zero G fragments leave it there).
 __global__ __launch_bounds__(256, SWPS) void sample_sims_max_kernel(SampleSimsArgs a) {
-    __shared__ __attribute__((aligned(16))) __bf16 Hp[3 * HPL];   // [3 pieces][SUT][LH] bf16: lane (i, h) of an A fragment reads
+    __shared__ __attribute__((aligned(16))) __bf16 Hp[2 * HPL];   // [2 pieces][SUT][LH] bf16: lane (i, h) of an A fragment reads
                                                                   // the 16 B at row i, k = 8 h of a plane (1 KB per 16 rows, dense)
     if ((int)blockIdx.x >= a.nchunks) {
         const size_t wg = ((size_t)blockIdx.x - a.nchunks) * gridDim.y + blockIdx.y, nwg = (size_t)a.zcols * gridDim.y;
@@ -1097,7 +1109,7 @@ __global__ __launch_bounds__(256, SWPS) void sample_sims_max_kernel(SampleSimsAr
     constexpr int NBW = STC / 16 / 4;                       // column blocks per wave: NBW x 16 = 64 types = one sub-chunk
     static_assert(NBW == 4 && SUT == 32, "a wave owns one 64-type sub-chunk of a 32-sample tile: eight (sample) slots per lane");
     const int sub = 4 * blockIdx.x + w, nsub = 4 * a.nchunks;
-    Split3 f_s[NBW];                                        // lane (j = ci, h = rh): G[64 sub + 16 q + j][8 h .. 8 h + 7] in three pieces
+    Split3 f_s[NBW];                                        // lane (j = ci, h = rh): G[64 sub + 16 q + j][8 h .. 8 h + 7] in pieces (the first two are used)
     float g0v[NBW];
 #pragma unroll
     for (int q = 0; q < NBW; q++) {
@@ -1120,18 +1132,18 @@ __global__ __launch_bounds__(256, SWPS) void sample_sims_max_kernel(SampleSimsAr
     for (int u0 = blockIdx.y * SUT; u0 < nrows; u0 += ustep) {
         __syncthreads();                                   // (the previous tile's fragments have been read)
         {
-            uint2 pq[3];
-            split3_4(nxt, pq);
+            uint2 pq[2];
+            split2_4(nxt, pq);
 #pragma unroll
-            for (int p3 = 0; p3 < 3; p3++) *reinterpret_cast<uint2*>(Hp + p3 * HPL + pr * LH + pc4) = pq[p3];
+            for (int p3 = 0; p3 < 2; p3++) *reinterpret_cast<uint2*>(Hp + p3 * HPL + pr * LH + pc4) = pq[p3];
         }
         if (u0 + ustep < nrows) nxt = fetch(u0 + ustep);
         __syncthreads();
-        bf16x8 ap[SUT / 16][3];                            // lane (i = ci, h = rh): hd[16 m + i][8 h .. 8 h + 7], piece p
+        bf16x8 ap[SUT / 16][2];                            // lane (i = ci, h = rh): hd[16 m + i][8 h .. 8 h + 7], piece p
 #pragma unroll
         for (int m = 0; m < SUT / 16; m++)
 #pragma unroll
-            for (int p3 = 0; p3 < 3; p3++)
+            for (int p3 = 0; p3 < 2; p3++)
                 ap[m][p3] = *reinterpret_cast<const bf16x8*>(Hp + p3 * HPL + (16 * m + ci) * LH + 8 * rh);
         f32x4v acc[NBW][SUT / 16];
 #pragma unroll
@@ -1142,7 +1154,7 @@ __global__ __launch_bounds__(256, SWPS) void sample_sims_max_kernel(SampleSimsAr
 #define PC_SS_TERM(PA, QB)                                                                              \
         _Pragma("unroll") for (int q = 0; q < NBW; q++)                                                 \
             _Pragma("unroll") for (int m = 0; m < SUT / 16; m++) acc[q][m] = mfma16_bf16(ap[m][PA], f_s[q].QB, acc[q][m]);
-        PC_SS_TERM(2, p0) PC_SS_TERM(0, p2) PC_SS_TERM(1, p1) PC_SS_TERM(1, p0) PC_SS_TERM(0, p1) PC_SS_TERM(0, p0)
+        PC_SS_TERM(1, p0) PC_SS_TERM(0, p1) PC_SS_TERM(0, p0)
 #undef PC_SS_TERM
         // slot s = 4 m + r of a lane is sample 16 m + 4 rh + r: the maximum over the lane's four column blocks ...
         // (one asm block per row block, opened by the wait states a VALU read of a matrix-core result needs -- 11 after an 8-pass
@@ -1180,22 +1192,28 @@ __global__ __launch_bounds__(256, SWPS) void sample_sims_max_kernel(SampleSimsAr
     }
 }
 
-// Pass 2 of 2: one wave per sample.  tau = the K-th largest of the sample's sub-chunk maxima; every sub-chunk whose maximum reaches
-// tau (exactly K of them unless maxima tie; a margin of 2^-15 relative lets in a sub-chunk whose maximum is a rounding-level tie
-// with tau -- the maxima come from the matrix cores' summation order, the values below from an fp32 fma chain) has its 64
-// similarities formed again, lane = type, and the exact selection -- two-word keys (value, ~index): descending, ties -> the lower
-// index, like torch.topk / pc_topk_rows -- runs over those.  100 MFLOP and 100 MB of L2 reads per step at B = 4096, K = 3.
+// Pass 2 of 2: one wave per row.  Pass 1's maximum of sub-chunk S is within e_S = PC_SS_EPS |hd_r| gnmax[S] of the true one, so with
+// L_S = cmax_S - e_S and tau = the K-th largest L: K different sub-chunks hold an element >= tau, hence the K-th best similarity of the
+// row is >= tau, and a sub-chunk with cmax_S + e_S < tau cannot hold one of the K best.  Every other sub-chunk (exactly K of them
+// unless maxima come within the error bound of each other, or tie) has its 64 similarities formed again in fp32, and the exact
+// selection -- two-word keys (value, ~index): descending, ties -> the lower index, like torch.topk / pc_topk_rows -- runs over those.
+// 100 MFLOP and 100 MB of L2 reads per step at B = 4096, K = 3.
 __global__ __launch_bounds__(256) void sample_topk_refine_kernel(const float* cmax, int nsub, const float* hd, const float* G,
-                                                                 const float* g0, int B, int T, int K, int32_t* topk,
-                                                                 const int32_t* ulist, const int32_t* n_rows) {
+                                                                 const float* g0, const float* gnmax, int B, int T, int K,
+                                                                 int32_t* topk, const int32_t* ulist, const int32_t* n_rows) {
     const int lane = threadIdx.x & 63;
     const int b = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (b >= (n_rows ? *n_rows : B)) return;                 // wave-uniform
     const int orow = ulist ? ulist[b] : b;                   // rows = listed query types: the result is filed under the type
     const float* row = cmax + (size_t)b * nsub;
-    float m0 = -INFINITY, m1 = -INFINITY, m2 = -INFINITY, m3 = -INFINITY;      // the lane's four largest maxima, descending
+    const int kq = lane & 7;
+    const float4 h4 = *reinterpret_cast<const float4*>(hd + (size_t)b * LH + 4 * kq);
+    float hn = h4.x * h4.x + h4.y * h4.y + h4.z * h4.z + h4.w * h4.w;
+    hn += __shfl_xor(hn, 1, 64); hn += __shfl_xor(hn, 2, 64); hn += __shfl_xor(hn, 4, 64);
+    const float escale = PC_SS_EPS * sqrtf(hn);
+    float m0 = -INFINITY, m1 = -INFINITY, m2 = -INFINITY, m3 = -INFINITY;      // the lane's four largest lower bounds, descending
     for (int i = lane; i < nsub; i += 64) {
-        const float x = row[i];
+        const float x = 64 * i < T ? row[i] - escale * gnmax[i] : -INFINITY;
         m3 = __builtin_amdgcn_fmed3f(m2, m3, x); m2 = __builtin_amdgcn_fmed3f(m1, m2, x); m1 = __builtin_amdgcn_fmed3f(m0, m1, x);
         m0 = fmaxf(m0, x);
     }
@@ -1205,21 +1223,20 @@ __global__ __launch_bounds__(256) void sample_topk_refine_kernel(const float* cm
 #pragma unroll
         for (int o = 32; o >= 1; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
         tau = m;
-        const bool own = m0 == m;                            // (equal maxima in two lanes retire together: tau can only come out lower)
+        const bool own = m0 == m;                            // (equal bounds in two lanes retire together: tau can only come out lower)
         m0 = own ? m1 : m0; m1 = own ? m2 : m1; m2 = own ? m3 : m2; m3 = own ? -INFINITY : m3;
     }
-    const float thr = tau > -INFINITY ? tau - (3.0517578125e-5f * fabsf(tau) + 1e-30f) : -INFINITY;
     // A sub-chunk's 64 rows of G are 8 KB in a row: the wave reads them as eight dense 1 KB requests -- request j, lane l: the 16 B
     // at float4 index 64 j + l, i.e. columns [4 (l & 7), 4 (l & 7) + 4) of row 8 j + (l >> 3) -- instead of every lane walking its
     // own 128-B row (64 cache lines per request).  The eight lanes of a row add their four-column partials in a fixed tree.
-    const int kq = lane & 7;
-    const float4 h4 = *reinterpret_cast<const float4*>(hd + (size_t)b * LH + 4 * kq);
     unsigned kh[FK], kl[FK];
 #pragma unroll
     for (int j = 0; j < FK; j++) { kh[j] = 0u; kl[j] = 0u; }
     for (int i0 = 0; i0 < nsub; i0 += 64) {
-        const float x = i0 + lane < nsub ? row[i0 + lane] : -INFINITY;
-        unsigned long long mask = __ballot(i0 + lane < nsub && x >= thr);
+        const int i = i0 + lane;
+        const bool live = i < nsub && 64 * i < T;
+        const float x = live ? row[i] + escale * gnmax[i] : -INFINITY;      // the sub-chunk's upper bound
+        unsigned long long mask = __ballot(live && x >= tau);
         while (mask) {                                       // wave-uniform: K trips in all (more on tied maxima)
             const int j0 = __ffsll((long long)mask) - 1;
             mask &= mask - 1;
@@ -1552,71 +1569,8 @@ __global__ __launch_bounds__(256) void joint_finish_kernel(FinishArgs a) {
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-// Large tables: table[idx[r]][0..63] += src[r][0..63] for TWO row lists in one launch (the dE_c rows of the selected / hinge
-// types and the dE_q rows), destination-partitioned over the XCDs: workgroup b serves the destination rows with
-// idx % 8 == b % 8 only (workgroups are dealt to the 8 XCDs round-robin), so all float atomics on one table row come from
-// one XCD and resolve in that XCD's L2.  With a few live types in a large table (config.py:27 NUM_TYPES = 34800 over 20-100
-// live types) thousands of source rows land on the same hundred rows: issued from every XCD at once those atomics are
-// device-scope read-modify-writes on the same lines (33 us for 20 k rows, measured).  A workgroup's four waves walk the
-// source rows r = slot, slot + 32, ... (slot = b / 8) 64 candidates at a time and add the matching ones, one row per step
-// across the wave's lanes.  (Also measured: no atomics at all -- destination row t owned by workgroup t % 256, which adds its
-// source rows in fixed order into an LDS slice and stores it, clears included: bitwise reproducible, but a hot destination
-// is one workgroup's serial chain: 121 us against 33 + 12 here.)
-struct ScatterList { float* table; const int32_t* idx; const float* src; int rows; };
-
-#define SC_SLOTS 64        /* distinct destinations a workgroup aggregates in LDS before it touches the table */
-__global__ __launch_bounds__(256) void scatter_add_rows_xcd_kernel(ScatterList l0, ScatterList l1) {
-    // rows with the same destination are first added up in LDS (a workgroup sees ~80 source rows over a dozen destinations
-    // when few types are live), then each distinct destination costs ONE row of float atomics
-    __shared__ float tab[SC_SLOTS * PC_L];
-    __shared__ int keys[SC_SLOTS];
-    __shared__ int nkeys;
-    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, nslot = gridDim.x >> 3;
-    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-#pragma unroll 1
-    for (int li = 0; li < 2; li++) {
-        const ScatterList& l = li ? l1 : l0;
-        __syncthreads();
-        for (int e = threadIdx.x; e < SC_SLOTS * PC_L; e += 256) tab[e] = 0.f;
-        if (threadIdx.x < SC_SLOTS) keys[threadIdx.x] = -1;
-        if (threadIdx.x == 0) nkeys = 0;
-        __syncthreads();
-        // wave w of slot s takes the candidate rows (s + nslot * (w + 4 i)), i = 0, 1, ...
-        for (int base = slot + nslot * w; base < l.rows; base += nslot * 4 * 64) {
-            const int r = base + nslot * 4 * lane;
-            const int d = r < l.rows ? l.idx[r] : -1;
-            unsigned long long m = __ballot(d >= 0 && (d & 7) == xcd);
-            while (m) {
-                const int j = __ffsll((long long)m) - 1;
-                m &= m - 1;
-                const int rj = base + nslot * 4 * j;
-                const int dj = __shfl(d, j, 64);
-                const float v = l.src[(size_t)rj * PC_L + lane];
-                // the destination's slot: known already, or a new one (two waves may each open one for the same destination
-                // at the same moment: both are flushed), or -- table full -- straight to the table
-                unsigned long long hit = __ballot(keys[lane] == dj);
-                int sl = hit ? __ffsll((long long)hit) - 1 : -1;
-                if (sl < 0) {
-                    int got = 0;
-                    if (lane == 0) {
-                        got = atomicAdd(&nkeys, 1);
-                        if (got < SC_SLOTS) keys[got] = dj;
-                    }
-                    got = __shfl(got, 0, 64);
-                    sl = got < SC_SLOTS ? got : -1;
-                }
-                if (sl >= 0) unsafeAtomicAdd(&tab[sl * PC_L + lane], v);          // ds_add_f32
-                else unsafeAtomicAdd(l.table + (size_t)dj * PC_L + lane, v);
-            }
-        }
-        __syncthreads();
-        const int nk = nkeys < SC_SLOTS ? nkeys : SC_SLOTS;
-        for (int sl = w; sl < nk; sl += 4) unsafeAtomicAdd(l.table + (size_t)keys[sl] * PC_L + lane, tab[sl * PC_L + lane]);
-    }
-}
-
-// ---------------------------------------------------------------------------------------------------------------
-// Large tables, DETERMINISTIC gradients (round 3; the atomics above remain the path for more than TG_CAP distinct rows):
+// Large tables, DETERMINISTIC gradients (round 3; float atomics remain the path for more than TG_CAP distinct rows of a table:
+// table_partials_kernel's own branch):
 // the reference's NUM_TYPES = 34800 (config.py:27) is a big table of which a batch touches few rows (20 live types at the
 // reference's catalogue, 100 at the benchmark's).
 //   touched_types_kernel   one workgroup per list: bitmap of the destination rows of both lists -> ascending lists ulist_c / ulist_q
@@ -1781,7 +1735,7 @@ struct FusedWs {
     int32_t *tl_c, *tp_c, *tl_q, *tp_q, *n_touch;       // touched rows of the two big tables: ascending lists, row -> list position
     float *tslab_c, *tslab_q;                           // [TG_WGS][TG_CAP][64] each
     float* part_val;
-    float *csamp, *gmat, *g0;                           // large tables with hidden-layer dropout: hd [B][32], G = E_c dec_w [T][32], g0 = E_c dec_b [T]
+    float *csamp, *gmat, *g0, *gnmax;                           // large tables with hidden-layer dropout: hd [B][32], G = E_c dec_w [T][32], g0 = E_c dec_b [T]
     float* wslabs; int wg_blocks, wslab_floats;      // joint_wgrad_kernel: one slab per workgroup
     int nchunks_s, ucap;               // chunks of the similarity kernels; capacity of the distinct-query-type list
     bool small;
@@ -1815,7 +1769,7 @@ static FusedWs fused_ws_layout(void* base, int B, int T, int K) {
     w.tl_c = w.tp_c = w.tl_q = w.tp_q = w.n_touch = nullptr;
     w.tslab_c = w.tslab_q = nullptr;
     w.part_val = nullptr;
-    w.csamp = w.gmat = w.g0 = nullptr;
+    w.csamp = w.gmat = w.g0 = w.gnmax = nullptr;
     if (w.small) {
     } else {
         const int nc = B * (K + 2);
@@ -1836,6 +1790,7 @@ static FusedWs fused_ws_layout(void* base, int B, int T, int K) {
         w.csamp = (float*)take((size_t)B * LH * 4);                // hd: the dropped hidden rows
         w.gmat = (float*)take((size_t)T * LH * 4);
         w.g0 = (float*)take((size_t)T * 4);
+        w.gnmax = (float*)take((size_t)((T + UT - 1) / UT) * 4);
     }
     w.total = off;
     return w;
@@ -1920,7 +1875,7 @@ static int fused_step_impl(const pc_joint_tensors* p, const pc_joint_tensors* g,
         }
         SampleHArgs ca = {p->enc_w, p->enc_b, p->dec_w, p->dec_b, p->query_types, p->comp_types, query_types,
                           pairs_in_tile ? src->pairs : nullptr, pairs_in_tile ? src->type_idx : nullptr, B, T, num_products,
-                          (rows_cap + UT - 1) / UT, make_dropcfg(p->dropout), w.csamp, w.gmat, w.g0, ulist, n_rows};
+                          (rows_cap + UT - 1) / UT, make_dropcfg(p->dropout), w.csamp, w.gmat, w.g0, ulist, n_rows, w.gnmax};
         PC_LAUNCH(sample_hidden_kernel, dim3(ca.nb_s + (T + UT - 1) / UT), dim3(256), 0, st, ca);
         SampleSimsArgs sa = {};
         sa.hd = w.csamp; sa.G = w.gmat; sa.g0 = w.g0; sa.B = B; sa.T = T; sa.K = K; sa.nchunks = w.nchunks_s;
@@ -1936,7 +1891,7 @@ static int fused_step_impl(const pc_joint_tensors* p, const pc_joint_tensors* g,
         // pass 1: the maximum of every 64-type sub-chunk per row; pass 2: the exact top K over each row's K best sub-chunks
         PC_LAUNCH(sample_sims_max_kernel, dim3(sa.nchunks + sa.zcols, gy), dim3(256), 0, st, sa);
         PC_LAUNCH(sample_topk_refine_kernel, dim3((rows_cap + 3) / 4), dim3(256), 0, st, w.part_val, 4 * sa.nchunks, w.csamp, w.gmat, w.g0,
-                  B, T, K, w.topk_by_type, ulist, n_rows);
+                  w.gnmax, B, T, K, w.topk_by_type, ulist, n_rows);
         PC_TRY(pc_launch_status());
     }
 
