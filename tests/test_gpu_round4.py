@@ -290,7 +290,7 @@ def test_config4_100M_products_dim256_zipf_negatives():
 @pytest.mark.parametrize("B,k,p", [(256, 3, 0.1), (250, 3, 0.1), (77, 2, 0.5)])
 def test_fused_joint_step_at_reference_num_types_with_dropout_against_the_oracle(B, k, p):
     """config.py:12 DROPOUT = 0.1 + config.py:27 NUM_TYPES = 34800 (round 3 sent this to the launch-per-op path): with hidden-layer
-    dropout the similarity row is formed per SAMPLE (sample_c_kernel, sample_sims_topk_kernel, merge).  Loss, top-k (index-exact),
+    dropout the similarity row is formed per SAMPLE (sample_hidden_kernel, sample_sims_max_kernel, sample_topk_refine_kernel).  Loss, top-k (index-exact),
     all ten gradients, untouched table rows exactly zero and the in-kernel Adam against oracle.joint_oracle.train_step with the
     same mask as an explicit input (oracle.philox_oracle.dropout_mask restates the generator)."""
     from oracle import joint_oracle, philox_oracle
@@ -347,10 +347,11 @@ def test_fused_joint_step_at_reference_num_types_with_dropout_against_the_oracle
 
 @pytest.mark.parametrize("k", [1, 3, 4])
 def test_per_sample_topk_resolves_ties_like_the_dense_path(k):
-    """sample_sims_topk_kernel selects with truncated 32-bit keys and falls back to the exact two-word keys when two of a row's
-    leading candidates agree in their upper bits.  A complementary table made of 12 distinct rows repeated over T = 2000 types
-    makes EVERY similarity row a field of exact ties (each value ~167 times): the selected types must be the lowest indices of
-    the best groups, in order -- what pc_topk_rows (tie rule of torch.topk) returns on the oracle's similarity matrix."""
+    """The per-row selection keeps the maximum of every 64-type sub-chunk and re-forms the sub-chunks whose upper bound reaches the
+    K-th largest lower bound; the exact two-word keys decide among those.  A complementary table made of 12 distinct rows repeated
+    over T = 2000 types makes EVERY similarity row a field of exact ties (each value ~167 times, every sub-chunk maximum equal to
+    the row's best): all 32 sub-chunks are candidates and the selected types must be the lowest indices of the best groups, in
+    order -- what pc_topk_rows (tie rule of torch.topk) returns on the oracle's similarity matrix."""
     from oracle import joint_oracle, philox_oracle
     from p_companion_amd import ops
     from p_companion_amd.p_companion import PCompanion
