@@ -66,3 +66,33 @@ def test_product_never_imports_oracle():
                 src = open(os.path.join(dirpath, f)).read()
                 assert not re.search(r"^\s*(from|import)\s+oracle\b", src, flags=re.M), f
                 assert "oracle/" not in src, f
+
+
+def test_exchange_slot_plumbing_without_a_gpu():
+    """ABI 6 on the host side only (no kernel runs): the exchange slot's trampoline delivers (pointer, count, stream) and turns a
+    Python exception into PC_ECOMM + a re-raise; pc_exchange_adam validates before anything is launched; the RCCL entry points
+    resolve from the copy of librccl torch has loaded; no exchange is made for a single process."""
+    import pytest
+    from p_companion_amd import _lib, distributed as pdist, ops
+    L = _lib.lib()
+    seen = []
+    ex = ops.CallbackExchange(lambda ptr, n, stream: seen.append((ptr, n, stream)))
+    fn = ops.EXCHANGE_FN(ex.fn.value)
+    assert fn(ex.ctx, ctypes.c_void_p(0x1000), 7, ctypes.c_void_p(0x20)) == 0 and seen == [(0x1000, 7, 0x20)]
+
+    def boom(ptr, n, stream):
+        raise KeyError("no such buffer")
+
+    bad = ops.CallbackExchange(boom)
+    assert ops.EXCHANGE_FN(bad.fn.value)(bad.ctx, None, 1, None) == -5
+    with pytest.raises(KeyError):
+        bad.reraise()
+    bad.reraise()                                                     # (delivered once)
+    # argument checks come before any launch: NULL buffers, and the device-counter form without its scratch scalars
+    assert L.pc_exchange_adam(None, None, None, None, None, None, 8, None, 1, None, 1e-3, 0.9, 0.999, 1e-8, None) == -1
+    assert L.pc_rccl_allreduce_mean(None, None, 0, None) == -1 and L.pc_rccl_comm_destroy(None) == -1
+    assert L.pc_rccl_available() in (0, 1) and isinstance(L.pc_rccl_last_error(), bytes)
+    if L.pc_rccl_available():
+        buf = ctypes.create_string_buffer(128)
+        assert L.pc_rccl_unique_id(None) == -1
+    assert pdist.make_exchange(1) is None

@@ -375,3 +375,44 @@ def test_per_sample_topk_resolves_ties_like_the_dense_path(k):
     got = tf.cpu().numpy()
     assert np.array_equal(got, want), f"{(got != want).any(1).sum()} of {B} rows differ"
     assert (got < 12 * k + 12).all()                               # the winners are the first members of their groups
+
+
+@pytest.mark.parametrize("p", [0.0, 0.1])
+def test_selection_among_sub_chunks_within_the_error_bound_is_right_to_rounding(p):
+    """Pass 1 of the T > 512 selection knows a sub-chunk's maximum only to within its error bound (two bf16 pieces per operand); pass 2
+    must then look at EVERY sub-chunk that could hold one of the K best.  A complementary table of 12 base rows repeated over
+    T = 2000 types, each copy scaled by 1 + d with |d| <= 3e-5, puts all 32 sub-chunk maxima of a row within that bound of each
+    other while every similarity is a distinct number: the selected types must be the K best of the oracle's similarity row up to
+    the rounding of the two fp32 summation orders (their oracle values within 2e-6 relative of the oracle's own K best, in
+    descending order), for rows = samples (dropout) and rows = distinct query types (no dropout)."""
+    from oracle import joint_oracle, philox_oracle
+    from p_companion_amd.p_companion import PCompanion
+    from tests.test_gpu_round3 import joint_batch
+    T, P, B, k = 2000, 300, 200, 3
+    g = torch.Generator().manual_seed(13)
+    table = torch.randn(P, 128, generator=g)
+    torch.manual_seed(14)
+    m = PCompanion(cfg(NUM_TYPES=T, DROPOUT=p, NUM_COMP_TYPES=k), table).to("cuda").train()
+    with torch.no_grad():
+        base = torch.randn(12, 64, generator=g)
+        scale = 1.0 + (torch.rand(T, 1, generator=g) * 2 - 1) * 3e-5
+        m.complementary_type_embeddings.weight.copy_((base[torch.arange(T) % 12] * scale).cuda())
+    st0 = {kk: v.detach().cpu().clone() for kk, v in m.state_dict().items()}
+    b = joint_batch(B, P, 50, seed=2)
+    tt = m.type_transition
+    tt._dropout_seed, tt._dropout_step = 99, 0
+    hmask = torch.from_numpy(philox_oracle.dropout_mask(99, 0, philox_oracle.STREAM_HIDDEN, B * 32, p)).view(B, 32) if p > 0 else None
+    _, tf = m.train_step(b)
+    ref = joint_oracle.forward(st0, b["query_idx"].cpu(), b["query_types"].cpu(), k, hidden_mask=hmask)
+    sims = ref["type_similarities"].double()
+    got = tf.cpu().long()
+    assert got.shape == (B, k) and int(got.min()) >= 0 and int(got.max()) < T
+    assert all(len(set(r.tolist())) == k for r in got)                               # K different types per row
+    best = sims.topk(k, dim=1).values                                                # the oracle's own K best, descending
+    mine = sims.gather(1, got)
+    tol = 2e-6 * sims.abs().amax(1, keepdim=True)
+    assert bool((mine >= best - tol).all()), float((best - mine).max())
+    assert bool((mine[:, :-1] >= mine[:, 1:] - tol).all())                           # in descending order (to rounding)
+    # and the field really is inside pass 1's error bound: the 32 sub-chunk maxima of a row spread over less than 1e-4 of its scale
+    sub_max = sims[:, :1984].view(B, 31, 64).amax(2)
+    assert float(((sub_max.amax(1) - sub_max.amin(1)) / sims.abs().amax(1)).max()) < 1e-4
