@@ -221,6 +221,13 @@ __device__ __forceinline__ void pc_adam_update(float& p, float& m, float& v, flo
     v = v * beta2 + (omb2 * g) * g;
     p = p - step_size * (m / (sqrtf(v) / bc2s + eps));
 }
+// Four elements whose gradient and both moments are exactly zero: torch.optim.Adam's update leaves them as they are (m' = 0, v' = 0,
+// p' = p - step * (0 / (0 + eps)) = p), so a kernel may skip their stores -- the dense update of the [NUM_TYPES, 64] tables
+// (p_companion.py:36-43) is mostly such elements: rows no batch has touched yet.
+__device__ __forceinline__ bool pc_adam_dead(const float4& g, const float4& m, const float4& v) {
+    return g.x == 0.f && g.y == 0.f && g.z == 0.f && g.w == 0.f && m.x == 0.f && m.y == 0.f && m.z == 0.f && m.w == 0.f &&
+           v.x == 0.f && v.y == 0.f && v.z == 0.f && v.w == 0.f;
+}
 // The N(0,1) filler rows of the complementary batch (data_loader.py:148-151: torch.randn_like in the reference's worker
 // -- input DATA): chunk t = 32 b + c (16-B chunk c of row b) takes the first Philox4x32-10 block of the stream
 // (seed; sample t, step) through Box-Muller.  One definition for the batch builder and for the fused step that builds

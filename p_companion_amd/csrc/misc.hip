@@ -128,6 +128,7 @@ __global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, 
         const float4 gv = *reinterpret_cast<const float4*>(g + i4);
         float4 mv = *reinterpret_cast<float4*>(m + i4);
         float4 vv = *reinterpret_cast<float4*>(v + i4);
+        if (pc_adam_dead(gv, mv, vv)) return;              // (g = m = v = 0: the update changes nothing -- nothing is written)
 #define ADAM1(c) pc_adam_update(pv.c, mv.c, vv.c, gv.c, step_size, bc2s, omb1, beta2, omb2, eps);
         ADAM1(x) ADAM1(y) ADAM1(z) ADAM1(w)
 #undef ADAM1
@@ -167,6 +168,7 @@ __global__ void adam_at_kernel(float* __restrict__ p, const float* __restrict__ 
         const float4 gv = *reinterpret_cast<const float4*>(g + i4);
         float4 mv = *reinterpret_cast<float4*>(m + i4);
         float4 vv = *reinterpret_cast<float4*>(v + i4);
+        if (pc_adam_dead(gv, mv, vv)) return;              // (g = m = v = 0: the update changes nothing -- nothing is written)
 #define ADAM1(c) pc_adam_update(pv.c, mv.c, vv.c, gv.c, step_size, bc2s, omb1, beta2f, omb2, eps);
         ADAM1(x) ADAM1(y) ADAM1(z) ADAM1(w)
 #undef ADAM1
