@@ -355,6 +355,10 @@ class GraphedJointStep:
         dev = model.query_type_embeddings.weight.device
         if dev.type != "cuda":
             raise RuntimeError("GraphedJointStep needs the model on the GPU")
+        if getattr(model, "dim", ops.D) != ops.D:
+            # (the fixed batch buffers, the fused step and the epoch calls are PRODUCT_EMB_DIM = 128 forms; at 256 the loop body is
+            # PCompanion.train_step(batch, optimizer): the per-op kernels, oracle-checked)
+            raise ValueError(f"GraphedJointStep serves PRODUCT_EMB_DIM = {ops.D}; step a dim-{model.dim} model with PCompanion.train_step")
         b = int(batch_size)
         i32 = lambda *shape: ops.alloc(int(np.prod(shape)), torch.int32, dev, zero=True).view(*shape)
         f32 = lambda: ops.alloc(b * ops.D, torch.float32, dev, zero=True).view(b, ops.D)

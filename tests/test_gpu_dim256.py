@@ -154,6 +154,10 @@ def test_joint_step_dim256_matches_the_oracle():
     torch.manual_seed(1)
     m = PCompanion(cfg, table).to("cuda").train()
     assert not m.use_fused_joint
+    import pytest
+    from p_companion_amd.p_companion import GraphedJointStep
+    with pytest.raises(ValueError, match="PRODUCT_EMB_DIM"):          # the fixed-buffer / fused / epoch forms are 128-wide: said, not guessed
+        GraphedJointStep(m, FusedAdam(m), B)
     st0 = {k: v.detach().cpu().clone() for k, v in m.state_dict().items()}
     b = {"query_idx": torch.randint(0, P, (B,), generator=g, dtype=torch.int32).cuda(),
          "query_types": torch.randint(0, T, (B,), generator=g).cuda(),
