@@ -476,8 +476,10 @@ int pc_joint_train_step(const pc_joint_tensors *p, const pc_joint_tensors *g,
  * fixed-order fold: bitwise reproducible) while a table has <= 512 touched rows in the batch -- the reference's catalogue
  * has 20 live types, the benchmark's 100 -- and float atomics into the cleared dense g beyond that.  With hidden-layer
  * dropout (p > 0: config.py:12 ships 0.1) c differs from sample to sample: the similarity row and its top-K are then formed
- * per SAMPLE (the [B,64] x [64,T] product of p_companion.py:60-63 on fp32 matrix cores, chunk top-K in its epilogue; still
- * never written), everything else as above (ABI 5; version 4 refused this combination).
+ * per SAMPLE (the [B,64] x [64,T] product of p_companion.py:60-63 through the 32-wide hidden layer on the bf16 matrix cores;
+ * still never written), everything else as above (ABI 5; version 4 refused this combination).  Either way the selection is
+ * exact (descending, ties -> the lower index, like torch.topk): a first pass keeps the maximum of every 64-type sub-chunk of a
+ * row with a rigorous error bound, a second re-forms in fp32 the sub-chunks that can hold one of the K best and selects there.
  * Ids outside their tables (query_idx vs num_products, the three type arrays vs num_types) are clamped, counted into
  * *bad_count (may be NULL) and never dereferenced out of bounds -- the reference raises at the lookup
  * (p_companion.py:48-54), the caller raises when it reads the counter.
