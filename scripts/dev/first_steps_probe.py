@@ -1,0 +1,39 @@
+"""Developer probe: host and device time of EACH of the first 30 Product2Vec steps of a process (the driver's headline flags time
+steps 5..24), and the shader clock rocm-smi reports right behind them."""
+import os, sys, time, subprocess
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+from types import SimpleNamespace
+import torch
+from p_companion_amd.data import SimilarityIndexLoader, generate_scaled_bpg
+from p_companion_amd.product2vec import FusedAdam, Product2Vec
+
+dev = torch.device("cuda:0")
+cfg = SimpleNamespace(PRODUCT_EMB_DIM=128, TYPE_EMB_DIM=64, HIDDEN_SIZE=256, NUM_ATTENTION_HEADS=4, DROPOUT=0.0, MARGIN=1.0,
+                      BATCH_SIZE=4096, LEARNING_RATE=1e-3, DEVICE=dev)
+bpg = generate_scaled_bpg(100_000, 100, seed=0)
+torch.manual_seed(0)
+model = Product2Vec(cfg).to(dev).train()
+opt = FusedAdam(model, lr=1e-3)
+table = bpg.cuda(dev)["features"]
+loader = SimilarityIndexLoader(bpg, 4096, shuffle=True, sampler="philox", seed=1, drop_last=True, device=dev, reuse_buffers=True)
+n = 30
+evs = [torch.cuda.Event(enable_timing=True) for _ in range(n + 1)]
+it = iter(loader)
+torch.cuda.synchronize()
+evs[0].record()
+host_load, host_step = [], []
+for i in range(n):
+    t0 = time.perf_counter()
+    b = next(it)
+    t1 = time.perf_counter()
+    model.train_step_indexed(table, b)
+    opt.step()
+    evs[i + 1].record()
+    host_load.append(t1 - t0)
+    host_step.append(time.perf_counter() - t1)
+    if os.environ.get("PC_SYNC_EVERY") and i < int(os.environ["PC_SYNC_EVERY"]):
+        torch.cuda.synchronize()
+torch.cuda.synchronize()
+ms = [evs[i].elapsed_time(evs[i + 1]) for i in range(n)]
+for i in range(n):
+    print(f"step {i:2d}: device {ms[i]:8.4f} ms   loader next() {1e3 * host_load[i]:8.3f} ms   step enqueue {1e3 * host_step[i]:8.3f} ms", flush=True)

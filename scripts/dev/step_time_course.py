@@ -13,7 +13,7 @@ cfg = SimpleNamespace(PRODUCT_EMB_DIM=128, TYPE_EMB_DIM=64, HIDDEN_SIZE=256, NUM
 bpg = generate_scaled_bpg(100_000, 100, seed=0)
 torch.manual_seed(0)
 model = Product2Vec(cfg).to(dev).train()
-opt = FusedAdam(model, lr=1e-3)
+opt = FusedAdam(model, lr=float(os.environ.get("PC_LR", "1e-3")))      # PC_LR=0: the parameters stand still -- does the step still get faster?
 table = bpg.cuda(dev)["features"]
 pre = float(os.environ.get("PREHEAT_MS", "0"))
 if pre > 0:                                   # an unrelated busy kernel before the first step: is the ramp the clock's?
