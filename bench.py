@@ -77,11 +77,11 @@ def committed_pmc(kind, match):
     """HBM bytes per launch of the kernels whose name `match` accepts, from the newest committed rocprofv3 --pmc passes of
     the SAME workload (profiles/<round tag>[_<kind>]_pmc_traffic.json: FETCH_SIZE and WRITE_SIZE in separate passes,
     KiB -> bytes, FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950).  kind: "" = configs[1] (100 k products),
-    "joint" / "joint34800" = the joint step at T = 100 / 34800, "cfg3" = 10 M products through the sharded lookup, "big" =
+    "joint" / "joint34800" / "joint34800d" = the joint step at T = 100 / 34800 / 34800 with DROPOUT = 0.1, "cfg3" = 10 M products through the sharded lookup, "big" =
     configs[4] (100 M x 256, Zipf).  None if no profile of that kind is committed (PMC counters cannot be collected from
     inside the bench process) -- a leg never borrows another workload's traffic."""
     import re
-    pat = re.compile(r"^(r\d+[a-z0-9]*)_(?:(joint34800|joint|big|cfg3)_)?pmc_traffic\.json$")
+    pat = re.compile(r"^(r\d+[a-z0-9]*)_(?:(joint34800d|joint34800|joint|big|cfg3)_)?pmc_traffic\.json$")
     files = []
     for f in sorted(os.listdir(os.path.join(ROOT, "profiles"))) if os.path.isdir(os.path.join(ROOT, "profiles")) else []:
         m = pat.match(f)
@@ -295,9 +295,11 @@ def run_joint(args, rank, world, dev, types, steps, warmup, want_cpu, dropout=0.
     value = world * args.batch * steps / el
     dev_ms = ev[0].elapsed_time(ev[1]) / steps               # HIP events on the launch stream, around the timed steps
     alg = joint_algorithmic_bytes(args.batch, types)
-    # (the committed counter passes are DROPOUT = 0 runs of T = 100 and T = 34800: other legs carry no traffic figure)
-    pmc = (committed_pmc("joint" if types == 100 else f"joint{types}", lambda k: k == "_step_total")
-           if dropout == 0.0 and types in (100, 34800) else None)
+    # (the committed counter passes: DROPOUT = 0 runs of T = 100 and T = 34800, and T = 34800 with DROPOUT = 0.1 -- the reference as
+    # shipped; other legs carry no traffic figure)
+    pmc_kind = ("joint" if types == 100 else f"joint{types}") if dropout == 0.0 and types in (100, 34800) else \
+               "joint34800d" if abs(dropout - 0.1) < 1e-9 and types == 34800 else None
+    pmc = committed_pmc(pmc_kind, lambda k: k == "_step_total") if pmc_kind else None
     achieved = alg / (dev_ms * 1e-3) / 1e9
     out = {"metric": "triplets/sec (P-Companion joint step: fwd + type/item hinge + bwd + Adam)", "value": round(value, 1),
            "unit": "triplets/s", "steps": steps, "ms_per_step": round(1e3 * el / steps, 4),

@@ -84,7 +84,8 @@ if fe:
 
 # ---- PMC passes of the joint phase: per kernel, and summed over one step (`_step_total`); the same for the run at the
 # reference's NUM_TYPES = 34800 (profiles/<tag>_joint34800_pmc_traffic.json, read by bench.py for that configuration)
-for dirs, out_name in ((("pmc_joint_fetch", "pmc_joint_write"), "joint"), (("pmc_joint34800_fetch", "pmc_joint34800_write"), "joint34800")):
+for dirs, out_name in ((("pmc_joint_fetch", "pmc_joint_write"), "joint"), (("pmc_joint34800_fetch", "pmc_joint34800_write"), "joint34800"),
+                       (("pmc_joint34800d_fetch", "pmc_joint34800d_write"), "joint34800d")):     # d: DROPOUT = 0.1, the reference as shipped
     fe, wr_ = pmc(dirs[0], "FETCH_SIZE"), pmc(dirs[1], "WRITE_SIZE")
     if not fe:
         continue

@@ -47,7 +47,12 @@ rocprofv3 --kernel-trace --stats -d $OUT/prof_cfg3 -o ${TAG}_cfg3 -- python3 $R/
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_cfg3_fetch -- python3 $R/bench.py $C3 --steps 5 --warmup 2 > /dev/null 2> $OUT/pmc_cfg3_fetch.err
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_cfg3_write -- python3 $R/bench.py $C3 --steps 5 --warmup 2 > /dev/null 2> $OUT/pmc_cfg3_write.err
 fi
-# JD=1: the joint step at the reference's shipped hyper-parameters (NUM_TYPES = 34800, DROPOUT = 0.1): kernel trace
+# JD=1: the joint step at the reference's shipped hyper-parameters (NUM_TYPES = 34800, DROPOUT = 0.1): kernel trace + HBM traffic
 if [ -n "$JD" ]; then
+if [ -z "$NO_PMC" ]; then
+JDA="--phase joint --types 34800 --dropout 0.1 --steps 5 --warmup 2 --no-cpu-baseline --no-sustained --no-ref-types --no-dropout-legs"
+rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_joint34800d_fetch -- python3 $R/bench.py $JDA > /dev/null 2> $OUT/pmc_joint34800d_fetch.err
+rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_joint34800d_write -- python3 $R/bench.py $JDA > /dev/null 2> $OUT/pmc_joint34800d_write.err
+fi
 rocprofv3 --kernel-trace --stats -d $OUT/prof_joint34800d -o ${TAG}_joint34800d -- python3 $R/bench.py --phase joint --types 34800 --dropout 0.1 --steps 25 --warmup 5 --no-cpu-baseline --no-sustained --no-ref-types --no-dropout-legs > $OUT/bench_joint34800d_under_rocprof.json 2> $OUT/rocprof_joint34800d.err
 fi
