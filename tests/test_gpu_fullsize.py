@@ -7,7 +7,9 @@ semantics imply:
   * permuting the samples of a batch permutes nothing observable (BatchNorm, the mean loss and every gradient are
     symmetric in the samples);
   * the step is bitwise reproducible run to run (no float atomics anywhere on the path);
-  * top-k of the similarities == torch.topk on the same matrix (index-exact), type loss / item loss additivity.
+  * top-k of the similarities == torch.topk on the same matrix (index-exact), type loss / item loss additivity;
+  * the FUSED step's selection at B = 4096, T = 34800 (sub-chunk maxima + exact refinement: the [B,T] matrix never exists) against
+    the module path's dense matrix, with and without dropout.
 Needs an MI355X."""
 import numpy as np
 import pytest
@@ -117,3 +119,42 @@ def test_joint_similarities_topk_and_loss_additivity_at_T34800():
         tl = model._compute_type_loss(sims, batch["positive_types"].squeeze(-1), batch["negative_types"].squeeze(-1))
         il = model._compute_item_loss(out["projected_embeddings"], batch["positive_items"], batch["negative_items"])
         assert abs(float(total) - (0.8 * float(il) + 0.2 * float(tl))) < 1e-5
+
+
+@pytest.mark.parametrize("p", [0.0, 0.1])
+def test_fused_selection_at_full_size_against_the_dense_similarity_matrix(p):
+    """B = 4096 rows over NUM_TYPES = 34800 (config.py:27), with and without config.py:12's DROPOUT: the FUSED step never forms the
+    [B,T] similarity matrix -- it keeps the maximum of every 64-type sub-chunk and re-forms the sub-chunks that can hold a row's K
+    best -- while the module path (p_companion.py:57-65 op by op) writes all 142 M similarities and selects with pc_topk_rows.
+    Same parameters, same dropout mask (seed and offset set alike): the fused selection must be the dense one up to the rounding of
+    two fp32 summation orders -- its types' dense similarities within 2e-6 (relative to the row's scale) of the dense K best, in
+    descending order, K different types per row, and index-exact on all but a handful of rows."""
+    from types import SimpleNamespace
+    from p_companion_amd.p_companion import PCompanion
+    T, B, K = 34800, 4096, 3
+    cfg = SimpleNamespace(PRODUCT_EMB_DIM=128, TYPE_EMB_DIM=64, HIDDEN_SIZE=256, NUM_ATTENTION_HEADS=4, DROPOUT=p,
+                          MARGIN=1.0, ALPHA=0.8, NUM_COMP_TYPES=K, NUM_TYPES=T, DEVICE=torch.device("cuda"),
+                          LEARNING_RATE=1e-3)
+    g = torch.Generator().manual_seed(7)
+    torch.manual_seed(7)
+    model = PCompanion(cfg, torch.randn(5000, 128, generator=g)).cuda().train()
+    batch = {"query_idx": torch.randint(0, 5000, (B,), generator=g, dtype=torch.int32).cuda(),
+             "query_types": torch.randint(0, T, (B,), generator=g).cuda(),            # ~3 900 distinct query types
+             "positive_types": torch.randint(0, T, (B, 1), generator=g).cuda(),
+             "negative_types": torch.randint(0, T, (B, 1), generator=g).cuda(),
+             "positive_items": torch.randn(B, 128, generator=g).cuda(), "negative_items": torch.randn(B, 128, generator=g).cuda()}
+    tt = model.type_transition
+    tt._dropout_seed, tt._dropout_step = 4242, 0
+    with torch.no_grad():
+        sims = model(batch)["type_similarities"].double()                             # the dense matrix, module path
+    tt._dropout_step = 0
+    _, got = model.train_step(batch)                                                  # the fused step, same mask
+    got = got.long()
+    assert got.shape == (B, K) and int(got.min()) >= 0 and int(got.max()) < T
+    assert bool((got[:, 0] != got[:, 1]).all() and (got[:, 1] != got[:, 2]).all() and (got[:, 0] != got[:, 2]).all())
+    best_v, best_i = sims.topk(K, dim=1)
+    mine = sims.gather(1, got)
+    tol = 2e-6 * sims.abs().amax(1, keepdim=True)
+    assert bool((mine >= best_v - tol).all()), float((best_v - mine).max())
+    assert bool((mine[:, :-1] >= mine[:, 1:] - tol).all())
+    assert int((got != best_i).any(1).sum()) <= 4                                     # (rounding-level ties only)
