@@ -1278,7 +1278,9 @@ __global__ __launch_bounds__(256) void sample_topk_refine_kernel(const float* cm
             for (int j = 0; j < FK - 1; j++) { kh[j] = kh[j + 1]; kl[j] = kl[j + 1]; }
             kh[FK - 1] = 0u; kl[FK - 1] = 0u;
         }
-        if (lane == 0) topk[(size_t)orow * K + r] = (int)~bl;
+        // (no candidate at all -- a row of NaN similarities, a diverged model -- must still leave an index inside the table: the
+        // tile kernel gathers E_c rows by it)
+        if (lane == 0) topk[(size_t)orow * K + r] = (bh | bl) ? (int)~bl : r;
     }
 }
 

@@ -416,3 +416,22 @@ def test_selection_among_sub_chunks_within_the_error_bound_is_right_to_rounding(
     # and the field really is inside pass 1's error bound: the 32 sub-chunk maxima of a row spread over less than 1e-4 of its scale
     sub_max = sims[:, :1984].view(B, 31, 64).amax(2)
     assert float(((sub_max.amax(1) - sub_max.amin(1)) / sims.abs().amax(1)).max()) < 1e-4
+
+
+@pytest.mark.parametrize("p", [0.0, 0.1])
+def test_selection_leaves_indices_in_range_when_every_similarity_is_nan(p):
+    """A diverged model (NaN weights) must not turn into an out-of-bounds gather: with no candidate at all the per-row selection
+    falls back to the first K types, the step completes and the tile kernel reads rows inside the table."""
+    from p_companion_amd.p_companion import PCompanion
+    from tests.test_gpu_round3 import joint_batch
+    T, P, B, k = 600, 300, 200, 3
+    g = torch.Generator().manual_seed(1)
+    torch.manual_seed(2)
+    m = PCompanion(cfg(NUM_TYPES=T, DROPOUT=p, NUM_COMP_TYPES=k), torch.randn(P, 128, generator=g)).to("cuda").train()
+    with torch.no_grad():
+        next(q for n, q in m.named_parameters() if "type_transition" in n and q.dim() == 2).fill_(float("nan"))
+    b = joint_batch(B, P, 50, seed=2)
+    _, tf = m.train_step(b)
+    torch.cuda.synchronize()
+    tk = tf.cpu().numpy()
+    assert tk.shape == (B, k) and tk.min() >= 0 and tk.max() < T
