@@ -33,6 +33,14 @@ for i in range(n):
     host_step.append(time.perf_counter() - t1)
     if os.environ.get("PC_SYNC_EVERY") and i < int(os.environ["PC_SYNC_EVERY"]):
         torch.cuda.synchronize()
+    if i == 4 and float(os.environ.get("PC_BUSY_MS", "0")) > 0:
+        # PC_BUSY_MS: an unrelated dense product keeps the chip loaded for that long behind step 4 -- is what steps 5.. pay the chip
+        # coming up from idle (the first step alone is 30 ms of host work), or something of the step's own?
+        x = torch.randn(8192, 8192, device=dev)
+        t_b = time.perf_counter()
+        while (time.perf_counter() - t_b) * 1e3 < float(os.environ["PC_BUSY_MS"]):
+            y = x @ x
+        del x, y
 torch.cuda.synchronize()
 ms = [evs[i].elapsed_time(evs[i + 1]) for i in range(n)]
 for i in range(n):
