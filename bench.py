@@ -186,6 +186,11 @@ def joint_algorithmic_bytes(b, t, k=3):
     return b * (512 + 1024 + 256 + k * 256 + 40) + t * 64 * 4 + 28 * (2 * t * 64 + 29024)
 
 
+# The joint legs choose their own number of timed steps (the contract's K is the Product2Vec headline's): a 0.05 ms step timed over
+# 100 steps is a 5 ms region -- the chip is still coming up from idle (0.0476 ms over 100 steps, 0.0459 over 1000; T = 34800: 0.127
+# over 25, 0.1215 over 250: scripts/dev/first_steps_probe.py) -- so these legs time at least 46 / 30 ms.
+JOINT_MIN_STEPS = 1000
+JOINT_REF_MIN_STEPS = 250
 EXCHANGE = {"ex": None}      # the replicas' gradient exchange (distributed.make_exchange), set once in main() when N > 1
 
 
@@ -734,18 +739,18 @@ def main():
     if args.phase in ("both", "joint"):
         # (with the Product2Vec phase in front, the joint legs are secondary to the headline value: guarded like the others)
         first = (lambda name, fn: fn()) if args.phase == "joint" else (lambda name, fn: guarded(name, fn, world))
-        joint = first("joint", lambda: run_joint(args, rank, world, dev, args.types, max(args.steps * 4, 100), max(args.warmup, 10), want_cpu,
+        joint = first("joint", lambda: run_joint(args, rank, world, dev, args.types, max(args.steps * 4, JOINT_MIN_STEPS), max(args.warmup, 10), want_cpu,
                                                  dropout=args.dropout))
         if not args.no_dropout_legs and args.dropout == 0.0:
-            extra["joint_dropout_0p1"] = guarded("joint_dropout_0p1", lambda: run_joint(args, rank, world, dev, args.types, max(args.steps * 4, 100),
+            extra["joint_dropout_0p1"] = guarded("joint_dropout_0p1", lambda: run_joint(args, rank, world, dev, args.types, max(args.steps * 4, JOINT_MIN_STEPS),
                                                                                          max(args.warmup, 10), False, dropout=0.1), world)
         if not args.no_ref_types and args.types != 34800:
-            joint_ref = guarded("joint_num_types_34800", lambda: run_joint(args, rank, world, dev, 34800, max(args.steps, 20), max(args.warmup, 10),
+            joint_ref = guarded("joint_num_types_34800", lambda: run_joint(args, rank, world, dev, 34800, max(args.steps, JOINT_REF_MIN_STEPS), max(args.warmup, 10),
                                                                            want_cpu, dropout=args.dropout), world)
             if not args.no_dropout_legs and args.dropout == 0.0:
                 extra["joint_num_types_34800_dropout_0p1"] = guarded(
                     "joint_num_types_34800_dropout_0p1",
-                    lambda: run_joint(args, rank, world, dev, 34800, max(args.steps, 20), max(args.warmup, 10), False, dropout=0.1), world)
+                    lambda: run_joint(args, rank, world, dev, 34800, max(args.steps, JOINT_REF_MIN_STEPS), max(args.warmup, 10), False, dropout=0.1), world)
     if args.phase in ("both", "p2v") and plain and not args.no_large:
         # BASELINE configs[3] / [4] at their real sizes, catalogue generated in HBM (this rank's shard of the table when N > 1).
         # One GPU holds configs[4] whole (102 GB of 288); the smaller catalogues are released first.
