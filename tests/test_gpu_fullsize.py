@@ -1,7 +1,16 @@
-"""Size-independent properties at BASELINE.json's full sizes (configs[1]: 100 k products, 100 types, B = 4096,
-neighbour lists padded to 32; configs[0]'s T = 34800 for the joint similarities).  The oracle finishes these
-sizes in minutes, not seconds, so here the HIP path is checked against itself through identities the reference
-semantics imply:
+"""BASELINE.json's full sizes (configs[1]: 100 k products, 100 types, B = 4096, neighbour lists padded to the batch max <= 32;
+configs[2]: the same catalogue through the joint step at T = 100 and at config.py:27's NUM_TYPES = 34800), through the entry
+points bench.py times.
+
+Against the ORACLE (it takes ~3 s per Product2Vec step and 0.2-1.1 s per joint step at these sizes on the GPU box's host cores):
+  * configs[1]: one batch of the loader bench.py uses (device sampler, unique-row layout) through pc_p2v_train_step_unique +
+    pc_adam_step vs p2v_oracle.train_step on the dense batch the reference's collate_fn would have built: loss <= 1e-4, all twelve
+    gradients, BatchNorm running statistics, parameters after the Adam step;
+  * configs[2]: the 100 k catalogue through ComplementaryIndexLoader(deferred=True) + GraphedJointStep -- one step through
+    pc_joint_fused_step_pairs (top-k, the three losses, ten gradients) and three steps through run_epoch (pc_joint_train_epoch:
+    per-step losses, parameters after three Adam steps) vs joint_oracle.train_step on the materialised batches, at T = 100 and at
+    T = 34800 without and with the explicit hidden-layer dropout mask.
+And through identities the reference semantics imply (no oracle needed):
   * the three row layouts of the step (every slot a row / padding once / every distinct product once) give the
     same loss, embeddings and gradients (identical rows are identical at every layer);
   * permuting the samples of a batch permutes nothing observable (BatchNorm, the mean loss and every gradient are
@@ -158,3 +167,192 @@ def test_fused_selection_at_full_size_against_the_dense_similarity_matrix(p):
     assert bool((mine >= best_v - tol).all()), float((best_v - mine).max())
     assert bool((mine[:, :-1] >= mine[:, 1:] - tol).all())
     assert int((got != best_i).any(1).sum()) <= 4                                     # (rounding-level ties only)
+
+
+# ------------------------------------------------------------------------------------------------------------------------
+# ORACLE parity at full size, through the entry points bench.py times
+# ------------------------------------------------------------------------------------------------------------------------
+def _adam_close(actual, desired, steps, tight, lr=1e-3):
+    """Parameters after `steps` Adam steps: nothing further from the oracle than the steps can move it, and all but a
+    handful of elements (gradients at rounding level, where the first Adam steps are sign-like) within `tight`."""
+    d = (actual - torch.as_tensor(desired)).abs()
+    assert float(d.max()) <= 1.05 * lr * steps, float(d.max())
+    assert float((d <= tight).float().mean()) >= 0.999, float((d <= tight).float().mean())
+
+
+@pytest.fixture(scope="module")
+def full_bpg():
+    from p_companion_amd.data import generate_scaled_bpg
+    return generate_scaled_bpg(100_000, 100, seed=0)               # bench.py's catalogue (configs[1] and [2])
+
+
+def test_config1_unique_layout_step_and_adam_against_the_oracle(full_bpg):
+    """configs[1] as bench.py runs it (product2vec.py:126-159 per step): a batch of the throughput loader -- device Philox
+    negatives, every distinct neighbour product once -- through Product2Vec.train_step_indexed (pc_p2v_train_step_unique)
+    and FusedAdam.step (pc_adam_step), against the oracle on the dense [B,N,128] batch collate_fn would have built."""
+    from types import SimpleNamespace
+    from oracle import p2v_oracle
+    from p_companion_amd.data import SimilarityIndexLoader
+    from p_companion_amd.product2vec import FusedAdam, Product2Vec
+    bpg = full_bpg
+    B = 4096
+    loader = SimilarityIndexLoader(bpg, B, shuffle=True, sampler="philox", seed=1, drop_last=True, device="cuda",
+                                   reuse_buffers=True)
+    assert loader.unique
+    batch = next(iter(loader))
+    nbc = batch["neighbor_compact"]
+    assert "weight" in nbc                                         # the unique-row layout (multiplicities)
+    # the layout says which product sits in every (sample, slot): exactly the anchor's co-view out-neighbours (bpg.py:24-38),
+    # the rest of the row padding (-1 = collate_fn's zero row, data_loader.py:186-198)
+    nb_dense = nbc["nb_rows"].cpu().numpy()[nbc["slot_row"].cpu().numpy()]
+    anchors = batch["anchor_idx"].cpu().numpy()
+    assert nb_dense.shape[0] == B and nb_dense.shape[1] <= 32 and nb_dense.shape[1] == batch["n_pad"]
+    for i in range(0, B, 97):
+        lo, hi = bpg.cv_rowptr[anchors[i]], bpg.cv_rowptr[anchors[i] + 1]
+        row = nb_dense[i]
+        assert sorted(row[row >= 0].tolist()) == sorted(bpg.cv_col[lo:hi].tolist()) and hi - lo >= 1
+    neg = batch["negative_idx"].cpu().numpy()
+    assert neg.shape == (B, 5) and bool((neg != anchors[:, None]).all())
+    cfg = SimpleNamespace(PRODUCT_EMB_DIM=128, TYPE_EMB_DIM=64, HIDDEN_SIZE=256, NUM_ATTENTION_HEADS=4, DROPOUT=0.0,
+                          MARGIN=1.0, BATCH_SIZE=B, LEARNING_RATE=1e-3, DEVICE=torch.device("cuda"))
+    torch.manual_seed(0)
+    model = Product2Vec(cfg).cuda().train()
+    opt = FusedAdam(model, lr=1e-3)
+    st = {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}
+    table = bpg.cuda("cuda")["features"]
+    loss = float(model.train_step_indexed(table, batch))
+    grads = {k: p.grad.detach().cpu().clone() for k, p in model.named_parameters()}
+    opt.step()
+    after = {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}
+    dense = p2v_oracle.gather_batch(torch.from_numpy(bpg.features), anchors, batch["positive_idx"].cpu().numpy(), neg, nb_dense)
+    assert dense["anchor_neighbors"].shape == (B, nb_dense.shape[1], 128)
+    ref = p2v_oracle.train_step(st, dense, 1.0, p2v_oracle.new_moments(st), 1)
+    assert abs(loss - float(ref["loss"])) < 1e-4, (loss, float(ref["loss"]))          # the north_star's bound
+    for k in p2v_oracle.TRAINABLE:
+        r = ref["grads"][k]
+        if k == "ffn.0.bias":
+            assert float(grads[k].abs().max()) < 1e-6                                  # analytically zero (BatchNorm follows)
+            continue
+        tol = 2e-6 + 2e-4 * float(r.abs().max())
+        assert float((grads[k] - r).abs().max()) < tol, (k, float((grads[k] - r).abs().max()), tol)
+    for k in ("ffn.1.running_mean", "ffn.1.running_var"):
+        assert torch.allclose(after[k], st[k], rtol=1e-5, atol=1e-5), k                # (the oracle updated `st` in place)
+    assert int(after["ffn.1.num_batches_tracked"]) == int(st["ffn.1.num_batches_tracked"]) == 4
+    for k in p2v_oracle.TRAINABLE:
+        if k != "ffn.0.bias":
+            _adam_close(after[k], st[k], 1, 5e-5)
+
+
+def _joint_setup(bpg, T, dropout, B=4096):
+    from types import SimpleNamespace
+    from p_companion_amd.data import ComplementaryIndexDataset, ComplementaryIndexLoader
+    from p_companion_amd.p_companion import GraphedJointStep, PCompanion
+    from p_companion_amd.product2vec import FusedAdam
+    cfg = SimpleNamespace(PRODUCT_EMB_DIM=128, TYPE_EMB_DIM=64, DROPOUT=float(dropout), MARGIN=1.0, ALPHA=0.8, NUM_COMP_TYPES=3,
+                          NUM_TYPES=T, DEVICE=torch.device("cuda"))
+    torch.manual_seed(0)
+    model = PCompanion(cfg, bpg.cuda("cuda")["features"]).cuda().train()
+    model.type_transition._dropout_seed, model.type_transition._dropout_step = 4242, 0
+    opt = FusedAdam(model, lr=1e-3)
+    step = GraphedJointStep(model, opt, B, warmup=0, mode="direct")
+    ds = ComplementaryIndexDataset(bpg, "train")
+    loader = ComplementaryIndexLoader(ds, B, shuffle=True, seed=0, device="cuda", out=step.static, deferred=True)
+    plain = ComplementaryIndexLoader(ds, B, shuffle=True, seed=0, device="cuda")          # the same batches, built up front
+    return cfg, model, opt, step, loader, plain
+
+
+def _host_batches(plain, n, bpg, B=4096):
+    """The first n batches of the epoch as host tensors, each checked against the label rules of data_loader.py:133-157."""
+    out = []
+    for b in plain:
+        lab = b["label"].cpu().numpy()
+        hb = {k: v.detach().cpu().clone() for k, v in b.items() if torch.is_tensor(v)}
+        q, qt = hb["query_idx"].numpy(), hb["query_types"].numpy()
+        assert q.shape == (B,) and np.array_equal(qt, bpg.type_idx[q])
+        pt, nt = hb["positive_types"].numpy()[:, 0], hb["negative_types"].numpy()[:, 0]
+        tgt_feat = hb["target_features"].numpy()
+        pos, neg = hb["positive_items"].numpy(), hb["negative_items"].numpy()
+        comp = lab == 1
+        assert comp.any() and (~comp).any()
+        assert np.array_equal(pos[comp], tgt_feat[comp]) and np.array_equal(neg[~comp], tgt_feat[~comp])
+        assert bool((pt[~comp] == 0).all()) and np.array_equal(nt[comp], (pt[comp] + 1) % bpg.n_types)
+        out.append(hb)
+        if len(out) == n:
+            break
+    return out
+
+
+def _hidden_mask(dropout, offset, B):
+    from oracle import philox_oracle
+    if dropout <= 0.0:
+        return None
+    return torch.from_numpy(philox_oracle.dropout_mask(4242, offset, philox_oracle.STREAM_HIDDEN, B * 32, dropout)).view(B, 32)
+
+
+@pytest.mark.parametrize("T,dropout", [(100, 0.0), (34800, 0.0), (34800, 0.1)])
+def test_config2_fused_pairs_step_against_the_oracle(full_bpg, T, dropout):
+    """configs[2] through pc_joint_fused_step_pairs (one step of train.py:42-48, the batch built inside the step's first
+    kernel) at B = 4096 over the 100 k catalogue: top-k index-exact, the three losses <= 1e-4, ten gradients."""
+    from oracle import joint_oracle
+    B = 4096
+    cfg, model, opt, step, loader, plain = _joint_setup(full_bpg, T, dropout)
+    st0 = {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}
+    hb = _host_batches(plain, 1, full_bpg)[0]
+    model.flatten_parameters()
+    opt.fused_state()
+    step._prepare()                                    # (as run_epoch does: the first call then already takes the pairs form)
+    batch = next(iter(loader))
+    assert "_deferred" in batch
+    losses, topk = step(batch)
+    assert step.prepared is not None and step.prepared.calls == 1 and "_deferred" not in batch
+    for k in ("query_idx", "query_types", "positive_types", "negative_types", "positive_items", "negative_items"):
+        assert torch.equal(step.static[k].cpu(), hb[k].reshape(step.static[k].shape)), k     # the step built THIS batch
+    grads = {k: p.grad.detach().cpu().clone() for k, p in model.named_parameters() if p.requires_grad}
+    ref = joint_oracle.train_step({k: v.clone() for k, v in st0.items()}, hb, joint_oracle.new_moments(st0), 1,
+                                  cfg.MARGIN, cfg.ALPHA, cfg.NUM_COMP_TYPES, hidden_mask=_hidden_mask(dropout, 0, B))
+    want = ref["out"]["complementary_types"]
+    got = topk.cpu().long()
+    differ = (got != want).any(1)
+    if bool(differ.any()):
+        # only where two similarities of a row agree to fp32 rounding may the selections differ
+        sims = ref["out"]["type_similarities"]
+        mine, best = sims.gather(1, got), sims.gather(1, want)
+        assert int(differ.sum()) <= 2 and bool(((mine - best).abs() <= 2e-6 * sims.abs().amax(1, keepdim=True))[differ].all())
+    lo = losses.cpu()
+    assert abs(float(lo[0]) - float(ref["loss"])) < 1e-4 and abs(float(lo[1]) - float(ref["type_loss"])) < 1e-4 \
+        and abs(float(lo[2]) - float(ref["item_loss"])) < 1e-4, (lo, ref["loss"], ref["type_loss"], ref["item_loss"])
+    slack = float(differ.sum()) * 4.0 / (B * cfg.NUM_COMP_TYPES)                          # (a swapped near-tie moves one row's share)
+    for k in joint_oracle.TRAINABLE:
+        r = ref["grads"][k]
+        tol = 2e-6 + 2e-4 * float(r.abs().max()) + slack
+        assert float((grads[k] - r).abs().max()) < tol, (k, float((grads[k] - r).abs().max()), tol)
+    untouched = ref["grads"]["query_type_embeddings.weight"].abs().sum(1) == 0
+    assert bool((grads["query_type_embeddings.weight"][untouched] == 0).all())
+
+
+@pytest.mark.parametrize("T,dropout", [(100, 0.0), (34800, 0.0), (34800, 0.1)])
+def test_config2_run_epoch_against_the_oracle(full_bpg, T, dropout):
+    """configs[2] through GraphedJointStep.run_epoch (pc_joint_train_epoch: what bench.py's joint legs time) at B = 4096
+    over the 100 k catalogue: the first three steps of the epoch vs three oracle steps on the materialised batches --
+    per-step losses <= 1e-4 and every parameter after three dense Adam steps (untouched type rows move too once their
+    moments are non-zero, p_companion.py:36-43 + train.py:24)."""
+    from oracle import joint_oracle
+    B, n = 4096, 3
+    cfg, model, opt, step, loader, plain = _joint_setup(full_bpg, T, dropout)
+    st = {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}
+    init = {k: v.clone() for k, v in st.items()}
+    hbs = _host_batches(plain, n, full_bpg)
+    got = step.run_epoch(loader, drop_last=True, max_steps=n)
+    assert got.shape == (n, 3) and int(opt.step_count) == n and loader.step == n
+    mom = joint_oracle.new_moments(st)
+    for i, hb in enumerate(hbs):
+        ref = joint_oracle.train_step(st, hb, mom, i + 1, cfg.MARGIN, cfg.ALPHA, cfg.NUM_COMP_TYPES,
+                                      hidden_mask=_hidden_mask(dropout, i, B))
+        g = got[i].cpu()
+        assert abs(float(g[0]) - float(ref["loss"])) < 1e-4 and abs(float(g[1]) - float(ref["type_loss"])) < 1e-4 \
+            and abs(float(g[2]) - float(ref["item_loss"])) < 1e-4, (i, g, ref["loss"], ref["type_loss"], ref["item_loss"])
+    after = {k: v.detach().cpu() for k, v in model.state_dict().items()}
+    for k in joint_oracle.TRAINABLE:
+        _adam_close(after[k], st[k], n, 5e-5)
+        assert not torch.equal(after[k], init[k]), k
+    assert torch.equal(after["product_embeddings.weight"], init["product_embeddings.weight"])    # frozen (p_companion.py:26-29)
