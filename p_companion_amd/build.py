@@ -55,5 +55,54 @@ def build(force=False, verbose=False):
     return LIB
 
 
+LLVM_BIN = os.environ.get("PC_LLVM_BIN", "/opt/rocm/lib/llvm/bin")
+
+
+def kernel_resources():
+    """Per kernel of every compiled translation unit: the code object's own metadata (llvm-readelf --notes on the gfx950 image
+    unbundled from the object's .hip_fatbin): {name: {vgpr_count, agpr_count, sgpr_count, vgpr_spill_count, sgpr_spill_count,
+    private_segment_fixed_size, lds (group_segment_fixed_size), unit}}.  Used by __graft_entry__.build() to refuse a build in
+    which a product kernel spills vector registers to scratch."""
+    import tempfile
+    import yaml
+    out = {}
+    with tempfile.TemporaryDirectory() as tmp:
+        for s in sources():
+            if not s.endswith(".hip"):
+                continue
+            unit = os.path.splitext(s)[0]
+            obj = os.path.join(OBJ, unit + ".o")
+            fat, co = os.path.join(tmp, unit + ".fat"), os.path.join(tmp, unit + ".co")
+            r = subprocess.run([os.path.join(LLVM_BIN, "llvm-objcopy"), "--dump-section", ".hip_fatbin=" + fat, obj],
+                               capture_output=True, text=True)
+            if r.returncode != 0 or not os.path.exists(fat):
+                continue                                          # (a unit without device code)
+            subprocess.run([os.path.join(LLVM_BIN, "clang-offload-bundler"), "--unbundle", "--type=o", "--input=" + fat,
+                            "--targets=hipv4-amdgcn-amd-amdhsa--gfx950", "--output=" + co], check=True, capture_output=True)
+            notes = subprocess.run([os.path.join(LLVM_BIN, "llvm-readelf"), "--notes", co], check=True, capture_output=True,
+                                   text=True).stdout
+            # the note is YAML between '---' and '...'
+            lines = notes.splitlines()
+            lo = next(i for i, ln in enumerate(lines) if ln.strip() == "---")
+            hi = next((i for i in range(lo + 1, len(lines)) if lines[i].strip() == "..."), len(lines))
+            meta = yaml.safe_load("\n".join(lines[lo + 1:hi]))
+            for k in meta.get("amdhsa.kernels", []):
+                out[k[".name"]] = {"unit": unit, "lds": int(k.get(".group_segment_fixed_size", 0)),
+                                   **{f: int(k.get("." + f, 0)) for f in ("vgpr_count", "agpr_count", "sgpr_count", "vgpr_spill_count",
+                                                                          "sgpr_spill_count", "private_segment_fixed_size")}}
+    return out
+
+
+def spilling_kernels():
+    """[(name, vgpr_spill_count, private_segment_fixed_size)] of kernels that keep vector registers in scratch."""
+    return sorted((n, r.get("vgpr_spill_count", 0), r.get("private_segment_fixed_size", 0)) for n, r in kernel_resources().items()
+                  if r.get("vgpr_spill_count", 0) > 0 or r.get("private_segment_fixed_size", 0) > 0)
+
+
 if __name__ == "__main__":
     print(build(force="--force" in sys.argv, verbose=True))
+    if "--resources" in sys.argv:
+        for n, r in sorted(kernel_resources().items()):
+            print(r["unit"], n, {k: v for k, v in r.items() if k != "unit"})
+    bad = spilling_kernels()
+    print("kernels with scratch:", bad if bad else "none")

@@ -578,16 +578,19 @@ int launch_gemm_tn(const TnArgs& a, hipStream_t st, TnDefer* defer) {
     const bool apro = a.prologue == NT_PRO_BNTANH, zpro = a.zaux != nullptr;
     const int pb = pc_prof_begin(PC_KIND_GEMM_TN, 2.0 * a.R * (double)a.No * a.Ni, st);
     if (tn_full_tile(a.R, a.No, a.Ni) && !(apro && zpro)) {
-#define TN8(WO, WI, TO, TI)                                                                                   \
+        // (TKC, NST): chunks of 32 rows in two stages, except the 256 x 256 tile -- 128 accumulator registers per lane: its DMA
+        // geometry and gather indices for 32-row chunks do not fit beside them (7-14 VGPRs went to scratch), so it takes 16-row
+        // chunks in three stages like the ZPRO forms (same steady-state rate: these kernels do not wait for HBM)
+#define TN8(WO, WI, TO, TI, TKC, NST)                                                                         \
     do {                                                                                                      \
-        if (apro) PC_LAUNCH((gemm_tn8_kernel<WO, WI, TO, TI, 32, 2, true, false>), dim3(nsplit), dim3(64 * WO * WI), 0, st, a, nsplit, rps, 1, (size_t)0);       \
+        if (apro) PC_LAUNCH((gemm_tn8_kernel<WO, WI, TO, TI, TKC, NST, true, false>), dim3(nsplit), dim3(64 * WO * WI), 0, st, a, nsplit, rps, 1, (size_t)0);    \
         else if (zpro && a.Ni > 128) PC_LAUNCH((gemm_tn8_kernel<2, 4, 4, 2, 16, 3, false, true>), dim3(nsplit), dim3(512), 0, st, a, nsplit, rps, 1, (size_t)0);  \
         else if (zpro) PC_LAUNCH((gemm_tn8_kernel<4, 2, 2, 2, 16, 3, false, true>), dim3(nsplit), dim3(512), 0, st, a, nsplit, rps, 1, (size_t)0);  \
-        else PC_LAUNCH((gemm_tn8_kernel<WO, WI, TO, TI, 32, 2, false, false>), dim3(nsplit), dim3(64 * WO * WI), 0, st, a, nsplit, rps, 1, (size_t)0);           \
+        else PC_LAUNCH((gemm_tn8_kernel<WO, WI, TO, TI, TKC, NST, false, false>), dim3(nsplit), dim3(64 * WO * WI), 0, st, a, nsplit, rps, 1, (size_t)0);        \
     } while (0)
-        if (a.No > 128 && a.Ni > 128) TN8(2, 4, 4, 2);
-        else if (a.No > 128) TN8(4, 2, 2, 2);
-        else TN8(2, 4, 2, 2);
+        if (a.No > 128 && a.Ni > 128) TN8(2, 4, 4, 2, 16, 3);
+        else if (a.No > 128) TN8(4, 2, 2, 2, 32, 2);
+        else TN8(2, 4, 2, 2, 32, 2);
 #undef TN8
     } else {
         PC_LAUNCH(gemm_tn_kernel, dim3(tiles_o * tiles_i * nsplit), dim3(256), 0, st, a, tiles_i, nsplit, rps);

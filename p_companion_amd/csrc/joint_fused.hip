@@ -1329,20 +1329,16 @@ __global__ __launch_bounds__(512) void joint_wgrad_kernel(WgradArgs a) {
     const int ntb = (a.T + 15) >> 4;                                    // 16-type column blocks of the tables
     constexpr int MBK = KC ? KC : FK;
 
-    f32x4v c_itm[8], c_typ[4], c_dec, c_enc, c_ec[NTW], c_eq[NTW];
-#pragma unroll
-    for (int i = 0; i < 8; i++) c_itm[i] = f32x4v{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int i = 0; i < 4; i++) c_typ[i] = f32x4v{0.f, 0.f, 0.f, 0.f};
-    c_dec = f32x4v{0.f, 0.f, 0.f, 0.f}; c_enc = f32x4v{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int i = 0; i < NTW; i++) { c_ec[i] = f32x4v{0.f, 0.f, 0.f, 0.f}; c_eq[i] = f32x4v{0.f, 0.f, 0.f, 0.f}; }
+    // One 16-sample subtile per workgroup (WG_S == 16): every product's accumulators live only from its own MFMA loop to its
+    // slab store -- the widest group (a table product: NTW x 4 registers) instead of all 184 at once (which left 28-31 VGPRs
+    // in scratch under the 256-register budget of two waves per SIMD).
+    static_assert(WG_S == 16, "one subtile per workgroup: accumulators are stored right behind their product");
     float bsum = 0.f;                          // bias column owned by this thread (tid < 352)
-
-    for (int sub = 0; sub < WG_S / 16; sub++) {
-        const int b0 = blockIdx.x * WG_S + sub * 16;
-        if (b0 >= a.B) break;                                           // workgroup-uniform
-        __syncthreads();
+    float* slab = a.slabs + (size_t)blockIdx.x * a.slab_floats;
+    auto st4 = [&](float* dst, const f32x4v& v) { *reinterpret_cast<float4*>(dst) = make_float4(v[0], v[1], v[2], v[3]); };
+    const int b0 = blockIdx.x * WG_S;
+    if (b0 >= a.B) return;                                              // workgroup-uniform (the grid is ceil(B / 16))
+    {
         // ---- stage the subtile: rows past the batch are zero
         auto rowf4 = [&](float* dst, int ld, const float* src, int width4, int rows, int first_row, int row_limit) {
             for (int e = tid; e < rows * width4; e += 512) {
@@ -1396,14 +1392,25 @@ __global__ __launch_bounds__(512) void joint_wgrad_kernel(WgradArgs a) {
         else if (tid < 256) { for (int r = 0; r < 16 * K; r++) bsum += DTP[r * WLD128 + tid - 128]; }
         else if (tid < 320) { for (int r = 0; r < 16; r++) bsum += DC[r * WLD64 + tid - 256]; }
         else if (tid < 352) { for (int r = 0; r < 16; r++) bsum += DH[r * WLD32 + tid - 320]; }
-        // ---- d itm_w^T: wave w owns input block w (16 of the 128 q dims) x all 8 output blocks
+    }
+    // result register r of a block = input index 4 h + r (+ block), column = output index
+    {   // ---- d itm_w^T: wave w owns input block w (16 of the 128 q dims) x all 8 output blocks
+        f32x4v c_itm[8];
+#pragma unroll
+        for (int i = 0; i < 8; i++) c_itm[i] = f32x4v{0.f, 0.f, 0.f, 0.f};
 #pragma unroll 2
         for (int q = 0; q < 4; q++) {
             const float av = Q[(4 * q + h) * WLD128 + 16 * w + i16];
 #pragma unroll
             for (int ob = 0; ob < 8; ob++) c_itm[ob] = mfma16(av, DPI[(4 * q + h) * WLD128 + 16 * ob + i16], c_itm[ob]);
         }
-        // ---- d typ_w^T: input block w & 3 (of 4) x output blocks 4 (w >> 2) .. + 3; 16 K rows
+#pragma unroll
+        for (int ob = 0; ob < 8; ob++) st4(slab + wg_off_itm_w() + (size_t)(16 * ob + i16) * PC_D + 16 * w + 4 * h, c_itm[ob]);
+    }
+    {   // ---- d typ_w^T: input block w & 3 (of 4) x output blocks 4 (w >> 2) .. + 3; 16 K rows
+        f32x4v c_typ[4];
+#pragma unroll
+        for (int i = 0; i < 4; i++) c_typ[i] = f32x4v{0.f, 0.f, 0.f, 0.f};
 #pragma unroll 2
         for (int q = 0; q < 4 * MBK; q++) {
             if (q < 4 * K) {
@@ -1413,14 +1420,26 @@ __global__ __launch_bounds__(512) void joint_wgrad_kernel(WgradArgs a) {
                     c_typ[ob] = mfma16(av, DTP[(4 * q + h) * WLD128 + 16 * (4 * (w >> 2) + ob) + i16], c_typ[ob]);
             }
         }
-        // ---- d dec_w^T [32 in][64 out]: input block w & 1, output block w >> 1;  d enc_w^T [64 in][32 out]: w & 3, w >> 2
+#pragma unroll
+        for (int ob = 0; ob < 4; ob++)
+            st4(slab + wg_off_typ_w() + (size_t)(16 * (4 * (w >> 2) + ob) + i16) * PC_L + 16 * (w & 3) + 4 * h, c_typ[ob]);
+    }
+    {   // ---- d dec_w^T [32 in][64 out]: input block w & 1, output block w >> 1;  d enc_w^T [64 in][32 out]: w & 3, w >> 2
+        f32x4v c_dec = f32x4v{0.f, 0.f, 0.f, 0.f}, c_enc = f32x4v{0.f, 0.f, 0.f, 0.f};
 #pragma unroll 1
         for (int q = 0; q < 4; q++) {
             c_dec = mfma16(Hh[(4 * q + h) * WLD32 + 16 * (w & 1) + i16], DC[(4 * q + h) * WLD64 + 16 * (w >> 1) + i16], c_dec);
             c_enc = mfma16(Tq[(4 * q + h) * WLD64 + 16 * (w & 3) + i16], DH[(4 * q + h) * WLD32 + 16 * (w >> 2) + i16], c_enc);
         }
-        // ---- table gradients, transposed: C[j][t] = sum_r src[r][j] [idx[r] == t]; wave: dims block w & 3, type blocks
-        // (w >> 2) + 2 n
+        st4(slab + wg_off_dec_w() + (size_t)(16 * (w >> 1) + i16) * LH + 16 * (w & 1) + 4 * h, c_dec);
+        st4(slab + wg_off_enc_w() + (size_t)(16 * (w >> 2) + i16) * PC_L + 16 * (w & 3) + 4 * h, c_enc);
+    }
+    // ---- table gradients, transposed: C[j][t] = sum_r src[r][j] [idx[r] == t]; wave: dims block w & 3, type blocks
+    // (w >> 2) + 2 n
+    {
+        f32x4v c_ec[NTW];
+#pragma unroll
+        for (int i = 0; i < NTW; i++) c_ec[i] = f32x4v{0.f, 0.f, 0.f, 0.f};
 #pragma unroll 1
         for (int q = 0; q < 4 * (MBK + 2); q++) {
             if (q < 4 * (K + 2)) {
@@ -1433,6 +1452,16 @@ __global__ __launch_bounds__(512) void joint_wgrad_kernel(WgradArgs a) {
                 }
             }
         }
+#pragma unroll
+        for (int n = 0; n < NTW; n++) {
+            const int t = 16 * ((w >> 2) + 2 * n) + i16;
+            if (t < a.T) st4(slab + wg_off_ec() + (size_t)t * PC_L + 16 * (w & 3) + 4 * h, c_ec[n]);
+        }
+    }
+    {
+        f32x4v c_eq[NTW];
+#pragma unroll
+        for (int i = 0; i < NTW; i++) c_eq[i] = f32x4v{0.f, 0.f, 0.f, 0.f};
 #pragma unroll 1
         for (int q = 0; q < 4; q++) {
             const float av = DT[(4 * q + h) * WLD64 + 16 * (w & 3) + i16];
@@ -1443,23 +1472,10 @@ __global__ __launch_bounds__(512) void joint_wgrad_kernel(WgradArgs a) {
                 if (tb < ntb) c_eq[n] = mfma16(av, d == 16 * tb + i16 ? 1.f : 0.f, c_eq[n]);
             }
         }
-    }
-    // ---- the workgroup's slab: result register r of a block = input index 4 h + r (+ block), column = output index
-    float* slab = a.slabs + (size_t)blockIdx.x * a.slab_floats;
-    auto st4 = [&](float* dst, const f32x4v& v) { *reinterpret_cast<float4*>(dst) = make_float4(v[0], v[1], v[2], v[3]); };
 #pragma unroll
-    for (int ob = 0; ob < 8; ob++) st4(slab + wg_off_itm_w() + (size_t)(16 * ob + i16) * PC_D + 16 * w + 4 * h, c_itm[ob]);
-#pragma unroll
-    for (int ob = 0; ob < 4; ob++)
-        st4(slab + wg_off_typ_w() + (size_t)(16 * (4 * (w >> 2) + ob) + i16) * PC_L + 16 * (w & 3) + 4 * h, c_typ[ob]);
-    st4(slab + wg_off_dec_w() + (size_t)(16 * (w >> 1) + i16) * LH + 16 * (w & 1) + 4 * h, c_dec);
-    st4(slab + wg_off_enc_w() + (size_t)(16 * (w >> 2) + i16) * PC_L + 16 * (w & 3) + 4 * h, c_enc);
-#pragma unroll
-    for (int n = 0; n < NTW; n++) {
-        const int t = 16 * ((w >> 2) + 2 * n) + i16;
-        if (t < a.T) {
-            st4(slab + wg_off_ec() + (size_t)t * PC_L + 16 * (w & 3) + 4 * h, c_ec[n]);
-            st4(slab + wg_off_eq(a.T) + (size_t)t * PC_L + 16 * (w & 3) + 4 * h, c_eq[n]);
+        for (int n = 0; n < NTW; n++) {
+            const int t = 16 * ((w >> 2) + 2 * n) + i16;
+            if (t < a.T) st4(slab + wg_off_eq(a.T) + (size_t)t * PC_L + 16 * (w & 3) + 4 * h, c_eq[n]);
         }
     }
     if (tid < 128) slab[wg_off_itm_b() + tid] = bsum;
