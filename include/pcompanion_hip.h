@@ -581,13 +581,30 @@ int pc_joint_train_epoch_dp(const pc_joint_tensors *p, const pc_joint_tensors *g
  *   pc_rccl_comm_destroy(comm)   ncclCommDestroy (streams drained by the caller)
  *   pc_rccl_allreduce_mean       a pc_exchange_fn: in-place ncclAllReduce(ncclFloat32, ncclAvg) of grad[0 .. n) on `stream`;
  *                                every rank receives the same bits
+ *   pc_rccl_allreduce_sum_f64    in-place ncclAllReduce(ncclFloat64, ncclSum) of buf[0 .. n): the cross-replica BatchNorm sums
+ *                                (ops.p2v_train_step(sync_reduce=...); replaces torch.distributed.all_reduce there)
+ *   pc_rccl_alltoall             the lookup all-to-all of the row-sharded table (the reference keeps its table in one
+ *                                process: src/models/p_companion.py:20-29, src/data/data_loader.py:45-55): bytes
+ *                                [p * bytes_per_peer, (p + 1) * bytes_per_peer) of `send` go to rank p, which finds them in its
+ *                                `recv` at [rank * bytes_per_peer, ...); one grouped ncclSend / ncclRecv per peer, constant splits
+ *                                (send != recv; both device buffers of world * bytes_per_peer bytes)
+ *   pc_rccl_comm_stats           {collectives issued on the communicator, cross-stream waits inserted}
  *   pc_rccl_last_error()         text of the calling thread's last PC_ECOMM (static storage; "" if none)
+ * ORDER.  Every collective of a step goes through this ONE communicator, and the communicator chains them: a collective
+ * enqueued on a stream other than its predecessor's first makes that stream wait for an event recorded behind the predecessor.
+ * The replicas issue the same sequence of calls, so the device-side order of the collectives is the same on every rank
+ * whichever streams carry them (the loader's side stream: pc_rccl_alltoall a few batches ahead; the step's stream:
+ * pc_rccl_allreduce_mean) -- two collectives of one job never race for the links in different orders on different ranks.
+ * One host thread at a time per communicator (calls are serialised by a mutex inside).
  * Returns PC_OK, PC_EINVAL, or PC_ECOMM. */
 int pc_rccl_available(void);
 int pc_rccl_unique_id(void *out_128_bytes);
 int pc_rccl_comm_create(const void *unique_id_128_bytes, int rank, int world, void **comm_out);
 int pc_rccl_comm_destroy(void *comm);
 int pc_rccl_allreduce_mean(void *comm, float *grad, size_t n, void *stream);
+int pc_rccl_allreduce_sum_f64(void *comm, double *buf, size_t n, void *stream);
+int pc_rccl_alltoall(void *comm, const void *send, void *recv, size_t bytes_per_peer, void *stream);
+int pc_rccl_comm_stats(void *comm, int64_t *issued, int64_t *chained);
 const char *pc_rccl_last_error(void);
 
 /* ---------------------------------------------------------------------------------

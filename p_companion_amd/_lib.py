@@ -145,6 +145,9 @@ SIGNATURES = {
     "pc_rccl_comm_create": (_i, [_vp, _i, _i, _P(ctypes.c_void_p)]),
     "pc_rccl_comm_destroy": (_i, [_vp]),
     "pc_rccl_allreduce_mean": (_i, [_vp, _vp, _sz, _vp]),
+    "pc_rccl_allreduce_sum_f64": (_i, [_vp, _vp, _sz, _vp]),
+    "pc_rccl_alltoall": (_i, [_vp, _vp, _vp, _sz, _vp]),
+    "pc_rccl_comm_stats": (_i, [_vp, _P(ctypes.c_int64), _P(ctypes.c_int64)]),
     "pc_rccl_last_error": (ctypes.c_char_p, []),
     "pc_linear_forward": (_i, [_vp, _vp, _i, _i, _vp, _vp, _i, _i, _vp, _vp]),
     "pc_linear_backward_input": (_i, [_vp, _i, _i, _vp, _i, _i, _vp, _vp, _vp, _vp]),

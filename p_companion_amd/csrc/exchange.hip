@@ -1,6 +1,9 @@
 // Data-parallel replicas (ABI 6): the gradient exchange of a step issued from the step's own call.
 //   pc_exchange_adam        exchange slot + torch.optim.Adam over the flat buffers: optimizer.step() of a replica as one call
-//   pc_rccl_*               the library's own RCCL communicator and ncclAllReduce(ncclAvg) as the native pc_exchange_fn
+//   pc_rccl_*               the library's own RCCL communicator: ncclAllReduce(ncclAvg) as the native pc_exchange_fn,
+//                           pc_rccl_alltoall (grouped ncclSend / ncclRecv, constant splits) for the row-sharded table's lookup
+//                           rounds, pc_rccl_allreduce_sum_f64 for cross-replica BatchNorm sums -- EVERY collective of a step on
+//                           ONE communicator, chained by an event when two of them sit on different streams (see PcComm)
 // The reference is single-process (train.py:46-48: loss.backward(); optimizer.step()); a replica averages the gradients
 // between the two.  RCCL is resolved at run time (dlopen of the copy the process has loaded already -- torch's -- else the
 // system's): the library has no link-time dependency on it and loads on a box without it.
@@ -21,6 +24,10 @@ struct RcclApi {
     decltype(&ncclCommInitRank) comm_init_rank = nullptr;
     decltype(&ncclCommDestroy) comm_destroy = nullptr;
     decltype(&ncclAllReduce) all_reduce = nullptr;
+    decltype(&ncclSend) send = nullptr;
+    decltype(&ncclRecv) recv = nullptr;
+    decltype(&ncclGroupStart) group_start = nullptr;
+    decltype(&ncclGroupEnd) group_end = nullptr;
     decltype(&ncclGetErrorString) error_string = nullptr;
     bool ok = false;
 };
@@ -49,7 +56,12 @@ const RcclApi& rccl_api() {
         api.comm_destroy = reinterpret_cast<decltype(api.comm_destroy)>(dlsym(api.handle, "ncclCommDestroy"));
         api.all_reduce = reinterpret_cast<decltype(api.all_reduce)>(dlsym(api.handle, "ncclAllReduce"));
         api.error_string = reinterpret_cast<decltype(api.error_string)>(dlsym(api.handle, "ncclGetErrorString"));
-        api.ok = api.get_unique_id && api.comm_init_rank && api.comm_destroy && api.all_reduce && api.error_string;
+        api.send = reinterpret_cast<decltype(api.send)>(dlsym(api.handle, "ncclSend"));
+        api.recv = reinterpret_cast<decltype(api.recv)>(dlsym(api.handle, "ncclRecv"));
+        api.group_start = reinterpret_cast<decltype(api.group_start)>(dlsym(api.handle, "ncclGroupStart"));
+        api.group_end = reinterpret_cast<decltype(api.group_end)>(dlsym(api.handle, "ncclGroupEnd"));
+        api.ok = api.get_unique_id && api.comm_init_rank && api.comm_destroy && api.all_reduce && api.error_string && api.send &&
+                 api.recv && api.group_start && api.group_end;
     });
     return api;
 }
@@ -59,10 +71,50 @@ int rccl_fail(const RcclApi& api, const char* what, ncclResult_t r) {
     return PC_ECOMM;
 }
 
+// ONE cross-rank launch order for everything a step exchanges.  The replicas run the same program, so every rank ISSUES its
+// collectives in the same host order -- but a step has two streams (the loader's side stream carries the lookup all-to-all of a
+// batch a few steps ahead, the step's stream the gradient all-reduce), and two collectives that are in flight on two streams at
+// once may start in different orders on different ranks: the classic way to deadlock a ring.  So the communicator keeps an
+// event behind its latest collective; a collective enqueued on ANOTHER stream first makes its stream wait for that event.  The
+// device-side order of the communicator's collectives is then their host issue order on every rank, whatever the streams do.
+// (Collectives that all sit on one stream -- the joint step, a replicated table -- never touch the event: stream order is the
+// chain.)  One host thread at a time per communicator: `mu`.
 struct PcComm {
     ncclComm_t comm;
     int rank, world;
+    hipEvent_t done = nullptr;             // behind the latest collective, once a second stream has appeared
+    hipStream_t last_stream = nullptr;
+    bool has_last = false, multi = false;
+    std::mutex mu;
+    long long chained = 0;                 // cross-stream waits inserted so far (pc_rccl_comm_stats)
+    long long issued = 0;
 };
+
+// before enqueuing on `st`: order it behind the communicator's latest collective
+int comm_order(PcComm* c, hipStream_t st) {
+    if (c->has_last && st != c->last_stream) {
+        if (!c->multi) {
+            // first time a second stream shows up: everything before lived on last_stream -- its tail is behind that collective
+            if (!c->done && hipEventCreateWithFlags(&c->done, hipEventDisableTiming) != hipSuccess) {
+                set_error("hipEventCreateWithFlags", "could not create the communicator's ordering event");
+                return PC_ECOMM;
+            }
+            if (hipEventRecord(c->done, c->last_stream) != hipSuccess) { set_error("hipEventRecord", "ordering event"); return PC_ECOMM; }
+            c->multi = true;
+        }
+        if (hipStreamWaitEvent(st, c->done, 0) != hipSuccess) { set_error("hipStreamWaitEvent", "ordering event"); return PC_ECOMM; }
+        c->chained++;
+    }
+    return PC_OK;
+}
+// after enqueuing on `st`
+int comm_issued(PcComm* c, hipStream_t st) {
+    c->issued++;
+    c->last_stream = st;
+    c->has_last = true;
+    if (c->multi && hipEventRecord(c->done, st) != hipSuccess) { set_error("hipEventRecord", "ordering event"); return PC_ECOMM; }
+    return PC_OK;
+}
 
 }  // namespace
 
@@ -91,7 +143,9 @@ extern "C" int pc_rccl_comm_create(const void* unique_id, int rank, int world, v
     ncclComm_t comm = nullptr;
     const ncclResult_t r = api.comm_init_rank(&comm, world, id, rank);
     if (r != ncclSuccess) return rccl_fail(api, "ncclCommInitRank", r);
-    *comm_out = new PcComm{comm, rank, world};
+    PcComm* c = new PcComm;
+    c->comm = comm; c->rank = rank; c->world = world;
+    *comm_out = c;
     return PC_OK;
 }
 
@@ -100,6 +154,7 @@ extern "C" int pc_rccl_comm_destroy(void* comm) {
     PcComm* c = static_cast<PcComm*>(comm);
     const RcclApi& api = rccl_api();
     const ncclResult_t r = api.ok ? api.comm_destroy(c->comm) : ncclSuccess;
+    if (c->done) (void)hipEventDestroy(c->done);
     delete c;
     return r == ncclSuccess ? PC_OK : rccl_fail(api, "ncclCommDestroy", r);
 }
@@ -111,8 +166,61 @@ extern "C" int pc_rccl_allreduce_mean(void* comm, float* grad, size_t n, void* s
     const RcclApi& api = rccl_api();
     if (!api.ok) { set_error("pc_rccl_allreduce_mean", "librccl.so.1 could not be loaded"); return PC_ECOMM; }
     PcComm* c = static_cast<PcComm*>(comm);
+    std::lock_guard<std::mutex> lk(c->mu);
+    PC_TRY(comm_order(c, (hipStream_t)stream));
     const ncclResult_t r = api.all_reduce(grad, grad, n, ncclFloat32, ncclAvg, c->comm, (hipStream_t)stream);
-    return r == ncclSuccess ? PC_OK : rccl_fail(api, "ncclAllReduce", r);
+    if (r != ncclSuccess) return rccl_fail(api, "ncclAllReduce", r);
+    return comm_issued(c, (hipStream_t)stream);
+}
+
+// In-place SUM of n doubles over the ranks (cross-replica BatchNorm: per-segment sums, sums of squares and row counts,
+// PC_BN_SYNC_DOUBLES): the same communicator and the same chain as the gradient exchange.
+extern "C" int pc_rccl_allreduce_sum_f64(void* comm, double* buf, size_t n, void* stream) {
+    if (!comm || !buf || n == 0) return PC_EINVAL;
+    const RcclApi& api = rccl_api();
+    if (!api.ok) { set_error("pc_rccl_allreduce_sum_f64", "librccl.so.1 could not be loaded"); return PC_ECOMM; }
+    PcComm* c = static_cast<PcComm*>(comm);
+    std::lock_guard<std::mutex> lk(c->mu);
+    PC_TRY(comm_order(c, (hipStream_t)stream));
+    const ncclResult_t r = api.all_reduce(buf, buf, n, ncclFloat64, ncclSum, c->comm, (hipStream_t)stream);
+    if (r != ncclSuccess) return rccl_fail(api, "ncclAllReduce(f64)", r);
+    return comm_issued(c, (hipStream_t)stream);
+}
+
+// The lookup all-to-all of the row-sharded table (north_star: "RCCL all-to-all over xGMI for cross-shard lookups"):
+// rank r's bytes [p * bytes_per_peer, (p + 1) * bytes_per_peer) of `send` land in rank p's `recv` at [r * bytes_per_peer, ...).
+// Constant splits (the request capacity is agreed once, at construction), so no size exchange precedes it.  One grouped
+// ncclSend / ncclRecv per peer: xGMI is point to point, every pair has its own link, and RCCL runs the group as one launch.
+extern "C" int pc_rccl_alltoall(void* comm, const void* send, void* recv, size_t bytes_per_peer, void* stream) {
+    if (!comm || !send || !recv || bytes_per_peer == 0 || send == recv) return PC_EINVAL;
+    const RcclApi& api = rccl_api();
+    if (!api.ok) { set_error("pc_rccl_alltoall", "librccl.so.1 could not be loaded"); return PC_ECOMM; }
+    PcComm* c = static_cast<PcComm*>(comm);
+    std::lock_guard<std::mutex> lk(c->mu);
+    PC_TRY(comm_order(c, (hipStream_t)stream));
+    ncclResult_t r = api.group_start();
+    if (r != ncclSuccess) return rccl_fail(api, "ncclGroupStart", r);
+    ncclResult_t bad = ncclSuccess;
+    for (int p = 0; p < c->world; p++) {
+        r = api.send(static_cast<const char*>(send) + (size_t)p * bytes_per_peer, bytes_per_peer, ncclInt8, p, c->comm, (hipStream_t)stream);
+        if (r != ncclSuccess && bad == ncclSuccess) bad = r;
+        r = api.recv(static_cast<char*>(recv) + (size_t)p * bytes_per_peer, bytes_per_peer, ncclInt8, p, c->comm, (hipStream_t)stream);
+        if (r != ncclSuccess && bad == ncclSuccess) bad = r;
+    }
+    r = api.group_end();                                         // (always closed: an open group would swallow every later call)
+    if (bad != ncclSuccess) return rccl_fail(api, "ncclSend/ncclRecv", bad);
+    if (r != ncclSuccess) return rccl_fail(api, "ncclGroupEnd", r);
+    return comm_issued(c, (hipStream_t)stream);
+}
+
+// {collectives issued, cross-stream waits inserted}: what the tests read to see the chain at work
+extern "C" int pc_rccl_comm_stats(void* comm, int64_t* issued, int64_t* chained) {
+    if (!comm) return PC_EINVAL;
+    PcComm* c = static_cast<PcComm*>(comm);
+    std::lock_guard<std::mutex> lk(c->mu);
+    if (issued) *issued = c->issued;
+    if (chained) *chained = c->chained;
+    return PC_OK;
 }
 
 extern "C" int pc_exchange_adam(pc_exchange_fn exchange, void* exchange_ctx, float* param, float* grad, float* exp_avg,
