@@ -313,6 +313,10 @@ def run_joint(args, rank, world, dev, types, steps, warmup, want_cpu, dropout=0.
                                   f"batch={args.batch}/GPU, K=3 (loader batch construction included)",
                       "global_batch": world * args.batch, "parallelism": f"dp{world}", "final_loss": round(float(losses[0]), 5),
                       "dropout": float(dropout),
+                      # N > 1: what one replica hands to the all-reduce per step -- the whole flat gradient buffer behind the slot
+                      # (T = 34800: both dense [T,64] tables, 17.8 MB: about what the touched rows would cost as constant-shape
+                      # padded lists at B = 4096); the Python hooks send the touched rows (sizes read back)
+                      "exchange_bytes_per_step": (int(gflat.numel()) * 4 if multi and graphed is not None and graphed.exchange is not None else None),
                       "exchange": (getattr(exchange, "kind", None) if multi and graphed is not None and graphed.exchange is not None else
                                    "python grad_hook per step (torch.distributed)" if multi else None),
                       "launch": (("pc_joint_train_epoch_dp: the replica's epoch (fused step without Adam, exchange slot, Adam) enqueued by one foreign call"
@@ -389,7 +393,8 @@ def run_p2v(args, rank, world, dev, products, steps, warmup, want_cpu, profile_k
     if table_mode == "sharded":
         # row r on rank r % world; the loader runs the per-batch exchange on its side stream, one batch ahead
         local = table if on_device else pdist.ShardedFeatureTable.shard(table, rank, world)
-        sharded = pdist.ShardedFeatureTable(local, bpg.num_products, rank, world)
+        # (the lookup rounds on the communicator that carries the gradient exchange: one cross-rank launch order per step)
+        sharded = pdist.ShardedFeatureTable(local, bpg.num_products, rank, world, exchange=exchange)
     loader = SimilarityIndexLoader(bpg, args.batch, shuffle=True, sampler="philox", seed=1 + rank, drop_last=True,
                                    device=dev, sharded=sharded, negatives=negatives, reuse_buffers=True)
 
@@ -406,7 +411,8 @@ def run_p2v(args, rank, world, dev, products, steps, warmup, want_cpu, profile_k
 
     def step(b, profile=None):
         tab = b.get("table", table)                       # sharded: the rows this batch's exchange delivered
-        sync = (lambda t: torch.distributed.all_reduce(t)) if (args.sync_bn and multi) else None
+        sync = ((exchange.all_reduce_sum_f64_ if exchange is not None else (lambda t: torch.distributed.all_reduce(t)))
+                if (args.sync_bn and multi) else None)
         loss = model.train_step_indexed(tab, b, profile=profile, sync_reduce=sync)
         if exchange is not None:
             opt.step(exchange=exchange)                   # pc_exchange_adam: the replicas' mean gradient + Adam, one foreign call

@@ -69,7 +69,9 @@ extern "C" {
 /* 6: the data-parallel exchange slot (pc_exchange_fn, pc_exchange_adam, pc_joint_train_epoch_dp) and the library's own RCCL
  *    communicator behind it (pc_rccl_*): the gradient exchange of a replica is issued from the step's own call, on the step's
  *    stream, not from a host-language hook per step. */
-#define PC_ABI_VERSION 6
+/* 7: pc_rccl_alltoall / pc_rccl_allreduce_sum_f64 / pc_rccl_comm_stats: every collective of a step on the library's ONE
+ *    communicator, chained across streams (the lookup all-to-all used to be torch.distributed's, on a second communicator). */
+#define PC_ABI_VERSION 7
 int pc_abi_version(void);
 /* Process-wide options.  PC_OPT_SIDE_QUEUE: 1 (default) = the unsplit fused Product2Vec step may use its side queue
  * (see "Library-owned device state" above), 0 = every launch stays on the caller's stream.  Unknown option / value:
@@ -591,7 +593,8 @@ int pc_joint_train_epoch_dp(const pc_joint_tensors *p, const pc_joint_tensors *g
  *   pc_rccl_comm_stats           {collectives issued on the communicator, cross-stream waits inserted}
  *   pc_rccl_last_error()         text of the calling thread's last PC_ECOMM (static storage; "" if none)
  * ORDER.  Every collective of a step goes through this ONE communicator, and the communicator chains them: a collective
- * enqueued on a stream other than its predecessor's first makes that stream wait for an event recorded behind the predecessor.
+ * enqueued on a stream other than its predecessor's first makes that stream wait for an event recorded (then) at the tail of the
+ * predecessor's stream; collectives that follow each other on one stream add nothing to it.
  * The replicas issue the same sequence of calls, so the device-side order of the collectives is the same on every rank
  * whichever streams carry them (the loader's side stream: pc_rccl_alltoall a few batches ahead; the step's stream:
  * pc_rccl_allreduce_mean) -- two collectives of one job never race for the links in different orders on different ranks.

@@ -74,17 +74,18 @@ int rccl_fail(const RcclApi& api, const char* what, ncclResult_t r) {
 // ONE cross-rank launch order for everything a step exchanges.  The replicas run the same program, so every rank ISSUES its
 // collectives in the same host order -- but a step has two streams (the loader's side stream carries the lookup all-to-all of a
 // batch a few steps ahead, the step's stream the gradient all-reduce), and two collectives that are in flight on two streams at
-// once may start in different orders on different ranks: the classic way to deadlock a ring.  So the communicator keeps an
-// event behind its latest collective; a collective enqueued on ANOTHER stream first makes its stream wait for that event.  The
-// device-side order of the communicator's collectives is then their host issue order on every rank, whatever the streams do.
-// (Collectives that all sit on one stream -- the joint step, a replicated table -- never touch the event: stream order is the
-// chain.)  One host thread at a time per communicator: `mu`.
+// once may start in different orders on different ranks: the classic way to deadlock a ring.  So a collective enqueued on a
+// stream OTHER than its predecessor's first makes its stream wait for an event recorded, at that moment, at the tail of the
+// predecessor's stream (everything enqueued there so far, the predecessor included).  The device-side order of the
+// communicator's collectives is then their host issue order on every rank, whatever the streams do.  Collectives that all sit
+// on one stream -- the joint step, a replicated table -- never touch the event: stream order is the chain, and the step's
+// stream carries no extra packet.  One host thread at a time per communicator: `mu`.
 struct PcComm {
     ncclComm_t comm;
     int rank, world;
-    hipEvent_t done = nullptr;             // behind the latest collective, once a second stream has appeared
+    hipEvent_t done = nullptr;             // re-recorded at every change of stream
     hipStream_t last_stream = nullptr;
-    bool has_last = false, multi = false;
+    bool has_last = false;
     std::mutex mu;
     long long chained = 0;                 // cross-stream waits inserted so far (pc_rccl_comm_stats)
     long long issued = 0;
@@ -93,15 +94,11 @@ struct PcComm {
 // before enqueuing on `st`: order it behind the communicator's latest collective
 int comm_order(PcComm* c, hipStream_t st) {
     if (c->has_last && st != c->last_stream) {
-        if (!c->multi) {
-            // first time a second stream shows up: everything before lived on last_stream -- its tail is behind that collective
-            if (!c->done && hipEventCreateWithFlags(&c->done, hipEventDisableTiming) != hipSuccess) {
-                set_error("hipEventCreateWithFlags", "could not create the communicator's ordering event");
-                return PC_ECOMM;
-            }
-            if (hipEventRecord(c->done, c->last_stream) != hipSuccess) { set_error("hipEventRecord", "ordering event"); return PC_ECOMM; }
-            c->multi = true;
+        if (!c->done && hipEventCreateWithFlags(&c->done, hipEventDisableTiming) != hipSuccess) {
+            set_error("hipEventCreateWithFlags", "could not create the communicator's ordering event");
+            return PC_ECOMM;
         }
+        if (hipEventRecord(c->done, c->last_stream) != hipSuccess) { set_error("hipEventRecord", "ordering event"); return PC_ECOMM; }
         if (hipStreamWaitEvent(st, c->done, 0) != hipSuccess) { set_error("hipStreamWaitEvent", "ordering event"); return PC_ECOMM; }
         c->chained++;
     }
@@ -112,7 +109,6 @@ int comm_issued(PcComm* c, hipStream_t st) {
     c->issued++;
     c->last_stream = st;
     c->has_last = true;
-    if (c->multi && hipEventRecord(c->done, st) != hipSuccess) { set_error("hipEventRecord", "ordering event"); return PC_ECOMM; }
     return PC_OK;
 }
 

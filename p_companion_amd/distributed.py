@@ -55,6 +55,52 @@ def all_reduce_mean_(flat, world):
     return flat
 
 
+class _TorchCollectives:
+    """The step's collectives on torch.distributed's communicator (gloo in the CPU tests; the all-torch `--exchange hook` form
+    on the GPU): the same three calls RcclExchange offers, so ShardedFeatureTable and the BatchNorm sums take either."""
+
+    def __init__(self, group=None):
+        self.group = group
+
+    def all_to_all(self, send, recv):
+        dist.all_to_all_single(recv, send, group=self.group)          # equal splits
+        return recv
+
+    def all_reduce_sum_f64_(self, t):
+        dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
+        return t
+
+
+def _run_with_deadline(fn, seconds, what, rank):
+    """fn() on a helper thread, waited for at most `seconds`.  ncclCommInitRank and the first collectives are host-blocking
+    rendezvous: a peer that died before joining leaves this rank inside them for good, and nothing in-process can unwind a
+    thread parked in a collective library.  So on expiry the PROCESS ends with a non-zero code (no re-exec, no retry): the
+    launcher then ends the job, which is the only recovery an asymmetric failure has.  Exceptions of fn are re-raised here."""
+    import threading
+    box = {}
+
+    def run():
+        try:
+            if torch.cuda.is_available():
+                torch.cuda.set_device(box["dev"])
+            box["res"] = fn()
+        except BaseException as e:                            # noqa: BLE001 -- handed to the waiting thread
+            box["err"] = e
+
+    box["dev"] = torch.cuda.current_device() if torch.cuda.is_available() else None
+    th = threading.Thread(target=run, daemon=True, name="pc-" + what)
+    th.start()
+    th.join(seconds)
+    if th.is_alive():
+        import sys
+        print(f"[p_companion_amd] rank {rank}: {what} did not return within {seconds:.0f} s (PC_DIST_TIMEOUT_S): a peer has "
+              "most likely failed before joining; ending this process so that the launcher ends the job", file=sys.stderr, flush=True)
+        os._exit(75)
+    if "err" in box:
+        raise box["err"]
+    return box.get("res")
+
+
 def make_exchange(world, rank=None, group=None, kind="auto", device=None):
     """The gradient exchange of a data-parallel replica as an ops.Exchange for the library's exchange slot
     (pc_exchange_adam, pc_joint_train_epoch_dp): issued from the step's own foreign call on the step's stream.
@@ -62,15 +108,29 @@ def make_exchange(world, rank=None, group=None, kind="auto", device=None):
                  torch.distributed broadcasts its 128 bytes, every rank joins (ncclCommInitRank) on its current device;
       'callback' torch.distributed.all_reduce behind a Python trampoline (what the gloo tests use; it blocks the host);
       'auto'     'rccl' when the process group's backend is nccl and the RCCL entry points resolve, else 'callback'.
-    None when no collective runs (world == 1 outside the one-rank rehearsal).  After construction 'rccl' is verified with one
-    all-reduce of a known vector; a failure on ANY rank (agreed by a MIN all-reduce over the process group) falls back to
-    'callback' on all of them."""
+    None when no collective runs (world == 1 outside the one-rank rehearsal).
+
+    ONE communicator per step.  Whatever this returns also carries the step's OTHER collectives (`.all_to_all(send, recv)`:
+    the sharded table's lookup rounds; `.all_reduce_sum_f64_(t)`: cross-replica BatchNorm sums): 'rccl' runs all of them on
+    the library's communicator, which chains collectives that sit on different streams (pcompanion_hip.h "ORDER");
+    'callback' runs all of them on torch's.  Two communicators with collectives in flight at once -- torch's on the loader
+    stream, the library's on the step's stream -- may start them in different orders on different ranks and deadlock; hand
+    the SAME object to ShardedFeatureTable(exchange=...) and to the optimizer (bench.py does).  torch's communicator is then
+    used only where the device is drained: construction, capacity agreement, the barriers around a timed region.
+
+    After construction 'rccl' is verified -- an all-reduce of a known vector on the current stream and an all-to-all of known
+    slices on a side stream, i.e. the step's own pattern -- under a host deadline (_run_with_deadline, PC_DIST_TIMEOUT_S).
+    What falls back: a failure EVERY rank sees alike (RCCL missing, an init error on all ranks, a wrong probe result): agreed
+    by a MIN all-reduce over the process group, every rank closes its communicator and takes 'callback'.  What cannot: a
+    failure on SOME ranks leaves the others inside the rendezvous -- they end at the deadline with exit code 75 and the
+    launcher ends the job."""
     if not collectives_on(world):
         return None
     from . import ops
     rank = dist.get_rank(group) if rank is None else rank
     backend = dist.get_backend(group)
-    dev = torch.device("cuda", torch.cuda.current_device()) if device is None else device
+    dev = device if device is not None else (torch.device("cuda", torch.cuda.current_device()) if torch.cuda.is_available()
+                                             else torch.device("cpu"))
 
     def callback():
         def fn(ptr, n, stream):
@@ -83,6 +143,9 @@ def make_exchange(world, rank=None, group=None, kind="auto", device=None):
         fn.tensors = {}
         ex = ops.CallbackExchange(fn, kind=f"torch.distributed.all_reduce ({backend}) behind a Python trampoline")
         ex.register = lambda t: fn.tensors.__setitem__(t.data_ptr(), t)
+        tc = _TorchCollectives(group)
+        ex.all_to_all, ex.all_reduce_sum_f64_ = tc.all_to_all, tc.all_reduce_sum_f64_
+        ex.native = False
         return ex
 
     want = kind
@@ -93,25 +156,48 @@ def make_exchange(world, rank=None, group=None, kind="auto", device=None):
     if want != "rccl":
         raise ValueError("make_exchange: kind 'auto', 'rccl' or 'callback'")
     ok, ex = 1, None
-    try:
+    deadline = float(os.environ.get("PC_DIST_TIMEOUT_S", "600"))
+    holder = {}
+
+    def build_and_probe():
         id_t = torch.zeros(128, dtype=torch.uint8, device=dev if backend == "nccl" else "cpu")
         if rank == 0:
             id_t.copy_(torch.frombuffer(bytearray(ops.RcclExchange.unique_id()), dtype=torch.uint8))
         dist.broadcast(id_t, src=0, group=group)
-        ex = ops.RcclExchange(bytes(id_t.cpu().numpy().tobytes()), rank, world)
+        e = holder["ex"] = ops.RcclExchange(bytes(id_t.cpu().numpy().tobytes()), rank, world)
         probe = torch.full((1024,), float(rank + 1), dtype=torch.float32, device=dev)
-        ex.all_reduce_mean_(probe)
+        send = (torch.arange(world * 256, device=dev, dtype=torch.int32) // 256 + 1000 * rank).contiguous()   # slice p: 1000 rank + p
+        recv = torch.empty_like(send)
+        side = torch.cuda.Stream(dev)
+        side.wait_stream(torch.cuda.current_stream(dev))
+        e.all_reduce_mean_(probe)                                # the step's stream
+        with torch.cuda.stream(side):
+            e.all_to_all(send, recv)                             # the loader's stream: chained behind the all-reduce by the library
+        e.all_reduce_mean_(probe)                                # ... and this one behind the all-to-all
+        torch.cuda.current_stream(dev).wait_stream(side)
         torch.cuda.synchronize()
-        ok = int(bool(torch.allclose(probe, torch.full_like(probe, (world + 1) / 2.0), rtol=1e-6, atol=0)))
+        want_recv = (1000 * (torch.arange(world * 256, device=dev, dtype=torch.int32) // 256) + rank)
+        good = torch.allclose(probe, torch.full_like(probe, (world + 1) / 2.0), rtol=1e-6, atol=0) and torch.equal(recv, want_recv)
+        return int(bool(good) and (world == 1 or e.stats()["chained"] >= 2))
+
+    try:
+        ok = _run_with_deadline(build_and_probe, deadline, "the native RCCL exchange's construction and probe", rank)
     except Exception as e:                                   # noqa: BLE001 -- any failure means: the host-driven exchange
         import sys
         print(f"[p_companion_amd] rank {rank}: native RCCL exchange unavailable ({e}); using torch.distributed", file=sys.stderr, flush=True)
         ok = 0
+    ex = holder.get("ex")
     flag = torch.tensor([ok], dtype=torch.int32, device=dev if backend == "nccl" else "cpu")
     dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=group)
     if int(flag.item()) == 1:
         ex.register = lambda t: None
+        ex.native = True
         return ex
+    if ex is not None:                                       # built here, failed elsewhere (or its probe failed): not left behind
+        try:
+            ex.close()
+        except Exception:                                    # noqa: BLE001
+            pass
     if kind == "rccl":
         raise RuntimeError("make_exchange(kind='rccl'): the native exchange failed its check on some rank")
     return callback()
@@ -125,7 +211,9 @@ class ShardedFeatureTable:
       1. pc_shard_bucket: the batch's id arrays -> per-owner request lists send_ids[G][C] (fixed capacity C, unused
          slots -1) and the batch's indices over the [G][C][D] buffer the exchange will return;
       2. all_to_all of the request lists (C int32 per peer), owner-side HIP row gather, all_to_all of the rows
-         (C x D fp32 per peer);
+         (C x D fp32 per peer) -- pc_rccl_alltoall on the library's communicator when `exchange` is the native
+         RcclExchange (the same communicator as the gradient all-reduce: one cross-rank launch order per step),
+         torch.distributed.all_to_all_single otherwise;
       3. the fused step runs unchanged over that buffer.  The table is frozen (p_companion.py:26-29,
          synthetic_data.py:50-58): no backward exchange.
     The unique-neighbour layout already carries every distinct neighbour product once; the remaining ids (anchors,
@@ -139,9 +227,13 @@ class ShardedFeatureTable:
     `gather_fn(local_table, idx_int32)` / `bucket_fn(...)`: the owner-side row gather and the bucketing -- the HIP
     kernels on the GPU; the CPU tests inject their own (test infrastructure only -- the product never falls back)."""
 
-    def __init__(self, local_rows, num_products, rank, world, gather_fn=None, group=None, capacity=None, bucket_fn=None):
+    def __init__(self, local_rows, num_products, rank, world, gather_fn=None, group=None, capacity=None, bucket_fn=None,
+                 exchange=None):
         self.local = local_rows
         self.P, self.rank, self.world, self.group = int(num_products), rank, world, group
+        # the two lookup rounds go where the step's gradient exchange goes (make_exchange: ONE communicator per step); without
+        # an exchange object they are torch.distributed's all_to_all_single (the all-torch form: bench.py --exchange hook)
+        self.collectives = exchange if exchange is not None else _TorchCollectives(group)
         if gather_fn is None:
             from . import ops
             gather_fn = ops.gather_rows
@@ -202,13 +294,13 @@ class ShardedFeatureTable:
                               bufs["counts"], bufs["send_ids"], bufs["overflow"])
         req = torch.empty_like(bufs["send_ids"])
         if collectives_on(G):
-            dist.all_to_all_single(req, bufs["send_ids"], group=self.group)       # equal splits: C int32 per peer
+            self.collectives.all_to_all(bufs["send_ids"], req)                    # equal splits: C int32 per peer
         else:
             req.copy_(bufs["send_ids"])
         rows_out = self.gather_fn(self.local, req)                                # -1 -> zero row
         tab = torch.empty_like(rows_out)
         if collectives_on(G):
-            dist.all_to_all_single(tab, rows_out, group=self.group)               # C x D fp32 per peer
+            self.collectives.all_to_all(rows_out, tab)                            # C x D fp32 per peer
         else:
             tab = rows_out
         out = {"anchor_idx": outs[0], "positive_idx": outs[2], "negative_idx": outs[3].view(B, K),

@@ -325,7 +325,10 @@ def rccl_available():
 
 
 class RcclExchange(Exchange):
-    """ncclAllReduce(ncclAvg) on the library's own RCCL communicator (pc_rccl_*).  One rank draws the unique id
+    """The library's own RCCL communicator (pc_rccl_*): ncclAllReduce(ncclAvg) behind the exchange slot, plus the step's
+    other collectives -- all_to_all (the row-sharded table's two lookup rounds) and all_reduce_sum_f64_ (cross-replica
+    BatchNorm sums) -- so that everything a step exchanges runs on ONE communicator, chained inside the library when two of
+    them sit on different streams (include/pcompanion_hip.h, "ORDER").  One rank draws the unique id
     (RcclExchange.unique_id()), every rank constructs with the same 128 bytes -- a collective (ncclCommInitRank) on the
     current device."""
 
@@ -351,6 +354,29 @@ class RcclExchange(Exchange):
             torch.cuda.synchronize()
             check(_lib.lib().pc_rccl_comm_destroy(self.ctx), "pc_rccl_comm_destroy")
             self.ctx = None
+
+    def all_to_all(self, send, recv):
+        """pc_rccl_alltoall on the current stream: equal splits, peer p's slice of `send` lands in peer p's `recv` at this
+        rank's slot.  Any dtype; both contiguous device tensors of the same byte size, a multiple of the world size."""
+        nbytes = send.numel() * send.element_size()
+        if not (send.is_cuda and recv.is_cuda and send.is_contiguous() and recv.is_contiguous()):
+            raise ValueError("all_to_all: contiguous device tensors")
+        if recv.numel() * recv.element_size() != nbytes or nbytes % self.world or send.data_ptr() == recv.data_ptr():
+            raise ValueError("all_to_all: send / recv of equal size (a multiple of the world size), not aliased")
+        check(_lib.lib().pc_rccl_alltoall(self.ctx, _p(send), _p(recv), nbytes // self.world, _stream()), "pc_rccl_alltoall")
+        return recv
+
+    def all_reduce_sum_f64_(self, t):
+        """pc_rccl_allreduce_sum_f64 on the current stream (cross-replica BatchNorm: ops.p2v_train_step(sync_reduce=...))."""
+        _req(t, torch.float64, "buf")
+        check(_lib.lib().pc_rccl_allreduce_sum_f64(self.ctx, _p(t), t.numel(), _stream()), "pc_rccl_allreduce_sum_f64")
+        return t
+
+    def stats(self):
+        """{collectives issued on the communicator, cross-stream waits the library inserted between them}."""
+        a, b = ctypes.c_int64(0), ctypes.c_int64(0)
+        check(_lib.lib().pc_rccl_comm_stats(self.ctx, ctypes.byref(a), ctypes.byref(b)), "pc_rccl_comm_stats")
+        return {"issued": int(a.value), "chained": int(b.value)}
 
 
 class CallbackExchange(Exchange):

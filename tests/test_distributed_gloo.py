@@ -179,3 +179,81 @@ def test_type_table_row_list_exchange_world2_equals_the_concatenated_batch():
     for p in procs:
         p.join(30)
     assert res == {0: True, 1: True}
+
+
+# ------------------------------------------------------------------ ONE communicator, one launch order per step
+def _order_worker(rank, world, port, q):
+    """A step's three collectives (two lookup rounds on the loader's side, the gradient exchange on the step's) all go through
+    the ONE object make_exchange returned: every rank issues the same sequence of calls."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    from p_companion_amd import distributed as pdist
+    pdist.init_from_env("cpu")
+    ex = pdist.make_exchange(world, rank=rank, kind="auto")          # gloo: torch.distributed behind the slot AND behind the lookups
+    ok = not ex.native and callable(ex.all_to_all) and callable(ex.all_reduce_sum_f64_)
+    calls = []
+    a2a, ar = ex.all_to_all, ex.all_reduce_sum_f64_
+    ex.all_to_all = lambda s, r: (calls.append(("a2a", s.numel() * s.element_size())), a2a(s, r))[1]
+    ex.all_reduce_sum_f64_ = lambda t: (calls.append(("sum64", t.numel())), ar(t))[1]
+    g = torch.Generator().manual_seed(0)
+    full = torch.randn(1000, 16, generator=g)
+    tab = pdist.ShardedFeatureTable(pdist.ShardedFeatureTable.shard(full, rank, world), 1000, rank, world,
+                                    gather_fn=lambda t, i: torch.cat([t, torch.zeros(1, 16)])[i.long()], bucket_fn=_cpu_bucket, exchange=ex)
+    wantf = torch.cat([full, torch.zeros(1, 16)])
+    for step in range(3):
+        gb = torch.Generator().manual_seed(300 + 10 * step + rank)
+        B, K = 8, 5
+        nb = torch.sort(torch.randperm(1000, generator=gb)[:20]).values.to(torch.int32)
+        batch = {"anchor_idx": torch.randint(0, 1000, (B,), generator=gb, dtype=torch.int32),
+                 "positive_idx": torch.randint(0, 1000, (B,), generator=gb, dtype=torch.int32),
+                 "negative_idx": torch.randint(0, 1000, (B, K), generator=gb, dtype=torch.int32),
+                 "neighbor_compact": {"nb_rows": torch.cat([nb, torch.tensor([-1], dtype=torch.int32)]), "weight": torch.ones(21),
+                                      "slot_row": torch.zeros(B, 4, dtype=torch.int32), "n_unique": 20,
+                                      "n_unique_dev": torch.tensor([20], dtype=torch.int32)}}
+        rows, rb = tab.lookup_batch(batch)
+        ext = torch.cat([rows, torch.zeros(1, 16)])
+        ok = ok and torch.equal(ext[rb["anchor_idx"].long()], wantf[batch["anchor_idx"].long()])
+        stats = torch.full((6,), float(rank + 1), dtype=torch.float64)
+        ex.all_reduce_sum_f64_(stats)                                 # (cross-replica BatchNorm sums of the step)
+        ok = ok and torch.equal(stats, torch.full((6,), 3.0, dtype=torch.float64))
+        grad = torch.full((10,), float(rank + 1))
+        ex.register(grad)
+        ex.all_reduce_mean_ = None                                   # (the slot itself is driven through pc_exchange_adam on the GPU)
+        pdist.all_reduce_mean_(grad, world)
+        ok = ok and torch.allclose(grad, torch.full((10,), 1.5))
+    seqs = [None] * world
+    dist.all_gather_object(seqs, calls)
+    ok = ok and seqs[0] == seqs[1] and [c[0] for c in calls] == ["a2a", "a2a", "sum64"] * 3
+    q.put((rank, bool(ok)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(180)
+def test_one_exchange_object_carries_every_collective_of_a_step_world2():
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_order_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=150) for _ in range(world))
+    for p in procs:
+        p.join(30)
+    assert res == {0: True, 1: True}
+
+
+def test_rendezvous_deadline_ends_the_process():
+    """make_exchange's construction and probe run under a host deadline: a rank whose peer never joins leaves with exit code 75
+    (the launcher then ends the job) instead of sitting in the rendezvous; exceptions inside are re-raised to the caller."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = ("import time; from p_companion_amd.distributed import _run_with_deadline as r; "
+            "r(lambda: time.sleep(30), 0.5, 'test rendezvous', 0); print('returned')")
+    out = subprocess.run([sys.executable, "-c", code], cwd=root, capture_output=True, text=True, timeout=60)
+    assert out.returncode == 75 and "returned" not in out.stdout and "did not return" in out.stderr
+    from p_companion_amd.distributed import _run_with_deadline
+    assert _run_with_deadline(lambda: 41 + 1, 5.0, "quick", 0) == 42
+    with pytest.raises(KeyError):
+        _run_with_deadline(lambda: {}["x"], 5.0, "raises", 0)

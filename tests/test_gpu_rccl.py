@@ -99,3 +99,74 @@ def test_lookup_and_row_list_exchange_over_rccl():
     out = subprocess.run([sys.executable, "-c", "import tests.test_gpu_rccl as t; t._worker_exchanges()"], env=_env(),
                          capture_output=True, text=True, timeout=300, cwd=ROOT)
     assert out.returncode == 0 and "exchanges ok" in out.stdout, out.stderr[-3000:]
+
+
+def _worker_native_collectives():
+    """(subprocess body) the library's own communicator on one rank: pc_rccl_alltoall / pc_rccl_allreduce_sum_f64 / the
+    cross-stream chain, and the sharded lookup with BOTH rounds on that communicator."""
+    import torch.distributed as dist
+    from p_companion_amd import distributed as pdist, ops
+    rank, world, local = pdist.init_from_env("cuda")
+    dev = torch.device("cuda", local)
+    ex = pdist.make_exchange(world, rank=rank, kind="rccl", device=dev)
+    assert ex.native and ex.kind.startswith("rccl")
+    base = ex.stats()
+    assert base["issued"] == 3 and base["chained"] == 2          # the probe: all-reduce | all-to-all on a side stream | all-reduce
+    # all-to-all of every dtype the lookup sends (int32 request lists, fp32 rows); one rank: the slice comes back
+    send_i = torch.arange(1000, dtype=torch.int32, device=dev)
+    recv_i = torch.full_like(send_i, -7)
+    ex.all_to_all(send_i, recv_i)
+    send_f = torch.randn(300, 128, device=dev)
+    recv_f = torch.zeros_like(send_f)
+    ex.all_to_all(send_f, recv_f)
+    d = torch.arange(ops.BN_SYNC_DOUBLES, dtype=torch.float64, device=dev) * 0.5
+    ex.all_reduce_sum_f64_(d)
+    torch.cuda.synchronize()
+    assert torch.equal(recv_i, send_i) and torch.equal(recv_f, send_f)
+    assert torch.equal(d, torch.arange(ops.BN_SYNC_DOUBLES, dtype=torch.float64, device=dev) * 0.5)
+    s1 = ex.stats()
+    assert s1["issued"] == base["issued"] + 3 and s1["chained"] == base["chained"]      # one stream: stream order is the chain
+    import pytest as _pt
+    with _pt.raises(ValueError):
+        ex.all_to_all(send_i, send_i)                            # aliased
+    # two streams, alternating: every change of stream is chained (a wait on an event at the other stream's tail)
+    side = torch.cuda.Stream(dev)
+    g = torch.ones(4096, device=dev)
+    for i in range(4):
+        with torch.cuda.stream(side):
+            ex.all_to_all(send_f, recv_f)
+        ex.all_reduce_mean_(g)
+    torch.cuda.synchronize()
+    s2 = ex.stats()
+    assert s2["issued"] == s1["issued"] + 8 and s2["chained"] == s1["chained"] + 8
+    assert torch.equal(g, torch.ones_like(g))
+    # the sharded lookup with its two rounds on the library's communicator == the same lookup on torch's
+    gen = torch.Generator().manual_seed(0)
+    table = torch.randn(5000, 128, generator=gen).to(dev)
+    B, K = 64, 5
+    nb = torch.randint(-1, 5000, (B, 9), generator=gen, dtype=torch.int32).to(dev)
+    batch = {"anchor_idx": torch.randint(0, 5000, (B,), generator=gen, dtype=torch.int32).to(dev),
+             "positive_idx": torch.randint(0, 5000, (B,), generator=gen, dtype=torch.int32).to(dev),
+             "negative_idx": torch.randint(0, 5000, (B, K), generator=gen, dtype=torch.int32).to(dev),
+             "neighbor_compact": ops.unique_neighbors(nb)}
+    outs = []
+    for exch in (ex, None):
+        sh = pdist.ShardedFeatureTable(table, 5000, 0, 1, exchange=exch)
+        tab, rb = sh.lookup_batch(batch)
+        assert sh.overflowed() == 0
+        outs.append((tab.clone(), {k: (v.clone() if torch.is_tensor(v) else v) for k, v in rb.items() if k != "neighbor_compact"},
+                     rb["neighbor_compact"]["nb_rows"].clone()))
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][2], outs[1][2])
+    for k in ("anchor_idx", "positive_idx", "negative_idx"):
+        assert torch.equal(outs[0][1][k], outs[1][1][k])
+        assert torch.equal(outs[0][0][outs[0][1][k].long()], table[batch[k].long()])
+    assert ex.stats()["issued"] == s2["issued"] + 2              # both rounds went through the library's communicator
+    ex.close()
+    dist.destroy_process_group()
+    print("native collectives ok")
+
+
+def test_library_alltoall_and_the_cross_stream_chain_over_rccl():
+    out = subprocess.run([sys.executable, "-c", "import tests.test_gpu_rccl as t; t._worker_native_collectives()"], env=_env(),
+                         capture_output=True, text=True, timeout=300, cwd=ROOT)
+    assert out.returncode == 0 and "native collectives ok" in out.stdout, out.stderr[-3000:]
