@@ -7,6 +7,13 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libpcompanion_hip.so")
+# Developer A/B runs (scripts/dev/ab_*.sh) point PC_DEV_LIB at another BUILD of the same library instead of copying it over the
+# product file (a copied-over .so looks up to date to build.py and would silently become what tests and bench.py run).  Said
+# out loud on stderr; never set by the tests, bench.py or the driver.
+if os.environ.get("PC_DEV_LIB"):
+    import sys as _sys
+    LIB_PATH = os.path.abspath(os.environ["PC_DEV_LIB"])
+    print(f"[p_companion_amd] PC_DEV_LIB: loading {LIB_PATH} instead of the in-tree library (developer A/B run)", file=_sys.stderr, flush=True)
 
 c_f32p = ctypes.c_void_p
 c_i32p = ctypes.c_void_p

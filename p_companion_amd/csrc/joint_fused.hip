@@ -1756,10 +1756,199 @@ __global__ __launch_bounds__(256) void table_reduce_kernel(TableList l0, TableLi
     if (g == 0) *reinterpret_cast<float4*>(l.table + (size_t)ulist[u] * PC_L + (j4 % (PC_L / 4)) * 4) = s;
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Large tables, DETERMINISTIC gradients at ANY number of touched rows (round 5; replaces the LDS-table form above -- 512 distinct
+// rows at most -- and its float-atomic branch wherever a list fits this kernel: T <= 65535 and <= TS_MAXN source rows, i.e.
+// B = 4096 at K <= 4 with the reference's NUM_TYPES = 34800, config.py:27):
+//   table_sort_kernel     one 1024-thread workgroup per list: a STABLE two-pass LSD radix sort (8 bits each) of the source rows
+//                         by destination row, in LDS -- rows of one destination stay in source order; then the distinct
+//                         destinations (ascending: the touched-row list of pc_joint_fused_touched) and where each one's run of
+//                         source rows starts
+//   table_segsum_kernel   one wave per destination: its source rows added IN SOURCE ORDER (eight rows in flight), written to
+//                         the (cleared) dense gradient; a run longer than TS_LONG rows is cut into four contiguous quarters,
+//                         one per wave of the workgroup, folded (w0 + w1) + (w2 + w3)
+// The order of every sum is a function of the index lists alone: bitwise reproducible whatever the number of touched rows --
+// with DROPOUT = 0.1 (config.py:12) every sample selects its own K types and the complementary table has thousands.
+// Ranking inside a wave: the lanes holding one digit find each other with eight ballots (one per digit bit); rank = the number
+// of lower lanes among them.  A wave owns a CONTIGUOUS block of the sequence and walks it in order, so (earlier waves' count)
+// + (this wave's earlier batches) + rank is the element's stable position among its digit.
+#define TS_MAXN 24576       /* source rows per list: 4 n bytes of LDS for the two 16-bit index arrays */
+#define TS_EPT (TS_MAXN / 1024)
+#define TS_LONG 256
+struct SortList { const int32_t* idx; int n; int32_t *sorted, *seg, *ulist; };   // sorted [n], seg [cap + 1], ulist [cap]: cap = min(n, T)
+
+__device__ __forceinline__ void ts_match8(unsigned dig, bool valid, int lane, unsigned& rank, unsigned& cnt) {
+    unsigned long long m = __ballot(valid);
+#pragma unroll
+    for (int b = 0; b < 8; b++) {
+        const bool bit = (dig >> b) & 1u;
+        const unsigned long long bal = __ballot(bit && valid);
+        m &= bit ? bal : ~bal;
+    }
+    rank = (unsigned)__popcll(m & ((1ull << lane) - 1ull));
+    cnt = (unsigned)__popcll(m);
+}
+
+__global__ __launch_bounds__(1024) void table_sort_kernel(SortList l0, SortList l1, int T, int32_t* n_touch) {
+    extern __shared__ unsigned ts_lds[];
+    const SortList& l = blockIdx.x ? l1 : l0;
+    const int n = l.n;
+    const int nb = (n + 1023) >> 10;                         // 64-element batches per wave (<= TS_EPT)
+    const int npad = nb << 10;
+    unsigned short* A = reinterpret_cast<unsigned short*>(ts_lds);      // [npad] source rows after pass 1
+    unsigned short* Bs = A + npad;                                       // [npad] ... after pass 2
+    volatile unsigned* hist = reinterpret_cast<volatile unsigned*>(Bs + npad);   // [16][256]
+    unsigned* dbase = const_cast<unsigned*>(hist) + 16 * 256;            // [256]
+    unsigned* part = dbase + 256;                                        // [16] scan scratch
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int e0 = w * (nb << 6) + lane;                     // the wave's contiguous block: element e0 + 64 j of batch j
+
+    unsigned key[TS_EPT];                                    // (destination << 16) | source row; destination 0xFFFF = none
+    unsigned loc[TS_EPT];
+    // one pass: elements `key` (this lane's, in sequence order), digit = (key >> shift) & 255; out[position] = source row
+    auto pass = [&](int shift, unsigned short* out) {
+#pragma unroll
+        for (int q = 0; q < 4; q++) hist[w * 256 + lane + 64 * q] = 0u;      // (the wave's own row: in order with its reads below)
+#pragma unroll
+        for (int j = 0; j < TS_EPT; j++) {
+            if (j >= nb) break;                              // workgroup-uniform
+            const bool valid = e0 + 64 * j < n;
+            const unsigned dig = (key[j] >> shift) & 255u;
+            unsigned rank, cnt;
+            ts_match8(dig, valid, lane, rank, cnt);
+            const unsigned prev = valid ? hist[w * 256 + dig] : 0u;       // this wave's earlier batches
+            loc[j] = prev + rank;
+            if (valid && rank == 0u) hist[w * 256 + dig] = prev + cnt;      // (one lane per digit; LDS operations of a wave stay in order)
+        }
+        __syncthreads();
+        unsigned tot = 0u;
+        if (tid < 256) {                                     // digit tid: exclusive prefix over the waves, and its total
+#pragma unroll
+            for (int ww = 0; ww < 16; ww++) { const unsigned c = hist[ww * 256 + tid]; hist[ww * 256 + tid] = tot; tot += c; }
+        }
+        const unsigned incl = (unsigned)block_scan_1024((int)tot, part);
+        if (tid < 256) dbase[tid] = incl - tot;
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < TS_EPT; j++) {
+            if (j >= nb) break;
+            if (e0 + 64 * j < n) {
+                const unsigned dig = (key[j] >> shift) & 255u;
+                out[dbase[dig] + hist[w * 256 + dig] + loc[j]] = (unsigned short)(key[j] & 0xffffu);
+            }
+        }
+        __syncthreads();
+    };
+
+    // pass 1: the sequence is the list itself
+#pragma unroll
+    for (int j = 0; j < TS_EPT; j++) {
+        const int e = e0 + 64 * j;
+        int d = (j < nb && e < n) ? l.idx[e] : -1;
+        if ((unsigned)d >= (unsigned)T) d = 0xffff;          // no destination: sorts behind every row of the table (T <= 65535)
+        key[j] = ((unsigned)d << 16) | (unsigned)(e & 0xffff);
+    }
+    pass(16, A);
+    // pass 2: the sequence is A; the destination of a row is fetched again (every request of the lane in flight together)
+#pragma unroll
+    for (int j = 0; j < TS_EPT; j++) {
+        const int e = e0 + 64 * j;
+        const unsigned r = (j < nb && e < n) ? A[e] : 0u;
+        int d = (j < nb && e < n) ? l.idx[r] : -1;
+        if ((unsigned)d >= (unsigned)T) d = 0xffff;
+        key[j] = ((unsigned)d << 16) | r;
+    }
+    pass(24, Bs);
+    // distinct destinations and the start of each one's run: thread t looks at positions [t nb, t nb + nb)
+    const int i0 = tid * nb;
+    int dprev = -2;
+    if (i0 > 0 && i0 - 1 < n) { const int d = l.idx[Bs[i0 - 1]]; dprev = (unsigned)d < (unsigned)T ? d : -1; }
+    int dd[TS_EPT];
+#pragma unroll
+    for (int j = 0; j < TS_EPT; j++) {
+        const int i = i0 + j;
+        dd[j] = -1;
+        if (j < nb && i < n) { const int d = l.idx[Bs[i]]; dd[j] = (unsigned)d < (unsigned)T ? d : -1; }
+    }
+    int packed = 0;                                          // low half: run starts, high half: rows with a destination
+    {
+        int pv = dprev;
+#pragma unroll
+        for (int j = 0; j < TS_EPT; j++) {
+            if (j < nb && dd[j] >= 0) packed += 0x10000 + (dd[j] != pv ? 1 : 0);
+            pv = dd[j];
+        }
+    }
+    const int incl = block_scan_1024(packed, part);
+    int pos = (incl - packed) & 0xffff;
+    {
+        int pv = dprev;
+#pragma unroll
+        for (int j = 0; j < TS_EPT; j++) {
+            const int i = i0 + j;
+            if (j < nb && i < n) {
+                l.sorted[i] = (int)Bs[i];
+                if (dd[j] >= 0 && dd[j] != pv) { l.ulist[pos] = dd[j]; l.seg[pos] = i; pos++; }
+            }
+            pv = dd[j];
+        }
+    }
+    if (tid == 1023) {
+        const int nu = incl & 0xffff;
+        n_touch[blockIdx.x] = nu;
+        l.seg[nu] = incl >> 16;                              // rows with a destination: they are the head of the sorted sequence
+    }
+}
+static size_t table_sort_lds_bytes(int n) {
+    const size_t npad = (size_t)((n + 1023) >> 10) << 10;
+    return npad * 4 + (16 * 256 + 256 + 16) * 4;
+}
+
+struct SegList { float* table; const float* src; const int32_t *sorted, *seg, *ulist; };
+__device__ __forceinline__ float ts_run_sum(const float* src, const int32_t* sorted, int b, int e, int lane) {
+    float acc = 0.f;
+    for (int i = b; i < e; i += 8) {
+        float v[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) v[u] = i + u < e ? src[(size_t)sorted[i + u] * PC_L + lane] : 0.f;
+#pragma unroll
+        for (int u = 0; u < 8; u++) acc += v[u];             // source order
+    }
+    return acc;
+}
+__global__ __launch_bounds__(256) void table_segsum_kernel(SegList l0, SegList l1, const int32_t* n_touch, int wgs0) {
+    __shared__ float fold[4][PC_L];
+    const int li = (int)blockIdx.x >= wgs0 ? 1 : 0;
+    const SegList& l = li ? l1 : l0;
+    const int s0 = ((int)blockIdx.x - li * wgs0) * 4;
+    const int nu = n_touch[li];
+    if (s0 >= nu) return;                                    // workgroup-uniform
+    const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int s = s0 + w;
+    if (s < nu) {
+        const int b = __builtin_amdgcn_readfirstlane(l.seg[s]), e = __builtin_amdgcn_readfirstlane(l.seg[s + 1]);
+        if (e - b <= TS_LONG) l.table[(size_t)l.ulist[s] * PC_L + lane] = ts_run_sum(l.src, l.sorted, b, e, lane);
+    }
+    for (int q = 0; q < 4; q++) {                            // the long runs, one after the other, four waves each
+        const int sq = s0 + q;
+        if (sq >= nu) break;
+        const int b = __builtin_amdgcn_readfirstlane(l.seg[sq]), e = __builtin_amdgcn_readfirstlane(l.seg[sq + 1]);
+        if (e - b <= TS_LONG) continue;                      // (workgroup-uniform: every wave reads the same two words)
+        const int per = (e - b + 3) >> 2;
+        const int mb = b + w * per, me = min(e, mb + per);
+        fold[w][lane] = ts_run_sum(l.src, l.sorted, mb, me, lane);
+        __syncthreads();
+        if (w == 0) l.table[(size_t)l.ulist[sq] * PC_L + lane] = (fold[0][lane] + fold[1][lane]) + (fold[2][lane] + fold[3][lane]);
+        __syncthreads();
+    }
+}
+
 struct FusedWs {
     float *part, *h, *dpi, *dtp, *dc, *dh, *dt, *ecsrc;
     int32_t *ecidx, *cids, *ulist, *n_u, *topk_by_type;
     int32_t *tl_c, *tp_c, *tl_q, *tp_q, *n_touch;       // touched rows of the two big tables: ascending lists, row -> list position
+    int32_t *srt_c, *srt_q, *seg_c, *seg_q;             // sort path: source rows ordered by destination, start of each destination's run
+    bool sorted_path;
     float *tslab_c, *tslab_q;                           // [TG_WGS][TG_CAP][64] each
     float* part_val;
     float *csamp, *gmat, *g0, *gnmax;                           // large tables with hidden-layer dropout: hd [B][32], G = E_c dec_w [T][32], g0 = E_c dec_b [T]
@@ -1795,6 +1984,8 @@ static FusedWs fused_ws_layout(void* base, int B, int T, int K) {
     w.ulist = w.n_u = w.topk_by_type = nullptr;
     w.tl_c = w.tp_c = w.tl_q = w.tp_q = w.n_touch = nullptr;
     w.tslab_c = w.tslab_q = nullptr;
+    w.srt_c = w.srt_q = w.seg_c = w.seg_q = nullptr;
+    w.sorted_path = false;
     w.part_val = nullptr;
     w.csamp = w.gmat = w.g0 = w.gnmax = nullptr;
     if (w.small) {
@@ -1805,8 +1996,16 @@ static FusedWs fused_ws_layout(void* base, int B, int T, int K) {
         w.tl_q = (int32_t*)take((size_t)(B < T ? B : T) * 4);
         w.tp_q = (int32_t*)take((size_t)T * 4);
         w.n_touch = (int32_t*)take(256);
-        w.tslab_c = (float*)take((size_t)TG_WGS * TG_CAP * PC_L * 4);
-        w.tslab_q = (float*)take((size_t)TG_WGS * TG_CAP * PC_L * 4);
+        w.sorted_path = T <= 65535 && nc <= TS_MAXN;
+        if (w.sorted_path) {
+            w.srt_c = (int32_t*)take((size_t)nc * 4);
+            w.srt_q = (int32_t*)take((size_t)B * 4);
+            w.seg_c = (int32_t*)take((size_t)((nc < T ? nc : T) + 1) * 4);
+            w.seg_q = (int32_t*)take((size_t)((B < T ? B : T) + 1) * 4);
+        } else {
+            w.tslab_c = (float*)take((size_t)TG_WGS * TG_CAP * PC_L * 4);
+            w.tslab_q = (float*)take((size_t)TG_WGS * TG_CAP * PC_L * 4);
+        }
         w.nchunks_s = (T + PC_STC - 1) / PC_STC;
         w.ucap = B < T ? B : T;
         w.ulist = (int32_t*)take((size_t)w.ucap * 4);
@@ -1996,8 +2195,21 @@ static int fused_step_impl(const pc_joint_tensors* p, const pc_joint_tensors* g,
         else PC_LAUNCH((joint_wgrad_kernel<16, 0>), dim3(w.wg_blocks), dim3(512), wl, st, wa);
         PC_TRY(pc_launch_status());
     }
-    if (!w.small) {
-        // table gradients: fixed-order sums over the touched rows (no float atomics while a table has <= TG_CAP touched rows)
+    if (!w.small && w.sorted_path) {
+        // table gradients: source rows sorted by destination (stable), then one wave per destination adds its run in source order
+        const int nc = B * (K + 2), cap_c = nc < T ? nc : T, cap_q = B < T ? B : T;
+        const SortList sc = {w.ecidx, nc, w.srt_c, w.seg_c, w.tl_c}, sq = {w.cids + B, B, w.srt_q, w.seg_q, w.tl_q};
+        static const hipError_t sattr = hipFuncSetAttribute(reinterpret_cast<const void*>(&table_sort_kernel),
+                                                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)sattr;
+        PC_LAUNCH(table_sort_kernel, dim3(2), dim3(1024), table_sort_lds_bytes(nc), st, sc, sq, T, w.n_touch);
+        const SegList gc = {g->comp_types, w.ecsrc, w.srt_c, w.seg_c, w.tl_c}, gq = {g->query_types, w.dt, w.srt_q, w.seg_q, w.tl_q};
+        const int wgs_c = (cap_c + 3) / 4, wgs_q = (cap_q + 3) / 4;
+        PC_LAUNCH(table_segsum_kernel, dim3(wgs_c + wgs_q), dim3(256), 0, st, gc, gq, w.n_touch, wgs_c);
+        PC_TRY(pc_launch_status());
+    } else if (!w.small) {
+        // (lists too long for the sort kernel's LDS, or T > 65535) fixed-order sums over the touched rows while a table has <= TG_CAP
+        // of them, float atomics beyond
         const int words = (T + 31) / 32;
         PC_LAUNCH(touched_types_kernel, dim3(2), dim3(1024), (size_t)(words + 1024) * 4, st, w.ecidx, B * (K + 2), w.cids + B, B, T,
                   w.tl_c, w.tp_c, w.tl_q, w.tp_q, w.n_touch);

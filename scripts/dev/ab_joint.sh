@@ -6,12 +6,10 @@ R=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$R/gpurun_out/$TAG; mkdir -p $OUT
 for i in $(seq 1 $ROUNDS); do
   for v in a b; do
-    cp $R/scripts/dev/ab/lib_$v.so $R/p_companion_amd/libpcompanion_hip.so
-    python3 $R/bench.py --phase joint --no-cpu-baseline --no-ref-types --no-dropout-legs "$@" > $OUT/${v}_$i.json 2> $OUT/${v}_$i.err
+    PC_DEV_LIB=$R/scripts/dev/ab/lib_$v.so python3 $R/bench.py --phase joint --no-cpu-baseline --no-ref-types --no-dropout-legs "$@" > $OUT/${v}_$i.json 2> $OUT/${v}_$i.err
     python3 -c "
 import json
 d=json.load(open('$OUT/${v}_$i.json'))
 print('$v $i', d['ms_per_step'], d['roofline']['device_ms_per_step'], d['config']['final_loss'], flush=True)"
   done
 done
-cp $R/scripts/dev/ab/lib_a.so $R/p_companion_amd/libpcompanion_hip.so
