@@ -77,11 +77,12 @@ def committed_pmc(kind, match):
     """HBM bytes per launch of the kernels whose name `match` accepts, from the newest committed rocprofv3 --pmc passes of
     the SAME workload (profiles/<round tag>[_<kind>]_pmc_traffic.json: FETCH_SIZE and WRITE_SIZE in separate passes,
     KiB -> bytes, FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950).  kind: "" = configs[1] (100 k products),
-    "joint" / "joint34800" / "joint34800d" = the joint step at T = 100 / 34800 / 34800 with DROPOUT = 0.1, "cfg3" = 10 M products through the sharded lookup, "big" =
+    "joint" / "jointd" / "joint34800" / "joint34800d" = the joint step at T = 100 / 100 with DROPOUT = 0.1 / 34800 / 34800 with DROPOUT = 0.1,
+    "p2vd" = configs[1] with DROPOUT = 0.1, "cfg3" = 10 M products through the sharded lookup, "big" =
     configs[4] (100 M x 256, Zipf).  None if no profile of that kind is committed (PMC counters cannot be collected from
     inside the bench process) -- a leg never borrows another workload's traffic."""
     import re
-    pat = re.compile(r"^(r\d+[a-z0-9]*)_(?:(joint34800d|joint34800|joint|big|cfg3)_)?pmc_traffic\.json$")
+    pat = re.compile(r"^(r\d+[a-z0-9]*)_(?:(joint34800d|joint34800|jointd|joint|p2vd|big|cfg3)_)?pmc_traffic\.json$")
     files = []
     for f in sorted(os.listdir(os.path.join(ROOT, "profiles"))) if os.path.isdir(os.path.join(ROOT, "profiles")) else []:
         m = pat.match(f)
@@ -109,7 +110,7 @@ def two_roof(flops, nbytes, seconds, peak_tflops):
 
 
 # ----------------------------------------------------------------------------------------------- CPU legs
-def p2v_cpu_baseline(bpg, batch, min_steps=20, max_seconds=100.0):
+def p2v_cpu_baseline(bpg, batch, min_steps=20, max_seconds=100.0, dropout=0.0):
     """The oracle (CPU restatement pinned to the reference's golden vectors) timed on this box's host cores: same
     workload shape, fwd+bwd+Adam.  compute-only: one pre-gathered dense batch, >= 20 steps; end to end: the host
     loader in parity mode (exact CPython negative sampler + CSR neighbour rows) + the dense gather of
@@ -124,15 +125,25 @@ def p2v_cpu_baseline(bpg, batch, min_steps=20, max_seconds=100.0):
                                     batch["negative_idx"].cpu().numpy(), nb_dense)
     mom = p2v_oracle.new_moments(st)
     b = dense["anchor"].shape[0]
-    p2v_oracle.train_step(st, dense, 1.0, mom, 1)            # warm-up
+    # DROPOUT > 0 (nn.MultiheadAttention(dropout=p), product2vec.py:23-28): the probabilities' mask is an explicit input of the
+    # oracle; a mask of the leg's keep probability and scale, drawn once (the work does not depend on which elements it drops)
+    amask = None
+    if dropout > 0.0:
+        g = torch.Generator().manual_seed(0)
+        amask = torch.bernoulli(torch.full((b, 4, dense["anchor_neighbors"].shape[1]), 1.0 - dropout), generator=g) / (1.0 - dropout)
+    p2v_oracle.train_step(st, dense, 1.0, mom, 1, attn_mask=amask)            # warm-up
     t0 = time.perf_counter()
     n = 0
     while n < min_steps:
-        p2v_oracle.train_step(st, dense, 1.0, mom, n + 2)
+        p2v_oracle.train_step(st, dense, 1.0, mom, n + 2, attn_mask=amask)
         n += 1
         if time.perf_counter() - t0 > max_seconds:
             break
     el = time.perf_counter() - t0
+    if dropout > 0.0:                                        # (the secondary legs report the compute-only figure)
+        return {"value": b * n / el, "unit": "triplets/s", "cores": torch.get_num_threads(), "kind": "port", "os_cpu_count": os.cpu_count(),
+                "sample": f"{n} steps of the same workload (B={b}, N={dense['anchor_neighbors'].shape[1]}, attention dropout p={dropout} as an "
+                          f"explicit mask, fwd+bwd+Adam, pre-gathered batch) on {os.cpu_count()} host cpus, torch {torch.get_num_threads()} threads"}
     # end to end: a few batches through the host loader
     ld = SimilarityIndexLoader(bpg, b, shuffle=True, sampler="cpython", seed=0, drop_last=True, device="cpu",
                                compact=False, prefetch=False, unique=False)
@@ -156,16 +167,24 @@ def p2v_cpu_baseline(bpg, batch, min_steps=20, max_seconds=100.0):
 
 
 def joint_cpu_baseline(model, batch, cfg, min_steps=20, max_seconds=40.0):
-    """oracle.joint_oracle.train_step on the same batch and the same initial state, on the host cores."""
+    """oracle.joint_oracle.train_step on the same batch and the same initial state, on the host cores.  DROPOUT > 0: the
+    hidden-layer mask is an explicit input of the oracle (nn.Dropout's stream cannot be reproduced); the timed steps use a mask of
+    the leg's keep probability and scale drawn once with torch.bernoulli -- what the oracle does with it does not depend on which
+    elements it drops."""
     from oracle import joint_oracle
     st = {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}
     hb = {k: (v.detach().cpu() if torch.is_tensor(v) else v) for k, v in batch.items()}
     mom = joint_oracle.new_moments(st)
-    joint_oracle.train_step(st, hb, mom, 1, cfg.MARGIN, cfg.ALPHA, cfg.NUM_COMP_TYPES)
+    p = float(getattr(cfg, "DROPOUT", 0.0))
+    mask = None
+    if p > 0.0:
+        g = torch.Generator().manual_seed(0)
+        mask = torch.bernoulli(torch.full((hb["query_idx"].numel(), 32), 1.0 - p), generator=g) / (1.0 - p)
+    joint_oracle.train_step(st, hb, mom, 1, cfg.MARGIN, cfg.ALPHA, cfg.NUM_COMP_TYPES, hidden_mask=mask)
     t0 = time.perf_counter()
     n = 0
     while n < min_steps:
-        joint_oracle.train_step(st, hb, mom, n + 2, cfg.MARGIN, cfg.ALPHA, cfg.NUM_COMP_TYPES)
+        joint_oracle.train_step(st, hb, mom, n + 2, cfg.MARGIN, cfg.ALPHA, cfg.NUM_COMP_TYPES, hidden_mask=mask)
         n += 1
         if time.perf_counter() - t0 > max_seconds:
             break
@@ -173,7 +192,8 @@ def joint_cpu_baseline(model, batch, cfg, min_steps=20, max_seconds=40.0):
     b = hb["query_idx"].numel()
     return {"value": b * n / el, "unit": "triplets/s", "cores": torch.get_num_threads(), "kind": "port",
             "os_cpu_count": os.cpu_count(),
-            "sample": f"{n} steps of the same batch (B={b}, T={st['query_type_embeddings.weight'].shape[0]}, forward + both "
+            "sample": f"{n} steps of the same batch (B={b}, T={st['query_type_embeddings.weight'].shape[0]}, "
+                      + (f"hidden-layer dropout p={p} as an explicit mask, " if p > 0.0 else "") + "forward + both "
                       f"hinges + autograd backward + dense Adam) on {os.cpu_count()} host cpus, torch "
                       f"{torch.get_num_threads()} threads"}
 
@@ -303,7 +323,7 @@ def run_joint(args, rank, world, dev, types, steps, warmup, want_cpu, dropout=0.
     # (the committed counter passes: DROPOUT = 0 runs of T = 100 and T = 34800, and T = 34800 with DROPOUT = 0.1 -- the reference as
     # shipped; other legs carry no traffic figure)
     pmc_kind = ("joint" if types == 100 else f"joint{types}") if dropout == 0.0 and types in (100, 34800) else \
-               "joint34800d" if abs(dropout - 0.1) < 1e-9 and types == 34800 else None
+               ("joint34800d" if types == 34800 else "jointd" if types == 100 else None) if abs(dropout - 0.1) < 1e-9 else None
     pmc = committed_pmc(pmc_kind, lambda k: k == "_step_total") if pmc_kind else None
     achieved = alg / (dev_ms * 1e-3) / 1e9
     out = {"metric": "triplets/sec (P-Companion joint step: fwd + type/item hinge + bwd + Adam)", "value": round(value, 1),
@@ -428,16 +448,14 @@ def run_p2v(args, rank, world, dev, products, steps, warmup, want_cpu, profile_k
     # HIP-event brackets around the dominant kernel family cost the stream ~5 us per bracket side (a marker packet each):
     # every PROFILE_EVERY-th step of the timed region carries them, the others run as a caller's loop does
     profiled_steps = 0
-    # (the host asks the loader for batch i + 1 right BEHIND step i's launches, not in front of step i + 1's: the loader's
-    # builders run four batches ahead on their own stream either way; what moves is ~0.1 ms of host work out of the gap
-    # between the opening synchronize and the region's first launch -- 5 us per step of a 20-step region)
-    nxt = next(it)
+    # (every loader call of the region is inside it: `steps` next() calls and `steps` train steps between the two clocks, as in a
+    # caller's loop -- round 4 took the first batch before the clock started)
     if multi:
         torch.distributed.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for i in range(steps):
-        last = nxt
+        last = next(it)
         n_sum += last["n_pad"]
         nbc_ = last["neighbor_compact"]
         real_sum += int(nbc_["n_unique"]) if "weight" in nbc_ else nbc_["nb_rows"].numel() - 1      # rows carried
@@ -446,8 +464,6 @@ def run_p2v(args, rank, world, dev, products, steps, warmup, want_cpu, profile_k
         bracket = profile_kernels and (args.profile_all or i % PROFILE_EVERY == min(PROFILE_EVERY // 2, steps - 1))
         profiled_steps += 1 if bracket else 0
         loss = step(last, profile=prof if bracket else None)
-        if i + 1 < steps:
-            nxt = next(it)
     host_ms = 1e3 * (time.perf_counter() - t0) / max(steps, 1)      # the host's time to enqueue a step (incl. its waits)
     torch.cuda.synchronize()
     if multi:
@@ -486,15 +502,23 @@ def run_p2v(args, rank, world, dev, products, steps, warmup, want_cpu, profile_k
         tfl = fl / sec / 1e12 if sec > 0 else 0.0
         gbs = alg / sec / 1e9 if sec > 0 else 0.0
         exe = executed_flops_per_step(args.batch, rows_avg + 1, dim)
+        # the contraction, not the gather, binds the Product2Vec step (1.7 kFLOP per gathered byte) -- `frac`
+        # is the matrix-core fraction of the dominant kernel family.  Beside it: the same launches against HBM with the DESIGN's own
+        # per-launch activation traffic (`frac_hbm_design`: every layer's [R,256] in and out of HBM -- which roof is nearer by that
+        # count is `nearer_roof_by_design_bytes`), and with section 8(d)'s bytes -- the gathered rows, 512 (N + 7) B per triplet, the
+        # only bytes the algorithm has to move -- spread over the family's launches (`frac_hbm_8d`)
+        alg8d = bytes_per_triplet(n_avg, dim) * args.batch / (launches / max(profiled_steps, 1))
+        step_pmc = committed_pmc(pmc_kind, lambda k: k == "_step_total")
         res["roofline"] = {
-            "bound": bound, "kernel": "gemm_nt_kernel",
-            "achieved": round(gbs if bound == "hbm" else tfl, 2), "peak": HBM_PEAK_GBS if bound == "hbm" else round(NT_PEAK_TFLOPS, 1),
-            "unit": "GB/s" if bound == "hbm" else "TFLOP/s", "frac": round(fh if bound == "hbm" else fm, 4),
-            "frac_hbm": round(fh, 4), "achieved_gbs": round(gbs, 1),
+            "bound": "mfma", "kernel": "gemm_nt_kernel",
+            "achieved": round(tfl, 2), "peak": round(NT_PEAK_TFLOPS, 1), "unit": "TFLOP/s", "frac": round(fm, 4),
             "frac_mfma": round(fm, 4), "achieved_tflops": round(tfl, 2), "peak_tflops": round(NT_PEAK_TFLOPS, 1),
-            "bound_note": "intensity %.1f FLOP/B vs the ridge %.1f FLOP/B of (2500 dense bf16 TFLOP/s / 6 products) over 8 TB/s: "
-                          "the binding roof is the larger of the two lower bounds on the launch time"
-                          % (fl / alg, NT_PEAK_TFLOPS * 1e3 / HBM_PEAK_GBS),
+            "frac_of_fp32_mfma_peak": round(tfl / FP32_MFMA_PEAK_TFLOPS, 4),
+            "frac_hbm_design": round(fh, 4), "achieved_gbs_design": round(gbs, 1), "nearer_roof_by_design_bytes": bound,
+            "frac_hbm_8d": round(alg8d / sec / 1e9 / HBM_PEAK_GBS, 5) if sec > 0 else 0.0, "algorithmic_bytes_per_launch_8d": round(alg8d),
+            "bound_note": "intensity %.1f FLOP/B by the design's activation bytes vs the ridge %.1f FLOP/B of (2500 dense bf16 TFLOP/s / "
+                          "6 products) over 8 TB/s; by section 8(d)'s gathered bytes the intensity is %.0f FLOP/B"
+                          % (fl / alg, NT_PEAK_TFLOPS * 1e3 / HBM_PEAK_GBS, fl / alg8d),
             "peak_note": "fp32 in / fp32 accumulate / fp32-grade result on the bf16 matrix cores: 6 bf16 MFMA products per fp32 "
                          "product, so the matrix peak is 2500 / 6 fp32-equivalent TFLOP/s; `achieved_tflops` counts each fp32 product once",
             "traffic": traffic["hbm_bytes_per_launch"] if traffic else None,
@@ -519,7 +543,12 @@ def run_p2v(args, rank, world, dev, products, steps, warmup, want_cpu, profile_k
                            "executed_frac_of_matrix_peak": round(exe / args.batch * value / world / 1e12 / NT_PEAK_TFLOPS, 4),
                            "reference_equivalent_flops_per_triplet": flops_per_triplet(round(n_avg), dim),
                            "gather_bytes_per_triplet": bytes_per_triplet(round(n_avg), dim),
-                           "frac_hbm_gather": round(bytes_per_triplet(n_avg, dim) * value / world / 1e9 / HBM_PEAK_GBS, 5)}}
+                           "frac_hbm_gather": round(bytes_per_triplet(n_avg, dim) * value / world / 1e9 / HBM_PEAK_GBS, 5),
+                           # every kernel of the step, from the committed counter passes of the same command (loader included)
+                           "hbm_traffic_bytes": step_pmc["hbm_bytes_per_launch"] if step_pmc else None,
+                           "hbm_traffic_source": step_pmc["source"] if step_pmc else None,
+                           "hbm_traffic_over_gather_bytes": (round(step_pmc["hbm_bytes_per_launch"] / (bytes_per_triplet(n_avg, dim) * args.batch), 1)
+                                                             if step_pmc else None)}}
     if want_cpu and last is not None:
         # `last` is a set of views into one slot of the loader's buffer ring (reuse_buffers=True); the sustained leg below
         # rebuilds that slot many times over, with other row counts.  The CPU baseline is timed on THIS batch: keep a copy.
@@ -558,7 +587,7 @@ def run_p2v(args, rank, world, dev, products, steps, warmup, want_cpu, profile_k
                         "hbm_bytes": bpg.nbytes() if on_device else None,
                         "similarity_pairs": len(loader) * args.batch}
     if want_cpu and sharded is None and not on_device and dim == 128:    # (the oracle reads host arrays; a sharded batch indexes its own gathered table)
-        res["cpu_baseline"] = p2v_cpu_baseline(bpg, last)
+        res["cpu_baseline"] = p2v_cpu_baseline(bpg, last, dropout=float(dropout))
     prof.close()
     return res
 
@@ -654,7 +683,7 @@ def guarded(name, fn, world):
     return res
 
 
-def leg(res, keys=("value", "ms_per_step", "host_enqueue_ms_per_step", "final_loss", "catalogue", "roofline", "sharded_lookup")):
+def leg(res, keys=("value", "ms_per_step", "host_enqueue_ms_per_step", "final_loss", "catalogue", "roofline", "sharded_lookup", "cpu_baseline")):
     """A secondary Product2Vec leg of the line: its own value / ms_per_step / roofline, nothing borrowed from the headline."""
     if res is None or "error" in res:
         return res
@@ -738,8 +767,8 @@ def main():
             large = run_p2v(args, rank, world, dev, args.large_catalogue, max(args.steps // 2, 5), args.warmup, False,
                             profile_kernels=False)
         if plain and not args.no_dropout_legs and args.dropout == 0.0:
-            r = guarded("p2v_dropout_0p1", lambda: run_p2v(args, rank, world, dev, args.products, max(args.steps, 30), args.warmup, False,
-                                                           dropout=0.1, pmc_kind="none"), world)
+            r = guarded("p2v_dropout_0p1", lambda: run_p2v(args, rank, world, dev, args.products, max(args.steps, 30), args.warmup, want_cpu,
+                                                           dropout=0.1, pmc_kind="p2vd"), world)
             if rank == 0:
                 extra["p2v_dropout_0p1"] = leg(r)
     if args.phase in ("both", "joint"):
@@ -749,14 +778,14 @@ def main():
                                                  dropout=args.dropout))
         if not args.no_dropout_legs and args.dropout == 0.0:
             extra["joint_dropout_0p1"] = guarded("joint_dropout_0p1", lambda: run_joint(args, rank, world, dev, args.types, max(args.steps * 4, JOINT_MIN_STEPS),
-                                                                                         max(args.warmup, 10), False, dropout=0.1), world)
+                                                                                         max(args.warmup, 10), want_cpu, dropout=0.1), world)
         if not args.no_ref_types and args.types != 34800:
             joint_ref = guarded("joint_num_types_34800", lambda: run_joint(args, rank, world, dev, 34800, max(args.steps, JOINT_REF_MIN_STEPS), max(args.warmup, 10),
                                                                            want_cpu, dropout=args.dropout), world)
             if not args.no_dropout_legs and args.dropout == 0.0:
                 extra["joint_num_types_34800_dropout_0p1"] = guarded(
                     "joint_num_types_34800_dropout_0p1",
-                    lambda: run_joint(args, rank, world, dev, 34800, max(args.steps, JOINT_REF_MIN_STEPS), max(args.warmup, 10), False, dropout=0.1), world)
+                    lambda: run_joint(args, rank, world, dev, 34800, max(args.steps, JOINT_REF_MIN_STEPS), max(args.warmup, 10), want_cpu, dropout=0.1), world)
     if args.phase in ("both", "p2v") and plain and not args.no_large:
         # BASELINE configs[3] / [4] at their real sizes, catalogue generated in HBM (this rank's shard of the table when N > 1).
         # One GPU holds configs[4] whole (102 GB of 288); the smaller catalogues are released first.

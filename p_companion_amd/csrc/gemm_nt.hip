@@ -67,7 +67,10 @@ __device__ __attribute__((aligned(16))) float pc_store_sink[4];
 __device__ __forceinline__ void store_stream_asm(float* p, const float4& v) {
     typedef float v4f __attribute__((ext_vector_type(4)));
     const v4f x = {v.x, v.y, v.z, v.w};
-    asm volatile("global_store_dwordx4 %0, %1, off nt" ::"v"(p), "v"(x) : "memory");
+    // (s_nop: a VALU write of the data registers right behind a store of more than 64 bits is a hazard the compiler's recogniser
+    // would cover for its own stores -- it does not look inside inline asm; the 4-wave prologue loop computes its next chunk
+    // into the same registers at once, and without the wait states the stored rows changed from run to run)
+    asm volatile("global_store_dwordx4 %0, %1, off nt\n\ts_nop 1" ::"v"(p), "v"(x) : "memory");
 }
 __device__ __forceinline__ float4 load_stream(const float* p) {
     typedef float v4f __attribute__((ext_vector_type(4)));
@@ -107,7 +110,8 @@ __global__ __launch_bounds__(64 * NWM * NWN, WPS) void gemm_nt_kernel(NtArgs a, 
     constexpr int NI = SR / RPI / NW;             // DMA instructions per wave and stage
     constexpr int NIA = BM / RPI / NW;            // ... the first NIA of them fetch rows of A
     static_assert(SR % (RPI * NW) == 0 && BM % (RPI * NW) == 0, "row blocks must split evenly over the waves");
-    static_assert(!PRO || BM * CPR == THREADS, "in-place prologue: one 16-B chunk per thread");
+    static_assert(!PRO || (BM * CPR) % THREADS == 0, "in-place prologue: whole 16-B chunks per thread");
+    constexpr int TPT = PRO ? BM * CPR / THREADS : 1;     // chunks of the A image a thread transforms per K-step (8 waves: 1, 4 waves: 2)
     constexpr int PATCH = NW * PROWS * PLD;
     constexpr int STAGE = SR * BK;                // floats per stage
     __shared__ __attribute__((aligned(1024))) float stages[2 * STAGE];
@@ -269,23 +273,34 @@ __global__ __launch_bounds__(64 * NWM * NWN, WPS) void gemm_nt_kernel(NtArgs a, 
     float4 pend_v = make_float4(0.f, 0.f, 0.f, 0.f);
     // BN-apply + tanh on the A image of a landed stage, in place (one 16-B chunk per thread)
     auto transform = [&](float* cur, int k0, int sg) {
-        const int row = tid / CPR, slot = tid % CPR;
-        const int k = k0 + ((slot ^ ((row / RB) % CPR)) << 2);
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (k < a.K) {
-            v = *reinterpret_cast<const float4*>(&cur[tid * 4]);
-            const float4 s = *reinterpret_cast<const float4*>(&pro_ss[(2 * sg) * 256 + k]);
-            const float4 h = *reinterpret_cast<const float4*>(&pro_ss[(2 * sg + 1) * 256 + k]);
-            v.x = fast_tanh(v.x * s.x + h.x);
-            v.y = fast_tanh(v.y * s.y + h.y);
-            v.z = fast_tanh(v.z * s.z + h.z);
-            v.w = fast_tanh(v.w * s.w + h.w);
-            *reinterpret_cast<float4*>(&cur[tid * 4]) = v;
-        }
-        if (a.pro_out) {                               // (wave-uniform) the transformed rows, for the weight gradient that follows
-            const bool live = k < a.K && row0 + row < row_end;
-            pend_p = live ? a.pro_out + (size_t)(row0 + row) * a.ldpo + k : pc_store_sink;
-            pend_v = v;
+#pragma unroll
+        for (int u = 0; u < TPT; u++) {
+            const int c = tid + THREADS * u;
+            const int row = c / CPR, slot = c % CPR;
+            const int k = k0 + ((slot ^ ((row / RB) % CPR)) << 2);
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (k < a.K) {
+                v = *reinterpret_cast<const float4*>(&cur[c * 4]);
+                const float4 s = *reinterpret_cast<const float4*>(&pro_ss[(2 * sg) * 256 + k]);
+                const float4 h = *reinterpret_cast<const float4*>(&pro_ss[(2 * sg + 1) * 256 + k]);
+                v.x = fast_tanh(v.x * s.x + h.x);
+                v.y = fast_tanh(v.y * s.y + h.y);
+                v.z = fast_tanh(v.z * s.z + h.z);
+                v.w = fast_tanh(v.w * s.w + h.w);
+                *reinterpret_cast<float4*>(&cur[c * 4]) = v;
+            }
+            if (a.pro_out) {                           // (wave-uniform) the transformed rows, for the weight gradient that follows
+                const bool live = k < a.K && row0 + row < row_end;
+                if (TPT == 1) {
+                    pend_p = live ? a.pro_out + (size_t)(row0 + row) * a.ldpo + k : pc_store_sink;
+                    pend_v = v;
+                } else if (live && n0 == 0) {
+                    // 4-wave tiles: the two column tiles of a row tile each transform their own copy of the A image; the first
+                    // one stores the rows, at once (the K-step's closing vmcnt(0) covers the store; with three workgroups per CU
+                    // somebody else's MFMAs run meanwhile)
+                    store_stream_asm(a.pro_out + (size_t)(row0 + row) * a.ldpo + k, v);
+                }
+            }
         }
     };
 
@@ -327,7 +342,7 @@ __global__ __launch_bounds__(64 * NWM * NWN, WPS) void gemm_nt_kernel(NtArgs a, 
         // one K-step: start the DMA of the following chunk (this tile's, or the next tile's first),
         // then multiply the landed one
         for (int kt = 0; kt < nk; kt++) {
-            if (PRO && a.pro_out && kt > 0) store_stream_asm(pend_p, pend_v);
+            if (PRO && TPT == 1 && a.pro_out && kt > 0) store_stream_asm(pend_p, pend_v);
 #ifndef PC_EXP_NO_DMA
             if (kt + 1 < nk) issue(cur ^ 1, (kt + 1) * BK);
             else if (ntile < total_tiles) { make_ptrs(nsrow, nn0); issue(cur ^ 1, 0); }
@@ -338,7 +353,7 @@ __global__ __launch_bounds__(64 * NWM * NWN, WPS) void gemm_nt_kernel(NtArgs a, 
             stage_sync();
             cur ^= 1;
         }
-        if (PRO && a.pro_out) store_stream_asm(pend_p, pend_v);       // the last K-step's rows
+        if (PRO && TPT == 1 && a.pro_out) store_stream_asm(pend_p, pend_v);       // the last K-step's rows
 
 #ifdef PC_NT_TIMING
         const unsigned long long t1 = __builtin_amdgcn_s_memtime();
@@ -1132,14 +1147,16 @@ static SegInfo retile(const SegInfo& in, int tile_rows) {
 
 template <bool PRO, int EPI, int STATS>
 static void launch_variant(const NtArgs& a, int ntm, hipStream_t st) {
-    if (!PRO && a.N > 128 && a.N <= 256 && ntm >= 192) {
+    if (a.N > 128 && a.N <= 256 && ntm >= 192 && (!PRO || (EPI == NT_EPI_TANH && STATS == NT_STAT_NONE))) {
         // many rows, 129..256 columns, no in-place prologue: 128x128 tiles of 4 waves, two column tiles per row tile,
         // THREE workgroups per CU.  A is fetched twice (the second time mostly from L2 / MALL), but one workgroup's
         // epilogue -- 30-54 % of a tile's time, during which its waves only move data -- overlaps the K loops of the
         // other two: dZ1 133 -> 115 us, dZ2 79 -> 70, Linear0 71 -> 67 against the 8-wave full-width tile (step 1.135 ->
         // 1.115 ms on the same box; two 4-wave workgroups with 256 registers each: no better than the 8-wave tile).
         const int total = (2 * ntm + 15) & ~15;                  // paired numbering (tile_geom): whole groups of 16
-        PC_LAUNCH((gemm_nt_kernel<2, 2, 16, 3, false, EPI, STATS>), dim3(total < 768 ? total : 768), dim3(256), 0, st, a,
+        // (PRO, round 5: Linear3 too -- each of the two column tiles transforms its own copy of the A image, two chunks per
+        // thread and K-step; the 8-wave tile it replaces is ONE workgroup per CU whose waves split, multiply and wait in step)
+        PC_LAUNCH((gemm_nt_kernel<2, 2, 16, 3, PRO, EPI, STATS>), dim3(total < 768 ? total : 768), dim3(256), 0, st, a,
                   2, total);
         return;
     }

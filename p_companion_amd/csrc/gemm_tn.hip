@@ -640,16 +640,18 @@ struct ForkSlot { int dev; hipStream_t main_st; int state; PcFork f; };      // 
 ForkSlot g_fork_slots[32];
 std::mutex g_fork_mu;
 std::atomic<int> g_opt_side_queue{1};
+std::atomic<int> g_opt_sorted_tables{0};
 }
+int pc_opt_sorted_tables() { return g_opt_sorted_tables.load(std::memory_order_relaxed); }
 
 extern "C" int pc_set_option(int option, int value) {
-    if (option != PC_OPT_SIDE_QUEUE || (value != 0 && value != 1)) return PC_EINVAL;
-    g_opt_side_queue.store(value, std::memory_order_relaxed);
+    if ((option != PC_OPT_SIDE_QUEUE && option != PC_OPT_SORTED_TABLE_GRADIENTS) || (value != 0 && value != 1)) return PC_EINVAL;
+    (option == PC_OPT_SIDE_QUEUE ? g_opt_side_queue : g_opt_sorted_tables).store(value, std::memory_order_relaxed);
     return PC_OK;
 }
 extern "C" int pc_get_option(int option, int* value) {
-    if (option != PC_OPT_SIDE_QUEUE || !value) return PC_EINVAL;
-    *value = g_opt_side_queue.load(std::memory_order_relaxed);
+    if ((option != PC_OPT_SIDE_QUEUE && option != PC_OPT_SORTED_TABLE_GRADIENTS) || !value) return PC_EINVAL;
+    *value = (option == PC_OPT_SIDE_QUEUE ? g_opt_side_queue : g_opt_sorted_tables).load(std::memory_order_relaxed);
     return PC_OK;
 }
 extern "C" int pc_release_device_state(void) {

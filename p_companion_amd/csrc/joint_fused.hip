@@ -1758,166 +1758,264 @@ __global__ __launch_bounds__(256) void table_reduce_kernel(TableList l0, TableLi
 
 // ---------------------------------------------------------------------------------------------------------------
 // Large tables, DETERMINISTIC gradients at ANY number of touched rows (round 5; replaces the LDS-table form above -- 512 distinct
-// rows at most -- and its float-atomic branch wherever a list fits this kernel: T <= 65535 and <= TS_MAXN source rows, i.e.
-// B = 4096 at K <= 4 with the reference's NUM_TYPES = 34800, config.py:27):
-//   table_sort_kernel     one 1024-thread workgroup per list: a STABLE two-pass LSD radix sort (8 bits each) of the source rows
-//                         by destination row, in LDS -- rows of one destination stay in source order; then the distinct
-//                         destinations (ascending: the touched-row list of pc_joint_fused_touched) and where each one's run of
-//                         source rows starts
-//   table_segsum_kernel   one wave per destination: its source rows added IN SOURCE ORDER (eight rows in flight), written to
-//                         the (cleared) dense gradient; a run longer than TS_LONG rows is cut into four contiguous quarters,
-//                         one per wave of the workgroup, folded (w0 + w1) + (w2 + w3)
+// rows at most -- and its float-atomic branch wherever a list fits this kernel's LDS: 2 T + 2 n bytes, e.g. the reference's
+// NUM_TYPES = 34800 (config.py:27) at B = 4096, K <= 4):
+//   table_sort_kernel     one 1024-thread workgroup per list: a COUNTING sort of the source rows by destination over ALL T rows of
+//                         the table, in LDS -- histogram (16-bit counts, two per word, integer atomics), scan over the T bins
+//                         (which also yields the distinct destinations, ascending -- the touched-row list of
+//                         pc_joint_fused_touched -- and where each one's run starts), placement through returning atomics.  The
+//                         placement order inside a run is whatever the atomics gave: every run is then SORTED by source row --
+//                         by the wave(s) that consume it (up to 64 rows: a bitonic network over the lanes; up to 1024: in 2 KB
+//                         of LDS), only a run longer than that here (the whole workgroup, in the dead histogram's LDS)
+//   table_segsum_kernel   one wave per destination: its source rows added in ascending source order (sixteen rows in flight),
+//                         written to the (cleared) dense gradient; a run longer than TS_LONG rows is cut into four contiguous
+//                         quarters, one per wave of the workgroup, folded (w0 + w1) + (w2 + w3)
 // The order of every sum is a function of the index lists alone: bitwise reproducible whatever the number of touched rows --
 // with DROPOUT = 0.1 (config.py:12) every sample selects its own K types and the complementary table has thousands.
-// Ranking inside a wave: the lanes holding one digit find each other with eight ballots (one per digit bit); rank = the number
-// of lower lanes among them.  A wave owns a CONTIGUOUS block of the sequence and walks it in order, so (earlier waves' count)
-// + (this wave's earlier batches) + rank is the element's stable position among its digit.
-#define TS_MAXN 24576       /* source rows per list: 4 n bytes of LDS for the two 16-bit index arrays */
-#define TS_EPT (TS_MAXN / 1024)
+// (Two earlier forms of the sort -- a stable two-pass LSD radix sort with ballot ranking, first with per-lane state in registers
+// and fully unrolled loops, then rolled with the state in LDS -- took 160 and 77 us: instruction fetch, then the ballots.)
+#define TS_MAXN 24576       /* source rows per list (16-bit positions and row numbers) */
 #define TS_LONG 256
+#define TS_SEG_SORT 1024    /* longest run its consumer sorts (table_segsum_kernel: 2 KB of LDS); longer ones are sorted by table_sort_kernel */
 struct SortList { const int32_t* idx; int n; int32_t *sorted, *seg, *ulist; };   // sorted [n], seg [cap + 1], ulist [cap]: cap = min(n, T)
 
-__device__ __forceinline__ void ts_match8(unsigned dig, bool valid, int lane, unsigned& rank, unsigned& cnt) {
-    unsigned long long m = __ballot(valid);
-#pragma unroll
-    for (int b = 0; b < 8; b++) {
-        const bool bit = (dig >> b) & 1u;
-        const unsigned long long bal = __ballot(bit && valid);
-        m &= bit ? bal : ~bal;
+#ifdef PC_SORT_TIMING
+// developer build (scripts/dev/sort_phase_times.py): shader-clock stamps of list 0's thread 0 at the phases of the sort kernel
+__device__ unsigned long long pc_sort_timing[16];
+extern "C" int pc_debug_sort_timing(unsigned long long* out) {
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(pc_sort_timing), sizeof(unsigned long long) * 16);
+}
+#define PC_ST(i) do { if (blockIdx.x == 0 && threadIdx.x == 0) pc_sort_timing[i] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define PC_ST(i) do { } while (0)
+#endif
+
+typedef __attribute__((address_space(3))) unsigned short ts_l16;
+typedef __attribute__((address_space(3))) unsigned ts_l32;
+// ascending bitonic sort of buf[0 .. p2) (p2 a power of two, padding 0xFFFF) by `nthreads` threads that share `sync`
+template <bool BLOCK>
+__device__ __forceinline__ void ts_bitonic(ts_l16* buf, int p2, int t, int nthreads) {
+    for (int k = 2; k <= p2; k <<= 1) {
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            for (int i = t; i < (p2 >> 1); i += nthreads) {
+                const int lo = ((i & ~(j - 1)) << 1) | (i & (j - 1)), hi = lo | j;      // the pair (lo, lo ^ j), lo's bit j clear
+                const unsigned a = buf[lo], b = buf[hi];
+                const bool up = (lo & k) == 0;
+                if ((a > b) == up) { buf[lo] = (unsigned short)b; buf[hi] = (unsigned short)a; }
+            }
+            if (BLOCK) __syncthreads(); else __builtin_amdgcn_wave_barrier();
+        }
     }
-    rank = (unsigned)__popcll(m & ((1ull << lane) - 1ull));
-    cnt = (unsigned)__popcll(m);
 }
 
 __global__ __launch_bounds__(1024) void table_sort_kernel(SortList l0, SortList l1, int T, int32_t* n_touch) {
     extern __shared__ unsigned ts_lds[];
+    PC_ST(0);
     const SortList& l = blockIdx.x ? l1 : l0;
     const int n = l.n;
-    const int nb = (n + 1023) >> 10;                         // 64-element batches per wave (<= TS_EPT)
-    const int npad = nb << 10;
-    unsigned short* A = reinterpret_cast<unsigned short*>(ts_lds);      // [npad] source rows after pass 1
-    unsigned short* Bs = A + npad;                                       // [npad] ... after pass 2
-    volatile unsigned* hist = reinterpret_cast<volatile unsigned*>(Bs + npad);   // [16][256]
-    unsigned* dbase = const_cast<unsigned*>(hist) + 16 * 256;            // [256]
-    unsigned* part = dbase + 256;                                        // [16] scan scratch
-    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-    const int e0 = w * (nb << 6) + lane;                     // the wave's contiguous block: element e0 + 64 j of batch j
-
-    unsigned key[TS_EPT];                                    // (destination << 16) | source row; destination 0xFFFF = none
-    unsigned loc[TS_EPT];
-    // one pass: elements `key` (this lane's, in sequence order), digit = (key >> shift) & 255; out[position] = source row
-    auto pass = [&](int shift, unsigned short* out) {
+    const int words = (T + 1) >> 1;                          // two 16-bit bins per word: bin d = half (d & 1) of word d >> 1
+    const int npad = ((n + 1023) >> 10) << 10;
+    const int hwords = words > 16384 ? words : 16384;        // (>= 64 KB: the scratch of the long runs' sorts)
+    ts_l32* hist = (ts_l32*)ts_lds;                          // [hwords] counts, then running positions, then scratch
+    ts_l16* out = (ts_l16*)(hist + hwords);                  // [npad] source rows by destination
+    ts_l32* longs = (ts_l32*)(out + npad);                   // [TS_MAXN / 64] runs longer than TS_SEG_SORT rows: (start << 16) | length
+    ts_l32* nlong = longs + TS_MAXN / 64;                    // [1] number of long runs, [1] rows with a destination
+    unsigned* part = reinterpret_cast<unsigned*>(ts_lds) + hwords + npad / 2 + TS_MAXN / 64 + 2;   // [16] scan scratch
+    const int tid = threadIdx.x;
+    for (int i = tid; i < words; i += 1024) hist[i] = 0u;
+    if (tid == 0) *nlong = 0u;
+    __syncthreads();
+    PC_ST(1);
+    // ---- histogram: a thread's list entries (e = tid + 1024 j) stay in registers for the placement below
+    constexpr int EPT = TS_MAXN / 1024;
+    int dreg[EPT];
 #pragma unroll
-        for (int q = 0; q < 4; q++) hist[w * 256 + lane + 64 * q] = 0u;      // (the wave's own row: in order with its reads below)
+    for (int j = 0; j < EPT; j++) { const int e = tid + 1024 * j; dreg[j] = e < n ? l.idx[e] : -1; }
 #pragma unroll
-        for (int j = 0; j < TS_EPT; j++) {
-            if (j >= nb) break;                              // workgroup-uniform
-            const bool valid = e0 + 64 * j < n;
-            const unsigned dig = (key[j] >> shift) & 255u;
-            unsigned rank, cnt;
-            ts_match8(dig, valid, lane, rank, cnt);
-            const unsigned prev = valid ? hist[w * 256 + dig] : 0u;       // this wave's earlier batches
-            loc[j] = prev + rank;
-            if (valid && rank == 0u) hist[w * 256 + dig] = prev + cnt;      // (one lane per digit; LDS operations of a wave stay in order)
-        }
-        __syncthreads();
-        unsigned tot = 0u;
-        if (tid < 256) {                                     // digit tid: exclusive prefix over the waves, and its total
+    for (int j = 0; j < EPT; j++)
+        if ((unsigned)dreg[j] < (unsigned)T)
+            __hip_atomic_fetch_add(&hist[dreg[j] >> 1], (dreg[j] & 1) ? 0x10000u : 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    __syncthreads();
+    PC_ST(2);
+    // ---- scan over the bins: thread t owns words [t wpt, t wpt + wpt) (read eight at a time); packed = rows (low half) | distinct
+    // destinations (high half)
+    const int wpt = (words + 1023) >> 10;
+    const int w0 = tid * wpt, w1 = min(words, w0 + wpt);
+    int packed = 0;
+    for (int i0 = w0; i0 < w1; i0 += 8) {
+        unsigned c[8];
 #pragma unroll
-            for (int ww = 0; ww < 16; ww++) { const unsigned c = hist[ww * 256 + tid]; hist[ww * 256 + tid] = tot; tot += c; }
-        }
-        const unsigned incl = (unsigned)block_scan_1024((int)tot, part);
-        if (tid < 256) dbase[tid] = incl - tot;
-        __syncthreads();
+        for (int u = 0; u < 8; u++) c[u] = i0 + u < w1 ? (unsigned)hist[i0 + u] : 0u;
 #pragma unroll
-        for (int j = 0; j < TS_EPT; j++) {
-            if (j >= nb) break;
-            if (e0 + 64 * j < n) {
-                const unsigned dig = (key[j] >> shift) & 255u;
-                out[dbase[dig] + hist[w * 256 + dig] + loc[j]] = (unsigned short)(key[j] & 0xffffu);
-            }
-        }
-        __syncthreads();
-    };
-
-    // pass 1: the sequence is the list itself
-#pragma unroll
-    for (int j = 0; j < TS_EPT; j++) {
-        const int e = e0 + 64 * j;
-        int d = (j < nb && e < n) ? l.idx[e] : -1;
-        if ((unsigned)d >= (unsigned)T) d = 0xffff;          // no destination: sorts behind every row of the table (T <= 65535)
-        key[j] = ((unsigned)d << 16) | (unsigned)(e & 0xffff);
-    }
-    pass(16, A);
-    // pass 2: the sequence is A; the destination of a row is fetched again (every request of the lane in flight together)
-#pragma unroll
-    for (int j = 0; j < TS_EPT; j++) {
-        const int e = e0 + 64 * j;
-        const unsigned r = (j < nb && e < n) ? A[e] : 0u;
-        int d = (j < nb && e < n) ? l.idx[r] : -1;
-        if ((unsigned)d >= (unsigned)T) d = 0xffff;
-        key[j] = ((unsigned)d << 16) | r;
-    }
-    pass(24, Bs);
-    // distinct destinations and the start of each one's run: thread t looks at positions [t nb, t nb + nb)
-    const int i0 = tid * nb;
-    int dprev = -2;
-    if (i0 > 0 && i0 - 1 < n) { const int d = l.idx[Bs[i0 - 1]]; dprev = (unsigned)d < (unsigned)T ? d : -1; }
-    int dd[TS_EPT];
-#pragma unroll
-    for (int j = 0; j < TS_EPT; j++) {
-        const int i = i0 + j;
-        dd[j] = -1;
-        if (j < nb && i < n) { const int d = l.idx[Bs[i]]; dd[j] = (unsigned)d < (unsigned)T ? d : -1; }
-    }
-    int packed = 0;                                          // low half: run starts, high half: rows with a destination
-    {
-        int pv = dprev;
-#pragma unroll
-        for (int j = 0; j < TS_EPT; j++) {
-            if (j < nb && dd[j] >= 0) packed += 0x10000 + (dd[j] != pv ? 1 : 0);
-            pv = dd[j];
-        }
+        for (int u = 0; u < 8; u++)
+            packed += (int)((c[u] & 0xffffu) + (c[u] >> 16)) + (((c[u] & 0xffffu) ? 0x10000 : 0) + ((c[u] >> 16) ? 0x10000 : 0));
     }
     const int incl = block_scan_1024(packed, part);
-    int pos = (incl - packed) & 0xffff;
-    {
-        int pv = dprev;
+    int run = (incl - packed) & 0xffff, pos = (incl - packed) >> 16;
+    for (int i0 = w0; i0 < w1; i0 += 8) {
+        unsigned c[8];
 #pragma unroll
-        for (int j = 0; j < TS_EPT; j++) {
-            const int i = i0 + j;
-            if (j < nb && i < n) {
-                l.sorted[i] = (int)Bs[i];
-                if (dd[j] >= 0 && dd[j] != pv) { l.ulist[pos] = dd[j]; l.seg[pos] = i; pos++; }
+        for (int u = 0; u < 8; u++) c[u] = i0 + u < w1 ? (unsigned)hist[i0 + u] : 0u;
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+            const int i = i0 + u;
+            if (i < w1) {
+                const unsigned c0 = c[u] & 0xffffu, c1 = c[u] >> 16;
+                const unsigned s0 = (unsigned)run, s1 = s0 + c0;
+                hist[i] = s0 | (s1 << 16);                   // running positions of the two bins
+                if (c0) { l.ulist[pos] = 2 * i; l.seg[pos] = (int)s0; pos++; if (c0 > TS_SEG_SORT) longs[__hip_atomic_fetch_add(nlong, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)] = (s0 << 16) | c0; }
+                if (c1) { l.ulist[pos] = 2 * i + 1; l.seg[pos] = (int)s1; pos++; if (c1 > TS_SEG_SORT) longs[__hip_atomic_fetch_add(nlong, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)] = (s1 << 16) | c1; }
+                run += (int)(c0 + c1);
             }
-            pv = dd[j];
         }
     }
     if (tid == 1023) {
-        const int nu = incl & 0xffff;
-        n_touch[blockIdx.x] = nu;
-        l.seg[nu] = incl >> 16;                              // rows with a destination: they are the head of the sorted sequence
+        n_touch[blockIdx.x] = incl >> 16;
+        l.seg[incl >> 16] = incl & 0xffff;                   // rows with a destination
+        nlong[1] = (unsigned)(incl & 0xffff);
     }
+    __syncthreads();
+    const int incl_total_rows = (int)nlong[1];
+    PC_ST(3);
+    // ---- placement: the returning atomic hands every row a slot of its destination's run (in no particular order)
+#pragma unroll
+    for (int j = 0; j < EPT; j++)
+        if ((unsigned)dreg[j] < (unsigned)T) {
+            const unsigned old = __hip_atomic_fetch_add(&hist[dreg[j] >> 1], (dreg[j] & 1) ? 0x10000u : 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            out[(dreg[j] & 1) ? old >> 16 : old & 0xffffu] = (unsigned short)(tid + 1024 * j);
+        }
+    __syncthreads();
+    PC_ST(4);
+    // ---- runs longer than TS_SEG_SORT rows (a destination most of the batch points at: rare) are sorted here, by the whole
+    // workgroup one after the other, in a scratch copy padded to a power of two (the histogram's words are dead now: they are the
+    // scratch -- at least 64 KB, see table_sort_lds_bytes); every shorter run is sorted by the wave(s) that consume it
+    const unsigned nl = *nlong;
+    ts_l16* scratch = (ts_l16*)hist;
+    for (unsigned q = 0; q < nl; q++) {
+        const unsigned rec = longs[q], start = rec >> 16, len = rec & 0xffffu;
+        int p2 = 2048;
+        while ((unsigned)p2 < len) p2 <<= 1;                 // <= 32768 = 64 KB of scratch
+        for (int i = tid; i < p2; i += 1024) scratch[i] = (unsigned)i < len ? (unsigned short)out[start + i] : (unsigned short)0xffff;
+        __syncthreads();
+        ts_bitonic<true>(scratch, p2, tid, 1024);
+        for (int i = tid; i < (int)len; i += 1024) out[start + i] = scratch[i];
+        __syncthreads();
+    }
+    PC_ST(5);
+    // ---- the order out to memory (runs of up to TS_SEG_SORT rows are still in placement order: their consumer sorts them)
+    const int nrows = incl_total_rows;
+    for (int i = tid; i < nrows; i += 1024) l.sorted[i] = (int)out[i];
+    PC_ST(6);
 }
-static size_t table_sort_lds_bytes(int n) {
+// LDS: [max(2 T, 64 KB)] histogram / scratch | [2 npad] order | long-run list | scan scratch
+static size_t table_sort_hist_words(int T) {
+    const size_t w = (size_t)((T + 1) >> 1);
+    return w > 16384 ? w : 16384;
+}
+static size_t table_sort_lds_bytes(int n, int T) {
     const size_t npad = (size_t)((n + 1023) >> 10) << 10;
-    return npad * 4 + (16 * 256 + 256 + 16) * 4;
+    return (table_sort_hist_words(T) + npad / 2 + TS_MAXN / 64 + 2 + 16) * 4;
 }
+static bool table_sort_fits(int n, int T) { return T <= 65535 && n <= TS_MAXN && table_sort_lds_bytes(n, T) <= 160 * 1024; }
 
 struct SegList { float* table; const float* src; const int32_t *sorted, *seg, *ulist; };
-__device__ __forceinline__ float ts_run_sum(const float* src, const int32_t* sorted, int b, int e, int lane) {
+// rows idx[0 .. m) of src added in that order, sixteen row loads in flight: the wave fetches 64 indices at a time with one load
+// (lane l: idx[c + l]) and hands them round by readlane -- one dependent chain per 64 rows instead of one per row.  LDSI: the
+// indices are 16-bit words in LDS (a run sorted there), else int32 in memory.
+template <bool LDSI>
+__device__ __forceinline__ float ts_sum_rows(const float* src, const int32_t* gidx, const unsigned short* lidx, int m, int lane) {
     float acc = 0.f;
-    for (int i = b; i < e; i += 8) {
-        float v[8];
+    for (int c = 0; c < m; c += 64) {
+        const int mm = min(64, m - c);                       // wave-uniform
+        const int mine = lane < mm ? (LDSI ? (int)lidx[c + lane] : gidx[c + lane]) : 0;
+        for (int i = 0; i < mm; i += 16) {
+            float v[16];
 #pragma unroll
-        for (int u = 0; u < 8; u++) v[u] = i + u < e ? src[(size_t)sorted[i + u] * PC_L + lane] : 0.f;
+            for (int u = 0; u < 16; u++) {
+                const int r = __builtin_amdgcn_readlane(mine, (i + u) & 63);
+                v[u] = i + u < mm ? src[(size_t)r * PC_L + lane] : 0.f;
+            }
 #pragma unroll
-        for (int u = 0; u < 8; u++) acc += v[u];             // source order
+            for (int u = 0; u < 16; u++) acc += v[u];
+        }
     }
     return acc;
 }
+// a run of up to 64 NQ rows (NQ = 1, 2, 4): sorted in registers -- element i = 64 q + lane sits in register q of lane `lane`; a
+// bitonic network whose steps with partner distance j < 64 exchange between lanes (one shuffle per register) and whose steps with
+// j >= 64 exchange between two registers of the same lane -- then added in that order
+template <int NQ>
+__device__ __forceinline__ float ts_sum_regs(const float* src, const int32_t* sorted, int b, int m, int lane) {
+    int x[NQ];
+#pragma unroll
+    for (int q = 0; q < NQ; q++) x[q] = 64 * q + lane < m ? sorted[b + 64 * q + lane] : 0x7fffffff;
+    if (m > 1) {
+#pragma unroll
+        for (int k = 2; k <= 64 * NQ; k <<= 1) {
+#pragma unroll
+            for (int j = k >> 1; j > 0; j >>= 1) {
+                if (j >= 64) {
+#pragma unroll
+                    for (int q = 0; q < NQ; q++) {
+                        const int pq = q ^ (j >> 6);
+                        if (pq > q) {                         // the pair (q, pq): ascending if bit k of the element index is clear
+                            const bool up = ((64 * q) & k) == 0;
+                            const int lo = min(x[q], x[pq]), hi = max(x[q], x[pq]);
+                            x[q] = up ? lo : hi; x[pq] = up ? hi : lo;
+                        }
+                    }
+                } else {
+#pragma unroll
+                    for (int q = 0; q < NQ; q++) {
+                        const int other = __shfl_xor(x[q], j, 64);
+                        const bool up = ((64 * q + lane) & k) == 0, lower = (lane & j) == 0;
+                        x[q] = (lower == up) ? min(x[q], other) : max(x[q], other);
+                    }
+                }
+            }
+        }
+    }
+    float acc = 0.f;
+#pragma unroll
+    for (int q = 0; q < NQ; q++) {
+        if (64 * q >= m) break;                              // wave-uniform
+        const int mm = min(64, m - 64 * q);
+        for (int i = 0; i < mm; i += 16) {
+            float v[16];
+#pragma unroll
+            for (int u = 0; u < 16; u++) {
+                const int r = __builtin_amdgcn_readlane(x[q], (i + u) & 63);
+                v[u] = i + u < mm ? src[(size_t)r * PC_L + lane] : 0.f;
+            }
+#pragma unroll
+            for (int u = 0; u < 16; u++) acc += v[u];
+        }
+    }
+    return acc;
+}
+// ascending bitonic sort of buf[0 .. p2) in generic-pointer LDS (p2 a power of two, padding 0xFFFF) by nthreads threads
+template <bool BLOCK>
+__device__ __forceinline__ void ts_bitonic_s(unsigned short* buf, int p2, int t, int nthreads) {
+    for (int k = 2; k <= p2; k <<= 1) {
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            for (int i = t; i < (p2 >> 1); i += nthreads) {
+                const int lo = ((i & ~(j - 1)) << 1) | (i & (j - 1)), hi = lo | j;
+                const unsigned a = buf[lo], b = buf[hi];
+                const bool up = (lo & k) == 0;
+                if ((a > b) == up) { buf[lo] = (unsigned short)b; buf[hi] = (unsigned short)a; }
+            }
+            if (BLOCK) __syncthreads(); else __builtin_amdgcn_wave_barrier();
+        }
+    }
+}
+// One wave per destination (four per workgroup).  By the length m of a destination's run:
+//   m <= TS_LONG        sorted in its wave's registers (one, two or four per lane), added by that wave
+//   m > TS_LONG         one after the other by the whole workgroup: (up to TS_SEG_SORT rows) copied into the 2 KB buffer and sorted by
+//                      all four waves, (beyond: sorted by table_sort_kernel already) then four contiguous quarters, one per wave,
+//                      folded (w0 + w1) + (w2 + w3)
 __global__ __launch_bounds__(256) void table_segsum_kernel(SegList l0, SegList l1, const int32_t* n_touch, int wgs0) {
     __shared__ float fold[4][PC_L];
+    __shared__ unsigned short sbuf[TS_SEG_SORT];
     const int li = (int)blockIdx.x >= wgs0 ? 1 : 0;
     const SegList& l = li ? l1 : l0;
     const int s0 = ((int)blockIdx.x - li * wgs0) * 4;
@@ -1926,22 +2024,38 @@ __global__ __launch_bounds__(256) void table_segsum_kernel(SegList l0, SegList l
     const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int s = s0 + w;
     if (s < nu) {
-        const int b = __builtin_amdgcn_readfirstlane(l.seg[s]), e = __builtin_amdgcn_readfirstlane(l.seg[s + 1]);
-        if (e - b <= TS_LONG) l.table[(size_t)l.ulist[s] * PC_L + lane] = ts_run_sum(l.src, l.sorted, b, e, lane);
+        const int b = __builtin_amdgcn_readfirstlane(l.seg[s]), m = __builtin_amdgcn_readfirstlane(l.seg[s + 1]) - b;
+        if (m <= 64) l.table[(size_t)l.ulist[s] * PC_L + lane] = ts_sum_regs<1>(l.src, l.sorted, b, m, lane);
+        else if (m <= 128) l.table[(size_t)l.ulist[s] * PC_L + lane] = ts_sum_regs<2>(l.src, l.sorted, b, m, lane);
+        else if (m <= TS_LONG) l.table[(size_t)l.ulist[s] * PC_L + lane] = ts_sum_regs<4>(l.src, l.sorted, b, m, lane);
     }
+    __syncthreads();                                         // (the slices are free)
     for (int q = 0; q < 4; q++) {                            // the long runs, one after the other, four waves each
         const int sq = s0 + q;
         if (sq >= nu) break;
-        const int b = __builtin_amdgcn_readfirstlane(l.seg[sq]), e = __builtin_amdgcn_readfirstlane(l.seg[sq + 1]);
-        if (e - b <= TS_LONG) continue;                      // (workgroup-uniform: every wave reads the same two words)
-        const int per = (e - b + 3) >> 2;
-        const int mb = b + w * per, me = min(e, mb + per);
-        fold[w][lane] = ts_run_sum(l.src, l.sorted, mb, me, lane);
+        const int b = __builtin_amdgcn_readfirstlane(l.seg[sq]), m = __builtin_amdgcn_readfirstlane(l.seg[sq + 1]) - b;
+        if (m <= TS_LONG) continue;                          // (workgroup-uniform: every wave reads the same two words)
+        const int per = (m + 3) >> 2;
+        const int mb = w * per, mm = max(0, min(m, mb + per) - mb);
+        float part;
+        if (m <= TS_SEG_SORT) {
+            int p2 = 512;
+            while (p2 < m) p2 <<= 1;
+            for (int i = threadIdx.x; i < p2; i += 256) sbuf[i] = i < m ? (unsigned short)l.sorted[b + i] : (unsigned short)0xffff;
+            __syncthreads();
+            ts_bitonic_s<true>(sbuf, p2, threadIdx.x, 256);
+            part = ts_sum_rows<true>(l.src, nullptr, sbuf + mb, mm, lane);
+        } else {
+            part = ts_sum_rows<false>(l.src, l.sorted + b + mb, nullptr, mm, lane);
+        }
+        fold[w][lane] = part;
         __syncthreads();
         if (w == 0) l.table[(size_t)l.ulist[sq] * PC_L + lane] = (fold[0][lane] + fold[1][lane]) + (fold[2][lane] + fold[3][lane]);
         __syncthreads();
     }
 }
+
+int pc_opt_sorted_tables();     // (gemm_tn.hip: pc_set_option)
 
 struct FusedWs {
     float *part, *h, *dpi, *dtp, *dc, *dh, *dt, *ecsrc;
@@ -1996,16 +2110,15 @@ static FusedWs fused_ws_layout(void* base, int B, int T, int K) {
         w.tl_q = (int32_t*)take((size_t)(B < T ? B : T) * 4);
         w.tp_q = (int32_t*)take((size_t)T * 4);
         w.n_touch = (int32_t*)take(256);
-        w.sorted_path = T <= 65535 && nc <= TS_MAXN;
+        w.sorted_path = table_sort_fits(nc, T);
         if (w.sorted_path) {
             w.srt_c = (int32_t*)take((size_t)nc * 4);
             w.srt_q = (int32_t*)take((size_t)B * 4);
             w.seg_c = (int32_t*)take((size_t)((nc < T ? nc : T) + 1) * 4);
             w.seg_q = (int32_t*)take((size_t)((B < T ? B : T) + 1) * 4);
-        } else {
-            w.tslab_c = (float*)take((size_t)TG_WGS * TG_CAP * PC_L * 4);
-            w.tslab_q = (float*)take((size_t)TG_WGS * TG_CAP * PC_L * 4);
         }
+        w.tslab_c = (float*)take((size_t)TG_WGS * TG_CAP * PC_L * 4);      // (the LDS-table form: PC_OPT_SORTED_TABLE_GRADIENTS, below)
+        w.tslab_q = (float*)take((size_t)TG_WGS * TG_CAP * PC_L * 4);
         w.nchunks_s = (T + PC_STC - 1) / PC_STC;
         w.ucap = B < T ? B : T;
         w.ulist = (int32_t*)take((size_t)w.ucap * 4);
@@ -2195,14 +2308,18 @@ static int fused_step_impl(const pc_joint_tensors* p, const pc_joint_tensors* g,
         else PC_LAUNCH((joint_wgrad_kernel<16, 0>), dim3(w.wg_blocks), dim3(512), wl, st, wa);
         PC_TRY(pc_launch_status());
     }
-    if (!w.small && w.sorted_path) {
-        // table gradients: source rows sorted by destination (stable), then one wave per destination adds its run in source order
+    // which form sums the table gradients (PC_OPT_SORTED_TABLE_GRADIENTS in the header): with hidden-layer dropout every sample
+    // selects its own K types -- thousands of touched rows, beyond the LDS-table form's 512 -- so the sorted form runs; without
+    // it the LDS-table form (22 us against 60) unless the caller asked for the sorted one
+    const bool sorted_tables = !w.small && w.sorted_path && (per_sample || pc_opt_sorted_tables());
+    if (sorted_tables) {
+        // table gradients: source rows sorted by destination, then one wave per destination adds its run in ascending source order
         const int nc = B * (K + 2), cap_c = nc < T ? nc : T, cap_q = B < T ? B : T;
         const SortList sc = {w.ecidx, nc, w.srt_c, w.seg_c, w.tl_c}, sq = {w.cids + B, B, w.srt_q, w.seg_q, w.tl_q};
         static const hipError_t sattr = hipFuncSetAttribute(reinterpret_cast<const void*>(&table_sort_kernel),
                                                             hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         (void)sattr;
-        PC_LAUNCH(table_sort_kernel, dim3(2), dim3(1024), table_sort_lds_bytes(nc), st, sc, sq, T, w.n_touch);
+        PC_LAUNCH(table_sort_kernel, dim3(2), dim3(1024), table_sort_lds_bytes(nc, T), st, sc, sq, T, w.n_touch);
         const SegList gc = {g->comp_types, w.ecsrc, w.srt_c, w.seg_c, w.tl_c}, gq = {g->query_types, w.dt, w.srt_q, w.seg_q, w.tl_q};
         const int wgs_c = (cap_c + 3) / 4, wgs_q = (cap_q + 3) / 4;
         PC_LAUNCH(table_segsum_kernel, dim3(wgs_c + wgs_q), dim3(256), 0, st, gc, gq, w.n_touch, wgs_c);

@@ -1,0 +1,30 @@
+"""Developer probe (GPU box; needs a -DPC_SORT_TIMING build: PC_EXTRA_HIPCC_FLAGS=-DPC_SORT_TIMING python -m p_companion_amd.build --force):
+shader clocks between the phases of table_sort_kernel for the complementary table's list of one fused step at T = 34800."""
+import ctypes, os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+from types import SimpleNamespace
+import torch
+from p_companion_amd import _lib
+from p_companion_amd.p_companion import PCompanion
+
+T, B, K, p = 34800, 4096, 3, float(sys.argv[1]) if len(sys.argv) > 1 else 0.1
+cfg = SimpleNamespace(PRODUCT_EMB_DIM=128, TYPE_EMB_DIM=64, HIDDEN_SIZE=256, NUM_ATTENTION_HEADS=4, DROPOUT=p, MARGIN=1.0, ALPHA=0.8,
+                      NUM_COMP_TYPES=K, NUM_TYPES=T, DEVICE=torch.device("cuda"), LEARNING_RATE=1e-3)
+g = torch.Generator().manual_seed(0)
+m = PCompanion(cfg, torch.randn(2000, 128, generator=g)).cuda().train()
+b = {"query_idx": torch.randint(0, 2000, (B,), generator=g, dtype=torch.int32).cuda(), "query_types": torch.randint(0, 100, (B,), generator=g).cuda(),
+     "positive_types": torch.randint(0, 100, (B, 1), generator=g).cuda(), "negative_types": torch.randint(0, 100, (B, 1), generator=g).cuda(),
+     "positive_items": torch.randn(B, 128, generator=g).cuda(), "negative_items": torch.randn(B, 128, generator=g).cuda()}
+for _ in range(5):
+    m.train_step(b)
+torch.cuda.synchronize()
+L = ctypes.CDLL(_lib.LIB_PATH)
+out = (ctypes.c_ulonglong * 16)()
+assert L.pc_debug_sort_timing(out) == 0
+t = list(out)
+names = ["zero", "histogram", "scan + run starts", "placement", "long runs sorted", "write-out"]
+seq = t[:7]
+print("stamps:", seq)
+for i in range(1, len(seq)):
+    print("%-18s %8d clk" % (names[i - 1], seq[i] - seq[i - 1]))
+print("total %d clk" % (seq[-1] - seq[0]))

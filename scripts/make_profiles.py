@@ -77,6 +77,12 @@ if fe:
         w = wr_.get(k, [n, 0.0])
         res[k] = {"launches": n, "fetch_kib_raw": round(v / n, 1), "fetch_bytes_corrected": round(v / n * 1024 * 2),
                   "write_bytes": round(w[1] / max(1, w[0]) * 1024)}
+    # the whole step: every kernel of the process over the steps run (adam_at_kernel is launched once per step)
+    steps = max([v["launches"] for k, v in res.items() if "adam" in k] or [1])
+    res["_step_total"] = {"launches": 1, "steps_counted": steps,
+                          "fetch_bytes_corrected": round(sum(v["fetch_bytes_corrected"] * v["launches"] for v in res.values()) / steps),
+                          "write_bytes": round(sum(v["write_bytes"] * v["launches"] for v in res.values()) / steps),
+                          "note": "all kernels of the process (loader, step, Adam) summed and divided by the steps run"}
     json.dump(res, open(os.path.join(dst, f"{tag}_pmc_traffic.json"), "w"), indent=1)
     nt = [v for k, v in res.items() if "gemm_nt_kernel<" in k]
     n = sum(v["launches"] for v in nt)
@@ -85,7 +91,8 @@ if fe:
 # ---- PMC passes of the joint phase: per kernel, and summed over one step (`_step_total`); the same for the run at the
 # reference's NUM_TYPES = 34800 (profiles/<tag>_joint34800_pmc_traffic.json, read by bench.py for that configuration)
 for dirs, out_name in ((("pmc_joint_fetch", "pmc_joint_write"), "joint"), (("pmc_joint34800_fetch", "pmc_joint34800_write"), "joint34800"),
-                       (("pmc_joint34800d_fetch", "pmc_joint34800d_write"), "joint34800d")):     # d: DROPOUT = 0.1, the reference as shipped
+                       (("pmc_joint34800d_fetch", "pmc_joint34800d_write"), "joint34800d"),      # d: DROPOUT = 0.1, the reference as shipped
+                       (("pmc_jointd_fetch", "pmc_jointd_write"), "jointd"), (("pmc_p2vd_fetch", "pmc_p2vd_write"), "p2vd")):
     fe, wr_ = pmc(dirs[0], "FETCH_SIZE"), pmc(dirs[1], "WRITE_SIZE")
     if not fe:
         continue

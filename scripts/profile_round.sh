@@ -26,6 +26,16 @@ rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_joint34800_fetch -- p
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_joint34800_write -- python3 $R/bench.py --phase joint --types 34800 --steps 5 --warmup 2 --no-cpu-baseline --no-sustained --no-ref-types --no-dropout-legs > /dev/null 2> $OUT/pmc_joint34800_write.err
 fi
 if [ -z "$NO_BENCH" ]; then cat $OUT/bench.json; fi
+# PD=1: the two DROPOUT = 0.1 legs of the default line that had no counter passes (Product2Vec and the joint step at T = 100):
+# HBM traffic of the same commands (bench.py reads profiles/<tag>_p2vd_pmc_traffic.json / <tag>_jointd_pmc_traffic.json)
+if [ -n "$PD" ]; then
+PDA="--phase p2v --dropout 0.1 --steps 5 --warmup 2 --no-cpu-baseline --no-sustained --no-large --no-dropout-legs"
+rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_p2vd_fetch -- python3 $R/bench.py $PDA > /dev/null 2> $OUT/pmc_p2vd_fetch.err
+rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_p2vd_write -- python3 $R/bench.py $PDA > /dev/null 2> $OUT/pmc_p2vd_write.err
+JDB="--phase joint --dropout 0.1 --steps 5 --warmup 2 --no-cpu-baseline --no-sustained --no-ref-types --no-dropout-legs"
+rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_jointd_fetch -- python3 $R/bench.py $JDB > /dev/null 2> $OUT/pmc_jointd_fetch.err
+rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_jointd_write -- python3 $R/bench.py $JDB > /dev/null 2> $OUT/pmc_jointd_write.err
+fi
 # BIG=1: BASELINE configs[4] on ONE GPU (100 M products x 256, Zipf negatives; the catalogue is generated in HBM): kernel
 # trace + the HBM-traffic counters + the L2 hit counters of the same command (the hot-row cache question)
 if [ -n "$BIG" ]; then

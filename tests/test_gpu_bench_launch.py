@@ -1,0 +1,40 @@
+"""bench.py --gpus N without a launcher starts its ranks itself (two ranks on the one card over gloo).  Needs an MI355X."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+# ------------------------------------------------------------------ bench.py --gpus N starts its N ranks itself
+@pytest.mark.timeout(900)
+def test_bench_self_launches_its_ranks():
+    """`python bench.py --gpus 2` with no launcher around it (the driver's N > 1 form if it calls the script like the N = 1 one):
+    the script starts two ranks itself, rank 0's line reports both.  Rehearsed on the one card of this box (PC_FORCE_DEVICE=0)
+    over gloo -- two ranks cannot share a GPU under RCCL; RCCL itself is rehearsed with one rank in tests/test_gpu_rccl.py."""
+    env = dict(os.environ, PC_DIST_BACKEND="gloo", PC_FORCE_DEVICE="0", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT", "PC_DIST_FORCE"):
+        env.pop(k, None)
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "2",
+                          "--products", "20000", "--batch", "512", "--no-cpu-baseline", "--no-sustained", "--no-large",
+                          "--no-dropout-legs", "--no-ref-types"], env=env, capture_output=True, text=True, timeout=800, cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-3000:]
+    line = json.loads(out.stdout.strip().splitlines()[-1])
+    assert line["n_gpus"] == 2 and line["config"]["global_batch"] == 1024 and line["config"]["parallelism"] == "dp2"
+    rccl = dict(line["rccl"])
+    exchange = rccl.pop("exchange")                     # (ABI 6: the gradient exchange through the library's slot; gloo behind it here)
+    assert rccl == {"backend": "gloo", "world": 2, "ranks_seen": [0, 1], "launcher": "self"} and "gloo" in exchange
+    assert "pc_joint_train_epoch_dp" in line["joint"]["config"]["launch"]
+    assert line["value"] > 0 and line["joint"]["value"] > 0 and line["joint"]["config"]["parallelism"] == "dp2"
+    # more ranks than GPUs, not a rehearsal: refused with a message, before any rank starts
+    env.pop("PC_FORCE_DEVICE")
+    bad = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(torch.cuda.device_count() + 1)], env=env,
+                         capture_output=True, text=True, timeout=120, cwd=ROOT)
+    assert bad.returncode != 0 and "visible GPUs" in bad.stderr and not bad.stdout.strip()

@@ -44,6 +44,18 @@ CASES = [(34800, 34800, 0.1, 4096, 3, True),     # thousands of touched rows in 
 
 @pytest.mark.parametrize("T,live,dropout,B,K,sorted_path", CASES)
 def test_table_gradients_against_the_oracle_and_run_to_run(T, live, dropout, B, K, sorted_path):
+    from p_companion_amd import _lib
+    L = _lib.lib()
+    # (without dropout the step takes the LDS-table form by default -- reproducible up to 512 touched rows per table; the sorted
+    # form is then the caller's choice: pc_set_option(PC_OPT_SORTED_TABLE_GRADIENTS, 1))
+    assert L.pc_set_option(_lib.PC_OPT_SORTED_TABLE_GRADIENTS, 1 if (sorted_path and dropout == 0.0) else 0) == 0
+    try:
+        _check_table_gradients(T, live, dropout, B, K, sorted_path)
+    finally:
+        assert L.pc_set_option(_lib.PC_OPT_SORTED_TABLE_GRADIENTS, 0) == 0
+
+
+def _check_table_gradients(T, live, dropout, B, K, sorted_path):
     model, cfg = _model(T, K, dropout)
     st0 = {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}
     hb = _batch(B, 2000, live, seed=11)
@@ -98,11 +110,15 @@ def test_touched_row_lists_are_the_distinct_destinations_at_thousands_of_rows():
     rc, rq, nt = ops.joint_fused_touched(step.prepared.ws, B, T, K)
     n_c, n_q = (int(v) for v in nt.tolist())
     params = dict(model.named_parameters())
-    for nm, ids in (("complementary_type_embeddings.weight", rc[:n_c]), ("query_type_embeddings.weight", rq[:n_q])):
+    db = step.static
+    # destinations of the two lists (p_companion.py:45-77, 95-103): E_c -- the K selected types of every sample and its hinge's
+    # positive / negative type; E_q -- the query types
+    dest_c = torch.unique(torch.cat([step.complementary_types.reshape(-1).long(), db["positive_types"].reshape(-1).long(),
+                                     db["negative_types"].reshape(-1).long()]))
+    dest_q = torch.unique(db["query_types"].reshape(-1).long())
+    for nm, ids, dest in (("complementary_type_embeddings.weight", rc[:n_c], dest_c), ("query_type_embeddings.weight", rq[:n_q], dest_q)):
+        assert torch.equal(ids.long().cpu(), dest.cpu()), nm           # ascending and distinct (torch.unique sorts)
         g = params[nm].grad
-        want = torch.nonzero(g.abs().amax(1) > 0).reshape(-1).to(torch.int32)
-        ids = ids.to(torch.int32)
-        assert bool((ids[1:] > ids[:-1]).all())
-        # (a touched row whose contributions cancel to exactly zero would be listed without a gradient: none here)
-        assert torch.equal(ids.cpu(), want.cpu()), nm
+        has = torch.nonzero(g.abs().amax(1) > 0).reshape(-1)
+        assert bool(torch.isin(has, dest.to(has.device)).all())        # (a listed row may hold a zero gradient: an inactive hinge)
     assert n_c > 512 and n_q > 512
