@@ -981,10 +981,20 @@ __global__ __launch_bounds__(256) void sample_hidden_kernel(SampleHArgs a) {
             const int t = t0 + 16 * w + 4 * rh + r;
             if (t < a.T) { a.G[(size_t)t * LH + ci] = a0[0][r]; a.G[(size_t)t * LH + 16 + ci] = a1[0][r]; }
         }
+        float g0abs = 0.f;
         if (tid < UT && t0 + tid < a.T) {
             float s = 0.f;
             for (int d = 0; d < PC_L; d++) s += Tin[tid * LD64 + d] * a.dec_b[d];
             a.g0[t0 + tid] = s;
+            g0abs = fabsf(s);
+        }
+        if (w == 0) {
+            // the largest |g0[t]| of the sub-chunk, behind the norms (gnmax [nsub] | g0max [nsub]): pass 1 starts its accumulators
+            // at g0 and pass 2 adds g0 last -- both round at the scale of |g0| + |G||hd|, which the |G||hd| bound alone does not
+            // cover when |g0| is the larger of the two
+#pragma unroll
+            for (int o = 32; o >= 1; o >>= 1) g0abs = fmaxf(g0abs, __shfl_xor(g0abs, o, 64));
+            if (lane == 0) a.gnmax[(a.T + UT - 1) / UT + t0 / UT] = g0abs;
         }
         // gnmax[sub] = the largest |G[t]|_2 of this workgroup's 64 types (= one sub-chunk of the similarity kernels): what bounds the
         // error of the two-piece products of sample_sims_max_kernel for that sub-chunk (Cauchy-Schwarz, see sample_topk_refine_kernel)
@@ -1062,6 +1072,7 @@ struct SampleSimsArgs {
 // 48 MFMAs per wave and tile, 23 us of the kernel's 42 at B = 4096, T = 34800; the first version's eight v_mfma_f32_16x16x4_f32 per
 // block 8 x 32 clocks against 3 x 16.)  The hd rows of a tile are split ONCE, by the thread that fetched them (one float4 each), and
 // staged as two bf16 piece planes; the chunk's G fragments are split once per workgroup and stay in registers.
+#define PC_SS_G0 9.6e-7f       /* 8 * 2^-23: the roundings of pass 1's accumulation from g0 and of pass 2's final + g0, relative to the sub-chunk's largest |g0| */
 #define PC_SS_EPS 2.5e-4f      /* > 3 * 2^-14 + 2^-17 + 2^-19 = 1.93e-4: bound of |pass-1 value - pass-2 value| / (|G[t]| |hd_r|), with a quarter to spare */
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ f32x4v mfma16_bf16(const bf16x8& a, const bf16x8& b, f32x4v c) {
@@ -1192,7 +1203,8 @@ __global__ __launch_bounds__(256, SWPS) void sample_sims_max_kernel(SampleSimsAr
     }
 }
 
-// Pass 2 of 2: one wave per row.  Pass 1's maximum of sub-chunk S is within e_S = PC_SS_EPS |hd_r| gnmax[S] of the true one, so with
+// Pass 2 of 2: one wave per row.  Pass 1's maximum of sub-chunk S is within e_S = PC_SS_EPS |hd_r| gnmax[S] + PC_SS_G0 g0max[S] of the true
+// one (the second term: the roundings at the scale of g0, where the accumulation starts and ends), so with
 // L_S = cmax_S - e_S and tau = the K-th largest L: K different sub-chunks hold an element >= tau, hence the K-th best similarity of the
 // row is >= tau, and a sub-chunk with cmax_S + e_S < tau cannot hold one of the K best.  Every other sub-chunk (exactly K of them
 // unless maxima come within the error bound of each other, or tie) has its 64 similarities formed again in fp32, and the exact
@@ -1211,9 +1223,10 @@ __global__ __launch_bounds__(256) void sample_topk_refine_kernel(const float* cm
     float hn = h4.x * h4.x + h4.y * h4.y + h4.z * h4.z + h4.w * h4.w;
     hn += __shfl_xor(hn, 1, 64); hn += __shfl_xor(hn, 2, 64); hn += __shfl_xor(hn, 4, 64);
     const float escale = PC_SS_EPS * sqrtf(hn);
+    const int nsub_real = (T + 63) >> 6;                     // gnmax [nsub_real] norms, then [nsub_real] largest |g0|
     float m0 = -INFINITY, m1 = -INFINITY, m2 = -INFINITY, m3 = -INFINITY;      // the lane's four largest lower bounds, descending
     for (int i = lane; i < nsub; i += 64) {
-        const float x = 64 * i < T ? row[i] - escale * gnmax[i] : -INFINITY;
+        const float x = 64 * i < T ? row[i] - (escale * gnmax[i] + PC_SS_G0 * gnmax[nsub_real + i]) : -INFINITY;
         m3 = __builtin_amdgcn_fmed3f(m2, m3, x); m2 = __builtin_amdgcn_fmed3f(m1, m2, x); m1 = __builtin_amdgcn_fmed3f(m0, m1, x);
         m0 = fmaxf(m0, x);
     }
@@ -1235,7 +1248,7 @@ __global__ __launch_bounds__(256) void sample_topk_refine_kernel(const float* cm
     for (int i0 = 0; i0 < nsub; i0 += 64) {
         const int i = i0 + lane;
         const bool live = i < nsub && 64 * i < T;
-        const float x = live ? row[i] + escale * gnmax[i] : -INFINITY;      // the sub-chunk's upper bound
+        const float x = live ? row[i] + (escale * gnmax[i] + PC_SS_G0 * gnmax[nsub_real + i]) : -INFINITY;      // the sub-chunk's upper bound
         unsigned long long mask = __ballot(live && x >= tau);
         while (mask) {                                       // wave-uniform: K trips in all (more on tied maxima)
             const int j0 = __ffsll((long long)mask) - 1;
@@ -2129,7 +2142,7 @@ static FusedWs fused_ws_layout(void* base, int B, int T, int K) {
         w.csamp = (float*)take((size_t)B * LH * 4);                // hd: the dropped hidden rows
         w.gmat = (float*)take((size_t)T * LH * 4);
         w.g0 = (float*)take((size_t)T * 4);
-        w.gnmax = (float*)take((size_t)((T + UT - 1) / UT) * 4);
+        w.gnmax = (float*)take((size_t)2 * ((T + UT - 1) / UT) * 4);     // the sub-chunks' largest |G[t]|, then their largest |g0[t]|
     }
     w.total = off;
     return w;
