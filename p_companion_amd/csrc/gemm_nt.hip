@@ -100,10 +100,13 @@ extern "C" int pc_debug_nt_timing(unsigned long long* out, int reset) {
     return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(pc_nt_timing), sizeof(unsigned long long) * 32 * 4);
 }
 #endif
-template <int NWM, int NWN, int BK, int WPS, bool PRO, int EPI, int STATS>
+// NBN: 32-column blocks per wave (2: 64 x 64 wave tiles; 4: 64 x 128 -- six operand splits and twelve fragment reads per 48 products
+// instead of eight and sixteen)
+template <int NWM, int NWN, int BK, int WPS, bool PRO, int EPI, int STATS, int NBN = 2>
 __global__ __launch_bounds__(64 * NWM * NWN, WPS) void gemm_nt_kernel(NtArgs a, int ntn, int total_tiles) {
     constexpr int NW = NWM * NWN, THREADS = 64 * NW;
-    constexpr int BM = 64 * NWM, BN = 64 * NWN, SR = BM + BN;     // stage rows: A image then W image
+    constexpr int WNC = 32 * NBN;                                 // columns per wave
+    constexpr int BM = 64 * NWM, BN = WNC * NWN, SR = BM + BN;    // stage rows: A image then W image
     constexpr int CPR = BK / 4;                   // 16-B chunks per stage row
     constexpr int RB = 64 / BK;                   // stage rows per 256 B (one pass over the 64 banks)
     constexpr int RPI = 256 / BK;                 // stage rows one wave instruction fills (1 KB)
@@ -205,12 +208,12 @@ __global__ __launch_bounds__(64 * NWM * NWN, WPS) void gemm_nt_kernel(NtArgs a, 
         }
     };
 
-    f32x16 acc[2][2];
+    f32x16 acc[2][NBN];
     auto zero_acc = [&]() {
 #pragma unroll
         for (int i = 0; i < 2; i++)
 #pragma unroll
-            for (int j = 0; j < 2; j++)
+            for (int j = 0; j < NBN; j++)
 #pragma unroll
                 for (int r = 0; r < 16; r++) acc[i][j][r] = 0.f;
     };
@@ -229,7 +232,7 @@ __global__ __launch_bounds__(64 * NWM * NWN, WPS) void gemm_nt_kernel(NtArgs a, 
         for (int g = 0; g < BK / 16; g++) {
             const int c0 = (((4 * g + 2 * (lane >> 5)) ^ gsw) << 2), c1 = (((4 * g + 2 * (lane >> 5) + 1) ^ gsw) << 2);
             const float* ar = cur + (wm * 64 + fr) * BK;
-            const float* br = cur + (BM + wn * 64 + fr) * BK;
+            const float* br = cur + (BM + wn * WNC + fr) * BK;
             // developer builds (scripts/dev/nt_decompose.sh; WRONG results, right instruction mix): what each part of the
             // loop costs.  -DPC_EXP_NO_SPLIT fragments used unsplit, -DPC_EXP_NO_LDSREAD fragments from loop-invariant
             // registers, -DPC_EXP_NO_MFMA products replaced by a register keep-alive, -DPC_EXP_NO_DMA only the first
@@ -257,7 +260,7 @@ __global__ __launch_bounds__(64 * NWM * NWN, WPS) void gemm_nt_kernel(NtArgs a, 
                 sa[i] = PC_SPLIT(lo, hi);
             }
 #pragma unroll
-            for (int j = 0; j < 2; j++) {
+            for (int j = 0; j < NBN; j++) {
                 const float4 wlo = PC_FRAG(br + j * 32 * BK, c0), whi = PC_FRAG(br + j * 32 * BK, c1);
                 const Split3 sb = PC_SPLIT(wlo, whi);
 #define PC_TERM(PA, PB)                                                   \
@@ -373,7 +376,7 @@ __global__ __launch_bounds__(64 * NWM * NWN, WPS) void gemm_nt_kernel(NtArgs a, 
         float4 xq[ADEPTH][2];
         auto aux_load = [&](int h, float4 (&x4)[2]) {
             const int nt = h >> 2, mt = (h >> 1) & 1, half = h & 1;
-            const int col = n0 + wn * 64 + nt * 32 + ec;
+            const int col = n0 + wn * WNC + nt * 32 + ec;
 #pragma unroll
             for (int i = 0; i < 2; i++) {
                 const int row = row0 + wm * 64 + mt * 32 + half * 16 + er + 8 * i;
@@ -395,9 +398,9 @@ __global__ __launch_bounds__(64 * NWM * NWN, WPS) void gemm_nt_kernel(NtArgs a, 
         }
         float bias[4], cs1[4], cs2[4];
 #pragma unroll
-        for (int h = 0; h < 8; h++) {
+        for (int h = 0; h < 4 * NBN; h++) {
             const int nt = h >> 2, mt = (h >> 1) & 1, half = h & 1;
-            const int col = n0 + wn * 64 + nt * 32 + ec;
+            const int col = n0 + wn * WNC + nt * 32 + ec;
             if ((h & 3) == 0) {
 #pragma unroll
                 for (int q = 0; q < 4; q++) {
@@ -458,7 +461,7 @@ __global__ __launch_bounds__(64 * NWM * NWN, WPS) void gemm_nt_kernel(NtArgs a, 
                     }
                 }
             }
-            if (HAS_AUX && h + ADEPTH < 8) aux_load(h + ADEPTH, xq[h % ADEPTH]);
+            if (HAS_AUX && h + ADEPTH < 4 * NBN) aux_load(h + ADEPTH, xq[h % ADEPTH]);
             __builtin_amdgcn_wave_barrier();
             if (STATS != NT_STAT_NONE && (h & 3) == 3) {
                 // fold the 8 row groups of the wave (lane >> 3); the M-waves meet in `red`
@@ -468,7 +471,7 @@ __global__ __launch_bounds__(64 * NWM * NWN, WPS) void gemm_nt_kernel(NtArgs a, 
 #pragma unroll
                     for (int o = 8; o <= 32; o <<= 1) { s1 += __shfl_xor(s1, o, 64); s2 += __shfl_xor(s2, o, 64); }
                     if (lane < 8) {
-                        const int c = wn * 64 + nt * 32 + lane * 4 + q;
+                        const int c = wn * WNC + nt * 32 + lane * 4 + q;
                         red[(0 * NWM + wm) * BN + c] = s1;
                         red[(1 * NWM + wm) * BN + c] = s2;
                     }
@@ -1153,11 +1156,19 @@ static void launch_variant(const NtArgs& a, int ntm, hipStream_t st) {
         // epilogue -- 30-54 % of a tile's time, during which its waves only move data -- overlaps the K loops of the
         // other two: dZ1 133 -> 115 us, dZ2 79 -> 70, Linear0 71 -> 67 against the 8-wave full-width tile (step 1.135 ->
         // 1.115 ms on the same box; two 4-wave workgroups with 256 registers each: no better than the 8-wave tile).
-        const int total = (2 * ntm + 15) & ~15;                  // paired numbering (tile_geom): whole groups of 16
-        // (PRO, round 5: Linear3 too -- each of the two column tiles transforms its own copy of the A image, two chunks per
-        // thread and K-step; the 8-wave tile it replaces is ONE workgroup per CU whose waves split, multiply and wait in step)
-        PC_LAUNCH((gemm_nt_kernel<2, 2, 16, 3, PRO, EPI, STATS>), dim3(total < 768 ? total : 768), dim3(256), 0, st, a,
-                  2, total);
+        if constexpr (PRO) {
+            // Linear3 (BN + tanh prologue, light epilogue; until round 5 an 8-wave 128 x 256 tile, ONE workgroup per CU whose waves split,
+            // multiplied and waited in step: 124.4 us): 128 x 256 tiles of four waves with 64 x 128 wave tiles (NBN = 4), two
+            // workgroups per CU -- the whole N in one workgroup (A fetched and transformed once), six operand splits and twelve
+            // fragment reads per 48 products instead of eight and sixteen: 110.1 us, against 114.6 as paired 128 x 128 tiles
+            // (round 5, same box).  The epilogue-heavy products lose with two workgroups per CU (Linear0 68.5 -> 74.7, dZ2 70.8 ->
+            // 83.4, dZ1 109.0 -> 124.1: one workgroup less to cover an epilogue) and keep the paired tiles.
+            PC_LAUNCH((gemm_nt_kernel<2, 2, 16, 2, PRO, EPI, STATS, 4>), dim3(ntm < 512 ? ntm : 512), dim3(256), 0, st, a, 1, ntm);
+        } else {
+            const int total = (2 * ntm + 15) & ~15;                  // paired numbering (tile_geom): whole groups of 16
+            PC_LAUNCH((gemm_nt_kernel<2, 2, 16, 3, PRO, EPI, STATS>), dim3(total < 768 ? total : 768), dim3(256), 0, st, a,
+                      2, total);
+        }
         return;
     }
     if (PRO || a.N > 128 || STATS != NT_STAT_NONE) {
