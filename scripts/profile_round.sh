@@ -6,7 +6,16 @@
 # run the counter passes, make_profiles.py, commit, then re-run with NO_PMC=1 for bench lines that carry the fresh figure).
 # NO_BENCH=1 skips the plain default bench line (the first step).
 # Kernel trace and the two PMC counters are separate rocprofv3 passes (never --pmc with a trace of the HIP/HSA domains).
+# STAGE=n runs one slice of the whole (a gpurun call is limited to 20 minutes): 1 = the plain bench line + the two kernel traces,
+# 2 = the six counter passes of the default workloads, 3 = the DROPOUT = 0.1 legs (PD + JD), 4 = CFG3, 5 = BIG.
 set -e
+case "${STAGE:-}" in
+  1) NO_PMC=1 ;;
+  2) NO_BENCH=1; NO_TRACE=1 ;;
+  3) NO_BENCH=1; NO_TRACE=1; SKIP_MAIN_PMC=1; PD=1; JD=1 ;;
+  4) NO_BENCH=1; NO_TRACE=1; SKIP_MAIN_PMC=1; CFG3=1 ;;
+  5) NO_BENCH=1; NO_TRACE=1; SKIP_MAIN_PMC=1; BIG=1 ;;
+esac
 TAG=${1:-r03}
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$R/gpurun_out/$TAG
@@ -15,9 +24,11 @@ cd /tmp && export TMPDIR=/tmp
 if [ -z "$NO_BENCH" ]; then
 python3 $R/bench.py > $OUT/bench.json 2> $OUT/bench.err
 fi
+if [ -z "$NO_TRACE" ]; then
 rocprofv3 --kernel-trace --stats -d $OUT/prof -o $TAG -- python3 $R/bench.py --phase p2v --steps 30 --warmup 5 --no-cpu-baseline --no-sustained --no-large --no-dropout-legs > $OUT/bench_under_rocprof.json 2> $OUT/rocprof.err
 rocprofv3 --kernel-trace --stats -d $OUT/prof_joint -o ${TAG}_joint -- python3 $R/bench.py --phase joint --steps 25 --warmup 5 --no-cpu-baseline --no-sustained --no-ref-types --no-dropout-legs > $OUT/bench_joint_under_rocprof.json 2> $OUT/rocprof_joint.err
-if [ -z "$NO_PMC" ]; then
+fi
+if [ -z "$NO_PMC" ] && [ -z "$SKIP_MAIN_PMC" ]; then
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -- python3 $R/bench.py --phase p2v --steps 5 --warmup 2 --no-cpu-baseline --no-sustained --no-large --no-dropout-legs > /dev/null 2> $OUT/pmc_fetch.err
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -- python3 $R/bench.py --phase p2v --steps 5 --warmup 2 --no-cpu-baseline --no-sustained --no-large --no-dropout-legs > /dev/null 2> $OUT/pmc_write.err
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_joint_fetch -- python3 $R/bench.py --phase joint --steps 5 --warmup 2 --no-cpu-baseline --no-sustained --no-ref-types --no-dropout-legs > /dev/null 2> $OUT/pmc_joint_fetch.err
