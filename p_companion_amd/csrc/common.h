@@ -102,6 +102,9 @@ __device__ __forceinline__ int seg_of_row(const SegInfo& si, int r) {
 
 // how many identical logical rows physical row r stands for (1 unless the caller said otherwise)
 __device__ __forceinline__ float row_multiplicity(const SegInfo& si, int r) {
+#ifdef PC_EXP_NO_ROWMULT
+    return 1.f;                                   // (developer experiment: what the per-row multiplicity loads cost; WRONG statistics)
+#endif
     if (si.roww && (unsigned)(r - si.w0) < (unsigned)si.wn) return si.roww[r - si.w0];
     return r == si.wrow ? si.wmult : 1.f;
 }
