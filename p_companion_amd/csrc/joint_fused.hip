@@ -50,6 +50,7 @@ struct FusedArgs {
     float* ecsrc; int32_t* ecidx;         // [B (K + 2)][64] / [B (K + 2)]: rows added into dE_c[ecidx[r]]
     int32_t* cids;                        // [2][B] validated (clamped) query_idx / query_types for the kernels that follow
     int32_t* bad; int64_t* step_count;
+    int32_t* run_counts;                  // (large tables, sorted gradients) the four run-list counters table_sort_kernel appends through: zeroed here
     float* slabs; int slab_floats;        // WGRAD: one gradient slab per workgroup (layout: wg_off_*)
     // PAIRS: the batch is built here from labelled pairs (data_loader.py:133-157, see pc_build_complementary_batch);
     // query_idx .. neg_items above are then OUTPUTS (the batch as the loader would have handed it), written on the way
@@ -311,6 +312,7 @@ __global__ __launch_bounds__(256) void joint_tile_kernel(FusedArgs a, int ldsims
     constexpr int MBK = KC ? KC : FK;          // row blocks of the K-row products
     PC_STAMP(0);
     if (blockIdx.x == 0 && tid == 0 && a.step_count) *a.step_count += 1;     // Adam's step (read by the finish kernel)
+    if (blockIdx.x == 0 && tid < 4 && a.run_counts) a.run_counts[tid] = 0;
 
     // ---- every weight fragment this wave will multiply by, requested now (see load_b)
     BFrag<4> f_h = {}, f_dh = {}, f_s0 = {}, f_s1 = {};
@@ -1790,7 +1792,9 @@ __global__ __launch_bounds__(256) void table_reduce_kernel(TableList l0, TableLi
 #define TS_MAXN 24576       /* source rows per list (16-bit positions and row numbers) */
 #define TS_LONG 256
 #define TS_SEG_SORT 1024    /* longest run its consumer sorts (table_segsum_kernel: 2 KB of LDS); longer ones are sorted by table_sort_kernel */
-struct SortList { const int32_t* idx; int n; int32_t *sorted, *seg, *ulist; };   // sorted [n], seg [cap + 1], ulist [cap]: cap = min(n, T)
+struct SortList { const int32_t* idx; int n; int32_t* sorted; int2* seg; int32_t *medium, *longl; };
+// sorted [n]; seg [cap + 1] = {start of the run, its destination}, cap = min(n, T); medium [n / 5]: the runs of 5 .. TS_LONG rows, longl
+// [n / TS_LONG]: the longer ones (indices into seg, in no particular order); n_touch [2 + 2 list], [3 + 2 list]: their counts
 
 #ifdef PC_SORT_TIMING
 // developer build (scripts/dev/sort_phase_times.py): shader-clock stamps of list 0's thread 0 at the phases of the sort kernel
@@ -1821,39 +1825,61 @@ __device__ __forceinline__ void ts_bitonic(ts_l16* buf, int p2, int t, int nthre
     }
 }
 
+// TS_NR workgroups per list, each owning a contiguous range of the table's rows (bins): every one builds the histogram of the bins
+// up to the end of its range itself (the list is 100 KB: reading it TS_NR times costs less than one workgroup talking to
+// another), sums the ranges in front of its own to know where its rows and its runs start, and scans / places / writes out its
+// own range only -- the scan over the bins, instruction-bound on one CU, is what the split divides.
+#define TS_NR 4
 __global__ __launch_bounds__(1024) void table_sort_kernel(SortList l0, SortList l1, int T, int32_t* n_touch) {
     extern __shared__ unsigned ts_lds[];
     PC_ST(0);
-    const SortList& l = blockIdx.x ? l1 : l0;
+    const int li = (int)blockIdx.x / TS_NR, rg = (int)blockIdx.x % TS_NR;
+    // (the list's fields by value: a reference chosen at run time between two kernel-argument structs puts both in scratch)
+    SortList l;
+    l.idx = li ? l1.idx : l0.idx; l.n = li ? l1.n : l0.n; l.sorted = li ? l1.sorted : l0.sorted; l.seg = li ? l1.seg : l0.seg;
+    l.medium = li ? l1.medium : l0.medium; l.longl = li ? l1.longl : l0.longl;
     const int n = l.n;
     const int words = (T + 1) >> 1;                          // two 16-bit bins per word: bin d = half (d & 1) of word d >> 1
+    const int rw = (words + TS_NR - 1) / TS_NR;
+    const int rlo = min(words, rg * rw), rhi = min(words, rlo + rw);      // this workgroup's words
     const int npad = ((n + 1023) >> 10) << 10;
     const int hwords = words > 16384 ? words : 16384;        // (>= 64 KB: the scratch of the long runs' sorts)
     ts_l32* hist = (ts_l32*)ts_lds;                          // [hwords] counts, then running positions, then scratch
-    ts_l16* out = (ts_l16*)(hist + hwords);                  // [npad] source rows by destination
+    ts_l16* out = (ts_l16*)(hist + hwords);                  // [npad] this range's source rows by destination
     ts_l32* longs = (ts_l32*)(out + npad);                   // [TS_MAXN / 64] runs longer than TS_SEG_SORT rows: (start << 16) | length
-    ts_l32* nlong = longs + TS_MAXN / 64;                    // [1] number of long runs, [1] rows with a destination
-    unsigned* part = reinterpret_cast<unsigned*>(ts_lds) + hwords + npad / 2 + TS_MAXN / 64 + 2;   // [16] scan scratch
+    ts_l32* nlong = longs + TS_MAXN / 64;                    // [4]: runs sorted here, -, -, -
+    unsigned* part = reinterpret_cast<unsigned*>(ts_lds) + hwords + npad / 2 + TS_MAXN / 64 + 4;   // [16] scan scratch
     const int tid = threadIdx.x;
-    for (int i = tid; i < words; i += 1024) hist[i] = 0u;
+    for (int i = tid; i < rhi; i += 1024) hist[i] = 0u;
     if (tid == 0) *nlong = 0u;
     __syncthreads();
     PC_ST(1);
-    // ---- histogram: a thread's list entries (e = tid + 1024 j) stay in registers for the placement below
+    // ---- histogram of the bins below rhi: a thread's list entries (e = tid + 1024 j) stay in registers for the placement below
     constexpr int EPT = TS_MAXN / 1024;
     int dreg[EPT];
 #pragma unroll
     for (int j = 0; j < EPT; j++) { const int e = tid + 1024 * j; dreg[j] = e < n ? l.idx[e] : -1; }
 #pragma unroll
     for (int j = 0; j < EPT; j++)
-        if ((unsigned)dreg[j] < (unsigned)T)
+        if ((unsigned)dreg[j] < (unsigned)T && (dreg[j] >> 1) < rhi)
             __hip_atomic_fetch_add(&hist[dreg[j] >> 1], (dreg[j] & 1) ? 0x10000u : 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     __syncthreads();
     PC_ST(2);
-    // ---- scan over the bins: thread t owns words [t wpt, t wpt + wpt) (read eight at a time); packed = rows (low half) | distinct
-    // destinations (high half)
-    const int wpt = (words + 1023) >> 10;
-    const int w0 = tid * wpt, w1 = min(words, w0 + wpt);
+    // ---- what lies in front of this range: packed = rows (low half) | distinct destinations (high half)
+    int before = 0;
+    for (int i = tid; i < rlo; i += 1024) {
+        const unsigned c = hist[i];
+        before += (int)((c & 0xffffu) + (c >> 16)) + (((c & 0xffffu) ? 0x10000 : 0) + ((c >> 16) ? 0x10000 : 0));
+    }
+    // total over the workgroup = the inclusive scan's value in the last thread
+    const int before_incl = block_scan_1024(before, part);
+    __shared__ int sh_base;
+    if (tid == 1023) sh_base = before_incl;
+    __syncthreads();
+    const int row_base = sh_base & 0xffff, run_base = sh_base >> 16;
+    // ---- scan over this range's bins: thread t owns words [rlo + t wpt, ... + wpt) (read eight at a time)
+    const int wpt = (rhi - rlo + 1023) >> 10;
+    const int w0 = min(rhi, rlo + tid * wpt), w1 = min(rhi, w0 + wpt);
     int packed = 0;
     for (int i0 = w0; i0 < w1; i0 += 8) {
         unsigned c[8];
@@ -1864,7 +1890,16 @@ __global__ __launch_bounds__(1024) void table_sort_kernel(SortList l0, SortList 
             packed += (int)((c[u] & 0xffffu) + (c[u] >> 16)) + (((c[u] & 0xffffu) ? 0x10000 : 0) + ((c[u] >> 16) ? 0x10000 : 0));
     }
     const int incl = block_scan_1024(packed, part);
-    int run = (incl - packed) & 0xffff, pos = (incl - packed) >> 16;
+    int run = row_base + ((incl - packed) & 0xffff), pos = run_base + ((incl - packed) >> 16);
+    // runs of more than four rows go on the consumer's lists (its workgroups take the short ones sixteen at a time and would walk
+    // a cluster of long ones -- the hot types sit side by side -- one after the other); the lists are shared by the list's
+    // workgroups (device-scope counters n_touch[2 + 2 list], [3 + 2 list], zeroed by the tile kernel of the step); runs beyond
+    // TS_SEG_SORT rows are sorted below
+    auto note_run = [&](int r, unsigned start, unsigned c) {
+        if (c > TS_LONG) l.longl[atomicAdd(&n_touch[3 + 2 * li], 1)] = r;
+        else if (c > 4u) l.medium[atomicAdd(&n_touch[2 + 2 * li], 1)] = r;
+        if (c > TS_SEG_SORT) longs[__hip_atomic_fetch_add(nlong, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)] = ((start - (unsigned)row_base) << 16) | c;
+    };
     for (int i0 = w0; i0 < w1; i0 += 8) {
         unsigned c[8];
 #pragma unroll
@@ -1875,27 +1910,31 @@ __global__ __launch_bounds__(1024) void table_sort_kernel(SortList l0, SortList 
             if (i < w1) {
                 const unsigned c0 = c[u] & 0xffffu, c1 = c[u] >> 16;
                 const unsigned s0 = (unsigned)run, s1 = s0 + c0;
-                hist[i] = s0 | (s1 << 16);                   // running positions of the two bins
-                if (c0) { l.ulist[pos] = 2 * i; l.seg[pos] = (int)s0; pos++; if (c0 > TS_SEG_SORT) longs[__hip_atomic_fetch_add(nlong, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)] = (s0 << 16) | c0; }
-                if (c1) { l.ulist[pos] = 2 * i + 1; l.seg[pos] = (int)s1; pos++; if (c1 > TS_SEG_SORT) longs[__hip_atomic_fetch_add(nlong, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)] = (s1 << 16) | c1; }
+                hist[i] = s0 | (s1 << 16);                   // running positions of the two bins (global row positions)
+                if (c0) { l.seg[pos] = make_int2((int)s0, 2 * i); note_run(pos, s0, c0); pos++; }
+                if (c1) { l.seg[pos] = make_int2((int)s1, 2 * i + 1); note_run(pos, s1, c1); pos++; }
                 run += (int)(c0 + c1);
             }
         }
     }
+    __shared__ int sh_rows;
     if (tid == 1023) {
-        n_touch[blockIdx.x] = incl >> 16;
-        l.seg[incl >> 16] = incl & 0xffff;                   // rows with a destination
-        nlong[1] = (unsigned)(incl & 0xffff);
+        sh_rows = incl & 0xffff;                             // rows of this range
+        if (rg == TS_NR - 1) {                               // the last range closes the list
+            const int nu = run_base + (incl >> 16);
+            n_touch[li] = nu;
+            l.seg[nu] = make_int2(row_base + (incl & 0xffff), -1);     // rows with a destination
+        }
     }
     __syncthreads();
-    const int incl_total_rows = (int)nlong[1];
+    const int nrows = sh_rows;
     PC_ST(3);
-    // ---- placement: the returning atomic hands every row a slot of its destination's run (in no particular order)
+    // ---- placement: the returning atomic hands every row of this range a slot of its destination's run (in no particular order)
 #pragma unroll
     for (int j = 0; j < EPT; j++)
-        if ((unsigned)dreg[j] < (unsigned)T) {
+        if ((unsigned)dreg[j] < (unsigned)T && (dreg[j] >> 1) >= rlo && (dreg[j] >> 1) < rhi) {
             const unsigned old = __hip_atomic_fetch_add(&hist[dreg[j] >> 1], (dreg[j] & 1) ? 0x10000u : 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            out[(dreg[j] & 1) ? old >> 16 : old & 0xffffu] = (unsigned short)(tid + 1024 * j);
+            out[((dreg[j] & 1) ? old >> 16 : old & 0xffffu) - (unsigned)row_base] = (unsigned short)(tid + 1024 * j);
         }
     __syncthreads();
     PC_ST(4);
@@ -1916,8 +1955,7 @@ __global__ __launch_bounds__(1024) void table_sort_kernel(SortList l0, SortList 
     }
     PC_ST(5);
     // ---- the order out to memory (runs of up to TS_SEG_SORT rows are still in placement order: their consumer sorts them)
-    const int nrows = incl_total_rows;
-    for (int i = tid; i < nrows; i += 1024) l.sorted[i] = (int)out[i];
+    for (int i = tid; i < nrows; i += 1024) l.sorted[row_base + i] = (int)out[i];
     PC_ST(6);
 }
 // LDS: [max(2 T, 64 KB)] histogram / scratch | [2 npad] order | long-run list | scan scratch
@@ -1927,11 +1965,10 @@ static size_t table_sort_hist_words(int T) {
 }
 static size_t table_sort_lds_bytes(int n, int T) {
     const size_t npad = (size_t)((n + 1023) >> 10) << 10;
-    return (table_sort_hist_words(T) + npad / 2 + TS_MAXN / 64 + 2 + 16) * 4;
+    return (table_sort_hist_words(T) + npad / 2 + TS_MAXN / 64 + 4 + 16) * 4;
 }
 static bool table_sort_fits(int n, int T) { return T <= 65535 && n <= TS_MAXN && table_sort_lds_bytes(n, T) <= 160 * 1024; }
 
-struct SegList { float* table; const float* src; const int32_t *sorted, *seg, *ulist; };
 // rows idx[0 .. m) of src added in that order, sixteen row loads in flight: the wave fetches 64 indices at a time with one load
 // (lane l: idx[c + l]) and hands them round by readlane -- one dependent chain per 64 rows instead of one per row.  LDSI: the
 // indices are 16-bit words in LDS (a run sorted there), else int32 in memory.
@@ -2021,50 +2058,106 @@ __device__ __forceinline__ void ts_bitonic_s(unsigned short* buf, int p2, int t,
         }
     }
 }
-// One wave per destination (four per workgroup).  By the length m of a destination's run:
-//   m <= TS_LONG        sorted in its wave's registers (one, two or four per lane), added by that wave
-//   m > TS_LONG         one after the other by the whole workgroup: (up to TS_SEG_SORT rows) copied into the 2 KB buffer and sorted by
-//                      all four waves, (beyond: sorted by table_sort_kernel already) then four contiguous quarters, one per wave,
-//                      folded (w0 + w1) + (w2 + w3)
-__global__ __launch_bounds__(256) void table_segsum_kernel(SegList l0, SegList l1, const int32_t* n_touch, int wgs0) {
+// By the length m of a destination's run:
+//   m <= 4              (most of them: a type a few samples selected) sixteen runs per workgroup, one 16-lane group per run, four
+//                       runs per wave instruction: the run's rows sorted over four lanes, added as float4 per lane
+//   m <= TS_LONG        (the list `medium`) one wave per run: sorted in the wave's registers (one, two or four per lane), added by
+//                       that wave
+//   m > TS_LONG         (the list `longl`) one workgroup per run: (up to TS_SEG_SORT rows) copied into the 2 KB buffer and sorted by
+//                       all four waves, (beyond: sorted by table_sort_kernel already) then four contiguous quarters, one per wave,
+//                       folded (w0 + w1) + (w2 + w3)
+// Grid regions per list: [short][medium][long], the two lists one after the other (SegGrid).  The short-run workgroups also write
+// the destination list (ulist: the touched rows of pc_joint_fused_touched, ascending).
+struct SegList { float* table; const float* src; const int32_t* sorted; const int2* seg; int32_t* ulist; const int32_t *medium, *longl; };
+struct SegGrid { int start[7]; };            // first workgroup of: short 0, medium 0, long 0, short 1, medium 1, long 1; total
+__global__ __launch_bounds__(256) void table_segsum_kernel(SegList l0, SegList l1, const int32_t* n_touch, SegGrid gr) {
     __shared__ float fold[4][PC_L];
     __shared__ unsigned short sbuf[TS_SEG_SORT];
-    const int li = (int)blockIdx.x >= wgs0 ? 1 : 0;
+    __shared__ int sh_b[17], sh_d[16];
+    const int bid = blockIdx.x;
+    int region = 0;
+#pragma unroll
+    for (int i = 1; i < 6; i++) region += bid >= gr.start[i] ? 1 : 0;
+    const int li = region >= 3 ? 1 : 0, kind = region - 3 * li, blk = bid - gr.start[region];
     const SegList& l = li ? l1 : l0;
-    const int s0 = ((int)blockIdx.x - li * wgs0) * 4;
-    const int nu = n_touch[li];
-    if (s0 >= nu) return;                                    // workgroup-uniform
-    const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int s = s0 + w;
-    if (s < nu) {
-        const int b = __builtin_amdgcn_readfirstlane(l.seg[s]), m = __builtin_amdgcn_readfirstlane(l.seg[s + 1]) - b;
-        if (m <= 64) l.table[(size_t)l.ulist[s] * PC_L + lane] = ts_sum_regs<1>(l.src, l.sorted, b, m, lane);
-        else if (m <= 128) l.table[(size_t)l.ulist[s] * PC_L + lane] = ts_sum_regs<2>(l.src, l.sorted, b, m, lane);
-        else if (m <= TS_LONG) l.table[(size_t)l.ulist[s] * PC_L + lane] = ts_sum_regs<4>(l.src, l.sorted, b, m, lane);
+    const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    if (kind == 0) {
+        const int s0 = blk * 16;
+        // (the run table is requested together with the count it is checked against: one round trip instead of two)
+        int2 e = make_int2(0, -1);
+        if (tid < 17) e = l.seg[s0 + tid];                   // (seg holds cap + 17 entries)
+        const int nu = n_touch[li];
+        if (s0 >= nu) return;                                // workgroup-uniform
+        if (tid < 17) {
+            const bool live = s0 + tid <= nu;                // entry nu closes the last run
+            sh_b[tid] = live ? e.x : 0;
+            if (tid < 16) { sh_d[tid] = (live && s0 + tid < nu) ? e.y : -1; if (s0 + tid < nu) l.ulist[s0 + tid] = e.y; }
+        }
+        __syncthreads();
+        // group g = tid >> 4, lane j of the group owns floats [4 j, 4 j + 4) of the row
+        const int g = tid >> 4, j = tid & 15;
+        const int dest = sh_d[g];
+        const int b = sh_b[g], m = dest >= 0 ? sh_b[g + 1] - b : 0;
+        if (m >= 1 && m <= 4) {
+            int x = j < m ? l.sorted[b + j] : 0x7fffffff;    // sorted over lanes 0..3 of the group (lanes 4..15 hold +infinity)
+            {
+                int o = __shfl_xor(x, 1, 64);
+                bool up = (j & 2) == 0, lower = (j & 1) == 0;
+                x = (lower == up) ? min(x, o) : max(x, o);
+                o = __shfl_xor(x, 2, 64);
+                lower = (j & 2) == 0;
+                x = lower ? min(x, o) : max(x, o);
+                o = __shfl_xor(x, 1, 64);
+                lower = (j & 1) == 0;
+                x = lower ? min(x, o) : max(x, o);
+            }
+            float4 v[4];
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                const int r = __shfl(x, (lane & ~15) + i, 64);
+                v[i] = i < m ? *reinterpret_cast<const float4*>(l.src + (size_t)r * PC_L + 4 * j) : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+            float4 acc = v[0];
+#pragma unroll
+            for (int i = 1; i < 4; i++) { acc.x += v[i].x; acc.y += v[i].y; acc.z += v[i].z; acc.w += v[i].w; }      // ascending source row
+            *reinterpret_cast<float4*>(l.table + (size_t)dest * PC_L + 4 * j) = acc;
+        }
+        return;
     }
-    __syncthreads();                                         // (the slices are free)
-    for (int q = 0; q < 4; q++) {                            // the long runs, one after the other, four waves each
-        const int sq = s0 + q;
-        if (sq >= nu) break;
-        const int b = __builtin_amdgcn_readfirstlane(l.seg[sq]), m = __builtin_amdgcn_readfirstlane(l.seg[sq + 1]) - b;
-        if (m <= TS_LONG) continue;                          // (workgroup-uniform: every wave reads the same two words)
+    if (kind == 1) {                                         // one wave per medium run
+        const int h = blk * 4 + w;
+        const int rs = h < n_touch[2 + 2 * li] ? l.medium[h] : -1;      // (the request rides with the count)
+        if (rs < 0) return;                                  // wave-uniform
+        const int2 e = l.seg[rs], e1 = l.seg[rs + 1];        // {start, destination}, {next start, -}
+        const int b = __builtin_amdgcn_readfirstlane(e.x), dest = __builtin_amdgcn_readfirstlane(e.y), m = __builtin_amdgcn_readfirstlane(e1.x) - b;
+        float r;
+        if (m <= 64) r = ts_sum_regs<1>(l.src, l.sorted, b, m, lane);
+        else if (m <= 128) r = ts_sum_regs<2>(l.src, l.sorted, b, m, lane);
+        else r = ts_sum_regs<4>(l.src, l.sorted, b, m, lane);
+        l.table[(size_t)dest * PC_L + lane] = r;
+        return;
+    }
+    {                                                        // one workgroup per long run
+        if (blk >= n_touch[3 + 2 * li]) return;
+        const int rs = l.longl[blk];
+        const int2 e = l.seg[rs], e1 = l.seg[rs + 1];
+        const int b = __builtin_amdgcn_readfirstlane(e.x), dest = __builtin_amdgcn_readfirstlane(e.y), m = __builtin_amdgcn_readfirstlane(e1.x) - b;
         const int per = (m + 3) >> 2;
         const int mb = w * per, mm = max(0, min(m, mb + per) - mb);
         float part;
         if (m <= TS_SEG_SORT) {
             int p2 = 512;
             while (p2 < m) p2 <<= 1;
-            for (int i = threadIdx.x; i < p2; i += 256) sbuf[i] = i < m ? (unsigned short)l.sorted[b + i] : (unsigned short)0xffff;
+            for (int i = tid; i < p2; i += 256) sbuf[i] = i < m ? (unsigned short)l.sorted[b + i] : (unsigned short)0xffff;
             __syncthreads();
-            ts_bitonic_s<true>(sbuf, p2, threadIdx.x, 256);
+            ts_bitonic_s<true>(sbuf, p2, tid, 256);
             part = ts_sum_rows<true>(l.src, nullptr, sbuf + mb, mm, lane);
         } else {
             part = ts_sum_rows<false>(l.src, l.sorted + b + mb, nullptr, mm, lane);
         }
         fold[w][lane] = part;
         __syncthreads();
-        if (w == 0) l.table[(size_t)l.ulist[sq] * PC_L + lane] = (fold[0][lane] + fold[1][lane]) + (fold[2][lane] + fold[3][lane]);
-        __syncthreads();
+        if (w == 0) l.table[(size_t)dest * PC_L + lane] = (fold[0][lane] + fold[1][lane]) + (fold[2][lane] + fold[3][lane]);
     }
 }
 
@@ -2074,7 +2167,8 @@ struct FusedWs {
     float *part, *h, *dpi, *dtp, *dc, *dh, *dt, *ecsrc;
     int32_t *ecidx, *cids, *ulist, *n_u, *topk_by_type;
     int32_t *tl_c, *tp_c, *tl_q, *tp_q, *n_touch;       // touched rows of the two big tables: ascending lists, row -> list position
-    int32_t *srt_c, *srt_q, *seg_c, *seg_q;             // sort path: source rows ordered by destination, start of each destination's run
+    int32_t *srt_c, *srt_q; int2 *seg_c, *seg_q;        // sort path: source rows ordered by destination, {start, destination} of each run
+    int32_t *med_c, *med_q, *lng_c, *lng_q;             // ... the runs of 5 .. TS_LONG rows and the longer ones (indices into seg)
     bool sorted_path;
     float *tslab_c, *tslab_q;                           // [TG_WGS][TG_CAP][64] each
     float* part_val;
@@ -2111,7 +2205,8 @@ static FusedWs fused_ws_layout(void* base, int B, int T, int K) {
     w.ulist = w.n_u = w.topk_by_type = nullptr;
     w.tl_c = w.tp_c = w.tl_q = w.tp_q = w.n_touch = nullptr;
     w.tslab_c = w.tslab_q = nullptr;
-    w.srt_c = w.srt_q = w.seg_c = w.seg_q = nullptr;
+    w.srt_c = w.srt_q = w.med_c = w.med_q = w.lng_c = w.lng_q = nullptr;
+    w.seg_c = w.seg_q = nullptr;
     w.sorted_path = false;
     w.part_val = nullptr;
     w.csamp = w.gmat = w.g0 = w.gnmax = nullptr;
@@ -2127,8 +2222,12 @@ static FusedWs fused_ws_layout(void* base, int B, int T, int K) {
         if (w.sorted_path) {
             w.srt_c = (int32_t*)take((size_t)nc * 4);
             w.srt_q = (int32_t*)take((size_t)B * 4);
-            w.seg_c = (int32_t*)take((size_t)((nc < T ? nc : T) + 1) * 4);
-            w.seg_q = (int32_t*)take((size_t)((B < T ? B : T) + 1) * 4);
+            w.seg_c = (int2*)take((size_t)((nc < T ? nc : T) + 17) * 8);      // (+ 16: a workgroup of the consumer requests 17 entries at once)
+            w.seg_q = (int2*)take((size_t)((B < T ? B : T) + 17) * 8);
+            w.med_c = (int32_t*)take((size_t)(nc / 5 + 1) * 4);
+            w.med_q = (int32_t*)take((size_t)(B / 5 + 1) * 4);
+            w.lng_c = (int32_t*)take((size_t)(nc / TS_LONG + 1) * 4);
+            w.lng_q = (int32_t*)take((size_t)(B / TS_LONG + 1) * 4);
         }
         w.tslab_c = (float*)take((size_t)TG_WGS * TG_CAP * PC_L * 4);      // (the LDS-table form: PC_OPT_SORTED_TABLE_GRADIENTS, below)
         w.tslab_q = (float*)take((size_t)TG_WGS * TG_CAP * PC_L * 4);
@@ -2260,6 +2359,7 @@ static int fused_step_impl(const pc_joint_tensors* p, const pc_joint_tensors* g,
     fa.topk = topk; fa.part_type = w.part; fa.part_item = w.part + B;
     fa.h = w.h; fa.dpi = w.dpi; fa.dtp = w.dtp; fa.dc = w.dc; fa.dh = w.dh; fa.dt = w.dt;
     fa.ecsrc = w.ecsrc; fa.ecidx = w.ecidx; fa.cids = w.cids; fa.bad = bad_count; fa.step_count = adam ? step_count : nullptr;
+    fa.run_counts = (!w.small && w.sorted_path) ? w.n_touch + 2 : nullptr;
     fa.slabs = w.wslabs; fa.slab_floats = w.wslab_floats;
     if (pairs_in_tile) {
         fa.pairs = src->pairs; fa.features = src->features; fa.type_idx = src->type_idx; fa.n_types_mod = src->n_types;
@@ -2328,14 +2428,21 @@ static int fused_step_impl(const pc_joint_tensors* p, const pc_joint_tensors* g,
     if (sorted_tables) {
         // table gradients: source rows sorted by destination, then one wave per destination adds its run in ascending source order
         const int nc = B * (K + 2), cap_c = nc < T ? nc : T, cap_q = B < T ? B : T;
-        const SortList sc = {w.ecidx, nc, w.srt_c, w.seg_c, w.tl_c}, sq = {w.cids + B, B, w.srt_q, w.seg_q, w.tl_q};
+        const SortList sc = {w.ecidx, nc, w.srt_c, w.seg_c, w.med_c, w.lng_c}, sq = {w.cids + B, B, w.srt_q, w.seg_q, w.med_q, w.lng_q};
         static const hipError_t sattr = hipFuncSetAttribute(reinterpret_cast<const void*>(&table_sort_kernel),
                                                             hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         (void)sattr;
-        PC_LAUNCH(table_sort_kernel, dim3(2), dim3(1024), table_sort_lds_bytes(nc, T), st, sc, sq, T, w.n_touch);
-        const SegList gc = {g->comp_types, w.ecsrc, w.srt_c, w.seg_c, w.tl_c}, gq = {g->query_types, w.dt, w.srt_q, w.seg_q, w.tl_q};
-        const int wgs_c = (cap_c + 3) / 4, wgs_q = (cap_q + 3) / 4;
-        PC_LAUNCH(table_segsum_kernel, dim3(wgs_c + wgs_q), dim3(256), 0, st, gc, gq, w.n_touch, wgs_c);
+        PC_LAUNCH(table_sort_kernel, dim3(2 * TS_NR), dim3(1024), table_sort_lds_bytes(nc, T), st, sc, sq, T, w.n_touch);
+        const SegList gc = {g->comp_types, w.ecsrc, w.srt_c, w.seg_c, w.tl_c, w.med_c, w.lng_c};
+        const SegList gq = {g->query_types, w.dt, w.srt_q, w.seg_q, w.tl_q, w.med_q, w.lng_q};
+        // grid regions sized for the capacities (the counts live on the device: workgroups past them leave at once): runs of up to
+        // four rows sixteen per workgroup, runs of 5 .. TS_LONG rows (at most n / 5 of them) a wave each, longer ones a workgroup each
+        SegGrid gr;
+        int at = 0;
+        const int sizes[6] = {(cap_c + 15) / 16, (nc / 5 + 3) / 4, nc / TS_LONG + 1, (cap_q + 15) / 16, (B / 5 + 3) / 4, B / TS_LONG + 1};
+        for (int i = 0; i < 6; i++) { gr.start[i] = at; at += sizes[i]; }
+        gr.start[6] = at;
+        PC_LAUNCH(table_segsum_kernel, dim3(at), dim3(256), 0, st, gc, gq, w.n_touch, gr);
         PC_TRY(pc_launch_status());
     } else if (!w.small) {
         // (lists too long for the sort kernel's LDS, or T > 65535) fixed-order sums over the touched rows while a table has <= TG_CAP
