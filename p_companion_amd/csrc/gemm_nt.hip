@@ -120,6 +120,11 @@ __global__ __launch_bounds__(64 * NWM * NWN, WPS) void gemm_nt_kernel(NtArgs a, 
     __shared__ __attribute__((aligned(1024))) float stages[2 * STAGE];
     __shared__ __attribute__((aligned(16))) float patch[PATCH];
     __shared__ float red[STATS != NT_STAT_NONE ? 2 * NWM * BN : 1];                           // [2 stats][NWM][BN]
+    // SUMSQ: the multiplicities of the tile's rows (a row of the unique-row layout stands for several), requested a whole tile
+    // ahead and parked here: read from memory inside the epilogue they were a dependent load per row and half-block -- 11.7 of
+    // Linear0's 67.4 us (round 5)
+    constexpr bool RWT = STATS == NT_STAT_SUMSQ;
+    __shared__ float row_wt[RWT ? BM : 1];
     __shared__ __attribute__((aligned(16))) float pro_ss[PRO ? 2 * PC_MAX_SEG * 256 : 4];   // [seg][scale|shift][K]
     // DTANH_BN: the per-column BN scale/shift of the epilogue are read from LDS at their use, not held in 8
     // registers per lane through the whole epilogue (the accumulators leave no room for them)
@@ -326,6 +331,7 @@ __global__ __launch_bounds__(64 * NWM * NWN, WPS) void gemm_nt_kernel(NtArgs a, 
     make_ptrs(nsrow, n0);
     issue(0, 0);
     zero_acc();
+    if (RWT && tid < BM) row_wt[tid] = row0 + tid < row_end ? row_multiplicity(a.seg, row0 + tid) : 0.f;
     stage_sync();
     int cur = 0;
 
@@ -338,9 +344,11 @@ __global__ __launch_bounds__(64 * NWM * NWN, WPS) void gemm_nt_kernel(NtArgs a, 
 #endif
         // next tile's identity; its gather indices are requested a whole tile early
         ntile = tile + gridDim.x;
+        float next_wt = 0.f;
         if (ntile < total_tiles) {
             tile_geom(ntile, nrow0, nrow_end, nn0, nseg);
             a_sources(nrow0, nrow_end, nsrow);
+            if (RWT && tid < BM && nrow0 + tid < nrow_end) next_wt = row_multiplicity(a.seg, nrow0 + tid);
         }
         // one K-step: start the DMA of the following chunk (this tile's, or the next tile's first),
         // then multiply the landed one
@@ -445,7 +453,7 @@ __global__ __launch_bounds__(64 * NWM * NWN, WPS) void gemm_nt_kernel(NtArgs a, 
                     v[q] = x;
                     if (rok && col + q < a.N) {
                         if (STATS == NT_STAT_SUMSQ) {
-                            const float wt = row_multiplicity(a.seg, row);            // a row may stand for many
+                            const float wt = row_wt[RWT ? row - row0 : 0];            // a row may stand for many
                             cs1[q] += wt * x; cs2[q] += wt * x * x;
                         }
                         else if (STATS == NT_STAT_BNBWD) { cs1[q] += x; cs2[q] += x * ax[q]; }      // raw moment: centred in fp64 by the finalize pass
@@ -504,6 +512,11 @@ __global__ __launch_bounds__(64 * NWM * NWN, WPS) void gemm_nt_kernel(NtArgs a, 
 #endif
         if (ntile >= total_tiles) break;
         zero_acc();
+        if (RWT) {
+            // (every wave has passed the lds_sync of the statistics fold, i.e. its last read of row_wt; the next tile's first
+            // stage_sync makes the new values visible long before its epilogue)
+            if (tid < BM) row_wt[tid] = next_wt;
+        }
         tile = ntile; row0 = nrow0; row_end = nrow_end; n0 = nn0; seg = nseg;
         // the DMA source pointers (two registers each) are rebuilt from the row indices rather than kept alive
         // across the epilogue, which is where the register budget is tightest
