@@ -389,6 +389,10 @@ __global__ __launch_bounds__(64 * NWM * NWN, WPS) void gemm_nt_kernel(NtArgs a, 
             for (int i = 0; i < 2; i++) {
                 const int row = row0 + wm * 64 + mt * 32 + half * 16 + er + 8 * i;
                 x4[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+#ifdef PC_EXP_NO_AUX
+                x4[i] = make_float4(0.25f, 0.5f, 0.125f, 0.75f);      // (developer experiment: no aux loads; WRONG results)
+                continue;
+#endif
                 if (fast) {
                     const int rc = row < row_end ? row : row_end - 1;      // clamped: the value of a dead row is never used
                     x4[i] = load_stream(a.aux + (size_t)rc * a.ldaux + col);
@@ -459,7 +463,11 @@ __global__ __launch_bounds__(64 * NWM * NWN, WPS) void gemm_nt_kernel(NtArgs a, 
                         else if (STATS == NT_STAT_BNBWD) { cs1[q] += x; cs2[q] += x * ax[q]; }      // raw moment: centred in fp64 by the finalize pass
                     }
                 }
+#ifdef PC_EXP_NO_CSTORE
+                if (rok && v[0] == 12345.678f) {                      // (developer experiment: the C stores never execute; WRONG results)
+#else
                 if (rok) {
+#endif
                     if (fast) {
                         store_stream(a.C + (size_t)row * a.ldc + col, make_float4(v[0], v[1], v[2], v[3]));
                     } else {
