@@ -348,11 +348,14 @@ def run_joint(args, rank, world, dev, types, steps, warmup, want_cpu, dropout=0.
                                            "2 (tile kernel: batch construction, forward, losses, backward and the tile's gradient slab; finish: slab "
                                             "sums + Adam)" if types <= 128 else
                                             "4 (batch builder, tile kernel, gradient products, finish + Adam)" if types <= 512 else
-                                            ("8 (hidden rows of the B samples + G = E_c dec_w, " if dropout > 0 else
-                                             "9 (distinct query types, their hidden rows + G = E_c dec_w, ") +
-                                            "sub-chunk maxima of the similarity rows with the table-gradient clear riding, exact top-K over each row's K best "
-                                            "sub-chunks, tile kernel incl. batch construction and the weight-gradient slabs, touched-row lists, per-workgroup "
-                                            "partial tables, fixed-order table sums, finish + Adam)")},
+                                            ("7 (hidden rows of the B samples + G = E_c dec_w, sub-chunk maxima of the similarity rows with the table-gradient "
+                                             "clear riding, exact top-K over each row's K best sub-chunks, tile kernel incl. batch construction and the "
+                                             "weight-gradient slabs, counting sort of the table gradients' source rows by destination, per-destination sums "
+                                             "in ascending source order, finish + Adam)" if dropout > 0 else
+                                             "9 (distinct query types, their hidden rows + G = E_c dec_w, sub-chunk maxima of the similarity rows with the "
+                                             "table-gradient clear riding, exact top-K over each row's K best sub-chunks, tile kernel incl. batch construction "
+                                             "and the weight-gradient slabs, touched-row lists, per-workgroup partial tables, fixed-order table sums, "
+                                             "finish + Adam)"))},
            "roofline": {"bound": "hbm", "kernel": "the whole step (batch builder + the fused step's kernels: a dependent chain)",
                         "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                         "frac": round(achieved / HBM_PEAK_GBS, 5),
