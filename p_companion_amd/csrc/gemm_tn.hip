@@ -286,17 +286,6 @@ __global__ __launch_bounds__(64 * WO * WI, WO * WI / 4) void gemm_tn8_kernel(TnA
     const int zrow = tid / ZT, zcol = (tid % ZT) * 4, arow = tid / AT, acol = (tid % AT) * 4;
     int zseg = -1;
     float4 zmu, zis, zsc, zc1, zc2;
-    // ZPRO: the multiplicities of the rows this thread corrects in the NEXT chunk, requested a chunk ahead (a dependent load per row
-    // inside the loader pass otherwise: 85.5 -> 82.8 us without them, round 5)
-    constexpr int ZPT = ZPRO ? TKC / (THREADS / ZT) : 1;
-    float zmul[ZPT];
-    auto load_zmul = [&](int r0) {
-#pragma unroll
-        for (int p = 0; p < ZPT; p++) {
-            const int r = r0 + zrow + (THREADS / ZT) * p;
-            zmul[p] = (ZPRO && r < r_end) ? row_multiplicity(a.seg, r) : 1.f;
-        }
-    };
     auto transform = [&](float* stage, int r0) {
         if (ZPRO && zcol < a.No) {
             float* Zs = stage;
@@ -318,7 +307,7 @@ __global__ __launch_bounds__(64 * WO * WI, WO * WI / 4) void gemm_tn8_kernel(TnA
                     const int zp = rr * ZRS + ((ZSW && (rr & 8)) ? zcol ^ 32 : zcol);
                     float4 z = *reinterpret_cast<const float4*>(&Zs[zp]);
                     const float4 h = *reinterpret_cast<const float4*>(&Hs[zp]);
-                    const float zm = zmul[p];
+                    const float zm = row_multiplicity(a.seg, r);
                     z.x = zsc.x * (z.x - zm * (zc1.x + (h.x - zmu.x) * zis.x * zc2.x));
                     z.y = zsc.y * (z.y - zm * (zc1.y + (h.y - zmu.y) * zis.y * zc2.y));
                     z.z = zsc.z * (z.z - zm * (zc1.z + (h.z - zmu.z) * zis.z * zc2.z));
@@ -388,7 +377,6 @@ __global__ __launch_bounds__(64 * WO * WI, WO * WI / 4) void gemm_tn8_kernel(TnA
 #pragma unroll
     for (int j = 0; j < TI; j++) xo[j] = (wi * (TI * 32) + 32 * j + (lane & 31)) ^ ((ASW && lane >= 32) ? 32 : 0);
     int cur = 0;
-    if (ZPRO) load_zmul(r_begin);
     for (int c = 0; c < nchunk; c++) {
 #ifndef PC_EXP_NO_VMWAIT
         if (c + NST - 1 <= nchunk) { asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NST - 2) * JALL) : "memory"); }
@@ -405,11 +393,7 @@ __global__ __launch_bounds__(64 * WO * WI, WO * WI / 4) void gemm_tn8_kernel(TnA
         }
 #endif
         float* stage = smem + cur * STAGE;
-        if (APRO || ZPRO) {
-            transform(stage, r_begin + c * TKC);
-            if (ZPRO && c + 1 < nchunk) load_zmul(r_begin + (c + 1) * TKC);      // (in flight behind this chunk's products)
-            tn_lds_sync();
-        }
+        if (APRO || ZPRO) { transform(stage, r_begin + c * TKC); tn_lds_sync(); }
         const float* Zs = stage + fz;
         const float* As = stage + (ZPRO ? 2 : 1) * ZF + fa;
 #pragma unroll
