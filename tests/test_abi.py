@@ -96,3 +96,19 @@ def test_exchange_slot_plumbing_without_a_gpu():
         buf = ctypes.create_string_buffer(128)
         assert L.pc_rccl_unique_id(None) == -1
     assert pdist.make_exchange(1) is None
+
+
+def test_no_shipped_kernel_spills_vector_registers():
+    """The code objects' own metadata (llvm-readelf --notes on the gfx950 images of the compiled units): no kernel keeps vector
+    registers in scratch, and the only private segments are the one-time generators' / the stand-alone batch builder's."""
+    from p_companion_amd import build
+    build.build()
+    res = build.kernel_resources()
+    assert len(res) > 100
+    assert not [(n, r["vgpr_spill_count"]) for n, r in res.items() if r["vgpr_spill_count"] > 0]
+    allowed = ("gen_coview_kernel", "gen_complementary_kernel", "build_complementary_batch_kernel")
+    assert all(any(a in n for a in allowed) for n, r in res.items() if r["private_segment_fixed_size"] > 0)
+    # the two persistent GEMM families at the occupancies their launches are sized for (registers per lane: 512 / waves per SIMD)
+    for n, r in res.items():
+        if "gemm_nt_kernelILi2ELi2ELi16ELi3E" in n:
+            assert r["vgpr_count"] <= 168, (n, r["vgpr_count"])          # three workgroups of four waves per CU
