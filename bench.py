@@ -290,6 +290,7 @@ def run_joint(args, rank, world, dev, types, steps, warmup, want_cpu, dropout=0.
         step(last)
     ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
     if multi:
+        torch.cuda.synchronize()          # (the device drained first: torch's communicator never runs beside the library's)
         torch.distributed.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -454,6 +455,7 @@ def run_p2v(args, rank, world, dev, products, steps, warmup, want_cpu, profile_k
     # (every loader call of the region is inside it: `steps` next() calls and `steps` train steps between the two clocks, as in a
     # caller's loop -- round 4 took the first batch before the clock started)
     if multi:
+        torch.cuda.synchronize()          # (the device drained first: torch's communicator never runs beside the library's)
         torch.distributed.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -568,6 +570,7 @@ def run_p2v(args, rank, world, dev, products, steps, warmup, want_cpu, profile_k
             step(next(it))
         for _rep in range(3):
             if multi:
+                torch.cuda.synchronize()
                 torch.distributed.barrier()
             torch.cuda.synchronize()
             ts = time.perf_counter()
@@ -678,6 +681,10 @@ def guarded(name, fn, world):
     if world > 1:
         import torch.distributed as dist
         flag = torch.tensor([0 if err else 1], dtype=torch.int32, device="cpu" if dist.get_backend() == "gloo" else torch.device("cuda", torch.cuda.current_device()))
+        try:
+            torch.cuda.synchronize()      # (a loader may still have lookups of batches nobody will train on in flight on the library's communicator)
+        except Exception:                 # noqa: BLE001
+            pass
         dist.all_reduce(flag, op=dist.ReduceOp.MIN)
         if int(flag.item()) == 0 and err is None:
             err = "failed on another rank"
