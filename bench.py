@@ -842,6 +842,9 @@ def main():
                      (" + P-Companion joint step under `joint`" if joint else ""),
            "value": round(p2v["value"], 1), **common, "ms_per_step": round(p2v["ms_per_step"], 4),
            "host_enqueue_ms_per_step": p2v.get("host_enqueue_ms_per_step"),
+           "host_enqueue_note": "wall time of the host between the region's two clocks / steps: its own work (~0.34 ms per step: loader next() "
+                                "0.11, train_step_indexed 0.18, optimizer.step 0.05 -- scripts/dev/host_breakdown.py) plus the time it waits "
+                                "behind a full launch queue; below ms_per_step = the device is the bound, not the host",
            "dtype_note": "fp32 storage, accumulation and result accuracy; the large GEMMs evaluate each fp32 product as six "
                          "bf16 matrix-core products of a three-way split (error <= the fp32 MFMA's, tests/test_gpu_ops.py)",
            "config": {"workload": f"Product2Vec GAT pretrain, {args.products} products, {args.types} types, dim={args.dim}, "
