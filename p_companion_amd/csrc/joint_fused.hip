@@ -1791,18 +1791,18 @@ __global__ __launch_bounds__(256) void table_reduce_kernel(TableList l0, TableLi
 // and fully unrolled loops, then rolled with the state in LDS -- took 160 and 77 us: instruction fetch, then the ballots.)
 #define TS_MAXN 24576       /* source rows per list (16-bit positions and row numbers) */
 #define TS_LONG 256
-#define TS_SEG_SORT 1024    /* longest run its consumer sorts (table_segsum_kernel: 2 KB of LDS); longer ones are sorted by table_sort_kernel */
-struct SortList { const int32_t* idx; int n; int32_t* sorted; int2* seg; int32_t *medium, *longl; };
-// sorted [n]; seg [cap + 1] = {start of the run, its destination}, cap = min(n, T); medium [n / 5]: the runs of 5 .. TS_LONG rows, longl
-// [n / TS_LONG]: the longer ones (indices into seg, in no particular order); n_touch [2 + 2 list], [3 + 2 list]: their counts
+struct SortList { const int32_t* idx; int n; int32_t* sorted; int2* seg; int32_t *medium, *longl, *nruns; };
+// sorted [n]; seg [TS_NR ts_range_stride(T)] = {start of the run, its destination}, one stretch per range of the table's rows (see
+// table_sort_kernel), nruns [TS_NR]: the runs in each; medium [n / 5]: the runs of 5 .. TS_LONG rows, longl [n / TS_LONG]: the longer
+// ones (indices into seg, in no particular order); n_touch [2 + 2 list], [3 + 2 list]: their counts
 
 #ifdef PC_SORT_TIMING
-// developer build (scripts/dev/sort_phase_times.py): shader-clock stamps of list 0's thread 0 at the phases of the sort kernel
-__device__ unsigned long long pc_sort_timing[16];
+// developer build (scripts/dev/sort_phase_times.py): shader-clock stamps of every workgroup's thread 0 at the phases of the sort kernel
+__device__ unsigned long long pc_sort_timing[1024];
 extern "C" int pc_debug_sort_timing(unsigned long long* out) {
-    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(pc_sort_timing), sizeof(unsigned long long) * 16);
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(pc_sort_timing), sizeof(unsigned long long) * 1024);
 }
-#define PC_ST(i) do { if (blockIdx.x == 0 && threadIdx.x == 0) pc_sort_timing[i] = __builtin_amdgcn_s_memtime(); } while (0)
+#define PC_ST(i) do { if (threadIdx.x == 0) pc_sort_timing[blockIdx.x * 16 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
 #else
 #define PC_ST(i) do { } while (0)
 #endif
@@ -1825,11 +1825,45 @@ __device__ __forceinline__ void ts_bitonic(ts_l16* buf, int p2, int t, int nthre
     }
 }
 
-// TS_NR workgroups per list, each owning a contiguous range of the table's rows (bins): every one builds the histogram of the bins
-// up to the end of its range itself (the list is 100 KB: reading it TS_NR times costs less than one workgroup talking to
-// another), sums the ranges in front of its own to know where its rows and its runs start, and scans / places / writes out its
-// own range only -- the scan over the bins, instruction-bound on one CU, is what the split divides.
-#define TS_NR 4
+// inclusive prefix sums of a and of b over the 1024 threads of a workgroup and the workgroup's total of c (returned in c): shuffles
+// inside each wave, the 3 x 16 wave totals through LDS (one barrier: ws is not in use before the call), where sixteen lanes of
+// every wave scan them again
+__device__ __forceinline__ void block_scan3_1024(int& a, int& b, int& c, ts_l32* ws /* [48] */) {
+    const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const int ua = __shfl_up(a, o, 64), ub = __shfl_up(b, o, 64), uc = __shfl_up(c, o, 64);
+        if (lane >= o) { a += ua; b += ub; c += uc; }
+    }
+    if (lane == 63) { ws[w] = (unsigned)a; ws[16 + w] = (unsigned)b; ws[32 + w] = (unsigned)c; }
+    __syncthreads();
+    int ta = 0, tb = 0, tc = 0;
+    if (lane < 16) { ta = (int)ws[lane]; tb = (int)ws[16 + lane]; tc = (int)ws[32 + lane]; }
+#pragma unroll
+    for (int o = 1; o < 16; o <<= 1) {
+        const int ua = __shfl_up(ta, o, 64), ub = __shfl_up(tb, o, 64), uc = __shfl_up(tc, o, 64);
+        if (lane >= o) { ta += ua; tb += ub; tc += uc; }
+    }
+    // waves in front of this one: lane w - 1 of the inclusive scan
+    const int ba = __builtin_amdgcn_readlane(ta, (w + 15) & 15), bb = __builtin_amdgcn_readlane(tb, (w + 15) & 15);
+    a += w ? ba : 0; b += w ? bb : 0;
+    c = __builtin_amdgcn_readlane(tc, 15);
+}
+
+// TS_NR workgroups per list, each owning a contiguous range of the table's rows (bins) and everything that follows from it: the
+// counts of ITS bins, ITS stretch of the order (starting at the number of list entries that point below the range: counted
+// while the list is read, no histogram needed) and ITS part of the run table (TS_NR stretches of ts_range_stride entries, each
+// closed by {end, -1}; nruns[range] = runs in it: what lies in front of a range -- the position of a run in the dense touched-row
+// list -- is summed by the consumer from those sixteen counts).  Every workgroup reads the whole list (80 KB, L2) and keeps its
+// own entries; nothing passes between workgroups.  The chip clocks near 1 GHz under this step's load (clock64 against the
+// kernel's duration): a phase that looks free at 2.4 GHz -- a barrier of sixteen waves, a round of shuffles -- is ~1 us here, so
+// the kernel is built from as few of them as it can be.
+#ifndef TS_NR
+#define TS_NR 16
+#endif
+static_assert(TS_NR <= 16, "the consumer sums the ranges' run counts over sixteen lanes");
+__host__ __device__ inline int ts_range_words(int T) { return (((T + 1) >> 1) + TS_NR - 1) / TS_NR; }
+__host__ __device__ inline int ts_range_stride(int T) { return 2 * ts_range_words(T) + 1; }       // runs of a range + its closing entry
 __global__ __launch_bounds__(1024) void table_sort_kernel(SortList l0, SortList l1, int T, int32_t* n_touch) {
     extern __shared__ unsigned ts_lds[];
     PC_ST(0);
@@ -1837,165 +1871,174 @@ __global__ __launch_bounds__(1024) void table_sort_kernel(SortList l0, SortList 
     // (the list's fields by value: a reference chosen at run time between two kernel-argument structs puts both in scratch)
     SortList l;
     l.idx = li ? l1.idx : l0.idx; l.n = li ? l1.n : l0.n; l.sorted = li ? l1.sorted : l0.sorted; l.seg = li ? l1.seg : l0.seg;
-    l.medium = li ? l1.medium : l0.medium; l.longl = li ? l1.longl : l0.longl;
+    l.medium = li ? l1.medium : l0.medium; l.longl = li ? l1.longl : l0.longl; l.nruns = li ? l1.nruns : l0.nruns;
     const int n = l.n;
     const int words = (T + 1) >> 1;                          // two 16-bit bins per word: bin d = half (d & 1) of word d >> 1
-    const int rw = (words + TS_NR - 1) / TS_NR;
-    const int rlo = min(words, rg * rw), rhi = min(words, rlo + rw);      // this workgroup's words
+    const int rw = ts_range_words(T), rs = ts_range_stride(T);
+    const int rlo = min(words, rg * rw), nw = min(words, rlo + rw) - rlo;      // this workgroup's words: [rlo, rlo + nw)
     const int npad = ((n + 1023) >> 10) << 10;
-    const int hwords = words > 16384 ? words : 16384;        // (>= 64 KB: the scratch of the long runs' sorts)
-    ts_l32* hist = (ts_l32*)ts_lds;                          // [hwords] counts, then running positions, then scratch
-    ts_l16* out = (ts_l16*)(hist + hwords);                  // [npad] this range's source rows by destination
-    ts_l32* longs = (ts_l32*)(out + npad);                   // [TS_MAXN / 64] runs longer than TS_SEG_SORT rows: (start << 16) | length
-    ts_l32* nlong = longs + TS_MAXN / 64;                    // [4]: runs sorted here, -, -, -
-    unsigned* part = reinterpret_cast<unsigned*>(ts_lds) + hwords + npad / 2 + TS_MAXN / 64 + 4;   // [16] scan scratch
+    ts_l32* hist = (ts_l32*)ts_lds;                          // [rw] counts, then running positions
+    ts_l16* out = (ts_l16*)(hist + rw);                      // [npad] run table in the making, then this range's source rows by destination
+    ts_l32* part = (ts_l32*)(out + npad);                    // [48] scan scratch
     const int tid = threadIdx.x;
-    for (int i = tid; i < rhi; i += 1024) hist[i] = 0u;
-    if (tid == 0) *nlong = 0u;
-    __syncthreads();
-    PC_ST(1);
-    // ---- histogram of the bins below rhi: a thread's list entries (e = tid + 1024 j) stay in registers for the placement below
+    // a thread's list entries (e = tid + 1024 j): requested before anything else -- written by the previous kernel on other
+    // XCDs, they come from memory while the bins are cleared -- and kept in registers for the placement below
     constexpr int EPT = TS_MAXN / 1024;
     int dreg[EPT];
 #pragma unroll
     for (int j = 0; j < EPT; j++) { const int e = tid + 1024 * j; dreg[j] = e < n ? l.idx[e] : -1; }
+    for (int i = tid; i < nw; i += 1024) hist[i] = 0u;
+    __syncthreads();
+    PC_ST(1);
+    // ---- counts of this range's bins; entries that point below the range are counted (their rows come first in the order);
+    // from here on dreg holds the bin RELATIVE to the range, -1 for every entry that is not this workgroup's
+    int below = 0;
 #pragma unroll
-    for (int j = 0; j < EPT; j++)
-        if ((unsigned)dreg[j] < (unsigned)T && (dreg[j] >> 1) < rhi)
-            __hip_atomic_fetch_add(&hist[dreg[j] >> 1], (dreg[j] & 1) ? 0x10000u : 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    for (int j = 0; j < EPT; j++) {
+        const int d = dreg[j], w = (d >> 1) - rlo;
+        const bool valid = (unsigned)d < (unsigned)T;
+        below += (valid && w < 0) ? 1 : 0;
+        const bool mine = valid && (unsigned)w < (unsigned)nw;
+        dreg[j] = mine ? d - 2 * rlo : -1;
+        if (mine) __hip_atomic_fetch_add(&hist[w], (d & 1) ? 0x10000u : 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    }
     __syncthreads();
     PC_ST(2);
-    // ---- what lies in front of this range: packed = rows (low half) | distinct destinations (high half)
-    int before = 0;
-    for (int i = tid; i < rlo; i += 1024) {
-        const unsigned c = hist[i];
-        before += (int)((c & 0xffffu) + (c >> 16)) + (((c & 0xffffu) ? 0x10000 : 0) + ((c >> 16) ? 0x10000 : 0));
+    // ---- scan over the range's bins: thread t owns words [t wpt, ... + wpt) (one or two at the shipped sizes).
+    // packed = rows (low half) | destinations (high half); lists = runs of 5 .. TS_LONG rows (low half) | longer ones (high half)
+    const int wpt = (nw + 1023) >> 10;
+    const int w0 = min(nw, tid * wpt), w1 = min(nw, w0 + wpt);
+    int packed = 0, lists = 0;
+    for (int i = w0; i < w1; i++) {
+        const unsigned c = hist[i], c0 = c & 0xffffu, c1 = c >> 16;
+        packed += (int)(c0 + c1) + ((c0 ? 0x10000 : 0) + (c1 ? 0x10000 : 0));
+        lists += (c0 > TS_LONG ? 0x10000 : c0 > 4u ? 1 : 0) + (c1 > TS_LONG ? 0x10000 : c1 > 4u ? 1 : 0);
     }
-    // total over the workgroup = the inclusive scan's value in the last thread
-    const int before_incl = block_scan_1024(before, part);
-    __shared__ int sh_base;
-    if (tid == 1023) sh_base = before_incl;
-    __syncthreads();
-    const int row_base = sh_base & 0xffff, run_base = sh_base >> 16;
-    // ---- scan over this range's bins: thread t owns words [rlo + t wpt, ... + wpt) (read eight at a time)
-    const int wpt = (rhi - rlo + 1023) >> 10;
-    const int w0 = min(rhi, rlo + tid * wpt), w1 = min(rhi, w0 + wpt);
-    int packed = 0;
-    for (int i0 = w0; i0 < w1; i0 += 8) {
-        unsigned c[8];
-#pragma unroll
-        for (int u = 0; u < 8; u++) c[u] = i0 + u < w1 ? (unsigned)hist[i0 + u] : 0u;
-#pragma unroll
-        for (int u = 0; u < 8; u++)
-            packed += (int)((c[u] & 0xffffu) + (c[u] >> 16)) + (((c[u] & 0xffffu) ? 0x10000 : 0) + ((c[u] >> 16) ? 0x10000 : 0));
-    }
-    const int incl = block_scan_1024(packed, part);
-    int run = row_base + ((incl - packed) & 0xffff), pos = run_base + ((incl - packed) >> 16);
-    // runs of more than four rows go on the consumer's lists (its workgroups take the short ones sixteen at a time and would walk
-    // a cluster of long ones -- the hot types sit side by side -- one after the other); the lists are shared by the list's
-    // workgroups (device-scope counters n_touch[2 + 2 list], [3 + 2 list], zeroed by the tile kernel of the step); runs beyond
-    // TS_SEG_SORT rows are sorted below
-    auto note_run = [&](int r, unsigned start, unsigned c) {
-        if (c > TS_LONG) l.longl[atomicAdd(&n_touch[3 + 2 * li], 1)] = r;
-        else if (c > 4u) l.medium[atomicAdd(&n_touch[2 + 2 * li], 1)] = r;
-        if (c > TS_SEG_SORT) longs[__hip_atomic_fetch_add(nlong, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)] = ((start - (unsigned)row_base) << 16) | c;
-    };
-    for (int i0 = w0; i0 < w1; i0 += 8) {
-        unsigned c[8];
-#pragma unroll
-        for (int u = 0; u < 8; u++) c[u] = i0 + u < w1 ? (unsigned)hist[i0 + u] : 0u;
-#pragma unroll
-        for (int u = 0; u < 8; u++) {
-            const int i = i0 + u;
-            if (i < w1) {
-                const unsigned c0 = c[u] & 0xffffu, c1 = c[u] >> 16;
-                const unsigned s0 = (unsigned)run, s1 = s0 + c0;
-                hist[i] = s0 | (s1 << 16);                   // running positions of the two bins (global row positions)
-                if (c0) { l.seg[pos] = make_int2((int)s0, 2 * i); note_run(pos, s0, c0); pos++; }
-                if (c1) { l.seg[pos] = make_int2((int)s1, 2 * i + 1); note_run(pos, s1, c1); pos++; }
-                run += (int)(c0 + c1);
-            }
-        }
-    }
-    __shared__ int sh_rows;
-    if (tid == 1023) {
-        sh_rows = incl & 0xffff;                             // rows of this range
-        if (rg == TS_NR - 1) {                               // the last range closes the list
-            const int nu = run_base + (incl >> 16);
-            n_touch[li] = nu;
-            l.seg[nu] = make_int2(row_base + (incl & 0xffff), -1);     // rows with a destination
-        }
-    }
-    __syncthreads();
-    const int nrows = sh_rows;
+    int incl = packed, lincl = lists;
     PC_ST(3);
+    block_scan3_1024(incl, lincl, below, part);
+    PC_ST(4);
+    const int row_base = below;                              // rows in front of this range's
+    const int run0 = row_base + ((incl - packed) & 0xffff), pos0 = (incl - packed) >> 16;
+    // ---- run lists: runs of more than four rows go on the consumer's lists (its workgroups take the short ones sixteen at a time
+    // and would walk a cluster of long ones -- the hot types sit side by side -- one after the other).  The lists are shared by
+    // the list's workgroups: ONE returning device atomic per workgroup and list reserves its entries (counters n_touch[2 + 2 list],
+    // [3 + 2 list], zeroed by the tile kernel of the step) -- issued here, answered while the placement below runs (one per run
+    // from the thread that scans it -- ten dependent round trips to L2 in a row -- was 60 % of an earlier form of this kernel)
+    __shared__ int sh_lbase[2], sh_rows, sh_runs;
+    int mres = 0, lres = 0;                                  // (handed to the workgroup behind the placement: no wait here)
+    if (tid == 1023) {
+        const int nm = lincl & 0xffff, nl = lincl >> 16, rows = incl & 0xffff, runs = incl >> 16;
+        if (nm) mres = atomicAdd(&n_touch[2 + 2 * li], nm);
+        if (nl) lres = atomicAdd(&n_touch[3 + 2 * li], nl);
+        sh_rows = rows; sh_runs = runs;
+        l.nruns[rg] = runs;
+        l.seg[(size_t)rg * rs + runs] = make_int2(row_base + rows, -1);       // closes the range's last run
+    }
+    {
+        int run = run0, pos = pos0;
+        for (int i = w0; i < w1; i++) {
+            const unsigned c = hist[i], c0 = c & 0xffffu, c1 = c >> 16;
+            const unsigned s0 = (unsigned)run, s1 = s0 + c0;
+            hist[i] = s0 | (s1 << 16);                       // running positions of the two bins (positions in the whole order)
+            // (the run table goes out from LDS below: written from here, a wave's store scatters over ~50 cache lines)
+            if (c0) { out[pos] = (unsigned short)(2 * i); pos++; }
+            if (c1) { out[pos] = (unsigned short)(2 * i + 1); pos++; }
+            run += (int)(c0 + c1);
+        }
+    }
+    PC_ST(5);
+    __syncthreads();
+    PC_ST(6);
+    const int nrows = sh_rows;
+    // the run table of this range, dense: {start of the run (its bin's running position, not yet advanced), destination}
+    for (int q = tid; q < sh_runs; q += 1024) {
+        const unsigned d = out[q], h = hist[d >> 1];
+        l.seg[(size_t)rg * rs + q] = make_int2((int)((d & 1u) ? h >> 16 : h & 0xffffu), 2 * rlo + (int)d);
+    }
+    __syncthreads();                                         // (`out` is the placement's from here)
+    PC_ST(7);
     // ---- placement: the returning atomic hands every row of this range a slot of its destination's run (in no particular order)
 #pragma unroll
     for (int j = 0; j < EPT; j++)
-        if ((unsigned)dreg[j] < (unsigned)T && (dreg[j] >> 1) >= rlo && (dreg[j] >> 1) < rhi) {
+        if (dreg[j] >= 0) {
             const unsigned old = __hip_atomic_fetch_add(&hist[dreg[j] >> 1], (dreg[j] & 1) ? 0x10000u : 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             out[((dreg[j] & 1) ? old >> 16 : old & 0xffffu) - (unsigned)row_base] = (unsigned short)(tid + 1024 * j);
         }
+    if (tid == 1023) { sh_lbase[0] = mres; sh_lbase[1] = lres; }
     __syncthreads();
-    PC_ST(4);
-    // ---- runs longer than TS_SEG_SORT rows (a destination most of the batch points at: rare) are sorted here, by the whole
-    // workgroup one after the other, in a scratch copy padded to a power of two (the histogram's words are dead now: they are the
-    // scratch -- at least 64 KB, see table_sort_lds_bytes); every shorter run is sorted by the wave(s) that consume it
-    const unsigned nl = *nlong;
-    ts_l16* scratch = (ts_l16*)hist;
-    for (unsigned q = 0; q < nl; q++) {
-        const unsigned rec = longs[q], start = rec >> 16, len = rec & 0xffffu;
-        int p2 = 2048;
-        while ((unsigned)p2 < len) p2 <<= 1;                 // <= 32768 = 64 KB of scratch
-        for (int i = tid; i < p2; i += 1024) scratch[i] = (unsigned)i < len ? (unsigned short)out[start + i] : (unsigned short)0xffff;
-        __syncthreads();
-        ts_bitonic<true>(scratch, p2, tid, 1024);
-        for (int i = tid; i < (int)len; i += 1024) out[start + i] = scratch[i];
-        __syncthreads();
+    PC_ST(8);
+    // ---- the run lists' entries: the placement left every bin's END in its half word, so a second walk over the thread's words
+    // has the lengths again
+    {
+        int mpos = sh_lbase[0] + ((lincl - lists) & 0xffff), lpos = sh_lbase[1] + ((lincl - lists) >> 16);
+        unsigned prev = (unsigned)run0;
+        int r = rg * rs + pos0;                              // the run's entry in the table
+        for (int i = w0; i < w1; i++) {
+            const unsigned h = hist[i], e0 = h & 0xffffu, e1 = h >> 16;
+            const unsigned cc[2] = {e0 - prev, e1 - e0};
+#pragma unroll
+            for (int u = 0; u < 2; u++) {
+                if (cc[u]) {
+                    if (cc[u] > TS_LONG) l.longl[lpos++] = r;
+                    else if (cc[u] > 4u) l.medium[mpos++] = r;
+                    r++;
+                }
+            }
+            prev = e1;
+        }
     }
-    PC_ST(5);
-    // ---- the order out to memory (runs of up to TS_SEG_SORT rows are still in placement order: their consumer sorts them)
+    PC_ST(9);
+    // ---- the order out to memory: every run in placement order -- the wave that consumes a run of up to TS_LONG rows sorts it in
+    // its registers; a longer one is not read from here at all (its consumer filters the list itself, in list order)
     for (int i = tid; i < nrows; i += 1024) l.sorted[row_base + i] = (int)out[i];
-    PC_ST(6);
+    PC_ST(10);
 }
-// LDS: [max(2 T, 64 KB)] histogram / scratch | [2 npad] order | long-run list | scan scratch
-static size_t table_sort_hist_words(int T) {
-    const size_t w = (size_t)((T + 1) >> 1);
-    return w > 16384 ? w : 16384;
-}
+// LDS: [a range's bins / 2] histogram | [2 npad] order | scan scratch
 static size_t table_sort_lds_bytes(int n, int T) {
     const size_t npad = (size_t)((n + 1023) >> 10) << 10;
-    return (table_sort_hist_words(T) + npad / 2 + TS_MAXN / 64 + 4 + 16) * 4;
+    return ((size_t)ts_range_words(T) + npad / 2 + 48) * 4;
 }
 static bool table_sort_fits(int n, int T) { return T <= 65535 && n <= TS_MAXN && table_sort_lds_bytes(n, T) <= 160 * 1024; }
 
-// rows idx[0 .. m) of src added in that order, sixteen row loads in flight: the wave fetches 64 indices at a time with one load
-// (lane l: idx[c + l]) and hands them round by readlane -- one dependent chain per 64 rows instead of one per row.  LDSI: the
-// indices are 16-bit words in LDS (a run sorted there), else int32 in memory.
+// Up to 64 rows of src, lane i holding the i-th row's number (`mine`), added as float4: the wave's four 16-lane groups each take
+// every fourth row (group g: rows g, g + 4, ...; lane j of a group: floats [4 j, 4 j + 4) of the row), sixteen 16-byte loads --
+// 64 rows -- in flight per lane.  The order is a function of the positions alone: group by group ascending, the groups folded
+// (g0 + g1) + (g2 + g3) by ts_fold_groups.
+__device__ __forceinline__ void ts_add64(float4& acc, const float* src, int mine, int mm, int lane) {
+    const int g = lane >> 4, j = lane & 15;
+    float4 v[16];
+#pragma unroll
+    for (int u = 0; u < 16; u++) {
+        const int i = 4 * u + g;
+        const int r = __shfl(mine, i, 64);
+        v[u] = i < mm ? *reinterpret_cast<const float4*>(src + (size_t)r * PC_L + 4 * j) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+#pragma unroll
+    for (int u = 0; u < 16; u++) { acc.x += v[u].x; acc.y += v[u].y; acc.z += v[u].z; acc.w += v[u].w; }
+}
+__device__ __forceinline__ float4 ts_fold_groups(float4 a) {
+    a.x += __shfl_xor(a.x, 16, 64); a.y += __shfl_xor(a.y, 16, 64); a.z += __shfl_xor(a.z, 16, 64); a.w += __shfl_xor(a.w, 16, 64);
+    a.x += __shfl_xor(a.x, 32, 64); a.y += __shfl_xor(a.y, 32, 64); a.z += __shfl_xor(a.z, 32, 64); a.w += __shfl_xor(a.w, 32, 64);
+    return a;
+}
+// rows idx[0 .. m) of src added in that order (ts_add64 per 64 of them).  LDSI: the indices are 16-bit words in LDS (a run sorted
+// there), else int32 in memory.  Every lane returns floats [4 (lane & 15), + 4) of the sum.
 template <bool LDSI>
-__device__ __forceinline__ float ts_sum_rows(const float* src, const int32_t* gidx, const unsigned short* lidx, int m, int lane) {
-    float acc = 0.f;
+__device__ __forceinline__ float4 ts_sum_rows(const float* src, const int32_t* gidx, const unsigned short* lidx, int m, int lane) {
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
     for (int c = 0; c < m; c += 64) {
         const int mm = min(64, m - c);                       // wave-uniform
         const int mine = lane < mm ? (LDSI ? (int)lidx[c + lane] : gidx[c + lane]) : 0;
-        for (int i = 0; i < mm; i += 16) {
-            float v[16];
-#pragma unroll
-            for (int u = 0; u < 16; u++) {
-                const int r = __builtin_amdgcn_readlane(mine, (i + u) & 63);
-                v[u] = i + u < mm ? src[(size_t)r * PC_L + lane] : 0.f;
-            }
-#pragma unroll
-            for (int u = 0; u < 16; u++) acc += v[u];
-        }
+        ts_add64(acc, src, mine, mm, lane);
     }
-    return acc;
+    return ts_fold_groups(acc);
 }
 // a run of up to 64 NQ rows (NQ = 1, 2, 4): sorted in registers -- element i = 64 q + lane sits in register q of lane `lane`; a
 // bitonic network whose steps with partner distance j < 64 exchange between lanes (one shuffle per register) and whose steps with
 // j >= 64 exchange between two registers of the same lane -- then added in that order
 template <int NQ>
-__device__ __forceinline__ float ts_sum_regs(const float* src, const int32_t* sorted, int b, int m, int lane) {
+__device__ __forceinline__ float4 ts_sum_regs(const float* src, const int32_t* sorted, int b, int m, int lane) {
     int x[NQ];
 #pragma unroll
     for (int q = 0; q < NQ; q++) x[q] = 64 * q + lane < m ? sorted[b + 64 * q + lane] : 0x7fffffff;
@@ -2025,23 +2068,13 @@ __device__ __forceinline__ float ts_sum_regs(const float* src, const int32_t* so
             }
         }
     }
-    float acc = 0.f;
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
     for (int q = 0; q < NQ; q++) {
         if (64 * q >= m) break;                              // wave-uniform
-        const int mm = min(64, m - 64 * q);
-        for (int i = 0; i < mm; i += 16) {
-            float v[16];
-#pragma unroll
-            for (int u = 0; u < 16; u++) {
-                const int r = __builtin_amdgcn_readlane(x[q], (i + u) & 63);
-                v[u] = i + u < mm ? src[(size_t)r * PC_L + lane] : 0.f;
-            }
-#pragma unroll
-            for (int u = 0; u < 16; u++) acc += v[u];
-        }
+        ts_add64(acc, src, x[q], min(64, m - 64 * q), lane);
     }
-    return acc;
+    return ts_fold_groups(acc);
 }
 // ascending bitonic sort of buf[0 .. p2) in generic-pointer LDS (p2 a power of two, padding 0xFFFF) by nthreads threads
 template <bool BLOCK>
@@ -2063,16 +2096,20 @@ __device__ __forceinline__ void ts_bitonic_s(unsigned short* buf, int p2, int t,
 //                       runs per wave instruction: the run's rows sorted over four lanes, added as float4 per lane
 //   m <= TS_LONG        (the list `medium`) one wave per run: sorted in the wave's registers (one, two or four per lane), added by
 //                       that wave
-//   m > TS_LONG         (the list `longl`) one workgroup per run: (up to TS_SEG_SORT rows) copied into the 2 KB buffer and sorted by
-//                       all four waves, (beyond: sorted by table_sort_kernel already) then four contiguous quarters, one per wave,
-//                       folded (w0 + w1) + (w2 + w3)
+//   m > TS_LONG         (the list `longl`: a destination hundreds of samples point at) one workgroup per run, and no sort at all:
+//                       each wave walks a quarter of the destination list itself, in list order, and adds the rows whose entry
+//                       is this destination, 64 at a time (an 80 KB read from L2 per such run, against a bitonic sort of the run
+//                       by the whole workgroup: 40 000 clocks for 2 048 rows); the quarters folded (w0 + w1) + (w2 + w3)
 // Grid regions per list: [short][medium][long], the two lists one after the other (SegGrid).  The short-run workgroups also write
 // the destination list (ulist: the touched rows of pc_joint_fused_touched, ascending).
-struct SegList { float* table; const float* src; const int32_t* sorted; const int2* seg; int32_t* ulist; const int32_t *medium, *longl; };
-struct SegGrid { int start[7]; };            // first workgroup of: short 0, medium 0, long 0, short 1, medium 1, long 1; total
-__global__ __launch_bounds__(256) void table_segsum_kernel(SegList l0, SegList l1, const int32_t* n_touch, SegGrid gr) {
+struct SegList { float* table; const float* src; const int32_t* sorted; const int2* seg; int32_t* ulist; const int32_t *medium, *longl, *nruns;
+                 const int32_t* idx; int n; };       // (idx [n]: the destination list itself)
+// first workgroup of: short 0, medium 0, long 0, short 1, medium 1, long 1; total.  spr: short-run workgroups per range of the table
+// (sixteen runs each), rs: ts_range_stride(T)
+struct SegGrid { int start[7]; int spr[2]; int rs; };
+__global__ __launch_bounds__(256) void table_segsum_kernel(SegList l0, SegList l1, int32_t* n_touch, SegGrid gr) {
     __shared__ float fold[4][PC_L];
-    __shared__ unsigned short sbuf[TS_SEG_SORT];
+    __shared__ unsigned short queue[4][128];
     __shared__ int sh_b[17], sh_d[16];
     const int bid = blockIdx.x;
     int region = 0;
@@ -2082,16 +2119,30 @@ __global__ __launch_bounds__(256) void table_segsum_kernel(SegList l0, SegList l
     const SegList& l = li ? l1 : l0;
     const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
     if (kind == 0) {
-        const int s0 = blk * 16;
-        // (the run table is requested together with the count it is checked against: one round trip instead of two)
+        const int spr = li ? gr.spr[1] : gr.spr[0];
+        const int rg = blk / spr, s0 = (blk - rg * spr) * 16;     // runs [s0, s0 + 16) of range rg
+        // (the run table is requested together with the counts it is checked against: one round trip instead of two)
         int2 e = make_int2(0, -1);
-        if (tid < 17) e = l.seg[s0 + tid];                   // (seg holds cap + 17 entries)
-        const int nu = n_touch[li];
+        if (tid < 17) e = l.seg[(size_t)rg * gr.rs + s0 + tid];   // (seg ends with 16 spare entries)
+        const int nu = l.nruns[rg];
+        int in_front = 0;
+        if (w == 0 && (s0 < nu || blk == 0)) {
+            // the ranges in front of this one: where its runs stand in the dense list of touched rows; the list's first
+            // workgroup also files the total
+            int c = lane < TS_NR ? l.nruns[lane] : 0;
+#pragma unroll
+            for (int o = 1; o < 16; o <<= 1) {
+                const int u = __shfl_up(c, o, 64);
+                if (lane >= o) c += u;
+            }
+            in_front = rg ? __builtin_amdgcn_readlane(c, (rg + 15) & 15) : 0;
+            if (blk == 0 && lane == 15) n_touch[li] = c;
+        }
         if (s0 >= nu) return;                                // workgroup-uniform
         if (tid < 17) {
             const bool live = s0 + tid <= nu;                // entry nu closes the last run
             sh_b[tid] = live ? e.x : 0;
-            if (tid < 16) { sh_d[tid] = (live && s0 + tid < nu) ? e.y : -1; if (s0 + tid < nu) l.ulist[s0 + tid] = e.y; }
+            if (tid < 16) { sh_d[tid] = (live && s0 + tid < nu) ? e.y : -1; if (s0 + tid < nu) l.ulist[in_front + s0 + tid] = e.y; }
         }
         __syncthreads();
         // group g = tid >> 4, lane j of the group owns floats [4 j, 4 j + 4) of the row
@@ -2130,32 +2181,50 @@ __global__ __launch_bounds__(256) void table_segsum_kernel(SegList l0, SegList l
         if (rs < 0) return;                                  // wave-uniform
         const int2 e = l.seg[rs], e1 = l.seg[rs + 1];        // {start, destination}, {next start, -}
         const int b = __builtin_amdgcn_readfirstlane(e.x), dest = __builtin_amdgcn_readfirstlane(e.y), m = __builtin_amdgcn_readfirstlane(e1.x) - b;
-        float r;
+        float4 r;
         if (m <= 64) r = ts_sum_regs<1>(l.src, l.sorted, b, m, lane);
         else if (m <= 128) r = ts_sum_regs<2>(l.src, l.sorted, b, m, lane);
         else r = ts_sum_regs<4>(l.src, l.sorted, b, m, lane);
-        l.table[(size_t)dest * PC_L + lane] = r;
+        if (lane < 16) *reinterpret_cast<float4*>(l.table + (size_t)dest * PC_L + 4 * lane) = r;
         return;
     }
     {                                                        // one workgroup per long run
         if (blk >= n_touch[3 + 2 * li]) return;
         const int rs = l.longl[blk];
-        const int2 e = l.seg[rs], e1 = l.seg[rs + 1];
-        const int b = __builtin_amdgcn_readfirstlane(e.x), dest = __builtin_amdgcn_readfirstlane(e.y), m = __builtin_amdgcn_readfirstlane(e1.x) - b;
-        const int per = (m + 3) >> 2;
-        const int mb = w * per, mm = max(0, min(m, mb + per) - mb);
-        float part;
-        if (m <= TS_SEG_SORT) {
-            int p2 = 512;
-            while (p2 < m) p2 <<= 1;
-            for (int i = tid; i < p2; i += 256) sbuf[i] = i < m ? (unsigned short)l.sorted[b + i] : (unsigned short)0xffff;
-            __syncthreads();
-            ts_bitonic_s<true>(sbuf, p2, tid, 256);
-            part = ts_sum_rows<true>(l.src, nullptr, sbuf + mb, mm, lane);
-        } else {
-            part = ts_sum_rows<false>(l.src, l.sorted + b + mb, nullptr, mm, lane);
+        const int dest = __builtin_amdgcn_readfirstlane(l.seg[rs].y);
+        const int nq = ((((l.n + 3) >> 2) + 63) >> 6) << 6;           // a wave's stretch of the list (whole chunks of 64 entries)
+        const int c0 = w * nq, c1 = min(l.n, c0 + nq);
+        ts_l16* qu = (ts_l16*)queue[w];                           // matching rows waiting for their turn (< 64 left over + 64 new)
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+        int pend = 0;                                             // wave-uniform
+        for (int c = c0; c < c1; c += 256) {                      // four chunks per round: their loads in flight together
+            int d[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++) { const int e = c + 64 * u + lane; d[u] = e < c1 ? l.idx[e] : -1; }
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                const bool hit = d[u] == dest;
+                const unsigned long long mk = __ballot(hit);
+                if (mk) {
+                    if (hit) qu[pend + __popcll(mk & ((1ull << lane) - 1ull))] = (unsigned short)(c + 64 * u + lane);
+                    pend += __popcll(mk);
+                    __builtin_amdgcn_wave_barrier();
+                    if (pend >= 64) {
+                        const int mine = qu[lane];
+                        const int rest = pend - 64;
+                        const unsigned short carry = lane < rest ? qu[64 + lane] : (unsigned short)0;
+                        __builtin_amdgcn_wave_barrier();
+                        if (lane < rest) qu[lane] = carry;
+                        __builtin_amdgcn_wave_barrier();
+                        ts_add64(acc, l.src, mine, 64, lane);
+                        pend = rest;
+                    }
+                }
+            }
         }
-        fold[w][lane] = part;
+        if (pend) ts_add64(acc, l.src, lane < pend ? (int)qu[lane] : 0, pend, lane);
+        const float4 part = ts_fold_groups(acc);
+        if (lane < 16) *reinterpret_cast<float4*>(&fold[w][4 * lane]) = part;
         __syncthreads();
         if (w == 0) l.table[(size_t)dest * PC_L + lane] = (fold[0][lane] + fold[1][lane]) + (fold[2][lane] + fold[3][lane]);
     }
@@ -2222,8 +2291,8 @@ static FusedWs fused_ws_layout(void* base, int B, int T, int K) {
         if (w.sorted_path) {
             w.srt_c = (int32_t*)take((size_t)nc * 4);
             w.srt_q = (int32_t*)take((size_t)B * 4);
-            w.seg_c = (int2*)take((size_t)((nc < T ? nc : T) + 17) * 8);      // (+ 16: a workgroup of the consumer requests 17 entries at once)
-            w.seg_q = (int2*)take((size_t)((B < T ? B : T) + 17) * 8);
+            w.seg_c = (int2*)take((size_t)(TS_NR * ts_range_stride(T) + 16) * 8);      // (+ 16: a workgroup of the consumer requests 17 entries at once)
+            w.seg_q = (int2*)take((size_t)(TS_NR * ts_range_stride(T) + 16) * 8);
             w.med_c = (int32_t*)take((size_t)(nc / 5 + 1) * 4);
             w.med_q = (int32_t*)take((size_t)(B / 5 + 1) * 4);
             w.lng_c = (int32_t*)take((size_t)(nc / TS_LONG + 1) * 4);
@@ -2428,18 +2497,24 @@ static int fused_step_impl(const pc_joint_tensors* p, const pc_joint_tensors* g,
     if (sorted_tables) {
         // table gradients: source rows sorted by destination, then one wave per destination adds its run in ascending source order
         const int nc = B * (K + 2), cap_c = nc < T ? nc : T, cap_q = B < T ? B : T;
-        const SortList sc = {w.ecidx, nc, w.srt_c, w.seg_c, w.med_c, w.lng_c}, sq = {w.cids + B, B, w.srt_q, w.seg_q, w.med_q, w.lng_q};
+        // (n_touch: [0, 1] touched rows per table, [2 .. 6) run-list counters, [8 .. 8 + 2 TS_NR) runs per range of either list)
+        const SortList sc = {w.ecidx, nc, w.srt_c, w.seg_c, w.med_c, w.lng_c, w.n_touch + 8};
+        const SortList sq = {w.cids + B, B, w.srt_q, w.seg_q, w.med_q, w.lng_q, w.n_touch + 8 + TS_NR};
         static const hipError_t sattr = hipFuncSetAttribute(reinterpret_cast<const void*>(&table_sort_kernel),
                                                             hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         (void)sattr;
         PC_LAUNCH(table_sort_kernel, dim3(2 * TS_NR), dim3(1024), table_sort_lds_bytes(nc, T), st, sc, sq, T, w.n_touch);
-        const SegList gc = {g->comp_types, w.ecsrc, w.srt_c, w.seg_c, w.tl_c, w.med_c, w.lng_c};
-        const SegList gq = {g->query_types, w.dt, w.srt_q, w.seg_q, w.tl_q, w.med_q, w.lng_q};
+        const SegList gc = {g->comp_types, w.ecsrc, w.srt_c, w.seg_c, w.tl_c, w.med_c, w.lng_c, sc.nruns, sc.idx, sc.n};
+        const SegList gq = {g->query_types, w.dt, w.srt_q, w.seg_q, w.tl_q, w.med_q, w.lng_q, sq.nruns, sq.idx, sq.n};
         // grid regions sized for the capacities (the counts live on the device: workgroups past them leave at once): runs of up to
         // four rows sixteen per workgroup, runs of 5 .. TS_LONG rows (at most n / 5 of them) a wave each, longer ones a workgroup each
         SegGrid gr;
         int at = 0;
-        const int sizes[6] = {(cap_c + 15) / 16, (nc / 5 + 3) / 4, nc / TS_LONG + 1, (cap_q + 15) / 16, (B / 5 + 3) / 4, B / TS_LONG + 1};
+        // (short runs: per range of the table's rows, at most min(its bins, the list's rows) of them)
+        const int bins = 2 * ts_range_words(T);
+        gr.rs = ts_range_stride(T);
+        gr.spr[0] = ((bins < cap_c ? bins : cap_c) + 15) / 16; gr.spr[1] = ((bins < cap_q ? bins : cap_q) + 15) / 16;
+        const int sizes[6] = {TS_NR * gr.spr[0], (nc / 5 + 3) / 4, nc / TS_LONG + 1, TS_NR * gr.spr[1], (B / 5 + 3) / 4, B / TS_LONG + 1};
         for (int i = 0; i < 6; i++) { gr.start[i] = at; at += sizes[i]; }
         gr.start[6] = at;
         PC_LAUNCH(table_segsum_kernel, dim3(at), dim3(256), 0, st, gc, gq, w.n_touch, gr);

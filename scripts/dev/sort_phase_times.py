@@ -19,12 +19,13 @@ for _ in range(5):
     m.train_step(b)
 torch.cuda.synchronize()
 L = ctypes.CDLL(_lib.LIB_PATH)
-out = (ctypes.c_ulonglong * 16)()
+out = (ctypes.c_ulonglong * 1024)()
 assert L.pc_debug_sort_timing(out) == 0
 t = list(out)
-names = ["zero", "histogram", "scan + run starts", "placement", "long runs sorted", "write-out"]
-seq = t[:7]
-print("stamps:", seq)
-for i in range(1, len(seq)):
-    print("%-18s %8d clk" % (names[i - 1], seq[i] - seq[i - 1]))
-print("total %d clk" % (seq[-1] - seq[0]))
+names = ["zero", "histogram", "bin loops", "scan", "run table to LDS", "barrier", "run table out", "placement", "run lists + long runs", "write-out"]
+live = [b for b in range(64) if t[16 * b]]
+nr = len(live) // 2
+for b in live:
+    seq = t[16 * b:16 * b + 11]
+    print("workgroup %2d (list %d, range %2d): total %d clk: " % (b, b // nr, b % nr, seq[-1] - seq[0])
+          + ", ".join("%s %d" % (names[i - 1], seq[i] - seq[i - 1]) for i in range(1, 11)))
