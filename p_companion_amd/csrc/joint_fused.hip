@@ -73,6 +73,14 @@ __device__ __forceinline__ float wave_sum_dpp(float v) {
     v = dpp_add<0x143, 0xc>(v);     // row_bcast:31 into rows 2, 3: lane 63 = everything
     return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
 }
+// inclusive prefix sum over the wave's 64 lanes on the same network (every lane keeps its prefix)
+template <int CTRL, int RM>
+__device__ __forceinline__ int dpp_addi(int v) { return v + __builtin_amdgcn_update_dpp(0, v, CTRL, RM, 0xf, true); }
+__device__ __forceinline__ int wave_scan_incl(int v) {
+    v = dpp_addi<0x111, 0xf>(v); v = dpp_addi<0x112, 0xf>(v); v = dpp_addi<0x114, 0xf>(v); v = dpp_addi<0x118, 0xf>(v);
+    v = dpp_addi<0x142, 0xa>(v); v = dpp_addi<0x143, 0xc>(v);
+    return v;
+}
 // ---- reductions inside a ROW of 16 lanes (four samples per wave side by side): an inclusive scan on the row_shr network
 // leaves the row total in lane 15 of the row in a FIXED order; every lane of the row then takes that one value (a
 // rotate-and-add all-reduce would give each lane its own association of the 16 terms: the hinge decisions of a sample
@@ -1773,28 +1781,31 @@ __global__ __launch_bounds__(256) void table_reduce_kernel(TableList l0, TableLi
 
 // ---------------------------------------------------------------------------------------------------------------
 // Large tables, DETERMINISTIC gradients at ANY number of touched rows (round 5; replaces the LDS-table form above -- 512 distinct
-// rows at most -- and its float-atomic branch wherever a list fits this kernel's LDS: 2 T + 2 n bytes, e.g. the reference's
-// NUM_TYPES = 34800 (config.py:27) at B = 4096, K <= 4):
-//   table_sort_kernel     one 1024-thread workgroup per list: a COUNTING sort of the source rows by destination over ALL T rows of
-//                         the table, in LDS -- histogram (16-bit counts, two per word, integer atomics), scan over the T bins
-//                         (which also yields the distinct destinations, ascending -- the touched-row list of
-//                         pc_joint_fused_touched -- and where each one's run starts), placement through returning atomics.  The
-//                         placement order inside a run is whatever the atomics gave: every run is then SORTED by source row --
-//                         by the wave(s) that consume it (up to 64 rows: a bitonic network over the lanes; up to 1024: in 2 KB
-//                         of LDS), only a run longer than that here (the whole workgroup, in the dead histogram's LDS)
-//   table_segsum_kernel   one wave per destination: its source rows added in ascending source order (sixteen rows in flight),
-//                         written to the (cleared) dense gradient; a run longer than TS_LONG rows is cut into four contiguous
-//                         quarters, one per wave of the workgroup, folded (w0 + w1) + (w2 + w3)
+// rows at most -- and its float-atomic branch wherever a list fits the sort kernel's LDS: n <= TS_MAXN source rows, T <= 65535,
+// e.g. the reference's NUM_TYPES = 34800 (config.py:27) at B = 4096, K <= 4):
+//   table_sort_kernel     TS_NR workgroups per list, each a contiguous range of the table's rows: a COUNTING sort of the source
+//                         rows that point into its range, in LDS -- histogram (16-bit counts, two per word, integer atomics), scan
+//                         over the range's bins (which also yields its distinct destinations, ascending, and where each one's run
+//                         starts), placement through returning atomics.  Out: the order (`sorted`), the run table (one entry per
+//                         destination; a run of up to four rows carries its rows), the lists of the runs of 5 .. TS_LONG rows and
+//                         of the longer ones.  The placement order inside a run is whatever the atomics gave: every run is SORTED
+//                         by source row by whoever consumes it
+//   table_segsum_kernel   per destination: its source rows added in ascending source order, written to the (cleared) dense
+//                         gradient -- sixteen short runs per workgroup, a wave per medium run, a workgroup per long one (four
+//                         contiguous quarters, folded (w0 + w1) + (w2 + w3)); also the dense ascending list of touched rows
+//                         (pc_joint_fused_touched)
 // The order of every sum is a function of the index lists alone: bitwise reproducible whatever the number of touched rows --
 // with DROPOUT = 0.1 (config.py:12) every sample selects its own K types and the complementary table has thousands.
-// (Two earlier forms of the sort -- a stable two-pass LSD radix sort with ballot ranking, first with per-lane state in registers
-// and fully unrolled loops, then rolled with the state in LDS -- took 160 and 77 us: instruction fetch, then the ballots.)
+// (Earlier forms, T = 34800, B = 4096, K = 3, both lists: a stable two-pass LSD radix sort with ballot ranking took 160 / 77 us;
+// the counting sort as one workgroup per list 52 us, as four range workgroups that each histogrammed everything below their range
+// 34 us, of which 60 % was one device atomic per run from the thread that scanned it; this form 12 us.  The consumer: 29 -> 21 us.)
 #define TS_MAXN 24576       /* source rows per list (16-bit positions and row numbers) */
-#define TS_LONG 256
-struct SortList { const int32_t* idx; int n; int32_t* sorted; int2* seg; int32_t *medium, *longl, *nruns; };
-// sorted [n]; seg [TS_NR ts_range_stride(T)] = {start of the run, its destination}, one stretch per range of the table's rows (see
-// table_sort_kernel), nruns [TS_NR]: the runs in each; medium [n / 5]: the runs of 5 .. TS_LONG rows, longl [n / TS_LONG]: the longer
-// ones (indices into seg, in no particular order); n_touch [2 + 2 list], [3 + 2 list]: their counts
+#define TS_LONG 64         /* a run of up to this many rows is summed by one wave, a longer one by a workgroup */
+struct SortList { const int32_t* idx; int n; int32_t* sorted; int4* seg; int2 *medium, *longl; int32_t* nruns; };
+// sorted [n]; seg [TS_NR ts_range_stride(T)] = {start of the run, its destination, its rows if it has up to four}, one stretch per
+// range of the table's rows (see table_sort_kernel), nruns [TS_NR]: the runs in each; medium [n / 5]: the runs of 5 .. TS_LONG rows,
+// longl [n / TS_LONG]: the longer ones ({start << 16 | rows, destination}, in no particular order); n_touch [2 + 2 list],
+// [3 + 2 list]: their counts
 
 #ifdef PC_SORT_TIMING
 // developer build (scripts/dev/sort_phase_times.py): shader-clock stamps of every workgroup's thread 0 at the phases of the sort kernel
@@ -1803,47 +1814,32 @@ extern "C" int pc_debug_sort_timing(unsigned long long* out) {
     return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(pc_sort_timing), sizeof(unsigned long long) * 1024);
 }
 #define PC_ST(i) do { if (threadIdx.x == 0) pc_sort_timing[blockIdx.x * 16 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
+// table_segsum_kernel: the longest wave of each grid region (slots 1000 + region), waves with work (1008 + region), rows of the longest run (1016 + region)
+#define PC_SEG_T0 const unsigned long long seg_t0 = __builtin_amdgcn_s_memtime()
+#define PC_SEG_T1(region, rows) do { if ((threadIdx.x & 63) == 0) { atomicMax(&pc_sort_timing[1000 + (region)], __builtin_amdgcn_s_memtime() - seg_t0); \
+        atomicAdd(&pc_sort_timing[1008 + (region)], 1ull); atomicMax(&pc_sort_timing[1016 + (region)], (unsigned long long)(rows)); } } while (0)
+// the phases of a medium run of >= 48 rows (slots 900 ..: whichever such wave wrote last)
+#define PC_SEG_P(i, rows) do { if ((rows) >= 48 && (threadIdx.x & 63) == 0) pc_sort_timing[900 + (i)] = __builtin_amdgcn_s_memtime() - seg_t0; } while (0)
 #else
 #define PC_ST(i) do { } while (0)
+#define PC_SEG_P(i, rows) do { } while (0)
+#define PC_SEG_T0 do { } while (0)
+#define PC_SEG_T1(region, rows) do { } while (0)
 #endif
 
 typedef __attribute__((address_space(3))) unsigned short ts_l16;
 typedef __attribute__((address_space(3))) unsigned ts_l32;
-// ascending bitonic sort of buf[0 .. p2) (p2 a power of two, padding 0xFFFF) by `nthreads` threads that share `sync`
-template <bool BLOCK>
-__device__ __forceinline__ void ts_bitonic(ts_l16* buf, int p2, int t, int nthreads) {
-    for (int k = 2; k <= p2; k <<= 1) {
-        for (int j = k >> 1; j > 0; j >>= 1) {
-            for (int i = t; i < (p2 >> 1); i += nthreads) {
-                const int lo = ((i & ~(j - 1)) << 1) | (i & (j - 1)), hi = lo | j;      // the pair (lo, lo ^ j), lo's bit j clear
-                const unsigned a = buf[lo], b = buf[hi];
-                const bool up = (lo & k) == 0;
-                if ((a > b) == up) { buf[lo] = (unsigned short)b; buf[hi] = (unsigned short)a; }
-            }
-            if (BLOCK) __syncthreads(); else __builtin_amdgcn_wave_barrier();
-        }
-    }
-}
-
-// inclusive prefix sums of a and of b over the 1024 threads of a workgroup and the workgroup's total of c (returned in c): shuffles
-// inside each wave, the 3 x 16 wave totals through LDS (one barrier: ws is not in use before the call), where sixteen lanes of
-// every wave scan them again
+// inclusive prefix sums of a and of b over the 1024 threads of a workgroup and the workgroup's total of c (returned in c): the DPP
+// scan inside each wave, the 3 x 16 wave totals through LDS (one barrier: ws is not in use before the call), where sixteen lanes
+// of every wave scan them again
 __device__ __forceinline__ void block_scan3_1024(int& a, int& b, int& c, ts_l32* ws /* [48] */) {
     const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-        const int ua = __shfl_up(a, o, 64), ub = __shfl_up(b, o, 64), uc = __shfl_up(c, o, 64);
-        if (lane >= o) { a += ua; b += ub; c += uc; }
-    }
+    a = wave_scan_incl(a); b = wave_scan_incl(b); c = wave_scan_incl(c);
     if (lane == 63) { ws[w] = (unsigned)a; ws[16 + w] = (unsigned)b; ws[32 + w] = (unsigned)c; }
     __syncthreads();
     int ta = 0, tb = 0, tc = 0;
     if (lane < 16) { ta = (int)ws[lane]; tb = (int)ws[16 + lane]; tc = (int)ws[32 + lane]; }
-#pragma unroll
-    for (int o = 1; o < 16; o <<= 1) {
-        const int ua = __shfl_up(ta, o, 64), ub = __shfl_up(tb, o, 64), uc = __shfl_up(tc, o, 64);
-        if (lane >= o) { ta += ua; tb += ub; tc += uc; }
-    }
+    ta = wave_scan_incl(ta); tb = wave_scan_incl(tb); tc = wave_scan_incl(tc);
     // waves in front of this one: lane w - 1 of the inclusive scan
     const int ba = __builtin_amdgcn_readlane(ta, (w + 15) & 15), bb = __builtin_amdgcn_readlane(tb, (w + 15) & 15);
     a += w ? ba : 0; b += w ? bb : 0;
@@ -1878,8 +1874,9 @@ __global__ __launch_bounds__(1024) void table_sort_kernel(SortList l0, SortList 
     const int rlo = min(words, rg * rw), nw = min(words, rlo + rw) - rlo;      // this workgroup's words: [rlo, rlo + nw)
     const int npad = ((n + 1023) >> 10) << 10;
     ts_l32* hist = (ts_l32*)ts_lds;                          // [rw] counts, then running positions
-    ts_l16* out = (ts_l16*)(hist + rw);                      // [npad] run table in the making, then this range's source rows by destination
-    ts_l32* part = (ts_l32*)(out + npad);                    // [48] scan scratch
+    ts_l16* out = (ts_l16*)(hist + rw);                      // [npad] this range's source rows by destination
+    ts_l16* dst16 = out + npad;                              // [2 rw] the range's runs: their bins (relative to the range), ascending
+    ts_l32* part = (ts_l32*)(dst16 + 2 * rw);                // [48] scan scratch
     const int tid = threadIdx.x;
     // a thread's list entries (e = tid + 1024 j): requested before anything else -- written by the previous kernel on other
     // XCDs, they come from memory while the bins are cleared -- and kept in registers for the placement below
@@ -1933,7 +1930,7 @@ __global__ __launch_bounds__(1024) void table_sort_kernel(SortList l0, SortList 
         if (nl) lres = atomicAdd(&n_touch[3 + 2 * li], nl);
         sh_rows = rows; sh_runs = runs;
         l.nruns[rg] = runs;
-        l.seg[(size_t)rg * rs + runs] = make_int2(row_base + rows, -1);       // closes the range's last run
+        l.seg[(size_t)rg * rs + runs] = make_int4(row_base + rows, -1, 0, 0);       // closes the range's last run
     }
     {
         int run = run0, pos = pos0;
@@ -1941,9 +1938,9 @@ __global__ __launch_bounds__(1024) void table_sort_kernel(SortList l0, SortList 
             const unsigned c = hist[i], c0 = c & 0xffffu, c1 = c >> 16;
             const unsigned s0 = (unsigned)run, s1 = s0 + c0;
             hist[i] = s0 | (s1 << 16);                       // running positions of the two bins (positions in the whole order)
-            // (the run table goes out from LDS below: written from here, a wave's store scatters over ~50 cache lines)
-            if (c0) { out[pos] = (unsigned short)(2 * i); pos++; }
-            if (c1) { out[pos] = (unsigned short)(2 * i + 1); pos++; }
+            // (the run table goes out from LDS further down: written from here, a wave's store scatters over ~50 cache lines)
+            if (c0) { dst16[pos] = (unsigned short)(2 * i); pos++; }
+            if (c1) { dst16[pos] = (unsigned short)(2 * i + 1); pos++; }
             run += (int)(c0 + c1);
         }
     }
@@ -1951,12 +1948,6 @@ __global__ __launch_bounds__(1024) void table_sort_kernel(SortList l0, SortList 
     __syncthreads();
     PC_ST(6);
     const int nrows = sh_rows;
-    // the run table of this range, dense: {start of the run (its bin's running position, not yet advanced), destination}
-    for (int q = tid; q < sh_runs; q += 1024) {
-        const unsigned d = out[q], h = hist[d >> 1];
-        l.seg[(size_t)rg * rs + q] = make_int2((int)((d & 1u) ? h >> 16 : h & 0xffffu), 2 * rlo + (int)d);
-    }
-    __syncthreads();                                         // (`out` is the placement's from here)
     PC_ST(7);
     // ---- placement: the returning atomic hands every row of this range a slot of its destination's run (in no particular order)
 #pragma unroll
@@ -1968,52 +1959,71 @@ __global__ __launch_bounds__(1024) void table_sort_kernel(SortList l0, SortList 
     if (tid == 1023) { sh_lbase[0] = mres; sh_lbase[1] = lres; }
     __syncthreads();
     PC_ST(8);
-    // ---- the run lists' entries: the placement left every bin's END in its half word, so a second walk over the thread's words
-    // has the lengths again
+    // ---- the run table of this range, dense (a wave's store: sixteen cache lines): {start of the run, destination, its rows if
+    // it has up to four (16 bits each, in placement order) -- the consumer of a short run needs nothing else}.  The placement left
+    // every bin's END in its half word: a run starts where the one before it ends.
+    for (int q = tid; q < sh_runs; q += 1024) {
+        const unsigned d = dst16[q], h = hist[d >> 1];
+        const unsigned end = (d & 1u) ? h >> 16 : h & 0xffffu;
+        unsigned start = (unsigned)row_base;
+        if (q) { const unsigned dp = dst16[q - 1], hp = hist[dp >> 1]; start = (dp & 1u) ? hp >> 16 : hp & 0xffffu; }
+        const unsigned m = end - start, o = start - (unsigned)row_base;
+        unsigned r01 = 0u, r23 = 0u;
+        if (m <= 4u) {
+            r01 = (unsigned)out[o] | (m > 1u ? (unsigned)out[o + 1] << 16 : 0u);
+            r23 = (m > 2u ? (unsigned)out[o + 2] : 0u) | (m > 3u ? (unsigned)out[o + 3] << 16 : 0u);
+        }
+        l.seg[(size_t)rg * rs + q] = make_int4((int)start, 2 * rlo + (int)d, (int)r01, (int)r23);
+    }
+    // ---- the run lists' entries, self-contained ({start << 16 | rows, destination}: their consumers do not read the run table):
+    // a second walk over the thread's words has the lengths again
     {
         int mpos = sh_lbase[0] + ((lincl - lists) & 0xffff), lpos = sh_lbase[1] + ((lincl - lists) >> 16);
         unsigned prev = (unsigned)run0;
-        int r = rg * rs + pos0;                              // the run's entry in the table
         for (int i = w0; i < w1; i++) {
             const unsigned h = hist[i], e0 = h & 0xffffu, e1 = h >> 16;
-            const unsigned cc[2] = {e0 - prev, e1 - e0};
+            const unsigned cc[2] = {e0 - prev, e1 - e0}, ss[2] = {prev, e0};
 #pragma unroll
             for (int u = 0; u < 2; u++) {
-                if (cc[u]) {
-                    if (cc[u] > TS_LONG) l.longl[lpos++] = r;
-                    else if (cc[u] > 4u) l.medium[mpos++] = r;
-                    r++;
-                }
+                const int2 ent = make_int2((int)((ss[u] << 16) | cc[u]), 2 * (rlo + i) + u);
+                if (cc[u] > TS_LONG) l.longl[lpos++] = ent;
+                else if (cc[u] > 4u) l.medium[mpos++] = ent;
             }
             prev = e1;
         }
     }
     PC_ST(9);
-    // ---- the order out to memory: every run in placement order -- the wave that consumes a run of up to TS_LONG rows sorts it in
-    // its registers; a longer one is not read from here at all (its consumer filters the list itself, in list order)
+    // ---- the order out to memory, every run in placement order: its consumer sorts it (the rows are distinct numbers below n:
+    // a bitmap in LDS, read back in ascending order)
     for (int i = tid; i < nrows; i += 1024) l.sorted[row_base + i] = (int)out[i];
     PC_ST(10);
 }
-// LDS: [a range's bins / 2] histogram | [2 npad] order | scan scratch
+// LDS: [a range's bins / 2] histogram | [2 npad] order | [a range's bins] 16-bit run destinations | scan scratch
 static size_t table_sort_lds_bytes(int n, int T) {
     const size_t npad = (size_t)((n + 1023) >> 10) << 10;
-    return ((size_t)ts_range_words(T) + npad / 2 + 48) * 4;
+    return ((size_t)2 * ts_range_words(T) + npad / 2 + 48) * 4;
 }
 static bool table_sort_fits(int n, int T) { return T <= 65535 && n <= TS_MAXN && table_sort_lds_bytes(n, T) <= 160 * 1024; }
 
-// Up to 64 rows of src, lane i holding the i-th row's number (`mine`), added as float4: the wave's four 16-lane groups each take
-// every fourth row (group g: rows g, g + 4, ...; lane j of a group: floats [4 j, 4 j + 4) of the row), sixteen 16-byte loads --
-// 64 rows -- in flight per lane.  The order is a function of the positions alone: group by group ascending, the groups folded
-// (g0 + g1) + (g2 + g3) by ts_fold_groups.
-__device__ __forceinline__ void ts_add64(float4& acc, const float* src, int mine, int mm, int lane) {
+// Up to 64 rows of src whose numbers stand in a wave's queue in LDS (q[0 .. mm), 16-bit, 16-byte aligned), added as float4: the
+// wave's four 16-lane groups take sixteen consecutive rows each (group g: rows 16 g .. 16 g + 15 -- its 32 bytes of the queue
+// are two LDS reads; handing the numbers round by lane shuffles, sixteen dependent LDS operations per block, cost more than the
+// rows' own round trip), lane j of a group floats [4 j, 4 j + 4) of the row: sixteen 16-byte loads -- 64 rows -- in flight per
+// lane.  The order is a function of the positions alone: every group ascending, the groups folded (g0 + g1) + (g2 + g3) by
+// ts_fold_groups.  ts_add128: two such blocks, all 32 loads in flight before the first add.
+__device__ __forceinline__ void ts_load64(float4 (&v)[16], const float* src, const ts_l16* q, int mm, int lane) {
     const int g = lane >> 4, j = lane & 15;
-    float4 v[16];
+    typedef unsigned ts_u4 __attribute__((ext_vector_type(4)));
+    typedef __attribute__((address_space(3))) const ts_u4 ts_l128;
+    const ts_u4 lo = *reinterpret_cast<ts_l128*>(q + 16 * g), hi = *reinterpret_cast<ts_l128*>(q + 16 * g + 8);
+    const unsigned wd[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
 #pragma unroll
     for (int u = 0; u < 16; u++) {
-        const int i = 4 * u + g;
-        const int r = __shfl(mine, i, 64);
-        v[u] = i < mm ? *reinterpret_cast<const float4*>(src + (size_t)r * PC_L + 4 * j) : make_float4(0.f, 0.f, 0.f, 0.f);
+        const unsigned r = (wd[u >> 1] >> (16 * (u & 1))) & 0xffffu;
+        v[u] = 16 * g + u < mm ? *reinterpret_cast<const float4*>(src + (size_t)r * PC_L + 4 * j) : make_float4(0.f, 0.f, 0.f, 0.f);
     }
+}
+__device__ __forceinline__ void ts_acc64(float4& acc, const float4 (&v)[16]) {
 #pragma unroll
     for (int u = 0; u < 16; u++) { acc.x += v[u].x; acc.y += v[u].y; acc.z += v[u].z; acc.w += v[u].w; }
 }
@@ -2022,95 +2032,57 @@ __device__ __forceinline__ float4 ts_fold_groups(float4 a) {
     a.x += __shfl_xor(a.x, 32, 64); a.y += __shfl_xor(a.y, 32, 64); a.z += __shfl_xor(a.z, 32, 64); a.w += __shfl_xor(a.w, 32, 64);
     return a;
 }
-// rows idx[0 .. m) of src added in that order (ts_add64 per 64 of them).  LDSI: the indices are 16-bit words in LDS (a run sorted
-// there), else int32 in memory.  Every lane returns floats [4 (lane & 15), + 4) of the sum.
-template <bool LDSI>
-__device__ __forceinline__ float4 ts_sum_rows(const float* src, const int32_t* gidx, const unsigned short* lidx, int m, int lane) {
-    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-    for (int c = 0; c < m; c += 64) {
-        const int mm = min(64, m - c);                       // wave-uniform
-        const int mine = lane < mm ? (LDSI ? (int)lidx[c + lane] : gidx[c + lane]) : 0;
-        ts_add64(acc, src, mine, mm, lane);
-    }
-    return ts_fold_groups(acc);
-}
-// a run of up to 64 NQ rows (NQ = 1, 2, 4): sorted in registers -- element i = 64 q + lane sits in register q of lane `lane`; a
-// bitonic network whose steps with partner distance j < 64 exchange between lanes (one shuffle per register) and whose steps with
-// j >= 64 exchange between two registers of the same lane -- then added in that order
-template <int NQ>
-__device__ __forceinline__ float4 ts_sum_regs(const float* src, const int32_t* sorted, int b, int m, int lane) {
-    int x[NQ];
-#pragma unroll
-    for (int q = 0; q < NQ; q++) x[q] = 64 * q + lane < m ? sorted[b + 64 * q + lane] : 0x7fffffff;
-    if (m > 1) {
-#pragma unroll
-        for (int k = 2; k <= 64 * NQ; k <<= 1) {
-#pragma unroll
-            for (int j = k >> 1; j > 0; j >>= 1) {
-                if (j >= 64) {
-#pragma unroll
-                    for (int q = 0; q < NQ; q++) {
-                        const int pq = q ^ (j >> 6);
-                        if (pq > q) {                         // the pair (q, pq): ascending if bit k of the element index is clear
-                            const bool up = ((64 * q) & k) == 0;
-                            const int lo = min(x[q], x[pq]), hi = max(x[q], x[pq]);
-                            x[q] = up ? lo : hi; x[pq] = up ? hi : lo;
-                        }
-                    }
-                } else {
-#pragma unroll
-                    for (int q = 0; q < NQ; q++) {
-                        const int other = __shfl_xor(x[q], j, 64);
-                        const bool up = ((64 * q + lane) & k) == 0, lower = (lane & j) == 0;
-                        x[q] = (lower == up) ? min(x[q], other) : max(x[q], other);
-                    }
-                }
-            }
-        }
-    }
-    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-#pragma unroll
-    for (int q = 0; q < NQ; q++) {
-        if (64 * q >= m) break;                              // wave-uniform
-        ts_add64(acc, src, x[q], min(64, m - 64 * q), lane);
-    }
-    return ts_fold_groups(acc);
-}
-// ascending bitonic sort of buf[0 .. p2) in generic-pointer LDS (p2 a power of two, padding 0xFFFF) by nthreads threads
-template <bool BLOCK>
-__device__ __forceinline__ void ts_bitonic_s(unsigned short* buf, int p2, int t, int nthreads) {
-    for (int k = 2; k <= p2; k <<= 1) {
-        for (int j = k >> 1; j > 0; j >>= 1) {
-            for (int i = t; i < (p2 >> 1); i += nthreads) {
-                const int lo = ((i & ~(j - 1)) << 1) | (i & (j - 1)), hi = lo | j;
-                const unsigned a = buf[lo], b = buf[hi];
-                const bool up = (lo & k) == 0;
-                if ((a > b) == up) { buf[lo] = (unsigned short)b; buf[hi] = (unsigned short)a; }
-            }
-            if (BLOCK) __syncthreads(); else __builtin_amdgcn_wave_barrier();
-        }
+// rows qu[0 .. m) (a wave's queue in LDS, ascending; readable up to the next multiple of 64) of src added in that order, 128 at a
+// time.  Every block of 64 has its own four group sums: folded into `acc` block by block, in order.
+__device__ __forceinline__ void ts_add_queue(float4& acc, const float* src, const ts_l16* qu, int m, int lane) {
+    for (int c = 0; c < m; c += 128) {
+        const int mm = min(128, m - c);                      // wave-uniform
+        float4 v0[16], v1[16];
+        ts_load64(v0, src, qu + c, min(mm, 64), lane);
+        if (mm > 64) ts_load64(v1, src, qu + c + 64, mm - 64, lane);
+        ts_acc64(acc, v0);
+        if (mm > 64) ts_acc64(acc, v1);
     }
 }
-// By the length m of a destination's run:
+// The wave's lanes each hold some bits of a bitmap of row numbers (v: the bits, base: the row number of bit 0) in ascending lane
+// order: the set bits' row numbers are appended to the queue qu at position `at`, ascending; returns how many.
+__device__ __forceinline__ int ts_expand_bits(ts_l16* qu, int at, unsigned v, int base, int lane) {
+    const int mine = __popc(v), incl = wave_scan_incl(mine);
+    int o = at + incl - mine;
+    while (v) {
+        qu[o++] = (unsigned short)(base + __ffs((int)v) - 1);
+        v &= v - 1u;
+    }
+    return __builtin_amdgcn_readlane(incl, 63);
+}
+// By the length m of a destination's run (its rows stand in `sorted` in the order the placement's atomics gave them):
 //   m <= 4              (most of them: a type a few samples selected) sixteen runs per workgroup, one 16-lane group per run, four
-//                       runs per wave instruction: the run's rows sorted over four lanes, added as float4 per lane
-//   m <= TS_LONG        (the list `medium`) one wave per run: sorted in the wave's registers (one, two or four per lane), added by
-//                       that wave
-//   m > TS_LONG         (the list `longl`: a destination hundreds of samples point at) one workgroup per run, and no sort at all:
-//                       each wave walks a quarter of the destination list itself, in list order, and adds the rows whose entry
-//                       is this destination, 64 at a time (an 80 KB read from L2 per such run, against a bitonic sort of the run
-//                       by the whole workgroup: 40 000 clocks for 2 048 rows); the quarters folded (w0 + w1) + (w2 + w3)
+//                       runs per wave instruction: the run's rows -- they came with the run table's entry -- sorted over four
+//                       lanes, added as float4 per lane
+//   m <= TS_LONG        (the list `medium`) one wave per run
+//   m > TS_LONG         (the list `longl`: a destination hundreds of samples point at) one workgroup per run, each wave a quarter
+//                       of the row NUMBERS (not of the run), the quarters folded (w0 + w1) + (w2 + w3)
+// Medium and long runs are sorted through a bitmap: the rows are distinct numbers below n (24 576 at most: 3 KB of LDS), every
+// row sets its bit, the bits read back in ascending order ARE the sorted run (~1 500 clocks whatever the length -- a bitonic
+// network over the wave's registers needs 21 dependent shuffles for 64 rows and 144 for 256, one over LDS 40 000 clocks for 2 048).
+// The chip clocks near 1 GHz in this step and a load that misses L2 (everything here was written by other XCDs a kernel ago)
+// takes ~2 500 clocks: the paths are counted in such round trips -- short: run table, rows; medium / long: list entry + count,
+// row numbers, rows (128 in flight per wave).
 // Grid regions per list: [short][medium][long], the two lists one after the other (SegGrid).  The short-run workgroups also write
 // the destination list (ulist: the touched rows of pc_joint_fused_touched, ascending).
-struct SegList { float* table; const float* src; const int32_t* sorted; const int2* seg; int32_t* ulist; const int32_t *medium, *longl, *nruns;
-                 const int32_t* idx; int n; };       // (idx [n]: the destination list itself)
+struct SegList { float* table; const float* src; const int32_t* sorted; const int4* seg; int32_t* ulist; const int2 *medium, *longl;
+                 const int32_t* nruns; int n; };
 // first workgroup of: short 0, medium 0, long 0, short 1, medium 1, long 1; total.  spr: short-run workgroups per range of the table
 // (sixteen runs each), rs: ts_range_stride(T)
 struct SegGrid { int start[7]; int spr[2]; int rs; };
+#define TS_QCAP 1088       /* a wave's queue of row numbers: 1024 from one round of the longest runs' path + up to 63 left over */
+#define TS_SHQ 1024        /* a long run of up to this many rows is laid out in one queue (the four waves' queues side by side hold 4352) */
 __global__ __launch_bounds__(256) void table_segsum_kernel(SegList l0, SegList l1, int32_t* n_touch, SegGrid gr) {
     __shared__ float fold[4][PC_L];
-    __shared__ unsigned short queue[4][128];
-    __shared__ int sh_b[17], sh_d[16];
+    __shared__ unsigned bits[4 * (TS_MAXN / 32)];            // medium: one bitmap per wave; long: the first one, shared
+    __shared__ __attribute__((aligned(16))) unsigned short queue[4 * TS_QCAP];
+    __shared__ int sh_b[17], sh_d[16], sh_r[16][2];
+    PC_SEG_T0;
     const int bid = blockIdx.x;
     int region = 0;
 #pragma unroll
@@ -2122,19 +2094,14 @@ __global__ __launch_bounds__(256) void table_segsum_kernel(SegList l0, SegList l
         const int spr = li ? gr.spr[1] : gr.spr[0];
         const int rg = blk / spr, s0 = (blk - rg * spr) * 16;     // runs [s0, s0 + 16) of range rg
         // (the run table is requested together with the counts it is checked against: one round trip instead of two)
-        int2 e = make_int2(0, -1);
+        int4 e = make_int4(0, -1, 0, 0);
         if (tid < 17) e = l.seg[(size_t)rg * gr.rs + s0 + tid];   // (seg ends with 16 spare entries)
         const int nu = l.nruns[rg];
         int in_front = 0;
         if (w == 0 && (s0 < nu || blk == 0)) {
             // the ranges in front of this one: where its runs stand in the dense list of touched rows; the list's first
             // workgroup also files the total
-            int c = lane < TS_NR ? l.nruns[lane] : 0;
-#pragma unroll
-            for (int o = 1; o < 16; o <<= 1) {
-                const int u = __shfl_up(c, o, 64);
-                if (lane >= o) c += u;
-            }
+            const int c = wave_scan_incl(lane < TS_NR ? l.nruns[lane] : 0);
             in_front = rg ? __builtin_amdgcn_readlane(c, (rg + 15) & 15) : 0;
             if (blk == 0 && lane == 15) n_touch[li] = c;
         }
@@ -2142,15 +2109,20 @@ __global__ __launch_bounds__(256) void table_segsum_kernel(SegList l0, SegList l
         if (tid < 17) {
             const bool live = s0 + tid <= nu;                // entry nu closes the last run
             sh_b[tid] = live ? e.x : 0;
-            if (tid < 16) { sh_d[tid] = (live && s0 + tid < nu) ? e.y : -1; if (s0 + tid < nu) l.ulist[in_front + s0 + tid] = e.y; }
+            if (tid < 16) {
+                sh_d[tid] = (live && s0 + tid < nu) ? e.y : -1;
+                sh_r[tid][0] = e.z; sh_r[tid][1] = e.w;
+                if (s0 + tid < nu) l.ulist[in_front + s0 + tid] = e.y;
+            }
         }
         __syncthreads();
         // group g = tid >> 4, lane j of the group owns floats [4 j, 4 j + 4) of the row
         const int g = tid >> 4, j = tid & 15;
         const int dest = sh_d[g];
-        const int b = sh_b[g], m = dest >= 0 ? sh_b[g + 1] - b : 0;
+        const int m = dest >= 0 ? sh_b[g + 1] - sh_b[g] : 0;
         if (m >= 1 && m <= 4) {
-            int x = j < m ? l.sorted[b + j] : 0x7fffffff;    // sorted over lanes 0..3 of the group (lanes 4..15 hold +infinity)
+            // sorted over lanes 0..3 of the group (lanes 4..15 hold +infinity)
+            int x = j < m ? (int)(((unsigned)sh_r[g][(j >> 1) & 1] >> (16 * (j & 1))) & 0xffffu) : 0x7fffffff;
             {
                 int o = __shfl_xor(x, 1, 64);
                 bool up = (j & 2) == 0, lower = (j & 1) == 0;
@@ -2173,60 +2145,144 @@ __global__ __launch_bounds__(256) void table_segsum_kernel(SegList l0, SegList l
             for (int i = 1; i < 4; i++) { acc.x += v[i].x; acc.y += v[i].y; acc.z += v[i].z; acc.w += v[i].w; }      // ascending source row
             *reinterpret_cast<float4*>(l.table + (size_t)dest * PC_L + 4 * j) = acc;
         }
+        PC_SEG_T1(region, 4);
         return;
     }
-    if (kind == 1) {                                         // one wave per medium run
+    const int nwords = (l.n + 31) >> 5;                      // words of a bitmap over the list's row numbers
+    if (kind == 1) {                                         // one wave per medium run (5 .. 64 rows)
         const int h = blk * 4 + w;
-        const int rs = h < n_touch[2 + 2 * li] ? l.medium[h] : -1;      // (the request rides with the count)
-        if (rs < 0) return;                                  // wave-uniform
-        const int2 e = l.seg[rs], e1 = l.seg[rs + 1];        // {start, destination}, {next start, -}
-        const int b = __builtin_amdgcn_readfirstlane(e.x), dest = __builtin_amdgcn_readfirstlane(e.y), m = __builtin_amdgcn_readfirstlane(e1.x) - b;
-        float4 r;
-        if (m <= 64) r = ts_sum_regs<1>(l.src, l.sorted, b, m, lane);
-        else if (m <= 128) r = ts_sum_regs<2>(l.src, l.sorted, b, m, lane);
-        else r = ts_sum_regs<4>(l.src, l.sorted, b, m, lane);
-        if (lane < 16) *reinterpret_cast<float4*>(l.table + (size_t)dest * PC_L + 4 * lane) = r;
-        return;
-    }
-    {                                                        // one workgroup per long run
-        if (blk >= n_touch[3 + 2 * li]) return;
-        const int rs = l.longl[blk];
-        const int dest = __builtin_amdgcn_readfirstlane(l.seg[rs].y);
-        const int nq = ((((l.n + 3) >> 2) + 63) >> 6) << 6;           // a wave's stretch of the list (whole chunks of 64 entries)
-        const int c0 = w * nq, c1 = min(l.n, c0 + nq);
-        ts_l16* qu = (ts_l16*)queue[w];                           // matching rows waiting for their turn (< 64 left over + 64 new)
-        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-        int pend = 0;                                             // wave-uniform
-        for (int c = c0; c < c1; c += 256) {                      // four chunks per round: their loads in flight together
-            int d[4];
+        const int2 ent = l.medium[h];                        // (the list is as long as this region has waves: requested with the count)
+        if (h >= n_touch[2 + 2 * li]) return;                // wave-uniform
+        const int start = __builtin_amdgcn_readfirstlane((int)((unsigned)ent.x >> 16)), m = __builtin_amdgcn_readfirstlane(ent.x & 0xffff);
+        const int dest = __builtin_amdgcn_readfirstlane(ent.y);
+        PC_SEG_P(0, m);
+        const int row = lane < m ? l.sorted[start + lane] : -1;
+        ts_l32* bm = (ts_l32*)bits + w * (TS_MAXN / 32);
+        ts_l16* qu = (ts_l16*)queue + w * TS_QCAP;
+        for (int i = lane; i < nwords; i += 64) bm[i] = 0u;
+        __builtin_amdgcn_wave_barrier();
+        if (row >= 0) __hip_atomic_fetch_or(&bm[row >> 5], 1u << (row & 31), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+        __builtin_amdgcn_wave_barrier();
+        PC_SEG_P(1, m);
+        // lane i reads words [i wpl, (i + 1) wpl): ascending from lane to lane, so one scan of the lanes' counts places everything
+        {
+            constexpr int WPL = TS_MAXN / 32 / 64;
+            const int wpl = (nwords + 63) >> 6;
+            unsigned vv[WPL];
+            int cnt = 0;
 #pragma unroll
-            for (int u = 0; u < 4; u++) { const int e = c + 64 * u + lane; d[u] = e < c1 ? l.idx[e] : -1; }
+            for (int u = 0; u < WPL; u++) {
+                const int i = lane * wpl + u;
+                vv[u] = (u < wpl && i < nwords) ? (unsigned)bm[i] : 0u;
+                cnt += __popc(vv[u]);
+            }
+            int o = wave_scan_incl(cnt) - cnt;               // exclusive prefix: where this lane's rows go
 #pragma unroll
-            for (int u = 0; u < 4; u++) {
-                const bool hit = d[u] == dest;
-                const unsigned long long mk = __ballot(hit);
-                if (mk) {
-                    if (hit) qu[pend + __popcll(mk & ((1ull << lane) - 1ull))] = (unsigned short)(c + 64 * u + lane);
-                    pend += __popcll(mk);
-                    __builtin_amdgcn_wave_barrier();
-                    if (pend >= 64) {
-                        const int mine = qu[lane];
-                        const int rest = pend - 64;
-                        const unsigned short carry = lane < rest ? qu[64 + lane] : (unsigned short)0;
-                        __builtin_amdgcn_wave_barrier();
-                        if (lane < rest) qu[lane] = carry;
-                        __builtin_amdgcn_wave_barrier();
-                        ts_add64(acc, l.src, mine, 64, lane);
-                        pend = rest;
-                    }
+            for (int u = 0; u < WPL; u++) {
+                unsigned v = vv[u];
+                const int base = 32 * (lane * wpl + u);
+                while (v) {
+                    qu[o++] = (unsigned short)(base + __ffs((int)v) - 1);
+                    v &= v - 1u;
                 }
             }
         }
-        if (pend) ts_add64(acc, l.src, lane < pend ? (int)qu[lane] : 0, pend, lane);
+        __builtin_amdgcn_wave_barrier();
+        PC_SEG_P(2, m);
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+        ts_add_queue(acc, l.src, qu, m, lane);
+        PC_SEG_P(3, m);
+        const float4 r = ts_fold_groups(acc);
+        if (lane < 16) *reinterpret_cast<float4*>(l.table + (size_t)dest * PC_L + 4 * lane) = r;
+        PC_SEG_T1(region, m);
+        return;
+    }
+    {                                                        // one workgroup per long run
+        const int2 ent = l.longl[blk];
+        if (blk >= n_touch[3 + 2 * li]) return;
+        const int start = __builtin_amdgcn_readfirstlane((int)((unsigned)ent.x >> 16)), m = __builtin_amdgcn_readfirstlane(ent.x & 0xffff);
+        const int dest = __builtin_amdgcn_readfirstlane(ent.y);
+        ts_l32* bm = (ts_l32*)bits;                          // one bitmap for the workgroup
+        // the run's row numbers, eight per thread and round (requested before the bitmap is cleared)
+        int rows[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) rows[u] = tid + 256 * u < m ? l.sorted[start + tid + 256 * u] : -1;
+        for (int i = tid; i < nwords; i += 256) bm[i] = 0u;
+        __syncthreads();
+        for (int i0 = 0; i0 < m; i0 += 8 * 256) {
+#pragma unroll
+            for (int u = 0; u < 8; u++)
+                if (rows[u] >= 0) __hip_atomic_fetch_or(&bm[rows[u] >> 5], 1u << (rows[u] & 31), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            if (i0 + 8 * 256 < m) {
+#pragma unroll
+                for (int u = 0; u < 8; u++) { const int i = i0 + 8 * 256 + tid + 256 * u; rows[u] = i < m ? l.sorted[start + i] : -1; }
+            }
+        }
+        __syncthreads();
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (m <= TS_SHQ) {
+            // the whole run in one queue: thread t reads words [t wpt, (t + 1) wpt), ascending from thread to thread; wave w then
+            // adds rows [w q, (w + 1) q) of it (q a multiple of 16: the groups' 32-byte reads stay aligned)
+            constexpr int WPT = TS_MAXN / 32 / 256;
+            const int wpt = (nwords + 255) >> 8;
+            unsigned vv[WPT];
+            int cnt = 0;
+#pragma unroll
+            for (int u = 0; u < WPT; u++) {
+                const int i = tid * wpt + u;
+                vv[u] = (u < wpt && i < nwords) ? (unsigned)bm[i] : 0u;
+                cnt += __popc(vv[u]);
+            }
+            const int incl = wave_scan_incl(cnt);
+            if (lane == 63) sh_b[w] = incl;
+            __syncthreads();
+            int o = incl - cnt;
+#pragma unroll
+            for (int k = 0; k < 3; k++) o += k < w ? sh_b[k] : 0;
+            ts_l16* qa = (ts_l16*)queue;
+#pragma unroll
+            for (int u = 0; u < WPT; u++) {
+                unsigned v = vv[u];
+                const int base = 32 * (tid * wpt + u);
+                while (v) {
+                    qa[o++] = (unsigned short)(base + __ffs((int)v) - 1);
+                    v &= v - 1u;
+                }
+            }
+            __syncthreads();
+            const int q = (((m + 3) >> 2) + 15) & ~15;
+            const int lo = w * q;
+            ts_add_queue(acc, l.src, qa + lo, max(0, min(m, lo + q) - lo), lane);
+        } else {
+            // wave w: words [w qw, (w + 1) qw) of the bitmap, 32 words -- 1024 row numbers, sixteen per lane -- a round; full blocks
+            // of 64 rows are added as they fill, what is left waits at the head of the wave's queue
+            ts_l16* qu = (ts_l16*)queue + w * TS_QCAP;
+            const int qw = (((nwords + 3) >> 2) + 31) & ~31;
+            const int wlo = w * qw, whi = min(nwords, wlo + qw);
+            int pend = 0;                                    // wave-uniform
+            for (int w0 = wlo; w0 < whi; w0 += 32) {
+                const int wi = w0 + (lane >> 1);
+                const unsigned v = wi < whi ? ((unsigned)bm[wi] >> (16 * (lane & 1))) & 0xffffu : 0u;
+                pend += ts_expand_bits(qu, pend, v, 32 * wi + 16 * (lane & 1), lane);
+                __builtin_amdgcn_wave_barrier();
+                const int full = pend & ~63;
+                if (full) {
+                    ts_add_queue(acc, l.src, qu, full, lane);
+                    const int rest = pend - full;
+                    const unsigned short carry = lane < rest ? (unsigned short)qu[full + lane] : (unsigned short)0;
+                    __builtin_amdgcn_wave_barrier();
+                    if (lane < rest) qu[lane] = carry;
+                    __builtin_amdgcn_wave_barrier();
+                    pend = rest;
+                }
+            }
+            if (pend) ts_add_queue(acc, l.src, qu, pend, lane);
+        }
         const float4 part = ts_fold_groups(acc);
         if (lane < 16) *reinterpret_cast<float4*>(&fold[w][4 * lane]) = part;
         __syncthreads();
         if (w == 0) l.table[(size_t)dest * PC_L + lane] = (fold[0][lane] + fold[1][lane]) + (fold[2][lane] + fold[3][lane]);
+        PC_SEG_T1(region, m);
     }
 }
 
@@ -2236,8 +2292,8 @@ struct FusedWs {
     float *part, *h, *dpi, *dtp, *dc, *dh, *dt, *ecsrc;
     int32_t *ecidx, *cids, *ulist, *n_u, *topk_by_type;
     int32_t *tl_c, *tp_c, *tl_q, *tp_q, *n_touch;       // touched rows of the two big tables: ascending lists, row -> list position
-    int32_t *srt_c, *srt_q; int2 *seg_c, *seg_q;        // sort path: source rows ordered by destination, {start, destination} of each run
-    int32_t *med_c, *med_q, *lng_c, *lng_q;             // ... the runs of 5 .. TS_LONG rows and the longer ones (indices into seg)
+    int32_t *srt_c, *srt_q; int4 *seg_c, *seg_q;        // sort path: source rows ordered by destination, the run table (see SortList)
+    int2 *med_c, *med_q, *lng_c, *lng_q;                // ... the runs of 5 .. TS_LONG rows and the longer ones
     bool sorted_path;
     float *tslab_c, *tslab_q;                           // [TG_WGS][TG_CAP][64] each
     float* part_val;
@@ -2274,7 +2330,8 @@ static FusedWs fused_ws_layout(void* base, int B, int T, int K) {
     w.ulist = w.n_u = w.topk_by_type = nullptr;
     w.tl_c = w.tp_c = w.tl_q = w.tp_q = w.n_touch = nullptr;
     w.tslab_c = w.tslab_q = nullptr;
-    w.srt_c = w.srt_q = w.med_c = w.med_q = w.lng_c = w.lng_q = nullptr;
+    w.srt_c = w.srt_q = nullptr;
+    w.med_c = w.med_q = w.lng_c = w.lng_q = nullptr;
     w.seg_c = w.seg_q = nullptr;
     w.sorted_path = false;
     w.part_val = nullptr;
@@ -2291,12 +2348,13 @@ static FusedWs fused_ws_layout(void* base, int B, int T, int K) {
         if (w.sorted_path) {
             w.srt_c = (int32_t*)take((size_t)nc * 4);
             w.srt_q = (int32_t*)take((size_t)B * 4);
-            w.seg_c = (int2*)take((size_t)(TS_NR * ts_range_stride(T) + 16) * 8);      // (+ 16: a workgroup of the consumer requests 17 entries at once)
-            w.seg_q = (int2*)take((size_t)(TS_NR * ts_range_stride(T) + 16) * 8);
-            w.med_c = (int32_t*)take((size_t)(nc / 5 + 1) * 4);
-            w.med_q = (int32_t*)take((size_t)(B / 5 + 1) * 4);
-            w.lng_c = (int32_t*)take((size_t)(nc / TS_LONG + 1) * 4);
-            w.lng_q = (int32_t*)take((size_t)(B / TS_LONG + 1) * 4);
+            w.seg_c = (int4*)take((size_t)(TS_NR * ts_range_stride(T) + 16) * 16);     // (+ 16: a workgroup of the consumer requests 17 entries at once)
+            w.seg_q = (int4*)take((size_t)(TS_NR * ts_range_stride(T) + 16) * 16);
+            // (the run lists: one entry per wave / workgroup of the consumer's grid regions -- read before the count is known)
+            w.med_c = (int2*)take((size_t)(nc / 5 + 8) * 8);
+            w.med_q = (int2*)take((size_t)(B / 5 + 8) * 8);
+            w.lng_c = (int2*)take((size_t)(nc / TS_LONG + 1) * 8);
+            w.lng_q = (int2*)take((size_t)(B / TS_LONG + 1) * 8);
         }
         w.tslab_c = (float*)take((size_t)TG_WGS * TG_CAP * PC_L * 4);      // (the LDS-table form: PC_OPT_SORTED_TABLE_GRADIENTS, below)
         w.tslab_q = (float*)take((size_t)TG_WGS * TG_CAP * PC_L * 4);
@@ -2492,7 +2550,7 @@ static int fused_step_impl(const pc_joint_tensors* p, const pc_joint_tensors* g,
     }
     // which form sums the table gradients (PC_OPT_SORTED_TABLE_GRADIENTS in the header): with hidden-layer dropout every sample
     // selects its own K types -- thousands of touched rows, beyond the LDS-table form's 512 -- so the sorted form runs; without
-    // it the LDS-table form (22 us against 60) unless the caller asked for the sorted one
+    // it the LDS-table form (22 us against 33) unless the caller asked for the sorted one
     const bool sorted_tables = !w.small && w.sorted_path && (per_sample || pc_opt_sorted_tables());
     if (sorted_tables) {
         // table gradients: source rows sorted by destination, then one wave per destination adds its run in ascending source order
@@ -2504,8 +2562,8 @@ static int fused_step_impl(const pc_joint_tensors* p, const pc_joint_tensors* g,
                                                             hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         (void)sattr;
         PC_LAUNCH(table_sort_kernel, dim3(2 * TS_NR), dim3(1024), table_sort_lds_bytes(nc, T), st, sc, sq, T, w.n_touch);
-        const SegList gc = {g->comp_types, w.ecsrc, w.srt_c, w.seg_c, w.tl_c, w.med_c, w.lng_c, sc.nruns, sc.idx, sc.n};
-        const SegList gq = {g->query_types, w.dt, w.srt_q, w.seg_q, w.tl_q, w.med_q, w.lng_q, sq.nruns, sq.idx, sq.n};
+        const SegList gc = {g->comp_types, w.ecsrc, w.srt_c, w.seg_c, w.tl_c, w.med_c, w.lng_c, sc.nruns, sc.n};
+        const SegList gq = {g->query_types, w.dt, w.srt_q, w.seg_q, w.tl_q, w.med_q, w.lng_q, sq.nruns, sq.n};
         // grid regions sized for the capacities (the counts live on the device: workgroups past them leave at once): runs of up to
         // four rows sixteen per workgroup, runs of 5 .. TS_LONG rows (at most n / 5 of them) a wave each, longer ones a workgroup each
         SegGrid gr;

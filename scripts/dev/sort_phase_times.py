@@ -8,8 +8,10 @@ from p_companion_amd import _lib
 from p_companion_amd.p_companion import PCompanion
 
 T, B, K, p = 34800, 4096, 3, float(sys.argv[1]) if len(sys.argv) > 1 else 0.1
+SEED = int(sys.argv[2]) if len(sys.argv) > 2 else 0
 cfg = SimpleNamespace(PRODUCT_EMB_DIM=128, TYPE_EMB_DIM=64, HIDDEN_SIZE=256, NUM_ATTENTION_HEADS=4, DROPOUT=p, MARGIN=1.0, ALPHA=0.8,
                       NUM_COMP_TYPES=K, NUM_TYPES=T, DEVICE=torch.device("cuda"), LEARNING_RATE=1e-3)
+torch.manual_seed(SEED)
 g = torch.Generator().manual_seed(0)
 m = PCompanion(cfg, torch.randn(2000, 128, generator=g)).cuda().train()
 b = {"query_idx": torch.randint(0, 2000, (B,), generator=g, dtype=torch.int32).cuda(), "query_types": torch.randint(0, 100, (B,), generator=g).cuda(),
@@ -29,3 +31,6 @@ for b in live:
     seq = t[16 * b:16 * b + 11]
     print("workgroup %2d (list %d, range %2d): total %d clk: " % (b, b // nr, b % nr, seq[-1] - seq[0])
           + ", ".join("%s %d" % (names[i - 1], seq[i] - seq[i - 1]) for i in range(1, 11)))
+reg = ["short c", "medium c", "long c", "short q", "medium q", "long q"]
+print("table_segsum_kernel, 5 steps: " + "; ".join("%s: longest wave %d clk, %d waves with work, longest run %d rows" % (reg[i], t[1000 + i], t[1008 + i], t[1016 + i]) for i in range(6)))
+print("a medium run of >= 48 rows: entry + count at %d clk, row numbers in the bitmap at %d, queue at %d, rows added at %d" % tuple(t[900:904]))
