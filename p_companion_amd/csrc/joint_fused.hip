@@ -2075,6 +2075,9 @@ struct SegList { float* table; const float* src; const int32_t* sorted; const in
 // first workgroup of: short 0, medium 0, long 0, short 1, medium 1, long 1; total.  spr: short-run workgroups per range of the table
 // (sixteen runs each), rs: ts_range_stride(T)
 struct SegGrid { int start[7]; int spr[2]; int rs; };
+#define TS_SPR 32          /* grid: short-run workgroups per range of the table and list (16 runs each; the workgroup walks on) */
+#define TS_GMED 128        /* ... workgroups of four medium runs per list */
+#define TS_GLONG 128       /* ... workgroups (long runs) per list */
 #define TS_QCAP 1088       /* a wave's queue of row numbers: 1024 from one round of the longest runs' path + up to 63 left over */
 #define TS_SHQ 1024        /* a long run of up to this many rows is laid out in one queue (the four waves' queues side by side hold 4352) */
 __global__ __launch_bounds__(256) void table_segsum_kernel(SegList l0, SegList l1, int32_t* n_touch, SegGrid gr) {
@@ -2092,7 +2095,8 @@ __global__ __launch_bounds__(256) void table_segsum_kernel(SegList l0, SegList l
     const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
     if (kind == 0) {
         const int spr = li ? gr.spr[1] : gr.spr[0];
-        const int rg = blk / spr, s0 = (blk - rg * spr) * 16;     // runs [s0, s0 + 16) of range rg
+        const int rg = blk / spr;
+        int s0 = (blk - rg * spr) * 16;                           // runs [s0, s0 + 16) of range rg, then spr blocks further on, ...
         // (the run table is requested together with the counts it is checked against: one round trip instead of two)
         int4 e = make_int4(0, -1, 0, 0);
         if (tid < 17) e = l.seg[(size_t)rg * gr.rs + s0 + tid];   // (seg ends with 16 spare entries)
@@ -2105,6 +2109,7 @@ __global__ __launch_bounds__(256) void table_segsum_kernel(SegList l0, SegList l
             in_front = rg ? __builtin_amdgcn_readlane(c, (rg + 15) & 15) : 0;
             if (blk == 0 && lane == 15) n_touch[li] = c;
         }
+        for (;;) {
         if (s0 >= nu) return;                                // workgroup-uniform
         if (tid < 17) {
             const bool live = s0 + tid <= nu;                // entry nu closes the last run
@@ -2146,13 +2151,19 @@ __global__ __launch_bounds__(256) void table_segsum_kernel(SegList l0, SegList l
             *reinterpret_cast<float4*>(l.table + (size_t)dest * PC_L + 4 * j) = acc;
         }
         PC_SEG_T1(region, 4);
-        return;
+        // (a range with more than 16 spr runs: rare -- the grid gives every range min(its capacity, TS_SPR) blocks)
+        s0 += 16 * spr;
+        if (s0 >= nu) return;
+        __syncthreads();
+        if (tid < 17) e = l.seg[(size_t)rg * gr.rs + s0 + tid];
+        }
     }
     const int nwords = (l.n + 31) >> 5;                      // words of a bitmap over the list's row numbers
     if (kind == 1) {                                         // one wave per medium run (5 .. 64 rows)
-        const int h = blk * 4 + w;
-        const int2 ent = l.medium[h];                        // (the list is as long as this region has waves: requested with the count)
-        if (h >= n_touch[2 + 2 * li]) return;                // wave-uniform
+        int h = blk * 4 + w;
+        int2 ent = l.medium[h];                              // (the list is as long as this region has waves: requested with the count)
+        const int nmed = n_touch[2 + 2 * li], hstep = 4 * (gr.start[region + 1] - gr.start[region]);
+        for (; h < nmed; h += hstep, ent = l.medium[min(h, nmed - 1)]) {       // wave-uniform
         const int start = __builtin_amdgcn_readfirstlane((int)((unsigned)ent.x >> 16)), m = __builtin_amdgcn_readfirstlane(ent.x & 0xffff);
         const int dest = __builtin_amdgcn_readfirstlane(ent.y);
         PC_SEG_P(0, m);
@@ -2195,11 +2206,14 @@ __global__ __launch_bounds__(256) void table_segsum_kernel(SegList l0, SegList l
         const float4 r = ts_fold_groups(acc);
         if (lane < 16) *reinterpret_cast<float4*>(l.table + (size_t)dest * PC_L + 4 * lane) = r;
         PC_SEG_T1(region, m);
+        __builtin_amdgcn_wave_barrier();
+        }
         return;
     }
     {                                                        // one workgroup per long run
-        const int2 ent = l.longl[blk];
-        if (blk >= n_touch[3 + 2 * li]) return;
+        int2 ent = l.longl[blk];
+        const int nlong = n_touch[3 + 2 * li], lstep = gr.start[region + 1] - gr.start[region];
+        for (int hb = blk; hb < nlong; hb += lstep, ent = l.longl[min(hb, nlong - 1)]) {
         const int start = __builtin_amdgcn_readfirstlane((int)((unsigned)ent.x >> 16)), m = __builtin_amdgcn_readfirstlane(ent.x & 0xffff);
         const int dest = __builtin_amdgcn_readfirstlane(ent.y);
         ts_l32* bm = (ts_l32*)bits;                          // one bitmap for the workgroup
@@ -2283,6 +2297,8 @@ __global__ __launch_bounds__(256) void table_segsum_kernel(SegList l0, SegList l
         __syncthreads();
         if (w == 0) l.table[(size_t)dest * PC_L + lane] = (fold[0][lane] + fold[1][lane]) + (fold[2][lane] + fold[3][lane]);
         PC_SEG_T1(region, m);
+        __syncthreads();
+        }
     }
 }
 
@@ -2571,8 +2587,13 @@ static int fused_step_impl(const pc_joint_tensors* p, const pc_joint_tensors* g,
         // (short runs: per range of the table's rows, at most min(its bins, the list's rows) of them)
         const int bins = 2 * ts_range_words(T);
         gr.rs = ts_range_stride(T);
-        gr.spr[0] = ((bins < cap_c ? bins : cap_c) + 15) / 16; gr.spr[1] = ((bins < cap_q ? bins : cap_q) + 15) / 16;
-        const int sizes[6] = {TS_NR * gr.spr[0], (nc / 5 + 3) / 4, nc / TS_LONG + 1, TS_NR * gr.spr[1], (B / 5 + 3) / 4, B / TS_LONG + 1};
+        // (every region is bounded: its workgroups walk on by the size of the region while their list lasts -- a workgroup that
+        // finds nothing to do still waits a round trip to memory for the count that tells it so, and five thousand of them, seven
+        // to a CU at a time, were half of this kernel)
+        auto upto = [](int v, int cap) { return v < cap ? v : cap; };
+        gr.spr[0] = upto(((bins < cap_c ? bins : cap_c) + 15) / 16, TS_SPR); gr.spr[1] = upto(((bins < cap_q ? bins : cap_q) + 15) / 16, TS_SPR);
+        const int sizes[6] = {TS_NR * gr.spr[0], upto((nc / 5 + 3) / 4, TS_GMED), upto(nc / TS_LONG + 1, TS_GLONG),
+                              TS_NR * gr.spr[1], upto((B / 5 + 3) / 4, TS_GMED), upto(B / TS_LONG + 1, TS_GLONG)};
         for (int i = 0; i < 6; i++) { gr.start[i] = at; at += sizes[i]; }
         gr.start[6] = at;
         PC_LAUNCH(table_segsum_kernel, dim3(at), dim3(256), 0, st, gc, gq, w.n_touch, gr);
