@@ -50,7 +50,7 @@ struct FusedArgs {
     float* ecsrc; int32_t* ecidx;         // [B (K + 2)][64] / [B (K + 2)]: rows added into dE_c[ecidx[r]]
     int32_t* cids;                        // [2][B] validated (clamped) query_idx / query_types for the kernels that follow
     int32_t* bad; int64_t* step_count;
-    int32_t* run_counts;                  // (large tables, sorted gradients) the four run-list counters table_sort_kernel appends through: zeroed here
+    int32_t* run_counts;                  // (large tables, sorted gradients) the six run-list counters table_sort_kernel appends through: zeroed here
     float* slabs; int slab_floats;        // WGRAD: one gradient slab per workgroup (layout: wg_off_*)
     // PAIRS: the batch is built here from labelled pairs (data_loader.py:133-157, see pc_build_complementary_batch);
     // query_idx .. neg_items above are then OUTPUTS (the batch as the loader would have handed it), written on the way
@@ -320,7 +320,7 @@ __global__ __launch_bounds__(256) void joint_tile_kernel(FusedArgs a, int ldsims
     constexpr int MBK = KC ? KC : FK;          // row blocks of the K-row products
     PC_STAMP(0);
     if (blockIdx.x == 0 && tid == 0 && a.step_count) *a.step_count += 1;     // Adam's step (read by the finish kernel)
-    if (blockIdx.x == 0 && tid < 4 && a.run_counts) a.run_counts[tid] = 0;
+    if (blockIdx.x == 0 && tid < 6 && a.run_counts) a.run_counts[tid] = 0;
 
     // ---- every weight fragment this wave will multiply by, requested now (see load_b)
     BFrag<4> f_h = {}, f_dh = {}, f_s0 = {}, f_s1 = {};
@@ -1801,11 +1801,15 @@ __global__ __launch_bounds__(256) void table_reduce_kernel(TableList l0, TableLi
 // 34 us, of which 60 % was one device atomic per run from the thread that scanned it; this form 12 us.  The consumer: 29 -> 21 us.)
 #define TS_MAXN 24576       /* source rows per list (16-bit positions and row numbers) */
 #define TS_LONG 64         /* a run of up to this many rows is summed by one wave, a longer one by a workgroup */
-struct SortList { const int32_t* idx; int n; int32_t* sorted; int4* seg; int2 *medium, *longl; int32_t* nruns; };
+#define TS_GIANT 256       /* ... and a run longer than this by several workgroups (256 rows each), the last of which adds their sums */
+struct SortList { const int32_t* idx; int n; int32_t* sorted; int4* seg; int2 *medium, *longl, *giant; int32_t *nruns, *gcnt; };
+// entries of the giant list: ceil(rows / 256) per run of more than TS_GIANT rows -- at most n / 256 full ones and one more per run
+static inline int ts_giant_cap(int n) { return n / 256 + n / (TS_GIANT + 1) + 4; }
 // sorted [n]; seg [TS_NR ts_range_stride(T)] = {start of the run, its destination, its rows if it has up to four}, one stretch per
 // range of the table's rows (see table_sort_kernel), nruns [TS_NR]: the runs in each; medium [n / 5]: the runs of 5 .. TS_LONG rows,
-// longl [n / TS_LONG]: the longer ones ({start << 16 | rows, destination}, in no particular order); n_touch [2 + 2 list],
-// [3 + 2 list]: their counts
+// longl [n / TS_LONG]: those of up to TS_GIANT ({start << 16 | rows, destination}, in no particular order); giant [ts_giant_cap(n)]:
+// the longer ones, one entry per 256 rows ({start << 16 | rows, destination | part << 16}, a run's parts side by side; gcnt
+// [first entry of the run]: parts done, zeroed here); n_touch [2 + 2 list], [3 + 2 list], [6 + list]: the lists' counts
 
 #ifdef PC_SORT_TIMING
 // developer build (scripts/dev/sort_phase_times.py): shader-clock stamps of every workgroup's thread 0 at the phases of the sort kernel
@@ -1858,6 +1862,10 @@ __device__ __forceinline__ void block_scan3_1024(int& a, int& b, int& c, ts_l32*
 #define TS_NR 16
 #endif
 static_assert(TS_NR <= 16, "the consumer sums the ranges' run counts over sixteen lanes");
+// a run's word in the `lists` counter of table_sort_kernel (see there)
+__device__ __forceinline__ int ts_list_word(unsigned c) {
+    return c > TS_GIANT ? (int)(((c + 255u) >> 8) << 23) : c > TS_LONG ? 1 << 13 : c > 4u ? 1 : 0;
+}
 __host__ __device__ inline int ts_range_words(int T) { return (((T + 1) >> 1) + TS_NR - 1) / TS_NR; }
 __host__ __device__ inline int ts_range_stride(int T) { return 2 * ts_range_words(T) + 1; }       // runs of a range + its closing entry
 __global__ __launch_bounds__(1024) void table_sort_kernel(SortList l0, SortList l1, int T, int32_t* n_touch) {
@@ -1868,6 +1876,7 @@ __global__ __launch_bounds__(1024) void table_sort_kernel(SortList l0, SortList 
     SortList l;
     l.idx = li ? l1.idx : l0.idx; l.n = li ? l1.n : l0.n; l.sorted = li ? l1.sorted : l0.sorted; l.seg = li ? l1.seg : l0.seg;
     l.medium = li ? l1.medium : l0.medium; l.longl = li ? l1.longl : l0.longl; l.nruns = li ? l1.nruns : l0.nruns;
+    l.giant = li ? l1.giant : l0.giant; l.gcnt = li ? l1.gcnt : l0.gcnt;
     const int n = l.n;
     const int words = (T + 1) >> 1;                          // two 16-bit bins per word: bin d = half (d & 1) of word d >> 1
     const int rw = ts_range_words(T), rs = ts_range_stride(T);
@@ -1902,14 +1911,15 @@ __global__ __launch_bounds__(1024) void table_sort_kernel(SortList l0, SortList 
     __syncthreads();
     PC_ST(2);
     // ---- scan over the range's bins: thread t owns words [t wpt, ... + wpt) (one or two at the shipped sizes).
-    // packed = rows (low half) | destinations (high half); lists = runs of 5 .. TS_LONG rows (low half) | longer ones (high half)
+    // packed = rows (low half) | destinations (high half); lists = runs of 5 .. TS_LONG rows (bits 0 .. 12) | of up to TS_GIANT
+    // (13 .. 22) | 256-row parts of the longer ones (23 .. 31) -- a list of 24 576 rows has at most 4 915 / 378 / 191 of them
     const int wpt = (nw + 1023) >> 10;
     const int w0 = min(nw, tid * wpt), w1 = min(nw, w0 + wpt);
     int packed = 0, lists = 0;
     for (int i = w0; i < w1; i++) {
         const unsigned c = hist[i], c0 = c & 0xffffu, c1 = c >> 16;
         packed += (int)(c0 + c1) + ((c0 ? 0x10000 : 0) + (c1 ? 0x10000 : 0));
-        lists += (c0 > TS_LONG ? 0x10000 : c0 > 4u ? 1 : 0) + (c1 > TS_LONG ? 0x10000 : c1 > 4u ? 1 : 0);
+        lists += ts_list_word(c0) + ts_list_word(c1);
     }
     int incl = packed, lincl = lists;
     PC_ST(3);
@@ -1922,12 +1932,13 @@ __global__ __launch_bounds__(1024) void table_sort_kernel(SortList l0, SortList 
     // the list's workgroups: ONE returning device atomic per workgroup and list reserves its entries (counters n_touch[2 + 2 list],
     // [3 + 2 list], zeroed by the tile kernel of the step) -- issued here, answered while the placement below runs (one per run
     // from the thread that scans it -- ten dependent round trips to L2 in a row -- was 60 % of an earlier form of this kernel)
-    __shared__ int sh_lbase[2], sh_rows, sh_runs;
-    int mres = 0, lres = 0;                                  // (handed to the workgroup behind the placement: no wait here)
+    __shared__ int sh_lbase[3], sh_rows, sh_runs;
+    int mres = 0, lres = 0, gres = 0;                        // (handed to the workgroup behind the placement: no wait here)
     if (tid == 1023) {
-        const int nm = lincl & 0xffff, nl = lincl >> 16, rows = incl & 0xffff, runs = incl >> 16;
+        const int nm = lincl & 0x1fff, nl = (lincl >> 13) & 0x3ff, ng = (int)((unsigned)lincl >> 23), rows = incl & 0xffff, runs = incl >> 16;
         if (nm) mres = atomicAdd(&n_touch[2 + 2 * li], nm);
         if (nl) lres = atomicAdd(&n_touch[3 + 2 * li], nl);
+        if (ng) gres = atomicAdd(&n_touch[6 + li], ng);
         sh_rows = rows; sh_runs = runs;
         l.nruns[rg] = runs;
         l.seg[(size_t)rg * rs + runs] = make_int4(row_base + rows, -1, 0, 0);       // closes the range's last run
@@ -1956,7 +1967,7 @@ __global__ __launch_bounds__(1024) void table_sort_kernel(SortList l0, SortList 
             const unsigned old = __hip_atomic_fetch_add(&hist[dreg[j] >> 1], (dreg[j] & 1) ? 0x10000u : 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             out[((dreg[j] & 1) ? old >> 16 : old & 0xffffu) - (unsigned)row_base] = (unsigned short)(tid + 1024 * j);
         }
-    if (tid == 1023) { sh_lbase[0] = mres; sh_lbase[1] = lres; }
+    if (tid == 1023) { sh_lbase[0] = mres; sh_lbase[1] = lres; sh_lbase[2] = gres; }
     __syncthreads();
     PC_ST(8);
     // ---- the run table of this range, dense (a wave's store: sixteen cache lines): {start of the run, destination, its rows if
@@ -1978,7 +1989,8 @@ __global__ __launch_bounds__(1024) void table_sort_kernel(SortList l0, SortList 
     // ---- the run lists' entries, self-contained ({start << 16 | rows, destination}: their consumers do not read the run table):
     // a second walk over the thread's words has the lengths again
     {
-        int mpos = sh_lbase[0] + ((lincl - lists) & 0xffff), lpos = sh_lbase[1] + ((lincl - lists) >> 16);
+        const unsigned excl = (unsigned)(lincl - lists);
+        int mpos = sh_lbase[0] + (int)(excl & 0x1fffu), lpos = sh_lbase[1] + (int)((excl >> 13) & 0x3ffu), gpos = sh_lbase[2] + (int)(excl >> 23);
         unsigned prev = (unsigned)run0;
         for (int i = w0; i < w1; i++) {
             const unsigned h = hist[i], e0 = h & 0xffffu, e1 = h >> 16;
@@ -1986,7 +1998,10 @@ __global__ __launch_bounds__(1024) void table_sort_kernel(SortList l0, SortList 
 #pragma unroll
             for (int u = 0; u < 2; u++) {
                 const int2 ent = make_int2((int)((ss[u] << 16) | cc[u]), 2 * (rlo + i) + u);
-                if (cc[u] > TS_LONG) l.longl[lpos++] = ent;
+                if (cc[u] > TS_GIANT) {                       // one entry per 256 rows of the run (ascending row order), side by side
+                    l.gcnt[gpos] = 0;
+                    for (unsigned pt = 0; pt < (cc[u] + 255u) >> 8; pt++) l.giant[gpos++] = make_int2(ent.x, ent.y | (int)(pt << 16));
+                } else if (cc[u] > TS_LONG) l.longl[lpos++] = ent;
                 else if (cc[u] > 4u) l.medium[mpos++] = ent;
             }
             prev = e1;
@@ -2044,24 +2059,17 @@ __device__ __forceinline__ void ts_add_queue(float4& acc, const float* src, cons
         if (mm > 64) ts_acc64(acc, v1);
     }
 }
-// The wave's lanes each hold some bits of a bitmap of row numbers (v: the bits, base: the row number of bit 0) in ascending lane
-// order: the set bits' row numbers are appended to the queue qu at position `at`, ascending; returns how many.
-__device__ __forceinline__ int ts_expand_bits(ts_l16* qu, int at, unsigned v, int base, int lane) {
-    const int mine = __popc(v), incl = wave_scan_incl(mine);
-    int o = at + incl - mine;
-    while (v) {
-        qu[o++] = (unsigned short)(base + __ffs((int)v) - 1);
-        v &= v - 1u;
-    }
-    return __builtin_amdgcn_readlane(incl, 63);
-}
 // By the length m of a destination's run (its rows stand in `sorted` in the order the placement's atomics gave them):
 //   m <= 4              (most of them: a type a few samples selected) sixteen runs per workgroup, one 16-lane group per run, four
 //                       runs per wave instruction: the run's rows -- they came with the run table's entry -- sorted over four
 //                       lanes, added as float4 per lane
 //   m <= TS_LONG        (the list `medium`) one wave per run
-//   m > TS_LONG         (the list `longl`: a destination hundreds of samples point at) one workgroup per run, each wave a quarter
-//                       of the row NUMBERS (not of the run), the quarters folded (w0 + w1) + (w2 + w3)
+//   m <= TS_GIANT       (the list `longl`) one workgroup per run, each wave 64 rows of its ascending order, the four sums folded
+//                       (w0 + w1) + (w2 + w3)
+//   m > TS_GIANT        (the list `giant`: a destination a good part of the batch points at) one workgroup per 256 rows of the run;
+//                       a CU keeps only so many cache lines in flight (a row is two of them, ~16 clocks per row and CU at this
+//                       step's memory latency: 1 900 rows by one workgroup were 15 us of this kernel's 20), eight of them do.  The
+//                       64-row sums wait in memory; the workgroup that finishes last adds them in ascending order
 // Medium and long runs are sorted through a bitmap: the rows are distinct numbers below n (24 576 at most: 3 KB of LDS), every
 // row sets its bit, the bits read back in ascending order ARE the sorted run (~1 500 clocks whatever the length -- a bitonic
 // network over the wave's registers needs 21 dependent shuffles for 64 rows and 144 for 256, one over LDS 40 000 clocks for 2 048).
@@ -2071,15 +2079,15 @@ __device__ __forceinline__ int ts_expand_bits(ts_l16* qu, int at, unsigned v, in
 // Grid regions per list: [short][medium][long], the two lists one after the other (SegGrid).  The short-run workgroups also write
 // the destination list (ulist: the touched rows of pc_joint_fused_touched, ascending).
 struct SegList { float* table; const float* src; const int32_t* sorted; const int4* seg; int32_t* ulist; const int2 *medium, *longl;
-                 const int32_t* nruns; int n; };
-// first workgroup of: short 0, medium 0, long 0, short 1, medium 1, long 1; total.  spr: short-run workgroups per range of the table
-// (sixteen runs each), rs: ts_range_stride(T)
-struct SegGrid { int start[7]; int spr[2]; int rs; };
+                 const int32_t* nruns; int n; const int2* giant; int32_t* gcnt; float* gprt; };
+// first workgroup of: short 0, medium 0, long 0, giant 0, short 1, medium 1, long 1, giant 1; total.  spr: short-run workgroups per
+// range of the table (sixteen runs each), rs: ts_range_stride(T)
+struct SegGrid { int start[9]; int spr[2]; int rs; };
 #define TS_SPR 32          /* grid: short-run workgroups per range of the table and list (16 runs each; the workgroup walks on) */
 #define TS_GMED 128        /* ... workgroups of four medium runs per list */
 #define TS_GLONG 128       /* ... workgroups (long runs) per list */
-#define TS_QCAP 1088       /* a wave's queue of row numbers: 1024 from one round of the longest runs' path + up to 63 left over */
-#define TS_SHQ 1024        /* a long run of up to this many rows is laid out in one queue (the four waves' queues side by side hold 4352) */
+#define TS_GGIANT 96        /* ... workgroups (256-row parts of giant runs) per list */
+#define TS_QCAP 64         /* a wave's queue of row numbers */
 __global__ __launch_bounds__(256) void table_segsum_kernel(SegList l0, SegList l1, int32_t* n_touch, SegGrid gr) {
     __shared__ float fold[4][PC_L];
     __shared__ unsigned bits[4 * (TS_MAXN / 32)];            // medium: one bitmap per wave; long: the first one, shared
@@ -2089,8 +2097,8 @@ __global__ __launch_bounds__(256) void table_segsum_kernel(SegList l0, SegList l
     const int bid = blockIdx.x;
     int region = 0;
 #pragma unroll
-    for (int i = 1; i < 6; i++) region += bid >= gr.start[i] ? 1 : 0;
-    const int li = region >= 3 ? 1 : 0, kind = region - 3 * li, blk = bid - gr.start[region];
+    for (int i = 1; i < 8; i++) region += bid >= gr.start[i] ? 1 : 0;
+    const int li = region >= 4 ? 1 : 0, kind = region - 4 * li, blk = bid - gr.start[region];
     const SegList& l = li ? l1 : l0;
     const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
     if (kind == 0) {
@@ -2210,12 +2218,15 @@ __global__ __launch_bounds__(256) void table_segsum_kernel(SegList l0, SegList l
         }
         return;
     }
-    {                                                        // one workgroup per long run
-        int2 ent = l.longl[blk];
-        const int nlong = n_touch[3 + 2 * li], lstep = gr.start[region + 1] - gr.start[region];
-        for (int hb = blk; hb < nlong; hb += lstep, ent = l.longl[min(hb, nlong - 1)]) {
+    // ---- long (65 .. TS_GIANT rows: the whole run) and giant runs (a 256-row part of one): a workgroup each.  All its threads
+    // fill ONE bitmap with the run's rows and read it back, thread t words [t wpt, (t + 1) wpt), ascending from thread to thread;
+    // the rows of ranks [64 w, 64 w + 64) (of the part) go to wave w's queue and are added by it -- one batch of loads.
+    const bool giant = kind == 3;
+    int2 ent = giant ? l.giant[blk] : l.longl[blk];
+    const int nent = giant ? n_touch[6 + li] : n_touch[3 + 2 * li], estep = gr.start[region + 1] - gr.start[region];
+    for (int hb = blk; hb < nent; hb += estep, ent = giant ? l.giant[min(hb, nent - 1)] : l.longl[min(hb, nent - 1)]) {
         const int start = __builtin_amdgcn_readfirstlane((int)((unsigned)ent.x >> 16)), m = __builtin_amdgcn_readfirstlane(ent.x & 0xffff);
-        const int dest = __builtin_amdgcn_readfirstlane(ent.y);
+        const int dest = __builtin_amdgcn_readfirstlane(ent.y & 0xffff), pt = __builtin_amdgcn_readfirstlane((int)((unsigned)ent.y >> 16));
         ts_l32* bm = (ts_l32*)bits;                          // one bitmap for the workgroup
         // the run's row numbers, eight per thread and round (requested before the bitmap is cleared)
         int rows[8];
@@ -2233,72 +2244,72 @@ __global__ __launch_bounds__(256) void table_segsum_kernel(SegList l0, SegList l
             }
         }
         __syncthreads();
-        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (m <= TS_SHQ) {
-            // the whole run in one queue: thread t reads words [t wpt, (t + 1) wpt), ascending from thread to thread; wave w then
-            // adds rows [w q, (w + 1) q) of it (q a multiple of 16: the groups' 32-byte reads stay aligned)
-            constexpr int WPT = TS_MAXN / 32 / 256;
-            const int wpt = (nwords + 255) >> 8;
-            unsigned vv[WPT];
-            int cnt = 0;
+        constexpr int WPT = TS_MAXN / 32 / 256;
+        const int wpt = (nwords + 255) >> 8;
+        unsigned vv[WPT];
+        int cnt = 0;
 #pragma unroll
-            for (int u = 0; u < WPT; u++) {
-                const int i = tid * wpt + u;
-                vv[u] = (u < wpt && i < nwords) ? (unsigned)bm[i] : 0u;
-                cnt += __popc(vv[u]);
-            }
-            const int incl = wave_scan_incl(cnt);
-            if (lane == 63) sh_b[w] = incl;
-            __syncthreads();
-            int o = incl - cnt;
+        for (int u = 0; u < WPT; u++) {
+            const int i = tid * wpt + u;
+            vv[u] = (u < wpt && i < nwords) ? (unsigned)bm[i] : 0u;
+            cnt += __popc(vv[u]);
+        }
+        const int incl = wave_scan_incl(cnt);
+        if (lane == 63) sh_b[w] = incl;
+        __syncthreads();
+        int o = incl - cnt - 256 * pt;                       // rank of this thread's first row, relative to the part
 #pragma unroll
-            for (int k = 0; k < 3; k++) o += k < w ? sh_b[k] : 0;
-            ts_l16* qa = (ts_l16*)queue;
+        for (int k = 0; k < 3; k++) o += k < w ? sh_b[k] : 0;
+        ts_l16* qa = (ts_l16*)queue;                         // [4][64]: wave w's queue = ranks [64 w, 64 w + 64)
+        if (o < 256 && o + cnt > 0) {
 #pragma unroll
             for (int u = 0; u < WPT; u++) {
                 unsigned v = vv[u];
                 const int base = 32 * (tid * wpt + u);
                 while (v) {
-                    qa[o++] = (unsigned short)(base + __ffs((int)v) - 1);
+                    if ((unsigned)o < 256u) qa[o] = (unsigned short)(base + __ffs((int)v) - 1);
+                    o++;
                     v &= v - 1u;
                 }
             }
-            __syncthreads();
-            const int q = (((m + 3) >> 2) + 15) & ~15;
-            const int lo = w * q;
-            ts_add_queue(acc, l.src, qa + lo, max(0, min(m, lo + q) - lo), lane);
-        } else {
-            // wave w: words [w qw, (w + 1) qw) of the bitmap, 32 words -- 1024 row numbers, sixteen per lane -- a round; full blocks
-            // of 64 rows are added as they fill, what is left waits at the head of the wave's queue
-            ts_l16* qu = (ts_l16*)queue + w * TS_QCAP;
-            const int qw = (((nwords + 3) >> 2) + 31) & ~31;
-            const int wlo = w * qw, whi = min(nwords, wlo + qw);
-            int pend = 0;                                    // wave-uniform
-            for (int w0 = wlo; w0 < whi; w0 += 32) {
-                const int wi = w0 + (lane >> 1);
-                const unsigned v = wi < whi ? ((unsigned)bm[wi] >> (16 * (lane & 1))) & 0xffffu : 0u;
-                pend += ts_expand_bits(qu, pend, v, 32 * wi + 16 * (lane & 1), lane);
-                __builtin_amdgcn_wave_barrier();
-                const int full = pend & ~63;
-                if (full) {
-                    ts_add_queue(acc, l.src, qu, full, lane);
-                    const int rest = pend - full;
-                    const unsigned short carry = lane < rest ? (unsigned short)qu[full + lane] : (unsigned short)0;
-                    __builtin_amdgcn_wave_barrier();
-                    if (lane < rest) qu[lane] = carry;
-                    __builtin_amdgcn_wave_barrier();
-                    pend = rest;
-                }
-            }
-            if (pend) ts_add_queue(acc, l.src, qu, pend, lane);
         }
-        const float4 part = ts_fold_groups(acc);
-        if (lane < 16) *reinterpret_cast<float4*>(&fold[w][4 * lane]) = part;
         __syncthreads();
-        if (w == 0) l.table[(size_t)dest * PC_L + lane] = (fold[0][lane] + fold[1][lane]) + (fold[2][lane] + fold[3][lane]);
+        const int mine = max(0, min(64, m - 256 * pt - 64 * w));      // rows of this wave
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+        ts_add_queue(acc, l.src, qa + 64 * w, mine, lane);
+        const float4 part = ts_fold_groups(acc);
+        if (!giant) {
+            if (lane < 16) *reinterpret_cast<float4*>(&fold[w][4 * lane]) = part;
+            __syncthreads();
+            if (w == 0) l.table[(size_t)dest * PC_L + lane] = (fold[0][lane] + fold[1][lane]) + (fold[2][lane] + fold[3][lane]);
+            PC_SEG_T1(region, m);
+            __syncthreads();
+            continue;
+        }
+        // giant: the 64-row sums of all the run's parts wait in gprt ([4 x first entry of the run + 64-row block]); the workgroup
+        // that finishes LAST (a device counter per run, zeroed by table_sort_kernel) adds them in ascending order -- the fences
+        // around the counter make the other workgroups' sums visible to it (they come from other XCDs' L2s)
+        const int e0 = hb - pt, nblk = (m + 63) >> 6, nparts = (m + 255) >> 8;
+        if (mine && lane < 16) *reinterpret_cast<float4*>(l.gprt + ((size_t)4 * e0 + 4 * pt + w) * PC_L + 4 * lane) = part;
+        __threadfence();
+        __syncthreads();
+        if (tid == 0) sh_b[4] = atomicAdd(&l.gcnt[e0], 1);
+        __syncthreads();
+        if (sh_b[4] == nparts - 1 && w == 0) {
+            __threadfence();
+            float acc1 = 0.f;
+            for (int k0 = 0; k0 < nblk; k0 += 16) {
+                float v[16];
+#pragma unroll
+                for (int u = 0; u < 16; u++)
+                    v[u] = k0 + u < nblk ? __builtin_nontemporal_load(l.gprt + ((size_t)4 * e0 + k0 + u) * PC_L + lane) : 0.f;
+#pragma unroll
+                for (int u = 0; u < 16; u++) acc1 += v[u];
+            }
+            l.table[(size_t)dest * PC_L + lane] = acc1;
+        }
         PC_SEG_T1(region, m);
         __syncthreads();
-        }
     }
 }
 
@@ -2310,6 +2321,7 @@ struct FusedWs {
     int32_t *tl_c, *tp_c, *tl_q, *tp_q, *n_touch;       // touched rows of the two big tables: ascending lists, row -> list position
     int32_t *srt_c, *srt_q; int4 *seg_c, *seg_q;        // sort path: source rows ordered by destination, the run table (see SortList)
     int2 *med_c, *med_q, *lng_c, *lng_q;                // ... the runs of 5 .. TS_LONG rows and the longer ones
+    int2 *gnt_c, *gnt_q; int32_t *gct_c, *gct_q; float *gpr_c, *gpr_q;      // ... the giant ones' parts, counters and 64-row sums
     bool sorted_path;
     float *tslab_c, *tslab_q;                           // [TG_WGS][TG_CAP][64] each
     float* part_val;
@@ -2348,6 +2360,7 @@ static FusedWs fused_ws_layout(void* base, int B, int T, int K) {
     w.tslab_c = w.tslab_q = nullptr;
     w.srt_c = w.srt_q = nullptr;
     w.med_c = w.med_q = w.lng_c = w.lng_q = nullptr;
+    w.gnt_c = w.gnt_q = nullptr; w.gct_c = w.gct_q = nullptr; w.gpr_c = w.gpr_q = nullptr;
     w.seg_c = w.seg_q = nullptr;
     w.sorted_path = false;
     w.part_val = nullptr;
@@ -2371,6 +2384,9 @@ static FusedWs fused_ws_layout(void* base, int B, int T, int K) {
             w.med_q = (int2*)take((size_t)(B / 5 + 8) * 8);
             w.lng_c = (int2*)take((size_t)(nc / TS_LONG + 1) * 8);
             w.lng_q = (int2*)take((size_t)(B / TS_LONG + 1) * 8);
+            w.gnt_c = (int2*)take((size_t)ts_giant_cap(nc) * 8); w.gnt_q = (int2*)take((size_t)ts_giant_cap(B) * 8);
+            w.gct_c = (int32_t*)take((size_t)ts_giant_cap(nc) * 4); w.gct_q = (int32_t*)take((size_t)ts_giant_cap(B) * 4);
+            w.gpr_c = (float*)take((size_t)ts_giant_cap(nc) * 4 * PC_L * 4); w.gpr_q = (float*)take((size_t)ts_giant_cap(B) * 4 * PC_L * 4);
         }
         w.tslab_c = (float*)take((size_t)TG_WGS * TG_CAP * PC_L * 4);      // (the LDS-table form: PC_OPT_SORTED_TABLE_GRADIENTS, below)
         w.tslab_q = (float*)take((size_t)TG_WGS * TG_CAP * PC_L * 4);
@@ -2572,14 +2588,14 @@ static int fused_step_impl(const pc_joint_tensors* p, const pc_joint_tensors* g,
         // table gradients: source rows sorted by destination, then one wave per destination adds its run in ascending source order
         const int nc = B * (K + 2), cap_c = nc < T ? nc : T, cap_q = B < T ? B : T;
         // (n_touch: [0, 1] touched rows per table, [2 .. 6) run-list counters, [8 .. 8 + 2 TS_NR) runs per range of either list)
-        const SortList sc = {w.ecidx, nc, w.srt_c, w.seg_c, w.med_c, w.lng_c, w.n_touch + 8};
-        const SortList sq = {w.cids + B, B, w.srt_q, w.seg_q, w.med_q, w.lng_q, w.n_touch + 8 + TS_NR};
+        const SortList sc = {w.ecidx, nc, w.srt_c, w.seg_c, w.med_c, w.lng_c, w.gnt_c, w.n_touch + 8, w.gct_c};
+        const SortList sq = {w.cids + B, B, w.srt_q, w.seg_q, w.med_q, w.lng_q, w.gnt_q, w.n_touch + 8 + TS_NR, w.gct_q};
         static const hipError_t sattr = hipFuncSetAttribute(reinterpret_cast<const void*>(&table_sort_kernel),
                                                             hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         (void)sattr;
         PC_LAUNCH(table_sort_kernel, dim3(2 * TS_NR), dim3(1024), table_sort_lds_bytes(nc, T), st, sc, sq, T, w.n_touch);
-        const SegList gc = {g->comp_types, w.ecsrc, w.srt_c, w.seg_c, w.tl_c, w.med_c, w.lng_c, sc.nruns, sc.n};
-        const SegList gq = {g->query_types, w.dt, w.srt_q, w.seg_q, w.tl_q, w.med_q, w.lng_q, sq.nruns, sq.n};
+        const SegList gc = {g->comp_types, w.ecsrc, w.srt_c, w.seg_c, w.tl_c, w.med_c, w.lng_c, sc.nruns, sc.n, w.gnt_c, w.gct_c, w.gpr_c};
+        const SegList gq = {g->query_types, w.dt, w.srt_q, w.seg_q, w.tl_q, w.med_q, w.lng_q, sq.nruns, sq.n, w.gnt_q, w.gct_q, w.gpr_q};
         // grid regions sized for the capacities (the counts live on the device: workgroups past them leave at once): runs of up to
         // four rows sixteen per workgroup, runs of 5 .. TS_LONG rows (at most n / 5 of them) a wave each, longer ones a workgroup each
         SegGrid gr;
@@ -2592,10 +2608,10 @@ static int fused_step_impl(const pc_joint_tensors* p, const pc_joint_tensors* g,
         // to a CU at a time, were half of this kernel)
         auto upto = [](int v, int cap) { return v < cap ? v : cap; };
         gr.spr[0] = upto(((bins < cap_c ? bins : cap_c) + 15) / 16, TS_SPR); gr.spr[1] = upto(((bins < cap_q ? bins : cap_q) + 15) / 16, TS_SPR);
-        const int sizes[6] = {TS_NR * gr.spr[0], upto((nc / 5 + 3) / 4, TS_GMED), upto(nc / TS_LONG + 1, TS_GLONG),
-                              TS_NR * gr.spr[1], upto((B / 5 + 3) / 4, TS_GMED), upto(B / TS_LONG + 1, TS_GLONG)};
-        for (int i = 0; i < 6; i++) { gr.start[i] = at; at += sizes[i]; }
-        gr.start[6] = at;
+        const int sizes[8] = {TS_NR * gr.spr[0], upto((nc / 5 + 3) / 4, TS_GMED), upto(nc / TS_LONG + 1, TS_GLONG), upto(ts_giant_cap(nc), TS_GGIANT),
+                              TS_NR * gr.spr[1], upto((B / 5 + 3) / 4, TS_GMED), upto(B / TS_LONG + 1, TS_GLONG), upto(ts_giant_cap(B), TS_GGIANT)};
+        for (int i = 0; i < 8; i++) { gr.start[i] = at; at += sizes[i]; }
+        gr.start[8] = at;
         PC_LAUNCH(table_segsum_kernel, dim3(at), dim3(256), 0, st, gc, gq, w.n_touch, gr);
         PC_TRY(pc_launch_status());
     } else if (!w.small) {
