@@ -55,10 +55,10 @@ def test_table_gradients_against_the_oracle_and_run_to_run(T, live, dropout, B, 
         assert L.pc_set_option(_lib.PC_OPT_SORTED_TABLE_GRADIENTS, 0) == 0
 
 
-def _check_table_gradients(T, live, dropout, B, K, sorted_path):
+def _check_table_gradients(T, live, dropout, B, K, sorted_path, hb=None):
     model, cfg = _model(T, K, dropout)
     st0 = {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}
-    hb = _batch(B, 2000, live, seed=11)
+    hb = _batch(B, 2000, live, seed=11) if hb is None else hb
     db = {k: v.cuda() for k, v in hb.items()}
     tt = model.type_transition
 
@@ -95,6 +95,32 @@ def _check_table_gradients(T, live, dropout, B, K, sorted_path):
         assert torch.equal(t1, t2)
         for k in g1:
             assert torch.allclose(g1[k], g2[k], rtol=1e-5, atol=1e-7), k
+
+
+def test_runs_of_every_length_class_and_their_boundaries():
+    """The consumer of the sorted table gradients treats a destination's run by its length (joint_fused.hip, table_segsum_kernel:
+    up to 4 rows / up to 64 / up to 256 / longer, in 256-row parts added by the last workgroup to finish): positive, negative and
+    query types drawn so that runs of 1 .. 5, 63 .. 66, 255 .. 258, 511 .. 513 and ~1 100 rows all occur in one step (the selected
+    types add a few rows here and there: the boundaries are hit from both sides over the three lists)."""
+    from p_companion_amd import _lib
+    T, B, K = 34800, 4096, 3
+    sizes = [1, 2, 3, 4, 5, 6, 63, 64, 65, 66, 255, 256, 257, 258, 511, 512, 513]
+    hb = _batch(B, 2000, T, seed=31)
+
+    def staircase(first_type, stride):
+        ids, t = [], first_type
+        for n in sizes:
+            ids += [t] * n
+            t += stride
+        ids += [t] * (B - len(ids))                          # the rest (~1 100 rows) on one more type
+        g = torch.Generator().manual_seed(first_type)
+        return torch.tensor(ids)[torch.randperm(B, generator=g)]
+
+    hb["positive_types"] = staircase(1000, 7).view(B, 1)
+    hb["negative_types"] = staircase(20000, 2175).view(B, 1) % T      # (spread over the sort kernel's ranges of the table)
+    hb["query_types"] = staircase(5, 1)
+    assert _lib.lib().pc_set_option(_lib.PC_OPT_SORTED_TABLE_GRADIENTS, 0) == 0
+    _check_table_gradients(T, T, 0.1, B, K, True, hb=hb)
 
 
 def test_touched_row_lists_are_the_distinct_destinations_at_thousands_of_rows():
