@@ -76,12 +76,12 @@ int pc_abi_version(void);
 /* Process-wide options.  PC_OPT_SIDE_QUEUE: 1 (default) = the unsplit fused Product2Vec step may use its side queue
  * (see "Library-owned device state" above), 0 = every launch stays on the caller's stream.
  * PC_OPT_SORTED_TABLE_GRADIENTS (the fused joint step at num_types > 512; src/models/p_companion.py:36-43): how the gradients of
- * the two [num_types,64] tables are summed.  0 (default) = by configuration: with hidden-layer dropout (every sample selects its
- * own K types: thousands of touched rows) the source rows are sorted by destination and every destination's run is added in
- * ascending source order -- bitwise reproducible at ANY number of touched rows; without dropout the per-workgroup LDS tables of
- * the touched rows, reproducible up to 512 touched rows per table (the case of a batch with few live types; float atomics
- * beyond).  1 = the sorted form always (37 us more per step at num_types = 34800, batch 4096).  Lists that do not fit the sort
- * kernel's LDS (num_types > 65535, more than 24576 source rows) take the other form either way.
+ * the two [num_types,64] tables are summed.  1 (default) = the sorted form: the source rows are sorted by destination and every
+ * destination's run is added in ascending source order -- bitwise reproducible at ANY number of touched rows (with hidden-layer
+ * dropout every sample selects its own K types: thousands).  0 = the sorted form only with hidden-layer dropout; without it the
+ * per-workgroup LDS tables of the touched rows, reproducible up to 512 touched rows per table (float atomics beyond) -- the
+ * default of ABI 7's first builds, 13 us slower per step at num_types = 34800, batch 4096, kept for comparison.  Lists that do
+ * not fit the sort kernel's LDS (num_types > 65535, more than 24576 source rows) take the LDS-table form either way.
  * Unknown option / value: PC_EINVAL.  Thread-safe. */
 enum { PC_OPT_SIDE_QUEUE = 1, PC_OPT_SORTED_TABLE_GRADIENTS = 2 };
 int pc_set_option(int option, int value);

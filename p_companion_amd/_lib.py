@@ -70,7 +70,7 @@ _vp, _i, _sz, _f, _d, _u64, _i64 = (ctypes.c_void_p, ctypes.c_int, ctypes.c_size
 _P = ctypes.POINTER
 
 PC_OPT_SIDE_QUEUE = 1      # pc_set_option: the fused Product2Vec step's side queue (include/pcompanion_hip.h)
-PC_OPT_SORTED_TABLE_GRADIENTS = 2    # ... the [T,64] table gradients of the fused joint step always through the sorted form
+PC_OPT_SORTED_TABLE_GRADIENTS = 2    # ... the [T,64] table gradients of the fused joint step through the sorted form wherever it fits (default 1)
 
 # name -> (restype, argtypes).  Must list every symbol include/pcompanion_hip.h declares
 # (tests/test_abi.py parses the header and checks this table and the .so against it).

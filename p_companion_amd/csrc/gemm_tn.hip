@@ -640,7 +640,7 @@ struct ForkSlot { int dev; hipStream_t main_st; int state; PcFork f; };      // 
 ForkSlot g_fork_slots[32];
 std::mutex g_fork_mu;
 std::atomic<int> g_opt_side_queue{1};
-std::atomic<int> g_opt_sorted_tables{0};
+std::atomic<int> g_opt_sorted_tables{1};
 }
 int pc_opt_sorted_tables() { return g_opt_sorted_tables.load(std::memory_order_relaxed); }
 

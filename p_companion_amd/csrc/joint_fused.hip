@@ -2580,9 +2580,10 @@ static int fused_step_impl(const pc_joint_tensors* p, const pc_joint_tensors* g,
         else PC_LAUNCH((joint_wgrad_kernel<16, 0>), dim3(w.wg_blocks), dim3(512), wl, st, wa);
         PC_TRY(pc_launch_status());
     }
-    // which form sums the table gradients (PC_OPT_SORTED_TABLE_GRADIENTS in the header): with hidden-layer dropout every sample
-    // selects its own K types -- thousands of touched rows, beyond the LDS-table form's 512 -- so the sorted form runs; without
-    // it the LDS-table form (22 us against 33) unless the caller asked for the sorted one
+    // which form sums the table gradients (PC_OPT_SORTED_TABLE_GRADIENTS in the header): the sorted one wherever the lists fit
+    // its sort kernel (24 us at T = 34800, B = 4096 -- the three launches of the LDS-table form take 37, and that form is
+    // reproducible only up to 512 touched rows per table); the option's value 0 keeps the LDS-table form for steps without
+    // hidden-layer dropout
     const bool sorted_tables = !w.small && w.sorted_path && (per_sample || pc_opt_sorted_tables());
     if (sorted_tables) {
         // table gradients: source rows sorted by destination, then one wave per destination adds its run in ascending source order

@@ -13,7 +13,7 @@ src = os.path.join(root, "gpurun_out", tag)
 dst = os.path.join(root, "profiles")
 os.makedirs(dst, exist_ok=True)
 for name in ("bench.json", "bench_under_rocprof.json", "bench_joint_under_rocprof.json", "bench_big.json", "bench_big_under_rocprof.json",
-             "bench_cfg3_under_rocprof.json", "bench_joint34800d_under_rocprof.json"):
+             "bench_cfg3_under_rocprof.json", "bench_joint34800d_under_rocprof.json", "bench_joint34800_under_rocprof.json"):
     if os.path.exists(os.path.join(src, name)):
         shutil.copy(os.path.join(src, name), os.path.join(dst, f"{tag}_{name}"))
 
@@ -60,6 +60,7 @@ kernel_stats("prof_joint", "_joint")
 kernel_stats("prof_big", "_big")
 kernel_stats("prof_cfg3", "_cfg3")
 kernel_stats("prof_joint34800d", "_joint34800d")
+kernel_stats("prof_joint34800", "_joint34800")
 
 # ---- PMC passes
 def pmc(dirname, counter):

@@ -46,13 +46,14 @@ CASES = [(34800, 34800, 0.1, 4096, 3, True),     # thousands of touched rows in 
 def test_table_gradients_against_the_oracle_and_run_to_run(T, live, dropout, B, K, sorted_path):
     from p_companion_amd import _lib
     L = _lib.lib()
-    # (without dropout the step takes the LDS-table form by default -- reproducible up to 512 touched rows per table; the sorted
-    # form is then the caller's choice: pc_set_option(PC_OPT_SORTED_TABLE_GRADIENTS, 1))
-    assert L.pc_set_option(_lib.PC_OPT_SORTED_TABLE_GRADIENTS, 1 if (sorted_path and dropout == 0.0) else 0) == 0
-    try:
-        _check_table_gradients(T, live, dropout, B, K, sorted_path)
-    finally:
-        assert L.pc_set_option(_lib.PC_OPT_SORTED_TABLE_GRADIENTS, 0) == 0
+    # (the sorted form is the default wherever the lists fit its sort kernel; pc_set_option(PC_OPT_SORTED_TABLE_GRADIENTS, 0) keeps
+    # the LDS-table form -- reproducible up to 512 touched rows per table -- for steps without dropout: both are run)
+    for option in ((1, 0) if dropout == 0.0 and sorted_path else (1,)):
+        assert L.pc_set_option(_lib.PC_OPT_SORTED_TABLE_GRADIENTS, option) == 0
+        try:
+            _check_table_gradients(T, live, dropout, B, K, sorted_path and option == 1)
+        finally:
+            assert L.pc_set_option(_lib.PC_OPT_SORTED_TABLE_GRADIENTS, 1) == 0
 
 
 def _check_table_gradients(T, live, dropout, B, K, sorted_path, hb=None):
@@ -102,7 +103,6 @@ def test_runs_of_every_length_class_and_their_boundaries():
     up to 4 rows / up to 64 / up to 256 / longer, in 256-row parts added by the last workgroup to finish): positive, negative and
     query types drawn so that runs of 1 .. 5, 63 .. 66, 255 .. 258, 511 .. 513 and ~1 100 rows all occur in one step (the selected
     types add a few rows here and there: the boundaries are hit from both sides over the three lists)."""
-    from p_companion_amd import _lib
     T, B, K = 34800, 4096, 3
     sizes = [1, 2, 3, 4, 5, 6, 63, 64, 65, 66, 255, 256, 257, 258, 511, 512, 513]
     hb = _batch(B, 2000, T, seed=31)
@@ -119,7 +119,6 @@ def test_runs_of_every_length_class_and_their_boundaries():
     hb["positive_types"] = staircase(1000, 7).view(B, 1)
     hb["negative_types"] = staircase(20000, 2175).view(B, 1) % T      # (spread over the sort kernel's ranges of the table)
     hb["query_types"] = staircase(5, 1)
-    assert _lib.lib().pc_set_option(_lib.PC_OPT_SORTED_TABLE_GRADIENTS, 0) == 0
     _check_table_gradients(T, T, 0.1, B, K, True, hb=hb)
 
 
