@@ -353,10 +353,10 @@ def run_joint(args, rank, world, dev, types, steps, warmup, want_cpu, dropout=0.
                                              "clear riding, exact top-K over each row's K best sub-chunks, tile kernel incl. batch construction and the "
                                              "weight-gradient slabs, counting sort of the table gradients' source rows by destination, per-destination sums "
                                              "in ascending source order, finish + Adam)" if dropout > 0 else
-                                             "9 (distinct query types, their hidden rows + G = E_c dec_w, sub-chunk maxima of the similarity rows with the "
+                                             "8 (distinct query types, their hidden rows + G = E_c dec_w, sub-chunk maxima of the similarity rows with the "
                                              "table-gradient clear riding, exact top-K over each row's K best sub-chunks, tile kernel incl. batch construction "
-                                             "and the weight-gradient slabs, touched-row lists, per-workgroup partial tables, fixed-order table sums, "
-                                             "finish + Adam)"))},
+                                             "and the weight-gradient slabs, counting sort of the table gradients' source rows by destination, per-destination "
+                                             "sums in ascending source order, finish + Adam)"))},
            "roofline": {"bound": "hbm", "kernel": "the whole step (batch builder + the fused step's kernels: a dependent chain)",
                         "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                         "frac": round(achieved / HBM_PEAK_GBS, 5),
