@@ -879,15 +879,11 @@ static size_t tile_lds_bytes(int T, bool sims_local, bool tables) {
 // (sample_hidden_kernel without a mask, sample_sims_max_kernel, sample_topk_refine_kernel -> topk_by_type[type][K]); U lives on
 // the device, so the grids are sized for min(B, T) rows and the workgroups past U leave at once.
 #define UT 64
-// inclusive prefix sum over the 1024 threads of a workgroup: shuffles inside each wave, the 16 wave totals through LDS -- two
+// inclusive prefix sum over the 1024 threads of a workgroup: the DPP scan inside each wave, the 16 wave totals through LDS -- two
 // barriers (the Hillis-Steele form over LDS this replaces took twenty: 3 us of a 10 us single-workgroup kernel)
 __device__ __forceinline__ int block_scan_1024(int v, unsigned* wsum /* [16] LDS */) {
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-        const int u = __shfl_up(v, o, 64);
-        if (lane >= o) v += u;
-    }
+    v = wave_scan_incl(v);
     __syncthreads();                                    // (wsum may still be read from a previous call)
     if (lane == 63) wsum[w] = (unsigned)v;
     __syncthreads();
