@@ -1272,9 +1272,9 @@ __global__ __launch_bounds__(256) void sample_topk_refine_kernel(const float* cm
 #pragma unroll
             for (int j = 0; j < 8; j++) {
                 float part = fmaf(gv[j].w, h4.w, fmaf(gv[j].z, h4.z, fmaf(gv[j].y, h4.y, gv[j].x * h4.x)));
-                part += __shfl_xor(part, 1, 64);
-                part += __shfl_xor(part, 2, 64);
-                part += __shfl_xor(part, 4, 64);
+                part = dpp_row_add<0xB1>(part);              // + the quad neighbour (lane ^ 1), on the DPP network
+                part = dpp_row_add<0x4E>(part);              // + the other pair of the quad (lane ^ 2)
+                part = dpp_row_add<0x141>(part);             // + the other quad of the eight (row_half_mirror)
                 mine = kq == j ? part : mine;
             }
             if (tmine < T) {
