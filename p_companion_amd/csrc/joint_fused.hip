@@ -1518,6 +1518,7 @@ struct FinishArgs {
     FinishJob job[FIN_JOBS]; int block0[FIN_JOBS + 1], njobs;
     const float *part_type, *part_item; int B, K; float alpha; float* losses;
     const int64_t* step_count; double lr, beta1, beta2, eps; int adam;
+    int sl16;                                             // 16 slab lanes per output float4 (else 8): see joint_finish_kernel
 };
 
 __global__ __launch_bounds__(256) void joint_finish_kernel(FinishArgs a) {
@@ -1553,16 +1554,25 @@ __global__ __launch_bounds__(256) void joint_finish_kernel(FinishArgs a) {
 #pragma unroll
     for (int i = 1; i < FIN_JOBS; i++) j += (i < a.njobs && b >= a.block0[i]) ? 1 : 0;
     const FinishJob& jb = a.job[j];
-    // eight lanes share one float4 of outputs: lane g sums slabs g, g + 8, ...; the partial sums fold in a fixed xor order
+    // 8 or 16 slab lanes share one float4 of outputs: lane g sums slabs g, g + 8 (16), ...; a wave is 8 consecutive float4s (one
+    // 128-byte line of every slab it reads) x 8 slab lanes; with 16 the other 8 slab lanes are the next wave; the partial sums fold
+    // in a fixed order (xor over the wave's slab lanes, then the wave pair through LDS).  Sixteen where the slab jobs are the whole
+    // kernel (T <= 512): the walk is bound by the cache lines a CU keeps in flight, so the kernel lasts as long as the CU with the
+    // most workgroups -- 330 workgroups of eight slab lanes put two on 74 of the 256 CUs and one on the rest (0.0459 -> 0.0445 ms at
+    // T = 100; beside the big tables' streaming jobs twice the workgroups cost 1.8 us instead).
     // (a job whose gradient is complete already -- nsplit == 0 -- gives every lane its own float4: pure streaming)
-    const int t = (b - a.block0[j]) * 256 + threadIdx.x;
+    __shared__ float4 xw[2][8];
     const bool direct = jb.nsplit == 0;
-    const int j4 = direct ? t : t >> 3, g = direct ? 0 : t & 7;
-    if (j4 * 4 >= jb.n) return;
+    const int tt = threadIdx.x, jl = tt & 7, gl = (tt >> 3) & 7, pair = tt >> 7, gh = a.sl16 ? (tt >> 6) & 1 : 0, sl = a.sl16 ? 16 : 8;
+    const int j4 = direct ? (b - a.block0[j]) * 256 + tt
+                          : a.sl16 ? (b - a.block0[j]) * 16 + pair * 8 + jl : (b - a.block0[j]) * 32 + (tt >> 6) * 8 + jl;
+    const int g = direct ? 0 : gl + 8 * gh;
+    const bool live = j4 * 4 < jb.n;
+    if (direct && !live) return;
     float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
     // Adam's operands are requested before the slab walk (they do not depend on it)
     float4 pv = make_float4(0.f, 0.f, 0.f, 0.f), mv = pv, vv = pv;
-    if (a.adam && g == 0) {
+    if (a.adam && g == 0 && live) {
         if (!direct) pv = *reinterpret_cast<const float4*>(jb.param + (size_t)j4 * 4);
         mv = *reinterpret_cast<const float4*>(jb.m + (size_t)j4 * 4);
         vv = *reinterpret_cast<const float4*>(jb.v + (size_t)j4 * 4);
@@ -1571,27 +1581,32 @@ __global__ __launch_bounds__(256) void joint_finish_kernel(FinishArgs a) {
         // 16 slab reads in flight per lane: the walk is a chain of memory latencies (32 dependent-free loads per lane at 256
         // slabs; four at a time took 16 us for 43 MB that sit in the last-level cache), the order of the additions is fixed
         const float* src = jb.slabs + (size_t)j4 * 4;
-        int k = g;
-        for (; k + 8 * 15 < jb.nsplit; k += 8 * 16) {
+        int k = live ? g : jb.nsplit;
+        for (; k + sl * 15 < jb.nsplit; k += sl * 16) {
             float4 v[16];
 #pragma unroll
-            for (int u = 0; u < 16; u++) v[u] = *reinterpret_cast<const float4*>(src + (size_t)(k + 8 * u) * jb.stride);
+            for (int u = 0; u < 16; u++) v[u] = *reinterpret_cast<const float4*>(src + (size_t)(k + sl * u) * jb.stride);
 #pragma unroll
             for (int u = 0; u < 16; u++) { s.x += v[u].x; s.y += v[u].y; s.z += v[u].z; s.w += v[u].w; }
         }
-        for (; k < jb.nsplit; k += 8) {
+        for (; k < jb.nsplit; k += sl) {
             const float4 v = *reinterpret_cast<const float4*>(src + (size_t)k * jb.stride);
             s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
         }
 #pragma unroll
-        for (int o = 1; o < 8; o <<= 1) {
+        for (int o = 8; o < 64; o <<= 1) {
             s.x += __shfl_xor(s.x, o, 64); s.y += __shfl_xor(s.y, o, 64);
             s.z += __shfl_xor(s.z, o, 64); s.w += __shfl_xor(s.w, o, 64);
+        }
+        if (a.sl16) {                                    // (uniform over the launch)
+            if (gh == 1 && gl == 0) xw[pair][jl] = s;
+            __syncthreads();
+            if (gh == 0 && gl == 0) { const float4 o4 = xw[pair][jl]; s.x += o4.x; s.y += o4.y; s.z += o4.z; s.w += o4.w; }
         }
     } else if (g == 0) {
         s = *reinterpret_cast<const float4*>(jb.grad + (size_t)j4 * 4);
     }
-    if (g != 0) return;
+    if (g != 0 || !live) return;
     if (jb.nsplit > 0) *reinterpret_cast<float4*>(jb.grad + (size_t)j4 * 4) = s;
     if (a.adam && direct) {
         // A big table's elements that no batch has ever touched have g = m = v = 0, and torch.optim.Adam's update leaves such an
@@ -2021,7 +2036,7 @@ static bool table_sort_fits(int n, int T) { return T <= 65535 && n <= TS_MAXN &&
 // are two LDS reads; handing the numbers round by lane shuffles, sixteen dependent LDS operations per block, cost more than the
 // rows' own round trip), lane j of a group floats [4 j, 4 j + 4) of the row: sixteen 16-byte loads -- 64 rows -- in flight per
 // lane.  The order is a function of the positions alone: every group ascending, the groups folded (g0 + g1) + (g2 + g3) by
-// ts_fold_groups.  ts_add128: two such blocks, all 32 loads in flight before the first add.
+// ts_fold_groups; ts_add_queue keeps two such blocks -- 32 loads -- in flight before the first add.
 __device__ __forceinline__ void ts_load64(float4 (&v)[16], const float* src, const ts_l16* q, int mm, int lane) {
     const int g = lane >> 4, j = lane & 15;
     typedef unsigned ts_u4 __attribute__((ext_vector_type(4)));
@@ -2630,12 +2645,13 @@ static int fused_step_impl(const pc_joint_tensors* p, const pc_joint_tensors* g,
 
     // ---- finish: slab sums -> .grad, the losses, Adam
     FinishArgs fin = {};
+    fin.sl16 = w.small ? 1 : 0;
     int blocks = 0, nj = 0;
     auto add = [&](const float* slabs, size_t stride, int nsplit, int n, float* grad, float* param, float* m, float* v) {
         FinishJob& j = fin.job[nj];
         j.slabs = slabs; j.stride = stride; j.nsplit = nsplit; j.n = n; j.grad = grad; j.param = param; j.m = m; j.v = v;
         fin.block0[nj++] = blocks;
-        blocks += nsplit > 0 ? (n / 4 * 8 + 255) / 256 : (n / 4 + 255) / 256;
+        blocks += nsplit > 0 ? (fin.sl16 ? (n / 4 + 15) / 16 : (n / 4 + 31) / 32) : (n / 4 + 255) / 256;
     };
     {
         const int Tt = wa.T;
