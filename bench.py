@@ -330,6 +330,8 @@ def run_joint(args, rank, world, dev, types, steps, warmup, want_cpu, dropout=0.
     out = {"metric": "triplets/sec (P-Companion joint step: fwd + type/item hinge + bwd + Adam)", "value": round(value, 1),
            "unit": "triplets/s", "steps": steps, "ms_per_step": round(1e3 * el / steps, 4),
            "host_enqueue_ms_per_step": round(host_ms, 4),
+           # (the wall clock of a 45 ms region is at the mercy of one host hiccup; the HIP events around the same steps are not)
+           "wall_over_device": round(1e3 * el / steps / dev_ms, 3) if dev_ms > 0 else None,
            "config": {"workload": f"P-Companion joint step, {jproducts} products, NUM_TYPES={types}, dim=128, "
                                   f"batch={args.batch}/GPU, K=3 (loader batch construction included)",
                       "global_batch": world * args.batch, "parallelism": f"dp{world}", "final_loss": round(float(losses[0]), 5),
