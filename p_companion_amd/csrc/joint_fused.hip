@@ -2298,22 +2298,27 @@ __global__ __launch_bounds__(256) void table_segsum_kernel(SegList l0, SegList l
             continue;
         }
         // giant: the 64-row sums of all the run's parts wait in gprt ([4 x first entry of the run + 64-row block]); the workgroup
-        // that finishes LAST (a device counter per run, zeroed by table_sort_kernel) adds them in ascending order -- the fences
-        // around the counter make the other workgroups' sums visible to it (they come from other XCDs' L2s)
+        // that finishes LAST (a device counter per run, zeroed by table_sort_kernel) adds them in ascending order.  The hand-off
+        // across XCDs (private L2s): every storing wave drains its stores, one lane releases at agent scope (writes the XCD's dirty
+        // lines back) and waits for that before it takes its ticket; the last arriver acquires at agent scope (drops stale lines)
+        // and reads with plain vector loads
         const int e0 = hb - pt, nblk = (m + 63) >> 6, nparts = (m + 255) >> 8;
         if (mine && lane < 16) *reinterpret_cast<float4*>(l.gprt + ((size_t)4 * e0 + 4 * pt + w) * PC_L + 4 * lane) = part;
-        __threadfence();
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
-        if (tid == 0) sh_b[4] = atomicAdd(&l.gcnt[e0], 1);
+        if (tid == 0) {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // (the fence's own wait is not to be relied on)
+            sh_b[4] = __hip_atomic_fetch_add(&l.gcnt[e0], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
         __syncthreads();
         if (sh_b[4] == nparts - 1 && w == 0) {
-            __threadfence();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
             float acc1 = 0.f;
             for (int k0 = 0; k0 < nblk; k0 += 16) {
                 float v[16];
 #pragma unroll
-                for (int u = 0; u < 16; u++)
-                    v[u] = k0 + u < nblk ? __builtin_nontemporal_load(l.gprt + ((size_t)4 * e0 + k0 + u) * PC_L + lane) : 0.f;
+                for (int u = 0; u < 16; u++) v[u] = k0 + u < nblk ? l.gprt[((size_t)4 * e0 + k0 + u) * PC_L + lane] : 0.f;
 #pragma unroll
                 for (int u = 0; u < 16; u++) acc1 += v[u];
             }

@@ -147,3 +147,31 @@ def test_touched_row_lists_are_the_distinct_destinations_at_thousands_of_rows():
         has = torch.nonzero(g.abs().amax(1) > 0).reshape(-1)
         assert bool(torch.isin(has, dest.to(has.device)).all())        # (a listed row may hold a zero gradient: an inactive hinge)
     assert n_c > 512 and n_q > 512
+
+
+def test_giant_runs_hand_their_sums_over_reliably():
+    """A destination most of the batch points at is summed by several workgroups (256 rows each) on different XCDs; the last one to
+    finish adds their 64-row sums, handed over through memory behind an agent-scope release / acquire (joint_fused.hip,
+    table_segsum_kernel).  A stale read there would show as a run-to-run difference: thirty steps on the same batch -- four hot types
+    with ~2 000 rows each and eight with ~500, the rest spread -- all bit for bit the first one."""
+    T, B, K = 34800, 4096, 3
+    model, cfg = _model(T, K, 0.1)
+    hb = _batch(B, 2000, T, seed=41)
+    g = torch.Generator().manual_seed(7)
+    hot = torch.randint(0, 4, (B,), generator=g) * 8000 + 17
+    warm = torch.randint(0, 8, (B,), generator=g) * 4000 + 333
+    hb["positive_types"] = hot.view(B, 1)
+    hb["negative_types"] = torch.where(torch.rand(B, generator=g) < 0.5, hot, warm).view(B, 1)
+    hb["query_types"] = warm
+    db = {k: v.cuda() for k, v in hb.items()}
+    tt = model.type_transition
+    first = None
+    for i in range(30):
+        tt._dropout_step = 0
+        model.train_step(db)
+        cur = {k: p.grad.detach().clone() for k, p in model.named_parameters() if p.requires_grad}
+        if first is None:
+            first = cur
+        else:
+            for k in first:
+                assert torch.equal(first[k], cur[k]), (i, k)
