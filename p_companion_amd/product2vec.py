@@ -532,12 +532,14 @@ class Product2Vec(nn.Module, _FlatParamsMixin):
         """Train Product2Vec model and generate embeddings for all products
         (product2vec.py:113-170).  Index batches take the fused HIP step; dense reference
         batches take the autograd path.  The loss stays on the device; it is read back once
-        per epoch for the log line (the reference syncs every step, :162)."""
+        per epoch for the log line (the reference syncs every step, :162).  With self.record_step_losses = True (or
+        config.RECORD_STEP_LOSSES) the per-step losses (what the reference's progress bar averages, :161-163) are kept in self.step_losses [steps]."""
         device = self.config.DEVICE
         logger = logging.getLogger(__name__)
         self.to(device)
         bpg = train_loader.dataset.bpg
         table = None
+        history = [] if (getattr(self, "record_step_losses", False) or getattr(self.config, "RECORD_STEP_LOSSES", False)) else None
         for epoch in range(num_epochs):
             self.train()
             total = None
@@ -558,8 +560,12 @@ class Product2Vec(nn.Module, _FlatParamsMixin):
                     loss = loss.detach().reshape(1)
                 total = loss.clone() if total is None else total + loss
                 num_batches += 1
+                if history is not None:
+                    history.append(loss.detach().reshape(1).clone())
             if num_batches:
                 logger.info(f"Epoch {epoch + 1}/{num_epochs}, Loss: {float(total) / num_batches:.4f}")
+        if history is not None:
+            self.step_losses = torch.cat(history).cpu() if history else torch.zeros(0)
         self.eval()
         return self.generate_all_embeddings(bpg)
 

@@ -62,7 +62,9 @@ def _check_ranges(config, loader, model):
 def train(config, train_loader, val_loader, pretrained_embeddings, fused=True):
     """Train P-Companion model (train.py:16-72): loop, per-epoch Metrics.evaluate_model, best
     hit@10 checkpoint.  fused=True runs the loop body as pc_joint_train_step + one Adam launch;
-    fused=False runs model(batch) / compute_loss / backward / torch Adam like the reference."""
+    fused=False runs model(batch) / compute_loss / backward / torch Adam like the reference.
+    Returns the model (the reference returns None); model.step_losses [steps] holds every step's total loss (what the
+    reference's progress bar averages, :50-51) and model.epoch_metrics the metrics dict of every epoch (:54)."""
     logger = logging.getLogger(__name__)
     model = PCompanion(config, pretrained_embeddings).to(config.DEVICE)
     optimizer = FusedAdam(model, lr=config.LEARNING_RATE) if fused else \
@@ -70,6 +72,7 @@ def train(config, train_loader, val_loader, pretrained_embeddings, fused=True):
     for ld in (train_loader, val_loader):
         _check_ranges(config, ld, model)
     best_hit10 = 0.0
+    history, epoch_metrics = [], []
     # the index loader of this package on the GPU: train.py:36-57's loop over an epoch runs as ONE foreign call
     # (GraphedJointStep.run_epoch -> pc_joint_train_epoch; same steps, same values as the loop below)
     epoch_runner = None
@@ -88,6 +91,7 @@ def train(config, train_loader, val_loader, pretrained_embeddings, fused=True):
         if epoch_runner is not None:
             per_step = epoch_runner.run_epoch(train_loader)
             total, nb = per_step[:, 0].sum().reshape(1), int(per_step.shape[0])
+            history.append(per_step[:, 0].detach().clone())
         for batch in (train_loader if epoch_runner is None else ()):
             batch = {k: v.to(config.DEVICE) if isinstance(v, torch.Tensor) else v for k, v in batch.items()}
             if fused:
@@ -101,11 +105,13 @@ def train(config, train_loader, val_loader, pretrained_embeddings, fused=True):
                 loss = loss.detach().reshape(1)
                 optimizer.step()
             total = loss.clone() if total is None else total + loss
+            history.append(loss.detach().clone())
             nb += 1
         if nb:
             logger.info(f"Epoch {epoch + 1}/{config.NUM_EPOCHS}, Loss: {float(total) / nb:.4f}")
         model.raise_index_errors()                   # ids outside the tables seen by the device this epoch -> IndexError
         metrics = Metrics.evaluate_model(model, val_loader, config.DEVICE)
+        epoch_metrics.append(dict(metrics))
         for name, value in metrics.items():
             logger.info(f"{name}: {value:.4f}")
         if metrics["hit@10"] > best_hit10:
@@ -119,6 +125,8 @@ def train(config, train_loader, val_loader, pretrained_embeddings, fused=True):
     if epoch_runner is not None:                     # the caller's loader leaves as it came (its batches no longer alias the step's buffers)
         train_loader.out, train_loader._prepared = loader_out
         train_loader._static_batch = None
+    model.step_losses = torch.cat([h.reshape(-1) for h in history]).cpu() if history else torch.zeros(0)
+    model.epoch_metrics = epoch_metrics
     return model
 
 

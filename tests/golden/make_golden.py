@@ -22,6 +22,18 @@ Vectors:
   g9_complementary.npz   ComplementaryDataset: pair order after random.shuffle + the 80/10/10 split for
                       train / val / test, and the integer fields / item rules of the first 256 samples of each
 
+  g6_joint_t1000.npz  the same joint step at NUM_TYPES = 1000, B = 256 (the first reference-made
+                      vector through the T > 512 kernels)
+  g10_p2v_epochs.npz  the reference's OWN Product2Vec.train_model (product2vec.py:113-170) run for two epochs over
+                      DataLoader(SimilarityDataset, 256, shuffle=False, collate_fn) on the g2 graph: per-step losses,
+                      the negatives it drew, the final state_dict (BatchNorm buffers included) and the embedding dict
+                      generate_all_embeddings returns for all 1 000 products
+  g11_joint_epochs.npz   the reference's OWN train.train (train.py:16-72) run for two epochs on the g2 graph with g10's
+                      embeddings as the pretrained table: pair order / split of both datasets, the order the shuffling
+                      DataLoader visited the samples in, the randn_like filler rows it drew (input data), per-step
+                      losses, the five metrics of Metrics.evaluate_model after each epoch (three val batches, ragged
+                      last), the final parameters and Adam moments, and what best_model.pth held
+
     PYTHONHASHSEED=0 python tests/golden/make_golden.py g9      # only the named vectors
 """
 import os
@@ -347,6 +359,191 @@ def g6(T, B, seed):
     save(f"g6_joint_t{T}.npz", **init, **tb, **cap)
 
 
+# --------------------------------------------------------------------------- G10 / G11
+class _RecordingBar:
+    """Stands where tqdm stands in the reference's loops (product2vec.py:125, train.py:34): hands the loader's batches on
+    unchanged and keeps the running means the loop reports through set_postfix; the per-step losses are recovered from
+    them in float64 (n * mean_n - (n - 1) * mean_{n-1}: the loop's own total_loss)."""
+    means = None
+
+    def __init__(self, it, desc=None, **kw):
+        self.it = it
+
+    def __enter__(self):
+        self.n = 0
+        return self
+
+    def __exit__(self, *a):
+        return False
+
+    def __iter__(self):
+        return iter(self.it)
+
+    def set_postfix(self, d):
+        self.n += 1
+        type(self).means.append((self.n, float(d["loss"])))
+
+
+def _losses_from_means(means):
+    out, prev = [], 0.0
+    for n, m in means:
+        if n == 1:
+            prev = 0.0
+        out.append(n * m - prev)
+        prev = n * m
+    return np.array(out, np.float64)
+
+
+def g10(bpg, ints, seed=1000, epochs=2):
+    import logging
+    import src.models.product2vec as ref_p2v
+    from torch.utils.data import DataLoader
+    from src.data.data_loader import SimilarityDataset, collate_fn
+    logging.disable(logging.CRITICAL)
+    cfg = stub_config()
+    ds = SimilarityDataset(bpg, cfg)
+    drawn = []
+
+    def recording_collate(samples):
+        drawn.append(np.array([[pid2int(p) for p in s["negative_ids"]] for s in samples], np.int32))
+        return collate_fn(samples)
+
+    loader = DataLoader(ds, batch_size=cfg.BATCH_SIZE, shuffle=False, num_workers=0, collate_fn=recording_collate)
+    torch.manual_seed(seed)
+    model = ref_p2v.Product2Vec(cfg)
+    init = sd_to_np(model.state_dict(), "init.")
+    opt = torch.optim.Adam(model.parameters(), lr=cfg.LEARNING_RATE)
+    random.seed(seed)                                   # the negatives' stream (data_loader.py:33)
+    class Bar(_RecordingBar):
+        means = []
+    keep, ref_p2v.tqdm = ref_p2v.tqdm, Bar
+    try:
+        emb = model.train_model(loader, opt, num_epochs=epochs)          # <- the reference's own function
+    finally:
+        ref_p2v.tqdm = keep
+    losses = _losses_from_means(Bar.means)
+    E = torch.stack([emb[f"P{i:06d}"] for i in range(len(emb))]).numpy()
+    assert list(emb.keys()) == [f"P{i:06d}" for i in range(len(emb))]
+    print("g10: %d steps, losses %.4f .. %.4f, degree-0 products %d" % (
+        len(losses), losses[0], losses[-1], int((np.diff(ints["cv_rowptr"]) == 0).sum())))
+    save("g10_p2v_epochs.npz", **init, **sd_to_np(model.state_dict(), "final."), seed=np.array(seed, np.int64),
+         epochs=np.array(epochs, np.int64), batch_size=np.array(cfg.BATCH_SIZE, np.int64), losses=losses,
+         negative_idx=np.concatenate(drawn), embeddings=E)
+    return emb
+
+
+def g11(bpg, ints, pretrained, seed=1100, epochs=2, T=100):
+    """train.py imports src/utils/visualization.py at module level, which imports seaborn (absent here).  train.train
+    never touches either; an EMPTY module object named seaborn lets `import train` through."""
+    import logging
+    from torch.utils.data import DataLoader, Dataset
+    sys.modules.setdefault("seaborn", types.ModuleType("seaborn"))
+    import train as ref_train
+    from src.data.data_loader import ComplementaryDataset, collate_fn
+    from src.utils.metrics import Metrics
+    logging.disable(logging.CRITICAL)
+    cfg = stub_config(NUM_TYPES=T, NUM_EPOCHS=epochs)
+    os.makedirs(cfg.MODEL_DIR, exist_ok=True)
+    best_path = os.path.join(cfg.MODEL_DIR, "best_model.pth")
+    if os.path.exists(best_path):
+        os.remove(best_path)
+    feats = torch.from_numpy(ints["features"])
+    random.seed(seed)
+    torch.manual_seed(seed)
+    train_ds = ComplementaryDataset(bpg, cfg, mode="train")          # back to back from one stream, as train.py:111-112
+    val_ds = ComplementaryDataset(bpg, cfg, mode="val")
+
+    class Visits(Dataset):
+        def __init__(self, inner):
+            self.inner, self.order = inner, []
+
+        def __len__(self):
+            return len(self.inner)
+
+        def __getitem__(self, i):
+            self.order.append(int(i))
+            return self.inner[i]
+
+    fill = {"train": [], "val": []}
+
+    def recording(which):
+        def collate(samples):
+            out = collate_fn(samples)
+            lab = out["label"]
+            f = torch.where((lab == 1).unsqueeze(1), out["negative_items"], out["positive_items"])
+            fill[which].append(f.numpy().copy())
+            return out
+        return collate
+
+    tr_vis, va_vis = Visits(train_ds), Visits(val_ds)
+    train_loader = DataLoader(tr_vis, batch_size=cfg.BATCH_SIZE, shuffle=True, num_workers=0,
+                              collate_fn=recording("train"))
+    val_loader = DataLoader(va_vis, batch_size=cfg.BATCH_SIZE, shuffle=False, num_workers=0,
+                            collate_fn=recording("val"))
+
+    made = {}
+
+    class Bar(_RecordingBar):
+        means = []
+
+    def make_model(config, emb):
+        made["model"] = ref_train.PCompanion_(config, emb)
+        made["init"] = sd_to_np(made["model"].state_dict(), "init.")
+        return made["model"]
+
+    def make_adam(params, lr):
+        made["opt"] = ref_train.Adam_(params, lr=lr)
+        return made["opt"]
+
+    class RecMetrics:
+        per_epoch = []
+
+        @staticmethod
+        def evaluate_model(model, loader, device):
+            m = Metrics.evaluate_model(model, loader, device)
+            RecMetrics.per_epoch.append(dict(m))
+            return m
+
+    ref_train.PCompanion_, ref_train.Adam_ = ref_train.PCompanion, ref_train.Adam
+    keep = (ref_train.tqdm, ref_train.PCompanion, ref_train.Adam, ref_train.Metrics)
+    ref_train.tqdm, ref_train.PCompanion, ref_train.Adam, ref_train.Metrics = Bar, make_model, make_adam, RecMetrics
+    torch.manual_seed(seed + 1)                       # model init, then the loader's shuffles and the randn_like fillers
+    try:
+        ref_train.train(cfg, train_loader, val_loader, pretrained)      # <- the reference's own function
+    finally:
+        ref_train.tqdm, ref_train.PCompanion, ref_train.Adam, ref_train.Metrics = keep
+    model, opt = made["model"], made["opt"]
+    losses = _losses_from_means(Bar.means)
+    n_tr, n_va = len(train_ds), len(val_ds)
+    assert len(tr_vis.order) == epochs * n_tr and len(va_vis.order) == epochs * n_va
+    names = sorted(RecMetrics.per_epoch[0])
+    out = {k: v for k, v in made["init"].items() if k != "init.product_embeddings.weight"}
+    out.update(sd_to_np({k: v for k, v in model.state_dict().items() if k != "product_embeddings.weight"}, "final."))
+    for p in opt.param_groups[0]["params"]:
+        st = opt.state[p]
+        if "exp_avg" in st:
+            name = [n for n, q in model.named_parameters() if q is p][0]
+            out["final.exp_avg." + name] = st["exp_avg"].numpy().copy()
+            out["final.exp_avg_sq." + name] = st["exp_avg_sq"].numpy().copy()
+            out["final.step." + name] = np.array(float(st["step"]))
+    best = torch.load(best_path, weights_only=False)
+    out.update(sd_to_np({k: v for k, v in best["model_state_dict"].items() if k != "product_embeddings.weight"}, "best."))
+    pairs = lambda ds: np.array([[pid2int(q), pid2int(t), lab] for q, t, lab in ds.pairs], np.int32)
+    print("g11: %d steps, losses %.4f .. %.4f; metrics %s; best epoch %d" % (
+        len(losses), losses[0], losses[-1], RecMetrics.per_epoch, best["epoch"]))
+    save("g11_joint_epochs.npz", **out, seed=np.array(seed, np.int64), epochs=np.array(epochs, np.int64),
+         num_types=np.array(T, np.int64), batch_size=np.array(cfg.BATCH_SIZE, np.int64),
+         train_pairs=pairs(train_ds), val_pairs=pairs(val_ds),
+         train_order=np.array(tr_vis.order, np.int32).reshape(epochs, n_tr),
+         val_order=np.array(va_vis.order, np.int32).reshape(epochs, n_va),
+         train_filler=np.concatenate(fill["train"]).reshape(epochs, n_tr, -1),
+         val_filler=np.concatenate(fill["val"]).reshape(epochs, n_va, -1),
+         losses=losses, metric_names=np.array(names),
+         metric_values=np.array([[m[k] for k in names] for m in RecMetrics.per_epoch], np.float64),
+         best_epoch=np.array(best["epoch"], np.int64),
+         best_metric_values=np.array([best["metrics"][k] for k in names], np.float64))
+
+
 # --------------------------------------------------------------------------- G7
 def g7():
     from src.data.data_loader import collate_fn
@@ -446,10 +643,16 @@ if __name__ == "__main__":
     if want("g6"):
         g6(100, 64, 600)
         g6(300, 64, 700)
+    if want("g6") or "g6_t1000" in only:
+        g6(1000, 256, 800)
     if want("g7"):
         g7()
     if want("g8"):
         g8()
     if want("g9"):
         g9(bpg, ints)
+    if want("g10") or want("g11"):
+        emb = g10(bpg, ints)
+    if want("g11"):
+        g11(bpg, ints, emb)
     print("done")

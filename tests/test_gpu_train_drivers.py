@@ -55,15 +55,26 @@ def test_hit_rank_and_cosine_vs_torch():
 
 def test_pipeline_end_to_end(golden, tmp_path):
     """train.py:main() on the reference's own 1k-product graph: both phases, checkpoints in the
-    reference's dict layouts, loss decreasing."""
+    reference's dict layouts, the loss falling over the epochs of both phases, metrics in range, the checkpoint the
+    best epoch's.  (Values against the reference's own run of the same loops: tests/test_gpu_epoch_goldens.py -- there the
+    negatives / shuffles are the reference's; here they are the throughput samplers' own.)"""
     from p_companion_amd import train as drv
     from p_companion_amd.data import (ComplementaryIndexDataset, ComplementaryIndexLoader, IntBPG,
                                       SimilarityIndexLoader)
     bpg = IntBPG.from_arrays(golden("g2_bpg1000.npz"))
     c = cfg(tmp_path, NUM_TYPES=bpg.n_types, PRODUCT2VEC_EPOCHS=3)
     torch.manual_seed(0)
+    c.RECORD_STEP_LOSSES = True
     emb = drv.pretrain_product2vec(c, bpg)
     assert len(emb) == 1000
+    p2v = drv.pretrain_product2vec.last_model
+    per_epoch = p2v.step_losses.view(3, -1).mean(1)               # 12 steps per epoch (2949 pairs, B = 256)
+    assert p2v.step_losses.numel() == 36 and torch.isfinite(p2v.step_losses).all()
+    assert per_epoch[2] < per_epoch[1] < per_epoch[0] and 0.3 < float(per_epoch[2]) < float(per_epoch[0]) < 1.2
+    # (the reference's own two epochs on this graph go 0.99 -> 0.55, tests/golden/g10_p2v_epochs.npz)
+    assert int(p2v.state_dict()["ffn.1.num_batches_tracked"]) == 4 * 36
+    E = torch.stack([emb[f"P{i:06d}"] for i in range(1000)])
+    assert torch.isfinite(E).all() and float(E.std()) > 1e-3
     ck = torch.load(os.path.join(c.MODEL_DIR, "product2vec.pth"), weights_only=True)
     assert set(ck) == {"model_state_dict", "embeddings", "type_to_idx"}                # pretrain_product2vec.py:44-49
     assert "ffn.1.running_var" in ck["model_state_dict"] and ck["embeddings"]["P000999"].shape == (128,)
@@ -79,6 +90,19 @@ def test_pipeline_end_to_end(golden, tmp_path):
     best = torch.load(os.path.join(c.MODEL_DIR, "best_model.pth"), weights_only=True)
     assert set(best) == {"epoch", "model_state_dict", "optimizer_state_dict", "metrics"}      # train.py:63-70
     assert set(best["metrics"]) == {"hit@1", "hit@3", "hit@10", "type_diversity", "mean_relevance"}
+    n_steps = 2 * len(tr)
+    assert model.step_losses.numel() == n_steps and torch.isfinite(model.step_losses).all()
+    first, second = model.step_losses[:len(tr)].mean(), model.step_losses[len(tr):].mean()
+    assert second < first and 0.5 < float(second) < float(first) < 2.0           # (the reference's run: 1.35 -> 0.85, g11)
+    assert len(model.epoch_metrics) == 2
+    for m in model.epoch_metrics:
+        assert 0.0 <= m["hit@1"] <= m["hit@3"] <= m["hit@10"] <= 1.0 / 3 + 1e-6     # rows >= B can never hit (metrics.py:95-100)
+        assert 0.0 < m["type_diversity"] <= 1.0 and -1.0 <= m["mean_relevance"] <= 1.0
+    hits = [m["hit@10"] for m in model.epoch_metrics]
+    want_epoch = 0 if hits[0] >= hits[1] else 1                                    # strict improvement only (train.py:62)
+    assert best["epoch"] == want_epoch and best["metrics"] == model.epoch_metrics[want_epoch]
+    steps_at_best = (want_epoch + 1) * len(tr)
+    assert all(float(s["step"]) == steps_at_best for s in best["optimizer_state_dict"]["state"].values())
     # reference-style (unfused, torch Adam) loop on the same data also runs
     c2 = cfg(tmp_path, NUM_TYPES=bpg.n_types, NUM_EPOCHS=1)
     drv.train(c2, tr, va, emb, fused=False)

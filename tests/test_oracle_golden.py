@@ -193,3 +193,143 @@ def test_metrics(golden):
                                       t(g["target_features"]))
     for name, val in zip(g["metric_names"], g["metric_values"]):
         assert abs(res[str(name)] - float(val)) < 1e-6, name
+
+
+# ------------------------------------------------------------------ G6 at T = 1000 (SURVEY 8c's size)
+def test_joint_step_t1000(golden):
+    g = golden("g6_joint_t1000.npz")
+    st = load_state(g, "init.")
+    batch = {k[6:]: t(g[k]) for k in g.files if k.startswith("batch.")}
+    mom = joint_oracle.new_moments(st)
+    losses = []
+    for step in range(1, 4):
+        r = joint_oracle.train_step(st, batch, mom, step)
+        losses.append(float(r["loss"]))
+        if step == 1:
+            assert np.array_equal(r["out"]["complementary_types"].numpy(), g["complementary_types"])
+            np.testing.assert_allclose(r["out"]["type_similarities"][:, :128], g["type_similarities"], atol=2e-6)
+            for k in joint_oracle.TRAINABLE:
+                np.testing.assert_allclose(r["grads"][k], g["grad." + k], atol=1e-7)
+    np.testing.assert_allclose(losses, g["losses"], atol=2e-6)
+    for k in joint_oracle.TRAINABLE:
+        np.testing.assert_allclose(st[k], g["after3." + k], atol=2e-6)
+        np.testing.assert_allclose(mom[k][0], g[f"after3.exp_avg.{k}"], atol=1e-7)
+
+
+# ------------------------------------------------------------------ G10: Product2Vec.train_model, two epochs
+def p2v_epoch_batches(ints, g):
+    """The batches DataLoader(SimilarityDataset, B, shuffle=False, collate_fn) yields (data_loader.py:45-71,171-206), in
+    index form, with the negatives of the CPython stream after random.seed(seed) (:27-40)."""
+    pairs = ints["similarity_pairs"]
+    B, S = int(g["batch_size"]), len(pairs)
+    rng = Random(int(g["seed"]))
+    at = 0
+    for epoch in range(int(g["epochs"])):
+        for lo in range(0, S, B):
+            ids = np.arange(lo, min(lo + B, S))
+            neg = rng.negative_samples(1000, pairs, pairs[ids, 0], 5)
+            assert np.array_equal(neg, g["negative_idx"][at:at + len(ids)])          # bit-exact negative-sample indices
+            at += len(ids)
+            yield data_oracle.similarity_batch(ints, ids, neg)
+    assert at == len(g["negative_idx"])
+
+
+def test_p2v_train_model_epochs(golden):
+    """The oracle's loop body iterated over the reference's own two-epoch run of Product2Vec.train_model
+    (product2vec.py:113-170): 24 steps with a ragged last batch (133 of 256), BatchNorm running statistics carried
+    through 96 calls, then the eval-mode export over all 1 000 products (32 of them without out-neighbours)."""
+    g = golden("g10_p2v_epochs.npz")
+    ints = golden("g2_bpg1000.npz")
+    st = load_state(g, "init.")
+    mom = p2v_oracle.new_moments(st)
+    feats = t(ints["features"])
+    losses = []
+    for step, b in enumerate(p2v_epoch_batches(ints, g), 1):
+        batch = p2v_oracle.gather_batch(feats, b["anchor_idx"], b["positive_idx"], b["negative_idx"], b["neighbor_idx"])
+        losses.append(float(p2v_oracle.train_step(st, batch, 1.0, mom, step)["loss"]))
+    assert len(losses) == len(g["losses"]) == 24 and len(ints["similarity_pairs"]) % 256 == 133
+    np.testing.assert_allclose(losses, g["losses"], rtol=0, atol=1e-5)
+    assert int(st["ffn.1.num_batches_tracked"]) == int(g["final.ffn.1.num_batches_tracked"]) == 96
+    # ffn.0.bias has an analytically zero gradient (BatchNorm removes the shift); Adam turns its rounding noise into
+    # steps of up to lr, on either side differently, and the running MEAN carries that bias: bounded by steps * lr, and
+    # without the bias's own drift it agrees closely
+    d_mean = (st["ffn.1.running_mean"] - t(g["final.ffn.1.running_mean"])).abs()
+    assert float(d_mean.max()) <= 24e-3
+    drift = st["ffn.0.bias"] - t(g["final.ffn.0.bias"])
+    print("running_mean: max diff %.2e, b0 drift max %.2e" % (float(d_mean.max()), float(drift.abs().max())))
+    np.testing.assert_allclose(st["ffn.1.running_var"], g["final.ffn.1.running_var"], rtol=1e-5, atol=1e-5)
+    for k in p2v_oracle.TRAINABLE:
+        if k != "ffn.0.bias":
+            assert_adam_close(st[k], g["final." + k], 24, 5e-5)
+    # the export from the REFERENCE's final weights (the oracle's export alone), then from the oracle's own
+    emb = p2v_oracle.generate_all_embeddings(feats, ints["cv_rowptr"], ints["cv_col"], load_state(g, "final."))
+    np.testing.assert_allclose(emb, g["embeddings"], atol=5e-6)
+    emb = p2v_oracle.generate_all_embeddings(feats, ints["cv_rowptr"], ints["cv_col"], st)
+    np.testing.assert_allclose(emb, g["embeddings"], atol=1e-3)
+    assert (np.diff(ints["cv_rowptr"]) == 0).sum() == 32
+
+
+# ------------------------------------------------------------------ G11: train.train, two epochs
+def joint_epoch_batches(ints, g, which, epoch):
+    """The batches of DataLoader(ComplementaryDataset, B, collate_fn) (data_loader.py:133-157) in the order the reference's
+    loader visited the samples, with the randn_like filler rows it drew as input data."""
+    pairs, order, filler = g[which + "_pairs"], g[which + "_order"][epoch], g[which + "_filler"][epoch]
+    B, n_types = int(g["batch_size"]), len(ints["type_names"])
+    feats = ints["features"]
+    for lo in range(0, len(order), B):
+        rows = pairs[order[lo:lo + B]]
+        f = filler[lo:lo + B]
+        ii = [data_oracle.complementary_sample_ints(q, tg, lab, ints["type_idx"], n_types) for q, tg, lab in rows]
+        real = feats[rows[:, 1]]
+        pos = rows[:, 2:3] == 1
+        yield {"query_idx": t(rows[:, 0].astype(np.int64)), "label": rows[:, 2],
+               "query_types": t(np.array([i["query_types"] for i in ii], np.int64)),
+               "positive_types": t(np.array([[i["positive_types"]] for i in ii], np.int64)),
+               "negative_types": t(np.array([[i["negative_types"]] for i in ii], np.int64)),
+               "positive_items": t(np.where(pos, real, f)), "negative_items": t(np.where(pos, f, real)),
+               "target_features": t(real)}
+
+
+def test_joint_train_epochs(golden):
+    """The oracle's loop body + evaluate_batch iterated over the reference's own two-epoch run of train.train
+    (train.py:16-72) on the g2 graph with g10's embeddings: 48 steps (ragged last batches), metrics over three
+    validation batches after each epoch, the best-checkpoint rule."""
+    g = golden("g11_joint_epochs.npz")
+    ints = golden("g2_bpg1000.npz")
+    st = load_state(g, "init.")
+    st["product_embeddings.weight"] = t(golden("g10_p2v_epochs.npz")["embeddings"]).clone()
+    # the datasets' pair order and split are the CPython stream's (data_loader.py:108-126), train then val from one stream
+    rng = Random(int(g["seed"]))
+    cp, sp = ints["complementary_pairs"], ints["similarity_pairs"]
+    allp = np.concatenate([np.c_[cp, np.ones(len(cp), np.int32)], np.c_[sp, -np.ones(len(sp), np.int32)]])
+    n = len(allp)
+    assert np.array_equal(allp[rng.shuffle_perm(n)][:int(0.8 * n)], g["train_pairs"])
+    assert np.array_equal(allp[rng.shuffle_perm(n)][int(0.8 * n):int(0.9 * n)], g["val_pairs"])
+    mom = joint_oracle.new_moments(st)
+    names = [str(x) for x in g["metric_names"]]
+    losses, step, best, best_epoch = [], 0, 0.0, None
+    for epoch in range(int(g["epochs"])):
+        for batch in joint_epoch_batches(ints, g, "train", epoch):
+            step += 1
+            losses.append(float(joint_oracle.train_step(st, batch, mom, step)["loss"]))
+        acc, nb = dict.fromkeys(names, 0.0), 0
+        for batch in joint_epoch_batches(ints, g, "val", epoch):
+            r = joint_oracle.evaluate_batch(st, batch["query_idx"], batch["query_types"], batch["positive_items"],
+                                            batch["target_features"])
+            for k in names:
+                acc[k] += r[k]
+            nb += 1
+        assert nb == 3
+        for k, want in zip(names, g["metric_values"][epoch]):
+            assert abs(acc[k] / nb - want) < 1e-6, (epoch, k, acc[k] / nb, want)
+        if acc["hit@10"] / nb > best:                                   # train.py:62
+            best, best_epoch = acc["hit@10"] / nb, epoch
+            best_state = {k: st[k].clone() for k in joint_oracle.TRAINABLE}
+    assert step == 48 and best_epoch == int(g["best_epoch"])
+    np.testing.assert_allclose(losses, g["losses"], rtol=0, atol=5e-6)
+    for k in joint_oracle.TRAINABLE:
+        np.testing.assert_allclose(st[k], g["final." + k], atol=1e-5, err_msg=k)
+        np.testing.assert_allclose(best_state[k], g["best." + k], atol=1e-5, err_msg=k)
+        np.testing.assert_allclose(mom[k][0], g["final.exp_avg." + k], atol=1e-6, err_msg=k)
+        np.testing.assert_allclose(mom[k][1], g["final.exp_avg_sq." + k], atol=1e-7, err_msg=k)
+        assert float(g["final.step." + k]) == 48.0
