@@ -36,6 +36,7 @@ FP32_MFMA_PEAK_TFLOPS = 157.3     # /opt/skills/guides/MI355X_MICROARCH.md, Peak
 BF16_MFMA_PEAK_TFLOPS = 2500.0    # same guide, dense bf16 (no sparsity)
 BF16_PRODUCTS = 6                 # common.h split3: x = p0 + p1 + p2 (bf16 each), x*y ~ the six products of weight <= 2
 NT_PEAK_TFLOPS = BF16_MFMA_PEAK_TFLOPS / BF16_PRODUCTS     # 416.7 fp32-equivalent TFLOP/s
+TN_PROFILE_STEPS = 4       # untimed steps behind the region whose weight-gradient (TN) launches carry HIP-event brackets
 PROFILE_EVERY = 20         # timed steps between two steps whose gemm_nt launches carry HIP-event brackets (each bracketed step pays ~60 us of event packets)
 HBM_PEAK_GBS = 8000.0
 
@@ -248,8 +249,10 @@ def run_joint(args, rank, world, dev, types, steps, warmup, want_cpu, dropout=0.
         # as row lists with one host-visible read per step, the 29 k dense weights as one all-reduce)
         try:
             if exchange is not None:
+                # (T > 512: the optimizer sharded over the replicas -- reduce-scatter, Adam on 1/world of the flat buffers,
+                # all-gather -- ABI 8; GraphedJointStep pads and registers the flat buffers)
                 graphed = GraphedJointStep(model, opt, args.batch, mode="direct", exchange=exchange)
-                exchange.register(gflat)
+                flat, gflat = model.flatten_parameters()
             else:
                 graphed = GraphedJointStep(model, opt, args.batch, mode="direct", grad_hook=lambda g: pdist.all_reduce_mean_(g, world))
                 graphed.grad_hook = pdist.joint_grad_hook(model, graphed, world)
@@ -336,12 +339,21 @@ def run_joint(args, rank, world, dev, types, steps, warmup, want_cpu, dropout=0.
                                   f"batch={args.batch}/GPU, K=3 (loader batch construction included)",
                       "global_batch": world * args.batch, "parallelism": f"dp{world}", "final_loss": round(float(losses[0]), 5),
                       "dropout": float(dropout),
+                      "topk": ("exact: index-identical to torch.topk of the full [B,T] similarity product" if types <= 512 else
+                               "per-sample selection over a re-associated fp32 product (sub-chunk maxima, then an exact top-K over each row's K "
+                               "best sub-chunks): identical to torch.topk of the oracle's product except at fp32-rounding TIES -- the full-size "
+                               "test allows <= 2 of 4096 rows to differ there (tests/test_gpu_fullsize.py), the one integer output of the "
+                               "path that is not asserted bit-exact at this size"),
                       # N > 1: what one replica hands to the all-reduce per step -- the whole flat gradient buffer behind the slot
                       # (T = 34800: both dense [T,64] tables, 17.8 MB: about what the touched rows would cost as constant-shape
                       # padded lists at B = 4096); the Python hooks send the touched rows (sizes read back)
                       "exchange_bytes_per_step": (int(gflat.numel()) * 4 if multi and graphed is not None and graphed.exchange is not None else None),
                       "exchange": (getattr(exchange, "kind", None) if multi and graphed is not None and graphed.exchange is not None else
                                    "python grad_hook per step (torch.distributed)" if multi else None),
+                      "optimizer": (("sharded over the replicas: reduce-scatter of the flat gradient, Adam on this rank's 1/%d of the flat "
+                                     "buffers, all-gather of the parameters (pc_exchange_adam_plan)" % world)
+                                    if multi and graphed is not None and getattr(graphed, "shard_optimizer", False) else
+                                    "all-reduce of the flat gradient, the whole Adam on every rank" if multi else "one process"),
                       "launch": (("pc_joint_train_epoch_dp: the replica's epoch (fused step without Adam, exchange slot, Adam) enqueued by one foreign call"
                                   if multi else "pc_joint_train_epoch: the epoch's steps enqueued by one foreign call") if by_epoch else
                                  {"direct": "fused step, arguments resolved once (one foreign call per step)" +
@@ -481,6 +493,16 @@ def run_p2v(args, rank, world, dev, products, steps, warmup, want_cpu, profile_k
     el = float(t)
     if sharded is not None:
         sharded.raise_if_overflowed()
+    # the second-largest kernel family (the weight-gradient products: gemm_tn8_kernel x3 + gemm_tn_group_kernel): HIP-event
+    # brackets around ITS launches over a few extra steps OUTSIDE the timed region (every bracket is two event packets on the
+    # stream; the timed region carries the dominant family's only).  All ranks step together (the step holds collectives).
+    tn_prof = None
+    if profile_kernels and not args.profile_all:
+        tn_prof = ops.KernelProfile(capacity=64)
+        tn_prof.set_kinds(["gemm_tn_kernel"])
+        for _ in range(TN_PROFILE_STEPS):
+            step(next(it), profile=tn_prof)
+        torch.cuda.synchronize()
     if rank != 0:
         return None
 
@@ -496,7 +518,10 @@ def run_p2v(args, rank, world, dev, products, steps, warmup, want_cpu, profile_k
            "rows_saved_by_duplicate_neighbours": round(1.0 - (7 * args.batch + rows_avg + 1) / (7 * args.batch + slots_avg + 1), 4)}
     if profile_kernels:
         nt = prof.summary("gemm_nt_kernel")
-        tn = prof.summary("gemm_tn_kernel")
+        tn = (tn_prof if tn_prof is not None else prof).summary("gemm_tn_kernel")
+        tn_steps = TN_PROFILE_STEPS if tn_prof is not None else profiled_steps
+        tn_traffic = committed_pmc(pmc_kind, lambda k: "gemm_tn" in k)
+        tn_red = committed_pmc(pmc_kind, lambda k: "tn_reduce" in k)
         sm = prof.summary("gemm_nt_small_kernel")
         traffic = committed_pmc(pmc_kind, lambda k: "gemm_nt_kernel<" in k and "<1, 2," not in k)
         launches = max(nt["launches"], 1)
@@ -535,10 +560,24 @@ def run_p2v(args, rank, world, dev, products, steps, warmup, want_cpu, profile_k
             "family_us_per_step": round(1e3 * nt["total_ms"] / max(profiled_steps, 1), 1),
             "bracketed_steps": profiled_steps,              # (every PROFILE_EVERY-th timed step carries the HIP-event brackets)
             "share_of_step": round(nt["total_ms"] / max(profiled_steps, 1) / (el * 1e3 / steps), 3),
+            # the weight-gradient family (dW0, dW3, dW5 + the attention block's grouped dW): fp32-grade six-product bf16 form like
+            # the NT family, so the same matrix peak; each launch writes per-workgroup partial-sum slabs that
+            # tn_reduce_group_kernel folds (slab bytes: the committed counter passes of the same command)
             "gemm_tn_kernel": ({"achieved_tflops": round(tn["total_flops"] / max(tn["total_ms"], 1e-9) / 1e9, 2),
-                                "launches": tn["launches"],
-                                "share_of_step": round(tn["total_ms"] / max(profiled_steps, 1) / (el * 1e3 / steps), 3)}
-                               if tn["launches"] else None),                     # bracketed with --profile-all only
+                                "peak_tflops": round(NT_PEAK_TFLOPS, 1),
+                                "frac": round(tn["total_flops"] / max(tn["total_ms"], 1e-9) / 1e9 / NT_PEAK_TFLOPS, 4),
+                                "flops_per_launch": round(tn["total_flops"] / max(tn["launches"], 1)),
+                                "avg_launch_us": round(1e3 * tn["total_ms"] / max(tn["launches"], 1), 2),
+                                "launches": tn["launches"], "launches_per_step": round(tn["launches"] / max(tn_steps, 1), 2),
+                                "family_us_per_step": round(1e3 * tn["total_ms"] / max(tn_steps, 1), 1),
+                                "share_of_step": round(tn["total_ms"] / max(tn_steps, 1) / (el * 1e3 / steps), 3),
+                                "bracketed_steps": tn_steps,
+                                "measured": "HIP events around the family's launches over %d steps after the timed region" % tn_steps
+                                            if tn_prof is not None else "--profile-all: inside the timed region",
+                                "traffic": tn_traffic["hbm_bytes_per_launch"] if tn_traffic else None,
+                                "slab_reduce_traffic": tn_red["hbm_bytes_per_launch"] if tn_red else None,
+                                "traffic_source": tn_traffic["source"] if tn_traffic else None}
+                               if tn["launches"] else None),
             "gemm_nt_small_kernel": ({"launches": sm["launches"],
                                       "avg_launch_us": round(1e3 * sm["total_ms"] / max(sm["launches"], 1), 2),
                                       "share_of_step": round(sm["total_ms"] / max(profiled_steps, 1) / (el * 1e3 / steps), 3)}
@@ -597,7 +636,70 @@ def run_p2v(args, rank, world, dev, products, steps, warmup, want_cpu, profile_k
     if want_cpu and sharded is None and not on_device and dim == 128:    # (the oracle reads host arrays; a sharded batch indexes its own gathered table)
         res["cpu_baseline"] = p2v_cpu_baseline(bpg, last, dropout=float(dropout))
     prof.close()
+    if tn_prof is not None:
+        tn_prof.close()
     return res
+
+
+def run_dropin_dense(args, dev, steps, warmup):
+    """The LITERAL plug-in surface (three import lines change): the reference's loop body
+    (product2vec.py:126-164), statement for statement, over device-resident batches in the reference's collate format
+    (anchor [B,128], positive [B,128], negative [B,5,128], anchor_neighbors [B,N,128] zero-padded), `model(...)` four times
+    through the autograd Functions of p_companion_amd.product2vec (every padded slot its own row: no identical-row merging, no
+    index form), torch's own pairwise_distance / relu / mean, loss.backward(), torch.optim.Adam.  One process."""
+    from types import SimpleNamespace
+    import torch.nn.functional as F
+    from p_companion_amd.data import SimilarityIndexLoader, generate_scaled_bpg
+    from p_companion_amd.product2vec import Product2Vec
+    cfg = SimpleNamespace(PRODUCT_EMB_DIM=128, TYPE_EMB_DIM=64, HIDDEN_SIZE=256, NUM_ATTENTION_HEADS=4, DROPOUT=0.0,
+                          MARGIN=1.0, BATCH_SIZE=args.batch, LEARNING_RATE=1e-3, DEVICE=dev)
+    bpg = run_joint.bpg if getattr(run_joint, "bpg", None) is not None else generate_scaled_bpg(args.products, args.types, seed=0)
+    table = bpg.cuda(dev)["features"]
+    ftab = torch.cat([table, torch.zeros(1, table.shape[1], device=dev)])           # slot -1 = collate_fn's zero padding row
+    loader = SimilarityIndexLoader(bpg, args.batch, shuffle=True, sampler="philox", seed=1, drop_last=True, device=dev,
+                                   compact=False, prefetch=False, unique=False)
+    batches = []
+    for b in loader:                                          # four distinct batches, resident, in the reference's format
+        batches.append({"anchor": table[b["anchor_idx"].long()], "positive": table[b["positive_idx"].long()],
+                        "negative": table[b["negative_idx"].long()], "anchor_neighbors": ftab[b["neighbor_idx"].long()],
+                        "anchor_ids": None})
+        if len(batches) == 4:
+            break
+    torch.manual_seed(0)
+    self = Product2Vec(cfg).to(dev)
+    optimizer = torch.optim.Adam(self.parameters(), lr=cfg.LEARNING_RATE)
+    self.train()
+    device = dev
+
+    def body(batch):
+        batch = {k: v.to(device) if isinstance(v, torch.Tensor) else v for k, v in batch.items()}
+        anchor_emb = self(batch['anchor'], batch.get('anchor_neighbors'))
+        positive_emb = self(batch['positive'])
+        negative_emb = self(batch['negative'])
+        pos_distance = F.pairwise_distance(anchor_emb, positive_emb)
+        anchor_expanded = anchor_emb.unsqueeze(1).expand(-1, negative_emb.size(1), -1)
+        neg_distance = torch.mean(F.pairwise_distance(anchor_expanded, negative_emb, p=2), dim=1)
+        loss = F.relu(self.config.MARGIN - pos_distance + neg_distance).mean()
+        optimizer.zero_grad()
+        loss.backward()
+        optimizer.step()
+        return loss
+
+    for i in range(warmup):
+        body(batches[i % 4])
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(steps):
+        loss = body(batches[i % 4])
+    torch.cuda.synchronize()
+    el = time.perf_counter() - t0
+    n = batches[0]["anchor_neighbors"].shape[1]
+    return {"value": round(args.batch * steps / el, 1), "unit": "triplets/s", "ms_per_step": round(1e3 * el / steps, 4), "steps": steps,
+            "final_loss": round(float(loss), 5),
+            "workload": f"the reference's loop body (product2vec.py:126-164) unmodified over device-resident reference-format batches "
+                        f"(B={args.batch}, N={n} padded slots, 5 negatives; {sum(t.numel() * 4 for t in batches[0].values() if torch.is_tensor(t)) / 1e6:.0f} MB "
+                        "per batch), model(...) x 4 through the HIP autograd Functions, torch pairwise_distance, loss.backward(), "
+                        "torch.optim.Adam; batches handed over from host memory add their PCIe time (DESIGN.md section 7)"}
 
 
 def self_launch(n, argv):
@@ -662,6 +764,41 @@ def rccl_info(world, dev):
             "ranks_seen": sorted(int(v) for v in seen.tolist()), "launcher": "self" if os.environ.get("PC_BENCH_SELF_LAUNCHED") else "torch.distributed.run"}
 
 
+FINAL = {"emit": None, "rank": 0}     # main() installs the function that prints the line from whatever legs exist so far
+
+
+def leg_watchdog(name, world):
+    """N > 1 only.  A secondary leg that HANGS (a collective some rank never joins: nothing raises) would take the headline
+    down with it when the harness kills the job.  Every rank arms the same timer when it enters the leg
+    (PC_BENCH_LEG_DEADLINE_S, default 180 s); if the leg is still running then, rank 0 prints the line with what has been
+    measured -- the headline leg ran first -- and this leg reported as an error, and every rank leaves with os._exit (a thread
+    parked inside a collective cannot be unwound)."""
+    if world <= 1:
+        return None
+    import threading
+    deadline = float(os.environ.get("PC_BENCH_LEG_DEADLINE_S", "180"))
+
+    def expire():
+        print(f"[bench] rank {FINAL['rank']}: leg `{name}` still running after {deadline:.0f} s -- ending the job with the legs measured so far",
+              file=sys.stderr, flush=True)
+        code = 75
+        if FINAL["rank"] == 0 and FINAL["emit"] is not None:
+            try:
+                FINAL["emit"]({name: {"error": f"did not finish within {deadline:.0f} s (PC_BENCH_LEG_DEADLINE_S); job ended", "leg": name}})
+                code = 0 if name != "headline" else 75
+            except Exception:                                   # noqa: BLE001
+                pass
+        elif FINAL["rank"] != 0:
+            code = 0
+        sys.stdout.flush()
+        os._exit(code)
+
+    t = threading.Timer(deadline, expire)
+    t.daemon = True
+    t.start()
+    return t
+
+
 def guarded(name, fn, world):
     """A SECONDARY leg must not take the headline down with it (an allocation that does not fit a smaller card, a path no
     multi-GPU box has exercised yet): its failure is reported in its place.  At N > 1 the ranks agree on the outcome (MIN
@@ -670,6 +807,7 @@ def guarded(name, fn, world):
     group's bounded timeout ends (then the launcher ends the job: nothing can report that case)."""
     err = None
     res = None
+    watchdog = leg_watchdog(name, world)
     try:
         res = fn()
     except Exception as e:                                      # noqa: BLE001 -- reported, not swallowed
@@ -690,6 +828,8 @@ def guarded(name, fn, world):
         dist.all_reduce(flag, op=dist.ReduceOp.MIN)
         if int(flag.item()) == 0 and err is None:
             err = "failed on another rank"
+    if watchdog is not None:
+        watchdog.cancel()
     if err:
         return {"error": err, "leg": name}
     return res
@@ -744,6 +884,7 @@ def main():
                          "configs[4]: 100 M products x 256, Zipf negatives; both generated in HBM)")
     ap.add_argument("--no-dropout-legs", action="store_true", help="skip the legs at the reference's shipped DROPOUT = 0.1 (config.py:12)")
     ap.add_argument("--no-ref-types", action="store_true", help="skip the joint leg at the reference's NUM_TYPES = 34800")
+    ap.add_argument("--no-dropin", action="store_true", help="skip the `dropin_dense` leg (the reference's loop body over reference-format batches)")
     ap.add_argument("--no-sustained", action="store_true", help="skip the `sustained` leg (3 x >= 300 P2V steps across epoch boundaries)")
     args = ap.parse_args()
 
@@ -751,6 +892,13 @@ def main():
         sys.exit(self_launch(args.gpus, sys.argv[1:]))           # (nothing has touched the GPU in this process)
 
     from p_companion_amd import distributed as pdist
+    if os.environ.get("PC_BENCH_SET_OPTIONS"):
+        # developer A/B on one box: "3=1,2=0" -> pc_set_option(3, 1), pc_set_option(2, 0) before anything runs (include/pcompanion_hip.h PC_OPT_*)
+        from p_companion_amd import _lib
+        for kv in os.environ["PC_BENCH_SET_OPTIONS"].split(","):
+            o, v = (int(x) for x in kv.split("="))
+            if _lib.lib().pc_set_option(o, v) != 0:
+                raise SystemExit(f"PC_BENCH_SET_OPTIONS: pc_set_option({o}, {v}) refused")
     rank, world, local = pdist.init_from_env("cuda")
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
@@ -769,12 +917,87 @@ def main():
             rccl["exchange"] = EXCHANGE["ex"].kind
     elif rccl is not None:
         rccl["exchange"] = "python hooks (torch.distributed), --exchange hook"
+    if rccl is not None:
+        if pdist.last_probe is not None:
+            rccl["native_probe"] = pdist.last_probe              # {"native", "reason" (the fallback's, if any), "seconds"}
+        rccl["timeouts_s"] = {"probe": pdist.probe_timeout_s(), "process_group": pdist.group_timeout_s(),
+                              "secondary_leg": float(os.environ.get("PC_BENCH_LEG_DEADLINE_S", "180"))}
+        if rank == 0:
+            # first contact with a multi-GPU node: what the ranks agreed on, BEFORE the first timed leg (stderr: stdout carries
+            # the one JSON line)
+            print("[bench] rccl " + json.dumps(rccl), file=sys.stderr, flush=True)
+    FINAL["rank"] = rank
 
     p2v = joint = joint_ref = large = None
     extra = {}
+    def emit(errors=None):
+        """Print THE line from the legs measured so far (closure over main's leg variables).  errors: {leg name: {"error": ...}} of a
+        leg the watchdog gave up on."""
+        if p2v is None and joint is None:
+            print(json.dumps({"metric": "triplets/sec (Product2Vec pretrain step: gather+fwd+bwd+Adam)", "value": None, "unit": "triplets/s",
+                              "n_gpus": world, "error": "the headline leg did not complete", **(errors or {})}), flush=True)
+            return
+        common = {"unit": "triplets/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "higher_is_better": True,
+                  "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic"}
+        if rccl:
+            common["rccl"] = rccl
+        if p2v is None:                                           # --phase joint: the joint step is the line
+            out = dict(common)
+            out.update(joint)
+            out["steps"] = joint["steps"]
+            if joint_ref:
+                out["joint_num_types_34800"] = joint_ref
+            out.update(extra)
+            print(json.dumps(out), flush=True)
+            return
+        out = {"metric": "triplets/sec (Product2Vec pretrain step: gather+fwd+bwd+Adam)" +
+                         (" + P-Companion joint step under `joint`" if joint else ""),
+               "value": round(p2v["value"], 1), **common, "ms_per_step": round(p2v["ms_per_step"], 4),
+               "host_enqueue_ms_per_step": p2v.get("host_enqueue_ms_per_step"),
+               "host_enqueue_note": "wall time of the host between the region's two clocks / steps: its own work (~0.34 ms per step: loader next() "
+                                    "0.11, train_step_indexed 0.18, optimizer.step 0.05 -- scripts/dev/host_breakdown.py) plus the time it waits "
+                                    "behind a full launch queue; below ms_per_step = the device is the bound, not the host",
+               "dtype_note": "fp32 storage, accumulation and result accuracy; the large GEMMs evaluate each fp32 product as six "
+                             "bf16 matrix-core products of a three-way split (error <= the fp32 MFMA's, tests/test_gpu_ops.py)",
+               "config": {"workload": f"Product2Vec GAT pretrain, {args.products} products, {args.types} types, dim={args.dim}, "
+                                      f"batch={args.batch}/GPU, 5 negatives, neighbours padded to batch max "
+                                      f"(avg N={p2v['n_avg']:.1f})", "global_batch": world * args.batch,
+                          "dropout": args.dropout,
+                          "dropout_note": "DROPOUT = 0.0 is the parity setting (ATen's mask stream cannot be reproduced: every golden-vector "
+                                          "test runs at 0); the reference ships config.py:12 DROPOUT = 0.1 -- legs `p2v_dropout_0p1`, "
+                                          "`joint_dropout_0p1`, `joint_num_types_34800_dropout_0p1` of this line run that setting",
+                          "table": args.table, "sharded_lookup": p2v.get("sharded_lookup"), "parallelism": f"dp{world}",
+                          "batchnorm": "cross-replica" if (args.sync_bn and pdist.collectives_on(world)) else "per-replica",
+                          "final_loss": round(p2v["final_loss"], 5),
+                          "neighbour_rows": "identical rows of the neighbour call carried once: avg %.0f distinct products (%.0f "
+                                            "real slots) + 1 shared padding row, of %d neighbour slots per step; the duplicates "
+                                            "are a property of the catalogue (%.0f %% of all FFN rows saved at %d products; none to "
+                                            "speak of at 10 M / 100 M products: `large_catalogue` of this line)"
+                                            % (p2v["distinct_neighbour_rows"], p2v["real_neighbour_slots"],
+                                               args.batch * round(p2v["n_avg"]), 100 * p2v["rows_saved_by_duplicate_neighbours"],
+                                               args.products)},
+               "sustained": p2v.get("sustained"), "catalogue": p2v.get("catalogue"),
+               "roofline": p2v.get("roofline"), "cpu_baseline": p2v.get("cpu_baseline")}
+        if large:
+            out["large_catalogue_extra"] = {"products": args.large_catalogue, "value": round(large["value"], 1),
+                                            "ms_per_step": round(large["ms_per_step"], 4),
+                                            "rows_saved_by_duplicate_neighbours": large["rows_saved_by_duplicate_neighbours"]}
+        if joint:
+            out["joint"] = joint
+        if joint_ref:
+            out["joint_num_types_34800"] = joint_ref
+        out.update(extra)
+        out.update(errors or {})
+        print(json.dumps(out), flush=True)
+    if rank == 0:
+        FINAL["emit"] = emit
+    headline_dog = leg_watchdog("headline", world)               # (N > 1: a headline leg that hangs ends the job with an error line)
     if args.phase in ("both", "p2v"):
         p2v = run_p2v(args, rank, world, dev, args.products, args.steps, args.warmup, want_cpu, sustained=not args.no_sustained,
                       dropout=args.dropout, pmc_kind="" if plain else ("big" if args.products == 100_000_000 else "cfg3" if args.products == 10_000_000 else "none"))
+        if headline_dog is not None:
+            headline_dog.cancel()
+            headline_dog = None
         if args.large_catalogue:
             large = run_p2v(args, rank, world, dev, args.large_catalogue, max(args.steps // 2, 5), args.warmup, False,
                             profile_kernels=False)
@@ -783,6 +1006,11 @@ def main():
                                                            dropout=0.1, pmc_kind="p2vd"), world)
             if rank == 0:
                 extra["p2v_dropout_0p1"] = leg(r)
+        if plain and world == 1 and not args.no_dropin:
+            # the literal plug-in surface: the reference's loop body over reference-format batches (one process: the reference has no N > 1)
+            extra["dropin_dense"] = guarded("dropin_dense", lambda: run_dropin_dense(args, dev, max(args.steps, 20), 5), world)
+    if headline_dog is not None:
+        headline_dog.cancel()
     if args.phase in ("both", "joint"):
         # (with the Product2Vec phase in front, the joint legs are secondary to the headline value: guarded like the others)
         first = (lambda name, fn: fn()) if args.phase == "joint" else (lambda name, fn: guarded(name, fn, world))
@@ -826,58 +1054,7 @@ def main():
         extra["large_catalogue"] = lc
     if rank != 0:
         return
-
-    common = {"unit": "triplets/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "higher_is_better": True,
-              "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic"}
-    if rccl:
-        common["rccl"] = rccl
-    if p2v is None:                                           # --phase joint: the joint step is the line
-        out = dict(common)
-        out.update(joint)
-        out["steps"] = joint["steps"]
-        if joint_ref:
-            out["joint_num_types_34800"] = joint_ref
-        out.update(extra)
-        print(json.dumps(out), flush=True)
-        return
-    out = {"metric": "triplets/sec (Product2Vec pretrain step: gather+fwd+bwd+Adam)" +
-                     (" + P-Companion joint step under `joint`" if joint else ""),
-           "value": round(p2v["value"], 1), **common, "ms_per_step": round(p2v["ms_per_step"], 4),
-           "host_enqueue_ms_per_step": p2v.get("host_enqueue_ms_per_step"),
-           "host_enqueue_note": "wall time of the host between the region's two clocks / steps: its own work (~0.34 ms per step: loader next() "
-                                "0.11, train_step_indexed 0.18, optimizer.step 0.05 -- scripts/dev/host_breakdown.py) plus the time it waits "
-                                "behind a full launch queue; below ms_per_step = the device is the bound, not the host",
-           "dtype_note": "fp32 storage, accumulation and result accuracy; the large GEMMs evaluate each fp32 product as six "
-                         "bf16 matrix-core products of a three-way split (error <= the fp32 MFMA's, tests/test_gpu_ops.py)",
-           "config": {"workload": f"Product2Vec GAT pretrain, {args.products} products, {args.types} types, dim={args.dim}, "
-                                  f"batch={args.batch}/GPU, 5 negatives, neighbours padded to batch max "
-                                  f"(avg N={p2v['n_avg']:.1f})", "global_batch": world * args.batch,
-                      "dropout": args.dropout,
-                      "dropout_note": "DROPOUT = 0.0 is the parity setting (ATen's mask stream cannot be reproduced: every golden-vector "
-                                      "test runs at 0); the reference ships config.py:12 DROPOUT = 0.1 -- legs `p2v_dropout_0p1`, "
-                                      "`joint_dropout_0p1`, `joint_num_types_34800_dropout_0p1` of this line run that setting",
-                      "table": args.table, "sharded_lookup": p2v.get("sharded_lookup"), "parallelism": f"dp{world}",
-                      "batchnorm": "cross-replica" if (args.sync_bn and pdist.collectives_on(world)) else "per-replica",
-                      "final_loss": round(p2v["final_loss"], 5),
-                      "neighbour_rows": "identical rows of the neighbour call carried once: avg %.0f distinct products (%.0f "
-                                        "real slots) + 1 shared padding row, of %d neighbour slots per step; the duplicates "
-                                        "are a property of the catalogue (%.0f %% of all FFN rows saved at %d products; none to "
-                                        "speak of at 10 M / 100 M products: `large_catalogue` of this line)"
-                                        % (p2v["distinct_neighbour_rows"], p2v["real_neighbour_slots"],
-                                           args.batch * round(p2v["n_avg"]), 100 * p2v["rows_saved_by_duplicate_neighbours"],
-                                           args.products)},
-           "sustained": p2v.get("sustained"), "catalogue": p2v.get("catalogue"),
-           "roofline": p2v.get("roofline"), "cpu_baseline": p2v.get("cpu_baseline")}
-    if large:
-        out["large_catalogue_extra"] = {"products": args.large_catalogue, "value": round(large["value"], 1),
-                                        "ms_per_step": round(large["ms_per_step"], 4),
-                                        "rows_saved_by_duplicate_neighbours": large["rows_saved_by_duplicate_neighbours"]}
-    if joint:
-        out["joint"] = joint
-    if joint_ref:
-        out["joint_num_types_34800"] = joint_ref
-    out.update(extra)
-    print(json.dumps(out), flush=True)
+    emit()
 
 
 if __name__ == "__main__":

@@ -14,7 +14,7 @@
  *   - caller-allocated outputs and workspace (pc_*_workspace_bytes queries);
  *   - return: 0 ok, <0 invalid argument (PC_E*), >0 a hipError_t; nothing throws;
  *   - re-entrant across host threads, streams and devices: two threads may step two models on two
- *     streams of one device concurrently (tests/test_gpu_round4.py runs exactly that, bit-equal to serial).
+ *     streams of one device concurrently (tests/test_gpu_streams.py runs exactly that, bit-equal to serial).
  *   Exceptions: the host-side helpers (pc_mt_*, pc_rccl_unique_id) take HOST pointers; pc_rccl_comm_create / _destroy are
  *   RCCL's communicator setup (they block until every rank has arrived and RCCL allocates its own buffers).
  *
@@ -71,7 +71,11 @@ extern "C" {
  *    stream, not from a host-language hook per step. */
 /* 7: pc_rccl_alltoall / pc_rccl_allreduce_sum_f64 / pc_rccl_comm_stats: every collective of a step on the library's ONE
  *    communicator, chained across streams (the lookup all-to-all used to be torch.distributed's, on a second communicator). */
-#define PC_ABI_VERSION 7
+/* 8: the optimizer SHARDED over the replicas (pc_exchange_plan, pc_exchange_adam_plan, pc_joint_train_epoch_plan,
+ *    pc_rccl_reduce_scatter_mean, pc_rccl_all_gather): reduce-scatter of the flat gradient, Adam on this rank's 1/world of it,
+ *    all-gather of the updated parameters -- instead of an all-reduce and the full dense Adam on every rank (the [num_types,64]
+ *    tables of src/models/p_companion.py:36-43 are 17.8 MB at config.py:27's num_types = 34800). */
+#define PC_ABI_VERSION 8
 int pc_abi_version(void);
 /* Process-wide options.  PC_OPT_SIDE_QUEUE: 1 (default) = the unsplit fused Product2Vec step may use its side queue
  * (see "Library-owned device state" above), 0 = every launch stays on the caller's stream.
@@ -82,8 +86,12 @@ int pc_abi_version(void);
  * per-workgroup LDS tables of the touched rows, reproducible up to 512 touched rows per table (float atomics beyond) -- the
  * default of ABI 7's first builds, 13 us slower per step at num_types = 34800, batch 4096, kept for comparison.  Lists that do
  * not fit the sort kernel's LDS (num_types > 65535, more than 24576 source rows) take the LDS-table form either way.
+ * PC_OPT_BN_FINALIZE_SIDE (ABI 8): where the fused Product2Vec step runs its BatchNorm-backward finalize (BatchNorm1d of
+ * product2vec.py:16; dgamma / dbeta and the coefficients dW0's loader applies).  0 (default) = on the step's own queue between
+ * dZ1 and dW3 (3 us); 1 = on the side queue beside dW3 (rounds 3-5: the kernel hidden, two cross-queue hops exposed), kept for
+ * comparison.
  * Unknown option / value: PC_EINVAL.  Thread-safe. */
-enum { PC_OPT_SIDE_QUEUE = 1, PC_OPT_SORTED_TABLE_GRADIENTS = 2 };
+enum { PC_OPT_SIDE_QUEUE = 1, PC_OPT_SORTED_TABLE_GRADIENTS = 2, PC_OPT_BN_FINALIZE_SIDE = 3 };
 int pc_set_option(int option, int value);
 int pc_get_option(int option, int* value);
 /* Destroys the library-owned device state (side queues and their events) of every device; 0 or a hipError_t. */
@@ -562,6 +570,39 @@ int pc_exchange_adam(pc_exchange_fn exchange, void *exchange_ctx, float *param, 
                      float *exp_avg_sq, size_t n, int64_t *step_count, int64_t t, float *scalars, double lr,
                      double beta1, double beta2, double eps, void *stream);
 
+/* --- ABI 8: the optimizer state sharded over the replicas ("ZeRO-1"; north_star: "reduce-scatter for the sparse grads").
+ * The reference's optimizer is torch.optim.Adam over EVERY parameter of one process (train.py:24,46-48): dense moments and a
+ * dense update for the two [num_types,64] tables (src/models/p_companion.py:36-43) whichever rows a batch touched.  G replicas
+ * that all-reduce the flat gradient each repeat that whole update (7 passes over 17.8 MB per step at num_types = 34800).
+ * Sharded: buf = world slices of n / world floats;
+ *   reduce_scatter_mean(ctx, grad, n / world, stream)   leaves in slice `rank` of grad the mean over the ranks of that slice
+ *                                                       (the other slices: unspecified), ordered on `stream`;
+ *   Adam (pc_adam_step / pc_adam_step_at) over slice `rank` of param / grad / exp_avg / exp_avg_sq only;
+ *   all_gather(ctx, param, n / world, stream)           every rank's slice `rank` of param -> all ranks, in place.
+ * The same bytes on the wire as the all-reduce (which is these two phases back to back), 1 / world of the update's traffic and
+ * of the moments' state that matters (this library keeps the moment buffers whole; only slice `rank` is ever read or written).
+ * Adam is elementwise, so the parameters after a step are those of the all-reduce form whenever the two reductions sum in
+ * the same order (always for world = 2; a ring all-reduce is this reduce-scatter + all-gather).
+ * plan->shard_optimizer == 0 (or world == 1 with reduce_scatter_mean == NULL): the plain form -- all_reduce_mean (may be NULL:
+ * no exchange) then Adam over all n.  n must be a multiple of world when sharded (the host pads the flat buffers), else PC_EINVAL.
+ * pc_rccl_reduce_scatter_mean / pc_rccl_all_gather are the native members: ncclReduceScatter(ncclAvg) / ncclAllGather in place
+ * on the library's communicator, chained like its other collectives. */
+typedef int (*pc_shard_collective_fn)(void *ctx, float *buf, size_t n_per_rank, void *stream);
+typedef struct pc_exchange_plan {
+    pc_exchange_fn all_reduce_mean;            /* the plain form's exchange (NULL: none) */
+    pc_shard_collective_fn reduce_scatter_mean;
+    pc_shard_collective_fn all_gather;
+    void *ctx;                                 /* handed to all three */
+    int rank, world;
+    int shard_optimizer;                       /* 1: reduce-scatter -> Adam on slice `rank` -> all-gather */
+} pc_exchange_plan;
+int pc_rccl_reduce_scatter_mean(void *comm, float *buf, size_t n_per_rank, void *stream);
+int pc_rccl_all_gather(void *comm, float *buf, size_t n_per_rank, void *stream);
+/* pc_exchange_adam with a plan (plan == NULL: no exchange, Adam over all n). */
+int pc_exchange_adam_plan(const pc_exchange_plan *plan, float *param, float *grad, float *exp_avg, float *exp_avg_sq,
+                          size_t n, int64_t *step_count, int64_t t, float *scalars, double lr, double beta1, double beta2,
+                          double eps, void *stream);
+
 /* pc_joint_train_epoch for a replica: every step is the fused step WITHOUT its Adam (gradients only), the exchange, then
  * Adam over the flat buffers -- train.py:36-57 with the replicas' mean gradient, all steps of the epoch enqueued by this one
  * call.  p / g must be views INTO param_flat / grad_flat (the [num_types,64] tables included: at num_types > 512 their dense
@@ -579,6 +620,18 @@ int pc_joint_train_epoch_dp(const pc_joint_tensors *p, const pc_joint_tensors *g
                             int32_t *neg_types, float *pos_items, float *neg_items, int batch, int drop_last,
                             int num_types, int k, int num_products, float margin, float alpha, float *losses_out,
                             int32_t *topk, int32_t *bad_count, void *ws, size_t ws_bytes, void *stream);
+
+/* pc_joint_train_epoch_dp with a plan in place of (exchange, exchange_ctx): per step the fused step without its Adam, then
+ * pc_exchange_adam_plan -- at num_types > 512 p_companion_amd passes shard_optimizer = 1. */
+int pc_joint_train_epoch_plan(const pc_joint_tensors *p, const pc_joint_tensors *g, float *param_flat, float *grad_flat,
+                              float *exp_avg_flat, float *exp_avg_sq_flat, size_t n_flat, int64_t *step_count,
+                              int64_t t_first, float *adam_scalars, double lr, double beta1, double beta2, double eps,
+                              const pc_exchange_plan *plan, const int32_t *pairs, int64_t n_pairs,
+                              const float *features, const int32_t *type_idx, int n_types, uint64_t seed,
+                              uint64_t first_step, int32_t *query_idx, int32_t *query_types, int32_t *pos_types,
+                              int32_t *neg_types, float *pos_items, float *neg_items, int batch, int drop_last,
+                              int num_types, int k, int num_products, float margin, float alpha, float *losses_out,
+                              int32_t *topk, int32_t *bad_count, void *ws, size_t ws_bytes, void *stream);
 
 /* The library's own RCCL communicator (librccl.so.1 is resolved at run time with dlopen -- the copy the process has
  * loaded already, e.g. torch's, else the system's; the library has no link-time dependency on it).
@@ -600,8 +653,12 @@ int pc_joint_train_epoch_dp(const pc_joint_tensors *p, const pc_joint_tensors *g
  *   pc_rccl_comm_stats           {collectives issued on the communicator, cross-stream waits inserted}
  *   pc_rccl_last_error()         text of the calling thread's last PC_ECOMM (static storage; "" if none)
  * ORDER.  Every collective of a step goes through this ONE communicator, and the communicator chains them: a collective
- * enqueued on a stream other than its predecessor's first makes that stream wait for an event recorded (then) at the tail of the
- * predecessor's stream; collectives that follow each other on one stream add nothing to it.
+ * enqueued on a stream other than its predecessor's first makes that stream wait for the predecessor.  Until the first change
+ * of stream nothing is recorded (collectives that follow each other on one stream are ordered by it: the joint step, a
+ * replicated table); at the first change the event is recorded at the tail of the predecessor's stream; from then on every
+ * collective records the event right behind itself on its own stream, so a later change of stream waits for the collective
+ * alone, not for whatever was enqueued behind it (the loader's look-ahead all-to-all is not serialised behind the step's
+ * kernels).  Streams handed to the communicator must outlive it.
  * The replicas issue the same sequence of calls, so the device-side order of the collectives is the same on every rank
  * whichever streams carry them (the loader's side stream: pc_rccl_alltoall a few batches ahead; the step's stream:
  * pc_rccl_allreduce_mean) -- two collectives of one job never race for the links in different orders on different ranks.

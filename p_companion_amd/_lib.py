@@ -70,6 +70,7 @@ _vp, _i, _sz, _f, _d, _u64, _i64 = (ctypes.c_void_p, ctypes.c_int, ctypes.c_size
 _P = ctypes.POINTER
 
 PC_OPT_SIDE_QUEUE = 1      # pc_set_option: the fused Product2Vec step's side queue (include/pcompanion_hip.h)
+PC_OPT_BN_FINALIZE_SIDE = 3          # ... the BatchNorm-backward finalize of the fused Product2Vec step on the side queue (default 0: on the step's own)
 PC_OPT_SORTED_TABLE_GRADIENTS = 2    # ... the [T,64] table gradients of the fused joint step through the sorted form wherever it fits (default 1)
 
 # name -> (restype, argtypes).  Must list every symbol include/pcompanion_hip.h declares
@@ -148,6 +149,13 @@ SIGNATURES = {
     "pc_joint_train_epoch_dp": (_i, [_P(JointTensors), _P(JointTensors), _vp, _vp, _vp, _vp, _sz, _vp, _i64, _vp, _d, _d, _d, _d,
                                      _vp, _vp, _vp, _i64, _vp, _vp, _i, _u64, _u64, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i,
                                      _i, _f, _f, _vp, _vp, _vp, _vp, _sz, _vp]),
+    # ABI 8: the optimizer sharded over the replicas (a pc_exchange_plan travels by reference)
+    "pc_exchange_adam_plan": (_i, [_vp, _vp, _vp, _vp, _vp, _sz, _vp, _i64, _vp, _d, _d, _d, _d, _vp]),
+    "pc_joint_train_epoch_plan": (_i, [_P(JointTensors), _P(JointTensors), _vp, _vp, _vp, _vp, _sz, _vp, _i64, _vp, _d, _d, _d, _d,
+                                       _vp, _vp, _i64, _vp, _vp, _i, _u64, _u64, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i,
+                                       _i, _f, _f, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "pc_rccl_reduce_scatter_mean": (_i, [_vp, _vp, _sz, _vp]),
+    "pc_rccl_all_gather": (_i, [_vp, _vp, _sz, _vp]),
     "pc_rccl_available": (_i, []),
     "pc_rccl_unique_id": (_i, [_vp]),
     "pc_rccl_comm_create": (_i, [_vp, _i, _i, _P(ctypes.c_void_p)]),

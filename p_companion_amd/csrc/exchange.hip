@@ -24,6 +24,8 @@ struct RcclApi {
     decltype(&ncclCommInitRank) comm_init_rank = nullptr;
     decltype(&ncclCommDestroy) comm_destroy = nullptr;
     decltype(&ncclAllReduce) all_reduce = nullptr;
+    decltype(&ncclReduceScatter) reduce_scatter = nullptr;
+    decltype(&ncclAllGather) all_gather = nullptr;
     decltype(&ncclSend) send = nullptr;
     decltype(&ncclRecv) recv = nullptr;
     decltype(&ncclGroupStart) group_start = nullptr;
@@ -55,13 +57,15 @@ const RcclApi& rccl_api() {
         api.comm_init_rank = reinterpret_cast<decltype(api.comm_init_rank)>(dlsym(api.handle, "ncclCommInitRank"));
         api.comm_destroy = reinterpret_cast<decltype(api.comm_destroy)>(dlsym(api.handle, "ncclCommDestroy"));
         api.all_reduce = reinterpret_cast<decltype(api.all_reduce)>(dlsym(api.handle, "ncclAllReduce"));
+        api.reduce_scatter = reinterpret_cast<decltype(api.reduce_scatter)>(dlsym(api.handle, "ncclReduceScatter"));
+        api.all_gather = reinterpret_cast<decltype(api.all_gather)>(dlsym(api.handle, "ncclAllGather"));
         api.error_string = reinterpret_cast<decltype(api.error_string)>(dlsym(api.handle, "ncclGetErrorString"));
         api.send = reinterpret_cast<decltype(api.send)>(dlsym(api.handle, "ncclSend"));
         api.recv = reinterpret_cast<decltype(api.recv)>(dlsym(api.handle, "ncclRecv"));
         api.group_start = reinterpret_cast<decltype(api.group_start)>(dlsym(api.handle, "ncclGroupStart"));
         api.group_end = reinterpret_cast<decltype(api.group_end)>(dlsym(api.handle, "ncclGroupEnd"));
         api.ok = api.get_unique_id && api.comm_init_rank && api.comm_destroy && api.all_reduce && api.error_string && api.send &&
-                 api.recv && api.group_start && api.group_end;
+                 api.recv && api.group_start && api.group_end && api.reduce_scatter && api.all_gather;
     });
     return api;
 }
@@ -75,17 +79,21 @@ int rccl_fail(const RcclApi& api, const char* what, ncclResult_t r) {
 // collectives in the same host order -- but a step has two streams (the loader's side stream carries the lookup all-to-all of a
 // batch a few steps ahead, the step's stream the gradient all-reduce), and two collectives that are in flight on two streams at
 // once may start in different orders on different ranks: the classic way to deadlock a ring.  So a collective enqueued on a
-// stream OTHER than its predecessor's first makes its stream wait for an event recorded, at that moment, at the tail of the
-// predecessor's stream (everything enqueued there so far, the predecessor included).  The device-side order of the
-// communicator's collectives is then their host issue order on every rank, whatever the streams do.  Collectives that all sit
-// on one stream -- the joint step, a replicated table -- never touch the event: stream order is the chain, and the step's
-// stream carries no extra packet.  One host thread at a time per communicator: `mu`.
+// stream OTHER than its predecessor's first makes its stream wait for the predecessor.  The device-side order of the
+// communicator's collectives is then their host issue order on every rank, whatever the streams do.
+// Collectives that all sit on one stream -- the joint step, a replicated table -- never touch the event: stream order is the
+// chain, and the step's stream carries no extra packet.  At the FIRST change of stream the event is recorded, then, at the tail
+// of the predecessor's stream (everything enqueued there so far: a one-time over-wait); from then on (`multi`) every collective
+// records the event right behind itself, on its own stream, and a change of stream waits for exactly that -- the loader's
+// look-ahead all-to-all is not serialised behind the step kernels queued after the gradient all-reduce, and no handle of a
+// stream the caller may since have destroyed is touched.  One host thread at a time per communicator: `mu`.
 struct PcComm {
     ncclComm_t comm;
     int rank, world;
-    hipEvent_t done = nullptr;             // re-recorded at every change of stream
+    hipEvent_t done = nullptr;             // behind the latest collective (multi), or recorded at the first change of stream
     hipStream_t last_stream = nullptr;
     bool has_last = false;
+    bool multi = false;                    // a change of stream has been seen: every collective records `done` behind itself
     std::mutex mu;
     long long chained = 0;                 // cross-stream waits inserted so far (pc_rccl_comm_stats)
     long long issued = 0;
@@ -98,7 +106,10 @@ int comm_order(PcComm* c, hipStream_t st) {
             set_error("hipEventCreateWithFlags", "could not create the communicator's ordering event");
             return PC_ECOMM;
         }
-        if (hipEventRecord(c->done, c->last_stream) != hipSuccess) { set_error("hipEventRecord", "ordering event"); return PC_ECOMM; }
+        if (!c->multi) {                   // the first change: nothing was recorded behind the predecessor -- its stream's tail, now
+            if (hipEventRecord(c->done, c->last_stream) != hipSuccess) { set_error("hipEventRecord", "ordering event"); return PC_ECOMM; }
+            c->multi = true;
+        }
         if (hipStreamWaitEvent(st, c->done, 0) != hipSuccess) { set_error("hipStreamWaitEvent", "ordering event"); return PC_ECOMM; }
         c->chained++;
     }
@@ -109,6 +120,7 @@ int comm_issued(PcComm* c, hipStream_t st) {
     c->issued++;
     c->last_stream = st;
     c->has_last = true;
+    if (c->multi && hipEventRecord(c->done, st) != hipSuccess) { set_error("hipEventRecord", "ordering event"); return PC_ECOMM; }
     return PC_OK;
 }
 
@@ -209,6 +221,33 @@ extern "C" int pc_rccl_alltoall(void* comm, const void* send, void* recv, size_t
     return comm_issued(c, (hipStream_t)stream);
 }
 
+// ABI 8: the two halves of the sharded optimizer's exchange, in place over a buffer of world * n_per_rank floats.
+// ncclReduceScatter is in place when recvbuff == sendbuff + rank * recvcount, ncclAllGather when sendbuff == recvbuff + rank * sendcount.
+extern "C" int pc_rccl_reduce_scatter_mean(void* comm, float* buf, size_t n_per_rank, void* stream) {
+    if (!comm || !buf || n_per_rank == 0) return PC_EINVAL;
+    const RcclApi& api = rccl_api();
+    if (!api.ok) { set_error("pc_rccl_reduce_scatter_mean", "librccl.so.1 could not be loaded"); return PC_ECOMM; }
+    PcComm* c = static_cast<PcComm*>(comm);
+    std::lock_guard<std::mutex> lk(c->mu);
+    PC_TRY(comm_order(c, (hipStream_t)stream));
+    const ncclResult_t r = api.reduce_scatter(buf, buf + (size_t)c->rank * n_per_rank, n_per_rank, ncclFloat32, ncclAvg, c->comm,
+                                              (hipStream_t)stream);
+    if (r != ncclSuccess) return rccl_fail(api, "ncclReduceScatter", r);
+    return comm_issued(c, (hipStream_t)stream);
+}
+
+extern "C" int pc_rccl_all_gather(void* comm, float* buf, size_t n_per_rank, void* stream) {
+    if (!comm || !buf || n_per_rank == 0) return PC_EINVAL;
+    const RcclApi& api = rccl_api();
+    if (!api.ok) { set_error("pc_rccl_all_gather", "librccl.so.1 could not be loaded"); return PC_ECOMM; }
+    PcComm* c = static_cast<PcComm*>(comm);
+    std::lock_guard<std::mutex> lk(c->mu);
+    PC_TRY(comm_order(c, (hipStream_t)stream));
+    const ncclResult_t r = api.all_gather(buf + (size_t)c->rank * n_per_rank, buf, n_per_rank, ncclFloat32, c->comm, (hipStream_t)stream);
+    if (r != ncclSuccess) return rccl_fail(api, "ncclAllGather", r);
+    return comm_issued(c, (hipStream_t)stream);
+}
+
 // {collectives issued, cross-stream waits inserted}: what the tests read to see the chain at work
 extern "C" int pc_rccl_comm_stats(void* comm, int64_t* issued, int64_t* chained) {
     if (!comm) return PC_EINVAL;
@@ -219,12 +258,31 @@ extern "C" int pc_rccl_comm_stats(void* comm, int64_t* issued, int64_t* chained)
     return PC_OK;
 }
 
+extern "C" int pc_exchange_adam_plan(const pc_exchange_plan* plan, float* param, float* grad, float* exp_avg, float* exp_avg_sq,
+                                     size_t n, int64_t* step_count, int64_t t, float* scalars, double lr, double beta1,
+                                     double beta2, double eps, void* stream) {
+    if (!param || !grad || !exp_avg || !exp_avg_sq || n == 0 || t < 0) return PC_EINVAL;
+    if (t == 0 && (!step_count || !scalars)) return PC_EINVAL;
+    size_t lo = 0, len = n;
+    const bool shard = plan && plan->shard_optimizer && (plan->world > 1 || plan->reduce_scatter_mean);
+    if (shard) {
+        if (plan->world < 1 || plan->rank < 0 || plan->rank >= plan->world || n % (size_t)plan->world) return PC_EINVAL;
+        if (!plan->reduce_scatter_mean || !plan->all_gather) return PC_EINVAL;
+        len = n / (size_t)plan->world;
+        lo = (size_t)plan->rank * len;
+        PC_TRY(plan->reduce_scatter_mean(plan->ctx, grad, len, stream));
+    } else if (plan && plan->all_reduce_mean) {
+        PC_TRY(plan->all_reduce_mean(plan->ctx, grad, n, stream));
+    }
+    if (t > 0) PC_TRY(pc_adam_step_at(param + lo, grad + lo, exp_avg + lo, exp_avg_sq + lo, len, step_count, t, lr, beta1, beta2, eps, stream));
+    else PC_TRY(pc_adam_step(param + lo, grad + lo, exp_avg + lo, exp_avg_sq + lo, len, step_count, scalars, lr, beta1, beta2, eps, stream));
+    if (shard) PC_TRY(plan->all_gather(plan->ctx, param, len, stream));
+    return PC_OK;
+}
+
 extern "C" int pc_exchange_adam(pc_exchange_fn exchange, void* exchange_ctx, float* param, float* grad, float* exp_avg,
                                 float* exp_avg_sq, size_t n, int64_t* step_count, int64_t t, float* scalars, double lr,
                                 double beta1, double beta2, double eps, void* stream) {
-    if (!param || !grad || !exp_avg || !exp_avg_sq || n == 0 || t < 0) return PC_EINVAL;
-    if (t == 0 && (!step_count || !scalars)) return PC_EINVAL;
-    if (exchange) PC_TRY(exchange(exchange_ctx, grad, n, stream));
-    if (t > 0) return pc_adam_step_at(param, grad, exp_avg, exp_avg_sq, n, step_count, t, lr, beta1, beta2, eps, stream);
-    return pc_adam_step(param, grad, exp_avg, exp_avg_sq, n, step_count, scalars, lr, beta1, beta2, eps, stream);
+    const pc_exchange_plan plan = {exchange, nullptr, nullptr, exchange_ctx, 0, 1, 0};
+    return pc_exchange_adam_plan(&plan, param, grad, exp_avg, exp_avg_sq, n, step_count, t, scalars, lr, beta1, beta2, eps, stream);
 }

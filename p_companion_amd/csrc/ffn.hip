@@ -14,6 +14,8 @@
 // BatchNorm statistics are per SEGMENT (= per reference FFN call), see pc_segments.
 #include "common.h"
 
+int pc_opt_bn_finalize_side();     // (gemm_tn.hip: pc_set_option)
+
 #define BN_EPS 1e-5f
 #define BN_MOMENTUM 0.1f
 
@@ -44,34 +46,63 @@ __device__ __forceinline__ void fold_partials(const float* p1, const float* p2, 
     __syncthreads();
 }
 
-// The same fold by 8 tile lanes per column (256-thread workgroups: 32 adjacent columns per tile row as above, four loads in
-// flight per lane).  The backward finalize runs on the side queue BESIDE the weight-gradient launches: a 1024-thread workgroup
-// needs a whole CU's worth of free wave slots and, since dW3 became one launch (round 4), found them only when that launch
-// drained (80-110 us of "duration" in the kernel trace: dW0, which waits for it, started that much later); four waves fit
-// anywhere.
-#define FINB_LANES 8
-__device__ __forceinline__ void fold_partials8(const float* p1, const float* p2, int t0, int t1, int j, int q,
-                                               double (*red)[FINB_LANES][FIN_COLS], double* o1, double* o2) {
-    double a[4] = {0.0, 0.0, 0.0, 0.0}, b[4] = {0.0, 0.0, 0.0, 0.0};
-    int t = t0 + q;
-    for (; t + 3 * FINB_LANES < t1; t += 4 * FINB_LANES) {
+// All segments in ONE pass with the loads in flight together (round 6).  The two folds above walk a segment's tiles in one or
+// two dependent chains per thread -- 11 round trips to L2 / HBM per segment, four segments one after the other: 12 us (forward)
+// and 12-32 us (backward, on the side queue) for 0.7 MB of partials, pure latency.  Here a thread takes every FIN_LANES-th tile
+// of the WHOLE tile range, eight tiles (sixteen loads) per batch before the first use, and adds each value to its segment's
+// accumulator by predicate (tiles never straddle segments: a tile's segment is three comparisons); one LDS exchange reduces the
+// lanes.  Fixed order: lane q adds its tiles ascending, the lanes are added ascending.  out[s][0..1] for s < PC_MAX_SEG in
+// the threads with q == s (every segment's finalize arithmetic then runs in its own thread).
+#define FOLD_BATCH 8
+__device__ __forceinline__ void fold_partials_all(const float* __restrict__ p1, const float* __restrict__ p2, const SegInfo& si,
+                                                  int j, int q, double (*red)[PC_MAX_SEG][FIN_LANES][FIN_COLS], double* o1,
+                                                  double* o2) {
+    double a[PC_MAX_SEG], b[PC_MAX_SEG];
 #pragma unroll
-        for (int u = 0; u < 4; u++) {
-            a[u] += (double)p1[(size_t)(t + u * FINB_LANES) * PC_H + j];
-            b[u] += (double)p2[(size_t)(t + u * FINB_LANES) * PC_H + j];
+    for (int s = 0; s < PC_MAX_SEG; s++) { a[s] = 0.0; b[s] = 0.0; }
+    const int t_end = si.tile0[si.nseg];
+    const int b1 = si.nseg > 1 ? si.tile0[1] : t_end, b2 = si.nseg > 2 ? si.tile0[2] : t_end, b3 = si.nseg > 3 ? si.tile0[3] : t_end;
+    int t = si.tile0[0] + q;
+    for (; t + (FOLD_BATCH - 1) * FIN_LANES < t_end; t += FOLD_BATCH * FIN_LANES) {
+        float x[FOLD_BATCH], y[FOLD_BATCH];
+#pragma unroll
+        for (int u = 0; u < FOLD_BATCH; u++) {
+            x[u] = p1[(size_t)(t + u * FIN_LANES) * PC_H + j];
+            y[u] = p2[(size_t)(t + u * FIN_LANES) * PC_H + j];
+        }
+#pragma unroll
+        for (int u = 0; u < FOLD_BATCH; u++) {
+            const int tt = t + u * FIN_LANES;
+            const int sg = (tt >= b1) + (tt >= b2) + (tt >= b3);
+#pragma unroll
+            for (int s = 0; s < PC_MAX_SEG; s++) { a[s] += sg == s ? (double)x[u] : 0.0; b[s] += sg == s ? (double)y[u] : 0.0; }
         }
     }
-    for (; t < t1; t += FINB_LANES) { a[0] += (double)p1[(size_t)t * PC_H + j]; b[0] += (double)p2[(size_t)t * PC_H + j]; }
-    red[0][q][threadIdx.x] = (a[0] + a[1]) + (a[2] + a[3]);
-    red[1][q][threadIdx.x] = (b[0] + b[1]) + (b[2] + b[3]);
-    __syncthreads();
-    if (q == 0) {
-        double s1 = 0.0, s2 = 0.0;
+    {   // the tail: up to FOLD_BATCH - 1 tiles per lane, loaded together as well
+        float x[FOLD_BATCH], y[FOLD_BATCH];
 #pragma unroll
-        for (int i = 0; i < FINB_LANES; i++) { s1 += red[0][i][threadIdx.x]; s2 += red[1][i][threadIdx.x]; }
+        for (int u = 0; u < FOLD_BATCH - 1; u++) {
+            const int tt = t + u * FIN_LANES;
+            x[u] = tt < t_end ? p1[(size_t)tt * PC_H + j] : 0.f;
+            y[u] = tt < t_end ? p2[(size_t)tt * PC_H + j] : 0.f;
+        }
+#pragma unroll
+        for (int u = 0; u < FOLD_BATCH - 1; u++) {
+            const int tt = t + u * FIN_LANES;
+            const int sg = (tt >= b1) + (tt >= b2) + (tt >= b3);
+#pragma unroll
+            for (int s = 0; s < PC_MAX_SEG; s++) { a[s] += sg == s ? (double)x[u] : 0.0; b[s] += sg == s ? (double)y[u] : 0.0; }
+        }
+    }
+#pragma unroll
+    for (int s = 0; s < PC_MAX_SEG; s++) { red[0][s][q][threadIdx.x] = a[s]; red[1][s][q][threadIdx.x] = b[s]; }
+    __syncthreads();
+    if (q < PC_MAX_SEG) {
+        double s1 = 0.0, s2 = 0.0;
+#pragma unroll 8
+        for (int i = 0; i < FIN_LANES; i++) { s1 += red[0][q][i][threadIdx.x]; s2 += red[1][q][i][threadIdx.x]; }
         *o1 = s1; *o2 = s2;
     }
-    __syncthreads();
 }
 
 // Cross-replica BatchNorm: the per-segment sums of THIS replica, in fp64, in the
@@ -95,25 +126,25 @@ __global__ __launch_bounds__(FIN_COLS * FIN_LANES) void bn_fold_kernel(const flo
 // gsum: NULL = statistics of this replica (fold the per-tile partials here); else the all-reduced exchange buffer.
 // (Round 4 tried the four segments side by side in 32-64 narrower workgroups -- 4-8 columns each: 12.6 -> 9.0 us at configs[1], but
 // a wave then touches 16 tile rows per load instead of 2, and beside configs[4]'s loader kernels (random reads over 114 GB: the
-// TLB is theirs) every one of those is a miss: 115-144 us there under the profiler.  Back to 32 adjacent columns per tile row.)
+// TLB is theirs) every one of those is a miss: 115-144 us there under the profiler.  Back to 32 adjacent columns per tile row.
+// Round 6: the same 32 columns x 32 tile lanes, all segments in one pass with sixteen loads in flight per thread
+// (fold_partials_all); thread (column, q = s) finalizes segment s, the running statistics are chained in segment order.)
 __global__ __launch_bounds__(FIN_COLS * FIN_LANES) void bn_finalize_fwd_kernel(
     const float* psum, const float* psq, SegInfo si, const double* gsum, const float* gamma, const float* beta,
     float* running_mean, float* running_var, int64_t* nbt, int update_running, float* mean_o, float* invstd_o,
     float* scale_o, float* shift_o) {
-    __shared__ double red[2][FIN_LANES][FIN_COLS];
+    __shared__ double red[2][PC_MAX_SEG][FIN_LANES][FIN_COLS];
+    __shared__ float seg_mean[PC_MAX_SEG][FIN_COLS], seg_unb[PC_MAX_SEG][FIN_COLS];
+    __shared__ int seg_live[PC_MAX_SEG][FIN_COLS];
     const int j = blockIdx.x * FIN_COLS + threadIdx.x, q = threadIdx.y;
-    float rm = 0.f, rv = 0.f;
-    if (q == 0 && update_running) { rm = running_mean[j]; rv = running_var[j]; }
-    int nseen = 0;
-    for (int s = 0; s < si.nseg; s++) {
-        double n = si.count[s];                               // logical rows (a weighted row counts wmult times)
-        double a = 0.0, b = 0.0;
-        if (gsum) {
-            a = gsum[(2 * s) * PC_H + j]; b = gsum[(2 * s + 1) * PC_H + j]; n = gsum[2 * PC_MAX_SEG * PC_H + s];
-        } else {
-            fold_partials(psum, psq, si.tile0[s], si.tile0[s + 1], j, q, red, &a, &b);
-        }
-        if (q == 0 && n > 0) {
+    double a = 0.0, b = 0.0;
+    if (!gsum) fold_partials_all(psum, psq, si, j, q, red, &a, &b);
+    if (q < PC_MAX_SEG) {
+        const int s = q;
+        double n = s < si.nseg ? (double)si.count[s] : 0.0;   // logical rows (a weighted row counts wmult times)
+        if (gsum && s < si.nseg) { a = gsum[(2 * s) * PC_H + j]; b = gsum[(2 * s + 1) * PC_H + j]; n = gsum[2 * PC_MAX_SEG * PC_H + s]; }
+        int live = 0;
+        if (s < si.nseg && n > 0) {
             const double m = a / n;
             double var = b / n - m * m;
             if (var < 0.0) var = 0.0;
@@ -124,15 +155,23 @@ __global__ __launch_bounds__(FIN_COLS * FIN_LANES) void bn_finalize_fwd_kernel(
             invstd_o[s * PC_H + j] = is;
             scale_o[s * PC_H + j] = sc;
             shift_o[s * PC_H + j] = beta[j] - mf * sc;
-            if (update_running) {
-                const float unb = n > 1 ? (float)(var * (n / (n - 1))) : vf;
-                rm = BN_MOMENTUM * mf + (1.0f - BN_MOMENTUM) * rm;
-                rv = BN_MOMENTUM * unb + (1.0f - BN_MOMENTUM) * rv;
-            }
+            seg_mean[s][threadIdx.x] = mf;
+            seg_unb[s][threadIdx.x] = n > 1 ? (float)(var * (n / (n - 1))) : vf;
+            live = 1;
+        }
+        seg_live[s][threadIdx.x] = live;
+    }
+    __syncthreads();
+    if (q == 0 && update_running) {
+        // nn.BatchNorm1d updates its buffers once per CALL: the segments in call order (product2vec.py:132-134)
+        float rm = running_mean[j], rv = running_var[j];
+        int nseen = 0;
+        for (int s = 0; s < si.nseg; s++) {
+            if (!seg_live[s][threadIdx.x]) continue;
+            rm = BN_MOMENTUM * seg_mean[s][threadIdx.x] + (1.0f - BN_MOMENTUM) * rm;
+            rv = BN_MOMENTUM * seg_unb[s][threadIdx.x] + (1.0f - BN_MOMENTUM) * rv;
             nseen++;
         }
-    }
-    if (q == 0 && update_running) {
         running_mean[j] = rm;
         running_var[j] = rv;
         if (j == 0 && nbt) *nbt += nseen;
@@ -149,23 +188,27 @@ __global__ void bn_eval_coeff_kernel(const float* gamma, const float* beta, cons
 }
 
 // per-tile (sum dz1, sum dz1*h0) -> dgamma, dbeta (+ per-segment means c1 = dbeta_s/n, c2 = dgamma_s/n)
-__global__ __launch_bounds__(FIN_COLS * FINB_LANES) void bn_finalize_bwd_kernel(
+// (round 6: one pass over all segments like the forward finalize, 32 tile lanes, on the step's own queue -- 3 us between dZ1 and
+// dW3 instead of 12-32 us on the side queue plus the two cross-queue hops, ~6.5 us each on the main queue)
+__global__ __launch_bounds__(FIN_COLS * FIN_LANES) void bn_finalize_bwd_kernel(
     const float* psum, const float* pdot, SegInfo si, const double* lsum, const double* gsum, const float* mean,
     const float* invstd, float* dgamma, float* dbeta, int accumulate, float* c1, float* c2) {
-    __shared__ double red[2][FINB_LANES][FIN_COLS];
+    __shared__ double red[2][PC_MAX_SEG][FIN_LANES][FIN_COLS];
+    __shared__ double seg_g[PC_MAX_SEG][FIN_COLS], seg_b[PC_MAX_SEG][FIN_COLS];
     const int j = blockIdx.x * FIN_COLS + threadIdx.x, q = threadIdx.y;
-    double tg = 0.0, tb = 0.0;
-    for (int s = 0; s < si.nseg; s++) {
-        double n = si.count[s];                               // logical rows (a weighted row counts wmult times)
-        double a = 0.0, b = 0.0;
-        if (lsum) { a = lsum[(2 * s) * PC_H + j]; b = lsum[(2 * s + 1) * PC_H + j]; }
-        else fold_partials8(psum, pdot, si.tile0[s], si.tile0[s + 1], j, q, red, &a, &b);
-        if (q == 0) {
+    double a = 0.0, b = 0.0;
+    if (!lsum) fold_partials_all(psum, pdot, si, j, q, red, &a, &b);
+    if (q < PC_MAX_SEG) {
+        const int s = q;
+        double tg = 0.0, tb = 0.0;
+        if (s < si.nseg) {
+            double n = si.count[s];                           // logical rows (a weighted row counts wmult times)
+            if (lsum) { a = lsum[(2 * s) * PC_H + j]; b = lsum[(2 * s + 1) * PC_H + j]; }
             // the tiles carry the raw moment sum dz1*h0: sum dz1*xhat = invstd * (sum dz1*h0 - mean * sum dz1)
             const double is = (double)invstd[s * PC_H + j], mu = (double)mean[s * PC_H + j];
             b = is * (b - mu * a);
-            tb += a;                                          // dbeta / dgamma: this replica's rows
-            tg += b;
+            tb = a;                                           // dbeta / dgamma: this replica's rows
+            tg = b;
             double ga = a, gb = b;                            // the BN-backward means run over ALL replicas' rows
             if (gsum) {
                 ga = gsum[(2 * s) * PC_H + j];
@@ -175,8 +218,13 @@ __global__ __launch_bounds__(FIN_COLS * FINB_LANES) void bn_finalize_bwd_kernel(
             c1[s * PC_H + j] = n > 0 ? (float)(ga / n) : 0.f;
             c2[s * PC_H + j] = n > 0 ? (float)(gb / n) : 0.f;
         }
+        seg_g[s][threadIdx.x] = tg;
+        seg_b[s][threadIdx.x] = tb;
     }
+    __syncthreads();
     if (q == 0) {
+        double tg = 0.0, tb = 0.0;
+        for (int s = 0; s < si.nseg; s++) { tg += seg_g[s][threadIdx.x]; tb += seg_b[s][threadIdx.x]; }     // segment order, as before
         dgamma[j] = accumulate ? dgamma[j] + (float)tg : (float)tg;
         dbeta[j] = accumulate ? dbeta[j] + (float)tb : (float)tb;
     }
@@ -458,12 +506,21 @@ int ffn_backward_part1(const pc_p2v_tensors* p, const pc_p2v_tensors* g, const f
     b2.stats = NT_STAT_BNBWD; b2.stat_sum = w.stat_a; b2.stat_aux = w.stat_b;
     PC_TRY(launch_gemm_nt(b2, st));
     if (df->fork && !local_sums) {
-        // the BatchNorm-backward finalize (8 workgroups, 12 us; only dW0 reads c1 / c2) on the side queue, beside dW3
-        PC_TRY(pc_fork_begin(df->fork, 1, st));
-        PC_LAUNCH(bn_finalize_bwd_kernel, dim3(PC_H / FIN_COLS), dim3(FIN_COLS, FINB_LANES), 0, df->fork->side, w.stat_a, w.stat_b, si,
-                  nullptr, nullptr, sv->bn_mean, sv->bn_invstd, g->gamma, g->beta, accumulate, w.c1, w.c2);
-        PC_TRY(pc_launch_status());
-        df->bn_finalized = 1;
+        // the BatchNorm-backward finalize (only dW0 reads c1 / c2).  Rounds 3-5: on the side queue beside dW3 -- the fork and the
+        // join each cost the main queue ~6.5 us (profiles/r06a_step_timeline.md) and the 8-workgroup kernel took 12-32 us there.
+        // Round 6: 3 us on the step's own queue, between dZ1 and dW3 (pc_get_option(PC_OPT_BN_FINALIZE_SIDE) = 1: the old placement)
+        if (pc_opt_bn_finalize_side()) {
+            PC_TRY(pc_fork_begin(df->fork, 1, st));
+            PC_LAUNCH(bn_finalize_bwd_kernel, dim3(PC_H / FIN_COLS), dim3(FIN_COLS, FIN_LANES), 0, df->fork->side, w.stat_a, w.stat_b, si,
+                      nullptr, nullptr, sv->bn_mean, sv->bn_invstd, g->gamma, g->beta, accumulate, w.c1, w.c2);
+            PC_TRY(pc_launch_status());
+            df->bn_finalized = 1;
+        } else {
+            PC_LAUNCH(bn_finalize_bwd_kernel, dim3(PC_H / FIN_COLS), dim3(FIN_COLS, FIN_LANES), 0, st, w.stat_a, w.stat_b, si,
+                      nullptr, nullptr, sv->bn_mean, sv->bn_invstd, g->gamma, g->beta, accumulate, w.c1, w.c2);
+            PC_TRY(pc_launch_status());
+            df->bn_finalized = 2;                            // done, on the step's queue: nothing to join
+        }
     }
 
     // dW3 = dZ2^T A1, db3 (A1 as the forward saved it; without the optional buffer it is recomputed from H0 in the loader:
@@ -509,9 +566,9 @@ int ffn_backward_part2(const pc_p2v_tensors* g, const float* table, const int32_
     FfnWs w = ffn_ws_layout(ws, rows);
     if (defer && defer->bn_finalized) {
         if (local_sums || global_sums) return PC_EINVAL;
-        PC_TRY(pc_fork_join(defer->fork, 0, st));              // part 1 ran the finalize on the side queue
+        if (defer->bn_finalized == 1) PC_TRY(pc_fork_join(defer->fork, 0, st));      // part 1 ran the finalize on the side queue
     } else {
-        PC_LAUNCH(bn_finalize_bwd_kernel, dim3(PC_H / FIN_COLS), dim3(FIN_COLS, FINB_LANES), 0, st, w.stat_a, w.stat_b, si, local_sums,
+        PC_LAUNCH(bn_finalize_bwd_kernel, dim3(PC_H / FIN_COLS), dim3(FIN_COLS, FIN_LANES), 0, st, w.stat_a, w.stat_b, si, local_sums,
                   global_sums, sv->bn_mean, sv->bn_invstd, g->gamma, g->beta, accumulate, w.c1, w.c2);
         PC_TRY(pc_launch_status());
     }

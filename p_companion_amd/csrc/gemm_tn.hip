@@ -641,17 +641,29 @@ ForkSlot g_fork_slots[32];
 std::mutex g_fork_mu;
 std::atomic<int> g_opt_side_queue{1};
 std::atomic<int> g_opt_sorted_tables{1};
+std::atomic<int> g_opt_bn_finalize_side{0};
+std::atomic<int>* opt_slot(int option) {
+    switch (option) {
+        case PC_OPT_SIDE_QUEUE: return &g_opt_side_queue;
+        case PC_OPT_SORTED_TABLE_GRADIENTS: return &g_opt_sorted_tables;
+        case PC_OPT_BN_FINALIZE_SIDE: return &g_opt_bn_finalize_side;
+        default: return nullptr;
+    }
+}
 }
 int pc_opt_sorted_tables() { return g_opt_sorted_tables.load(std::memory_order_relaxed); }
+int pc_opt_bn_finalize_side() { return g_opt_bn_finalize_side.load(std::memory_order_relaxed); }
 
 extern "C" int pc_set_option(int option, int value) {
-    if ((option != PC_OPT_SIDE_QUEUE && option != PC_OPT_SORTED_TABLE_GRADIENTS) || (value != 0 && value != 1)) return PC_EINVAL;
-    (option == PC_OPT_SIDE_QUEUE ? g_opt_side_queue : g_opt_sorted_tables).store(value, std::memory_order_relaxed);
+    std::atomic<int>* o = opt_slot(option);
+    if (!o || (value != 0 && value != 1)) return PC_EINVAL;
+    o->store(value, std::memory_order_relaxed);
     return PC_OK;
 }
 extern "C" int pc_get_option(int option, int* value) {
-    if ((option != PC_OPT_SIDE_QUEUE && option != PC_OPT_SORTED_TABLE_GRADIENTS) || !value) return PC_EINVAL;
-    *value = (option == PC_OPT_SIDE_QUEUE ? g_opt_side_queue : g_opt_sorted_tables).load(std::memory_order_relaxed);
+    std::atomic<int>* o = opt_slot(option);
+    if (!o || !value) return PC_EINVAL;
+    *value = o->load(std::memory_order_relaxed);
     return PC_OK;
 }
 extern "C" int pc_release_device_state(void) {

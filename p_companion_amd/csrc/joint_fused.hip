@@ -2751,10 +2751,10 @@ extern "C" int pc_joint_train_epoch(const pc_joint_tensors* p, const pc_joint_te
 // step's stream, then Adam over the flat buffers.  The gradient exchange sits where train.py:46-48 has nothing
 // (loss.backward(); optimizer.step()): issued from this call, between two kernel launches, not from a host-language hook per
 // step (the step is ~2 kernel latencies long).
-extern "C" int pc_joint_train_epoch_dp(const pc_joint_tensors* p, const pc_joint_tensors* g, float* param_flat, float* grad_flat,
+extern "C" int pc_joint_train_epoch_plan(const pc_joint_tensors* p, const pc_joint_tensors* g, float* param_flat, float* grad_flat,
                                        float* exp_avg_flat, float* exp_avg_sq_flat, size_t n_flat, int64_t* step_count,
                                        int64_t t_first, float* adam_scalars, double lr, double beta1, double beta2, double eps,
-                                       pc_exchange_fn exchange, void* exchange_ctx, const int32_t* pairs, int64_t n_pairs,
+                                       const pc_exchange_plan* plan, const int32_t* pairs, int64_t n_pairs,
                                        const float* features, const int32_t* type_idx, int n_types, uint64_t seed,
                                        uint64_t first_step, int32_t* query_idx, int32_t* query_types, int32_t* pos_types,
                                        int32_t* neg_types, float* pos_items, float* neg_items, int B, int drop_last, int T, int K,
@@ -2782,9 +2782,25 @@ extern "C" int pc_joint_train_epoch_dp(const pc_joint_tensors* p, const pc_joint
         PC_TRY(fused_step_impl(&pl, g, nullptr, nullptr, nullptr, lr, beta1, beta2, eps, &src, query_idx, query_types, pos_types,
                                neg_types, pos_items, neg_items, b, T, K, num_products, margin, alpha, losses_out + 3 * i, topk,
                                bad_count, ws, ws_bytes, stream));
-        PC_TRY(pc_exchange_adam(exchange, exchange_ctx, param_flat, grad_flat, exp_avg_flat, exp_avg_sq_flat, n_flat, step_count,
-                                t_first > 0 ? t_first + i : 0, adam_scalars, lr, beta1, beta2, eps, stream));
+        PC_TRY(pc_exchange_adam_plan(plan, param_flat, grad_flat, exp_avg_flat, exp_avg_sq_flat, n_flat, step_count,
+                                     t_first > 0 ? t_first + i : 0, adam_scalars, lr, beta1, beta2, eps, stream));
         done += b;
     }
     return PC_OK;
+}
+
+extern "C" int pc_joint_train_epoch_dp(const pc_joint_tensors* p, const pc_joint_tensors* g, float* param_flat, float* grad_flat,
+                                       float* exp_avg_flat, float* exp_avg_sq_flat, size_t n_flat, int64_t* step_count,
+                                       int64_t t_first, float* adam_scalars, double lr, double beta1, double beta2, double eps,
+                                       pc_exchange_fn exchange, void* exchange_ctx, const int32_t* pairs, int64_t n_pairs,
+                                       const float* features, const int32_t* type_idx, int n_types, uint64_t seed,
+                                       uint64_t first_step, int32_t* query_idx, int32_t* query_types, int32_t* pos_types,
+                                       int32_t* neg_types, float* pos_items, float* neg_items, int B, int drop_last, int T, int K,
+                                       int num_products, float margin, float alpha, float* losses_out, int32_t* topk,
+                                       int32_t* bad_count, void* ws, size_t ws_bytes, void* stream) {
+    const pc_exchange_plan plan = {exchange, nullptr, nullptr, exchange_ctx, 0, 1, 0};
+    return pc_joint_train_epoch_plan(p, g, param_flat, grad_flat, exp_avg_flat, exp_avg_sq_flat, n_flat, step_count, t_first,
+                                     adam_scalars, lr, beta1, beta2, eps, &plan, pairs, n_pairs, features, type_idx, n_types, seed,
+                                     first_step, query_idx, query_types, pos_types, neg_types, pos_items, neg_items, B, drop_last, T,
+                                     K, num_products, margin, alpha, losses_out, topk, bad_count, ws, ws_bytes, stream);
 }

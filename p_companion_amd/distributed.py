@@ -43,8 +43,21 @@ def init_from_env(device_type="cuda"):
         # default half hour)
         import datetime
         dist.init_process_group(backend=backend, rank=rank, world_size=world,
-                                timeout=datetime.timedelta(seconds=int(os.environ.get("PC_DIST_TIMEOUT_S", "600"))))
+                                timeout=datetime.timedelta(seconds=group_timeout_s()))
     return rank, world, local
+
+
+def group_timeout_s():
+    """Collective timeout of the process group (PC_DIST_TIMEOUT_S, default 300 s): a rank that died inside a step ends the
+    job well inside a 10-minute harness limit instead of parking its peers for the backend's half hour."""
+    return int(os.environ.get("PC_DIST_TIMEOUT_S", "300"))
+
+
+def probe_timeout_s():
+    """Host deadline of the native communicator's construction + probe (PC_DIST_PROBE_TIMEOUT_S, default 90 s, never above the
+    group's timeout): first contact with a new node must resolve -- native exchange, torch.distributed fallback, or exit
+    code 75 -- long before the harness gives up on the job."""
+    return float(min(int(os.environ.get("PC_DIST_PROBE_TIMEOUT_S", "90")), group_timeout_s()))
 
 
 def all_reduce_mean_(flat, world):
@@ -71,11 +84,17 @@ class _TorchCollectives:
         return t
 
 
-def _run_with_deadline(fn, seconds, what, rank):
+class _Expired(Exception):
+    pass
+
+
+def _run_with_deadline(fn, seconds, what, rank, on_expire="exit"):
     """fn() on a helper thread, waited for at most `seconds`.  ncclCommInitRank and the first collectives are host-blocking
     rendezvous: a peer that died before joining leaves this rank inside them for good, and nothing in-process can unwind a
-    thread parked in a collective library.  So on expiry the PROCESS ends with a non-zero code (no re-exec, no retry): the
-    launcher then ends the job, which is the only recovery an asymmetric failure has.  Exceptions of fn are re-raised here."""
+    thread parked in a collective library.  on_expire="exit": the PROCESS ends with code 75 (no re-exec, no retry): the
+    launcher then ends the job, which is the only recovery an asymmetric failure has.  on_expire="abandon": _Expired is
+    raised and the helper thread is left behind (a daemon: it does not keep the process alive) -- for a step whose failure
+    the ranks can still agree on over another communicator.  Exceptions of fn are re-raised here."""
     import threading
     box = {}
 
@@ -93,12 +112,19 @@ def _run_with_deadline(fn, seconds, what, rank):
     th.join(seconds)
     if th.is_alive():
         import sys
-        print(f"[p_companion_amd] rank {rank}: {what} did not return within {seconds:.0f} s (PC_DIST_TIMEOUT_S): a peer has "
-              "most likely failed before joining; ending this process so that the launcher ends the job", file=sys.stderr, flush=True)
+        if on_expire == "abandon":
+            print(f"[p_companion_amd] rank {rank}: {what} did not return within {seconds:.0f} s; leaving it behind",
+                  file=sys.stderr, flush=True)
+            raise _Expired(what)
+        print(f"[p_companion_amd] rank {rank}: {what} did not return within {seconds:.0f} s: a peer has most likely failed "
+              "before joining; ending this process (exit code 75) so that the launcher ends the job", file=sys.stderr, flush=True)
         os._exit(75)
     if "err" in box:
         raise box["err"]
     return box.get("res")
+
+
+last_probe = None          # what the latest make_exchange(kind='auto'/'rccl') found: {"native", "reason", "seconds"}
 
 
 def make_exchange(world, rank=None, group=None, kind="auto", device=None):
@@ -118,12 +144,15 @@ def make_exchange(world, rank=None, group=None, kind="auto", device=None):
     the SAME object to ShardedFeatureTable(exchange=...) and to the optimizer (bench.py does).  torch's communicator is then
     used only where the device is drained: construction, capacity agreement, the barriers around a timed region.
 
-    After construction 'rccl' is verified -- an all-reduce of a known vector on the current stream and an all-to-all of known
-    slices on a side stream, i.e. the step's own pattern -- under a host deadline (_run_with_deadline, PC_DIST_TIMEOUT_S).
-    What falls back: a failure EVERY rank sees alike (RCCL missing, an init error on all ranks, a wrong probe result): agreed
-    by a MIN all-reduce over the process group, every rank closes its communicator and takes 'callback'.  What cannot: a
-    failure on SOME ranks leaves the others inside the rendezvous -- they end at the deadline with exit code 75 and the
-    launcher ends the job."""
+    After construction 'rccl' is verified -- an all-reduce of a known vector and an all-to-all of known slices on two side
+    streams, i.e. the step's own pattern -- under a host deadline (probe_timeout_s(): 90 s).  The outcome is agreed by a
+    MIN all-reduce over the process group (itself under a deadline):
+      * every rank succeeded: the native exchange;
+      * a failure or a TIME-OUT on any rank (RCCL missing, an init error, a wrong probe result, a rendezvous that never
+        completes on this node): every rank drops its communicator -- one whose construction is still parked in the
+        rendezvous is left behind on its daemon thread, its streams never touched again -- and takes 'callback';
+      * the agreement itself does not complete (a peer is gone): exit code 75, the launcher ends the job.
+    `last_probe` (module attribute) records what happened for the bench line: {"native": bool, "reason": str, "seconds": float}."""
     if not collectives_on(world):
         return None
     from . import ops
@@ -141,7 +170,31 @@ def make_exchange(world, rank=None, group=None, kind="auto", device=None):
             dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
             t.mul_(1.0 / world)
         fn.tensors = {}
-        ex = ops.CallbackExchange(fn, kind=f"torch.distributed.all_reduce ({backend}) behind a Python trampoline")
+
+        def known(ptr, n):
+            t = fn.tensors.get(ptr)
+            if t is None or t.numel() != n:
+                raise RuntimeError("callback exchange: unknown flat buffer %#x (register it with exchange.register(t))" % ptr)
+            return t
+
+        def rs(ptr, n_per, stream):
+            # the sharded optimizer's first half: slice `rank` must hold the mean (the other slices are unspecified) -- gloo has
+            # no reduce-scatter, so the whole buffer is reduced; NCCL's reduce_scatter_tensor where the backend offers it
+            t = known(ptr, n_per * world)
+            if backend == "nccl":
+                own = t[rank * n_per:(rank + 1) * n_per]
+                dist.reduce_scatter_tensor(own, t, op=dist.ReduceOp.SUM, group=group)
+                own.mul_(1.0 / world)
+            else:
+                dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+                t.mul_(1.0 / world)
+
+        def ag(ptr, n_per, stream):
+            t = known(ptr, n_per * world)
+            dist.all_gather([t[r * n_per:(r + 1) * n_per] for r in range(world)], t[rank * n_per:(rank + 1) * n_per].clone(), group=group)
+
+        ex = ops.CallbackExchange(fn, kind=f"torch.distributed.all_reduce ({backend}) behind a Python trampoline",
+                                  reduce_scatter=rs, all_gather=ag, rank=rank, world=world)
         ex.register = lambda t: fn.tensors.__setitem__(t.data_ptr(), t)
         tc = _TorchCollectives(group)
         ex.all_to_all, ex.all_reduce_sum_f64_ = tc.all_to_all, tc.all_reduce_sum_f64_
@@ -156,8 +209,11 @@ def make_exchange(world, rank=None, group=None, kind="auto", device=None):
     if want != "rccl":
         raise ValueError("make_exchange: kind 'auto', 'rccl' or 'callback'")
     ok, ex = 1, None
-    deadline = float(os.environ.get("PC_DIST_TIMEOUT_S", "600"))
+    deadline = probe_timeout_s()
     holder = {}
+    import time as _time
+    t_probe = _time.perf_counter()
+    reason = "ok"
 
     def build_and_probe():
         id_t = torch.zeros(128, dtype=torch.uint8, device=dev if backend == "nccl" else "cpu")
@@ -168,32 +224,52 @@ def make_exchange(world, rank=None, group=None, kind="auto", device=None):
         probe = torch.full((1024,), float(rank + 1), dtype=torch.float32, device=dev)
         send = (torch.arange(world * 256, device=dev, dtype=torch.int32) // 256 + 1000 * rank).contiguous()   # slice p: 1000 rank + p
         recv = torch.empty_like(send)
-        side = torch.cuda.Stream(dev)
+        # two SIDE streams stand in for the step's and the loader's: if a collective never completes, the streams the job
+        # goes on to use (the default stream included) hold nothing of the probe's
+        main_s, side = torch.cuda.Stream(dev), torch.cuda.Stream(dev)
+        main_s.wait_stream(torch.cuda.current_stream(dev))
         side.wait_stream(torch.cuda.current_stream(dev))
-        e.all_reduce_mean_(probe)                                # the step's stream
+        with torch.cuda.stream(main_s):
+            e.all_reduce_mean_(probe)                            # "the step's stream"
         with torch.cuda.stream(side):
-            e.all_to_all(send, recv)                             # the loader's stream: chained behind the all-reduce by the library
-        e.all_reduce_mean_(probe)                                # ... and this one behind the all-to-all
-        torch.cuda.current_stream(dev).wait_stream(side)
-        torch.cuda.synchronize()
+            e.all_to_all(send, recv)                             # "the loader's stream": chained behind the all-reduce by the library
+        with torch.cuda.stream(main_s):
+            e.all_reduce_mean_(probe)                            # ... and this one behind the all-to-all
+        main_s.synchronize()
+        side.synchronize()
         want_recv = (1000 * (torch.arange(world * 256, device=dev, dtype=torch.int32) // 256) + rank)
         good = torch.allclose(probe, torch.full_like(probe, (world + 1) / 2.0), rtol=1e-6, atol=0) and torch.equal(recv, want_recv)
         return int(bool(good) and (world == 1 or e.stats()["chained"] >= 2))
 
+    abandoned = False
     try:
-        ok = _run_with_deadline(build_and_probe, deadline, "the native RCCL exchange's construction and probe", rank)
+        ok = _run_with_deadline(build_and_probe, deadline, "the native RCCL exchange's construction and probe", rank, on_expire="abandon")
+        if not ok:
+            reason = "probe returned wrong values"
+    except _Expired:
+        ok, abandoned, reason = 0, True, f"construction / probe did not complete within {deadline:.0f} s on rank {rank}"
     except Exception as e:                                   # noqa: BLE001 -- any failure means: the host-driven exchange
         import sys
         print(f"[p_companion_amd] rank {rank}: native RCCL exchange unavailable ({e}); using torch.distributed", file=sys.stderr, flush=True)
-        ok = 0
+        ok, reason = 0, f"{type(e).__name__}: {e}"[:200]
     ex = holder.get("ex")
-    flag = torch.tensor([ok], dtype=torch.int32, device=dev if backend == "nccl" else "cpu")
-    dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=group)
-    if int(flag.item()) == 1:
+
+    def agree():
+        flag = torch.tensor([ok], dtype=torch.int32, device=dev if backend == "nccl" else "cpu")
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=group)
+        return int(flag.item())
+
+    agreed = _run_with_deadline(agree, max(deadline, 30.0), "the ranks' agreement on the exchange kind", rank)
+    global last_probe
+    if agreed == 1:
         ex.register = lambda t: None
         ex.native = True
+        last_probe = {"native": True, "reason": "ok", "seconds": round(_time.perf_counter() - t_probe, 2)}
         return ex
-    if ex is not None:                                       # built here, failed elsewhere (or its probe failed): not left behind
+    if ok and reason == "ok":
+        reason = "failed on another rank"
+    last_probe = {"native": False, "reason": reason, "seconds": round(_time.perf_counter() - t_probe, 2)}
+    if ex is not None and not abandoned:                     # built here, failed elsewhere (or its probe failed): not left behind
         try:
             ex.close()
         except Exception:                                    # noqa: BLE001
@@ -261,6 +337,8 @@ class ShardedFeatureTable:
         all-reduced (MAX) over the group once, at construction time (one tiny host-visible collective)."""
         capacity = int(capacity)
         if collectives_on(self.world) and dist.is_initialized():
+            if getattr(self.collectives, "native", False) and self.local.is_cuda:
+                torch.cuda.synchronize(self.local.device)        # torch's communicator only on a drained device (make_exchange)
             dev = self.local.device if dist.get_backend(self.group) != "gloo" else torch.device("cpu")
             t = torch.tensor([capacity], dtype=torch.int64, device=dev)
             dist.all_reduce(t, op=dist.ReduceOp.MAX, group=self.group)
@@ -270,6 +348,11 @@ class ShardedFeatureTable:
 
     def _buffers(self, n_ids, dev):
         if self.capacity is None:
+            if getattr(self.collectives, "native", False):
+                # agree_capacity is a collective on TORCH's communicator; here it would run from the loader's side stream with
+                # the library's collectives possibly in flight (two communicators, two launch orders: make_exchange's docstring)
+                raise ValueError("ShardedFeatureTable(exchange=<native>): pass `capacity`, or let SimilarityIndexLoader agree it "
+                                 "at construction (before the first step) -- not lazily inside a lookup")
             self.agree_capacity(self.capacity_for(n_ids, self.world))
         if self._bufs is None or self._bufs["send_ids"].device != dev:
             G, C = self.world, self.capacity
@@ -327,6 +410,9 @@ class ShardedFeatureTable:
                                "lookup: construct ShardedFeatureTable with a larger `capacity`")
 
     def lookup(self, ids):
+        if getattr(self.collectives, "native", False):
+            raise ValueError("ShardedFeatureTable.lookup (variable splits, host read-backs) runs on torch.distributed's "
+                             "communicator; with the native exchange use lookup_batch (constant shapes, the library's communicator)")
         dev = ids.device
         flat = ids.reshape(-1).to(torch.int64)
         valid = flat >= 0

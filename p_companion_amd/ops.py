@@ -308,9 +308,26 @@ def adam_step_at(param, grad, exp_avg, exp_avg_sq, step_count, t, lr=1e-3, betas
 EXCHANGE_FN = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p)
 
 
+class ExchangePlan(ctypes.Structure):
+    """pc_exchange_plan (ABI 8): the plain exchange (all_reduce_mean) and the two halves of the sharded optimizer's."""
+    _fields_ = [("all_reduce_mean", ctypes.c_void_p), ("reduce_scatter_mean", ctypes.c_void_p), ("all_gather", ctypes.c_void_p),
+                ("ctx", ctypes.c_void_p), ("rank", ctypes.c_int), ("world", ctypes.c_int), ("shard_optimizer", ctypes.c_int)]
+
+
 class Exchange:
     fn = None       # ctypes.c_void_p: address of a pc_exchange_fn
     ctx = None      # ctypes.c_void_p
+    rs_fn = ag_fn = None      # ctypes.c_void_p: addresses of the pc_shard_collective_fn pair (None: no sharded form)
+    rank, world = 0, 1
+
+    def plan(self, shard=False):
+        """The pc_exchange_plan of this exchange (kept alive by the caller for the duration of the foreign call).
+        shard=True: reduce-scatter -> Adam on this rank's slice -> all-gather (needs the sharded pair)."""
+        if shard and (self.rs_fn is None or self.ag_fn is None):
+            raise ValueError("this exchange has no reduce-scatter / all-gather pair")
+        val = lambda f: f.value if f is not None else None
+        return ExchangePlan(val(self.fn), val(self.rs_fn), val(self.ag_fn), val(self.ctx), int(self.rank), int(self.world),
+                            1 if shard else 0)
 
     def all_reduce_mean_(self, t):
         """The exchange applied to a device tensor, in place, on the current stream (what a step's call does through the slot)."""
@@ -346,6 +363,8 @@ class RcclExchange(Exchange):
         check(L.pc_rccl_comm_create(ctypes.c_char_p(bytes(unique_id)), int(rank), int(world), ctypes.byref(h)), "pc_rccl_comm_create")
         self.ctx = h
         self.fn = ctypes.cast(L.pc_rccl_allreduce_mean, ctypes.c_void_p)
+        self.rs_fn = ctypes.cast(L.pc_rccl_reduce_scatter_mean, ctypes.c_void_p)
+        self.ag_fn = ctypes.cast(L.pc_rccl_all_gather, ctypes.c_void_p)
         self.rank, self.world = int(rank), int(world)
         self.kind = "rccl (library-owned communicator, ncclAvg)"
 
@@ -372,6 +391,22 @@ class RcclExchange(Exchange):
         check(_lib.lib().pc_rccl_allreduce_sum_f64(self.ctx, _p(t), t.numel(), _stream()), "pc_rccl_allreduce_sum_f64")
         return t
 
+    def reduce_scatter_mean_(self, t):
+        """pc_rccl_reduce_scatter_mean on the current stream: slice `rank` of t <- the mean over the ranks of that slice."""
+        _req(t, torch.float32, "buf")
+        if t.numel() % self.world:
+            raise ValueError("reduce_scatter_mean_: a multiple of the world size")
+        check(_lib.lib().pc_rccl_reduce_scatter_mean(self.ctx, _p(t), t.numel() // self.world, _stream()), "pc_rccl_reduce_scatter_mean")
+        return t
+
+    def all_gather_(self, t):
+        """pc_rccl_all_gather on the current stream: every rank's slice `rank` of t -> all ranks' t."""
+        _req(t, torch.float32, "buf")
+        if t.numel() % self.world:
+            raise ValueError("all_gather_: a multiple of the world size")
+        check(_lib.lib().pc_rccl_all_gather(self.ctx, _p(t), t.numel() // self.world, _stream()), "pc_rccl_all_gather")
+        return t
+
     def stats(self):
         """{collectives issued on the communicator, cross-stream waits the library inserted between them}."""
         a, b = ctypes.c_int64(0), ctypes.c_int64(0)
@@ -384,19 +419,28 @@ class CallbackExchange(Exchange):
     device address ptr, ordered on the stream (it may block).  An exception inside is reported as PC_ECOMM and re-raised by
     the wrapper that made the call."""
 
-    def __init__(self, pyfn, kind="python callback"):
+    def __init__(self, pyfn, kind="python callback", reduce_scatter=None, all_gather=None, rank=0, world=1):
+        """reduce_scatter / all_gather (optional): pyfn-style callables (ptr, n_per_rank, stream) for the sharded optimizer's
+        two halves over the buffer at device address ptr (world * n_per_rank floats)."""
         self.error = None
 
-        def tramp(_ctx, grad, n, stream):
-            try:
-                pyfn(int(grad or 0), int(n), int(stream or 0))
-                return 0
-            except BaseException as e:                # noqa: BLE001 -- nothing may unwind through the C frames
-                self.error = e
-                return -5
+        def wrap(f):
+            def tramp(_ctx, buf, n, stream):
+                try:
+                    f(int(buf or 0), int(n), int(stream or 0))
+                    return 0
+                except BaseException as e:            # noqa: BLE001 -- nothing may unwind through the C frames
+                    self.error = e
+                    return -5
+            return EXCHANGE_FN(tramp)
 
-        self._tramp = EXCHANGE_FN(tramp)              # (kept alive with the object: the C side holds a bare address)
+        self._tramp = wrap(pyfn)                      # (kept alive with the object: the C side holds a bare address)
         self.fn = ctypes.cast(self._tramp, ctypes.c_void_p)
+        if reduce_scatter is not None and all_gather is not None:
+            self._tramp_rs, self._tramp_ag = wrap(reduce_scatter), wrap(all_gather)
+            self.rs_fn = ctypes.cast(self._tramp_rs, ctypes.c_void_p)
+            self.ag_fn = ctypes.cast(self._tramp_ag, ctypes.c_void_p)
+        self.rank, self.world = int(rank), int(world)
         self.ctx = ctypes.c_void_p(0)
         self.kind = kind
 
@@ -406,10 +450,29 @@ class CallbackExchange(Exchange):
             raise e
 
 
-def exchange_adam(exchange, param, grad, exp_avg, exp_avg_sq, step_count, t, scalars, lr=1e-3, betas=(0.9, 0.999), eps=1e-8):
+def exchange_adam(exchange, param, grad, exp_avg, exp_avg_sq, step_count, t, scalars, lr=1e-3, betas=(0.9, 0.999), eps=1e-8,
+                  shard=False):
     """pc_exchange_adam: the replicas' mean gradient (exchange may be None: single process), then Adam -- optimizer.step() of a
-    replica as one foreign call.  t >= 1: the host-known step number; t == 0: the device counter (scalars required)."""
+    replica as one foreign call.  t >= 1: the host-known step number; t == 0: the device counter (scalars required).
+    shard=True (pc_exchange_adam_plan, ABI 8): reduce-scatter of the flat gradient, Adam on this rank's 1/world of the flat
+    buffers, all-gather of the updated parameters; the buffers' length must be a multiple of exchange.world."""
     n = param.numel()
+    if shard:
+        if exchange is None:
+            raise ValueError("exchange_adam(shard=True) needs an exchange")
+        for x, nm in ((param, "param"), (grad, "grad"), (exp_avg, "exp_avg"), (exp_avg_sq, "exp_avg_sq")):
+            _req(x, torch.float32, nm, (n,))
+        if n % exchange.world:
+            raise ValueError(f"exchange_adam(shard=True): {n} floats are not a multiple of the world size {exchange.world} "
+                             "(flatten_parameters(pad_multiple=world))")
+        _req(step_count, torch.int64, "step_count")
+        plan = exchange.plan(shard=True)
+        rc = _lib.lib().pc_exchange_adam_plan(ctypes.byref(plan), _p(param), _p(grad), _p(exp_avg), _p(exp_avg_sq), n, _p(step_count),
+                                              int(t), _p(scalars), float(lr), float(betas[0]), float(betas[1]), float(eps), _stream())
+        if rc and isinstance(exchange, CallbackExchange):
+            exchange.reraise()
+        check(rc, "pc_exchange_adam_plan")
+        return
     for x, nm in ((param, "param"), (grad, "grad"), (exp_avg, "exp_avg"), (exp_avg_sq, "exp_avg_sq")):
         _req(x, torch.float32, nm)
         if x.numel() != n:
@@ -975,10 +1038,11 @@ PreparedJointStep.run_epoch = _prepared_run_epoch
 
 
 def _prepared_run_epoch_dp(self, pairs_dev, source, first_step, flat, gflat, exp_avg, exp_avg_sq, step_count, t_first, scalars,
-                           exchange, drop_last=True, dropout_offset=0):
-    """pc_joint_train_epoch_dp: the epoch of a data-parallel REPLICA as one foreign call -- per step the fused step without its
-    Adam, the exchange slot (ops.RcclExchange / CallbackExchange / None) and Adam over the flat buffers.  The object must have
-    been prepared WITHOUT adam (gradients only) over parameters / gradients that are views of flat / gflat."""
+                           exchange, drop_last=True, dropout_offset=0, shard=False):
+    """pc_joint_train_epoch_plan: the epoch of a data-parallel REPLICA as one foreign call -- per step the fused step without its
+    Adam, the exchange (ops.RcclExchange / CallbackExchange / None) and Adam over the flat buffers; shard=True: reduce-scatter,
+    Adam on this rank's slice, all-gather (ABI 8).  The object must have been prepared WITHOUT adam (gradients only) over
+    parameters / gradients that are views of flat / gflat."""
     if self._args[2] is not None:
         raise ValueError("run_epoch_dp: prepare the step without adam= (the epoch applies Adam over the flat buffers itself)")
     features, type_idx, n_types, seed = source
@@ -995,17 +1059,19 @@ def _prepared_run_epoch_dp(self, pairs_dev, source, first_step, flat, gflat, exp
     if self.dropout is not None:
         self.st.dropout.offset = int(dropout_offset)
     a = self._args
-    rc = _lib.lib().pc_joint_train_epoch_dp(a[0], a[1], _p(flat), _p(gflat), _p(exp_avg), _p(exp_avg_sq), nf, _p(step_count),
-                                            int(t_first), _p(scalars), float(self._hyper[0]), float(self._hyper[1]),
-                                            float(self._hyper[2]), float(self._hyper[3]),
-                                            exchange.fn if exchange is not None else None,
-                                            exchange.ctx if exchange is not None else None,
-                                            _p(pairs_dev), n, _p(features), _p(type_idx), int(n_types), int(seed), int(first_step),
-                                            *a[9:16], int(bool(drop_last)), *a[16:21], _p(losses), *a[22:], _stream())
+    if shard and (exchange is None or nf % exchange.world):
+        raise ValueError("run_epoch_dp(shard=True): an exchange, and flat buffers whose length is a multiple of its world size")
+    plan = exchange.plan(shard=bool(shard)) if exchange is not None else None
+    rc = _lib.lib().pc_joint_train_epoch_plan(a[0], a[1], _p(flat), _p(gflat), _p(exp_avg), _p(exp_avg_sq), nf, _p(step_count),
+                                              int(t_first), _p(scalars), float(self._hyper[0]), float(self._hyper[1]),
+                                              float(self._hyper[2]), float(self._hyper[3]),
+                                              ctypes.byref(plan) if plan is not None else None,
+                                              _p(pairs_dev), n, _p(features), _p(type_idx), int(n_types), int(seed), int(first_step),
+                                              *a[9:16], int(bool(drop_last)), *a[16:21], _p(losses), *a[22:], _stream())
     if rc and isinstance(exchange, CallbackExchange):
         exchange.reraise()
     if rc:
-        check(rc, "pc_joint_train_epoch_dp")
+        check(rc, "pc_joint_train_epoch_plan")
     self.calls += steps
     self._keep_epoch = (pairs_dev, features, type_idx, flat, gflat, exp_avg, exp_avg_sq, step_count, scalars, exchange)
     return losses[:steps], steps

@@ -347,7 +347,12 @@ class GraphedJointStep:
     host-driven form: fused step, grad_hook, optimizer.step() per iteration; no run_epoch.  'graph' is a single-process form (a
     collective would have to sit inside the captured sequence)."""
 
-    def __init__(self, model, optimizer, batch_size, warmup=3, mode="auto", grad_hook=None, exchange=None):
+    def __init__(self, model, optimizer, batch_size, warmup=3, mode="auto", grad_hook=None, exchange=None, shard_optimizer=None):
+        """shard_optimizer (with `exchange`): the optimizer sharded over the replicas (include/pcompanion_hip.h ABI 8:
+        reduce-scatter of the flat gradient, Adam on this rank's 1/world of the flat buffers, all-gather of the parameters)
+        instead of an all-reduce and the whole dense Adam on every rank.  None = automatic: at NUM_TYPES > 512, where the two
+        [NUM_TYPES,64] tables make the flat buffer megabytes (17.8 MB at config.py:27's 34800: the full update is 125 MB of
+        traffic per rank and step), when the exchange offers the pair."""
         from .product2vec import FusedAdam
         if not isinstance(optimizer, FusedAdam):
             raise TypeError("GraphedJointStep drives pc_adam_step / the fused step's Adam: pass a FusedAdam")
@@ -379,6 +384,19 @@ class GraphedJointStep:
             raise ValueError("grad_hook OR exchange")
         if (grad_hook is not None or exchange is not None) and self.mode != "direct":
             raise ValueError("grad_hook / exchange need mode 'direct' (a configuration pc_joint_fused_step serves)")
+        if shard_optimizer is None:
+            shard_optimizer = (exchange is not None and getattr(exchange, "rs_fn", None) is not None
+                               and model.query_type_embeddings.weight.shape[0] > 512)
+        if shard_optimizer and (exchange is None or getattr(exchange, "rs_fn", None) is None):
+            raise ValueError("shard_optimizer needs an exchange with the reduce-scatter / all-gather pair")
+        self.shard_optimizer = bool(shard_optimizer)
+        if exchange is not None:
+            # the slices of the sharded form are world equal parts of the flat buffers; a host-driven exchange finds the
+            # buffers by address
+            flat, gflat = model.flatten_parameters(pad_multiple=exchange.world if self.shard_optimizer else None)
+            if hasattr(exchange, "register"):
+                exchange.register(gflat)
+                exchange.register(flat)
         self.graph = self.prepared = None
         self._eager_steps = 0
         self.losses = self.complementary_types = None
@@ -395,7 +413,7 @@ class GraphedJointStep:
             self.losses, self.complementary_types = self.model.train_step(self.static)
             if self.grad_hook is not None:
                 self.grad_hook(self.model.flatten_parameters()[1])
-            self.optimizer.step(exchange=self.exchange)
+            self.optimizer.step(exchange=self.exchange, shard=self.shard_optimizer)
             return
         self.losses, self.complementary_types = self.model.train_step(self.static, optimizer=self.optimizer)
 
@@ -449,8 +467,8 @@ class GraphedJointStep:
             if self.grad_hook is not None:                 # data-parallel: gradients only above; average, then Adam
                 self.grad_hook(self._gflat)
                 self.optimizer.step()
-            elif self.exchange is not None:                # the same from one foreign call (pc_exchange_adam), no host hook
-                self.optimizer.step(exchange=self.exchange)
+            elif self.exchange is not None:                # the same from one foreign call (pc_exchange_adam[_plan]), no host hook
+                self.optimizer.step(exchange=self.exchange, shard=self.shard_optimizer)
             return self.losses, self.complementary_types
         if self.graph is None:
             if self._eager_steps < self.warmup:
@@ -501,7 +519,8 @@ def _graphed_run_epoch(self, loader, drop_last=False, max_steps=None):
         flat, gflat = self.model.flatten_parameters()
         m, v, step_count, scalars, t_first = self.optimizer.epoch_state()
         losses, steps = self.prepared.run_epoch_dp(pairs, loader._source, loader.step, flat, gflat, m, v, step_count, t_first,
-                                                   scalars, self.exchange, drop_last=drop_last, dropout_offset=tt._dropout_step)
+                                                   scalars, self.exchange, drop_last=drop_last, dropout_offset=tt._dropout_step,
+                                                   shard=self.shard_optimizer)
         self.optimizer.advance(steps)
     else:
         losses, steps = self.prepared.run_epoch(pairs, loader._source, loader.step, drop_last=drop_last, dropout_offset=tt._dropout_step)

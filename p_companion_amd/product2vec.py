@@ -168,9 +168,12 @@ class FusedAdam(torch.optim.Optimizer):
         return flat, gflat
 
     @torch.no_grad()
-    def step(self, closure=None, exchange=None):
+    def step(self, closure=None, exchange=None, shard=False):
         """exchange (ops.Exchange, optional): a data-parallel replica's gradient exchange, issued from the same foreign call as
-        the update (pc_exchange_adam) -- the flat gradient buffer holds the replicas' mean afterwards."""
+        the update (pc_exchange_adam) -- the flat gradient buffer holds the replicas' mean afterwards.
+        shard=True: the optimizer sharded over the replicas (pc_exchange_adam_plan: reduce-scatter, Adam on this rank's slice of
+        the flat buffers, all-gather of the parameters); the module's flat buffers must be padded to a multiple of the world
+        size (module.flatten_parameters(pad_multiple=exchange.world) before the first step)."""
         flat, gflat = self._ensure()
         g = self.param_groups[0]
         if self._host_step is not None and flat.is_cuda and torch.cuda.is_current_stream_capturing():
@@ -184,14 +187,14 @@ class FusedAdam(torch.optim.Optimizer):
             self._host_step += 1
             if exchange is not None:
                 ops.exchange_adam(exchange, flat, gflat, self.exp_avg, self.exp_avg_sq, self.step_count, self._host_step,
-                                  self.scalars, g["lr"], g["betas"], g["eps"])
+                                  self.scalars, g["lr"], g["betas"], g["eps"], shard=shard)
                 return
             ops.adam_step_at(flat, gflat, self.exp_avg, self.exp_avg_sq, self.step_count, self._host_step, g["lr"],
                              g["betas"], g["eps"])
             return
         if exchange is not None:
             ops.exchange_adam(exchange, flat, gflat, self.exp_avg, self.exp_avg_sq, self.step_count, 0, self.scalars, g["lr"],
-                              g["betas"], g["eps"])
+                              g["betas"], g["eps"], shard=shard)
             return
         ops.adam_step(flat, gflat, self.exp_avg, self.exp_avg_sq, self.step_count, self.scalars, g["lr"],
                       g["betas"], g["eps"])
@@ -307,10 +310,15 @@ class _FlatParamsMixin:
         sd = dict(self.named_parameters())
         return [(k, sd[k]) for k in self._flat_keys]
 
-    def flatten_parameters(self):
+    def flatten_parameters(self, pad_multiple=None):
+        """pad_multiple (sticky once given): the flat buffers' length is rounded up to a multiple of it (zeros behind the last
+        parameter) -- the sharded optimizer splits them into world equal slices (ops.exchange_adam(shard=True))."""
+        if pad_multiple is not None:
+            self._flat_pad = max(1, int(pad_multiple))
+        pad = getattr(self, "_flat_pad", 1)
         items = self._named_flat()
         flat = getattr(self, "_flat", None)
-        ok = flat is not None and flat.device == items[0][1].device
+        ok = flat is not None and flat.device == items[0][1].device and flat.numel() % pad == 0
         if ok:
             off = 0
             for _, p in items:
@@ -322,7 +330,8 @@ class _FlatParamsMixin:
         if not ok:
             dev = items[0][1].device
             n = sum(p.numel() for _, p in items)
-            flat = ops.alloc(n, torch.float32, dev)
+            n = (n + pad - 1) // pad * pad
+            flat = ops.alloc(n, torch.float32, dev, zero=True)
             gflat = ops.alloc(n, torch.float32, dev, zero=True)
             off = 0
             for _, p in items:

@@ -51,13 +51,79 @@ def main():
                 break
         res.update(ok=bool(worst == 0.0 and sharded.overflowed() == 0), worst=worst, steps=steps,
                    capacity=sharded.capacity, bytes_per_peer=sharded.bytes_per_peer)
+        res["sharded_optimizer"] = sharded_optimizer_check(rank, dev)
+        res["ok"] = bool(res["ok"] and res["sharded_optimizer"]["ok"])
         dist.barrier()
         dist.destroy_process_group()
     except Exception as e:                                       # noqa: BLE001 -- reported to the parent test
         import traceback
         res["error"] = traceback.format_exc()
+        res["ok"] = False
     with open(out, "w") as f:
         json.dump(res, f)
+
+
+def sharded_optimizer_check(rank, dev):
+    """ABI 8 at world 2: the joint step's optimizer sharded over the replicas (reduce-scatter of the flat gradient, Adam on this
+    rank's half of the flat buffers, all-gather of the parameters) against the all-reduce + whole-Adam form -- the same
+    parameters bit for bit (two addends commute), moments untouched outside this rank's half, both ranks identical."""
+    from types import SimpleNamespace
+    import torch
+    import torch.distributed as dist
+    from p_companion_amd import distributed as pdist
+    from p_companion_amd.data import ComplementaryIndexDataset, ComplementaryIndexLoader, generate_scaled_bpg
+    from p_companion_amd.p_companion import GraphedJointStep, PCompanion
+    from p_companion_amd.product2vec import FusedAdam
+    T, B = 601, 256
+    cfg = SimpleNamespace(PRODUCT_EMB_DIM=128, TYPE_EMB_DIM=64, DROPOUT=0.0, MARGIN=1.0, ALPHA=0.8, NUM_COMP_TYPES=3,
+                          NUM_TYPES=T, DEVICE=dev)
+    bpg = generate_scaled_bpg(3000, 40, seed=3)
+    out = {}
+
+    def make(shard):
+        torch.manual_seed(5)
+        m = PCompanion(cfg, bpg.cuda(dev)["features"]).to(dev).train()
+        o = FusedAdam(m, lr=1e-2)
+        ex = pdist.make_exchange(2, rank=rank, kind="callback", device=dev)
+        g = GraphedJointStep(m, o, B, warmup=1, mode="direct", exchange=ex, shard_optimizer=shard)
+        ld = ComplementaryIndexLoader(ComplementaryIndexDataset(bpg, "train"), B, shuffle=True, seed=20 + rank, device=dev,
+                                      out=g.static)
+        return m, o, g, ld
+
+    m_a, o_a, g_a, ld_a = make(False)
+    m_b, o_b, g_b, ld_b = make(True)
+    assert g_b.shard_optimizer and not g_a.shard_optimizer
+    n_real = sum(p.numel() for _, p in m_b._named_flat())
+    flat_b = m_b.flatten_parameters()[0]
+    assert flat_b.numel() % 2 == 0 and flat_b.numel() == n_real            # (29 024 + 2 * 64 T floats: even at any T)
+    steps = 0
+    for ba, bb in zip(ld_a, ld_b):
+        if ba["query_idx"].numel() != B:
+            continue
+        la, _ = g_a(ba)
+        lb, _ = g_b(bb)
+        assert torch.equal(la, lb), (steps, la, lb)
+        steps += 1
+        if steps == 4:
+            break
+    got = g_b.run_epoch(ld_b, drop_last=True, max_steps=3)            # pc_joint_train_epoch_plan, shard_optimizer = 1
+    ref = g_a.run_epoch(ld_a, drop_last=True, max_steps=3)
+    same = torch.equal(got, ref)
+    for (k, pa), (_, pb) in zip(m_a.named_parameters(), m_b.named_parameters()):
+        same = same and torch.equal(pa, pb)
+    half = flat_b.numel() // 2
+    lo, hi = rank * half, (rank + 1) * half
+    own = o_b.exp_avg[lo:hi]
+    other = torch.cat([o_b.exp_avg[:lo], o_b.exp_avg[hi:]])
+    # both ranks hold the same parameters: compare a checksum over the process group
+    chk = torch.stack([flat_b.double().sum(), flat_b.double().abs().sum()]).cpu()
+    both = [torch.zeros_like(chk) for _ in range(2)]
+    dist.all_gather(both, chk)
+    out.update(ok=bool(same and float(other.abs().max()) == 0.0 and float(own.abs().max()) > 0.0 and torch.equal(both[0], both[1])
+                       and int(o_a.step_count) == int(o_b.step_count) == 7),
+               same=bool(same), moments_outside_own_half=float(other.abs().max()), ranks_equal=bool(torch.equal(both[0], both[1])),
+               steps=int(o_b.step_count), flat=int(flat_b.numel()), real=int(n_real))
+    return out
 
 
 if __name__ == "__main__":

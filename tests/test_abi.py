@@ -28,7 +28,7 @@ def test_library_exports_every_declared_symbol():
     L = ctypes.CDLL(_lib.LIB_PATH)
     for name in header_functions():
         assert hasattr(L, name), f"{name} declared in the header but not exported"
-    assert L.pc_abi_version() == 7
+    assert L.pc_abi_version() == 8
     assert L.pc_build_flags() == 0, "a developer-knob build (PC_EXP_* / *_TIMING) is not the product"
 
 

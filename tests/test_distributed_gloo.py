@@ -257,3 +257,11 @@ def test_rendezvous_deadline_ends_the_process():
     assert _run_with_deadline(lambda: 41 + 1, 5.0, "quick", 0) == 42
     with pytest.raises(KeyError):
         _run_with_deadline(lambda: {}["x"], 5.0, "raises", 0)
+    # on_expire="abandon" (the native exchange's probe): the caller gets control back and can agree on the fallback
+    import time
+    from p_companion_amd.distributed import _Expired, probe_timeout_s, group_timeout_s
+    t0 = time.perf_counter()
+    with pytest.raises(_Expired):
+        _run_with_deadline(lambda: time.sleep(5), 0.3, "parked rendezvous", 0, on_expire="abandon")
+    assert time.perf_counter() - t0 < 2.0
+    assert probe_timeout_s() <= 90 and probe_timeout_s() <= group_timeout_s() <= 300       # first contact resolves inside a 10-minute harness limit

@@ -270,3 +270,46 @@ def test_graph_mode_of_the_launch_per_op_step_advances_adam_like_eager(how):
     sd = o_g.state_dict()
     o_g.load_state_dict(sd)
     assert o_g._host_step is None and int(o_g.step_count) == n
+
+
+def test_padded_flat_buffers_change_no_bit():
+    """flatten_parameters(pad_multiple=7) -- what the sharded optimizer asks for at an odd world size: the flat buffers' length is
+    a multiple of 7 with zeros behind the last parameter, every parameter / gradient stays a view of them, a re-flatten of a model
+    that was flattened unpadded keeps its values, and three fused steps + FusedAdam give the unpadded twin's bits; the checkpoint
+    layout (torch.optim.Adam's) is the same."""
+    from p_companion_amd.p_companion import PCompanion
+    from p_companion_amd.product2vec import FusedAdam
+    T = 45
+    c = cfg(NUM_TYPES=T)
+    g = torch.Generator().manual_seed(1)
+    table = torch.randn(300, 128, generator=g)
+    b = joint_batch(96, 300, T, seed=3)
+    models = []
+    for pad in (None, 7):
+        torch.manual_seed(9)
+        m = PCompanion(c, table).to("cuda").train()
+        o = FusedAdam(m, lr=1e-2)
+        if pad is not None:
+            m.flatten_parameters()                                 # flattened unpadded first: the padded call rebuilds the buffers
+            before = {k: p.detach().clone() for k, p in m.named_parameters()}
+            flat, gflat = m.flatten_parameters(pad_multiple=pad)
+            n_real = sum(p.numel() for _, p in m._named_flat())
+            assert n_real % pad != 0 and flat.numel() % pad == 0 and 0 < flat.numel() - n_real < pad
+            assert float(flat[n_real:].abs().max()) == 0.0 and float(gflat[n_real:].abs().max()) == 0.0
+            for k, p in m.named_parameters():
+                assert torch.equal(p, before[k]), k
+            off = 0
+            for _, p in m._named_flat():
+                assert p.data_ptr() == flat.data_ptr() + 4 * off and p.grad.data_ptr() == gflat.data_ptr() + 4 * off
+                off += p.numel()
+            assert m.flatten_parameters()[0].data_ptr() == flat.data_ptr()            # sticky: a later plain call keeps the padding
+        for _ in range(3):
+            m.train_step(b, optimizer=o)
+        models.append((m, o))
+    (m0, o0), (m1, o1) = models
+    for (k, p0), (_, p1) in zip(m0.named_parameters(), m1.named_parameters()):
+        assert torch.equal(p0, p1), k
+    s0, s1 = o0.state_dict(), o1.state_dict()
+    assert s0["state"].keys() == s1["state"].keys()
+    for i in s0["state"]:
+        assert torch.equal(s0["state"][i]["exp_avg"], s1["state"][i]["exp_avg"]) and float(s0["state"][i]["step"]) == float(s1["state"][i]["step"]) == 3.0

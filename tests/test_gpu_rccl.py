@@ -51,6 +51,8 @@ def test_bench_multi_rank_branches_run_over_rccl(exchange):
         assert line["rccl"]["exchange"].startswith("rccl"), line["rccl"]
         assert "pc_joint_train_epoch_dp" in j["config"]["launch"] and j["config"]["exchange"].startswith("rccl")
         assert "pc_joint_train_epoch_dp" in jr["config"]["launch"]
+        # ABI 8: at T > 512 the optimizer is sharded over the replicas (ncclReduceScatter, Adam on 1/world, ncclAllGather)
+        assert jr["config"]["optimizer"].startswith("sharded") and j["config"]["optimizer"].startswith("all-reduce")
     else:
         assert "all-reduce" in j["config"]["launch"] and "hook" in line["rccl"]["exchange"]
     assert j["value"] > 1e6
@@ -125,7 +127,9 @@ def _worker_native_collectives():
     assert torch.equal(recv_i, send_i) and torch.equal(recv_f, send_f)
     assert torch.equal(d, torch.arange(ops.BN_SYNC_DOUBLES, dtype=torch.float64, device=dev) * 0.5)
     s1 = ex.stats()
-    assert s1["issued"] == base["issued"] + 3 and s1["chained"] == base["chained"]      # one stream: stream order is the chain
+    # (the probe ran on two streams of its own: the first collective here changes stream once; the next two follow it on the
+    # same stream, where stream order is the chain)
+    assert s1["issued"] == base["issued"] + 3 and s1["chained"] == base["chained"] + 1
     import pytest as _pt
     with _pt.raises(ValueError):
         ex.all_to_all(send_i, send_i)                            # aliased
@@ -152,8 +156,13 @@ def _worker_native_collectives():
     # (the owner-side slot of an id is handed out by integer atomics: the request lists of two calls may differ in order, the
     # rows every index of the remapped batch points at may not)
     zrow = torch.zeros(1, 128, device=dev)
+    n_ids = 2 * B + B * K + batch["neighbor_compact"]["nb_rows"].numel()
+    with _pt.raises(ValueError):                                 # a native exchange: no lazy capacity agreement inside a lookup
+        pdist.ShardedFeatureTable(table, 5000, 0, 1, exchange=ex).lookup_batch(batch)
+    with _pt.raises(ValueError):                                 # ... and no variable-split lookup on torch's communicator
+        pdist.ShardedFeatureTable(table, 5000, 0, 1, exchange=ex, capacity=n_ids).lookup(batch["anchor_idx"])
     for exch in (ex, None):
-        sh = pdist.ShardedFeatureTable(table, 5000, 0, 1, exchange=exch)
+        sh = pdist.ShardedFeatureTable(table, 5000, 0, 1, exchange=exch, capacity=pdist.ShardedFeatureTable.capacity_for(n_ids, 1))
         tab, rb = sh.lookup_batch(batch)
         assert sh.overflowed() == 0
         for k in ("anchor_idx", "positive_idx", "negative_idx"):
@@ -164,6 +173,27 @@ def _worker_native_collectives():
         ext, ext_t = torch.cat([tab, zrow]), torch.cat([table, zrow])
         assert torch.equal(ext[got_rows], ext_t[want_rows]), exch is None             # (-1 = the padding row: a zero row)
     assert ex.stats()["issued"] == s2["issued"] + 2              # both rounds went through the library's communicator
+    # ABI 8: the sharded optimizer's two halves (one rank: both are the identity) and pc_exchange_adam_plan against the plain form
+    t = torch.randn(4096, device=dev)
+    ref = t.clone()
+    ex.reduce_scatter_mean_(t)
+    ex.all_gather_(t)
+    torch.cuda.synchronize()
+    assert torch.equal(t, ref) and ex.stats()["issued"] == s2["issued"] + 4
+    n = 10000
+    gen2 = torch.Generator().manual_seed(3)
+    p0, g0 = torch.randn(n, generator=gen2).to(dev), torch.randn(n, generator=gen2).to(dev)
+    outs = []
+    for shard in (False, True):
+        p_, g_ = p0.clone(), g0.clone()
+        m_, v_ = torch.zeros_like(p_), torch.zeros_like(p_)
+        cnt, sc = torch.zeros(1, dtype=torch.int64, device=dev), torch.zeros(2, device=dev)
+        for step in (1, 2, 3):
+            ops.exchange_adam(ex, p_, g_, m_, v_, cnt, step, sc, 1e-2, shard=shard)
+        ops.exchange_adam(ex, p_, g_, m_, v_, cnt, 0, sc, 1e-2, shard=shard)       # the device-counter form
+        torch.cuda.synchronize()
+        outs.append((p_, m_, v_, int(cnt)))
+    assert all(torch.equal(a, b) for a, b in zip(outs[0][:3], outs[1][:3])) and outs[0][3] == outs[1][3] == 4
     ex.close()
     dist.destroy_process_group()
     print("native collectives ok")

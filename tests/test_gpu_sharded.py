@@ -125,3 +125,7 @@ def test_sharded_step_world2_on_one_card(world2_job):
     for r in results:
         assert r["steps"] == 3 and r["worst"] == 0.0
         assert r["bytes_per_peer"]["rows"] == 512 * r["capacity"]
+        # ABI 8: reduce-scatter -> Adam on the rank's half -> all-gather == all-reduce + whole Adam, bit for bit at world 2
+        so = r["sharded_optimizer"]
+        assert so["ok"] and so["same"] and so["moments_outside_own_half"] == 0.0 and so["ranks_equal"], so
+        assert so["steps"] == 7 and so["flat"] == so["real"]

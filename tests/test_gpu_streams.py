@@ -70,9 +70,15 @@ def test_side_queue_fork_changes_no_bit():
             outs.append(_fork_digest())
             torch.cuda.synchronize()
             assert L.pc_release_device_state() == 0
+        # the BatchNorm-backward finalize on the side queue beside dW3 (rounds 3-5) or on the step's own queue (default): same bits
+        assert L.pc_get_option(_lib.PC_OPT_BN_FINALIZE_SIDE, ctypes.byref(v)) == 0 and v.value == 0
+        assert L.pc_set_option(_lib.PC_OPT_BN_FINALIZE_SIDE, 1) == 0
+        outs.append(_fork_digest())
+        torch.cuda.synchronize()
     finally:
         L.pc_set_option(_lib.PC_OPT_SIDE_QUEUE, 1)
-    assert outs[0] == outs[1] == outs[2]
+        L.pc_set_option(_lib.PC_OPT_BN_FINALIZE_SIDE, 0)
+    assert outs[0] == outs[1] == outs[2] == outs[3]
 
 
 def test_fused_p2v_step_under_stream_capture_stays_on_one_queue():
