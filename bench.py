@@ -387,7 +387,7 @@ def run_joint(args, rank, world, dev, types, steps, warmup, want_cpu, dropout=0.
 
 # ----------------------------------------------------------------------------------------------- P2V phase
 def run_p2v(args, rank, world, dev, products, steps, warmup, want_cpu, profile_kernels=True, sustained=False, dim=None,
-            negatives=None, table_mode=None, dropout=0.0, pmc_kind="", exchange=None):
+            negatives=None, table_mode=None, dropout=0.0, pmc_kind="", exchange=None, hot_rows=0):
     """One Product2Vec leg.  dim / negatives / table_mode default to the command line's; dropout = config.py:12's DROPOUT of
     the attention probabilities (0.0: the parity setting, every golden test; 0.1: the reference as shipped)."""
     from types import SimpleNamespace
@@ -432,7 +432,9 @@ def run_p2v(args, rank, world, dev, products, steps, warmup, want_cpu, profile_k
         # row r on rank r % world; the loader runs the per-batch exchange on its side stream, one batch ahead
         local = table if on_device else pdist.ShardedFeatureTable.shard(table, rank, world)
         # (the lookup rounds on the communicator that carries the gradient exchange: one cross-rank launch order per step)
-        sharded = pdist.ShardedFeatureTable(local, bpg.num_products, rank, world, exchange=exchange)
+        # hot_rows: the replicated hot set of the Zipf head (configs[4]): ids below it are served from a local replica
+        sharded = pdist.ShardedFeatureTable(local, bpg.num_products, rank, world, exchange=exchange,
+                                            hot_rows=hot_rows if negatives == "zipf" else 0)
     loader = SimilarityIndexLoader(bpg, args.batch, shuffle=True, sampler="philox", seed=1 + rank, drop_last=True,
                                    device=dev, sharded=sharded, negatives=negatives, reuse_buffers=True)
 
@@ -491,8 +493,11 @@ def run_p2v(args, rank, world, dev, products, steps, warmup, want_cpu, profile_k
     if multi:
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
     el = float(t)
+    hot_served = None
     if sharded is not None:
         sharded.raise_if_overflowed()
+        if sharded.hot_rows:
+            hot_served = sharded.hot_rows_served()          # entries served from the replica since construction (warm-up included)
     # the second-largest kernel family (the weight-gradient products: gemm_tn8_kernel x3 + gemm_tn_group_kernel): HIP-event
     # brackets around ITS launches over a few extra steps OUTSIDE the timed region (every bracket is two event packets on the
     # stream; the timed region carries the dominant family's only).  All ranks step together (the step holds collectives).
@@ -514,7 +519,12 @@ def run_p2v(args, rank, world, dev, products, steps, warmup, want_cpu, profile_k
            "host_enqueue_ms_per_step": round(host_ms, 4), "profiled_steps": profiled_steps,
            "distinct_neighbour_rows": rows_avg, "real_neighbour_slots": slots_avg,
            "sharded_lookup": ({"capacity_rows_per_peer": sharded.capacity, "bytes_per_peer_and_step": sharded.bytes_per_peer,
-                               "host_syncs_per_step": 0} if sharded is not None else None),
+                               "host_syncs_per_step": 0, "hot_rows": sharded.hot_rows,
+                               # (the loader builds a few batches ahead of the step: lookups counted = batches BUILT since construction)
+                               "hot_rows_served": hot_served,
+                               "hot_rows_served_per_batch": (round(hot_served / max(loader.step, 1), 1) if hot_served is not None else None),
+                               "ids_per_batch": 2 * args.batch + 5 * args.batch + int(round(rows_avg)) + 1}
+                              if sharded is not None else None),
            "rows_saved_by_duplicate_neighbours": round(1.0 - (7 * args.batch + rows_avg + 1) / (7 * args.batch + slots_avg + 1), 4)}
     if profile_kernels:
         nt = prof.summary("gemm_nt_kernel")
@@ -884,6 +894,9 @@ def main():
                          "configs[4]: 100 M products x 256, Zipf negatives; both generated in HBM)")
     ap.add_argument("--no-dropout-legs", action="store_true", help="skip the legs at the reference's shipped DROPOUT = 0.1 (config.py:12)")
     ap.add_argument("--no-ref-types", action="store_true", help="skip the joint leg at the reference's NUM_TYPES = 34800")
+    ap.add_argument("--hot-rows", type=int, default=1024,
+                    help="replicated hot set under the row-sharded table with Zipf negatives (configs[4] at N > 1, and the `hot_set` leg): "
+                         "this many most popular products live on every rank; 0 = off")
     ap.add_argument("--no-dropin", action="store_true", help="skip the `dropin_dense` leg (the reference's loop body over reference-format batches)")
     ap.add_argument("--no-sustained", action="store_true", help="skip the `sustained` leg (3 x >= 300 P2V steps across epoch boundaries)")
     args = ap.parse_args()
@@ -1043,12 +1056,34 @@ def main():
         gc.collect()
         torch.cuda.empty_cache()
         r = guarded("config4", lambda: run_p2v(args, rank, world, dev, 100_000_000, 30, 10, False, dim=256, negatives="zipf",
-                                               table_mode="sharded" if world > 1 else "replicated", pmc_kind="big"), world)
+                                               table_mode="sharded" if world > 1 else "replicated", pmc_kind="big",
+                                               hot_rows=args.hot_rows), world)
         if rank == 0:
             lc["config4"] = dict(leg(r), workload=f"BASELINE configs[4]: 100 M products, dim=256, Zipf(1) negatives, "
                                                   + (f"table row-sharded over {world} GPUs" if world > 1 else "whole table (102 GB) on one GPU")
-                                                  + f", batch={args.batch}/GPU; hot-row cache measured unnecessary (DESIGN.md section 7)")
+                                                  + f", batch={args.batch}/GPU; "
+                                                  + (f"the {args.hot_rows} most popular products replicated on every rank (pc_shard_bucket_hot)"
+                                                     if world > 1 and args.hot_rows else "one process holds every row: no lookup to cache")
+                                                  + "; an LDS cache of hot rows measured unnecessary (DESIGN.md section 7: gather traffic 1.02x algorithmic)")
         del r
+        gc.collect()
+        torch.cuda.empty_cache()
+        if args.hot_rows:
+            # the replicated hot set at work where one card can show it: 10 M products, Zipf negatives, the sharded lookup chain
+            # (pc_shard_bucket[_hot] + two constant-shape exchange rounds + pc_gather_rows; G = 1: the rounds are copies) with and
+            # without the H most popular products served from the replica
+            hs = {}
+            for name, h in (("without", 0), ("with", args.hot_rows)):
+                rr = guarded("hot_set_" + name, lambda h=h: run_p2v(args, rank, world, dev, 10_000_000, 20, 8, False, dim=128, negatives="zipf",
+                                                                    table_mode="sharded", pmc_kind="none", hot_rows=h, profile_kernels=False), world)
+                if rank == 0:
+                    hs[name] = leg(rr, keys=("value", "ms_per_step", "final_loss", "sharded_lookup"))
+                del rr
+                gc.collect()
+                torch.cuda.empty_cache()
+            if rank == 0:
+                lc["hot_set"] = dict(hs, workload=f"10 M products, dim=128, Zipf(1) negatives, table row-sharded over {world} GPU(s), "
+                                                  f"hot_rows={args.hot_rows}: request-list entries per batch = ids_per_batch - hot_rows_served_per_batch")
         gc.collect()
         torch.cuda.empty_cache()
         extra["large_catalogue"] = lc

@@ -824,6 +824,17 @@ int pc_epoch_plan(const int32_t *order, const int32_t *deg, int n, int batch, in
 int pc_shard_bucket(const int32_t *const *ids, const int *n, const int32_t *const *n_dev, const int *n_dev_add,
                     int32_t *const *remap_out, int count, int world, int capacity, int32_t *counts,
                     int32_t *send_ids, int32_t *overflow, void *stream);
+/* The same with a REPLICATED HOT SET (ABI 8; BASELINE configs[4]: "Zipf-skewed negative sampling + hot-row cache"; the
+ * reference draws negatives uniformly, src/data/data_loader.py:27-40, and keeps its table in one process): the hot_rows most
+ * popular products live on EVERY rank as rows [world * capacity, world * capacity + hot_rows) of the table the step reads
+ * (the caller keeps that replica behind the exchange buffer), and an id of the set maps there instead of taking a request slot.
+ * hot_ids: the set as ascending product ids [hot_rows] (device; NULL = the ids [0, hot_rows): popularity rank = product id, the
+ * Zipf sampler's default); hot slot = position in the set.  *hot_served (device, may be NULL) is increased by the number of
+ * live entries served from the replica.  hot_rows = 0: pc_shard_bucket.  Lookups stay constant-shape. */
+int pc_shard_bucket_hot(const int32_t *const *ids, const int *n, const int32_t *const *n_dev, const int *n_dev_add,
+                        int32_t *const *remap_out, int count, int world, int capacity, const int32_t *hot_ids,
+                        int hot_rows, int32_t *counts, int32_t *send_ids, int32_t *overflow, int32_t *hot_served,
+                        void *stream);
 
 /* nn.Dropout of ComplementaryTypeTransition (type_transition.py:13,17) in training mode on the hidden activations
  * x[n] (n % 4 == 0, rows of 32): y = x * mask, mask = stream 1 of pc_dropout (0 or 1/(1-p)).  The same call with the

@@ -198,6 +198,8 @@ SIGNATURES = {
     "pc_epoch_plan": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp]),
     "pc_shard_bucket": (_i, [_P(ctypes.c_void_p), _P(ctypes.c_int), _P(ctypes.c_void_p), _P(ctypes.c_int), _P(ctypes.c_void_p),
                              _i, _i, _i, _vp, _vp, _vp, _vp]),
+    "pc_shard_bucket_hot": (_i, [_P(ctypes.c_void_p), _P(ctypes.c_int), _P(ctypes.c_void_p), _P(ctypes.c_int), _P(ctypes.c_void_p),
+                                 _i, _i, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp]),
     "pc_dropout_hidden": (_i, [_vp, _sz, _P(Dropout), _vp, _vp]),
     "pc_check_indices": (_i, [_P(ctypes.c_void_p), _P(ctypes.c_int), _P(ctypes.c_int), _P(ctypes.c_int), _i, _vp, _vp]),
 }

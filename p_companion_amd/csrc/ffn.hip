@@ -46,61 +46,74 @@ __device__ __forceinline__ void fold_partials(const float* p1, const float* p2, 
     __syncthreads();
 }
 
-// All segments in ONE pass with the loads in flight together (round 6).  The two folds above walk a segment's tiles in one or
-// two dependent chains per thread -- 11 round trips to L2 / HBM per segment, four segments one after the other: 12 us (forward)
-// and 12-32 us (backward, on the side queue) for 0.7 MB of partials, pure latency.  Here a thread takes every FIN_LANES-th tile
-// of the WHOLE tile range, eight tiles (sixteen loads) per batch before the first use, and adds each value to its segment's
-// accumulator by predicate (tiles never straddle segments: a tile's segment is three comparisons); one LDS exchange reduces the
-// lanes.  Fixed order: lane q adds its tiles ascending, the lanes are added ascending.  out[s][0..1] for s < PC_MAX_SEG in
-// the threads with q == s (every segment's finalize arithmetic then runs in its own thread).
-#define FOLD_BATCH 8
-__device__ __forceinline__ void fold_partials_all(const float* __restrict__ p1, const float* __restrict__ p2, const SegInfo& si,
-                                                  int j, int q, double (*red)[PC_MAX_SEG][FIN_LANES][FIN_COLS], double* o1,
-                                                  double* o2) {
-    double a[PC_MAX_SEG], b[PC_MAX_SEG];
+// All segments in ONE pass, 16-byte loads (round 6).  The folds above walk a segment's tiles with one dword load per lane and
+// tile: a wave-load moves 256 B and the kernel is bound by the address pipe of its eight CUs, not by latency (5.6 us for 4
+// tiles, 8.8 for 352, 13.1 for 704 when run alone -- scripts/dev/bn_finalize_probe.sh -- and 12-14 us inside the step, four
+// segments one after the other).  Here a thread owns FOUR adjacent columns (one float4 per tile and array), a workgroup is
+// 8 column groups x 64 tile lanes (512 threads: 128 registers per thread would spill the 64 accumulator registers' neighbours),
+// so a wave-load moves 1 KB (eight tile rows x 128 B) and a 352-tile fold is six loads per lane and array, all in flight
+// before the first use.  A value is added to its segment's accumulator by predicate (tiles never
+// straddle segments).  Lanes are reduced in a fixed order: xor-shuffles over the wave's eight tile lanes, then one LDS exchange
+// over the eight waves.  Result: thread f < 128 holds the two sums of (segment f / 32, column f % 32 of the workgroup's 32).
+#define FIN4_CG 8
+#define FIN4_LANES 64
+#define FIN4_WAVES (FIN4_CG * FIN4_LANES / 64)
+#define FIN4_BATCH 6
+__device__ __forceinline__ void fold_partials_all4(const float* __restrict__ p1, const float* __restrict__ p2, const SegInfo& si,
+                                                   int col0, double (*red)[2][PC_MAX_SEG][FIN_COLS], double* o1, double* o2) {
+    const int cg = threadIdx.x, q = threadIdx.y;
+    const int tid = q * FIN4_CG + cg, wave = tid >> 6, lane = tid & 63;
+    double a[PC_MAX_SEG][4], b[PC_MAX_SEG][4];
 #pragma unroll
-    for (int s = 0; s < PC_MAX_SEG; s++) { a[s] = 0.0; b[s] = 0.0; }
+    for (int s = 0; s < PC_MAX_SEG; s++)
+#pragma unroll
+        for (int c = 0; c < 4; c++) { a[s][c] = 0.0; b[s][c] = 0.0; }
     const int t_end = si.tile0[si.nseg];
     const int b1 = si.nseg > 1 ? si.tile0[1] : t_end, b2 = si.nseg > 2 ? si.tile0[2] : t_end, b3 = si.nseg > 3 ? si.tile0[3] : t_end;
-    int t = si.tile0[0] + q;
-    for (; t + (FOLD_BATCH - 1) * FIN_LANES < t_end; t += FOLD_BATCH * FIN_LANES) {
-        float x[FOLD_BATCH], y[FOLD_BATCH];
+    const size_t c0 = (size_t)col0 + cg * 4;
+    for (int t = si.tile0[0] + q; t < t_end; t += FIN4_BATCH * FIN4_LANES) {
+        float4 x[FIN4_BATCH], y[FIN4_BATCH];
 #pragma unroll
-        for (int u = 0; u < FOLD_BATCH; u++) {
-            x[u] = p1[(size_t)(t + u * FIN_LANES) * PC_H + j];
-            y[u] = p2[(size_t)(t + u * FIN_LANES) * PC_H + j];
+        for (int u = 0; u < FIN4_BATCH; u++) {
+            const int tt = t + u * FIN4_LANES;
+            const int tc = tt < t_end ? tt : t;                    // (a lane past the end re-reads its first tile: no branch, no use)
+            x[u] = *reinterpret_cast<const float4*>(p1 + (size_t)tc * PC_H + c0);
+            y[u] = *reinterpret_cast<const float4*>(p2 + (size_t)tc * PC_H + c0);
         }
 #pragma unroll
-        for (int u = 0; u < FOLD_BATCH; u++) {
-            const int tt = t + u * FIN_LANES;
-            const int sg = (tt >= b1) + (tt >= b2) + (tt >= b3);
+        for (int u = 0; u < FIN4_BATCH; u++) {
+            const int tt = t + u * FIN4_LANES;
+            const int sg = tt < t_end ? (tt >= b1) + (tt >= b2) + (tt >= b3) : -1;
 #pragma unroll
-            for (int s = 0; s < PC_MAX_SEG; s++) { a[s] += sg == s ? (double)x[u] : 0.0; b[s] += sg == s ? (double)y[u] : 0.0; }
-        }
-    }
-    {   // the tail: up to FOLD_BATCH - 1 tiles per lane, loaded together as well
-        float x[FOLD_BATCH], y[FOLD_BATCH];
-#pragma unroll
-        for (int u = 0; u < FOLD_BATCH - 1; u++) {
-            const int tt = t + u * FIN_LANES;
-            x[u] = tt < t_end ? p1[(size_t)tt * PC_H + j] : 0.f;
-            y[u] = tt < t_end ? p2[(size_t)tt * PC_H + j] : 0.f;
-        }
-#pragma unroll
-        for (int u = 0; u < FOLD_BATCH - 1; u++) {
-            const int tt = t + u * FIN_LANES;
-            const int sg = (tt >= b1) + (tt >= b2) + (tt >= b3);
-#pragma unroll
-            for (int s = 0; s < PC_MAX_SEG; s++) { a[s] += sg == s ? (double)x[u] : 0.0; b[s] += sg == s ? (double)y[u] : 0.0; }
+            for (int s = 0; s < PC_MAX_SEG; s++) {
+                const bool on = sg == s;
+                a[s][0] += on ? (double)x[u].x : 0.0; a[s][1] += on ? (double)x[u].y : 0.0;
+                a[s][2] += on ? (double)x[u].z : 0.0; a[s][3] += on ? (double)x[u].w : 0.0;
+                b[s][0] += on ? (double)y[u].x : 0.0; b[s][1] += on ? (double)y[u].y : 0.0;
+                b[s][2] += on ? (double)y[u].z : 0.0; b[s][3] += on ? (double)y[u].w : 0.0;
+            }
         }
     }
+    // the wave's eight tile lanes (lane bits 3..5), fixed order
 #pragma unroll
-    for (int s = 0; s < PC_MAX_SEG; s++) { red[0][s][q][threadIdx.x] = a[s]; red[1][s][q][threadIdx.x] = b[s]; }
+    for (int s = 0; s < PC_MAX_SEG; s++)
+#pragma unroll
+        for (int c = 0; c < 4; c++) {
+#pragma unroll
+            for (int o = 8; o < 64; o <<= 1) { a[s][c] += __shfl_xor(a[s][c], o, 64); b[s][c] += __shfl_xor(b[s][c], o, 64); }
+        }
+    if (lane < FIN4_CG) {
+#pragma unroll
+        for (int s = 0; s < PC_MAX_SEG; s++)
+#pragma unroll
+            for (int c = 0; c < 4; c++) { red[wave][0][s][cg * 4 + c] = a[s][c]; red[wave][1][s][cg * 4 + c] = b[s][c]; }
+    }
     __syncthreads();
-    if (q < PC_MAX_SEG) {
+    if (tid < PC_MAX_SEG * FIN_COLS) {
+        const int s = tid / FIN_COLS, col = tid % FIN_COLS;
         double s1 = 0.0, s2 = 0.0;
-#pragma unroll 8
-        for (int i = 0; i < FIN_LANES; i++) { s1 += red[0][q][i][threadIdx.x]; s2 += red[1][q][i][threadIdx.x]; }
+#pragma unroll
+        for (int w = 0; w < FIN4_WAVES; w++) { s1 += red[w][0][s][col]; s2 += red[w][1][s][col]; }
         *o1 = s1; *o2 = s2;
     }
 }
@@ -129,18 +142,18 @@ __global__ __launch_bounds__(FIN_COLS * FIN_LANES) void bn_fold_kernel(const flo
 // TLB is theirs) every one of those is a miss: 115-144 us there under the profiler.  Back to 32 adjacent columns per tile row.
 // Round 6: the same 32 columns x 32 tile lanes, all segments in one pass with sixteen loads in flight per thread
 // (fold_partials_all); thread (column, q = s) finalizes segment s, the running statistics are chained in segment order.)
-__global__ __launch_bounds__(FIN_COLS * FIN_LANES) void bn_finalize_fwd_kernel(
+__global__ __launch_bounds__(FIN4_CG * FIN4_LANES) void bn_finalize_fwd_kernel(
     const float* psum, const float* psq, SegInfo si, const double* gsum, const float* gamma, const float* beta,
     float* running_mean, float* running_var, int64_t* nbt, int update_running, float* mean_o, float* invstd_o,
     float* scale_o, float* shift_o) {
-    __shared__ double red[2][PC_MAX_SEG][FIN_LANES][FIN_COLS];
+    __shared__ double red[FIN4_WAVES][2][PC_MAX_SEG][FIN_COLS];
     __shared__ float seg_mean[PC_MAX_SEG][FIN_COLS], seg_unb[PC_MAX_SEG][FIN_COLS];
     __shared__ int seg_live[PC_MAX_SEG][FIN_COLS];
-    const int j = blockIdx.x * FIN_COLS + threadIdx.x, q = threadIdx.y;
+    const int tid = threadIdx.y * FIN4_CG + threadIdx.x;
     double a = 0.0, b = 0.0;
-    if (!gsum) fold_partials_all(psum, psq, si, j, q, red, &a, &b);
-    if (q < PC_MAX_SEG) {
-        const int s = q;
+    if (!gsum) fold_partials_all4(psum, psq, si, blockIdx.x * FIN_COLS, red, &a, &b);
+    if (tid < PC_MAX_SEG * FIN_COLS) {
+        const int s = tid / FIN_COLS, col = tid % FIN_COLS, j = blockIdx.x * FIN_COLS + col;
         double n = s < si.nseg ? (double)si.count[s] : 0.0;   // logical rows (a weighted row counts wmult times)
         if (gsum && s < si.nseg) { a = gsum[(2 * s) * PC_H + j]; b = gsum[(2 * s + 1) * PC_H + j]; n = gsum[2 * PC_MAX_SEG * PC_H + s]; }
         int live = 0;
@@ -155,21 +168,22 @@ __global__ __launch_bounds__(FIN_COLS * FIN_LANES) void bn_finalize_fwd_kernel(
             invstd_o[s * PC_H + j] = is;
             scale_o[s * PC_H + j] = sc;
             shift_o[s * PC_H + j] = beta[j] - mf * sc;
-            seg_mean[s][threadIdx.x] = mf;
-            seg_unb[s][threadIdx.x] = n > 1 ? (float)(var * (n / (n - 1))) : vf;
+            seg_mean[s][col] = mf;
+            seg_unb[s][col] = n > 1 ? (float)(var * (n / (n - 1))) : vf;
             live = 1;
         }
-        seg_live[s][threadIdx.x] = live;
+        seg_live[s][col] = live;
     }
     __syncthreads();
-    if (q == 0 && update_running) {
+    if (tid < FIN_COLS && update_running) {
         // nn.BatchNorm1d updates its buffers once per CALL: the segments in call order (product2vec.py:132-134)
+        const int j = blockIdx.x * FIN_COLS + tid;
         float rm = running_mean[j], rv = running_var[j];
         int nseen = 0;
         for (int s = 0; s < si.nseg; s++) {
-            if (!seg_live[s][threadIdx.x]) continue;
-            rm = BN_MOMENTUM * seg_mean[s][threadIdx.x] + (1.0f - BN_MOMENTUM) * rm;
-            rv = BN_MOMENTUM * seg_unb[s][threadIdx.x] + (1.0f - BN_MOMENTUM) * rv;
+            if (!seg_live[s][tid]) continue;
+            rm = BN_MOMENTUM * seg_mean[s][tid] + (1.0f - BN_MOMENTUM) * rm;
+            rv = BN_MOMENTUM * seg_unb[s][tid] + (1.0f - BN_MOMENTUM) * rv;
             nseen++;
         }
         running_mean[j] = rm;
@@ -190,16 +204,16 @@ __global__ void bn_eval_coeff_kernel(const float* gamma, const float* beta, cons
 // per-tile (sum dz1, sum dz1*h0) -> dgamma, dbeta (+ per-segment means c1 = dbeta_s/n, c2 = dgamma_s/n)
 // (round 6: one pass over all segments like the forward finalize, 32 tile lanes, on the step's own queue -- 3 us between dZ1 and
 // dW3 instead of 12-32 us on the side queue plus the two cross-queue hops, ~6.5 us each on the main queue)
-__global__ __launch_bounds__(FIN_COLS * FIN_LANES) void bn_finalize_bwd_kernel(
+__global__ __launch_bounds__(FIN4_CG * FIN4_LANES) void bn_finalize_bwd_kernel(
     const float* psum, const float* pdot, SegInfo si, const double* lsum, const double* gsum, const float* mean,
     const float* invstd, float* dgamma, float* dbeta, int accumulate, float* c1, float* c2) {
-    __shared__ double red[2][PC_MAX_SEG][FIN_LANES][FIN_COLS];
+    __shared__ double red[FIN4_WAVES][2][PC_MAX_SEG][FIN_COLS];
     __shared__ double seg_g[PC_MAX_SEG][FIN_COLS], seg_b[PC_MAX_SEG][FIN_COLS];
-    const int j = blockIdx.x * FIN_COLS + threadIdx.x, q = threadIdx.y;
+    const int tid = threadIdx.y * FIN4_CG + threadIdx.x;
     double a = 0.0, b = 0.0;
-    if (!lsum) fold_partials_all(psum, pdot, si, j, q, red, &a, &b);
-    if (q < PC_MAX_SEG) {
-        const int s = q;
+    if (!lsum) fold_partials_all4(psum, pdot, si, blockIdx.x * FIN_COLS, red, &a, &b);
+    if (tid < PC_MAX_SEG * FIN_COLS) {
+        const int s = tid / FIN_COLS, col = tid % FIN_COLS, j = blockIdx.x * FIN_COLS + col;
         double tg = 0.0, tb = 0.0;
         if (s < si.nseg) {
             double n = si.count[s];                           // logical rows (a weighted row counts wmult times)
@@ -218,13 +232,14 @@ __global__ __launch_bounds__(FIN_COLS * FIN_LANES) void bn_finalize_bwd_kernel(
             c1[s * PC_H + j] = n > 0 ? (float)(ga / n) : 0.f;
             c2[s * PC_H + j] = n > 0 ? (float)(gb / n) : 0.f;
         }
-        seg_g[s][threadIdx.x] = tg;
-        seg_b[s][threadIdx.x] = tb;
+        seg_g[s][col] = tg;
+        seg_b[s][col] = tb;
     }
     __syncthreads();
-    if (q == 0) {
+    if (tid < FIN_COLS) {
+        const int j = blockIdx.x * FIN_COLS + tid;
         double tg = 0.0, tb = 0.0;
-        for (int s = 0; s < si.nseg; s++) { tg += seg_g[s][threadIdx.x]; tb += seg_b[s][threadIdx.x]; }     // segment order, as before
+        for (int s = 0; s < si.nseg; s++) { tg += seg_g[s][tid]; tb += seg_b[s][tid]; }     // segment order, as before
         dgamma[j] = accumulate ? dgamma[j] + (float)tg : (float)tg;
         dbeta[j] = accumulate ? dbeta[j] + (float)tb : (float)tb;
     }
@@ -397,7 +412,7 @@ int ffn_forward_part2(const pc_p2v_tensors* p, int rows, const pc_segments* seg,
     hipStream_t st = (hipStream_t)stream;
     const SegInfo si = make_seginfo(seg, rows, 128);
     FfnWs w = ffn_ws_layout(ws, rows);
-    PC_LAUNCH(bn_finalize_fwd_kernel, dim3(PC_H / FIN_COLS), dim3(FIN_COLS, FIN_LANES), 0, st, w.stat_a, w.stat_b, si, global_sums,
+    PC_LAUNCH(bn_finalize_fwd_kernel, dim3(PC_H / FIN_COLS), dim3(FIN4_CG, FIN4_LANES), 0, st, w.stat_a, w.stat_b, si, global_sums,
               p->gamma, p->beta, p->running_mean, p->running_var, p->num_batches_tracked, update_running,
               sv->bn_mean, sv->bn_invstd, sv->bn_scale, sv->bn_shift);
     PC_TRY(pc_launch_status());
@@ -511,12 +526,12 @@ int ffn_backward_part1(const pc_p2v_tensors* p, const pc_p2v_tensors* g, const f
         // Round 6: 3 us on the step's own queue, between dZ1 and dW3 (pc_get_option(PC_OPT_BN_FINALIZE_SIDE) = 1: the old placement)
         if (pc_opt_bn_finalize_side()) {
             PC_TRY(pc_fork_begin(df->fork, 1, st));
-            PC_LAUNCH(bn_finalize_bwd_kernel, dim3(PC_H / FIN_COLS), dim3(FIN_COLS, FIN_LANES), 0, df->fork->side, w.stat_a, w.stat_b, si,
+            PC_LAUNCH(bn_finalize_bwd_kernel, dim3(PC_H / FIN_COLS), dim3(FIN4_CG, FIN4_LANES), 0, df->fork->side, w.stat_a, w.stat_b, si,
                       nullptr, nullptr, sv->bn_mean, sv->bn_invstd, g->gamma, g->beta, accumulate, w.c1, w.c2);
             PC_TRY(pc_launch_status());
             df->bn_finalized = 1;
         } else {
-            PC_LAUNCH(bn_finalize_bwd_kernel, dim3(PC_H / FIN_COLS), dim3(FIN_COLS, FIN_LANES), 0, st, w.stat_a, w.stat_b, si,
+            PC_LAUNCH(bn_finalize_bwd_kernel, dim3(PC_H / FIN_COLS), dim3(FIN4_CG, FIN4_LANES), 0, st, w.stat_a, w.stat_b, si,
                       nullptr, nullptr, sv->bn_mean, sv->bn_invstd, g->gamma, g->beta, accumulate, w.c1, w.c2);
             PC_TRY(pc_launch_status());
             df->bn_finalized = 2;                            // done, on the step's queue: nothing to join
@@ -568,7 +583,7 @@ int ffn_backward_part2(const pc_p2v_tensors* g, const float* table, const int32_
         if (local_sums || global_sums) return PC_EINVAL;
         if (defer->bn_finalized == 1) PC_TRY(pc_fork_join(defer->fork, 0, st));      // part 1 ran the finalize on the side queue
     } else {
-        PC_LAUNCH(bn_finalize_bwd_kernel, dim3(PC_H / FIN_COLS), dim3(FIN_COLS, FIN_LANES), 0, st, w.stat_a, w.stat_b, si, local_sums,
+        PC_LAUNCH(bn_finalize_bwd_kernel, dim3(PC_H / FIN_COLS), dim3(FIN4_CG, FIN4_LANES), 0, st, w.stat_a, w.stat_b, si, local_sums,
                   global_sums, sv->bn_mean, sv->bn_invstd, g->gamma, g->beta, accumulate, w.c1, w.c2);
         PC_TRY(pc_launch_status());
     }

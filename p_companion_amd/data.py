@@ -299,6 +299,8 @@ class SimilarityIndexLoader:
             # (anchor + positive + k negatives + a full neighbour list per sample, + the padding row), not for this rank's first one
             max_ids = self.batch_size * (2 + k_neg + self._max_deg) + 1
             sharded.agree_capacity(sharded.capacity_for(max_ids, sharded.world))     # MAX over the ranks: a split size of the exchange
+        if sharded is not None and getattr(sharded, "hot_rows", 0):
+            sharded.build_hot_replica()          # (a collective, once: the replicated hot set of the Zipf head, before the first lookup)
         if negatives == "zipf":
             # the rejection sampler needs k_neg eligible products for every anchor (not itself, not one of its positives)
             max_pos = self._max_deg if self._on_device else (int(np.diff(bpg.sim_rowptr).max()) if len(bpg.sim_rowptr) > 1 else 0)

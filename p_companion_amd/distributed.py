@@ -300,11 +300,19 @@ class ShardedFeatureTable:
     lookup(ids): general-purpose variant for arbitrary id tensors (tools, tests): de-duplicates, exact sizes, but
     reads the bucket sizes back to the host.
 
+    HOT SET (hot_rows = H > 0; BASELINE configs[4]: Zipf-skewed negatives): the H most popular products -- `hot_ids`
+    (ascending product ids; None = the ids below H: popularity rank = product id, the Zipf sampler's default) -- are
+    REPLICATED on every rank: fetched once at construction through the same constant-shape exchange (build_hot_replica, a
+    collective), kept as a [H, D] tensor, and copied behind every batch's exchange buffer as rows [G*C, G*C + H) of the
+    table the step reads.  pc_shard_bucket_hot maps an id of the set there instead of giving it a request slot: the
+    request lists lose the Zipf head (37 % of all negative draws at H = 1024 over 100 M products), the wire with them; the
+    rows the batch's indices resolve to are the same bits.  `hot_served` counts the entries served from the replica.
+
     `gather_fn(local_table, idx_int32)` / `bucket_fn(...)`: the owner-side row gather and the bucketing -- the HIP
     kernels on the GPU; the CPU tests inject their own (test infrastructure only -- the product never falls back)."""
 
     def __init__(self, local_rows, num_products, rank, world, gather_fn=None, group=None, capacity=None, bucket_fn=None,
-                 exchange=None):
+                 exchange=None, hot_rows=0, hot_ids=None):
         self.local = local_rows
         self.P, self.rank, self.world, self.group = int(num_products), rank, world, group
         # the two lookup rounds go where the step's gradient exchange goes (make_exchange: ONE communicator per step); without
@@ -320,10 +328,29 @@ class ShardedFeatureTable:
         self.capacity = capacity                 # rows per peer and step; None: sized from the first batch
         self._bufs = None
         self.bytes_per_peer = None
+        self.hot_rows = int(hot_rows)
+        if self.hot_rows < 0 or self.hot_rows > self.P:
+            raise ValueError("hot_rows: between 0 and the number of products")
+        self.hot_ids = None
+        if hot_ids is not None:
+            hot_ids = torch.as_tensor(hot_ids, dtype=torch.int32, device=local_rows.device).contiguous()
+            if hot_ids.numel() != self.hot_rows or (hot_ids.numel() > 1 and bool((hot_ids[1:] <= hot_ids[:-1]).any())):
+                raise ValueError("hot_ids: hot_rows distinct product ids in ascending order")
+            self.hot_ids = hot_ids
+        self.hot_replica = None                  # [H, D]: built by build_hot_replica() (a collective) before the first lookup
+        self.hot_served = None
 
     @staticmethod
     def shard(full_table, rank, world):
         return full_table[rank::world].contiguous()
+
+    @staticmethod
+    def hot_ids_from_popularity(popularity, hot_rows):
+        """The hot set of a popularity permutation (product id per popularity rank, what SimilarityIndexLoader(negatives='zipf',
+        popularity=...) samples over): its first hot_rows entries, ascending.  None for the identity ranking (ids below hot_rows)."""
+        if popularity is None:
+            return None
+        return torch.sort(torch.as_tensor(popularity)[:int(hot_rows)].to(torch.int32)).values
 
     @staticmethod
     def capacity_for(ids_per_step, world, slack=1.25):
@@ -361,8 +388,45 @@ class ShardedFeatureTable:
             self.bytes_per_peer = {"request_ids": 4 * C, "rows": 4 * C * self.local.shape[1]}
         return self._bufs
 
+    def build_hot_replica(self):
+        """The replica of the hot set on this rank: the H rows fetched once through the table's own constant-shape exchange
+        (bucket without a hot set, two all-to-all rounds, owner-side gather).  A COLLECTIVE: every rank calls it, at the same
+        point, before the first lookup_batch (SimilarityIndexLoader does at construction)."""
+        H = self.hot_rows
+        if H == 0 or self.hot_replica is not None:
+            return self.hot_replica
+        dev = self.local.device
+        ids = self.hot_ids if self.hot_ids is not None else torch.arange(H, dtype=torch.int32, device=dev)
+        G = self.world
+        C = H                                        # (every rank's H requests fit one owner's bucket whatever the set)
+        i32 = lambda n: torch.zeros(n, dtype=torch.int32, device=dev)
+        counts, send_ids, overflow = i32(G), i32(G * C), i32(1)
+        (remap,) = self.bucket_fn([(ids, None, 0)], G, C, counts, send_ids, overflow)
+        req = torch.empty_like(send_ids)
+        if collectives_on(G):
+            self.collectives.all_to_all(send_ids, req)
+        else:
+            req.copy_(send_ids)
+        rows_out = self.gather_fn(self.local, req)
+        tab = torch.empty_like(rows_out)
+        if collectives_on(G):
+            self.collectives.all_to_all(rows_out, tab)
+        else:
+            tab = rows_out
+        self.hot_replica = tab[remap.long()].contiguous()
+        self.hot_served = i32(1)
+        return self.hot_replica
+
+    def hot_rows_served(self) -> int:
+        """Entries served from the replica since the last call (synchronises)."""
+        if self.hot_served is None:
+            return 0
+        n = int(self.hot_served.item())
+        self.hot_served.zero_()
+        return n
+
     def lookup_batch(self, batch):
-        """Index batch over GLOBAL product ids -> (table of the rows this rank asked for, [G*C, D]; the same batch over
+        """Index batch over GLOBAL product ids -> (table of the rows this rank asked for, [G*C (+ H), D]; the same batch over
         that table).  Unique / compact neighbour layouts; asynchronous."""
         nbc = batch["neighbor_compact"]
         uq = "weight" in nbc
@@ -372,20 +436,30 @@ class ShardedFeatureTable:
         nb_rows = nbc["nb_rows"]
         n_live = nbc.get("n_unique_dev") if uq else None                      # [1] int32 on the device: rows 0..n_unique are live
         bufs = self._buffers(2 * B + B * K + nb_rows.numel(), dev)
-        G, C = self.world, self.capacity
-        outs = self.bucket_fn([(a, None, 0), (nb_rows, n_live, 1), (p, None, 0), (ng.reshape(-1), None, 0)], G, C,
-                              bufs["counts"], bufs["send_ids"], bufs["overflow"])
+        G, C, H = self.world, self.capacity, self.hot_rows
+        jobs = [(a, None, 0), (nb_rows, n_live, 1), (p, None, 0), (ng.reshape(-1), None, 0)]
+        if H:
+            if self.hot_replica is None:
+                raise RuntimeError("ShardedFeatureTable(hot_rows=...): call build_hot_replica() (a collective) before the first lookup")
+            outs = self.bucket_fn(jobs, G, C, bufs["counts"], bufs["send_ids"], bufs["overflow"], hot_rows=H, hot_ids=self.hot_ids,
+                                  hot_served=self.hot_served)
+        else:
+            outs = self.bucket_fn(jobs, G, C, bufs["counts"], bufs["send_ids"], bufs["overflow"])
         req = torch.empty_like(bufs["send_ids"])
         if collectives_on(G):
             self.collectives.all_to_all(bufs["send_ids"], req)                    # equal splits: C int32 per peer
         else:
             req.copy_(bufs["send_ids"])
         rows_out = self.gather_fn(self.local, req)                                # -1 -> zero row
-        tab = torch.empty_like(rows_out)
+        # the table the step reads: the exchange buffer [G*C, D], then the hot replica [H, D]
+        full = torch.empty(G * C + H, rows_out.shape[1], dtype=rows_out.dtype, device=dev) if (H or collectives_on(G)) else None
         if collectives_on(G):
-            self.collectives.all_to_all(rows_out, tab)                            # C x D fp32 per peer
-        else:
-            tab = rows_out
+            self.collectives.all_to_all(rows_out, full[:G * C])                   # C x D fp32 per peer
+        elif H:
+            full[:G * C].copy_(rows_out)
+        if H:
+            full[G * C:].copy_(self.hot_replica)
+        tab = full if full is not None else rows_out
         out = {"anchor_idx": outs[0], "positive_idx": outs[2], "negative_idx": outs[3].view(B, K),
                "neighbor_compact": dict({"nb_rows": outs[1], "slot_row": nbc["slot_row"]},
                                         **({k: nbc[k] for k in ("weight", "n_unique", "n_unique_dev", "ref_off", "ref_slot", "n_real")

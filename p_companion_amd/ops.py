@@ -1341,9 +1341,11 @@ def sample_negatives_zipf(pair_ids, graph, k_neg, seed, step, thresholds, perm=N
     return ng
 
 
-def shard_bucket(arrays, world, capacity, counts, send_ids, overflow):
-    """pc_shard_bucket.  arrays: up to four (ids int32 tensor, live-length device tensor or None, add) triples; returns
-    the remapped index tensors (same shapes).  counts [world], send_ids [world*capacity], overflow [1]: int32 device."""
+def shard_bucket(arrays, world, capacity, counts, send_ids, overflow, hot_rows=0, hot_ids=None, hot_served=None):
+    """pc_shard_bucket[_hot].  arrays: up to four (ids int32 tensor, live-length device tensor or None, add) triples; returns
+    the remapped index tensors (same shapes).  counts [world], send_ids [world*capacity], overflow [1]: int32 device.
+    hot_rows > 0: ids of the replicated hot set (hot_ids ascending [hot_rows] int32, None = the ids below hot_rows) map to
+    world * capacity + their position in the set and take no request slot; hot_served [1] int32 counts them."""
     n = len(arrays)
     if not 1 <= n <= 4:
         raise ValueError("1..4 id arrays per launch")
@@ -1355,6 +1357,14 @@ def shard_bucket(arrays, world, capacity, counts, send_ids, overflow):
     ndev = (ctypes.c_void_p * n)(*[(_req(d, torch.int32, "live length").data_ptr() if d is not None else None) for _, d, _ in arrays])
     nadd = (ctypes.c_int * n)(*[int(a) for _, _, a in arrays])
     optrs = (ctypes.c_void_p * n)(*[o.data_ptr() for o in outs])
+    if hot_rows:
+        if hot_ids is not None:
+            _req(hot_ids, torch.int32, "hot_ids", (int(hot_rows),))
+        if hot_served is not None:
+            _req(hot_served, torch.int32, "hot_served", (1,))
+        check(_lib.lib().pc_shard_bucket_hot(ptrs, lens, ndev, nadd, optrs, n, int(world), int(capacity), _p(hot_ids), int(hot_rows),
+                                             _p(counts), _p(send_ids), _p(overflow), _p(hot_served), _stream()), "pc_shard_bucket_hot")
+        return outs
     check(_lib.lib().pc_shard_bucket(ptrs, lens, ndev, nadd, optrs, n, int(world), int(capacity), _p(counts), _p(send_ids),
                                      _p(overflow), _stream()), "pc_shard_bucket")
     return outs

@@ -52,7 +52,8 @@ def main():
         res.update(ok=bool(worst == 0.0 and sharded.overflowed() == 0), worst=worst, steps=steps,
                    capacity=sharded.capacity, bytes_per_peer=sharded.bytes_per_peer)
         res["sharded_optimizer"] = sharded_optimizer_check(rank, dev)
-        res["ok"] = bool(res["ok"] and res["sharded_optimizer"]["ok"])
+        res["hot_set"] = hot_set_check(rank, dev, bpg, table)
+        res["ok"] = bool(res["ok"] and res["sharded_optimizer"]["ok"] and res["hot_set"]["ok"])
         dist.barrier()
         dist.destroy_process_group()
     except Exception as e:                                       # noqa: BLE001 -- reported to the parent test
@@ -61,6 +62,44 @@ def main():
         res["ok"] = False
     with open(out, "w") as f:
         json.dump(res, f)
+
+
+def hot_set_check(rank, dev, bpg, table):
+    """The replicated hot set at world 2 (two ranks on the one card, gloo): Zipf negatives, the 512 most popular products
+    replicated on both ranks.  Against the same loader without the hot set: the rows the batch resolves to and the fused step's
+    loss / gradients bit for bit, the request lists shorter by exactly the entries the replica served."""
+    from types import SimpleNamespace
+    import torch
+    from p_companion_amd import distributed as pdist
+    from p_companion_amd.data import SimilarityIndexLoader
+    from p_companion_amd.product2vec import Product2Vec
+    H = 512
+    cfg = SimpleNamespace(PRODUCT_EMB_DIM=128, TYPE_EMB_DIM=64, HIDDEN_SIZE=256, NUM_ATTENTION_HEADS=4, DROPOUT=0.0, MARGIN=1.0, DEVICE=dev)
+    local = pdist.ShardedFeatureTable.shard(table, rank, 2)
+    plain = pdist.ShardedFeatureTable(local, bpg.num_products, rank, 2)
+    hot = pdist.ShardedFeatureTable(local, bpg.num_products, rank, 2, hot_rows=H)
+    mk = lambda sh: SimilarityIndexLoader(bpg, 1024, seed=7 + rank, drop_last=True, device=dev, sharded=sh, negatives="zipf", prefetch=False)
+    ld_p, ld_h = mk(plain), mk(hot)                               # (capacity agreement + build_hot_replica: collectives, both ranks)
+    same = torch.equal(hot.hot_replica, table[:H])
+    torch.manual_seed(0)
+    m_p, m_h = Product2Vec(cfg).to(dev).train(), Product2Vec(cfg).to(dev).train()
+    m_h.load_state_dict(m_p.state_dict())
+    zrow = torch.zeros(1, 128, device=dev)
+    served_sum = saved_sum = 0
+    for n, (bp, bh) in enumerate(zip(ld_p, ld_h)):
+        used_p, used_h = int(plain._bufs["counts"].sum()), int(hot._bufs["counts"].sum())
+        ep, eh = torch.cat([bp["table"], zrow]), torch.cat([bh["table"], zrow])
+        for k in ("anchor_idx", "positive_idx", "negative_idx"):
+            same = same and torch.equal(eh[bh[k].long()], ep[bp[k].long()])
+        served = hot.hot_rows_served()
+        served_sum += served
+        saved_sum += used_p - used_h
+        lp, lh = m_p.train_step_indexed(bp["table"], bp), m_h.train_step_indexed(bh["table"], bh)
+        same = same and torch.equal(lp, lh) and torch.equal(m_p.flatten_parameters()[1], m_h.flatten_parameters()[1])
+        if n == 2:
+            break
+    return {"ok": bool(same and served_sum == saved_sum > 0 and hot.overflowed() == 0), "same": bool(same), "served": served_sum,
+            "request_slots_saved": saved_sum, "table_rows": int(bh["table"].shape[0]), "capacity": int(hot.capacity)}
 
 
 def sharded_optimizer_check(rank, dev):

@@ -20,9 +20,10 @@ def _cpu_gather(table, idx):
     return table[idx.long()]
 
 
-def _cpu_bucket(arrays, G, C, counts, send_ids, overflow):
-    """Test-side restatement of pc_shard_bucket's contract (include/pcompanion_hip.h) for CPU tensors."""
+def _cpu_bucket(arrays, G, C, counts, send_ids, overflow, hot_rows=0, hot_ids=None, hot_served=None):
+    """Test-side restatement of pc_shard_bucket[_hot]'s contract (include/pcompanion_hip.h) for CPU tensors."""
     counts.zero_(); send_ids.fill_(-1)
+    hot = {int(v): k for k, v in enumerate(hot_ids.tolist())} if hot_ids is not None else None
     outs = []
     for ids, n_dev, add in arrays:
         live = ids.numel() if n_dev is None else min(ids.numel(), int(n_dev) + add)
@@ -30,6 +31,12 @@ def _cpu_bucket(arrays, G, C, counts, send_ids, overflow):
         for pos in range(live):
             i = int(ids[pos])
             if i < 0:
+                continue
+            hs = (hot.get(i, -1) if hot is not None else (i if i < hot_rows else -1)) if hot_rows else -1
+            if hs >= 0:                                          # the replicated hot set: no request slot
+                out[pos] = G * C + hs
+                if hot_served is not None:
+                    hot_served += 1
                 continue
             o = i % G
             slot = int(counts[o]); counts[o] += 1
@@ -85,6 +92,36 @@ def _worker(rank, world, port, q):
     ok = ok and torch.equal(ext2[nbr[:41].long()], wantf[batch["neighbor_compact"]["nb_rows"][:41].long()])
     ok = ok and bool((nbr[41:] == -1).all()) and int(nbr[40]) == -1
     ok = ok and tab2.bytes_per_peer == {"request_ids": 4 * tab2.capacity, "rows": 64 * tab2.capacity}
+    # the replicated hot set (configs[4]): ids of the set are served from the local replica behind the exchange buffer -- the
+    # rows every index resolves to are the same bits, the request lists are shorter by exactly the entries served
+    zg = lambda t, i: torch.cat([t, torch.zeros(1, 16)])[i.long()]
+    for hot_ids in (None, torch.tensor(sorted([5, 999, 17, 400, 401, 402, 3, 250]), dtype=torch.int32)):
+        H = 64 if hot_ids is None else hot_ids.numel()
+        hb = {k: (v.clone() if torch.is_tensor(v) else dict(v)) for k, v in batch.items()}
+        hot_list = list(range(H)) if hot_ids is None else hot_ids.tolist()
+        hb["negative_idx"][:, 0] = torch.tensor([hot_list[i % H] for i in range(B)], dtype=torch.int32)     # a Zipf-like head
+        hb["anchor_idx"][:3] = torch.tensor(hot_list[:3], dtype=torch.int32)
+        plain = pdist.ShardedFeatureTable(pdist.ShardedFeatureTable.shard(full, rank, world), 1000, rank, world, gather_fn=zg,
+                                          bucket_fn=_cpu_bucket, capacity=tab2.capacity)
+        hot = pdist.ShardedFeatureTable(pdist.ShardedFeatureTable.shard(full, rank, world), 1000, rank, world, gather_fn=zg,
+                                        bucket_fn=_cpu_bucket, capacity=tab2.capacity, hot_rows=H, hot_ids=hot_ids)
+        rep = hot.build_hot_replica()                            # a collective: both ranks
+        ok = ok and torch.equal(rep, full[torch.tensor(hot_list).long()])
+        rows_p, rb_p = plain.lookup_batch(hb)
+        used_p = int(plain._bufs["counts"].sum())
+        rows_h, rb_h = hot.lookup_batch(hb)
+        used_h = int(hot._bufs["counts"].sum())
+        ok = ok and rows_h.shape == (world * hot.capacity + H, 16) and rows_p.shape == (world * plain.capacity, 16)
+        ext_p, ext_h = torch.cat([rows_p, torch.zeros(1, 16)]), torch.cat([rows_h, torch.zeros(1, 16)])
+        for k in ("anchor_idx", "positive_idx", "negative_idx"):
+            ok = ok and torch.equal(ext_h[rb_h[k].long()], ext_p[rb_p[k].long()])
+            ok = ok and torch.equal(ext_h[rb_h[k].long()], wantf[hb[k].long()])
+        ok = ok and torch.equal(ext_h[rb_h["neighbor_compact"]["nb_rows"][:41].long()], wantf[hb["neighbor_compact"]["nb_rows"][:41].long()])
+        served = hot.hot_rows_served()
+        in_set = sum(int(x) in set(hot_list) for k in ("anchor_idx", "positive_idx", "negative_idx") for x in hb[k].reshape(-1).tolist())
+        in_set += sum(int(x) in set(hot_list) for x in hb["neighbor_compact"]["nb_rows"][:41].tolist())
+        ok = ok and served == in_set >= B + 3 and used_p - used_h == served and hot.hot_rows_served() == 0
+        ok = ok and hot.overflowed() == 0 and bool((rb_h["negative_idx"][:, 0] >= world * hot.capacity).all())
     grad = torch.full((10,), float(rank + 1))
     pdist.all_reduce_mean_(grad, world)
     ok = ok and torch.allclose(grad, torch.full((10,), (1 + world) / 2))

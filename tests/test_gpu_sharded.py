@@ -129,3 +129,65 @@ def test_sharded_step_world2_on_one_card(world2_job):
         so = r["sharded_optimizer"]
         assert so["ok"] and so["same"] and so["moments_outside_own_half"] == 0.0 and so["ranks_equal"], so
         assert so["steps"] == 7 and so["flat"] == so["real"]
+        # the replicated hot set under the sharded table at world 2: same rows, same step, shorter request lists
+        hs = r["hot_set"]
+        assert hs["ok"] and hs["same"] and hs["served"] == hs["request_slots_saved"] > 0 and hs["table_rows"] == 2 * hs["capacity"] + 512, hs
+
+
+@pytest.mark.parametrize("popularity", ["identity", "permuted"])
+def test_hot_set_serves_the_zipf_head_from_the_replica(popularity):
+    """BASELINE configs[4]'s hot rows: the H most popular products replicated behind the exchange buffer
+    (pc_shard_bucket_hot).  Same loader seed with and without the hot set: identical id batches, the rows every index of the
+    batch resolves to are bit-identical, the fused step's loss and gradients are bit-identical, and the request lists shrink
+    by exactly the entries served -- the Zipf head's share of the negatives (about a third at H = 1024 over 200 k products)."""
+    from p_companion_amd import distributed as pdist
+    from p_companion_amd.data import SimilarityIndexLoader, generate_scaled_bpg
+    from p_companion_amd.product2vec import Product2Vec
+    P, B, H = 200_000, 2048, 1024
+    bpg = generate_scaled_bpg(P, 100, seed=2)
+    table = bpg.cuda()["features"]
+    pop = None
+    if popularity == "permuted":
+        pop = torch.randperm(P, generator=torch.Generator().manual_seed(11)).to(torch.int32)
+    hot_ids = pdist.ShardedFeatureTable.hot_ids_from_popularity(pop, H)
+    plain = pdist.ShardedFeatureTable(table, P, 0, 1)
+    hot = pdist.ShardedFeatureTable(table, P, 0, 1, hot_rows=H, hot_ids=hot_ids)
+    mk = lambda sh: SimilarityIndexLoader(bpg, B, seed=3, drop_last=True, sharded=sh, negatives="zipf",
+                                          popularity=None if pop is None else pop.numpy(), prefetch=False)
+    ld_p, ld_h = mk(plain), mk(hot)
+    want_rep = table[(hot_ids if hot_ids is not None else torch.arange(H)).long().cuda()]
+    assert torch.equal(hot.hot_replica, want_rep)                                # built at the loader's construction
+    torch.manual_seed(0)
+    m_p, m_h = Product2Vec(cfg()).cuda().train(), Product2Vec(cfg()).cuda().train()
+    m_h.load_state_dict(m_p.state_dict())
+    zrow = torch.zeros(1, 128, device="cuda")
+    served_total = neg_total = 0
+    for n, (bp, bh) in enumerate(zip(ld_p, ld_h)):
+        used_p, used_h = int(plain._bufs["counts"].sum()), int(hot._bufs["counts"].sum())
+        assert bh["table"].shape[0] == hot.capacity + H and bp["table"].shape[0] == plain.capacity
+        assert torch.equal(bh["table"][hot.capacity:], want_rep)
+        ep, eh = torch.cat([bp["table"], zrow]), torch.cat([bh["table"], zrow])
+        for k in ("anchor_idx", "positive_idx", "negative_idx"):
+            assert torch.equal(eh[bh[k].long()], ep[bp[k].long()]), k            # the same rows, bit for bit
+        nu = int(bp["neighbor_compact"]["n_unique"])
+        assert torch.equal(eh[bh["neighbor_compact"]["nb_rows"][:nu + 1].long()], ep[bp["neighbor_compact"]["nb_rows"][:nu + 1].long()])
+        served = hot.hot_rows_served()
+        assert used_p - used_h == served > 0                                     # request-list occupancy down by what the replica served
+        in_replica = int((bh["negative_idx"] >= hot.capacity).sum())
+        assert in_replica <= served
+        served_total += in_replica
+        neg_total += bh["negative_idx"].numel()
+        lp, lh = m_p.train_step_indexed(bp["table"], bp), m_h.train_step_indexed(bh["table"], bh)
+        assert torch.equal(lp, lh) and torch.equal(m_p.flatten_parameters()[1], m_h.flatten_parameters()[1])
+        if n == 2:
+            break
+    share = served_total / neg_total
+    # Zipf(1) over P ranks: P(rank <= H) = H_H / H_P = 7.51 / 12.78 = 0.59 of the PROPOSALS at P = 200 k (0.37 at 100 M); rejections
+    # (the anchor, its positives, duplicates within a sample's five) move it a little
+    assert 0.45 < share < 0.70, share
+    assert hot.overflowed() == 0 and plain.overflowed() == 0
+    with pytest.raises(ValueError):
+        pdist.ShardedFeatureTable(table, P, 0, 1, hot_rows=4, hot_ids=torch.tensor([3, 2, 1, 0]))
+    with pytest.raises(RuntimeError):
+        pdist.ShardedFeatureTable(table, P, 0, 1, hot_rows=4, capacity=plain.capacity).lookup_batch(
+            next(iter(SimilarityIndexLoader(bpg, B, seed=3, drop_last=True, prefetch=False))))
