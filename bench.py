@@ -453,6 +453,9 @@ def run_p2v(args, rank, world, dev, products, steps, warmup, want_cpu, profile_k
         tab = b.get("table", table)                       # sharded: the rows this batch's exchange delivered
         sync = ((exchange.all_reduce_sum_f64_ if exchange is not None else (lambda t: torch.distributed.all_reduce(t)))
                 if (args.sync_bn and multi) else None)
+        if not multi:
+            # one process: optimizer.step() rides in the step's last gradient launch (pc_p2v_train_step_unique_adam)
+            return model.train_step_indexed(tab, b, profile=profile, optimizer=opt)
         loss = model.train_step_indexed(tab, b, profile=profile, sync_reduce=sync)
         if exchange is not None:
             opt.step(exchange=exchange)                   # pc_exchange_adam: the replicas' mean gradient + Adam, one foreign call
@@ -552,7 +555,9 @@ def run_p2v(args, rank, world, dev, products, steps, warmup, want_cpu, profile_k
         alg8d = bytes_per_triplet(n_avg, dim) * args.batch / (launches / max(profiled_steps, 1))
         step_pmc = committed_pmc(pmc_kind, lambda k: k == "_step_total")
         res["roofline"] = {
-            "bound": "mfma", "kernel": "gemm_nt_kernel",
+            # 1.7 kFLOP per gathered byte -- the contraction, not the gather, binds this step, so `frac` is the matrix-core
+            # fraction; which roof is nearer by the DESIGN's own per-launch activation bytes is `nearer_roof_by_design_bytes`
+            "bound": "mfma", "bound_basis": "SURVEY 8(d) algorithmic bytes and flops", "kernel": "gemm_nt_kernel",
             "achieved": round(tfl, 2), "peak": round(NT_PEAK_TFLOPS, 1), "unit": "TFLOP/s", "frac": round(fm, 4),
             "frac_mfma": round(fm, 4), "achieved_tflops": round(tfl, 2), "peak_tflops": round(NT_PEAK_TFLOPS, 1),
             "frac_of_fp32_mfma_peak": round(tfl / FP32_MFMA_PEAK_TFLOPS, 4),

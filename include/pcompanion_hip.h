@@ -549,6 +549,30 @@ int pc_joint_train_epoch(const pc_joint_tensors *p, const pc_joint_tensors *g, c
                          int num_products, float margin, float alpha, float *losses_out, int32_t *topk,
                          int32_t *bad_count, void *ws, size_t ws_bytes, void *stream);
 
+/* --- ABI 8: the optimizer step inside the Product2Vec step's last gradient launch.
+ * product2vec.py:156-158 is optimizer.zero_grad(); loss.backward(); optimizer.step(): the step functions above are the first two,
+ * pc_adam_step[_at] the third -- one more launch over 0.8 MB behind a step whose last kernel (the slab reduce of the weight
+ * gradients) has every gradient in hand.  With `adam` the reduce applies torch.optim.Adam's update to each parameter right
+ * behind its gradient (and rider workgroups to the parameters whose gradients other kernels finished): the same expressions as
+ * pc_adam_step_at(t), the same bits, one launch fewer.  adam->grad must be the flat buffer `g`'s tensors are views of,
+ * param / exp_avg / exp_avg_sq the buffers with the same offsets (n floats, n % 4 == 0, 16-byte aligned); t >= 1 the step number
+ * (the host's count: *step_count is set to t).  adam == NULL: pc_p2v_train_step_unique.  phase must be -1 (the unsplit step: a
+ * replica that exchanges gradients or BatchNorm sums between the phases keeps its optimizer step apart). */
+typedef struct pc_adam_fused {
+    float *param, *grad, *exp_avg, *exp_avg_sq;
+    size_t n;
+    int64_t *step_count;
+    int64_t t;
+    double lr, beta1, beta2, eps;
+} pc_adam_fused;
+int pc_p2v_train_step_unique_adam(const pc_p2v_tensors *p, const pc_p2v_tensors *g, const float *table,
+                                  const int32_t *anchor_idx, const int32_t *positive_idx,
+                                  const int32_t *negative_idx, const int32_t *nb_rows, const float *nb_weight,
+                                  int n_unique, const int32_t *slot_row, const int32_t *ref_off,
+                                  const int32_t *ref_slot, int batch, int n_nbr, int k_neg, float margin,
+                                  float *loss, float *d_pos, float *d_neg, float *anchor_emb, void *profile,
+                                  void *ws, size_t ws_bytes, const pc_adam_fused *adam, void *stream);
+
 /* ---------------------------------------------------------------------------------
  * Data-parallel replicas (the reference is single-process: train.py:46-48 is loss.backward(); optimizer.step()
  * with nothing between -- a replica of a data-parallel job averages the gradients there).  ABI 6.

@@ -69,6 +69,13 @@ _vp, _i, _sz, _f, _d, _u64, _i64 = (ctypes.c_void_p, ctypes.c_int, ctypes.c_size
                                     ctypes.c_double, ctypes.c_uint64, ctypes.c_int64)
 _P = ctypes.POINTER
 
+class AdamFused(ctypes.Structure):
+    """pc_adam_fused (ABI 8): torch.optim.Adam riding in the Product2Vec step's last gradient launch."""
+    _fields_ = [("param", ctypes.c_void_p), ("grad", ctypes.c_void_p), ("exp_avg", ctypes.c_void_p), ("exp_avg_sq", ctypes.c_void_p),
+                ("n", ctypes.c_size_t), ("step_count", ctypes.c_void_p), ("t", ctypes.c_int64),
+                ("lr", ctypes.c_double), ("beta1", ctypes.c_double), ("beta2", ctypes.c_double), ("eps", ctypes.c_double)]
+
+
 PC_OPT_SIDE_QUEUE = 1      # pc_set_option: the fused Product2Vec step's side queue (include/pcompanion_hip.h)
 PC_OPT_BN_FINALIZE_SIDE = 3          # ... the BatchNorm-backward finalize of the fused Product2Vec step on the side queue (default 0: on the step's own)
 PC_OPT_SORTED_TABLE_GRADIENTS = 2    # ... the [T,64] table gradients of the fused joint step through the sorted form wherever it fits (default 1)
@@ -101,6 +108,8 @@ SIGNATURES = {
                                _vp, _vp, _vp, _vp, _sz, _vp]),
     "pc_p2v_train_step_compact": (_i, [_P(P2VTensors), _P(P2VTensors), _vp, _vp, _vp, _vp, _vp, _i, _vp, _i, _i, _i, _f,
                                        _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "pc_p2v_train_step_unique_adam": (_i, [_P(P2VTensors), _P(P2VTensors), _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _i, _i,
+                                           _i, _f, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _P(AdamFused), _vp]),
     "pc_p2v_train_step_unique": (_i, [_P(P2VTensors), _P(P2VTensors), _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _i, _i,
                                       _i, _f, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _sz, _vp]),
     "pc_build_similarity_batch_unique_scratch_bytes": (_sz, [_i, _i]),

@@ -64,7 +64,13 @@ def kernel_resources():
     private_segment_fixed_size, lds (group_segment_fixed_size), unit}}.  Used by __graft_entry__.build() to refuse a build in
     which a product kernel spills vector registers to scratch."""
     import tempfile
-    import yaml
+    try:
+        import yaml
+    except ImportError as e:
+        raise RuntimeError("spill gate unavailable: PyYAML missing (the code objects' metadata note is YAML)") from e
+    for tool in ("llvm-objcopy", "clang-offload-bundler", "llvm-readelf"):
+        if not os.path.exists(os.path.join(LLVM_BIN, tool)):
+            raise RuntimeError(f"spill gate unavailable: {tool} missing under {LLVM_BIN}")
     out = {}
     with tempfile.TemporaryDirectory() as tmp:
         for s in sources():
@@ -76,7 +82,9 @@ def kernel_resources():
             r = subprocess.run([os.path.join(LLVM_BIN, "llvm-objcopy"), "--dump-section", ".hip_fatbin=" + fat, obj],
                                capture_output=True, text=True)
             if r.returncode != 0 or not os.path.exists(fat):
-                continue                                          # (a unit without device code)
+                if "hip_fatbin" in (r.stderr or "") or not os.path.exists(obj):
+                    continue                                      # (a unit without device code / not built: no section to dump)
+                raise RuntimeError(f"spill gate: llvm-objcopy failed on {obj}: {(r.stderr or '').strip()[:300]}")
             subprocess.run([os.path.join(LLVM_BIN, "clang-offload-bundler"), "--unbundle", "--type=o", "--input=" + fat,
                             "--targets=hipv4-amdgcn-amd-amdhsa--gfx950", "--output=" + co], check=True, capture_output=True)
             notes = subprocess.run([os.path.join(LLVM_BIN, "llvm-readelf"), "--notes", co], check=True, capture_output=True,

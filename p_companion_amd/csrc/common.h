@@ -424,9 +424,21 @@ size_t gemm_tn_workspace_floats(int R, int No, int Ni);
 #define PC_TN_RGROUP (PC_TN_GROUP + PC_TN_EXTRA + 4)      // + the four large FFN gradients when a step's reduces are deferred
 struct TnGroup { TnArgs a[PC_TN_GROUP]; int tiles_i[PC_TN_GROUP], nsplit[PC_TN_GROUP], rps[PC_TN_GROUP], block0[PC_TN_GROUP + 1], n; };
 struct TnReduceJob { const float* slabs; int nsplit, n; float* out; int accumulate; };   // out[n] (+)= sum of nsplit slabs of n floats
+// torch.optim.Adam riding in the step's LAST gradient launch (round 6; pc_p2v_train_step_unique_adam): every float4 of gradient the
+// slab reduce forms is followed, in the same thread, by the update of its parameter and moments (the flat buffers share offsets),
+// and rider workgroups behind the reduce blocks update the ranges no reduce job produces (biases and BatchNorm parameters other
+// kernels of the step finished earlier).  Same expressions as adam_at_kernel: same bits as the separate launch.
+#define PC_ADAM_REST 2 * (PC_TN_GROUP + PC_TN_EXTRA + 4) + 1
+struct AdamRider {
+    float *p, *m, *v; const float* g; size_t n;       // flat parameter / moment / gradient buffers (g: what the reduce jobs' outputs point into)
+    int64_t* step_count; long long t; double lr, beta1, beta2; float omb1, beta2f, omb2, eps;
+    int block0;                                       // first rider block of the launch
+    int n_rest, rest_lo[PC_ADAM_REST], rest_hi[PC_ADAM_REST], rest_block0[PC_ADAM_REST + 1];      // float offsets, multiples of 4
+};
 struct TnReduceGroup {
     const float* slabs[PC_TN_RGROUP]; float* dW[PC_TN_RGROUP]; float* db[PC_TN_RGROUP];
     int nsplit[PC_TN_RGROUP], n_w[PC_TN_RGROUP], n_b[PC_TN_RGROUP], accumulate[PC_TN_RGROUP], block0[PC_TN_RGROUP + 1], n;
+    AdamRider ad;                                     // ad.p == NULL: no optimizer rides
 };
 // A second queue for the few launches of the fused Product2Vec step that nothing on the main queue waits for until much
 // later: the attention block's ten few-row weight gradients (24 us, needed by the slab reduce at the end of the step) beside
@@ -441,12 +453,12 @@ int pc_fork_begin(PcFork* f, int i, hipStream_t main_st);    // the side queue c
 int pc_fork_mark(PcFork* f, int i);                          // a point on the side queue ...
 int pc_fork_wait(PcFork* f, int i, hipStream_t main_st);     // ... behind which main continues (the side queue may go on)
 int pc_fork_join(PcFork* f, int i, hipStream_t main_st);     // mark + wait, and nothing is pending afterwards
-struct TnDefer { TnReduceGroup r; int rblocks; PcFork* fork; int bn_finalized; };
+struct TnDefer { TnReduceGroup r; int rblocks; PcFork* fork; int bn_finalized; const pc_adam_fused* adam; };
 static_assert(sizeof(TnGroup) <= 4096, "kernel argument segment");
 int launch_gemm_tn_group(const TnArgs* args, int n, const TnReduceJob* extra, int n_extra, hipStream_t st,
                          TnDefer* defer = nullptr);
 int launch_tn_reduce_deferred(TnDefer* d, hipStream_t st);
-static inline void tn_defer_init(TnDefer* d) { d->r = TnReduceGroup{}; d->rblocks = 0; d->fork = nullptr; d->bn_finalized = 0; }
+static inline void tn_defer_init(TnDefer* d) { d->r = TnReduceGroup{}; d->rblocks = 0; d->fork = nullptr; d->bn_finalized = 0; d->adam = nullptr; }
 int scatter_add_slab_blocks(int table_rows, int rows, int width);
 int launch_scatter_add_slabs(const int32_t* idx, int rows, int width, int table_rows, const float* src, float* slabs,
                              hipStream_t st);

@@ -470,8 +470,22 @@ __global__ __launch_bounds__(64 * WO * WI, WO * WI / 4) void gemm_tn8_kernel(TnA
 // out[j] (+)= sum_s slabs[s][j], j over [No*Ni] then [No] (bias).  Eight lanes share one float4 of
 // outputs: lane g sums slabs g, g+8, ... and the eight partial sums fold in a fixed xor order
 // (bitwise reproducible), so a 256x256 gradient keeps ~500 workgroups streaming from HBM.
+__device__ __forceinline__ void adam_rider4(const AdamRider& ad, size_t off, const float4 gv, float step_size, float bc2s) {
+    float4 pv = *reinterpret_cast<float4*>(ad.p + off);
+    float4 mv = *reinterpret_cast<float4*>(ad.m + off);
+    float4 vv = *reinterpret_cast<float4*>(ad.v + off);
+    if (pc_adam_dead(gv, mv, vv)) return;                   // (as adam_at_kernel: g = m = v = 0 changes nothing)
+#define ADAM1(c) pc_adam_update(pv.c, mv.c, vv.c, gv.c, step_size, bc2s, ad.omb1, ad.beta2f, ad.omb2, ad.eps);
+    ADAM1(x) ADAM1(y) ADAM1(z) ADAM1(w)
+#undef ADAM1
+    *reinterpret_cast<float4*>(ad.p + off) = pv;
+    *reinterpret_cast<float4*>(ad.m + off) = mv;
+    *reinterpret_cast<float4*>(ad.v + off) = vv;
+}
+
 __device__ __forceinline__ void tn_reduce_body(const float* slabs, int nsplit, int n_w, int n_b, float* dW, float* db,
-                                               int accumulate, int bid) {
+                                               int accumulate, int bid, const AdamRider* ad = nullptr, float step_size = 0.f,
+                                               float bc2s = 0.f) {
     const int total4 = (n_w + (db ? n_b : 0)) / 4;          // n_w, n_b multiples of 4
     const int t = bid * blockDim.x + threadIdx.x;
     const int j4 = t >> 3, g = t & 7;
@@ -497,6 +511,7 @@ __device__ __forceinline__ void tn_reduce_body(const float* slabs, int nsplit, i
             s.x += old.x; s.y += old.y; s.z += old.z; s.w += old.w;
         }
         *reinterpret_cast<float4*>(dst) = s;
+        if (ad) adam_rider4(*ad, (size_t)(dst - ad->g), s, step_size, bc2s);      // the parameter right behind its gradient
     }
 }
 
@@ -505,11 +520,34 @@ __global__ __launch_bounds__(256) void tn_reduce_kernel(const float* slabs, int 
     tn_reduce_body(slabs, nsplit, n_w, n_b, dW, db, accumulate, blockIdx.x);
 }
 __global__ __launch_bounds__(256) void tn_reduce_group_kernel(TnReduceGroup g) {
+    __shared__ float sc[2];
     const int b = blockIdx.x;
+    const bool with_adam = g.ad.p != nullptr;
+    if (with_adam) {
+        if (threadIdx.x == 0) {                             // adam_at_kernel's scalars, the same fp64 expressions
+            const double bc1 = 1.0 - pow(g.ad.beta1, (double)g.ad.t);
+            const double bc2 = 1.0 - pow(g.ad.beta2, (double)g.ad.t);
+            sc[0] = (float)(g.ad.lr / bc1);
+            sc[1] = (float)sqrt(bc2);
+            if (b == 0 && g.ad.step_count) *g.ad.step_count = g.ad.t;
+        }
+        __syncthreads();
+        if (b >= g.ad.block0) {
+            // rider: a gradient range no reduce job of this launch produces (finished by earlier kernels of the step)
+            const int rb = b - g.ad.block0;
+            int r = 0;
+            for (int i = 1; i < g.ad.n_rest; i++) r += rb >= g.ad.rest_block0[i] ? 1 : 0;
+            const int off = g.ad.rest_lo[r] + ((rb - g.ad.rest_block0[r]) * 256 + (int)threadIdx.x) * 4;
+            if (off < g.ad.rest_hi[r])
+                adam_rider4(g.ad, (size_t)off, *reinterpret_cast<const float4*>(g.ad.g + off), sc[0], sc[1]);
+            return;
+        }
+    }
     int j = 0;
 #pragma unroll
     for (int i = 1; i < PC_TN_RGROUP; i++) j += (i < g.n && b >= g.block0[i]) ? 1 : 0;
-    tn_reduce_body(g.slabs[j], g.nsplit[j], g.n_w[j], g.n_b[j], g.dW[j], g.db[j], g.accumulate[j], b - g.block0[j]);
+    tn_reduce_body(g.slabs[j], g.nsplit[j], g.n_w[j], g.n_b[j], g.dW[j], g.db[j], g.accumulate[j], b - g.block0[j],
+                   with_adam ? &g.ad : nullptr, with_adam ? sc[0] : 0.f, with_adam ? sc[1] : 0.f);
 }
 
 static bool tn_full_tile(int R, int No, int Ni) {
@@ -735,9 +773,53 @@ int pc_fork_join(PcFork* f, int i, hipStream_t main_st) {
 int launch_tn_reduce_deferred(TnDefer* d, hipStream_t st) {
     if (!d) return PC_EINVAL;
     if (d->fork && d->fork->pending) PC_TRY(pc_fork_join(d->fork, 1, st));      // side-queue products: their slabs are summed here
-    if (d->r.n == 0) return PC_OK;
+    if (d->r.n == 0 && !d->adam) return PC_OK;
     for (int k = d->r.n; k <= PC_TN_RGROUP; k++) d->r.block0[k] = d->rblocks;
-    PC_LAUNCH(tn_reduce_group_kernel, dim3(d->rblocks), dim3(256), 0, st, d->r);
+    int blocks = d->rblocks;
+    if (d->adam) {
+        // the optimizer rides: every reduce output must lie in the flat gradient buffer; the ranges between them get rider blocks
+        const pc_adam_fused* a = d->adam;
+        if (!a->param || !a->grad || !a->exp_avg || !a->exp_avg_sq || a->n == 0 || a->n % 4 || a->t < 1 || a->n > 0x7fffffffu) return PC_EINVAL;
+        if (((uintptr_t)a->param | (uintptr_t)a->grad | (uintptr_t)a->exp_avg | (uintptr_t)a->exp_avg_sq) & 15) return PC_ESHAPE;
+        AdamRider& ad = d->r.ad;
+        ad.p = a->param; ad.m = a->exp_avg; ad.v = a->exp_avg_sq; ad.g = a->grad; ad.n = a->n;
+        ad.step_count = a->step_count; ad.t = (long long)a->t; ad.lr = a->lr; ad.beta1 = a->beta1; ad.beta2 = a->beta2;
+        ad.omb1 = (float)(1.0 - a->beta1); ad.beta2f = (float)a->beta2; ad.omb2 = (float)(1.0 - a->beta2); ad.eps = (float)a->eps;
+        long lo[2 * PC_TN_RGROUP], hi[2 * PC_TN_RGROUP];
+        int ni = 0;
+        for (int k = 0; k < d->r.n; k++) {
+            const float* outs[2] = {d->r.dW[k], d->r.db[k]};
+            const int lens[2] = {d->r.n_w[k], d->r.db[k] ? d->r.n_b[k] : 0};
+            for (int u = 0; u < 2; u++) {
+                if (!outs[u] || lens[u] == 0) continue;
+                const long o = outs[u] - a->grad;
+                if (o < 0 || o + lens[u] > (long)a->n || (o & 3) || (lens[u] & 3)) return PC_EINVAL;
+                lo[ni] = o; hi[ni] = o + lens[u]; ni++;
+            }
+        }
+        for (int i = 1; i < ni; i++)                          // insertion sort by start (<= 32 intervals)
+            for (int j2 = i; j2 > 0 && lo[j2] < lo[j2 - 1]; j2--) { long t0 = lo[j2]; lo[j2] = lo[j2 - 1]; lo[j2 - 1] = t0; t0 = hi[j2]; hi[j2] = hi[j2 - 1]; hi[j2 - 1] = t0; }
+        long cur = 0;
+        int nr = 0, rb = 0;
+        for (int i = 0; i <= ni; i++) {
+            const long stop = i < ni ? lo[i] : (long)a->n;
+            if (stop > cur) {
+                if (nr >= PC_ADAM_REST) return PC_EINVAL;
+                ad.rest_lo[nr] = (int)cur; ad.rest_hi[nr] = (int)stop; ad.rest_block0[nr] = rb;
+                rb += (int)((stop - cur + 1023) / 1024);
+                nr++;
+            }
+            if (i < ni) {
+                if (lo[i] < cur) return PC_EINVAL;            // two reduce jobs writing the same gradient range
+                cur = hi[i];
+            }
+        }
+        ad.n_rest = nr; ad.rest_block0[nr] = rb;
+        ad.block0 = d->rblocks;
+        blocks += rb;
+    }
+    if (blocks == 0) { tn_defer_init(d); return PC_OK; }
+    PC_LAUNCH(tn_reduce_group_kernel, dim3(blocks), dim3(256), 0, st, d->r);
     tn_defer_init(d);
     return pc_launch_status();
 }

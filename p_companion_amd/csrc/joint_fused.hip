@@ -879,6 +879,7 @@ static size_t tile_lds_bytes(int T, bool sims_local, bool tables) {
 // (sample_hidden_kernel without a mask, sample_sims_max_kernel, sample_topk_refine_kernel -> topk_by_type[type][K]); U lives on
 // the device, so the grids are sized for min(B, T) rows and the workgroups past U leave at once.
 #define UT 64
+#define PRESENT256_MAX_T ((UT * 68 - 8) * 32)      /* the riding workgroup's bitmap lives in sample_hidden_kernel's Tin (UT x LD64 floats) */
 // inclusive prefix sum over the 1024 threads of a workgroup: the DPP scan inside each wave, the 16 wave totals through LDS -- two
 // barriers (the Hillis-Steele form over LDS this replaces took twenty: 3 us of a 10 us single-workgroup kernel)
 __device__ __forceinline__ int block_scan_1024(int v, unsigned* wsum /* [16] LDS */) {
@@ -936,6 +937,53 @@ __global__ __launch_bounds__(1024) void present_types_kernel(const int32_t* quer
     if (threadIdx.x == 1023) *n_u = incl;
 }
 
+// The same list by ONE 256-thread workgroup riding in another launch (round 6): the list of step i + 1 depends on that step's
+// labelled pairs alone, which an epoch call holds for every step in advance -- so it is formed during step i (an extra workgroup
+// of sample_hidden_kernel, beside the G workgroups it has nothing to do with) into the other half of a double buffer, and step
+// i + 1 starts with its hidden rows: the 10 us single-workgroup launch leaves the critical path of every step but an epoch's first.
+// bits: LDS, (T + 31) / 32 words + 8.
+__device__ __forceinline__ void present_types_body256(const int32_t* pairs, const int32_t* type_idx, int P, int B, int T,
+                                                      int32_t* ulist, int32_t* n_u, unsigned* bits) {
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int words = (T + 31) >> 5;
+    unsigned* wsum = bits + words;
+    for (int i = tid; i < words; i += 256) bits[i] = 0u;
+    __syncthreads();
+    for (int b0 = tid; b0 < B; b0 += 8 * 256) {              // eight samples per thread and round: their two dependent loads overlap
+        int t[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) { const int b = b0 + 256 * u; t[u] = b < B ? pairs[3 * b] : -1; }
+#pragma unroll
+        for (int u = 0; u < 8; u++)
+            if (b0 + 256 * u < B) t[u] = type_idx[(unsigned)t[u] < (unsigned)P ? t[u] : 0];
+#pragma unroll
+        for (int u = 0; u < 8; u++)
+            if ((unsigned)t[u] < (unsigned)T) atomicOr(&bits[t[u] >> 5], 1u << (t[u] & 31));
+    }
+    __syncthreads();
+    const int per = (words + 255) / 256;
+    const int lo = tid * per, hi = min(words, lo + per);
+    int cnt = 0;
+    for (int i = lo; i < hi; i++) cnt += __popc(bits[i]);
+    int incl = wave_scan_incl(cnt);
+    if (lane == 63) wsum[w] = (unsigned)incl;
+    __syncthreads();
+    int base = 0;
+#pragma unroll
+    for (int i = 0; i < 4; i++) base += i < w ? (int)wsum[i] : 0;
+    incl += base;
+    int pos = incl - cnt;
+    for (int i = lo; i < hi; i++) {
+        unsigned m = bits[i];
+        while (m) {
+            const int bit = __ffs(m) - 1;
+            m &= m - 1;
+            ulist[pos++] = 32 * i + bit;
+        }
+    }
+    if (tid == 255) *n_u = incl;
+}
+
 // ---------------------------------------------------------------------------------------------------------------
 // Large tables: the similarity row and its top-K per ROW -- a row is a distinct query type of the batch without dropout (above)
 // and a SAMPLE with hidden-layer dropout (the reference as shipped: config.py:12 DROPOUT = 0.1, config.py:27 NUM_TYPES = 34800;
@@ -961,12 +1009,19 @@ struct SampleHArgs {
     float *hd, *G, *g0;
     const int32_t *ulist, *n_rows;          // rows = listed query types (dropout off): row b is type ulist[b], b < *n_rows; else NULL
     float* gnmax;                           // [T / 64 rounded up]: max |G[t]| per 64-type sub-chunk
+    // look-ahead (the LAST workgroup of the launch when next_pairs != NULL): the distinct-query-type list of the NEXT step
+    const int32_t* next_pairs; int next_B; int32_t *next_ulist, *next_n_u;
 };
 static_assert(UT == 64, "a G workgroup of sample_hidden_kernel is one 64-type sub-chunk of sample_sims_max_kernel");
 
 __global__ __launch_bounds__(256) void sample_hidden_kernel(SampleHArgs a) {
     __shared__ __attribute__((aligned(16))) float Tin[UT * LD64];
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, ci = lane & 15, rh = lane >> 4;
+    if (a.next_pairs && blockIdx.x == gridDim.x - 1) {
+        // (Tin's 17 KB are this workgroup's bitmap: T <= PRESENT256_MAX_T, checked by the host)
+        present_types_body256(a.next_pairs, a.type_idx, a.P, a.next_B, a.T, a.next_ulist, a.next_n_u, reinterpret_cast<unsigned*>(Tin));
+        return;
+    }
     if ((int)blockIdx.x >= a.nb_s) {
         // ---- G[t][j] = sum_d E_c[t][d] dec_w[d][j], g0[t] = sum_d E_c[t][d] dec_b[d] for 64 types
         const int t0 = ((int)blockIdx.x - a.nb_s) * UT;
@@ -2408,8 +2463,8 @@ static FusedWs fused_ws_layout(void* base, int B, int T, int K) {
         w.tslab_q = (float*)take((size_t)TG_WGS * TG_CAP * PC_L * 4);
         w.nchunks_s = (T + PC_STC - 1) / PC_STC;
         w.ucap = B < T ? B : T;
-        w.ulist = (int32_t*)take((size_t)w.ucap * 4);
-        w.n_u = (int32_t*)take(256);
+        w.ulist = (int32_t*)take((size_t)2 * w.ucap * 4);          // two lists: this step's, and the next one's formed ahead (JointLookahead)
+        w.n_u = (int32_t*)take(256);                                // n_u[0], n_u[1]
         // (sized for either regime: rows = distinct query types without dropout, = the B samples with it)
         w.topk_by_type = (int32_t*)take((size_t)(T > B ? T : B) * K * 4);
         w.part_val = (float*)take((size_t)B * 4 * w.nchunks_s * 4);   // cmax [rows <= B][4 nchunks_s]: the sub-chunk maxima of sample_sims_max_kernel
@@ -2460,6 +2515,10 @@ extern "C" int pc_build_complementary_batch(const int32_t* pairs, int batch, con
                                             float* target_features, void* stream);
 
 struct PairsSrc { const int32_t* pairs; const float* features; const int32_t* type_idx; int n_types; uint64_t seed, step; };
+// Across the steps of ONE epoch call (num_types > 512, no hidden-layer dropout): `have` -- the previous step of this call formed
+// this step's distinct-query-type list into half `parity` of the double buffer; next_pairs -- the labelled pairs of the next step
+// (same batch size: the workspace layout, hence the buffer, is the same), whose list this step forms into the other half.
+struct JointLookahead { bool have; int parity; const int32_t* next_pairs; };
 
 static int fused_step_impl(const pc_joint_tensors* p, const pc_joint_tensors* g, const pc_joint_tensors* exp_avg,
                            const pc_joint_tensors* exp_avg_sq, int64_t* step_count, double lr, double beta1,
@@ -2467,7 +2526,7 @@ static int fused_step_impl(const pc_joint_tensors* p, const pc_joint_tensors* g,
                            const int32_t* pos_types, const int32_t* neg_types, const float* pos_items,
                            const float* neg_items, int B, int T, int K, int num_products, float margin, float alpha,
                            float* losses, int32_t* topk, int32_t* bad_count, void* ws, size_t ws_bytes,
-                           void* stream) {
+                           void* stream, JointLookahead* la = nullptr) {
     if (!tensors_ok(p, true) || !tensors_ok(g, false)) return PC_EINVAL;
     const bool adam = exp_avg != nullptr;
     if (adam && (!tensors_ok(exp_avg, false) || !tensors_ok(exp_avg_sq, false) || !step_count)) return PC_EINVAL;
@@ -2492,17 +2551,29 @@ static int fused_step_impl(const pc_joint_tensors* p, const pc_joint_tensors* g,
         // rows of the similarity product: the B samples (dropout), else the U distinct query types of the batch -- U is a device
         // scalar, the launches are sized for its capacity min(B, T) and the workgroups past U leave at once
         const int rows_cap = per_sample ? B : w.ucap;
-        const int32_t* ulist = per_sample ? nullptr : w.ulist;
-        const int32_t* n_rows = per_sample ? nullptr : w.n_u;
-        if (!per_sample) {
+        // the look-ahead serves the path whose query types come from the pairs (the epoch calls), lists that fit the riding
+        // workgroup's LDS bitmap
+        const bool la_ok = la && !per_sample && pairs_in_tile && T <= PRESENT256_MAX_T;
+        const int par = la_ok ? (la->parity & 1) : 0;
+        int32_t* ulist_w = per_sample ? nullptr : w.ulist + (size_t)par * w.ucap;
+        int32_t* n_rows_w = per_sample ? nullptr : w.n_u + par;
+        const int32_t* ulist = ulist_w;
+        const int32_t* n_rows = n_rows_w;
+        if (!per_sample && !(la_ok && la->have)) {
             const int words = (T + 31) / 32;
-            PC_LAUNCH(present_types_kernel, dim3(1), dim3(1024), (size_t)(words + 1024) * 4, st, query_types, B, T, w.ulist, w.n_u,
+            PC_LAUNCH(present_types_kernel, dim3(1), dim3(1024), (size_t)(words + 1024) * 4, st, query_types, B, T, ulist_w, n_rows_w,
                       pairs_in_tile ? src->pairs : nullptr, pairs_in_tile ? src->type_idx : nullptr, num_products);
         }
         SampleHArgs ca = {p->enc_w, p->enc_b, p->dec_w, p->dec_b, p->query_types, p->comp_types, query_types,
                           pairs_in_tile ? src->pairs : nullptr, pairs_in_tile ? src->type_idx : nullptr, B, T, num_products,
-                          (rows_cap + UT - 1) / UT, make_dropcfg(p->dropout), w.csamp, w.gmat, w.g0, ulist, n_rows, w.gnmax};
-        PC_LAUNCH(sample_hidden_kernel, dim3(ca.nb_s + (T + UT - 1) / UT), dim3(256), 0, st, ca);
+                          (rows_cap + UT - 1) / UT, make_dropcfg(p->dropout), w.csamp, w.gmat, w.g0, ulist, n_rows, w.gnmax,
+                          nullptr, 0, nullptr, nullptr};
+        if (la_ok && la->next_pairs) {
+            ca.next_pairs = la->next_pairs; ca.next_B = B;
+            ca.next_ulist = w.ulist + (size_t)(par ^ 1) * w.ucap; ca.next_n_u = w.n_u + (par ^ 1);
+        }
+        if (la) { la->have = la_ok && la->next_pairs != nullptr; la->parity = par ^ 1; }
+        PC_LAUNCH(sample_hidden_kernel, dim3(ca.nb_s + (T + UT - 1) / UT + (ca.next_pairs ? 1 : 0)), dim3(256), 0, st, ca);
         SampleSimsArgs sa = {};
         sa.hd = w.csamp; sa.G = w.gmat; sa.g0 = w.g0; sa.B = B; sa.T = T; sa.K = K; sa.nchunks = w.nchunks_s;
         sa.part_val = w.part_val; sa.n_rows = n_rows;
@@ -2732,15 +2803,18 @@ extern "C" int pc_joint_train_epoch(const pc_joint_tensors* p, const pc_joint_te
     if (!exp_avg || !exp_avg_sq) return PC_EINVAL;               // an epoch without the optimizer step trains nothing
     pc_joint_tensors pl = *p;
     int64_t done = 0;
+    JointLookahead la = {false, 0, nullptr};
     for (int64_t i = 0; done < n_pairs; i++) {
         const int64_t left = n_pairs - done;
         const int b = left >= B ? B : (int)left;
         if (b < B && drop_last) break;
         const PairsSrc src = {pairs + 3 * done, features, type_idx, n_types, seed, first_step + (uint64_t)i};
         pl.dropout.offset = p->dropout.offset + (uint64_t)i;
+        // (the next step's list only when that step has this one's batch size: the workspace layout is a function of it)
+        la.next_pairs = (left - b >= b && b == B) ? pairs + 3 * (done + b) : nullptr;
         PC_TRY(fused_step_impl(&pl, g, exp_avg, exp_avg_sq, step_count, lr, beta1, beta2, eps, &src, query_idx, query_types,
                                pos_types, neg_types, pos_items, neg_items, b, T, K, num_products, margin, alpha,
-                               losses_out + 3 * i, topk, bad_count, ws, ws_bytes, stream));
+                               losses_out + 3 * i, topk, bad_count, ws, ws_bytes, stream, &la));
         done += b;
     }
     return PC_OK;
@@ -2773,15 +2847,17 @@ extern "C" int pc_joint_train_epoch_plan(const pc_joint_tensors* p, const pc_joi
     }
     pc_joint_tensors pl = *p;
     int64_t done = 0;
+    JointLookahead la = {false, 0, nullptr};
     for (int64_t i = 0; done < n_pairs; i++) {
         const int64_t left = n_pairs - done;
         const int b = left >= B ? B : (int)left;
         if (b < B && drop_last) break;
         const PairsSrc src = {pairs + 3 * done, features, type_idx, n_types, seed, first_step + (uint64_t)i};
         pl.dropout.offset = p->dropout.offset + (uint64_t)i;
+        la.next_pairs = (left - b >= b && b == B) ? pairs + 3 * (done + b) : nullptr;
         PC_TRY(fused_step_impl(&pl, g, nullptr, nullptr, nullptr, lr, beta1, beta2, eps, &src, query_idx, query_types, pos_types,
                                neg_types, pos_items, neg_items, b, T, K, num_products, margin, alpha, losses_out + 3 * i, topk,
-                               bad_count, ws, ws_bytes, stream));
+                               bad_count, ws, ws_bytes, stream, &la));
         PC_TRY(pc_exchange_adam_plan(plan, param_flat, grad_flat, exp_avg_flat, exp_avg_sq_flat, n_flat, step_count,
                                      t_first > 0 ? t_first + i : 0, adam_scalars, lr, beta1, beta2, eps, stream));
         done += b;

@@ -140,11 +140,12 @@ static int p2v_step_impl(const pc_p2v_tensors* p, const pc_p2v_tensors* g, const
                          size_t ws_bytes, void* stream, int phase = -1, double* fwd_sums = nullptr,
                          double* bwd_local = nullptr, const double* bwd_global = nullptr,
                          const float* nb_weight = nullptr, const int32_t* ref_off = nullptr,
-                         const int32_t* ref_slot = nullptr) {
+                         const int32_t* ref_slot = nullptr, const pc_adam_fused* adam = nullptr) {
     // nb_weight (unique-neighbour layout): multiplicity of each of the nbc neighbour rows (its last entry = the
     // number of padding slots); replaces the single weighted row of the compact layout
     // phase -1: the whole step with this replica's BatchNorm statistics; 0/1/2: see pc_p2v_train_step_compact_sync
     const bool p0 = phase <= 0, p1 = phase == -1 || phase == 1, p2 = phase == -1 || phase == 2;
+    if (adam && phase != -1) return PC_EINVAL;               // (the optimizer rides in the unsplit step's last launch only)
     ProfileScope prof_scope((pc_profile*)profile);
     if (!p || !g || !table || !anchor_idx || !positive_idx || !negative_idx || !loss || !ws) return PC_EINVAL;
     if (B <= 0 || N < 0 || K <= 0 || (N > 0 && !nb_idx) || nbc < 0 || nbc > B * N + 1) return PC_EINVAL;
@@ -231,6 +232,7 @@ static int p2v_step_impl(const pc_p2v_tensors* p, const pc_p2v_tensors* g, const
     TnDefer df;
     tn_defer_init(&df);
     if (phase == -1) df.fork = pc_fork_get(st);              // (the unsplit step: two small launches leave the main queue, common.h PcFork)
+    df.adam = adam;                                          // torch.optim.Adam inside the final slab reduce (pc_p2v_train_step_unique_adam)
     // an error return below must not leave work on the side queue that nothing orders before the caller's next use (or
     // free) of the workspace and gradient buffers: join it into the main queue on the way out (a no-op after the normal
     // end of the step, whose reduce launch has joined already)
@@ -309,4 +311,24 @@ extern "C" int pc_p2v_train_step_unique(const pc_p2v_tensors* p, const pc_p2v_te
     return p2v_step_impl(p, g, table, anchor_idx, positive_idx, negative_idx, nb_rows, n_unique + 1, slot_row, B, N, K,
                          margin, loss, d_pos, d_neg, anchor_emb, profile, ws, ws_bytes, stream, phase, fwd_sums,
                          bwd_local, bwd_global, nb_weight, ref_off, ref_slot);
+}
+
+extern "C" int pc_p2v_train_step_unique_adam(const pc_p2v_tensors* p, const pc_p2v_tensors* g, const float* table,
+                                             const int32_t* anchor_idx, const int32_t* positive_idx,
+                                             const int32_t* negative_idx, const int32_t* nb_rows, const float* nb_weight,
+                                             int n_unique, const int32_t* slot_row, const int32_t* ref_off,
+                                             const int32_t* ref_slot, int B, int N, int K, float margin, float* loss,
+                                             float* d_pos, float* d_neg, float* anchor_emb, void* profile, void* ws,
+                                             size_t ws_bytes, const pc_adam_fused* adam, void* stream) {
+    if (!slot_row || !nb_rows || !nb_weight || !ref_off || !ref_slot || N <= 0 || n_unique < 0 || n_unique > B * N)
+        return PC_EINVAL;
+    if (adam && g) {
+        // the gradient tensors must be views of the flat buffer the optimizer updates
+        const float* gt[4] = {g->w0, g->w3, g->w5, g->out_proj_w};
+        for (const float* x : gt)
+            if (!x || x < adam->grad || x >= adam->grad + adam->n) return PC_EINVAL;
+    }
+    return p2v_step_impl(p, g, table, anchor_idx, positive_idx, negative_idx, nb_rows, n_unique + 1, slot_row, B, N, K,
+                         margin, loss, d_pos, d_neg, anchor_emb, profile, ws, ws_bytes, stream, -1, nullptr, nullptr, nullptr,
+                         nb_weight, ref_off, ref_slot, adam);
 }

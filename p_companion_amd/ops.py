@@ -520,13 +520,17 @@ BN_SYNC_DOUBLES = PC_MAX_SEG * 2 * H + PC_MAX_SEG
 
 
 def p2v_train_step(params, grads, table, anchor_idx, positive_idx, negative_idx, neighbor_idx, margin,
-                   want_emb=False, profile=None, sync_reduce=None):
+                   want_emb=False, profile=None, sync_reduce=None, adam=None):
     """One loop-body iteration of Product2Vec.train_model in index form (grads overwritten).
 
     sync_reduce: None = BatchNorm statistics of this batch; else a callable `reduce(buf)` that sums a
     [BN_SYNC_DOUBLES] float64 device tensor over the data-parallel replicas in place (e.g.
     `lambda t: dist.all_reduce(t)`): the step then runs as pc_p2v_train_step_compact_sync's three phases
-    with batch-wide (cross-replica) BatchNorm statistics.  Compact neighbour layout only."""
+    with batch-wide (cross-replica) BatchNorm statistics.  Compact neighbour layout only.
+
+    adam (unique-neighbour layout, no sync_reduce): {"param", "grad", "exp_avg", "exp_avg_sq" (the flat buffers `grads` are views
+    of), "step_count", "t" >= 1, "lr", "betas", "eps"} -- torch.optim.Adam's update inside the step's last gradient launch
+    (pc_p2v_train_step_unique_adam): optimizer.step() costs no launch of its own."""
     st, dev = p2v_struct(params)
     gst, _ = p2v_struct(grads, with_buffers=False)
     b = anchor_idx.numel()
@@ -583,6 +587,24 @@ def p2v_train_step(params, grads, table, anchor_idx, positive_idx, negative_idx,
         bwd_global = bwd_local.clone()
         sync_reduce(bwd_global)
         phase(2)
+        return out
+    if adam is not None and not unique:
+        raise ValueError("p2v_train_step(adam=...): the unique-neighbour layout (the device loader's) carries the fused optimizer step")
+    if unique and adam is not None:
+        af = _lib.AdamFused()
+        n_flat = adam["param"].numel()
+        for key in ("param", "grad", "exp_avg", "exp_avg_sq"):
+            _req(adam[key], torch.float32, key, (n_flat,))
+        _req(adam["step_count"], torch.int64, "step_count")
+        af.param, af.grad, af.exp_avg, af.exp_avg_sq = (adam[key].data_ptr() for key in ("param", "grad", "exp_avg", "exp_avg_sq"))
+        af.n, af.step_count, af.t = n_flat, adam["step_count"].data_ptr(), int(adam["t"])
+        af.lr, af.beta1, af.beta2, af.eps = float(adam["lr"]), float(adam["betas"][0]), float(adam["betas"][1]), float(adam["eps"])
+        check(_lib.lib().pc_p2v_train_step_unique_adam(
+            ctypes.byref(st), ctypes.byref(gst), _p(table), _p(anchor_idx), _p(positive_idx), _p(negative_idx),
+            _p(nb_rows), _p(neighbor_idx["weight"]), n_real, _p(slot_row), _p(neighbor_idx["ref_off"]),
+            _p(neighbor_idx["ref_slot"]), b, n, k, float(margin), _p(out["loss"]),
+            _p(out["d_pos"]), _p(out["d_neg"]), _p(out.get("anchor_emb")), profile.handle if profile else None,
+            _p(ws), nbytes, ctypes.byref(af), _stream()), "pc_p2v_train_step_unique_adam")
         return out
     if unique:
         check(_lib.lib().pc_p2v_train_step_unique(

@@ -199,6 +199,19 @@ class FusedAdam(torch.optim.Optimizer):
         ops.adam_step(flat, gflat, self.exp_avg, self.exp_avg_sq, self.step_count, self.scalars, g["lr"],
                       g["betas"], g["eps"])
 
+    def riding_state(self):
+        """For a step that applies this optimizer's update in its own last gradient launch (Product2Vec.train_step_indexed(
+        optimizer=...): pc_p2v_train_step_unique_adam): the flat buffers, the hyper-parameters and the step number t of THIS
+        update.  Counts the step (the caller must not call step() for it).  None when the host does not know the step number
+        (a captured graph / a fused joint step has advanced the device counter on its own): the caller then steps separately."""
+        flat, gflat = self._ensure()
+        if self._host_step is None or (flat.is_cuda and torch.cuda.is_current_stream_capturing()):
+            return None
+        self._host_step += 1
+        g = self.param_groups[0]
+        return {"param": flat, "grad": gflat, "exp_avg": self.exp_avg, "exp_avg_sq": self.exp_avg_sq, "step_count": self.step_count,
+                "t": self._host_step, "lr": g["lr"], "betas": g["betas"], "eps": g["eps"]}
+
     def epoch_state(self):
         """What an epoch-in-one-call of a replica (ops.PreparedJointStep.run_epoch_dp) needs: the flat moment buffers, the device
         step counter, the scratch scalars and t_first -- the Adam step number of the epoch's first step when the host knows it,
@@ -524,17 +537,28 @@ class Product2Vec(nn.Module, _FlatParamsMixin):
         return next(self.parameters()).device
 
     # ------------------------------------------------------------------ P9 loop
-    def train_step_indexed(self, table, batch, profile=None, sync_reduce=None):
+    def train_step_indexed(self, table, batch, profile=None, sync_reduce=None, optimizer=None):
         """One loop-body iteration (product2vec.py:130-158 minus optimizer.step) on an index
         batch.  Gradients land in .grad (flat-buffer views); returns the device loss tensor.
-        sync_reduce: see ops.p2v_train_step (cross-replica BatchNorm statistics for data-parallel runs)."""
+        sync_reduce: see ops.p2v_train_step (cross-replica BatchNorm statistics for data-parallel runs).
+        optimizer (a FusedAdam over this module): product2vec.py:158's optimizer.step() as well -- inside the step's last
+        gradient launch where the batch's layout carries it (the device loader's unique-neighbour batches, one process), by the
+        optimizer's own launch otherwise.  Either way the caller does NOT call optimizer.step() for this iteration."""
         self.flatten_parameters()
         params = self._tensor_dict(self._next_dropout())
         grads = {k: p.grad for k, p in self.named_parameters()}
         nbr = batch.get("neighbor_compact", batch.get("neighbor_idx"))      # compact rows when the loader built them
+        adam = None
+        if optimizer is not None:
+            if not hasattr(optimizer, "riding_state") or optimizer.module is not self:
+                raise TypeError("train_step_indexed(optimizer=...) takes the FusedAdam built over this module")
+            if sync_reduce is None and isinstance(nbr, dict) and "weight" in nbr:
+                adam = optimizer.riding_state()
         out = ops.p2v_train_step(params, grads, table, batch["anchor_idx"], batch["positive_idx"],
                                  batch["negative_idx"], nbr, float(self.config.MARGIN), profile=profile,
-                                 sync_reduce=sync_reduce)
+                                 sync_reduce=sync_reduce, adam=adam)
+        if optimizer is not None and adam is None:
+            optimizer.step()
         return out["loss"]
 
     def train_model(self, train_loader, optimizer, num_epochs=10) -> Dict[str, torch.Tensor]:
@@ -559,8 +583,11 @@ class Product2Vec(nn.Module, _FlatParamsMixin):
                 if "anchor_idx" in batch:
                     if table is None:
                         table = bpg.cuda(device)["features"]
-                    loss = self.train_step_indexed(table, batch)       # zero_grad + backward, fused
-                    optimizer.step()
+                    if hasattr(optimizer, "riding_state") and optimizer.module is self:
+                        loss = self.train_step_indexed(table, batch, optimizer=optimizer)   # zero_grad + backward + step, fused
+                    else:
+                        loss = self.train_step_indexed(table, batch)                        # zero_grad + backward, fused
+                        optimizer.step()
                 else:
                     loss = self.dense_loss(batch)
                     optimizer.zero_grad()

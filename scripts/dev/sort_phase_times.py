@@ -38,13 +38,17 @@ L = ctypes.CDLL(_lib.LIB_PATH)
 out = (ctypes.c_ulonglong * 1024)()
 assert L.pc_debug_sort_timing(out) == 0
 t = list(out)
-names = ["zero", "histogram", "bin loops", "scan", "run table to LDS", "barrier", "run table out", "placement", "run lists + long runs", "write-out"]
+# stamps 0..10 of table_sort_kernel (PC_ST in csrc/joint_fused.hip): the phase that ENDS at stamp i
+names = ["read the list + clear the bins", "count the range's bins (LDS atomics)", "per-thread bin sums", "block scan (rows, runs, lists)",
+         "run starts back into the bins + the workgroup's list atomics", "barrier", "row base", "placement (returning LDS atomics)",
+         "run table + run lists", "write-out of the order"]
 live = [b for b in range(64) if t[16 * b]]
 nr = len(live) // 2
 for b in live:
     seq = t[16 * b:16 * b + 11]
     print("workgroup %2d (list %d, range %2d): total %d clk: " % (b, b // nr, b % nr, seq[-1] - seq[0])
           + ", ".join("%s %d" % (names[i - 1], seq[i] - seq[i - 1]) for i in range(1, 11)))
-reg = ["short c", "medium c", "long c", "short q", "medium q", "long q"]
-print("table_segsum_kernel, all steps: " + "; ".join("%s: longest wave %d clk, %d waves with work, longest run %d rows" % (reg[i], t[1000 + i], t[1008 + i], t[1016 + i]) for i in range(6)))
+# the eight grid regions of table_segsum_kernel: runs of up to 4 rows / 5..64 / 65..256 / parts of longer ones, per table
+reg = ["short c", "medium c", "long c", "giant c", "short q", "medium q", "long q", "giant q"]
+print("table_segsum_kernel, all steps: " + "; ".join("%s: longest wave %d clk, %d waves with work, longest run %d rows" % (reg[i], t[1000 + i], t[1008 + i], t[1016 + i]) for i in range(8)))
 print("a medium run of >= 48 rows: entry + count at %d clk, row numbers in the bitmap at %d, queue at %d, rows added at %d" % tuple(t[900:904]))

@@ -1,5 +1,6 @@
-"""Developer probe (GPU box): the joint step at NUM_TYPES = 34800 WITHOUT dropout, default table-gradient form (per-workgroup LDS
-tables) against pc_set_option(PC_OPT_SORTED_TABLE_GRADIENTS, 1): python scripts/dev/sorted_option_cost.py"""
+"""Developer probe (GPU box): the joint step at NUM_TYPES = 34800 WITHOUT dropout, the per-workgroup LDS tables
+(pc_set_option(PC_OPT_SORTED_TABLE_GRADIENTS, 0): rounds 1-4's form) against the sorted form (1: the default since round 5):
+python scripts/dev/sorted_option_cost.py"""
 import contextlib, io, json, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)

@@ -1,7 +1,7 @@
 """Per-kernel roofline table of one Product2Vec step from a rocprofv3 kernel trace (profiles/<tag>_kernel_stats.json)
 and the shapes of the benchmark (profiles/<tag>_bench.json): algorithmic FLOPs and HBM bytes per launch, the achieved
 rates and their fractions of the two roofs (dense bf16 MFMA / 6 products = 416.7 TFLOP/s fp32-equivalent; 8 TB/s).
-    python scripts/step_roofline.py r03c  ->  profiles/r03c_step_roofline.md"""
+    python scripts/step_roofline.py r03c  ->  profiles/archive/r03c_step_roofline.md"""
 import json, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 tag = sys.argv[1]

@@ -30,6 +30,10 @@ def test_bench_self_launches_its_ranks():
     assert line["n_gpus"] == 2 and line["config"]["global_batch"] == 1024 and line["config"]["parallelism"] == "dp2"
     rccl = dict(line["rccl"])
     exchange = rccl.pop("exchange")                     # (ABI 6: the gradient exchange through the library's slot; gloo behind it here)
+    timeouts = rccl.pop("timeouts_s")                   # first-contact deadlines, all well inside a 10-minute harness limit
+    assert timeouts["probe"] <= 90 and timeouts["process_group"] <= 300 and timeouts["secondary_leg"] <= 180
+    rccl.pop("native_probe", None)
+    assert "[bench] rccl {" in out.stderr               # the block is out before the first timed leg
     assert rccl == {"backend": "gloo", "world": 2, "ranks_seen": [0, 1], "launcher": "self"} and "gloo" in exchange
     assert "pc_joint_train_epoch_dp" in line["joint"]["config"]["launch"]
     assert line["value"] > 0 and line["joint"]["value"] > 0 and line["joint"]["config"]["parallelism"] == "dp2"
