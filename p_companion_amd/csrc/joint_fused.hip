@@ -879,7 +879,8 @@ static size_t tile_lds_bytes(int T, bool sims_local, bool tables) {
 // (sample_hidden_kernel without a mask, sample_sims_max_kernel, sample_topk_refine_kernel -> topk_by_type[type][K]); U lives on
 // the device, so the grids are sized for min(B, T) rows and the workgroups past U leave at once.
 #define UT 64
-#define PRESENT256_MAX_T ((UT * 68 - 8) * 32)      /* the riding workgroup's bitmap lives in sample_hidden_kernel's Tin (UT x LD64 floats) */
+#define PRESENT256_WORDS 2048                      /* LDS bitmap of the riding workgroup (joint_finish_kernel): num_types <= 65 536 */
+#define PRESENT256_MAX_T (PRESENT256_WORDS * 32)
 // inclusive prefix sum over the 1024 threads of a workgroup: the DPP scan inside each wave, the 16 wave totals through LDS -- two
 // barriers (the Hillis-Steele form over LDS this replaces took twenty: 3 us of a 10 us single-workgroup kernel)
 __device__ __forceinline__ int block_scan_1024(int v, unsigned* wsum /* [16] LDS */) {
@@ -1009,19 +1010,12 @@ struct SampleHArgs {
     float *hd, *G, *g0;
     const int32_t *ulist, *n_rows;          // rows = listed query types (dropout off): row b is type ulist[b], b < *n_rows; else NULL
     float* gnmax;                           // [T / 64 rounded up]: max |G[t]| per 64-type sub-chunk
-    // look-ahead (the LAST workgroup of the launch when next_pairs != NULL): the distinct-query-type list of the NEXT step
-    const int32_t* next_pairs; int next_B; int32_t *next_ulist, *next_n_u;
 };
 static_assert(UT == 64, "a G workgroup of sample_hidden_kernel is one 64-type sub-chunk of sample_sims_max_kernel");
 
 __global__ __launch_bounds__(256) void sample_hidden_kernel(SampleHArgs a) {
     __shared__ __attribute__((aligned(16))) float Tin[UT * LD64];
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, ci = lane & 15, rh = lane >> 4;
-    if (a.next_pairs && blockIdx.x == gridDim.x - 1) {
-        // (Tin's 17 KB are this workgroup's bitmap: T <= PRESENT256_MAX_T, checked by the host)
-        present_types_body256(a.next_pairs, a.type_idx, a.P, a.next_B, a.T, a.next_ulist, a.next_n_u, reinterpret_cast<unsigned*>(Tin));
-        return;
-    }
     if ((int)blockIdx.x >= a.nb_s) {
         // ---- G[t][j] = sum_d E_c[t][d] dec_w[d][j], g0[t] = sum_d E_c[t][d] dec_b[d] for 64 types
         const int t0 = ((int)blockIdx.x - a.nb_s) * UT;
@@ -1574,12 +1568,22 @@ struct FinishArgs {
     const float *part_type, *part_item; int B, K; float alpha; float* losses;
     const int64_t* step_count; double lr, beta1, beta2, eps; int adam;
     int sl16;                                             // 16 slab lanes per output float4 (else 8): see joint_finish_kernel
+    // look-ahead rider (workgroup 0 when next_pairs != NULL, the others shifted by one): the distinct-query-type list of the
+    // NEXT step of an epoch call (present_types_body256)
+    const int32_t *next_pairs, *type_idx; int P, next_B, T; int32_t *next_ulist, *next_n_u;
 };
 
 __global__ __launch_bounds__(256) void joint_finish_kernel(FinishArgs a) {
     __shared__ float r0[256], r1[256];
     __shared__ float scal[2];
-    const int b = blockIdx.x;
+    __shared__ unsigned pbits[PRESENT256_WORDS + 8];
+    // (the rider is workgroup 0: dispatched first, it runs beside the whole launch -- as the LAST workgroup it started when the
+    // others were done and the launch lasted its 10 us longer: 18 -> 27 us)
+    if (a.next_pairs && blockIdx.x == 0) {
+        present_types_body256(a.next_pairs, a.type_idx, a.P, a.next_B, a.T, a.next_ulist, a.next_n_u, pbits);
+        return;
+    }
+    const int b = (int)blockIdx.x - (a.next_pairs ? 1 : 0);
     if (b == a.block0[a.njobs]) {                       // the extra workgroup: the two hinge means
         float x = 0.f, y = 0.f;
         for (int i = threadIdx.x; i < a.B; i += 256) { x += a.part_type[i]; y += a.part_item[i]; }
@@ -2547,6 +2551,7 @@ static int fused_step_impl(const pc_joint_tensors* p, const pc_joint_tensors* g,
                                             const_cast<float*>(pos_items), const_cast<float*>(neg_items), nullptr, stream));
 
     const bool per_sample = !w.small && p->dropout.p > 0.f;      // hidden-layer dropout: c is a function of the SAMPLE
+    const int32_t* look_pairs = nullptr; int32_t *look_ulist = nullptr, *look_n_u = nullptr;      // JointLookahead: see joint_finish_kernel
     if (!w.small) {
         // rows of the similarity product: the B samples (dropout), else the U distinct query types of the batch -- U is a device
         // scalar, the launches are sized for its capacity min(B, T) and the workgroups past U leave at once
@@ -2566,14 +2571,13 @@ static int fused_step_impl(const pc_joint_tensors* p, const pc_joint_tensors* g,
         }
         SampleHArgs ca = {p->enc_w, p->enc_b, p->dec_w, p->dec_b, p->query_types, p->comp_types, query_types,
                           pairs_in_tile ? src->pairs : nullptr, pairs_in_tile ? src->type_idx : nullptr, B, T, num_products,
-                          (rows_cap + UT - 1) / UT, make_dropcfg(p->dropout), w.csamp, w.gmat, w.g0, ulist, n_rows, w.gnmax,
-                          nullptr, 0, nullptr, nullptr};
-        if (la_ok && la->next_pairs) {
-            ca.next_pairs = la->next_pairs; ca.next_B = B;
-            ca.next_ulist = w.ulist + (size_t)(par ^ 1) * w.ucap; ca.next_n_u = w.n_u + (par ^ 1);
+                          (rows_cap + UT - 1) / UT, make_dropcfg(p->dropout), w.csamp, w.gmat, w.g0, ulist, n_rows, w.gnmax};
+        if (la_ok && la->next_pairs) {                           // (the finish kernel of this step forms the next step's list)
+            look_pairs = la->next_pairs;
+            look_ulist = w.ulist + (size_t)(par ^ 1) * w.ucap; look_n_u = w.n_u + (par ^ 1);
         }
         if (la) { la->have = la_ok && la->next_pairs != nullptr; la->parity = par ^ 1; }
-        PC_LAUNCH(sample_hidden_kernel, dim3(ca.nb_s + (T + UT - 1) / UT + (ca.next_pairs ? 1 : 0)), dim3(256), 0, st, ca);
+        PC_LAUNCH(sample_hidden_kernel, dim3(ca.nb_s + (T + UT - 1) / UT), dim3(256), 0, st, ca);
         SampleSimsArgs sa = {};
         sa.hd = w.csamp; sa.G = w.gmat; sa.g0 = w.g0; sa.B = B; sa.T = T; sa.K = K; sa.nchunks = w.nchunks_s;
         sa.part_val = w.part_val; sa.n_rows = n_rows;
@@ -2754,7 +2758,11 @@ static int fused_step_impl(const pc_joint_tensors* p, const pc_joint_tensors* g,
     for (int k = nj; k <= FIN_JOBS; k++) fin.block0[k] = blocks;
     fin.part_type = w.part; fin.part_item = w.part + B; fin.B = B; fin.K = K; fin.alpha = alpha; fin.losses = losses;
     fin.step_count = step_count; fin.lr = lr; fin.beta1 = beta1; fin.beta2 = beta2; fin.eps = eps; fin.adam = adam ? 1 : 0;
-    PC_LAUNCH(joint_finish_kernel, dim3(blocks + 1), dim3(256), 0, st, fin);
+    if (look_pairs) {
+        fin.next_pairs = look_pairs; fin.type_idx = src->type_idx; fin.P = num_products; fin.next_B = B; fin.T = T;
+        fin.next_ulist = look_ulist; fin.next_n_u = look_n_u;
+    }
+    PC_LAUNCH(joint_finish_kernel, dim3(blocks + 1 + (look_pairs ? 1 : 0)), dim3(256), 0, st, fin);
     return pc_launch_status();
 }
 

@@ -2,7 +2,7 @@
 
     python scripts/step_timeline.py gpurun_out/<tag>/prof/<tag>_results.db profiles/<name>.md [step]
 
-For one steady-state step (delimited by the Adam launch that ends the previous one) every dispatch with its queue, start and
+For one steady-state step (delimited by the launch that ends the previous one: Adam, or the slab reduce it rides in) every dispatch with its queue, start and
 duration, the gap to its predecessor ON THE SAME QUEUE (end -> start: launch boundary / dependency wait) and, for the queue that
 carries the step (the main queue), whether another queue's kernel was running beside it.  Then the sums: kernel time on the
 main queue, gaps on the main queue, what ran on side queues, and the median over all traced steps of the step's span."""
@@ -32,9 +32,12 @@ def main():
     ks = [t for t in tabs if t.startswith("rocpd_info_kernel_symbol")][0]
     rows = cur.execute(f"select s.kernel_name, d.start, d.end, d.queue_id, d.grid_size_x, d.workgroup_size_x from {kd} d "
                        f"join {ks} s on d.kernel_id=s.id order by d.start").fetchall()
+    # a step ends with its Adam launch -- or, since the optimizer rides in the slab reduce (round 6), with that launch
     ends = [i for i, r in enumerate(rows) if "adam_at_kernel" in r[0] or "adam_kernel" in r[0]]
     if len(ends) < 8:
-        raise SystemExit("fewer than 8 Adam launches in the trace")
+        ends = [i for i, r in enumerate(rows) if "tn_reduce_group_kernel" in r[0]]
+    if len(ends) < 8:
+        raise SystemExit("fewer than 8 step-ending launches in the trace")
     # the loader's builders (uq_* kernels, copies) run on their own queue, several steps ahead: attributed to the step whose
     # span they fall in
     steps = []
