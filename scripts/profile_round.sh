@@ -25,12 +25,12 @@ if [ -z "$NO_BENCH" ]; then
 python3 $R/bench.py > $OUT/bench.json 2> $OUT/bench.err
 fi
 if [ -z "$NO_TRACE" ]; then
-rocprofv3 --kernel-trace --stats -d $OUT/prof -o $TAG -- python3 $R/bench.py --phase p2v --steps 30 --warmup 5 --no-cpu-baseline --no-sustained --no-large --no-dropout-legs > $OUT/bench_under_rocprof.json 2> $OUT/rocprof.err
+rocprofv3 --kernel-trace --stats -d $OUT/prof -o $TAG -- python3 $R/bench.py --phase p2v --steps 30 --warmup 5 --no-cpu-baseline --no-sustained --no-large --no-dropout-legs --no-dropin > $OUT/bench_under_rocprof.json 2> $OUT/rocprof.err
 rocprofv3 --kernel-trace --stats -d $OUT/prof_joint -o ${TAG}_joint -- python3 $R/bench.py --phase joint --steps 25 --warmup 5 --no-cpu-baseline --no-sustained --no-ref-types --no-dropout-legs > $OUT/bench_joint_under_rocprof.json 2> $OUT/rocprof_joint.err
 fi
 if [ -z "$NO_PMC" ] && [ -z "$SKIP_MAIN_PMC" ]; then
-rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -- python3 $R/bench.py --phase p2v --steps 5 --warmup 2 --no-cpu-baseline --no-sustained --no-large --no-dropout-legs > /dev/null 2> $OUT/pmc_fetch.err
-rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -- python3 $R/bench.py --phase p2v --steps 5 --warmup 2 --no-cpu-baseline --no-sustained --no-large --no-dropout-legs > /dev/null 2> $OUT/pmc_write.err
+rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -- python3 $R/bench.py --phase p2v --steps 5 --warmup 2 --no-cpu-baseline --no-sustained --no-large --no-dropout-legs --no-dropin > /dev/null 2> $OUT/pmc_fetch.err
+rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -- python3 $R/bench.py --phase p2v --steps 5 --warmup 2 --no-cpu-baseline --no-sustained --no-large --no-dropout-legs --no-dropin > /dev/null 2> $OUT/pmc_write.err
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_joint_fetch -- python3 $R/bench.py --phase joint --steps 5 --warmup 2 --no-cpu-baseline --no-sustained --no-ref-types --no-dropout-legs > /dev/null 2> $OUT/pmc_joint_fetch.err
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_joint_write -- python3 $R/bench.py --phase joint --steps 5 --warmup 2 --no-cpu-baseline --no-sustained --no-ref-types --no-dropout-legs > /dev/null 2> $OUT/pmc_joint_write.err
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_joint34800_fetch -- python3 $R/bench.py --phase joint --types 34800 --steps 5 --warmup 2 --no-cpu-baseline --no-sustained --no-ref-types --no-dropout-legs > /dev/null 2> $OUT/pmc_joint34800_fetch.err
@@ -40,7 +40,7 @@ if [ -z "$NO_BENCH" ]; then cat $OUT/bench.json; fi
 # PD=1: the two DROPOUT = 0.1 legs of the default line that had no counter passes (Product2Vec and the joint step at T = 100):
 # HBM traffic of the same commands (bench.py reads profiles/<tag>_p2vd_pmc_traffic.json / <tag>_jointd_pmc_traffic.json)
 if [ -n "$PD" ]; then
-PDA="--phase p2v --dropout 0.1 --steps 5 --warmup 2 --no-cpu-baseline --no-sustained --no-large --no-dropout-legs"
+PDA="--phase p2v --dropout 0.1 --steps 5 --warmup 2 --no-cpu-baseline --no-sustained --no-large --no-dropout-legs --no-dropin"
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_p2vd_fetch -- python3 $R/bench.py $PDA > /dev/null 2> $OUT/pmc_p2vd_fetch.err
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_p2vd_write -- python3 $R/bench.py $PDA > /dev/null 2> $OUT/pmc_p2vd_write.err
 JDB="--phase joint --dropout 0.1 --steps 5 --warmup 2 --no-cpu-baseline --no-sustained --no-ref-types --no-dropout-legs"

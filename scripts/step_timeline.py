@@ -40,6 +40,10 @@ def main():
         raise SystemExit("fewer than 8 step-ending launches in the trace")
     # the loader's builders (uq_* kernels, copies) run on their own queue, several steps ahead: attributed to the step whose
     # span they fall in
+    # (only the fused index step's iterations: a trace may also hold the dense drop-in leg, whose autograd path ends in the same
+    # reduce kernel but never launches the prologue)
+    keep = [(a, b) for a, b in zip(ends[:-1], ends[1:]) if any("p2v_prologue_kernel" in r[0] for r in rows[a + 1:b + 1])]
+    ends = [keep[0][0]] + [b for _, b in keep] if keep else ends
     steps = []
     for a, b in zip(ends[:-1], ends[1:]):
         steps.append(rows[a + 1:b + 1])
