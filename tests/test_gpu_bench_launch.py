@@ -42,3 +42,26 @@ def test_bench_self_launches_its_ranks():
     bad = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(torch.cuda.device_count() + 1)], env=env,
                          capture_output=True, text=True, timeout=120, cwd=ROOT)
     assert bad.returncode != 0 and "visible GPUs" in bad.stderr and not bad.stdout.strip()
+
+
+@pytest.mark.timeout(900)
+def test_bench_world2_drives_the_large_legs():
+    """The N > 1 branches of the `large_catalogue` legs, which only an 8-GPU run would otherwise reach: configs[3] (10 M products,
+    sharded lookup), configs[4] (100 M x 256 row-sharded over the two ranks, Zipf negatives, the replicated hot set) and the
+    hot_set comparison -- two ranks on the one card of this box over gloo (a rehearsal of the code path, not a timing)."""
+    env = dict(os.environ, PC_DIST_BACKEND="gloo", PC_FORCE_DEVICE="0", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT", "PC_DIST_FORCE"):
+        env.pop(k, None)
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "2", "--phase", "p2v",
+                          "--no-cpu-baseline", "--no-sustained", "--no-dropout-legs"], env=env, capture_output=True, text=True,
+                         timeout=800, cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-3000:]
+    line = json.loads(out.stdout.strip().splitlines()[-1])
+    lc = line["large_catalogue"]
+    assert line["n_gpus"] == 2 and "error" not in lc["config3"] and "error" not in lc["config4"], lc
+    c4 = lc["config4"]["sharded_lookup"]
+    assert c4["hot_rows"] == 1024 and c4["hot_rows_served_per_batch"] > 1000          # the Zipf head served from the replica
+    assert lc["config3"]["sharded_lookup"]["hot_rows"] == 0                            # uniform negatives: no hot set
+    hs = lc["hot_set"]
+    assert hs["with"]["sharded_lookup"]["hot_rows_served_per_batch"] > 1000 and hs["without"]["sharded_lookup"]["hot_rows_served"] is None
+    assert abs(hs["with"]["final_loss"] - hs["without"]["final_loss"]) < 1e-6          # the same rows: the same training
