@@ -791,15 +791,17 @@ def leg_watchdog(name, world):
     if world <= 1:
         return None
     import threading
-    deadline = float(os.environ.get("PC_BENCH_LEG_DEADLINE_S", "180"))
+    # (the headline leg -- catalogue, model, loader set-up, warm-up, the timed region, the sustained leg -- gets its own, longer limit)
+    deadline = float(os.environ.get("PC_BENCH_HEADLINE_DEADLINE_S", "300")) if name == "headline" else \
+        float(os.environ.get("PC_BENCH_LEG_DEADLINE_S", "180"))
 
     def expire():
-        print(f"[bench] rank {FINAL['rank']}: leg `{name}` still running after {deadline:.0f} s -- ending the job with the legs measured so far",
+        print(f"[bench] rank {FINAL['rank']}: leg `{name}` still running after {deadline:g} s -- ending the job with the legs measured so far",
               file=sys.stderr, flush=True)
         code = 75
         if FINAL["rank"] == 0 and FINAL["emit"] is not None:
             try:
-                FINAL["emit"]({name: {"error": f"did not finish within {deadline:.0f} s (PC_BENCH_LEG_DEADLINE_S); job ended", "leg": name}})
+                FINAL["emit"]({name: {"error": f"did not finish within {deadline:g} s (PC_BENCH_LEG_DEADLINE_S); job ended", "leg": name}})
                 code = 0 if name != "headline" else 75
             except Exception:                                   # noqa: BLE001
                 pass

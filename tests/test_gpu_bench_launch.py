@@ -65,3 +65,21 @@ def test_bench_world2_drives_the_large_legs():
     hs = lc["hot_set"]
     assert hs["with"]["sharded_lookup"]["hot_rows_served_per_batch"] > 1000 and hs["without"]["sharded_lookup"]["hot_rows_served"] is None
     assert abs(hs["with"]["final_loss"] - hs["without"]["final_loss"]) < 1e-6          # the same rows: the same training
+
+
+@pytest.mark.timeout(600)
+def test_bench_world2_leg_watchdog_keeps_the_headline():
+    """N > 1: a secondary leg that does not finish inside its deadline (here: 0.25 s, which the joint leg's set-up alone exceeds)
+    must not cost the headline -- rank 0 prints the line with the legs measured so far and the leg reported as an error, every
+    rank leaves, the launcher exits 0."""
+    env = dict(os.environ, PC_DIST_BACKEND="gloo", PC_FORCE_DEVICE="0", HSA_ENABLE_IPC_MODE_LEGACY="0", PC_BENCH_LEG_DEADLINE_S="0.25")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT", "PC_DIST_FORCE"):
+        env.pop(k, None)
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "2",
+                          "--products", "20000", "--batch", "512", "--no-cpu-baseline", "--no-sustained", "--no-large",
+                          "--no-dropout-legs", "--no-ref-types"], env=env, capture_output=True, text=True, timeout=500, cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-3000:]
+    line = json.loads(out.stdout.strip().splitlines()[-1])
+    assert line["n_gpus"] == 2 and line["value"] > 0                      # the headline leg ran first and is in the line
+    assert "did not finish within 0.25 s" in line["joint"]["error"], line.get("joint")
+    assert "still running after 0.25 s" in out.stderr
