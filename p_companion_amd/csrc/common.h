@@ -428,7 +428,7 @@ struct TnReduceJob { const float* slabs; int nsplit, n; float* out; int accumula
 // slab reduce forms is followed, in the same thread, by the update of its parameter and moments (the flat buffers share offsets),
 // and rider workgroups behind the reduce blocks update the ranges no reduce job produces (biases and BatchNorm parameters other
 // kernels of the step finished earlier).  Same expressions as adam_at_kernel: same bits as the separate launch.
-#define PC_ADAM_REST 2 * (PC_TN_GROUP + PC_TN_EXTRA + 4) + 1
+#define PC_ADAM_REST (2 * (PC_TN_GROUP + PC_TN_EXTRA + 4) + 1)
 struct AdamRider {
     float *p, *m, *v; const float* g; size_t n;       // flat parameter / moment / gradient buffers (g: what the reduce jobs' outputs point into)
     int64_t* step_count; long long t; double lr, beta1, beta2; float omb1, beta2f, omb2, eps;
