@@ -511,8 +511,6 @@ class SimilarityIndexLoader:
                 done = torch.cuda.Event()
                 done.record(cur)
                 self._ring_done = done
-            if i + depth < n:
-                ahead.append(launch(i + depth))
             # the builder ran a step ago: normally its event has completed, and then nothing needs to be queued (a
             # cross-stream wait costs the consuming stream a barrier packet, ~10-40 us in front of every step's first kernel)
             if not ev.query():
@@ -527,6 +525,12 @@ class SimilarityIndexLoader:
                         if torch.is_tensor(t):
                             t.record_stream(cur)        # allocated on the side stream, consumed on this one
             yield batch
+            # the look-ahead builder is queued BEHIND the hand-out (round 6): when the consumer comes back for batch i + 1 it has
+            # launched step i, so the ~0.1 ms of host work of a builder launch no longer stands between a drained device and the
+            # first kernel of a loop's first step (profiles/r06_region_probe.txt: a region's first step ran 1.03-1.14 ms against
+            # 0.83).  The builder still has depth - 1 steps of lead; its ring wait is the latest event, as before.
+            if i + depth < n:
+                ahead.append(launch(i + depth))
         self._ring_base = base + n
         self._ring_clean = True
         self._end_of_epoch_checks()

@@ -520,7 +520,7 @@ BN_SYNC_DOUBLES = PC_MAX_SEG * 2 * H + PC_MAX_SEG
 
 
 def p2v_train_step(params, grads, table, anchor_idx, positive_idx, negative_idx, neighbor_idx, margin,
-                   want_emb=False, profile=None, sync_reduce=None, adam=None):
+                   want_emb=False, profile=None, sync_reduce=None, adam=None, structs=None):
     """One loop-body iteration of Product2Vec.train_model in index form (grads overwritten).
 
     sync_reduce: None = BatchNorm statistics of this batch; else a callable `reduce(buf)` that sums a
@@ -530,9 +530,18 @@ def p2v_train_step(params, grads, table, anchor_idx, positive_idx, negative_idx,
 
     adam (unique-neighbour layout, no sync_reduce): {"param", "grad", "exp_avg", "exp_avg_sq" (the flat buffers `grads` are views
     of), "step_count", "t" >= 1, "lr", "betas", "eps"} -- torch.optim.Adam's update inside the step's last gradient launch
-    (pc_p2v_train_step_unique_adam): optimizer.step() costs no launch of its own."""
-    st, dev = p2v_struct(params)
-    gst, _ = p2v_struct(grads, with_buffers=False)
+    (pc_p2v_train_step_unique_adam): optimizer.step() costs no launch of its own.
+
+    structs: (st, gst, dev) built earlier by p2v_struct over the SAME tensors (a training loop whose parameters are views of
+    fixed flat buffers builds them once: ~25 tensor checks per step less between a drained device and the step's first launch);
+    the dropout entry of `params` is applied to it per call."""
+    if structs is not None:
+        st, gst, dev = structs
+        st.dropout.p = 0.0
+        _set_dropout(st, params.get(DROPOUT_KEY))
+    else:
+        st, dev = p2v_struct(params)
+        gst, _ = p2v_struct(grads, with_buffers=False)
     b = anchor_idx.numel()
     k = negative_idx.shape[1]
     compact = isinstance(neighbor_idx, dict)          # {"nb_rows": [M+1], "slot_row": [B,N]} (+ "weight", "n_unique")

@@ -544,9 +544,24 @@ class Product2Vec(nn.Module, _FlatParamsMixin):
         optimizer (a FusedAdam over this module): product2vec.py:158's optimizer.step() as well -- inside the step's last
         gradient launch where the batch's layout carries it (the device loader's unique-neighbour batches, one process), by the
         optimizer's own launch otherwise.  Either way the caller does NOT call optimizer.step() for this iteration."""
-        self.flatten_parameters()
-        params = self._tensor_dict(self._next_dropout())
-        grads = {k: p.grad for k, p in self.named_parameters()}
+        flat, gflat = self.flatten_parameters()
+        # the tensor dicts and the C structs over them are rebuilt only when a buffer they describe has moved (the parameters and
+        # gradients are views of the flat buffers; the BatchNorm buffers are checked by address): a module-tree walk and ~25
+        # tensor checks per step otherwise stand between a drained device and the step's first launch
+        bn = self.ffn[1]
+        key = (flat.data_ptr(), gflat.data_ptr(), bn.running_mean.data_ptr(), bn.running_var.data_ptr(),
+               bn.num_batches_tracked.data_ptr(), self.dim)
+        cache = getattr(self, "_step_cache", None)
+        if cache is None or cache[0] != key:
+            params = self._tensor_dict()
+            grads = {k: p.grad for k, p in self.named_parameters()}
+            st, dev = ops.p2v_struct(params)
+            gst, _ = ops.p2v_struct(grads, with_buffers=False)
+            cache = self._step_cache = (key, params, grads, (st, gst, dev))
+        params, grads, structs = dict(cache[1]), cache[2], cache[3]
+        drop = self._next_dropout()
+        if drop is not None:
+            params[ops.DROPOUT_KEY] = drop
         nbr = batch.get("neighbor_compact", batch.get("neighbor_idx"))      # compact rows when the loader built them
         adam = None
         if optimizer is not None:
@@ -556,7 +571,7 @@ class Product2Vec(nn.Module, _FlatParamsMixin):
                 adam = optimizer.riding_state()
         out = ops.p2v_train_step(params, grads, table, batch["anchor_idx"], batch["positive_idx"],
                                  batch["negative_idx"], nbr, float(self.config.MARGIN), profile=profile,
-                                 sync_reduce=sync_reduce, adam=adam)
+                                 sync_reduce=sync_reduce, adam=adam, structs=structs)
         if optimizer is not None and adam is None:
             optimizer.step()
         return out["loss"]
