@@ -25,6 +25,9 @@ import torch.nn as nn
 
 from . import ops
 
+import weakref
+
+_STEP_CACHE = weakref.WeakKeyDictionary()        # Product2Vec -> (buffer addresses, tensor dicts, C structs) of train_step_indexed
 _FFN_KEYS = ops.P2V_KEYS[:8]
 _ATT_KEYS = ops.P2V_KEYS[8:]
 
@@ -551,13 +554,13 @@ class Product2Vec(nn.Module, _FlatParamsMixin):
         bn = self.ffn[1]
         key = (flat.data_ptr(), gflat.data_ptr(), bn.running_mean.data_ptr(), bn.running_var.data_ptr(),
                bn.num_batches_tracked.data_ptr(), self.dim)
-        cache = getattr(self, "_step_cache", None)
+        cache = _STEP_CACHE.get(self)               # (kept beside the module, not in it: ctypes structs do not pickle / deepcopy)
         if cache is None or cache[0] != key:
             params = self._tensor_dict()
             grads = {k: p.grad for k, p in self.named_parameters()}
             st, dev = ops.p2v_struct(params)
             gst, _ = ops.p2v_struct(grads, with_buffers=False)
-            cache = self._step_cache = (key, params, grads, (st, gst, dev))
+            cache = _STEP_CACHE[self] = (key, params, grads, (st, gst, dev))
         params, grads, structs = dict(cache[1]), cache[2], cache[3]
         drop = self._next_dropout()
         if drop is not None:

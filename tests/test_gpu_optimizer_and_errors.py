@@ -355,3 +355,30 @@ def test_adam_riding_in_the_steps_last_launch_equals_the_separate_launch(dim):
     assert torch.equal(m_a.flatten_parameters()[0], m_b.flatten_parameters()[0]) and int(o_b.step_count) == 7
     with pytest.raises(TypeError):
         m_a.train_step_indexed(table, bc, optimizer=o_b)                           # another module's optimizer
+
+
+def test_module_stays_copyable_and_picklable_after_fused_steps(tmp_path):
+    """The step wrapper keeps C structs over the module's buffers between steps -- beside the module, not in it: a trained module
+    still deep-copies and torch.save()s whole (the reference saves state_dicts, scripts/pretrain_product2vec.py:44-49, but a
+    caller may pickle the module), and the copy trains on from the same bits through its own buffers."""
+    import copy
+    from p_companion_amd.data import SimilarityIndexLoader, generate_scaled_bpg
+    from p_companion_amd.product2vec import FusedAdam, Product2Vec
+    bpg = generate_scaled_bpg(5000, 20, seed=4)
+    table = bpg.cuda()["features"]
+    torch.manual_seed(1)
+    m = Product2Vec(cfg()).to("cuda").train()
+    o = FusedAdam(m, lr=1e-3)
+    it = iter(SimilarityIndexLoader(bpg, 256, seed=1, drop_last=True, device="cuda", prefetch=False))
+    b1, b2 = next(it), next(it)
+    m.train_step_indexed(table, b1, optimizer=o)
+    m2 = copy.deepcopy(m)
+    torch.save(m, str(tmp_path / "module.pt"))
+    m3 = torch.load(str(tmp_path / "module.pt"), weights_only=False)
+    for other in (m2, m3):
+        for (k, p), (_, q) in zip(m.named_parameters(), other.named_parameters()):
+            assert torch.equal(p, q) and p.data_ptr() != q.data_ptr(), k
+    l1 = m.train_step_indexed(table, b2)
+    l2 = m2.train_step_indexed(table, b2)
+    assert torch.equal(l1, l2) and torch.equal(m.flatten_parameters()[1], m2.flatten_parameters()[1])
+    assert m.flatten_parameters()[0].data_ptr() != m2.flatten_parameters()[0].data_ptr()
