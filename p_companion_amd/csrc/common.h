@@ -432,7 +432,7 @@ struct TnReduceJob { const float* slabs; int nsplit, n; float* out; int accumula
 struct AdamRider {
     float *p, *m, *v; const float* g; size_t n;       // flat parameter / moment / gradient buffers (g: what the reduce jobs' outputs point into)
     int64_t* step_count; long long t; double lr, beta1, beta2; float omb1, beta2f, omb2, eps;
-    int block0;                                       // first rider block of the launch
+    int block0;                                       // reduce blocks of the launch (the rider blocks come FIRST in the grid, the reduce blocks behind them)
     int n_rest, rest_lo[PC_ADAM_REST], rest_hi[PC_ADAM_REST], rest_block0[PC_ADAM_REST + 1];      // float offsets, multiples of 4
 };
 struct TnReduceGroup {

@@ -521,20 +521,22 @@ __global__ __launch_bounds__(256) void tn_reduce_kernel(const float* slabs, int 
 }
 __global__ __launch_bounds__(256) void tn_reduce_group_kernel(TnReduceGroup g) {
     __shared__ float sc[2];
-    const int b = blockIdx.x;
     const bool with_adam = g.ad.p != nullptr;
+    // (the rider blocks come FIRST in the grid: dispatched first, they run beside the reduce blocks instead of behind them)
+    const int n_rider = with_adam ? g.ad.rest_block0[g.ad.n_rest] : 0;
+    const int b = (int)blockIdx.x - n_rider;
     if (with_adam) {
         if (threadIdx.x == 0) {                             // adam_at_kernel's scalars, the same fp64 expressions
             const double bc1 = 1.0 - pow(g.ad.beta1, (double)g.ad.t);
             const double bc2 = 1.0 - pow(g.ad.beta2, (double)g.ad.t);
             sc[0] = (float)(g.ad.lr / bc1);
             sc[1] = (float)sqrt(bc2);
-            if (b == 0 && g.ad.step_count) *g.ad.step_count = g.ad.t;
+            if (blockIdx.x == 0 && g.ad.step_count) *g.ad.step_count = g.ad.t;
         }
         __syncthreads();
-        if (b >= g.ad.block0) {
+        if (b < 0) {
             // rider: a gradient range no reduce job of this launch produces (finished by earlier kernels of the step)
-            const int rb = b - g.ad.block0;
+            const int rb = (int)blockIdx.x;
             int r = 0;
             for (int i = 1; i < g.ad.n_rest; i++) r += rb >= g.ad.rest_block0[i] ? 1 : 0;
             const int off = g.ad.rest_lo[r] + ((rb - g.ad.rest_block0[r]) * 256 + (int)threadIdx.x) * 4;

@@ -1583,8 +1583,10 @@ __global__ __launch_bounds__(256) void joint_finish_kernel(FinishArgs a) {
         present_types_body256(a.next_pairs, a.type_idx, a.P, a.next_B, a.T, a.next_ulist, a.next_n_u, pbits);
         return;
     }
-    const int b = (int)blockIdx.x - (a.next_pairs ? 1 : 0);
-    if (b == a.block0[a.njobs]) {                       // the extra workgroup: the two hinge means
+    // (the hinge means come next, for the same reason: at num_types > 512 the grid is thousands of streaming workgroups and its
+    // last one starts when the others are nearly done)
+    const int b = (int)blockIdx.x - (a.next_pairs ? 2 : 1);
+    if (b == -1) {                                      // the extra workgroup: the two hinge means
         float x = 0.f, y = 0.f;
         for (int i = threadIdx.x; i < a.B; i += 256) { x += a.part_type[i]; y += a.part_item[i]; }
         r0[threadIdx.x] = x; r1[threadIdx.x] = y;
