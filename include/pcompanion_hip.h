@@ -88,10 +88,13 @@ int pc_abi_version(void);
  * not fit the sort kernel's LDS (num_types > 65535, more than 24576 source rows) take the LDS-table form either way.
  * PC_OPT_BN_FINALIZE_SIDE (ABI 8): where the fused Product2Vec step runs its BatchNorm-backward finalize (BatchNorm1d of
  * product2vec.py:16; dgamma / dbeta and the coefficients dW0's loader applies).  0 (default) = on the step's own queue between
- * dZ1 and dW3 (3 us); 1 = on the side queue beside dW3 (rounds 3-5: the kernel hidden, two cross-queue hops exposed), kept for
+ * dZ1 and dW3 (12-14 us there, no hops); 1 = on the side queue beside dW3 (rounds 3-5: the kernel hidden, two ~7 us cross-queue hops exposed), kept for
  * comparison.
+ * PC_OPT_FUSED_LOSS (ABI 8): 1 (default) = the fused Product2Vec step at PRODUCT_EMB_DIM = 128 forms the triplet hinge of
+ * product2vec.py:137-154 and its three input gradients inside the first launch of the attention backward (the 16 samples of a
+ * tile compute their own rows: the same arithmetic, the same bits); 0 = as its own launch (rounds 1-5), kept for comparison.
  * Unknown option / value: PC_EINVAL.  Thread-safe. */
-enum { PC_OPT_SIDE_QUEUE = 1, PC_OPT_SORTED_TABLE_GRADIENTS = 2, PC_OPT_BN_FINALIZE_SIDE = 3 };
+enum { PC_OPT_SIDE_QUEUE = 1, PC_OPT_SORTED_TABLE_GRADIENTS = 2, PC_OPT_BN_FINALIZE_SIDE = 3, PC_OPT_FUSED_LOSS = 4 };
 int pc_set_option(int option, int value);
 int pc_get_option(int option, int* value);
 /* Destroys the library-owned device state (side queues and their events) of every device; 0 or a hipError_t. */

@@ -361,7 +361,88 @@ enum { NT_MODE_PLAIN = 0, NT_MODE_KHEAD = 1, NT_MODE_AHEAD = 2 };
 // rider (optional): loss = mean_b relu(margin - d+ + d-) (product2vec.py:154) by ONE extra workgroup of the chain launch that
 // follows the triplet-loss kernel in the fused step (a launch of its own costs ~4.5 us of latency for 16 KB of work)
 struct HingeMeanJob { const float* d_pos; const float* d_neg; int B; float margin; float* loss; };
-int launch_gemm_nt_chain(const NtArgs* args, const int* modes, int n, hipStream_t st, const HingeMeanJob* rider = nullptr);
+#ifdef __HIPCC__
+// One sample of the triplet hinge (product2vec.py:137-154) by a group of 16 lanes at PRODUCT_EMB_DIM = 128: lane l16 owns dims
+// [8 l16, 8 l16 + 8); d+ = ||a - p + eps||, d-_j = ||a - n_j + eps||, d- = mean_j d-_j; gradients of mean_b relu(margin - d+ + d-)
+// w.r.t. a, p and every n_j.  ONE definition for the stand-alone kernel (four samples per wave) and for the prologue of the
+// attention backward's first chain (the tile's sixteen samples at once): the same bits either way.  Rows past the batch
+// (live == false) are read from sample 0 and nothing of them is stored; ga[8] returns d(loss)/d(a) (zeros when not live).
+#define PC_LOSS_MAX_K 8
+#define PC_PAIR_EPS 1e-6f
+__device__ __forceinline__ void triplet_sample16(const float* __restrict__ a, const float* __restrict__ p, const float* __restrict__ n,
+                                                 int b, int B, int K, float margin, bool live, float* d_pos, float* d_neg,
+                                                 float* dp, float* dn, bool grads, int l16, float (&ga)[8]) {
+    constexpr int D = 128;
+    const size_t bb = live ? (size_t)b : 0;
+    float av[8], dpv[8], dnv[PC_LOSS_MAX_K][8], dn_j[PC_LOSS_MAX_K];
+    {
+        const float4 a0 = *reinterpret_cast<const float4*>(a + bb * D + 8 * l16), a1 = *reinterpret_cast<const float4*>(a + bb * D + 8 * l16 + 4);
+        const float4 p0 = *reinterpret_cast<const float4*>(p + bb * D + 8 * l16), p1 = *reinterpret_cast<const float4*>(p + bb * D + 8 * l16 + 4);
+        av[0] = a0.x; av[1] = a0.y; av[2] = a0.z; av[3] = a0.w; av[4] = a1.x; av[5] = a1.y; av[6] = a1.z; av[7] = a1.w;
+        const float pv[8] = {p0.x, p0.y, p0.z, p0.w, p1.x, p1.y, p1.z, p1.w};
+#pragma unroll
+        for (int c = 0; c < 8; c++) dpv[c] = av[c] - pv[c] + PC_PAIR_EPS;
+    }
+#pragma unroll
+    for (int j = 0; j < PC_LOSS_MAX_K; j++)
+        if (j < K) {
+            const float* r = n + (bb * K + j) * D + 8 * l16;
+            const float4 n0 = *reinterpret_cast<const float4*>(r), n1 = *reinterpret_cast<const float4*>(r + 4);
+            const float nv[8] = {n0.x, n0.y, n0.z, n0.w, n1.x, n1.y, n1.z, n1.w};
+#pragma unroll
+            for (int c = 0; c < 8; c++) dnv[j][c] = av[c] - nv[c] + PC_PAIR_EPS;
+        }
+    float s = 0.f;
+#pragma unroll
+    for (int c = 0; c < 8; c++) s += dpv[c] * dpv[c];
+    const float dpos = sqrtf(group16_sum(s));
+    float dneg = 0.f;
+#pragma unroll
+    for (int j = 0; j < PC_LOSS_MAX_K; j++)
+        if (j < K) {
+            float t = 0.f;
+#pragma unroll
+            for (int c = 0; c < 8; c++) t += dnv[j][c] * dnv[j][c];
+            dn_j[j] = sqrtf(group16_sum(t));
+            dneg += dn_j[j];
+        }
+    dneg /= (float)K;
+    if (live && l16 == 0) { d_pos[b] = dpos; d_neg[b] = dneg; }
+#pragma unroll
+    for (int c = 0; c < 8; c++) ga[c] = 0.f;
+    if (!grads) return;
+    const bool active = (margin - dpos + dneg) > 0.f;      // relu'(0) = 0 as in torch
+    const float gs = (active && live) ? 1.0f / (float)B : 0.f;        // d(mean)/d(l_b)
+    const float ip = gs / dpos;                            // d l / d d+ = -1 ; d l / d d-_j = 1/K
+#pragma unroll
+    for (int c = 0; c < 8; c++) ga[c] = -dpv[c] * ip;
+    if (live) {
+        *reinterpret_cast<float4*>(dp + bb * D + 8 * l16) = make_float4(dpv[0] * ip, dpv[1] * ip, dpv[2] * ip, dpv[3] * ip);
+        *reinterpret_cast<float4*>(dp + bb * D + 8 * l16 + 4) = make_float4(dpv[4] * ip, dpv[5] * ip, dpv[6] * ip, dpv[7] * ip);
+    }
+#pragma unroll
+    for (int j = 0; j < PC_LOSS_MAX_K; j++)
+        if (j < K) {
+            const float in = gs / ((float)K * dn_j[j]);
+#pragma unroll
+            for (int c = 0; c < 8; c++) ga[c] += dnv[j][c] * in;
+            if (live) {
+                float* r = dn + (bb * K + j) * D + 8 * l16;
+                *reinterpret_cast<float4*>(r) = make_float4(-dnv[j][0] * in, -dnv[j][1] * in, -dnv[j][2] * in, -dnv[j][3] * in);
+                *reinterpret_cast<float4*>(r + 4) = make_float4(-dnv[j][4] * in, -dnv[j][5] * in, -dnv[j][6] * in, -dnv[j][7] * in);
+            }
+        }
+}
+#endif
+
+// The hinge of product2vec.py:137-154 (forward and all three input gradients) as the PROLOGUE of the attention backward's first
+// chain (round 6): the 16 samples of a chain tile form their own rows of d(loss)/d(anchor embedding) -- the chain's A operand --
+// straight into the tile's LDS image (and into `demb` for the out-projection's weight gradient), beside d_pos / d_neg and the
+// positives' / negatives' gradient rows: triplet_sample16, the stand-alone kernel's own arithmetic, without its launch (10.5 us
+// between two 11 us chains, each at the floor of a launch of dependent round trips).  emb == NULL: no prologue.
+struct LossPro { const float *emb, *pos, *neg; int B, K; float margin; float *d_pos, *d_neg, *dp, *dn, *demb; };
+int launch_gemm_nt_chain(const NtArgs* args, const int* modes, int n, hipStream_t st, const HingeMeanJob* rider = nullptr,
+                         const LossPro* loss = nullptr);
 #ifdef __HIPCC__
 // one workgroup of >= 256 threads (the first 256 add, in the same fixed order whatever the workgroup size; the others only
 // take part in the barriers)

@@ -202,8 +202,8 @@ __global__ void bn_eval_coeff_kernel(const float* gamma, const float* beta, cons
 }
 
 // per-tile (sum dz1, sum dz1*h0) -> dgamma, dbeta (+ per-segment means c1 = dbeta_s/n, c2 = dgamma_s/n)
-// (round 6: one pass over all segments like the forward finalize, 32 tile lanes, on the step's own queue -- 3 us between dZ1 and
-// dW3 instead of 12-32 us on the side queue plus the two cross-queue hops, ~6.5 us each on the main queue)
+// (round 6: one pass over all segments like the forward finalize, on the step's own queue between dZ1 and dW3 instead of the
+// side queue: the two cross-queue hops it needed there cost the main queue ~6.5 us each)
 __global__ __launch_bounds__(FIN4_CG * FIN4_LANES) void bn_finalize_bwd_kernel(
     const float* psum, const float* pdot, SegInfo si, const double* lsum, const double* gsum, const float* mean,
     const float* invstd, float* dgamma, float* dbeta, int accumulate, float* c1, float* c2) {
@@ -523,7 +523,8 @@ int ffn_backward_part1(const pc_p2v_tensors* p, const pc_p2v_tensors* g, const f
     if (df->fork && !local_sums) {
         // the BatchNorm-backward finalize (only dW0 reads c1 / c2).  Rounds 3-5: on the side queue beside dW3 -- the fork and the
         // join each cost the main queue ~6.5 us (profiles/r06a_step_timeline.md) and the 8-workgroup kernel took 12-32 us there.
-        // Round 6: 3 us on the step's own queue, between dZ1 and dW3 (pc_get_option(PC_OPT_BN_FINALIZE_SIDE) = 1: the old placement)
+        // Round 6: on the step's own queue, between dZ1 and dW3: 12-14 us exposed, no hops, -8 us per step in A/B
+        // (pc_set_option(PC_OPT_BN_FINALIZE_SIDE, 1): the old placement)
         if (pc_opt_bn_finalize_side()) {
             PC_TRY(pc_fork_begin(df->fork, 1, st));
             PC_LAUNCH(bn_finalize_bwd_kernel, dim3(PC_H / FIN_COLS), dim3(FIN4_CG, FIN4_LANES), 0, df->fork->side, w.stat_a, w.stat_b, si,

@@ -691,7 +691,7 @@ static SegInfo retile_plain(int M) {
 //          product; wave h multiplies its head's 32 k's against all four column blocks; ldc = 512)
 //   AHEAD  C[r][32h + j]   = sum_{d<128} A[r][h*128 + d] W[32h + j][d]  (+ bias[32h + j] * brs[r][h]; A is four staged
 //          32 x 128 images, one per head; wave h takes image h and its own 32 output columns)
-struct NtChain { NtArgs a[2]; int mode[2], epi[2], n, tiles; HingeMeanJob rider; };
+struct NtChain { NtArgs a[2]; int mode[2], epi[2], n, tiles; HingeMeanJob rider; LossPro loss; };
 
 // The burst goes global -> registers -> LDS here (every lane up to 32 independent 16-B loads in flight, then the
 // swizzled ds_write_b128s): measured with in-kernel clocks (scripts/dev/chain_phase_times.py), a 4-wave workgroup issuing its
@@ -833,6 +833,23 @@ __global__ __launch_bounds__(256) void gemm_nt_chain_kernel(NtChain c) {
 // are read again later in the step) instead of through a store / vmcnt(0) / reload round trip.
 //   AHEAD_FIRST = false:  PLAIN -> KHEAD   (q -> qt, dctx -> dc)
 //   AHEAD_FIRST = true:   AHEAD -> PLAIN   (c -> ctx -> out, dqt -> dq -> dquery)
+// LossPro (common.h): wave w of a 16-sample chain tile takes samples 4 w .. 4 w + 3, one per 16-lane group, all sixteen of the
+// tile at once (triplet_sample16: the stand-alone kernel's definition -- the same bits).  (A first version gave every sample a
+// whole wave, four in turn: the fused launch then lasted exactly as long as the two it replaced.)
+#define LP_MAX_K PC_LOSS_MAX_K
+__device__ __forceinline__ void loss_prologue16(const LossPro& lp, int row0, float* sA, int lda, int w, int lane) {
+    const int g = lane >> 4, l16 = lane & 15, row = 4 * w + g, b = row0 + row;
+    const bool live = b < lp.B;
+    float ga[8];
+    triplet_sample16(lp.emb, lp.pos, lp.neg, b, lp.B, lp.K, lp.margin, live, lp.d_pos, lp.d_neg, lp.dp, lp.dn, true, l16, ga);
+    *reinterpret_cast<float4*>(&sA[row * lda + 8 * l16]) = make_float4(ga[0], ga[1], ga[2], ga[3]);
+    *reinterpret_cast<float4*>(&sA[row * lda + 8 * l16 + 4]) = make_float4(ga[4], ga[5], ga[6], ga[7]);
+    if (live) {
+        *reinterpret_cast<float4*>(lp.demb + (size_t)b * 128 + 8 * l16) = make_float4(ga[0], ga[1], ga[2], ga[3]);
+        *reinterpret_cast<float4*>(lp.demb + (size_t)b * 128 + 8 * l16 + 4) = make_float4(ga[4], ga[5], ga[6], ga[7]);
+    }
+}
+
 #define CH_LDA 132          /* LDS row strides: width + 4 floats */
 #define CH_LDA4 516
 template <bool AHEAD_FIRST>
@@ -881,12 +898,17 @@ __global__ __launch_bounds__(256) void gemm_nt_chain16_kernel(NtChain c) {
 #pragma unroll
         for (int nb = 0; nb < 8; nb++) fk[nb] = load_b<32, false>(a1.W + 32 * w, a1.ldw, 16 * nb, 128, lane);
         const float bp[2] = {a0.bias ? a0.bias[16 * (2 * w) + ci] : 0.f, a0.bias ? a0.bias[16 * (2 * w + 1) + ci] : 0.f};
+        if (c.loss.emb) {
+            // the tile's A rows are d(loss)/d(anchor embedding) of its 16 samples: formed here (LossPro), behind the weight requests
+            loss_prologue16(c.loss, row0, sA, CH_LDA, w, lane);
+        } else {
 #pragma unroll
-        for (int u = 0; u < 2; u++) {
-            const int e = tid + 256 * u, r = e >> 5, c4 = (e & 31) * 4;
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (row0 + r < M) v = *reinterpret_cast<const float4*>(a0.A + (size_t)(row0 + r) * a0.lda + c4);
-            *reinterpret_cast<float4*>(&sA[r * CH_LDA + c4]) = v;
+            for (int u = 0; u < 2; u++) {
+                const int e = tid + 256 * u, r = e >> 5, c4 = (e & 31) * 4;
+                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (row0 + r < M) v = *reinterpret_cast<const float4*>(a0.A + (size_t)(row0 + r) * a0.lda + c4);
+                *reinterpret_cast<float4*>(&sA[r * CH_LDA + c4]) = v;
+            }
         }
         lds_sync();
         plain(a0, fp, bp, sA, sS);
@@ -1083,9 +1105,18 @@ __global__ __launch_bounds__(256) void gemm_nt_chain16_d256_kernel(NtChain c) {
 }
 
 // The attention chains: every stage M rows (the same M); D = 128 or 256: K = N = D per plain stage / head structure above.
-int launch_gemm_nt_chain(const NtArgs* args, const int* modes, int n, hipStream_t st, const HingeMeanJob* rider) {
+int launch_gemm_nt_chain(const NtArgs* args, const int* modes, int n, hipStream_t st, const HingeMeanJob* rider, const LossPro* loss) {
     if (!args || !modes || n < 1 || n > 2) return PC_EINVAL;
     NtChain c = {};
+    if (loss) {
+        // the loss prologue serves the attention backward's first chain at PRODUCT_EMB_DIM = 128: PLAIN (d_out -> d_ctx) then KHEAD,
+        // 16-row tiles, the prologue's rows ARE the first product's A operand
+        if (n != 2 || modes[0] != NT_MODE_PLAIN || modes[1] != NT_MODE_KHEAD || args[0].N != 128 || args[0].K != 128 || args[0].brs)
+            return PC_ESHAPE;
+        if (!loss->emb || !loss->pos || !loss->neg || !loss->d_pos || !loss->d_neg || !loss->dp || !loss->dn || !loss->demb) return PC_EINVAL;
+        if (loss->B != args[0].M || loss->K < 1 || loss->K > LP_MAX_K || loss->demb != args[0].A || args[0].lda != 128) return PC_EINVAL;
+        c.loss = *loss;
+    }
     c.n = n;
     double flops = 0.0;
     for (int i = 0; i < n; i++) {

@@ -76,6 +76,21 @@ __global__ void hinge_mean_kernel(HingeMeanJob j) {
     hinge_mean_body(j, red);
 }
 
+// PRODUCT_EMB_DIM = 128: a 16-lane group per sample, sixteen samples per workgroup (triplet_sample16, common.h: the definition the
+// fused step's loss prologue shares)
+__global__ __launch_bounds__(256) void triplet_loss16_kernel(const float* a, const float* p, const float* n, int B, int K, float margin,
+                                                             float* d_pos, float* d_neg, float* da, float* dp, float* dn) {
+    const int l16 = threadIdx.x & 15;
+    const int b = blockIdx.x * 16 + (threadIdx.x >> 4);
+    const bool live = b < B;
+    float ga[8];
+    triplet_sample16(a, p, n, b, B, K, margin, live, d_pos, d_neg, dp, dn, da != nullptr, l16, ga);
+    if (da && live) {
+        *reinterpret_cast<float4*>(da + (size_t)b * 128 + 8 * l16) = make_float4(ga[0], ga[1], ga[2], ga[3]);
+        *reinterpret_cast<float4*>(da + (size_t)b * 128 + 8 * l16 + 4) = make_float4(ga[4], ga[5], ga[6], ga[7]);
+    }
+}
+
 // with_mean == 0: the caller folds the mean into a later launch (HingeMeanJob rider of launch_gemm_nt_chain)
 int triplet_loss_launch(const float* a, const float* p, const float* n, int batch, int k_neg, int dim, float margin,
                         float* loss, float* d_pos, float* d_neg, float* da, float* dp, float* dn, void* stream, int with_mean) {
@@ -83,7 +98,7 @@ int triplet_loss_launch(const float* a, const float* p, const float* n, int batc
     if (k_neg < 1 || k_neg > LOSS_MAX_K || (dim != 128 && dim != 256)) return PC_ESHAPE;
     if (da && (!dp || !dn)) return PC_EINVAL;
     hipStream_t st = (hipStream_t)stream;
-    if (dim == 128) PC_LAUNCH(triplet_loss_kernel<2>, dim3((batch + 3) / 4), dim3(256), 0, st, a, p, n, batch, k_neg, margin,
+    if (dim == 128) PC_LAUNCH(triplet_loss16_kernel, dim3((batch + 15) / 16), dim3(256), 0, st, a, p, n, batch, k_neg, margin,
                               d_pos, d_neg, da, dp, dn);
     else PC_LAUNCH(triplet_loss_kernel<4>, dim3((batch + 3) / 4), dim3(256), 0, st, a, p, n, batch, k_neg, margin,
                    d_pos, d_neg, da, dp, dn);

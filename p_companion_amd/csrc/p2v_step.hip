@@ -126,7 +126,8 @@ int attention_backward_impl(const pc_p2v_tensors* p, const pc_p2v_tensors* g, co
                             int B, int N, int key_rows, const int32_t* slot_row, int pad_row, const float* dout,
                             const pc_attn_saved* sv, float* dquery, float* dkeys, int accumulate, void* ws,
                             size_t ws_bytes, void* stream, const int32_t* ref_off, const int32_t* ref_slot,
-                            int transposed, TnDefer* defer, const HingeMeanJob* rider);
+                            int transposed, TnDefer* defer, const HingeMeanJob* rider, const LossPro* lossp);
+int pc_opt_fused_loss();       // (gemm_tn.hip: pc_set_option)
 int triplet_loss_launch(const float* a, const float* p, const float* n, int batch, int k_neg, int dim, float margin,
                         float* loss, float* d_pos, float* d_neg, float* da, float* dp, float* dn, void* stream, int with_mean);
 
@@ -221,8 +222,14 @@ static int p2v_step_impl(const pc_p2v_tensors* p, const pc_p2v_tensors* g, const
     float* demb = N > 0 ? w.demb : w.dy + (size_t)rA * D;
     // the hinge mean rides on the first launch of the attention backward (D = 128 with neighbours); nothing in the step reads it
     const bool mean_rides = N > 0 && D == 128;
-    PC_TRY(triplet_loss_launch(emb, w.y + (size_t)rP * D, w.y + (size_t)rG * D, B, K, D, margin, loss, dp_out,
-                               dn_out, demb, w.dy + (size_t)rP * D, w.dy + (size_t)rG * D, stream, mean_rides ? 0 : 1));
+    // ... and so does the hinge itself (round 6): the prologue of the attention backward's first chain (LossPro, common.h) --
+    // pc_set_option(PC_OPT_FUSED_LOSS, 0) keeps its own launch
+    const bool loss_rides = mean_rides && K <= 8 && pc_opt_fused_loss();
+    const LossPro lp = {emb, w.y + (size_t)rP * D, w.y + (size_t)rG * D, B, K, margin, dp_out, dn_out,
+                        w.dy + (size_t)rP * D, w.dy + (size_t)rG * D, w.demb};
+    if (!loss_rides)
+        PC_TRY(triplet_loss_launch(emb, w.y + (size_t)rP * D, w.y + (size_t)rG * D, B, K, D, margin, loss, dp_out,
+                                   dn_out, demb, w.dy + (size_t)rP * D, w.dy + (size_t)rG * D, stream, mean_rides ? 0 : 1));
     const HingeMeanJob hm = {dp_out, dn_out, B, margin, loss};
     if (anchor_emb)
         PC_HIP_TRY(hipMemcpyAsync(anchor_emb, emb, (size_t)B * D * 4, hipMemcpyDeviceToDevice, st));
@@ -244,7 +251,7 @@ static int p2v_step_impl(const pc_p2v_tensors* p, const pc_p2v_tensors* g, const
         PC_TRY(attention_backward_impl(p, g, w.y + (size_t)rA * D, w.y + (size_t)rN * D, B, N, nbc, slot_row,
                                        slot_row ? nbc - 1 : -1, w.demb, &as, w.dy + (size_t)rA * D,
                                        w.dy + (size_t)rN * D, 0, w.attn_ws, w.attn_bytes, stream, ref_off, ref_slot, 1, &df,
-                                       mean_rides ? &hm : nullptr));
+                                       mean_rides ? &hm : nullptr, loss_rides ? &lp : nullptr));
     } else {
         PC_HIP_TRY(hipMemsetAsync(g->in_proj_w, 0, 3 * D * D * 4, st));
         PC_HIP_TRY(hipMemsetAsync(g->in_proj_b, 0, 3 * D * 4, st));

@@ -75,10 +75,17 @@ def test_side_queue_fork_changes_no_bit():
         assert L.pc_set_option(_lib.PC_OPT_BN_FINALIZE_SIDE, 1) == 0
         outs.append(_fork_digest())
         torch.cuda.synchronize()
+        assert L.pc_set_option(_lib.PC_OPT_BN_FINALIZE_SIDE, 0) == 0
+        # the triplet hinge inside the attention backward's first launch (default) or as its own launch (rounds 1-5): same bits
+        assert L.pc_get_option(_lib.PC_OPT_FUSED_LOSS, ctypes.byref(v)) == 0 and v.value == 1
+        assert L.pc_set_option(_lib.PC_OPT_FUSED_LOSS, 0) == 0
+        outs.append(_fork_digest())
+        torch.cuda.synchronize()
     finally:
         L.pc_set_option(_lib.PC_OPT_SIDE_QUEUE, 1)
         L.pc_set_option(_lib.PC_OPT_BN_FINALIZE_SIDE, 0)
-    assert outs[0] == outs[1] == outs[2] == outs[3]
+        L.pc_set_option(_lib.PC_OPT_FUSED_LOSS, 1)
+    assert outs[0] == outs[1] == outs[2] == outs[3] == outs[4]
 
 
 def test_fused_p2v_step_under_stream_capture_stays_on_one_queue():
