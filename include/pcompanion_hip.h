@@ -93,8 +93,12 @@ int pc_abi_version(void);
  * PC_OPT_FUSED_LOSS (ABI 8): 1 (default) = the fused Product2Vec step at PRODUCT_EMB_DIM = 128 forms the triplet hinge of
  * product2vec.py:137-154 and its three input gradients inside the first launch of the attention backward (the 16 samples of a
  * tile compute their own rows: the same arithmetic, the same bits); 0 = as its own launch (rounds 1-5), kept for comparison.
+ * PC_OPT_FUSED_OUT_CHAIN (ABI 8; needs PC_OPT_FUSED_LOSS): 1 (default) = the attention forward's last launch (ctx and the
+ * out-projection, MultiheadAttention of product2vec.py:23-28,48-68) runs in front of that prologue in the same launch -- per
+ * 16-sample tile: out-projection forward, hinge, out-projection backward; 0 = its own launch.  Same bits.
  * Unknown option / value: PC_EINVAL.  Thread-safe. */
-enum { PC_OPT_SIDE_QUEUE = 1, PC_OPT_SORTED_TABLE_GRADIENTS = 2, PC_OPT_BN_FINALIZE_SIDE = 3, PC_OPT_FUSED_LOSS = 4 };
+enum { PC_OPT_SIDE_QUEUE = 1, PC_OPT_SORTED_TABLE_GRADIENTS = 2, PC_OPT_BN_FINALIZE_SIDE = 3, PC_OPT_FUSED_LOSS = 4,
+       PC_OPT_FUSED_OUT_CHAIN = 5 };
 int pc_set_option(int option, int value);
 int pc_get_option(int option, int* value);
 /* Destroys the library-owned device state (side queues and their events) of every device; 0 or a hipError_t. */

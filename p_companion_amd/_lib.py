@@ -77,6 +77,7 @@ class AdamFused(ctypes.Structure):
 
 
 PC_OPT_SIDE_QUEUE = 1      # pc_set_option: the fused Product2Vec step's side queue (include/pcompanion_hip.h)
+PC_OPT_FUSED_OUT_CHAIN = 5           # ... and the out-projection's forward chain in front of it in the same launch (default 1)
 PC_OPT_FUSED_LOSS = 4                # ... the triplet hinge inside the attention backward's first launch (default 1)
 PC_OPT_BN_FINALIZE_SIDE = 3          # ... the BatchNorm-backward finalize of the fused Product2Vec step on the side queue (default 0: on the step's own)
 PC_OPT_SORTED_TABLE_GRADIENTS = 2    # ... the [T,64] table gradients of the fused joint step through the sorted form wherever it fits (default 1)

@@ -443,6 +443,7 @@ __device__ __forceinline__ void triplet_sample16(const float* __restrict__ a, co
 struct LossPro { const float *emb, *pos, *neg; int B, K; float margin; float *d_pos, *d_neg, *dp, *dn, *demb; };
 int launch_gemm_nt_chain(const NtArgs* args, const int* modes, int n, hipStream_t st, const HingeMeanJob* rider = nullptr,
                          const LossPro* loss = nullptr);
+int launch_gemm_nt_chain_pair(const NtArgs* fwd, const NtArgs* bwd, const LossPro* loss, hipStream_t st);
 #ifdef __HIPCC__
 // one workgroup of >= 256 threads (the first 256 add, in the same fixed order whatever the workgroup size; the others only
 // take part in the barriers)

@@ -852,20 +852,12 @@ __device__ __forceinline__ void loss_prologue16(const LossPro& lp, int row0, flo
 
 #define CH_LDA 132          /* LDS row strides: width + 4 floats */
 #define CH_LDA4 516
+// one two-stage chain over the 16-row tile at row0 (sA: 16 x CH_LDA4 floats when AHEAD_FIRST, else 16 x CH_LDA; sS: 16 x CH_LDA)
 template <bool AHEAD_FIRST>
-__global__ __launch_bounds__(256) void gemm_nt_chain16_kernel(NtChain c) {
-    __shared__ __attribute__((aligned(16))) float sA[16 * (AHEAD_FIRST ? CH_LDA4 : CH_LDA)];
-    __shared__ __attribute__((aligned(16))) float sS[16 * CH_LDA];
-    if ((int)blockIdx.x >= c.tiles) {                            // the rider's workgroup (see HingeMeanJob)
-        __shared__ float red[256];
-        hinge_mean_body(c.rider, red);
-        return;
-    }
+__device__ __forceinline__ void chain16_body(const NtArgs& a0, const NtArgs& a1, const LossPro& loss, float* sA, float* sS, int row0) {
     const int tid = threadIdx.x, lane = tid & 63, ci = lane & 15, rh = lane >> 4;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const NtArgs& a0 = c.a[0];
-    const NtArgs& a1 = c.a[1];
-    const int row0 = blockIdx.x * 16, M = a0.M;
+    const int M = a0.M;
     auto lds_sync = [&]() {
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
@@ -898,9 +890,9 @@ __global__ __launch_bounds__(256) void gemm_nt_chain16_kernel(NtChain c) {
 #pragma unroll
         for (int nb = 0; nb < 8; nb++) fk[nb] = load_b<32, false>(a1.W + 32 * w, a1.ldw, 16 * nb, 128, lane);
         const float bp[2] = {a0.bias ? a0.bias[16 * (2 * w) + ci] : 0.f, a0.bias ? a0.bias[16 * (2 * w + 1) + ci] : 0.f};
-        if (c.loss.emb) {
+        if (loss.emb) {
             // the tile's A rows are d(loss)/d(anchor embedding) of its 16 samples: formed here (LossPro), behind the weight requests
-            loss_prologue16(c.loss, row0, sA, CH_LDA, w, lane);
+            loss_prologue16(loss, row0, sA, CH_LDA, w, lane);
         } else {
 #pragma unroll
             for (int u = 0; u < 2; u++) {
@@ -969,6 +961,35 @@ __global__ __launch_bounds__(256) void gemm_nt_chain16_kernel(NtChain c) {
         lds_sync();
         plain(a1, fp, bp, sS, nullptr);
     }
+}
+
+template <bool AHEAD_FIRST>
+__global__ __launch_bounds__(256) void gemm_nt_chain16_kernel(NtChain c) {
+    __shared__ __attribute__((aligned(16))) float sA[16 * (AHEAD_FIRST ? CH_LDA4 : CH_LDA)];
+    __shared__ __attribute__((aligned(16))) float sS[16 * CH_LDA];
+    if ((int)blockIdx.x >= c.tiles) {                            // the rider's workgroup (see HingeMeanJob)
+        __shared__ float red[256];
+        hinge_mean_body(c.rider, red);
+        return;
+    }
+    chain16_body<AHEAD_FIRST>(c.a[0], c.a[1], c.loss, sA, sS, blockIdx.x * 16);
+}
+
+// The out-projection's forward chain (ctx = c Wv^T ..., out = ctx Wo^T + bo), the triplet hinge and the backward chain
+// (d_ctx = d_out Wo, d_c = d_ctx Wv_h) of the fused Product2Vec step as ONE launch (round 6): everything in them is per SAMPLE,
+// so the 16 samples of a tile run all four products and their loss back to back -- the rows a stage needs from the one before
+// it were written by this workgroup (global memory behind a workgroup-scope release / acquire, or the LDS tiles).
+struct NtChainPair { NtArgs a[4]; int tiles; LossPro loss; };
+__global__ __launch_bounds__(256) void gemm_nt_chain16_pair_kernel(NtChainPair c) {
+    __shared__ __attribute__((aligned(16))) float sA[16 * CH_LDA4];
+    __shared__ __attribute__((aligned(16))) float sS[16 * CH_LDA];
+    const LossPro none = {};
+    chain16_body<true>(c.a[0], c.a[1], none, sA, sS, blockIdx.x * 16);
+    // the embedding rows of this tile (a[1].C) are the loss's input: written above by this workgroup's waves
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __syncthreads();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    chain16_body<false>(c.a[2], c.a[3], c.loss, sA, sS, blockIdx.x * 16);
 }
 
 // The same chains at PRODUCT_EMB_DIM = 256 (BASELINE configs[4]; head dim 64): the attention block's per-sample products ran as
@@ -1185,6 +1206,35 @@ int launch_gemm_nt_chain(const NtArgs* args, const int* modes, int n, hipStream_
     (void)lds_attr;
     const int pb = pc_prof_begin(PC_KIND_GEMM_NT_SMALL, flops, st);
     PC_LAUNCH(gemm_nt_chain_kernel, dim3(tiles + (rider ? 1 : 0)), dim3(256), lds, st, c);
+    pc_prof_end(pb, st);
+    return pc_launch_status();
+}
+
+// fwd: {AHEAD (c -> ctx), PLAIN (ctx -> out)}; bwd: {PLAIN (d_out -> d_ctx), KHEAD (d_ctx -> d_c)}; loss->emb == fwd[1].C and
+// loss->demb == bwd[0].A (gemm_nt_chain16_pair_kernel)
+int launch_gemm_nt_chain_pair(const NtArgs* fwd, const NtArgs* bwd, const LossPro* loss, hipStream_t st) {
+    if (!fwd || !bwd || !loss) return PC_EINVAL;
+    NtChainPair c = {};
+    double flops = 0.0;
+    for (int i = 0; i < 4; i++) {
+        const NtArgs& a = i < 2 ? fwd[i] : bwd[i - 2];
+        if (!a.A || !a.W || !a.C || a.M <= 0 || a.M != fwd[0].M) return PC_EINVAL;
+        if (a.gather || a.prologue != NT_PRO_NONE || a.stats != NT_STAT_NONE || a.epilogue != NT_EPI_NONE) return PC_ESHAPE;
+        if (a.lda % 4 || a.ldw % 4 || a.ldc % 4 || (((uintptr_t)a.A | (uintptr_t)a.W | (uintptr_t)a.C) & 15)) return PC_ESHAPE;
+        c.a[i] = a;
+        c.a[i].seg = retile_plain(a.M);
+    }
+    if (fwd[0].N != 128 || fwd[0].K != 512 || fwd[1].N != 128 || fwd[1].K != 128 || fwd[1].brs) return PC_ESHAPE;      // AHEAD, PLAIN
+    if (bwd[0].N != 128 || bwd[0].K != 128 || bwd[0].brs || bwd[1].N != 512 || bwd[1].K != 128 || bwd[1].bias || bwd[1].brs) return PC_ESHAPE;   // PLAIN, KHEAD
+    if (!loss->emb || !loss->pos || !loss->neg || !loss->d_pos || !loss->d_neg || !loss->dp || !loss->dn || !loss->demb) return PC_EINVAL;
+    if (loss->B != fwd[0].M || loss->K < 1 || loss->K > LP_MAX_K || loss->demb != bwd[0].A || bwd[0].lda != 128 ||
+        loss->emb != fwd[1].C || fwd[1].ldc != 128)
+        return PC_EINVAL;
+    c.loss = *loss;
+    c.tiles = (fwd[0].M + 15) / 16;
+    flops = 2.0 * fwd[0].M * (3.0 * 128 * 128 + 512 * 32);
+    const int pb = pc_prof_begin(PC_KIND_GEMM_NT_SMALL, flops, st);
+    PC_LAUNCH(gemm_nt_chain16_pair_kernel, dim3(c.tiles), dim3(256), 0, st, c);
     pc_prof_end(pb, st);
     return pc_launch_status();
 }

@@ -683,12 +683,14 @@ std::atomic<int> g_opt_side_queue{1};
 std::atomic<int> g_opt_sorted_tables{1};
 std::atomic<int> g_opt_bn_finalize_side{0};
 std::atomic<int> g_opt_fused_loss{1};
+std::atomic<int> g_opt_fused_out_chain{1};
 std::atomic<int>* opt_slot(int option) {
     switch (option) {
         case PC_OPT_SIDE_QUEUE: return &g_opt_side_queue;
         case PC_OPT_SORTED_TABLE_GRADIENTS: return &g_opt_sorted_tables;
         case PC_OPT_BN_FINALIZE_SIDE: return &g_opt_bn_finalize_side;
         case PC_OPT_FUSED_LOSS: return &g_opt_fused_loss;
+        case PC_OPT_FUSED_OUT_CHAIN: return &g_opt_fused_out_chain;
         default: return nullptr;
     }
 }
@@ -696,6 +698,7 @@ std::atomic<int>* opt_slot(int option) {
 int pc_opt_sorted_tables() { return g_opt_sorted_tables.load(std::memory_order_relaxed); }
 int pc_opt_bn_finalize_side() { return g_opt_bn_finalize_side.load(std::memory_order_relaxed); }
 int pc_opt_fused_loss() { return g_opt_fused_loss.load(std::memory_order_relaxed); }
+int pc_opt_fused_out_chain() { return g_opt_fused_out_chain.load(std::memory_order_relaxed); }
 
 extern "C" int pc_set_option(int option, int value) {
     std::atomic<int>* o = opt_slot(option);

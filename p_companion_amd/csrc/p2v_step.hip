@@ -121,13 +121,15 @@ int ffn_transposes(const pc_p2v_tensors* p, void* ws, int rows, int with_dx, Tra
 int attention_transposes(const pc_p2v_tensors* p, void* ws, int B, int N, int key_rows, TransposeBatch* tb, float* zero_bk);
 int attention_forward_impl(const pc_p2v_tensors* p, const float* query, const float* keys, int B, int N,
                            int key_rows, const int32_t* slot_row, float* out, const pc_attn_saved* sv, void* ws,
-                           size_t ws_bytes, void* stream, int transposed);
+                           size_t ws_bytes, void* stream, int transposed, NtArgs* defer_out_chain);
 int attention_backward_impl(const pc_p2v_tensors* p, const pc_p2v_tensors* g, const float* query, const float* keys,
                             int B, int N, int key_rows, const int32_t* slot_row, int pad_row, const float* dout,
                             const pc_attn_saved* sv, float* dquery, float* dkeys, int accumulate, void* ws,
                             size_t ws_bytes, void* stream, const int32_t* ref_off, const int32_t* ref_slot,
-                            int transposed, TnDefer* defer, const HingeMeanJob* rider, const LossPro* lossp);
+                            int transposed, TnDefer* defer, const HingeMeanJob* rider, const LossPro* lossp,
+                            const NtArgs* fwd_out_chain);
 int pc_opt_fused_loss();       // (gemm_tn.hip: pc_set_option)
+int pc_opt_fused_out_chain();
 int triplet_loss_launch(const float* a, const float* p, const float* n, int batch, int k_neg, int dim, float margin,
                         float* loss, float* d_pos, float* d_neg, float* da, float* dp, float* dn, void* stream, int with_mean);
 
@@ -211,9 +213,12 @@ static int p2v_step_impl(const pc_p2v_tensors* p, const pc_p2v_tensors* g, const
     pc_attn_saved as;
     as.q = w.q; as.qt = w.qt; as.probs = w.probs; as.c = w.c; as.sp = w.sp; as.ctx = w.ctx;
     const float* emb = w.y;                     // anchor embedding = FFN output when there are no neighbours
+    // (D = 128 with neighbours, the hinge riding: the forward's out-projection chain is deferred into the backward's first launch)
+    const bool out_chain_rides = N > 0 && D == 128 && K <= 8 && pc_opt_fused_loss() && pc_opt_fused_out_chain();
+    NtArgs fwd_out_chain[2];
     if (N > 0) {
         PC_TRY(attention_forward_impl(p, w.y + (size_t)rA * D, w.y + (size_t)rN * D, B, N, nbc, slot_row, w.emb,
-                                      &as, w.attn_ws, w.attn_bytes, stream, 1));
+                                      &as, w.attn_ws, w.attn_bytes, stream, 1, out_chain_rides ? fwd_out_chain : nullptr));
         emb = w.emb;
     }
 
@@ -231,7 +236,7 @@ static int p2v_step_impl(const pc_p2v_tensors* p, const pc_p2v_tensors* g, const
         PC_TRY(triplet_loss_launch(emb, w.y + (size_t)rP * D, w.y + (size_t)rG * D, B, K, D, margin, loss, dp_out,
                                    dn_out, demb, w.dy + (size_t)rP * D, w.dy + (size_t)rG * D, stream, mean_rides ? 0 : 1));
     const HingeMeanJob hm = {dp_out, dn_out, B, margin, loss};
-    if (anchor_emb)
+    if (anchor_emb && !out_chain_rides)
         PC_HIP_TRY(hipMemcpyAsync(anchor_emb, emb, (size_t)B * D * 4, hipMemcpyDeviceToDevice, st));
 
     // the slab sums of ALL weight gradients of the step (attention: 10 few-row products, FFN: dW5, dW3 x 2, dW0) fold in
@@ -251,7 +256,10 @@ static int p2v_step_impl(const pc_p2v_tensors* p, const pc_p2v_tensors* g, const
         PC_TRY(attention_backward_impl(p, g, w.y + (size_t)rA * D, w.y + (size_t)rN * D, B, N, nbc, slot_row,
                                        slot_row ? nbc - 1 : -1, w.demb, &as, w.dy + (size_t)rA * D,
                                        w.dy + (size_t)rN * D, 0, w.attn_ws, w.attn_bytes, stream, ref_off, ref_slot, 1, &df,
-                                       mean_rides ? &hm : nullptr, loss_rides ? &lp : nullptr));
+                                       mean_rides ? &hm : nullptr, loss_rides ? &lp : nullptr,
+                                       out_chain_rides ? fwd_out_chain : nullptr));
+        if (anchor_emb && out_chain_rides)                    // (the embedding exists once the backward's first launch has run)
+            PC_HIP_TRY(hipMemcpyAsync(anchor_emb, emb, (size_t)B * D * 4, hipMemcpyDeviceToDevice, st));
     } else {
         PC_HIP_TRY(hipMemsetAsync(g->in_proj_w, 0, 3 * D * D * 4, st));
         PC_HIP_TRY(hipMemsetAsync(g->in_proj_b, 0, 3 * D * 4, st));

@@ -81,11 +81,18 @@ def test_side_queue_fork_changes_no_bit():
         assert L.pc_set_option(_lib.PC_OPT_FUSED_LOSS, 0) == 0
         outs.append(_fork_digest())
         torch.cuda.synchronize()
+        # ... and with the hinge riding, the out-projection's forward chain in the same launch (default) or on its own
+        assert L.pc_set_option(_lib.PC_OPT_FUSED_LOSS, 1) == 0
+        assert L.pc_get_option(_lib.PC_OPT_FUSED_OUT_CHAIN, ctypes.byref(v)) == 0 and v.value == 1
+        assert L.pc_set_option(_lib.PC_OPT_FUSED_OUT_CHAIN, 0) == 0
+        outs.append(_fork_digest())
+        torch.cuda.synchronize()
     finally:
+        L.pc_set_option(_lib.PC_OPT_FUSED_OUT_CHAIN, 1)
         L.pc_set_option(_lib.PC_OPT_SIDE_QUEUE, 1)
         L.pc_set_option(_lib.PC_OPT_BN_FINALIZE_SIDE, 0)
         L.pc_set_option(_lib.PC_OPT_FUSED_LOSS, 1)
-    assert outs[0] == outs[1] == outs[2] == outs[3] == outs[4]
+    assert outs[0] == outs[1] == outs[2] == outs[3] == outs[4] == outs[5]
 
 
 def test_fused_p2v_step_under_stream_capture_stays_on_one_queue():
