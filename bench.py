@@ -212,6 +212,7 @@ def joint_algorithmic_bytes(b, t, k=3):
 # over 25, 0.1215 over 250: scripts/dev/first_steps_probe.py) -- so these legs time at least 46 / 30 ms.
 JOINT_MIN_STEPS = 1000
 JOINT_REF_MIN_STEPS = 250
+LOADER_OPTS = {}             # developer A/B (PC_BENCH_SET_OPTIONS "rows=0"): attributes set on the Product2Vec leg's loader
 EXCHANGE = {"ex": None}      # the replicas' gradient exchange (distributed.make_exchange), set once in main() when N > 1
 
 
@@ -437,6 +438,8 @@ def run_p2v(args, rank, world, dev, products, steps, warmup, want_cpu, profile_k
                                             hot_rows=hot_rows if negatives == "zipf" else 0)
     loader = SimilarityIndexLoader(bpg, args.batch, shuffle=True, sampler="philox", seed=1 + rank, drop_last=True,
                                    device=dev, sharded=sharded, negatives=negatives, reuse_buffers=True)
+    for k_, v_ in LOADER_OPTS.items():
+        setattr(loader, k_, v_)
 
     def batches():
         while True:
@@ -916,6 +919,9 @@ def main():
         # developer A/B on one box: "3=1,2=0" -> pc_set_option(3, 1), pc_set_option(2, 0) before anything runs (include/pcompanion_hip.h PC_OPT_*)
         from p_companion_amd import _lib
         for kv in os.environ["PC_BENCH_SET_OPTIONS"].split(","):
+            if kv.startswith("rows="):
+                LOADER_OPTS["step_rows"] = bool(int(kv[5:]))       # (the loader's row concatenation, a Python-side switch)
+                continue
             o, v = (int(x) for x in kv.split("="))
             if _lib.lib().pc_set_option(o, v) != 0:
                 raise SystemExit(f"PC_BENCH_SET_OPTIONS: pc_set_option({o}, {v}) refused")

@@ -580,6 +580,24 @@ int pc_p2v_train_step_unique_adam(const pc_p2v_tensors *p, const pc_p2v_tensors 
                                   float *loss, float *d_pos, float *d_neg, float *anchor_emb, void *profile,
                                   void *ws, size_t ws_bytes, const pc_adam_fused *adam, void *stream);
 
+/* The same step without a launch of its own in front of Linear0 (product2vec.py:73, the first nn.Linear of self.ffn).  The step
+ * functions above begin by concatenating the four index arrays of product2vec.py:132-134 into the row list the segmented FFN
+ * runs over; a loader that builds its batches on another stream (DeviceSimilarityLoader) does that there instead:
+ * pc_p2v_concat_step_rows, queued behind pc_build_similarity_batch_unique, writes rows_out = [anchor_idx[B] | nb_rows[0 .. n_unique]
+ * (n_unique read from the DEVICE: n_unique_dev, clamped to nb_capacity - 1) | positive_idx[B] | negative_idx[B*K]];
+ * rows_capacity >= B * (2 + K) + nb_capacity entries.  pc_p2v_train_step_unique_rows then takes step_rows = rows_out in
+ * place of the three index arrays (n_unique: the host's copy of the same count); the transposed weights of the step ride in
+ * the FFN forward's BatchNorm finalize launch.  Same results, bit for bit, as pc_p2v_train_step_unique_adam. */
+int pc_p2v_concat_step_rows(const int32_t *anchor_idx, const int32_t *positive_idx, const int32_t *negative_idx,
+                            const int32_t *nb_rows, const int32_t *n_unique_dev, int nb_capacity, int batch, int k_neg,
+                            int32_t *rows_out, int rows_capacity, void *stream);
+int pc_p2v_train_step_unique_rows(const pc_p2v_tensors *p, const pc_p2v_tensors *g, const float *table,
+                                  const int32_t *step_rows, const int32_t *nb_rows, const float *nb_weight, int n_unique,
+                                  const int32_t *slot_row, const int32_t *ref_off, const int32_t *ref_slot, int batch,
+                                  int n_nbr, int k_neg, float margin, float *loss, float *d_pos, float *d_neg,
+                                  float *anchor_emb, void *profile, void *ws, size_t ws_bytes, const pc_adam_fused *adam,
+                                  void *stream);
+
 /* ---------------------------------------------------------------------------------
  * Data-parallel replicas (the reference is single-process: train.py:46-48 is loss.backward(); optimizer.step()
  * with nothing between -- a replica of a data-parallel job averages the gradients there).  ABI 6.

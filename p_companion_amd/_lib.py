@@ -112,6 +112,9 @@ SIGNATURES = {
                                        _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "pc_p2v_train_step_unique_adam": (_i, [_P(P2VTensors), _P(P2VTensors), _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _i, _i,
                                            _i, _f, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _P(AdamFused), _vp]),
+    "pc_p2v_concat_step_rows": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp, _i, _vp]),
+    "pc_p2v_train_step_unique_rows": (_i, [_P(P2VTensors), _P(P2VTensors), _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _i, _i,
+                                           _i, _f, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _P(AdamFused), _vp]),
     "pc_p2v_train_step_unique": (_i, [_P(P2VTensors), _P(P2VTensors), _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _i, _i,
                                       _i, _f, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _sz, _vp]),
     "pc_build_similarity_batch_unique_scratch_bytes": (_sz, [_i, _i]),

@@ -471,6 +471,34 @@ struct TransposeJob { const float* in; float* out; int rows, cols; };   // out[c
 // a separate fill would be one more launch boundary)
 struct TransposeBatch { TransposeJob job[PC_TRANSPOSE_JOBS]; int n; float* zero; int nzero; };
 int launch_transpose_batch(const TransposeBatch& tb, hipStream_t st);
+#ifdef __HIPCC__
+// one 32 x 32 tile of one job, by a workgroup of NT threads that has this launch to itself or rides in another's (tile counts
+// tiles_x x tiles_y per job); t: 32 x 33 floats of LDS
+template <int NT>
+__device__ __forceinline__ void transpose_tile_body(const TransposeBatch& tb, int tile, int tiles_x, int tiles_y, float (*t)[33], int tid) {
+    const int jz = tile / (tiles_x * tiles_y), rem = tile % (tiles_x * tiles_y);
+    const TransposeJob j = tb.job[jz];
+    const int tx = tid & 31, ty = tid >> 5;
+    if (tb.zero && tile == 0)
+        for (int i = tid; i < tb.nzero; i += NT) tb.zero[i] = 0.f;
+    const int bx = (rem % tiles_x) * 32, by = (rem / tiles_x) * 32;
+    if (bx >= j.cols || by >= j.rows) return;                 // (uniform over the workgroup)
+    for (int i = ty; i < 32; i += NT / 32) {
+        const int r = by + i, cc = bx + tx;
+        t[i][tx] = (r < j.rows && cc < j.cols) ? j.in[(size_t)r * j.cols + cc] : 0.f;
+    }
+    __syncthreads();
+    for (int i = ty; i < 32; i += NT / 32) {
+        const int cc = bx + i, r = by + tx;
+        if (r < j.rows && cc < j.cols) j.out[(size_t)cc * j.rows + r] = t[tx][i];
+    }
+}
+#endif
+static inline void transpose_batch_tiles(const TransposeBatch& tb, int* tiles_x, int* tiles_y) {
+    int mx = 0, my = 0;
+    for (int i = 0; i < tb.n; i++) { mx = tb.job[i].cols > mx ? tb.job[i].cols : mx; my = tb.job[i].rows > my ? tb.job[i].rows : my; }
+    *tiles_x = (mx + 31) / 32; *tiles_y = (my + 31) / 32;
+}
 
 struct TnArgs {
     // dW[No,Ni] (+)= sum_r Z[r][o] * A[r][i];  db[o] (+)= sum_r Z[r][o]

@@ -145,11 +145,19 @@ __global__ __launch_bounds__(FIN_COLS * FIN_LANES) void bn_fold_kernel(const flo
 __global__ __launch_bounds__(FIN4_CG * FIN4_LANES) void bn_finalize_fwd_kernel(
     const float* psum, const float* psq, SegInfo si, const double* gsum, const float* gamma, const float* beta,
     float* running_mean, float* running_var, int64_t* nbt, int update_running, float* mean_o, float* invstd_o,
-    float* scale_o, float* shift_o) {
+    float* scale_o, float* shift_o, TransposeBatch ride, int tiles_x, int tiles_y) {
     __shared__ double red[FIN4_WAVES][2][PC_MAX_SEG][FIN_COLS];
     __shared__ float seg_mean[PC_MAX_SEG][FIN_COLS], seg_unb[PC_MAX_SEG][FIN_COLS];
     __shared__ int seg_live[PC_MAX_SEG][FIN_COLS];
     const int tid = threadIdx.y * FIN4_CG + threadIdx.x;
+    if (blockIdx.x >= PC_H / FIN_COLS) {
+        // riders (the unsplit step with loader-made row indices): the transposed weights of the attention and of the backward --
+        // nothing before this launch's successor needs them, and the eight finalize workgroups leave 248 CUs idle
+        static_assert(sizeof(red) >= 32 * 33 * sizeof(float), "transpose tile");
+        transpose_tile_body<FIN4_CG * FIN4_LANES>(ride, (int)blockIdx.x - PC_H / FIN_COLS, tiles_x, tiles_y,
+                                                  reinterpret_cast<float(*)[33]>(&red[0][0][0][0]), tid);
+        return;
+    }
     double a = 0.0, b = 0.0;
     if (!gsum) fold_partials_all4(psum, psq, si, blockIdx.x * FIN_COLS, red, &a, &b);
     if (tid < PC_MAX_SEG * FIN_COLS) {
@@ -407,14 +415,18 @@ int ffn_forward_part1(const pc_p2v_tensors* p, const float* table, const int32_t
 }
 
 int ffn_forward_part2(const pc_p2v_tensors* p, int rows, const pc_segments* seg, int update_running, float* y,
-                      const pc_ffn_saved* sv, const double* global_sums, void* ws, size_t ws_bytes, void* stream) {
+                      const pc_ffn_saved* sv, const double* global_sums, void* ws, size_t ws_bytes, void* stream,
+                      const TransposeBatch* ride) {
     if (!y || (update_running && (!p->running_mean || !p->running_var))) return PC_EINVAL;
     hipStream_t st = (hipStream_t)stream;
     const SegInfo si = make_seginfo(seg, rows, 128);
     FfnWs w = ffn_ws_layout(ws, rows);
-    PC_LAUNCH(bn_finalize_fwd_kernel, dim3(PC_H / FIN_COLS), dim3(FIN4_CG, FIN4_LANES), 0, st, w.stat_a, w.stat_b, si, global_sums,
-              p->gamma, p->beta, p->running_mean, p->running_var, p->num_batches_tracked, update_running,
-              sv->bn_mean, sv->bn_invstd, sv->bn_scale, sv->bn_shift);
+    TransposeBatch tb = {};
+    int tiles_x = 0, tiles_y = 0;
+    if (ride && ride->n > 0) { tb = *ride; transpose_batch_tiles(tb, &tiles_x, &tiles_y); }
+    PC_LAUNCH(bn_finalize_fwd_kernel, dim3(PC_H / FIN_COLS + tiles_x * tiles_y * tb.n), dim3(FIN4_CG, FIN4_LANES), 0, st, w.stat_a,
+              w.stat_b, si, global_sums, p->gamma, p->beta, p->running_mean, p->running_var, p->num_batches_tracked, update_running,
+              sv->bn_mean, sv->bn_invstd, sv->bn_scale, sv->bn_shift, tb, tiles_x, tiles_y);
     PC_TRY(pc_launch_status());
 
     NtArgs g2 = nt_plain(sv->h0, PC_H, p->w3, PC_H, p->b3, sv->a2, PC_H, rows, PC_H, PC_H, si);
@@ -433,7 +445,7 @@ extern "C" int pc_p2v_ffn_forward_train(const pc_p2v_tensors* p, const float* ta
                                         const pc_ffn_saved* sv, void* ws, size_t ws_bytes, void* stream) {
     if (!y) return PC_EINVAL;
     PC_TRY(ffn_forward_part1(p, table, idx, rows, seg, sv, nullptr, ws, ws_bytes, stream));
-    return ffn_forward_part2(p, rows, seg, update_running, y, sv, nullptr, ws, ws_bytes, stream);
+    return ffn_forward_part2(p, rows, seg, update_running, y, sv, nullptr, ws, ws_bytes, stream, nullptr);
 }
 
 extern "C" int pc_p2v_ffn_forward_eval(const pc_p2v_tensors* p, const float* table, const int32_t* idx, int rows,

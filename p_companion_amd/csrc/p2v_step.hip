@@ -75,6 +75,27 @@ __global__ void concat_idx_kernel(const int32_t* a, int na, const int32_t* b, in
     concat_idx_body(a, na, b, nb, c, nc, d, nd, out, blockIdx.x * blockDim.x + threadIdx.x);
 }
 
+// The loader's side of the unsplit step's first launch (round 6): the same concatenation, queued behind the batch builder on
+// ITS stream, with the neighbour row count read from the device (the host learns it a step later).
+__global__ void concat_rows_dev_kernel(const int32_t* a, int na, const int32_t* b, const int32_t* nb_dev, int nb_cap, const int32_t* c,
+                                       int nc, const int32_t* d, int nd, int32_t* out) {
+    int nb = *nb_dev + 1;                                    // the distinct neighbours and the -1 row
+    nb = nb < 1 ? 1 : (nb > nb_cap ? nb_cap : nb);
+    concat_idx_body(a, na, b, nb, c, nc, d, nd, out, blockIdx.x * blockDim.x + threadIdx.x);
+}
+
+extern "C" int pc_p2v_concat_step_rows(const int32_t* anchor_idx, const int32_t* positive_idx, const int32_t* negative_idx,
+                                       const int32_t* nb_rows, const int32_t* n_unique_dev, int nb_capacity, int B, int K,
+                                       int32_t* rows_out, int rows_capacity, void* stream) {
+    if (!anchor_idx || !positive_idx || !negative_idx || !nb_rows || !n_unique_dev || !rows_out) return PC_EINVAL;
+    if (B <= 0 || K <= 0 || nb_capacity < 1) return PC_EINVAL;
+    const long long most = (long long)B * (2 + K) + nb_capacity;
+    if (most > rows_capacity) return PC_ESHAPE;
+    PC_LAUNCH(concat_rows_dev_kernel, dim3((unsigned)((most + 255) / 256)), dim3(256), 0, (hipStream_t)stream, anchor_idx, B, nb_rows,
+              n_unique_dev, nb_capacity, positive_idx, B, negative_idx, B * K, rows_out);
+    return pc_launch_status();
+}
+
 // The step's first launch: the row-index concatenation AND every transposed weight of the step (workgroups
 // [0, concat_blocks) concatenate, the rest are 32 x 32 transpose tiles, tiles_x x tiles_y per job) -- the two were separate
 // launches of ~5 us each, i.e. of pure launch latency.
@@ -86,29 +107,14 @@ __global__ __launch_bounds__(256) void p2v_prologue_kernel(const int32_t* a, int
         concat_idx_body(a, na, b, nb, c, nc, d, nd, out, blockIdx.x * 256 + threadIdx.x);
         return;
     }
-    const int tile = (int)blockIdx.x - concat_blocks;
-    const int jz = tile / (tiles_x * tiles_y), rem = tile % (tiles_x * tiles_y);
-    const TransposeJob j = tb.job[jz];
-    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
-    if (tb.zero && tile == 0)
-        for (int i = threadIdx.x; i < tb.nzero; i += 256) tb.zero[i] = 0.f;
-    const int bx = (rem % tiles_x) * 32, by = (rem / tiles_x) * 32;
-    if (bx >= j.cols || by >= j.rows) return;
-    for (int i = ty; i < 32; i += 8) {
-        const int r = by + i, cc = bx + tx;
-        t[i][tx] = (r < j.rows && cc < j.cols) ? j.in[(size_t)r * j.cols + cc] : 0.f;
-    }
-    __syncthreads();
-    for (int i = ty; i < 32; i += 8) {
-        const int cc = bx + i, r = by + tx;
-        if (r < j.rows && cc < j.cols) j.out[(size_t)cc * j.rows + r] = t[tx][i];
-    }
+    transpose_tile_body<256>(tb, (int)blockIdx.x - concat_blocks, tiles_x, tiles_y, t, threadIdx.x);
 }
 
 int ffn_forward_part1(const pc_p2v_tensors* p, const float* table, const int32_t* idx, int rows, const pc_segments* seg,
                       const pc_ffn_saved* sv, double* local_sums, void* ws, size_t ws_bytes, void* stream);
 int ffn_forward_part2(const pc_p2v_tensors* p, int rows, const pc_segments* seg, int update_running, float* y,
-                      const pc_ffn_saved* sv, const double* global_sums, void* ws, size_t ws_bytes, void* stream);
+                      const pc_ffn_saved* sv, const double* global_sums, void* ws, size_t ws_bytes, void* stream,
+                      const TransposeBatch* ride = nullptr);
 int ffn_backward_part1(const pc_p2v_tensors* p, const pc_p2v_tensors* g, const float* table, const int32_t* idx,
                        int rows, const pc_segments* seg, const float* dy, const pc_ffn_saved* sv, int with_dx,
                        int accumulate, double* local_sums, void* ws, size_t ws_bytes, void* stream, int transposed,
@@ -143,12 +149,17 @@ static int p2v_step_impl(const pc_p2v_tensors* p, const pc_p2v_tensors* g, const
                          size_t ws_bytes, void* stream, int phase = -1, double* fwd_sums = nullptr,
                          double* bwd_local = nullptr, const double* bwd_global = nullptr,
                          const float* nb_weight = nullptr, const int32_t* ref_off = nullptr,
-                         const int32_t* ref_slot = nullptr, const pc_adam_fused* adam = nullptr) {
+                         const int32_t* ref_slot = nullptr, const pc_adam_fused* adam = nullptr,
+                         const int32_t* rows_ready = nullptr) {
     // nb_weight (unique-neighbour layout): multiplicity of each of the nbc neighbour rows (its last entry = the
     // number of padding slots); replaces the single weighted row of the compact layout
     // phase -1: the whole step with this replica's BatchNorm statistics; 0/1/2: see pc_p2v_train_step_compact_sync
     const bool p0 = phase <= 0, p1 = phase == -1 || phase == 1, p2 = phase == -1 || phase == 2;
     if (adam && phase != -1) return PC_EINVAL;               // (the optimizer rides in the unsplit step's last launch only)
+    // rows_ready: [anchor | neighbour rows | positive | negatives] as the loader concatenated them (pc_p2v_concat_step_rows).  The
+    // step then has no launch of its own in front of Linear0: the transposed weights, which nothing needs before the attention,
+    // ride in the BatchNorm finalize launch of the FFN forward.
+    if (rows_ready && phase != -1) return PC_EINVAL;
     ProfileScope prof_scope((pc_profile*)profile);
     if (!p || !g || !table || !anchor_idx || !positive_idx || !negative_idx || !loss || !ws) return PC_EINVAL;
     if (B <= 0 || N < 0 || K <= 0 || (N > 0 && !nb_idx) || nbc < 0 || nbc > B * N + 1) return PC_EINVAL;
@@ -160,6 +171,7 @@ static int p2v_step_impl(const pc_p2v_tensors* p, const pc_p2v_tensors* g, const
     if (ws_bytes < pc_p2v_train_step_workspace_bytes_dim(B, N, K, D)) return PC_EWORKSPACE;
     hipStream_t st = (hipStream_t)stream;
     StepWs w = step_ws_layout(ws, B, N, K, D);
+    const int32_t* rows = rows_ready ? rows_ready : w.idx_all;
     const int R = 2 * B + nbc + B * K;
     const int rA = 0, rN = B, rP = B + nbc, rG = rP + B;
 
@@ -189,10 +201,12 @@ static int p2v_step_impl(const pc_p2v_tensors* p, const pc_p2v_tensors* g, const
         if (N > 0) PC_TRY(attention_transposes(p, w.attn_ws, B, N, slot_row ? nbc : B * N, &tb, g->in_proj_b + D));
     }
     if (p0) {
-        if (phase == -1) {
-            int mx = 0, my = 0;
-            for (int i = 0; i < tb.n; i++) { mx = tb.job[i].cols > mx ? tb.job[i].cols : mx; my = tb.job[i].rows > my ? tb.job[i].rows : my; }
-            const int tiles_x = (mx + 31) / 32, tiles_y = (my + 31) / 32, cb = (R + 255) / 256;
+        if (rows_ready) {
+            // (nothing to launch)
+        } else if (phase == -1) {
+            int tiles_x, tiles_y;
+            transpose_batch_tiles(tb, &tiles_x, &tiles_y);
+            const int cb = (R + 255) / 256;
             PC_LAUNCH(p2v_prologue_kernel, dim3(cb + tiles_x * tiles_y * tb.n), dim3(256), 0, st, anchor_idx, B, nb_idx, nbc,
                       positive_idx, B, negative_idx, B * K, w.idx_all, cb, tb, tiles_x, tiles_y);
         } else {
@@ -200,15 +214,16 @@ static int p2v_step_impl(const pc_p2v_tensors* p, const pc_p2v_tensors* g, const
                       negative_idx, B * K, w.idx_all);
         }
         PC_TRY(pc_launch_status());
-        PC_TRY(ffn_forward_part1(p, table, w.idx_all, R, &seg, &sv, phase == 0 ? fwd_sums : nullptr, w.ffn_ws, w.ffn_bytes,
+        PC_TRY(ffn_forward_part1(p, table, rows, R, &seg, &sv, phase == 0 ? fwd_sums : nullptr, w.ffn_ws, w.ffn_bytes,
                                  stream));
         if (phase == 0) return PC_OK;
     }
     if (p2 && !p1)
-        return ffn_backward_part2(g, table, w.idx_all, R, &seg, &sv, nullptr, 0, bwd_local, bwd_global, w.ffn_ws,
+        return ffn_backward_part2(g, table, rows, R, &seg, &sv, nullptr, 0, bwd_local, bwd_global, w.ffn_ws,
                                   w.ffn_bytes, stream, nullptr);
     if (phase == 1) PC_TRY(launch_transpose_batch(tb, st));      // (the split step: phase 0 ran the concatenation alone)
-    PC_TRY(ffn_forward_part2(p, R, &seg, 1, w.y, &sv, phase == 1 ? fwd_sums : nullptr, w.ffn_ws, w.ffn_bytes, stream));
+    PC_TRY(ffn_forward_part2(p, R, &seg, 1, w.y, &sv, phase == 1 ? fwd_sums : nullptr, w.ffn_ws, w.ffn_bytes, stream,
+                             rows_ready ? &tb : nullptr));
 
     pc_attn_saved as;
     as.q = w.q; as.qt = w.qt; as.probs = w.probs; as.c = w.c; as.sp = w.sp; as.ctx = w.ctx;
@@ -266,10 +281,10 @@ static int p2v_step_impl(const pc_p2v_tensors* p, const pc_p2v_tensors* g, const
         PC_HIP_TRY(hipMemsetAsync(g->out_proj_w, 0, D * D * 4, st));
         PC_HIP_TRY(hipMemsetAsync(g->out_proj_b, 0, D * 4, st));
     }
-    PC_TRY(ffn_backward_part1(p, g, table, w.idx_all, R, &seg, w.dy, &sv, 0, 0, phase == 1 ? bwd_local : nullptr, w.ffn_ws,
+    PC_TRY(ffn_backward_part1(p, g, table, rows, R, &seg, w.dy, &sv, 0, 0, phase == 1 ? bwd_local : nullptr, w.ffn_ws,
                               w.ffn_bytes, stream, 1, &df));
     if (phase == 1) return launch_tn_reduce_deferred(&df, st);
-    PC_TRY(ffn_backward_part2(g, table, w.idx_all, R, &seg, &sv, nullptr, 0, nullptr, nullptr, w.ffn_ws, w.ffn_bytes, stream, &df));
+    PC_TRY(ffn_backward_part2(g, table, rows, R, &seg, &sv, nullptr, 0, nullptr, nullptr, w.ffn_ws, w.ffn_bytes, stream, &df));
     return launch_tn_reduce_deferred(&df, st);
 }
 
@@ -328,13 +343,11 @@ extern "C" int pc_p2v_train_step_unique(const pc_p2v_tensors* p, const pc_p2v_te
                          bwd_local, bwd_global, nb_weight, ref_off, ref_slot);
 }
 
-extern "C" int pc_p2v_train_step_unique_adam(const pc_p2v_tensors* p, const pc_p2v_tensors* g, const float* table,
-                                             const int32_t* anchor_idx, const int32_t* positive_idx,
-                                             const int32_t* negative_idx, const int32_t* nb_rows, const float* nb_weight,
-                                             int n_unique, const int32_t* slot_row, const int32_t* ref_off,
-                                             const int32_t* ref_slot, int B, int N, int K, float margin, float* loss,
-                                             float* d_pos, float* d_neg, float* anchor_emb, void* profile, void* ws,
-                                             size_t ws_bytes, const pc_adam_fused* adam, void* stream) {
+static int unique_adam_impl(const pc_p2v_tensors* p, const pc_p2v_tensors* g, const float* table, const int32_t* anchor_idx,
+                            const int32_t* positive_idx, const int32_t* negative_idx, const int32_t* nb_rows, const float* nb_weight,
+                            int n_unique, const int32_t* slot_row, const int32_t* ref_off, const int32_t* ref_slot, int B, int N, int K,
+                            float margin, float* loss, float* d_pos, float* d_neg, float* anchor_emb, void* profile, void* ws,
+                            size_t ws_bytes, const pc_adam_fused* adam, void* stream, const int32_t* rows_ready) {
     if (!slot_row || !nb_rows || !nb_weight || !ref_off || !ref_slot || N <= 0 || n_unique < 0 || n_unique > B * N)
         return PC_EINVAL;
     if (adam && g) {
@@ -345,5 +358,30 @@ extern "C" int pc_p2v_train_step_unique_adam(const pc_p2v_tensors* p, const pc_p
     }
     return p2v_step_impl(p, g, table, anchor_idx, positive_idx, negative_idx, nb_rows, n_unique + 1, slot_row, B, N, K,
                          margin, loss, d_pos, d_neg, anchor_emb, profile, ws, ws_bytes, stream, -1, nullptr, nullptr, nullptr,
-                         nb_weight, ref_off, ref_slot, adam);
+                         nb_weight, ref_off, ref_slot, adam, rows_ready);
+}
+
+extern "C" int pc_p2v_train_step_unique_adam(const pc_p2v_tensors* p, const pc_p2v_tensors* g, const float* table,
+                                             const int32_t* anchor_idx, const int32_t* positive_idx,
+                                             const int32_t* negative_idx, const int32_t* nb_rows, const float* nb_weight,
+                                             int n_unique, const int32_t* slot_row, const int32_t* ref_off,
+                                             const int32_t* ref_slot, int B, int N, int K, float margin, float* loss,
+                                             float* d_pos, float* d_neg, float* anchor_emb, void* profile, void* ws,
+                                             size_t ws_bytes, const pc_adam_fused* adam, void* stream) {
+    return unique_adam_impl(p, g, table, anchor_idx, positive_idx, negative_idx, nb_rows, nb_weight, n_unique, slot_row, ref_off,
+                            ref_slot, B, N, K, margin, loss, d_pos, d_neg, anchor_emb, profile, ws, ws_bytes, adam, stream, nullptr);
+}
+
+// ... with the step's row indices [anchor | nb_rows[0 .. n_unique] | positive | negatives] already concatenated
+// (pc_p2v_concat_step_rows behind the loader's builder): the step's first launch is Linear0
+extern "C" int pc_p2v_train_step_unique_rows(const pc_p2v_tensors* p, const pc_p2v_tensors* g, const float* table,
+                                             const int32_t* step_rows, const int32_t* nb_rows, const float* nb_weight, int n_unique,
+                                             const int32_t* slot_row, const int32_t* ref_off, const int32_t* ref_slot, int B, int N,
+                                             int K, float margin, float* loss, float* d_pos, float* d_neg, float* anchor_emb,
+                                             void* profile, void* ws, size_t ws_bytes, const pc_adam_fused* adam, void* stream) {
+    if (!step_rows || B <= 0 || N <= 0 || n_unique < 0 || n_unique > B * N) return PC_EINVAL;
+    const int32_t* a = step_rows;
+    return unique_adam_impl(p, g, table, a, a + B + n_unique + 1, a + 2 * B + n_unique + 1, nb_rows, nb_weight, n_unique, slot_row,
+                            ref_off, ref_slot, B, N, K, margin, loss, d_pos, d_neg, anchor_emb, profile, ws, ws_bytes, adam, stream,
+                            step_rows);
 }

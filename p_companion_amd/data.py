@@ -257,6 +257,9 @@ class SimilarityIndexLoader:
         # code that keeps batches (tests collecting an epoch) must not.
         self.reuse_buffers = bool(reuse_buffers)
         self._ring, self._ring_done = None, None
+        # the step's row list [anchor | neighbour rows | positive | negatives] is concatenated HERE, behind the builder on its
+        # stream (ops.concat_step_rows), so that the fused step needs no launch of its own in front of Linear0
+        self.step_rows = True
         # negatives='zipf' (BASELINE configs[4]; an extension, the reference draws uniformly): P(rank) ~ 1 / rank over the
         # popularity permutation `popularity` ([P] int32 product id per rank; None: product 0 is the most popular),
         # same rejection rules, device sampler only
@@ -411,7 +414,7 @@ class SimilarityIndexLoader:
             else:
                 ids = perm[lo:hi]
                 n_pad = int(self._deg[ids].max())           # collate_fn pads to the batch maximum
-            nbc = None
+            nbc = out = None
             if self.sampler == "philox" and self.compact and n_pad > 0:
                 n_real = n_real_plan if plan is not None else int(np.minimum(self._deg[ids], n_pad).sum())
                 slot = self._ring_slot(base + i) if ring_ok else None
@@ -447,6 +450,10 @@ class SimilarityIndexLoader:
             if self._zipf is not None:
                 self.ops.sample_negatives_zipf(perm_dev[lo:hi], self.g, self.k_neg, self.seed, self.step, self._zipf[0],
                                                self._zipf[1], out=ng, failed=self._zipf_failed)
+            if nbc is not None and "n_unique_dev" in nbc and self.step_rows and self.sharded is None:
+                # (a row-sharded table renumbers the rows: its lookup hands the step a remapped batch)
+                nbc["step_rows"] = self.ops.concat_step_rows(a, p, ng, nbc["nb_rows"], nbc["n_unique_dev"],
+                                                             out=out["step_rows"] if out is not None else None)
             self.step += 1
             batch = {"anchor_idx": a, "positive_idx": p, "negative_idx": ng, "n_pad": n_pad}
             if nb is not None:

@@ -599,21 +599,36 @@ def p2v_train_step(params, grads, table, anchor_idx, positive_idx, negative_idx,
         return out
     if adam is not None and not unique:
         raise ValueError("p2v_train_step(adam=...): the unique-neighbour layout (the device loader's) carries the fused optimizer step")
-    if unique and adam is not None:
-        af = _lib.AdamFused()
-        n_flat = adam["param"].numel()
-        for key in ("param", "grad", "exp_avg", "exp_avg_sq"):
-            _req(adam[key], torch.float32, key, (n_flat,))
-        _req(adam["step_count"], torch.int64, "step_count")
-        af.param, af.grad, af.exp_avg, af.exp_avg_sq = (adam[key].data_ptr() for key in ("param", "grad", "exp_avg", "exp_avg_sq"))
-        af.n, af.step_count, af.t = n_flat, adam["step_count"].data_ptr(), int(adam["t"])
-        af.lr, af.beta1, af.beta2, af.eps = float(adam["lr"]), float(adam["betas"][0]), float(adam["betas"][1]), float(adam["eps"])
+    step_rows = neighbor_idx.get("step_rows") if unique else None
+    if unique and (adam is not None or step_rows is not None):
+        af = None
+        if adam is not None:
+            af = _lib.AdamFused()
+            n_flat = adam["param"].numel()
+            for key in ("param", "grad", "exp_avg", "exp_avg_sq"):
+                _req(adam[key], torch.float32, key, (n_flat,))
+            _req(adam["step_count"], torch.int64, "step_count")
+            af.param, af.grad, af.exp_avg, af.exp_avg_sq = (adam[key].data_ptr() for key in ("param", "grad", "exp_avg", "exp_avg_sq"))
+            af.n, af.step_count, af.t = n_flat, adam["step_count"].data_ptr(), int(adam["t"])
+            af.lr, af.beta1, af.beta2, af.eps = float(adam["lr"]), float(adam["betas"][0]), float(adam["betas"][1]), float(adam["eps"])
+        afp = ctypes.byref(af) if af is not None else None
+        if step_rows is not None:
+            # the loader concatenated the step's row indices behind its builder (concat_step_rows): the step starts with Linear0
+            _req(step_rows, torch.int32, "step_rows")
+            if step_rows.numel() < b * (2 + k) + n_real + 1:
+                raise ValueError("step_rows shorter than B * (2 + K) + n_unique + 1")
+            check(_lib.lib().pc_p2v_train_step_unique_rows(
+                ctypes.byref(st), ctypes.byref(gst), _p(table), _p(step_rows), _p(nb_rows), _p(neighbor_idx["weight"]), n_real,
+                _p(slot_row), _p(neighbor_idx["ref_off"]), _p(neighbor_idx["ref_slot"]), b, n, k, float(margin), _p(out["loss"]),
+                _p(out["d_pos"]), _p(out["d_neg"]), _p(out.get("anchor_emb")), profile.handle if profile else None,
+                _p(ws), nbytes, afp, _stream()), "pc_p2v_train_step_unique_rows")
+            return out
         check(_lib.lib().pc_p2v_train_step_unique_adam(
             ctypes.byref(st), ctypes.byref(gst), _p(table), _p(anchor_idx), _p(positive_idx), _p(negative_idx),
             _p(nb_rows), _p(neighbor_idx["weight"]), n_real, _p(slot_row), _p(neighbor_idx["ref_off"]),
             _p(neighbor_idx["ref_slot"]), b, n, k, float(margin), _p(out["loss"]),
             _p(out["d_pos"]), _p(out["d_neg"]), _p(out.get("anchor_emb")), profile.handle if profile else None,
-            _p(ws), nbytes, ctypes.byref(af), _stream()), "pc_p2v_train_step_unique_adam")
+            _p(ws), nbytes, afp, _stream()), "pc_p2v_train_step_unique_adam")
         return out
     if unique:
         check(_lib.lib().pc_p2v_train_step_unique(
@@ -673,6 +688,7 @@ class BatchBuffers:
         self.nb_rows, self.ref_off, self.ref_slot, self.slot_row = i32(slots + 2), i32(slots + 3), i32(slots + 1), i32(slots)
         self.weight = torch.empty(slots + 2, dtype=torch.float32, device=device)
         self.n_unique, self.row_off = i32(1), i32(b + 1)
+        self.step_rows = i32(b * (2 + k_neg) + slots + 2)      # [anchor | nb_rows | positive | negatives] (concat_step_rows)
         self.host_n = torch.empty(1, dtype=torch.int32).pin_memory()
 
     def views(self, b, n_pad, n_real, unique):
@@ -682,7 +698,7 @@ class BatchBuffers:
              "slot_row": self.slot_row[:b * n_pad].view(b, n_pad), "row_off": self.row_off[:b + 1]}
         if unique:
             v.update(weight=self.weight[:n_real + 1], ref_off=self.ref_off[:n_real + 2], ref_slot=self.ref_slot[:max(n_real, 1)],
-                     n_unique=self.n_unique)
+                     n_unique=self.n_unique, step_rows=self.step_rows[:b * (2 + self.k) + n_real + 1])
         return v
 
 
@@ -749,6 +765,26 @@ def build_similarity_batch_unique(pair_ids, graph, n_pad, k_neg, seed, step, n_r
         "pc_build_similarity_batch_unique")
     return a, p, ng, {"nb_rows": nb_rows, "weight": weight, "slot_row": slot_row, "ref_off": ref_off,
                       "ref_slot": ref_slot, "n_unique": n_unique}
+
+
+def concat_step_rows(anchor_idx, positive_idx, negative_idx, nb_rows, n_unique_dev, out=None):
+    """pc_p2v_concat_step_rows on the current stream: [anchor | nb_rows[0 .. n_unique] | positive | negatives] with n_unique read
+    on the device -- what the fused step would otherwise concatenate in a launch of its own.  nb_rows: the builder's [n_real + 1]
+    buffer.  Returns the int32 row list (`out` or a new tensor of B * (2 + K) + n_real + 1 entries)."""
+    b, k = anchor_idx.numel(), negative_idx.shape[1]
+    cap = nb_rows.numel()
+    for t, nm in ((anchor_idx, "anchor_idx"), (positive_idx, "positive_idx"), (negative_idx, "negative_idx"), (nb_rows, "nb_rows"),
+                  (n_unique_dev, "n_unique")):
+        _req(t, torch.int32, nm)
+    need = b * (2 + k) + cap
+    if out is None:
+        out = torch.empty(need, dtype=torch.int32, device=anchor_idx.device)
+    _req(out, torch.int32, "step_rows")
+    if out.numel() < need:
+        raise ValueError(f"step_rows: {out.numel()} entries, B * (2 + K) + len(nb_rows) = {need} needed")
+    check(_lib.lib().pc_p2v_concat_step_rows(_p(anchor_idx), _p(positive_idx), _p(negative_idx), _p(nb_rows), _p(n_unique_dev), cap, b,
+                                             k, _p(out), out.numel(), _stream()), "pc_p2v_concat_step_rows")
+    return out
 
 
 def unique_neighbors(neighbor_idx):

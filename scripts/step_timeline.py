@@ -42,7 +42,9 @@ def main():
     # span they fall in
     # (only the fused index step's iterations: a trace may also hold the dense drop-in leg, whose autograd path ends in the same
     # reduce kernel but never launches the prologue)
-    keep = [(a, b) for a, b in zip(ends[:-1], ends[1:]) if any("p2v_prologue_kernel" in r[0] for r in rows[a + 1:b + 1])]
+    # (... and, with the loader concatenating the step's rows, no prologue at all: then every step has the FFN's finalize)
+    marker = "p2v_prologue_kernel" if any("p2v_prologue_kernel" in r[0] for r in rows) else "bn_finalize_fwd_kernel"
+    keep = [(a, b) for a, b in zip(ends[:-1], ends[1:]) if any(marker in r[0] for r in rows[a + 1:b + 1])]
     ends = [keep[0][0]] + [b for _, b in keep] if keep else ends
     steps = []
     for a, b in zip(ends[:-1], ends[1:]):

@@ -357,6 +357,59 @@ def test_adam_riding_in_the_steps_last_launch_equals_the_separate_launch(dim):
         m_a.train_step_indexed(table, bc, optimizer=o_b)                           # another module's optimizer
 
 
+@pytest.mark.parametrize("dim,reuse,negatives", [(128, True, "uniform"), (128, False, "zipf"), (256, True, "uniform")])
+def test_loader_made_step_rows_change_no_bit(dim, reuse, negatives):
+    """pc_p2v_concat_step_rows + pc_p2v_train_step_unique_rows: the loader concatenates the step's row indices behind its builder
+    (n_unique read on the device) and the step starts with Linear0, its transposed weights riding in the BatchNorm finalize
+    launch -- against the step that concatenates in a launch of its own: row list, losses, gradients, parameters and optimizer
+    state over six steps, bit for bit; with and without the buffer ring, with the Zipf negatives overwritten behind the builder,
+    with and without the optimizer riding."""
+    from p_companion_amd import ops
+    from p_companion_amd.data import SimilarityIndexLoader, generate_scaled_bpg
+    from p_companion_amd.product2vec import FusedAdam, Product2Vec
+    bpg = generate_scaled_bpg(20_000, 100, seed=4, dim=dim)
+    table = bpg.cuda()["features"]
+    c = cfg(PRODUCT_EMB_DIM=dim)
+    twins = []
+    for _ in range(2):
+        torch.manual_seed(1)
+        m = Product2Vec(c).to("cuda").train()
+        twins.append((m, FusedAdam(m, lr=3e-3)))
+    (m_a, o_a), (m_b, o_b) = twins
+    kw = dict(seed=1, drop_last=True, device="cuda", reuse_buffers=reuse, negatives=negatives)
+    ld_a = SimilarityIndexLoader(bpg, 512, **kw)
+    ld_a.step_rows = False
+    ld_b = SimilarityIndexLoader(bpg, 512, **kw)
+    for n, (ba, bb) in enumerate(zip(ld_a, ld_b)):
+        nbc = bb["neighbor_compact"]
+        assert "step_rows" in nbc and "step_rows" not in ba["neighbor_compact"]
+        nu = int(nbc["n_unique"])
+        want = torch.cat([bb["anchor_idx"], nbc["nb_rows"][:nu + 1], bb["positive_idx"], bb["negative_idx"].reshape(-1)])
+        assert torch.equal(nbc["step_rows"][:want.numel()], want), n
+        assert torch.equal(ba["negative_idx"], bb["negative_idx"])
+        riding = n % 2 == 0                                                        # both entries: adam NULL and not
+        la = m_a.train_step_indexed(table, ba, optimizer=o_a if riding else None)
+        lb = m_b.train_step_indexed(table, bb, optimizer=o_b if riding else None)
+        if not riding:
+            o_a.step(); o_b.step()
+        assert torch.equal(la, lb), n
+        assert torch.equal(m_a.flatten_parameters()[1], m_b.flatten_parameters()[1]), n
+        if n == 5:
+            break
+    assert torch.equal(m_a.flatten_parameters()[0], m_b.flatten_parameters()[0])
+    assert torch.equal(o_a.exp_avg, o_b.exp_avg) and torch.equal(o_a.exp_avg_sq, o_b.exp_avg_sq)
+    assert torch.equal(m_a.ffn[1].running_mean, m_b.ffn[1].running_mean)
+    assert torch.equal(m_a.ffn[1].running_var, m_b.ffn[1].running_var)
+    assert int(m_a.ffn[1].num_batches_tracked) == int(m_b.ffn[1].num_batches_tracked) == 24
+    # the C-ABI's refusals: a row list too short for the call, a NULL row list
+    a, p_, ng = bb["anchor_idx"], bb["positive_idx"], bb["negative_idx"]
+    with pytest.raises(ValueError):
+        ops.concat_step_rows(a, p_, ng, nbc["nb_rows"], nbc["n_unique_dev"], out=torch.empty(16, dtype=torch.int32, device="cuda"))
+    short = dict(nbc, step_rows=nbc["step_rows"][:64].contiguous())
+    with pytest.raises(ValueError):
+        m_b.train_step_indexed(table, dict(bb, neighbor_compact=short))
+
+
 def test_module_stays_copyable_and_picklable_after_fused_steps(tmp_path):
     """The step wrapper keeps C structs over the module's buffers between steps -- beside the module, not in it: a trained module
     still deep-copies and torch.save()s whole (the reference saves state_dicts, scripts/pretrain_product2vec.py:44-49, but a
