@@ -922,6 +922,9 @@ def main():
             if kv.startswith("rows="):
                 LOADER_OPTS["step_rows"] = bool(int(kv[5:]))       # (the loader's row concatenation, a Python-side switch)
                 continue
+            if kv.startswith("kick="):
+                LOADER_OPTS["kick_after_step"] = bool(int(kv[5:]))  # (the step queues the loader's look-ahead builder)
+                continue
             o, v = (int(x) for x in kv.split("="))
             if _lib.lib().pc_set_option(o, v) != 0:
                 raise SystemExit(f"PC_BENCH_SET_OPTIONS: pc_set_option({o}, {v}) refused")

@@ -260,6 +260,8 @@ class SimilarityIndexLoader:
         # the step's row list [anchor | neighbour rows | positive | negatives] is concatenated HERE, behind the builder on its
         # stream (ops.concat_step_rows), so that the fused step needs no launch of its own in front of Linear0
         self.step_rows = True
+        # the fused step queues the loader's next look-ahead builder right behind its own launches (batch["_after_step"])
+        self.kick_after_step = True
         # negatives='zipf' (BASELINE configs[4]; an extension, the reference draws uniformly): P(rank) ~ 1 / rank over the
         # popularity permutation `popularity` ([P] int32 product id per rank; None: product 0 is the most popular),
         # same rejection rules, device sampler only
@@ -506,7 +508,16 @@ class SimilarityIndexLoader:
                              f"covers at most {self.RING - self.RING_EVERY} batches in flight")
         from collections import deque
         ahead = deque(launch(j) for j in range(min(depth, n)))
+        owed = []                                              # the look-ahead builder not yet queued (at most one)
+
+        def kick():
+            # queue the owed look-ahead builder.  The fused step calls this (batch["_after_step"]) right behind its own launches:
+            # the builder's ~0.1 ms of host work then never stands between a drained device and the next step's first kernel --
+            # a loop that steps through other code gets it at the next hand-out, as before.
+            if owed:
+                ahead.append(launch(owed.pop()))
         for i in range(n):
+            kick()
             batch, ev = ahead.popleft()
             cur = torch.cuda.current_stream(self.device)
             if ring_ok and (base + i) % self.RING_EVERY == 0:
@@ -531,13 +542,16 @@ class SimilarityIndexLoader:
                     for t in (v.values() if isinstance(v, dict) else [v]):
                         if torch.is_tensor(t):
                             t.record_stream(cur)        # allocated on the side stream, consumed on this one
-            yield batch
-            # the look-ahead builder is queued BEHIND the hand-out (round 6): when the consumer comes back for batch i + 1 it has
-            # launched step i, so the ~0.1 ms of host work of a builder launch no longer stands between a drained device and the
-            # first kernel of a loop's first step (profiles/r06_region_probe.txt: a region's first step ran 1.03-1.14 ms against
-            # 0.83).  The builder still has depth - 1 steps of lead; its ring wait is the latest event, as before.
+            # the look-ahead builder is queued BEHIND the hand-out (round 6): by the step itself once its launches are out
+            # (kick), else when the consumer comes back for batch i + 1 -- so the ~0.1 ms of host work of a builder launch does
+            # not stand between a drained device and the first kernel of a loop's first step (profiles/r06_region_probe.txt: a
+            # region's first step ran 1.03-1.14 ms against 0.83).  The builder still has depth - 1 steps of lead; its ring wait
+            # is the latest event, as before.
             if i + depth < n:
-                ahead.append(launch(i + depth))
+                owed.append(i + depth)
+                if self.kick_after_step:
+                    batch["_after_step"] = kick
+            yield batch
         self._ring_base = base + n
         self._ring_clean = True
         self._end_of_epoch_checks()

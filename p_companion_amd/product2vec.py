@@ -577,6 +577,9 @@ class Product2Vec(nn.Module, _FlatParamsMixin):
                                  sync_reduce=sync_reduce, adam=adam, structs=structs)
         if optimizer is not None and adam is None:
             optimizer.step()
+        after = batch.get("_after_step")           # the device loader's look-ahead builder, queued behind this step's launches
+        if after is not None:
+            after()
         return out["loss"]
 
     def train_model(self, train_loader, optimizer, num_epochs=10) -> Dict[str, torch.Tensor]:

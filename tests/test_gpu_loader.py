@@ -155,6 +155,38 @@ def test_loader_buffer_ring_hands_out_the_same_batches(unique):
         assert torch.equal(p, q), k
 
 
+def test_look_ahead_builder_queued_by_the_step_hands_out_the_same_batches():
+    """batch["_after_step"] (what train_step_indexed calls behind its launches): the loader's next look-ahead builder is queued
+    then instead of at the next hand-out.  Same batches, bit for bit, as a loader that never offers it (kick_after_step False) and
+    as one whose consumer ignores it; calling it twice queues nothing twice; an epoch's last `depth` batches carry none."""
+    from p_companion_amd.data import SimilarityIndexLoader, generate_scaled_bpg
+    bpg = generate_scaled_bpg(6000, 30, seed=2)
+    mk = lambda: SimilarityIndexLoader(bpg, 512, seed=9, drop_last=False, device="cuda", reuse_buffers=True)
+    kicked, ignored, plain = mk(), mk(), mk()
+    plain.kick_after_step = False
+    n = len(kicked)
+    for epoch in range(2):
+        seen = 0
+        for i, (x, y, z) in enumerate(zip(kicked, ignored, plain)):
+            assert "_after_step" not in z
+            assert ("_after_step" in x) == (i + 4 < n) == ("_after_step" in y), i     # prefetch depth 4 with the ring
+            nu = int(x["neighbor_compact"]["n_unique"])
+            for other in (y, z):
+                for k in ("anchor_idx", "positive_idx", "negative_idx"):
+                    assert torch.equal(x[k], other[k]), (epoch, i, k)
+                assert int(other["neighbor_compact"]["n_unique"]) == nu
+                for k in ("nb_rows", "weight"):
+                    assert torch.equal(x["neighbor_compact"][k][:nu + 1], other["neighbor_compact"][k][:nu + 1]), (epoch, i, k)
+                assert torch.equal(x["neighbor_compact"]["slot_row"], other["neighbor_compact"]["slot_row"])
+                rows = x["anchor_idx"].numel() * 7 + nu + 1
+                assert torch.equal(x["neighbor_compact"]["step_rows"][:rows], other["neighbor_compact"]["step_rows"][:rows])
+            if "_after_step" in x:
+                x["_after_step"]()
+                x["_after_step"]()                                   # nothing owed any more: a no-op
+            seen += 1
+        assert seen == n
+
+
 @pytest.mark.parametrize("mode", ["train", "val"])
 def test_complementary_batch_against_reference_golden(golden, mode):
     """J1 end to end in parity mode: sampler='cpython' pair order + pc_build_complementary_batch on the device against
