@@ -246,6 +246,8 @@ class SimilarityIndexLoader:
         # build batch i+1 on a side stream while the consumer trains on batch i (what the reference's
         # DataLoader workers do on the host, scripts/pretrain_product2vec.py:24-30); same batches either way
         self.prefetch = prefetch and sampler == "philox" and torch.device(device).type == "cuda"
+        # batches are born on the device (the philox builders): train_model iterates this loader directly, without its staging wrapper
+        self.yields_device_batches = sampler == "philox" and torch.device(device).type == "cuda"
         self.epoch = 0
         self.step = 0
         # reuse_buffers (training loops: train_model, bench.py): batches are built into a RING of preallocated buffers instead

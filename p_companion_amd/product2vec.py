@@ -594,13 +594,23 @@ class Product2Vec(nn.Module, _FlatParamsMixin):
         bpg = train_loader.dataset.bpg
         table = None
         history = [] if (getattr(self, "record_step_losses", False) or getattr(self.config, "RECORD_STEP_LOSSES", False)) else None
+        # a device index loader hands out batches that are already where the step reads them: iterated directly (the staging
+        # wrapper would put a cross-stream wait in front of every step's first kernel)
+        direct = bool(getattr(train_loader, "yields_device_batches", False))
+        from .data import prefetch_to_device
         for epoch in range(num_epochs):
             self.train()
-            total = None
+            total, pending = None, []
             num_batches = 0
-            from .data import prefetch_to_device
-            for batch in prefetch_to_device(train_loader, device):       # dense batches: next batch's PCIe copy overlaps this step
-                batch = {k: v.to(device) if isinstance(v, torch.Tensor) else v for k, v in batch.items()}
+
+            def fold(total, pending):
+                # the epoch's loss sum, on the device: one small reduction per 256 steps instead of an add kernel per step
+                part = torch.cat(pending).sum().reshape(1)
+                return part if total is None else total + part
+            # dense batches: next batch's PCIe copy overlaps this step
+            for batch in (train_loader if direct else prefetch_to_device(train_loader, device)):
+                if not direct:
+                    batch = {k: v.to(device) if isinstance(v, torch.Tensor) else v for k, v in batch.items()}
                 if "anchor_idx" in batch:
                     if table is None:
                         table = bpg.cuda(device)["features"]
@@ -615,10 +625,14 @@ class Product2Vec(nn.Module, _FlatParamsMixin):
                     loss.backward()
                     optimizer.step()
                     loss = loss.detach().reshape(1)
-                total = loss.clone() if total is None else total + loss
+                pending.append(loss.reshape(1))
+                if len(pending) == 256:
+                    total, pending = fold(total, pending), []
                 num_batches += 1
                 if history is not None:
                     history.append(loss.detach().reshape(1).clone())
+            if pending:
+                total = fold(total, pending)
             if num_batches:
                 logger.info(f"Epoch {epoch + 1}/{num_epochs}, Loss: {float(total) / num_batches:.4f}")
         if history is not None:
