@@ -368,10 +368,11 @@ def run_joint(args, rank, world, dev, types, steps, warmup, want_cpu, dropout=0.
                                              "clear riding, exact top-K over each row's K best sub-chunks, tile kernel incl. batch construction and the "
                                              "weight-gradient slabs, counting sort of the table gradients' source rows by destination, per-destination sums "
                                              "in ascending source order, finish + Adam)" if dropout > 0 else
-                                             "8 (distinct query types, their hidden rows + G = E_c dec_w, sub-chunk maxima of the similarity rows with the "
+                                             "7 (hidden rows of the distinct query types + G = E_c dec_w, sub-chunk maxima of the similarity rows with the "
                                              "table-gradient clear riding, exact top-K over each row's K best sub-chunks, tile kernel incl. batch construction "
                                              "and the weight-gradient slabs, counting sort of the table gradients' source rows by destination, per-destination "
-                                             "sums in ascending source order, finish + Adam)"))},
+                                             "sums in ascending source order, finish + Adam -- whose first workgroup forms the NEXT step's distinct-type list; "
+                                             "an epoch's first step has an eighth launch for its own list)"))},
            "roofline": {"bound": "hbm", "kernel": "the whole step (batch builder + the fused step's kernels: a dependent chain)",
                         "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                         "frac": round(achieved / HBM_PEAK_GBS, 5),
@@ -983,9 +984,9 @@ def main():
                          (" + P-Companion joint step under `joint`" if joint else ""),
                "value": round(p2v["value"], 1), **common, "ms_per_step": round(p2v["ms_per_step"], 4),
                "host_enqueue_ms_per_step": p2v.get("host_enqueue_ms_per_step"),
-               "host_enqueue_note": "wall time of the host between the region's two clocks / steps: its own work (~0.34 ms per step: loader next() "
-                                    "0.11, train_step_indexed 0.18, optimizer.step 0.05 -- scripts/dev/host_breakdown.py) plus the time it waits "
-                                    "behind a full launch queue; below ms_per_step = the device is the bound, not the host",
+               "host_enqueue_note": "wall time of the host between the region's two clocks / steps: its own work (loader hand-out, step wrapper, "
+                                    "the foreign call's launches, the look-ahead builder: scripts/dev/first_step_probe.py takes it apart) plus the "
+                                    "time it waits behind a full launch queue; below ms_per_step = the device is the bound, not the host",
                "dtype_note": "fp32 storage, accumulation and result accuracy; the large GEMMs evaluate each fp32 product as six "
                              "bf16 matrix-core products of a three-way split (error <= the fp32 MFMA's, tests/test_gpu_ops.py)",
                "config": {"workload": f"Product2Vec GAT pretrain, {args.products} products, {args.types} types, dim={args.dim}, "
