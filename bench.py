@@ -971,6 +971,12 @@ def main():
                   "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic"}
         if rccl:
             common["rccl"] = rccl
+        # developer knobs compiled into the library (pc_build_flags: PC_EXP_* builds compute WRONG numbers by design): 0 for the product
+        from p_companion_amd import _lib as _l
+        common["build_flags"] = int(_l.lib().pc_build_flags())
+        if common["build_flags"]:
+            print(f"[bench] WARNING: developer-knob library (pc_build_flags = {common['build_flags']:#x}): not the product's numbers",
+                  file=sys.stderr, flush=True)
         if p2v is None:                                           # --phase joint: the joint step is the line
             out = dict(common)
             out.update(joint)

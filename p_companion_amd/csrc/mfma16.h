@@ -5,7 +5,14 @@
 
 typedef float f32x4v __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ f32x4v mfma16(float a, float b, f32x4v c) {
+#ifdef PC_EXP_NO_MFMA
+    // developer build (scripts/dev/joint_mfma_knockout.sh; WRONG results): the product replaced by a keep-alive of its operands --
+    // what is left is everything a faster matrix instruction could NOT shorten
+    asm volatile("" ::"v"(a), "v"(b));
+    return c;
+#else
     return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+#endif
 }
 
 // ---- 16 x 16 output blocks on v_mfma_f32_16x16x4_f32 ----------------------------------------------------------
