@@ -179,6 +179,19 @@ __device__ __forceinline__ Split3 split3(const float4& lo, const float4& hi) {
 __device__ __forceinline__ f32x16 mfma_bf16(const bf16x8& a, const bf16x8& b, f32x16 c) {
     return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
 }
+// Wave priority 1 around a matrix-instruction cluster of a large product's K loop (cdna_hip_programming.md T5), per kernel
+// variant.  Measured in A/B on two boxes (round 6, profiles/r06_setprio_ab.txt: alternating runs of the builds, three boxes): around the
+// twelve-product clusters of the PLAIN weight-gradient kernel (gemm_tn8_kernel without a prologue: dW5, dW3's halves; 8 waves,
+// two per SIMD) the step is 4.5 / 10 / 15 us shorter; in the in-place-prologue variants, held across a whole k group, or at level 3
+// it gains less or nothing; in gemm_nt_kernel it gains nothing on Linear3's tile and LENGTHENS the three-workgroups-per-CU
+// variants (dZ1 +2.6 %, dZ2 +2.4 %).  The conditions are compile-time (developer builds: -DPC_PRIO_NT_COND=..., -DPC_PRIO_TN_COND=...).
+#define PC_PRIO_MFMA(COND, x) do { if constexpr (COND) __builtin_amdgcn_s_setprio(x); } while (0)
+#ifndef PC_PRIO_NT_COND
+#define PC_PRIO_NT_COND false                     // gemm_nt_kernel: nowhere
+#endif
+#ifndef PC_PRIO_TN_COND
+#define PC_PRIO_TN_COND (!APRO && !ZPRO)          // gemm_tn8_kernel: the plain weight gradients
+#endif
 #endif
 
 // ---- training-mode dropout masks (pc_dropout in the header; restated for the tests by philox_oracle.dropout_mask)

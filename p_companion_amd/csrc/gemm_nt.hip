@@ -271,7 +271,9 @@ __global__ __launch_bounds__(64 * NWM * NWN, WPS) void gemm_nt_kernel(NtArgs a, 
 #define PC_TERM(PA, PB)                                                   \
                 acc[0][j] = PC_MFMA(sa[0].PA, sb.PB, acc[0][j]);          \
                 acc[1][j] = PC_MFMA(sa[1].PA, sb.PB, acc[1][j]);
+                PC_PRIO_MFMA(PC_PRIO_NT_COND, 1);
                 PC_TERM(p2, p0) PC_TERM(p0, p2) PC_TERM(p1, p1) PC_TERM(p1, p0) PC_TERM(p0, p1) PC_TERM(p0, p0)
+                PC_PRIO_MFMA(PC_PRIO_NT_COND, 0);
             }
 #undef PC_TERM
         }

@@ -433,7 +433,9 @@ __global__ __launch_bounds__(64 * WO * WI, WO * WI / 4) void gemm_tn8_kernel(TnA
                 zsum[i] += ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]));
                 const Split3 sz = PC_TNSPLIT(make_float4(v[0], v[1], v[2], v[3]), make_float4(v[4], v[5], v[6], v[7]));
 #define PC_TERM(PZ, PX) _Pragma("unroll") for (int j = 0; j < TI; j++) acc[i][j] = PC_TNMFMA(sz.PZ, sx[j].PX, acc[i][j]);
+                PC_PRIO_MFMA(PC_PRIO_TN_COND, 1);
                 PC_TERM(p2, p0) PC_TERM(p0, p2) PC_TERM(p1, p1) PC_TERM(p1, p0) PC_TERM(p0, p1) PC_TERM(p0, p0)
+                PC_PRIO_MFMA(PC_PRIO_TN_COND, 0);
 #undef PC_TERM
             }
         }
