@@ -184,7 +184,8 @@ __device__ __forceinline__ f32x16 mfma_bf16(const bf16x8& a, const bf16x8& b, f3
 // twelve-product clusters of the PLAIN weight-gradient kernel (gemm_tn8_kernel without a prologue: dW5, dW3's halves; 8 waves,
 // two per SIMD) the step is 4.5 / 10 / 15 us shorter; in the in-place-prologue variants, held across a whole k group, or at level 3
 // it gains less or nothing; in gemm_nt_kernel it gains nothing on Linear3's tile and LENGTHENS the three-workgroups-per-CU
-// variants (dZ1 +2.6 %, dZ2 +2.4 %).  The conditions are compile-time (developer builds: -DPC_PRIO_NT_COND=..., -DPC_PRIO_TN_COND=...).
+// variants (dZ1 +2.6 %, dZ2 +2.4 %); priority 1 through gemm_nt_kernel's EPILOGUE (its memory streams against the
+// neighbours' K loops) changes nothing (+-2 us).  The conditions are compile-time (developer builds: -DPC_PRIO_NT_COND=..., -DPC_PRIO_TN_COND=...).
 #define PC_PRIO_MFMA(COND, x) do { if constexpr (COND) __builtin_amdgcn_s_setprio(x); } while (0)
 #ifndef PC_PRIO_NT_COND
 #define PC_PRIO_NT_COND false                     // gemm_nt_kernel: nowhere
