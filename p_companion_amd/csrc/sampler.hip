@@ -191,9 +191,13 @@ __global__ __launch_bounds__(128) void uq_pairs_count_kernel(const int32_t* pair
 }
 
 // per chunk of products: (number present, number of slots) -> blocksum[2 * blk], blocksum[2 * blk + 1]
-__global__ __launch_bounds__(1024) void uq_block_sums_kernel(const int32_t* cnt, int P, int32_t* blocksum) {
-    __shared__ int red[2][16];
-    const int base = blockIdx.x * UQ_CHUNK + threadIdx.x * 4;
+// THREADS = 1024 (chunks of 4096 products) or 256 (chunks of 1024): the builders run BESIDE the training stream's persistent
+// kernels, and a 1024-thread workgroup takes sixteen wave slots of ONE CU for its whole life, a 256-thread one four
+template <int THREADS>
+__global__ __launch_bounds__(THREADS) void uq_block_sums_kernel(const int32_t* cnt, int P, int32_t* blocksum) {
+    constexpr int NWV = THREADS / 64;
+    __shared__ int red[2][NWV];
+    const int base = blockIdx.x * (4 * THREADS) + threadIdx.x * 4;
     int s = 0, c = 0;
 #pragma unroll
     for (int i = 0; i < 4; i++) { const int v = base + i < P ? cnt[base + i] : 0; s += v > 0 ? 1 : 0; c += v; }
@@ -203,7 +207,7 @@ __global__ __launch_bounds__(1024) void uq_block_sums_kernel(const int32_t* cnt,
     __syncthreads();
     if (threadIdx.x == 0) {
         int ts = 0, tc = 0;
-        for (int i = 0; i < 16; i++) { ts += red[0][i]; tc += red[1][i]; }
+        for (int i = 0; i < NWV; i++) { ts += red[0][i]; tc += red[1][i]; }
         blocksum[2 * blockIdx.x] = ts;
         blocksum[2 * blockIdx.x + 1] = tc;
     }
@@ -212,27 +216,29 @@ __global__ __launch_bounds__(1024) void uq_block_sums_kernel(const int32_t* cnt,
 // row of every present product (ascending product order), its multiplicity, and the start of its slot list
 // blocksum: the per-chunk sums of uq_block_sums_kernel (NOT scanned): every workgroup adds up its predecessors' sums itself
 // (25 chunks at 100 k products; a scan launch of its own cost more than these few loads); the last one writes n_unique
-__global__ __launch_bounds__(1024) void uq_assign_kernel(const int32_t* cnt, int P, const int32_t* blocksum, int32_t* rank,
+template <int THREADS>
+__global__ __launch_bounds__(THREADS) void uq_assign_kernel(const int32_t* cnt, int P, const int32_t* blocksum, int32_t* rank,
                                                          int32_t* nb_rows, float* nb_weight, int32_t* ref_off,
                                                          int32_t* cursor, int32_t* n_unique) {
-    __shared__ int wsum[2][16];
+    constexpr int NWV = THREADS / 64;
+    __shared__ int wsum[2][NWV];
     __shared__ int boff[2];
     {
         int ps = 0, pc = 0;
-        for (int i = threadIdx.x; i < (int)blockIdx.x; i += 1024) { ps += blocksum[2 * i]; pc += blocksum[2 * i + 1]; }
+        for (int i = threadIdx.x; i < (int)blockIdx.x; i += THREADS) { ps += blocksum[2 * i]; pc += blocksum[2 * i + 1]; }
 #pragma unroll
         for (int o = 32; o >= 1; o >>= 1) { ps += __shfl_xor(ps, o, 64); pc += __shfl_xor(pc, o, 64); }
         if ((threadIdx.x & 63) == 0) { wsum[0][threadIdx.x >> 6] = ps; wsum[1][threadIdx.x >> 6] = pc; }
         __syncthreads();
         if (threadIdx.x == 0) {
             int a = 0, b = 0;
-            for (int i = 0; i < 16; i++) { a += wsum[0][i]; b += wsum[1][i]; }
+            for (int i = 0; i < NWV; i++) { a += wsum[0][i]; b += wsum[1][i]; }
             boff[0] = a; boff[1] = b;
             if (blockIdx.x == gridDim.x - 1) n_unique[0] = a + blocksum[2 * blockIdx.x];
         }
         __syncthreads();
     }
-    const int base = blockIdx.x * UQ_CHUNK + threadIdx.x * 4;
+    const int base = blockIdx.x * (4 * THREADS) + threadIdx.x * 4;
     int f[4], c[4], s = 0, cs = 0;
 #pragma unroll
     for (int i = 0; i < 4; i++) { c[i] = base + i < P ? cnt[base + i] : 0; f[i] = c[i] > 0; s += f[i]; cs += c[i]; }
@@ -281,9 +287,15 @@ __global__ void uq_slots_kernel(const int32_t* anchor_idx, int B, const int32_t*
 }
 
 // layout: cnt[P] | rank[P] | blocksum[2 * nblk] | cursor[S]      (S = slots: an upper bound of the row count)
+// chunk of the per-product scans: 1024 products (256-thread workgroups) up to UQ_SMALL_MAX products, 4096 beyond (every
+// workgroup adds up its predecessors' chunk sums itself: quadratic in the chunk count)
+#ifndef UQ_SMALL_MAX
+#define UQ_SMALL_MAX (1 << 20)
+#endif
+static inline int uq_chunk(int n_products) { return n_products <= UQ_SMALL_MAX ? 1024 : UQ_CHUNK; }
 extern "C" size_t pc_build_similarity_batch_unique_scratch_bytes(int n_products, int max_slots) {
     if (n_products <= 0 || max_slots <= 0) return 0;
-    const size_t nblk = ((size_t)n_products + UQ_CHUNK - 1) / UQ_CHUNK;
+    const size_t nblk = ((size_t)n_products + 1023) / 1024;         // (the smaller chunk: an upper bound for either)
     return ((size_t)n_products * 2 + 2 * nblk + (size_t)max_slots + 1) * sizeof(int32_t);
 }
 
@@ -301,14 +313,15 @@ extern "C" int pc_build_similarity_batch_unique(const int32_t* pair_ids, int bat
         return PC_EINVAL;
     if (batch <= 0 || n_pad <= 0 || k_neg <= 0 || n_products <= k_neg + 1 || n_real < 0 || n_real > batch * n_pad)
         return PC_EINVAL;
-    const int nblk = (n_products + UQ_CHUNK - 1) / UQ_CHUNK;
+    const int chunk = uq_chunk(n_products);
+    const int nblk = (n_products + chunk - 1) / chunk;
     if (nblk > 4096) return PC_ESHAPE;                        // 16.7 M products with one scan workgroup
     const int total = batch * n_pad;
     if (scratch_bytes < pc_build_similarity_batch_unique_scratch_bytes(n_products, total)) return PC_EWORKSPACE;
     int32_t* cnt = (int32_t*)scratch;
     int32_t* rank = cnt + n_products;
     int32_t* blocksum = rank + n_products;
-    int32_t* cursor = blocksum + 2 * nblk;
+    int32_t* cursor = blocksum + 2 * (((size_t)n_products + 1023) / 1024);      // (the layout of ..._scratch_bytes)
     hipStream_t st = (hipStream_t)stream;
     // four launches (round 2: six): sampler ∥ occurrence count, per-chunk sums, row assignment (own prefix of the sums), slots
     const int pair_blocks = (batch + 127) / 128;
@@ -316,9 +329,15 @@ extern "C" int pc_build_similarity_batch_unique(const int32_t* pair_ids, int bat
               sim_rowptr, sim_col, n_products, k_neg, seed, step, anchor_idx, positive_idx, negative_idx, pair_blocks, cv_rowptr,
               cv_col, n_pad, cnt);
     PC_TRY(pc_launch_status());
-    PC_LAUNCH(uq_block_sums_kernel, dim3(nblk), dim3(1024), 0, st, cnt, n_products, blocksum);
-    PC_LAUNCH(uq_assign_kernel, dim3(nblk), dim3(1024), 0, st, cnt, n_products, blocksum, rank, nb_rows, nb_weight, ref_off,
-              cursor, n_unique);
+    if (chunk == 1024) {
+        PC_LAUNCH(uq_block_sums_kernel<256>, dim3(nblk), dim3(256), 0, st, cnt, n_products, blocksum);
+        PC_LAUNCH(uq_assign_kernel<256>, dim3(nblk), dim3(256), 0, st, cnt, n_products, blocksum, rank, nb_rows, nb_weight, ref_off,
+                  cursor, n_unique);
+    } else {
+        PC_LAUNCH(uq_block_sums_kernel<1024>, dim3(nblk), dim3(1024), 0, st, cnt, n_products, blocksum);
+        PC_LAUNCH(uq_assign_kernel<1024>, dim3(nblk), dim3(1024), 0, st, cnt, n_products, blocksum, rank, nb_rows, nb_weight, ref_off,
+                  cursor, n_unique);
+    }
     PC_LAUNCH(uq_slots_kernel, dim3((total + 255) / 256), dim3(256), 0, st, anchor_idx, batch, cv_rowptr, cv_col, n_pad,
               rank, n_unique, n_real, cnt, nb_rows, nb_weight, slot_row, ref_off, cursor, ref_slot);
     return pc_launch_status();
