@@ -212,6 +212,7 @@ def joint_algorithmic_bytes(b, t, k=3):
 # over 25, 0.1215 over 250: scripts/dev/first_steps_probe.py) -- so these legs time at least 46 / 30 ms.
 JOINT_MIN_STEPS = 1000
 JOINT_REF_MIN_STEPS = 250
+BENCH_T0 = time.monotonic()  # process start (module import): the legs' total budget counts from here
 LOADER_OPTS = {}             # developer A/B (PC_BENCH_SET_OPTIONS "rows=0"): attributes set on the Product2Vec leg's loader
 EXCHANGE = {"ex": None}      # the replicas' gradient exchange (distributed.make_exchange), set once in main() when N > 1
 
@@ -828,6 +829,22 @@ def guarded(name, fn, world):
     group's bounded timeout ends (then the launcher ends the job: nothing can report that case)."""
     err = None
     res = None
+    # The line goes out only when every leg is through, and the harness ends the job at ITS limit (600 s, line or no line): a run in
+    # which set-up, first contact and the legs before this one were slow -- not hung: the watchdogs see nothing -- must stop adding
+    # legs while the line can still be printed.  Past PC_BENCH_TOTAL_BUDGET_S (default 330 s since the process started; a default
+    # one-GPU run takes ~180 s) a secondary leg is not started and says so in its place; at N > 1 the ranks agree (MAX of the
+    # elapsed times, on the drained device: the previous leg ended behind a synchronize), so that all of them skip the same legs.
+    elapsed = time.monotonic() - BENCH_T0
+    if world > 1:
+        import torch.distributed as dist
+        el = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if dist.get_backend() == "gloo" else torch.device("cuda", torch.cuda.current_device()))
+        dist.all_reduce(el, op=dist.ReduceOp.MAX)
+        elapsed = float(el.item())
+    budget = float(os.environ.get("PC_BENCH_TOTAL_BUDGET_S", "330"))
+    if elapsed > budget:
+        print(f"[bench] leg `{name}` not started: {elapsed:.0f} s since the process started > PC_BENCH_TOTAL_BUDGET_S = {budget:g} s", file=sys.stderr, flush=True)
+        return {"error": f"skipped: {elapsed:.0f} s since the process started > PC_BENCH_TOTAL_BUDGET_S = {budget:g} s (the line has to go out "
+                         f"inside the harness's limit)", "leg": name}
     watchdog = leg_watchdog(name, world)
     try:
         res = fn()

@@ -83,3 +83,20 @@ def test_bench_world2_leg_watchdog_keeps_the_headline():
     assert line["n_gpus"] == 2 and line["value"] > 0                      # the headline leg ran first and is in the line
     assert "did not finish within 0.25 s" in line["joint"]["error"], line.get("joint")
     assert "still running after 0.25 s" in out.stderr
+
+
+@pytest.mark.timeout(600)
+def test_bench_world2_total_budget_skips_secondary_legs():
+    """N > 1: once the process is older than PC_BENCH_TOTAL_BUDGET_S no further secondary leg is started (the harness ends the job
+    at its own limit, line or no line); the ranks agree on it, the headline is in the line, the skipped legs say so, exit 0."""
+    env = dict(os.environ, PC_DIST_BACKEND="gloo", PC_FORCE_DEVICE="0", HSA_ENABLE_IPC_MODE_LEGACY="0", PC_BENCH_TOTAL_BUDGET_S="0.5")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT", "PC_DIST_FORCE"):
+        env.pop(k, None)
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "2",
+                          "--products", "20000", "--batch", "512", "--no-cpu-baseline", "--no-sustained", "--no-large",
+                          "--no-ref-types"], env=env, capture_output=True, text=True, timeout=500, cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-3000:]
+    line = json.loads(out.stdout.strip().splitlines()[-1])
+    assert line["n_gpus"] == 2 and line["value"] > 0
+    assert line["joint"]["error"].startswith("skipped:") and line["joint_dropout_0p1"]["error"].startswith("skipped:"), line.get("joint")
+    assert "not started" in out.stderr
